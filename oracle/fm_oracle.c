@@ -1,0 +1,683 @@
+/*
+ * fm_oracle.c -- CPU restatement of the FMwR hot path (degree-2 FM forward,
+ * per-example SGD / FTRL-Proximal, ALS V-column sweep).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is product code: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only
+ * as the checker / timed CPU baseline.  The product (fmwr_amd/) never links,
+ * imports or falls back to anything here.
+ *
+ * Every function cites the reference file:line (relative to /root/reference/) whose
+ * arithmetic AND operation order it restates.  All parameters and accumulators are
+ * fp64, inputs (CSR values, labels) are fp32 promoted at use, exactly as in the
+ * reference.  Compile with -ffp-contract=off so no FMA is formed.
+ *
+ * Pinning: checked in tests/test_oracle_kat.py against the known-answer vectors of
+ * SURVEY.md Appendix B (outputs of the reference's own SGD/FTRL learners on a 6x5
+ * matrix) and against the analytic FM identity (src/test/model.cpp:77-83).
+ *
+ * Layouts follow the reference: V is factor-major [k][p] (util/Dmatrix.h:34-46),
+ * element (f, j) at v[f*p + j].  Row offsets are int64 here (value-equivalent to the
+ * reference's uint32, util/Smatrix.h:10-12).
+ *
+ * The *_minibatch_* functions at the end are NOT in the reference: they define the
+ * synchronous mini-batch semantics of the MI355X engine in fp64
+ * and reduce to the reference's per-example step at batch size 1 (tested).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FMO_CLASSIFICATION 10 /* util/Macros.h:11 */
+#define FMO_REGRESSION 20     /* util/Macros.h:12 */
+
+#define FMO_LL 0     /* util/Macros.h:24-29 */
+#define FMO_AUC 111
+#define FMO_ACC 222
+#define FMO_RMSE 333
+#define FMO_MSE 444
+#define FMO_MAE 555
+
+typedef struct fmo_params {
+  int32_t task;        /* FMO_CLASSIFICATION | FMO_REGRESSION */
+  int32_t k;           /* num_factor */
+  int32_t k0, k1;      /* keep.w0, keep.w1 */
+  double l1_regw, l1_regv;
+  double l2_reg0, l2_regw, l2_regv;
+  double min_target, max_target;
+  double learn_rate;                        /* SGD.solver */
+  double alpha_w, beta_w, alpha_v, beta_v;  /* FTRL.solver */
+  int32_t random_step;
+  int32_t eval_type;   /* tracker metric */
+  int64_t trace_step;  /* tracker.step_size, <=0: off */
+  double conv_condition;
+} fmo_params;
+
+typedef struct fmo_csr {
+  int64_t n;
+  uint32_t p;
+  const int64_t* row_ptr; /* [n+1] */
+  const uint32_t* col;    /* [nnz] */
+  const float* val;       /* [nnz] */
+} fmo_csr;
+
+/* ------------------------------------------------------------------ util/Random.h */
+
+/* util/Random.h:20-24 fast_runif: libc rand() / (RAND_MAX + 1.0) */
+static double fmo_fast_runif(void) { return rand() / ((double)RAND_MAX + 1); }
+
+/* util/Random.h:126-132 random_select */
+uint32_t fmo_random_select(int n) {
+  if (n == 1) return 1;
+  return (uint32_t)(fmo_fast_runif() * n + 1);
+}
+
+/* The example visiting order of SGD_Learner.h:86-88 / FTRL_Learner.h:72-74:
+ *   for(;;) for (i = random_select(step); i < n; i += random_select(step)) {...; if (++iter >= max_iter) break;}
+ * written out as a list of row ids (row 0 is never visited when step == 1, SURVEY A-2).
+ * Returns the number of entries written (== max_iter unless n is too small to ever visit). */
+int64_t fmo_visit_order(int64_t n, int random_step, int64_t max_iter, int64_t* out) {
+  int64_t iter = 0;
+  int guard = 0;
+  for (;;) {
+    int64_t before = iter;
+    for (uint32_t i = fmo_random_select(random_step); i < (uint64_t)n; i += fmo_random_select(random_step)) {
+      out[iter++] = i;
+      if (iter >= max_iter) break;
+    }
+    if (iter >= max_iter) break;
+    if (iter == before && ++guard > 1000) break; /* n <= 1: reference would spin forever */
+  }
+  return iter;
+}
+
+void fmo_srand(unsigned seed) { srand(seed); }
+
+/* ------------------------------------------------------------------ core/Model.h */
+
+/* core/Model.h:75-103 Model::predict -- one row; leaves sum_f / sum_sqr_f in m_sum / m_sum_sqr. */
+double fmo_predict(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
+                   const fmo_csr* X, int64_t row, double* m_sum, double* m_sum_sqr) {
+  double pred = 0.0;
+  if (P->k0) pred += w0;
+  for (int f = 0; f < P->k; ++f) { m_sum[f] = 0.0; m_sum_sqr[f] = 0.0; }
+  for (int64_t j = X->row_ptr[row]; j < X->row_ptr[row + 1]; ++j) {
+    double _val = X->val[j];
+    uint32_t _idx = X->col[j];
+    if (P->k1) pred += w[_idx] * _val;
+    const double* it_v = v + _idx;
+    for (int f = 0; f < P->k; ++f) {
+      double _tmp = *it_v * _val;
+      m_sum[f] += _tmp;
+      m_sum_sqr[f] += _tmp * _tmp;
+      it_v += p;
+    }
+  }
+  for (int f = 0; f < P->k; ++f) pred += 0.5 * (m_sum[f] * m_sum[f] - m_sum_sqr[f]);
+  return pred;
+}
+
+/* core/Model.h:106-161 Model::predict_batch (loop order f outer, nz inner; association as written). */
+void fmo_predict_batch(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
+                       const fmo_csr* X, double* out) {
+  for (int64_t i = 0; i < X->n; ++i) out[i] = P->k0 ? w0 : 0.0;
+  if (P->k1) {
+    for (int64_t i = 0; i < X->n; ++i) {
+      double w_sum = 0.0;
+      for (int64_t j = X->row_ptr[i]; j < X->row_ptr[i + 1]; ++j) w_sum += w[X->col[j]] * X->val[j];
+      out[i] += w_sum;
+    }
+  }
+  if (P->k > 0) {
+    for (int64_t i = 0; i < X->n; ++i) {
+      double v_res = 0.0;
+      for (int f = 0; f < P->k; ++f) {
+        double v_sum = 0, v_sum_sqr = 0;
+        for (int64_t j = X->row_ptr[i]; j < X->row_ptr[i + 1]; ++j) {
+          double tmp_ = X->val[j] * v[(size_t)f * p + X->col[j]];
+          v_sum += tmp_;
+          v_sum_sqr += tmp_ * tmp_;
+        }
+        v_res += (0.5 * v_sum * v_sum - 0.5 * v_sum_sqr);
+      }
+      out[i] += v_res;
+    }
+  }
+}
+
+/* core/Model.h:163-180 Model::predict_prob, SGD/FTRL/TDAP branch: logistic link. */
+void fmo_predict_prob(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
+                      const fmo_csr* X, double* out) {
+  fmo_predict_batch(P, p, w0, w, v, X, out);
+  for (int64_t i = 0; i < X->n; ++i) out[i] = 1.0 / (1.0 + exp(-out[i]));
+}
+
+/* FM.cpp:202-210 / SGD_Learner.h:147-153: clamp regression predictions to the target range. */
+void fmo_clamp(double* out, int64_t n, double lo, double hi) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (out[i] < lo) out[i] = lo;
+    else if (out[i] > hi) out[i] = hi;
+  }
+}
+
+/* ------------------------------------------------------------------ core/Evaluation.h */
+
+static int fmo_cmp_abs(const void* a, const void* b) {
+  double x = fabs(*(const double*)a), y = fabs(*(const double*)b);
+  return (x < y) ? -1 : (x > y) ? 1 : 0;
+}
+
+/* core/Evaluation.h:20-115 evaluates() and the five metrics (quirks kept: mae() takes a sqrt,
+ * MSE falls into the RMSE branch, AUC sorts by |score| with sign-encoded labels; SURVEY A-15). */
+double fmo_evaluate(int task, int type, const double* y_hat, const float* y_true, int64_t n) {
+  if (task == FMO_REGRESSION) {
+    if (type <= FMO_RMSE) { /* Evaluation.h:91-102 */
+      double s = 0.0;
+      for (int64_t i = 0; i < n; ++i) { double err = y_hat[i] - y_true[i]; s += err * err; }
+      return sqrt(s / n);
+    } else { /* Evaluation.h:104-115 */
+      double s = 0.0;
+      for (int64_t i = 0; i < n; ++i) { double err = y_hat[i] - y_true[i]; s += fabs(err); }
+      return sqrt(s / n);
+    }
+  }
+  if (type >= FMO_ACC) { /* Evaluation.h:43-53, cutoff 0.5 */
+    uint32_t ok = 0;
+    for (int64_t i = 0; i < n; ++i)
+      if (((y_hat[i] >= 0.5) && (y_true[i] > 0)) || ((y_hat[i] < 0.5) && (y_true[i] < 0))) ok += 1;
+    return (double)ok / (double)n;
+  } else if (type == FMO_LL) { /* Evaluation.h:80-89 */
+    double res = 0.0;
+    for (int64_t i = 0; i < n; ++i)
+      res += (1 + y_true[i]) * log(y_hat[i] + 1e-20) + (1 - y_true[i]) * log(1 - y_hat[i] - 1e-20);
+    return res / 2.0;
+  } else { /* Evaluation.h:55-78 */
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) tmp[i] = y_true[i] > 0 ? y_hat[i] : (-y_hat[i]);
+    qsort(tmp, (size_t)n, sizeof(double), fmo_cmp_abs);
+    double area = 0, cum_tp = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      if (tmp[i] > 0) cum_tp += 1.0; else area += cum_tp;
+    }
+    free(tmp);
+    if (cum_tp == 0 || cum_tp == n) return 1.0;
+    area /= cum_tp * (n - cum_tp);
+    return area < 0.5 ? 1 - area : area;
+  }
+}
+
+/* ------------------------------------------------------------------ solver/SGD_Learner.h */
+
+/* solver/SGD_Learner.h:180-191 calculate_grad_mult (identical copy FTRL_Learner.h:204-215).
+ * Regression clamps y_hat in place BEFORE the residual (SURVEY A-12). */
+double fmo_grad_mult(const fmo_params* P, double* y_hat, float y_true) {
+  double mult = 0.0;
+  if (P->task == FMO_REGRESSION) {
+    *y_hat = (P->max_target < *y_hat) ? P->max_target : *y_hat; /* std::min(max_target, y_hat) */
+    *y_hat = (P->min_target < *y_hat) ? *y_hat : P->min_target; /* std::max(min_target, y_hat) */
+    mult = -(y_true - *y_hat);
+  } else if (P->task == FMO_CLASSIFICATION) {
+    mult = -y_true * (1.0 - 1.0 / (1.0 + exp(-y_true * *y_hat)));
+  }
+  return mult;
+}
+
+/* solver/SGD_Learner.h:195-204 apply_penalty (Tsuruoka cumulative L1). */
+static void fmo_apply_penalty(double* theta, double u, double* q) {
+  double theta_old = *theta;
+  if (*theta > 0) {
+    double t = theta_old - (u + *q);
+    *theta = (0.0 < t) ? t : 0.0; /* std::max(0.0, t) */
+  } else if (*theta < 0) {
+    double t = theta_old + (u - *q);
+    *theta = (t < 0.0) ? t : 0.0; /* std::min(0.0, t) */
+  }
+  *q += *theta - theta_old;
+}
+
+/* solver/SGD_Learner.h:44-59 init(): regularisation mode selection (SURVEY A-9). */
+static void fmo_sgd_mode(const fmo_params* P, int* l1_penalty, double* regw, double* regv) {
+  *l1_penalty = 0;
+  if (P->l1_regw > 0 || P->l1_regv > 0) {
+    *l1_penalty = 1;
+    *regw = P->l1_regw;
+    *regv = P->l1_regv;
+  } else {
+    *regw = P->l2_regw;
+    *regv = P->l2_regv;
+  }
+  if (P->task != FMO_CLASSIFICATION) *l1_penalty = 0;
+}
+
+/* Tracker evaluation block shared by SGD_Learner.h:140-166 and FTRL_Learner.h:118-144. */
+static double fmo_track_eval(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
+                             const fmo_csr* X, const float* y, double* scratch) {
+  if (P->task == FMO_REGRESSION) {
+    fmo_predict_batch(P, p, w0, w, v, X, scratch);
+    fmo_clamp(scratch, X->n, P->min_target, P->max_target);
+  } else {
+    fmo_predict_prob(P, p, w0, w, v, X, scratch);
+  }
+  return fmo_evaluate(P->task, P->eval_type, scratch, y, X->n);
+}
+
+/* One SGD example step, SGD_Learner.h:92-138, on caller-owned state.
+ * q_w/q_v (L1 mode only) are [p] / [k][p]; u_w/u_v the running cumulative penalties. */
+static void fmo_sgd_example(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                            const fmo_csr* X, const float* y, int64_t i, int l1_penalty, double regw,
+                            double regv, double* q_w, double* q_v, double* u_w, double* u_v,
+                            double* m_sum, double* m_sum_sqr) {
+  const double learn_rate = P->learn_rate;
+  if (l1_penalty) {
+    *u_w += learn_rate * regw;
+    *u_v += learn_rate * regv;
+  }
+  double y_hat = fmo_predict(P, p, *w0, w, v, X, i, m_sum, m_sum_sqr);
+  double mult = fmo_grad_mult(P, &y_hat, y[i]);
+  if (P->k0) *w0 -= learn_rate * (mult + P->l2_reg0 * *w0);
+  const int64_t b = X->row_ptr[i], e = X->row_ptr[i + 1];
+  if (P->k1) {
+    for (int64_t j = b; j < e; ++j) {
+      double* wj = &w[X->col[j]];
+      *wj -= learn_rate * mult * X->val[j];
+      if (l1_penalty) fmo_apply_penalty(wj, *u_w, &q_w[X->col[j]]);
+      else *wj -= learn_rate * regw * *wj;
+    }
+  }
+  for (int f = 0; f < P->k; ++f) {
+    double sum_ = m_sum[f];
+    for (int64_t j = b; j < e; ++j) {
+      double* vv = &v[(size_t)f * p + X->col[j]];
+      double grad = sum_ * X->val[j] - *vv * X->val[j] * X->val[j];
+      *vv -= learn_rate * mult * grad;
+      if (l1_penalty) fmo_apply_penalty(vv, *u_v, &q_v[(size_t)f * p + X->col[j]]);
+      else *vv -= learn_rate * regv * *vv;
+    }
+  }
+}
+
+/* solver/SGD_Learner.h:79-178 SGD_Learner::learn (init() at :44-77 folded in: fresh q/u state).
+ * order == NULL: visit rows exactly as the reference does, drawing strides from libc rand().
+ * order != NULL: visit order[0..max_iter) (a list made by fmo_visit_order).
+ * trace_*: tracker records (iteration index, metric); returns the number of examples processed. */
+int64_t fmo_sgd_learn(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                      const fmo_csr* X, const float* y, int64_t max_iter, const int64_t* order,
+                      int64_t* trace_iters, double* trace_vals, int64_t trace_cap, int64_t* trace_n,
+                      int32_t* convergent) {
+  int l1_penalty; double regw, regv;
+  fmo_sgd_mode(P, &l1_penalty, &regw, &regv);
+  double *q_w = NULL, *q_v = NULL, u_w = 0.0, u_v = 0.0;
+  if (l1_penalty) {
+    q_w = (double*)calloc(p ? p : 1, sizeof(double));
+    q_v = (double*)calloc((size_t)(P->k ? P->k : 1) * (p ? p : 1), sizeof(double));
+  }
+  double* m_sum = (double*)calloc((size_t)(P->k ? P->k : 1) * 2, sizeof(double));
+  double* m_sum_sqr = m_sum + (P->k ? P->k : 1);
+  double* scratch = (P->trace_step > 0) ? (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1)) : NULL;
+  int64_t iter = 0, ii = -1, tn = 0;
+  int conv_times = 0;
+  double eval_score_old = 0.0;
+  if (convergent) *convergent = 0;
+  int stop = 0, guard = 0;
+  int64_t opos = 0;
+  for (;;) {
+    int64_t before = iter;
+    uint64_t i = order ? 0 : fmo_random_select(P->random_step);
+    for (;;) {
+      if (order) { if (opos >= max_iter) { stop = 1; break; } i = (uint64_t)order[opos++]; }
+      else if (i >= (uint64_t)X->n) break;
+      fmo_sgd_example(P, p, w0, w, v, X, y, (int64_t)i, l1_penalty, regw, regv, q_w, q_v, &u_w, &u_v, m_sum, m_sum_sqr);
+      if (P->trace_step > 0) {
+        ii++;
+        if (ii == P->trace_step) ii = 0;
+        if (ii == 0 || iter == max_iter - 1) {
+          double eval_score = fmo_track_eval(P, p, *w0, w, v, X, y, scratch);
+          if (iter > P->trace_step && fabs((eval_score - eval_score_old) / (eval_score_old + 1e-30)) <= P->conv_condition) conv_times++;
+          else conv_times = 0;
+          eval_score_old = eval_score;
+          if (tn < trace_cap) { trace_iters[tn] = iter; trace_vals[tn] = eval_score; }
+          tn++;
+        }
+      }
+      iter++;
+      if (conv_times >= 3) { if (convergent) *convergent = 1; stop = 1; break; }
+      if (iter >= max_iter) { stop = 1; break; }
+      if (!order) i += fmo_random_select(P->random_step);
+    }
+    if (stop) break;
+    if (iter == before && ++guard > 1000) break;
+  }
+  if (trace_n) *trace_n = tn;
+  free(q_w); free(q_v); free(m_sum); free(scratch);
+  return iter;
+}
+
+/* ------------------------------------------------------------------ solver/FTRL_Learner.h */
+
+/* solver/FTRL_Learner.h:158-202 calculate_param on the touched coordinates of row i. */
+static void fmo_ftrl_calculate_param(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                                     const fmo_csr* X, int64_t i, double z_w0, double n_w0,
+                                     const double* z_w, const double* n_w, const double* z_v, const double* n_v) {
+  *w0 = -z_w0 * P->alpha_w / (P->beta_w + sqrt(n_w0));
+  const int64_t b = X->row_ptr[i], e = X->row_ptr[i + 1];
+  for (int64_t j = b; j < e; ++j) {
+    uint32_t col_idx = X->col[j];
+    double z = z_w[col_idx];
+    if (fabs(z) <= P->l1_regw) {
+      w[col_idx] = 0.0;
+    } else {
+      double sign = z < 0.0 ? -1.0 : 1.0;
+      w[col_idx] = -(z - sign * P->l1_regw) / ((P->beta_w + sqrt(n_w[col_idx])) / P->alpha_w + P->l2_regw);
+    }
+  }
+  for (int f = 0; f < P->k; ++f) {
+    for (int64_t j = b; j < e; ++j) {
+      size_t at = (size_t)f * p + X->col[j];
+      double z = z_v[at];
+      if (fabs(z) <= P->l1_regv) {
+        v[at] = 0.0;
+      } else {
+        double sign = z < 0.0 ? -1.0 : 1.0;
+        v[at] = -(z - sign * P->l1_regv) / ((P->beta_v + sqrt(n_v[at])) / P->alpha_v + P->l2_regv);
+      }
+    }
+  }
+}
+
+/* One FTRL example step, FTRL_Learner.h:76-116. */
+static void fmo_ftrl_example(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                             const fmo_csr* X, const float* y, int64_t i, double* z_w0, double* n_w0,
+                             double* z_w, double* n_w, double* z_v, double* n_v, double* m_sum, double* m_sum_sqr) {
+  double g, delta;
+  double y_hat = fmo_predict(P, p, *w0, w, v, X, i, m_sum, m_sum_sqr);
+  double mult = fmo_grad_mult(P, &y_hat, y[i]);
+  const int64_t b = X->row_ptr[i], e = X->row_ptr[i + 1];
+  if (P->k0) {
+    g = mult;
+    double n_old = *n_w0;
+    *n_w0 += g * g;
+    delta = (sqrt(*n_w0) - sqrt(n_old)) / P->alpha_w;
+    *z_w0 += g - delta * *w0;
+  }
+  if (P->k1) {
+    for (int64_t j = b; j < e; ++j) {
+      uint32_t c = X->col[j];
+      g = mult * X->val[j];
+      double n_old = n_w[c];
+      n_w[c] += g * g;
+      delta = (sqrt(n_w[c]) - sqrt(n_old)) / P->alpha_w;
+      z_w[c] += g - delta * w[c];
+    }
+  }
+  for (int f = 0; f < P->k; ++f) {
+    double sum_ = m_sum[f];
+    for (int64_t j = b; j < e; ++j) {
+      size_t at = (size_t)f * p + X->col[j];
+      g = mult * (sum_ * X->val[j] - v[at] * X->val[j] * X->val[j]);
+      double n_old = n_v[at];
+      n_v[at] += g * g;
+      delta = (sqrt(n_v[at]) - sqrt(n_old)) / P->alpha_v;
+      z_v[at] += g - delta * v[at];
+    }
+  }
+  fmo_ftrl_calculate_param(P, p, w0, w, v, X, i, *z_w0, *n_w0, z_w, n_w, z_v, n_v);
+}
+
+/* solver/FTRL_Learner.h:64-156 FTRL_Learner::learn (init() at :48-61 folded in: z, n start at 0). */
+int64_t fmo_ftrl_learn(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                       const fmo_csr* X, const float* y, int64_t max_iter, const int64_t* order,
+                       int64_t* trace_iters, double* trace_vals, int64_t trace_cap, int64_t* trace_n,
+                       int32_t* convergent) {
+  size_t kp = (size_t)(P->k ? P->k : 1) * (p ? p : 1);
+  double z_w0 = 0.0, n_w0 = 0.0;
+  double* z_w = (double*)calloc(p ? p : 1, sizeof(double));
+  double* n_w = (double*)calloc(p ? p : 1, sizeof(double));
+  double* z_v = (double*)calloc(kp, sizeof(double));
+  double* n_v = (double*)calloc(kp, sizeof(double));
+  double* m_sum = (double*)calloc((size_t)(P->k ? P->k : 1) * 2, sizeof(double));
+  double* m_sum_sqr = m_sum + (P->k ? P->k : 1);
+  double* scratch = (P->trace_step > 0) ? (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1)) : NULL;
+  int64_t iter = 0, ii = -1, tn = 0;
+  int conv_times = 0;
+  double eval_score_old = 0.0;
+  if (convergent) *convergent = 0;
+  int stop = 0, guard = 0;
+  int64_t opos = 0;
+  for (;;) {
+    int64_t before = iter;
+    uint64_t i = order ? 0 : fmo_random_select(P->random_step);
+    for (;;) {
+      if (order) { if (opos >= max_iter) { stop = 1; break; } i = (uint64_t)order[opos++]; }
+      else if (i >= (uint64_t)X->n) break;
+      fmo_ftrl_example(P, p, w0, w, v, X, y, (int64_t)i, &z_w0, &n_w0, z_w, n_w, z_v, n_v, m_sum, m_sum_sqr);
+      if (P->trace_step > 0) {
+        ii++;
+        if (ii == P->trace_step) ii = 0;
+        if (ii == 0 || iter == max_iter - 1) {
+          double eval_score = fmo_track_eval(P, p, *w0, w, v, X, y, scratch);
+          if (iter > P->trace_step && fabs((eval_score - eval_score_old) / (eval_score_old + 1e-30)) <= P->conv_condition) conv_times++;
+          else conv_times = 0;
+          eval_score_old = eval_score;
+          if (tn < trace_cap) { trace_iters[tn] = iter; trace_vals[tn] = eval_score; }
+          tn++;
+        }
+      }
+      iter++;
+      if (conv_times >= 3) { if (convergent) *convergent = 1; stop = 1; break; }
+      if (iter >= max_iter) { stop = 1; break; }
+      if (!order) i += fmo_random_select(P->random_step);
+    }
+    if (stop) break;
+    if (iter == before && ++guard > 1000) break;
+  }
+  if (trace_n) *trace_n = tn;
+  free(z_w); free(n_w); free(z_v); free(n_v); free(m_sum); free(scratch);
+  return iter;
+}
+
+/* ------------------------------------------------------------------ solver/MCMC_ALS_Learner.h */
+
+/* util/Smatrix.h:155-185 SMatrix::transpose, by result: CSC whose per-feature entries are in
+ * ascending row order.  (The reference's O(p*n) scan is not restated; only its output is.) */
+void fmo_transpose(const fmo_csr* X, int64_t* col_ptr, uint32_t* row_idx, float* val_t) {
+  uint32_t p = X->p;
+  for (uint32_t j = 0; j <= p; ++j) col_ptr[j] = 0;
+  for (int64_t t = 0; t < X->row_ptr[X->n]; ++t) col_ptr[X->col[t] + 1]++;
+  for (uint32_t j = 0; j < p; ++j) col_ptr[j + 1] += col_ptr[j];
+  int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (size_t)(p ? p : 1));
+  for (uint32_t j = 0; j < p; ++j) cur[j] = col_ptr[j];
+  for (int64_t i = 0; i < X->n; ++i)
+    for (int64_t t = X->row_ptr[i]; t < X->row_ptr[i + 1]; ++t) {
+      int64_t at = cur[X->col[t]]++;
+      row_idx[at] = (uint32_t)i;
+      val_t[at] = X->val[t];
+    }
+  free(cur);
+}
+
+/* solver/MCMC_ALS_Learner.h:520-527 calculate_error, REGRESSION branch: e = y_hat - y. */
+void fmo_als_error_regression(double* error, const float* y, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) error[i] -= y[i];
+}
+
+static int fmo_bad(double x) { return isnan(x) || isinf(x); }
+
+/* solver/MCMC_ALS_Learner.h:272-354 update_v, ALS branch (do_sample == false), one attribute group.
+ * The reference works on private copies of error / v_q and never writes them back (SURVEY A-1);
+ * here `error` and `v_q` ARE those copies (caller passes copies) so a test can also read their end state.
+ * csc: col_ptr[p+1], row_idx[nnz], val_t[nnz] (train.data_t).  v_lambda, v_mu: [k] (group 0). */
+void fmo_als_update_v(int k, uint32_t p, double* v, int64_t n, const int64_t* col_ptr, const uint32_t* row_idx,
+                      const float* val_t, double* error, double* v_q, double alpha,
+                      const double* v_lambda, const double* v_mu) {
+  for (int f = 0; f < k; ++f) {
+    for (int64_t r = 0; r < n; ++r) v_q[r] = 0.0;
+    for (uint32_t i = 0; i < p; ++i) {
+      double v_ = v[(size_t)f * p + i];
+      for (int64_t j = col_ptr[i]; j < col_ptr[i + 1]; ++j) v_q[row_idx[j]] += val_t[j] * v_;
+    }
+    for (uint32_t i = 0; i < p; ++i) {
+      double v_mean = 0, v_var = 0;
+      int update_err = 1;
+      double v_old = v[(size_t)f * p + i];
+      double v_ = v_old;
+      for (int64_t m = col_ptr[i]; m < col_ptr[i + 1]; ++m) {
+        float val_ = val_t[m];
+        uint32_t idx_ = row_idx[m];
+        double h = val_ * v_q[idx_] - val_ * val_ * v_; /* val_*val_ is a FLOAT product, as in :314 */
+        v_mean += h * error[idx_];
+        v_var += h * h;
+      }
+      v_mean -= v_ * v_var;
+      v_var = (double)1.0 / (v_lambda[f] + alpha * v_var);
+      v_mean = -v_var * (alpha * v_mean - v_mu[f] * v_lambda[f]);
+      if (fmo_bad(v_var)) v_ = 0.0; else v_ = v_mean;
+      if (fmo_bad(v_)) { v_ = v_old; update_err = 0; } /* CHECK_PARAM, util/Macros.h:36-41 */
+      v[(size_t)f * p + i] = v_;
+      double v_diff = v_old - v_;
+      if (update_err) {
+        for (int64_t m = col_ptr[i]; m < col_ptr[i + 1]; ++m) {
+          float val_ = val_t[m];
+          uint32_t idx_ = row_idx[m];
+          double h = val_ * v_q[idx_] - val_ * val_ * v_old;
+          v_q[idx_] -= val_ * v_diff;
+          error[idx_] -= h * v_diff;
+        }
+      }
+    }
+  }
+}
+
+/* ================================================================== engine semantics (not in reference)
+ * Synchronous mini-batch steps of the MI355X engine, fp64.  Every example of rows [b0,b1) is
+ * evaluated at the batch-start parameters; per touched coordinate the per-example gradients are
+ * SUMMED (G = sum g_i, Q = sum g_i^2, c = number of occurrences) and one update is applied:
+ *   SGD/L2 : theta <- (theta - lr*G) * (1 - lr*reg)^c        (reference: c == 1, SGD_Learner.h:114-119)
+ *   SGD/L1 : theta <- penalty(theta - lr*G; u_end, q)         (u advanced by B*lr*reg first)
+ *   FTRL   : n' = n + Q; z += G - theta*(sqrt(n') - sqrt(n))/alpha; theta <- prox(z, n')
+ * which is the reference's example step when the batch holds one example (tests assert that).
+ */
+
+typedef struct fmo_touch { double G, Q, A2; int64_t c; } fmo_touch;
+
+/* forward + per-coordinate sums over rows [b0,b1); Gw/Qw/cw over [p], Gv/Qv over [k][p]. */
+static void fmo_batch_sums(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
+                           const fmo_csr* X, const float* y, int64_t b0, int64_t b1,
+                           double* G0, double* Q0, double* Gw, double* Qw, double* cw, double* Gv, double* Qv) {
+  int k = P->k;
+  double* m_sum = (double*)calloc((size_t)(k ? k : 1) * 2, sizeof(double));
+  double* m_sum_sqr = m_sum + (k ? k : 1);
+  *G0 = 0.0; *Q0 = 0.0;
+  for (int64_t i = b0; i < b1; ++i) {
+    double y_hat = fmo_predict(P, p, w0, w, v, X, i, m_sum, m_sum_sqr);
+    double mult = fmo_grad_mult(P, &y_hat, y[i]);
+    *G0 += mult; *Q0 += mult * mult;
+    for (int64_t j = X->row_ptr[i]; j < X->row_ptr[i + 1]; ++j) {
+      uint32_t c = X->col[j];
+      double x = X->val[j];
+      double g = mult * x;
+      Gw[c] += g; Qw[c] += g * g; cw[c] += 1.0;
+      for (int f = 0; f < k; ++f) {
+        size_t at = (size_t)f * p + c;
+        double gv = mult * (m_sum[f] * x - v[at] * x * x);
+        Gv[at] += gv; Qv[at] += gv * gv;
+      }
+    }
+  }
+  free(m_sum);
+}
+
+/* state: q_w [p], q_v [k][p], u[2] = {u_w, u_v} (L1 mode; may be NULL otherwise). */
+void fmo_sgd_minibatch_step(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                            const fmo_csr* X, const float* y, int64_t b0, int64_t b1,
+                            double* q_w, double* q_v, double* u) {
+  int l1_penalty; double regw, regv;
+  fmo_sgd_mode(P, &l1_penalty, &regw, &regv);
+  int k = P->k;
+  size_t kp = (size_t)(k ? k : 1) * (p ? p : 1);
+  double* Gw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* Qw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* cw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* Gv = (double*)calloc(kp, sizeof(double));
+  double* Qv = (double*)calloc(kp, sizeof(double));
+  double G0, Q0;
+  fmo_batch_sums(P, p, *w0, w, v, X, y, b0, b1, &G0, &Q0, Gw, Qw, cw, Gv, Qv);
+  const double lr = P->learn_rate;
+  const double B = (double)(b1 - b0);
+  if (l1_penalty) { u[0] += B * (lr * regw); u[1] += B * (lr * regv); }
+  if (P->k0) *w0 -= lr * (G0 + B * P->l2_reg0 * *w0);
+  for (uint32_t j = 0; j < p; ++j) {
+    if (cw[j] == 0.0) continue;
+    if (P->k1) {
+      double t = w[j] - lr * Gw[j];
+      if (l1_penalty) fmo_apply_penalty(&t, u[0], &q_w[j]);
+      else t *= pow(1.0 - lr * regw, cw[j]);
+      w[j] = t;
+    }
+    for (int f = 0; f < k; ++f) {
+      size_t at = (size_t)f * p + j;
+      double t = v[at] - lr * Gv[at];
+      if (l1_penalty) fmo_apply_penalty(&t, u[1], &q_v[at]);
+      else t *= pow(1.0 - lr * regv, cw[j]);
+      v[at] = t;
+    }
+  }
+  free(Gw); free(Qw); free(cw); free(Gv); free(Qv);
+}
+
+/* state: zn0[2] = {z_w0, n_w0}; z_w, n_w [p]; z_v, n_v [k][p]. */
+void fmo_ftrl_minibatch_step(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                             const fmo_csr* X, const float* y, int64_t b0, int64_t b1,
+                             double* zn0, double* z_w, double* n_w, double* z_v, double* n_v) {
+  int k = P->k;
+  size_t kp = (size_t)(k ? k : 1) * (p ? p : 1);
+  double* Gw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* Qw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* cw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* Gv = (double*)calloc(kp, sizeof(double));
+  double* Qv = (double*)calloc(kp, sizeof(double));
+  double G0, Q0;
+  fmo_batch_sums(P, p, *w0, w, v, X, y, b0, b1, &G0, &Q0, Gw, Qw, cw, Gv, Qv);
+  if (P->k0) {
+    double n_new = zn0[1] + Q0;
+    zn0[0] += G0 - *w0 * (sqrt(n_new) - sqrt(zn0[1])) / P->alpha_w;
+    zn0[1] = n_new;
+  }
+  *w0 = -zn0[0] * P->alpha_w / (P->beta_w + sqrt(zn0[1]));
+  for (uint32_t j = 0; j < p; ++j) {
+    if (cw[j] == 0.0) continue;
+    if (P->k1) {
+      double n_new = n_w[j] + Qw[j];
+      z_w[j] += Gw[j] - w[j] * (sqrt(n_new) - sqrt(n_w[j])) / P->alpha_w;
+      n_w[j] = n_new;
+    }
+    {
+      double z = z_w[j];
+      if (fabs(z) <= P->l1_regw) w[j] = 0.0;
+      else {
+        double sign = z < 0.0 ? -1.0 : 1.0;
+        w[j] = -(z - sign * P->l1_regw) / ((P->beta_w + sqrt(n_w[j])) / P->alpha_w + P->l2_regw);
+      }
+    }
+    for (int f = 0; f < k; ++f) {
+      size_t at = (size_t)f * p + j;
+      double n_new = n_v[at] + Qv[at];
+      z_v[at] += Gv[at] - v[at] * (sqrt(n_new) - sqrt(n_v[at])) / P->alpha_v;
+      n_v[at] = n_new;
+      double z = z_v[at];
+      if (fabs(z) <= P->l1_regv) v[at] = 0.0;
+      else {
+        double sign = z < 0.0 ? -1.0 : 1.0;
+        v[at] = -(z - sign * P->l1_regv) / ((P->beta_v + sqrt(n_v[at])) / P->alpha_v + P->l2_regv);
+      }
+    }
+  }
+  free(Gw); free(Qw); free(cw); free(Gv); free(Qv);
+}
+
+/* Timed CPU baseline helper for bench.py: reference-order serial SGD over rows 1..n-1
+ * (random_step == 1), no tracker.  Same code path as fmo_sgd_learn. */
+int64_t fmo_sgd_pass(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                     const fmo_csr* X, const float* y) {
+  return fmo_sgd_learn(P, p, w0, w, v, X, y, X->n - 1, NULL, NULL, NULL, 0, NULL, NULL);
+}
