@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- examples/sec of the FM SGD hot path on the BASELINE.json workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one synchronous mini-batch SGD step (forward + gradient sums + update) over `--batch-rows` rows PER GPU of
+the synthetic 10M x 1M, 30 nnz/row, k=16 workload (BASELINE.json configs[1]); the matrix is generated on the device
+and is resident in HBM before the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), each rank
+owns a contiguous row range, computes its gradient sums, the (k+2)*p buffer is all-reduced, every replica applies the
+same update ("scaling": "weak": per-GPU rows per step are fixed).
+
+Rank 0 prints ONE JSON line: metric/value (whole-job examples/s), the dominant kernel's roofline (HIP-event timed on
+the engine's stream inside the timed region) and, at N == 1, the oracle's serial reference-order SGD timed on the
+host on a bounded sample of the same rows ("cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows of the whole synthetic matrix")
+    ap.add_argument("--features", type=int, default=1_000_000)
+    ap.add_argument("--nnz", type=int, default=30)
+    ap.add_argument("--factors", type=int, default=16)
+    ap.add_argument("--batch-rows", type=int, default=262_144, help="mini-batch rows per GPU per step")
+    ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
+    ap.add_argument("--seed", type=int, default=20240001)
+    ap.add_argument("--cpu-rows", type=int, default=1_500_000, help="rows of the CPU-baseline sample (0: skip)")
+    return ap.parse_args()
+
+
+class _DevBuf:
+    """Exposes a raw device pointer to torch (zero copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def algorithmic_bytes(z, k, p, rows):
+    """Per-launch algorithmic HBM bytes of the two hot kernels and of the SURVEY 8(d) fused step (fp32 state)."""
+    rows_fwd = rows * (z * (4 + 4 + 4 + 4 * k) + 8 + 4 + 4 * k + 4)   # idx,val,w,V row | row_ptr, y, S row, mult
+    cols_upd = rows * z * (4 + 4 + 4 + 4 * k) + p * (4 + 8 * k + 8)    # row,val,mult,S row | bptr, V RMW, w RMW
+    survey_step = rows * (z * (16 + 8 * k) + 12)
+    return rows_fwd, cols_upd, survey_step
+
+
+def cpu_baseline(m, args, v0):
+    """Oracle (reference-order serial SGD, one core) on the first cpu_rows rows of the same matrix."""
+    import oracle
+    n = min(args.cpu_rows, m.n)
+    rp, col, val, y = m.export(0, n)
+    X = oracle.Matrix(rp, col, val, args.features)
+    P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
+    w = np.zeros(args.features)
+    v = np.ascontiguousarray(v0.astype(np.float64))  # [k][p] factor-major, the reference's layout
+    oracle.lib()
+    t0 = time.perf_counter()
+    done = oracle.sgd_pass(P, X, y, 0.0, w, v.ravel())
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "examples/s", "cores": 1, "kind": "port",
+            "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial pass ({dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from fmwr_amd import _lib as L
+    from fmwr_amd import engine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    z, k, p = args.nnz, args.factors, args.features
+    n_local = args.rows // world
+    B = min(args.batch_rows, n_local)
+    m = engine.Matrix.synthetic(n_local, p, z, args.seed, row_offset=rank * n_local, device=local_rank)
+    solver = L.SOLVER_SGD if args.solver == "sgd" else L.SOLVER_FTRL
+    e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=solver, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
+                      l1_w1=1e-4 if args.solver == "ftrl" else 0.0, l1_v=1e-4 if args.solver == "ftrl" else 0.0,
+                      mode=L.MODE_MINIBATCH, batch_rows=B, device=local_rank)
+    v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
+    e.set_params(0.0, None, v0.astype(np.float64))
+    nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work
+    e.num_batches(m)              # builds the per-batch CSC (ingest, not timed)
+
+    gbuf = None
+    ext_stream = torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", local_rank))
+    if world > 1:
+        ptr, nfl = e.grad_buffer()
+        gbuf = torch.as_tensor(_DevBuf(ptr, nfl), device=torch.device("cuda", local_rank))
+
+    def one_step(i):
+        b = i % nb_full
+        if world == 1:
+            e.step(m, b)
+        else:
+            e.grad(m, b)
+            with torch.cuda.stream(ext_stream):
+                dist.all_reduce(gbuf)
+            e.apply(B * world)
+
+    def fence():
+        e.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    e.profile_reset()
+    e.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    e.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    w0, _, vv = e.get_params()
+    if not (np.isfinite(w0) and np.all(np.isfinite(vv))):
+        raise SystemExit("non-finite parameters after the timed region")
+
+    if rank == 0:
+        rows_step = B * world
+        value = rows_step * args.steps / dt
+        fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
+        upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
+        b_fwd, b_upd, b_step = algorithmic_bytes(z, k, p, B)
+        kernels = {
+            "fm_rows_forward": (b_fwd, fwd_ms / max(fwd_n, 1)),
+            "fm_cols_update": (b_upd, upd_ms / max(upd_n, 1)),
+        }
+        dom = max(kernels, key=lambda name: kernels[name][1])
+        dbytes, dms = kernels[dom]
+        achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        out = {
+            "metric": "training examples/sec, 10Mx1M sparse FM SGD", "value": value, "unit": "examples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch "
+                                   f"(BASELINE.json configs[{1 if args.solver == 'sgd' else 2}])",
+                       "batch_rows_per_gpu": B, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
+                       "state": "fp32 V[p][k] + w[p], fp64 accumulation", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dbytes, "avg_launch_ms": dms,
+                         "kernels_ms": {name: kv[1] for name, kv in kernels.items()},
+                         "step_algorithmic_GBps": b_step / (dt / args.steps) / 1e9 / world},
+        }
+        if world == 1 and args.cpu_rows > 0:
+            out["cpu_baseline"] = cpu_baseline(m, args, v0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

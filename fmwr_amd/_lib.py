@@ -1,0 +1,75 @@
+"""ctypes binding of libfmx.so (include/fmx.h).  This is the same binding a reference-side
+maintainer would write (INTEGRATION.md shows the Rcpp form); Python is only the test/bench driver.
+
+There is no fallback: if the library is missing, or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfmx.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NOGPU, ERR_STATE = 0, 1, 2, 3, 4
+TASK_CLASSIFICATION, TASK_REGRESSION = 10, 20
+SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL = 200, 300, 500
+MODE_SEQUENTIAL, MODE_MINIBATCH = 0, 1
+LINK_NONE, LINK_LOGISTIC, LINK_CLAMP = 0, 1, 2
+KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3
+
+# every symbol include/fmx.h declares (tests/test_abi.py checks the library exports all of them)
+SYMBOLS = [
+    "fmx_last_error", "fmx_config_default", "fmx_engine_create", "fmx_engine_destroy", "fmx_set_params",
+    "fmx_get_params", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
+    "fmx_matrix_info", "fmx_matrix_export", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
+    "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
+    "fmx_als_vsweep", "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("task", C.c_int32), ("solver", C.c_int32), ("num_factor", C.c_int32),
+        ("keep_w0", C.c_int32), ("keep_w1", C.c_int32),
+        ("l2_w0", C.c_double), ("l1_w1", C.c_double), ("l2_w1", C.c_double), ("l1_v", C.c_double), ("l2_v", C.c_double),
+        ("learn_rate", C.c_double),
+        ("alpha_w", C.c_double), ("alpha_v", C.c_double), ("beta_w", C.c_double), ("beta_v", C.c_double),
+        ("random_step", C.c_int32), ("mode", C.c_int32), ("batch_rows", C.c_int64),
+        ("min_target", C.c_double), ("max_target", C.c_double),
+        ("device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class FmxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load libfmx.so; raises if it has not been built (python -m fmwr_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build the HIP library first (python -m fmwr_amd.build). "
+                              "fmwr_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.fmx_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            if name != "fmx_last_error":
+                getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        raise FmxError(status, lib().fmx_last_error().decode("utf-8", "replace"))
+
+
+def default_config():
+    cfg = Config()
+    check(lib().fmx_config_default(C.byref(cfg)))
+    return cfg

@@ -1,0 +1,469 @@
+// Mini-batch hot path for gfx950: two gather-reduce kernels over sparse lists plus a scalar kernel.
+//
+//   phase 1  fm_rows_forward : per example (CSR row) gather the V rows of its nonzeros, reduce
+//                              sum_f / sum_sqr_f, form y_hat and the gradient multiplier.
+//                              Replaces Model::predict (core/Model.h:75-103) + calculate_grad_mult
+//                              (solver/SGD_Learner.h:180-191) for a whole batch, and
+//                              Model::predict_batch / predict_prob (core/Model.h:106-180) when !TRAIN.
+//   scalar   fm_scalar_update: deterministic reduction of the multipliers and the w0 step
+//                              (SGD_Learner.h:106-109, FTRL_Learner.h:80-86,161).
+//   phase 2  fm_cols_update  : per feature (row of the batch's CSC) gather the per-example factor sums,
+//                              reduce the coordinate's gradient sums and apply the update
+//                              (SGD_Learner.h:111-138, FTRL_Learner.h:88-113,158-202) once.
+//
+// Both gathers use one skeleton: a group of LPR lanes owns one list; each lane keeps a 16-byte slice of
+// the table row (4 floats / 2 doubles), so one wave-instruction fetches 64/LPR whole rows, every row as
+// one contiguous 16*LPR-byte segment (k=16 fp32: 64 B).  The (id, x) entries of all lists of a workgroup
+// are contiguous in memory; they are staged through LDS with coalesced loads so the row gathers issue
+// back to back.  Accumulation is fp64 in registers (the kernels are HBM/fabric bound; VALU is idle), in
+// list order, which makes every result independent of launch geometry and bitwise reproducible.
+// No MFMA: this is a sparse gather-reduce, not a dense contraction.
+#include "fmx_internal.h"
+
+namespace fmx {
+
+template <typename T> struct Slice;
+template <> struct Slice<float> { using vec = float4; static constexpr int N = 4; };
+template <> struct Slice<double> { using vec = double2; static constexpr int N = 2; };
+
+__device__ __forceinline__ void slice_get(const float4& v, double* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void slice_get(const double2& v, double* o) { o[0] = v.x; o[1] = v.y; }
+
+// solver/SGD_Learner.h:180-191 (copy in FTRL_Learner.h:204-215)
+__device__ __forceinline__ double grad_mult(const Hyper& h, double y_hat, float y) {
+  if (h.task == FMX_TASK_REGRESSION) {
+    y_hat = fmin(h.max_t, y_hat);
+    y_hat = fmax(h.min_t, y_hat);
+    return -((double)y - y_hat);
+  }
+  return -(double)y * (1.0 - 1.0 / (1.0 + exp(-(double)y * y_hat)));
+}
+
+__device__ __forceinline__ double link_apply(const Hyper& h, double y_hat, int link) {
+  if (link == FMX_LINK_LOGISTIC) return 1.0 / (1.0 + exp(-y_hat));  // core/Model.h:173-178
+  if (link == FMX_LINK_CLAMP) {                                       // src/FM.cpp:204-210
+    if (y_hat < h.min_t) return h.min_t;
+    if (y_hat > h.max_t) return h.max_t;
+  }
+  return y_hat;
+}
+
+// coalesced copy of `cnt` (id, x) entries starting at absolute offset c0 into LDS
+__device__ __forceinline__ void stage_entries(uint2* stage, const uint32_t* __restrict__ ids,
+                                              const float* __restrict__ xs, int64_t c0, int cnt) {
+  for (int i = threadIdx.x; i < cnt; i += WG_THREADS)
+    stage[i] = make_uint2(ids[c0 + i], __float_as_uint(xs[c0 + i]));
+}
+
+// ------------------------------------------------------------------------------------------------ phase 1
+template <typename T, int LPR, bool TRAIN>
+__global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hyper h) {
+  using vec_t = typename Slice<T>::vec;
+  constexpr int VEC = Slice<T>::N;
+  constexpr int KP = LPR * VEC;
+  constexpr int RPW = WG_THREADS / LPR;  // rows (lists) per workgroup
+  __shared__ uint2 stage[STAGE_ENTRIES];
+  __shared__ double red[TRAIN ? RPW : 1];
+
+  const int tid = threadIdx.x;
+  const int gid = tid / LPR;
+  const int lig = tid % LPR;
+  const int64_t R0 = (int64_t)blockIdx.x * RPW;
+  const int64_t R1 = (R0 + RPW < a.nrows) ? R0 + RPW : a.nrows;
+  const int64_t lo = a.row_ptr[a.r0 + R0];
+  const int64_t hi = a.row_ptr[a.r0 + R1];
+  const int64_t row = R0 + gid;
+  const bool have = row < a.nrows;
+  int64_t ta = 0, tb = 0;
+  if (have) {
+    ta = a.row_ptr[a.r0 + row];
+    tb = a.row_ptr[a.r0 + row + 1];
+  }
+  const T* __restrict__ Vt = reinterpret_cast<const T*>(a.V) + lig * VEC;
+  const T* __restrict__ wt = reinterpret_cast<const T*>(a.w);
+  const bool k1 = h.k1 != 0;
+
+  double s[VEC], q[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s[i] = 0.0; q[i] = 0.0; }
+  double lin = h.k0 ? a.scal[SC_W0] : 0.0;  // core/Model.h:77-78
+
+  for (int64_t c0 = lo; c0 < hi; c0 += STAGE_ENTRIES) {
+    const int cnt = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
+    stage_entries(stage, a.col, a.val, c0, cnt);
+    __syncthreads();
+    const int64_t b = ta > c0 ? ta : c0;
+    const int64_t e = tb < c0 + cnt ? tb : c0 + cnt;
+    for (int64_t t = b; t < e; t += 4) {
+      const int o = (int)(t - c0);
+      uint2 en[4];
+      en[0] = stage[o];
+#pragma unroll
+      for (int u = 1; u < 4; ++u) en[u] = (t + u < e) ? stage[o + u] : make_uint2(en[0].x, 0u);  // x = +0.0f pads
+      vec_t vv[4];
+      T wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vv[u] = *reinterpret_cast<const vec_t*>(Vt + (size_t)en[u].x * KP);
+        wv[u] = k1 ? wt[en[u].x] : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // nonzeros in row order: same association as core/Model.h:83-97
+        const double x = (double)__uint_as_float(en[u].y);
+        lin += (double)wv[u] * x;
+        double vf[VEC];
+        slice_get(vv[u], vf);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const double tmp = vf[i] * x;
+          s[i] += tmp;
+          q[i] += tmp * tmp;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  double pair = 0.0;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) pair += 0.5 * (s[i] * s[i] - q[i]);  // core/Model.h:100
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) pair += __shfl_xor(pair, off);
+  const double y_hat = lin + pair;
+
+  if constexpr (TRAIN) {
+    double mult = 0.0;
+    if (have) {
+      mult = grad_mult(h, y_hat, a.y[a.r0 + row]);
+      float4 sf = make_float4((float)s[0], (float)s[1], (float)s[VEC > 2 ? 2 : 0], (float)s[VEC > 3 ? 3 : 0]);
+      *reinterpret_cast<float4*>(a.S + (size_t)row * KP + lig * VEC) = sf;
+      if (lig == 0) a.amul[row] = (float)mult;
+    }
+    if (lig == 0) red[gid] = mult;
+    __syncthreads();
+    if (tid == 0) {  // fixed-order partial sums for the w0 step
+      double g0 = 0.0, q0 = 0.0;
+      for (int i = 0; i < RPW; ++i) { g0 += red[i]; q0 += red[i] * red[i]; }
+      a.partials[2 * (size_t)blockIdx.x] = g0;
+      a.partials[2 * (size_t)blockIdx.x + 1] = q0;
+    }
+  } else {
+    if (have && lig == 0) a.yhat[row] = link_apply(h, y_hat, a.link);
+  }
+}
+
+template <typename T, bool TRAIN>
+static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
+  constexpr int VEC = Slice<T>::N;
+  const int lpr = kp / VEC;
+  const int rpw = WG_THREADS / lpr;
+  const int64_t grid = (a.nrows + rpw - 1) / rpw;
+  if (grid == 0) return FMX_OK;
+  FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "rows_forward: grid too large (%lld)", (long long)grid);
+  dim3 g((unsigned)grid), b(WG_THREADS);
+#define FMX_ROWS_CASE(L)                                                                              \
+  case L: hipLaunchKernelGGL((fm_rows_forward_k<T, L, TRAIN>), g, b, 0, e->stream, a, e->hyper); break;
+  switch (lpr) {
+    FMX_ROWS_CASE(1) FMX_ROWS_CASE(2) FMX_ROWS_CASE(4) FMX_ROWS_CASE(8)
+    FMX_ROWS_CASE(16) FMX_ROWS_CASE(32) FMX_ROWS_CASE(64)
+    default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", kp);
+  }
+#undef FMX_ROWS_CASE
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables) {
+  prof_begin(e, FMX_KERNEL_ROWS_FORWARD);
+  int st;
+  if (fp64_tables) {
+    FMX_CHECK(!train, FMX_ERR_INVALID, "mini-batch training runs on fp32 tables");
+    st = launch_rows_t<double, false>(e, a, e->kp64);
+  } else if (train) {
+    st = launch_rows_t<float, true>(e, a, e->kp32);
+  } else {
+    st = launch_rows_t<float, false>(e, a, e->kp32);
+  }
+  prof_end(e);
+  return st;
+}
+
+// ------------------------------------------------------------------------------------------------ scalar
+// phase: 0 fused (reduce + update), 1 reduce only -> exchange buffer tail, 2 update from exchange buffer tail
+__global__ __launch_bounds__(WG_THREADS) void fm_scalar_update_k(const double* __restrict__ partials, int64_t n_partials,
+                                                                 double* scal, float* gtail, Hyper h, double rows, int phase) {
+  __shared__ double sg[WG_THREADS], sq[WG_THREADS];
+  double g0 = 0.0, q0 = 0.0;
+  if (phase != 2) {
+    for (int64_t i = threadIdx.x; i < n_partials; i += WG_THREADS) { g0 += partials[2 * i]; q0 += partials[2 * i + 1]; }
+  }
+  sg[threadIdx.x] = g0; sq[threadIdx.x] = q0;
+  __syncthreads();
+  for (int off = WG_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { sg[threadIdx.x] += sg[threadIdx.x + off]; sq[threadIdx.x] += sq[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  g0 = sg[0]; q0 = sq[0];
+  if (phase == 1) { gtail[0] = (float)g0; gtail[1] = (float)q0; gtail[2] = (float)rows; gtail[3] = 0.f; return; }
+  if (phase == 2) { g0 = gtail[0]; q0 = gtail[1]; }
+  scal[SC_G0] = g0; scal[SC_Q0] = q0;
+  double w0 = scal[SC_W0];
+  if (h.kind == UPD_FTRL) {
+    if (h.k0) {  // solver/FTRL_Learner.h:80-86 with the batch sums G0, Q0
+      const double n_old = scal[SC_N0], n_new = n_old + q0;
+      scal[SC_Z0] += g0 - w0 * (sqrt(n_new) - sqrt(n_old)) / h.alpha_w;
+      scal[SC_N0] = n_new;
+    }
+    scal[SC_W0] = -scal[SC_Z0] * h.alpha_w / (h.beta_w + sqrt(scal[SC_N0]));  // FTRL_Learner.h:161
+  } else {
+    if (h.kind == UPD_SGD_L1) {  // solver/SGD_Learner.h:92-97, once per example of the batch
+      scal[SC_UW] += rows * (h.lr * h.regw);
+      scal[SC_UV] += rows * (h.lr * h.regv);
+    }
+    if (h.k0) scal[SC_W0] = w0 - h.lr * (g0 + rows * h.reg0 * w0);  // SGD_Learner.h:106-109
+  }
+}
+
+int launch_scalar_update(fmx_engine* e, int64_t n_partials, double batch_rows, int phase) {
+  prof_begin(e, FMX_KERNEL_SCALAR);
+  float* tail = e->gbuf ? e->gbuf + (e->gbuf_floats - 4) : nullptr;
+  hipLaunchKernelGGL(fm_scalar_update_k, dim3(1), dim3(WG_THREADS), 0, e->stream, e->partials, n_partials, e->scal, tail,
+                     e->hyper, batch_rows, phase);
+  prof_end(e);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ phase 2
+struct ColsTables {
+  float *V, *w, *sV, *sw, *nV, *nw;
+  const float* S;
+  const float* amul;
+  const double* scal;
+  float* gbuf;
+  uint32_t p;
+};
+
+// solver/SGD_Learner.h:195-204
+__device__ __forceinline__ void apply_penalty(double& theta, double u, double& q) {
+  const double old = theta;
+  if (theta > 0) theta = fmax(0.0, old - (u + q));
+  else if (theta < 0) theta = fmin(0.0, old + (u - q));
+  q += theta - old;
+}
+
+// solver/FTRL_Learner.h:177-182 / :194-199
+__device__ __forceinline__ double ftrl_prox(double z, double n, double l1, double l2, double alpha, double beta) {
+  if (fabs(z) <= l1) return 0.0;
+  const double sign = z < 0.0 ? -1.0 : 1.0;
+  return -(z - sign * l1) / ((beta + sqrt(n)) / alpha + l2);
+}
+
+// One coordinate's update from its batch sums (G = sum g, Q = sum g^2, cnt occurrences); state in/out.
+template <int KIND>
+__device__ __forceinline__ double coord_update(const Hyper& h, bool is_w, double theta, double G, double Q, double cnt,
+                                               double decay, double u, float& st_a, float& st_b, bool keep) {
+  if constexpr (KIND == UPD_SGD_L2) {
+    (void)Q; (void)u; (void)st_a; (void)st_b; (void)cnt; (void)is_w;
+    if (!keep) return theta;
+    return (theta - h.lr * G) * decay;  // SGD_Learner.h:114-119 / :130-135 with c touches folded: (1 - lr*reg)^c
+  } else if constexpr (KIND == UPD_SGD_L1) {
+    (void)Q; (void)decay; (void)st_b; (void)cnt; (void)is_w;
+    if (!keep) return theta;
+    double t = theta - h.lr * G;
+    double q = st_a;
+    apply_penalty(t, u, q);
+    st_a = (float)q;
+    return t;
+  } else {
+    (void)decay; (void)u; (void)cnt;
+    const double alpha = is_w ? h.alpha_w : h.alpha_v, beta = is_w ? h.beta_w : h.beta_v;
+    const double l1 = is_w ? h.l1w : h.l1v, l2 = is_w ? h.l2w : h.l2v;
+    double z = st_a, n = st_b;
+    if (keep) {  // FTRL_Learner.h:88-113 with the batch sums (the sigma terms telescope)
+      const double n_new = n + Q;
+      z += G - theta * (sqrt(n_new) - sqrt(n)) / alpha;
+      n = n_new;
+      st_a = (float)z; st_b = (float)n;
+    }
+    return ftrl_prox((double)st_a, (double)st_b, l1, l2, alpha, beta);
+  }
+}
+
+template <int LPR, int KIND>
+__global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables T) {
+  constexpr int VEC = 4;
+  constexpr int KP = LPR * VEC;
+  constexpr int FPW = WG_THREADS / LPR;  // features (lists) per workgroup
+  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  __shared__ uint2 stage[STAGE_ENTRIES];
+
+  const int tid = threadIdx.x;
+  const int gid = tid / LPR;
+  const int lig = tid % LPR;
+  const int64_t J0 = (int64_t)blockIdx.x * FPW;
+  const int64_t J1 = (J0 + FPW < (int64_t)T.p) ? J0 + FPW : (int64_t)T.p;
+  const int64_t j = J0 + gid;
+  const bool have = j < (int64_t)T.p;
+
+  float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (have) v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
+  double vf[VEC];
+  slice_get(v4, vf);
+
+  double G[VEC], Q[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { G[i] = 0.0; Q[i] = 0.0; }
+  double Gw = 0.0, Qw = 0.0, cnt = 0.0;
+
+  // exchange buffer planes: GV [p][KP] | GW [p] | CNT [p] | (FTRL) QV [p][KP] | QW [p] | tail[4]
+  float* gGV = T.gbuf;
+  float* gGW = T.gbuf ? T.gbuf + (size_t)T.p * KP : nullptr;
+  float* gCN = T.gbuf ? gGW + T.p : nullptr;
+  float* gQV = T.gbuf ? gCN + T.p : nullptr;
+  float* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
+
+  if (a.phase != 2) {
+    const int64_t lo = a.bptr[J0], hi = a.bptr[J1];
+    int64_t ta = 0, tb = 0;
+    if (have) { ta = a.bptr[j]; tb = a.bptr[j + 1]; }
+    const float* __restrict__ St = T.S + lig * VEC;
+    for (int64_t c0 = lo; c0 < hi; c0 += STAGE_ENTRIES) {
+      const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
+      stage_entries(stage, a.brow, a.bval, c0, cn);
+      __syncthreads();
+      const int64_t b = ta > c0 ? ta : c0;
+      const int64_t e = tb < c0 + cn ? tb : c0 + cn;
+      for (int64_t t = b; t < e; t += 4) {
+        const int o = (int)(t - c0);
+        uint2 en[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          en[u] = (t + u < e) ? stage[o + u] : make_uint2(0xFFFFFFFFu, 0u);
+          ok[u] = en[u].x < a.rows_active;  // truncated batch: rows beyond the limit do not take part
+          if (!ok[u]) en[u].x = 0;
+        }
+        float4 sv[4];
+        float av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sv[u] = *reinterpret_cast<const float4*>(St + (size_t)en[u].x * KP);
+          av[u] = T.amul[en[u].x];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // occurrences in row order
+          if (!ok[u]) continue;
+          const double x = (double)__uint_as_float(en[u].y);
+          const double ax = (double)av[u] * x;  // mult * x: the w gradient, SGD_Learner.h:114
+          Gw += ax;
+          if (NEED_Q) Qw += ax * ax;
+          cnt += 1.0;
+          double sf[VEC];
+          slice_get(sv[u], sf);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const double g = ax * (sf[i] - vf[i] * x);  // mult*(sum_f*x - v*x*x), SGD_Learner.h:129
+            G[i] += g;
+            if (NEED_Q) Q[i] += g * g;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else if (have) {  // apply-only: sums come from the (all-reduced) exchange buffer
+    float4 g4 = *reinterpret_cast<const float4*>(gGV + (size_t)j * KP + lig * VEC);
+    slice_get(g4, G);
+    Gw = gGW[j];
+    cnt = gCN[j];
+    if (NEED_Q) {
+      float4 q4 = *reinterpret_cast<const float4*>(gQV + (size_t)j * KP + lig * VEC);
+      slice_get(q4, Q);
+      Qw = gQW[j];
+    }
+  }
+  if (!have) return;
+
+  if (a.phase == 1) {  // accumulate-only: publish the local sums (every feature, zeros included)
+    *reinterpret_cast<float4*>(gGV + (size_t)j * KP + lig * VEC) = make_float4((float)G[0], (float)G[1], (float)G[2], (float)G[3]);
+    if (NEED_Q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)Q[0], (float)Q[1], (float)Q[2], (float)Q[3]);
+    if (lig == 0) {
+      gGW[j] = (float)Gw;
+      gCN[j] = (float)cnt;
+      if (NEED_Q) gQW[j] = (float)Qw;
+    }
+    return;
+  }
+
+  if (cnt == 0.0) return;  // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
+
+  double decay_v = 1.0, decay_w = 1.0, u_w = 0.0, u_v = 0.0;
+  if constexpr (KIND == UPD_SGD_L2) {
+    if (h.regv != 0.0) decay_v = pow(1.0 - h.lr * h.regv, cnt);
+    if (h.regw != 0.0) decay_w = pow(1.0 - h.lr * h.regw, cnt);
+  }
+  if constexpr (KIND == UPD_SGD_L1) { u_w = T.scal[SC_UW]; u_v = T.scal[SC_UV]; }
+
+  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+  if constexpr (KIND != UPD_SGD_L2) sa = *reinterpret_cast<const float4*>(T.sV + (size_t)j * KP + lig * VEC);
+  if constexpr (KIND == UPD_FTRL) sb = *reinterpret_cast<const float4*>(T.nV + (size_t)j * KP + lig * VEC);
+  float sa_[VEC] = {sa.x, sa.y, sa.z, sa.w}, sb_[VEC] = {sb.x, sb.y, sb.z, sb.w};
+  float out[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+    out[i] = (float)coord_update<KIND>(h, false, vf[i], G[i], Q[i], cnt, decay_v, u_v, sa_[i], sb_[i], true);
+  *reinterpret_cast<float4*>(T.V + (size_t)j * KP + lig * VEC) = make_float4(out[0], out[1], out[2], out[3]);
+  if constexpr (KIND != UPD_SGD_L2) *reinterpret_cast<float4*>(T.sV + (size_t)j * KP + lig * VEC) = make_float4(sa_[0], sa_[1], sa_[2], sa_[3]);
+  if constexpr (KIND == UPD_FTRL) *reinterpret_cast<float4*>(T.nV + (size_t)j * KP + lig * VEC) = make_float4(sb_[0], sb_[1], sb_[2], sb_[3]);
+
+  if (lig == 0) {
+    // FTRL recomputes w on every touched column even when keep.w1 is off (FTRL_Learner.h:172-183); SGD skips (:111)
+    const bool k1 = h.k1 != 0;
+    if (k1 || KIND == UPD_FTRL) {
+      float wa = 0.f, wb = 0.f;
+      if constexpr (KIND != UPD_SGD_L2) wa = T.sw[j];
+      if constexpr (KIND == UPD_FTRL) wb = T.nw[j];
+      const double wn = coord_update<KIND>(h, true, (double)T.w[j], Gw, Qw, cnt, decay_w, u_w, wa, wb, k1);
+      T.w[j] = (float)wn;
+      if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
+      if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
+    }
+  }
+}
+
+template <int KIND>
+static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const ColsTables& T) {
+  const int lpr = e->kp32 / 4;
+  const int fpw = WG_THREADS / lpr;
+  const int64_t grid = ((int64_t)T.p + fpw - 1) / fpw;
+  if (grid == 0) return FMX_OK;
+  FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "cols_update: grid too large");
+  dim3 g((unsigned)grid), b(WG_THREADS);
+#define FMX_COLS_CASE(L) \
+  case L: hipLaunchKernelGGL((fm_cols_update_k<L, KIND>), g, b, 0, e->stream, a, e->hyper, T); break;
+  switch (lpr) {
+    FMX_COLS_CASE(1) FMX_COLS_CASE(2) FMX_COLS_CASE(4) FMX_COLS_CASE(8)
+    FMX_COLS_CASE(16) FMX_COLS_CASE(32) FMX_COLS_CASE(64)
+    default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", e->kp32);
+  }
+#undef FMX_COLS_CASE
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
+  ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->gbuf, (uint32_t)e->p};
+  FMX_CHECK(a.phase == 0 || e->gbuf != nullptr, FMX_ERR_STATE, "exchange buffer not allocated");
+  prof_begin(e, FMX_KERNEL_COLS_UPDATE);
+  int st;
+  switch (e->hyper.kind) {
+    case UPD_SGD_L2: st = launch_cols_kind<UPD_SGD_L2>(e, a, T); break;
+    case UPD_SGD_L1: st = launch_cols_kind<UPD_SGD_L1>(e, a, T); break;
+    default: st = launch_cols_kind<UPD_FTRL>(e, a, T); break;
+  }
+  prof_end(e);
+  return st;
+}
+
+}  // namespace fmx

@@ -1,0 +1,236 @@
+// Ingest side of the path (one-off per matrix, not the hot loop):
+//   * per-batch CSC ("inverted index": for every feature the (local row, x) pairs of one batch in row order),
+//     which phase 2 of the mini-batch step walks; built with a stable device radix sort by column;
+//   * CSC of the whole matrix for the ALS sweep -- the reference builds it with an O(p*n) scan
+//     (util/Smatrix.h:155-185, called at src/FM.cpp:148-152); result layout is the same (rows ascending per feature);
+//   * the synthetic workload generator, Philox4x32-10 keyed by (seed, global row id);
+//   * the strictly-ascending-rows check the sequential learner uses.
+#include <hip/hip_runtime.h>
+
+#include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include "fmx_internal.h"
+
+namespace fmx {
+
+// ------------------------------------------------------------------------------------------------ CSC builders
+__global__ void pack_entries_k(const int64_t* __restrict__ row_ptr, const float* __restrict__ val, int64_t r0, int64_t nrows,
+                               int64_t base, int64_t cnt, uint64_t* __restrict__ packed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const int64_t t = base + i;
+  // row of entry t: last r in [r0, r0+nrows) with row_ptr[r] <= t
+  int64_t lo = r0, hi = r0 + nrows;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (row_ptr[mid] <= t) lo = mid; else hi = mid;
+  }
+  packed[i] = ((uint64_t)(uint32_t)(lo - r0) << 32) | (uint64_t)__float_as_uint(val[t]);
+}
+
+__global__ void unpack_entries_k(const uint64_t* __restrict__ packed, int64_t cnt, uint32_t* __restrict__ rows, float* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const uint64_t v = packed[i];
+  rows[i] = (uint32_t)(v >> 32);
+  vals[i] = __uint_as_float((uint32_t)v);
+}
+
+template <typename OffT>
+__global__ void feature_offsets_k(const uint32_t* __restrict__ sorted_cols, int64_t cnt, uint32_t p, OffT* __restrict__ ptr) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > (int64_t)p) return;
+  int64_t lo = 0, hi = cnt;  // lower_bound(sorted_cols, j)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)sorted_cols[mid] < j) lo = mid + 1; else hi = mid;
+  }
+  ptr[j] = (OffT)lo;
+}
+
+__global__ void gather_i64_k(const int64_t* __restrict__ src, int64_t stride, int64_t n, int64_t count, int64_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t at = i * stride;
+  dst[i] = src[at < n ? at : n];
+}
+
+static int col_bits(uint32_t p) {
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < (uint64_t)p) ++bits;
+  return bits;
+}
+
+struct SortScratch {
+  uint32_t* keys_out = nullptr;
+  uint64_t *vals_in = nullptr, *vals_out = nullptr;
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+  ~SortScratch() {
+    (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(temp);
+  }
+};
+
+static int sort_scratch_alloc(SortScratch& s, int64_t max_cnt, int bits, hipStream_t stream) {
+  const size_t m = (size_t)(max_cnt > 0 ? max_cnt : 1);
+  FMX_HIP(hipMalloc(&s.keys_out, m * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&s.vals_in, m * sizeof(uint64_t)));
+  FMX_HIP(hipMalloc(&s.vals_out, m * sizeof(uint64_t)));
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, s.temp_bytes, (const uint32_t*)nullptr, s.keys_out, s.vals_in, s.vals_out, m, 0, bits, stream));
+  FMX_HIP(hipMalloc(&s.temp, s.temp_bytes ? s.temp_bytes : 16));
+  return FMX_OK;
+}
+
+// sort entries [base, base+cnt) of rows [r0, r0+nrows) by column (stable => rows stay ascending per column)
+template <typename OffT>
+static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r0, int64_t nrows, int64_t base, int64_t cnt,
+                        uint32_t* out_rows, float* out_vals, OffT* out_ptr, hipStream_t stream) {
+  const int T = 256;
+  if (cnt > 0) {
+    hipLaunchKernelGGL(pack_entries_k, dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, stream, m->row_ptr, m->val, r0, nrows, base, cnt, s.vals_in);
+    FMX_HIP(rocprim::radix_sort_pairs(s.temp, s.temp_bytes, m->col + base, s.keys_out, s.vals_in, s.vals_out, (size_t)cnt, 0, bits, stream));
+    hipLaunchKernelGGL(unpack_entries_k, dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, stream, s.vals_out, cnt, out_rows, out_vals);
+  }
+  hipLaunchKernelGGL((feature_offsets_k<OffT>), dim3((unsigned)(((int64_t)m->p + 1 + T - 1) / T)), dim3(T), 0, stream, s.keys_out, cnt, m->p, out_ptr);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int build_batch_csc(fmx_matrix* m, int64_t batch_rows, hipStream_t stream) {
+  FMX_CHECK(batch_rows > 0, FMX_ERR_INVALID, "batch_rows must be positive");
+  if (m->batch_rows == batch_rows && m->bptr) return FMX_OK;
+  FMX_HIP(hipSetDevice(m->device));
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
+  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr;
+  const int64_t nb = (m->n + batch_rows - 1) / batch_rows;
+  m->batch_rows = batch_rows;
+  m->n_batches = nb;
+  // row_ptr at the batch boundaries -> host
+  m->h_row_ptr_batches.assign((size_t)nb + 1, 0);
+  {
+    int64_t* d = nullptr;
+    FMX_HIP(hipMalloc(&d, ((size_t)nb + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(gather_i64_k, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, stream, m->row_ptr, batch_rows, m->n, nb + 1, d);
+    FMX_HIP(hipMemcpyAsync(m->h_row_ptr_batches.data(), d, ((size_t)nb + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    FMX_HIP(hipStreamSynchronize(stream));
+    FMX_HIP(hipFree(d));
+  }
+  int64_t max_cnt = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t c = m->h_row_ptr_batches[b + 1] - m->h_row_ptr_batches[b];
+    FMX_CHECK(c < (1LL << 32), FMX_ERR_INVALID, "a batch holds %lld nonzeros; at most 2^32-1 are supported (lower batch_rows)", (long long)c);
+    if (c > max_cnt) max_cnt = c;
+  }
+  FMX_HIP(hipMalloc(&m->bptr, (size_t)nb * ((size_t)m->p + 1) * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&m->brow, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&m->bval, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(float)));
+  const int bits = col_bits(m->p);
+  SortScratch s;
+  FMX_TRY(sort_scratch_alloc(s, max_cnt, bits, stream));
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t r0 = b * batch_rows;
+    const int64_t nrows = (r0 + batch_rows <= m->n) ? batch_rows : m->n - r0;
+    const int64_t base = m->h_row_ptr_batches[b], cnt = m->h_row_ptr_batches[b + 1] - base;
+    FMX_TRY(csc_of_range<uint32_t>(m, s, bits, r0, nrows, base, cnt, m->brow + base, m->bval + base,
+                                   m->bptr + (size_t)b * ((size_t)m->p + 1), stream));
+  }
+  FMX_HIP(hipStreamSynchronize(stream));
+  return FMX_OK;
+}
+
+int build_full_csc(fmx_matrix* m, hipStream_t stream) {
+  if (m->col_ptr) return FMX_OK;
+  FMX_CHECK(m->n < (1LL << 32), FMX_ERR_INVALID, "ALS sweep supports fewer than 2^32 rows");
+  FMX_HIP(hipSetDevice(m->device));
+  FMX_HIP(hipMalloc(&m->col_ptr, ((size_t)m->p + 1) * sizeof(int64_t)));
+  FMX_HIP(hipMalloc(&m->crow, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&m->cval, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(float)));
+  const int bits = col_bits(m->p);
+  SortScratch s;
+  FMX_TRY(sort_scratch_alloc(s, m->nnz, bits, stream));
+  FMX_TRY(csc_of_range<int64_t>(m, s, bits, 0, m->n, 0, m->nnz, m->crow, m->cval, m->col_ptr, stream));
+  FMX_HIP(hipStreamSynchronize(stream));
+  return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ synthetic data
+struct Philox {
+  uint32_t c[4];
+};
+__host__ __device__ inline Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox{{c0, c1, c2, c3}};
+}
+
+// entry i of global row g: stratum i of nnz equal-width strata of [0,p); position inside it from Philox(seed; g, i/4)[i%4]
+__global__ void synth_entries_k(int64_t n, uint32_t p, int32_t z, uint64_t seed, int64_t row_offset, uint32_t* __restrict__ col,
+                                float* __restrict__ val) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * z) return;
+  const int64_t r = t / z;
+  const uint32_t i = (uint32_t)(t - r * z);
+  const uint64_t g = (uint64_t)(row_offset + r);
+  const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), i >> 2, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t rnd = ph.c[i & 3];
+  const uint32_t lo = (uint32_t)(((uint64_t)i * p) / (uint32_t)z);
+  const uint32_t hi = (uint32_t)(((uint64_t)(i + 1) * p) / (uint32_t)z);
+  col[t] = lo + (uint32_t)(((uint64_t)rnd * (hi - lo)) >> 32);
+  val[t] = 1.0f;
+}
+
+__global__ void synth_rows_k(int64_t n, int32_t z, uint64_t seed, int64_t row_offset, int64_t* __restrict__ row_ptr, float* __restrict__ y) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  row_ptr[r] = r * z;
+  if (r < n) {
+    const uint64_t g = (uint64_t)(row_offset + r);
+    const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 0xFFFFFFFFu, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    y[r] = (ph.c[0] & 1u) ? 1.0f : -1.0f;
+  }
+}
+
+int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offset) {
+  const int T = 256;
+  const int64_t total = m->n * z;
+  if (total > 0)
+    hipLaunchKernelGGL(synth_entries_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, nullptr, m->n, m->p, z, seed, row_offset, m->col, m->val);
+  hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((m->n + 1 + T - 1) / T)), dim3(T), 0, nullptr, m->n, z, seed, row_offset, m->row_ptr, m->y);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipDeviceSynchronize());
+  m->rows_sorted = 1;  // strata are disjoint and ascending
+  return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ sortedness
+__global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int* __restrict__ unsorted) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int bad = 0;
+  for (int64_t t = row_ptr[r]; t + 1 < row_ptr[r + 1]; ++t) bad |= (col[t] >= col[t + 1]);
+  if (bad) *unsorted = 1;
+}
+
+int check_rows_sorted(fmx_matrix* m) {
+  int* d = nullptr;
+  int h = 0;
+  FMX_HIP(hipMalloc(&d, sizeof(int)));
+  FMX_HIP(hipMemset(d, 0, sizeof(int)));
+  if (m->n > 0) hipLaunchKernelGGL(rows_sorted_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->n, d);
+  FMX_HIP(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
+  FMX_HIP(hipFree(d));
+  m->rows_sorted = !h;
+  return FMX_OK;
+}
+
+}  // namespace fmx

@@ -1,0 +1,651 @@
+// Host side of libfmx.so: the extern "C" entry points of include/fmx.h.
+// What FM() / FMPredict() do around learner->learn() and fm.predict_batch() in the reference
+// (src/FM.cpp:7-173, :177-214) minus the R list (un)marshalling, which stays in the Rcpp glue.
+// There is no CPU fallback anywhere in this library: without a usable HIP device every entry point fails.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "fmx_internal.h"
+
+namespace fmx {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+void prof_begin(fmx_engine* e, int kernel) {
+  if (!e->profile) return;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  (void)hipEventRecord(a, e->stream);
+  e->prof_pending.push_back({kernel, {a, b}});
+}
+
+void prof_end(fmx_engine* e) {
+  if (!e->profile || e->prof_pending.empty()) return;
+  (void)hipEventRecord(e->prof_pending.back().second.second, e->stream);
+}
+
+static int prof_collect(fmx_engine* e) {
+  if (e->prof_pending.empty()) return FMX_OK;
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  for (auto& pr : e->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.second.first, pr.second.second) == hipSuccess) {
+      e->prof_ms[pr.first] += ms;
+      e->prof_n[pr.first] += 1;
+    }
+    (void)hipEventDestroy(pr.second.first);
+    (void)hipEventDestroy(pr.second.second);
+  }
+  e->prof_pending.clear();
+  return FMX_OK;
+}
+
+static int use_device(int device) {
+  int count = 0;
+  hipError_t err = hipGetDeviceCount(&count);
+  if (err != hipSuccess || count <= 0) {
+    set_error("no HIP device available (%s); libfmx has no CPU fallback", err == hipSuccess ? "device count 0" : hipGetErrorString(err));
+    return FMX_ERR_NOGPU;
+  }
+  FMX_CHECK(device >= 0 && device < count, FMX_ERR_INVALID, "device %d out of range (0..%d)", device, count - 1);
+  FMX_HIP(hipSetDevice(device));
+  return FMX_OK;
+}
+
+template <typename T>
+static int dev_alloc_zero(T** ptr, size_t count) {
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  FMX_HIP(hipMalloc(ptr, bytes));
+  FMX_HIP(hipMemset(*ptr, 0, bytes));
+  return FMX_OK;
+}
+
+// solver/SGD_Learner.h:44-59 (regularisation mode) and FM.cpp:87-144 (plumbing) as one struct for the kernels
+static int make_hyper(const fmx_config& c, Hyper* h) {
+  h->task = c.task;
+  h->k0 = c.keep_w0 != 0;
+  h->k1 = c.keep_w1 != 0;
+  h->lr = c.learn_rate;
+  h->reg0 = c.l2_w0;
+  h->l1w = c.l1_w1; h->l1v = c.l1_v; h->l2w = c.l2_w1; h->l2v = c.l2_v;
+  h->alpha_w = c.alpha_w; h->alpha_v = c.alpha_v; h->beta_w = c.beta_w; h->beta_v = c.beta_v;
+  h->min_t = c.min_target; h->max_t = c.max_target;
+  if (c.solver == FMX_SOLVER_FTRL) {
+    h->kind = UPD_FTRL;
+    h->regw = 0; h->regv = 0;
+  } else {
+    bool l1 = false;
+    if (c.l1_w1 > 0 || c.l1_v > 0) {  // SGD_Learner.h:46-51: any L1 > 0 => L1 rates are used, L2 dropped
+      l1 = true;
+      h->regw = c.l1_w1; h->regv = c.l1_v;
+    } else {
+      h->regw = c.l2_w1; h->regv = c.l2_v;
+    }
+    if (c.task != FMX_TASK_CLASSIFICATION) l1 = false;  // SGD_Learner.h:57-59 (the L1 rates then act as L2, SURVEY A-9)
+    h->kind = l1 ? UPD_SGD_L1 : UPD_SGD_L2;
+  }
+  return FMX_OK;
+}
+
+static bool seq_mode(const fmx_engine* e) { return e->cfg.mode == FMX_MODE_SEQUENTIAL; }
+
+static int reset_optimizer_state(fmx_engine* e) {
+  const size_t p = e->p;
+  double zeros[SC_COUNT] = {0};
+  double w0 = 0;
+  FMX_HIP(hipMemcpy(&w0, e->scal + SC_W0, sizeof(double), hipMemcpyDeviceToHost));
+  zeros[SC_W0] = w0;
+  FMX_HIP(hipMemcpy(e->scal, zeros, sizeof(zeros), hipMemcpyHostToDevice));
+  if (e->sV) FMX_HIP(hipMemset(e->sV, 0, p * e->kp32 * sizeof(float)));
+  if (e->sw) FMX_HIP(hipMemset(e->sw, 0, p * sizeof(float)));
+  if (e->nV) FMX_HIP(hipMemset(e->nV, 0, p * e->kp32 * sizeof(float)));
+  if (e->nw) FMX_HIP(hipMemset(e->nw, 0, p * sizeof(float)));
+  if (e->dsV) FMX_HIP(hipMemset(e->dsV, 0, p * e->kp64 * sizeof(double)));
+  if (e->dsw) FMX_HIP(hipMemset(e->dsw, 0, p * sizeof(double)));
+  if (e->dnV) FMX_HIP(hipMemset(e->dnV, 0, p * e->kp64 * sizeof(double)));
+  if (e->dnw) FMX_HIP(hipMemset(e->dnw, 0, p * sizeof(double)));
+  return FMX_OK;
+}
+
+static int ensure_workspace(fmx_engine* e, int64_t rows) {
+  if (rows <= e->ws_rows) return FMX_OK;
+  (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
+  e->S = nullptr; e->amul = nullptr; e->partials = nullptr; e->ws_rows = 0;
+  const int rpw = WG_THREADS / (e->kp32 / 4);
+  e->ws_partials = (rows + rpw - 1) / rpw;
+  FMX_HIP(hipMalloc(&e->S, (size_t)rows * e->kp32 * sizeof(float)));
+  FMX_HIP(hipMalloc(&e->amul, (size_t)rows * sizeof(float)));
+  FMX_HIP(hipMalloc(&e->partials, (size_t)e->ws_partials * 2 * sizeof(double)));
+  e->ws_rows = rows;
+  return FMX_OK;
+}
+
+static int ensure_gbuf(fmx_engine* e) {
+  if (e->gbuf) return FMX_OK;
+  const int64_t planes = (e->hyper.kind == UPD_FTRL) ? 2 : 1;
+  // GV [p][kp] | GW [p] | CNT [p] | (FTRL) QV [p][kp] | QW [p] | tail[4]; the FTRL planes are always reserved
+  // behind CNT so the layout does not depend on the solver
+  (void)planes;
+  e->gbuf_floats = (int64_t)e->p * e->kp32 * 2 + (int64_t)e->p * 3 + 4;
+  FMX_TRY(dev_alloc_zero(&e->gbuf, (size_t)e->gbuf_floats));
+  return FMX_OK;
+}
+
+// The reference's visiting order, solver/SGD_Learner.h:86-88 with util/Random.h:20-24,126-132: strides from libc rand()
+// (unseeded in the reference, SURVEY A-4), row 0 skipped when random_step == 1 (A-2).
+static uint32_t random_select(int n) {
+  if (n == 1) return 1;
+  return (uint32_t)((rand() / ((double)RAND_MAX + 1)) * n + 1);
+}
+
+static void visit_order(int64_t n, int random_step, int64_t max_iter, std::vector<int64_t>* out) {
+  out->clear();
+  out->reserve((size_t)max_iter);
+  int idle = 0;
+  while ((int64_t)out->size() < max_iter) {
+    const size_t before = out->size();
+    for (uint64_t i = random_select(random_step); i < (uint64_t)n; i += random_select(random_step)) {
+      out->push_back((int64_t)i);
+      if ((int64_t)out->size() >= max_iter) break;
+    }
+    if (out->size() == before && ++idle > 1000) break;  // n <= 1: nothing can ever be visited
+  }
+}
+
+static void free_matrix(fmx_matrix* m) {
+  if (!m) return;
+  (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
+  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
+  delete m;
+}
+
+static int alloc_matrix(int device, int64_t n, uint32_t p, int64_t nnz, bool labels, fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(n >= 0 && nnz >= 0, FMX_ERR_INVALID, "negative size");
+  FMX_TRY(use_device(device));
+  std::unique_ptr<fmx_matrix, void (*)(fmx_matrix*)> m(new fmx_matrix(), free_matrix);
+  m->device = device; m->n = n; m->p = p; m->nnz = nnz; m->has_labels = labels;
+  FMX_HIP(hipMalloc(&m->row_ptr, ((size_t)n + 1) * sizeof(int64_t)));
+  // one spare entry, like the reference's over-read guard (SURVEY A-13); keeps zero-nnz matrices allocatable too
+  FMX_HIP(hipMalloc(&m->col, ((size_t)nnz + 1) * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&m->val, ((size_t)nnz + 1) * sizeof(float)));
+  FMX_HIP(hipMalloc(&m->y, ((size_t)n + 1) * sizeof(float)));
+  FMX_HIP(hipMemset(m->y, 0, ((size_t)n + 1) * sizeof(float)));
+  *out = m.release();
+  return FMX_OK;
+}
+
+static int upload_matrix(fmx_matrix* m, const int64_t* row_ptr, const uint32_t* col, const float* val, const float* y) {
+  FMX_HIP(hipMemcpy(m->row_ptr, row_ptr, ((size_t)m->n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  if (m->nnz) {
+    FMX_HIP(hipMemcpy(m->col, col, (size_t)m->nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FMX_HIP(hipMemcpy(m->val, val, (size_t)m->nnz * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (y && m->n) FMX_HIP(hipMemcpy(m->y, y, (size_t)m->n * sizeof(float), hipMemcpyHostToDevice));
+  return check_rows_sorted(m);
+}
+
+static int check_pair(const fmx_engine* e, const fmx_matrix* m) {
+  FMX_CHECK(e && m, FMX_ERR_INVALID, "NULL handle");
+  // core/Model.h:115: "number of input's features is not correct..."
+  FMX_CHECK((uint64_t)m->p == e->p, FMX_ERR_INVALID, "number of input's features is not correct...");
+  FMX_CHECK(m->device == e->cfg.device, FMX_ERR_INVALID, "matrix lives on device %d, engine on %d", m->device, e->cfg.device);
+  return FMX_OK;
+}
+
+static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r1, double* d_out, int link) {
+  const int64_t SLAB = 1 << 22;
+  for (int64_t b = r0; b < r1; b += SLAB) {
+    RowsArgs a{};
+    a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = nullptr;
+    a.r0 = b; a.nrows = (r1 - b < SLAB) ? r1 - b : SLAB;
+    a.V = seq_mode(e) ? (const void*)e->dV : (const void*)e->V;
+    a.w = seq_mode(e) ? (const void*)e->dw : (const void*)e->w;
+    a.scal = e->scal;
+    a.yhat = d_out + (b - r0);
+    a.link = link;
+    FMX_TRY(launch_rows_forward(e, a, false, seq_mode(e)));
+  }
+  return FMX_OK;
+}
+
+static int batch_geometry(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, int64_t* b0, int64_t* nrows) {
+  FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "step interface needs FMX_MODE_MINIBATCH");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");  // R/fm_train.R:72-74
+  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, e->stream));
+  FMX_CHECK(batch >= 0 && batch < m->n_batches, FMX_ERR_INVALID, "batch %lld out of range (0..%lld)", (long long)batch, (long long)m->n_batches - 1);
+  *b0 = batch * m->batch_rows;
+  *nrows = (*b0 + m->batch_rows <= m->n) ? m->batch_rows : m->n - *b0;
+  if (rows_limit > 0 && rows_limit < *nrows) *nrows = rows_limit;
+  FMX_TRY(ensure_workspace(e, m->batch_rows < m->n ? m->batch_rows : m->n));
+  return FMX_OK;
+}
+
+static int rows_phase(fmx_engine* e, fmx_matrix* m, int64_t b0, int64_t nrows, int64_t* n_partials) {
+  RowsArgs a{};
+  a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = m->y;
+  a.r0 = b0; a.nrows = nrows;
+  a.V = e->V; a.w = e->w; a.scal = e->scal;
+  a.S = e->S; a.amul = e->amul; a.partials = e->partials;
+  const int rpw = WG_THREADS / (e->kp32 / 4);
+  *n_partials = (nrows + rpw - 1) / rpw;
+  return launch_rows_forward(e, a, true, false);
+}
+
+static ColsArgs cols_args(fmx_matrix* m, int64_t batch, int64_t nrows, int phase, double global_rows) {
+  const int64_t base = m->h_row_ptr_batches[(size_t)batch];
+  ColsArgs c{};
+  c.bptr = m->bptr + (size_t)batch * ((size_t)m->p + 1);
+  c.brow = m->brow + base;
+  c.bval = m->bval + base;
+  c.rows_active = (uint32_t)nrows;
+  c.phase = phase;
+  c.global_rows = global_rows;
+  return c;
+}
+
+}  // namespace fmx
+
+using namespace fmx;
+
+extern "C" {
+
+const char* fmx_last_error(void) { return g_error.c_str(); }
+
+int fmx_config_default(fmx_config* cfg) {
+  FMX_CHECK(cfg != nullptr, FMX_ERR_INVALID, "cfg is NULL");
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->struct_size = sizeof(fmx_config);
+  cfg->task = FMX_TASK_CLASSIFICATION;  // R/fm_control.R:43 (first of match.arg)
+  cfg->solver = FMX_SOLVER_SGD;
+  cfg->num_factor = 2;                  // R/fm_control.R:60
+  cfg->keep_w0 = 1; cfg->keep_w1 = 1;   // R/fm_control.R:54,57
+  cfg->learn_rate = 0.01;               // R/fm_solver_control.R:91-94
+  cfg->alpha_w = 0.1; cfg->alpha_v = 0.1; cfg->beta_w = 1.0; cfg->beta_v = 1.0;  // :109-115
+  cfg->random_step = 1;
+  cfg->mode = FMX_MODE_SEQUENTIAL;
+  cfg->batch_rows = 65536;
+  cfg->min_target = -1.0; cfg->max_target = 1.0;
+  cfg->device = 0;
+  return FMX_OK;
+}
+
+int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(cfg != nullptr, FMX_ERR_INVALID, "cfg is NULL");
+  FMX_CHECK(cfg->struct_size == sizeof(fmx_config), FMX_ERR_INVALID, "fmx_config size mismatch (%u vs %zu): header/library skew",
+            cfg->struct_size, sizeof(fmx_config));
+  FMX_CHECK(cfg->task == FMX_TASK_CLASSIFICATION || cfg->task == FMX_TASK_REGRESSION, FMX_ERR_INVALID, "unknown task...");
+  FMX_CHECK(cfg->solver == FMX_SOLVER_SGD || cfg->solver == FMX_SOLVER_FTRL || cfg->solver == FMX_SOLVER_ALS, FMX_ERR_INVALID,
+            "Unknown solver...");  // src/FM.cpp:85
+  FMX_CHECK(cfg->num_factor >= 0 && cfg->num_factor <= 128, FMX_ERR_INVALID, "factor.number must be in 0..128 (got %d)", cfg->num_factor);
+  FMX_CHECK(cfg->mode == FMX_MODE_SEQUENTIAL || cfg->mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID, "unknown mode %d", cfg->mode);
+  FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
+  FMX_CHECK(num_features > 0 && num_features < (1ull << 32), FMX_ERR_INVALID, "number of features must be in 1..2^32-1");
+  if (cfg->mode == FMX_MODE_MINIBATCH) FMX_CHECK(cfg->batch_rows >= 1, FMX_ERR_INVALID, "batch_rows must be >= 1");
+  FMX_TRY(use_device(cfg->device));
+
+  std::unique_ptr<fmx_engine, int (*)(fmx_engine*)> e(new fmx_engine(), fmx_engine_destroy);
+  e->cfg = *cfg;
+  e->p = num_features;
+  e->k = cfg->num_factor;
+  e->kp32 = pad_factor(e->k, 4);
+  e->kp64 = pad_factor(e->k, 2);
+  FMX_TRY(make_hyper(*cfg, &e->hyper));
+  FMX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  FMX_TRY(dev_alloc_zero(&e->scal, (size_t)SC_COUNT));
+  const size_t p = (size_t)e->p;
+  if (cfg->mode == FMX_MODE_MINIBATCH) {
+    FMX_TRY(dev_alloc_zero(&e->V, p * e->kp32));
+    FMX_TRY(dev_alloc_zero(&e->w, p));
+    if (e->hyper.kind != UPD_SGD_L2) { FMX_TRY(dev_alloc_zero(&e->sV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->sw, p)); }
+    if (e->hyper.kind == UPD_FTRL) { FMX_TRY(dev_alloc_zero(&e->nV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->nw, p)); }
+  } else {
+    FMX_TRY(dev_alloc_zero(&e->dV, p * e->kp64));
+    FMX_TRY(dev_alloc_zero(&e->dw, p));
+    if (e->hyper.kind != UPD_SGD_L2) { FMX_TRY(dev_alloc_zero(&e->dsV, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dsw, p)); }
+    if (e->hyper.kind == UPD_FTRL) { FMX_TRY(dev_alloc_zero(&e->dnV, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dnw, p)); }
+  }
+  FMX_HIP(hipDeviceSynchronize());  // the zero fills ran on the null stream; the engine stream does not wait for it
+  *out = e.release();
+  return FMX_OK;
+}
+
+int fmx_engine_destroy(fmx_engine* e) {
+  if (!e) return FMX_OK;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto& pr : e->prof_pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
+  (void)hipFree(e->scal);
+  (void)hipFree(e->V); (void)hipFree(e->w); (void)hipFree(e->sV); (void)hipFree(e->sw); (void)hipFree(e->nV); (void)hipFree(e->nw);
+  (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
+  (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return FMX_OK;
+}
+
+int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  const size_t p = (size_t)e->p;
+  const int k = e->k;
+  FMX_HIP(hipMemcpy(e->scal + SC_W0, &w0, sizeof(double), hipMemcpyHostToDevice));
+  if (seq_mode(e)) {
+    const int kp = e->kp64;
+    std::vector<double> hv(p * kp, 0.0);
+    if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = v[f + j * (size_t)k];
+    FMX_HIP(hipMemcpy(e->dV, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (w) FMX_HIP(hipMemcpy(e->dw, w, p * sizeof(double), hipMemcpyHostToDevice));
+    else FMX_HIP(hipMemset(e->dw, 0, p * sizeof(double)));
+  } else {
+    const int kp = e->kp32;
+    std::vector<float> hv(p * kp, 0.f);
+    if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = (float)v[f + j * (size_t)k];
+    FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> hw(p, 0.f);
+    if (w) for (size_t j = 0; j < p; ++j) hw[j] = (float)w[j];
+    FMX_HIP(hipMemcpy(e->w, hw.data(), p * sizeof(float), hipMemcpyHostToDevice));
+  }
+  FMX_TRY(reset_optimizer_state(e));  // learner->init() zeroes q/u (SGD_Learner.h:61-69) and z/n (FTRL_Learner.h:50-55)
+  FMX_HIP(hipDeviceSynchronize());
+  return FMX_OK;
+}
+
+int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  const size_t p = (size_t)e->p;
+  const int k = e->k;
+  if (w0) FMX_HIP(hipMemcpy(w0, e->scal + SC_W0, sizeof(double), hipMemcpyDeviceToHost));
+  if (seq_mode(e)) {
+    if (w) FMX_HIP(hipMemcpy(w, e->dw, p * sizeof(double), hipMemcpyDeviceToHost));
+    if (v && k > 0) {
+      const int kp = e->kp64;
+      std::vector<double> hv(p * kp);
+      FMX_HIP(hipMemcpy(hv.data(), e->dV, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * kp + f];
+    }
+  } else {
+    if (w) {
+      std::vector<float> hw(p);
+      FMX_HIP(hipMemcpy(hw.data(), e->w, p * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t j = 0; j < p; ++j) w[j] = hw[j];
+    }
+    if (v && k > 0) {
+      const int kp = e->kp32;
+      std::vector<float> hv(p * kp);
+      FMX_HIP(hipMemcpy(hv.data(), e->V, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * kp + f];
+    }
+  }
+  return FMX_OK;
+}
+
+int fmx_matrix_from_csr(int device, int64_t n, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
+                        const float* y, fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(row_ptr != nullptr && n >= 0, FMX_ERR_INVALID, "row_ptr is NULL or n < 0");
+  FMX_CHECK(row_ptr[0] == 0, FMX_ERR_INVALID, "row_ptr[0] must be 0");
+  for (int64_t i = 0; i < n; ++i) FMX_CHECK(row_ptr[i + 1] >= row_ptr[i], FMX_ERR_INVALID, "row_ptr decreases at row %lld", (long long)i);
+  const int64_t nnz = row_ptr[n];
+  FMX_CHECK(nnz == 0 || (col && val), FMX_ERR_INVALID, "col/val is NULL");
+  // the reference leaves this check commented out (core/Model.h:88); on a GPU an out-of-range column is a fault, so it is enforced
+  for (int64_t t = 0; t < nnz; ++t) FMX_CHECK(col[t] < p, FMX_ERR_INVALID, "Length of x is greater then then number of attributes... (col %u at %lld, p=%u)", col[t], (long long)t, p);
+  fmx_matrix* m = nullptr;
+  FMX_TRY(alloc_matrix(device, n, p, nnz, y != nullptr, &m));
+  int st = upload_matrix(m, row_ptr, col, val, y);
+  if (st != FMX_OK) { free_matrix(m); return st; }
+  *out = m;
+  return FMX_OK;
+}
+
+int fmx_matrix_from_rlist(int device, int64_t n, uint32_t p, int64_t nnz, const double* value, const int32_t* col_idx,
+                          const int32_t* row_size, const double* labels, fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(n >= 0 && nnz >= 0 && (n == 0 || row_size), FMX_ERR_INVALID, "the length of input's row_size is not correct...");
+  FMX_CHECK(nnz == 0 || (value && col_idx), FMX_ERR_INVALID, "value/col_idx is NULL");
+  // util/Smatrix.h:53-60: narrow value f64->f32, col_idx i32->u32, prefix-sum row_size into row_idx
+  std::vector<int64_t> rp((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    FMX_CHECK(row_size[i] >= 0, FMX_ERR_INVALID, "negative row_size at row %lld", (long long)i);
+    rp[(size_t)i + 1] = rp[(size_t)i] + row_size[i];
+  }
+  FMX_CHECK(rp[(size_t)n] == nnz, FMX_ERR_INVALID, "the length of input's row_size is not correct... (sum %lld, size %lld)", (long long)rp[(size_t)n], (long long)nnz);
+  std::vector<uint32_t> c((size_t)nnz);
+  std::vector<float> x((size_t)nnz);
+  for (int64_t t = 0; t < nnz; ++t) {
+    FMX_CHECK(col_idx[t] >= 0 && (uint32_t)col_idx[t] < p, FMX_ERR_INVALID, "col_idx %d out of range at %lld", col_idx[t], (long long)t);
+    c[(size_t)t] = (uint32_t)col_idx[t];
+    x[(size_t)t] = (float)value[t];
+  }
+  std::vector<float> yl;
+  if (labels) { yl.resize((size_t)n); for (int64_t i = 0; i < n; ++i) yl[(size_t)i] = (float)labels[i]; }  // util/Dvector.h:89-99
+  return fmx_matrix_from_csr(device, n, p, rp.data(), c.data(), x.data(), labels ? yl.data() : nullptr, out);
+}
+
+int fmx_matrix_synthetic(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(n >= 0 && nnz_per_row >= 1 && (uint32_t)nnz_per_row <= p, FMX_ERR_INVALID, "need 1 <= nnz_per_row <= p");
+  fmx_matrix* m = nullptr;
+  FMX_TRY(alloc_matrix(device, n, p, n * nnz_per_row, true, &m));
+  int st = generate_synthetic(m, nnz_per_row, seed, row_offset);
+  if (st != FMX_OK) { free_matrix(m); return st; }
+  *out = m;
+  return FMX_OK;
+}
+
+int fmx_matrix_destroy(fmx_matrix* m) {
+  if (m) (void)hipSetDevice(m->device);
+  free_matrix(m);
+  return FMX_OK;
+}
+
+int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz) {
+  FMX_CHECK(m != nullptr, FMX_ERR_INVALID, "NULL matrix");
+  if (n) *n = m->n;
+  if (p) *p = m->p;
+  if (nnz) *nnz = m->nnz;
+  return FMX_OK;
+}
+
+int fmx_matrix_export(const fmx_matrix* m, int64_t r0, int64_t r1, int64_t* row_ptr, uint32_t* col, float* val, float* y) {
+  FMX_CHECK(m != nullptr, FMX_ERR_INVALID, "NULL matrix");
+  FMX_CHECK(r0 >= 0 && r0 <= r1 && r1 <= m->n, FMX_ERR_INVALID, "row range [%lld,%lld) out of bounds", (long long)r0, (long long)r1);
+  FMX_TRY(use_device(m->device));
+  std::vector<int64_t> rp((size_t)(r1 - r0) + 1);
+  FMX_HIP(hipMemcpy(rp.data(), m->row_ptr + r0, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  const int64_t base = rp[0], cnt = rp.back() - base;
+  if (row_ptr) for (size_t i = 0; i < rp.size(); ++i) row_ptr[i] = rp[i] - base;
+  if (col && cnt) FMX_HIP(hipMemcpy(col, m->col + base, (size_t)cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (val && cnt) FMX_HIP(hipMemcpy(val, m->val + base, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost));
+  if (y && r1 > r0) FMX_HIP(hipMemcpy(y, m->y + r0, (size_t)(r1 - r0) * sizeof(float), hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+
+int fmx_predict(fmx_engine* e, const fmx_matrix* m, double* out, int link) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(out != nullptr || m->n == 0, FMX_ERR_INVALID, "out is NULL");
+  FMX_CHECK(link == FMX_LINK_NONE || link == FMX_LINK_LOGISTIC || link == FMX_LINK_CLAMP, FMX_ERR_INVALID, "unknown link %d", link);
+  FMX_TRY(use_device(e->cfg.device));
+  if (m->n == 0) return FMX_OK;
+  double* d = nullptr;
+  FMX_HIP(hipMalloc(&d, (size_t)m->n * sizeof(double)));
+  int st = forward_rows(e, m, 0, m->n, d, link);
+  if (st == FMX_OK && hipStreamSynchronize(e->stream) != hipSuccess) { set_error("forward kernel failed"); st = FMX_ERR_HIP; }
+  if (st == FMX_OK && hipMemcpy(out, d, (size_t)m->n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { set_error("copy of predictions failed"); st = FMX_ERR_HIP; }
+  (void)hipFree(d);
+  return st;
+}
+
+int fmx_predict_device(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r1, void* dev_out_f64, int link) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(r0 >= 0 && r0 <= r1 && r1 <= m->n && dev_out_f64, FMX_ERR_INVALID, "bad row range or NULL output");
+  FMX_TRY(use_device(e->cfg.device));
+  return forward_rows(e, m, r0, r1, (double*)dev_out_f64, link);
+}
+
+int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t count) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "an explicit visiting order needs FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS, FMX_ERR_STATE, "ALS engines train through fmx_als_vsweep");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  FMX_CHECK(count >= 0 && (count == 0 || order), FMX_ERR_INVALID, "order is NULL");
+  for (int64_t i = 0; i < count; ++i) FMX_CHECK(order[i] >= 0 && order[i] < m->n, FMX_ERR_INVALID, "order[%lld]=%lld out of range", (long long)i, (long long)order[i]);
+  if (count == 0) return FMX_OK;
+  FMX_TRY(use_device(e->cfg.device));
+  int64_t* d = nullptr;
+  FMX_HIP(hipMalloc(&d, (size_t)count * sizeof(int64_t)));
+  int st = FMX_OK;
+  if (hipMemcpy(d, order, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the visiting order failed"); st = FMX_ERR_HIP; }
+  if (st == FMX_OK) st = launch_seq_learn(e, m, d, count);
+  if (st == FMX_OK) {
+    hipError_t err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) { set_error("sequential learner failed: %s", hipGetErrorString(err)); st = FMX_ERR_HIP; }
+  }
+  (void)hipFree(d);
+  return st;
+}
+
+int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
+  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS, FMX_ERR_STATE, "ALS engines train through fmx_als_vsweep");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  if (examples_done) *examples_done = 0;
+  if (max_iter == 0 || m->n == 0) return FMX_OK;
+  if (seq_mode(e)) {
+    std::vector<int64_t> order;
+    visit_order(m->n, e->cfg.random_step, max_iter, &order);
+    FMX_TRY(fmx_train_order(e, m, order.data(), (int64_t)order.size()));
+    if (examples_done) *examples_done = (int64_t)order.size();
+    return FMX_OK;
+  }
+  int64_t nb = 0;
+  FMX_TRY(fmx_num_batches(e, m, &nb));
+  int64_t done = 0;
+  for (int64_t step = 0; done < max_iter; ++step) {
+    const int64_t batch = step % nb;
+    const int64_t b0 = batch * m->batch_rows;
+    int64_t rows = (b0 + m->batch_rows <= m->n) ? m->batch_rows : m->n - b0;
+    if (rows > max_iter - done) rows = max_iter - done;
+    FMX_TRY(fmx_step(e, m, batch, rows));
+    done += rows;
+  }
+  FMX_TRY(fmx_sync(e));
+  if (examples_done) *examples_done = done;
+  return FMX_OK;
+}
+
+int fmx_num_batches(fmx_engine* e, fmx_matrix* m, int64_t* n_batches) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "batches exist only in FMX_MODE_MINIBATCH");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, e->stream));
+  if (n_batches) *n_batches = m->n_batches;
+  return FMX_OK;
+}
+
+int fmx_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
+  FMX_TRY(check_pair(e, m));
+  int64_t b0, nrows, n_partials;
+  FMX_TRY(batch_geometry(e, m, batch, rows_limit, &b0, &nrows));
+  if (nrows == 0) return FMX_OK;
+  FMX_TRY(rows_phase(e, m, b0, nrows, &n_partials));
+  FMX_TRY(launch_scalar_update(e, n_partials, (double)nrows, 0));
+  return launch_cols_update(e, cols_args(m, batch, nrows, 0, (double)nrows));
+}
+
+int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
+  FMX_TRY(check_pair(e, m));
+  int64_t b0, nrows, n_partials;
+  FMX_TRY(batch_geometry(e, m, batch, rows_limit, &b0, &nrows));
+  FMX_TRY(ensure_gbuf(e));
+  FMX_TRY(rows_phase(e, m, b0, nrows, &n_partials));
+  FMX_TRY(launch_scalar_update(e, n_partials, (double)nrows, 1));
+  return launch_cols_update(e, cols_args(m, batch, nrows, 1, (double)nrows));
+}
+
+int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "the exchange buffer exists only in FMX_MODE_MINIBATCH");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(ensure_gbuf(e));
+  if (dev_ptr) *dev_ptr = e->gbuf;
+  if (n_floats) *n_floats = e->gbuf_floats;
+  return FMX_OK;
+}
+
+int fmx_apply(fmx_engine* e, int64_t global_rows) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_CHECK(!seq_mode(e) && e->gbuf, FMX_ERR_STATE, "fmx_apply needs a preceding fmx_grad");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(launch_scalar_update(e, 0, (double)global_rows, 2));
+  ColsArgs c{};
+  c.phase = 2;
+  c.global_rows = (double)global_rows;
+  return launch_cols_update(e, c);
+}
+
+int fmx_sync(fmx_engine* e) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  hipError_t err = hipStreamSynchronize(e->stream);
+  FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(err));
+  return FMX_OK;
+}
+
+int fmx_stream(fmx_engine* e, void** stream) {
+  FMX_CHECK(e != nullptr && stream != nullptr, FMX_ERR_INVALID, "NULL argument");
+  *stream = (void*)e->stream;
+  return FMX_OK;
+}
+
+int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda, const double* v_mu) {
+  FMX_TRY(check_pair(e, m));
+  (void)error; (void)alpha; (void)v_lambda; (void)v_mu;
+  set_error("fmx_als_vsweep: not built yet");
+  return FMX_ERR_INVALID;
+}
+
+int fmx_profile_enable(fmx_engine* e, int on) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_TRY(prof_collect(e));
+  e->profile = on != 0;
+  return FMX_OK;
+}
+
+int fmx_profile_get(fmx_engine* e, int kernel, double* total_ms, int64_t* launches) {
+  FMX_CHECK(e != nullptr && kernel >= 0 && kernel < FMX_KERNEL_COUNT, FMX_ERR_INVALID, "bad kernel id");
+  FMX_TRY(prof_collect(e));
+  if (total_ms) *total_ms = e->prof_ms[kernel];
+  if (launches) *launches = e->prof_n[kernel];
+  return FMX_OK;
+}
+
+int fmx_profile_reset(fmx_engine* e) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_TRY(prof_collect(e));
+  for (int i = 0; i < FMX_KERNEL_COUNT; ++i) { e->prof_ms[i] = 0; e->prof_n[i] = 0; }
+  return FMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// Internal declarations shared by the libfmx.so translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/fmx.h"
+
+namespace fmx {
+
+void set_error(const char* fmt, ...);
+
+#define FMX_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      fmx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return FMX_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define FMX_CHECK(cond, code, ...)  \
+  do {                              \
+    if (!(cond)) {                  \
+      fmx::set_error(__VA_ARGS__);  \
+      return (code);                \
+    }                               \
+  } while (0)
+
+#define FMX_TRY(call)             \
+  do {                            \
+    int _s = (call);              \
+    if (_s != FMX_OK) return _s;  \
+  } while (0)
+
+// regularisation flavour of the update, fixed at engine creation
+enum UpdateKind : int {
+  UPD_SGD_L2 = 0,  // solver/SGD_Learner.h:119,135 (lazy L2 on touched coordinates)
+  UPD_SGD_L1 = 1,  // solver/SGD_Learner.h:195-204 (cumulative penalty)
+  UPD_FTRL = 2,    // solver/FTRL_Learner.h:158-202
+};
+
+// hyper-parameters as the kernels consume them (passed by value)
+struct Hyper {
+  int task, k0, k1;
+  int kind;  // UpdateKind
+  double lr, reg0, regw, regv;  // SGD: regw/regv are the L1 OR L2 rates (SGD_Learner.h:44-59)
+  double l1w, l1v, l2w, l2v;    // FTRL prox
+  double alpha_w, alpha_v, beta_w, beta_v;
+  double min_t, max_t;
+};
+
+// device scalars (double[SC_COUNT]) living next to the parameters
+enum Scalar : int {
+  SC_W0 = 0,
+  SC_Z0 = 1,  // FTRL z_w0
+  SC_N0 = 2,  // FTRL n_w0
+  SC_UW = 3,  // SGD-L1 cumulative penalty u_w
+  SC_UV = 4,  // SGD-L1 u_v
+  SC_G0 = 5,  // last batch: sum of grad multipliers
+  SC_Q0 = 6,  // last batch: sum of squared grad multipliers
+  SC_COUNT = 8
+};
+
+constexpr int WG_THREADS = 256;
+constexpr int STAGE_ENTRIES = 2048;  // (id, x) pairs staged in LDS per chunk: 16 KiB
+
+inline int pad_factor(int k, int vec) {
+  int kp = vec;
+  while (kp < k) kp <<= 1;
+  return kp;
+}
+
+}  // namespace fmx
+
+struct fmx_matrix {
+  int device = 0;
+  int64_t n = 0;
+  uint32_t p = 0;
+  int64_t nnz = 0;
+  int64_t* row_ptr = nullptr;  // [n+1]
+  uint32_t* col = nullptr;     // [nnz]
+  float* val = nullptr;        // [nnz]
+  float* y = nullptr;          // [n] or null
+  int has_labels = 0;
+  int rows_sorted = 0;  // every row strictly ascending in col (=> no duplicate column inside a row)
+  // per-batch CSC ("inverted index" of each batch), built lazily for one batch_rows value
+  int64_t batch_rows = 0;
+  int64_t n_batches = 0;
+  uint32_t* bptr = nullptr;  // [n_batches][p+1] offsets relative to row_ptr[batch*batch_rows]
+  uint32_t* brow = nullptr;  // [nnz] row index local to the batch
+  float* bval = nullptr;     // [nnz]
+  // CSC of the whole matrix (ALS sweep), built lazily
+  int64_t* col_ptr = nullptr;  // [p+1]
+  uint32_t* crow = nullptr;    // [nnz]
+  float* cval = nullptr;       // [nnz]
+  std::vector<int64_t> h_row_ptr_batches;  // host copy of row_ptr at batch boundaries
+};
+
+struct fmx_engine {
+  fmx_config cfg{};
+  fmx::Hyper hyper{};
+  uint64_t p = 0;
+  int k = 0;
+  int kp32 = 0;  // padded factor count of the fp32 tables (multiple of 4)
+  int kp64 = 0;  // padded factor count of the fp64 tables (multiple of 2)
+  hipStream_t stream = nullptr;
+  double* scal = nullptr;  // [SC_COUNT]
+  // mini-batch (fp32) state: tables are [p][kp32]
+  float *V = nullptr, *w = nullptr;
+  float *sV = nullptr, *sw = nullptr;    // q (SGD-L1) or z (FTRL)
+  float *nV = nullptr, *nw = nullptr;    // n (FTRL)
+  // sequential (fp64) state: tables are [p][kp64]
+  double *dV = nullptr, *dw = nullptr;
+  double *dsV = nullptr, *dsw = nullptr;
+  double *dnV = nullptr, *dnw = nullptr;
+  // workspaces (mini-batch)
+  int64_t ws_rows = 0;
+  float* S = nullptr;         // [ws_rows][kp32] per-row factor sums
+  float* amul = nullptr;      // [ws_rows] per-row gradient multiplier
+  double* partials = nullptr; // [ws_partials][2]
+  int64_t ws_partials = 0;
+  float* gbuf = nullptr;      // multi-GPU exchange buffer
+  int64_t gbuf_floats = 0;
+  // measurement
+  int profile = 0;
+  double prof_ms[FMX_KERNEL_COUNT] = {0};
+  int64_t prof_n[FMX_KERNEL_COUNT] = {0};
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+};
+
+namespace fmx {
+
+// ---- launchers implemented in the kernel translation units -------------------------------------------------
+struct RowsArgs {
+  const int64_t* row_ptr;
+  const uint32_t* col;
+  const float* val;
+  const float* y;       // may be null when !train
+  int64_t r0;           // first row (global index into the matrix)
+  int64_t nrows;        // rows to process
+  const void* V;        // [p][kp] float or double
+  const void* w;        // [p]
+  const double* scal;
+  float* S;             // [nrows][kp32] (train)
+  float* amul;          // [nrows]       (train)
+  double* partials;     // [grid][2]     (train)
+  double* yhat;         // [nrows]       (predict) -- indexed from 0
+  int link;
+};
+int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
+
+struct ColsArgs {
+  const uint32_t* bptr;  // [p+1] for this batch
+  const uint32_t* brow;  // based at the batch's first entry
+  const float* bval;
+  uint32_t rows_active;
+  int phase;             // 0 fused, 1 accumulate-only (write gbuf), 2 apply-only (read gbuf)
+  double global_rows;    // rows of the whole (global) batch, for the L1 cumulative penalty
+};
+int launch_cols_update(fmx_engine* e, const ColsArgs& a);
+int launch_scalar_update(fmx_engine* e, int64_t n_partials, double batch_rows, int phase);
+
+int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count);
+
+// ingest
+int build_batch_csc(fmx_matrix* m, int64_t batch_rows, hipStream_t stream);
+int build_full_csc(fmx_matrix* m, hipStream_t stream);
+int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
+int check_rows_sorted(fmx_matrix* m);
+
+int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* d_lambda, const double* d_mu);
+
+// profiling helpers
+void prof_begin(fmx_engine* e, int kernel);
+void prof_end(fmx_engine* e);
+
+}  // namespace fmx

@@ -1,0 +1,186 @@
+"""Thin object wrappers over the C ABI handles (fmx_engine, fmx_matrix).  numpy in, numpy out."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Matrix:
+    """A device-resident fm.matrix (fmx_matrix*)."""
+
+    def __init__(self, handle, n, p, nnz):
+        self.h, self.n, self.p, self.nnz = handle, n, p, nnz
+
+    @classmethod
+    def _wrap(cls, handle):
+        n, p, nnz = C.c_int64(), C.c_uint32(), C.c_int64()
+        L.check(L.lib().fmx_matrix_info(handle, C.byref(n), C.byref(p), C.byref(nnz)))
+        return cls(handle, n.value, p.value, nnz.value)
+
+    @classmethod
+    def from_csr(cls, row_ptr, col, val, p, y=None, device=0):
+        row_ptr = np.ascontiguousarray(row_ptr, np.int64)
+        col = np.ascontiguousarray(col, np.uint32)
+        val = np.ascontiguousarray(val, np.float32)
+        y = None if y is None else np.ascontiguousarray(y, np.float32)
+        n = len(row_ptr) - 1
+        if len(col) != len(val) or (n >= 0 and len(col) != int(row_ptr[-1])):
+            raise ValueError("col/val length does not match row_ptr")
+        if y is not None and len(y) != n:
+            raise ValueError("target's length is not equal the number of cases...")  # core/Data.h:75-76
+        h = C.c_void_p()
+        L.check(L.lib().fmx_matrix_from_csr(C.c_int(device), C.c_int64(n), C.c_uint32(p), _p(row_ptr), _p(col), _p(val), _p(y),
+                                            C.byref(h)))
+        return cls._wrap(h)
+
+    @classmethod
+    def from_rlist(cls, value, col_idx, row_size, p, labels=None, device=0):
+        """R's fm.matrix$features layout (R/fm_matrix.R:25-34)."""
+        value = np.ascontiguousarray(value, np.float64)
+        col_idx = np.ascontiguousarray(col_idx, np.int32)
+        row_size = np.ascontiguousarray(row_size, np.int32)
+        labels = None if labels is None else np.ascontiguousarray(labels, np.float64)
+        h = C.c_void_p()
+        L.check(L.lib().fmx_matrix_from_rlist(C.c_int(device), C.c_int64(len(row_size)), C.c_uint32(p), C.c_int64(len(value)),
+                                              _p(value), _p(col_idx), _p(row_size), _p(labels), C.byref(h)))
+        return cls._wrap(h)
+
+    @classmethod
+    def synthetic(cls, n, p, nnz_per_row, seed, row_offset=0, device=0):
+        h = C.c_void_p()
+        L.check(L.lib().fmx_matrix_synthetic(C.c_int(device), C.c_int64(n), C.c_uint32(p), C.c_int32(nnz_per_row), C.c_uint64(seed),
+                                             C.c_int64(row_offset), C.byref(h)))
+        return cls._wrap(h)
+
+    def export(self, r0=0, r1=None):
+        """rows [r0, r1) -> (row_ptr, col, val, y) numpy arrays (row_ptr rebased to 0)."""
+        r1 = self.n if r1 is None else r1
+        rp = np.zeros(r1 - r0 + 1, np.int64)
+        L.check(L.lib().fmx_matrix_export(self.h, C.c_int64(r0), C.c_int64(r1), _p(rp), None, None, None))
+        cnt = int(rp[-1])
+        col = np.zeros(max(cnt, 1), np.uint32); val = np.zeros(max(cnt, 1), np.float32); y = np.zeros(max(r1 - r0, 1), np.float32)
+        L.check(L.lib().fmx_matrix_export(self.h, C.c_int64(r0), C.c_int64(r1), _p(rp), _p(col), _p(val), _p(y)))
+        return rp, col[:cnt], val[:cnt], y[: r1 - r0]
+
+    def close(self):
+        if self.h:
+            L.lib().fmx_matrix_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """Parameters + optimizer state on one GPU (fmx_engine*)."""
+
+    def __init__(self, num_features, **kw):
+        cfg = L.default_config()
+        for key, value in kw.items():
+            if not hasattr(cfg, key):
+                raise TypeError(f"unknown engine option {key!r}")
+            setattr(cfg, key, value)
+        self.cfg = cfg
+        self.p = int(num_features)
+        self.k = int(cfg.num_factor)
+        self.h = C.c_void_p()
+        L.check(L.lib().fmx_engine_create(C.byref(cfg), C.c_uint64(self.p), C.byref(self.h)))
+
+    def set_params(self, w0=0.0, w=None, v=None):
+        """v: (k, p) array as R holds it (k x p matrix); stored column-major for the ABI."""
+        w = None if w is None else np.ascontiguousarray(w, np.float64)
+        vv = None
+        if v is not None:
+            v = np.asarray(v, np.float64)
+            if v.shape != (self.k, self.p):
+                raise ValueError(f"v must have shape ({self.k}, {self.p})")
+            vv = np.ascontiguousarray(v.T).ravel()  # element (f, j) at f + j*k
+        if w is not None and w.shape != (self.p,):
+            raise ValueError(f"w must have shape ({self.p},)")
+        L.check(L.lib().fmx_set_params(self.h, C.c_double(w0), _p(w), _p(vv)))
+
+    def get_params(self):
+        w0 = C.c_double()
+        w = np.zeros(self.p)
+        vv = np.zeros(max(self.k * self.p, 1))
+        L.check(L.lib().fmx_get_params(self.h, C.byref(w0), _p(w), _p(vv)))
+        v = vv[: self.k * self.p].reshape(self.p, self.k).T.copy()
+        return w0.value, w, v
+
+    def predict(self, m, link=L.LINK_NONE):
+        out = np.zeros(max(m.n, 1))
+        L.check(L.lib().fmx_predict(self.h, m.h, _p(out), C.c_int(link)))
+        return out[: m.n]
+
+    def train(self, m, max_iter):
+        done = C.c_int64()
+        L.check(L.lib().fmx_train(self.h, m.h, C.c_int64(max_iter), C.byref(done)))
+        return done.value
+
+    def train_order(self, m, order):
+        order = np.ascontiguousarray(order, np.int64)
+        L.check(L.lib().fmx_train_order(self.h, m.h, _p(order), C.c_int64(len(order))))
+
+    def num_batches(self, m):
+        nb = C.c_int64()
+        L.check(L.lib().fmx_num_batches(self.h, m.h, C.byref(nb)))
+        return nb.value
+
+    def step(self, m, batch, rows_limit=0):
+        L.check(L.lib().fmx_step(self.h, m.h, C.c_int64(batch), C.c_int64(rows_limit)))
+
+    def grad(self, m, batch, rows_limit=0):
+        L.check(L.lib().fmx_grad(self.h, m.h, C.c_int64(batch), C.c_int64(rows_limit)))
+
+    def grad_buffer(self):
+        ptr, n = C.c_void_p(), C.c_int64()
+        L.check(L.lib().fmx_grad_buffer(self.h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def apply(self, global_rows):
+        L.check(L.lib().fmx_apply(self.h, C.c_int64(global_rows)))
+
+    def sync(self):
+        L.check(L.lib().fmx_sync(self.h))
+
+    def stream(self):
+        s = C.c_void_p()
+        L.check(L.lib().fmx_stream(self.h, C.byref(s)))
+        return s.value
+
+    def als_vsweep(self, m, error, alpha=1.0, v_lambda=None, v_mu=None):
+        error = np.ascontiguousarray(error, np.float64).copy()
+        lam = None if v_lambda is None else np.ascontiguousarray(v_lambda, np.float64)
+        mu = None if v_mu is None else np.ascontiguousarray(v_mu, np.float64)
+        L.check(L.lib().fmx_als_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu)))
+        return error
+
+    def profile(self, on=True):
+        L.check(L.lib().fmx_profile_enable(self.h, C.c_int(1 if on else 0)))
+
+    def profile_reset(self):
+        L.check(L.lib().fmx_profile_reset(self.h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().fmx_profile_get(self.h, C.c_int(kernel), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self.h:
+            L.lib().fmx_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

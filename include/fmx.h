@@ -1,0 +1,174 @@
+/*
+ * fmx.h -- C ABI of the MI355X-native Factorization Machine engine (libfmx.so).
+ *
+ * This is the drop-in boundary for ONE path of evanwang1990/FMwR: the degree-2 FM forward and the
+ * SGD / FTRL-Proximal training step (plus the ALS V-column sweep).  It replaces what the Rcpp entry
+ * points FM() / FMPredict() do between unmarshalling the R lists and marshalling the result
+ * (reference src/FM.cpp:7-173, :177-214), i.e. the seam
+ *
+ *     learner->init(); learner->learn(data);        src/FM.cpp:145,153   (core/Learner.h:49-51)
+ *     fm.predict_batch(..) / fm.predict_prob(..)    src/FM.cpp:199-203   (core/Model.h:106-180)
+ *
+ * Plain pointers and sizes only; no C++/torch types; nothing throws across the boundary: every call
+ * returns an int status (FMX_OK == 0) and fmx_last_error() gives the message (the glue turns a
+ * non-zero status into Rcpp::stop(msg), as END_RCPP does for the reference, src/RcppExports.cpp:11,22).
+ * The caller keeps ownership of every host pointer it passes; no pointer is retained after return
+ * (the reference deep-copies too: util/Smatrix.h:53-60, util/Dvector.h:89-99).
+ *
+ * A handle is used from one host thread at a time (R is single-threaded; Model::predict is not
+ * re-entrant either, core/Model.h:26-27).
+ */
+#ifndef FMX_H_
+#define FMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMX_OK 0
+#define FMX_ERR_INVALID 1  /* bad argument / unsupported configuration */
+#define FMX_ERR_HIP 2      /* HIP runtime error (message holds hipGetErrorString) */
+#define FMX_ERR_NOGPU 3    /* no usable device: the engine has NO CPU fallback */
+#define FMX_ERR_STATE 4    /* call order / handle state */
+
+/* task and solver ids are the reference's (util/Macros.h:11-21) */
+#define FMX_TASK_CLASSIFICATION 10
+#define FMX_TASK_REGRESSION 20
+#define FMX_SOLVER_ALS 200
+#define FMX_SOLVER_SGD 300
+#define FMX_SOLVER_FTRL 500
+
+/* FMX_MODE_SEQUENTIAL: the reference's algorithm as is -- one example per update, visited in the
+ *   reference's order (solver/SGD_Learner.h:86-88), fp64 state.  The parity mode.
+ * FMX_MODE_MINIBATCH : synchronous mini-batches of batch_rows examples, fp32 state, gradient sums per
+ *   coordinate.  The throughput mode; equals the reference step at batch_rows == 1. */
+#define FMX_MODE_SEQUENTIAL 0
+#define FMX_MODE_MINIBATCH 1
+
+/* output transform of fmx_predict */
+#define FMX_LINK_NONE 0      /* raw y_hat: Model::predict_batch, core/Model.h:106-161 */
+#define FMX_LINK_LOGISTIC 1  /* 1/(1+exp(-y_hat)): Model::predict_prob, core/Model.h:173-178 */
+#define FMX_LINK_CLAMP 2     /* clamp to [min_target, max_target]: src/FM.cpp:202-210 */
+
+/* Mirrors the three R control lists (R/fm_control.R:52-66 model.control, R/fm_solver_control.R:91-115
+ * SGD.solver / FTRL.solver) as FM() reads them by key (src/FM.cpp:48-63, :97-144). */
+typedef struct fmx_config {
+  uint32_t struct_size;    /* = sizeof(fmx_config); ABI guard */
+  int32_t task;            /* model.control(task)                       */
+  int32_t solver;          /* attr(solver, "solver")                    */
+  int32_t num_factor;      /* hyper.params$factor.number   (default 2)  */
+  int32_t keep_w0;         /* hyper.params$keep.w0                      */
+  int32_t keep_w1;         /* hyper.params$keep.w1                      */
+  double l2_w0;            /* hyper.params$L2.w0                        */
+  double l1_w1, l2_w1;     /* hyper.params$L1.w1, L2.w1                 */
+  double l1_v, l2_v;       /* hyper.params$L1.v, L2.v                   */
+  double learn_rate;       /* SGD.solver(learn_rate = 0.01)             */
+  double alpha_w, alpha_v; /* FTRL.solver(alpha_w = .1, alpha_v = .1)   */
+  double beta_w, beta_v;   /* FTRL.solver(beta_w = 1, beta_v = 1)       */
+  int32_t random_step;     /* SGD/FTRL.solver(random_step = 1L)         */
+  int32_t mode;            /* FMX_MODE_*                                */
+  int64_t batch_rows;      /* mini-batch rows per step per GPU          */
+  double min_target;       /* learner->min_target, src/FM.cpp:89-96     */
+  double max_target;       /* learner->max_target                       */
+  int32_t device;          /* HIP device ordinal                        */
+  int32_t reserved;
+} fmx_config;
+
+typedef struct fmx_engine fmx_engine; /* parameters + optimizer state on one GPU */
+typedef struct fmx_matrix fmx_matrix; /* a device-resident fm.matrix (CSR + labels [+ per-batch CSC]) */
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* fmx_last_error(void);
+
+/* Fill *cfg with the reference's defaults (R/fm_control.R:52-66, R/fm_solver_control.R:91-115). */
+int fmx_config_default(fmx_config* cfg);
+
+/* ---- engine: replaces `Model fm; fm.init(); learner = new XXX_Learner(); learner->init()`
+ *      (src/FM.cpp:47-64, :78-145).  Parameters start at w0 = 0, w = 0, V = 0: V0 is an INPUT
+ *      (fmx_set_params), because the reference draws it from R's RNG (util/Dmatrix.h:143-146). */
+int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine** out);
+int fmx_engine_destroy(fmx_engine* e);
+
+/* w: [p] or NULL (zeros); v: the R NumericMatrix k x p, column-major, i.e. v[f + j*k] (what
+ * Model::save_model / load_model exchange, core/Model.h:182-227) or NULL (zeros).
+ * Warm start of fm.update(): src/FM.cpp:66-72.  Optimizer state is reset, as learner->init() does. */
+int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v);
+int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v);
+
+/* ---- data: replaces `SMatrix<float> m; m.assign(X); DVector<float> tg; tg.assign(target)`
+ *      (src/FM.cpp:31-44).  All inputs are host pointers; the matrix is copied to HBM. */
+
+/* R's fm.matrix layout (R/fm_matrix.R:25-34): value f64[nnz], col_idx i32[nnz] 0-based, row_size i32[n];
+ * narrowed to f32 / u32 like util/Smatrix.h:44-61.  labels may be NULL (prediction). */
+int fmx_matrix_from_rlist(int device, int64_t n, uint32_t p, int64_t nnz, const double* value,
+                          const int32_t* col_idx, const int32_t* row_size, const double* labels,
+                          fmx_matrix** out);
+/* Plain CSR: row_ptr i64[n+1], col u32[nnz], val f32[nnz], y f32[n] or NULL. */
+int fmx_matrix_from_csr(int device, int64_t n, uint32_t p, const int64_t* row_ptr, const uint32_t* col,
+                        const float* val, const float* y, fmx_matrix** out);
+/* Synthetic workload generated on the device: rows [row_offset, row_offset+n) of a
+ * stream keyed by (seed, global row id): nnz_per_row stratified-uniform sorted distinct columns, value 1,
+ * label +-1.  Shard-independent: a rank asks for its own row range. */
+int fmx_matrix_synthetic(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed,
+                         int64_t row_offset, fmx_matrix** out);
+int fmx_matrix_destroy(fmx_matrix* m);
+int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz);
+/* Copy rows [r0, r1) back to the host (row_ptr is rebased to 0); any pointer may be NULL. */
+int fmx_matrix_export(const fmx_matrix* m, int64_t r0, int64_t r1, int64_t* row_ptr, uint32_t* col,
+                      float* val, float* y);
+
+/* ---- the hot path */
+
+/* Model::predict_batch / predict_prob (+ clamp) for every row; out: f64[n] on the host. */
+int fmx_predict(fmx_engine* e, const fmx_matrix* m, double* out, int link);
+
+/* Learner::learn(data): run max_iter EXAMPLES (the reference counts examples, solver/SGD_Learner.h:168-173).
+ * SEQUENTIAL: rows visited as the reference visits them (libc rand() strides when random_step > 1).
+ * MINIBATCH : consecutive batches of batch_rows rows, wrapping at the end of the matrix.
+ * examples_done (may be NULL) receives the number actually processed. */
+int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
+/* Same, but with an explicit visiting order (row ids, SEQUENTIAL mode only). */
+int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t count);
+
+/* ---- step-level interface (what fmx_train loops over; used by bench.py and the multi-GPU driver).
+ * All of these enqueue on the engine's stream and return without waiting; fmx_sync waits. */
+
+/* number of batches the matrix splits into for the engine's batch_rows (builds the per-batch CSC on first use) */
+int fmx_num_batches(fmx_engine* e, fmx_matrix* m, int64_t* n_batches);
+/* one full mini-batch step on this GPU: forward -> gradient sums -> update, rows of batch `batch`
+ * (rows_limit > 0 truncates the batch to its first rows_limit rows). */
+int fmx_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
+/* multi-GPU split of the same step: local gradient sums into the exchange buffer ... */
+int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
+/* ... device pointer / element count (fp32) of that buffer, for an in-place all-reduce(sum) ... */
+int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats);
+/* ... and the update from the (reduced) buffer; global_rows = rows of the whole global batch. */
+int fmx_apply(fmx_engine* e, int64_t global_rows);
+int fmx_sync(fmx_engine* e);
+/* the hipStream_t the engine launches on (as void*), so a caller can order its own work after it */
+int fmx_stream(fmx_engine* e, void** stream);
+/* device-side forward: y_hat (f64) for rows [r0, r1) into a device buffer the caller owns */
+int fmx_predict_device(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r1, void* dev_out_f64, int link);
+
+/* ---- ALS V-column sweep (solver/MCMC_ALS_Learner.h:272-354, ALS branch, one attribute group):
+ * error: f64[n] residual on entry (y_hat - y, :520-527), updated in place; v_lambda, v_mu: f64[k] or NULL (zeros). */
+int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda,
+                   const double* v_mu);
+
+/* ---- measurement: HIP-event timing of each kernel on the engine's stream (bench.py roofline leg). */
+#define FMX_KERNEL_ROWS_FORWARD 0 /* phase 1: V-row gather + forward + grad multiplier */
+#define FMX_KERNEL_COLS_UPDATE 1  /* phase 2: per-feature gradient sums + update */
+#define FMX_KERNEL_SCALAR 2       /* w0 reduction/update */
+#define FMX_KERNEL_SEQ 3          /* sequential-exact learner */
+#define FMX_KERNEL_COUNT 8
+int fmx_profile_enable(fmx_engine* e, int on);
+int fmx_profile_get(fmx_engine* e, int kernel, double* total_ms, int64_t* launches);
+int fmx_profile_reset(fmx_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMX_H_ */
