@@ -165,13 +165,13 @@ def test_minibatch_matches_oracle(fm, c, batch):
     e.set_params(w0, w, v)
     m = engine.Matrix.from_csr(rp, col, val, p, y)
     total = n + n // 2 + 5  # one and a half passes, last batch truncated
-    done = 0
-    while done < total:
-        b0 = (done // batch * batch) % (-(-n // batch) * batch)
-        b0 = ((done // batch) % (-(-n // batch))) * batch
+    done, step, nb = 0, 0, -(-n // batch)
+    while done < total:  # consecutive batches, wrapping at the end of the matrix (fmx.h: fmx_train, MINIBATCH)
+        b0 = (step % nb) * batch
         rows = min(batch, n - b0, total - done)
         mb.step(b0, b0 + rows)
         done += rows
+        step += 1
     assert e.train(m, total) == total
     g0, gw, gv = e.get_params()
     rv = mb.v.reshape(P.k, p)
