@@ -1,0 +1,156 @@
+// ALS V-column sweep: MCMC_ALS_Learner::update_v, ALS branch (solver/MCMC_ALS_Learner.h:272-354), with the
+// cached residual e and the per-factor cache q = X v_f it maintains (:291-299, :341-350).
+//
+// The reference walks the features of one factor strictly in index order (Gauss-Seidel): feature i reads and then
+// corrects q[r], e[r] of every row r that holds it.  Two features interact only if they share a row, so the exact
+// sequential result is kept by "level scheduling": level(i) = 1 + max level of the smaller-index features sharing a
+// row with i; all features of one level are independent and are processed by one launch, levels in ascending order.
+// Field-structured data (one active feature per field and row: one-hot encodings, the synthetic workload's strata,
+// MovieLens user/item) has as many levels as fields.  One wavefront owns one feature: lanes stride over the
+// feature's CSC column, reduce sum(h*e), sum(h*h), form the new v, then apply the rank-1 corrections with plain
+// stores (no two features of a level touch the same row, so there are no atomics and the result is reproducible).
+// fp64 throughout, like the reference; x*x is a float product there (:314,:345) and here.
+#include "fmx_internal.h"
+
+namespace fmx {
+
+// ---- levels ------------------------------------------------------------------------------------------------
+// one relaxation sweep over the rows (columns ascending inside a row): level[c_j] >= level[c_{j-1}] + 1
+__global__ void level_relax_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n,
+                              int* __restrict__ level, int* __restrict__ changed) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int run = -1;
+  bool ch = false;
+  for (int64_t t = row_ptr[r]; t < row_ptr[r + 1]; ++t) {
+    const uint32_t c = col[t];
+    const int want = run + 1;
+    int cur = level[c];
+    if (cur < want) {
+      const int old = atomicMax(&level[c], want);
+      cur = old > want ? old : want;
+      ch = true;
+    }
+    run = cur;
+  }
+  if (ch) *changed = 1;
+}
+
+// ---- per-factor cache q = X v_f (rows parallel; same ascending-feature association as :291-299) -------------------
+__global__ void als_q_init_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val,
+                             int64_t n, const double* __restrict__ V, int kp, int f, double* __restrict__ q) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double acc = 0.0;
+  for (int64_t t = row_ptr[r]; t < row_ptr[r + 1]; ++t) acc += (double)val[t] * V[(size_t)col[t] * kp + f];
+  q[r] = acc;
+}
+
+__device__ __forceinline__ bool bad_number(double x) { return isnan(x) || isinf(x); }
+
+// one wave per feature of the level
+__global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
+                                                          const uint32_t* __restrict__ crow, const float* __restrict__ cval,
+                                                          double* __restrict__ V, int kp, int f, double* __restrict__ q,
+                                                          double* __restrict__ err, double alpha, double lambda, double mu) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6);
+  if (wid >= n_feats) return;
+  const uint32_t i = feats[wid];
+  const int64_t b = col_ptr[i], e = col_ptr[i + 1];
+  const double v_old = V[(size_t)i * kp + f];
+  double v_mean = 0.0, v_var = 0.0;
+  for (int64_t t = b + lane; t < e; t += 64) {  // :310-317
+    const float x = cval[t];
+    const uint32_t r = crow[t];
+    const float xx = x * x;
+    const double h = (double)x * q[r] - (double)xx * v_old;
+    v_mean += h * err[r];
+    v_var += h * h;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v_mean += __shfl_xor(v_mean, off);
+    v_var += __shfl_xor(v_var, off);
+  }
+  v_mean -= v_old * v_var;                               // :318
+  v_var = 1.0 / (lambda + alpha * v_var);                // :319
+  v_mean = -v_var * (alpha * v_mean - mu * lambda);      // :320
+  double v_new = bad_number(v_var) ? 0.0 : v_mean;       // :323-333 (ALS: no sampling)
+  if (bad_number(v_new)) return;                         // CHECK_PARAM (:336): keep the old value, skip the corrections
+  if (lane == 0) V[(size_t)i * kp + f] = v_new;
+  const double v_diff = v_old - v_new;
+  for (int64_t t = b + lane; t < e; t += 64) {  // :341-350
+    const float x = cval[t];
+    const uint32_t r = crow[t];
+    const float xx = x * x;
+    const double qr = q[r];
+    const double h = (double)x * qr - (double)xx * v_old;
+    q[r] = qr - (double)x * v_diff;
+    err[r] -= h * v_diff;
+  }
+}
+
+struct AlsPlan {
+  std::vector<int64_t> level_ptr;  // [L+1] into feats
+  uint32_t* d_feats = nullptr;     // features ordered by (level, index)
+};
+
+static int build_plan(fmx_matrix* m, hipStream_t stream, AlsPlan* plan) {
+  const uint32_t p = m->p;
+  int *d_level = nullptr, *d_changed = nullptr;
+  FMX_HIP(hipMalloc(&d_level, (size_t)p * sizeof(int)));
+  FMX_HIP(hipMalloc(&d_changed, sizeof(int)));
+  FMX_HIP(hipMemsetAsync(d_level, 0, (size_t)p * sizeof(int), stream));
+  int rounds = 0;
+  for (;;) {
+    int h = 0;
+    FMX_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+    if (m->n > 0) hipLaunchKernelGGL(level_relax_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->n, d_level, d_changed);
+    FMX_HIP(hipMemcpyAsync(&h, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+    FMX_HIP(hipStreamSynchronize(stream));
+    if (!h) break;
+    FMX_CHECK(++rounds <= (int64_t)p + 1, FMX_ERR_STATE, "level scheduling did not converge");
+  }
+  std::vector<int> level(p);
+  FMX_HIP(hipMemcpy(level.data(), d_level, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(d_level); (void)hipFree(d_changed);
+  int L = 0;
+  for (uint32_t j = 0; j < p; ++j) if (level[j] + 1 > L) L = level[j] + 1;
+  plan->level_ptr.assign((size_t)L + 1, 0);
+  for (uint32_t j = 0; j < p; ++j) plan->level_ptr[(size_t)level[j] + 1]++;
+  for (int l = 0; l < L; ++l) plan->level_ptr[(size_t)l + 1] += plan->level_ptr[(size_t)l];
+  std::vector<uint32_t> feats(p);
+  std::vector<int64_t> cur(plan->level_ptr.begin(), plan->level_ptr.end() - 1);
+  for (uint32_t j = 0; j < p; ++j) feats[(size_t)cur[(size_t)level[j]]++] = j;  // ascending index inside a level
+  FMX_HIP(hipMalloc(&plan->d_feats, (size_t)p * sizeof(uint32_t)));
+  FMX_HIP(hipMemcpy(plan->d_feats, feats.data(), (size_t)p * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return FMX_OK;
+}
+
+int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu) {
+  FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweep needs every row's columns strictly ascending (as R's dgCMatrix rows are)");
+  FMX_TRY(build_full_csc(m, e->stream));
+  AlsPlan plan;
+  int st = build_plan(m, e->stream, &plan);
+  if (st != FMX_OK) { (void)hipFree(plan.d_feats); return st; }
+  const int L = (int)plan.level_ptr.size() - 1;
+  for (int f = 0; f < e->k; ++f) {
+    if (m->n > 0) hipLaunchKernelGGL(als_q_init_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_q);
+    const double lambda = h_lambda ? h_lambda[f] : 0.0, mu = h_mu ? h_mu[f] : 0.0;
+    for (int l = 0; l < L; ++l) {
+      const int64_t cnt = plan.level_ptr[(size_t)l + 1] - plan.level_ptr[(size_t)l];
+      if (cnt == 0) continue;
+      const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
+      hipLaunchKernelGGL(als_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, plan.d_feats + plan.level_ptr[(size_t)l], (int)cnt,
+                         m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_q, d_error, alpha, lambda, mu);
+    }
+  }
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  (void)hipFree(plan.d_feats);
+  FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "ALS sweep failed: %s", hipGetErrorString(err));
+  return FMX_OK;
+}
+
+}  // namespace fmx

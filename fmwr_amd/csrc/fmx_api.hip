@@ -621,9 +621,20 @@ int fmx_stream(fmx_engine* e, void** stream) {
 
 int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda, const double* v_mu) {
   FMX_TRY(check_pair(e, m));
-  (void)error; (void)alpha; (void)v_lambda; (void)v_mu;
-  set_error("fmx_als_vsweep: not built yet");
-  return FMX_ERR_INVALID;
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweep runs on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(error != nullptr || m->n == 0, FMX_ERR_INVALID, "error is NULL");
+  FMX_TRY(use_device(e->cfg.device));
+  if (m->n == 0 || e->k == 0) return FMX_OK;
+  double *d_err = nullptr, *d_q = nullptr;
+  const size_t bytes = (size_t)m->n * sizeof(double);
+  FMX_HIP(hipMalloc(&d_err, bytes));
+  if (hipMalloc(&d_q, bytes) != hipSuccess) { (void)hipFree(d_err); set_error("out of device memory"); return FMX_ERR_HIP; }
+  int st = FMX_OK;
+  if (hipMemcpy(d_err, error, bytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the residual failed"); st = FMX_ERR_HIP; }
+  if (st == FMX_OK) st = launch_als_vsweep(e, m, d_err, d_q, alpha, v_lambda, v_mu);
+  if (st == FMX_OK && hipMemcpy(error, d_err, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("download of the residual failed"); st = FMX_ERR_HIP; }
+  (void)hipFree(d_err); (void)hipFree(d_q);
+  return st;
 }
 
 int fmx_profile_enable(fmx_engine* e, int on) {

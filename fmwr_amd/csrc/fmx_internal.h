@@ -173,7 +173,7 @@ int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int check_rows_sorted(fmx_matrix* m);
 
-int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* d_lambda, const double* d_mu);
+int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu);
 
 // profiling helpers
 void prof_begin(fmx_engine* e, int kernel);

@@ -231,3 +231,33 @@ def test_grad_apply_equals_step(fm):
         ea.sync(); eb.sync()
         pa, pb = ea.get_params(), eb.get_params()
         assert util.rel_err(pb[2], pa[2]) < 1e-6 and util.rel_err(pb[1], pa[1]) < 1e-6 and abs(pa[0] - pb[0]) < 1e-6
+
+
+@pytest.mark.parametrize("shape", ["fields", "ragged"])
+def test_als_vsweep_matches_oracle(fm, shape):
+    """MCMC_ALS_Learner::update_v (ALS branch): exact Gauss-Seidel order through level scheduling."""
+    engine, L = fm
+    rng = np.random.default_rng(11)
+    if shape == "fields":  # one active feature per field and row (one-hot style): as many levels as fields
+        n, fields, width, k = 2000, 6, 50, 5
+        p = fields * width
+        rp = np.arange(n + 1, dtype=np.int64) * fields
+        col = (rng.integers(0, width, (n, fields)) + np.arange(fields)[None, :] * width).astype(np.uint32).ravel()
+        val = rng.normal(0, 1, n * fields).astype(np.float32)
+    else:
+        n, p, k = 1500, 120, 4
+        rp, col, val = util.random_csr(n, p, 7, seed=12)
+    y = util.labels(n, 5, "regression")
+    w0, w, v = util.params(p, k, 6, stdev=0.3, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y  # calculate_error, MCMC_ALS_Learner.h:520-527
+    lam = np.linspace(0.0, 0.5, k); mu = np.linspace(-0.1, 0.1, k)
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=1.3, v_lambda=lam, v_mu=mu)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    gerr = e.als_vsweep(m, err0, alpha=1.3, v_lambda=lam, v_mu=mu)
+    gv = e.get_params()[2]
+    assert util.rel_err(gv, rv.reshape(k, p)) < 1e-10
+    assert util.rel_err(gerr, rerr) < 1e-10
