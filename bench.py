@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--batch-rows", type=int, default=262_144, help="mini-batch rows per GPU per step")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
+    ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
     ap.add_argument("--cpu-rows", type=int, default=1_500_000, help="rows of the CPU-baseline sample (0: skip)")
     return ap.parse_args()
 
@@ -103,7 +104,7 @@ def main():
     solver = L.SOLVER_SGD if args.solver == "sgd" else L.SOLVER_FTRL
     e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=solver, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
                       l1_w1=1e-4 if args.solver == "ftrl" else 0.0, l1_v=1e-4 if args.solver == "ftrl" else 0.0,
-                      mode=L.MODE_MINIBATCH, batch_rows=B, device=local_rank)
+                      mode=L.MODE_MINIBATCH, batch_rows=B, device=local_rank, keep_w1=0 if args.no_linear else 1)
     v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
     e.set_params(0.0, None, v0.astype(np.float64))
     nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work

@@ -1,0 +1,257 @@
+"""Python mirror of the reference's user-facing operator interface for the hot path.
+
+The reference's host side for this path is R + Rcpp (R/fm_train.R, R/fm_update.R, R/fm_predict.R, R/fm_control.R,
+R/fm_solver_control.R, R/fm_track_control.R, R/fm_matrix.R -> src/FM.cpp).  R is not available in this image, so the
+same surface is mirrored here with the same names (dots -> underscores), argument meaning, defaults and error
+messages, on top of the C ABI (include/fmx.h).  The Rcpp glue a maintainer would add is in INTEGRATION.md.
+
+Outside the path: the TDAP and MCMC solvers, tracker snapshots (track.control(step_size > 0)),
+fm.select / fm.track, column normalisation (normalize=TRUE).  Asking for them raises NotImplementedError.
+"""
+import warnings
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine, Matrix
+
+_TASKS = {"CLASSIFICATION": L.TASK_CLASSIFICATION, "REGRESSION": L.TASK_REGRESSION}
+_SOLVERS = {"SGD": L.SOLVER_SGD, "FTRL": L.SOLVER_FTRL, "ALS": L.SOLVER_ALS}
+
+# R/fm_control.R:52-66
+MODEL_CONTROL_DEFAULT = {
+    "keep.w0": True, "L2.w0": 0.0, "keep.w1": True, "L1.w1": 0.0, "L2.w1": 0.0,
+    "factor.number": 2, "v.init_mean": 0.0, "v.init_stdev": 0.01, "L1.v": 0.0, "L2.v": 0.0,
+}
+SGD_SOLVER_DEFAULT = {"learn_rate": 0.01, "random_step": 1}                                        # R/fm_solver_control.R:91-94
+FTRL_SOLVER_DEFAULT = {"alpha_w": 0.1, "alpha_v": 0.1, "beta_w": 1.0, "beta_v": 1.0, "random_step": 1}  # :109-115
+ALS_SOLVER_DEFAULT = {"alpha_0": 1.0, "gamma_0": 1.0, "beta_0": 1.0, "mu_0": 0.0, "alpha": 1.0, "w0_mean_0": 1.0}  # :64-71
+
+
+def _control_assign(default, given):
+    """R/control_tools.R:1-37: overlay named arguments on the defaults, coerce integers, warn on unknown names."""
+    out = dict(default)
+    unknown = 0
+    for name, value in given.items():
+        key = name.replace("_", ".") if name.replace("_", ".") in default else name
+        if key not in default:
+            unknown += 1
+            continue
+        d = default[key]
+        if isinstance(d, bool):
+            if not isinstance(value, (bool, np.bool_)):
+                raise TypeError(f"{key} must be logical")
+        elif isinstance(d, int):
+            iv = int(value)
+            if iv != value:
+                iv = max(d, iv)
+                warnings.warn(f"{key} is not integer, it will be set as {iv}")
+            value = iv
+        out[key] = value
+    if unknown:
+        warnings.warn("some arguments are unknown...")
+    return out
+
+
+def model_control(task="CLASSIFICATION", **hyper):
+    """model.control() -- R/fm_control.R:43-50."""
+    if task not in ("CLASSIFICATION", "REGRESSION", "RANK"):
+        raise ValueError("'arg' should be one of 'CLASSIFICATION', 'REGRESSION', 'RANK'")
+    return {"class": "model.control", "task": task, "hyper.params": _control_assign(MODEL_CONTROL_DEFAULT, hyper)}
+
+
+def SGD_solver(**kw):
+    """SGD.solver() -- R/fm_solver_control.R:96-107."""
+    return {"solver": "SGD", **_control_assign(SGD_SOLVER_DEFAULT, kw)}
+
+
+def FTRL_solver(**kw):
+    """FTRL.solver() -- R/fm_solver_control.R:117-130."""
+    return {"solver": "FTRL", **_control_assign(FTRL_SOLVER_DEFAULT, kw)}
+
+
+def ALS_solver(**kw):
+    """ALS.solver() -- R/fm_solver_control.R:73-87 (its parameters are ignored by the reference too: SURVEY A-7)."""
+    return {"solver": "ALS", **_control_assign(ALS_SOLVER_DEFAULT, kw)}
+
+
+def TDAP_solver(**kw):
+    raise NotImplementedError("TDAP.solver is outside the accelerated path (SURVEY.md section 8, row f-3)")
+
+
+def MCMC_solver(**kw):
+    raise NotImplementedError("MCMC.solver is outside the accelerated path (it samples from R's RNG)")
+
+
+def solver_control(max_iter=10000, solver=None):
+    """solver.control() -- R/fm_solver_control.R:22-33.  The reference defaults to TDAP.solver(), which is outside
+    the accelerated path; the default here is SGD.solver()."""
+    solver = SGD_solver() if solver is None else solver
+    if solver["solver"] in ("MCMC", "ALS") and max_iter > 100:
+        warnings.warn("the maximum number of iteratorions for MCMC/ALS solver is 100, so max_iter will be set to 100")
+        max_iter = min(max_iter, 100)
+    return {"class": "solver.control", "max_iter": int(max_iter), "solver": solver}
+
+
+def track_control(step_size=-1, evaluate_metric="LL", convergence=1e-4):
+    """track.control() -- R/fm_track_control.R:20-26."""
+    if evaluate_metric not in ("AUC", "ACC", "LL", "RMSE", "MAE"):
+        raise ValueError('evaluate.metric %in% c("AUC", "ACC", "LL", "RMSE", "MAE") is not TRUE')
+    return {"class": "track.control", "max_iter": 1, "step_size": int(step_size), "evaluate.metric": evaluate_metric,
+            "convergence": convergence}
+
+
+class FmMatrix:
+    """fm.matrix -- R/fm_matrix.R:6-43: features = list(value, col_idx, row_size, dim, size), labels."""
+
+    def __init__(self, features, labels, feature_names):
+        self.features, self.labels, self.feature_names = features, labels, feature_names
+
+    @property
+    def dim(self):
+        return self.features["dim"]
+
+
+def fm_matrix(data, labels=None, feature_names=None):
+    """fm.matrix(): accepts a scipy.sparse matrix or a dense 2-D array (rows = cases, columns = features)."""
+    import scipy.sparse as sp
+    if labels is not None:
+        labels = np.asarray(labels, np.float64)
+        if labels.ndim != 1:
+            raise ValueError("is.numeric(labels) is not TRUE")
+        if np.any(np.isnan(labels)):
+            raise ValueError("!any(is.na(labels)) is not TRUE")
+    X = data.tocsr() if sp.issparse(data) else sp.csr_matrix(np.asarray(data, np.float64))
+    X.sort_indices()
+    n, p = X.shape
+    if labels is not None and len(labels) != n:
+        raise ValueError("length(labels) == nrow(data) is not TRUE")
+    if feature_names is None:
+        feature_names = [f"V{j + 1}" for j in range(p)]  # numpy has no colnames; R would stop("there's no feature_names")
+    elif len(feature_names) != p:
+        raise ValueError("ncol(data) == length(feature_names) is not TRUE")
+    features = {"value": X.data.astype(np.float64), "col_idx": X.indices.astype(np.int32),
+                "row_size": np.diff(X.indptr).astype(np.int32), "dim": (n, p), "size": int(X.nnz)}
+    return FmMatrix(features, labels, list(feature_names))
+
+
+def _device_matrix(data, labels, device):
+    f = data.features
+    return Matrix.from_rlist(f["value"], f["col_idx"], f["row_size"], f["dim"][1], labels, device=device)
+
+
+def _engine_for(controls, p, target_range, mode, batch_rows, device):
+    model, solver_ctl = controls["model"], controls["solver"]
+    hp, sol = model["hyper.params"], solver_ctl["solver"]
+    if model["task"] not in _TASKS:
+        raise NotImplementedError("task RANK is not implemented by the reference either (FM.cpp:64 -> 'unknown task...')")
+    return Engine(p, task=_TASKS[model["task"]], solver=_SOLVERS[sol["solver"]], num_factor=int(hp["factor.number"]),
+                  keep_w0=int(hp["keep.w0"]), keep_w1=int(hp["keep.w1"]), l2_w0=hp["L2.w0"], l1_w1=hp["L1.w1"], l2_w1=hp["L2.w1"],
+                  l1_v=hp["L1.v"], l2_v=hp["L2.v"], learn_rate=sol.get("learn_rate", 0.01), alpha_w=sol.get("alpha_w", 0.1),
+                  alpha_v=sol.get("alpha_v", 0.1), beta_w=sol.get("beta_w", 1.0), beta_v=sol.get("beta_v", 1.0),
+                  random_step=int(sol.get("random_step", 1)), mode=L.MODE_SEQUENTIAL if mode == "sequential" else L.MODE_MINIBATCH,
+                  batch_rows=int(batch_rows), min_target=target_range[0], max_target=target_range[1], device=device)
+
+
+def _merge_controls(data, control):
+    n = data.dim[0]
+    merged = {"model": model_control(), "solver": solver_control(max_iter=max(10000, 2 * n)), "track": track_control()}  # R/fm_train.R:90-93
+    for c in (control or []):
+        cls = c.get("class", "")
+        if not cls.endswith(".control"):
+            raise ValueError("control list is wrong")
+        merged[cls.split(".")[0]] = c
+    if merged["track"]["step_size"] > 0:
+        raise NotImplementedError("tracker snapshots (track.control(step_size > 0)) are outside the accelerated path (row f-1)")
+    return merged
+
+
+def _check_labels(data, task):
+    if data.labels is None:
+        raise ValueError("there are no labels in data")  # R/fm_train.R:72-74
+    y = np.asarray(data.labels, np.float64)
+    if task == "CLASSIFICATION":  # R/fm_train.R:112-122
+        u = np.unique(y)
+        if len(u) != 2:
+            raise ValueError("target should have two levels")
+        if np.array_equal(u, [0.0, 1.0]):
+            y = np.where(y < 1, -1.0, 1.0)
+        elif not np.array_equal(u, [-1.0, 1.0]):
+            raise ValueError("target should be c(0, 1) or c(-1, 1)")
+    return y
+
+
+def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device):
+    p = data.dim[1]
+    y = _check_labels(data, controls["model"]["task"])
+    lo, hi = float(y.min()), float(y.max())  # src/FM.cpp:89-90
+    if target_range is not None:               # src/FM.cpp:91-96 (fm.update widens the range)
+        lo, hi = min(lo, target_range[0]), max(hi, target_range[1])
+    eng = _engine_for(controls, p, (lo, hi), mode, batch_rows, device)
+    eng.set_params(w0, w, v)
+    m = _device_matrix(data, y, device)
+    sol = controls["solver"]["solver"]["solver"]
+    if sol == "ALS":
+        raise NotImplementedError("ALS training beyond the V sweep is outside the accelerated path (row f-4); use Engine.als_vsweep")
+    eng.train(m, controls["solver"]["max_iter"])
+    w0, w, v = eng.get_params()
+    model = {"w0": w0, "w": w, "v": v, "model.control": controls["model"], "solver.control": controls["solver"],
+             "track.control": controls["track"], "convergence": False}
+    scales = {"mean": None, "std": None, "model.vars": data.feature_names, "target.range": (lo, hi)}
+    return {"class": "FM", "Model": model, "Scales": scales, "engine": {"mode": mode, "batch_rows": batch_rows, "device": device}}
+
+
+def fm_train(data, normalize=False, control=None, seed=None, mode="sequential", batch_rows=65536, device=0):
+    """fm.train() -- R/fm_train.R:70-127.  `control` is a list of *.control objects.  V0 ~ N(v.init_mean, v.init_stdev)
+    is drawn here (the reference draws it from R's RNG inside Model::init, core/Model.h:63-72); `seed` makes it repeatable.
+    mode="sequential" is the reference's algorithm; mode="minibatch" the synchronous mini-batch engine."""
+    if not isinstance(data, FmMatrix):
+        raise TypeError("data must be a fm.matrix object")
+    if normalize:
+        raise NotImplementedError("column normalisation (SMatrix::scales) is outside the accelerated path (row f-2); pass normalize=False")
+    controls = _merge_controls(data, control)
+    hp = controls["model"]["hyper.params"]
+    k, p = int(hp["factor.number"]), data.dim[1]
+    rng = np.random.default_rng(seed)
+    v0 = rng.normal(hp["v.init_mean"], hp["v.init_stdev"], (k, p)) if k > 0 else np.zeros((0, p))
+    return _train(data, controls, 0.0, np.zeros(p), v0, None, mode, batch_rows, device)
+
+
+def fm_update(object, data, max_iter=None, mode=None, batch_rows=None, device=None):
+    """fm.update() -- R/fm_update.R:18-135: continue training from a fitted FM with the controls stored on it.
+    Optimizer state (FTRL z/n, SGD q/u) is NOT carried over, exactly as in the reference."""
+    if not isinstance(object, dict) or object.get("class") != "FM":
+        raise TypeError("object must be a FM object")
+    if not isinstance(data, FmMatrix):
+        raise TypeError("data must be a fm.matrix object")
+    if list(data.feature_names) != list(object["Scales"]["model.vars"]):  # R/fm_update.R:27-37
+        raise ValueError("the features in data are not the same as those in FM model")
+    mdl = object["Model"]
+    controls = {"model": mdl["model.control"], "solver": dict(mdl["solver.control"]), "track": mdl["track.control"]}
+    if max_iter is not None:
+        controls["solver"]["max_iter"] = int(max_iter)
+    eng = object.get("engine", {})
+    return _train(data, controls, mdl["w0"], mdl["w"], mdl["v"], object["Scales"]["target.range"],
+                  mode or eng.get("mode", "sequential"), batch_rows or eng.get("batch_rows", 65536),
+                  eng.get("device", 0) if device is None else device)
+
+
+def predict(object, newdata=None, normalize=False):
+    """predict.FM() -- R/fm_predict.R:12-34 -> FMPredict (src/FM.cpp:177-214): probabilities for CLASSIFICATION
+    (logistic link for SGD/FTRL models), predictions clamped to the training target range for REGRESSION."""
+    if newdata is None:
+        raise ValueError("newdata is null")
+    if not isinstance(newdata, FmMatrix):
+        raise TypeError("newdata must be a fm.matrix object")
+    if np.any(np.isnan(newdata.features["value"])):
+        raise ValueError("there are NAs in newdata")
+    if normalize and object["Scales"]["mean"] is None:
+        raise ValueError("can not normalize newdata because all the variables have not been normalized in FM model")
+    mdl = object["Model"]
+    controls = {"model": mdl["model.control"], "solver": mdl["solver.control"], "track": mdl["track.control"]}
+    device = object.get("engine", {}).get("device", 0)
+    eng = _engine_for(controls, newdata.dim[1], object["Scales"]["target.range"], "sequential", 1, device)
+    eng.set_params(mdl["w0"], mdl["w"], mdl["v"])
+    m = _device_matrix(newdata, None, device)
+    link = L.LINK_LOGISTIC if controls["model"]["task"] == "CLASSIFICATION" else L.LINK_CLAMP
+    return eng.predict(m, link)

@@ -1,0 +1,93 @@
+"""The reference's user-facing surface (fm.train / fm.update / predict.FM mirrored in fmwr_amd.api) on the GPU,
+including BASELINE.json configs[0]: MovieLens-100K-shaped, k=8, SGD (shape-matched synthetic: the data set itself is
+not available offline)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _movielens_shaped(n=100_000, users=943, items=1682, seed=0):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, users, n); i = rng.integers(0, items, n) + users
+    rating = rng.integers(1, 6, n).astype(np.float64)
+    X = sp.csr_matrix((np.ones(2 * n), np.stack([u, i], 1).ravel(), np.arange(0, 2 * n + 1, 2)), shape=(n, users + items))
+    return X, rating
+
+
+@pytest.mark.parametrize("task", ["REGRESSION", "CLASSIFICATION"])
+def test_config0_movielens_shaped_sgd(task):
+    import fmwr_amd as fm
+    X, rating = _movielens_shaped()
+    y = rating if task == "REGRESSION" else (rating >= 4).astype(np.float64)  # {0,1} labels -> {-1,+1} (R/fm_train.R:112-122)
+    data = fm.fm_matrix(X, y)
+    ctl = [fm.model_control(task, **{"factor.number": 8, "L2.w1": 1e-3, "L2.v": 1e-3, "v.init_stdev": 0.05}),
+           fm.solver_control(max_iter=100_000, solver=fm.SGD_solver(learn_rate=0.02))]
+    fit = fm.fm_train(data, control=ctl, seed=42, mode="sequential")
+    # oracle run from the same V0
+    k, p, n = 8, X.shape[1], X.shape[0]
+    v0 = np.random.default_rng(42).normal(0.0, 0.05, (k, p))
+    yy = y if task == "REGRESSION" else np.where(y < 1, -1.0, 1.0)
+    P = oracle.params(task=oracle.REGRESSION if task == "REGRESSION" else oracle.CLASSIFICATION, k=k, l2_regw=1e-3, l2_regv=1e-3,
+                      learn_rate=0.02, min_target=float(yy.min()), max_target=float(yy.max()))
+    Xo = oracle.Matrix(X.indptr, X.indices, X.data, p)
+    ref = oracle.sgd_learn(P, Xo, yy.astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 100_000)
+    rv = ref["v"].reshape(k, p)
+    assert np.max(np.abs(fit["Model"]["v"] - rv)) <= 1e-5 * np.max(np.abs(rv))       # north_star: 1e-5 relative on V
+    assert np.max(np.abs(fit["Model"]["v"] - rv)) <= 1e-10 * np.max(np.abs(rv))      # in fact ~1e-15
+    assert abs(fit["Model"]["w0"] - ref["w0"]) < 1e-10
+    pred = fm.predict(fit, data)
+    raw = oracle.predict_batch(P, Xo, ref["w0"], ref["w"], ref["v"])
+    want = np.clip(raw, yy.min(), yy.max()) if task == "REGRESSION" else 1.0 / (1.0 + np.exp(-raw))
+    np.testing.assert_allclose(pred, want, rtol=1e-9, atol=1e-12)
+    if task == "CLASSIFICATION":
+        assert np.array_equal(pred >= 0.5, raw >= 0)  # prediction sign bit-exact
+    assert fit["Scales"]["target.range"] == (float(yy.min()), float(yy.max()))
+
+
+def test_update_warm_start_and_errors():
+    import fmwr_amd as fm
+    X, rating = _movielens_shaped(n=5000, users=50, items=80, seed=3)
+    data = fm.fm_matrix(X, rating)
+    ctl = [fm.model_control("REGRESSION", **{"factor.number": 4, "L2.v": 1e-3}), fm.solver_control(max_iter=4000, solver=fm.FTRL_solver(alpha_v=0.05))]
+    fit = fm.fm_train(data, control=ctl, seed=1)
+    fit2 = fm.fm_update(fit, data, max_iter=3000)
+    # oracle: two learn() calls, parameters carried over, z/n reset
+    p, k = X.shape[1], 4
+    v0 = np.random.default_rng(1).normal(0.0, 0.01, (k, p))
+    P = oracle.params(task=oracle.REGRESSION, k=k, l2_regv=1e-3, alpha_v=0.05, min_target=1.0, max_target=5.0)
+    Xo = oracle.Matrix(X.indptr, X.indices, X.data, p)
+    r1 = oracle.ftrl_learn(P, Xo, rating.astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 4000)
+    r2 = oracle.ftrl_learn(P, Xo, rating.astype(np.float32), r1["w0"], r1["w"], r1["v"], 3000)
+    assert np.max(np.abs(fit2["Model"]["v"] - r2["v"].reshape(k, p))) <= 1e-10 * np.max(np.abs(r2["v"]))
+    # error behaviour mirrored from R/fm_train.R, R/fm_predict.R
+    with pytest.raises(ValueError, match="there are no labels in data"):
+        fm.fm_train(fm.fm_matrix(X))
+    with pytest.raises(ValueError, match="target should have two levels"):
+        fm.fm_train(fm.fm_matrix(X, rating), control=[fm.model_control("CLASSIFICATION")])
+    with pytest.raises(ValueError, match="newdata is null"):
+        fm.predict(fit)
+    with pytest.raises(ValueError, match="not the same"):
+        fm.fm_update(fit, fm.fm_matrix(X[:, :100], rating))
+    with pytest.raises(NotImplementedError):
+        fm.solver_control(solver=fm.TDAP_solver())
+
+
+def test_minibatch_mode_through_api_learns():
+    """Mini-batch engine behind the same API: the loss goes down on a learnable problem."""
+    import fmwr_amd as fm
+    rng = np.random.default_rng(5)
+    n, p, k = 20000, 200, 4
+    X = sp.random(n, p, density=0.05, format="csr", random_state=5, data_rvs=lambda s: rng.normal(0, 1, s))
+    vt = rng.normal(0, 0.3, (k, p)); wt = rng.normal(0, 0.3, p)
+    Xd = X.toarray()
+    score = Xd @ wt + 0.5 * (((Xd @ vt.T) ** 2).sum(1) - ((Xd ** 2) @ (vt.T ** 2)).sum(1))
+    y = (score > 0).astype(np.float64)
+    data = fm.fm_matrix(X, y)
+    ctl = [fm.model_control("CLASSIFICATION", **{"factor.number": k, "v.init_stdev": 0.1}), fm.solver_control(max_iter=20 * n, solver=fm.SGD_solver(learn_rate=0.05))]
+    fit = fm.fm_train(data, control=ctl, seed=0, mode="minibatch", batch_rows=256)
+    acc = np.mean((fm.predict(fit, data) >= 0.5) == (y > 0))
+    assert acc > 0.85, acc
