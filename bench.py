@@ -40,15 +40,9 @@ def parse():
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--cpu-rows", type=int, default=1_500_000, help="rows of the CPU-baseline sample (0: skip)")
     return ap.parse_args()
-
-
-class _DevBuf:
-    """Exposes a raw device pointer to torch (zero copy) through __cuda_array_interface__."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
 def algorithmic_bytes(z, k, p, rows):
@@ -93,14 +87,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # FMX_BENCH_SHARED_DEVICE=1: every rank uses device 0 (rehearsal of the N > 1 path on a one-GPU box, backend gloo)
+    if os.environ.get("FMX_BENCH_SHARED_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     z, k, p = args.nnz, args.factors, args.features
-    n_local = args.rows // world
-    B = min(args.batch_rows, n_local)
-    m = engine.Matrix.synthetic(n_local, p, z, args.seed, row_offset=rank * n_local, device=local_rank)
+    from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows
+    r0, r1 = shard_rows(args.rows, rank, world)
+    n_local = r1 - r0
+    B = min(args.batch_rows, args.rows // world)
+    m = engine.Matrix.synthetic(n_local, p, z, args.seed, row_offset=r0, device=local_rank)
     solver = L.SOLVER_SGD if args.solver == "sgd" else L.SOLVER_FTRL
     e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=solver, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
                       l1_w1=1e-4 if args.solver == "ftrl" else 0.0, l1_v=1e-4 if args.solver == "ftrl" else 0.0,
@@ -110,21 +112,14 @@ def main():
     nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work
     e.num_batches(m)              # builds the per-batch CSC (ingest, not timed)
 
-    gbuf = None
-    ext_stream = torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", local_rank))
-    if world > 1:
-        ptr, nfl = e.grad_buffer()
-        gbuf = torch.as_tensor(_DevBuf(ptr, nfl), device=torch.device("cuda", local_rank))
+    dp = DataParallel(EngineStepper(e, m, local_rank)) if world > 1 else None
 
     def one_step(i):
         b = i % nb_full
         if world == 1:
-            e.step(m, b)
+            e.step(m, b)      # fused: forward -> w0 step -> gradient sums + update
         else:
-            e.grad(m, b)
-            with torch.cuda.stream(ext_stream):
-                dist.all_reduce(gbuf)
-            e.apply(B * world)
+            dp.step(b)        # gradient sums -> RCCL all-reduce -> update
 
     def fence():
         e.sync()

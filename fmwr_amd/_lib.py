@@ -14,6 +14,7 @@ TASK_CLASSIFICATION, TASK_REGRESSION = 10, 20
 SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL = 200, 300, 500
 MODE_SEQUENTIAL, MODE_MINIBATCH = 0, 1
 LINK_NONE, LINK_LOGISTIC, LINK_CLAMP = 0, 1, 2
+REDUCE_MEAN, REDUCE_SUM = 0, 1
 KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3
 
 # every symbol include/fmx.h declares (tests/test_abi.py checks the library exports all of them)
@@ -35,7 +36,7 @@ class Config(C.Structure):
         ("alpha_w", C.c_double), ("alpha_v", C.c_double), ("beta_w", C.c_double), ("beta_v", C.c_double),
         ("random_step", C.c_int32), ("mode", C.c_int32), ("batch_rows", C.c_int64),
         ("min_target", C.c_double), ("max_target", C.c_double),
-        ("device", C.c_int32), ("reserved", C.c_int32),
+        ("device", C.c_int32), ("batch_reduce", C.c_int32),
     ]
 
 

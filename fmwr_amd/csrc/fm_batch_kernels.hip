@@ -206,8 +206,13 @@ __global__ __launch_bounds__(WG_THREADS) void fm_scalar_update_k(const double* _
   if (threadIdx.x != 0) return;
   g0 = sg[0]; q0 = sq[0];
   if (phase == 1) { gtail[0] = (float)g0; gtail[1] = (float)q0; gtail[2] = (float)rows; gtail[3] = 0.f; return; }
-  if (phase == 2) { g0 = gtail[0]; q0 = gtail[1]; }
+  if (phase == 2) { g0 = gtail[0]; q0 = gtail[1]; if (rows <= 0.0) rows = gtail[2]; }
   scal[SC_G0] = g0; scal[SC_Q0] = q0;
+  if (h.mean && rows > 0.0) {  // FMX_REDUCE_MEAN: w0 occurs in every example -> one step with the batch-mean multiplier
+    g0 /= rows;
+    q0 = g0 * g0;
+    rows = 1.0;
+  }
   double w0 = scal[SC_W0];
   if (h.kind == UPD_FTRL) {
     if (h.k0) {  // solver/FTRL_Learner.h:80-86 with the batch sums G0, Q0
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_scalar_update_k(const double* _
     }
     scal[SC_W0] = -scal[SC_Z0] * h.alpha_w / (h.beta_w + sqrt(scal[SC_N0]));  // FTRL_Learner.h:161
   } else {
-    if (h.kind == UPD_SGD_L1) {  // solver/SGD_Learner.h:92-97, once per example of the batch
+    if (h.kind == UPD_SGD_L1) {  // solver/SGD_Learner.h:92-97, once per example (SUM) or once per batch (MEAN)
       scal[SC_UW] += rows * (h.lr * h.regw);
       scal[SC_UV] += rows * (h.lr * h.regv);
     }
@@ -397,6 +402,13 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   }
 
   if (cnt == 0.0) return;  // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
+  if (h.mean) {  // FMX_REDUCE_MEAN: one reference step with the mean gradient of the coordinate's occurrences
+    const double inv = 1.0 / cnt;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { G[i] *= inv; Q[i] = G[i] * G[i]; }
+    Gw *= inv; Qw = Gw * Gw;
+    cnt = 1.0;
+  }
 
   double decay_v = 1.0, decay_w = 1.0, u_w = 0.0, u_v = 0.0;
   if constexpr (KIND == UPD_SGD_L2) {

@@ -81,6 +81,7 @@ static int make_hyper(const fmx_config& c, Hyper* h) {
   h->l1w = c.l1_w1; h->l1v = c.l1_v; h->l2w = c.l2_w1; h->l2v = c.l2_v;
   h->alpha_w = c.alpha_w; h->alpha_v = c.alpha_v; h->beta_w = c.beta_w; h->beta_v = c.beta_v;
   h->min_t = c.min_target; h->max_t = c.max_target;
+  h->mean = (c.batch_reduce == FMX_REDUCE_MEAN);
   if (c.solver == FMX_SOLVER_FTRL) {
     h->kind = UPD_FTRL;
     h->regw = 0; h->regv = 0;
@@ -280,6 +281,7 @@ int fmx_config_default(fmx_config* cfg) {
   cfg->batch_rows = 65536;
   cfg->min_target = -1.0; cfg->max_target = 1.0;
   cfg->device = 0;
+  cfg->batch_reduce = FMX_REDUCE_MEAN;
   return FMX_OK;
 }
 
@@ -295,6 +297,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->num_factor >= 0 && cfg->num_factor <= 128, FMX_ERR_INVALID, "factor.number must be in 0..128 (got %d)", cfg->num_factor);
   FMX_CHECK(cfg->mode == FMX_MODE_SEQUENTIAL || cfg->mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID, "unknown mode %d", cfg->mode);
   FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
+  FMX_CHECK(cfg->batch_reduce == FMX_REDUCE_MEAN || cfg->batch_reduce == FMX_REDUCE_SUM, FMX_ERR_INVALID, "unknown batch_reduce %d", cfg->batch_reduce);
   FMX_CHECK(num_features > 0 && num_features < (1ull << 32), FMX_ERR_INVALID, "number of features must be in 1..2^32-1");
   if (cfg->mode == FMX_MODE_MINIBATCH) FMX_CHECK(cfg->batch_rows >= 1, FMX_ERR_INVALID, "batch_rows must be >= 1");
   FMX_TRY(use_device(cfg->device));

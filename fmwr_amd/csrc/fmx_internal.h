@@ -48,6 +48,7 @@ enum UpdateKind : int {
 struct Hyper {
   int task, k0, k1;
   int kind;  // UpdateKind
+  int mean;  // FMX_REDUCE_MEAN: per-coordinate mean gradient, one update per batch
   double lr, reg0, regw, regv;  // SGD: regw/regv are the L1 OR L2 rates (SGD_Learner.h:44-59)
   double l1w, l1v, l2w, l2v;    // FTRL prox
   double alpha_w, alpha_v, beta_w, beta_v;

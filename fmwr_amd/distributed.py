@@ -1,0 +1,74 @@
+"""Synchronous data-parallel mini-batch training: one process per GPU, rows sharded contiguously by rank, one
+all-reduce(sum) of the gradient-sum buffer per step (RCCL over xGMI through torch.distributed, backend "nccl").
+
+The reference has no counterpart (single process); BASELINE.json's north_star prescribes the scheme.
+Every replica holds the full (w0, w, V) and applies the identical update from the identical reduced sums, so replicas
+stay in lock step.  The buffer is the engine's own exchange buffer (fmx_grad_buffer), viewed as a torch tensor without
+a copy; the all-reduce is enqueued on the engine's HIP stream, so no host synchronisation happens inside a step.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_total, rank, world):
+    """Contiguous row range [r0, r1) of rank `rank`: rank r gets rows [r*n/N, (r+1)*n/N)."""
+    return (n_total * rank) // world, (n_total * (rank + 1)) // world
+
+
+class GradLayout:
+    """Element offsets (fp32) inside the exchange buffer, mirroring fm_batch_kernels.hip:
+    GV [p][kp] | GW [p] | CNT [p] | QV [p][kp] | QW [p] | tail = [G0, Q0, rows, 0]."""
+
+    def __init__(self, p, kp):
+        self.p, self.kp = p, kp
+        self.gv = 0
+        self.gw = p * kp
+        self.cnt = self.gw + p
+        self.qv = self.cnt + p
+        self.qw = self.qv + p * kp
+        self.tail = self.qw + p
+        self.size = self.tail + 4
+
+
+class _DevBuf:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class EngineStepper:
+    """The product stepper: fmx_grad / fmx_grad_buffer / fmx_apply on one GPU."""
+
+    def __init__(self, engine, matrix, device):
+        self.e, self.m = engine, matrix
+        self.device = torch.device("cuda", device)
+        ptr, n = engine.grad_buffer()
+        self.buf = torch.as_tensor(_DevBuf(ptr, n), device=self.device)
+        self.stream = torch.cuda.ExternalStream(engine.stream(), device=self.device)
+
+    def grad(self, batch, rows_limit=0):
+        self.e.grad(self.m, batch, rows_limit)
+
+    def buffer(self):
+        return self.buf
+
+    def apply(self):
+        self.e.apply(0)  # global row count is read from the reduced buffer tail
+
+    def comm_context(self):
+        return torch.cuda.stream(self.stream)
+
+
+class DataParallel:
+    """step(batch): local gradient sums -> all-reduce(sum) -> identical update on every replica."""
+
+    def __init__(self, stepper, group=None):
+        self.s = stepper
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def step(self, batch, rows_limit=0):
+        self.s.grad(batch, rows_limit)
+        if self.world > 1:
+            with self.s.comm_context():
+                dist.all_reduce(self.s.buffer(), op=dist.ReduceOp.SUM, group=self.group)
+        self.s.apply()

@@ -48,6 +48,15 @@ extern "C" {
 #define FMX_MODE_SEQUENTIAL 0
 #define FMX_MODE_MINIBATCH 1
 
+/* How a mini-batch combines the per-example gradients of one coordinate (c = its occurrences in the batch):
+ * FMX_REDUCE_MEAN: one reference step with the MEAN gradient G/c (and one lazy-L2 / L1 / FTRL update) per touched
+ *   coordinate per batch -- stable for any batch size with the reference's learning rates; the default.
+ * FMX_REDUCE_SUM : the SUM G with c-fold decay -- what processing the c examples one after the other with frozen
+ *   gradients does; first-order equal to the reference's pass, but dense coordinates (w0!) overshoot once
+ *   learn_rate * c is not small.  Both are the reference's example step at batch_rows == 1. */
+#define FMX_REDUCE_MEAN 0
+#define FMX_REDUCE_SUM 1
+
 /* output transform of fmx_predict */
 #define FMX_LINK_NONE 0      /* raw y_hat: Model::predict_batch, core/Model.h:106-161 */
 #define FMX_LINK_LOGISTIC 1  /* 1/(1+exp(-y_hat)): Model::predict_prob, core/Model.h:173-178 */
@@ -74,7 +83,7 @@ typedef struct fmx_config {
   double min_target;       /* learner->min_target, src/FM.cpp:89-96     */
   double max_target;       /* learner->max_target                       */
   int32_t device;          /* HIP device ordinal                        */
-  int32_t reserved;
+  int32_t batch_reduce;    /* FMX_REDUCE_* (mini-batch mode)            */
 } fmx_config;
 
 typedef struct fmx_engine fmx_engine; /* parameters + optimizer state on one GPU */
@@ -145,7 +154,8 @@ int fmx_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
 int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
 /* ... device pointer / element count (fp32) of that buffer, for an in-place all-reduce(sum) ... */
 int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats);
-/* ... and the update from the (reduced) buffer; global_rows = rows of the whole global batch. */
+/* ... and the update from the (reduced) buffer; global_rows = rows of the whole global batch, or <= 0 to take the
+ * count that travelled in the buffer's tail (each rank's fmx_grad wrote its own row count there; the all-reduce summed them). */
 int fmx_apply(fmx_engine* e, int64_t global_rows);
 int fmx_sync(fmx_engine* e);
 /* the hipStream_t the engine launches on (as void*), so a caller can order its own work after it */

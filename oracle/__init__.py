@@ -27,6 +27,7 @@ class Params(C.Structure):
         ("alpha_w", C.c_double), ("beta_w", C.c_double), ("alpha_v", C.c_double), ("beta_v", C.c_double),
         ("random_step", C.c_int32), ("eval_type", C.c_int32),
         ("trace_step", C.c_int64), ("conv_condition", C.c_double),
+        ("batch_mean", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -63,9 +64,9 @@ def lib():
 
 def params(task=CLASSIFICATION, k=2, k0=True, k1=True, l1_regw=0.0, l1_regv=0.0, l2_reg0=0.0, l2_regw=0.0,
            l2_regv=0.0, min_target=-1.0, max_target=1.0, learn_rate=0.01, alpha_w=0.1, beta_w=1.0, alpha_v=0.1,
-           beta_v=1.0, random_step=1, eval_type=LL, trace_step=-1, conv_condition=1e-4):
+           beta_v=1.0, random_step=1, eval_type=LL, trace_step=-1, conv_condition=1e-4, batch_mean=True):
     return Params(task, k, int(k0), int(k1), l1_regw, l1_regv, l2_reg0, l2_regw, l2_regv, min_target, max_target,
-                  learn_rate, alpha_w, beta_w, alpha_v, beta_v, random_step, eval_type, trace_step, conv_condition)
+                  learn_rate, alpha_w, beta_w, alpha_v, beta_v, random_step, eval_type, trace_step, conv_condition, int(batch_mean), 0)
 
 
 def _ptr(a):
@@ -209,3 +210,29 @@ def sgd_pass(P, X, y, w0, w, v):
     y = np.ascontiguousarray(y, np.float32)
     w0c = C.c_double(w0)
     return lib().fmo_sgd_pass(C.byref(P), C.c_uint32(X.p), C.byref(w0c), _ptr(w), _ptr(v), C.byref(X.c), _ptr(y))
+
+
+def batch_sums(P, X, y, w0, w, v, b0, b1, acc=None):
+    """Per-coordinate gradient sums of rows [b0, b1) at parameters (w0, w, v), accumulated into `acc`
+    (dict G0,Q0 scalars + Gw,Qw,cw [p], Gv,Qv [k][p]); fm_oracle.c fmo_batch_sums."""
+    k, p = max(P.k, 1), max(X.p, 1)
+    if acc is None:
+        acc = dict(G0=0.0, Q0=0.0, Gw=np.zeros(p), Qw=np.zeros(p), cw=np.zeros(p), Gv=np.zeros(k * p), Qv=np.zeros(k * p))
+    y = np.ascontiguousarray(y, np.float32); w = _f64(w); v = _f64(v)
+    g0, q0 = C.c_double(), C.c_double()
+    lib().fmo_batch_sums(C.byref(P), C.c_uint32(X.p), C.c_double(w0), _ptr(w), _ptr(v), C.byref(X.c), _ptr(y), C.c_int64(b0), C.c_int64(b1),
+                         C.byref(g0), C.byref(q0), _ptr(acc["Gw"]), _ptr(acc["Qw"]), _ptr(acc["cw"]), _ptr(acc["Gv"]), _ptr(acc["Qv"]))
+    acc["G0"] += g0.value; acc["Q0"] += q0.value
+    return acc
+
+
+def sgd_apply_sums(P, p, state, B, acc):
+    """state: dict w0 (c_double), w, v, q_w, q_v, u -- fm_oracle.c fmo_sgd_apply_sums."""
+    lib().fmo_sgd_apply_sums(C.byref(P), C.c_uint32(p), C.byref(state["w0"]), _ptr(state["w"]), _ptr(state["v"]), C.c_double(B), C.c_double(acc["G0"]),
+                             _ptr(acc["Gw"]), _ptr(acc["cw"]), _ptr(acc["Gv"]), _ptr(state["q_w"]), _ptr(state["q_v"]), _ptr(state["u"]))
+
+
+def ftrl_apply_sums(P, p, state, B, acc):
+    lib().fmo_ftrl_apply_sums(C.byref(P), C.c_uint32(p), C.byref(state["w0"]), _ptr(state["w"]), _ptr(state["v"]), C.c_double(B), C.c_double(acc["G0"]), C.c_double(acc["Q0"]),
+                              _ptr(acc["Gw"]), _ptr(acc["Qw"]), _ptr(acc["cw"]), _ptr(acc["Gv"]), _ptr(acc["Qv"]),
+                              _ptr(state["zn0"]), _ptr(state["z_w"]), _ptr(state["n_w"]), _ptr(state["z_v"]), _ptr(state["n_v"]))

@@ -52,6 +52,8 @@ typedef struct fmo_params {
   int32_t eval_type;   /* tracker metric */
   int64_t trace_step;  /* tracker.step_size, <=0: off */
   double conv_condition;
+  int32_t batch_mean;  /* engine semantics only: 1 = per-coordinate MEAN gradient, 0 = SUM */
+  int32_t pad_;
 } fmo_params;
 
 typedef struct fmo_csr {
@@ -556,12 +558,13 @@ void fmo_als_update_v(int k, uint32_t p, double* v, int64_t n, const int64_t* co
  *   SGD/L1 : theta <- penalty(theta - lr*G; u_end, q)         (u advanced by B*lr*reg first)
  *   FTRL   : n' = n + Q; z += G - theta*(sqrt(n') - sqrt(n))/alpha; theta <- prox(z, n')
  * which is the reference's example step when the batch holds one example (tests assert that).
+ * With P->batch_mean the sums are first turned into ONE pseudo-example per coordinate: G <- G/c, Q <- (G/c)^2, c <- 1
+ * (w0: c = B), i.e. one reference step with the mean gradient; identical at batch size 1.
  */
 
-typedef struct fmo_touch { double G, Q, A2; int64_t c; } fmo_touch;
-
-/* forward + per-coordinate sums over rows [b0,b1); Gw/Qw/cw over [p], Gv/Qv over [k][p]. */
-static void fmo_batch_sums(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
+/* forward + per-coordinate sums over rows [b0,b1); Gw/Qw/cw over [p], Gv/Qv over [k][p] (all accumulated INTO the
+ * arrays, which the caller zeroes).  Exported: the gloo rehearsal of the data-parallel driver shards this call. */
+void fmo_batch_sums(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
                            const fmo_csr* X, const float* y, int64_t b0, int64_t b1,
                            double* G0, double* Q0, double* Gw, double* Qw, double* cw, double* Gv, double* Qv) {
   int k = P->k;
@@ -587,12 +590,41 @@ static void fmo_batch_sums(const fmo_params* P, uint32_t p, double w0, const dou
   free(m_sum);
 }
 
+/* The update half of the mini-batch SGD step, from (possibly all-reduced) sums over B examples. */
+void fmo_sgd_apply_sums(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, double B, double G0,
+                        const double* Gw, const double* cw, const double* Gv, double* q_w, double* q_v, double* u) {
+  int l1_penalty; double regw, regv;
+  fmo_sgd_mode(P, &l1_penalty, &regw, &regv);
+  int k = P->k;
+  const double lr = P->learn_rate;
+  const int mean = P->batch_mean;
+  if (mean && B > 0.0) { G0 /= B; B = 1.0; }
+  if (l1_penalty) { u[0] += B * (lr * regw); u[1] += B * (lr * regv); }
+  if (P->k0) *w0 -= lr * (G0 + B * P->l2_reg0 * *w0);
+  for (uint32_t j = 0; j < p; ++j) {
+    if (cw[j] == 0.0) continue;
+    const double c = mean ? 1.0 : cw[j];
+    const double inv = mean ? 1.0 / cw[j] : 1.0;
+    if (P->k1) {
+      double t = w[j] - lr * (Gw[j] * inv);
+      if (l1_penalty) fmo_apply_penalty(&t, u[0], &q_w[j]);
+      else t *= pow(1.0 - lr * regw, c);
+      w[j] = t;
+    }
+    for (int f = 0; f < k; ++f) {
+      size_t at = (size_t)f * p + j;
+      double t = v[at] - lr * (Gv[at] * inv);
+      if (l1_penalty) fmo_apply_penalty(&t, u[1], &q_v[at]);
+      else t *= pow(1.0 - lr * regv, c);
+      v[at] = t;
+    }
+  }
+}
+
 /* state: q_w [p], q_v [k][p], u[2] = {u_w, u_v} (L1 mode; may be NULL otherwise). */
 void fmo_sgd_minibatch_step(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
                             const fmo_csr* X, const float* y, int64_t b0, int64_t b1,
                             double* q_w, double* q_v, double* u) {
-  int l1_penalty; double regw, regv;
-  fmo_sgd_mode(P, &l1_penalty, &regw, &regv);
   int k = P->k;
   size_t kp = (size_t)(k ? k : 1) * (p ? p : 1);
   double* Gw = (double*)calloc(p ? p : 1, sizeof(double));
@@ -602,27 +634,54 @@ void fmo_sgd_minibatch_step(const fmo_params* P, uint32_t p, double* w0, double*
   double* Qv = (double*)calloc(kp, sizeof(double));
   double G0, Q0;
   fmo_batch_sums(P, p, *w0, w, v, X, y, b0, b1, &G0, &Q0, Gw, Qw, cw, Gv, Qv);
-  const double lr = P->learn_rate;
-  const double B = (double)(b1 - b0);
-  if (l1_penalty) { u[0] += B * (lr * regw); u[1] += B * (lr * regv); }
-  if (P->k0) *w0 -= lr * (G0 + B * P->l2_reg0 * *w0);
+  fmo_sgd_apply_sums(P, p, w0, w, v, (double)(b1 - b0), G0, Gw, cw, Gv, q_w, q_v, u);
+  free(Gw); free(Qw); free(cw); free(Gv); free(Qv);
+}
+
+/* The update half of the mini-batch FTRL step, from (possibly all-reduced) sums. */
+void fmo_ftrl_apply_sums(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, double B, double G0, double Q0,
+                         const double* Gw, const double* Qw, const double* cw, const double* Gv, const double* Qv,
+                         double* zn0, double* z_w, double* n_w, double* z_v, double* n_v) {
+  int k = P->k;
+  const int mean = P->batch_mean;
+  if (mean && B > 0.0) { G0 /= B; Q0 = G0 * G0; }
+  if (P->k0) {
+    double n_new = zn0[1] + Q0;
+    zn0[0] += G0 - *w0 * (sqrt(n_new) - sqrt(zn0[1])) / P->alpha_w;
+    zn0[1] = n_new;
+  }
+  *w0 = -zn0[0] * P->alpha_w / (P->beta_w + sqrt(zn0[1]));
   for (uint32_t j = 0; j < p; ++j) {
     if (cw[j] == 0.0) continue;
+    const double inv = mean ? 1.0 / cw[j] : 1.0;
     if (P->k1) {
-      double t = w[j] - lr * Gw[j];
-      if (l1_penalty) fmo_apply_penalty(&t, u[0], &q_w[j]);
-      else t *= pow(1.0 - lr * regw, cw[j]);
-      w[j] = t;
+      const double g = Gw[j] * inv, qq = mean ? g * g : Qw[j];
+      double n_new = n_w[j] + qq;
+      z_w[j] += g - w[j] * (sqrt(n_new) - sqrt(n_w[j])) / P->alpha_w;
+      n_w[j] = n_new;
+    }
+    {
+      double z = z_w[j];
+      if (fabs(z) <= P->l1_regw) w[j] = 0.0;
+      else {
+        double sign = z < 0.0 ? -1.0 : 1.0;
+        w[j] = -(z - sign * P->l1_regw) / ((P->beta_w + sqrt(n_w[j])) / P->alpha_w + P->l2_regw);
+      }
     }
     for (int f = 0; f < k; ++f) {
       size_t at = (size_t)f * p + j;
-      double t = v[at] - lr * Gv[at];
-      if (l1_penalty) fmo_apply_penalty(&t, u[1], &q_v[at]);
-      else t *= pow(1.0 - lr * regv, cw[j]);
-      v[at] = t;
+      const double g = Gv[at] * inv, qq = mean ? g * g : Qv[at];
+      double n_new = n_v[at] + qq;
+      z_v[at] += g - v[at] * (sqrt(n_new) - sqrt(n_v[at])) / P->alpha_v;
+      n_v[at] = n_new;
+      double z = z_v[at];
+      if (fabs(z) <= P->l1_regv) v[at] = 0.0;
+      else {
+        double sign = z < 0.0 ? -1.0 : 1.0;
+        v[at] = -(z - sign * P->l1_regv) / ((P->beta_v + sqrt(n_v[at])) / P->alpha_v + P->l2_regv);
+      }
     }
   }
-  free(Gw); free(Qw); free(cw); free(Gv); free(Qv);
 }
 
 /* state: zn0[2] = {z_w0, n_w0}; z_w, n_w [p]; z_v, n_v [k][p]. */
@@ -638,40 +697,7 @@ void fmo_ftrl_minibatch_step(const fmo_params* P, uint32_t p, double* w0, double
   double* Qv = (double*)calloc(kp, sizeof(double));
   double G0, Q0;
   fmo_batch_sums(P, p, *w0, w, v, X, y, b0, b1, &G0, &Q0, Gw, Qw, cw, Gv, Qv);
-  if (P->k0) {
-    double n_new = zn0[1] + Q0;
-    zn0[0] += G0 - *w0 * (sqrt(n_new) - sqrt(zn0[1])) / P->alpha_w;
-    zn0[1] = n_new;
-  }
-  *w0 = -zn0[0] * P->alpha_w / (P->beta_w + sqrt(zn0[1]));
-  for (uint32_t j = 0; j < p; ++j) {
-    if (cw[j] == 0.0) continue;
-    if (P->k1) {
-      double n_new = n_w[j] + Qw[j];
-      z_w[j] += Gw[j] - w[j] * (sqrt(n_new) - sqrt(n_w[j])) / P->alpha_w;
-      n_w[j] = n_new;
-    }
-    {
-      double z = z_w[j];
-      if (fabs(z) <= P->l1_regw) w[j] = 0.0;
-      else {
-        double sign = z < 0.0 ? -1.0 : 1.0;
-        w[j] = -(z - sign * P->l1_regw) / ((P->beta_w + sqrt(n_w[j])) / P->alpha_w + P->l2_regw);
-      }
-    }
-    for (int f = 0; f < k; ++f) {
-      size_t at = (size_t)f * p + j;
-      double n_new = n_v[at] + Qv[at];
-      z_v[at] += Gv[at] - v[at] * (sqrt(n_new) - sqrt(n_v[at])) / P->alpha_v;
-      n_v[at] = n_new;
-      double z = z_v[at];
-      if (fabs(z) <= P->l1_regv) v[at] = 0.0;
-      else {
-        double sign = z < 0.0 ? -1.0 : 1.0;
-        v[at] = -(z - sign * P->l1_regv) / ((P->beta_v + sqrt(n_v[at])) / P->alpha_v + P->l2_regv);
-      }
-    }
-  }
+  fmo_ftrl_apply_sums(P, p, w0, w, v, (double)(b1 - b0), G0, Q0, Gw, Qw, cw, Gv, Qv, zn0, z_w, n_w, z_v, n_v);
   free(Gw); free(Qw); free(cw); free(Gv); free(Qv);
 }
 

@@ -1,0 +1,90 @@
+"""Rehearsal of the N > 1 path on ONE GPU: two ranks share device 0 and exchange through gloo (RCCL needs one GPU per
+rank; the driver runs the real N = 2/4/8 RCCL bench on an 8-GPU node).  Checks that bench.py's multi-rank path runs and
+that two data-parallel replicas reproduce the single-process result on the same global batches."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from fmwr_amd import _lib as L, engine
+from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+n, p, z, k, B = 40000, 5000, 10, 16, 4000
+r0, r1 = shard_rows(n, rank, world)
+m = engine.Matrix.synthetic(r1 - r0, p, z, 7, row_offset=r0, device=0)
+kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD if sys.argv[2] == "sgd" else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05,
+          l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if sys.argv[2] == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B // world)
+e = engine.Engine(p, **kw)
+v0 = np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+e.set_params(0.0, None, v0)
+dp = DataParallel(EngineStepper(e, m, 0))
+for s in range(8):
+    dp.step(s % e.num_batches(m))
+e.sync()
+w0, w, v = e.get_params()
+if rank == 0:
+    np.savez(sys.argv[3], w0=w0, w=w, v=v)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("solver", ["sgd", "ftrl"])
+def test_two_replicas_match_single_process(tmp_path, solver):
+    from fmwr_amd import _lib as L, engine
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "dp.npz"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", str(script), ROOT, solver, str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    # single process: the same global batches = union of the two ranks' local batches
+    n, p, z, k, B = 40000, 5000, 10, 16, 4000
+    halves = [engine.Matrix.synthetic(n // 2, p, z, 7, row_offset=r * (n // 2)) for r in range(2)]
+    rows = [hm.export() for hm in halves]
+    nb = (n // 2) // (B // 2)
+    # interleave: global batch b = rank0 batch b ++ rank1 batch b
+    rp = [0]; col = []; val = []; y = []
+    for b in range(nb):
+        for (rpi, ci, vi, yi) in rows:
+            a, c = b * (B // 2), (b + 1) * (B // 2)
+            col.append(ci[rpi[a]:rpi[c]]); val.append(vi[rpi[a]:rpi[c]]); y.append(yi[a:c])
+            rp.extend((rpi[a + 1:c + 1] - rpi[a] + rp[-1]).tolist())
+    m = engine.Matrix.from_csr(np.array(rp, np.int64), np.concatenate(col), np.concatenate(val), p, np.concatenate(y))
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD if solver == "sgd" else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05,
+              l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B)
+    e = engine.Engine(p, **kw)
+    e.set_params(0.0, None, np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64))
+    for s in range(8):
+        e.step(m, s % nb)
+    e.sync()
+    w0, w, v = e.get_params()
+    scale = np.max(np.abs(v))
+    assert np.max(np.abs(got["v"] - v)) < 1e-5 * scale
+    assert np.max(np.abs(got["w"] - w)) < 1e-5 * max(np.max(np.abs(w)), 1e-3)
+    assert abs(float(got["w0"]) - w0) < 1e-5 * max(1.0, abs(w0))
+
+
+def test_bench_multirank_path_runs(tmp_path):
+    env = dict(os.environ, FMX_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29518", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rows", "400000", "--features", "50000", "--batch-rows", "32768", "--backend", "gloo", "--cpu-rows", "0"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch_rows"] == 65536

@@ -24,7 +24,7 @@ def fm():
 
 def _engine(fm, p, P, solver, mode, batch_rows=64):
     engine, L = fm
-    return engine.Engine(p, task=P.task, solver=solver, num_factor=P.k, keep_w0=P.k0, keep_w1=P.k1, l2_w0=P.l2_reg0,
+    return engine.Engine(p, batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM, task=P.task, solver=solver, num_factor=P.k, keep_w0=P.k0, keep_w1=P.k1, l2_w0=P.l2_reg0,
                          l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv, l2_v=P.l2_regv, learn_rate=P.learn_rate,
                          alpha_w=P.alpha_w, alpha_v=P.alpha_v, beta_w=P.beta_w, beta_v=P.beta_v, random_step=P.random_step,
                          mode=mode, batch_rows=batch_rows, min_target=P.min_target, max_target=P.max_target)
@@ -151,12 +151,14 @@ def test_sequential_unsorted_rows_with_duplicates(fm):
 
 @pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
 @pytest.mark.parametrize("batch", [1, 64, 257])
-def test_minibatch_matches_oracle(fm, c, batch):
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_minibatch_matches_oracle(fm, c, batch, reduce):
     engine, L = fm
     if batch == 1 and c["name"] not in ("sgd_l2_cls", "ftrl_l1l2_cls"):
         pytest.skip("batch 1 covered on two cases")
     n = 300 if batch == 1 else 1200
     rp, col, val, y, P, seed = _problem(c, n=n)
+    P.batch_mean = int(reduce == "mean")
     p = 300
     w0, w, v = util.params(p, P.k, seed, fp32=True)
     X = oracle.Matrix(rp, col, val, p)

@@ -44,10 +44,12 @@ def test_minibatch_semantics_reduce_to_reference_step():
     ]
     for P, learn, MB in cases:
         ref = learn(P, X, y, w0, w, v.ravel(), n, order=np.arange(n))
-        mb = MB(P, X, y, w0, w, v.ravel())
-        for i in range(n):
-            mb.step(i, i + 1)
-        assert util.rel_err(mb.v, ref["v"]) < 1e-13 and util.rel_err(mb.w, ref["w"]) < 1e-13 and abs(mb.w0.value - ref["w0"]) < 1e-13
+        for mean in (0, 1):  # both batch reductions are the reference step at batch size 1
+            P.batch_mean = mean
+            mb = MB(P, X, y, w0, w, v.ravel())
+            for i in range(n):
+                mb.step(i, i + 1)
+            assert util.rel_err(mb.v, ref["v"]) < 1e-13 and util.rel_err(mb.w, ref["w"]) < 1e-13 and abs(mb.w0.value - ref["w0"]) < 1e-13
 
 
 def test_als_update_v_decreases_squared_error():
