@@ -248,6 +248,7 @@ struct ColsTables {
   const double* scal;
   float* gbuf;
   uint32_t p;
+  int has_q;  // exchange buffer carries the sum-of-squares planes (FTRL with FMX_REDUCE_SUM only)
 };
 
 // solver/SGD_Learner.h:195-204
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   for (int i = 0; i < VEC; ++i) { G[i] = 0.0; Q[i] = 0.0; }
   double Gw = 0.0, Qw = 0.0, cnt = 0.0;
 
-  // exchange buffer planes: GV [p][KP] | GW [p] | CNT [p] | (FTRL) QV [p][KP] | QW [p] | tail[4]
+  // exchange buffer planes: GV [p][KP] | GW [p] | CNT [p] | (has_q: QV [p][KP] | QW [p]) | tail[4]
   float* gGV = T.gbuf;
   float* gGW = T.gbuf ? T.gbuf + (size_t)T.p * KP : nullptr;
   float* gCN = T.gbuf ? gGW + T.p : nullptr;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
     slice_get(g4, G);
     Gw = gGW[j];
     cnt = gCN[j];
-    if (NEED_Q) {
+    if (NEED_Q && T.has_q) {
       float4 q4 = *reinterpret_cast<const float4*>(gQV + (size_t)j * KP + lig * VEC);
       slice_get(q4, Q);
       Qw = gQW[j];
@@ -392,11 +393,11 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
 
   if (a.phase == 1) {  // accumulate-only: publish the local sums (every feature, zeros included)
     *reinterpret_cast<float4*>(gGV + (size_t)j * KP + lig * VEC) = make_float4((float)G[0], (float)G[1], (float)G[2], (float)G[3]);
-    if (NEED_Q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)Q[0], (float)Q[1], (float)Q[2], (float)Q[3]);
+    if (NEED_Q && T.has_q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)Q[0], (float)Q[1], (float)Q[2], (float)Q[3]);
     if (lig == 0) {
       gGW[j] = (float)Gw;
       gCN[j] = (float)cnt;
-      if (NEED_Q) gQW[j] = (float)Qw;
+      if (NEED_Q && T.has_q) gQW[j] = (float)Qw;
     }
     return;
   }
@@ -412,8 +413,12 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
 
   double decay_v = 1.0, decay_w = 1.0, u_w = 0.0, u_v = 0.0;
   if constexpr (KIND == UPD_SGD_L2) {
-    if (h.regv != 0.0) decay_v = pow(1.0 - h.lr * h.regv, cnt);
-    if (h.regw != 0.0) decay_w = pow(1.0 - h.lr * h.regw, cnt);
+    // (1 - lr*reg)^cnt; cnt == 1 always under FMX_REDUCE_MEAN, so the transcendental is off the common path
+    if (cnt == 1.0) { decay_v = h.decay_v; decay_w = h.decay_w; }
+    else {
+      decay_v = h.decay_v > 0.0 ? exp(cnt * h.log_decay_v) : pow(h.decay_v, cnt);
+      decay_w = h.decay_w > 0.0 ? exp(cnt * h.log_decay_w) : pow(h.decay_w, cnt);
+    }
   }
   if constexpr (KIND == UPD_SGD_L1) { u_w = T.scal[SC_UW]; u_v = T.scal[SC_UV]; }
 
@@ -465,7 +470,8 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const ColsTables& 
 }
 
 int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
-  ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->gbuf, (uint32_t)e->p};
+  ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->gbuf, (uint32_t)e->p,
+               (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0};
   FMX_CHECK(a.phase == 0 || e->gbuf != nullptr, FMX_ERR_STATE, "exchange buffer not allocated");
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;

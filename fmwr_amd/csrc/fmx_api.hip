@@ -96,6 +96,10 @@ static int make_hyper(const fmx_config& c, Hyper* h) {
     if (c.task != FMX_TASK_CLASSIFICATION) l1 = false;  // SGD_Learner.h:57-59 (the L1 rates then act as L2, SURVEY A-9)
     h->kind = l1 ? UPD_SGD_L1 : UPD_SGD_L2;
   }
+  h->decay_w = 1.0 - h->lr * h->regw;
+  h->decay_v = 1.0 - h->lr * h->regv;
+  h->log_decay_w = h->decay_w > 0 ? std::log(h->decay_w) : 0.0;
+  h->log_decay_v = h->decay_v > 0 ? std::log(h->decay_v) : 0.0;
   return FMX_OK;
 }
 
@@ -134,12 +138,11 @@ static int ensure_workspace(fmx_engine* e, int64_t rows) {
 
 static int ensure_gbuf(fmx_engine* e) {
   if (e->gbuf) return FMX_OK;
-  const int64_t planes = (e->hyper.kind == UPD_FTRL) ? 2 : 1;
-  // GV [p][kp] | GW [p] | CNT [p] | (FTRL) QV [p][kp] | QW [p] | tail[4]; the FTRL planes are always reserved
-  // behind CNT so the layout does not depend on the solver
-  (void)planes;
-  e->gbuf_floats = (int64_t)e->p * e->kp32 * 2 + (int64_t)e->p * 3 + 4;
+  // GV [p][kp] | GW [p] | CNT [p] | (QV [p][kp] | QW [p]: only FTRL with FMX_REDUCE_SUM needs sum(g^2)) | tail[4]
+  const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
+  e->gbuf_floats = (int64_t)e->p * e->kp32 * (has_q ? 2 : 1) + (int64_t)e->p * (has_q ? 3 : 2) + 4;
   FMX_TRY(dev_alloc_zero(&e->gbuf, (size_t)e->gbuf_floats));
+  FMX_HIP(hipDeviceSynchronize());
   return FMX_OK;
 }
 

@@ -53,6 +53,8 @@ struct Hyper {
   double l1w, l1v, l2w, l2v;    // FTRL prox
   double alpha_w, alpha_v, beta_w, beta_v;
   double min_t, max_t;
+  double decay_w, decay_v;          // 1 - lr*reg (SGD lazy L2, one touch)
+  double log_decay_w, log_decay_v;  // log of the above, for c touches: exp(c * log)
 };
 
 // device scalars (double[SC_COUNT]) living next to the parameters

@@ -17,16 +17,17 @@ def shard_rows(n_total, rank, world):
 
 class GradLayout:
     """Element offsets (fp32) inside the exchange buffer, mirroring fm_batch_kernels.hip:
-    GV [p][kp] | GW [p] | CNT [p] | QV [p][kp] | QW [p] | tail = [G0, Q0, rows, 0]."""
+    GV [p][kp] | GW [p] | CNT [p] | (has_q: QV [p][kp] | QW [p]) | tail = [G0, Q0, rows, 0].
+    has_q: only FTRL with FMX_REDUCE_SUM exchanges the sums of squared gradients."""
 
-    def __init__(self, p, kp):
-        self.p, self.kp = p, kp
+    def __init__(self, p, kp, has_q=False):
+        self.p, self.kp, self.has_q = p, kp, has_q
         self.gv = 0
         self.gw = p * kp
         self.cnt = self.gw + p
         self.qv = self.cnt + p
-        self.qw = self.qv + p * kp
-        self.tail = self.qw + p
+        self.qw = self.qv + (p * kp if has_q else 0)
+        self.tail = self.qw + (p if has_q else 0)
         self.size = self.tail + 4
 
 

@@ -51,7 +51,7 @@ class OracleStepper:
         self.X = oracle.Matrix(rp, col, val, P_FEAT)
         self.y = y
         self.st = _state(solver, w0, w, v)
-        self.lay = GradLayout(P_FEAT, K)
+        self.lay = GradLayout(P_FEAT, K, has_q=(solver == "ftrl"))  # this test runs FTRL with SUM, SGD with MEAN
         self.buf = torch.zeros(self.lay.size, dtype=torch.float32)
 
     def grad(self, batch, rows_limit=0):
@@ -61,7 +61,8 @@ class OracleStepper:
         L, b = self.lay, self.buf.numpy()
         b[L.gv:L.gw] = acc["Gv"].reshape(K, P_FEAT).T.ravel()   # [p][kp] feature-major, as the kernels store it
         b[L.gw:L.cnt] = acc["Gw"]; b[L.cnt:L.qv] = acc["cw"]
-        b[L.qv:L.qw] = acc["Qv"].reshape(K, P_FEAT).T.ravel(); b[L.qw:L.tail] = acc["Qw"]
+        if L.has_q:
+            b[L.qv:L.qw] = acc["Qv"].reshape(K, P_FEAT).T.ravel(); b[L.qw:L.tail] = acc["Qw"]
         b[L.tail:L.tail + 4] = [acc["G0"], acc["Q0"], b1 - b0, 0.0]
 
     def buffer(self):
@@ -72,8 +73,10 @@ class OracleStepper:
 
     def apply(self):
         L, b = self.lay, self.buf.numpy().astype(np.float64)
-        acc = dict(G0=b[L.tail], Q0=b[L.tail + 1], Gw=b[L.gw:L.cnt].copy(), cw=b[L.cnt:L.qv].copy(), Qw=b[L.qw:L.tail].copy(),
-                   Gv=b[L.gv:L.gw].reshape(P_FEAT, K).T.ravel().copy(), Qv=b[L.qv:L.qw].reshape(P_FEAT, K).T.ravel().copy())
+        acc = dict(G0=b[L.tail], Q0=b[L.tail + 1], Gw=b[L.gw:L.cnt].copy(), cw=b[L.cnt:L.qv].copy(),
+                   Gv=b[L.gv:L.gw].reshape(P_FEAT, K).T.ravel().copy())
+        acc["Qw"] = b[L.qw:L.tail].copy() if L.has_q else np.zeros(P_FEAT)
+        acc["Qv"] = b[L.qv:L.qw].reshape(P_FEAT, K).T.ravel().copy() if L.has_q else np.zeros(K * P_FEAT)
         if self.solver == "sgd":
             oracle.sgd_apply_sums(self.P, P_FEAT, self.st, b[L.tail + 2], acc)
         else:

@@ -1,0 +1,133 @@
+"""Properties at BASELINE.json's full size (10M x 1M, 30 nnz/row, k=16) that need no CPU pass over the whole matrix,
+plus the synthetic generator against an independent numpy Philox4x32-10."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, P, Z, K, SEED, B = 10_000_000, 1_000_000, 30, 16, 20240001, 262_144
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    c0, c1, c2, c3 = (np.asarray(x, np.uint64) for x in (c0, c1, c2, c3))
+    k0 = np.uint64(k0); k1 = np.uint64(k1)
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M
+        n1 = p1 & M
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M
+        n3 = p0 & M
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    return c0, c1, c2, c3
+
+
+def numpy_synthetic(n, p, z, seed, row_offset):
+    g = np.arange(row_offset, row_offset + n, dtype=np.uint64)
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    col = np.zeros((n, z), np.uint32)
+    for blk in range((z + 3) // 4):
+        words = philox4x32_10(g & np.uint64(0xFFFFFFFF), g >> np.uint64(32), np.full(n, blk, np.uint64), np.zeros(n, np.uint64), k0, k1)
+        for j in range(4):
+            i = blk * 4 + j
+            if i >= z:
+                break
+            lo, hi = (i * p) // z, ((i + 1) * p) // z
+            col[:, i] = lo + ((words[j] * np.uint64(hi - lo)) >> np.uint64(32)).astype(np.uint32)
+    lab = philox4x32_10(g & np.uint64(0xFFFFFFFF), g >> np.uint64(32), np.full(n, 0xFFFFFFFF, np.uint64), np.zeros(n, np.uint64), k0, k1)[0]
+    y = np.where(lab & np.uint64(1), 1.0, -1.0).astype(np.float32)
+    return col, y
+
+
+@pytest.fixture(scope="module")
+def fm():
+    from fmwr_amd import engine, _lib
+    return engine, _lib
+
+
+@pytest.fixture(scope="module")
+def big(fm):
+    engine, L = fm
+    return engine.Matrix.synthetic(N, P, Z, SEED)
+
+
+def test_generator_matches_numpy_philox(fm):
+    engine, L = fm
+    for (n, p, z, off) in [(5000, 1000, 7, 0), (3000, 1_000_000, 30, 9_999_000), (100, 64, 64, 2 ** 33)]:
+        m = engine.Matrix.synthetic(n, p, z, SEED, row_offset=off)
+        rp, col, val, y = m.export()
+        ecol, ey = numpy_synthetic(n, p, z, SEED, off)
+        np.testing.assert_array_equal(rp, np.arange(n + 1) * z)
+        np.testing.assert_array_equal(col.reshape(n, z), ecol)
+        np.testing.assert_array_equal(y, ey)
+        assert np.all(val == 1.0) and np.all(np.diff(col.reshape(n, z).astype(np.int64), axis=1) > 0)
+    # shard independence: rows [a, b) of the stream are the same whoever generates them
+    whole = engine.Matrix.synthetic(4000, 5000, 9, 5).export()
+    part = engine.Matrix.synthetic(1000, 5000, 9, 5, row_offset=3000).export()
+    np.testing.assert_array_equal(whole[1][3000 * 9:], part[1])
+    np.testing.assert_array_equal(whole[3][3000:], part[3])
+
+
+def test_full_size_forward_closed_form(fm, big):
+    """Every row holds exactly Z distinct features with x = 1: with w = c and every V row = a,
+    y_hat = w0 + Z*c + 0.5*(Z*Z - Z)*sum(a^2) for all 10M rows."""
+    engine, L = fm
+    e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH)
+    a = (np.arange(1, K + 1) / 64.0)
+    e.set_params(0.25, np.full(P, 0.5), np.repeat(a[:, None], P, axis=1))
+    out = e.predict(big)
+    want = 0.25 + Z * 0.5 + 0.5 * (Z * Z - Z) * np.sum(a * a)
+    assert out.shape == (N,)
+    np.testing.assert_allclose(out, want, rtol=1e-13)
+    # geometry independence: a slab predicted on its own is bitwise the same
+    import ctypes as C
+    sub = engine.Matrix.synthetic(50_000, P, Z, SEED, row_offset=7_000_000)
+    np.testing.assert_array_equal(e.predict(sub), out[7_000_000:7_050_000])
+
+
+def test_full_size_first_step_against_host_counts(fm, big):
+    """From w = 0, V = 0 every example has y_hat = 0, mult = -y/2.  One SUM-mode step therefore gives
+    w0 = lr/2 * sum(y) and w_j = lr/2 * sum of the labels of the batch rows holding j: checks the w0 reduction and the
+    per-batch CSC at full size against a host bincount on the exported batch."""
+    engine, L = fm
+    lr = 0.125
+    e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH, batch_rows=B, batch_reduce=L.REDUCE_SUM, learn_rate=lr)
+    nb = e.num_batches(big)
+    assert nb == -(-N // B)
+    for batch in (0, nb - 1):  # a full batch and the ragged last one
+        e.set_params(0.0, None, None)
+        e.step(big, batch)
+        e.sync()
+        w0, w, v = e.get_params()
+        r0 = batch * B
+        rp, col, val, y = big.export(r0, min(r0 + B, N))
+        assert w0 == lr * 0.5 * float(np.sum(y.astype(np.float64)))
+        want = lr * 0.5 * np.bincount(col, weights=np.repeat(y.astype(np.float64), Z), minlength=P)
+        np.testing.assert_allclose(w, want, rtol=0, atol=1e-6)
+        assert np.all(v == 0.0)  # s_f = 0 and v = 0: the pairwise gradient vanishes
+
+
+def test_full_size_training_is_reproducible_and_lr0_is_identity(fm, big):
+    engine, L = fm
+    v0 = np.random.default_rng(3).normal(0, 0.01, (K, P)).astype(np.float32).astype(np.float64)
+    res = []
+    for _ in range(2):
+        e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH, batch_rows=B, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4)
+        e.set_params(0.0, None, v0)
+        for b in range(6):
+            e.step(big, b)
+        e.sync()
+        res.append(e.get_params())
+    assert res[0][0] == res[1][0]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    assert np.all(np.isfinite(res[0][2])) and np.any(res[0][2] != v0)
+    e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH, batch_rows=B, learn_rate=0.0)
+    e.set_params(0.5, None, v0)
+    e.step(big, 1)
+    e.sync()
+    w0, w, v = e.get_params()
+    assert w0 == 0.5 and np.all(w == 0) and np.array_equal(v, v0)
