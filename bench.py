@@ -53,6 +53,26 @@ def algorithmic_bytes(z, k, p, rows):
     return rows_fwd, cols_upd, survey_step
 
 
+def pmc_traffic(kernel, args):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r*_pmc_summary.json,
+    made by profiles/pmc_run.sh with the SAME workload arguments), or None.  bench.py cannot run rocprofv3 on itself."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        a = d.get("_bench_args", [])
+        def opt(name, default):
+            return int(a[a.index(name) + 1]) if name in a else default
+        same = (opt("--batch-rows", 262_144) == args.batch_rows and opt("--factors", 16) == args.factors and opt("--features", 1_000_000) == args.features
+                and opt("--rows", 10_000_000) == args.rows and opt("--nnz", 30) == args.nnz and ("ftrl" in a) == (args.solver == "ftrl"))
+        if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
+            best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
 def cpu_baseline(m, args, v0):
     """Oracle (reference-order serial SGD, one core) on the first cpu_rows rows of the same matrix."""
     import oracle
@@ -132,13 +152,13 @@ def main():
         one_step(i)
     fence()
     e.profile_reset()
-    e.profile(True)
+    e.profile(4)  # HIP events around every 4th launch of each kernel, on the engine's stream, inside the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    e.profile(False)
+    e.profile(0)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,6 +181,7 @@ def main():
         dom = max(kernels, key=lambda name: kernels[name][1])
         dbytes, dms = kernels[dom]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        traffic = pmc_traffic(dom, args) if world == 1 else None
         out = {
             "metric": "training examples/sec, 10Mx1M sparse FM SGD", "value": value, "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -170,7 +191,9 @@ def main():
                        "batch_rows_per_gpu": B, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
                        "state": "fp32 V[p][k] + w[p], fp64 accumulation", "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_source": (f"profiles/{traffic[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB per launch, separate --pmc passes; "
+                                            "upper bound, see DESIGN.md section 6") if traffic else None,
                          "algorithmic_bytes_per_launch": dbytes, "avg_launch_ms": dms,
                          "kernels_ms": {name: kv[1] for name, kv in kernels.items()},
                          "step_algorithmic_GBps": b_step / (dt / args.steps) / 1e9 / world},

@@ -16,7 +16,7 @@ SOURCES = ["fmx_api.hip", "fm_batch_kernels.hip", "fm_seq_kernels.hip", "fm_inge
 HEADERS = [os.path.join(CSRC, "fmx_internal.h"), os.path.join(PKG, "..", "include", "fmx.h")]
 # -ffp-contract=off: the fp64 update formulas keep the reference's operation order (no FMA fusion)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result", "-Wno-deprecated-declarations"]
+         "-Wno-unused-result", "-Wno-deprecated-declarations"] + os.environ.get("FMX_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

@@ -18,7 +18,13 @@
 // back to back.  Accumulation is fp64 in registers (the kernels are HBM/fabric bound; VALU is idle), in
 // list order, which makes every result independent of launch geometry and bitwise reproducible.
 // No MFMA: this is a sparse gather-reduce, not a dense contraction.
+#include <utility>
+
 #include "fmx_internal.h"
+
+#ifndef FMX_U
+#define FMX_U 4  // row gathers kept in flight per lane
+#endif
 
 namespace fmx {
 
@@ -94,21 +100,21 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
     __syncthreads();
     const int64_t b = ta > c0 ? ta : c0;
     const int64_t e = tb < c0 + cnt ? tb : c0 + cnt;
-    for (int64_t t = b; t < e; t += 4) {
+    for (int64_t t = b; t < e; t += FMX_U) {
       const int o = (int)(t - c0);
-      uint2 en[4];
+      uint2 en[FMX_U];
       en[0] = stage[o];
 #pragma unroll
-      for (int u = 1; u < 4; ++u) en[u] = (t + u < e) ? stage[o + u] : make_uint2(en[0].x, 0u);  // x = +0.0f pads
-      vec_t vv[4];
-      T wv[4];
+      for (int u = 1; u < FMX_U; ++u) en[u] = (t + u < e) ? stage[o + u] : make_uint2(en[0].x, 0u);  // x = +0.0f pads
+      vec_t vv[FMX_U];
+      T wv[FMX_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < FMX_U; ++u) {
         vv[u] = *reinterpret_cast<const vec_t*>(Vt + (size_t)en[u].x * KP);
         wv[u] = k1 ? wt[en[u].x] : (T)0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {  // nonzeros in row order: same association as core/Model.h:83-97
+      for (int u = 0; u < FMX_U; ++u) {  // nonzeros in row order: same association as core/Model.h:83-97
         const double x = (double)__uint_as_float(en[u].y);
         lin += (double)wv[u] * x;
         double vf[VEC];
@@ -189,10 +195,13 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_
 }
 
 // ------------------------------------------------------------------------------------------------ scalar
-// phase: 0 fused (reduce + update), 1 reduce only -> exchange buffer tail, 2 update from exchange buffer tail
-__global__ __launch_bounds__(WG_THREADS) void fm_scalar_update_k(const double* __restrict__ partials, int64_t n_partials,
-                                                                 double* scal, float* gtail, Hyper h, double rows, int phase) {
-  __shared__ double sg[WG_THREADS], sq[WG_THREADS];
+// Runs in workgroup 0 of fm_cols_update_k: deterministic reduction of phase 1's per-workgroup partial sums and the w0
+// step (SGD_Learner.h:106-109; FTRL_Learner.h:80-86,161).  Scalars are double-buffered: every kernel of a step reads
+// `sin` (the step's start state) and only this function writes `sout`; the host flips the two after the launch.
+// phase: 0 fused (reduce + update), 1 reduce only -> exchange-buffer tail, 2 update from the (all-reduced) tail.
+__device__ __forceinline__ void scalar_update(const double* __restrict__ partials, int64_t n_partials, const double* sin,
+                                              double* sout, float* gtail, const Hyper& h, double rows, int phase,
+                                              double* sg, double* sq) {
   double g0 = 0.0, q0 = 0.0;
   if (phase != 2) {
     for (int64_t i = threadIdx.x; i < n_partials; i += WG_THREADS) { g0 += partials[2 * i]; q0 += partials[2 * i + 1]; }
@@ -207,37 +216,30 @@ __global__ __launch_bounds__(WG_THREADS) void fm_scalar_update_k(const double* _
   g0 = sg[0]; q0 = sq[0];
   if (phase == 1) { gtail[0] = (float)g0; gtail[1] = (float)q0; gtail[2] = (float)rows; gtail[3] = 0.f; return; }
   if (phase == 2) { g0 = gtail[0]; q0 = gtail[1]; if (rows <= 0.0) rows = gtail[2]; }
-  scal[SC_G0] = g0; scal[SC_Q0] = q0;
+  for (int i = 0; i < SC_COUNT; ++i) sout[i] = sin[i];
+  sout[SC_G0] = g0; sout[SC_Q0] = q0;
   if (h.mean && rows > 0.0) {  // FMX_REDUCE_MEAN: w0 occurs in every example -> one step with the batch-mean multiplier
     g0 /= rows;
     q0 = g0 * g0;
     rows = 1.0;
   }
-  double w0 = scal[SC_W0];
+  const double w0 = sin[SC_W0];
   if (h.kind == UPD_FTRL) {
+    double z0 = sin[SC_Z0], n0 = sin[SC_N0];
     if (h.k0) {  // solver/FTRL_Learner.h:80-86 with the batch sums G0, Q0
-      const double n_old = scal[SC_N0], n_new = n_old + q0;
-      scal[SC_Z0] += g0 - w0 * (sqrt(n_new) - sqrt(n_old)) / h.alpha_w;
-      scal[SC_N0] = n_new;
+      const double n_new = n0 + q0;
+      z0 += g0 - w0 * (sqrt(n_new) - sqrt(n0)) / h.alpha_w;
+      n0 = n_new;
     }
-    scal[SC_W0] = -scal[SC_Z0] * h.alpha_w / (h.beta_w + sqrt(scal[SC_N0]));  // FTRL_Learner.h:161
+    sout[SC_Z0] = z0; sout[SC_N0] = n0;
+    sout[SC_W0] = -z0 * h.alpha_w / (h.beta_w + sqrt(n0));  // FTRL_Learner.h:161
   } else {
     if (h.kind == UPD_SGD_L1) {  // solver/SGD_Learner.h:92-97, once per example (SUM) or once per batch (MEAN)
-      scal[SC_UW] += rows * (h.lr * h.regw);
-      scal[SC_UV] += rows * (h.lr * h.regv);
+      sout[SC_UW] = sin[SC_UW] + rows * (h.lr * h.regw);
+      sout[SC_UV] = sin[SC_UV] + rows * (h.lr * h.regv);
     }
-    if (h.k0) scal[SC_W0] = w0 - h.lr * (g0 + rows * h.reg0 * w0);  // SGD_Learner.h:106-109
+    if (h.k0) sout[SC_W0] = w0 - h.lr * (g0 + rows * h.reg0 * w0);  // SGD_Learner.h:106-109
   }
-}
-
-int launch_scalar_update(fmx_engine* e, int64_t n_partials, double batch_rows, int phase) {
-  prof_begin(e, FMX_KERNEL_SCALAR);
-  float* tail = e->gbuf ? e->gbuf + (e->gbuf_floats - 4) : nullptr;
-  hipLaunchKernelGGL(fm_scalar_update_k, dim3(1), dim3(WG_THREADS), 0, e->stream, e->partials, n_partials, e->scal, tail,
-                     e->hyper, batch_rows, phase);
-  prof_end(e);
-  FMX_HIP(hipGetLastError());
-  return FMX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ phase 2
@@ -245,7 +247,10 @@ struct ColsTables {
   float *V, *w, *sV, *sw, *nV, *nw;
   const float* S;
   const float* amul;
-  const double* scal;
+  const double* scal;   // this step's start scalars (read-only during the step)
+  double* scal_out;     // next step's scalars (written by workgroup 0)
+  const double* partials;
+  int64_t n_partials;
   float* gbuf;
   uint32_t p;
   int has_q;  // exchange buffer carries the sum-of-squares planes (FTRL with FMX_REDUCE_SUM only)
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   constexpr int FPW = WG_THREADS / LPR;  // features (lists) per workgroup
   constexpr bool NEED_Q = (KIND == UPD_FTRL);
   __shared__ uint2 stage[STAGE_ENTRIES];
+  __shared__ double red_g[WG_THREADS], red_q[WG_THREADS];
 
   const int tid = threadIdx.x;
   const int gid = tid / LPR;
@@ -341,25 +347,25 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       __syncthreads();
       const int64_t b = ta > c0 ? ta : c0;
       const int64_t e = tb < c0 + cn ? tb : c0 + cn;
-      for (int64_t t = b; t < e; t += 4) {
+      for (int64_t t = b; t < e; t += FMX_U) {
         const int o = (int)(t - c0);
-        uint2 en[4];
-        bool ok[4];
+        uint2 en[FMX_U];
+        bool ok[FMX_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FMX_U; ++u) {
           en[u] = (t + u < e) ? stage[o + u] : make_uint2(0xFFFFFFFFu, 0u);
           ok[u] = en[u].x < a.rows_active;  // truncated batch: rows beyond the limit do not take part
           if (!ok[u]) en[u].x = 0;
         }
-        float4 sv[4];
-        float av[4];
+        float4 sv[FMX_U];
+        float av[FMX_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FMX_U; ++u) {
           sv[u] = *reinterpret_cast<const float4*>(St + (size_t)en[u].x * KP);
           av[u] = T.amul[en[u].x];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // occurrences in row order
+        for (int u = 0; u < FMX_U; ++u) {  // occurrences in row order
           if (!ok[u]) continue;
           const double x = (double)__uint_as_float(en[u].y);
           const double ax = (double)av[u] * x;  // mult * x: the w gradient, SGD_Learner.h:114
@@ -389,9 +395,11 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       Qw = gQW[j];
     }
   }
-  if (!have) return;
+  float* gtail = T.gbuf ? (T.has_q ? gQW + T.p : gCN + T.p) : nullptr;  // the Q planes exist only with has_q
+  double rows = a.global_rows;
+  if (a.phase == 2 && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
 
-  if (a.phase == 1) {  // accumulate-only: publish the local sums (every feature, zeros included)
+  if (have && a.phase == 1) {  // accumulate-only: publish the local sums (every feature, zeros included)
     *reinterpret_cast<float4*>(gGV + (size_t)j * KP + lig * VEC) = make_float4((float)G[0], (float)G[1], (float)G[2], (float)G[3]);
     if (NEED_Q && T.has_q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)Q[0], (float)Q[1], (float)Q[2], (float)Q[3]);
     if (lig == 0) {
@@ -399,10 +407,10 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       gCN[j] = (float)cnt;
       if (NEED_Q && T.has_q) gQW[j] = (float)Qw;
     }
-    return;
   }
 
-  if (cnt == 0.0) return;  // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
+  // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
+  if (have && a.phase != 1 && cnt != 0.0) {
   if (h.mean) {  // FMX_REDUCE_MEAN: one reference step with the mean gradient of the coordinate's occurrences
     const double inv = 1.0 / cnt;
 #pragma unroll
@@ -420,7 +428,11 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       decay_w = h.decay_w > 0.0 ? exp(cnt * h.log_decay_w) : pow(h.decay_w, cnt);
     }
   }
-  if constexpr (KIND == UPD_SGD_L1) { u_w = T.scal[SC_UW]; u_v = T.scal[SC_UV]; }
+  if constexpr (KIND == UPD_SGD_L1) {  // the penalty level after this batch (same expression as scalar_update)
+    const double r = h.mean ? 1.0 : rows;
+    u_w = T.scal[SC_UW] + r * (h.lr * h.regw);
+    u_v = T.scal[SC_UV] + r * (h.lr * h.regv);
+  }
 
   float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
   if constexpr (KIND != UPD_SGD_L2) sa = *reinterpret_cast<const float4*>(T.sV + (size_t)j * KP + lig * VEC);
@@ -447,6 +459,10 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
     }
   }
+  }  // touched coordinate
+
+  if (blockIdx.x == 0)
+    scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.phase, red_g, red_q);
 }
 
 template <int KIND>
@@ -470,8 +486,8 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const ColsTables& 
 }
 
 int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
-  ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->gbuf, (uint32_t)e->p,
-               (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0};
+  ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->scal_next, e->partials, a.n_partials,
+               e->gbuf, (uint32_t)e->p, (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0};
   FMX_CHECK(a.phase == 0 || e->gbuf != nullptr, FMX_ERR_STATE, "exchange buffer not allocated");
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
@@ -481,6 +497,7 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
     default: st = launch_cols_kind<UPD_FTRL>(e, a, T); break;
   }
   prof_end(e);
+  if (st == FMX_OK && a.phase != 1) std::swap(e->scal, e->scal_next);  // the kernel wrote the next step's scalars
   return st;
 }
 

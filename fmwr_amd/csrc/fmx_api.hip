@@ -23,15 +23,19 @@ void set_error(const char* fmt, ...) {
 }
 
 void prof_begin(fmx_engine* e, int kernel) {
+  e->prof_open = 0;
   if (!e->profile) return;
+  if ((e->prof_seen[kernel]++ % e->profile) != 0) return;  // sampled: events between kernels cost ~µs of stream time
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
   (void)hipEventRecord(a, e->stream);
   e->prof_pending.push_back({kernel, {a, b}});
+  e->prof_open = 1;
 }
 
 void prof_end(fmx_engine* e) {
-  if (!e->profile || e->prof_pending.empty()) return;
+  if (!e->prof_open || e->prof_pending.empty()) return;
+  e->prof_open = 0;
   (void)hipEventRecord(e->prof_pending.back().second.second, e->stream);
 }
 
@@ -249,13 +253,14 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, int64_t b0, int64_t nrows, i
   return launch_rows_forward(e, a, true, false);
 }
 
-static ColsArgs cols_args(fmx_matrix* m, int64_t batch, int64_t nrows, int phase, double global_rows) {
+static ColsArgs cols_args(fmx_matrix* m, int64_t batch, int64_t nrows, int64_t n_partials, int phase, double global_rows) {
   const int64_t base = m->h_row_ptr_batches[(size_t)batch];
   ColsArgs c{};
   c.bptr = m->bptr + (size_t)batch * ((size_t)m->p + 1);
   c.brow = m->brow + base;
   c.bval = m->bval + base;
   c.rows_active = (uint32_t)nrows;
+  c.n_partials = n_partials;
   c.phase = phase;
   c.global_rows = global_rows;
   return c;
@@ -313,7 +318,9 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   e->kp64 = pad_factor(e->k, 2);
   FMX_TRY(make_hyper(*cfg, &e->hyper));
   FMX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  FMX_TRY(dev_alloc_zero(&e->scal, (size_t)SC_COUNT));
+  FMX_TRY(dev_alloc_zero(&e->scal_base, (size_t)2 * SC_COUNT));
+  e->scal = e->scal_base;
+  e->scal_next = e->scal_base + SC_COUNT;
   const size_t p = (size_t)e->p;
   if (cfg->mode == FMX_MODE_MINIBATCH) {
     FMX_TRY(dev_alloc_zero(&e->V, p * e->kp32));
@@ -336,7 +343,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto& pr : e->prof_pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
-  (void)hipFree(e->scal);
+  (void)hipFree(e->scal_base);
   (void)hipFree(e->V); (void)hipFree(e->w); (void)hipFree(e->sV); (void)hipFree(e->sw); (void)hipFree(e->nV); (void)hipFree(e->nw);
   (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
@@ -577,8 +584,7 @@ int fmx_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(batch_geometry(e, m, batch, rows_limit, &b0, &nrows));
   if (nrows == 0) return FMX_OK;
   FMX_TRY(rows_phase(e, m, b0, nrows, &n_partials));
-  FMX_TRY(launch_scalar_update(e, n_partials, (double)nrows, 0));
-  return launch_cols_update(e, cols_args(m, batch, nrows, 0, (double)nrows));
+  return launch_cols_update(e, cols_args(m, batch, nrows, n_partials, 0, (double)nrows));
 }
 
 int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
@@ -587,8 +593,7 @@ int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(batch_geometry(e, m, batch, rows_limit, &b0, &nrows));
   FMX_TRY(ensure_gbuf(e));
   FMX_TRY(rows_phase(e, m, b0, nrows, &n_partials));
-  FMX_TRY(launch_scalar_update(e, n_partials, (double)nrows, 1));
-  return launch_cols_update(e, cols_args(m, batch, nrows, 1, (double)nrows));
+  return launch_cols_update(e, cols_args(m, batch, nrows, n_partials, 1, (double)nrows));
 }
 
 int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats) {
@@ -605,7 +610,6 @@ int fmx_apply(fmx_engine* e, int64_t global_rows) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_CHECK(!seq_mode(e) && e->gbuf, FMX_ERR_STATE, "fmx_apply needs a preceding fmx_grad");
   FMX_TRY(use_device(e->cfg.device));
-  FMX_TRY(launch_scalar_update(e, 0, (double)global_rows, 2));
   ColsArgs c{};
   c.phase = 2;
   c.global_rows = (double)global_rows;
@@ -646,7 +650,8 @@ int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, co
 int fmx_profile_enable(fmx_engine* e, int on) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_TRY(prof_collect(e));
-  e->profile = on != 0;
+  e->profile = on > 0 ? on : 0;
+  for (int i = 0; i < FMX_KERNEL_COUNT; ++i) e->prof_seen[i] = 0;
   return FMX_OK;
 }
 

@@ -112,7 +112,9 @@ struct fmx_engine {
   int kp32 = 0;  // padded factor count of the fp32 tables (multiple of 4)
   int kp64 = 0;  // padded factor count of the fp64 tables (multiple of 2)
   hipStream_t stream = nullptr;
-  double* scal = nullptr;  // [SC_COUNT]
+  double* scal = nullptr;       // [SC_COUNT] current scalars (one half of scal_base)
+  double* scal_next = nullptr;  // the other half: written by the step's last kernel, then swapped in
+  double* scal_base = nullptr;  // [2][SC_COUNT] allocation
   // mini-batch (fp32) state: tables are [p][kp32]
   float *V = nullptr, *w = nullptr;
   float *sV = nullptr, *sw = nullptr;    // q (SGD-L1) or z (FTRL)
@@ -130,7 +132,9 @@ struct fmx_engine {
   float* gbuf = nullptr;      // multi-GPU exchange buffer
   int64_t gbuf_floats = 0;
   // measurement
-  int profile = 0;
+  int profile = 0;      // 0 off, n > 0: time every n-th launch of each kernel
+  int64_t prof_seen[FMX_KERNEL_COUNT] = {0};
+  int prof_open = 0;    // a begin without its end is pending
   double prof_ms[FMX_KERNEL_COUNT] = {0};
   int64_t prof_n[FMX_KERNEL_COUNT] = {0};
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
@@ -162,11 +166,11 @@ struct ColsArgs {
   const uint32_t* brow;  // based at the batch's first entry
   const float* bval;
   uint32_t rows_active;
+  int64_t n_partials;    // phase 1's per-workgroup partial sums to reduce (phases 0, 1)
   int phase;             // 0 fused, 1 accumulate-only (write gbuf), 2 apply-only (read gbuf)
   double global_rows;    // rows of the whole (global) batch, for the L1 cumulative penalty
 };
 int launch_cols_update(fmx_engine* e, const ColsArgs& a);
-int launch_scalar_update(fmx_engine* e, int64_t n_partials, double batch_rows, int phase);
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count);
 

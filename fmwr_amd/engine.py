@@ -163,8 +163,9 @@ class Engine:
         L.check(L.lib().fmx_als_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu)))
         return error
 
-    def profile(self, on=True):
-        L.check(L.lib().fmx_profile_enable(self.h, C.c_int(1 if on else 0)))
+    def profile(self, every=1):
+        """every = 0: off; n > 0: HIP-event time every n-th launch of each kernel."""
+        L.check(L.lib().fmx_profile_enable(self.h, C.c_int(int(every))))
 
     def profile_reset(self):
         L.check(L.lib().fmx_profile_reset(self.h))

@@ -174,6 +174,8 @@ int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, co
 #define FMX_KERNEL_SCALAR 2       /* w0 reduction/update */
 #define FMX_KERNEL_SEQ 3          /* sequential-exact learner */
 #define FMX_KERNEL_COUNT 8
+/* on == 0: off; on == n > 0: time every n-th launch of each kernel (n = 1: all; sampling keeps the events' own cost,
+ * a few microseconds of stream time per timed launch, out of the measured throughput). */
 int fmx_profile_enable(fmx_engine* e, int on);
 int fmx_profile_get(fmx_engine* e, int kernel, double* total_ms, int64_t* launches);
 int fmx_profile_reset(fmx_engine* e);

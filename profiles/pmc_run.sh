@@ -10,4 +10,4 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pass$i" -- python3 bench.py --cpu-rows 0 "$@" > "$OUT/pass$i.log" 2>&1
 done
-python3 profiles/pmc_summarize.py "$OUT"
+python3 profiles/pmc_summarize.py "$OUT" "$@"

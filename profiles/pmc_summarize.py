@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+bench_args = sys.argv[2:]
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
@@ -28,5 +29,11 @@ for k, d in res.items():
         d["write_bytes"] = d["WRITE_SIZE"] * 1024
     if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d["TCC_MISS_sum"], 1)
+for k, d in res.items():
+    if "fetch_bytes_x2" in d and "write_bytes" in d:
+        # the figure bench.py quotes as roofline.traffic: guide's gfx950 correction (x2 on FETCH_SIZE) applied to every
+        # read request -- an UPPER bound here, because only part of the reads are wide coalesced streams
+        d["traffic_bytes_per_launch"] = d["fetch_bytes_x2"] + d["write_bytes"]
+res["_bench_args"] = bench_args
 json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))

@@ -227,12 +227,24 @@ def test_grad_apply_equals_step(fm):
         ea = _engine(fm, p, P, solver, L.MODE_MINIBATCH, batch_rows=250)
         eb = _engine(fm, p, P, solver, L.MODE_MINIBATCH, batch_rows=250)
         ea.set_params(w0, w, v); eb.set_params(w0, w, v)
+        ec = _engine(fm, p, P, solver, L.MODE_MINIBATCH, batch_rows=250)
+        ec.set_params(w0, w, v)
         for b in range(4):
             ea.step(m, b)
             eb.grad(m, b); eb.apply(250)
-        ea.sync(); eb.sync()
-        pa, pb = ea.get_params(), eb.get_params()
+            ec.grad(m, b); ec.apply(0)  # row count taken from the exchange buffer's tail
+        ea.sync(); eb.sync(); ec.sync()
+        pa, pb, pc = ea.get_params(), eb.get_params(), ec.get_params()
         assert util.rel_err(pb[2], pa[2]) < 1e-6 and util.rel_err(pb[1], pa[1]) < 1e-6 and abs(pa[0] - pb[0]) < 1e-6
+        assert pb[0] == pc[0] and np.array_equal(pb[1], pc[1]) and np.array_equal(pb[2], pc[2])
+        # the tail sits right behind the planes: [sum mult, sum mult^2, rows, 0]
+        import ctypes as C
+        ptr, nfl = ec.grad_buffer()
+        kp = 4
+        while kp < P.k:
+            kp *= 2
+        has_q = c["solver"] == "ftrl" and not P.batch_mean
+        assert nfl == p * kp * (2 if has_q else 1) + p * (3 if has_q else 2) + 4
 
 
 @pytest.mark.parametrize("shape", ["fields", "ragged"])
