@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
-    ap.add_argument("--cpu-rows", type=int, default=1_500_000, help="rows of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--cpu-rows", type=int, default=5_000_000, help="rows of the CPU-baseline sample (0: skip)")
     return ap.parse_args()
 
 

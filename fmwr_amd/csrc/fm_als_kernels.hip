@@ -10,6 +10,8 @@
 // feature's CSC column, reduce sum(h*e), sum(h*h), form the new v, then apply the rank-1 corrections with plain
 // stores (no two features of a level touch the same row, so there are no atomics and the result is reproducible).
 // fp64 throughout, like the reference; x*x is a float product there (:314,:345) and here.
+// q and e live interleaved as one {q[r], e[r]} pair per row, so a stored nonzero costs one 16-byte gather (one line)
+// per pass instead of two.
 #include "fmx_internal.h"
 
 namespace fmx {
@@ -38,12 +40,22 @@ __global__ void level_relax_k(const int64_t* __restrict__ row_ptr, const uint32_
 
 // ---- per-factor cache q = X v_f (rows parallel; same ascending-feature association as :291-299) -------------------
 __global__ void als_q_init_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val,
-                             int64_t n, const double* __restrict__ V, int kp, int f, double* __restrict__ q) {
+                             int64_t n, const double* __restrict__ V, int kp, int f, double2* __restrict__ qe) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   double acc = 0.0;
   for (int64_t t = row_ptr[r]; t < row_ptr[r + 1]; ++t) acc += (double)val[t] * V[(size_t)col[t] * kp + f];
-  q[r] = acc;
+  qe[r].x = acc;
+}
+
+__global__ void als_pack_k(const double* __restrict__ err, int64_t n, double2* __restrict__ qe) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) qe[r] = make_double2(0.0, err[r]);
+}
+
+__global__ void als_unpack_k(const double2* __restrict__ qe, int64_t n, double* __restrict__ err) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) err[r] = qe[r].y;
 }
 
 __device__ __forceinline__ bool bad_number(double x) { return isnan(x) || isinf(x); }
@@ -51,8 +63,8 @@ __device__ __forceinline__ bool bad_number(double x) { return isnan(x) || isinf(
 // one wave per feature of the level
 __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
                                                           const uint32_t* __restrict__ crow, const float* __restrict__ cval,
-                                                          double* __restrict__ V, int kp, int f, double* __restrict__ q,
-                                                          double* __restrict__ err, double alpha, double lambda, double mu) {
+                                                          double* __restrict__ V, int kp, int f, double2* __restrict__ qe,
+                                                          double alpha, double lambda, double mu) {
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6);
   if (wid >= n_feats) return;
@@ -64,8 +76,9 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
     const float x = cval[t];
     const uint32_t r = crow[t];
     const float xx = x * x;
-    const double h = (double)x * q[r] - (double)xx * v_old;
-    v_mean += h * err[r];
+    const double2 c = qe[r];
+    const double h = (double)x * c.x - (double)xx * v_old;
+    v_mean += h * c.y;
     v_var += h * h;
   }
 #pragma unroll
@@ -84,19 +97,15 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
     const float x = cval[t];
     const uint32_t r = crow[t];
     const float xx = x * x;
-    const double qr = q[r];
-    const double h = (double)x * qr - (double)xx * v_old;
-    q[r] = qr - (double)x * v_diff;
-    err[r] -= h * v_diff;
+    const double2 c = qe[r];
+    const double h = (double)x * c.x - (double)xx * v_old;
+    qe[r] = make_double2(c.x - (double)x * v_diff, c.y - h * v_diff);
   }
 }
 
-struct AlsPlan {
-  std::vector<int64_t> level_ptr;  // [L+1] into feats
-  uint32_t* d_feats = nullptr;     // features ordered by (level, index)
-};
-
-static int build_plan(fmx_matrix* m, hipStream_t stream, AlsPlan* plan) {
+// the level plan depends on the matrix only: built once, kept in the fmx_matrix
+static int build_plan(fmx_matrix* m, hipStream_t stream) {
+  if (m->als_feats) return FMX_OK;
   const uint32_t p = m->p;
   int *d_level = nullptr, *d_changed = nullptr;
   FMX_HIP(hipMalloc(&d_level, (size_t)p * sizeof(int)));
@@ -117,38 +126,40 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, AlsPlan* plan) {
   (void)hipFree(d_level); (void)hipFree(d_changed);
   int L = 0;
   for (uint32_t j = 0; j < p; ++j) if (level[j] + 1 > L) L = level[j] + 1;
-  plan->level_ptr.assign((size_t)L + 1, 0);
-  for (uint32_t j = 0; j < p; ++j) plan->level_ptr[(size_t)level[j] + 1]++;
-  for (int l = 0; l < L; ++l) plan->level_ptr[(size_t)l + 1] += plan->level_ptr[(size_t)l];
+  m->als_level_ptr.assign((size_t)L + 1, 0);
+  for (uint32_t j = 0; j < p; ++j) m->als_level_ptr[(size_t)level[j] + 1]++;
+  for (int l = 0; l < L; ++l) m->als_level_ptr[(size_t)l + 1] += m->als_level_ptr[(size_t)l];
   std::vector<uint32_t> feats(p);
-  std::vector<int64_t> cur(plan->level_ptr.begin(), plan->level_ptr.end() - 1);
+  std::vector<int64_t> cur(m->als_level_ptr.begin(), m->als_level_ptr.end() - 1);
   for (uint32_t j = 0; j < p; ++j) feats[(size_t)cur[(size_t)level[j]]++] = j;  // ascending index inside a level
-  FMX_HIP(hipMalloc(&plan->d_feats, (size_t)p * sizeof(uint32_t)));
-  FMX_HIP(hipMemcpy(plan->d_feats, feats.data(), (size_t)p * sizeof(uint32_t), hipMemcpyHostToDevice));
+  FMX_HIP(hipMalloc(&m->als_feats, (size_t)p * sizeof(uint32_t)));
+  FMX_HIP(hipMemcpy(m->als_feats, feats.data(), (size_t)p * sizeof(uint32_t), hipMemcpyHostToDevice));
   return FMX_OK;
 }
 
-int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu) {
+int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_qe_raw, double alpha, const double* h_lambda, const double* h_mu) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweep needs every row's columns strictly ascending (as R's dgCMatrix rows are)");
   FMX_TRY(build_full_csc(m, e->stream));
-  AlsPlan plan;
-  int st = build_plan(m, e->stream, &plan);
-  if (st != FMX_OK) { (void)hipFree(plan.d_feats); return st; }
-  const int L = (int)plan.level_ptr.size() - 1;
+  FMX_TRY(build_plan(m, e->stream));
+  double2* d_qe = reinterpret_cast<double2*>(d_qe_raw);
+  const unsigned row_grid = (unsigned)((m->n + 255) / 256);
+  const std::vector<int64_t>& level_ptr = m->als_level_ptr;
+  const int L = (int)level_ptr.size() - 1;
+  hipLaunchKernelGGL(als_pack_k, dim3(row_grid), dim3(256), 0, e->stream, d_error, m->n, d_qe);
   for (int f = 0; f < e->k; ++f) {
-    if (m->n > 0) hipLaunchKernelGGL(als_q_init_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_q);
+    hipLaunchKernelGGL(als_q_init_k, dim3(row_grid), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_qe);
     const double lambda = h_lambda ? h_lambda[f] : 0.0, mu = h_mu ? h_mu[f] : 0.0;
     for (int l = 0; l < L; ++l) {
-      const int64_t cnt = plan.level_ptr[(size_t)l + 1] - plan.level_ptr[(size_t)l];
+      const int64_t cnt = level_ptr[(size_t)l + 1] - level_ptr[(size_t)l];
       if (cnt == 0) continue;
       const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
-      hipLaunchKernelGGL(als_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, plan.d_feats + plan.level_ptr[(size_t)l], (int)cnt,
-                         m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_q, d_error, alpha, lambda, mu);
+      hipLaunchKernelGGL(als_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
+                         m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_qe, alpha, lambda, mu);
     }
   }
+  hipLaunchKernelGGL(als_unpack_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, m->n, d_error);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-  (void)hipFree(plan.d_feats);
   FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "ALS sweep failed: %s", hipGetErrorString(err));
   return FMX_OK;
 }

@@ -175,7 +175,7 @@ static void free_matrix(fmx_matrix* m) {
   if (!m) return;
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
   (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
-  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
+  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats);
   delete m;
 }
 
@@ -638,7 +638,11 @@ int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, co
   double *d_err = nullptr, *d_q = nullptr;
   const size_t bytes = (size_t)m->n * sizeof(double);
   FMX_HIP(hipMalloc(&d_err, bytes));
-  if (hipMalloc(&d_q, bytes) != hipSuccess) { (void)hipFree(d_err); set_error("out of device memory"); return FMX_ERR_HIP; }
+  if (hipMalloc(&d_q, 2 * bytes) != hipSuccess) {  // interleaved (q, e) pairs
+    (void)hipFree(d_err);
+    set_error("out of device memory");
+    return FMX_ERR_HIP;
+  }
   int st = FMX_OK;
   if (hipMemcpy(d_err, error, bytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the residual failed"); st = FMX_ERR_HIP; }
   if (st == FMX_OK) st = launch_als_vsweep(e, m, d_err, d_q, alpha, v_lambda, v_mu);

@@ -102,6 +102,9 @@ struct fmx_matrix {
   uint32_t* crow = nullptr;    // [nnz]
   float* cval = nullptr;       // [nnz]
   std::vector<int64_t> h_row_ptr_batches;  // host copy of row_ptr at batch boundaries
+  // ALS level plan (features ordered by (level, index)), built lazily
+  uint32_t* als_feats = nullptr;
+  std::vector<int64_t> als_level_ptr;
 };
 
 struct fmx_engine {
