@@ -36,7 +36,7 @@ class Config(C.Structure):
         ("alpha_w", C.c_double), ("alpha_v", C.c_double), ("beta_w", C.c_double), ("beta_v", C.c_double),
         ("random_step", C.c_int32), ("mode", C.c_int32), ("batch_rows", C.c_int64),
         ("min_target", C.c_double), ("max_target", C.c_double),
-        ("device", C.c_int32), ("batch_reduce", C.c_int32),
+        ("device", C.c_int32), ("batch_reduce", C.c_int32), ("tile_rows", C.c_int64),
     ]
 
 

@@ -28,6 +28,29 @@
 
 namespace fmx {
 
+// table-row gather; FMX_NT_GATHER=1 marks it non-temporal (experiment: does the fill granularity / L2 policy change?)
+#ifndef FMX_NT_GATHER
+#define FMX_NT_GATHER 0
+#endif
+typedef float fx4 __attribute__((ext_vector_type(4)));
+typedef double dx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 gather_row(const float* p) {
+#if FMX_NT_GATHER
+  fx4 v = __builtin_nontemporal_load(reinterpret_cast<const fx4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ double2 gather_row(const double* p) {
+#if FMX_NT_GATHER
+  dx2 v = __builtin_nontemporal_load(reinterpret_cast<const dx2*>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *reinterpret_cast<const double2*>(p);
+#endif
+}
+
 template <typename T> struct Slice;
 template <> struct Slice<float> { using vec = float4; static constexpr int N = 4; };
 template <> struct Slice<double> { using vec = double2; static constexpr int N = 2; };
@@ -110,7 +133,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
       T wv[FMX_U];
 #pragma unroll
       for (int u = 0; u < FMX_U; ++u) {
-        vv[u] = *reinterpret_cast<const vec_t*>(Vt + (size_t)en[u].x * KP);
+        vv[u] = gather_row(Vt + (size_t)en[u].x * KP);
         wv[u] = k1 ? wt[en[u].x] : (T)0;
       }
 #pragma unroll
@@ -198,10 +221,12 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_
 // Runs in workgroup 0 of fm_cols_update_k: deterministic reduction of phase 1's per-workgroup partial sums and the w0
 // step (SGD_Learner.h:106-109; FTRL_Learner.h:80-86,161).  Scalars are double-buffered: every kernel of a step reads
 // `sin` (the step's start state) and only this function writes `sout`; the host flips the two after the launch.
-// phase: 0 fused (reduce + update), 1 reduce only -> exchange-buffer tail, 2 update from the (all-reduced) tail.
+// mode: SCALAR_FUSED reduce + update, SCALAR_PUBLISH reduce only -> exchange-buffer tail, SCALAR_FROM_TAIL update from the
+// (all-reduced) tail.
 __device__ __forceinline__ void scalar_update(const double* __restrict__ partials, int64_t n_partials, const double* sin,
-                                              double* sout, float* gtail, const Hyper& h, double rows, int phase,
+                                              double* sout, float* gtail, const Hyper& h, double rows, int mode,
                                               double* sg, double* sq) {
+  const int phase = (mode == SCALAR_PUBLISH) ? 1 : (mode == SCALAR_FROM_TAIL) ? 2 : 0;
   double g0 = 0.0, q0 = 0.0;
   if (phase != 2) {
     for (int64_t i = threadIdx.x; i < n_partials; i += WG_THREADS) { g0 += partials[2 * i]; q0 += partials[2 * i + 1]; }
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   float* gQV = T.gbuf ? gCN + T.p : nullptr;
   float* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
 
-  if (a.phase != 2) {
+  if (a.walk) {
     const int64_t lo = a.bptr[J0], hi = a.bptr[J1];
     int64_t ta = 0, tb = 0;
     if (have) { ta = a.bptr[j]; tb = a.bptr[j + 1]; }
@@ -361,7 +386,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
         float av[FMX_U];
 #pragma unroll
         for (int u = 0; u < FMX_U; ++u) {
-          sv[u] = *reinterpret_cast<const float4*>(St + (size_t)en[u].x * KP);
+          sv[u] = gather_row(St + (size_t)en[u].x * KP);
           av[u] = T.amul[en[u].x];
         }
 #pragma unroll
@@ -384,22 +409,23 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       }
       __syncthreads();
     }
-  } else if (have) {  // apply-only: sums come from the (all-reduced) exchange buffer
+  }
+  if (have && a.load_gbuf) {  // sums of earlier tiles of this step, or the all-reduced sums of the whole global batch
     float4 g4 = *reinterpret_cast<const float4*>(gGV + (size_t)j * KP + lig * VEC);
-    slice_get(g4, G);
-    Gw = gGW[j];
-    cnt = gCN[j];
+    G[0] += g4.x; G[1] += g4.y; G[2] += g4.z; G[3] += g4.w;
+    Gw += gGW[j];
+    cnt += gCN[j];
     if (NEED_Q && T.has_q) {
       float4 q4 = *reinterpret_cast<const float4*>(gQV + (size_t)j * KP + lig * VEC);
-      slice_get(q4, Q);
-      Qw = gQW[j];
+      Q[0] += q4.x; Q[1] += q4.y; Q[2] += q4.z; Q[3] += q4.w;
+      Qw += gQW[j];
     }
   }
   float* gtail = T.gbuf ? (T.has_q ? gQW + T.p : gCN + T.p) : nullptr;  // the Q planes exist only with has_q
   double rows = a.global_rows;
-  if (a.phase == 2 && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
+  if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
 
-  if (have && a.phase == 1) {  // accumulate-only: publish the local sums (every feature, zeros included)
+  if (have && a.store_gbuf) {  // publish the sums so far (every feature, zeros included)
     *reinterpret_cast<float4*>(gGV + (size_t)j * KP + lig * VEC) = make_float4((float)G[0], (float)G[1], (float)G[2], (float)G[3]);
     if (NEED_Q && T.has_q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)Q[0], (float)Q[1], (float)Q[2], (float)Q[3]);
     if (lig == 0) {
@@ -410,7 +436,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   }
 
   // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
-  if (have && a.phase != 1 && cnt != 0.0) {
+  if (have && a.apply && cnt != 0.0) {
   if (h.mean) {  // FMX_REDUCE_MEAN: one reference step with the mean gradient of the coordinate's occurrences
     const double inv = 1.0 / cnt;
 #pragma unroll
@@ -461,8 +487,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   }
   }  // touched coordinate
 
-  if (blockIdx.x == 0)
-    scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.phase, red_g, red_q);
+  if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
+    scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
 }
 
 template <int KIND>
@@ -488,7 +514,8 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const ColsTables& 
 int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
   ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->scal_next, e->partials, a.n_partials,
                e->gbuf, (uint32_t)e->p, (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0};
-  FMX_CHECK(a.phase == 0 || e->gbuf != nullptr, FMX_ERR_STATE, "exchange buffer not allocated");
+  FMX_CHECK(!(a.load_gbuf || a.store_gbuf || a.scalar == SCALAR_PUBLISH || a.scalar == SCALAR_FROM_TAIL) || e->gbuf != nullptr,
+            FMX_ERR_STATE, "exchange buffer not allocated");
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
   switch (e->hyper.kind) {
@@ -497,7 +524,7 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
     default: st = launch_cols_kind<UPD_FTRL>(e, a, T); break;
   }
   prof_end(e);
-  if (st == FMX_OK && a.phase != 1) std::swap(e->scal, e->scal_next);  // the kernel wrote the next step's scalars
+  if (st == FMX_OK && (a.scalar == SCALAR_FUSED || a.scalar == SCALAR_FROM_TAIL)) std::swap(e->scal, e->scal_next);  // the kernel wrote the next step's scalars
   return st;
 }
 

@@ -98,43 +98,62 @@ static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r
   return FMX_OK;
 }
 
-int build_batch_csc(fmx_matrix* m, int64_t batch_rows, hipStream_t stream) {
-  FMX_CHECK(batch_rows > 0, FMX_ERR_INVALID, "batch_rows must be positive");
-  if (m->batch_rows == batch_rows && m->bptr) return FMX_OK;
+__global__ void gather_rows_k(const int64_t* __restrict__ src, const int64_t* __restrict__ rows, int64_t count, int64_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = src[rows[i]];
+}
+
+int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream) {
+  FMX_CHECK(batch_rows > 0 && tile_rows > 0, FMX_ERR_INVALID, "batch_rows and tile_rows must be positive");
+  if (m->batch_rows == batch_rows && m->tile_rows == tile_rows && m->bptr) return FMX_OK;
   FMX_HIP(hipSetDevice(m->device));
   (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
   m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr;
+  // steps of batch_rows rows, each cut into tiles of at most tile_rows rows
   const int64_t nb = (m->n + batch_rows - 1) / batch_rows;
   m->batch_rows = batch_rows;
+  m->tile_rows = tile_rows;
   m->n_batches = nb;
-  // row_ptr at the batch boundaries -> host
-  m->h_row_ptr_batches.assign((size_t)nb + 1, 0);
+  m->tile_start.clear();
+  m->step_first_tile.assign((size_t)nb + 1, 0);
+  for (int64_t s = 0; s < nb; ++s) {
+    m->step_first_tile[(size_t)s] = (int64_t)m->tile_start.size();
+    const int64_t end = (s + 1) * batch_rows < m->n ? (s + 1) * batch_rows : m->n;
+    for (int64_t r = s * batch_rows; r < end; r += tile_rows) m->tile_start.push_back(r);
+  }
+  m->step_first_tile[(size_t)nb] = (int64_t)m->tile_start.size();
+  m->tile_start.push_back(m->n);
+  const int64_t nt = (int64_t)m->tile_start.size() - 1;
+  // row_ptr at the tile boundaries -> host
+  m->h_row_ptr_batches.assign((size_t)nt + 1, 0);
   {
-    int64_t* d = nullptr;
-    FMX_HIP(hipMalloc(&d, ((size_t)nb + 1) * sizeof(int64_t)));
-    hipLaunchKernelGGL(gather_i64_k, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, stream, m->row_ptr, batch_rows, m->n, nb + 1, d);
-    FMX_HIP(hipMemcpyAsync(m->h_row_ptr_batches.data(), d, ((size_t)nb + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    int64_t *d_rows = nullptr, *d = nullptr;
+    FMX_HIP(hipMalloc(&d_rows, ((size_t)nt + 1) * sizeof(int64_t)));
+    FMX_HIP(hipMalloc(&d, ((size_t)nt + 1) * sizeof(int64_t)));
+    FMX_HIP(hipMemcpyAsync(d_rows, m->tile_start.data(), ((size_t)nt + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(gather_rows_k, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), 0, stream, m->row_ptr, d_rows, nt + 1, d);
+    FMX_HIP(hipMemcpyAsync(m->h_row_ptr_batches.data(), d, ((size_t)nt + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     FMX_HIP(hipStreamSynchronize(stream));
-    FMX_HIP(hipFree(d));
+    FMX_HIP(hipFree(d)); FMX_HIP(hipFree(d_rows));
   }
   int64_t max_cnt = 0;
-  for (int64_t b = 0; b < nb; ++b) {
-    const int64_t c = m->h_row_ptr_batches[b + 1] - m->h_row_ptr_batches[b];
-    FMX_CHECK(c < (1LL << 32), FMX_ERR_INVALID, "a batch holds %lld nonzeros; at most 2^32-1 are supported (lower batch_rows)", (long long)c);
+  for (int64_t t = 0; t < nt; ++t) {
+    const int64_t c = m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t];
+    FMX_CHECK(c < (1LL << 32), FMX_ERR_INVALID, "a tile holds %lld nonzeros; at most 2^32-1 are supported (lower tile_rows)", (long long)c);
     if (c > max_cnt) max_cnt = c;
   }
-  FMX_HIP(hipMalloc(&m->bptr, (size_t)nb * ((size_t)m->p + 1) * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&m->bptr, (size_t)(nt > 0 ? nt : 1) * ((size_t)m->p + 1) * sizeof(uint32_t)));
   FMX_HIP(hipMalloc(&m->brow, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(uint32_t)));
   FMX_HIP(hipMalloc(&m->bval, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(float)));
   const int bits = col_bits(m->p);
   SortScratch s;
   FMX_TRY(sort_scratch_alloc(s, max_cnt, bits, stream));
-  for (int64_t b = 0; b < nb; ++b) {
-    const int64_t r0 = b * batch_rows;
-    const int64_t nrows = (r0 + batch_rows <= m->n) ? batch_rows : m->n - r0;
-    const int64_t base = m->h_row_ptr_batches[b], cnt = m->h_row_ptr_batches[b + 1] - base;
+  for (int64_t t = 0; t < nt; ++t) {
+    const int64_t r0 = m->tile_start[(size_t)t];
+    const int64_t nrows = m->tile_start[(size_t)t + 1] - r0;
+    const int64_t base = m->h_row_ptr_batches[t], cnt = m->h_row_ptr_batches[t + 1] - base;
     FMX_TRY(csc_of_range<uint32_t>(m, s, bits, r0, nrows, base, cnt, m->brow + base, m->bval + base,
-                                   m->bptr + (size_t)b * ((size_t)m->p + 1), stream));
+                                   m->bptr + (size_t)t * ((size_t)m->p + 1), stream));
   }
   FMX_HIP(hipStreamSynchronize(stream));
   return FMX_OK;

@@ -127,16 +127,19 @@ static int reset_optimizer_state(fmx_engine* e) {
   return FMX_OK;
 }
 
-static int ensure_workspace(fmx_engine* e, int64_t rows) {
-  if (rows <= e->ws_rows) return FMX_OK;
-  (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
-  e->S = nullptr; e->amul = nullptr; e->partials = nullptr; e->ws_rows = 0;
+static int ensure_workspace(fmx_engine* e, int64_t tile_rows, int64_t step_rows) {
   const int rpw = WG_THREADS / (e->kp32 / 4);
-  e->ws_partials = (rows + rpw - 1) / rpw;
-  FMX_HIP(hipMalloc(&e->S, (size_t)rows * e->kp32 * sizeof(float)));
-  FMX_HIP(hipMalloc(&e->amul, (size_t)rows * sizeof(float)));
-  FMX_HIP(hipMalloc(&e->partials, (size_t)e->ws_partials * 2 * sizeof(double)));
-  e->ws_rows = rows;
+  const int64_t tiles = (step_rows + tile_rows - 1) / tile_rows;
+  const int64_t partials = ((tile_rows + rpw - 1) / rpw) * (tiles > 0 ? tiles : 1);
+  if (tile_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
+  e->S = nullptr; e->amul = nullptr; e->partials = nullptr; e->ws_rows = 0; e->ws_partials = 0;
+  FMX_HIP(hipMalloc(&e->S, (size_t)tile_rows * e->kp32 * sizeof(float)));
+  FMX_HIP(hipMalloc(&e->amul, (size_t)tile_rows * sizeof(float)));
+  FMX_HIP(hipMalloc(&e->partials, (size_t)partials * 2 * sizeof(double)));
+  e->ws_rows = tile_rows;
+  e->ws_partials = partials;
   return FMX_OK;
 }
 
@@ -230,40 +233,92 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
   return FMX_OK;
 }
 
-static int batch_geometry(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, int64_t* b0, int64_t* nrows) {
+// rows-per-tile actually used: a step of batch_rows rows is cut into ceil(batch_rows / tile) equal-ish tiles
+static int64_t effective_tile_rows(const fmx_engine* e) {
+  const int64_t want = e->cfg.tile_rows > 0 ? e->cfg.tile_rows : 262144;  // S (tile x 64 B at k=16) stays cache resident
+  if (e->cfg.batch_rows <= want) return e->cfg.batch_rows;
+  const int64_t tiles = (e->cfg.batch_rows + want - 1) / want;
+  return (e->cfg.batch_rows + tiles - 1) / tiles;
+}
+
+struct TileRun {
+  int64_t tile;    // global tile index
+  int64_t r0;      // first row
+  int64_t nrows;   // rows taking part
+};
+
+// the tiles of step `batch`, cut at rows_limit (> 0: only the first rows_limit rows of the step take part)
+static int step_tiles(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, std::vector<TileRun>* out, int64_t* step_rows) {
   FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "step interface needs FMX_MODE_MINIBATCH");
   FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");  // R/fm_train.R:72-74
-  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, e->stream));
+  const int64_t tile = effective_tile_rows(e);
+  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, tile, e->stream));
   FMX_CHECK(batch >= 0 && batch < m->n_batches, FMX_ERR_INVALID, "batch %lld out of range (0..%lld)", (long long)batch, (long long)m->n_batches - 1);
-  *b0 = batch * m->batch_rows;
-  *nrows = (*b0 + m->batch_rows <= m->n) ? m->batch_rows : m->n - *b0;
-  if (rows_limit > 0 && rows_limit < *nrows) *nrows = rows_limit;
-  FMX_TRY(ensure_workspace(e, m->batch_rows < m->n ? m->batch_rows : m->n));
+  FMX_TRY(ensure_workspace(e, tile < m->n ? tile : (m->n > 0 ? m->n : 1), e->cfg.batch_rows));
+  out->clear();
+  int64_t left = rows_limit > 0 ? rows_limit : (int64_t)1 << 62;
+  int64_t total = 0;
+  for (int64_t t = m->step_first_tile[(size_t)batch]; t < m->step_first_tile[(size_t)batch + 1] && left > 0; ++t) {
+    int64_t nrows = m->tile_start[(size_t)t + 1] - m->tile_start[(size_t)t];
+    if (nrows > left) nrows = left;
+    out->push_back({t, m->tile_start[(size_t)t], nrows});
+    left -= nrows;
+    total += nrows;
+  }
+  *step_rows = total;
   return FMX_OK;
 }
 
-static int rows_phase(fmx_engine* e, fmx_matrix* m, int64_t b0, int64_t nrows, int64_t* n_partials) {
+static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t partial_offset, int64_t* n_partials) {
   RowsArgs a{};
   a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = m->y;
-  a.r0 = b0; a.nrows = nrows;
+  a.r0 = t.r0; a.nrows = t.nrows;
   a.V = e->V; a.w = e->w; a.scal = e->scal;
-  a.S = e->S; a.amul = e->amul; a.partials = e->partials;
+  a.S = e->S; a.amul = e->amul; a.partials = e->partials + 2 * partial_offset;
   const int rpw = WG_THREADS / (e->kp32 / 4);
-  *n_partials = (nrows + rpw - 1) / rpw;
+  *n_partials = (t.nrows + rpw - 1) / rpw;
   return launch_rows_forward(e, a, true, false);
 }
 
-static ColsArgs cols_args(fmx_matrix* m, int64_t batch, int64_t nrows, int64_t n_partials, int phase, double global_rows) {
-  const int64_t base = m->h_row_ptr_batches[(size_t)batch];
+static ColsArgs cols_args(fmx_matrix* m, const TileRun& t) {
+  const int64_t base = m->h_row_ptr_batches[(size_t)t.tile];
   ColsArgs c{};
-  c.bptr = m->bptr + (size_t)batch * ((size_t)m->p + 1);
+  c.bptr = m->bptr + (size_t)t.tile * ((size_t)m->p + 1);
   c.brow = m->brow + base;
   c.bval = m->bval + base;
-  c.rows_active = (uint32_t)nrows;
-  c.n_partials = n_partials;
-  c.phase = phase;
-  c.global_rows = global_rows;
+  c.rows_active = (uint32_t)t.nrows;
+  c.walk = 1;
   return c;
+}
+
+// run the tiles of one step: every tile accumulates; `finish_local` applies the update after the last tile (single GPU),
+// otherwise the sums (and the partial-sum tail) are left in the exchange buffer for the all-reduce
+static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, bool finish_local) {
+  std::vector<TileRun> tiles;
+  int64_t step_rows = 0;
+  FMX_TRY(step_tiles(e, m, batch, rows_limit, &tiles, &step_rows));
+  if (tiles.empty()) {
+    if (finish_local) return FMX_OK;
+    tiles.push_back({m->step_first_tile[(size_t)batch], 0, 0});  // an empty share still has to publish zeros
+  }
+  const bool single = tiles.size() == 1;
+  if (!(single && finish_local)) FMX_TRY(ensure_gbuf(e));
+  int64_t partials = 0;
+  for (size_t i = 0; i < tiles.size(); ++i) {
+    int64_t np = 0;
+    FMX_TRY(rows_phase(e, m, tiles[i], partials, &np));
+    partials += np;
+    const bool last = i + 1 == tiles.size();
+    ColsArgs c = cols_args(m, tiles[i]);
+    c.load_gbuf = i > 0;
+    c.store_gbuf = !(last && finish_local);
+    c.apply = last && finish_local;
+    c.scalar = !last ? SCALAR_NONE : (finish_local ? SCALAR_FUSED : SCALAR_PUBLISH);
+    c.n_partials = last ? partials : 0;
+    c.global_rows = (double)step_rows;
+    FMX_TRY(launch_cols_update(e, c));
+  }
+  return FMX_OK;
 }
 
 }  // namespace fmx
@@ -307,7 +362,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
   FMX_CHECK(cfg->batch_reduce == FMX_REDUCE_MEAN || cfg->batch_reduce == FMX_REDUCE_SUM, FMX_ERR_INVALID, "unknown batch_reduce %d", cfg->batch_reduce);
   FMX_CHECK(num_features > 0 && num_features < (1ull << 32), FMX_ERR_INVALID, "number of features must be in 1..2^32-1");
-  if (cfg->mode == FMX_MODE_MINIBATCH) FMX_CHECK(cfg->batch_rows >= 1, FMX_ERR_INVALID, "batch_rows must be >= 1");
+  if (cfg->mode == FMX_MODE_MINIBATCH) FMX_CHECK(cfg->batch_rows >= 1 && cfg->tile_rows >= 0, FMX_ERR_INVALID, "batch_rows must be >= 1 and tile_rows >= 0");
   FMX_TRY(use_device(cfg->device));
 
   std::unique_ptr<fmx_engine, int (*)(fmx_engine*)> e(new fmx_engine(), fmx_engine_destroy);
@@ -573,27 +628,21 @@ int fmx_num_batches(fmx_engine* e, fmx_matrix* m, int64_t* n_batches) {
   FMX_TRY(check_pair(e, m));
   FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "batches exist only in FMX_MODE_MINIBATCH");
   FMX_TRY(use_device(e->cfg.device));
-  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, e->stream));
+  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, effective_tile_rows(e), e->stream));
   if (n_batches) *n_batches = m->n_batches;
   return FMX_OK;
 }
 
 int fmx_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(check_pair(e, m));
-  int64_t b0, nrows, n_partials;
-  FMX_TRY(batch_geometry(e, m, batch, rows_limit, &b0, &nrows));
-  if (nrows == 0) return FMX_OK;
-  FMX_TRY(rows_phase(e, m, b0, nrows, &n_partials));
-  return launch_cols_update(e, cols_args(m, batch, nrows, n_partials, 0, (double)nrows));
+  FMX_TRY(use_device(e->cfg.device));
+  return run_step(e, m, batch, rows_limit, true);
 }
 
 int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(check_pair(e, m));
-  int64_t b0, nrows, n_partials;
-  FMX_TRY(batch_geometry(e, m, batch, rows_limit, &b0, &nrows));
-  FMX_TRY(ensure_gbuf(e));
-  FMX_TRY(rows_phase(e, m, b0, nrows, &n_partials));
-  return launch_cols_update(e, cols_args(m, batch, nrows, n_partials, 1, (double)nrows));
+  FMX_TRY(use_device(e->cfg.device));
+  return run_step(e, m, batch, rows_limit, false);
 }
 
 int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats) {
@@ -611,7 +660,9 @@ int fmx_apply(fmx_engine* e, int64_t global_rows) {
   FMX_CHECK(!seq_mode(e) && e->gbuf, FMX_ERR_STATE, "fmx_apply needs a preceding fmx_grad");
   FMX_TRY(use_device(e->cfg.device));
   ColsArgs c{};
-  c.phase = 2;
+  c.load_gbuf = 1;
+  c.apply = 1;
+  c.scalar = SCALAR_FROM_TAIL;
   c.global_rows = (double)global_rows;
   return launch_cols_update(e, c);
 }

@@ -91,17 +91,21 @@ struct fmx_matrix {
   float* y = nullptr;          // [n] or null
   int has_labels = 0;
   int rows_sorted = 0;  // every row strictly ascending in col (=> no duplicate column inside a row)
-  // per-batch CSC ("inverted index" of each batch), built lazily for one batch_rows value
+  // per-tile CSC ("inverted index" of each tile of rows), built lazily for one (batch_rows, tile_rows) pair.
+  // A step covers batch_rows consecutive rows and is cut into tiles of at most tile_rows rows.
   int64_t batch_rows = 0;
-  int64_t n_batches = 0;
-  uint32_t* bptr = nullptr;  // [n_batches][p+1] offsets relative to row_ptr[batch*batch_rows]
-  uint32_t* brow = nullptr;  // [nnz] row index local to the batch
+  int64_t tile_rows = 0;
+  int64_t n_batches = 0;                 // steps
+  std::vector<int64_t> tile_start;       // [n_tiles+1] first row of every tile
+  std::vector<int64_t> step_first_tile;  // [n_batches+1]
+  uint32_t* bptr = nullptr;  // [n_tiles][p+1] offsets relative to row_ptr[tile_start[t]]
+  uint32_t* brow = nullptr;  // [nnz] row index local to the tile
   float* bval = nullptr;     // [nnz]
   // CSC of the whole matrix (ALS sweep), built lazily
   int64_t* col_ptr = nullptr;  // [p+1]
   uint32_t* crow = nullptr;    // [nnz]
   float* cval = nullptr;       // [nnz]
-  std::vector<int64_t> h_row_ptr_batches;  // host copy of row_ptr at batch boundaries
+  std::vector<int64_t> h_row_ptr_batches;  // host copy of row_ptr at the tile boundaries
   // ALS level plan (features ordered by (level, index)), built lazily
   uint32_t* als_feats = nullptr;
   std::vector<int64_t> als_level_ptr;
@@ -128,6 +132,7 @@ struct fmx_engine {
   double *dnV = nullptr, *dnw = nullptr;
   // workspaces (mini-batch)
   int64_t ws_rows = 0;
+  int64_t tile_rows = 0;      // rows per tile (<= cfg.batch_rows)
   float* S = nullptr;         // [ws_rows][kp32] per-row factor sums
   float* amul = nullptr;      // [ws_rows] per-row gradient multiplier
   double* partials = nullptr; // [ws_partials][2]
@@ -164,21 +169,29 @@ struct RowsArgs {
 };
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
 
+enum ScalarMode : int { SCALAR_NONE = 0, SCALAR_FUSED = 1, SCALAR_PUBLISH = 2, SCALAR_FROM_TAIL = 3 };
+
+// One launch of fm_cols_update_k.  A step is one or more tiles (each with its own CSC); the flags say what this launch
+// does with the coordinate sums:  walk the tile's lists -> [+ load_gbuf] -> [store_gbuf] -> [apply the update].
 struct ColsArgs {
-  const uint32_t* bptr;  // [p+1] for this batch
-  const uint32_t* brow;  // based at the batch's first entry
+  const uint32_t* bptr;  // [p+1] for this tile
+  const uint32_t* brow;  // based at the tile's first entry
   const float* bval;
-  uint32_t rows_active;
-  int64_t n_partials;    // phase 1's per-workgroup partial sums to reduce (phases 0, 1)
-  int phase;             // 0 fused, 1 accumulate-only (write gbuf), 2 apply-only (read gbuf)
-  double global_rows;    // rows of the whole (global) batch, for the L1 cumulative penalty
+  uint32_t rows_active;  // tile rows taking part (a truncated step cuts the last tile)
+  int walk;              // accumulate this tile's sums from S / amul
+  int load_gbuf;         // add the sums already in the exchange buffer (earlier tiles, or the all-reduced global sums)
+  int store_gbuf;        // write the sums back to the exchange buffer
+  int apply;             // apply the update to V / w / optimizer state
+  int scalar;            // ScalarMode: what workgroup 0 does for w0
+  int64_t n_partials;    // phase 1's per-workgroup partial sums to reduce (SCALAR_FUSED / SCALAR_PUBLISH)
+  double global_rows;    // rows of the whole step (all tiles; all ranks when known), <= 0: take it from the buffer tail
 };
 int launch_cols_update(fmx_engine* e, const ColsArgs& a);
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count);
 
 // ingest
-int build_batch_csc(fmx_matrix* m, int64_t batch_rows, hipStream_t stream);
+int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream);
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int check_rows_sorted(fmx_matrix* m);

@@ -84,6 +84,9 @@ typedef struct fmx_config {
   double max_target;       /* learner->max_target                       */
   int32_t device;          /* HIP device ordinal                        */
   int32_t batch_reduce;    /* FMX_REDUCE_* (mini-batch mode)            */
+  int64_t tile_rows;       /* 0: default.  A step of batch_rows rows is processed in tiles of at most this many
+                              rows (parameters frozen across the tiles, sums accumulated): keeps the per-tile
+                              tables cache resident for large batches.  Does not change any result.           */
 } fmx_config;
 
 typedef struct fmx_engine fmx_engine; /* parameters + optimizer state on one GPU */
@@ -145,7 +148,7 @@ int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t 
 /* ---- step-level interface (what fmx_train loops over; used by bench.py and the multi-GPU driver).
  * All of these enqueue on the engine's stream and return without waiting; fmx_sync waits. */
 
-/* number of batches the matrix splits into for the engine's batch_rows (builds the per-batch CSC on first use) */
+/* number of steps (batches of batch_rows rows) the matrix splits into (builds the per-tile CSC on first use) */
 int fmx_num_batches(fmx_engine* e, fmx_matrix* m, int64_t* n_batches);
 /* one full mini-batch step on this GPU: forward -> gradient sums -> update, rows of batch `batch`
  * (rows_limit > 0 truncates the batch to its first rows_limit rows). */

@@ -275,3 +275,45 @@ def test_als_vsweep_matches_oracle(fm, shape):
     gv = e.get_params()[2]
     assert util.rel_err(gv, rv.reshape(k, p)) < 1e-10
     assert util.rel_err(gerr, rerr) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["sgd_l2_cls", "sgd_l1_cls", "ftrl_l1l2_cls"])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_tiled_step_equals_the_batch_semantics(fm, name, reduce):
+    """A step cut into tiles (parameters frozen across them, sums accumulated) is the same mini-batch step: the oracle
+    knows nothing about tiles.  Also through the multi-GPU split (grad over tiles -> apply)."""
+    engine, L = fm
+    c = next(x for x in CASES if x["name"] == name)
+    n, p, batch = 1500, 300, 600
+    rp, col, val, y, P, seed = _problem(c, n=n)
+    P.batch_mean = int(reduce == "mean")
+    w0, w, v = util.params(p, P.k, seed, fp32=True)
+    X = oracle.Matrix(rp, col, val, p)
+    mb = (oracle.SgdMinibatch if c["solver"] == "sgd" else oracle.FtrlMinibatch)(P, X, y, w0, w, v.ravel())
+    steps = [(0, 600), (600, 1200), (1200, 1500), (0, 600), (600, 900)]  # last one truncated by max_iter
+    for b0, b1 in steps:
+        mb.step(b0, b1)
+    total = sum(b1 - b0 for b0, b1 in steps)
+    solver = L.SOLVER_SGD if c["solver"] == "sgd" else L.SOLVER_FTRL
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    rv = mb.v.reshape(P.k, p)
+    for tile in (128, 250, 600):
+        e = engine.Engine(p, task=P.task, solver=solver, num_factor=P.k, l2_w0=P.l2_reg0, l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv,
+                          l2_v=P.l2_regv, learn_rate=P.learn_rate, mode=L.MODE_MINIBATCH, batch_rows=batch, tile_rows=tile,
+                          batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM)
+        e.set_params(w0, w, v)
+        assert e.num_batches(m) == 3
+        assert e.train(m, total) == total
+        g0, gw, gv = e.get_params()
+        assert util.rel_err(gv, rv) < V_RTOL and util.rel_err(gw, mb.w) < V_RTOL and abs(g0 - mb.w0.value) < V_RTOL * max(1.0, abs(mb.w0.value))
+        # the grad/apply split over the same tiles
+        e2 = engine.Engine(p, task=P.task, solver=solver, num_factor=P.k, l2_w0=P.l2_reg0, l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv,
+                           l2_v=P.l2_regv, learn_rate=P.learn_rate, mode=L.MODE_MINIBATCH, batch_rows=batch, tile_rows=tile,
+                           batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM)
+        e2.set_params(w0, w, v)
+        for i, (b0, b1) in enumerate(steps):
+            e2.grad(m, i % 3, b1 - b0)
+            e2.apply(0)
+        e2.sync()
+        h0, hw, hv = e2.get_params()
+        assert util.rel_err(hv, gv) < 1e-6 and util.rel_err(hw, gw) < 1e-6 and abs(h0 - g0) < 1e-6 * max(1.0, abs(g0))
