@@ -5,7 +5,8 @@
 
 A "step" is one synchronous mini-batch SGD step (forward + gradient sums + update) over `--batch-rows` rows PER GPU of
 the synthetic 10M x 1M, 30 nnz/row, k=16 workload (BASELINE.json configs[1]); the matrix is generated on the device
-and is resident in HBM before the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), each rank
+and is resident in HBM before the timed region.  The engine cuts a step into tiles of <= 262144 rows (two kernel
+launches per tile: fm_rows_forward, fm_cols_update) with the parameters frozen across the tiles.  N > 1: one process per GPU (torch.distributed / RCCL), each rank
 owns a contiguous row range, computes its gradient sums, the (k+2)*p buffer is all-reduced, every replica applies the
 same update ("scaling": "weak": per-GPU rows per step are fixed).
 
@@ -36,7 +37,8 @@ def parse():
     ap.add_argument("--features", type=int, default=1_000_000)
     ap.add_argument("--nnz", type=int, default=30)
     ap.add_argument("--factors", type=int, default=16)
-    ap.add_argument("--batch-rows", type=int, default=262_144, help="mini-batch rows per GPU per step")
+    ap.add_argument("--batch-rows", type=int, default=1_048_576,
+                    help="mini-batch rows per GPU per step (processed in cache-resident tiles of <= 262144 rows)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
@@ -66,7 +68,7 @@ def pmc_traffic(kernel, args):
         a = d.get("_bench_args", [])
         def opt(name, default):
             return int(a[a.index(name) + 1]) if name in a else default
-        same = (opt("--batch-rows", 262_144) == args.batch_rows and opt("--factors", 16) == args.factors and opt("--features", 1_000_000) == args.features
+        same = (-(-opt("--batch-rows", 1_048_576) // -(-opt("--batch-rows", 1_048_576) // 262_144)) == -(-args.batch_rows // -(-args.batch_rows // 262_144)) and opt("--factors", 16) == args.factors and opt("--features", 1_000_000) == args.features
                 and opt("--rows", 10_000_000) == args.rows and opt("--nnz", 30) == args.nnz and ("ftrl" in a) == (args.solver == "ftrl"))
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
             best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f))
@@ -173,7 +175,10 @@ def main():
         value = rows_step * args.steps / dt
         fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
         upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
-        b_fwd, b_upd, b_step = algorithmic_bytes(z, k, p, B)
+        tiles = -(-B // 262_144)            # fmx_api.hip effective_tile_rows()
+        tile_rows = -(-B // tiles)
+        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p, tile_rows)   # per LAUNCH: one tile
+        b_step = algorithmic_bytes(z, k, p, B)[2]
         kernels = {
             "fm_rows_forward": (b_fwd, fwd_ms / max(fwd_n, 1)),
             "fm_cols_update": (b_upd, upd_ms / max(upd_n, 1)),
@@ -188,7 +193,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch "
                                    f"(BASELINE.json configs[{1 if args.solver == 'sgd' else 2}])",
-                       "batch_rows_per_gpu": B, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
+                       "batch_rows_per_gpu": B, "tile_rows": tile_rows, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
                        "state": "fp32 V[p][k] + w[p], fp64 accumulation", "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,

@@ -87,4 +87,4 @@ def test_bench_multirank_path_runs(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch_rows"] == 65536
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch_rows"] == 65536 and d["config"]["tile_rows"] == 32768
