@@ -166,6 +166,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # forward-only rate (Model::predict_batch + logistic link over the rank's rows, output left on the device)
+    fwd_rate = None
+    if world == 1:
+        out_dev = torch.empty(n_local, dtype=torch.float64, device=torch.device("cuda", local_rank))
+        import ctypes as C
+        def forward_all():
+            L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(n_local), C.c_void_p(out_dev.data_ptr()), C.c_int(L.LINK_LOGISTIC)))
+        forward_all(); e.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            forward_all()
+        e.sync()
+        fwd_rate = 3 * n_local / (time.perf_counter() - t1)
+
     w0, _, vv = e.get_params()
     if not (np.isfinite(w0) and np.all(np.isfinite(vv))):
         raise SystemExit("non-finite parameters after the timed region")
@@ -203,6 +217,8 @@ def main():
                          "kernels_ms": {name: kv[1] for name, kv in kernels.items()},
                          "step_algorithmic_GBps": b_step / (dt / args.steps) / 1e9 / world},
         }
+        if fwd_rate is not None:
+            out["forward_rows_per_s"] = fwd_rate
         if world == 1 and args.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(m, args, v0)
         print(json.dumps(out), flush=True)
