@@ -15,6 +15,7 @@ SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL = 200, 300, 500
 MODE_SEQUENTIAL, MODE_MINIBATCH = 0, 1
 LINK_NONE, LINK_LOGISTIC, LINK_CLAMP = 0, 1, 2
 REDUCE_MEAN, REDUCE_SUM = 0, 1
+EVAL_LL, EVAL_AUC, EVAL_ACC, EVAL_RMSE, EVAL_MSE, EVAL_MAE = 0, 111, 222, 333, 444, 555
 KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3
 
 # every symbol include/fmx.h declares (tests/test_abi.py checks the library exports all of them)
@@ -23,7 +24,8 @@ SYMBOLS = [
     "fmx_get_params", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
     "fmx_matrix_info", "fmx_matrix_export", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
     "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
-    "fmx_als_vsweep", "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset",
+    "fmx_als_vsweep", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
+    "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset",
 ]
 
 
@@ -38,6 +40,11 @@ class Config(C.Structure):
         ("min_target", C.c_double), ("max_target", C.c_double),
         ("device", C.c_int32), ("batch_reduce", C.c_int32), ("tile_rows", C.c_int64),
     ]
+
+
+class TrackConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("metric", C.c_int32), ("step_size", C.c_int64), ("convergence", C.c_double),
+                ("keep_params", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FmxError(RuntimeError):

@@ -5,8 +5,8 @@ R/fm_solver_control.R, R/fm_track_control.R, R/fm_matrix.R -> src/FM.cpp).  R is
 same surface is mirrored here with the same names (dots -> underscores), argument meaning, defaults and error
 messages, on top of the C ABI (include/fmx.h).  The Rcpp glue a maintainer would add is in INTEGRATION.md.
 
-Outside the path: the TDAP and MCMC solvers, tracker snapshots (track.control(step_size > 0)),
-fm.select / fm.track, column normalisation (normalize=TRUE).  Asking for them raises NotImplementedError.
+Outside the path: the TDAP and MCMC solvers and column normalisation (normalize=TRUE); asking for them
+raises NotImplementedError.  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
 """
 import warnings
 
@@ -161,8 +161,7 @@ def _merge_controls(data, control):
         if not cls.endswith(".control"):
             raise ValueError("control list is wrong")
         merged[cls.split(".")[0]] = c
-    if merged["track"]["step_size"] > 0:
-        raise NotImplementedError("tracker snapshots (track.control(step_size > 0)) are outside the accelerated path (row f-1)")
+    merged["track"]["max_iter"] = merged["solver"]["max_iter"]  # R/fm_train.R:106
     return merged
 
 
@@ -193,12 +192,24 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device):
     sol = controls["solver"]["solver"]["solver"]
     if sol == "ALS":
         raise NotImplementedError("ALS training beyond the V sweep is outside the accelerated path (row f-4); use Engine.als_vsweep")
-    eng.train(m, controls["solver"]["max_iter"])
+    track = controls["track"]
+    trace, convergent = None, False
+    if track["step_size"] > 0:  # learner->tracker.step_size > 0: Learner::learn evaluates, snapshots and may stop early
+        metric = getattr(L, "EVAL_" + track["evaluate.metric"])
+        r = eng.train_tracked(m, controls["solver"]["max_iter"], track["step_size"], metric, track["convergence"], keep_params=True)
+        convergent = r["convergent"]
+        # Tracker::save (core/Tracker.h:96-119): trace = list(record_index, {w0,w,v}...), evaluation.train
+        trace = {"trace": [r["iters"]] + [{"w0": a, "w": b, "v": c} for (a, b, c) in r["params"]], "evaluation.train": r["evals"]}
+    else:
+        eng.train(m, controls["solver"]["max_iter"])
     w0, w, v = eng.get_params()
     model = {"w0": w0, "w": w, "v": v, "model.control": controls["model"], "solver.control": controls["solver"],
-             "track.control": controls["track"], "convergence": False}
+             "track.control": controls["track"], "convergence": convergent}
     scales = {"mean": None, "std": None, "model.vars": data.feature_names, "target.range": (lo, hi)}
-    return {"class": "FM", "Model": model, "Scales": scales, "engine": {"mode": mode, "batch_rows": batch_rows, "device": device}}
+    fit = {"class": "FM", "Model": model, "Scales": scales, "engine": {"mode": mode, "batch_rows": batch_rows, "device": device}}
+    if trace is not None:
+        fit["Trace"] = trace
+    return fit
 
 
 def fm_train(data, normalize=False, control=None, seed=None, mode="sequential", batch_rows=65536, device=0):
@@ -255,3 +266,89 @@ def predict(object, newdata=None, normalize=False):
     m = _device_matrix(newdata, None, device)
     link = L.LINK_LOGISTIC if controls["model"]["task"] == "CLASSIFICATION" else L.LINK_CLAMP
     return eng.predict(m, link)
+
+
+def _check_track_labels(data, task, what):
+    y = np.asarray(data.labels, np.float64)
+    if task == "CLASSIFICATION":  # R/fm_track.R:44-53
+        u = np.unique(y)
+        if len(u) != 2:
+            raise ValueError(f"{what}'s target should have two levels")
+        if np.array_equal(u, [0.0, 1.0]):
+            y = np.where(y < 1, -1.0, 1.0)
+        elif not np.array_equal(u, [-1.0, 1.0]):
+            raise ValueError(f"{what}'s target should be c(0, 1) or c(-1, 1)")
+    return y
+
+
+def _fm_track_eval(object, data, metric):
+    """FMTrack (src/FM.cpp:218-258): the metric of every recorded snapshot on `data` (Tracker::report, core/Tracker.h:70-94)."""
+    mdl = object["Model"]
+    controls = {"model": mdl["model.control"], "solver": mdl["solver.control"], "track": mdl["track.control"]}
+    task = controls["model"]["task"]
+    device = object.get("engine", {}).get("device", 0)
+    eng = _engine_for(controls, data.dim[1], object["Scales"]["target.range"], "sequential", 1, device)
+    m = _device_matrix(data, _check_track_labels(data, task, "data"), device)
+    out = []
+    for snap in object["Trace"]["trace"][1:]:
+        eng.set_params(snap["w0"], snap["w"], snap["v"])
+        out.append(eng.evaluate(m, getattr(L, "EVAL_" + metric)))
+    return np.array(out)
+
+
+def fm_track(object, data=None, newdata=None, evaluate_metric="LL"):
+    """fm.track() -- R/fm_track.R:28-86: the training-trace metric and the same metric on new data per snapshot."""
+    if object.get("Trace") is None:
+        raise ValueError("no Trace in fm object")
+    task = object["Model"]["model.control"]["task"]
+    if evaluate_metric not in ("LL", "AUC", "ACC", "RMSE", "MAE"):
+        raise ValueError("'arg' should be one of 'LL', 'AUC', 'ACC', 'RMSE', 'MAE'")
+    if (task == "CLASSIFICATION" and evaluate_metric in ("RMSE", "MAE")) or (task == "REGRESSION" and evaluate_metric in ("LL", "AUC", "ACC")):
+        raise ValueError("evaluate.metric is error")
+    if object["Model"]["track.control"]["evaluate.metric"] != evaluate_metric:
+        if data is None:
+            raise ValueError("data is missing")
+        if not isinstance(data, FmMatrix):
+            raise TypeError("data is not a fm.matrix object")
+        val1 = _fm_track_eval(object, data, evaluate_metric)
+    else:
+        val1 = np.asarray(object["Trace"]["evaluation.train"])
+    if newdata is None:
+        raise ValueError("newdata is missing")
+    if not isinstance(newdata, FmMatrix):
+        raise TypeError("newdata is not a fm.matrix object")
+    val2 = _fm_track_eval(object, newdata, evaluate_metric)
+    return {"class": "FMTrace", "iter": np.asarray(object["Trace"]["trace"][0]), "trace.train": val1, "trace.test": val2,
+            "evaluate.metric": evaluate_metric}
+
+
+def fm_select(object, trace=None, best_iter=None, drop_trace=False):
+    """fm.select() -- R/fm_select.R:22-66: put the best snapshot (by the test trace) into the model."""
+    if trace is None:
+        raise ValueError("trace is missing")
+    if not isinstance(trace, dict) or trace.get("class") != "FMTrace":
+        raise TypeError("trace is not a FMTrace object")
+    if object.get("Trace") is None or len(object["Trace"]) <= 1:
+        raise ValueError("the Trace part in object have been dropped")
+    bigger_is_better = object["Model"]["track.control"]["evaluate.metric"] in ("LL", "ACC", "AUC")  # cmp(), R/fm_select.R:69-77
+    better = (lambda a, b: a > b) if bigger_is_better else (lambda a, b: a < b)
+    pick = np.max if bigger_is_better else np.min
+    iterations = np.asarray(object["Trace"]["trace"][0])
+    test, train = np.asarray(trace["trace.test"]), np.asarray(trace["trace.train"])
+    if best_iter is not None:
+        if best_iter < iterations[0] or best_iter > iterations[-1]:
+            raise ValueError("best.iter is out of range")
+        if best_iter in iterations:
+            idx = int(np.where(iterations == best_iter)[0][0])
+        else:  # the recorded neighbour with the better test metric (R/fm_select.R:43-48, 1-based there)
+            i1 = int(np.argmin(best_iter >= iterations)) - 1
+            idx = i1 if (i1 + 1 >= len(iterations) or better(test[i1], test[i1 + 1])) else i1 + 1
+    else:
+        cand = np.where(test == pick(test))[0]
+        idx = int(cand[0]) if len(cand) == 1 else int(np.where(train == pick(train[cand]))[0][0])
+    snap = object["Trace"]["trace"][idx + 1]
+    out = dict(object)
+    out["Model"] = dict(object["Model"], w0=snap["w0"], w=snap["w"], v=snap["v"])
+    if drop_trace:
+        out.pop("Trace", None)
+    return out

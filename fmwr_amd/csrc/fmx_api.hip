@@ -430,6 +430,7 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
     if (w) for (size_t j = 0; j < p; ++j) hw[j] = (float)w[j];
     FMX_HIP(hipMemcpy(e->w, hw.data(), p * sizeof(float), hipMemcpyHostToDevice));
   }
+  e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   FMX_TRY(reset_optimizer_state(e));  // learner->init() zeroes q/u (SGD_Learner.h:61-69) and z/n (FTRL_Learner.h:50-55)
   FMX_HIP(hipDeviceSynchronize());
   return FMX_OK;
@@ -621,6 +622,154 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
   }
   FMX_TRY(fmx_sync(e));
   if (examples_done) *examples_done = done;
+  return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ tracker
+namespace fmx {
+
+// the evaluation block of solver/SGD_Learner.h:143-155: prediction with the task's link, then tracker.evaluate
+static int track_eval(fmx_engine* e, const fmx_matrix* m, int metric, double* d_yhat, double* score) {
+  const int link = e->cfg.task == FMX_TASK_REGRESSION ? FMX_LINK_CLAMP : FMX_LINK_LOGISTIC;
+  FMX_TRY(forward_rows(e, m, 0, m->n, d_yhat, link));
+  return evaluate_device(e, d_yhat, m->y, m->n, metric, score);
+}
+
+static int track_record(fmx_engine* e, int64_t iter, double score, bool keep) {  // Tracker::record, core/Tracker.h:54-63
+  e->trace_iters.push_back(iter);
+  e->trace_evals.push_back(score);
+  if (keep) {
+    fmx_engine::Snapshot s;
+    s.w.resize((size_t)e->p);
+    s.v.resize((size_t)e->p * (e->k > 0 ? e->k : 1));
+    FMX_TRY(fmx_get_params(e, &s.w0, s.w.data(), s.v.data()));
+    e->trace_params.push_back(std::move(s));
+  }
+  return FMX_OK;
+}
+
+}  // namespace fmx
+
+int fmx_evaluate(fmx_engine* e, const fmx_matrix* m, int metric, double* out) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  FMX_TRY(use_device(e->cfg.device));
+  double* d = nullptr;
+  FMX_HIP(hipMalloc(&d, (size_t)(m->n > 0 ? m->n : 1) * sizeof(double)));
+  int st = track_eval(e, m, metric, d, out);
+  (void)hipFree(d);
+  return st;
+}
+
+int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_track_config* track, int64_t* examples_done,
+                      int32_t* convergent) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(track != nullptr && track->struct_size == sizeof(fmx_track_config), FMX_ERR_INVALID, "bad fmx_track_config");
+  FMX_CHECK(track->step_size > 0, FMX_ERR_INVALID, "step_size must be > 0 (use fmx_train when the tracker is off)");
+  FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
+  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS, FMX_ERR_STATE, "ALS engines train through fmx_als_vsweep");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  FMX_TRY(use_device(e->cfg.device));
+  e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
+  if (examples_done) *examples_done = 0;
+  if (convergent) *convergent = 0;
+  if (max_iter == 0 || m->n == 0) return FMX_OK;
+
+  // Tracker::init (core/Tracker.h:41-52): at most MAX_REC = 10000 records, else the step is widened
+  int64_t step = track->step_size;
+  {
+    const int64_t MAX_REC = 10000;
+    int64_t record_times = (int64_t)std::ceil(((double)max_iter - 0.5) / (double)step) + 1;
+    if (record_times > MAX_REC) step = (int64_t)((double)(max_iter + 1) / (double)MAX_REC) + 1;
+  }
+  const bool keep = track->keep_params != 0;
+  double* d_yhat = nullptr;
+  FMX_HIP(hipMalloc(&d_yhat, (size_t)m->n * sizeof(double)));
+  int64_t* d_order = nullptr;
+  int st = FMX_OK;
+  int conv_times = 0;
+  double old_score = 0.0;
+  int64_t done = 0;
+  auto after_eval = [&](int64_t iter, double score) {  // solver/SGD_Learner.h:157-164
+    if (iter > step && std::fabs((score - old_score) / (old_score + 1e-30)) <= track->convergence) conv_times++;
+    else conv_times = 0;
+    old_score = score;
+    return track_record(e, iter, score, keep);
+  };
+
+  if (seq_mode(e)) {
+    std::vector<int64_t> order;
+    visit_order(m->n, e->cfg.random_step, max_iter, &order);
+    const int64_t count = (int64_t)order.size();
+    if (count > 0) {
+      if (hipMalloc(&d_order, (size_t)count * sizeof(int64_t)) != hipSuccess ||
+          hipMemcpy(d_order, order.data(), (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("upload of the visiting order failed"); st = FMX_ERR_HIP;
+      }
+    }
+    int64_t pos = 0;
+    while (st == FMX_OK && pos < count) {
+      // next evaluation: after example `next`, the first index >= pos with next % step == 0, or the last example
+      int64_t next = (pos % step == 0) ? pos : (pos / step + 1) * step;
+      if (next > count - 1) next = count - 1;
+      st = launch_seq_learn(e, m, d_order + pos, next - pos + 1);
+      double score = 0.0;
+      if (st == FMX_OK) st = track_eval(e, m, track->metric, d_yhat, &score);
+      if (st == FMX_OK) st = after_eval(next, score);
+      pos = next + 1;
+      done = pos;
+      if (conv_times >= 3) { if (convergent) *convergent = 1; break; }  // SGD_Learner.h:169-172
+    }
+  } else {
+    int64_t nb = 0;
+    st = fmx_num_batches(e, m, &nb);
+    for (int64_t s = 0; st == FMX_OK && done < max_iter; ++s) {
+      const int64_t batch = s % nb;
+      const int64_t b0 = batch * m->batch_rows;
+      int64_t rows = (b0 + m->batch_rows <= m->n) ? m->batch_rows : m->n - b0;
+      if (rows > max_iter - done) rows = max_iter - done;
+      st = fmx_step(e, m, batch, rows);
+      const int64_t first = done, last = done + rows - 1;
+      done += rows;
+      // the step covered example indices [first, last]: evaluate if one of them is a record point
+      const bool hit = (last / step) * step >= first || last == max_iter - 1;  // a multiple of step in [first, last], or the end
+      if (st == FMX_OK && hit) {
+        double score = 0.0;
+        st = track_eval(e, m, track->metric, d_yhat, &score);
+        if (st == FMX_OK) st = after_eval(last, score);
+        if (conv_times >= 3) { if (convergent) *convergent = 1; break; }
+      }
+    }
+  }
+  if (st == FMX_OK) st = fmx_sync(e);
+  (void)hipFree(d_yhat); (void)hipFree(d_order);
+  if (examples_done) *examples_done = done;
+  return st;
+}
+
+int fmx_trace_size(fmx_engine* e, int64_t* n_records) {
+  FMX_CHECK(e != nullptr && n_records != nullptr, FMX_ERR_INVALID, "NULL argument");
+  *n_records = (int64_t)e->trace_iters.size();
+  return FMX_OK;
+}
+
+int fmx_trace_get(fmx_engine* e, int64_t* iters, double* evals) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  for (size_t i = 0; i < e->trace_iters.size(); ++i) {
+    if (iters) iters[i] = e->trace_iters[i];
+    if (evals) evals[i] = e->trace_evals[i];
+  }
+  return FMX_OK;
+}
+
+int fmx_trace_params(fmx_engine* e, int64_t record, double* w0, double* w, double* v) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_CHECK(record >= 0 && record < (int64_t)e->trace_params.size(), FMX_ERR_INVALID, "no snapshot %lld (the trace holds %zu)", (long long)record, e->trace_params.size());
+  const auto& s = e->trace_params[(size_t)record];
+  if (w0) *w0 = s.w0;
+  if (w) memcpy(w, s.w.data(), s.w.size() * sizeof(double));
+  if (v && e->k > 0) memcpy(v, s.v.data(), (size_t)e->p * e->k * sizeof(double));
   return FMX_OK;
 }
 

@@ -139,6 +139,11 @@ struct fmx_engine {
   int64_t ws_partials = 0;
   float* gbuf = nullptr;      // multi-GPU exchange buffer
   int64_t gbuf_floats = 0;
+  // tracker (core/Tracker.h): records of the last fmx_train_tracked
+  struct Snapshot { double w0; std::vector<double> w, v; };
+  std::vector<int64_t> trace_iters;
+  std::vector<double> trace_evals;
+  std::vector<Snapshot> trace_params;
   // measurement
   int profile = 0;      // 0 off, n > 0: time every n-th launch of each kernel
   int64_t prof_seen[FMX_KERNEL_COUNT] = {0};
@@ -197,6 +202,8 @@ int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_
 int check_rows_sorted(fmx_matrix* m);
 
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu);
+
+int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);
 
 // profiling helpers
 void prof_begin(fmx_engine* e, int kernel);

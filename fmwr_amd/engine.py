@@ -125,6 +125,30 @@ class Engine:
         L.check(L.lib().fmx_train(self.h, m.h, C.c_int64(max_iter), C.byref(done)))
         return done.value
 
+    def train_tracked(self, m, max_iter, step_size, metric=L.EVAL_LL, convergence=1e-4, keep_params=True):
+        """Learner::learn with the tracker on; returns dict(done, convergent, iters, evals[, params])."""
+        tc = L.TrackConfig(C.sizeof(L.TrackConfig), int(metric), int(step_size), float(convergence), int(bool(keep_params)), 0)
+        done, conv = C.c_int64(), C.c_int32()
+        L.check(L.lib().fmx_train_tracked(self.h, m.h, C.c_int64(max_iter), C.byref(tc), C.byref(done), C.byref(conv)))
+        n = C.c_int64()
+        L.check(L.lib().fmx_trace_size(self.h, C.byref(n)))
+        iters = np.zeros(max(n.value, 1), np.int64); evals = np.zeros(max(n.value, 1))
+        L.check(L.lib().fmx_trace_get(self.h, _p(iters), _p(evals)))
+        out = dict(done=done.value, convergent=bool(conv.value), iters=iters[: n.value], evals=evals[: n.value])
+        if keep_params:
+            out["params"] = [self.trace_params(i) for i in range(n.value)]
+        return out
+
+    def trace_params(self, record):
+        w0 = C.c_double(); w = np.zeros(self.p); vv = np.zeros(max(self.k * self.p, 1))
+        L.check(L.lib().fmx_trace_params(self.h, C.c_int64(record), C.byref(w0), _p(w), _p(vv)))
+        return w0.value, w, vv[: self.k * self.p].reshape(self.p, self.k).T.copy()
+
+    def evaluate(self, m, metric):
+        out = C.c_double()
+        L.check(L.lib().fmx_evaluate(self.h, m.h, C.c_int(metric), C.byref(out)))
+        return out.value
+
     def train_order(self, m, order):
         order = np.ascontiguousarray(order, np.int64)
         L.check(L.lib().fmx_train_order(self.h, m.h, _p(order), C.c_int64(len(order))))

@@ -145,6 +145,41 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
 /* Same, but with an explicit visiting order (row ids, SEQUENTIAL mode only). */
 int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t count);
 
+/* ---- tracker (core/Tracker.h, the evaluation blocks of solver/SGD_Learner.h:140-176 and FTRL_Learner.h:118-154) */
+
+/* metric ids are the reference's (util/Macros.h:24-29); evaluates() picks by task (core/Evaluation.h:20-41) */
+#define FMX_EVAL_LL 0
+#define FMX_EVAL_AUC 111
+#define FMX_EVAL_ACC 222
+#define FMX_EVAL_RMSE 333
+#define FMX_EVAL_MSE 444
+#define FMX_EVAL_MAE 555
+
+/* track.control() (R/fm_track_control.R:20-26) as FM() plumbs it (src/FM.cpp:99-103) */
+typedef struct fmx_track_config {
+  uint32_t struct_size;  /* = sizeof(fmx_track_config) */
+  int32_t metric;        /* FMX_EVAL_*: evaluate.metric */
+  int64_t step_size;     /* evaluate + snapshot every step_size examples (> 0) */
+  double convergence;    /* stop after 3 consecutive relative changes <= this (conv_condition) */
+  int32_t keep_params;   /* 1: snapshot (w0, w, V) at every record like Tracker::record (core/Tracker.h:54-63); 0: metrics only */
+  int32_t reserved;
+} fmx_track_config;
+
+/* Metric of the engine's current parameters on a data set: forward + link (probability for CLASSIFICATION, clamp to
+ * the target range for REGRESSION) + evaluates().  What Tracker::report computes per snapshot (core/Tracker.h:70-94). */
+int fmx_evaluate(fmx_engine* e, const fmx_matrix* m, int metric, double* out);
+
+/* Learner::learn with the tracker on: as fmx_train, plus an evaluation on the training matrix after example 0,
+ * step_size, 2*step_size, ... and after the last one; stops early when converged.  The trace stays in the engine
+ * until the next fmx_train_tracked / fmx_set_params. */
+int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_track_config* track,
+                      int64_t* examples_done, int32_t* convergent);
+int fmx_trace_size(fmx_engine* e, int64_t* n_records);
+/* iters: the example index of each record (Trace$trace[[1]]), evals: Trace$evaluation.train */
+int fmx_trace_get(fmx_engine* e, int64_t* iters, double* evals);
+/* snapshot `record` (needs keep_params): same layouts as fmx_get_params */
+int fmx_trace_params(fmx_engine* e, int64_t record, double* w0, double* w, double* v);
+
 /* ---- step-level interface (what fmx_train loops over; used by bench.py and the multi-GPU driver).
  * All of these enqueue on the engine's stream and return without waiting; fmx_sync waits. */
 

@@ -91,3 +91,40 @@ def test_minibatch_mode_through_api_learns():
     fit = fm.fm_train(data, control=ctl, seed=0, mode="minibatch", batch_rows=256)
     acc = np.mean((fm.predict(fit, data) >= 0.5) == (y > 0))
     assert acc > 0.85, acc
+
+
+def test_track_and_select_through_the_api():
+    """track.control(step_size > 0) -> Trace; fm.track on new data; fm.select picks the best snapshot (R/fm_select.R)."""
+    import fmwr_amd as fm
+    rng = np.random.default_rng(8)
+    n, p, k = 4000, 60, 3
+    X = sp.random(n, p, density=0.15, format="csr", random_state=8, data_rvs=lambda s: rng.normal(0, 1, s))
+    vt = rng.normal(0, 0.4, (k, p)); Xd = X.toarray()
+    score = 0.5 * (((Xd @ vt.T) ** 2).sum(1) - ((Xd ** 2) @ (vt.T ** 2)).sum(1)) + Xd @ rng.normal(0, 0.5, p)
+    y = (score > np.median(score)).astype(np.float64)
+    train, test = fm.fm_matrix(X[:3000], y[:3000]), fm.fm_matrix(X[3000:], y[3000:])
+    ctl = [fm.model_control("CLASSIFICATION", **{"factor.number": k, "v.init_stdev": 0.1}),
+           fm.solver_control(max_iter=9000, solver=fm.SGD_solver(learn_rate=0.02)), fm.track_control(step_size=1000, evaluate_metric="LL", convergence=0.0)]
+    fit = fm.fm_train(train, control=ctl, seed=4)
+    assert list(fit["Trace"]["trace"][0]) == [0, 1000, 2000, 3000, 4000, 5000, 6000, 7000, 8000, 8999]
+    assert len(fit["Trace"]["trace"]) == 11 and len(fit["Trace"]["evaluation.train"]) == 10
+    ll = fit["Trace"]["evaluation.train"]
+    assert ll[-1] > ll[0]  # log-likelihood improves
+    tr = fm.fm_track(fit, newdata=test, evaluate_metric="LL")
+    assert tr["trace.train"] is not None and len(tr["trace.test"]) == 10
+    acc = fm.fm_track(fit, data=train, newdata=test, evaluate_metric="ACC")
+    # the oracle's metric on the last snapshot
+    snap = fit["Trace"]["trace"][-1]
+    P = oracle.params(k=k)
+    Xo = oracle.Matrix(X[3000:].indptr, X[3000:].indices, X[3000:].data, p)
+    prob = oracle.predict_batch(P, Xo, snap["w0"], snap["w"], snap["v"].ravel(), prob=True)
+    yt = np.where(y[3000:] < 1, -1.0, 1.0).astype(np.float32)
+    assert abs(acc["trace.test"][-1] - oracle.evaluate(oracle.CLASSIFICATION, oracle.ACC, prob, yt)) < 1e-12
+    assert abs(tr["trace.test"][-1] - oracle.evaluate(oracle.CLASSIFICATION, oracle.LL, prob, yt)) < 1e-9
+    best = fm.fm_select(fit, trace=tr)
+    bi = int(np.argmax(tr["trace.test"]))
+    assert np.array_equal(best["Model"]["v"], fit["Trace"]["trace"][bi + 1]["v"])
+    with pytest.raises(ValueError, match="evaluate.metric is error"):
+        fm.fm_track(fit, newdata=test, evaluate_metric="RMSE")
+    with pytest.raises(ValueError, match="trace is missing"):
+        fm.fm_select(fit)
