@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libfmx.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOGPU, ERR_STATE = 0, 1, 2, 3, 4
 TASK_CLASSIFICATION, TASK_REGRESSION = 10, 20
-SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL = 200, 300, 500
+SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL, SOLVER_TDAP = 200, 300, 500, 600
 MODE_SEQUENTIAL, MODE_MINIBATCH = 0, 1
 LINK_NONE, LINK_LOGISTIC, LINK_CLAMP = 0, 1, 2
 REDUCE_MEAN, REDUCE_SUM = 0, 1
@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("alpha_w", C.c_double), ("alpha_v", C.c_double), ("beta_w", C.c_double), ("beta_v", C.c_double),
         ("random_step", C.c_int32), ("mode", C.c_int32), ("batch_rows", C.c_int64),
         ("min_target", C.c_double), ("max_target", C.c_double),
-        ("device", C.c_int32), ("batch_reduce", C.c_int32), ("tile_rows", C.c_int64),
+        ("device", C.c_int32), ("batch_reduce", C.c_int32), ("gamma", C.c_double), ("tile_rows", C.c_int64),
     ]
 
 

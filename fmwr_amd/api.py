@@ -5,7 +5,7 @@ R/fm_solver_control.R, R/fm_track_control.R, R/fm_matrix.R -> src/FM.cpp).  R is
 same surface is mirrored here with the same names (dots -> underscores), argument meaning, defaults and error
 messages, on top of the C ABI (include/fmx.h).  The Rcpp glue a maintainer would add is in INTEGRATION.md.
 
-Outside the path: the TDAP and MCMC solvers and column normalisation (normalize=TRUE); asking for them
+Outside the path: the MCMC solver, ALS beyond the V sweep, and column normalisation (normalize=TRUE); asking for them
 raises NotImplementedError.  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
 """
 import warnings
@@ -16,7 +16,7 @@ from . import _lib as L
 from .engine import Engine, Matrix
 
 _TASKS = {"CLASSIFICATION": L.TASK_CLASSIFICATION, "REGRESSION": L.TASK_REGRESSION}
-_SOLVERS = {"SGD": L.SOLVER_SGD, "FTRL": L.SOLVER_FTRL, "ALS": L.SOLVER_ALS}
+_SOLVERS = {"SGD": L.SOLVER_SGD, "FTRL": L.SOLVER_FTRL, "ALS": L.SOLVER_ALS, "TDAP": L.SOLVER_TDAP}
 
 # R/fm_control.R:52-66
 MODEL_CONTROL_DEFAULT = {
@@ -75,8 +75,12 @@ def ALS_solver(**kw):
     return {"solver": "ALS", **_control_assign(ALS_SOLVER_DEFAULT, kw)}
 
 
+TDAP_SOLVER_DEFAULT = {"gamma": 1e-4, "alpha_w": 0.1, "alpha_v": 0.1, "random_step": 1}  # R/fm_solver_control.R:134-139
+
+
 def TDAP_solver(**kw):
-    raise NotImplementedError("TDAP.solver is outside the accelerated path (SURVEY.md section 8, row f-3)")
+    """TDAP.solver() -- R/fm_solver_control.R:141-155 (row f-3; runs in mode="sequential" only)."""
+    return {"solver": "TDAP", **_control_assign(TDAP_SOLVER_DEFAULT, kw)}
 
 
 def MCMC_solver(**kw):
@@ -84,9 +88,8 @@ def MCMC_solver(**kw):
 
 
 def solver_control(max_iter=10000, solver=None):
-    """solver.control() -- R/fm_solver_control.R:22-33.  The reference defaults to TDAP.solver(), which is outside
-    the accelerated path; the default here is SGD.solver()."""
-    solver = SGD_solver() if solver is None else solver
+    """solver.control() -- R/fm_solver_control.R:22-33 (default solver TDAP.solver(), as in the reference)."""
+    solver = TDAP_solver() if solver is None else solver
     if solver["solver"] in ("MCMC", "ALS") and max_iter > 100:
         warnings.warn("the maximum number of iteratorions for MCMC/ALS solver is 100, so max_iter will be set to 100")
         max_iter = min(max_iter, 100)
@@ -149,7 +152,7 @@ def _engine_for(controls, p, target_range, mode, batch_rows, device):
                   keep_w0=int(hp["keep.w0"]), keep_w1=int(hp["keep.w1"]), l2_w0=hp["L2.w0"], l1_w1=hp["L1.w1"], l2_w1=hp["L2.w1"],
                   l1_v=hp["L1.v"], l2_v=hp["L2.v"], learn_rate=sol.get("learn_rate", 0.01), alpha_w=sol.get("alpha_w", 0.1),
                   alpha_v=sol.get("alpha_v", 0.1), beta_w=sol.get("beta_w", 1.0), beta_v=sol.get("beta_v", 1.0),
-                  random_step=int(sol.get("random_step", 1)), mode=L.MODE_SEQUENTIAL if mode == "sequential" else L.MODE_MINIBATCH,
+                  gamma=sol.get("gamma", 1e-4), random_step=int(sol.get("random_step", 1)), mode=L.MODE_SEQUENTIAL if mode == "sequential" else L.MODE_MINIBATCH,
                   batch_rows=int(batch_rows), min_target=target_range[0], max_target=target_range[1], device=device)
 
 

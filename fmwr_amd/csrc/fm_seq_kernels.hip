@@ -4,6 +4,7 @@
 //
 //   SGD  : solver/SGD_Learner.h:88-138   (L2 lazy decay or cumulative L1 penalty)
 //   FTRL : solver/FTRL_Learner.h:74-116 + calculate_param :158-202
+//   TDAP : solver/TDAP_Learner.h:87-146 + calculate_param :189-233 (its z_w[i] indexing bug kept, SURVEY A-6)
 //
 // Lane mapping inside the wave: the forward and the V update put factor f on lane f (f + 64 for k > 64)
 // and walk the row's nonzeros in row order, so sum_f / sum_sqr_f are accumulated in exactly the
@@ -23,6 +24,7 @@ struct SeqArgs {
   const int64_t* order;
   int64_t count;
   double *V, *w, *sV, *sw, *nV, *nw;
+  double *t1V, *t1w, *t2V, *t2w, *t3V, *t3w;  // TDAP: nu, delta, h (u in nV/nw, z in sV/sw)
   double* scal;
   int k, kp;
   int sorted_rows;  // every row strictly ascending in col => no duplicate column inside a row
@@ -58,12 +60,34 @@ __device__ __forceinline__ double seq_prox(double z, double n, double l1, double
   return -(z - sign * l1) / ((beta + sqrt(n)) / alpha + l2);
 }
 
+// One coordinate's TDAP accumulation (TDAP_Learner.h:97-105): returns nothing, updates the five state values.
+__device__ __forceinline__ void tdap_coord(double g, double theta, double alpha, double egamma, double& u, double& nu, double& delta,
+                                           double& h, double& z) {
+  const double u_old = u;
+  u += g * g;
+  nu += g;
+  const double sigma = (sqrt(u) - sqrt(u_old)) / alpha;
+  delta = egamma * (delta + sigma);
+  h = egamma * (h + sigma * theta);
+  z = nu - h;
+}
+
+__device__ __forceinline__ double tdap_prox(double z, double delta, double l1, double l2) {  // TDAP_Learner.h:208-213
+  if (fabs(z) <= l1) return 0.0;
+  const double sign = z < 0.0 ? -1.0 : 1.0;
+  return -(z - sign * l1) / (delta + l2);
+}
+
 constexpr int FI = 2;  // factor slots per lane: k <= 128
 constexpr int UB = 8;  // nonzeros whose V loads are issued together on the no-duplicate path
 
 template <int KIND>
 __device__ __forceinline__ void seq_w_one(const SeqArgs& a, const Hyper& h, uint32_t c, double x, double mult, double uw) {
-  if constexpr (KIND == UPD_FTRL) {  // FTRL_Learner.h:90-97
+  if constexpr (KIND == UPD_TDAP) {  // TDAP_Learner.h:110-127
+    double u = a.nw[c], nu = a.t1w[c], dl = a.t2w[c], hh = a.t3w[c], z;
+    tdap_coord(mult * x, a.w[c], h.alpha_w, h.egamma, u, nu, dl, hh, z);
+    a.nw[c] = u; a.t1w[c] = nu; a.t2w[c] = dl; a.t3w[c] = hh; a.sw[c] = z;
+  } else if constexpr (KIND == UPD_FTRL) {  // FTRL_Learner.h:90-97
     const double g = mult * x;
     const double n_old = a.nw[c];
     const double n_new = n_old + g * g;
@@ -82,7 +106,12 @@ __device__ __forceinline__ void seq_w_one(const SeqArgs& a, const Hyper& h, uint
 template <int KIND>
 __device__ __forceinline__ void seq_v_one(const SeqArgs& a, const Hyper& h, size_t at, double vv, double sum, double x,
                                           double mult, double uv) {
-  if constexpr (KIND == UPD_FTRL) {  // FTRL_Learner.h:106-111
+  if constexpr (KIND == UPD_TDAP) {  // TDAP_Learner.h:133-141
+    const double g = mult * (sum * x - vv * x * x);
+    double u = a.nV[at], nu = a.t1V[at], dl = a.t2V[at], hh = a.t3V[at], z;
+    tdap_coord(g, vv, h.alpha_v, h.egamma, u, nu, dl, hh, z);
+    a.nV[at] = u; a.t1V[at] = nu; a.t2V[at] = dl; a.t3V[at] = hh; a.sV[at] = z;
+  } else if constexpr (KIND == UPD_FTRL) {  // FTRL_Learner.h:106-111
     const double g = mult * (sum * x - vv * x * x);
     const double n_old = a.nV[at];
     const double n_new = n_old + g * g;
@@ -104,6 +133,7 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
   const int k = a.k, kp = a.kp;
   const bool k0 = h.k0 != 0, k1 = h.k1 != 0;
   double w0 = a.scal[SC_W0], z0 = a.scal[SC_Z0], n0 = a.scal[SC_N0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
+  double t_nu = a.scal[SC_T_NU], t_delta = a.scal[SC_T_DELTA], t_h = a.scal[SC_T_H];
 
   for (int64_t ex = 0; ex < a.count; ++ex) {
     const int64_t row = a.order[ex];
@@ -152,7 +182,9 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
 
     // ---------------------------------------------------------------- w0
     if (k0) {
-      if constexpr (KIND == UPD_FTRL) {  // FTRL_Learner.h:80-86
+      if constexpr (KIND == UPD_TDAP) {  // TDAP_Learner.h:96-106
+        tdap_coord(mult, w0, h.alpha_w, h.egamma, n0, t_nu, t_delta, t_h, z0);
+      } else if constexpr (KIND == UPD_FTRL) {  // FTRL_Learner.h:80-86
         const double n_old = n0;
         n0 += mult * mult;
         const double delta = (sqrt(n0) - sqrt(n_old)) / h.alpha_w;
@@ -247,18 +279,44 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
         }
       }
     }
+    // ---------------------------------------------------------------- TDAP calculate_param, :189-233
+    if constexpr (KIND == UPD_TDAP) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      w0 = -z0 / t_delta;
+      for (int c = 0; c < len; c += 64) {
+        const int t = c + lane;
+        const bool valid = t < len;
+        const uint32_t mycol = valid ? a.col[b + t] : 0u;
+        // sic: z_w is indexed by the POSITION inside the row, not by the column (TDAP_Learner.h:207, SURVEY A-6)
+        if (valid) a.w[mycol] = tdap_prox(a.sw[t], a.t2w[mycol], h.l1w, h.l2w);
+        const int n_in = (len - c < 64) ? len - c : 64;
+        for (int u = 0; u < n_in; ++u) {
+          const uint32_t cu = bcast(mycol, u);
+#pragma unroll
+          for (int i = 0; i < FI; ++i) {
+            const int f = lane + 64 * i;
+            if (f < k) {
+              const size_t at = (size_t)cu * kp + f;
+              a.V[at] = tdap_prox(a.sV[at], a.t2V[at], h.l1v, h.l2v);
+            }
+          }
+        }
+      }
+    }
     // the next example must see these stores (other lanes of this wave wrote them)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   }
 
   if (lane == 0) {
     a.scal[SC_W0] = w0; a.scal[SC_Z0] = z0; a.scal[SC_N0] = n0; a.scal[SC_UW] = uw; a.scal[SC_UV] = uv;
+    a.scal[SC_T_NU] = t_nu; a.scal[SC_T_DELTA] = t_delta; a.scal[SC_T_H] = t_h;
   }
 }
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
   FMX_CHECK(e->k <= 64 * FI, FMX_ERR_INVALID, "sequential mode supports factor.number <= %d", 64 * FI);
-  SeqArgs a{m->row_ptr, m->col, m->val, m->y, d_order, 0, e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw, e->scal,
+  SeqArgs a{m->row_ptr, m->col, m->val, m->y, d_order, 0, e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw,
+            e->dt1V, e->dt1w, e->dt2V, e->dt2w, e->dt3V, e->dt3w, e->scal,
             e->k, e->kp64, m->rows_sorted};
   // bounded launches: a single wave walking millions of examples in one dispatch would run for seconds
   const int64_t CHUNK = 1 << 16;
@@ -269,6 +327,7 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
     switch (e->hyper.kind) {
       case UPD_SGD_L2: hipLaunchKernelGGL(fm_seq_learn_k<UPD_SGD_L2>, dim3(1), dim3(64), 0, e->stream, a, e->hyper); break;
       case UPD_SGD_L1: hipLaunchKernelGGL(fm_seq_learn_k<UPD_SGD_L1>, dim3(1), dim3(64), 0, e->stream, a, e->hyper); break;
+      case UPD_TDAP: hipLaunchKernelGGL(fm_seq_learn_k<UPD_TDAP>, dim3(1), dim3(64), 0, e->stream, a, e->hyper); break;
       default: hipLaunchKernelGGL(fm_seq_learn_k<UPD_FTRL>, dim3(1), dim3(64), 0, e->stream, a, e->hyper); break;
     }
     prof_end(e);

@@ -86,8 +86,9 @@ static int make_hyper(const fmx_config& c, Hyper* h) {
   h->alpha_w = c.alpha_w; h->alpha_v = c.alpha_v; h->beta_w = c.beta_w; h->beta_v = c.beta_v;
   h->min_t = c.min_target; h->max_t = c.max_target;
   h->mean = (c.batch_reduce == FMX_REDUCE_MEAN);
-  if (c.solver == FMX_SOLVER_FTRL) {
-    h->kind = UPD_FTRL;
+  h->egamma = std::exp(-c.gamma);  // solver/TDAP_Learner.h:83
+  if (c.solver == FMX_SOLVER_FTRL || c.solver == FMX_SOLVER_TDAP) {
+    h->kind = c.solver == FMX_SOLVER_FTRL ? UPD_FTRL : UPD_TDAP;
     h->regw = 0; h->regv = 0;
   } else {
     bool l1 = false;
@@ -124,6 +125,8 @@ static int reset_optimizer_state(fmx_engine* e) {
   if (e->dsw) FMX_HIP(hipMemset(e->dsw, 0, p * sizeof(double)));
   if (e->dnV) FMX_HIP(hipMemset(e->dnV, 0, p * e->kp64 * sizeof(double)));
   if (e->dnw) FMX_HIP(hipMemset(e->dnw, 0, p * sizeof(double)));
+  for (double* t : {e->dt1V, e->dt2V, e->dt3V}) if (t) FMX_HIP(hipMemset(t, 0, p * e->kp64 * sizeof(double)));
+  for (double* t : {e->dt1w, e->dt2w, e->dt3w}) if (t) FMX_HIP(hipMemset(t, 0, p * sizeof(double)));
   return FMX_OK;
 }
 
@@ -345,6 +348,7 @@ int fmx_config_default(fmx_config* cfg) {
   cfg->min_target = -1.0; cfg->max_target = 1.0;
   cfg->device = 0;
   cfg->batch_reduce = FMX_REDUCE_MEAN;
+  cfg->gamma = 1e-4;                    // R/fm_solver_control.R:134-139
   return FMX_OK;
 }
 
@@ -355,8 +359,9 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->struct_size == sizeof(fmx_config), FMX_ERR_INVALID, "fmx_config size mismatch (%u vs %zu): header/library skew",
             cfg->struct_size, sizeof(fmx_config));
   FMX_CHECK(cfg->task == FMX_TASK_CLASSIFICATION || cfg->task == FMX_TASK_REGRESSION, FMX_ERR_INVALID, "unknown task...");
-  FMX_CHECK(cfg->solver == FMX_SOLVER_SGD || cfg->solver == FMX_SOLVER_FTRL || cfg->solver == FMX_SOLVER_ALS, FMX_ERR_INVALID,
-            "Unknown solver...");  // src/FM.cpp:85
+  FMX_CHECK(cfg->solver == FMX_SOLVER_SGD || cfg->solver == FMX_SOLVER_FTRL || cfg->solver == FMX_SOLVER_ALS || cfg->solver == FMX_SOLVER_TDAP,
+            FMX_ERR_INVALID, "Unknown solver...");  // src/FM.cpp:85
+  FMX_CHECK(cfg->solver != FMX_SOLVER_TDAP || cfg->mode == FMX_MODE_SEQUENTIAL, FMX_ERR_INVALID, "the TDAP solver runs in FMX_MODE_SEQUENTIAL only");
   FMX_CHECK(cfg->num_factor >= 0 && cfg->num_factor <= 128, FMX_ERR_INVALID, "factor.number must be in 0..128 (got %d)", cfg->num_factor);
   FMX_CHECK(cfg->mode == FMX_MODE_SEQUENTIAL || cfg->mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID, "unknown mode %d", cfg->mode);
   FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
@@ -386,7 +391,12 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
     FMX_TRY(dev_alloc_zero(&e->dV, p * e->kp64));
     FMX_TRY(dev_alloc_zero(&e->dw, p));
     if (e->hyper.kind != UPD_SGD_L2) { FMX_TRY(dev_alloc_zero(&e->dsV, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dsw, p)); }
-    if (e->hyper.kind == UPD_FTRL) { FMX_TRY(dev_alloc_zero(&e->dnV, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dnw, p)); }
+    if (e->hyper.kind == UPD_FTRL || e->hyper.kind == UPD_TDAP) { FMX_TRY(dev_alloc_zero(&e->dnV, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dnw, p)); }
+    if (e->hyper.kind == UPD_TDAP) {
+      FMX_TRY(dev_alloc_zero(&e->dt1V, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dt1w, p));
+      FMX_TRY(dev_alloc_zero(&e->dt2V, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dt2w, p));
+      FMX_TRY(dev_alloc_zero(&e->dt3V, p * e->kp64)); FMX_TRY(dev_alloc_zero(&e->dt3w, p));
+    }
   }
   FMX_HIP(hipDeviceSynchronize());  // the zero fills ran on the null stream; the engine stream does not wait for it
   *out = e.release();
@@ -401,6 +411,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->scal_base);
   (void)hipFree(e->V); (void)hipFree(e->w); (void)hipFree(e->sV); (void)hipFree(e->sw); (void)hipFree(e->nV); (void)hipFree(e->nw);
   (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
+  (void)hipFree(e->dt1V); (void)hipFree(e->dt1w); (void)hipFree(e->dt2V); (void)hipFree(e->dt2w); (void)hipFree(e->dt3V); (void)hipFree(e->dt3w);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;

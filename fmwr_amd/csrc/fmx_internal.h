@@ -42,6 +42,7 @@ enum UpdateKind : int {
   UPD_SGD_L2 = 0,  // solver/SGD_Learner.h:119,135 (lazy L2 on touched coordinates)
   UPD_SGD_L1 = 1,  // solver/SGD_Learner.h:195-204 (cumulative penalty)
   UPD_FTRL = 2,    // solver/FTRL_Learner.h:158-202
+  UPD_TDAP = 3,    // solver/TDAP_Learner.h:79-233 (sequential mode only)
 };
 
 // hyper-parameters as the kernels consume them (passed by value)
@@ -53,6 +54,7 @@ struct Hyper {
   double l1w, l1v, l2w, l2v;    // FTRL prox
   double alpha_w, alpha_v, beta_w, beta_v;
   double min_t, max_t;
+  double egamma;                    // TDAP: exp(-gamma)
   double decay_w, decay_v;          // 1 - lr*reg (SGD lazy L2, one touch)
   double log_decay_w, log_decay_v;  // log of the above, for c touches: exp(c * log)
 };
@@ -66,7 +68,10 @@ enum Scalar : int {
   SC_UV = 4,  // SGD-L1 u_v
   SC_G0 = 5,  // last batch: sum of grad multipliers
   SC_Q0 = 6,  // last batch: sum of squared grad multipliers
-  SC_COUNT = 8
+  SC_T_NU = 7,     // TDAP nu_w0 (u_w0 lives in SC_N0, z_w0 in SC_Z0)
+  SC_T_DELTA = 8,  // TDAP delta_w0
+  SC_T_H = 9,      // TDAP h_w0
+  SC_COUNT = 12
 };
 
 constexpr int WG_THREADS = 256;
@@ -130,6 +135,9 @@ struct fmx_engine {
   double *dV = nullptr, *dw = nullptr;
   double *dsV = nullptr, *dsw = nullptr;
   double *dnV = nullptr, *dnw = nullptr;
+  double *dt1V = nullptr, *dt1w = nullptr;  // TDAP nu   (u in dnV/dnw, z in dsV/dsw)
+  double *dt2V = nullptr, *dt2w = nullptr;  // TDAP delta
+  double *dt3V = nullptr, *dt3w = nullptr;  // TDAP h
   // workspaces (mini-batch)
   int64_t ws_rows = 0;
   int64_t tile_rows = 0;      // rows per tile (<= cfg.batch_rows)

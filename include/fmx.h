@@ -40,6 +40,7 @@ extern "C" {
 #define FMX_SOLVER_ALS 200
 #define FMX_SOLVER_SGD 300
 #define FMX_SOLVER_FTRL 500
+#define FMX_SOLVER_TDAP 600 /* FMX_MODE_SEQUENTIAL only */
 
 /* FMX_MODE_SEQUENTIAL: the reference's algorithm as is -- one example per update, visited in the
  *   reference's order (solver/SGD_Learner.h:86-88), fp64 state.  The parity mode.
@@ -84,6 +85,7 @@ typedef struct fmx_config {
   double max_target;       /* learner->max_target                       */
   int32_t device;          /* HIP device ordinal                        */
   int32_t batch_reduce;    /* FMX_REDUCE_* (mini-batch mode)            */
+  double gamma;            /* TDAP.solver(gamma = 1e-4): decay rate (alpha_w, alpha_v shared with FTRL) */
   int64_t tile_rows;       /* 0: default.  A step of batch_rows rows is processed in tiles of at most this many
                               rows (parameters frozen across the tiles, sums accumulated): keeps the per-tile
                               tables cache resident for large batches.  Does not change any result.           */

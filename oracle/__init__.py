@@ -27,7 +27,7 @@ class Params(C.Structure):
         ("alpha_w", C.c_double), ("beta_w", C.c_double), ("alpha_v", C.c_double), ("beta_v", C.c_double),
         ("random_step", C.c_int32), ("eval_type", C.c_int32),
         ("trace_step", C.c_int64), ("conv_condition", C.c_double),
-        ("batch_mean", C.c_int32), ("pad_", C.c_int32),
+        ("batch_mean", C.c_int32), ("pad_", C.c_int32), ("gamma", C.c_double),
     ]
 
 
@@ -56,6 +56,7 @@ def lib():
         _lib.fmo_evaluate.restype = C.c_double
         _lib.fmo_sgd_learn.restype = C.c_int64
         _lib.fmo_ftrl_learn.restype = C.c_int64
+        _lib.fmo_tdap_learn.restype = C.c_int64
         _lib.fmo_sgd_pass.restype = C.c_int64
         _lib.fmo_visit_order.restype = C.c_int64
         _lib.fmo_random_select.restype = C.c_uint32
@@ -64,9 +65,9 @@ def lib():
 
 def params(task=CLASSIFICATION, k=2, k0=True, k1=True, l1_regw=0.0, l1_regv=0.0, l2_reg0=0.0, l2_regw=0.0,
            l2_regv=0.0, min_target=-1.0, max_target=1.0, learn_rate=0.01, alpha_w=0.1, beta_w=1.0, alpha_v=0.1,
-           beta_v=1.0, random_step=1, eval_type=LL, trace_step=-1, conv_condition=1e-4, batch_mean=True):
+           beta_v=1.0, random_step=1, eval_type=LL, trace_step=-1, conv_condition=1e-4, batch_mean=True, gamma=1e-4):
     return Params(task, k, int(k0), int(k1), l1_regw, l1_regv, l2_reg0, l2_regw, l2_regv, min_target, max_target,
-                  learn_rate, alpha_w, beta_w, alpha_v, beta_v, random_step, eval_type, trace_step, conv_condition, int(batch_mean), 0)
+                  learn_rate, alpha_w, beta_w, alpha_v, beta_v, random_step, eval_type, trace_step, conv_condition, int(batch_mean), 0, gamma)
 
 
 def _ptr(a):
@@ -162,6 +163,11 @@ def sgd_learn(P, X, y, w0, w, v, max_iter, order=None, trace_cap=0):
 def ftrl_learn(P, X, y, w0, w, v, max_iter, order=None, trace_cap=0):
     """solver/FTRL_Learner.h:64-156."""
     return _learn(lib().fmo_ftrl_learn, P, X, y, w0, w, v, max_iter, order, trace_cap)
+
+
+def tdap_learn(P, X, y, w0, w, v, max_iter, order=None, trace_cap=0):
+    """solver/TDAP_Learner.h:79-233."""
+    return _learn(lib().fmo_tdap_learn, P, X, y, w0, w, v, max_iter, order, trace_cap)
 
 
 class SgdMinibatch:

@@ -47,13 +47,14 @@ typedef struct fmo_params {
   double l2_reg0, l2_regw, l2_regv;
   double min_target, max_target;
   double learn_rate;                        /* SGD.solver */
-  double alpha_w, beta_w, alpha_v, beta_v;  /* FTRL.solver */
+  double alpha_w, beta_w, alpha_v, beta_v;  /* FTRL.solver (TDAP.solver uses alpha_w, alpha_v) */
   int32_t random_step;
   int32_t eval_type;   /* tracker metric */
   int64_t trace_step;  /* tracker.step_size, <=0: off */
   double conv_condition;
   int32_t batch_mean;  /* engine semantics only: 1 = per-coordinate MEAN gradient, 0 = SUM */
   int32_t pad_;
+  double gamma;        /* TDAP.solver decay rate */
 } fmo_params;
 
 typedef struct fmo_csr {
@@ -475,6 +476,113 @@ int64_t fmo_ftrl_learn(const fmo_params* P, uint32_t p, double* w0, double* w, d
   }
   if (trace_n) *trace_n = tn;
   free(z_w); free(n_w); free(z_v); free(n_v); free(m_sum); free(scratch);
+  return iter;
+}
+
+/* ------------------------------------------------------------------ solver/TDAP_Learner.h */
+
+/* One coordinate's TDAP accumulation, TDAP_Learner.h:97-105 / :115-126 / :134-141. */
+static void fmo_tdap_coord(double g, double theta, double alpha, double egamma, double* u, double* nu, double* delta, double* h, double* z) {
+  double u_old = *u;
+  *u += g * g;
+  *nu += g;
+  double sigma = (sqrt(*u) - sqrt(u_old)) / alpha;
+  *delta = egamma * (*delta + sigma);
+  *h = egamma * (*h + sigma * theta);
+  *z = *nu - *h;
+}
+
+/* solver/TDAP_Learner.h:79-186 TDAP_Learner::learn + calculate_param :189-233 (init :56-77 folded in).
+ * The shipped indexing bug is kept: calculate_param reads z_w[i] with i the POSITION inside the row, not the column
+ * (:207, SURVEY A-6).  State: 5 arrays per parameter (u, nu, delta, h, z). */
+int64_t fmo_tdap_learn(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                       const fmo_csr* X, const float* y, int64_t max_iter, const int64_t* order,
+                       int64_t* trace_iters, double* trace_vals, int64_t trace_cap, int64_t* trace_n,
+                       int32_t* convergent) {
+  size_t pp = p ? p : 1, kp = (size_t)(P->k ? P->k : 1) * pp;
+  double s0[5] = {0, 0, 0, 0, 0}; /* u, nu, delta, h, z of w0 */
+  double* sw = (double*)calloc(5 * pp, sizeof(double));
+  double* sv = (double*)calloc(5 * kp, sizeof(double));
+  double *u_w = sw, *nu_w = sw + pp, *delta_w = sw + 2 * pp, *h_w = sw + 3 * pp, *z_w = sw + 4 * pp;
+  double *u_v = sv, *nu_v = sv + kp, *delta_v = sv + 2 * kp, *h_v = sv + 3 * kp, *z_v = sv + 4 * kp;
+  double* m_sum = (double*)calloc((size_t)(P->k ? P->k : 1) * 2, sizeof(double));
+  double* m_sum_sqr = m_sum + (P->k ? P->k : 1);
+  double* scratch = (P->trace_step > 0) ? (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1)) : NULL;
+  const double egamma = exp(-P->gamma);
+  int64_t iter = 0, ii = -1, tn = 0;
+  int conv_times = 0;
+  double eval_score_old = 0.0;
+  if (convergent) *convergent = 0;
+  int stop = 0, guard = 0;
+  int64_t opos = 0;
+  for (;;) {
+    int64_t before = iter;
+    uint64_t i = order ? 0 : fmo_random_select(P->random_step);
+    for (;;) {
+      if (order) { if (opos >= max_iter) { stop = 1; break; } i = (uint64_t)order[opos++]; }
+      else if (i >= (uint64_t)X->n) break;
+      {
+        double y_hat = fmo_predict(P, p, *w0, w, v, X, (int64_t)i, m_sum, m_sum_sqr);
+        double mult = fmo_grad_mult(P, &y_hat, y[i]);
+        const int64_t b = X->row_ptr[i], e = X->row_ptr[i + 1];
+        if (P->k0) fmo_tdap_coord(mult, *w0, P->alpha_w, egamma, &s0[0], &s0[1], &s0[2], &s0[3], &s0[4]);
+        if (P->k1)
+          for (int64_t j = b; j < e; ++j) {
+            uint32_t c = X->col[j];
+            fmo_tdap_coord(mult * X->val[j], w[c], P->alpha_w, egamma, &u_w[c], &nu_w[c], &delta_w[c], &h_w[c], &z_w[c]);
+          }
+        for (int f = 0; f < P->k; ++f) {
+          double sum_ = m_sum[f];
+          for (int64_t j = b; j < e; ++j) {
+            size_t at = (size_t)f * p + X->col[j];
+            double g = mult * (sum_ * X->val[j] - v[at] * X->val[j] * X->val[j]);
+            fmo_tdap_coord(g, v[at], P->alpha_v, egamma, &u_v[at], &nu_v[at], &delta_v[at], &h_v[at], &z_v[at]);
+          }
+        }
+        /* calculate_param, :189-233 */
+        *w0 = -s0[4] / s0[2];
+        for (int64_t j = b; j < e; ++j) {
+          uint32_t col_idx = X->col[j];
+          double z = z_w[j - b]; /* sic: position in the row, :207 */
+          if (fabs(z) <= P->l1_regw) w[col_idx] = 0.0;
+          else {
+            double sign = z < 0.0 ? -1.0 : 1.0;
+            w[col_idx] = -(z - sign * P->l1_regw) / (delta_w[col_idx] + P->l2_regw);
+          }
+        }
+        for (int f = 0; f < P->k; ++f)
+          for (int64_t j = b; j < e; ++j) {
+            size_t at = (size_t)f * p + X->col[j];
+            double z = z_v[at];
+            if (fabs(z) <= P->l1_regv) v[at] = 0.0;
+            else {
+              double sign = z < 0.0 ? -1.0 : 1.0;
+              v[at] = -(z - sign * P->l1_regv) / (delta_v[at] + P->l2_regv);
+            }
+          }
+      }
+      if (P->trace_step > 0) {
+        ii++;
+        if (ii == P->trace_step) ii = 0;
+        if (ii == 0 || iter == max_iter - 1) {
+          double eval_score = fmo_track_eval(P, p, *w0, w, v, X, y, scratch);
+          if (iter > P->trace_step && fabs((eval_score - eval_score_old) / (eval_score_old + 1e-30)) <= P->conv_condition) conv_times++;
+          else conv_times = 0;
+          eval_score_old = eval_score;
+          if (tn < trace_cap) { trace_iters[tn] = iter; trace_vals[tn] = eval_score; }
+          tn++;
+        }
+      }
+      iter++;
+      if (conv_times >= 3) { if (convergent) *convergent = 1; stop = 1; break; }
+      if (iter >= max_iter) { stop = 1; break; }
+      if (!order) i += fmo_random_select(P->random_step);
+    }
+    if (stop) break;
+    if (iter == before && ++guard > 1000) break;
+  }
+  if (trace_n) *trace_n = tn;
+  free(sw); free(sv); free(m_sum); free(scratch);
   return iter;
 }
 

@@ -19,6 +19,9 @@ SGD_V0 = [0.010527388918283573, 0.086610025327578929, -0.15601382906491748, -0.0
 SGD_LL = [-4.087788511, -3.760688163, -3.531096602, -3.356440428, -3.215448292, -3.105536052]
 FTRL_W0 = -0.10237722059750001
 FTRL_LL = [-4.097225536, -3.789926011, -3.597139176, -3.45248008, -3.336440102, -3.249096699]
+TDAP_W0 = -0.22442994088195486   # TDAP_Learner class defaults: gamma = 0.001, alpha_w = alpha_v = 0.1, no L1
+TDAP_LL = [-3.937315206, -3.68040471, -3.296405521, -2.9887651, -2.773177912, -2.613076344]
+TDAP_GAMMA = 0.001
 TRACE_ITERS = [0, 10, 20, 30, 40, 49]
 
 

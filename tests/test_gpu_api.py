@@ -73,7 +73,8 @@ def test_update_warm_start_and_errors():
     with pytest.raises(ValueError, match="not the same"):
         fm.fm_update(fit, fm.fm_matrix(X[:, :100], rating))
     with pytest.raises(NotImplementedError):
-        fm.solver_control(solver=fm.TDAP_solver())
+        fm.solver_control(solver=fm.MCMC_solver())
+    assert fm.solver_control()["solver"]["solver"] == "TDAP"  # the reference's default (R/fm_solver_control.R:22)
 
 
 def test_minibatch_mode_through_api_learns():

@@ -98,7 +98,7 @@ def test_errors(fm):
     with pytest.raises(L.FmxError, match="factor.number"):
         engine.Engine(10, num_factor=1000)
     with pytest.raises(L.FmxError, match="Unknown solver"):
-        engine.Engine(10, solver=600)
+        engine.Engine(10, solver=400)  # BGD: declared in util/Macros.h:19, never implemented
     e = engine.Engine(10, num_factor=2, mode=L.MODE_MINIBATCH)
     m = engine.Matrix.from_csr(np.array([0, 1], np.int64), np.array([3], np.uint32), np.array([1.0], np.float32), 11)
     with pytest.raises(L.FmxError, match="number of input's features is not correct"):

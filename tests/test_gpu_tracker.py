@@ -16,13 +16,16 @@ def fm():
     return engine, _lib
 
 
-@pytest.mark.parametrize("solver", ["sgd", "ftrl"])
+@pytest.mark.parametrize("solver", ["sgd", "ftrl", "tdap"])
 def test_reference_ll_trace_kat(fm, solver):
     engine, L = fm
     kw = dict(task=L.TASK_CLASSIFICATION, num_factor=kat.K, l2_w1=kat.L2_REGW, l2_v=kat.L2_REGV, mode=L.MODE_SEQUENTIAL)
     if solver == "sgd":
         e = engine.Engine(kat.P_FEAT, solver=L.SOLVER_SGD, learn_rate=0.05, **kw)
         want = kat.SGD_LL
+    elif solver == "tdap":
+        e = engine.Engine(kat.P_FEAT, solver=L.SOLVER_TDAP, gamma=kat.TDAP_GAMMA, **kw)
+        want = kat.TDAP_LL
     else:
         e = engine.Engine(kat.P_FEAT, solver=L.SOLVER_FTRL, l1_w1=0.001, l1_v=0.001, **kw)
         want = kat.FTRL_LL
@@ -36,6 +39,7 @@ def test_reference_ll_trace_kat(fm, solver):
     w0, w, v = e.get_params()
     s0, sw, sv = r["params"][-1]
     assert s0 == w0 and np.array_equal(sw, w) and np.array_equal(sv, v)
+    assert abs(w0 - {"sgd": kat.SGD_W0, "ftrl": kat.FTRL_W0, "tdap": kat.TDAP_W0}[solver]) < 1e-13
 
 
 def test_metrics_match_oracle(fm):

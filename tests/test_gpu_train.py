@@ -107,6 +107,28 @@ def test_sequential_matches_oracle(fm, c):
     assert np.array_equal(np.sign(out), np.sign(refp))
 
 
+@pytest.mark.parametrize("task", [oracle.CLASSIFICATION, oracle.REGRESSION])
+def test_sequential_tdap_matches_oracle(fm, task):
+    """TDAP (row f-3), sequential mode: the reference's default solver, shipped indexing bug included."""
+    engine, L = fm
+    c = dict(name="tdap%d" % task, solver="tdap", task=task, k=6, l1_regw=1e-3, l1_regv=5e-4, l2_regw=1e-2, l2_regv=1e-2, alpha_v=0.05, gamma=3e-4)
+    rp, col, val, y, P, seed = _problem(c)
+    n, p = len(rp) - 1, 300
+    w0, w, v = util.params(p, P.k, seed, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    iters = 2 * n + 11
+    ref = oracle.tdap_learn(P, X, y, w0, w, v.ravel(), iters)
+    e = engine.Engine(p, task=P.task, solver=L.SOLVER_TDAP, num_factor=P.k, l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv, l2_v=P.l2_regv,
+                      alpha_w=P.alpha_w, alpha_v=P.alpha_v, gamma=P.gamma, mode=L.MODE_SEQUENTIAL, min_target=P.min_target, max_target=P.max_target)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert e.train(m, iters) == iters
+    g0, gw, gv = e.get_params()
+    assert util.rel_err(gv, ref["v"].reshape(P.k, p)) < 1e-10 and util.rel_err(gw, ref["w"]) < 1e-10 and abs(g0 - ref["w0"]) < 1e-10
+    with pytest.raises(L.FmxError, match="SEQUENTIAL only"):
+        engine.Engine(p, solver=L.SOLVER_TDAP, mode=L.MODE_MINIBATCH)
+
+
 def test_sequential_random_step(fm):
     """random_step > 1: strides come from libc rand() (util/Random.h:20-24), unseeded in the reference."""
     engine, L = fm

@@ -33,3 +33,14 @@ def test_ftrl_kat():
     np.testing.assert_allclose(r["trace_vals"], kat.FTRL_LL, rtol=0, atol=5e-10)
     # feature 3 occurs only in row 0 (never visited, A-2) and single-nnz row 3 (pairwise grad == 0)
     assert np.all(r["v"].reshape(kat.K, kat.P_FEAT)[:, 3] == 0.0)
+
+
+def test_tdap_kat():
+    """TDAP is SURVEY row f-3; the reference's own numbers pin the restatement (incl. the z_w[i] bug, A-6)."""
+    P = oracle.params(task=oracle.CLASSIFICATION, k=kat.K, l2_regw=kat.L2_REGW, l2_regv=kat.L2_REGV, gamma=kat.TDAP_GAMMA, random_step=1,
+                      eval_type=oracle.LL, trace_step=kat.TRACE_STEP, conv_condition=0.0)
+    r = oracle.tdap_learn(P, _mat(), kat.Y, 0.0, np.zeros(kat.P_FEAT), kat.harness_v0(), kat.MAX_ITER, trace_cap=16)
+    assert abs(r["w0"] - kat.TDAP_W0) < 1e-15
+    assert list(r["trace_iters"]) == kat.TRACE_ITERS
+    np.testing.assert_allclose(r["trace_vals"], kat.TDAP_LL, rtol=0, atol=5e-10)
+    assert np.all(r["v"].reshape(kat.K, kat.P_FEAT)[:, 3] == 0.0)
