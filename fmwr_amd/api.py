@@ -5,8 +5,8 @@ R/fm_solver_control.R, R/fm_track_control.R, R/fm_matrix.R -> src/FM.cpp).  R is
 same surface is mirrored here with the same names (dots -> underscores), argument meaning, defaults and error
 messages, on top of the C ABI (include/fmx.h).  The Rcpp glue a maintainer would add is in INTEGRATION.md.
 
-Outside the path: the MCMC solver, ALS beyond the V sweep, and column normalisation (normalize=TRUE); asking for them
-raises NotImplementedError.  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
+Outside the path: the MCMC solver and ALS beyond the V sweep; asking for them raises
+NotImplementedError.  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
 """
 import warnings
 
@@ -183,7 +183,19 @@ def _check_labels(data, task):
     return y
 
 
-def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device):
+def _normalize_columns(normalize, p):
+    """R/fm_train.R:75-87: TRUE -> every column, FALSE -> none, or an integer vector of columns (0-based here, R is 1-based)."""
+    if isinstance(normalize, (bool, np.bool_)):
+        return np.arange(p, dtype=np.int32) if normalize else None
+    cols = np.asarray(normalize)
+    if cols.dtype.kind not in "iu":
+        raise TypeError("normalize should be a logical value or an integer vector")
+    if cols.size and (cols.min() < 0 or cols.max() >= p):
+        raise ValueError("the columns to be normalized is out of range")
+    return np.sort(cols).astype(np.int32)
+
+
+def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, norm_cols=None):
     p = data.dim[1]
     y = _check_labels(data, controls["model"]["task"])
     lo, hi = float(y.min()), float(y.max())  # src/FM.cpp:89-90
@@ -192,6 +204,9 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device):
     eng = _engine_for(controls, p, (lo, hi), mode, batch_rows, device)
     eng.set_params(w0, w, v)
     m = _device_matrix(data, y, device)
+    mean = std = None
+    if norm_cols is not None:  # src/FM.cpp:36-38: scales = m.scales(normalize)
+        mean, std = m.scales(norm_cols)
     sol = controls["solver"]["solver"]["solver"]
     if sol == "ALS":
         raise NotImplementedError("ALS training beyond the V sweep is outside the accelerated path (row f-4); use Engine.als_vsweep")
@@ -208,30 +223,29 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device):
     w0, w, v = eng.get_params()
     model = {"w0": w0, "w": w, "v": v, "model.control": controls["model"], "solver.control": controls["solver"],
              "track.control": controls["track"], "convergence": convergent}
-    scales = {"mean": None, "std": None, "model.vars": data.feature_names, "target.range": (lo, hi)}
+    scales = {"mean": mean, "std": std, "model.vars": data.feature_names, "target.range": (lo, hi)}
     fit = {"class": "FM", "Model": model, "Scales": scales, "engine": {"mode": mode, "batch_rows": batch_rows, "device": device}}
     if trace is not None:
         fit["Trace"] = trace
     return fit
 
 
-def fm_train(data, normalize=False, control=None, seed=None, mode="sequential", batch_rows=65536, device=0):
+def fm_train(data, normalize=True, control=None, seed=None, mode="sequential", batch_rows=65536, device=0):
     """fm.train() -- R/fm_train.R:70-127.  `control` is a list of *.control objects.  V0 ~ N(v.init_mean, v.init_stdev)
     is drawn here (the reference draws it from R's RNG inside Model::init, core/Model.h:63-72); `seed` makes it repeatable.
     mode="sequential" is the reference's algorithm; mode="minibatch" the synchronous mini-batch engine."""
     if not isinstance(data, FmMatrix):
         raise TypeError("data must be a fm.matrix object")
-    if normalize:
-        raise NotImplementedError("column normalisation (SMatrix::scales) is outside the accelerated path (row f-2); pass normalize=False")
+    norm_cols = _normalize_columns(normalize, data.dim[1])
     controls = _merge_controls(data, control)
     hp = controls["model"]["hyper.params"]
     k, p = int(hp["factor.number"]), data.dim[1]
     rng = np.random.default_rng(seed)
     v0 = rng.normal(hp["v.init_mean"], hp["v.init_stdev"], (k, p)) if k > 0 else np.zeros((0, p))
-    return _train(data, controls, 0.0, np.zeros(p), v0, None, mode, batch_rows, device)
+    return _train(data, controls, 0.0, np.zeros(p), v0, None, mode, batch_rows, device, norm_cols)
 
 
-def fm_update(object, data, max_iter=None, mode=None, batch_rows=None, device=None):
+def fm_update(object, data, normalize=True, max_iter=None, mode=None, batch_rows=None, device=None):
     """fm.update() -- R/fm_update.R:18-135: continue training from a fitted FM with the controls stored on it.
     Optimizer state (FTRL z/n, SGD q/u) is NOT carried over, exactly as in the reference."""
     if not isinstance(object, dict) or object.get("class") != "FM":
@@ -241,16 +255,41 @@ def fm_update(object, data, max_iter=None, mode=None, batch_rows=None, device=No
     if list(data.feature_names) != list(object["Scales"]["model.vars"]):  # R/fm_update.R:27-37
         raise ValueError("the features in data are not the same as those in FM model")
     mdl = object["Model"]
+    # normalisation settings, R/fm_update.R:39-83 (its interactive readline() branches become errors here)
+    p = data.dim[1]
+    sc = object["Scales"]
+    model_normalized = sc["mean"] is not None
+    model_cols = np.where((np.asarray(sc["mean"]) != 0) | (np.asarray(sc["std"]) != 1))[0].astype(np.int32) if model_normalized else None
+    if isinstance(normalize, (bool, np.bool_)):
+        if normalize:
+            if not model_normalized:
+                raise ValueError("all the features are not normalized in the previously saved model; pass normalize=False or the columns explicitly")
+            norm_cols = model_cols  # "follow the normalization settings in the previously saved model"
+        else:
+            if model_normalized:
+                warnings.warn("some features have been normalized in previously saved model, but those in data will not")
+            norm_cols = None
+    else:
+        norm_cols = _normalize_columns(normalize, p)
+        if model_normalized and not np.array_equal(model_cols, norm_cols):
+            raise ValueError("the selected features to normalize are different from those in previously saved model")
     controls = {"model": mdl["model.control"], "solver": dict(mdl["solver.control"]), "track": mdl["track.control"]}
+    controls["solver"]["max_iter"] = max(10000, 2 * data.dim[0])  # R/fm_update.R:90
     if max_iter is not None:
         controls["solver"]["max_iter"] = int(max_iter)
     eng = object.get("engine", {})
-    return _train(data, controls, mdl["w0"], mdl["w"], mdl["v"], object["Scales"]["target.range"],
-                  mode or eng.get("mode", "sequential"), batch_rows or eng.get("batch_rows", 65536),
-                  eng.get("device", 0) if device is None else device)
+    fit = _train(data, controls, mdl["w0"], mdl["w"], mdl["v"], object["Scales"]["target.range"],
+                 mode or eng.get("mode", "sequential"), batch_rows or eng.get("batch_rows", 65536),
+                 eng.get("device", 0) if device is None else device, norm_cols)
+    if object.get("Trace") is not None and fit.get("Trace") is not None:  # R/fm_update.R:125-133: traces are concatenated
+        old, new = object["Trace"], fit["Trace"]
+        idx = np.concatenate([np.asarray(old["trace"][0]), np.asarray(new["trace"][0]) + np.asarray(old["trace"][0])[-1]])
+        fit["Trace"] = {"trace": [idx] + list(old["trace"][1:]) + list(new["trace"][1:]),
+                        "evaluation.train": np.concatenate([old["evaluation.train"], new["evaluation.train"]])}
+    return fit
 
 
-def predict(object, newdata=None, normalize=False):
+def predict(object, newdata=None, normalize=True):
     """predict.FM() -- R/fm_predict.R:12-34 -> FMPredict (src/FM.cpp:177-214): probabilities for CLASSIFICATION
     (logistic link for SGD/FTRL models), predictions clamped to the training target range for REGRESSION."""
     if newdata is None:
@@ -266,7 +305,11 @@ def predict(object, newdata=None, normalize=False):
     device = object.get("engine", {}).get("device", 0)
     eng = _engine_for(controls, newdata.dim[1], object["Scales"]["target.range"], "sequential", 1, device)
     eng.set_params(mdl["w0"], mdl["w"], mdl["v"])
+    if not normalize and object["Scales"]["mean"] is not None:
+        warnings.warn("some variables in FM model are normalized, but those in newdata will not")
     m = _device_matrix(newdata, None, device)
+    if normalize:  # src/FM.cpp:183-186: m.normalize(scales)
+        m.normalize(object["Scales"]["mean"], object["Scales"]["std"])
     link = L.LINK_LOGISTIC if controls["model"]["task"] == "CLASSIFICATION" else L.LINK_CLAMP
     return eng.predict(m, link)
 

@@ -231,6 +231,99 @@ int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offs
   return FMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ scales / normalize
+// Column sums in the reference run over the entries in storage order, i.e. ascending row inside a column: the full CSC
+// gives exactly that order, so the sums (hence every scaled float) are bit-identical to util/Smatrix.h:104-111.
+__global__ void col_moments_k(const int64_t* __restrict__ col_ptr, const float* __restrict__ cval, uint32_t p, double* __restrict__ sum,
+                              double* __restrict__ sumsq) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= (int64_t)p) return;
+  double s = 0.0, q = 0.0;
+  for (int64_t t = col_ptr[c]; t < col_ptr[c + 1]; ++t) {
+    const double v = cval[t];
+    s += v;
+    q += v * v;
+  }
+  sum[c] = s;
+  sumsq[c] = q;
+}
+
+__global__ void scales_finish_k(uint32_t p, int64_t n, const uint8_t* __restrict__ listed, double* __restrict__ mean, double* __restrict__ std) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= (int64_t)p) return;
+  if (listed[c]) {  // util/Smatrix.h:116-118
+    const double mult_dim = (double)n * ((double)n - 1);
+    std[c] = sqrt(std[c] / (double)(n - 1) - mean[c] * mean[c] / mult_dim);
+    mean[c] /= (double)n;
+  } else {
+    std[c] = 1.0;
+    mean[c] = 0.0;
+  }
+}
+
+__global__ void scales_apply_k(int64_t nnz, const uint32_t* __restrict__ col, float* __restrict__ val, const double* __restrict__ mean,
+                               const double* __restrict__ std) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nnz) return;
+  float v = val[t];
+  v = (float)((double)v - mean[col[t]]);           // value[p] -= colSum[idx]        (:127)
+  v = (float)((double)v / (std[col[t]] + 1e-30));  // value[p] /= (colSumSqr + 1e-30) (:128)
+  val[t] = v;
+}
+
+__global__ void normalize_apply_k(int64_t nnz, const uint32_t* __restrict__ col, float* __restrict__ val, const double* __restrict__ mean,
+                                  const double* __restrict__ std) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nnz) return;
+  const uint32_t i = col[t];
+  if (std[i] != 0) val[t] = (float)(((double)val[t] - mean[i]) / std[i]);  // util/Smatrix.h:148-150
+}
+
+// the cached inverted indices hold copies of the values: drop them so they are rebuilt from the new values
+static void drop_value_caches(fmx_matrix* m) {
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
+  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
+  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
+  m->batch_rows = 0; m->tile_rows = 0;
+}
+
+int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double* h_std) {
+  FMX_CHECK(m->n >= 2, FMX_ERR_INVALID, "scales needs at least two rows");
+  FMX_TRY(build_full_csc(m, nullptr));
+  const uint32_t p = m->p;
+  double *d_mean = nullptr, *d_std = nullptr;
+  uint8_t* d_listed = nullptr;
+  FMX_HIP(hipMalloc(&d_mean, (size_t)p * sizeof(double)));
+  FMX_HIP(hipMalloc(&d_std, (size_t)p * sizeof(double)));
+  FMX_HIP(hipMalloc(&d_listed, (size_t)p));
+  FMX_HIP(hipMemcpy(d_listed, h_listed, (size_t)p, hipMemcpyHostToDevice));
+  const unsigned gp = (unsigned)(((int64_t)p + 255) / 256);
+  hipLaunchKernelGGL(col_moments_k, dim3(gp), dim3(256), 0, nullptr, m->col_ptr, m->cval, p, d_mean, d_std);
+  hipLaunchKernelGGL(scales_finish_k, dim3(gp), dim3(256), 0, nullptr, p, m->n, d_listed, d_mean, d_std);
+  if (m->nnz > 0) hipLaunchKernelGGL(scales_apply_k, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, nullptr, m->nnz, m->col, m->val, d_mean, d_std);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipMemcpy(h_mean, d_mean, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+  FMX_HIP(hipMemcpy(h_std, d_std, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(d_mean); (void)hipFree(d_std); (void)hipFree(d_listed);
+  drop_value_caches(m);
+  return FMX_OK;
+}
+
+int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std) {
+  const uint32_t p = m->p;
+  double *d_mean = nullptr, *d_std = nullptr;
+  FMX_HIP(hipMalloc(&d_mean, (size_t)p * sizeof(double)));
+  FMX_HIP(hipMalloc(&d_std, (size_t)p * sizeof(double)));
+  FMX_HIP(hipMemcpy(d_mean, h_mean, (size_t)p * sizeof(double), hipMemcpyHostToDevice));
+  FMX_HIP(hipMemcpy(d_std, h_std, (size_t)p * sizeof(double), hipMemcpyHostToDevice));
+  if (m->nnz > 0) hipLaunchKernelGGL(normalize_apply_k, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, nullptr, m->nnz, m->col, m->val, d_mean, d_std);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipDeviceSynchronize());
+  (void)hipFree(d_mean); (void)hipFree(d_std);
+  drop_value_caches(m);
+  return FMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ sortedness
 __global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int* __restrict__ unsorted) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

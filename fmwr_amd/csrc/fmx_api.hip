@@ -562,6 +562,25 @@ int fmx_matrix_export(const fmx_matrix* m, int64_t r0, int64_t r1, int64_t* row_
   return FMX_OK;
 }
 
+int fmx_matrix_scales(fmx_matrix* m, const int32_t* norm_columns, int64_t n_norm, double* mean, double* std) {
+  FMX_CHECK(m != nullptr && mean != nullptr && std != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_CHECK(n_norm >= 0 && (n_norm == 0 || norm_columns), FMX_ERR_INVALID, "norm_columns is NULL");
+  FMX_TRY(use_device(m->device));
+  std::vector<uint8_t> listed((size_t)m->p, 0);
+  // util/Smatrix.h:113-124 walks the columns in ascending order against an ascending id list; ids that are out of order
+  // or out of range are never matched there (R/fm_train.R:84-86 rejects them before)
+  int64_t i = 0;
+  for (uint32_t c = 0; c < m->p && i < n_norm; ++c)
+    if ((int64_t)c == (int64_t)norm_columns[i]) { listed[c] = 1; ++i; }
+  return matrix_scales(m, listed.data(), mean, std);
+}
+
+int fmx_matrix_normalize(fmx_matrix* m, const double* mean, const double* std) {
+  FMX_CHECK(m != nullptr && mean != nullptr && std != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_TRY(use_device(m->device));
+  return matrix_normalize(m, mean, std);
+}
+
 int fmx_predict(fmx_engine* e, const fmx_matrix* m, double* out, int link) {
   FMX_TRY(check_pair(e, m));
   FMX_CHECK(out != nullptr || m->n == 0, FMX_ERR_INVALID, "out is NULL");

@@ -208,6 +208,8 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int check_rows_sorted(fmx_matrix* m);
+int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double* h_std);
+int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std);
 
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu);
 

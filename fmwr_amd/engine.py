@@ -57,6 +57,20 @@ class Matrix:
                                              C.c_int64(row_offset), C.byref(h)))
         return cls._wrap(h)
 
+    def scales(self, norm_columns):
+        """SMatrix::scales: z-score the listed columns in place; returns (mean[p], std[p])."""
+        nc = np.ascontiguousarray(norm_columns, np.int32)
+        mean = np.zeros(max(self.p, 1)); std = np.zeros(max(self.p, 1))
+        L.check(L.lib().fmx_matrix_scales(self.h, _p(nc), C.c_int64(len(nc)), _p(mean), _p(std)))
+        return mean[: self.p], std[: self.p]
+
+    def normalize(self, mean, std):
+        """SMatrix::normalize: apply a model's Scales."""
+        mean = np.ascontiguousarray(mean, np.float64); std = np.ascontiguousarray(std, np.float64)
+        if len(mean) != self.p or len(std) != self.p:
+            raise ValueError("the length of scale:mean or scale:std is not equal")  # util/Smatrix.h:143-145
+        L.check(L.lib().fmx_matrix_normalize(self.h, _p(mean), _p(std)))
+
     def export(self, r0=0, r1=None):
         """rows [r0, r1) -> (row_ptr, col, val, y) numpy arrays (row_ptr rebased to 0)."""
         r1 = self.n if r1 is None else r1

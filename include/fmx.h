@@ -134,6 +134,13 @@ int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz);
 int fmx_matrix_export(const fmx_matrix* m, int64_t r0, int64_t r1, int64_t* row_ptr, uint32_t* col,
                       float* val, float* y);
 
+/* ---- preprocessing on the device
+ * SMatrix::scales (util/Smatrix.h:98-135, called at src/FM.cpp:36-38): z-score the stored entries of the listed columns
+ * (ascending 0-based ids, as R passes `normalize - 1`) in place; mean/std: f64[p] outputs = Scales$mean / Scales$std. */
+int fmx_matrix_scales(fmx_matrix* m, const int32_t* norm_columns, int64_t n_norm, double* mean, double* std);
+/* SMatrix::normalize (util/Smatrix.h:137-153, src/FM.cpp:183-186): apply a fitted model's Scales to new data. */
+int fmx_matrix_normalize(fmx_matrix* m, const double* mean, const double* std);
+
 /* ---- the hot path */
 
 /* Model::predict_batch / predict_prob (+ clamp) for every row; out: f64[n] on the host. */

@@ -242,3 +242,19 @@ def ftrl_apply_sums(P, p, state, B, acc):
     lib().fmo_ftrl_apply_sums(C.byref(P), C.c_uint32(p), C.byref(state["w0"]), _ptr(state["w"]), _ptr(state["v"]), C.c_double(B), C.c_double(acc["G0"]), C.c_double(acc["Q0"]),
                               _ptr(acc["Gw"]), _ptr(acc["Qw"]), _ptr(acc["cw"]), _ptr(acc["Gv"]), _ptr(acc["Qv"]),
                               _ptr(state["zn0"]), _ptr(state["z_w"]), _ptr(state["n_w"]), _ptr(state["z_v"]), _ptr(state["n_v"]))
+
+
+def scales(n, p, col, val, norm_columns):
+    """util/Smatrix.h:98-135: returns (scaled float32 values, mean[p], std[p])."""
+    col = np.ascontiguousarray(col, np.uint32); v = np.ascontiguousarray(val, np.float32).copy()
+    nc = np.ascontiguousarray(norm_columns, np.int32)
+    mean = np.zeros(max(p, 1)); std = np.zeros(max(p, 1))
+    lib().fmo_scales(C.c_int64(n), C.c_uint32(p), C.c_int64(len(v)), _ptr(col), _ptr(v), _ptr(nc), C.c_int64(len(nc)), _ptr(mean), _ptr(std))
+    return v, mean[:p], std[:p]
+
+
+def normalize(col, val, mean, std):
+    """util/Smatrix.h:137-153."""
+    col = np.ascontiguousarray(col, np.uint32); v = np.ascontiguousarray(val, np.float32).copy()
+    lib().fmo_normalize(C.c_int64(len(v)), _ptr(col), _ptr(v), _ptr(_f64(mean)), _ptr(_f64(std)))
+    return v

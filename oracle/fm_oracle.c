@@ -97,6 +97,47 @@ int64_t fmo_visit_order(int64_t n, int random_step, int64_t max_iter, int64_t* o
 
 void fmo_srand(unsigned seed) { srand(seed); }
 
+/* ------------------------------------------------------------------ util/Smatrix.h (preprocessing) */
+
+/* util/Smatrix.h:98-135 SMatrix::scales: z-score the STORED entries of the listed columns (ascending 0-based ids),
+ * in place, in float like the reference (two narrowings: after the subtraction and after the division).
+ * mean/std [p] receive Scales$mean / Scales$std (0 / 1 for columns not listed).
+ * The reference reads norm_columns[i] one past its end once every listed column was seen (SURVEY A-17, undefined
+ * behaviour); here running off the list simply means "no more columns". */
+void fmo_scales(int64_t n, uint32_t p, int64_t nnz, const uint32_t* col, float* val, const int32_t* norm_columns,
+                int64_t n_norm, double* mean, double* std) {
+  for (uint32_t c = 0; c < p; ++c) { mean[c] = 0.0; std[c] = 0.0; }
+  for (int64_t t = 0; t < nnz; ++t) {
+    double v = val[t];
+    mean[col[t]] += v;
+    std[col[t]] += v * v;
+  }
+  double mult_dim = (double)(n) * ((double)n - 1);
+  int64_t i = 0;
+  for (uint32_t c = 0; c < p; ++c) {
+    if (i < n_norm && c == (uint32_t)norm_columns[i]) {
+      std[c] = sqrt(std[c] / (n - 1) - mean[c] * mean[c] / mult_dim);
+      mean[c] /= n;
+      i++;
+    } else {
+      std[c] = 1.0;
+      mean[c] = 0.0;
+    }
+  }
+  for (int64_t t = 0; t < nnz; ++t) {
+    val[t] -= mean[col[t]];
+    val[t] /= (std[col[t]] + 1e-30);
+  }
+}
+
+/* util/Smatrix.h:137-153 SMatrix::normalize: apply stored Scales to new data. */
+void fmo_normalize(int64_t nnz, const uint32_t* col, float* val, const double* mean, const double* std) {
+  for (int64_t t = 0; t < nnz; ++t) {
+    uint32_t i = col[t];
+    if (std[i] != 0) val[t] = (val[t] - mean[i]) / std[i];
+  }
+}
+
 /* ------------------------------------------------------------------ core/Model.h */
 
 /* core/Model.h:75-103 Model::predict -- one row; leaves sum_f / sum_sqr_f in m_sum / m_sum_sqr. */

@@ -26,7 +26,7 @@ def test_config0_movielens_shaped_sgd(task):
     data = fm.fm_matrix(X, y)
     ctl = [fm.model_control(task, **{"factor.number": 8, "L2.w1": 1e-3, "L2.v": 1e-3, "v.init_stdev": 0.05}),
            fm.solver_control(max_iter=100_000, solver=fm.SGD_solver(learn_rate=0.02))]
-    fit = fm.fm_train(data, control=ctl, seed=42, mode="sequential")
+    fit = fm.fm_train(data, normalize=False, control=ctl, seed=42, mode="sequential")
     # oracle run from the same V0
     k, p, n = 8, X.shape[1], X.shape[0]
     v0 = np.random.default_rng(42).normal(0.0, 0.05, (k, p))
@@ -39,7 +39,7 @@ def test_config0_movielens_shaped_sgd(task):
     assert np.max(np.abs(fit["Model"]["v"] - rv)) <= 1e-5 * np.max(np.abs(rv))       # north_star: 1e-5 relative on V
     assert np.max(np.abs(fit["Model"]["v"] - rv)) <= 1e-10 * np.max(np.abs(rv))      # in fact ~1e-15
     assert abs(fit["Model"]["w0"] - ref["w0"]) < 1e-10
-    pred = fm.predict(fit, data)
+    pred = fm.predict(fit, data, normalize=False)
     raw = oracle.predict_batch(P, Xo, ref["w0"], ref["w"], ref["v"])
     want = np.clip(raw, yy.min(), yy.max()) if task == "REGRESSION" else 1.0 / (1.0 + np.exp(-raw))
     np.testing.assert_allclose(pred, want, rtol=1e-9, atol=1e-12)
@@ -53,8 +53,8 @@ def test_update_warm_start_and_errors():
     X, rating = _movielens_shaped(n=5000, users=50, items=80, seed=3)
     data = fm.fm_matrix(X, rating)
     ctl = [fm.model_control("REGRESSION", **{"factor.number": 4, "L2.v": 1e-3}), fm.solver_control(max_iter=4000, solver=fm.FTRL_solver(alpha_v=0.05))]
-    fit = fm.fm_train(data, control=ctl, seed=1)
-    fit2 = fm.fm_update(fit, data, max_iter=3000)
+    fit = fm.fm_train(data, normalize=False, control=ctl, seed=1)
+    fit2 = fm.fm_update(fit, data, normalize=False, max_iter=3000)
     # oracle: two learn() calls, parameters carried over, z/n reset
     p, k = X.shape[1], 4
     v0 = np.random.default_rng(1).normal(0.0, 0.01, (k, p))
@@ -71,7 +71,7 @@ def test_update_warm_start_and_errors():
     with pytest.raises(ValueError, match="newdata is null"):
         fm.predict(fit)
     with pytest.raises(ValueError, match="not the same"):
-        fm.fm_update(fit, fm.fm_matrix(X[:, :100], rating))
+        fm.fm_update(fit, fm.fm_matrix(X[:, :100], rating), normalize=False)
     with pytest.raises(NotImplementedError):
         fm.solver_control(solver=fm.MCMC_solver())
     assert fm.solver_control()["solver"]["solver"] == "TDAP"  # the reference's default (R/fm_solver_control.R:22)
@@ -89,8 +89,8 @@ def test_minibatch_mode_through_api_learns():
     y = (score > 0).astype(np.float64)
     data = fm.fm_matrix(X, y)
     ctl = [fm.model_control("CLASSIFICATION", **{"factor.number": k, "v.init_stdev": 0.1}), fm.solver_control(max_iter=20 * n, solver=fm.SGD_solver(learn_rate=0.05))]
-    fit = fm.fm_train(data, control=ctl, seed=0, mode="minibatch", batch_rows=256)
-    acc = np.mean((fm.predict(fit, data) >= 0.5) == (y > 0))
+    fit = fm.fm_train(data, normalize=False, control=ctl, seed=0, mode="minibatch", batch_rows=256)
+    acc = np.mean((fm.predict(fit, data, normalize=False) >= 0.5) == (y > 0))
     assert acc > 0.85, acc
 
 
@@ -106,7 +106,7 @@ def test_track_and_select_through_the_api():
     train, test = fm.fm_matrix(X[:3000], y[:3000]), fm.fm_matrix(X[3000:], y[3000:])
     ctl = [fm.model_control("CLASSIFICATION", **{"factor.number": k, "v.init_stdev": 0.1}),
            fm.solver_control(max_iter=9000, solver=fm.SGD_solver(learn_rate=0.02)), fm.track_control(step_size=1000, evaluate_metric="LL", convergence=0.0)]
-    fit = fm.fm_train(train, control=ctl, seed=4)
+    fit = fm.fm_train(train, normalize=False, control=ctl, seed=4)
     assert list(fit["Trace"]["trace"][0]) == [0, 1000, 2000, 3000, 4000, 5000, 6000, 7000, 8000, 8999]
     assert len(fit["Trace"]["trace"]) == 11 and len(fit["Trace"]["evaluation.train"]) == 10
     ll = fit["Trace"]["evaluation.train"]
@@ -129,3 +129,39 @@ def test_track_and_select_through_the_api():
         fm.fm_track(fit, newdata=test, evaluate_metric="RMSE")
     with pytest.raises(ValueError, match="trace is missing"):
         fm.fm_select(fit)
+
+
+def test_normalize_true_scales_columns_like_the_reference():
+    """fm.train(normalize=TRUE): SMatrix::scales on the stored entries (util/Smatrix.h:98-135), Scales returned, predict
+    applies them (SMatrix::normalize); all against the oracle's restatement."""
+    import fmwr_amd as fm
+    rng = np.random.default_rng(12)
+    n, p, k = 1500, 40, 3
+    X = sp.random(n, p, density=0.2, format="csr", random_state=12, data_rvs=lambda s: rng.normal(2.0, 3.0, s))
+    X.sort_indices()
+    y = rng.normal(0, 1, n)
+    data = fm.fm_matrix(X, y)
+    ctl = [fm.model_control("REGRESSION", **{"factor.number": k, "L2.v": 1e-3}), fm.solver_control(max_iter=2500, solver=fm.SGD_solver(learn_rate=0.01))]
+    fit = fm.fm_train(data, normalize=True, control=ctl, seed=6)
+    sval, mean, std = oracle.scales(n, p, X.indices, X.data, np.arange(p))
+    np.testing.assert_array_equal(fit["Scales"]["mean"], mean)
+    np.testing.assert_array_equal(fit["Scales"]["std"], std)
+    v0 = np.random.default_rng(6).normal(0.0, 0.01, (k, p))
+    P = oracle.params(task=oracle.REGRESSION, k=k, l2_regv=1e-3, learn_rate=0.01, min_target=float(y.min()), max_target=float(y.max()))  # FM.cpp:89-90: min/max of the R (double) labels
+    Xo = oracle.Matrix(X.indptr, X.indices, sval, p)
+    ref = oracle.sgd_learn(P, Xo, y.astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 2500)
+    assert np.max(np.abs(fit["Model"]["v"] - ref["v"].reshape(k, p))) <= 1e-10 * np.max(np.abs(ref["v"]))
+    # predict on new data with the model's Scales
+    Xn = sp.random(300, p, density=0.2, format="csr", random_state=13, data_rvs=lambda s: rng.normal(2.0, 3.0, s)); Xn.sort_indices()
+    pred = fm.predict(fit, fm.fm_matrix(Xn))
+    nval = oracle.normalize(Xn.indices, Xn.data, mean, std)
+    raw = oracle.predict_batch(P, oracle.Matrix(Xn.indptr, Xn.indices, nval, p), ref["w0"], ref["w"], ref["v"])
+    np.testing.assert_allclose(pred, np.clip(raw, P.min_target, P.max_target), rtol=1e-9, atol=1e-11)
+    # a subset of columns, and fm.update following the model's settings
+    fit2 = fm.fm_train(data, normalize=[3, 7, 8], control=ctl, seed=6)
+    _, mean2, std2 = oracle.scales(n, p, X.indices, X.data, [3, 7, 8])
+    np.testing.assert_array_equal(fit2["Scales"]["mean"], mean2)
+    fit3 = fm.fm_update(fit2, data, max_iter=500)
+    np.testing.assert_array_equal(fit3["Scales"]["std"], std2)
+    with pytest.raises(ValueError, match="different from those in previously saved model"):
+        fm.fm_update(fit2, data, normalize=[1, 2])
