@@ -23,6 +23,9 @@ struct SeqArgs {
   const float* y;
   const int64_t* order;
   int64_t count;
+  const int64_t* ex_b;  // per example: first entry, length, label (gathered by seq_prepare_k so the walker reads them in order)
+  const int* ex_len;
+  const float* ex_y;
   double *V, *w, *sV, *sw, *nV, *nw;
   double *t1V, *t1w, *t2V, *t2w, *t3V, *t3w;  // TDAP: nu, delta, h (u in nV/nw, z in sV/sw)
   double* scal;
@@ -127,6 +130,66 @@ __device__ __forceinline__ void seq_v_one(const SeqArgs& a, const Hyper& h, size
   }
 }
 
+// ---- fast example: rows of at most FAST_NZ strictly ascending columns, k <= 64 ---------------------------------------
+// All gathers of the example (V rows, optimizer state, w) are issued as ONE batch into registers, the forward runs from
+// registers in the reference's order, and every coordinate is updated from its registers and stored once.  With no column
+// repeated inside the row, a coordinate's FTRL/TDAP prox depends only on its own state, so it is applied right after the
+// accumulation instead of in a second pass (same values as calculate_param).
+constexpr int FAST_NZ = 32;
+
+template <int KIND> struct SeqState { static constexpr int N = KIND == UPD_SGD_L2 ? 0 : KIND == UPD_SGD_L1 ? 1 : KIND == UPD_FTRL ? 2 : 4; };
+
+// one coordinate's step on registers; `grad` is x for w and (sum*x - theta*x*x) for V.  st: L1 {q}; FTRL {z, n}; TDAP {u, nu, delta, h}
+// returns the z value for TDAP (stored by the caller), 0 otherwise
+template <int KIND>
+__device__ __forceinline__ double coord_seq(const Hyper& h, bool is_w, bool accumulate, double& theta, double grad, double mult,
+                                            double u_pen, double* st) {
+  const double alpha = is_w ? h.alpha_w : h.alpha_v, beta = is_w ? h.beta_w : h.beta_v;
+  const double l1 = is_w ? h.l1w : h.l1v, l2 = is_w ? h.l2w : h.l2v, reg = is_w ? h.regw : h.regv;
+  if constexpr (KIND == UPD_SGD_L2) {
+    theta -= h.lr * mult * grad;
+    theta -= h.lr * reg * theta;
+    return 0.0;
+  } else if constexpr (KIND == UPD_SGD_L1) {
+    theta -= h.lr * mult * grad;
+    seq_penalty(theta, u_pen, st[0]);
+    return 0.0;
+  } else if constexpr (KIND == UPD_FTRL) {
+    if (accumulate) {
+      const double g = mult * grad;
+      const double n_old = st[1];
+      st[1] += g * g;
+      const double delta = (sqrt(st[1]) - sqrt(n_old)) / alpha;
+      st[0] += g - delta * theta;
+    }
+    theta = seq_prox(st[0], st[1], l1, l2, alpha, beta);
+    return 0.0;
+  } else {
+    double z = 0.0;
+    tdap_coord(mult * grad, theta, alpha, h.egamma, st[0], st[1], st[2], st[3], z);
+    if (!is_w) theta = tdap_prox(z, st[2], l1, l2);
+    return z;
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ double* seq_state_ptr(const SeqArgs& a, bool is_w, int j) {
+  if constexpr (KIND == UPD_SGD_L1) return is_w ? a.sw : a.sV;
+  if constexpr (KIND == UPD_FTRL) return j == 0 ? (is_w ? a.sw : a.sV) : (is_w ? a.nw : a.nV);
+  if constexpr (KIND == UPD_TDAP) return j == 0 ? (is_w ? a.nw : a.nV) : j == 1 ? (is_w ? a.t1w : a.t1V) : j == 2 ? (is_w ? a.t2w : a.t2V) : (is_w ? a.t3w : a.t3V);
+  return nullptr;
+}
+
+__global__ void seq_prepare_k(const int64_t* __restrict__ order, int64_t count, const int64_t* __restrict__ row_ptr, const float* __restrict__ y,
+                              int64_t* __restrict__ ex_b, int* __restrict__ ex_len, float* __restrict__ ex_y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t r = order[i];
+  ex_b[i] = row_ptr[r];
+  ex_len[i] = (int)(row_ptr[r + 1] - row_ptr[r]);
+  ex_y[i] = y[r];
+}
+
 template <int KIND>
 __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
   const int lane = threadIdx.x;
@@ -135,12 +198,115 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
   double w0 = a.scal[SC_W0], z0 = a.scal[SC_Z0], n0 = a.scal[SC_N0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
   double t_nu = a.scal[SC_T_NU], t_delta = a.scal[SC_T_DELTA], t_h = a.scal[SC_T_H];
 
+  constexpr int NS = SeqState<KIND>::N;
+  const bool fast_ok = a.sorted_rows && k <= 64;
+  // the first 64 entries of the NEXT example are fetched while the current one is processed
+  uint32_t ncol = 0u;
+  float nx = 0.f;
+  if (a.count > 0 && lane < a.ex_len[0]) { ncol = a.col[a.ex_b[0] + lane]; nx = a.val[a.ex_b[0] + lane]; }
+
   for (int64_t ex = 0; ex < a.count; ++ex) {
-    const int64_t row = a.order[ex];
-    const int64_t b = a.row_ptr[row];
-    const int len = (int)(a.row_ptr[row + 1] - b);
-    const float yv = a.y[row];
+    const int64_t b = a.ex_b[ex];
+    const int len = a.ex_len[ex];
+    const float yv = a.ex_y[ex];
+    const uint32_t ccol = ncol;
+    const float cx = nx;
+    if (ex + 1 < a.count) {
+      const int64_t nb = a.ex_b[ex + 1];
+      const bool nv = lane < a.ex_len[ex + 1];
+      ncol = nv ? a.col[nb + lane] : 0u;
+      nx = nv ? a.val[nb + lane] : 0.f;
+    }
     if constexpr (KIND == UPD_SGD_L1) { uw += h.lr * h.regw; uv += h.lr * h.regv; }  // SGD_Learner.h:92-97
+
+    if (fast_ok && len <= FAST_NZ) {
+      const bool tv = lane < len;            // this lane owns nonzero `lane` (w side)
+      const bool fv = lane < k;              // this lane owns factor `lane` (V side)
+      const uint32_t mycol = tv ? ccol : 0u;
+      const double myx = tv ? (double)cx : 0.0;
+      // ---- one batch of gathers.  Every load is UNCONDITIONAL (idle lanes / slots read a valid dummy address: column 0,
+      // factor 0) -- loads under divergent control flow make the compiler wait vmcnt(0) before every later store, and vmcnt
+      // counts stores too, so each store would wait for the previous one to complete.
+      const int fl = fv ? lane : 0;
+      double myw = a.w[mycol];
+      double stw[NS > 0 ? NS : 1];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) stw[j] = seq_state_ptr<KIND>(a, true, j)[mycol];
+      double vv[FAST_NZ];
+      double stv[NS > 0 ? NS : 1][FAST_NZ];
+#pragma unroll
+      for (int u = 0; u < FAST_NZ; ++u) {
+        const size_t at = (size_t)bcast(mycol, u) * kp + fl;
+        vv[u] = a.V[at];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) stv[j][u] = seq_state_ptr<KIND>(a, false, j)[at];
+      }
+      // ---- forward from registers, core/Model.h:75-103 (row order; linear term first, then the factors in order)
+      double s1 = 0.0, q1 = 0.0;
+      double pred = k0 ? w0 : 0.0;
+      const double wlin = k1 ? myw : 0.0;
+#pragma unroll
+      for (int u = 0; u < FAST_NZ; ++u) {  // slots beyond the row carry x = 0: they add +0.0, which changes nothing
+        const double xu = bcast(myx, u);
+        pred += bcast(wlin, u) * xu;
+        const double tmp = vv[u] * xu;
+        s1 += tmp;
+        q1 += tmp * tmp;
+      }
+      for (int fl = 0; fl < k; ++fl) {
+        const double sf = bcast(s1, fl), qf = bcast(q1, fl);
+        pred += 0.5 * (sf * sf - qf);
+      }
+      const double mult = seq_grad_mult(h, pred, yv);
+      // ---- w0
+      if (k0) {
+        if constexpr (KIND == UPD_TDAP) tdap_coord(mult, w0, h.alpha_w, h.egamma, n0, t_nu, t_delta, t_h, z0);
+        else if constexpr (KIND == UPD_FTRL) {
+          const double n_old = n0;
+          n0 += mult * mult;
+          const double delta = (sqrt(n0) - sqrt(n_old)) / h.alpha_w;
+          z0 += mult - delta * w0;
+        } else w0 -= h.lr * (mult + h.reg0 * w0);
+      }
+      if constexpr (KIND == UPD_FTRL) w0 = -z0 * h.alpha_w / (h.beta_w + sqrt(n0));
+      if constexpr (KIND == UPD_TDAP) w0 = -z0 / t_delta;
+      // ---- w (lane = nonzero)
+      if (tv && (k1 || KIND == UPD_FTRL)) {
+        if constexpr (KIND == UPD_TDAP) {
+          const double z = coord_seq<KIND>(h, true, true, myw, myx, mult, uw, stw);
+          a.sw[mycol] = z;
+        } else {
+          coord_seq<KIND>(h, true, k1, myw, myx, mult, uw, stw);
+          a.w[mycol] = myw;
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) if (k1) seq_state_ptr<KIND>(a, true, j)[mycol] = stw[j];
+      }
+      // ---- V (lane = factor)
+#pragma unroll
+      for (int u = 0; u < FAST_NZ; ++u) {
+        const double xu = bcast(myx, u);
+        const size_t at = (size_t)bcast(mycol, u) * kp + lane;
+        if (u < len && fv) {
+          double th = vv[u];
+          double st[NS > 0 ? NS : 1];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) st[j] = stv[j][u];
+          const double grad = s1 * xu - th * xu * xu;
+          const double z = coord_seq<KIND>(h, false, true, th, grad, mult, uv, st);
+          a.V[at] = th;
+          if constexpr (KIND == UPD_TDAP) a.sV[at] = z;
+#pragma unroll
+          for (int j = 0; j < NS; ++j) seq_state_ptr<KIND>(a, false, j)[at] = st[j];
+        }
+      }
+      if constexpr (KIND == UPD_TDAP) {  // w prox reads z_w by POSITION (TDAP_Learner.h:207): needs every z_w of the example stored
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (tv) a.w[mycol] = tdap_prox(a.sw[lane], k1 ? stw[2] : a.t2w[mycol], h.l1w, h.l2w);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      continue;
+    }
 
     // ---------------------------------------------------------------- forward, core/Model.h:75-103
     double s[FI], q[FI];
@@ -315,13 +481,28 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
   FMX_CHECK(e->k <= 64 * FI, FMX_ERR_INVALID, "sequential mode supports factor.number <= %d", 64 * FI);
-  SeqArgs a{m->row_ptr, m->col, m->val, m->y, d_order, 0, e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw,
+  if (count <= 0) return FMX_OK;
+  if (count > e->seq_cap) {  // grow-only workspace; stream order makes reuse across calls safe
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
+    e->seq_b = nullptr; e->seq_len = nullptr; e->seq_y = nullptr; e->seq_cap = 0;
+    FMX_HIP(hipMalloc(&e->seq_b, (size_t)count * sizeof(int64_t)));
+    FMX_HIP(hipMalloc(&e->seq_len, (size_t)count * sizeof(int)));
+    FMX_HIP(hipMalloc(&e->seq_y, (size_t)count * sizeof(float)));
+    e->seq_cap = count;
+  }
+  int64_t* ex_b = e->seq_b;
+  int* ex_len = e->seq_len;
+  float* ex_y = e->seq_y;
+  hipLaunchKernelGGL(seq_prepare_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, d_order, count, m->row_ptr, m->y, ex_b, ex_len, ex_y);
+  SeqArgs a{m->row_ptr, m->col, m->val, m->y, d_order, 0, ex_b, ex_len, ex_y, e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw,
             e->dt1V, e->dt1w, e->dt2V, e->dt2w, e->dt3V, e->dt3w, e->scal,
             e->k, e->kp64, m->rows_sorted};
   // bounded launches: a single wave walking millions of examples in one dispatch would run for seconds
   const int64_t CHUNK = 1 << 16;
   for (int64_t off = 0; off < count; off += CHUNK) {
     a.order = d_order + off;
+    a.ex_b = ex_b + off; a.ex_len = ex_len + off; a.ex_y = ex_y + off;
     a.count = (count - off < CHUNK) ? count - off : CHUNK;
     prof_begin(e, FMX_KERNEL_SEQ);
     switch (e->hyper.kind) {

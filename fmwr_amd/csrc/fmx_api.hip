@@ -136,6 +136,7 @@ static int ensure_workspace(fmx_engine* e, int64_t tile_rows, int64_t step_rows)
   const int64_t partials = ((tile_rows + rpw - 1) / rpw) * (tiles > 0 ? tiles : 1);
   if (tile_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
   e->S = nullptr; e->amul = nullptr; e->partials = nullptr; e->ws_rows = 0; e->ws_partials = 0;
   FMX_HIP(hipMalloc(&e->S, (size_t)tile_rows * e->kp32 * sizeof(float)));
@@ -412,6 +413,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->V); (void)hipFree(e->w); (void)hipFree(e->sV); (void)hipFree(e->sw); (void)hipFree(e->nV); (void)hipFree(e->nw);
   (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
   (void)hipFree(e->dt1V); (void)hipFree(e->dt1w); (void)hipFree(e->dt2V); (void)hipFree(e->dt2w); (void)hipFree(e->dt3V); (void)hipFree(e->dt3w);
+  (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;

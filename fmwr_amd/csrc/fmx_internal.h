@@ -138,6 +138,11 @@ struct fmx_engine {
   double *dt1V = nullptr, *dt1w = nullptr;  // TDAP nu   (u in dnV/dnw, z in dsV/dsw)
   double *dt2V = nullptr, *dt2w = nullptr;  // TDAP delta
   double *dt3V = nullptr, *dt3w = nullptr;  // TDAP h
+  // workspace of the sequential learner: per-example (first entry, length, label) in visiting order
+  int64_t* seq_b = nullptr;
+  int* seq_len = nullptr;
+  float* seq_y = nullptr;
+  int64_t seq_cap = 0;
   // workspaces (mini-batch)
   int64_t ws_rows = 0;
   int64_t tile_rows = 0;      // rows per tile (<= cfg.batch_rows)
