@@ -25,7 +25,8 @@ MODEL_CONTROL_DEFAULT = {
 }
 SGD_SOLVER_DEFAULT = {"learn_rate": 0.01, "random_step": 1}                                        # R/fm_solver_control.R:91-94
 FTRL_SOLVER_DEFAULT = {"alpha_w": 0.1, "alpha_v": 0.1, "beta_w": 1.0, "beta_v": 1.0, "random_step": 1}  # :109-115
-ALS_SOLVER_DEFAULT = {"alpha_0": 1.0, "gamma_0": 1.0, "beta_0": 1.0, "mu_0": 0.0, "alpha": 1.0, "w0_mean_0": 1.0}  # :64-71
+ALS_SOLVER_DEFAULT = {"alpha_0": 1.0, "gamma_0": 1.0, "beta_0": 1.0, "mu_0": 0.0, "alpha": 1.0, "w0_mean_0": 1.0,  # :64-71
+                      "update_v": False}  # not in the reference: also run the V sweep its update_all leaves out
 
 
 def _control_assign(default, given):
@@ -201,6 +202,8 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, nor
     lo, hi = float(y.min()), float(y.max())  # src/FM.cpp:89-90
     if target_range is not None:               # src/FM.cpp:91-96 (fm.update widens the range)
         lo, hi = min(lo, target_range[0]), max(hi, target_range[1])
+    if controls["solver"]["solver"]["solver"] == "ALS":
+        mode = "sequential"  # ALS works on the fp64 tables
     eng = _engine_for(controls, p, (lo, hi), mode, batch_rows, device)
     eng.set_params(w0, w, v)
     m = _device_matrix(data, y, device)
@@ -208,8 +211,6 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, nor
     if norm_cols is not None:  # src/FM.cpp:36-38: scales = m.scales(normalize)
         mean, std = m.scales(norm_cols)
     sol = controls["solver"]["solver"]["solver"]
-    if sol == "ALS":
-        raise NotImplementedError("ALS training beyond the V sweep is outside the accelerated path (row f-4); use Engine.als_vsweep")
     track = controls["track"]
     trace, convergent = None, False
     if track["step_size"] > 0:  # learner->tracker.step_size > 0: Learner::learn evaluates, snapshots and may stop early
@@ -218,6 +219,10 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, nor
         convergent = r["convergent"]
         # Tracker::save (core/Tracker.h:96-119): trace = list(record_index, {w0,w,v}...), evaluation.train
         trace = {"trace": [r["iters"]] + [{"w0": a, "w": b, "v": c} for (a, b, c) in r["params"]], "evaluation.train": r["evals"]}
+    elif sol == "ALS":  # MCMC_ALS_Learner::learn; as shipped it never sweeps V (SURVEY A-1) unless als_update_v is asked for
+        if controls["model"]["task"] != "REGRESSION":
+            raise NotImplementedError("ALS on the device covers REGRESSION (the classification residual needs the reference's probit tables)")
+        eng.als_train(m, controls["solver"]["max_iter"], with_v=bool(controls["solver"]["solver"].get("update_v", False)))
     else:
         eng.train(m, controls["solver"]["max_iter"])
     w0, w, v = eng.get_params()

@@ -103,6 +103,90 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
   }
 }
 
+// ---- w0 and w sweeps of the ALS learner (MCMC_ALS_Learner.h:162-270, ALS branch, the exact one-thread form) -------------
+__global__ void als_residual_k(const double* __restrict__ yhat, const float* __restrict__ y, int64_t n, double2* __restrict__ qe) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) qe[r] = make_double2(0.0, yhat[r] - (double)y[r]);  // calculate_error, REGRESSION, :520-527
+}
+
+constexpr int ALS_SLAB = 4096;
+__global__ __launch_bounds__(WG_THREADS) void als_w0_partial_k(const double2* __restrict__ qe, int64_t n, const double* __restrict__ scal,
+                                                              double* __restrict__ partials) {
+  __shared__ double red[WG_THREADS];
+  const double w0 = scal[SC_W0];
+  const int64_t base = (int64_t)blockIdx.x * ALS_SLAB;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < ALS_SLAB; i += WG_THREADS) {
+    const int64_t r = base + i;
+    if (r < n) acc += qe[r].y - w0;  // :166-167
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = WG_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// one workgroup: finish the sum, set the new w0, leave (old - new) in partials[n_partials]
+__global__ __launch_bounds__(WG_THREADS) void als_w0_final_k(double* __restrict__ partials, int64_t n_partials, int64_t n, double* __restrict__ scal,
+                                                            double reg0, double alpha, double w0_mean_0) {
+  __shared__ double red[WG_THREADS];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n_partials; i += WG_THREADS) acc += partials[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = WG_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double err = red[0];
+  const double w0_var = 1.0 / (reg0 + alpha * (double)n);               // :169
+  const double w0_mean = -(alpha * err - w0_mean_0 * reg0) * w0_var;    // :170
+  const double w0_old = scal[SC_W0];
+  double w0_new = w0_mean;
+  if (isnan(w0_new) || isinf(w0_new)) w0_new = w0_old;                  // CHECK_PARAM, :180
+  scal[SC_W0] = w0_new;
+  partials[n_partials] = w0_old - w0_new;
+}
+
+__global__ void als_shift_k(double2* __restrict__ qe, int64_t n, const double* __restrict__ diff) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) qe[r].y -= *diff;  // :184-187
+}
+
+// one wave per feature of the level: w sweep, :208-256 with one thread's residual
+__global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
+                                                            const uint32_t* __restrict__ crow, const float* __restrict__ cval,
+                                                            double* __restrict__ w, double2* __restrict__ qe, double alpha, double lambda, double mu) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6);
+  if (wid >= n_feats) return;
+  const uint32_t i = feats[wid];
+  const int64_t b = col_ptr[i], e = col_ptr[i + 1];
+  const double w_old = w[i];
+  double w_mean = 0.0, w_var = 0.0;
+  for (int64_t t = b + lane; t < e; t += 64) {
+    const double x = (double)cval[t];
+    w_mean += qe[crow[t]].y * x - w_old * x * x;
+    w_var += x * x;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    w_mean += __shfl_xor(w_mean, off);
+    w_var += __shfl_xor(w_var, off);
+  }
+  w_var = 1.0 / (lambda + alpha * w_var);
+  w_mean = -w_var * (alpha * w_mean - mu * lambda);
+  const double w_new = bad_number(w_var) ? 0.0 : w_mean;
+  if (bad_number(w_new)) return;  // CHECK_PARAM: keep the old value, skip the corrections
+  if (lane == 0) w[i] = w_new;
+  const double w_diff = w_old - w_new;
+  for (int64_t t = b + lane; t < e; t += 64) qe[crow[t]].y -= (double)cval[t] * w_diff;
+}
+
 // the level plan depends on the matrix only: built once, kept in the fmx_matrix
 static int build_plan(fmx_matrix* m, hipStream_t stream) {
   if (m->als_feats) return FMX_OK;
@@ -137,15 +221,11 @@ static int build_plan(fmx_matrix* m, hipStream_t stream) {
   return FMX_OK;
 }
 
-int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_qe_raw, double alpha, const double* h_lambda, const double* h_mu) {
-  FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweep needs every row's columns strictly ascending (as R's dgCMatrix rows are)");
-  FMX_TRY(build_full_csc(m, e->stream));
-  FMX_TRY(build_plan(m, e->stream));
-  double2* d_qe = reinterpret_cast<double2*>(d_qe_raw);
+// V sweep over all factors on the interleaved (q, e) pairs
+static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu) {
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   const std::vector<int64_t>& level_ptr = m->als_level_ptr;
   const int L = (int)level_ptr.size() - 1;
-  hipLaunchKernelGGL(als_pack_k, dim3(row_grid), dim3(256), 0, e->stream, d_error, m->n, d_qe);
   for (int f = 0; f < e->k; ++f) {
     hipLaunchKernelGGL(als_q_init_k, dim3(row_grid), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_qe);
     const double lambda = h_lambda ? h_lambda[f] : 0.0, mu = h_mu ? h_mu[f] : 0.0;
@@ -157,6 +237,68 @@ int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q
                          m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_qe, alpha, lambda, mu);
     }
   }
+}
+
+// MCMC_ALS_Learner::learn for the ALS learner, REGRESSION (:91-156): per iteration a fresh forward, e = y_hat - y, the w0
+// update, the w sweep; with_v adds the V sweep the shipped update_all leaves out (SURVEY A-1).  init() fixes alpha = 1,
+// w0_mean_0 = 0 and all lambda / mu = 0 (A-7), so the R-side solver parameters do not enter.
+int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
+  FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
+  FMX_CHECK(e->cfg.task == FMX_TASK_REGRESSION, FMX_ERR_INVALID, "ALS on the device covers REGRESSION (the classification residual needs the reference's probit tables)");
+  FMX_TRY(build_full_csc(m, e->stream));
+  FMX_TRY(build_plan(m, e->stream));
+  const int64_t n = m->n;
+  const unsigned row_grid = (unsigned)((n + 255) / 256);
+  const int64_t np = (n + ALS_SLAB - 1) / ALS_SLAB;
+  double *d_yhat = nullptr, *d_part = nullptr;
+  double2* d_qe = nullptr;
+  FMX_HIP(hipMalloc(&d_yhat, (size_t)n * sizeof(double)));
+  if (hipMalloc(&d_qe, (size_t)n * sizeof(double2)) != hipSuccess || hipMalloc(&d_part, ((size_t)np + 1) * sizeof(double)) != hipSuccess) {
+    (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part);
+    set_error("out of device memory"); return FMX_ERR_HIP;
+  }
+  const std::vector<int64_t>& level_ptr = m->als_level_ptr;
+  const int L = (int)level_ptr.size() - 1;
+  int st = FMX_OK;
+  for (int it = 0; it < max_iter && st == FMX_OK; ++it) {
+    RowsArgs a{};
+    a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = n;
+    a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
+    st = launch_rows_forward(e, a, false, true);  // fm->predict_batch(train, train_err), :100
+    if (st != FMX_OK) break;
+    hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe);
+    if (e->hyper.k0) {
+      hipLaunchKernelGGL(als_w0_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, e->scal, d_part);
+      hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, 1.0, 0.0);
+      hipLaunchKernelGGL(als_shift_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, n, d_part + np);
+    }
+    if (e->hyper.k1) {
+      for (int l = 0; l < L; ++l) {
+        const int64_t cnt = level_ptr[(size_t)l + 1] - level_ptr[(size_t)l];
+        if (cnt == 0) continue;
+        const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
+        hipLaunchKernelGGL(als_w_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
+                           m->col_ptr, m->crow, m->cval, e->dw, d_qe, 1.0, 0.0, 0.0);
+      }
+    }
+    if (with_v && e->k > 0) v_sweep_enqueue(e, m, d_qe, 1.0, nullptr, nullptr);
+  }
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part);
+  FMX_TRY(st);
+  FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "ALS training failed: %s", hipGetErrorString(err));
+  return FMX_OK;
+}
+
+int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_qe_raw, double alpha, const double* h_lambda, const double* h_mu) {
+  FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweep needs every row's columns strictly ascending (as R's dgCMatrix rows are)");
+  FMX_TRY(build_full_csc(m, e->stream));
+  FMX_TRY(build_plan(m, e->stream));
+  double2* d_qe = reinterpret_cast<double2*>(d_qe_raw);
+  const unsigned row_grid = (unsigned)((m->n + 255) / 256);
+  hipLaunchKernelGGL(als_pack_k, dim3(row_grid), dim3(256), 0, e->stream, d_error, m->n, d_qe);
+  v_sweep_enqueue(e, m, d_qe, alpha, h_lambda, h_mu);
   hipLaunchKernelGGL(als_unpack_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, m->n, d_error);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(e->stream);

@@ -883,6 +883,16 @@ int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, co
   return st;
 }
 
+int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "ALS runs on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  FMX_TRY(use_device(e->cfg.device));
+  if (m->n == 0 || max_iter == 0) return FMX_OK;
+  return launch_als_train(e, m, max_iter, with_v);
+}
+
 int fmx_profile_enable(fmx_engine* e, int on) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_TRY(prof_collect(e));

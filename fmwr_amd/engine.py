@@ -201,6 +201,9 @@ class Engine:
         L.check(L.lib().fmx_als_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu)))
         return error
 
+    def als_train(self, m, max_iter, with_v=False):
+        L.check(L.lib().fmx_als_train(self.h, m.h, C.c_int32(max_iter), C.c_int32(int(with_v))))
+
     def profile(self, every=1):
         """every = 0: off; n > 0: HIP-event time every n-th launch of each kernel."""
         L.check(L.lib().fmx_profile_enable(self.h, C.c_int(int(every))))

@@ -215,6 +215,13 @@ int fmx_predict_device(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r
 int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda,
                    const double* v_mu);
 
+/* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
+ * w0 update (:162-188); w sweep (:190-270, the exact one-thread form) }.  As shipped the reference never sweeps V (its
+ * update_v call is commented out, :151-155): with_v = 0 reproduces that, with_v = 1 adds the V sweep after the w sweep.
+ * The R-side ALS.solver parameters are overridden by learner->init() in the reference and do not enter (alpha = 1,
+ * lambdas = 0).  Needs an FMX_MODE_SEQUENTIAL engine (fp64 tables). */
+int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v);
+
 /* ---- measurement: HIP-event timing of each kernel on the engine's stream (bench.py roofline leg). */
 #define FMX_KERNEL_ROWS_FORWARD 0 /* phase 1: V-row gather + forward + grad multiplier */
 #define FMX_KERNEL_COLS_UPDATE 1  /* phase 2: per-feature gradient sums + update */

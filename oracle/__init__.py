@@ -258,3 +258,15 @@ def normalize(col, val, mean, std):
     col = np.ascontiguousarray(col, np.uint32); v = np.ascontiguousarray(val, np.float32).copy()
     lib().fmo_normalize(C.c_int64(len(v)), _ptr(col), _ptr(v), _ptr(_f64(mean)), _ptr(_f64(std)))
     return v
+
+
+def als_learn(P, X, y, w0, w, v, max_iter, with_v=False):
+    """solver/MCMC_ALS_Learner.h:91-156 (ALS learner, regression): returns (w0, w, v)."""
+    col_ptr, row_idx, val_t = X.transpose()
+    row_idx = np.ascontiguousarray(row_idx); val_t = np.ascontiguousarray(val_t)
+    y = np.ascontiguousarray(y, np.float32)
+    w = _f64(w).copy(); v = _f64(v).copy()
+    w0c = C.c_double(w0)
+    lib().fmo_als_learn(C.byref(P), C.c_uint32(X.p), C.byref(w0c), _ptr(w), _ptr(v), C.byref(X.c), _ptr(col_ptr), _ptr(row_idx), _ptr(val_t),
+                        _ptr(y), C.c_int(max_iter), C.c_int(int(with_v)))
+    return w0c.value, w, v

@@ -699,6 +699,63 @@ void fmo_als_update_v(int k, uint32_t p, double* v, int64_t n, const int64_t* co
   }
 }
 
+/* solver/MCMC_ALS_Learner.h:162-188 update_w0, ALS branch (do_sample == false; alpha = alpha_0). */
+static void fmo_als_update_w0(const fmo_params* P, double* w0, double* error, int64_t n, double alpha, double w0_mean_0) {
+  double err = 0;
+  for (int64_t i = 0; i < n; ++i) err += error[i] - *w0;
+  double w0_var = (double)1.0 / (P->l2_reg0 + alpha * n);
+  double w0_mean = -(alpha * err - w0_mean_0 * P->l2_reg0) * w0_var;
+  double w0_old = *w0, w0_new = w0_mean;
+  if (fmo_bad(w0_new)) w0_new = w0_old; /* CHECK_PARAM */
+  *w0 = w0_new;
+  double diff_w0 = w0_old - w0_new;
+  for (int64_t i = 0; i < n; ++i) error[i] -= diff_w0;
+}
+
+/* solver/MCMC_ALS_Learner.h:190-270 update_w, ALS branch, nthreads == 1 (the exact, sequential form: with one thread
+ * the per-thread residual copy IS the residual).  w_lambda / w_mu: the one attribute group's values (0 for ALS, :73-76,:400-405). */
+static void fmo_als_update_w(uint32_t p, double* w, const int64_t* col_ptr, const uint32_t* row_idx, const float* val_t,
+                             double* error, double alpha, double w_lambda, double w_mu) {
+  for (uint32_t i = 0; i < p; ++i) {
+    double w_mean = 0.0, w_var = 0.0;
+    double w_old = w[i], w_ = w[i];
+    int update_err = 1;
+    for (int64_t j = col_ptr[i]; j < col_ptr[i + 1]; ++j) {
+      double val_ = val_t[j];
+      w_mean += error[row_idx[j]] * val_ - w_ * val_ * val_;
+      w_var += val_ * val_;
+    }
+    w_var = (double)1.0 / (w_lambda + alpha * w_var);
+    w_mean = -w_var * (alpha * w_mean - w_mu * w_lambda);
+    if (fmo_bad(w_var)) w_ = 0.0; else w_ = w_mean;
+    if (fmo_bad(w_)) { w_ = w_old; update_err = 0; }
+    w[i] = w_;
+    if (update_err) {
+      double w_diff = w_old - w_;
+      for (int64_t j = col_ptr[i]; j < col_ptr[i + 1]; ++j) error[row_idx[j]] -= val_t[j] * w_diff;
+    }
+  }
+}
+
+/* solver/MCMC_ALS_Learner.h:91-156 learn + update_all for the ALS learner on a REGRESSION task: per iteration a fresh
+ * predict_batch, e = y_hat - y (:520-527), update_w0, update_w.  As shipped, update_all never calls update_v (SURVEY A-1);
+ * with_v != 0 adds the V sweep (:272-354) after the w sweep, on the carried residual -- the engine's extension.
+ * init() resets the solver parameters (A-7): alpha = 1, w0_mean_0 = 0, lambdas = 0, mus = 0. */
+void fmo_als_learn(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, const fmo_csr* X,
+                   const int64_t* col_ptr, const uint32_t* row_idx, const float* val_t, const float* y, int max_iter, int with_v) {
+  double* error = (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1));
+  double* v_q = (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1));
+  double* zeros = (double*)calloc((size_t)(P->k ? P->k : 1), sizeof(double));
+  for (int it = 0; it < max_iter; ++it) {
+    fmo_predict_batch(P, p, *w0, w, v, X, error);
+    fmo_als_error_regression(error, y, X->n);
+    if (P->k0) fmo_als_update_w0(P, w0, error, X->n, 1.0, 0.0);
+    if (P->k1) fmo_als_update_w(p, w, col_ptr, row_idx, val_t, error, 1.0, 0.0, 0.0);
+    if (with_v && P->k > 0) fmo_als_update_v(P->k, p, v, X->n, col_ptr, row_idx, val_t, error, v_q, 1.0, zeros, zeros);
+  }
+  free(error); free(v_q); free(zeros);
+}
+
 /* ================================================================== engine semantics (not in reference)
  * Synchronous mini-batch steps of the MI355X engine, fp64.  Every example of rows [b0,b1) is
  * evaluated at the batch-start parameters; per touched coordinate the per-example gradients are

@@ -165,3 +165,22 @@ def test_normalize_true_scales_columns_like_the_reference():
     np.testing.assert_array_equal(fit3["Scales"]["std"], std2)
     with pytest.raises(ValueError, match="different from those in previously saved model"):
         fm.fm_update(fit2, data, normalize=[1, 2])
+
+
+def test_als_solver_through_the_api():
+    import fmwr_amd as fm
+    rng = np.random.default_rng(15)
+    n, p, k = 2000, 50, 2
+    X = sp.random(n, p, density=0.1, format="csr", random_state=15, data_rvs=lambda s: rng.normal(0, 1, s)); X.sort_indices()
+    y = X @ rng.normal(0, 1, p) + rng.normal(0, 0.1, n)
+    data = fm.fm_matrix(X, y)
+    with pytest.warns(UserWarning, match="maximum number of iteratorions"):
+        sc = fm.solver_control(max_iter=500, solver=fm.ALS_solver())
+    assert sc["max_iter"] == 100
+    fit = fm.fm_train(data, normalize=False, control=[fm.model_control("REGRESSION", **{"factor.number": k}), fm.solver_control(max_iter=5, solver=fm.ALS_solver())], seed=2)
+    v0 = np.random.default_rng(2).normal(0.0, 0.01, (k, p))
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    r0, rw, rv = oracle.als_learn(P, oracle.Matrix(X.indptr, X.indices, X.data, p), y.astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 5)
+    assert abs(fit["Model"]["w0"] - r0) < 1e-10 and np.max(np.abs(fit["Model"]["w"] - rw)) < 1e-9
+    pred = fm.predict(fit, data, normalize=False)
+    assert np.mean((pred - y) ** 2) < 0.1 * np.var(y)  # the linear part is recovered

@@ -339,3 +339,27 @@ def test_tiled_step_equals_the_batch_semantics(fm, name, reduce):
         e2.sync()
         h0, hw, hv = e2.get_params()
         assert util.rel_err(hv, gv) < 1e-6 and util.rel_err(hw, gw) < 1e-6 and abs(h0 - g0) < 1e-6 * max(1.0, abs(g0))
+
+
+@pytest.mark.parametrize("with_v", [False, True])
+def test_als_training_loop_matches_oracle(fm, with_v):
+    """MCMC_ALS_Learner::learn, ALS learner, regression: w0 update + w sweep per iteration (row f-4); as shipped V stays
+    untouched (SURVEY A-1), with_v adds the sweep."""
+    engine, L = fm
+    n, p, k = 1200, 90, 3
+    rp, col, val = util.random_csr(n, p, 6, seed=61, empty_rows=True)
+    y = util.labels(n, 61, "regression")
+    w0, w, v = util.params(p, k, 61, stdev=0.2, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=k, l2_reg0=0.05)
+    r0, rw, rv = oracle.als_learn(P, X, y, w0, w, v.ravel(), 4, with_v=with_v)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, l2_w0=0.05, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    e.als_train(m, 4, with_v=with_v)
+    g0, gw, gv = e.get_params()
+    assert abs(g0 - r0) < 1e-10 and util.rel_err(gw, rw) < 1e-10 and util.rel_err(gv, rv.reshape(k, p)) < 1e-10
+    if not with_v:
+        assert np.array_equal(gv, v)  # the reference's ALS never moves V
+    sse = lambda a, b, c: float(np.sum((oracle.predict_batch(P, X, a, b, np.asarray(c).ravel()) - y) ** 2))
+    assert sse(g0, gw, gv) < sse(w0, w, v)
