@@ -339,10 +339,15 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   const int tid = threadIdx.x;
   const int gid = tid / LPR;
   const int lig = tid % LPR;
-  const int64_t J0 = (int64_t)blockIdx.x * FPW;
-  const int64_t J1 = (J0 + FPW < (int64_t)T.p) ? J0 + FPW : (int64_t)T.p;
-  const int64_t j = J0 + gid;
-  const bool have = j < (int64_t)T.p;
+  // lists of this workgroup: features J0.. (dense walk) or the J0..-th occurring features (sparse tile)
+  const int64_t n_lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)T.p;
+  const int64_t I0 = (int64_t)blockIdx.x * FPW;
+  const int64_t I1 = (I0 + FPW < n_lists) ? I0 + FPW : n_lists;
+  const bool have = I0 + gid < n_lists;
+  const int64_t j = !have ? 0 : (a.tfeat ? (int64_t)a.tfeat[I0 + gid] : I0 + gid);
+  // list offsets: the dense per-feature array, or its compact copy for the occurring features (their entries are
+  // contiguous: the features between them have none)
+  const uint32_t* __restrict__ off = a.tfeat ? a.toff : a.bptr;
 
   float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (have) v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
@@ -362,9 +367,9 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   float* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
 
   if (a.walk) {
-    const int64_t lo = a.bptr[J0], hi = a.bptr[J1];
+    const int64_t lo = off[I0], hi = off[I1];
     int64_t ta = 0, tb = 0;
-    if (have) { ta = a.bptr[j]; tb = a.bptr[j + 1]; }
+    if (have) { ta = off[I0 + gid]; tb = off[I0 + gid + 1]; }
     const float* __restrict__ St = T.S + lig * VEC;
     for (int64_t c0 = lo; c0 < hi; c0 += STAGE_ENTRIES) {
       const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
@@ -495,8 +500,8 @@ template <int KIND>
 static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const ColsTables& T) {
   const int lpr = e->kp32 / 4;
   const int fpw = WG_THREADS / lpr;
-  const int64_t grid = ((int64_t)T.p + fpw - 1) / fpw;
-  if (grid == 0) return FMX_OK;
+  const int64_t lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)T.p;
+  const int64_t grid = lists > 0 ? (lists + fpw - 1) / fpw : 1;  // at least workgroup 0: it also does the w0 step
   FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "cols_update: grid too large");
   dim3 g((unsigned)grid), b(WG_THREADS);
 #define FMX_COLS_CASE(L) \

@@ -98,6 +98,19 @@ static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r
   return FMX_OK;
 }
 
+// flags[j] = feature j has at least one entry in the tile
+__global__ void touched_flags_k(const uint32_t* __restrict__ bptr, uint32_t p, uint8_t* __restrict__ flags) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < (int64_t)p) flags[j] = bptr[j + 1] > bptr[j];
+}
+
+__global__ void touched_offsets_k(const uint32_t* __restrict__ bptr, const uint32_t* __restrict__ tfeat, uint32_t n, uint32_t end,
+                                  uint32_t* __restrict__ toff) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)n) toff[i] = bptr[tfeat[i]];
+  else if (i == (int64_t)n) toff[i] = end;
+}
+
 __global__ void gather_rows_k(const int64_t* __restrict__ src, const int64_t* __restrict__ rows, int64_t count, int64_t* __restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) dst[i] = src[rows[i]];
@@ -107,8 +120,8 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
   FMX_CHECK(batch_rows > 0 && tile_rows > 0, FMX_ERR_INVALID, "batch_rows and tile_rows must be positive");
   if (m->batch_rows == batch_rows && m->tile_rows == tile_rows && m->bptr) return FMX_OK;
   FMX_HIP(hipSetDevice(m->device));
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
-  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr;
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff);
+  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->tfeat = nullptr; m->toff = nullptr;
   // steps of batch_rows rows, each cut into tiles of at most tile_rows rows
   const int64_t nb = (m->n + batch_rows - 1) / batch_rows;
   m->batch_rows = batch_rows;
@@ -154,6 +167,48 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     const int64_t base = m->h_row_ptr_batches[t], cnt = m->h_row_ptr_batches[t + 1] - base;
     FMX_TRY(csc_of_range<uint32_t>(m, s, bits, r0, nrows, base, cnt, m->brow + base, m->bval + base,
                                    m->bptr + (size_t)t * ((size_t)m->p + 1), stream));
+  }
+  // Sparse tiles: when a tile holds fewer entries than half the features, most features do not occur in it and the
+  // per-feature walk should skip them: keep the ascending list of the features that do occur.
+  m->tfeat_ptr.assign((size_t)nt + 1, 0);
+  int64_t total = 0;
+  for (int64_t t = 0; t < nt; ++t) {
+    const int64_t cnt = m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t];
+    m->tfeat_ptr[(size_t)t] = total;
+    if (cnt * 2 < (int64_t)m->p) total += cnt;  // upper bound of the list length
+  }
+  m->tfeat_ptr[(size_t)nt] = total;
+  if (total > 0) {
+    FMX_HIP(hipMalloc(&m->tfeat, (size_t)total * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&m->toff, ((size_t)total + (size_t)nt) * sizeof(uint32_t)));
+    uint8_t* d_flags = nullptr;
+    uint32_t* d_count = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    FMX_HIP(hipMalloc(&d_flags, (size_t)m->p));
+    FMX_HIP(hipMalloc(&d_count, sizeof(uint32_t)));
+    rocprim::counting_iterator<uint32_t> ids(0);
+    FMX_HIP(rocprim::select(nullptr, tmp_bytes, ids, d_flags, m->tfeat, d_count, (size_t)m->p, stream));
+    FMX_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    std::vector<int64_t> real_ptr((size_t)nt + 1, 0);
+    int64_t at = 0;
+    for (int64_t t = 0; t < nt; ++t) {
+      real_ptr[(size_t)t] = at;
+      if (m->tfeat_ptr[(size_t)t + 1] == m->tfeat_ptr[(size_t)t]) continue;
+      hipLaunchKernelGGL(touched_flags_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream,
+                         m->bptr + (size_t)t * ((size_t)m->p + 1), m->p, d_flags);
+      FMX_HIP(rocprim::select(d_tmp, tmp_bytes, ids, d_flags, m->tfeat + at, d_count, (size_t)m->p, stream));
+      uint32_t h = 0;
+      FMX_HIP(hipMemcpyAsync(&h, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      FMX_HIP(hipStreamSynchronize(stream));
+      const uint32_t entries = (uint32_t)(m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t]);
+      hipLaunchKernelGGL(touched_offsets_k, dim3((unsigned)((h + 1 + 255) / 256)), dim3(256), 0, stream,
+                         m->bptr + (size_t)t * ((size_t)m->p + 1), m->tfeat + at, h, entries, m->toff + at + t);
+      at += h;
+    }
+    real_ptr[(size_t)nt] = at;
+    m->tfeat_ptr = real_ptr;
+    (void)hipFree(d_flags); (void)hipFree(d_count); (void)hipFree(d_tmp);
   }
   FMX_HIP(hipStreamSynchronize(stream));
   return FMX_OK;
@@ -281,9 +336,9 @@ __global__ void normalize_apply_k(int64_t nnz, const uint32_t* __restrict__ col,
 
 // the cached inverted indices hold copies of the values: drop them so they are rebuilt from the new values
 static void drop_value_caches(fmx_matrix* m) {
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
-  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
+  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->tfeat = nullptr; m->toff = nullptr; m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
   m->batch_rows = 0; m->tile_rows = 0;
 }
 

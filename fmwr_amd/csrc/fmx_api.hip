@@ -181,7 +181,7 @@ static void visit_order(int64_t n, int random_step, int64_t max_iter, std::vecto
 static void free_matrix(fmx_matrix* m) {
   if (!m) return;
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval);
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats);
   delete m;
 }
@@ -320,6 +320,14 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
     c.scalar = !last ? SCALAR_NONE : (finish_local ? SCALAR_FUSED : SCALAR_PUBLISH);
     c.n_partials = last ? partials : 0;
     c.global_rows = (double)step_rows;
+    // a sparse tile that is a whole fused step walks only the features occurring in it (the exchange buffer is dense:
+    // tiles that read or write it visit every feature)
+    const int64_t tl = m->tfeat_ptr.empty() ? 0 : m->tfeat_ptr[(size_t)tiles[i].tile + 1] - m->tfeat_ptr[(size_t)tiles[i].tile];
+    if (single && finish_local && tl > 0) {
+      c.tfeat = m->tfeat + m->tfeat_ptr[(size_t)tiles[i].tile];
+      c.toff = m->toff + m->tfeat_ptr[(size_t)tiles[i].tile] + tiles[i].tile;
+      c.n_tfeat = (uint32_t)tl;
+    }
     FMX_TRY(launch_cols_update(e, c));
   }
   return FMX_OK;

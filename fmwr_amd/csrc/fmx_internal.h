@@ -104,6 +104,10 @@ struct fmx_matrix {
   std::vector<int64_t> tile_start;       // [n_tiles+1] first row of every tile
   std::vector<int64_t> step_first_tile;  // [n_batches+1]
   uint32_t* bptr = nullptr;  // [n_tiles][p+1] offsets relative to row_ptr[tile_start[t]]
+  // sparse tiles (far fewer entries than features): the ascending ids of the features that occur in the tile
+  uint32_t* tfeat = nullptr;               // concatenated over the tiles that have a list
+  uint32_t* toff = nullptr;                // their entry offsets (bptr[tfeat[i]]), one extra end marker per tile: at tfeat_ptr[t] + t
+  std::vector<int64_t> tfeat_ptr;          // [n_tiles+1] into tfeat; an empty range = no list (dense walk over all p)
   uint32_t* brow = nullptr;  // [nnz] row index local to the tile
   float* bval = nullptr;     // [nnz]
   // CSC of the whole matrix (ALS sweep), built lazily
@@ -196,6 +200,9 @@ struct ColsArgs {
   const uint32_t* brow;  // based at the tile's first entry
   const float* bval;
   uint32_t rows_active;  // tile rows taking part (a truncated step cuts the last tile)
+  const uint32_t* tfeat; // ids of the features occurring in the tile (ascending), or null: walk all p features
+  const uint32_t* toff;  // [n_tfeat+1] entry offsets of those features (compact copy of bptr)
+  uint32_t n_tfeat;
   int walk;              // accumulate this tile's sums from S / amul
   int load_gbuf;         // add the sums already in the exchange buffer (earlier tiles, or the all-reduced global sums)
   int store_gbuf;        // write the sums back to the exchange buffer

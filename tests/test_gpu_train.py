@@ -363,3 +363,34 @@ def test_als_training_loop_matches_oracle(fm, with_v):
         assert np.array_equal(gv, v)  # the reference's ALS never moves V
     sse = lambda a, b, c: float(np.sum((oracle.predict_batch(P, X, a, b, np.asarray(c).ravel()) - y) ** 2))
     assert sse(g0, gw, gv) < sse(w0, w, v)
+
+
+@pytest.mark.parametrize("name", ["sgd_l2_cls", "sgd_l1_cls", "ftrl_l1l2_cls"])
+def test_sparse_tiles_walk_only_occurring_features(fm, name):
+    """Far more features than entries per batch (the usual FM regime): phase 2 walks the per-tile list of occurring
+    features instead of all p.  Same results as the oracle, and as the dense walk (forced through the grad/apply split)."""
+    engine, L = fm
+    c = next(x for x in CASES if x["name"] == name)
+    n, p, batch = 700, 6000, 100
+    rp, col, val, y, P, seed = _problem(c, n=n, p=p, mean_nnz=6)
+    w0, w, v = util.params(p, P.k, seed, fp32=True)
+    X = oracle.Matrix(rp, col, val, p)
+    mb = (oracle.SgdMinibatch if c["solver"] == "sgd" else oracle.FtrlMinibatch)(P, X, y, w0, w, v.ravel())
+    for s in range(10):
+        b0 = (s % 7) * batch
+        mb.step(b0, b0 + batch)
+    solver = L.SOLVER_SGD if c["solver"] == "sgd" else L.SOLVER_FTRL
+    kw = dict(task=P.task, solver=solver, num_factor=P.k, l2_w0=P.l2_reg0, l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv, l2_v=P.l2_regv,
+              learn_rate=P.learn_rate, mode=L.MODE_MINIBATCH, batch_rows=batch)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    e = engine.Engine(p, **kw); e.set_params(w0, w, v)
+    e2 = engine.Engine(p, **kw); e2.set_params(w0, w, v)
+    for s in range(10):
+        e.step(m, s % 7)                   # sparse walk
+        e2.grad(m, s % 7); e2.apply(0)     # dense walk through the exchange buffer
+    e.sync(); e2.sync()
+    g0, gw, gv = e.get_params()
+    h0, hw, hv = e2.get_params()
+    rv = mb.v.reshape(P.k, p)
+    assert util.rel_err(gv, rv) < V_RTOL and util.rel_err(gw, mb.w) < V_RTOL and abs(g0 - mb.w0.value) < V_RTOL * max(1.0, abs(mb.w0.value))
+    assert util.rel_err(hv, gv) < 1e-6 and util.rel_err(hw, gw) < 1e-6
