@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--factors", type=int, default=16)
     ap.add_argument("--batch-rows", type=int, default=1_048_576,
                     help="mini-batch rows per GPU per step (processed in cache-resident tiles of <= 262144 rows)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
@@ -128,7 +129,7 @@ def main():
     solver = L.SOLVER_SGD if args.solver == "sgd" else L.SOLVER_FTRL
     e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=solver, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
                       l1_w1=1e-4 if args.solver == "ftrl" else 0.0, l1_v=1e-4 if args.solver == "ftrl" else 0.0,
-                      mode=L.MODE_MINIBATCH, batch_rows=B, device=local_rank, keep_w1=0 if args.no_linear else 1)
+                      mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=args.tile_rows, device=local_rank, keep_w1=0 if args.no_linear else 1)
     v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
     e.set_params(0.0, None, v0.astype(np.float64))
     nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work
@@ -189,7 +190,7 @@ def main():
         value = rows_step * args.steps / dt
         fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
         upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
-        tiles = -(-B // 262_144)            # fmx_api.hip effective_tile_rows()
+        tiles = -(-B // (args.tile_rows or (524_288 if k > 32 else 262_144)))  # fmx_api.hip effective_tile_rows()
         tile_rows = -(-B // tiles)
         b_fwd, b_upd, _ = algorithmic_bytes(z, k, p, tile_rows)   # per LAUNCH: one tile
         b_step = algorithmic_bytes(z, k, p, B)[2]

@@ -239,7 +239,9 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
 
 // rows-per-tile actually used: a step of batch_rows rows is cut into ceil(batch_rows / tile) equal-ish tiles
 static int64_t effective_tile_rows(const fmx_engine* e) {
-  const int64_t want = e->cfg.tile_rows > 0 ? e->cfg.tile_rows : 262144;  // S (tile x 64 B at k=16) stays cache resident
+  // measured optimum (profiles/r01_sweep_batch.txt, r01_sweep_tile.txt): 262144 rows up to k = 32 (S = tile x 64..128 B stays
+  // in the Infinity Cache next to V), 524288 for wider rows where the per-tile sweep over all p features weighs more
+  const int64_t want = e->cfg.tile_rows > 0 ? e->cfg.tile_rows : (e->kp32 >= 64 ? 524288 : 262144);
   if (e->cfg.batch_rows <= want) return e->cfg.batch_rows;
   const int64_t tiles = (e->cfg.batch_rows + want - 1) / want;
   return (e->cfg.batch_rows + tiles - 1) / tiles;
