@@ -27,7 +27,9 @@ CASES = {
     "sgd_l2_reg": dict(solver="sgd", task=oracle.REGRESSION, k=16, l2_regw=1e-3, l2_regv=1e-3, learn_rate=0.02),
     "sgd_rs3": dict(solver="sgd", task=oracle.CLASSIFICATION, k=4, l2_regv=1e-3, learn_rate=0.05, random_step=3),
     "ftrl_l1l2": dict(solver="ftrl", task=oracle.CLASSIFICATION, k=8, l1_regw=1e-3, l1_regv=1e-3, l2_regw=1e-2, l2_regv=1e-2),
+    "tdap": dict(solver="tdap", task=oracle.CLASSIFICATION, k=4, l1_regw=1e-3, l1_regv=5e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=3e-4, alpha_v=0.05),
 }
+LEARN = {"sgd": oracle.sgd_learn, "ftrl": oracle.ftrl_learn, "tdap": oracle.tdap_learn}
 N, P, ITERS = 240, 60, 500
 
 
@@ -49,8 +51,7 @@ def main():
         rp, col, val, y, w0, w, v, Pm = problem(name, c)
         X = oracle.Matrix(rp, col, val, P)
         order = oracle.visit_order(N, Pm.random_step, ITERS, seed=1)
-        learn = oracle.sgd_learn if c["solver"] == "sgd" else oracle.ftrl_learn
-        r = learn(Pm, X, y, w0, w, v.ravel(), ITERS, order=order)
+        r = LEARN[c["solver"]](Pm, X, y, w0, w, v.ravel(), ITERS, order=order)
         pred = oracle.predict_batch(Pm, X, r["w0"], r["w"], r["v"])
         for key, arr in dict(row_ptr=rp, col=col, val=val, y=y, w0_in=w0, w_in=w, v_in=v, order=order, w0=r["w0"], w=r["w"],
                              v=r["v"].reshape(c["k"], P), pred=pred).items():

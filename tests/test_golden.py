@@ -28,8 +28,7 @@ def test_oracle_reproduces_fixture(name):
     rp, col, val, y, w0, w, v, Pm = mg.problem(name, c)
     np.testing.assert_array_equal(col, g[f"{name}/col"])
     X = oracle.Matrix(rp, col, val, mg.P)
-    learn = oracle.sgd_learn if c["solver"] == "sgd" else oracle.ftrl_learn
-    r = learn(Pm, X, y, w0, w, v.ravel(), mg.ITERS, order=g[f"{name}/order"])
+    r = mg.LEARN[c["solver"]](Pm, X, y, w0, w, v.ravel(), mg.ITERS, order=g[f"{name}/order"])
     np.testing.assert_allclose(r["v"].reshape(c["k"], mg.P), g[f"{name}/v"], rtol=0, atol=1e-14)
     np.testing.assert_allclose(r["w"], g[f"{name}/w"], rtol=0, atol=1e-14)
     assert abs(r["w0"] - float(g[f"{name}/w0"])) < 1e-14
@@ -44,7 +43,7 @@ def test_gpu_sequential_matches_fixture(name):
     g = _load()
     c = mg.CASES[name]
     _, _, _, y, _, _, _, Pm = mg.problem(name, c)
-    e = engine.Engine(mg.P, task=Pm.task, solver=L.SOLVER_SGD if c["solver"] == "sgd" else L.SOLVER_FTRL, num_factor=Pm.k,
+    e = engine.Engine(mg.P, task=Pm.task, solver={"sgd": L.SOLVER_SGD, "ftrl": L.SOLVER_FTRL, "tdap": L.SOLVER_TDAP}[c["solver"]], num_factor=Pm.k, gamma=Pm.gamma,
                       l2_w0=Pm.l2_reg0, l1_w1=Pm.l1_regw, l2_w1=Pm.l2_regw, l1_v=Pm.l1_regv, l2_v=Pm.l2_regv, learn_rate=Pm.learn_rate,
                       alpha_w=Pm.alpha_w, alpha_v=Pm.alpha_v, beta_w=Pm.beta_w, beta_v=Pm.beta_v, mode=L.MODE_SEQUENTIAL,
                       min_target=Pm.min_target, max_target=Pm.max_target)
