@@ -24,7 +24,7 @@ SYMBOLS = [
     "fmx_get_params", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
     "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
     "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
-    "fmx_als_vsweep", "fmx_als_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
+    "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset",
 ]
 

@@ -64,7 +64,7 @@ __device__ __forceinline__ bool bad_number(double x) { return isnan(x) || isinf(
 __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
                                                           const uint32_t* __restrict__ crow, const float* __restrict__ cval,
                                                           double* __restrict__ V, int kp, int f, double2* __restrict__ qe,
-                                                          double alpha, double lambda, double mu) {
+                                                          double alpha, double lambda, double mu, const double* __restrict__ znorm) {
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6);
   if (wid >= n_feats) return;
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
   v_mean -= v_old * v_var;                               // :318
   v_var = 1.0 / (lambda + alpha * v_var);                // :319
   v_mean = -v_var * (alpha * v_mean - mu * lambda);      // :320
-  double v_new = bad_number(v_var) ? 0.0 : v_mean;       // :323-333 (ALS: no sampling)
+  // :323-333: ALS takes the mean; MCMC draws Rf_rnorm(v_mean, sqrt(v_var)) = v_mean + sqrt(v_var) * (the caller's standard normal)
+  double v_new = bad_number(v_var) ? 0.0 : (znorm ? v_mean + sqrt(v_var) * znorm[i] : v_mean);
   if (bad_number(v_new)) return;                         // CHECK_PARAM (:336): keep the old value, skip the corrections
   if (lane == 0) V[(size_t)i * kp + f] = v_new;
   const double v_diff = v_old - v_new;
@@ -222,7 +223,8 @@ static int build_plan(fmx_matrix* m, hipStream_t stream) {
 }
 
 // V sweep over all factors on the interleaved (q, e) pairs
-static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu) {
+static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu,
+                            const double* d_znorm = nullptr) {
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   const std::vector<int64_t>& level_ptr = m->als_level_ptr;
   const int L = (int)level_ptr.size() - 1;
@@ -234,7 +236,8 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
       if (cnt == 0) continue;
       const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
       hipLaunchKernelGGL(als_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
-                         m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_qe, alpha, lambda, mu);
+                         m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_qe, alpha, lambda, mu,
+                         d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
     }
   }
 }
@@ -291,14 +294,15 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
   return FMX_OK;
 }
 
-int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_qe_raw, double alpha, const double* h_lambda, const double* h_mu) {
+int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_qe_raw, double alpha, const double* h_lambda, const double* h_mu,
+                      const double* d_znorm) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweep needs every row's columns strictly ascending (as R's dgCMatrix rows are)");
   FMX_TRY(build_full_csc(m, e->stream));
   FMX_TRY(build_plan(m, e->stream));
   double2* d_qe = reinterpret_cast<double2*>(d_qe_raw);
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   hipLaunchKernelGGL(als_pack_k, dim3(row_grid), dim3(256), 0, e->stream, d_error, m->n, d_qe);
-  v_sweep_enqueue(e, m, d_qe, alpha, h_lambda, h_mu);
+  v_sweep_enqueue(e, m, d_qe, alpha, h_lambda, h_mu, d_znorm);
   hipLaunchKernelGGL(als_unpack_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, m->n, d_error);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(e->stream);

@@ -871,26 +871,39 @@ int fmx_stream(fmx_engine* e, void** stream) {
   return FMX_OK;
 }
 
-int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda, const double* v_mu) {
+static int vsweep_impl(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda, const double* v_mu,
+                       const double* std_normals) {
   FMX_TRY(check_pair(e, m));
   FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweep runs on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
   FMX_CHECK(error != nullptr || m->n == 0, FMX_ERR_INVALID, "error is NULL");
   FMX_TRY(use_device(e->cfg.device));
   if (m->n == 0 || e->k == 0) return FMX_OK;
-  double *d_err = nullptr, *d_q = nullptr;
+  double *d_err = nullptr, *d_q = nullptr, *d_z = nullptr;
   const size_t bytes = (size_t)m->n * sizeof(double);
+  const size_t zbytes = (size_t)e->k * (size_t)e->p * sizeof(double);
   FMX_HIP(hipMalloc(&d_err, bytes));
-  if (hipMalloc(&d_q, 2 * bytes) != hipSuccess) {  // interleaved (q, e) pairs
-    (void)hipFree(d_err);
+  if (hipMalloc(&d_q, 2 * bytes) != hipSuccess || (std_normals && hipMalloc(&d_z, zbytes) != hipSuccess)) {  // interleaved (q, e) pairs
+    (void)hipFree(d_err); (void)hipFree(d_q);
     set_error("out of device memory");
     return FMX_ERR_HIP;
   }
   int st = FMX_OK;
   if (hipMemcpy(d_err, error, bytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the residual failed"); st = FMX_ERR_HIP; }
-  if (st == FMX_OK) st = launch_als_vsweep(e, m, d_err, d_q, alpha, v_lambda, v_mu);
+  if (st == FMX_OK && std_normals && hipMemcpy(d_z, std_normals, zbytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the normal draws failed"); st = FMX_ERR_HIP; }
+  if (st == FMX_OK) st = launch_als_vsweep(e, m, d_err, d_q, alpha, v_lambda, v_mu, d_z);
   if (st == FMX_OK && hipMemcpy(error, d_err, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("download of the residual failed"); st = FMX_ERR_HIP; }
-  (void)hipFree(d_err); (void)hipFree(d_q);
+  (void)hipFree(d_err); (void)hipFree(d_q); (void)hipFree(d_z);
   return st;
+}
+
+int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda, const double* v_mu) {
+  return vsweep_impl(e, m, error, alpha, v_lambda, v_mu, nullptr);
+}
+
+int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda, const double* v_mu,
+                    const double* std_normals) {
+  FMX_CHECK(std_normals != nullptr, FMX_ERR_INVALID, "std_normals is NULL (use fmx_als_vsweep for the ALS form)");
+  return vsweep_impl(e, m, error, alpha, v_lambda, v_mu, std_normals);
 }
 
 int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v) {

@@ -194,11 +194,18 @@ class Engine:
         L.check(L.lib().fmx_stream(self.h, C.byref(s)))
         return s.value
 
-    def als_vsweep(self, m, error, alpha=1.0, v_lambda=None, v_mu=None):
+    def als_vsweep(self, m, error, alpha=1.0, v_lambda=None, v_mu=None, std_normals=None):
+        """ALS V sweep; std_normals ((k, p) standard normal draws) switches to the MCMC (Gibbs) form."""
         error = np.ascontiguousarray(error, np.float64).copy()
         lam = None if v_lambda is None else np.ascontiguousarray(v_lambda, np.float64)
         mu = None if v_mu is None else np.ascontiguousarray(v_mu, np.float64)
-        L.check(L.lib().fmx_als_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu)))
+        if std_normals is None:
+            L.check(L.lib().fmx_als_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu)))
+        else:
+            z = np.ascontiguousarray(std_normals, np.float64)
+            if z.shape != (self.k, self.p):
+                raise ValueError(f"std_normals must have shape ({self.k}, {self.p})")
+            L.check(L.lib().fmx_mcmc_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu), _p(z)))
         return error
 
     def als_train(self, m, max_iter, with_v=False):

@@ -214,6 +214,13 @@ int fmx_predict_device(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r
  * error: f64[n] residual on entry (y_hat - y, :520-527), updated in place; v_lambda, v_mu: f64[k] or NULL (zeros). */
 int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda,
                    const double* v_mu);
+/* The MCMC (Gibbs) form of the same sweep (do_sample, :329-331): every coordinate is drawn from N(mean, var) instead of set
+ * to the mean.  The reference draws with R's Rf_rnorm inside the loop; here the caller pre-draws the standard normals in the
+ * same order -- std_normals: f64[k][p], element (f, j) at f*p + j, e.g. rnorm(k*p) under the same seed -- so the engine
+ * needs no RNG and reproduces the reference's chain.  The hyper-prior draws (update_v_lambda / update_v_mu) stay with the
+ * caller, who passes their current values in v_lambda / v_mu. */
+int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda,
+                    const double* v_mu, const double* std_normals);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
  * w0 update (:162-188); w sweep (:190-270, the exact one-thread form) }.  As shipped the reference never sweeps V (its

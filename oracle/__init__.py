@@ -200,14 +200,14 @@ class FtrlMinibatch:
                                       _ptr(self.zn0), _ptr(self.z_w), _ptr(self.n_w), _ptr(self.z_v), _ptr(self.n_v))
 
 
-def als_update_v(k, X, v, error, alpha=1.0, v_lambda=None, v_mu=None):
-    """solver/MCMC_ALS_Learner.h:272-354 (ALS branch); returns (v_new, error_end, v_q_end)."""
+def als_update_v(k, X, v, error, alpha=1.0, v_lambda=None, v_mu=None, znorm=None):
+    """solver/MCMC_ALS_Learner.h:272-354; znorm ([k][p] standard normals) switches to the MCMC draw; returns (v_new, error_end, v_q_end)."""
     col_ptr, row_idx, val_t = X.transpose()
     v = _f64(v).copy(); err = _f64(error).copy(); vq = np.zeros(max(X.n, 1))
     lam = _f64(v_lambda if v_lambda is not None else np.zeros(k)); mu = _f64(v_mu if v_mu is not None else np.zeros(k))
     row_idx = np.ascontiguousarray(row_idx); val_t = np.ascontiguousarray(val_t)
     lib().fmo_als_update_v(C.c_int(k), C.c_uint32(X.p), _ptr(v), C.c_int64(X.n), _ptr(col_ptr), _ptr(row_idx), _ptr(val_t),
-                           _ptr(err), _ptr(vq), C.c_double(alpha), _ptr(lam), _ptr(mu))
+                           _ptr(err), _ptr(vq), C.c_double(alpha), _ptr(lam), _ptr(mu), _ptr(None if znorm is None else _f64(znorm)))
     return v, err, vq
 
 

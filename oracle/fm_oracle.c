@@ -654,13 +654,16 @@ void fmo_als_error_regression(double* error, const float* y, int64_t n) {
 
 static int fmo_bad(double x) { return isnan(x) || isinf(x); }
 
-/* solver/MCMC_ALS_Learner.h:272-354 update_v, ALS branch (do_sample == false), one attribute group.
+/* solver/MCMC_ALS_Learner.h:272-354 update_v, one attribute group.  znorm == NULL: the ALS branch (do_sample == false).
+ * znorm != NULL: the MCMC branch -- the reference draws TMP(v) = Rf_rnorm(v_mean, sqrt(v_var)) (:330), i.e.
+ * v_mean + sqrt(v_var) * norm_rand(), once per (factor, feature) in loop order; znorm[f*p + i] is that standard normal,
+ * pre-drawn by the caller in the same order (R's RNG is not available to the oracle or to the engine).
  * The reference works on private copies of error / v_q and never writes them back (SURVEY A-1);
  * here `error` and `v_q` ARE those copies (caller passes copies) so a test can also read their end state.
  * csc: col_ptr[p+1], row_idx[nnz], val_t[nnz] (train.data_t).  v_lambda, v_mu: [k] (group 0). */
 void fmo_als_update_v(int k, uint32_t p, double* v, int64_t n, const int64_t* col_ptr, const uint32_t* row_idx,
                       const float* val_t, double* error, double* v_q, double alpha,
-                      const double* v_lambda, const double* v_mu) {
+                      const double* v_lambda, const double* v_mu, const double* znorm) {
   for (int f = 0; f < k; ++f) {
     for (int64_t r = 0; r < n; ++r) v_q[r] = 0.0;
     for (uint32_t i = 0; i < p; ++i) {
@@ -682,7 +685,8 @@ void fmo_als_update_v(int k, uint32_t p, double* v, int64_t n, const int64_t* co
       v_mean -= v_ * v_var;
       v_var = (double)1.0 / (v_lambda[f] + alpha * v_var);
       v_mean = -v_var * (alpha * v_mean - v_mu[f] * v_lambda[f]);
-      if (fmo_bad(v_var)) v_ = 0.0; else v_ = v_mean;
+      if (fmo_bad(v_var)) v_ = 0.0;
+      else v_ = znorm ? v_mean + sqrt(v_var) * znorm[(size_t)f * p + i] : v_mean;
       if (fmo_bad(v_)) { v_ = v_old; update_err = 0; } /* CHECK_PARAM, util/Macros.h:36-41 */
       v[(size_t)f * p + i] = v_;
       double v_diff = v_old - v_;
@@ -751,7 +755,7 @@ void fmo_als_learn(const fmo_params* P, uint32_t p, double* w0, double* w, doubl
     fmo_als_error_regression(error, y, X->n);
     if (P->k0) fmo_als_update_w0(P, w0, error, X->n, 1.0, 0.0);
     if (P->k1) fmo_als_update_w(p, w, col_ptr, row_idx, val_t, error, 1.0, 0.0, 0.0);
-    if (with_v && P->k > 0) fmo_als_update_v(P->k, p, v, X->n, col_ptr, row_idx, val_t, error, v_q, 1.0, zeros, zeros);
+    if (with_v && P->k > 0) fmo_als_update_v(P->k, p, v, X->n, col_ptr, row_idx, val_t, error, v_q, 1.0, zeros, zeros, NULL);
   }
   free(error); free(v_q); free(zeros);
 }

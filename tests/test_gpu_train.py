@@ -394,3 +394,28 @@ def test_sparse_tiles_walk_only_occurring_features(fm, name):
     rv = mb.v.reshape(P.k, p)
     assert util.rel_err(gv, rv) < V_RTOL and util.rel_err(gw, mb.w) < V_RTOL and abs(g0 - mb.w0.value) < V_RTOL * max(1.0, abs(mb.w0.value))
     assert util.rel_err(hv, gv) < 1e-6 and util.rel_err(hw, gw) < 1e-6
+
+
+def test_mcmc_vsweep_with_caller_drawn_normals(fm):
+    """The Gibbs form of update_v (MCMC_ALS_Learner.h:329-331): v ~ N(mean, var) with the standard normals pre-drawn by
+    the caller in loop order (BASELINE.json configs[4]: 'MCMC.solver Gibbs sweep over V columns')."""
+    engine, L = fm
+    rng = np.random.default_rng(71)
+    n, fields, width, k = 1800, 5, 40, 4
+    p = fields * width
+    rp = np.arange(n + 1, dtype=np.int64) * fields
+    col = (rng.integers(0, width, (n, fields)) + np.arange(fields)[None, :] * width).astype(np.uint32).ravel()
+    val = rng.normal(0, 1, n * fields).astype(np.float32)
+    y = util.labels(n, 71, "regression")
+    w0, w, v = util.params(p, k, 71, stdev=0.3, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(oracle.params(task=oracle.REGRESSION, k=k), X, w0, w, v.ravel()) - y
+    z = rng.normal(0, 1, (k, p))
+    lam = np.full(k, 2.0); mu = np.linspace(-0.05, 0.05, k)
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=0.7, v_lambda=lam, v_mu=mu, znorm=z.ravel())
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    gerr = e.als_vsweep(m, err0, alpha=0.7, v_lambda=lam, v_mu=mu, std_normals=z)
+    assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    assert not np.allclose(rv, oracle.als_update_v(k, X, v.ravel(), err0, alpha=0.7, v_lambda=lam, v_mu=mu)[0])  # it really sampled
