@@ -327,6 +327,131 @@ __device__ __forceinline__ double coord_update(const Hyper& h, bool is_w, double
   }
 }
 
+// One (feature, lane-slice) worth of batch sums: the lane's 4 factors plus the feature's linear term
+struct CoordSums {
+  double G[4], Q[4];
+  double Gw, Qw, cnt;
+};
+
+__device__ __forceinline__ void sums_zero(CoordSums& s) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s.G[i] = 0.0; s.Q[i] = 0.0; }
+  s.Gw = 0.0; s.Qw = 0.0; s.cnt = 0.0;
+}
+
+// one occurrence (row r with value x) of the feature whose batch-start V slice is vf
+template <bool NEED_Q>
+__device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const float4& srow, float amul, float xf) {
+  const double x = (double)xf;
+  const double ax = (double)amul * x;  // mult * x: the w gradient, SGD_Learner.h:114
+  s.Gw += ax;
+  if (NEED_Q) s.Qw += ax * ax;
+  s.cnt += 1.0;
+  double sf[4];
+  slice_get(srow, sf);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double g = ax * (sf[i] - vf[i] * x);  // mult*(sum_f*x - v*x*x), SGD_Learner.h:129
+    s.G[i] += g;
+    if (NEED_Q) s.Q[i] += g * g;
+  }
+}
+
+// What happens to a feature's sums: [+ the exchange buffer's] -> [publish] -> [apply the update].  Shared by the main
+// kernel (short lists) and the long-list finisher.  Called by every lane of the feature's group; lig == 0 handles w.
+template <int LPR, int KIND>
+__device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, const ColsTables& T, int64_t j, int lig, const double* vf,
+                                            CoordSums& s, double rows) {
+  constexpr int VEC = 4;
+  constexpr int KP = LPR * VEC;
+  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  // exchange buffer planes: GV [p][KP] | GW [p] | CNT [p] | (has_q: QV [p][KP] | QW [p]) | tail[4]
+  float* gGV = T.gbuf;
+  float* gGW = T.gbuf ? T.gbuf + (size_t)T.p * KP : nullptr;
+  float* gCN = T.gbuf ? gGW + T.p : nullptr;
+  float* gQV = T.gbuf ? gCN + T.p : nullptr;
+  float* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
+
+  if (a.load_gbuf) {  // sums of earlier tiles of this step, or the all-reduced sums of the whole global batch
+    float4 g4 = *reinterpret_cast<const float4*>(gGV + (size_t)j * KP + lig * VEC);
+    s.G[0] += g4.x; s.G[1] += g4.y; s.G[2] += g4.z; s.G[3] += g4.w;
+    s.Gw += gGW[j];
+    s.cnt += gCN[j];
+    if (NEED_Q && T.has_q) {
+      float4 q4 = *reinterpret_cast<const float4*>(gQV + (size_t)j * KP + lig * VEC);
+      s.Q[0] += q4.x; s.Q[1] += q4.y; s.Q[2] += q4.z; s.Q[3] += q4.w;
+      s.Qw += gQW[j];
+    }
+  }
+  if (a.store_gbuf) {  // publish the sums so far (every feature, zeros included)
+    *reinterpret_cast<float4*>(gGV + (size_t)j * KP + lig * VEC) = make_float4((float)s.G[0], (float)s.G[1], (float)s.G[2], (float)s.G[3]);
+    if (NEED_Q && T.has_q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)s.Q[0], (float)s.Q[1], (float)s.Q[2], (float)s.Q[3]);
+    if (lig == 0) {
+      gGW[j] = (float)s.Gw;
+      gCN[j] = (float)s.cnt;
+      if (NEED_Q && T.has_q) gQW[j] = (float)s.Qw;
+    }
+  }
+  // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
+  if (!a.apply || s.cnt == 0.0) return;
+
+  double cnt = s.cnt;
+  if (h.mean) {  // FMX_REDUCE_MEAN: one reference step with the mean gradient of the coordinate's occurrences
+    const double inv = 1.0 / cnt;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s.G[i] *= inv; s.Q[i] = s.G[i] * s.G[i]; }
+    s.Gw *= inv; s.Qw = s.Gw * s.Gw;
+    cnt = 1.0;
+  }
+  double decay_v = 1.0, decay_w = 1.0, u_w = 0.0, u_v = 0.0;
+  if constexpr (KIND == UPD_SGD_L2) {
+    // (1 - lr*reg)^cnt; cnt == 1 always under FMX_REDUCE_MEAN, so the transcendental is off the common path
+    if (cnt == 1.0) { decay_v = h.decay_v; decay_w = h.decay_w; }
+    else {
+      decay_v = h.decay_v > 0.0 ? exp(cnt * h.log_decay_v) : pow(h.decay_v, cnt);
+      decay_w = h.decay_w > 0.0 ? exp(cnt * h.log_decay_w) : pow(h.decay_w, cnt);
+    }
+  }
+  if constexpr (KIND == UPD_SGD_L1) {  // the penalty level after this batch (same expression as scalar_update)
+    const double r = h.mean ? 1.0 : rows;
+    u_w = T.scal[SC_UW] + r * (h.lr * h.regw);
+    u_v = T.scal[SC_UV] + r * (h.lr * h.regv);
+  }
+  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+  if constexpr (KIND != UPD_SGD_L2) sa = *reinterpret_cast<const float4*>(T.sV + (size_t)j * KP + lig * VEC);
+  if constexpr (KIND == UPD_FTRL) sb = *reinterpret_cast<const float4*>(T.nV + (size_t)j * KP + lig * VEC);
+  float sa_[VEC] = {sa.x, sa.y, sa.z, sa.w}, sb_[VEC] = {sb.x, sb.y, sb.z, sb.w};
+  float out[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+    out[i] = (float)coord_update<KIND>(h, false, vf[i], s.G[i], s.Q[i], cnt, decay_v, u_v, sa_[i], sb_[i], true);
+  *reinterpret_cast<float4*>(T.V + (size_t)j * KP + lig * VEC) = make_float4(out[0], out[1], out[2], out[3]);
+  if constexpr (KIND != UPD_SGD_L2) *reinterpret_cast<float4*>(T.sV + (size_t)j * KP + lig * VEC) = make_float4(sa_[0], sa_[1], sa_[2], sa_[3]);
+  if constexpr (KIND == UPD_FTRL) *reinterpret_cast<float4*>(T.nV + (size_t)j * KP + lig * VEC) = make_float4(sb_[0], sb_[1], sb_[2], sb_[3]);
+  if (lig == 0) {
+    // FTRL recomputes w on every touched column even when keep.w1 is off (FTRL_Learner.h:172-183); SGD skips (:111)
+    const bool k1 = h.k1 != 0;
+    if (k1 || KIND == UPD_FTRL) {
+      float wa = 0.f, wb = 0.f;
+      if constexpr (KIND != UPD_SGD_L2) wa = T.sw[j];
+      if constexpr (KIND == UPD_FTRL) wb = T.nw[j];
+      const double wn = coord_update<KIND>(h, true, (double)T.w[j], s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
+      T.w[j] = (float)wn;
+      if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
+      if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
+    }
+  }
+}
+
+template <int LPR>
+__device__ __forceinline__ float* exchange_tail(const ColsTables& T) {
+  if (!T.gbuf) return nullptr;
+  float* gCN = T.gbuf + (size_t)T.p * (LPR * 4) + T.p;
+  return T.has_q ? gCN + T.p + (size_t)T.p * (LPR * 4) + T.p : gCN + T.p;  // the Q planes exist only with has_q
+}
+
+// Main phase-2 kernel: one group of LPR lanes per feature list.  Lists longer than a.long_min entries (heavy hitters of a
+// skewed feature distribution) are left to the long-list kernels below; walking them with one group would serialise the tile.
 template <int LPR, int KIND>
 __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables T) {
   constexpr int VEC = 4;
@@ -339,11 +464,11 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   const int tid = threadIdx.x;
   const int gid = tid / LPR;
   const int lig = tid % LPR;
-  // lists of this workgroup: features J0.. (dense walk) or the J0..-th occurring features (sparse tile)
+  // lists of this workgroup: features I0.. (dense walk) or the I0..-th occurring features (sparse tile)
   const int64_t n_lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)T.p;
   const int64_t I0 = (int64_t)blockIdx.x * FPW;
   const int64_t I1 = (I0 + FPW < n_lists) ? I0 + FPW : n_lists;
-  const bool have = I0 + gid < n_lists;
+  bool have = I0 + gid < n_lists;
   const int64_t j = !have ? 0 : (a.tfeat ? (int64_t)a.tfeat[I0 + gid] : I0 + gid);
   // list offsets: the dense per-feature array, or its compact copy for the occurring features (their entries are
   // contiguous: the features between them have none)
@@ -353,30 +478,23 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   if (have) v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
   double vf[VEC];
   slice_get(v4, vf);
-
-  double G[VEC], Q[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { G[i] = 0.0; Q[i] = 0.0; }
-  double Gw = 0.0, Qw = 0.0, cnt = 0.0;
-
-  // exchange buffer planes: GV [p][KP] | GW [p] | CNT [p] | (has_q: QV [p][KP] | QW [p]) | tail[4]
-  float* gGV = T.gbuf;
-  float* gGW = T.gbuf ? T.gbuf + (size_t)T.p * KP : nullptr;
-  float* gCN = T.gbuf ? gGW + T.p : nullptr;
-  float* gQV = T.gbuf ? gCN + T.p : nullptr;
-  float* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
+  CoordSums s;
+  sums_zero(s);
 
   if (a.walk) {
     const int64_t lo = off[I0], hi = off[I1];
     int64_t ta = 0, tb = 0;
     if (have) { ta = off[I0 + gid]; tb = off[I0 + gid + 1]; }
+    if (a.long_min > 0 && tb - ta > (int64_t)a.long_min) { have = false; ta = tb = 0; }  // a long list: not ours
     const float* __restrict__ St = T.S + lig * VEC;
     for (int64_t c0 = lo; c0 < hi; c0 += STAGE_ENTRIES) {
       const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
-      stage_entries(stage, a.brow, a.bval, c0, cn);
-      __syncthreads();
       const int64_t b = ta > c0 ? ta : c0;
       const int64_t e = tb < c0 + cn ? tb : c0 + cn;
+      // chunks that only hold entries of long lists are skipped by the whole workgroup
+      if (a.long_min > 0 && !__syncthreads_or(b < e)) continue;
+      stage_entries(stage, a.brow, a.bval, c0, cn);
+      __syncthreads();
       for (int64_t t = b; t < e; t += FMX_U) {
         const int o = (int)(t - c0);
         uint2 en[FMX_U];
@@ -395,117 +513,135 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
           av[u] = T.amul[en[u].x];
         }
 #pragma unroll
-        for (int u = 0; u < FMX_U; ++u) {  // occurrences in row order
-          if (!ok[u]) continue;
-          const double x = (double)__uint_as_float(en[u].y);
-          const double ax = (double)av[u] * x;  // mult * x: the w gradient, SGD_Learner.h:114
-          Gw += ax;
-          if (NEED_Q) Qw += ax * ax;
-          cnt += 1.0;
-          double sf[VEC];
-          slice_get(sv[u], sf);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            const double g = ax * (sf[i] - vf[i] * x);  // mult*(sum_f*x - v*x*x), SGD_Learner.h:129
-            G[i] += g;
-            if (NEED_Q) Q[i] += g * g;
-          }
-        }
+        for (int u = 0; u < FMX_U; ++u)  // occurrences in row order
+          if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(en[u].y));
       }
       __syncthreads();
     }
   }
-  if (have && a.load_gbuf) {  // sums of earlier tiles of this step, or the all-reduced sums of the whole global batch
-    float4 g4 = *reinterpret_cast<const float4*>(gGV + (size_t)j * KP + lig * VEC);
-    G[0] += g4.x; G[1] += g4.y; G[2] += g4.z; G[3] += g4.w;
-    Gw += gGW[j];
-    cnt += gCN[j];
-    if (NEED_Q && T.has_q) {
-      float4 q4 = *reinterpret_cast<const float4*>(gQV + (size_t)j * KP + lig * VEC);
-      Q[0] += q4.x; Q[1] += q4.y; Q[2] += q4.z; Q[3] += q4.w;
-      Qw += gQW[j];
-    }
-  }
-  float* gtail = T.gbuf ? (T.has_q ? gQW + T.p : gCN + T.p) : nullptr;  // the Q planes exist only with has_q
+  float* gtail = exchange_tail<LPR>(T);
   double rows = a.global_rows;
   if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
 
-  if (have && a.store_gbuf) {  // publish the sums so far (every feature, zeros included)
-    *reinterpret_cast<float4*>(gGV + (size_t)j * KP + lig * VEC) = make_float4((float)G[0], (float)G[1], (float)G[2], (float)G[3]);
-    if (NEED_Q && T.has_q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)Q[0], (float)Q[1], (float)Q[2], (float)Q[3]);
-    if (lig == 0) {
-      gGW[j] = (float)Gw;
-      gCN[j] = (float)cnt;
-      if (NEED_Q && T.has_q) gQW[j] = (float)Qw;
-    }
-  }
-
-  // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
-  if (have && a.apply && cnt != 0.0) {
-  if (h.mean) {  // FMX_REDUCE_MEAN: one reference step with the mean gradient of the coordinate's occurrences
-    const double inv = 1.0 / cnt;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { G[i] *= inv; Q[i] = G[i] * G[i]; }
-    Gw *= inv; Qw = Gw * Gw;
-    cnt = 1.0;
-  }
-
-  double decay_v = 1.0, decay_w = 1.0, u_w = 0.0, u_v = 0.0;
-  if constexpr (KIND == UPD_SGD_L2) {
-    // (1 - lr*reg)^cnt; cnt == 1 always under FMX_REDUCE_MEAN, so the transcendental is off the common path
-    if (cnt == 1.0) { decay_v = h.decay_v; decay_w = h.decay_w; }
-    else {
-      decay_v = h.decay_v > 0.0 ? exp(cnt * h.log_decay_v) : pow(h.decay_v, cnt);
-      decay_w = h.decay_w > 0.0 ? exp(cnt * h.log_decay_w) : pow(h.decay_w, cnt);
-    }
-  }
-  if constexpr (KIND == UPD_SGD_L1) {  // the penalty level after this batch (same expression as scalar_update)
-    const double r = h.mean ? 1.0 : rows;
-    u_w = T.scal[SC_UW] + r * (h.lr * h.regw);
-    u_v = T.scal[SC_UV] + r * (h.lr * h.regv);
-  }
-
-  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
-  if constexpr (KIND != UPD_SGD_L2) sa = *reinterpret_cast<const float4*>(T.sV + (size_t)j * KP + lig * VEC);
-  if constexpr (KIND == UPD_FTRL) sb = *reinterpret_cast<const float4*>(T.nV + (size_t)j * KP + lig * VEC);
-  float sa_[VEC] = {sa.x, sa.y, sa.z, sa.w}, sb_[VEC] = {sb.x, sb.y, sb.z, sb.w};
-  float out[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i)
-    out[i] = (float)coord_update<KIND>(h, false, vf[i], G[i], Q[i], cnt, decay_v, u_v, sa_[i], sb_[i], true);
-  *reinterpret_cast<float4*>(T.V + (size_t)j * KP + lig * VEC) = make_float4(out[0], out[1], out[2], out[3]);
-  if constexpr (KIND != UPD_SGD_L2) *reinterpret_cast<float4*>(T.sV + (size_t)j * KP + lig * VEC) = make_float4(sa_[0], sa_[1], sa_[2], sa_[3]);
-  if constexpr (KIND == UPD_FTRL) *reinterpret_cast<float4*>(T.nV + (size_t)j * KP + lig * VEC) = make_float4(sb_[0], sb_[1], sb_[2], sb_[3]);
-
-  if (lig == 0) {
-    // FTRL recomputes w on every touched column even when keep.w1 is off (FTRL_Learner.h:172-183); SGD skips (:111)
-    const bool k1 = h.k1 != 0;
-    if (k1 || KIND == UPD_FTRL) {
-      float wa = 0.f, wb = 0.f;
-      if constexpr (KIND != UPD_SGD_L2) wa = T.sw[j];
-      if constexpr (KIND == UPD_FTRL) wb = T.nw[j];
-      const double wn = coord_update<KIND>(h, true, (double)T.w[j], Gw, Qw, cnt, decay_w, u_w, wa, wb, k1);
-      T.w[j] = (float)wn;
-      if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
-      if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
-    }
-  }
-  }  // touched coordinate
+  if (have) cols_finish<LPR, KIND>(a, h, T, j, lig, vf, s, rows);
 
   if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
     scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
 }
 
+// ---- long lists ---------------------------------------------------------------------------------------------------
+// A list longer than long_min entries is cut into segments of <= LIST_SEG entries; one WAVE walks a segment: its 64/LPR lane
+// groups take every (64/LPR)-th entry, partial sums are combined across the groups by a fixed butterfly and written out (fp64).
+// A second kernel adds a feature's segment sums in segment order and finishes the feature exactly like the main kernel.
+// Fixed geometry and order: results stay bitwise reproducible.
+constexpr int LONG_STRIDE(int kp) { return 2 * kp + 4; }  // doubles per segment: G[kp] | Q[kp] | Gw, Qw, cnt, pad
+
+template <int LPR, bool NEED_Q>
+__global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la, ColsArgs a, ColsTables T) {
+  constexpr int VEC = 4;
+  constexpr int KP = LPR * VEC;
+  constexpr int NSUB = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t seg = (int64_t)blockIdx.x * (WG_THREADS / 64) + (threadIdx.x >> 6);
+  if (seg >= la.n_seg) return;
+  const int sub = lane / LPR, lig = lane % LPR;
+  const int64_t j = la.lfeat[la.seg_feat[seg]];
+  const int64_t ta = la.seg_begin[seg], tb = la.seg_end[seg];
+  const float4 v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
+  double vf[VEC];
+  slice_get(v4, vf);
+  CoordSums s;
+  sums_zero(s);
+  const float* __restrict__ St = T.S + lig * VEC;
+  for (int64_t t = ta + sub; t < tb; t += (int64_t)NSUB * FMX_U) {
+    uint32_t r[FMX_U];
+    float x[FMX_U];
+    bool ok[FMX_U];
+#pragma unroll
+    for (int u = 0; u < FMX_U; ++u) {
+      const int64_t tt = t + (int64_t)u * NSUB;
+      const bool in = tt < tb;
+      r[u] = in ? a.brow[tt] : 0xFFFFFFFFu;
+      x[u] = in ? a.bval[tt] : 0.f;
+      ok[u] = r[u] < a.rows_active;
+      if (!ok[u]) r[u] = 0;
+    }
+    float4 sv[FMX_U];
+    float av[FMX_U];
+#pragma unroll
+    for (int u = 0; u < FMX_U; ++u) {
+      sv[u] = gather_row(St + (size_t)r[u] * KP);
+      av[u] = T.amul[r[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < FMX_U; ++u)
+      if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], x[u]);
+  }
+  // combine the NSUB lane groups (fixed butterfly => deterministic)
+#pragma unroll
+  for (int o = 32; o >= LPR; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      s.G[i] += __shfl_xor(s.G[i], o);
+      if (NEED_Q) s.Q[i] += __shfl_xor(s.Q[i], o);
+    }
+    s.Gw += __shfl_xor(s.Gw, o);
+    if (NEED_Q) s.Qw += __shfl_xor(s.Qw, o);
+    s.cnt += __shfl_xor(s.cnt, o);
+  }
+  if (sub == 0) {
+    double* out = la.partial + (size_t)seg * LONG_STRIDE(KP);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { out[lig * VEC + i] = s.G[i]; out[KP + lig * VEC + i] = s.Q[i]; }
+    if (lig == 0) { out[2 * KP] = s.Gw; out[2 * KP + 1] = s.Qw; out[2 * KP + 2] = s.cnt; }
+  }
+}
+
+template <int LPR, int KIND>
+__global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la, ColsArgs a, Hyper h, ColsTables T) {
+  constexpr int VEC = 4;
+  constexpr int KP = LPR * VEC;
+  constexpr int FPW = WG_THREADS / LPR;
+  const int gid = threadIdx.x / LPR, lig = threadIdx.x % LPR;
+  const int64_t i = (int64_t)blockIdx.x * FPW + gid;
+  if (i >= la.n_long) return;
+  const int64_t j = la.lfeat[i];
+  const float4 v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
+  double vf[VEC];
+  slice_get(v4, vf);
+  CoordSums s;
+  sums_zero(s);
+  for (uint32_t sg = la.lseg_ptr[i]; sg < la.lseg_ptr[i + 1]; ++sg) {  // segment order
+    const double* in = la.partial + (size_t)sg * LONG_STRIDE(KP);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { s.G[q] += in[lig * VEC + q]; s.Q[q] += in[KP + lig * VEC + q]; }
+    s.Gw += in[2 * KP]; s.Qw += in[2 * KP + 1]; s.cnt += in[2 * KP + 2];
+  }
+  float* gtail = exchange_tail<LPR>(T);
+  double rows = a.global_rows;
+  if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];
+  cols_finish<LPR, KIND>(a, h, T, j, lig, vf, s, rows);
+}
+
 template <int KIND>
-static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const ColsTables& T) {
+static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la, const ColsTables& T) {
   const int lpr = e->kp32 / 4;
   const int fpw = WG_THREADS / lpr;
   const int64_t lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)T.p;
   const int64_t grid = lists > 0 ? (lists + fpw - 1) / fpw : 1;  // at least workgroup 0: it also does the w0 step
   FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "cols_update: grid too large");
   dim3 g((unsigned)grid), b(WG_THREADS);
-#define FMX_COLS_CASE(L) \
-  case L: hipLaunchKernelGGL((fm_cols_update_k<L, KIND>), g, b, 0, e->stream, a, e->hyper, T); break;
+  const bool lng = a.walk && la.n_long > 0;
+  dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + fpw - 1) / fpw));
+  constexpr bool NQ = (KIND == UPD_FTRL);
+#define FMX_COLS_CASE(L)                                                                                        \
+  case L:                                                                                                       \
+    hipLaunchKernelGGL((fm_cols_update_k<L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                         \
+    if (lng) {                                                                                                  \
+      hipLaunchKernelGGL((fm_cols_long_partial_k<L, NQ>), g1, b, 0, e->stream, la, a, T);                       \
+      hipLaunchKernelGGL((fm_cols_long_finish_k<L, KIND>), g2, b, 0, e->stream, la, a, e->hyper, T);            \
+    }                                                                                                           \
+    break;
   switch (lpr) {
     FMX_COLS_CASE(1) FMX_COLS_CASE(2) FMX_COLS_CASE(4) FMX_COLS_CASE(8)
     FMX_COLS_CASE(16) FMX_COLS_CASE(32) FMX_COLS_CASE(64)
@@ -516,7 +652,7 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const ColsTables& 
   return FMX_OK;
 }
 
-int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
+int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la) {
   ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->scal_next, e->partials, a.n_partials,
                e->gbuf, (uint32_t)e->p, (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0};
   FMX_CHECK(!(a.load_gbuf || a.store_gbuf || a.scalar == SCALAR_PUBLISH || a.scalar == SCALAR_FROM_TAIL) || e->gbuf != nullptr,
@@ -524,9 +660,9 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a) {
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
   switch (e->hyper.kind) {
-    case UPD_SGD_L2: st = launch_cols_kind<UPD_SGD_L2>(e, a, T); break;
-    case UPD_SGD_L1: st = launch_cols_kind<UPD_SGD_L1>(e, a, T); break;
-    default: st = launch_cols_kind<UPD_FTRL>(e, a, T); break;
+    case UPD_SGD_L2: st = launch_cols_kind<UPD_SGD_L2>(e, a, la, T); break;
+    case UPD_SGD_L1: st = launch_cols_kind<UPD_SGD_L1>(e, a, la, T); break;
+    default: st = launch_cols_kind<UPD_FTRL>(e, a, la, T); break;
   }
   prof_end(e);
   if (st == FMX_OK && (a.scalar == SCALAR_FUSED || a.scalar == SCALAR_FROM_TAIL)) std::swap(e->scal, e->scal_next);  // the kernel wrote the next step's scalars

@@ -104,6 +104,14 @@ __global__ void touched_flags_k(const uint32_t* __restrict__ bptr, uint32_t p, u
   if (j < (int64_t)p) flags[j] = bptr[j + 1] > bptr[j];
 }
 
+__global__ void max_list_len_k(const uint32_t* __restrict__ bptr, uint32_t p, uint32_t* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < (int64_t)p) {
+    const uint32_t len = bptr[j + 1] - bptr[j];
+    if (len > LIST_LONG_MIN) atomicMax(out, len);
+  }
+}
+
 __global__ void touched_offsets_k(const uint32_t* __restrict__ bptr, const uint32_t* __restrict__ tfeat, uint32_t n, uint32_t end,
                                   uint32_t* __restrict__ toff) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,6 +176,54 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     FMX_TRY(csc_of_range<uint32_t>(m, s, bits, r0, nrows, base, cnt, m->brow + base, m->bval + base,
                                    m->bptr + (size_t)t * ((size_t)m->p + 1), stream));
   }
+  // Long lists (heavy hitters of a skewed feature distribution): per tile the features whose list exceeds LIST_LONG_MIN entries,
+  // each cut into segments of LIST_SEG entries (fm_batch_kernels.hip walks a segment with one wave).
+  (void)hipFree(m->lplan); m->lplan = nullptr;
+  m->long_tiles.assign((size_t)nt, fmx_matrix::LongTile{0, 0, 0, 0, 0, 0, 0});
+  m->max_long_seg = 0;
+  {
+    uint32_t* d_max = nullptr;
+    FMX_HIP(hipMalloc(&d_max, sizeof(uint32_t)));
+    std::vector<uint32_t> plan;  // all tiles: lfeat | lseg_ptr | seg_feat | seg_begin | seg_end
+    std::vector<uint32_t> hb((size_t)m->p + 1);
+    for (int64_t t = 0; t < nt; ++t) {
+      const uint32_t* tb = m->bptr + (size_t)t * ((size_t)m->p + 1);
+      uint32_t h = 0;
+      FMX_HIP(hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream));
+      hipLaunchKernelGGL(max_list_len_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream, tb, m->p, d_max);
+      FMX_HIP(hipMemcpyAsync(&h, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      FMX_HIP(hipStreamSynchronize(stream));
+      if (h == 0) continue;  // no list above LIST_LONG_MIN in this tile
+      FMX_HIP(hipMemcpy(hb.data(), tb, hb.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> lfeat, lseg{0}, sfeat, sbeg, send;
+      for (uint32_t j = 0; j < m->p; ++j) {
+        const uint32_t len = hb[j + 1] - hb[j];
+        if (len <= LIST_LONG_MIN) continue;
+        const uint32_t li = (uint32_t)lfeat.size();
+        lfeat.push_back(j);
+        for (uint32_t b = hb[j]; b < hb[j + 1]; b += LIST_SEG) {
+          sfeat.push_back(li);
+          sbeg.push_back(b);
+          send.push_back(b + LIST_SEG < hb[j + 1] ? b + LIST_SEG : hb[j + 1]);
+        }
+        lseg.push_back((uint32_t)sfeat.size());
+      }
+      auto& lt = m->long_tiles[(size_t)t];
+      lt.n_long = (int64_t)lfeat.size(); lt.n_seg = (int64_t)sfeat.size();
+      lt.off_lfeat = (int64_t)plan.size(); plan.insert(plan.end(), lfeat.begin(), lfeat.end());
+      lt.off_lseg = (int64_t)plan.size(); plan.insert(plan.end(), lseg.begin(), lseg.end());
+      lt.off_sfeat = (int64_t)plan.size(); plan.insert(plan.end(), sfeat.begin(), sfeat.end());
+      lt.off_sbeg = (int64_t)plan.size(); plan.insert(plan.end(), sbeg.begin(), sbeg.end());
+      lt.off_send = (int64_t)plan.size(); plan.insert(plan.end(), send.begin(), send.end());
+      if (lt.n_seg > m->max_long_seg) m->max_long_seg = lt.n_seg;
+    }
+    (void)hipFree(d_max);
+    if (!plan.empty()) {
+      FMX_HIP(hipMalloc(&m->lplan, plan.size() * sizeof(uint32_t)));
+      FMX_HIP(hipMemcpy(m->lplan, plan.data(), plan.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+  }
+
   // Sparse tiles: when a tile holds fewer entries than half the features, most features do not occur in it and the
   // per-feature walk should skip them: keep the ascending list of the features that do occur.
   m->tfeat_ptr.assign((size_t)nt + 1, 0);
@@ -336,9 +392,9 @@ __global__ void normalize_apply_k(int64_t nnz, const uint32_t* __restrict__ col,
 
 // the cached inverted indices hold copies of the values: drop them so they are rebuilt from the new values
 static void drop_value_caches(fmx_matrix* m) {
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff);
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff); (void)hipFree(m->lplan);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
-  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->tfeat = nullptr; m->toff = nullptr; m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
+  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->tfeat = nullptr; m->toff = nullptr; m->lplan = nullptr; m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
   m->batch_rows = 0; m->tile_rows = 0;
 }
 

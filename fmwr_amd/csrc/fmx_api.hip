@@ -137,6 +137,7 @@ static int ensure_workspace(fmx_engine* e, int64_t tile_rows, int64_t step_rows)
   if (tile_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(e->stream));
   (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
+  (void)hipFree(e->long_partial);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
   e->S = nullptr; e->amul = nullptr; e->partials = nullptr; e->ws_rows = 0; e->ws_partials = 0;
   FMX_HIP(hipMalloc(&e->S, (size_t)tile_rows * e->kp32 * sizeof(float)));
@@ -181,7 +182,7 @@ static void visit_order(int64_t n, int random_step, int64_t max_iter, std::vecto
 static void free_matrix(fmx_matrix* m) {
   if (!m) return;
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff);
+  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff); (void)hipFree(m->lplan);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats);
   delete m;
 }
@@ -322,6 +323,20 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
     c.scalar = !last ? SCALAR_NONE : (finish_local ? SCALAR_FUSED : SCALAR_PUBLISH);
     c.n_partials = last ? partials : 0;
     c.global_rows = (double)step_rows;
+    LongArgs la{};
+    if (!m->long_tiles.empty() && m->long_tiles[(size_t)tiles[i].tile].n_long > 0) {  // heavy hitters in this tile
+      const auto& lt = m->long_tiles[(size_t)tiles[i].tile];
+      const int64_t need = m->max_long_seg * (2 * (int64_t)e->kp32 + 4);
+      if (need > e->long_partial_cap) {
+        FMX_HIP(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->long_partial); e->long_partial = nullptr; e->long_partial_cap = 0;
+        FMX_HIP(hipMalloc(&e->long_partial, (size_t)need * sizeof(double)));
+        e->long_partial_cap = need;
+      }
+      la = LongArgs{m->lplan + lt.off_lfeat, m->lplan + lt.off_lseg, m->lplan + lt.off_sfeat, m->lplan + lt.off_sbeg, m->lplan + lt.off_send,
+                    e->long_partial, lt.n_long, lt.n_seg};
+      c.long_min = LIST_LONG_MIN;
+    }
     // a sparse tile that is a whole fused step walks only the features occurring in it (the exchange buffer is dense:
     // tiles that read or write it visit every feature)
     const int64_t tl = m->tfeat_ptr.empty() ? 0 : m->tfeat_ptr[(size_t)tiles[i].tile + 1] - m->tfeat_ptr[(size_t)tiles[i].tile];
@@ -330,7 +345,7 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
       c.toff = m->toff + m->tfeat_ptr[(size_t)tiles[i].tile] + tiles[i].tile;
       c.n_tfeat = (uint32_t)tl;
     }
-    FMX_TRY(launch_cols_update(e, c));
+    FMX_TRY(launch_cols_update(e, c, la));
   }
   return FMX_OK;
 }
@@ -424,6 +439,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
   (void)hipFree(e->dt1V); (void)hipFree(e->dt1w); (void)hipFree(e->dt2V); (void)hipFree(e->dt2w); (void)hipFree(e->dt3V); (void)hipFree(e->dt3w);
   (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
+  (void)hipFree(e->long_partial);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -855,7 +871,7 @@ int fmx_apply(fmx_engine* e, int64_t global_rows) {
   c.apply = 1;
   c.scalar = SCALAR_FROM_TAIL;
   c.global_rows = (double)global_rows;
-  return launch_cols_update(e, c);
+  return launch_cols_update(e, c, LongArgs{});
 }
 
 int fmx_sync(fmx_engine* e) {

@@ -105,6 +105,11 @@ struct fmx_matrix {
   std::vector<int64_t> step_first_tile;  // [n_batches+1]
   uint32_t* bptr = nullptr;  // [n_tiles][p+1] offsets relative to row_ptr[tile_start[t]]
   // sparse tiles (far fewer entries than features): the ascending ids of the features that occur in the tile
+  // long lists per tile (plan built at ingest; empty for data without heavy hitters)
+  uint32_t* lplan = nullptr;               // one allocation: per tile lfeat | lseg_ptr | seg_feat | seg_begin | seg_end
+  struct LongTile { int64_t off_lfeat, off_lseg, off_sfeat, off_sbeg, off_send, n_long, n_seg; };
+  std::vector<LongTile> long_tiles;        // [n_tiles]
+  int64_t max_long_seg = 0;                // largest n_seg over the tiles (sizes the partial buffer)
   uint32_t* tfeat = nullptr;               // concatenated over the tiles that have a list
   uint32_t* toff = nullptr;                // their entry offsets (bptr[tfeat[i]]), one extra end marker per tile: at tfeat_ptr[t] + t
   std::vector<int64_t> tfeat_ptr;          // [n_tiles+1] into tfeat; an empty range = no list (dense walk over all p)
@@ -154,6 +159,8 @@ struct fmx_engine {
   float* amul = nullptr;      // [ws_rows] per-row gradient multiplier
   double* partials = nullptr; // [ws_partials][2]
   int64_t ws_partials = 0;
+  double* long_partial = nullptr;  // segment sums of the long lists
+  int64_t long_partial_cap = 0;
   float* gbuf = nullptr;      // multi-GPU exchange buffer
   int64_t gbuf_floats = 0;
   // tracker (core/Tracker.h): records of the last fmx_train_tracked
@@ -200,6 +207,7 @@ struct ColsArgs {
   const uint32_t* brow;  // based at the tile's first entry
   const float* bval;
   uint32_t rows_active;  // tile rows taking part (a truncated step cuts the last tile)
+  uint32_t long_min;     // lists longer than this are handled by the long-list kernels (0: none in this tile)
   const uint32_t* tfeat; // ids of the features occurring in the tile (ascending), or null: walk all p features
   const uint32_t* toff;  // [n_tfeat+1] entry offsets of those features (compact copy of bptr)
   uint32_t n_tfeat;
@@ -211,7 +219,19 @@ struct ColsArgs {
   int64_t n_partials;    // phase 1's per-workgroup partial sums to reduce (SCALAR_FUSED / SCALAR_PUBLISH)
   double global_rows;    // rows of the whole step (all tiles; all ranks when known), <= 0: take it from the buffer tail
 };
-int launch_cols_update(fmx_engine* e, const ColsArgs& a);
+// long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
+struct LongArgs {
+  const uint32_t* lfeat;      // [n_long] feature ids, ascending
+  const uint32_t* lseg_ptr;   // [n_long+1] segments of each long feature
+  const uint32_t* seg_feat;   // [n_seg] index into lfeat
+  const uint32_t* seg_begin;  // [n_seg] entry range of the segment (offsets like bptr)
+  const uint32_t* seg_end;
+  double* partial;            // [n_seg][2*kp+4] segment sums
+  int64_t n_long, n_seg;
+};
+constexpr uint32_t LIST_LONG_MIN = 64;    // a list of more than this many entries is a long list
+constexpr uint32_t LIST_SEG = 1024;  // entries per segment (one wave)
+int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la);
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count);
 

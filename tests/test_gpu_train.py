@@ -419,3 +419,52 @@ def test_mcmc_vsweep_with_caller_drawn_normals(fm):
     gerr = e.als_vsweep(m, err0, alpha=0.7, v_lambda=lam, v_mu=mu, std_normals=z)
     assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
     assert not np.allclose(rv, oracle.als_update_v(k, X, v.ravel(), err0, alpha=0.7, v_lambda=lam, v_mu=mu)[0])  # it really sampled
+
+
+@pytest.mark.parametrize("name", ["sgd_l2_cls", "sgd_l1_cls", "ftrl_l1l2_cls"])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_long_lists_heavy_hitter_features(fm, name, reduce):
+    """Skewed data: a few features occur in (almost) every row, so their per-tile lists are far longer than the 64-entry
+    threshold and are cut into wave-sized segments (two extra kernels).  Same answers as the oracle, through the fused
+    step, tiled steps and the grad/apply split; and bitwise reproducible."""
+    engine, L = fm
+    c = next(x for x in CASES if x["name"] == name)
+    rng = np.random.default_rng(5)
+    n, p, batch = 3000, 400, 1500
+    rows = []
+    for r in range(n):
+        hot = [j for j in (0, 1, 7) if rng.random() < (0.95, 0.6, 0.3)[(0, 1, 7).index(j)]]
+        cold = rng.choice(np.arange(8, p), 5, replace=False).tolist()
+        rows.append(np.sort(np.array(hot + cold)))
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows).astype(np.uint32)
+    val = rng.normal(0, 1, len(col)).astype(np.float32)
+    task = "classification" if c["task"] == oracle.CLASSIFICATION else "regression"
+    y = util.labels(n, 9, task)
+    kw = {k: v for k, v in c.items() if k not in ("name", "solver")}
+    P = oracle.params(min_target=float(y.min()), max_target=float(y.max()), batch_mean=(reduce == "mean"), **kw)
+    w0, w, v = util.params(p, P.k, 9, fp32=True)
+    X = oracle.Matrix(rp, col, val, p)
+    mb = (oracle.SgdMinibatch if c["solver"] == "sgd" else oracle.FtrlMinibatch)(P, X, y, w0, w, v.ravel())
+    for s in range(6):
+        b0 = (s % 2) * batch
+        mb.step(b0, b0 + batch)
+    solver = L.SOLVER_SGD if c["solver"] == "sgd" else L.SOLVER_FTRL
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    rv = mb.v.reshape(P.k, p)
+    outs = []
+    for tile, split in ((0, False), (0, False), (400, False), (0, True)):  # fused twice (reproducibility), tiled, grad/apply
+        e = engine.Engine(p, task=P.task, solver=solver, num_factor=P.k, l2_w0=P.l2_reg0, l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv,
+                          l2_v=P.l2_regv, learn_rate=P.learn_rate, mode=L.MODE_MINIBATCH, batch_rows=batch, tile_rows=tile,
+                          batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM)
+        e.set_params(w0, w, v)
+        for s in range(6):
+            if split:
+                e.grad(m, s % 2); e.apply(0)
+            else:
+                e.step(m, s % 2)
+        e.sync()
+        g0, gw, gv = e.get_params()
+        assert util.rel_err(gv, rv) < 3e-5 and util.rel_err(gw, mb.w) < 3e-5 and abs(g0 - mb.w0.value) < 3e-5 * max(1.0, abs(mb.w0.value)), (tile, split)
+        outs.append((g0, gw, gv))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
