@@ -468,3 +468,27 @@ def test_long_lists_heavy_hitter_features(fm, name, reduce):
         assert util.rel_err(gv, rv) < 3e-5 and util.rel_err(gw, mb.w) < 3e-5 and abs(g0 - mb.w0.value) < 3e-5 * max(1.0, abs(mb.w0.value)), (tile, split)
         outs.append((g0, gw, gv))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_long_lists_inside_a_sparse_tile(fm):
+    """Both ingest plans at once: far fewer entries than features (occurring-feature walk) AND a heavy hitter (long list)."""
+    engine, L = fm
+    rng = np.random.default_rng(17)
+    n, p, batch, k = 4000, 20000, 2000, 8
+    rows = [np.sort(np.concatenate([[3] if rng.random() < 0.9 else [], rng.choice(np.arange(10, p), 3, replace=False)]).astype(np.int64)) for _ in range(n)]
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows).astype(np.uint32)
+    val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, 17)
+    P = oracle.params(k=k, l2_regw=1e-3, l2_regv=1e-3, learn_rate=0.05)
+    w0, w, v = util.params(p, k, 17, fp32=True)
+    mb = oracle.SgdMinibatch(P, oracle.Matrix(rp, col, val, p), y, w0, w, v.ravel())
+    e = engine.Engine(p, num_factor=k, l2_w1=1e-3, l2_v=1e-3, learn_rate=0.05, mode=L.MODE_MINIBATCH, batch_rows=batch)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    for s in range(4):
+        mb.step((s % 2) * batch, (s % 2 + 1) * batch)
+        e.step(m, s % 2)
+    e.sync()
+    g0, gw, gv = e.get_params()
+    assert util.rel_err(gv, mb.v.reshape(k, p)) < V_RTOL and util.rel_err(gw, mb.w) < V_RTOL and abs(g0 - mb.w0.value) < V_RTOL
