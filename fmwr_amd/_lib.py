@@ -21,7 +21,7 @@ KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3
 # every symbol include/fmx.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
     "fmx_last_error", "fmx_config_default", "fmx_engine_create", "fmx_engine_destroy", "fmx_set_params",
-    "fmx_get_params", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
+    "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
     "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
     "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
     "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",

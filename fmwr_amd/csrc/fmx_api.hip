@@ -506,6 +506,98 @@ int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v) {
   return FMX_OK;
 }
 
+namespace fmx {
+
+struct CkptHeader {
+  char magic[4];
+  uint32_t version;
+  uint64_t p;
+  int32_t k, kp, mode, kind;
+  uint32_t scalars;
+  uint32_t reserved[7];
+};
+static_assert(sizeof(CkptHeader) == 64, "checkpoint header is 64 bytes");
+
+// every device table of the engine with its element size and count, in file order
+static void ckpt_tables(fmx_engine* e, std::vector<std::pair<void*, size_t>>* out) {
+  const size_t p = (size_t)e->p;
+  auto add = [&](void* ptr, size_t bytes) { if (ptr) out->push_back({ptr, bytes}); };
+  add(e->V, p * e->kp32 * sizeof(float)); add(e->w, p * sizeof(float));
+  add(e->sV, p * e->kp32 * sizeof(float)); add(e->sw, p * sizeof(float));
+  add(e->nV, p * e->kp32 * sizeof(float)); add(e->nw, p * sizeof(float));
+  add(e->dV, p * e->kp64 * sizeof(double)); add(e->dw, p * sizeof(double));
+  add(e->dsV, p * e->kp64 * sizeof(double)); add(e->dsw, p * sizeof(double));
+  add(e->dnV, p * e->kp64 * sizeof(double)); add(e->dnw, p * sizeof(double));
+  add(e->dt1V, p * e->kp64 * sizeof(double)); add(e->dt1w, p * sizeof(double));
+  add(e->dt2V, p * e->kp64 * sizeof(double)); add(e->dt2w, p * sizeof(double));
+  add(e->dt3V, p * e->kp64 * sizeof(double)); add(e->dt3w, p * sizeof(double));
+}
+
+static CkptHeader ckpt_header(const fmx_engine* e) {
+  CkptHeader h{};
+  memcpy(h.magic, "FMX1", 4);
+  h.version = 1; h.p = e->p; h.k = e->k; h.kp = seq_mode(e) ? e->kp64 : e->kp32; h.mode = e->cfg.mode; h.kind = e->hyper.kind;
+  h.scalars = SC_COUNT;
+  return h;
+}
+
+}  // namespace fmx
+
+int fmx_engine_save(fmx_engine* e, const char* path) {
+  FMX_CHECK(e != nullptr && path != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  FILE* f = fopen(path, "wb");
+  FMX_CHECK(f != nullptr, FMX_ERR_INVALID, "cannot open %s for writing", path);
+  const CkptHeader h = ckpt_header(e);
+  double scal[SC_COUNT];
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && hipMemcpy(scal, e->scal, sizeof(scal), hipMemcpyDeviceToHost) == hipSuccess &&
+            fwrite(scal, sizeof(scal), 1, f) == 1;
+  std::vector<std::pair<void*, size_t>> tabs;
+  ckpt_tables(e, &tabs);
+  std::vector<char> buf;
+  for (auto& t : tabs) {
+    if (!ok) break;
+    buf.resize(t.second);
+    ok = hipMemcpy(buf.data(), t.first, t.second, hipMemcpyDeviceToHost) == hipSuccess && fwrite(buf.data(), 1, t.second, f) == t.second;
+  }
+  ok = (fclose(f) == 0) && ok;
+  FMX_CHECK(ok, FMX_ERR_INVALID, "writing %s failed", path);
+  return FMX_OK;
+}
+
+int fmx_engine_load(fmx_engine* e, const char* path) {
+  FMX_CHECK(e != nullptr && path != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  FILE* f = fopen(path, "rb");
+  FMX_CHECK(f != nullptr, FMX_ERR_INVALID, "cannot open %s", path);
+  CkptHeader h{}, want = ckpt_header(e);
+  bool ok = fread(&h, sizeof(h), 1, f) == 1;
+  if (!ok || memcmp(h.magic, "FMX1", 4) != 0 || h.version != 1) { fclose(f); set_error("%s is not an fmx checkpoint", path); return FMX_ERR_INVALID; }
+  if (h.p != want.p || h.k != want.k || h.kp != want.kp || h.mode != want.mode || h.kind != want.kind || h.scalars != want.scalars) {
+    fclose(f);
+    set_error("checkpoint shape (p=%llu k=%d mode=%d kind=%d) does not match the engine (p=%llu k=%d mode=%d kind=%d)", (unsigned long long)h.p, h.k, h.mode,
+              h.kind, (unsigned long long)want.p, want.k, want.mode, want.kind);
+    return FMX_ERR_INVALID;
+  }
+  double scal[SC_COUNT];
+  ok = fread(scal, sizeof(scal), 1, f) == 1 && hipMemcpy(e->scal, scal, sizeof(scal), hipMemcpyHostToDevice) == hipSuccess;
+  std::vector<std::pair<void*, size_t>> tabs;
+  ckpt_tables(e, &tabs);
+  std::vector<char> buf;
+  for (auto& t : tabs) {
+    if (!ok) break;
+    buf.resize(t.second);
+    ok = fread(buf.data(), 1, t.second, f) == t.second && hipMemcpy(t.first, buf.data(), t.second, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  fclose(f);
+  FMX_CHECK(ok, FMX_ERR_INVALID, "reading %s failed (truncated?)", path);
+  e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
+  FMX_HIP(hipDeviceSynchronize());
+  return FMX_OK;
+}
+
 int fmx_matrix_from_csr(int device, int64_t n, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
                         const float* y, fmx_matrix** out) {
   FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");

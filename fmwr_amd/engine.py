@@ -129,6 +129,12 @@ class Engine:
         v = vv[: self.k * self.p].reshape(self.p, self.k).T.copy()
         return w0.value, w, v
 
+    def save(self, path):
+        L.check(L.lib().fmx_engine_save(self.h, str(path).encode()))
+
+    def load(self, path):
+        L.check(L.lib().fmx_engine_load(self.h, str(path).encode()))
+
     def predict(self, m, link=L.LINK_NONE):
         out = np.zeros(max(m.n, 1))
         L.check(L.lib().fmx_predict(self.h, m.h, _p(out), C.c_int(link)))

@@ -112,6 +112,13 @@ int fmx_engine_destroy(fmx_engine* e);
 int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v);
 int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v);
 
+/* ---- checkpoint (the reference keeps a model only as an R list and drops the optimizer state on fm.update):
+ * parameters AND optimizer state (SGD-L1 q/u, FTRL z/n, TDAP u/nu/delta/h/z) to a file and back.  The loading engine must
+ * have the same feature count, factor count, solver kind and mode.  Format: 64-byte header ("FMX1", version, shape),
+ * the device scalars, then the tables as stored on the device (little endian). */
+int fmx_engine_save(fmx_engine* e, const char* path);
+int fmx_engine_load(fmx_engine* e, const char* path);
+
 /* ---- data: replaces `SMatrix<float> m; m.assign(X); DVector<float> tg; tg.assign(target)`
  *      (src/FM.cpp:31-44).  All inputs are host pointers; the matrix is copied to HBM. */
 

@@ -492,3 +492,34 @@ def test_long_lists_inside_a_sparse_tile(fm):
     e.sync()
     g0, gw, gv = e.get_params()
     assert util.rel_err(gv, mb.v.reshape(k, p)) < V_RTOL and util.rel_err(gw, mb.w) < V_RTOL and abs(g0 - mb.w0.value) < V_RTOL
+
+
+@pytest.mark.parametrize("mode,solver", [("minibatch", "sgd_l1"), ("minibatch", "ftrl"), ("sequential", "ftrl"), ("sequential", "tdap")])
+def test_checkpoint_resumes_bit_identically(fm, tmp_path, mode, solver):
+    """fmx_engine_save / _load carry parameters AND optimizer state: a run interrupted by a save/load equals the
+    uninterrupted one bit for bit (the reference's fm.update drops the optimizer state)."""
+    engine, L = fm
+    n, p, k = 900, 120, 5
+    rp, col, val = util.random_csr(n, p, 8, seed=81)
+    y = util.labels(n, 81)
+    w0, w, v = util.params(p, k, 81)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    kw = dict(num_factor=k, learn_rate=0.05, l2_v=1e-3, l1_w1=1e-3, l1_v=1e-3, mode=L.MODE_MINIBATCH if mode == "minibatch" else L.MODE_SEQUENTIAL,
+              batch_rows=128, solver={"sgd_l1": L.SOLVER_SGD, "ftrl": L.SOLVER_FTRL, "tdap": L.SOLVER_TDAP}[solver])
+    order = np.arange(1, 601)
+    def advance(e, part):
+        if mode == "minibatch":
+            for s in range(4 * part, 4 * part + 4):
+                e.step(m, s % 8)
+            e.sync()
+        else:
+            e.train_order(m, order[300 * part:300 * (part + 1)])
+    a = engine.Engine(p, **kw); a.set_params(w0, w, v); advance(a, 0); advance(a, 1)
+    b = engine.Engine(p, **kw); b.set_params(w0, w, v); advance(b, 0)
+    path = tmp_path / "ck.fmx"
+    b.save(path)
+    c = engine.Engine(p, **kw); c.load(path); advance(c, 1)
+    pa, pc = a.get_params(), c.get_params()
+    assert pa[0] == pc[0] and np.array_equal(pa[1], pc[1]) and np.array_equal(pa[2], pc[2])
+    with pytest.raises(L.FmxError, match="does not match"):
+        engine.Engine(p + 1, **kw).load(path)
