@@ -48,6 +48,12 @@ __global__ void als_q_init_k(const int64_t* __restrict__ row_ptr, const uint32_t
   qe[r].x = acc;
 }
 
+// q of factor f out of the all-factor table Q[n][kp] (one strided read per row instead of a gather per nonzero)
+__global__ void als_q_pick_k(const double* __restrict__ Q, int kp, int f, int64_t n, double2* __restrict__ qe) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) qe[r].x = Q[(size_t)r * kp + f];
+}
+
 __global__ void als_pack_k(const double* __restrict__ err, int64_t n, double2* __restrict__ qe) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) qe[r] = make_double2(0.0, err[r]);
@@ -60,7 +66,9 @@ __global__ void als_unpack_k(const double2* __restrict__ qe, int64_t n, double* 
 
 __device__ __forceinline__ bool bad_number(double x) { return isnan(x) || isinf(x); }
 
-// one wave per feature of the level
+// one wave per feature of the level.  The first ALS_KEEP entries per lane (512 per wave: almost every column) stay in
+// registers between the two passes, so the rank-1 correction pass does not gather q/e again.
+constexpr int ALS_KEEP = 8;
 __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
                                                           const uint32_t* __restrict__ crow, const float* __restrict__ cval,
                                                           double* __restrict__ V, int kp, int f, double2* __restrict__ qe,
@@ -72,7 +80,25 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
   const int64_t b = col_ptr[i], e = col_ptr[i + 1];
   const double v_old = V[(size_t)i * kp + f];
   double v_mean = 0.0, v_var = 0.0;
-  for (int64_t t = b + lane; t < e; t += 64) {  // :310-317
+  float kx[ALS_KEEP];
+  uint32_t kr[ALS_KEEP];
+  double2 kc[ALS_KEEP];
+#pragma unroll
+  for (int s = 0; s < ALS_KEEP; ++s) {  // :310-317, entries lane, lane+64, ... (independent gathers: all in flight together)
+    const int64_t t = b + lane + 64 * s;
+    const bool in = t < e;
+    kx[s] = in ? cval[t] : 0.f;
+    kr[s] = in ? crow[t] : 0u;
+    kc[s] = in ? qe[kr[s]] : make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int s = 0; s < ALS_KEEP; ++s) {
+    const float xx = kx[s] * kx[s];
+    const double h = (double)kx[s] * kc[s].x - (double)xx * v_old;  // x = 0 for the padding slots: h = 0
+    v_mean += h * kc[s].y;
+    v_var += h * h;
+  }
+  for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
     const float x = cval[t];
     const uint32_t r = crow[t];
     const float xx = x * x;
@@ -94,7 +120,15 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
   if (bad_number(v_new)) return;                         // CHECK_PARAM (:336): keep the old value, skip the corrections
   if (lane == 0) V[(size_t)i * kp + f] = v_new;
   const double v_diff = v_old - v_new;
-  for (int64_t t = b + lane; t < e; t += 64) {  // :341-350
+#pragma unroll
+  for (int s = 0; s < ALS_KEEP; ++s) {  // :341-350 from the kept entries
+    if (b + lane + 64 * s < e) {
+      const float xx = kx[s] * kx[s];
+      const double h = (double)kx[s] * kc[s].x - (double)xx * v_old;
+      qe[kr[s]] = make_double2(kc[s].x - (double)kx[s] * v_diff, kc[s].y - h * v_diff);
+    }
+  }
+  for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
     const float x = cval[t];
     const uint32_t r = crow[t];
     const float xx = x * x;
@@ -228,8 +262,18 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   const std::vector<int64_t>& level_ptr = m->als_level_ptr;
   const int L = (int)level_ptr.size() - 1;
+  // q_f = X v_f only depends on column f of V, which no other factor's sweep touches: all k of them come out of ONE
+  // row-gather pass (the forward kernel on the fp64 tables) instead of one gather per nonzero per factor
+  double* d_Q = nullptr;
+  if (hipMalloc(&d_Q, (size_t)m->n * e->kp64 * sizeof(double)) == hipSuccess) {
+    RowsArgs a{};
+    a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
+    a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.link = FMX_LINK_NONE;
+    if (launch_rows_forward(e, a, false, true) != FMX_OK) { (void)hipFree(d_Q); d_Q = nullptr; }
+  }
   for (int f = 0; f < e->k; ++f) {
-    hipLaunchKernelGGL(als_q_init_k, dim3(row_grid), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_qe);
+    if (d_Q) hipLaunchKernelGGL(als_q_pick_k, dim3(row_grid), dim3(256), 0, e->stream, d_Q, e->kp64, f, m->n, d_qe);
+    else hipLaunchKernelGGL(als_q_init_k, dim3(row_grid), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_qe);
     const double lambda = h_lambda ? h_lambda[f] : 0.0, mu = h_mu ? h_mu[f] : 0.0;
     for (int l = 0; l < L; ++l) {
       const int64_t cnt = level_ptr[(size_t)l + 1] - level_ptr[(size_t)l];
@@ -240,6 +284,7 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
                          d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
     }
   }
+  if (d_Q) { (void)hipStreamSynchronize(e->stream); (void)hipFree(d_Q); }
 }
 
 // MCMC_ALS_Learner::learn for the ALS learner, REGRESSION (:91-156): per iteration a fresh forward, e = y_hat - y, the w0

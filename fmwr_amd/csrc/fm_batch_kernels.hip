@@ -177,7 +177,10 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
       a.partials[2 * (size_t)blockIdx.x + 1] = q0;
     }
   } else {
-    if (have && lig == 0) a.yhat[row] = link_apply(h, y_hat, a.link);
+    if (have && lig == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link);
+    if constexpr (sizeof(T) == 8) {  // fp64 tables: optionally the per-row factor sums q[row][f] = sum_j x_j v_jf (ALS sweeps)
+      if (have && a.qout) *reinterpret_cast<double2*>(a.qout + (size_t)row * KP + lig * VEC) = make_double2(s[0], s[1]);
+    }
   }
 }
 

@@ -193,7 +193,8 @@ struct RowsArgs {
   float* S;             // [nrows][kp32] (train)
   float* amul;          // [nrows]       (train)
   double* partials;     // [grid][2]     (train)
-  double* yhat;         // [nrows]       (predict) -- indexed from 0
+  double* yhat;         // [nrows]       (predict) -- indexed from 0; may be null when only qout is wanted
+  double* qout;         // [nrows][kp64] (predict, fp64 tables) per-row factor sums, or null
   int link;
 };
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
