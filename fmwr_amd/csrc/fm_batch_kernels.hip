@@ -1,23 +1,27 @@
-// Mini-batch hot path for gfx950: two gather-reduce kernels over sparse lists plus a scalar kernel.
+// Mini-batch hot path for gfx950: two gather-reduce kernels over sparse lists.
 //
 //   phase 1  fm_rows_forward : per example (CSR row) gather the V rows of its nonzeros, reduce
 //                              sum_f / sum_sqr_f, form y_hat and the gradient multiplier.
 //                              Replaces Model::predict (core/Model.h:75-103) + calculate_grad_mult
-//                              (solver/SGD_Learner.h:180-191) for a whole batch, and
+//                              (solver/SGD_Learner.h:180-191) for a whole tile, and
 //                              Model::predict_batch / predict_prob (core/Model.h:106-180) when !TRAIN.
-//   scalar   fm_scalar_update: deterministic reduction of the multipliers and the w0 step
-//                              (SGD_Learner.h:106-109, FTRL_Learner.h:80-86,161).
-//   phase 2  fm_cols_update  : per feature (row of the batch's CSC) gather the per-example factor sums,
-//                              reduce the coordinate's gradient sums and apply the update
-//                              (SGD_Learner.h:111-138, FTRL_Learner.h:88-113,158-202) once.
+//   phase 2  fm_cols_update  : per feature (row of the tile's CSC) gather the per-example factor sums,
+//                              reduce the coordinate's gradient sums and finish the coordinate: add / publish through the
+//                              exchange buffer and/or apply the update (SGD_Learner.h:111-138,
+//                              FTRL_Learner.h:88-113,158-202) once.  Its workgroup 0 also reduces phase 1's partial sums
+//                              and does the w0 step (SGD_Learner.h:106-109, FTRL_Learner.h:80-86,161).
+//            fm_cols_long_*  : the same for heavy-hitter features whose lists are too long for one lane group.
+//
+// A step (batch) is one or more tiles; parameters are frozen across the tiles of a step and the sums accumulate in the
+// exchange buffer (which is also what N > 1 GPUs all-reduce).
 //
 // Both gathers use one skeleton: a group of LPR lanes owns one list; each lane keeps a 16-byte slice of
 // the table row (4 floats / 2 doubles), so one wave-instruction fetches 64/LPR whole rows, every row as
 // one contiguous 16*LPR-byte segment (k=16 fp32: 64 B).  The (id, x) entries of all lists of a workgroup
 // are contiguous in memory; they are staged through LDS with coalesced loads so the row gathers issue
-// back to back.  Accumulation is fp64 in registers (the kernels are HBM/fabric bound; VALU is idle), in
-// list order, which makes every result independent of launch geometry and bitwise reproducible.
-// No MFMA: this is a sparse gather-reduce, not a dense contraction.
+// back to back.  Accumulation is fp64 in registers (the kernels are bound by the memory system's random-line rate;
+// VALU is idle), in list order, which makes every result independent of launch geometry and bitwise reproducible.
+// No MFMA: this is a sparse gather-reduce, not a dense contraction.  No atomics anywhere.
 #include <utility>
 
 #include "fmx_internal.h"
