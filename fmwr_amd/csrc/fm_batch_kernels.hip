@@ -467,6 +467,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   constexpr bool NEED_Q = (KIND == UPD_FTRL);
   __shared__ uint2 stage[STAGE_ENTRIES];
   __shared__ double red_g[WG_THREADS], red_q[WG_THREADS];
+  __shared__ unsigned long long wg_next;
 
   const int tid = threadIdx.x;
   const int gid = tid / LPR;
@@ -494,12 +495,23 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
     if (have) { ta = off[I0 + gid]; tb = off[I0 + gid + 1]; }
     if (a.long_min > 0 && tb - ta > (int64_t)a.long_min) { have = false; ta = tb = 0; }  // a long list: not ours
     const float* __restrict__ St = T.S + lig * VEC;
-    for (int64_t c0 = lo; c0 < hi; c0 += STAGE_ENTRIES) {
+    int64_t c0 = lo;
+    while (c0 < hi) {
+      if (a.long_min > 0) {
+        // The entries of long lists lie between those of this workgroup's short lists (one heavy hitter can hold 10^5 of
+        // them): jump straight to the first entry that a short list still needs.
+        if (tid == 0) wg_next = ~0ull;
+        __syncthreads();
+        if (tb > c0) atomicMin(&wg_next, (unsigned long long)(ta > c0 ? ta : c0));
+        __syncthreads();
+        const unsigned long long nx = wg_next;
+        __syncthreads();
+        if (nx == ~0ull) break;
+        c0 = (int64_t)nx;
+      }
       const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
       const int64_t b = ta > c0 ? ta : c0;
       const int64_t e = tb < c0 + cn ? tb : c0 + cn;
-      // chunks that only hold entries of long lists are skipped by the whole workgroup
-      if (a.long_min > 0 && !__syncthreads_or(b < e)) continue;
       stage_entries(stage, a.brow, a.bval, c0, cn);
       __syncthreads();
       for (int64_t t = b; t < e; t += FMX_U) {
@@ -524,6 +536,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
           if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(en[u].y));
       }
       __syncthreads();
+      c0 += STAGE_ENTRIES;
     }
   }
   float* gtail = exchange_tail<LPR>(T);

@@ -104,11 +104,11 @@ __global__ void touched_flags_k(const uint32_t* __restrict__ bptr, uint32_t p, u
   if (j < (int64_t)p) flags[j] = bptr[j + 1] > bptr[j];
 }
 
-__global__ void max_list_len_k(const uint32_t* __restrict__ bptr, uint32_t p, uint32_t* __restrict__ out) {
+__global__ void max_list_len_k(const uint32_t* __restrict__ bptr, uint32_t p, uint32_t long_min, uint32_t* __restrict__ out) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < (int64_t)p) {
     const uint32_t len = bptr[j + 1] - bptr[j];
-    if (len > LIST_LONG_MIN) atomicMax(out, len);
+    if (len > long_min) atomicMax(out, len);
   }
 }
 
@@ -176,7 +176,7 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     FMX_TRY(csc_of_range<uint32_t>(m, s, bits, r0, nrows, base, cnt, m->brow + base, m->bval + base,
                                    m->bptr + (size_t)t * ((size_t)m->p + 1), stream));
   }
-  // Long lists (heavy hitters of a skewed feature distribution): per tile the features whose list exceeds LIST_LONG_MIN entries,
+  // Long lists (heavy hitters of a skewed feature distribution): per tile the features whose list exceeds list_long_min() entries,
   // each cut into segments of LIST_SEG entries (fm_batch_kernels.hip walks a segment with one wave).
   (void)hipFree(m->lplan); m->lplan = nullptr;
   m->long_tiles.assign((size_t)nt, fmx_matrix::LongTile{0, 0, 0, 0, 0, 0, 0});
@@ -190,15 +190,15 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
       const uint32_t* tb = m->bptr + (size_t)t * ((size_t)m->p + 1);
       uint32_t h = 0;
       FMX_HIP(hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream));
-      hipLaunchKernelGGL(max_list_len_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream, tb, m->p, d_max);
+      hipLaunchKernelGGL(max_list_len_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream, tb, m->p, list_long_min(), d_max);
       FMX_HIP(hipMemcpyAsync(&h, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       FMX_HIP(hipStreamSynchronize(stream));
-      if (h == 0) continue;  // no list above LIST_LONG_MIN in this tile
+      if (h == 0) continue;  // no list above list_long_min() in this tile
       FMX_HIP(hipMemcpy(hb.data(), tb, hb.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
       std::vector<uint32_t> lfeat, lseg{0}, sfeat, sbeg, send;
       for (uint32_t j = 0; j < m->p; ++j) {
         const uint32_t len = hb[j + 1] - hb[j];
-        if (len <= LIST_LONG_MIN) continue;
+        if (len <= list_long_min()) continue;
         const uint32_t li = (uint32_t)lfeat.size();
         lfeat.push_back(j);
         for (uint32_t b = hb[j]; b < hb[j + 1]; b += LIST_SEG) {

@@ -335,7 +335,7 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
       }
       la = LongArgs{m->lplan + lt.off_lfeat, m->lplan + lt.off_lseg, m->lplan + lt.off_sfeat, m->lplan + lt.off_sbeg, m->lplan + lt.off_send,
                     e->long_partial, lt.n_long, lt.n_seg};
-      c.long_min = LIST_LONG_MIN;
+      c.long_min = list_long_min();
     }
     // a sparse tile that is a whole fused step walks only the features occurring in it (the exchange buffer is dense:
     // tiles that read or write it visit every feature)

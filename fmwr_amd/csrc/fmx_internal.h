@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -230,7 +231,11 @@ struct LongArgs {
   double* partial;            // [n_seg][2*kp+4] segment sums
   int64_t n_long, n_seg;
 };
-constexpr uint32_t LIST_LONG_MIN = 64;    // a list of more than this many entries is a long list
+// a list of more than this many entries is a long list (FMX_LONG_MIN in the environment overrides it: tuning only)
+inline uint32_t list_long_min() {
+  static const uint32_t v = [] { const char* s = getenv("FMX_LONG_MIN"); const long x = s ? atol(s) : 0; return x > 0 ? (uint32_t)x : 64u; }();
+  return v;
+}
 constexpr uint32_t LIST_SEG = 1024;  // entries per segment (one wave)
 int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la);
 
