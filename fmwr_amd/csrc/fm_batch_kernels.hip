@@ -617,26 +617,42 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   }
 }
 
+// one WAVE per long feature: its lane groups add the feature's segment sums strided (a heavy hitter has hundreds of
+// segments), a fixed butterfly combines them, group 0 finishes the feature
 template <int LPR, int KIND>
 __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la, ColsArgs a, Hyper h, ColsTables T) {
   constexpr int VEC = 4;
   constexpr int KP = LPR * VEC;
-  constexpr int FPW = WG_THREADS / LPR;
-  const int gid = threadIdx.x / LPR, lig = threadIdx.x % LPR;
-  const int64_t i = (int64_t)blockIdx.x * FPW + gid;
+  constexpr int NSUB = 64 / LPR;
+  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (WG_THREADS / 64) + (threadIdx.x >> 6);
   if (i >= la.n_long) return;
+  const int sub = lane / LPR, lig = lane % LPR;
   const int64_t j = la.lfeat[i];
   const float4 v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
   double vf[VEC];
   slice_get(v4, vf);
   CoordSums s;
   sums_zero(s);
-  for (uint32_t sg = la.lseg_ptr[i]; sg < la.lseg_ptr[i + 1]; ++sg) {  // segment order
+  for (uint32_t sg = la.lseg_ptr[i] + sub; sg < la.lseg_ptr[i + 1]; sg += NSUB) {
     const double* in = la.partial + (size_t)sg * LONG_STRIDE(KP);
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) { s.G[q] += in[lig * VEC + q]; s.Q[q] += in[KP + lig * VEC + q]; }
-    s.Gw += in[2 * KP]; s.Qw += in[2 * KP + 1]; s.cnt += in[2 * KP + 2];
+    for (int q = 0; q < VEC; ++q) { s.G[q] += in[lig * VEC + q]; if (NEED_Q) s.Q[q] += in[KP + lig * VEC + q]; }
+    s.Gw += in[2 * KP]; if (NEED_Q) s.Qw += in[2 * KP + 1]; s.cnt += in[2 * KP + 2];
   }
+#pragma unroll
+  for (int o = 32; o >= LPR; o >>= 1) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      s.G[q] += __shfl_xor(s.G[q], o);
+      if (NEED_Q) s.Q[q] += __shfl_xor(s.Q[q], o);
+    }
+    s.Gw += __shfl_xor(s.Gw, o);
+    if (NEED_Q) s.Qw += __shfl_xor(s.Qw, o);
+    s.cnt += __shfl_xor(s.cnt, o);
+  }
+  if (sub != 0) return;
   float* gtail = exchange_tail<LPR>(T);
   double rows = a.global_rows;
   if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];
@@ -652,7 +668,7 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "cols_update: grid too large");
   dim3 g((unsigned)grid), b(WG_THREADS);
   const bool lng = a.walk && la.n_long > 0;
-  dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + fpw - 1) / fpw));
+  dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + (WG_THREADS / 64) - 1) / (WG_THREADS / 64)));
   constexpr bool NQ = (KIND == UPD_FTRL);
 #define FMX_COLS_CASE(L)                                                                                        \
   case L:                                                                                                       \

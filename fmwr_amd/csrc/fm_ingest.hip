@@ -224,46 +224,57 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     }
   }
 
-  // Sparse tiles: when a tile holds fewer entries than half the features, most features do not occur in it and the
-  // per-feature walk should skip them: keep the ascending list of the features that do occur.
+  // Sparse tiles: when fewer than half the features occur in a tile (few entries, or a skewed feature distribution whose
+  // entries pile up on few features), the per-feature walk should skip the rest: keep the ascending list of the features
+  // that do occur, with a compact copy of their entry offsets.
   m->tfeat_ptr.assign((size_t)nt + 1, 0);
-  int64_t total = 0;
-  for (int64_t t = 0; t < nt; ++t) {
-    const int64_t cnt = m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t];
-    m->tfeat_ptr[(size_t)t] = total;
-    if (cnt * 2 < (int64_t)m->p) total += cnt;  // upper bound of the list length
-  }
-  m->tfeat_ptr[(size_t)nt] = total;
-  if (total > 0) {
-    FMX_HIP(hipMalloc(&m->tfeat, (size_t)total * sizeof(uint32_t)));
-    FMX_HIP(hipMalloc(&m->toff, ((size_t)total + (size_t)nt) * sizeof(uint32_t)));
+  {
     uint8_t* d_flags = nullptr;
     uint32_t* d_count = nullptr;
     void* d_tmp = nullptr;
-    size_t tmp_bytes = 0;
+    size_t tmp_bytes = 0, tb2 = 0;
     FMX_HIP(hipMalloc(&d_flags, (size_t)m->p));
     FMX_HIP(hipMalloc(&d_count, sizeof(uint32_t)));
     rocprim::counting_iterator<uint32_t> ids(0);
-    FMX_HIP(rocprim::select(nullptr, tmp_bytes, ids, d_flags, m->tfeat, d_count, (size_t)m->p, stream));
+    auto flags32 = rocprim::make_transform_iterator(d_flags, [] __device__(uint8_t v) { return (uint32_t)v; });
+    FMX_HIP(rocprim::select(nullptr, tmp_bytes, ids, d_flags, (uint32_t*)nullptr, d_count, (size_t)m->p, stream));
+    FMX_HIP(rocprim::reduce(nullptr, tb2, flags32, d_count, (uint32_t)0, (size_t)m->p, rocprim::plus<uint32_t>(), stream));
+    if (tb2 > tmp_bytes) tmp_bytes = tb2;
     FMX_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    std::vector<int64_t> real_ptr((size_t)nt + 1, 0);
-    int64_t at = 0;
+    // pass 1: how many features occur in each tile
+    std::vector<uint32_t> occ((size_t)nt, 0);
+    int64_t total = 0;
     for (int64_t t = 0; t < nt; ++t) {
-      real_ptr[(size_t)t] = at;
-      if (m->tfeat_ptr[(size_t)t + 1] == m->tfeat_ptr[(size_t)t]) continue;
+      const int64_t cnt = m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t];
+      if (cnt >= (int64_t)m->p * 4) continue;  // dense enough that (almost) every feature occurs: not worth counting
       hipLaunchKernelGGL(touched_flags_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream,
                          m->bptr + (size_t)t * ((size_t)m->p + 1), m->p, d_flags);
-      FMX_HIP(rocprim::select(d_tmp, tmp_bytes, ids, d_flags, m->tfeat + at, d_count, (size_t)m->p, stream));
+      FMX_HIP(rocprim::reduce(d_tmp, tmp_bytes, flags32, d_count, (uint32_t)0, (size_t)m->p, rocprim::plus<uint32_t>(), stream));
       uint32_t h = 0;
       FMX_HIP(hipMemcpyAsync(&h, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       FMX_HIP(hipStreamSynchronize(stream));
+      if ((int64_t)h * 2 < (int64_t)m->p) { occ[(size_t)t] = h; total += h; }
+    }
+    // pass 2: the lists
+    if (total > 0) {
+      FMX_HIP(hipMalloc(&m->tfeat, (size_t)total * sizeof(uint32_t)));
+      FMX_HIP(hipMalloc(&m->toff, ((size_t)total + (size_t)nt) * sizeof(uint32_t)));
+    }
+    int64_t at = 0;
+    for (int64_t t = 0; t < nt; ++t) {
+      m->tfeat_ptr[(size_t)t] = at;
+      if (occ[(size_t)t] == 0) continue;
+      hipLaunchKernelGGL(touched_flags_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream,
+                         m->bptr + (size_t)t * ((size_t)m->p + 1), m->p, d_flags);
+      FMX_HIP(rocprim::select(d_tmp, tmp_bytes, ids, d_flags, m->tfeat + at, d_count, (size_t)m->p, stream));
+      const uint32_t h = occ[(size_t)t];
       const uint32_t entries = (uint32_t)(m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t]);
       hipLaunchKernelGGL(touched_offsets_k, dim3((unsigned)((h + 1 + 255) / 256)), dim3(256), 0, stream,
                          m->bptr + (size_t)t * ((size_t)m->p + 1), m->tfeat + at, h, entries, m->toff + at + t);
       at += h;
     }
-    real_ptr[(size_t)nt] = at;
-    m->tfeat_ptr = real_ptr;
+    m->tfeat_ptr[(size_t)nt] = at;
+    FMX_HIP(hipStreamSynchronize(stream));
     (void)hipFree(d_flags); (void)hipFree(d_count); (void)hipFree(d_tmp);
   }
   FMX_HIP(hipStreamSynchronize(stream));
