@@ -42,17 +42,19 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
+    ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--cpu-rows", type=int, default=5_000_000, help="rows of the CPU-baseline sample (0: skip)")
     return ap.parse_args()
 
 
-def algorithmic_bytes(z, k, p, rows):
-    """Per-launch algorithmic HBM bytes of the two hot kernels and of the SURVEY 8(d) fused step (fp32 state)."""
-    rows_fwd = rows * (z * (4 + 4 + 4 + 4 * k) + 8 + 4 + 4 * k + 4)   # idx,val,w,V row | row_ptr, y, S row, mult
-    cols_upd = rows * z * (4 + 4 + 4 + 4 * k) + p * (4 + 8 * k + 8)    # row,val,mult,S row | bptr, V RMW, w RMW
-    survey_step = rows * (z * (16 + 8 * k) + 12)
+def algorithmic_bytes(z, k, p, rows, e=4):
+    """Per-launch algorithmic HBM bytes of the two hot kernels and of the SURVEY 8(d) fused step; e = bytes per state
+    element (4: the fp32 state SURVEY 8(d) prices; 8 with --state-fp64)."""
+    rows_fwd = rows * (z * (4 + 4 + e + e * k) + 8 + 4 + e * k + e)   # idx,val,w,V row | row_ptr, y, S row, mult
+    cols_upd = rows * z * (4 + 4 + e + e * k) + p * (4 + 2 * e * k + 2 * e)  # row,val,mult,S row | bptr, V RMW, w RMW
+    survey_step = rows * (z * (8 + 2 * e + 2 * e * k) + 12)
     return rows_fwd, cols_upd, survey_step
 
 
@@ -70,7 +72,8 @@ def pmc_traffic(kernel, args):
         def opt(name, default):
             return int(a[a.index(name) + 1]) if name in a else default
         same = (-(-opt("--batch-rows", 1_048_576) // -(-opt("--batch-rows", 1_048_576) // 262_144)) == -(-args.batch_rows // -(-args.batch_rows // 262_144)) and opt("--factors", 16) == args.factors and opt("--features", 1_000_000) == args.features
-                and opt("--rows", 10_000_000) == args.rows and opt("--nnz", 30) == args.nnz and ("ftrl" in a) == (args.solver == "ftrl"))
+                and opt("--rows", 10_000_000) == args.rows and opt("--nnz", 30) == args.nnz and ("ftrl" in a) == (args.solver == "ftrl")
+                and ("--state-fp64" in a) == bool(args.state_fp64))
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
             best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f))
     return best
@@ -129,7 +132,8 @@ def main():
     solver = L.SOLVER_SGD if args.solver == "sgd" else L.SOLVER_FTRL
     e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=solver, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
                       l1_w1=1e-4 if args.solver == "ftrl" else 0.0, l1_v=1e-4 if args.solver == "ftrl" else 0.0,
-                      mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=args.tile_rows, device=local_rank, keep_w1=0 if args.no_linear else 1)
+                      mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=args.tile_rows, device=local_rank, keep_w1=0 if args.no_linear else 1,
+                      state_fp64=int(args.state_fp64))
     v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
     e.set_params(0.0, None, v0.astype(np.float64))
     nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work
@@ -194,8 +198,9 @@ def main():
         upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
         tiles = -(-B // (args.tile_rows or (524_288 if k > 32 else 262_144)))  # fmx_api.hip effective_tile_rows()
         tile_rows = -(-B // tiles)
-        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p, tile_rows)   # per LAUNCH: one tile
-        b_step = algorithmic_bytes(z, k, p, B)[2]
+        eb = 8 if args.state_fp64 else 4
+        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p, tile_rows, eb)   # per LAUNCH: one tile
+        b_step = algorithmic_bytes(z, k, p, B, eb)[2]
         kernels = {
             "fm_rows_forward": (b_fwd, fwd_ms / max(fwd_n, 1)),
             "fm_cols_update": (b_upd, upd_ms / max(upd_n, 1)),
@@ -207,11 +212,11 @@ def main():
         out = {
             "metric": "training examples/sec, 10Mx1M sparse FM SGD", "value": value, "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.state_fp64 else "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch "
                                    f"(BASELINE.json configs[{1 if args.solver == 'sgd' else 2}])",
                        "batch_rows_per_gpu": B, "tile_rows": tile_rows, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
-                       "state": "fp32 V[p][k] + w[p], fp64 accumulation", "parallelism": f"dp{world}"},
+                       "state": ("fp64" if args.state_fp64 else "fp32") + " V[p][k] + w[p], fp64 accumulation", "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": (f"profiles/{traffic[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB per launch, separate --pmc passes; "

@@ -61,6 +61,10 @@ template <> struct Slice<double> { using vec = double2; static constexpr int N =
 
 __device__ __forceinline__ void slice_get(const float4& v, double* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 __device__ __forceinline__ void slice_get(const double2& v, double* o) { o[0] = v.x; o[1] = v.y; }
+// the other direction; the second argument only selects the element type
+__device__ __forceinline__ float4 slice_make(const double* v, float) { return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
+__device__ __forceinline__ double2 slice_make(const double* v, double) { return make_double2(v[0], v[1]); }
+__device__ __forceinline__ float4 slice_make(const float* v, float) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // solver/SGD_Learner.h:180-191 (copy in FTRL_Learner.h:204-215)
 __device__ __forceinline__ double grad_mult(const Hyper& h, double y_hat, float y) {
@@ -168,9 +172,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
     double mult = 0.0;
     if (have) {
       mult = grad_mult(h, y_hat, a.y[a.r0 + row]);
-      float4 sf = make_float4((float)s[0], (float)s[1], (float)s[VEC > 2 ? 2 : 0], (float)s[VEC > 3 ? 3 : 0]);
-      *reinterpret_cast<float4*>(a.S + (size_t)row * KP + lig * VEC) = sf;
-      if (lig == 0) a.amul[row] = (float)mult;
+      *reinterpret_cast<vec_t*>(reinterpret_cast<T*>(a.S) + (size_t)row * KP + lig * VEC) = slice_make(s, T());
+      if (lig == 0) reinterpret_cast<T*>(a.amul)[row] = (T)mult;
     }
     if (lig == 0) red[gid] = mult;
     __syncthreads();
@@ -213,8 +216,7 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_
   prof_begin(e, FMX_KERNEL_ROWS_FORWARD);
   int st;
   if (fp64_tables) {
-    FMX_CHECK(!train, FMX_ERR_INVALID, "mini-batch training runs on fp32 tables");
-    st = launch_rows_t<double, false>(e, a, e->kp64);
+    st = train ? launch_rows_t<double, true>(e, a, e->kp64) : launch_rows_t<double, false>(e, a, e->kp64);
   } else if (train) {
     st = launch_rows_t<float, true>(e, a, e->kp32);
   } else {
@@ -230,8 +232,9 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_
 // `sin` (the step's start state) and only this function writes `sout`; the host flips the two after the launch.
 // mode: SCALAR_FUSED reduce + update, SCALAR_PUBLISH reduce only -> exchange-buffer tail, SCALAR_FROM_TAIL update from the
 // (all-reduced) tail.
+template <typename ST>
 __device__ __forceinline__ void scalar_update(const double* __restrict__ partials, int64_t n_partials, const double* sin,
-                                              double* sout, float* gtail, const Hyper& h, double rows, int mode,
+                                              double* sout, ST* gtail, const Hyper& h, double rows, int mode,
                                               double* sg, double* sq) {
   const int phase = (mode == SCALAR_PUBLISH) ? 1 : (mode == SCALAR_FROM_TAIL) ? 2 : 0;
   double g0 = 0.0, q0 = 0.0;
@@ -246,7 +249,7 @@ __device__ __forceinline__ void scalar_update(const double* __restrict__ partial
   }
   if (threadIdx.x != 0) return;
   g0 = sg[0]; q0 = sq[0];
-  if (phase == 1) { gtail[0] = (float)g0; gtail[1] = (float)q0; gtail[2] = (float)rows; gtail[3] = 0.f; return; }
+  if (phase == 1) { gtail[0] = (ST)g0; gtail[1] = (ST)q0; gtail[2] = (ST)rows; gtail[3] = (ST)0; return; }
   if (phase == 2) { g0 = gtail[0]; q0 = gtail[1]; if (rows <= 0.0) rows = gtail[2]; }
   for (int i = 0; i < SC_COUNT; ++i) sout[i] = sin[i];
   sout[SC_G0] = g0; sout[SC_Q0] = q0;
@@ -275,15 +278,16 @@ __device__ __forceinline__ void scalar_update(const double* __restrict__ partial
 }
 
 // ------------------------------------------------------------------------------------------------ phase 2
+template <typename ST>
 struct ColsTables {
-  float *V, *w, *sV, *sw, *nV, *nw;
-  const float* S;
-  const float* amul;
+  ST *V, *w, *sV, *sw, *nV, *nw;
+  const ST* S;
+  const ST* amul;
   const double* scal;   // this step's start scalars (read-only during the step)
   double* scal_out;     // next step's scalars (written by workgroup 0)
   const double* partials;
   int64_t n_partials;
-  float* gbuf;
+  ST* gbuf;
   uint32_t p;
   int has_q;  // exchange buffer carries the sum-of-squares planes (FTRL with FMX_REDUCE_SUM only)
 };
@@ -304,9 +308,9 @@ __device__ __forceinline__ double ftrl_prox(double z, double n, double l1, doubl
 }
 
 // One coordinate's update from its batch sums (G = sum g, Q = sum g^2, cnt occurrences); state in/out.
-template <int KIND>
+template <int KIND, typename ST>
 __device__ __forceinline__ double coord_update(const Hyper& h, bool is_w, double theta, double G, double Q, double cnt,
-                                               double decay, double u, float& st_a, float& st_b, bool keep) {
+                                               double decay, double u, ST& st_a, ST& st_b, bool keep) {
   if constexpr (KIND == UPD_SGD_L2) {
     (void)Q; (void)u; (void)st_a; (void)st_b; (void)cnt; (void)is_w;
     if (!keep) return theta;
@@ -317,7 +321,7 @@ __device__ __forceinline__ double coord_update(const Hyper& h, bool is_w, double
     double t = theta - h.lr * G;
     double q = st_a;
     apply_penalty(t, u, q);
-    st_a = (float)q;
+    st_a = (ST)q;
     return t;
   } else {
     (void)decay; (void)u; (void)cnt;
@@ -328,13 +332,14 @@ __device__ __forceinline__ double coord_update(const Hyper& h, bool is_w, double
       const double n_new = n + Q;
       z += G - theta * (sqrt(n_new) - sqrt(n)) / alpha;
       n = n_new;
-      st_a = (float)z; st_b = (float)n;
+      st_a = (ST)z; st_b = (ST)n;
     }
     return ftrl_prox((double)st_a, (double)st_b, l1, l2, alpha, beta);
   }
 }
 
-// One (feature, lane-slice) worth of batch sums: the lane's 4 factors plus the feature's linear term
+// One (feature, lane-slice) worth of batch sums: the lane's factors (4 of an fp32 table, 2 of an fp64 one) plus the
+// feature's linear term
 struct CoordSums {
   double G[4], Q[4];
   double Gw, Qw, cnt;
@@ -347,8 +352,9 @@ __device__ __forceinline__ void sums_zero(CoordSums& s) {
 }
 
 // one occurrence (row r with value x) of the feature whose batch-start V slice is vf
-template <bool NEED_Q>
-__device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const float4& srow, float amul, float xf) {
+template <bool NEED_Q, typename VT, typename ST>
+__device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const VT& srow, ST amul, float xf) {
+  constexpr int VEC = 16 / sizeof(ST);
   const double x = (double)xf;
   const double ax = (double)amul * x;  // mult * x: the w gradient, SGD_Learner.h:114
   s.Gw += ax;
@@ -357,7 +363,7 @@ __device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const f
   double sf[4];
   slice_get(srow, sf);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < VEC; ++i) {
     const double g = ax * (sf[i] - vf[i] * x);  // mult*(sum_f*x - v*x*x), SGD_Learner.h:129
     s.G[i] += g;
     if (NEED_Q) s.Q[i] += g * g;
@@ -366,37 +372,42 @@ __device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const f
 
 // What happens to a feature's sums: [+ the exchange buffer's] -> [publish] -> [apply the update].  Shared by the main
 // kernel (short lists) and the long-list finisher.  Called by every lane of the feature's group; lig == 0 handles w.
-template <int LPR, int KIND>
-__device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, const ColsTables& T, int64_t j, int lig, const double* vf,
+template <typename ST, int LPR, int KIND>
+__device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, const ColsTables<ST>& T, int64_t j, int lig, const double* vf,
                                             CoordSums& s, double rows) {
-  constexpr int VEC = 4;
+  using vec_t = typename Slice<ST>::vec;
+  constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr bool NEED_Q = (KIND == UPD_FTRL);
   // exchange buffer planes: GV [p][KP] | GW [p] | CNT [p] | (has_q: QV [p][KP] | QW [p]) | tail[4]
-  float* gGV = T.gbuf;
-  float* gGW = T.gbuf ? T.gbuf + (size_t)T.p * KP : nullptr;
-  float* gCN = T.gbuf ? gGW + T.p : nullptr;
-  float* gQV = T.gbuf ? gCN + T.p : nullptr;
-  float* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
+  ST* gGV = T.gbuf;
+  ST* gGW = T.gbuf ? T.gbuf + (size_t)T.p * KP : nullptr;
+  ST* gCN = T.gbuf ? gGW + T.p : nullptr;
+  ST* gQV = T.gbuf ? gCN + T.p : nullptr;
+  ST* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
+  const size_t at = (size_t)j * KP + lig * VEC;
 
   if (a.load_gbuf) {  // sums of earlier tiles of this step, or the all-reduced sums of the whole global batch
-    float4 g4 = *reinterpret_cast<const float4*>(gGV + (size_t)j * KP + lig * VEC);
-    s.G[0] += g4.x; s.G[1] += g4.y; s.G[2] += g4.z; s.G[3] += g4.w;
+    double g[VEC];
+    slice_get(*reinterpret_cast<const vec_t*>(gGV + at), g);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s.G[i] += g[i];
     s.Gw += gGW[j];
     s.cnt += gCN[j];
     if (NEED_Q && T.has_q) {
-      float4 q4 = *reinterpret_cast<const float4*>(gQV + (size_t)j * KP + lig * VEC);
-      s.Q[0] += q4.x; s.Q[1] += q4.y; s.Q[2] += q4.z; s.Q[3] += q4.w;
+      slice_get(*reinterpret_cast<const vec_t*>(gQV + at), g);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s.Q[i] += g[i];
       s.Qw += gQW[j];
     }
   }
   if (a.store_gbuf) {  // publish the sums so far (every feature, zeros included)
-    *reinterpret_cast<float4*>(gGV + (size_t)j * KP + lig * VEC) = make_float4((float)s.G[0], (float)s.G[1], (float)s.G[2], (float)s.G[3]);
-    if (NEED_Q && T.has_q) *reinterpret_cast<float4*>(gQV + (size_t)j * KP + lig * VEC) = make_float4((float)s.Q[0], (float)s.Q[1], (float)s.Q[2], (float)s.Q[3]);
+    *reinterpret_cast<vec_t*>(gGV + at) = slice_make(s.G, ST());
+    if (NEED_Q && T.has_q) *reinterpret_cast<vec_t*>(gQV + at) = slice_make(s.Q, ST());
     if (lig == 0) {
-      gGW[j] = (float)s.Gw;
-      gCN[j] = (float)s.cnt;
-      if (NEED_Q && T.has_q) gQW[j] = (float)s.Qw;
+      gGW[j] = (ST)s.Gw;
+      gCN[j] = (ST)s.cnt;
+      if (NEED_Q && T.has_q) gQW[j] = (ST)s.Qw;
     }
   }
   // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
@@ -424,44 +435,56 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
     u_w = T.scal[SC_UW] + r * (h.lr * h.regw);
     u_v = T.scal[SC_UV] + r * (h.lr * h.regv);
   }
-  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
-  if constexpr (KIND != UPD_SGD_L2) sa = *reinterpret_cast<const float4*>(T.sV + (size_t)j * KP + lig * VEC);
-  if constexpr (KIND == UPD_FTRL) sb = *reinterpret_cast<const float4*>(T.nV + (size_t)j * KP + lig * VEC);
-  float sa_[VEC] = {sa.x, sa.y, sa.z, sa.w}, sb_[VEC] = {sb.x, sb.y, sb.z, sb.w};
-  float out[VEC];
+  double tmp[VEC];
+  ST sa_[VEC], sb_[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { sa_[i] = (ST)0; sb_[i] = (ST)0; }
+  if constexpr (KIND != UPD_SGD_L2) {
+    slice_get(*reinterpret_cast<const vec_t*>(T.sV + at), tmp);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sa_[i] = (ST)tmp[i];
+  }
+  if constexpr (KIND == UPD_FTRL) {
+    slice_get(*reinterpret_cast<const vec_t*>(T.nV + at), tmp);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sb_[i] = (ST)tmp[i];
+  }
+  double out[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i)
-    out[i] = (float)coord_update<KIND>(h, false, vf[i], s.G[i], s.Q[i], cnt, decay_v, u_v, sa_[i], sb_[i], true);
-  *reinterpret_cast<float4*>(T.V + (size_t)j * KP + lig * VEC) = make_float4(out[0], out[1], out[2], out[3]);
-  if constexpr (KIND != UPD_SGD_L2) *reinterpret_cast<float4*>(T.sV + (size_t)j * KP + lig * VEC) = make_float4(sa_[0], sa_[1], sa_[2], sa_[3]);
-  if constexpr (KIND == UPD_FTRL) *reinterpret_cast<float4*>(T.nV + (size_t)j * KP + lig * VEC) = make_float4(sb_[0], sb_[1], sb_[2], sb_[3]);
+    out[i] = coord_update<KIND, ST>(h, false, vf[i], s.G[i], s.Q[i], cnt, decay_v, u_v, sa_[i], sb_[i], true);
+  *reinterpret_cast<vec_t*>(T.V + at) = slice_make(out, ST());
+  if constexpr (KIND != UPD_SGD_L2) *reinterpret_cast<vec_t*>(T.sV + at) = slice_make(sa_, ST());
+  if constexpr (KIND == UPD_FTRL) *reinterpret_cast<vec_t*>(T.nV + at) = slice_make(sb_, ST());
   if (lig == 0) {
     // FTRL recomputes w on every touched column even when keep.w1 is off (FTRL_Learner.h:172-183); SGD skips (:111)
     const bool k1 = h.k1 != 0;
     if (k1 || KIND == UPD_FTRL) {
-      float wa = 0.f, wb = 0.f;
+      ST wa = (ST)0, wb = (ST)0;
       if constexpr (KIND != UPD_SGD_L2) wa = T.sw[j];
       if constexpr (KIND == UPD_FTRL) wb = T.nw[j];
-      const double wn = coord_update<KIND>(h, true, (double)T.w[j], s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
-      T.w[j] = (float)wn;
+      const double wn = coord_update<KIND, ST>(h, true, (double)T.w[j], s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
+      T.w[j] = (ST)wn;
       if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
       if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
     }
   }
 }
 
-template <int LPR>
-__device__ __forceinline__ float* exchange_tail(const ColsTables& T) {
+template <typename ST, int LPR>
+__device__ __forceinline__ ST* exchange_tail(const ColsTables<ST>& T) {
   if (!T.gbuf) return nullptr;
-  float* gCN = T.gbuf + (size_t)T.p * (LPR * 4) + T.p;
-  return T.has_q ? gCN + T.p + (size_t)T.p * (LPR * 4) + T.p : gCN + T.p;  // the Q planes exist only with has_q
+  constexpr int KP = LPR * Slice<ST>::N;
+  ST* gCN = T.gbuf + (size_t)T.p * KP + T.p;
+  return T.has_q ? gCN + T.p + (size_t)T.p * KP + T.p : gCN + T.p;  // the Q planes exist only with has_q
 }
 
 // Main phase-2 kernel: one group of LPR lanes per feature list.  Lists longer than a.long_min entries (heavy hitters of a
 // skewed feature distribution) are left to the long-list kernels below; walking them with one group would serialise the tile.
-template <int LPR, int KIND>
-__global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables T) {
-  constexpr int VEC = 4;
+template <typename ST, int LPR, int KIND>
+__global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables<ST> T) {
+  using vec_t = typename Slice<ST>::vec;
+  constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr int FPW = WG_THREADS / LPR;  // features (lists) per workgroup
   constexpr bool NEED_Q = (KIND == UPD_FTRL);
@@ -482,10 +505,10 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   // contiguous: the features between them have none)
   const uint32_t* __restrict__ off = a.tfeat ? a.toff : a.bptr;
 
-  float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (have) v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
   double vf[VEC];
-  slice_get(v4, vf);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) vf[i] = 0.0;
+  if (have) slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
   CoordSums s;
   sums_zero(s);
 
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
     int64_t ta = 0, tb = 0;
     if (have) { ta = off[I0 + gid]; tb = off[I0 + gid + 1]; }
     if (a.long_min > 0 && tb - ta > (int64_t)a.long_min) { have = false; ta = tb = 0; }  // a long list: not ours
-    const float* __restrict__ St = T.S + lig * VEC;
+    const ST* __restrict__ St = T.S + lig * VEC;
     int64_t c0 = lo;
     while (c0 < hi) {
       if (a.long_min > 0) {
@@ -524,8 +547,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
           ok[u] = en[u].x < a.rows_active;  // truncated batch: rows beyond the limit do not take part
           if (!ok[u]) en[u].x = 0;
         }
-        float4 sv[FMX_U];
-        float av[FMX_U];
+        vec_t sv[FMX_U];
+        ST av[FMX_U];
 #pragma unroll
         for (int u = 0; u < FMX_U; ++u) {
           sv[u] = gather_row(St + (size_t)en[u].x * KP);
@@ -539,11 +562,11 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       c0 += STAGE_ENTRIES;
     }
   }
-  float* gtail = exchange_tail<LPR>(T);
+  ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
   if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
 
-  if (have) cols_finish<LPR, KIND>(a, h, T, j, lig, vf, s, rows);
+  if (have) cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
 
   if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
     scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
@@ -556,9 +579,10 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
 // Fixed geometry and order: results stay bitwise reproducible.
 constexpr int LONG_STRIDE(int kp) { return 2 * kp + 4; }  // doubles per segment: G[kp] | Q[kp] | Gw, Qw, cnt, pad
 
-template <int LPR, bool NEED_Q>
-__global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la, ColsArgs a, ColsTables T) {
-  constexpr int VEC = 4;
+template <typename ST, int LPR, bool NEED_Q>
+__global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la, ColsArgs a, ColsTables<ST> T) {
+  using vec_t = typename Slice<ST>::vec;
+  constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr int NSUB = 64 / LPR;
   const int lane = threadIdx.x & 63;
@@ -567,12 +591,11 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   const int sub = lane / LPR, lig = lane % LPR;
   const int64_t j = la.lfeat[la.seg_feat[seg]];
   const int64_t ta = la.seg_begin[seg], tb = la.seg_end[seg];
-  const float4 v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
   double vf[VEC];
-  slice_get(v4, vf);
+  slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
   CoordSums s;
   sums_zero(s);
-  const float* __restrict__ St = T.S + lig * VEC;
+  const ST* __restrict__ St = T.S + lig * VEC;
   for (int64_t t = ta + sub; t < tb; t += (int64_t)NSUB * FMX_U) {
     uint32_t r[FMX_U];
     float x[FMX_U];
@@ -586,8 +609,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
       ok[u] = r[u] < a.rows_active;
       if (!ok[u]) r[u] = 0;
     }
-    float4 sv[FMX_U];
-    float av[FMX_U];
+    vec_t sv[FMX_U];
+    ST av[FMX_U];
 #pragma unroll
     for (int u = 0; u < FMX_U; ++u) {
       sv[u] = gather_row(St + (size_t)r[u] * KP);
@@ -619,9 +642,10 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
 
 // one WAVE per long feature: its lane groups add the feature's segment sums strided (a heavy hitter has hundreds of
 // segments), a fixed butterfly combines them, group 0 finishes the feature
-template <int LPR, int KIND>
-__global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la, ColsArgs a, Hyper h, ColsTables T) {
-  constexpr int VEC = 4;
+template <typename ST, int LPR, int KIND>
+__global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la, ColsArgs a, Hyper h, ColsTables<ST> T) {
+  using vec_t = typename Slice<ST>::vec;
+  constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr int NSUB = 64 / LPR;
   constexpr bool NEED_Q = (KIND == UPD_FTRL);
@@ -630,9 +654,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
   if (i >= la.n_long) return;
   const int sub = lane / LPR, lig = lane % LPR;
   const int64_t j = la.lfeat[i];
-  const float4 v4 = *reinterpret_cast<const float4*>(T.V + (size_t)j * KP + lig * VEC);
   double vf[VEC];
-  slice_get(v4, vf);
+  slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
   CoordSums s;
   sums_zero(s);
   for (uint32_t sg = la.lseg_ptr[i] + sub; sg < la.lseg_ptr[i + 1]; sg += NSUB) {
@@ -653,15 +676,15 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
     s.cnt += __shfl_xor(s.cnt, o);
   }
   if (sub != 0) return;
-  float* gtail = exchange_tail<LPR>(T);
+  ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
   if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];
-  cols_finish<LPR, KIND>(a, h, T, j, lig, vf, s, rows);
+  cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
 }
 
-template <int KIND>
-static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la, const ColsTables& T) {
-  const int lpr = e->kp32 / 4;
+template <typename ST, int KIND>
+static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la, const ColsTables<ST>& T) {
+  const int lpr = mb_lpr(e);
   const int fpw = WG_THREADS / lpr;
   const int64_t lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)T.p;
   const int64_t grid = lists > 0 ? (lists + fpw - 1) / fpw : 1;  // at least workgroup 0: it also does the w0 step
@@ -672,33 +695,45 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   constexpr bool NQ = (KIND == UPD_FTRL);
 #define FMX_COLS_CASE(L)                                                                                        \
   case L:                                                                                                       \
-    hipLaunchKernelGGL((fm_cols_update_k<L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                         \
+    hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                     \
     if (lng) {                                                                                                  \
-      hipLaunchKernelGGL((fm_cols_long_partial_k<L, NQ>), g1, b, 0, e->stream, la, a, T);                       \
-      hipLaunchKernelGGL((fm_cols_long_finish_k<L, KIND>), g2, b, 0, e->stream, la, a, e->hyper, T);            \
+      hipLaunchKernelGGL((fm_cols_long_partial_k<ST, L, NQ>), g1, b, 0, e->stream, la, a, T);                   \
+      hipLaunchKernelGGL((fm_cols_long_finish_k<ST, L, KIND>), g2, b, 0, e->stream, la, a, e->hyper, T);        \
     }                                                                                                           \
     break;
   switch (lpr) {
     FMX_COLS_CASE(1) FMX_COLS_CASE(2) FMX_COLS_CASE(4) FMX_COLS_CASE(8)
     FMX_COLS_CASE(16) FMX_COLS_CASE(32) FMX_COLS_CASE(64)
-    default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", e->kp32);
+    default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", mb_kp(e));
   }
 #undef FMX_COLS_CASE
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 
+template <typename ST>
+static int launch_cols_state(fmx_engine* e, const ColsArgs& a, const LongArgs& la, const ColsTables<ST>& T) {
+  switch (e->hyper.kind) {
+    case UPD_SGD_L2: return launch_cols_kind<ST, UPD_SGD_L2>(e, a, la, T);
+    case UPD_SGD_L1: return launch_cols_kind<ST, UPD_SGD_L1>(e, a, la, T);
+    default: return launch_cols_kind<ST, UPD_FTRL>(e, a, la, T);
+  }
+}
+
 int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la) {
-  ColsTables T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, e->S, e->amul, e->scal, e->scal_next, e->partials, a.n_partials,
-               e->gbuf, (uint32_t)e->p, (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0};
   FMX_CHECK(!(a.load_gbuf || a.store_gbuf || a.scalar == SCALAR_PUBLISH || a.scalar == SCALAR_FROM_TAIL) || e->gbuf != nullptr,
             FMX_ERR_STATE, "exchange buffer not allocated");
+  const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
-  switch (e->hyper.kind) {
-    case UPD_SGD_L2: st = launch_cols_kind<UPD_SGD_L2>(e, a, la, T); break;
-    case UPD_SGD_L1: st = launch_cols_kind<UPD_SGD_L1>(e, a, la, T); break;
-    default: st = launch_cols_kind<UPD_FTRL>(e, a, la, T); break;
+  if (mb_wide(e)) {
+    ColsTables<double> T{e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw, (const double*)e->S, (const double*)e->amul, e->scal, e->scal_next,
+                         e->partials, a.n_partials, (double*)e->gbuf, (uint32_t)e->p, has_q};
+    st = launch_cols_state<double>(e, a, la, T);
+  } else {
+    ColsTables<float> T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, (const float*)e->S, (const float*)e->amul, e->scal, e->scal_next,
+                        e->partials, a.n_partials, (float*)e->gbuf, (uint32_t)e->p, has_q};
+    st = launch_cols_state<float>(e, a, la, T);
   }
   prof_end(e);
   if (st == FMX_OK && (a.scalar == SCALAR_FUSED || a.scalar == SCALAR_FROM_TAIL)) std::swap(e->scal, e->scal_next);  // the kernel wrote the next step's scalars

@@ -131,7 +131,7 @@ static int reset_optimizer_state(fmx_engine* e) {
 }
 
 static int ensure_workspace(fmx_engine* e, int64_t tile_rows, int64_t step_rows) {
-  const int rpw = WG_THREADS / (e->kp32 / 4);
+  const int rpw = WG_THREADS / mb_lpr(e);
   const int64_t tiles = (step_rows + tile_rows - 1) / tile_rows;
   const int64_t partials = ((tile_rows + rpw - 1) / rpw) * (tiles > 0 ? tiles : 1);
   if (tile_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
@@ -140,8 +140,8 @@ static int ensure_workspace(fmx_engine* e, int64_t tile_rows, int64_t step_rows)
   (void)hipFree(e->long_partial);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
   e->S = nullptr; e->amul = nullptr; e->partials = nullptr; e->ws_rows = 0; e->ws_partials = 0;
-  FMX_HIP(hipMalloc(&e->S, (size_t)tile_rows * e->kp32 * sizeof(float)));
-  FMX_HIP(hipMalloc(&e->amul, (size_t)tile_rows * sizeof(float)));
+  FMX_HIP(hipMalloc(&e->S, (size_t)tile_rows * mb_kp(e) * mb_elem(e)));
+  FMX_HIP(hipMalloc(&e->amul, (size_t)tile_rows * mb_elem(e)));
   FMX_HIP(hipMalloc(&e->partials, (size_t)partials * 2 * sizeof(double)));
   e->ws_rows = tile_rows;
   e->ws_partials = partials;
@@ -152,8 +152,9 @@ static int ensure_gbuf(fmx_engine* e) {
   if (e->gbuf) return FMX_OK;
   // GV [p][kp] | GW [p] | CNT [p] | (QV [p][kp] | QW [p]: only FTRL with FMX_REDUCE_SUM needs sum(g^2)) | tail[4]
   const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
-  e->gbuf_floats = (int64_t)e->p * e->kp32 * (has_q ? 2 : 1) + (int64_t)e->p * (has_q ? 3 : 2) + 4;
-  FMX_TRY(dev_alloc_zero(&e->gbuf, (size_t)e->gbuf_floats));
+  e->gbuf_floats = (int64_t)e->p * mb_kp(e) * (has_q ? 2 : 1) + (int64_t)e->p * (has_q ? 3 : 2) + 4;
+  FMX_HIP(hipMalloc(&e->gbuf, (size_t)e->gbuf_floats * mb_elem(e)));
+  FMX_HIP(hipMemset(e->gbuf, 0, (size_t)e->gbuf_floats * mb_elem(e)));
   FMX_HIP(hipDeviceSynchronize());
   return FMX_OK;
 }
@@ -228,12 +229,12 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = nullptr;
     a.r0 = b; a.nrows = (r1 - b < SLAB) ? r1 - b : SLAB;
-    a.V = seq_mode(e) ? (const void*)e->dV : (const void*)e->V;
-    a.w = seq_mode(e) ? (const void*)e->dw : (const void*)e->w;
+    a.V = wide_state(e) ? (const void*)e->dV : (const void*)e->V;
+    a.w = wide_state(e) ? (const void*)e->dw : (const void*)e->w;
     a.scal = e->scal;
     a.yhat = d_out + (b - r0);
     a.link = link;
-    FMX_TRY(launch_rows_forward(e, a, false, seq_mode(e)));
+    FMX_TRY(launch_rows_forward(e, a, false, wide_state(e)));
   }
   return FMX_OK;
 }
@@ -280,11 +281,13 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t pa
   RowsArgs a{};
   a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = m->y;
   a.r0 = t.r0; a.nrows = t.nrows;
-  a.V = e->V; a.w = e->w; a.scal = e->scal;
+  a.V = mb_wide(e) ? (const void*)e->dV : (const void*)e->V;
+  a.w = mb_wide(e) ? (const void*)e->dw : (const void*)e->w;
+  a.scal = e->scal;
   a.S = e->S; a.amul = e->amul; a.partials = e->partials + 2 * partial_offset;
-  const int rpw = WG_THREADS / (e->kp32 / 4);
+  const int rpw = WG_THREADS / mb_lpr(e);
   *n_partials = (t.nrows + rpw - 1) / rpw;
-  return launch_rows_forward(e, a, true, false);
+  return launch_rows_forward(e, a, true, mb_wide(e));
 }
 
 static ColsArgs cols_args(fmx_matrix* m, const TileRun& t) {
@@ -326,7 +329,7 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
     LongArgs la{};
     if (!m->long_tiles.empty() && m->long_tiles[(size_t)tiles[i].tile].n_long > 0) {  // heavy hitters in this tile
       const auto& lt = m->long_tiles[(size_t)tiles[i].tile];
-      const int64_t need = m->max_long_seg * (2 * (int64_t)e->kp32 + 4);
+      const int64_t need = m->max_long_seg * (2 * (int64_t)mb_kp(e) + 4);
       if (need > e->long_partial_cap) {
         FMX_HIP(hipStreamSynchronize(e->stream));
         (void)hipFree(e->long_partial); e->long_partial = nullptr; e->long_partial_cap = 0;
@@ -408,7 +411,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   e->scal = e->scal_base;
   e->scal_next = e->scal_base + SC_COUNT;
   const size_t p = (size_t)e->p;
-  if (cfg->mode == FMX_MODE_MINIBATCH) {
+  if (cfg->mode == FMX_MODE_MINIBATCH && !cfg->state_fp64) {
     FMX_TRY(dev_alloc_zero(&e->V, p * e->kp32));
     FMX_TRY(dev_alloc_zero(&e->w, p));
     if (e->hyper.kind != UPD_SGD_L2) { FMX_TRY(dev_alloc_zero(&e->sV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->sw, p)); }
@@ -453,7 +456,7 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
   const size_t p = (size_t)e->p;
   const int k = e->k;
   FMX_HIP(hipMemcpy(e->scal + SC_W0, &w0, sizeof(double), hipMemcpyHostToDevice));
-  if (seq_mode(e)) {
+  if (wide_state(e)) {
     const int kp = e->kp64;
     std::vector<double> hv(p * kp, 0.0);
     if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = v[f + j * (size_t)k];
@@ -482,7 +485,7 @@ int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v) {
   const size_t p = (size_t)e->p;
   const int k = e->k;
   if (w0) FMX_HIP(hipMemcpy(w0, e->scal + SC_W0, sizeof(double), hipMemcpyDeviceToHost));
-  if (seq_mode(e)) {
+  if (wide_state(e)) {
     if (w) FMX_HIP(hipMemcpy(w, e->dw, p * sizeof(double), hipMemcpyDeviceToHost));
     if (v && k > 0) {
       const int kp = e->kp64;
@@ -536,8 +539,9 @@ static void ckpt_tables(fmx_engine* e, std::vector<std::pair<void*, size_t>>* ou
 static CkptHeader ckpt_header(const fmx_engine* e) {
   CkptHeader h{};
   memcpy(h.magic, "FMX1", 4);
-  h.version = 1; h.p = e->p; h.k = e->k; h.kp = seq_mode(e) ? e->kp64 : e->kp32; h.mode = e->cfg.mode; h.kind = e->hyper.kind;
+  h.version = 1; h.p = e->p; h.k = e->k; h.kp = wide_state(e) ? e->kp64 : e->kp32; h.mode = e->cfg.mode; h.kind = e->hyper.kind;
   h.scalars = SC_COUNT;
+  h.reserved[0] = mb_wide(e) ? 1u : 0u;  // mini-batch state kept in the fp64 tables
   return h;
 }
 
@@ -575,7 +579,8 @@ int fmx_engine_load(fmx_engine* e, const char* path) {
   CkptHeader h{}, want = ckpt_header(e);
   bool ok = fread(&h, sizeof(h), 1, f) == 1;
   if (!ok || memcmp(h.magic, "FMX1", 4) != 0 || h.version != 1) { fclose(f); set_error("%s is not an fmx checkpoint", path); return FMX_ERR_INVALID; }
-  if (h.p != want.p || h.k != want.k || h.kp != want.kp || h.mode != want.mode || h.kind != want.kind || h.scalars != want.scalars) {
+  if (h.p != want.p || h.k != want.k || h.kp != want.kp || h.mode != want.mode || h.kind != want.kind || h.scalars != want.scalars ||
+      h.reserved[0] != want.reserved[0]) {
     fclose(f);
     set_error("checkpoint shape (p=%llu k=%d mode=%d kind=%d) does not match the engine (p=%llu k=%d mode=%d kind=%d)", (unsigned long long)h.p, h.k, h.mode,
               h.kind, (unsigned long long)want.p, want.k, want.mode, want.kind);
@@ -951,6 +956,12 @@ int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats) {
   FMX_TRY(ensure_gbuf(e));
   if (dev_ptr) *dev_ptr = e->gbuf;
   if (n_floats) *n_floats = e->gbuf_floats;
+  return FMX_OK;
+}
+
+int fmx_grad_elem_bytes(const fmx_engine* e, int32_t* bytes) {
+  FMX_CHECK(e != nullptr && bytes != nullptr, FMX_ERR_INVALID, "NULL argument");
+  *bytes = (int32_t)mb_elem(e);
   return FMX_OK;
 }
 

@@ -137,11 +137,11 @@ struct fmx_engine {
   double* scal = nullptr;       // [SC_COUNT] current scalars (one half of scal_base)
   double* scal_next = nullptr;  // the other half: written by the step's last kernel, then swapped in
   double* scal_base = nullptr;  // [2][SC_COUNT] allocation
-  // mini-batch (fp32) state: tables are [p][kp32]
+  // mini-batch fp32 state (cfg.state_fp64 == 0): tables are [p][kp32]
   float *V = nullptr, *w = nullptr;
   float *sV = nullptr, *sw = nullptr;    // q (SGD-L1) or z (FTRL)
   float *nV = nullptr, *nw = nullptr;    // n (FTRL)
-  // sequential (fp64) state: tables are [p][kp64]
+  // fp64 state (sequential mode, or mini-batch mode with cfg.state_fp64): tables are [p][kp64]
   double *dV = nullptr, *dw = nullptr;
   double *dsV = nullptr, *dsw = nullptr;
   double *dnV = nullptr, *dnw = nullptr;
@@ -156,14 +156,14 @@ struct fmx_engine {
   // workspaces (mini-batch)
   int64_t ws_rows = 0;
   int64_t tile_rows = 0;      // rows per tile (<= cfg.batch_rows)
-  float* S = nullptr;         // [ws_rows][kp32] per-row factor sums
-  float* amul = nullptr;      // [ws_rows] per-row gradient multiplier
+  void* S = nullptr;          // [ws_rows][kp] per-row factor sums (element type = state type, see mb_wide)
+  void* amul = nullptr;       // [ws_rows] per-row gradient multiplier
   double* partials = nullptr; // [ws_partials][2]
   int64_t ws_partials = 0;
   double* long_partial = nullptr;  // segment sums of the long lists
   int64_t long_partial_cap = 0;
-  float* gbuf = nullptr;      // multi-GPU exchange buffer
-  int64_t gbuf_floats = 0;
+  void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
+  int64_t gbuf_floats = 0;    // its element count
   // tracker (core/Tracker.h): records of the last fmx_train_tracked
   struct Snapshot { double w0; std::vector<double> w, v; };
   std::vector<int64_t> trace_iters;
@@ -180,6 +180,13 @@ struct fmx_engine {
 
 namespace fmx {
 
+// mini-batch mode keeps its state in fp32 tables unless cfg.state_fp64 asks for the sequential mode's fp64 tables
+inline bool mb_wide(const fmx_engine* e) { return e->cfg.mode == FMX_MODE_MINIBATCH && e->cfg.state_fp64 != 0; }
+inline bool wide_state(const fmx_engine* e) { return e->cfg.mode == FMX_MODE_SEQUENTIAL || e->cfg.state_fp64 != 0; }
+inline int mb_kp(const fmx_engine* e) { return mb_wide(e) ? e->kp64 : e->kp32; }        // padded factor count of the mini-batch tables
+inline int mb_lpr(const fmx_engine* e) { return mb_wide(e) ? e->kp64 / 2 : e->kp32 / 4; } // lanes per row / per feature list (16 B each)
+inline size_t mb_elem(const fmx_engine* e) { return mb_wide(e) ? sizeof(double) : sizeof(float); }
+
 // ---- launchers implemented in the kernel translation units -------------------------------------------------
 struct RowsArgs {
   const int64_t* row_ptr;
@@ -191,8 +198,8 @@ struct RowsArgs {
   const void* V;        // [p][kp] float or double
   const void* w;        // [p]
   const double* scal;
-  float* S;             // [nrows][kp32] (train)
-  float* amul;          // [nrows]       (train)
+  void* S;              // [nrows][kp]   (train) element type of the tables
+  void* amul;           // [nrows]       (train)
   double* partials;     // [grid][2]     (train)
   double* yhat;         // [nrows]       (predict) -- indexed from 0; may be null when only qout is wanted
   double* qout;         // [nrows][kp64] (predict, fp64 tables) per-row factor sums, or null

@@ -5,9 +5,21 @@ The reference has no counterpart (single process); BASELI
 Every replica holds the full (w0, w, V) and applies the identical update from the identical reduced sums, so replicas
 stay in lock step.  The buffer is the engine's own exchange buffer (fmx_grad_buffer), viewed as a torch tensor without
 a copy; the all-reduce is enqueued on the engine's HIP stream, so no host synchronisation happens inside a step.
+
+Import order: the torch wheel carries its own copy of the HIP runtime.  When torch is imported first, libfmx.so binds
+to that same copy and both share one runtime (what bench.py and the tests' workers do).  Loading libfmx.so first and
+torch afterwards leaves two runtimes in the process and torch then finds no GPU, so that order is refused here.
 """
-import torch
-import torch.distributed as dist
+import sys
+
+from . import _lib as _L
+
+if _L._lib is not None and "torch" not in sys.modules:
+    raise ImportError("fmwr_amd.distributed (or torch) must be imported before the first fmwr_amd call: libfmx.so is already "
+                      "loaded with the system HIP runtime and torch would bring a second one")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def shard_rows(n_total, rank, world):
@@ -16,7 +28,7 @@ def shard_rows(n_total, rank, world):
 
 
 class GradLayout:
-    """Element offsets (fp32) inside the exchange buffer, mirroring fm_batch_kernels.hip:
+    """Element offsets (elements are fp32, or fp64 with state_fp64) inside the exchange buffer, mirroring fm_batch_kernels.hip:
     GV [p][kp] | GW [p] | CNT [p] | (has_q: QV [p][kp] | QW [p]) | tail = [G0, Q0, rows, 0].
     has_q: only FTRL with FMX_REDUCE_SUM exchanges the sums of squared gradients."""
 
@@ -32,8 +44,8 @@ class GradLayout:
 
 
 class _DevBuf:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr, n, elem_bytes=4):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f%d" % elem_bytes, "data": (ptr, False), "version": 2}
 
 
 class EngineStepper:
@@ -43,7 +55,7 @@ class EngineStepper:
         self.e, self.m = engine, matrix
         self.device = torch.device("cuda", device)
         ptr, n = engine.grad_buffer()
-        self.buf = torch.as_tensor(_DevBuf(ptr, n), device=self.device)
+        self.buf = torch.as_tensor(_DevBuf(ptr, n, engine.grad_elem_bytes()), device=self.device)
         self.stream = torch.cuda.ExternalStream(engine.stream(), device=self.device)
 
     def grad(self, batch, rows_limit=0):

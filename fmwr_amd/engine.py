@@ -189,6 +189,11 @@ class Engine:
         L.check(L.lib().fmx_grad_buffer(self.h, C.byref(ptr), C.byref(n)))
         return ptr.value, n.value
 
+    def grad_elem_bytes(self):
+        b = C.c_int32()
+        L.check(L.lib().fmx_grad_elem_bytes(self.h, C.byref(b)))
+        return b.value
+
     def apply(self, global_rows):
         L.check(L.lib().fmx_apply(self.h, C.c_int64(global_rows)))
 

@@ -89,6 +89,10 @@ typedef struct fmx_config {
   int64_t tile_rows;       /* 0: default.  A step of batch_rows rows is processed in tiles of at most this many
                               rows (parameters frozen across the tiles, sums accumulated): keeps the per-tile
                               tables cache resident for large batches.  Does not change any result.           */
+  int32_t state_fp64;      /* mini-batch mode: 0 = fp32 parameter/optimizer tables (default, half the HBM traffic),
+                              1 = the fp64 tables of the sequential mode (the reference's precision; per-row sums and
+                              the exchange buffer become fp64 too)                                               */
+  int32_t reserved_;
 } fmx_config;
 
 typedef struct fmx_engine fmx_engine; /* parameters + optimizer state on one GPU */
@@ -206,8 +210,10 @@ int fmx_num_batches(fmx_engine* e, fmx_matrix* m, int64_t* n_batches);
 int fmx_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
 /* multi-GPU split of the same step: local gradient sums into the exchange buffer ... */
 int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
-/* ... device pointer / element count (fp32) of that buffer, for an in-place all-reduce(sum) ... */
+/* ... device pointer / element count of that buffer, for an in-place all-reduce(sum); elements are fp32, or fp64
+ * with cfg.state_fp64 (fmx_grad_elem_bytes says which: 4 or 8) ... */
 int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats);
+int fmx_grad_elem_bytes(const fmx_engine* e, int32_t* bytes);
 /* ... and the update from the (reduced) buffer; global_rows = rows of the whole global batch, or <= 0 to take the
  * count that travelled in the buffer's tail (each rank's fmx_grad wrote its own row count there; the all-reduce summed them). */
 int fmx_apply(fmx_engine* e, int64_t global_rows);

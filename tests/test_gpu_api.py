@@ -92,6 +92,12 @@ def test_minibatch_mode_through_api_learns():
     fit = fm.fm_train(data, normalize=False, control=ctl, seed=0, mode="minibatch", batch_rows=256)
     acc = np.mean((fm.predict(fit, data, normalize=False) >= 0.5) == (y > 0))
     assert acc > 0.85, acc
+    # the same run on fp64 state: the same model up to the fp32 storage rounding
+    fit64 = fm.fm_train(data, normalize=False, control=ctl, seed=0, mode="minibatch_fp64", batch_rows=256)
+    v32, v64 = np.asarray(fit["Model"]["v"]), np.asarray(fit64["Model"]["v"])
+    assert np.max(np.abs(v32 - v64)) < 1e-4 * np.max(np.abs(v64))
+    upd = fm.fm_update(fit64, data, normalize=False, max_iter=n)  # the engine choice travels with the fit
+    assert upd["engine"]["mode"] == "minibatch_fp64"
 
 
 def test_track_and_select_through_the_api():

@@ -25,11 +25,14 @@ n, p, z, k, B = 40000, 5000, 10, 16, 4000
 r0, r1 = shard_rows(n, rank, world)
 m = engine.Matrix.synthetic(r1 - r0, p, z, 7, row_offset=r0, device=0)
 kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD if sys.argv[2] == "sgd" else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05,
-          l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if sys.argv[2] == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B // world)
+          l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if sys.argv[2] == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B // world,
+          state_fp64=int(sys.argv[4]))
 e = engine.Engine(p, **kw)
 v0 = np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
 e.set_params(0.0, None, v0)
-dp = DataParallel(EngineStepper(e, m, 0))
+st = EngineStepper(e, m, 0)
+assert st.buffer().dtype == (torch.float64 if int(sys.argv[4]) else torch.float32) and st.buffer().numel() == e.grad_buffer()[1]
+dp = DataParallel(st)
 for s in range(8):
     dp.step(s % e.num_batches(m))
 e.sync()
@@ -40,15 +43,16 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
+@pytest.mark.parametrize("state_fp64", [0, 1])
 @pytest.mark.parametrize("solver", ["sgd", "ftrl"])
-def test_two_replicas_match_single_process(tmp_path, solver):
+def test_two_replicas_match_single_process(tmp_path, solver, state_fp64):
     from fmwr_amd import _lib as L, engine
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = tmp_path / "dp.npz"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", str(script), ROOT, solver, str(out)], capture_output=True, text=True, env=env, timeout=600)
+                        "--master-port", "29517", str(script), ROOT, solver, str(out), str(state_fp64)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out)
     # single process: the same global batches = union of the two ranks' local batches
@@ -65,7 +69,7 @@ def test_two_replicas_match_single_process(tmp_path, solver):
             rp.extend((rpi[a + 1:c + 1] - rpi[a] + rp[-1]).tolist())
     m = engine.Matrix.from_csr(np.array(rp, np.int64), np.concatenate(col), np.concatenate(val), p, np.concatenate(y))
     kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD if solver == "sgd" else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05,
-              l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B)
+              l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B, state_fp64=state_fp64)
     e = engine.Engine(p, **kw)
     e.set_params(0.0, None, np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64))
     for s in range(8):
@@ -73,9 +77,10 @@ def test_two_replicas_match_single_process(tmp_path, solver):
     e.sync()
     w0, w, v = e.get_params()
     scale = np.max(np.abs(v))
-    assert np.max(np.abs(got["v"] - v)) < 1e-5 * scale
-    assert np.max(np.abs(got["w"] - w)) < 1e-5 * max(np.max(np.abs(w)), 1e-3)
-    assert abs(float(got["w0"]) - w0) < 1e-5 * max(1.0, abs(w0))
+    tol = 1e-11 if state_fp64 else 1e-5  # fp64 state: only the association of the two ranks' sums differs
+    assert np.max(np.abs(got["v"] - v)) < tol * scale
+    assert np.max(np.abs(got["w"] - w)) < tol * max(np.max(np.abs(w)), 1e-3)
+    assert abs(float(got["w0"]) - w0) < tol * max(1.0, abs(w0))
 
 
 def test_bench_multirank_path_runs(tmp_path):
