@@ -23,7 +23,7 @@ SYMBOLS = [
     "fmx_last_error", "fmx_config_default", "fmx_engine_create", "fmx_engine_destroy", "fmx_set_params",
     "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
     "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
-    "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_grad_elem_bytes", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
+    "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_grad_elem_bytes", "fmx_grad_layout", "fmx_grad_begin", "fmx_grad_chunk", "fmx_apply_chunk", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
     "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset",
 ]
@@ -39,7 +39,7 @@ class Config(C.Structure):
         ("random_step", C.c_int32), ("mode", C.c_int32), ("batch_rows", C.c_int64),
         ("min_target", C.c_double), ("max_target", C.c_double),
         ("device", C.c_int32), ("batch_reduce", C.c_int32), ("gamma", C.c_double), ("tile_rows", C.c_int64),
-        ("state_fp64", C.c_int32), ("reserved_", C.c_int32),
+        ("state_fp64", C.c_int32), ("exchange_chunks", C.c_int32),
     ]
 
 

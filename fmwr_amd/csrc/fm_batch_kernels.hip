@@ -289,7 +289,10 @@ struct ColsTables {
   int64_t n_partials;
   ST* gbuf;
   uint32_t p;
-  int has_q;  // exchange buffer carries the sum-of-squares planes (FTRL with FMX_REDUCE_SUM only)
+  int has_q;
+  uint32_t gb_feats;         // features per exchange-buffer block
+  int64_t gb_block_elems;    // elements per block
+  int64_t gb_tail;           // element offset of the tail  // exchange buffer carries the sum-of-squares planes (FTRL with FMX_REDUCE_SUM only)
 };
 
 // solver/SGD_Learner.h:195-204
@@ -379,35 +382,39 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr bool NEED_Q = (KIND == UPD_FTRL);
-  // exchange buffer planes: GV [p][KP] | GW [p] | CNT [p] | (has_q: QV [p][KP] | QW [p]) | tail[4]
-  ST* gGV = T.gbuf;
-  ST* gGW = T.gbuf ? T.gbuf + (size_t)T.p * KP : nullptr;
-  ST* gCN = T.gbuf ? gGW + T.p : nullptr;
-  ST* gQV = T.gbuf ? gCN + T.p : nullptr;
-  ST* gQW = T.gbuf ? gQV + (size_t)T.p * KP : nullptr;
-  const size_t at = (size_t)j * KP + lig * VEC;
-
-  if (a.load_gbuf) {  // sums of earlier tiles of this step, or the all-reduced sums of the whole global batch
-    double g[VEC];
-    slice_get(*reinterpret_cast<const vec_t*>(gGV + at), g);
+  // exchange buffer: blocks of F features, each GV [F][KP] | GW [F] | CNT [F] | (has_q: QV [F][KP] | QW [F]); then tail[4]
+  const size_t at = (size_t)j * KP + lig * VEC;  // in the parameter tables
+  if (a.load_gbuf || a.store_gbuf) {
+    const uint32_t F = T.gb_feats;
+    const uint32_t blk = (uint32_t)j / F, r = (uint32_t)j - blk * F;
+    ST* gGV = T.gbuf + (size_t)blk * T.gb_block_elems;
+    ST* gGW = gGV + (size_t)F * KP;
+    ST* gCN = gGW + F;
+    ST* gQV = gCN + F;
+    ST* gQW = gQV + (size_t)F * KP;
+    const size_t gat = (size_t)r * KP + lig * VEC;
+    if (a.load_gbuf) {  // sums of earlier tiles of this step, or the all-reduced sums of the whole global batch
+      double g[VEC];
+      slice_get(*reinterpret_cast<const vec_t*>(gGV + gat), g);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) s.G[i] += g[i];
-    s.Gw += gGW[j];
-    s.cnt += gCN[j];
-    if (NEED_Q && T.has_q) {
-      slice_get(*reinterpret_cast<const vec_t*>(gQV + at), g);
+      for (int i = 0; i < VEC; ++i) s.G[i] += g[i];
+      s.Gw += gGW[r];
+      s.cnt += gCN[r];
+      if (NEED_Q && T.has_q) {
+        slice_get(*reinterpret_cast<const vec_t*>(gQV + gat), g);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) s.Q[i] += g[i];
-      s.Qw += gQW[j];
+        for (int i = 0; i < VEC; ++i) s.Q[i] += g[i];
+        s.Qw += gQW[r];
+      }
     }
-  }
-  if (a.store_gbuf) {  // publish the sums so far (every feature, zeros included)
-    *reinterpret_cast<vec_t*>(gGV + at) = slice_make(s.G, ST());
-    if (NEED_Q && T.has_q) *reinterpret_cast<vec_t*>(gQV + at) = slice_make(s.Q, ST());
-    if (lig == 0) {
-      gGW[j] = (ST)s.Gw;
-      gCN[j] = (ST)s.cnt;
-      if (NEED_Q && T.has_q) gQW[j] = (ST)s.Qw;
+    if (a.store_gbuf) {  // publish the sums so far (every feature, zeros included)
+      *reinterpret_cast<vec_t*>(gGV + gat) = slice_make(s.G, ST());
+      if (NEED_Q && T.has_q) *reinterpret_cast<vec_t*>(gQV + gat) = slice_make(s.Q, ST());
+      if (lig == 0) {
+        gGW[r] = (ST)s.Gw;
+        gCN[r] = (ST)s.cnt;
+        if (NEED_Q && T.has_q) gQW[r] = (ST)s.Qw;
+      }
     }
   }
   // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
@@ -473,10 +480,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
 
 template <typename ST, int LPR>
 __device__ __forceinline__ ST* exchange_tail(const ColsTables<ST>& T) {
-  if (!T.gbuf) return nullptr;
-  constexpr int KP = LPR * Slice<ST>::N;
-  ST* gCN = T.gbuf + (size_t)T.p * KP + T.p;
-  return T.has_q ? gCN + T.p + (size_t)T.p * KP + T.p : gCN + T.p;  // the Q planes exist only with has_q
+  return T.gbuf ? T.gbuf + T.gb_tail : nullptr;
 }
 
 // Main phase-2 kernel: one group of LPR lanes per feature list.  Lists longer than a.long_min entries (heavy hitters of a
@@ -496,8 +500,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   const int gid = tid / LPR;
   const int lig = tid % LPR;
   // lists of this workgroup: features I0.. (dense walk) or the I0..-th occurring features (sparse tile)
-  const int64_t n_lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)T.p;
-  const int64_t I0 = (int64_t)blockIdx.x * FPW;
+  const int64_t n_lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)a.f1;
+  const int64_t I0 = (a.tfeat ? 0 : (int64_t)a.f0) + (int64_t)blockIdx.x * FPW;
   const int64_t I1 = (I0 + FPW < n_lists) ? I0 + FPW : n_lists;
   bool have = I0 + gid < n_lists;
   const int64_t j = !have ? 0 : (a.tfeat ? (int64_t)a.tfeat[I0 + gid] : I0 + gid);
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   }
   ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
-  if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
+  if (a.apply && a.load_gbuf && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
 
   if (have) cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
 
@@ -590,6 +594,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   if (seg >= la.n_seg) return;
   const int sub = lane / LPR, lig = lane % LPR;
   const int64_t j = la.lfeat[la.seg_feat[seg]];
+  if (j < (int64_t)a.f0 || j >= (int64_t)a.f1) return;  // not in this launch's feature range (uniform over the wave)
   const int64_t ta = la.seg_begin[seg], tb = la.seg_end[seg];
   double vf[VEC];
   slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
@@ -654,6 +659,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
   if (i >= la.n_long) return;
   const int sub = lane / LPR, lig = lane % LPR;
   const int64_t j = la.lfeat[i];
+  if (j < (int64_t)a.f0 || j >= (int64_t)a.f1) return;
   double vf[VEC];
   slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
   CoordSums s;
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
   if (sub != 0) return;
   ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
-  if (a.scalar == SCALAR_FROM_TAIL && rows <= 0.0) rows = gtail[2];
+  if (a.apply && a.load_gbuf && rows <= 0.0) rows = gtail[2];
   cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
 }
 
@@ -686,7 +692,7 @@ template <typename ST, int KIND>
 static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la, const ColsTables<ST>& T) {
   const int lpr = mb_lpr(e);
   const int fpw = WG_THREADS / lpr;
-  const int64_t lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)T.p;
+  const int64_t lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)a.f1 - (int64_t)a.f0;
   const int64_t grid = lists > 0 ? (lists + fpw - 1) / fpw : 1;  // at least workgroup 0: it also does the w0 step
   FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "cols_update: grid too large");
   dim3 g((unsigned)grid), b(WG_THREADS);
@@ -720,19 +726,24 @@ static int launch_cols_state(fmx_engine* e, const ColsArgs& a, const LongArgs& l
   }
 }
 
-int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la) {
+int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) {
+  ColsArgs a = a_in;
+  if (a.f1 == 0 && a.f0 == 0) a.f1 = (uint32_t)e->p;  // the whole feature range
+  FMX_CHECK(a.f0 <= a.f1 && a.f1 <= e->p && !(a.tfeat && (a.f0 != 0 || a.f1 != e->p)), FMX_ERR_INVALID, "bad feature range [%u, %u)", a.f0, a.f1);
   FMX_CHECK(!(a.load_gbuf || a.store_gbuf || a.scalar == SCALAR_PUBLISH || a.scalar == SCALAR_FROM_TAIL) || e->gbuf != nullptr,
             FMX_ERR_STATE, "exchange buffer not allocated");
   const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
   if (mb_wide(e)) {
-    ColsTables<double> T{e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw, (const double*)e->S, (const double*)e->amul, e->scal, e->scal_next,
-                         e->partials, a.n_partials, (double*)e->gbuf, (uint32_t)e->p, has_q};
+    ColsTables<double> T{e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw, (const double*)e->S + (size_t)a.s_row0 * e->kp64,
+                         (const double*)e->amul + a.s_row0, e->scal, e->scal_next, e->partials, a.n_partials, (double*)e->gbuf, (uint32_t)e->p, has_q,
+                         (uint32_t)e->gb_feats, e->gb_block_elems, e->gb_blocks * e->gb_block_elems};
     st = launch_cols_state<double>(e, a, la, T);
   } else {
-    ColsTables<float> T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, (const float*)e->S, (const float*)e->amul, e->scal, e->scal_next,
-                        e->partials, a.n_partials, (float*)e->gbuf, (uint32_t)e->p, has_q};
+    ColsTables<float> T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, (const float*)e->S + (size_t)a.s_row0 * e->kp32,
+                        (const float*)e->amul + a.s_row0, e->scal, e->scal_next, e->partials, a.n_partials, (float*)e->gbuf, (uint32_t)e->p, has_q,
+                        (uint32_t)e->gb_feats, e->gb_block_elems, e->gb_blocks * e->gb_block_elems};
     st = launch_cols_state<float>(e, a, la, T);
   }
   prof_end(e);

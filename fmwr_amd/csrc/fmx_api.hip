@@ -130,29 +130,34 @@ static int reset_optimizer_state(fmx_engine* e) {
   return FMX_OK;
 }
 
-static int ensure_workspace(fmx_engine* e, int64_t tile_rows, int64_t step_rows) {
+// S / multiplier rows for `s_rows` rows (one tile, or a whole step for the chunked exchange) and phase 1's per-workgroup
+// partial sums for one step; grow-only
+static int ensure_workspace(fmx_engine* e, int64_t s_rows, int64_t step_rows, int64_t tiles_per_step) {
   const int rpw = WG_THREADS / mb_lpr(e);
-  const int64_t tiles = (step_rows + tile_rows - 1) / tile_rows;
-  const int64_t partials = ((tile_rows + rpw - 1) / rpw) * (tiles > 0 ? tiles : 1);
-  if (tile_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
+  const int64_t partials = (step_rows + rpw - 1) / rpw + (tiles_per_step > 0 ? tiles_per_step : 1) + 8;  // sum over tiles of ceil(rows_t / rpw)
+  if (s_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(e->stream));
-  (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
-  (void)hipFree(e->long_partial);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
   e->S = nullptr; e->amul = nullptr; e->partials = nullptr; e->ws_rows = 0; e->ws_partials = 0;
-  FMX_HIP(hipMalloc(&e->S, (size_t)tile_rows * mb_kp(e) * mb_elem(e)));
-  FMX_HIP(hipMalloc(&e->amul, (size_t)tile_rows * mb_elem(e)));
+  FMX_HIP(hipMalloc(&e->S, (size_t)s_rows * mb_kp(e) * mb_elem(e)));
+  FMX_HIP(hipMalloc(&e->amul, (size_t)s_rows * mb_elem(e)));
   FMX_HIP(hipMalloc(&e->partials, (size_t)partials * 2 * sizeof(double)));
-  e->ws_rows = tile_rows;
+  e->ws_rows = s_rows;
   e->ws_partials = partials;
   return FMX_OK;
 }
 
 static int ensure_gbuf(fmx_engine* e) {
   if (e->gbuf) return FMX_OK;
-  // GV [p][kp] | GW [p] | CNT [p] | (QV [p][kp] | QW [p]: only FTRL with FMX_REDUCE_SUM needs sum(g^2)) | tail[4]
+  // blocks of F features: GV [F][kp] | GW [F] | CNT [F] | (QV [F][kp] | QW [F]: only FTRL with FMX_REDUCE_SUM needs
+  // sum(g^2)); then tail[4].  One block holding all p features unless cfg.exchange_chunks > 1.
   const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
-  e->gbuf_floats = (int64_t)e->p * mb_kp(e) * (has_q ? 2 : 1) + (int64_t)e->p * (has_q ? 3 : 2) + 4;
+  const int64_t chunks = e->cfg.exchange_chunks > 1 ? e->cfg.exchange_chunks : 1;
+  const int64_t per = ((int64_t)e->p + chunks - 1) / chunks;
+  e->gb_feats = chunks > 1 ? (per + 63) / 64 * 64 : ((int64_t)e->p + 3) / 4 * 4;  // keeps every plane 16-byte aligned
+  e->gb_blocks = ((int64_t)e->p + e->gb_feats - 1) / e->gb_feats;
+  e->gb_block_elems = e->gb_feats * mb_kp(e) * (has_q ? 2 : 1) + e->gb_feats * (has_q ? 3 : 2);
+  e->gbuf_floats = e->gb_blocks * e->gb_block_elems + 4;
   FMX_HIP(hipMalloc(&e->gbuf, (size_t)e->gbuf_floats * mb_elem(e)));
   FMX_HIP(hipMemset(e->gbuf, 0, (size_t)e->gbuf_floats * mb_elem(e)));
   FMX_HIP(hipDeviceSynchronize());
@@ -262,7 +267,8 @@ static int step_tiles(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_
   const int64_t tile = effective_tile_rows(e);
   FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, tile, e->stream));
   FMX_CHECK(batch >= 0 && batch < m->n_batches, FMX_ERR_INVALID, "batch %lld out of range (0..%lld)", (long long)batch, (long long)m->n_batches - 1);
-  FMX_TRY(ensure_workspace(e, tile < m->n ? tile : (m->n > 0 ? m->n : 1), e->cfg.batch_rows));
+  const int64_t step_cap = e->cfg.batch_rows < m->n ? e->cfg.batch_rows : (m->n > 0 ? m->n : 1);  // rows of the largest step
+  FMX_TRY(ensure_workspace(e, tile < step_cap ? tile : step_cap, step_cap, (step_cap + tile - 1) / tile));
   out->clear();
   int64_t left = rows_limit > 0 ? rows_limit : (int64_t)1 << 62;
   int64_t total = 0;
@@ -277,14 +283,16 @@ static int step_tiles(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_
   return FMX_OK;
 }
 
-static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t partial_offset, int64_t* n_partials) {
+static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t partial_offset, int64_t* n_partials, int64_t s_row0 = 0) {
   RowsArgs a{};
   a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = m->y;
   a.r0 = t.r0; a.nrows = t.nrows;
   a.V = mb_wide(e) ? (const void*)e->dV : (const void*)e->V;
   a.w = mb_wide(e) ? (const void*)e->dw : (const void*)e->w;
   a.scal = e->scal;
-  a.S = e->S; a.amul = e->amul; a.partials = e->partials + 2 * partial_offset;
+  a.S = (char*)e->S + (size_t)s_row0 * mb_kp(e) * mb_elem(e);
+  a.amul = (char*)e->amul + (size_t)s_row0 * mb_elem(e);
+  a.partials = e->partials + 2 * partial_offset;
   const int rpw = WG_THREADS / mb_lpr(e);
   *n_partials = (t.nrows + rpw - 1) / rpw;
   return launch_rows_forward(e, a, true, mb_wide(e));
@@ -299,6 +307,23 @@ static ColsArgs cols_args(fmx_matrix* m, const TileRun& t) {
   c.rows_active = (uint32_t)t.nrows;
   c.walk = 1;
   return c;
+}
+
+// heavy hitters of a tile: the long-list plan and its partial-sum buffer
+static int long_args(fmx_engine* e, fmx_matrix* m, int64_t tile, LongArgs* la, ColsArgs* c) {
+  if (m->long_tiles.empty() || m->long_tiles[(size_t)tile].n_long <= 0) return FMX_OK;
+  const auto& lt = m->long_tiles[(size_t)tile];
+  const int64_t need = m->max_long_seg * (2 * (int64_t)mb_kp(e) + 4);
+  if (need > e->long_partial_cap) {
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->long_partial); e->long_partial = nullptr; e->long_partial_cap = 0;
+    FMX_HIP(hipMalloc(&e->long_partial, (size_t)need * sizeof(double)));
+    e->long_partial_cap = need;
+  }
+  *la = LongArgs{m->lplan + lt.off_lfeat, m->lplan + lt.off_lseg, m->lplan + lt.off_sfeat, m->lplan + lt.off_sbeg, m->lplan + lt.off_send,
+                 e->long_partial, lt.n_long, lt.n_seg};
+  c->long_min = list_long_min();
+  return FMX_OK;
 }
 
 // run the tiles of one step: every tile accumulates; `finish_local` applies the update after the last tile (single GPU),
@@ -327,19 +352,7 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
     c.n_partials = last ? partials : 0;
     c.global_rows = (double)step_rows;
     LongArgs la{};
-    if (!m->long_tiles.empty() && m->long_tiles[(size_t)tiles[i].tile].n_long > 0) {  // heavy hitters in this tile
-      const auto& lt = m->long_tiles[(size_t)tiles[i].tile];
-      const int64_t need = m->max_long_seg * (2 * (int64_t)mb_kp(e) + 4);
-      if (need > e->long_partial_cap) {
-        FMX_HIP(hipStreamSynchronize(e->stream));
-        (void)hipFree(e->long_partial); e->long_partial = nullptr; e->long_partial_cap = 0;
-        FMX_HIP(hipMalloc(&e->long_partial, (size_t)need * sizeof(double)));
-        e->long_partial_cap = need;
-      }
-      la = LongArgs{m->lplan + lt.off_lfeat, m->lplan + lt.off_lseg, m->lplan + lt.off_sfeat, m->lplan + lt.off_sbeg, m->lplan + lt.off_send,
-                    e->long_partial, lt.n_long, lt.n_seg};
-      c.long_min = list_long_min();
-    }
+    FMX_TRY(long_args(e, m, tiles[i].tile, &la, &c));
     // a sparse tile that is a whole fused step walks only the features occurring in it (the exchange buffer is dense:
     // tiles that read or write it visit every feature)
     const int64_t tl = m->tfeat_ptr.empty() ? 0 : m->tfeat_ptr[(size_t)tiles[i].tile + 1] - m->tfeat_ptr[(size_t)tiles[i].tile];
@@ -351,6 +364,78 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
     FMX_TRY(launch_cols_update(e, c, la));
   }
   return FMX_OK;
+}
+
+// ---- chunked exchange (cfg.exchange_chunks > 1): phase 1 of the whole step first, then phase 2 one feature block at a
+// time over all the step's tiles, so that the all-reduce of a block overlaps phase 2 of the next one ---------------------
+static int grad_begin(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
+  std::vector<TileRun> tiles;
+  int64_t step_rows = 0;
+  FMX_TRY(step_tiles(e, m, batch, rows_limit, &tiles, &step_rows));
+  FMX_TRY(ensure_gbuf(e));
+  // the whole step's S / multipliers stay resident until its last block has been walked
+  const int64_t cap = e->cfg.batch_rows < m->n ? e->cfg.batch_rows : (m->n > 0 ? m->n : 1);
+  FMX_TRY(ensure_workspace(e, cap, cap, (int64_t)tiles.size()));
+  e->open_tiles.clear();
+  int64_t partials = 0, s_row0 = 0;
+  for (const TileRun& t : tiles) {
+    int64_t np = 0;
+    FMX_TRY(rows_phase(e, m, t, partials, &np, s_row0));
+    partials += np;
+    e->open_tiles.push_back({t.tile, t.r0, t.nrows, s_row0});
+    s_row0 += t.nrows;
+  }
+  e->open_rows = step_rows;
+  e->open_partials = partials;
+  e->open_matrix = m;
+  // the tail {sum mult, sum mult^2, rows, 0} is known after phase 1: publish it now so that it can travel first
+  ColsArgs c{};
+  c.f0 = c.f1 = (uint32_t)e->p;  // no features: workgroup 0's scalar work only
+  c.scalar = SCALAR_PUBLISH;
+  c.n_partials = partials;
+  c.global_rows = (double)step_rows;
+  return launch_cols_update(e, c, LongArgs{});
+}
+
+static int grad_block(fmx_engine* e, fmx_matrix* m, int64_t block) {
+  FMX_CHECK(e->open_matrix == m && m != nullptr, FMX_ERR_STATE, "fmx_grad_chunk needs a preceding fmx_grad_begin on the same matrix");
+  FMX_CHECK(block >= 0 && block < e->gb_blocks, FMX_ERR_INVALID, "chunk %lld out of range (0..%lld)", (long long)block, (long long)e->gb_blocks - 1);
+  const uint32_t f0 = (uint32_t)(block * e->gb_feats);
+  const uint32_t f1 = (uint32_t)(((block + 1) * e->gb_feats < (int64_t)e->p) ? (block + 1) * e->gb_feats : (int64_t)e->p);
+  if (e->open_tiles.empty()) {  // an empty share still publishes zeros
+    ColsArgs c{};
+    c.f0 = f0; c.f1 = f1; c.store_gbuf = 1;
+    return launch_cols_update(e, c, LongArgs{});
+  }
+  for (size_t i = 0; i < e->open_tiles.size(); ++i) {
+    const auto& ot = e->open_tiles[i];
+    const TileRun t{ot.tile, ot.r0, ot.nrows};
+    ColsArgs c = cols_args(m, t);
+    c.f0 = f0; c.f1 = f1;
+    c.s_row0 = ot.s_row0;
+    c.load_gbuf = i > 0;
+    c.store_gbuf = 1;
+    c.global_rows = (double)e->open_rows;
+    LongArgs la{};
+    FMX_TRY(long_args(e, m, t.tile, &la, &c));
+    FMX_TRY(launch_cols_update(e, c, la));
+  }
+  return FMX_OK;
+}
+
+static int apply_block(fmx_engine* e, int64_t block, int64_t global_rows, bool last) {
+  FMX_CHECK(e->gbuf != nullptr, FMX_ERR_STATE, "fmx_apply_chunk needs a preceding fmx_grad_begin");
+  FMX_CHECK(block >= 0 && block < e->gb_blocks, FMX_ERR_INVALID, "chunk %lld out of range (0..%lld)", (long long)block, (long long)e->gb_blocks - 1);
+  ColsArgs c{};
+  c.f0 = (uint32_t)(block * e->gb_feats);
+  c.f1 = (uint32_t)(((block + 1) * e->gb_feats < (int64_t)e->p) ? (block + 1) * e->gb_feats : (int64_t)e->p);
+  c.load_gbuf = 1;
+  c.apply = 1;
+  // every block reads the step's START scalars (penalty level, w0 ...): only the last launch writes the next ones
+  c.scalar = last ? SCALAR_FROM_TAIL : SCALAR_NONE;
+  c.global_rows = (double)global_rows;
+  if (last) e->open_matrix = nullptr;
+  return launch_cols_update(e, c, LongArgs{});
 }
 
 }  // namespace fmx
@@ -957,6 +1042,36 @@ int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats) {
   if (dev_ptr) *dev_ptr = e->gbuf;
   if (n_floats) *n_floats = e->gbuf_floats;
   return FMX_OK;
+}
+
+int fmx_grad_layout(fmx_engine* e, int64_t* n_chunks, int64_t* chunk_features, int64_t* chunk_elems, int64_t* tail_offset) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "the exchange buffer exists only in FMX_MODE_MINIBATCH");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(ensure_gbuf(e));
+  if (n_chunks) *n_chunks = e->gb_blocks;
+  if (chunk_features) *chunk_features = e->gb_feats;
+  if (chunk_elems) *chunk_elems = e->gb_block_elems;
+  if (tail_offset) *tail_offset = e->gb_blocks * e->gb_block_elems;
+  return FMX_OK;
+}
+
+int fmx_grad_begin(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
+  FMX_TRY(check_pair(e, m));
+  FMX_TRY(use_device(e->cfg.device));
+  return grad_begin(e, m, batch, rows_limit);
+}
+
+int fmx_grad_chunk(fmx_engine* e, fmx_matrix* m, int64_t chunk) {
+  FMX_TRY(check_pair(e, m));
+  FMX_TRY(use_device(e->cfg.device));
+  return grad_block(e, m, chunk);
+}
+
+int fmx_apply_chunk(fmx_engine* e, int64_t chunk, int64_t global_rows, int32_t last) {
+  FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "fmx_apply_chunk needs a mini-batch engine");
+  FMX_TRY(use_device(e->cfg.device));
+  return apply_block(e, chunk, global_rows, last != 0);
 }
 
 int fmx_grad_elem_bytes(const fmx_engine* e, int32_t* bytes) {

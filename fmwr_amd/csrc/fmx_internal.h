@@ -164,6 +164,16 @@ struct fmx_engine {
   int64_t long_partial_cap = 0;
   void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
   int64_t gbuf_floats = 0;    // its element count
+  // Layout of the exchange buffer: blocks of gb_feats features, each block GV[F][kp] | GW[F] | CNT[F] (| QV[F][kp] | QW[F]),
+  // then the tail {G0, Q0, rows, 0}.  One block (F >= p) unless cfg.exchange_chunks > 1: a block is then the unit of the
+  // pipelined all-reduce (fmwr_amd/distributed.py).
+  int64_t gb_feats = 0, gb_blocks = 0, gb_block_elems = 0;
+  // the step opened by fmx_grad_begin (chunked exchange): its tiles and row count
+  struct OpenTile { int64_t tile, r0, nrows, s_row0; };
+  std::vector<OpenTile> open_tiles;
+  int64_t open_rows = 0;
+  int64_t open_partials = 0;
+  fmx_matrix* open_matrix = nullptr;
   // tracker (core/Tracker.h): records of the last fmx_train_tracked
   struct Snapshot { double w0; std::vector<double> w, v; };
   std::vector<int64_t> trace_iters;
@@ -227,6 +237,8 @@ struct ColsArgs {
   int scalar;            // ScalarMode: what workgroup 0 does for w0
   int64_t n_partials;    // phase 1's per-workgroup partial sums to reduce (SCALAR_FUSED / SCALAR_PUBLISH)
   double global_rows;    // rows of the whole step (all tiles; all ranks when known), <= 0: take it from the buffer tail
+  uint32_t f0, f1;       // dense walk over the features [f0, f1) only (f1 == 0: all p): one chunk of the chunked exchange
+  int64_t s_row0;        // row of the S / multiplier workspace where this tile's rows start (0 unless a whole step is resident)
 };
 // long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
 struct LongArgs {

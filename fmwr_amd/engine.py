@@ -194,6 +194,21 @@ class Engine:
         L.check(L.lib().fmx_grad_elem_bytes(self.h, C.byref(b)))
         return b.value
 
+    def grad_layout(self):
+        """(n_chunks, chunk_features, chunk_elems, tail_offset) of the exchange buffer."""
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().fmx_grad_layout(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    def grad_begin(self, m, batch, rows_limit=0):
+        L.check(L.lib().fmx_grad_begin(self.h, m.h, C.c_int64(batch), C.c_int64(rows_limit)))
+
+    def grad_chunk(self, m, chunk):
+        L.check(L.lib().fmx_grad_chunk(self.h, m.h, C.c_int64(chunk)))
+
+    def apply_chunk(self, chunk, global_rows=0, last=False):
+        L.check(L.lib().fmx_apply_chunk(self.h, C.c_int64(chunk), C.c_int64(global_rows), C.c_int32(int(last))))
+
     def apply(self, global_rows):
         L.check(L.lib().fmx_apply(self.h, C.c_int64(global_rows)))
 

@@ -92,7 +92,9 @@ typedef struct fmx_config {
   int32_t state_fp64;      /* mini-batch mode: 0 = fp32 parameter/optimizer tables (default, half the HBM traffic),
                               1 = the fp64 tables of the sequential mode (the reference's precision; per-row sums and
                               the exchange buffer become fp64 too)                                               */
-  int32_t reserved_;
+  int32_t exchange_chunks; /* 0/1: the exchange buffer is one block.  n > 1: it is laid out in n blocks of consecutive
+                              features so that a multi-GPU driver can pipeline the exchange (fmx_grad_begin/_chunk/
+                              _apply_chunk): the all-reduce of one block overlaps the gradient sums of the next.   */
 } fmx_config;
 
 typedef struct fmx_engine fmx_engine; /* parameters + optimizer state on one GPU */
@@ -214,6 +216,18 @@ int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
  * with cfg.state_fp64 (fmx_grad_elem_bytes says which: 4 or 8) ... */
 int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats);
 int fmx_grad_elem_bytes(const fmx_engine* e, int32_t* bytes);
+/* Pipelined form of the same split (cfg.exchange_chunks > 1).  The buffer is n_chunks blocks of chunk_elems elements,
+ * block c holding the sums of features [c*chunk_features, (c+1)*chunk_features), followed at tail_offset by 4 elements
+ * {sum of multipliers, sum of their squares, rows, 0}:
+ *   fmx_grad_begin          forward of the whole step (all its tiles), writes the tail        -> all-reduce the tail
+ *   fmx_grad_chunk(c)       gradient sums of block c over all tiles                            -> all-reduce block c (async)
+ *   fmx_apply_chunk(c,..)   update of block c's features from the reduced block; `last` != 0 on the final call of the
+ *                           step also applies the w0 / penalty-level update (every block reads the step's start scalars).
+ * Results are identical to fmx_grad + fmx_apply (same sums in the same order). */
+int fmx_grad_layout(fmx_engine* e, int64_t* n_chunks, int64_t* chunk_features, int64_t* chunk_elems, int64_t* tail_offset);
+int fmx_grad_begin(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
+int fmx_grad_chunk(fmx_engine* e, fmx_matrix* m, int64_t chunk);
+int fmx_apply_chunk(fmx_engine* e, int64_t chunk, int64_t global_rows, int32_t last);
 /* ... and the update from the (reduced) buffer; global_rows = rows of the whole global batch, or <= 0 to take the
  * count that travelled in the buffer's tail (each rank's fmx_grad wrote its own row count there; the all-reduce summed them). */
 int fmx_apply(fmx_engine* e, int64_t global_rows);

@@ -43,7 +43,7 @@ def _state(solver, w0, w, v):
 class OracleStepper:
     """CPU stand-in with the engine stepper's interface and buffer layout (fp32 buffer, like the GPU's)."""
 
-    def __init__(self, solver, rows, problem):
+    def __init__(self, solver, rows, problem, chunks=1):
         from fmwr_amd.distributed import GradLayout
         rp, col, val, y, w0, w, v = problem
         self.solver, self.r0, self.r1 = solver, rows[0], rows[1]
@@ -51,19 +51,49 @@ class OracleStepper:
         self.X = oracle.Matrix(rp, col, val, P_FEAT)
         self.y = y
         self.st = _state(solver, w0, w, v)
-        self.lay = GradLayout(P_FEAT, K, has_q=(solver == "ftrl"))  # this test runs FTRL with SUM, SGD with MEAN
+        self.lay = GradLayout(P_FEAT, K, has_q=(solver == "ftrl"), chunks=chunks)  # this test runs FTRL with SUM, SGD with MEAN
+        self.n_chunks = self.lay.n_chunks
         self.buf = torch.zeros(self.lay.size, dtype=torch.float32)
 
-    def grad(self, batch, rows_limit=0):
+    def _sums(self, batch):
         b0 = self.r0 + batch * B_LOCAL
         b1 = min(b0 + B_LOCAL, self.r1)
-        acc = oracle.batch_sums(self.P, self.X, self.y, self.st["w0"].value, self.st["w"], self.st["v"], b0, b1)
+        return oracle.batch_sums(self.P, self.X, self.y, self.st["w0"].value, self.st["w"], self.st["v"], b0, b1), b1 - b0
+
+    def _pack(self, acc, c):
         L, b = self.lay, self.buf.numpy()
-        b[L.gv:L.gw] = acc["Gv"].reshape(K, P_FEAT).T.ravel()   # [p][kp] feature-major, as the kernels store it
-        b[L.gw:L.cnt] = acc["Gw"]; b[L.cnt:L.qv] = acc["cw"]
+        (f0, f1), (e0, _) = L.features(c), L.block(c)
+        n = f1 - f0
+        gv = acc["Gv"].reshape(K, P_FEAT).T  # [p][kp] feature-major, as the kernels store it
+        b[e0 + L.gv:e0 + L.gv + n * K] = gv[f0:f1].ravel()
+        b[e0 + L.gw:e0 + L.gw + n] = acc["Gw"][f0:f1]; b[e0 + L.cnt:e0 + L.cnt + n] = acc["cw"][f0:f1]
         if L.has_q:
-            b[L.qv:L.qw] = acc["Qv"].reshape(K, P_FEAT).T.ravel(); b[L.qw:L.tail] = acc["Qw"]
-        b[L.tail:L.tail + 4] = [acc["G0"], acc["Q0"], b1 - b0, 0.0]
+            b[e0 + L.qv:e0 + L.qv + n * K] = acc["Qv"].reshape(K, P_FEAT).T[f0:f1].ravel(); b[e0 + L.qw:e0 + L.qw + n] = acc["Qw"][f0:f1]
+
+    def _unpack(self, acc, c):
+        L, b = self.lay, self.buf.numpy().astype(np.float64)
+        (f0, f1), (e0, _) = L.features(c), L.block(c)
+        n = f1 - f0
+        acc["Gv"][f0:f1] = b[e0 + L.gv:e0 + L.gv + n * K].reshape(n, K)
+        acc["Gw"][f0:f1] = b[e0 + L.gw:e0 + L.gw + n]; acc["cw"][f0:f1] = b[e0 + L.cnt:e0 + L.cnt + n]
+        if L.has_q:
+            acc["Qv"][f0:f1] = b[e0 + L.qv:e0 + L.qv + n * K].reshape(n, K); acc["Qw"][f0:f1] = b[e0 + L.qw:e0 + L.qw + n]
+
+    def _finish(self, acc):
+        b = self.buf.numpy().astype(np.float64)
+        t = self.lay.tail
+        full = dict(G0=b[t], Q0=b[t + 1], Gw=acc["Gw"], cw=acc["cw"], Qw=acc["Qw"], Gv=acc["Gv"].T.ravel().copy(), Qv=acc["Qv"].T.ravel().copy())
+        (oracle.sgd_apply_sums if self.solver == "sgd" else oracle.ftrl_apply_sums)(self.P, P_FEAT, self.st, b[t + 2], full)
+
+    @staticmethod
+    def _empty():
+        return dict(Gv=np.zeros((P_FEAT, K)), Qv=np.zeros((P_FEAT, K)), Gw=np.zeros(P_FEAT), Qw=np.zeros(P_FEAT), cw=np.zeros(P_FEAT))
+
+    # unchunked interface
+    def grad(self, batch, rows_limit=0):
+        self.grad_begin(batch, rows_limit)
+        for c in range(self.n_chunks):
+            self.grad_chunk(c)
 
     def buffer(self):
         return self.buf
@@ -72,22 +102,37 @@ class OracleStepper:
         return contextlib.nullcontext()
 
     def apply(self):
-        L, b = self.lay, self.buf.numpy().astype(np.float64)
-        acc = dict(G0=b[L.tail], Q0=b[L.tail + 1], Gw=b[L.gw:L.cnt].copy(), cw=b[L.cnt:L.qv].copy(),
-                   Gv=b[L.gv:L.gw].reshape(P_FEAT, K).T.ravel().copy())
-        acc["Qw"] = b[L.qw:L.tail].copy() if L.has_q else np.zeros(P_FEAT)
-        acc["Qv"] = b[L.qv:L.qw].reshape(P_FEAT, K).T.ravel().copy() if L.has_q else np.zeros(K * P_FEAT)
-        if self.solver == "sgd":
-            oracle.sgd_apply_sums(self.P, P_FEAT, self.st, b[L.tail + 2], acc)
-        else:
-            oracle.ftrl_apply_sums(self.P, P_FEAT, self.st, b[L.tail + 2], acc)
+        for c in range(self.n_chunks):
+            self.apply_chunk(c, c == self.n_chunks - 1)
+
+    # chunked interface
+    def grad_begin(self, batch, rows_limit=0):
+        self.acc, rows = self._sums(batch)
+        t = self.lay.tail
+        self.buf.numpy()[t:t + 4] = [self.acc["G0"], self.acc["Q0"], rows, 0.0]
+        self.reduced = self._empty()
+
+    def grad_chunk(self, c):
+        self._pack(self.acc, c)
+
+    def tail(self):
+        return self.buf[self.lay.tail:self.lay.tail + 4]
+
+    def chunk(self, c):
+        e0, e1 = self.lay.block(c)
+        return self.buf[e0:e1]
+
+    def apply_chunk(self, c, last):
+        self._unpack(self.reduced, c)
+        if last:
+            self._finish(self.reduced)  # the oracle applies all coordinates at once; coordinates are independent
 
 
-def _worker(rank, world, port, solver, out_dir):
+def _worker(rank, world, port, solver, out_dir, chunks):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fmwr_amd.distributed import DataParallel, shard_rows
-    stepper = OracleStepper(solver, shard_rows(N, rank, world), _problem())
+    stepper = OracleStepper(solver, shard_rows(N, rank, world), _problem(), chunks)
     dp = DataParallel(stepper)
     for s in range(STEPS):
         dp.step(s % 4)
@@ -122,9 +167,9 @@ def _expected(solver, world):
     return st
 
 
-def _run(solver, tmp_path):
+def _run(solver, tmp_path, chunks=1):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), solver, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), solver, str(tmp_path), chunks), nprocs=world, join=True)
     exp = _expected(solver, world)
     got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     # replicas are bit-identical ...
@@ -142,6 +187,23 @@ def test_data_parallel_sgd_world2(tmp_path):
 
 def test_data_parallel_ftrl_world2(tmp_path):
     _run("ftrl", tmp_path)
+
+
+def test_data_parallel_pipelined_exchange_world2(tmp_path):
+    """exchange_chunks > 1: tail first, then one asynchronous all-reduce per block of features (2 blocks of 64 features)."""
+    _run("sgd", tmp_path, chunks=2)
+    _run("ftrl", tmp_path, chunks=2)
+
+
+def test_grad_layout_blocks():
+    from fmwr_amd.distributed import GradLayout
+    one = GradLayout(1_000_000, 16)
+    assert (one.n_chunks, one.F, one.size) == (1, 1_000_000, 1_000_000 * 18 + 4)
+    L = GradLayout(1_000_000, 16, has_q=True, chunks=8)
+    assert L.F % 64 == 0 and L.n_chunks == 8 and L.F * 8 >= 1_000_000 > L.F * 7
+    assert L.block_elems == L.F * (2 * 16 + 3) and L.tail == 8 * L.block_elems and L.size == L.tail + 4
+    assert L.features(7) == (7 * L.F, 1_000_000)
+    assert GradLayout(10, 4).F == 12  # one block, feature count rounded up to a multiple of 4: planes stay 16-byte aligned
 
 
 def test_shard_rows_partition():

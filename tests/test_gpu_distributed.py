@@ -26,7 +26,7 @@ r0, r1 = shard_rows(n, rank, world)
 m = engine.Matrix.synthetic(r1 - r0, p, z, 7, row_offset=r0, device=0)
 kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD if sys.argv[2] == "sgd" else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05,
           l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if sys.argv[2] == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B // world,
-          state_fp64=int(sys.argv[4]))
+          state_fp64=int(sys.argv[4]), exchange_chunks=int(sys.argv[5]))
 e = engine.Engine(p, **kw)
 v0 = np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
 e.set_params(0.0, None, v0)
@@ -43,16 +43,17 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
 @pytest.mark.parametrize("state_fp64", [0, 1])
 @pytest.mark.parametrize("solver", ["sgd", "ftrl"])
-def test_two_replicas_match_single_process(tmp_path, solver, state_fp64):
+def test_two_replicas_match_single_process(tmp_path, solver, state_fp64, chunks):
     from fmwr_amd import _lib as L, engine
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = tmp_path / "dp.npz"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", str(script), ROOT, solver, str(out), str(state_fp64)], capture_output=True, text=True, env=env, timeout=600)
+                        "--master-port", "29517", str(script), ROOT, solver, str(out), str(state_fp64), str(chunks)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out)
     # single process: the same global batches = union of the two ranks' local batches

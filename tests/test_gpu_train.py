@@ -523,3 +523,66 @@ def test_checkpoint_resumes_bit_identically(fm, tmp_path, mode, solver):
     assert pa[0] == pc[0] and np.array_equal(pa[1], pc[1]) and np.array_equal(pa[2], pc[2])
     with pytest.raises(L.FmxError, match="does not match"):
         engine.Engine(p + 1, **kw).load(path)
+
+
+@pytest.mark.parametrize("wide", [0, 1], ids=["fp32", "fp64"])
+@pytest.mark.parametrize("name", ["sgd_l2_cls", "sgd_l1_cls", "ftrl_l1l2_cls"])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_chunked_exchange_equals_the_split_step(fm, name, reduce, wide):
+    """exchange_chunks > 1 (the pipelined multi-GPU step): forward of the whole step, then gradient sums and update one
+    block of features at a time.  Bitwise the same as fmx_grad + fmx_apply, on data with heavy hitters, over several
+    tiles per step and a truncated step; and equal to the oracle."""
+    engine, L = fm
+    c = next(x for x in CASES if x["name"] == name)
+    rng = np.random.default_rng(11)
+    n, p, batch = 2400, 500, 1200
+    rows = []
+    for r in range(n):
+        hot = [j for j, q in ((2, 0.9), (130, 0.5), (499, 0.4)) if rng.random() < q]  # one heavy hitter in each block
+        cold = [j for j in rng.choice(p, 6, replace=False).tolist() if j not in (2, 130, 499)]
+        rows.append(np.sort(np.array(hot + cold)))
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows).astype(np.uint32)
+    val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, 11, "classification")
+    kw = {k: v for k, v in c.items() if k not in ("name", "solver")}
+    P = oracle.params(min_target=float(y.min()), max_target=float(y.max()), batch_mean=(reduce == "mean"), **kw)
+    w0, w, v = util.params(p, P.k, 11, fp32=not wide)
+    mb = (oracle.SgdMinibatch if c["solver"] == "sgd" else oracle.FtrlMinibatch)(P, oracle.Matrix(rp, col, val, p), y, w0, w, v.ravel())
+    steps = [(0, 0), (1, 0), (0, 700), (1, 0)]  # (batch, rows_limit)
+    for b, lim in steps:
+        mb.step(b * batch, b * batch + (lim or batch))
+    solver = L.SOLVER_SGD if c["solver"] == "sgd" else L.SOLVER_FTRL
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    base = dict(task=P.task, solver=solver, num_factor=P.k, l2_w0=P.l2_reg0, l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv, l2_v=P.l2_regv,
+                learn_rate=P.learn_rate, mode=L.MODE_MINIBATCH, batch_rows=batch, tile_rows=500, state_fp64=wide,
+                batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM)
+    ref = engine.Engine(p, **base); ref.set_params(w0, w, v)
+    for b, lim in steps:
+        ref.grad(m, b, lim); ref.apply(0)
+    ref.sync()
+    r0, rw, rv = ref.get_params()
+    tol = 1e-10 if wide else 3e-5
+    assert util.rel_err(rv, mb.v.reshape(P.k, p)) < tol and util.rel_err(rw, mb.w) < tol and abs(r0 - mb.w0.value) < tol * max(1.0, abs(mb.w0.value))
+    for chunks in (2, 3, 7):
+        e = engine.Engine(p, exchange_chunks=chunks, **base); e.set_params(w0, w, v)
+        nc, feats, elems, tail = e.grad_layout()
+        assert feats % 64 == 0 and nc == -(-p // feats) and tail == nc * elems and e.grad_buffer()[1] == tail + 4
+        for b, lim in steps:
+            e.grad_begin(m, b, lim)
+            for ch in range(nc):
+                e.grad_chunk(m, ch)
+            for ch in range(nc):
+                e.apply_chunk(ch, 0, ch == nc - 1)
+        e.sync()
+        g0, gw, gv = e.get_params()
+        assert g0 == r0 and np.array_equal(gw, rw) and np.array_equal(gv, rv), chunks
+        # the unchunked calls work on the blocked layout as well
+        e2 = engine.Engine(p, exchange_chunks=chunks, **base); e2.set_params(w0, w, v)
+        for b, lim in steps:
+            e2.grad(m, b, lim); e2.apply(0)
+        e2.sync()
+        h0, hw, hv = e2.get_params()
+        assert h0 == r0 and np.array_equal(hw, rw) and np.array_equal(hv, rv), chunks
+    with pytest.raises(L.FmxError, match="fmx_grad_begin"):
+        engine.Engine(p, exchange_chunks=2, **base).grad_chunk(m, 0)
