@@ -13,7 +13,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NOGPU, ERR_STATE = 0, 1, 2, 3, 4
 TASK_CLASSIFICATION, TASK_REGRESSION = 10, 20
 SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL, SOLVER_TDAP = 200, 300, 500, 600
 MODE_SEQUENTIAL, MODE_MINIBATCH = 0, 1
-LINK_NONE, LINK_LOGISTIC, LINK_CLAMP = 0, 1, 2
+LINK_NONE, LINK_LOGISTIC, LINK_CLAMP, LINK_PROBIT = 0, 1, 2, 3
 REDUCE_MEAN, REDUCE_SUM = 0, 1
 EVAL_LL, EVAL_AUC, EVAL_ACC, EVAL_RMSE, EVAL_MSE, EVAL_MAE = 0, 111, 222, 333, 444, 555
 KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3

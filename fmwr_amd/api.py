@@ -5,8 +5,8 @@ R/fm_solver_control.R, R/fm_track_control.R, R/fm_matrix.R -> src/FM.cpp).  R is
 same surface is mirrored here with the same names (dots -> underscores), argument meaning, defaults and error
 messages, on top of the C ABI (include/fmx.h).  The Rcpp glue a maintainer would add is in INTEGRATION.md.
 
-Outside the path: the MCMC solver and ALS beyond the V sweep; asking for them raises
-NotImplementedError.  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
+Outside the path: the MCMC solver (its Gibbs draws come from R's RNG); asking for it raises
+NotImplementedError.  ALS runs for REGRESSION and CLASSIFICATION (probit tables regenerated, csrc/fm_probit.h).  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
 """
 import warnings
 
@@ -220,8 +220,6 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, nor
         # Tracker::save (core/Tracker.h:96-119): trace = list(record_index, {w0,w,v}...), evaluation.train
         trace = {"trace": [r["iters"]] + [{"w0": a, "w": b, "v": c} for (a, b, c) in r["params"]], "evaluation.train": r["evals"]}
     elif sol == "ALS":  # MCMC_ALS_Learner::learn; as shipped it never sweeps V (SURVEY A-1) unless als_update_v is asked for
-        if controls["model"]["task"] != "REGRESSION":
-            raise NotImplementedError("ALS on the device covers REGRESSION (the classification residual needs the reference's probit tables)")
         eng.als_train(m, controls["solver"]["max_iter"], with_v=bool(controls["solver"]["solver"].get("update_v", False)))
     else:
         eng.train(m, controls["solver"]["max_iter"])
@@ -297,7 +295,7 @@ def fm_update(object, data, normalize=True, max_iter=None, mode=None, batch_rows
 
 def predict(object, newdata=None, normalize=True):
     """predict.FM() -- R/fm_predict.R:12-34 -> FMPredict (src/FM.cpp:177-214): probabilities for CLASSIFICATION
-    (logistic link for SGD/FTRL models), predictions clamped to the training target range for REGRESSION."""
+    (logistic link for SGD/FTRL/TDAP models, the probit table for ALS models), predictions clamped to the training target range for REGRESSION."""
     if newdata is None:
         raise ValueError("newdata is null")
     if not isinstance(newdata, FmMatrix):
@@ -316,7 +314,10 @@ def predict(object, newdata=None, normalize=True):
     m = _device_matrix(newdata, None, device)
     if normalize:  # src/FM.cpp:183-186: m.normalize(scales)
         m.normalize(object["Scales"]["mean"], object["Scales"]["std"])
-    link = L.LINK_LOGISTIC if controls["model"]["task"] == "CLASSIFICATION" else L.LINK_CLAMP
+    if controls["model"]["task"] != "CLASSIFICATION":
+        link = L.LINK_CLAMP
+    else:  # Model::predict_prob, core/Model.h:163-180: probit table for MCMC / ALS models, logistic otherwise
+        link = L.LINK_PROBIT if controls["solver"]["solver"]["solver"] in ("MCMC", "ALS") else L.LINK_LOGISTIC
     return eng.predict(m, link)
 
 

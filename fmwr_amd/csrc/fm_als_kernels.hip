@@ -13,6 +13,7 @@
 // q and e live interleaved as one {q[r], e[r]} pair per row, so a stored nonzero costs one 16-byte gather (one line)
 // per pass instead of two.
 #include "fmx_internal.h"
+#include "fm_probit.h"
 
 namespace fmx {
 
@@ -139,9 +140,14 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
 }
 
 // ---- w0 and w sweeps of the ALS learner (MCMC_ALS_Learner.h:162-270, ALS branch, the exact one-thread form) -------------
-__global__ void als_residual_k(const double* __restrict__ yhat, const float* __restrict__ y, int64_t n, double2* __restrict__ qe) {
+__global__ void als_residual_k(const double* __restrict__ yhat, const float* __restrict__ y, int64_t n, double2* __restrict__ qe,
+                               const double* __restrict__ dp_y) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) qe[r] = make_double2(0.0, yhat[r] - (double)y[r]);  // calculate_error, REGRESSION, :520-527
+  if (r >= n) return;
+  double e;
+  if (dp_y == nullptr) e = yhat[r] - (double)y[r];  // calculate_error, REGRESSION, :520-527
+  else e = (y[r] >= 0.0f) ? -fast_dpnorm(dp_y, -yhat[r]) : fast_dpnorm(dp_y, yhat[r]);  // CLASSIFICATION, ALS learner, :545-559
+  qe[r] = make_double2(0.0, e);
 }
 
 constexpr int ALS_SLAB = 4096;
@@ -287,12 +293,17 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
   if (d_Q) { (void)hipStreamSynchronize(e->stream); (void)hipFree(d_Q); }
 }
 
-// MCMC_ALS_Learner::learn for the ALS learner, REGRESSION (:91-156): per iteration a fresh forward, e = y_hat - y, the w0
+// MCMC_ALS_Learner::learn for the ALS learner (:91-156): per iteration a fresh forward, the residual of the task
+// (e = y_hat - y, or the probit-table ratio for CLASSIFICATION, :520-562), the w0
 // update, the w sweep; with_v adds the V sweep the shipped update_all leaves out (SURVEY A-1).  init() fixes alpha = 1,
 // w0_mean_0 = 0 and all lambda / mu = 0 (A-7), so the R-side solver parameters do not enter.
 int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
-  FMX_CHECK(e->cfg.task == FMX_TASK_REGRESSION, FMX_ERR_INVALID, "ALS on the device covers REGRESSION (the classification residual needs the reference's probit tables)");
+  const double* dp_y = nullptr;
+  if (e->cfg.task == FMX_TASK_CLASSIFICATION) {
+    FMX_TRY(ensure_probit(e));
+    dp_y = e->probit + PN_POINTS + 1;
+  }
   FMX_TRY(build_full_csc(m, e->stream));
   FMX_TRY(build_plan(m, e->stream));
   const int64_t n = m->n;
@@ -314,7 +325,7 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
     st = launch_rows_forward(e, a, false, true);  // fm->predict_batch(train, train_err), :100
     if (st != FMX_OK) break;
-    hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe);
+    hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, dp_y);
     if (e->hyper.k0) {
       hipLaunchKernelGGL(als_w0_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, e->scal, d_part);
       hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, 1.0, 0.0);

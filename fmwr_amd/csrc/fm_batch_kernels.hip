@@ -25,6 +25,7 @@
 #include <utility>
 
 #include "fmx_internal.h"
+#include "fm_probit.h"
 
 #ifndef FMX_U
 #define FMX_U 4  // row gathers kept in flight per lane
@@ -76,8 +77,9 @@ __device__ __forceinline__ double grad_mult(const Hyper& h, double y_hat, float 
   return -(double)y * (1.0 - 1.0 / (1.0 + exp(-(double)y * y_hat)));
 }
 
-__device__ __forceinline__ double link_apply(const Hyper& h, double y_hat, int link) {
+__device__ __forceinline__ double link_apply(const Hyper& h, double y_hat, int link, const double* __restrict__ pn_y) {
   if (link == FMX_LINK_LOGISTIC) return 1.0 / (1.0 + exp(-y_hat));  // core/Model.h:173-178
+  if (link == FMX_LINK_PROBIT) return fast_pnorm(pn_y, y_hat);       // core/Model.h:166-171 (MCMC / ALS models)
   if (link == FMX_LINK_CLAMP) {                                       // src/FM.cpp:204-210
     if (y_hat < h.min_t) return h.min_t;
     if (y_hat > h.max_t) return h.max_t;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
       a.partials[2 * (size_t)blockIdx.x + 1] = q0;
     }
   } else {
-    if (have && lig == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link);
+    if (have && lig == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link, a.pn_y);
     if constexpr (sizeof(T) == 8) {  // fp64 tables: optionally the per-row factor sums q[row][f] = sum_j x_j v_jf (ALS sweeps)
       if (have && a.qout) *reinterpret_cast<double2*>(a.qout + (size_t)row * KP + lig * VEC) = make_double2(s[0], s[1]);
     }

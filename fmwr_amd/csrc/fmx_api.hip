@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "fmx_internal.h"
+#include "fm_probit.h"
 
 namespace fmx {
 
@@ -229,6 +230,8 @@ static int check_pair(const fmx_engine* e, const fmx_matrix* m) {
 }
 
 static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r1, double* d_out, int link) {
+  FMX_CHECK(link >= FMX_LINK_NONE && link <= FMX_LINK_PROBIT, FMX_ERR_INVALID, "unknown link %d", link);
+  if (link == FMX_LINK_PROBIT) FMX_TRY(ensure_probit(e));
   const int64_t SLAB = 1 << 22;
   for (int64_t b = r0; b < r1; b += SLAB) {
     RowsArgs a{};
@@ -239,8 +242,28 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
     a.scal = e->scal;
     a.yhat = d_out + (b - r0);
     a.link = link;
+    a.pn_y = e->probit;
     FMX_TRY(launch_rows_forward(e, a, false, wide_state(e)));
   }
+  return FMX_OK;
+}
+
+// util/Random.h:95-124's tables (fm_probit.h), generated from their formulas and uploaded on first use
+int ensure_probit(fmx_engine* e) {
+  if (e->probit) return FMX_OK;
+  std::vector<double> t((size_t)PN_POINTS + 1 + DP_POINTS + 1);
+  for (int i = 0; i < PN_POINTS; ++i) t[(size_t)i] = 0.5 * std::erfc(-pn_x(i) / std::sqrt(2.0));
+  t[PN_POINTS] = t[PN_POINTS - 1];  // x == MAX reads one past the shipped table
+  double* dp = t.data() + PN_POINTS + 1;
+  for (int i = 0; i < DP_POINTS; ++i) {
+    const double x = dp_x(i);
+    // the shipped values carry this formula's cancellation and 12 decimals
+    const double r = std::exp(-0.5 * x * x) / std::sqrt(2.0 * 3.14159265358979323846) / (1.0 - 0.5 * std::erfc(-x / std::sqrt(2.0)));
+    dp[i] = std::round(r * 1e12) / 1e12;
+  }
+  dp[DP_POINTS] = dp[DP_POINTS - 1];
+  FMX_HIP(hipMalloc(&e->probit, t.size() * sizeof(double)));
+  FMX_HIP(hipMemcpy(e->probit, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
   return FMX_OK;
 }
 
@@ -527,7 +550,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
   (void)hipFree(e->dt1V); (void)hipFree(e->dt1w); (void)hipFree(e->dt2V); (void)hipFree(e->dt2w); (void)hipFree(e->dt3V); (void)hipFree(e->dt3w);
   (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
-  (void)hipFree(e->long_partial);
+  (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -794,7 +817,7 @@ int fmx_matrix_normalize(fmx_matrix* m, const double* mean, const double* std) {
 int fmx_predict(fmx_engine* e, const fmx_matrix* m, double* out, int link) {
   FMX_TRY(check_pair(e, m));
   FMX_CHECK(out != nullptr || m->n == 0, FMX_ERR_INVALID, "out is NULL");
-  FMX_CHECK(link == FMX_LINK_NONE || link == FMX_LINK_LOGISTIC || link == FMX_LINK_CLAMP, FMX_ERR_INVALID, "unknown link %d", link);
+  FMX_CHECK(link >= FMX_LINK_NONE && link <= FMX_LINK_PROBIT, FMX_ERR_INVALID, "unknown link %d", link);
   FMX_TRY(use_device(e->cfg.device));
   if (m->n == 0) return FMX_OK;
   double* d = nullptr;
@@ -870,7 +893,8 @@ namespace fmx {
 
 // the evaluation block of solver/SGD_Learner.h:143-155: prediction with the task's link, then tracker.evaluate
 static int track_eval(fmx_engine* e, const fmx_matrix* m, int metric, double* d_yhat, double* score) {
-  const int link = e->cfg.task == FMX_TASK_REGRESSION ? FMX_LINK_CLAMP : FMX_LINK_LOGISTIC;
+  // Model::predict_prob, core/Model.h:163-180: MCMC / ALS models answer through the probit table, the others logistic
+  const int link = e->cfg.task == FMX_TASK_REGRESSION ? FMX_LINK_CLAMP : (e->cfg.solver == FMX_SOLVER_ALS ? FMX_LINK_PROBIT : FMX_LINK_LOGISTIC);
   FMX_TRY(forward_rows(e, m, 0, m->n, d_yhat, link));
   return evaluate_device(e, d_yhat, m->y, m->n, metric, score);
 }

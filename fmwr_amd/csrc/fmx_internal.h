@@ -160,6 +160,7 @@ struct fmx_engine {
   void* amul = nullptr;       // [ws_rows] per-row gradient multiplier
   double* partials = nullptr; // [ws_partials][2]
   int64_t ws_partials = 0;
+  double* probit = nullptr;        // [PN_POINTS + 1 | DP_POINTS + 1] probit tables (fm_probit.h), uploaded on first use
   double* long_partial = nullptr;  // segment sums of the long lists
   int64_t long_partial_cap = 0;
   void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
@@ -213,9 +214,11 @@ struct RowsArgs {
   double* partials;     // [grid][2]     (train)
   double* yhat;         // [nrows]       (predict) -- indexed from 0; may be null when only qout is wanted
   double* qout;         // [nrows][kp64] (predict, fp64 tables) per-row factor sums, or null
+  const double* pn_y;   // fast_pnorm table (FMX_LINK_PROBIT)
   int link;
 };
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
+int ensure_probit(fmx_engine* e);  // builds and uploads the probit tables (fm_probit.h) on first use
 
 enum ScalarMode : int { SCALAR_NONE = 0, SCALAR_FUSED = 1, SCALAR_PUBLISH = 2, SCALAR_FROM_TAIL = 3 };
 

@@ -62,6 +62,7 @@ extern "C" {
 #define FMX_LINK_NONE 0      /* raw y_hat: Model::predict_batch, core/Model.h:106-161 */
 #define FMX_LINK_LOGISTIC 1  /* 1/(1+exp(-y_hat)): Model::predict_prob, core/Model.h:173-178 */
 #define FMX_LINK_CLAMP 2     /* clamp to [min_target, max_target]: src/FM.cpp:202-210 */
+#define FMX_LINK_PROBIT 3    /* fast_pnorm(y_hat), the table-driven Phi of MCMC / ALS models: core/Model.h:166-171 */
 
 /* Mirrors the three R control lists (R/fm_control.R:52-66 model.control, R/fm_solver_control.R:91-115
  * SGD.solver / FTRL.solver) as FM() reads them by key (src/FM.cpp:48-63, :97-144). */

@@ -112,12 +112,33 @@ def predict(P, X, w0, w, v, row):
 
 
 def predict_batch(P, X, w0, w, v, prob=False):
-    """core/Model.h:106-161 (prob=True: :163-180 logistic)."""
+    """core/Model.h:106-161 (prob=True: :163-180 logistic; prob="probit": the MCMC/ALS table link)."""
     out = np.zeros(max(X.n, 1))
     w = _f64(w); v = _f64(v)
-    fn = lib().fmo_predict_prob if prob else lib().fmo_predict_batch
+    fn = lib().fmo_predict_probit if prob == "probit" else lib().fmo_predict_prob if prob else lib().fmo_predict_batch
     fn(C.byref(P), C.c_uint32(X.p), C.c_double(w0), _ptr(w), _ptr(v), C.byref(X.c), _ptr(out))
     return out[: X.n]
+
+
+def fast_pnorm(x):
+    """util/Random.h:95-111, elementwise."""
+    f = lib().fmo_fast_pnorm
+    f.restype = C.c_double
+    return np.array([f(C.c_double(float(t))) for t in np.atleast_1d(x)])
+
+
+def fast_dpnorm(x):
+    """util/Random.h:113-124, elementwise."""
+    f = lib().fmo_fast_dpnorm
+    f.restype = C.c_double
+    return np.array([f(C.c_double(float(t))) for t in np.atleast_1d(x)])
+
+
+def probit_tables():
+    """The regenerated grids (pn_y[2861], dp_y[40001]) of util/RandomData.h / RandomData_.h."""
+    pn, dp = np.zeros(2861), np.zeros(40001)
+    lib().fmo_probit_tables(_ptr(pn), _ptr(dp))
+    return pn, dp
 
 
 def grad_mult(P, y_hat, y):
@@ -261,7 +282,7 @@ def normalize(col, val, mean, std):
 
 
 def als_learn(P, X, y, w0, w, v, max_iter, with_v=False):
-    """solver/MCMC_ALS_Learner.h:91-156 (ALS learner, regression): returns (w0, w, v)."""
+    """solver/MCMC_ALS_Learner.h:91-156 (ALS learner; P.task picks the residual of :520-562): returns (w0, w, v)."""
     col_ptr, row_idx, val_t = X.transpose()
     row_idx = np.ascontiguousarray(row_idx); val_t = np.ascontiguousarray(val_t)
     y = np.ascontiguousarray(y, np.float32)

@@ -197,6 +197,79 @@ void fmo_predict_prob(const fmo_params* P, uint32_t p, double w0, const double* 
   for (int64_t i = 0; i < X->n; ++i) out[i] = 1.0 / (1.0 + exp(-out[i]));
 }
 
+/* ------------------------------------------------------------------ util/Random.h:95-124 probit tables
+ * fast_pnorm: Phi on a 2861-point grid x_i = i / HINV over [0, 5.2003...] with linear interpolation, saturating at
+ * 0.999999900524235 (:102); fast_dpnorm: dnorm(x) / (1 - pnorm(x)) on the 40001-point grid -3 + i * 2e-4 over [-3, 5],
+ * 0 below -3 (:119), an asymptote formula above 5 (:120).  The reference ships the grids as ~1 MB of literals
+ * (util/RandomData.h, util/RandomData_.h); they are REGENERATED here from their defining formulas: Phi = erfc(-x/sqrt2)/2
+ * (agrees with the shipped 15-digit values to 7e-16), and the ratio computed the way the shipped values evidently were --
+ * dnorm(x) / (1 - pnorm(x)), cancellation included -- rounded to their 12 decimals (agrees to ~2e-12).
+ * tests/test_oracle_probit.py checks both claims against the reference's files when they are present, and against a
+ * committed sample of them (tests/golden/probit_tables.json) everywhere. */
+#define FMO_PN_POINTS 2861
+#define FMO_DP_POINTS 40001
+static const double FMO_PN_MAX = 5.20031455849973;
+static const double FMO_PN_HINV = 549.966731401936;
+static double g_pn_y[FMO_PN_POINTS + 1];
+static double g_dp_y[FMO_DP_POINTS + 1];
+static int g_probit_ready = 0;
+
+static double fmo_pn_x(int i) { return (double)i / FMO_PN_HINV; }
+static double fmo_dp_x(int i) { return (double)(-30000 + 2 * i) / 10000.0; }  /* the double nearest to the 4-decimal literal */
+
+static void fmo_probit_init(void) {
+  if (g_probit_ready) return;
+  for (int i = 0; i < FMO_PN_POINTS; ++i) g_pn_y[i] = 0.5 * erfc(-fmo_pn_x(i) / sqrt(2.0));
+  g_pn_y[FMO_PN_POINTS] = g_pn_y[FMO_PN_POINTS - 1];  /* x == MAX reads one past the shipped table (w ~ 0 there) */
+  for (int i = 0; i < FMO_DP_POINTS; ++i) {
+    const double x = fmo_dp_x(i);
+    const double r = exp(-0.5 * x * x) / sqrt(2.0 * 3.14159265358979323846) / (1.0 - 0.5 * erfc(-x / sqrt(2.0)));
+    g_dp_y[i] = round(r * 1e12) / 1e12;
+  }
+  g_dp_y[FMO_DP_POINTS] = g_dp_y[FMO_DP_POINTS - 1];
+  g_probit_ready = 1;
+}
+
+/* the regenerated grids, for the tests: pn_y[2861], dp_y[40001] */
+void fmo_probit_tables(double* pn_y, double* dp_y) {
+  fmo_probit_init();
+  memcpy(pn_y, g_pn_y, sizeof(double) * FMO_PN_POINTS);
+  memcpy(dp_y, g_dp_y, sizeof(double) * FMO_DP_POINTS);
+}
+
+/* util/Random.h:95-111 */
+double fmo_fast_pnorm(double x) {
+  fmo_probit_init();
+  double ax = x < 0 ? -x : x;
+  double res;
+  if (ax > FMO_PN_MAX) {
+    res = 0.999999900524235;
+  } else {
+    int i = (int)(ax * FMO_PN_HINV);
+    double w = (ax - fmo_pn_x(i)) * FMO_PN_HINV;
+    res = w * g_pn_y[i + 1] + (1.0 - w) * g_pn_y[i];
+  }
+  return ax == x ? res : 1.0 - res;
+}
+
+/* util/Random.h:113-124 */
+double fmo_fast_dpnorm(double x) {
+  fmo_probit_init();
+  double ax = x < 0 ? -x : x;
+  if (x < -3.0) return 0.0;
+  if (x > 5.0) return 0.1943369 + 0.9754752 * x + 0.4136861 * sqrt(ax) - 0.5034295 * log(ax + 1e-07);
+  int i = (int)((x - -3.0) * 5000);
+  double w = (x - fmo_dp_x(i)) * 5000;
+  return w * g_dp_y[i + 1] + (1.0 - w) * g_dp_y[i];
+}
+
+/* core/Model.h:163-172 Model::predict_prob, MCMC/ALS branch: probit link through the table. */
+void fmo_predict_probit(const fmo_params* P, uint32_t p, double w0, const double* w, const double* v,
+                        const fmo_csr* X, double* out) {
+  fmo_predict_batch(P, p, w0, w, v, X, out);
+  for (int64_t i = 0; i < X->n; ++i) out[i] = fmo_fast_pnorm(out[i]);
+}
+
 /* FM.cpp:202-210 / SGD_Learner.h:147-153: clamp regression predictions to the target range. */
 void fmo_clamp(double* out, int64_t n, double lo, double hi) {
   for (int64_t i = 0; i < n; ++i) {
@@ -652,6 +725,15 @@ void fmo_als_error_regression(double* error, const float* y, int64_t n) {
   for (int64_t i = 0; i < n; ++i) error[i] -= y[i];
 }
 
+/* solver/MCMC_ALS_Learner.h:545-559 calculate_error, CLASSIFICATION branch of the ALS learner (do_sample == false):
+ * e = -phi(-y_hat)/(1 - Phi(-y_hat)) for a non-negative label, phi(y_hat)/(1 - Phi(y_hat)) otherwise, through the table. */
+void fmo_als_error_classification(double* error, const float* y, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    const double e = error[i];
+    error[i] = (y[i] >= 0.0f) ? -fmo_fast_dpnorm(-e) : fmo_fast_dpnorm(e);
+  }
+}
+
 static int fmo_bad(double x) { return isnan(x) || isinf(x); }
 
 /* solver/MCMC_ALS_Learner.h:272-354 update_v, one attribute group.  znorm == NULL: the ALS branch (do_sample == false).
@@ -752,7 +834,8 @@ void fmo_als_learn(const fmo_params* P, uint32_t p, double* w0, double* w, doubl
   double* zeros = (double*)calloc((size_t)(P->k ? P->k : 1), sizeof(double));
   for (int it = 0; it < max_iter; ++it) {
     fmo_predict_batch(P, p, *w0, w, v, X, error);
-    fmo_als_error_regression(error, y, X->n);
+    if (P->task == FMO_REGRESSION) fmo_als_error_regression(error, y, X->n);
+    else fmo_als_error_classification(error, y, X->n);
     if (P->k0) fmo_als_update_w0(P, w0, error, X->n, 1.0, 0.0);
     if (P->k1) fmo_als_update_w(p, w, col_ptr, row_idx, val_t, error, 1.0, 0.0, 0.0);
     if (with_v && P->k > 0) fmo_als_update_v(P->k, p, v, X->n, col_ptr, row_idx, val_t, error, v_q, 1.0, zeros, zeros, NULL);

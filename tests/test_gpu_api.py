@@ -190,3 +190,25 @@ def test_als_solver_through_the_api():
     assert abs(fit["Model"]["w0"] - r0) < 1e-10 and np.max(np.abs(fit["Model"]["w"] - rw)) < 1e-9
     pred = fm.predict(fit, data, normalize=False)
     assert np.mean((pred - y) ** 2) < 0.1 * np.var(y)  # the linear part is recovered
+
+
+def test_als_classification_through_the_api_uses_the_probit_tables():
+    """ALS on CLASSIFICATION: residual -/+ dnorm/(1-pnorm) through the table (MCMC_ALS_Learner.h:545-559), predictions
+    through fast_pnorm (Model::predict_prob, core/Model.h:166-171)."""
+    import fmwr_amd as fm
+    rng = np.random.default_rng(23)
+    n, p, k = 3000, 60, 2
+    X = sp.random(n, p, density=0.1, format="csr", random_state=23, data_rvs=lambda s: rng.normal(0, 1, s)); X.sort_indices()
+    y = np.where(X @ rng.normal(0, 1, p) + 0.2 > 0, 1.0, 0.0)  # 0/1 labels: the API maps them to -1/+1 (R/fm_train.R:60-69)
+    data = fm.fm_matrix(X, y)
+    ctl = [fm.model_control("CLASSIFICATION", **{"factor.number": k}), fm.solver_control(max_iter=8, solver=fm.ALS_solver())]
+    fit = fm.fm_train(data, normalize=False, control=ctl, seed=3)
+    v0 = np.random.default_rng(3).normal(0.0, 0.01, (k, p))
+    P = oracle.params(task=oracle.CLASSIFICATION, k=k)
+    Xo = oracle.Matrix(X.indptr, X.indices, X.data, p)
+    r0, rw, rv = oracle.als_learn(P, Xo, np.where(y > 0, 1.0, -1.0).astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 8)
+    assert abs(fit["Model"]["w0"] - r0) < 1e-10 and np.max(np.abs(fit["Model"]["w"] - rw)) < 1e-9
+    prob = fm.predict(fit, data, normalize=False)
+    ref = oracle.predict_batch(P, Xo, r0, rw, rv, prob="probit")
+    np.testing.assert_allclose(prob, ref, rtol=0, atol=1e-9)
+    assert np.mean((prob >= 0.5) == (y > 0)) > 0.93

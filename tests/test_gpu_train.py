@@ -365,6 +365,31 @@ def test_als_training_loop_matches_oracle(fm, with_v):
     assert sse(g0, gw, gv) < sse(w0, w, v)
 
 
+@pytest.mark.parametrize("with_v", [False, True])
+def test_als_classification_matches_oracle(fm, with_v):
+    """The CLASSIFICATION residual of the ALS learner (MCMC_ALS_Learner.h:545-559: -/+ dnorm/(1-pnorm) through the
+    40001-point table) and the probit link of its predictions (fast_pnorm, core/Model.h:166-171)."""
+    engine, L = fm
+    n, p, k = 1500, 80, 3
+    rp, col, val = util.random_csr(n, p, 6, seed=67, empty_rows=True)
+    y = util.labels(n, 67)
+    w0, w, v = util.params(p, k, 67, stdev=0.3, fp32=False)
+    w = w * 5.0  # scores well beyond +-3 and +-5.2: both tables' saturation branches are visited
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.CLASSIFICATION, k=k, l2_reg0=0.02)
+    e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_ALS, num_factor=k, l2_w0=0.02, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    raw = oracle.predict_batch(P, X, w0, w, v.ravel())
+    assert raw.max() > 5.3 and raw.min() < -5.3
+    np.testing.assert_allclose(e.predict(m, L.LINK_PROBIT), oracle.fast_pnorm(raw), rtol=0, atol=1e-15)
+    assert abs(e.evaluate(m, L.EVAL_LL) - oracle.evaluate(oracle.CLASSIFICATION, oracle.LL, oracle.fast_pnorm(raw), y)) < 1e-9
+    r0, rw, rv = oracle.als_learn(P, X, y, w0, w, v.ravel(), 3, with_v=with_v)
+    e.als_train(m, 3, with_v=with_v)
+    g0, gw, gv = e.get_params()
+    assert abs(g0 - r0) < 1e-10 and util.rel_err(gw, rw) < 1e-10 and util.rel_err(gv, rv.reshape(k, p)) < 1e-10
+
+
 @pytest.mark.parametrize("name", ["sgd_l2_cls", "sgd_l1_cls", "ftrl_l1l2_cls"])
 def test_sparse_tiles_walk_only_occurring_features(fm, name):
     """Far more features than entries per batch (the usual FM regime): phase 2 walks the per-tile list of occurring
