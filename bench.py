@@ -81,6 +81,18 @@ def pmc_traffic(kernel, args):
     return best
 
 
+def host_cpu_share():
+    """Cores this process may really use: affinity mask, cgroup quota, and at most 16 (a one-GPU box's CPU share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(m, args, v0):
     """Oracle (reference-order serial SGD, one core) on the first cpu_rows rows of the same matrix."""
     import oracle
@@ -94,8 +106,22 @@ def cpu_baseline(m, args, v0):
     t0 = time.perf_counter()
     done = oracle.sgd_pass(P, X, y, 0.0, w, v.ravel())
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "examples/s", "cores": 1, "kind": "port",
-            "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial pass ({dt:.1f} s)"}
+    out = {"value": done / dt, "unit": "examples/s", "cores": 1, "kind": "port",
+           "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial pass ({dt:.1f} s)"}
+    # SURVEY 8(d) item ii, reported beside it: what all host cores give.  The reference has no parallel training, so the
+    # yardstick is its example step run lock-free over row ranges (Hogwild); its forward is OpenMP over rows as shipped.
+    threads = min(oracle.omp_threads(), host_cpu_share())
+    w = np.zeros(args.features)
+    v = np.ascontiguousarray(v0.astype(np.float64))
+    t0 = time.perf_counter()
+    done = oracle.omp_sgd_hogwild(P, X, y, 0.0, w, v.ravel(), threads)
+    dt_h = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.omp_predict_batch(P, X, 0.0, w, v.ravel(), threads)
+    dt_f = time.perf_counter() - t0
+    out["all_cores"] = {"cores": threads, "hogwild_examples_per_s": done / dt_h, "forward_rows_per_s": n / dt_f,
+                        "sample": f"rows 0..{n - 1}, one lock-free OpenMP pass ({dt_h:.1f} s) and one OpenMP forward ({dt_f:.1f} s)"}
+    return out
 
 
 def main():

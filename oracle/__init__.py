@@ -35,12 +35,29 @@ class Csr(C.Structure):
     _fields_ = [("n", C.c_int64), ("p", C.c_uint32), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p)]
 
 
+_OMP_PATH = os.path.join(_HERE, "_build", "libfm_oracle_omp.so")
+
+
 def build(force=False):
-    """Compile oracle/fm_oracle.c -> oracle/_build/libfm_oracle.so (gcc)."""
-    src = os.path.join(_HERE, "fm_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    """Compile oracle/fm_oracle.c -> oracle/_build/libfm_oracle.so and the all-core baselines (gcc)."""
+    srcs = [os.path.join(_HERE, "fm_oracle.c"), os.path.join(_HERE, "fm_oracle_omp.c")]
+    stale = any(not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s) for s in srcs) for o in (_LIB_PATH, _OMP_PATH))
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
+
+
+_omp = None
+
+
+def lib_omp():
+    """The OpenMP baselines (fm_oracle_omp.c): bench.py's all-core CPU numbers only."""
+    global _omp
+    if _omp is None:
+        build()
+        _omp = C.CDLL(_OMP_PATH)
+        _omp.fmo_omp_sgd_hogwild.restype = C.c_int64
+    return _omp
 
 
 _lib = None
@@ -237,6 +254,24 @@ def sgd_pass(P, X, y, w0, w, v):
     y = np.ascontiguousarray(y, np.float32)
     w0c = C.c_double(w0)
     return lib().fmo_sgd_pass(C.byref(P), C.c_uint32(X.p), C.byref(w0c), _ptr(w), _ptr(v), C.byref(X.c), _ptr(y))
+
+
+def omp_threads():
+    return lib_omp().fmo_omp_max_threads()
+
+
+def omp_predict_batch(P, X, w0, w, v, threads):
+    """The reference's OpenMP-over-rows forward (core/Model.h:106-161) on `threads` cores."""
+    out = np.zeros(max(X.n, 1))
+    lib_omp().fmo_omp_predict_batch(C.byref(P), C.c_uint32(X.p), C.c_double(w0), _ptr(_f64(w)), _ptr(_f64(v)), C.byref(X.c), _ptr(out), C.c_int(threads))
+    return out[: X.n]
+
+
+def omp_sgd_hogwild(P, X, y, w0, w, v, threads):
+    """One lock-free (Hogwild) pass of the reference's example step over all rows; w, v updated in place."""
+    y = np.ascontiguousarray(y, np.float32)
+    w0c = C.c_double(w0)
+    return lib_omp().fmo_omp_sgd_hogwild(C.byref(P), C.c_uint32(X.p), C.byref(w0c), _ptr(w), _ptr(v), C.byref(X.c), _ptr(y), C.c_int(threads))
 
 
 def batch_sums(P, X, y, w0, w, v, b0, b1, acc=None):
