@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfmx.so")
+LIB_PATH = os.environ.get("FMX_LIB_PATH") or os.path.join(_PKG, "libfmx.so")  # FMX_LIB_PATH: A/B builds of the library (tuning only)
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOGPU, ERR_STATE = 0, 1, 2, 3, 4
 TASK_CLASSIFICATION, TASK_REGRESSION = 10, 20

@@ -90,6 +90,7 @@ __device__ __forceinline__ double link_apply(const Hyper& h, double y_hat, int l
 // coalesced copy of `cnt` (id, x) entries starting at absolute offset c0 into LDS
 __device__ __forceinline__ void stage_entries(uint2* stage, const uint32_t* __restrict__ ids,
                                               const float* __restrict__ xs, int64_t c0, int cnt) {
+  // (non-temporal loads for these read-once streams were tried: phase 1 1.7 % slower, the forward-only pass 2 % faster)
   for (int i = threadIdx.x; i < cnt; i += WG_THREADS)
     stage[i] = make_uint2(ids[c0 + i], __float_as_uint(xs[c0 + i]));
 }
