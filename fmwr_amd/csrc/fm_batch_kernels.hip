@@ -217,13 +217,23 @@ static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
 
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables) {
   prof_begin(e, FMX_KERNEL_ROWS_FORWARD);
-  int st;
-  if (fp64_tables) {
-    st = train ? launch_rows_t<double, true>(e, a, e->kp64) : launch_rows_t<double, false>(e, a, e->kp64);
-  } else if (train) {
-    st = launch_rows_t<float, true>(e, a, e->kp32);
+  int st = FMX_OK;
+  if (train) {
+    st = fp64_tables ? launch_rows_t<double, true>(e, a, e->kp64) : launch_rows_t<float, true>(e, a, e->kp32);
   } else {
-    st = launch_rows_t<float, false>(e, a, e->kp32);
+    // Forward-only passes over many rows go out as launches of 262 144 rows: measured at configs[1]
+    // (profiles/forward_probe.py) such launches run at 0.58 ns/row, 1 M-row launches at 0.69, 4 M-row launches at 0.75 --
+    // the same optimum as the training tiles.
+    const int64_t SLAB = 1 << 18;
+    const int kp = fp64_tables ? e->kp64 : e->kp32;
+    for (int64_t off = 0; off < a.nrows && st == FMX_OK; off += SLAB) {
+      RowsArgs s = a;
+      s.r0 = a.r0 + off;
+      s.nrows = a.nrows - off < SLAB ? a.nrows - off : SLAB;
+      if (a.yhat) s.yhat = a.yhat + off;
+      if (a.qout) s.qout = a.qout + (size_t)off * kp;
+      st = fp64_tables ? launch_rows_t<double, false>(e, s, kp) : launch_rows_t<float, false>(e, s, kp);
+    }
   }
   prof_end(e);
   return st;

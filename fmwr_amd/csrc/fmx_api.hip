@@ -232,19 +232,16 @@ static int check_pair(const fmx_engine* e, const fmx_matrix* m) {
 static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r1, double* d_out, int link) {
   FMX_CHECK(link >= FMX_LINK_NONE && link <= FMX_LINK_PROBIT, FMX_ERR_INVALID, "unknown link %d", link);
   if (link == FMX_LINK_PROBIT) FMX_TRY(ensure_probit(e));
-  const int64_t SLAB = 1 << 22;
-  for (int64_t b = r0; b < r1; b += SLAB) {
-    RowsArgs a{};
-    a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = nullptr;
-    a.r0 = b; a.nrows = (r1 - b < SLAB) ? r1 - b : SLAB;
-    a.V = wide_state(e) ? (const void*)e->dV : (const void*)e->V;
-    a.w = wide_state(e) ? (const void*)e->dw : (const void*)e->w;
-    a.scal = e->scal;
-    a.yhat = d_out + (b - r0);
-    a.link = link;
-    a.pn_y = e->probit;
-    FMX_TRY(launch_rows_forward(e, a, false, wide_state(e)));
-  }
+  RowsArgs a{};  // launch_rows_forward cuts the range into launches of 262 144 rows
+  a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = nullptr;
+  a.r0 = r0; a.nrows = r1 - r0;
+  a.V = wide_state(e) ? (const void*)e->dV : (const void*)e->V;
+  a.w = wide_state(e) ? (const void*)e->dw : (const void*)e->w;
+  a.scal = e->scal;
+  a.yhat = d_out;
+  a.link = link;
+  a.pn_y = e->probit;
+  FMX_TRY(launch_rows_forward(e, a, false, wide_state(e)));
   return FMX_OK;
 }
 
