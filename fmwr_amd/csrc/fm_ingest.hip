@@ -350,6 +350,7 @@ int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offs
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipDeviceSynchronize());
   m->rows_sorted = 1;  // strata are disjoint and ascending
+  m->max_row_len = z;
   return FMX_OK;
 }
 
@@ -447,23 +448,26 @@ int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std) {
 }
 
 // ------------------------------------------------------------------------------------------------ sortedness
-__global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int* __restrict__ unsorted) {
+__global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int* __restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   int bad = 0;
   for (int64_t t = row_ptr[r]; t + 1 < row_ptr[r + 1]; ++t) bad |= (col[t] >= col[t + 1]);
-  if (bad) *unsorted = 1;
+  if (bad) out[0] = 1;
+  const int64_t len = row_ptr[r + 1] - row_ptr[r];
+  atomicMax(out + 1, (int)(len > 0x7fffffff ? 0x7fffffff : len));  // longest row
 }
 
 int check_rows_sorted(fmx_matrix* m) {
   int* d = nullptr;
-  int h = 0;
-  FMX_HIP(hipMalloc(&d, sizeof(int)));
-  FMX_HIP(hipMemset(d, 0, sizeof(int)));
+  int h[2] = {0, 0};
+  FMX_HIP(hipMalloc(&d, 2 * sizeof(int)));
+  FMX_HIP(hipMemset(d, 0, 2 * sizeof(int)));
   if (m->n > 0) hipLaunchKernelGGL(rows_sorted_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->n, d);
-  FMX_HIP(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
+  FMX_HIP(hipMemcpy(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost));
   FMX_HIP(hipFree(d));
-  m->rows_sorted = !h;
+  m->rows_sorted = !h[0];
+  m->max_row_len = h[1];
   return FMX_OK;
 }
 

@@ -12,6 +12,12 @@
 // reference's order too.  With -ffp-contract=off the only arithmetic difference to the CPU code is the
 // device exp().  The w update puts nonzero t on lane t (rows whose columns are not strictly ascending may
 // hold a column twice and take a one-lane serial path instead).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include "fmx_internal.h"
 
 namespace fmx {
@@ -479,6 +485,283 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
   }
 }
 
+// ---- windowed learner ------------------------------------------------------------------------------------------------
+// The same algorithm, the same visiting order, the same arithmetic in the same association -- but consecutive examples
+// that share no feature touch disjoint parameters, so only the w0 chain orders them.  A workgroup of NW waves takes a
+// GROUP of up to NW consecutive examples that are pairwise feature-disjoint (one example per wave):
+//   A  every wave gathers its example's parameters and forms the terms of y_hat (w_j x_j in row order, then
+//      0.5 (s_f^2 - q_f) in factor order) -- everything of the forward except the running sum that starts at w0;
+//   S  wave 0 runs the scalar chain example by example in order: pred = w0 + terms (the reference's association,
+//      core/Model.h:77-100), the gradient multiplier, the w0 step -- the only truly sequential work;
+//   C  every wave applies its example's update from its registers.
+// A group ends at the first example that shares a feature with an earlier member (it then reads what that member wrote).
+// `conf[t]`, the last earlier example of the launch sharing a feature with t, comes from a stable sort of the launch's
+// (feature, example) pairs; TDAP examples holding a feature id < FAST_NZ run alone (its w prox reads z_w by POSITION, A-6).
+// Bitwise the same results as the one-wave kernel above (tests/test_gpu_seq_window.py).
+constexpr int WIN_TERMS = FAST_NZ + 64;
+template <int KIND> struct SeqWin { static constexpr int NW = (KIND == UPD_TDAP) ? 4 : 8; };  // registers: FAST_NZ x (1 + state) doubles per lane
+
+struct WinArgs {
+  const uint2* packed;  // [count][FAST_NZ] (column, x bits), idle slots (0, +0.0f)
+  const int* ex_len;
+  const float* ex_y;
+  const int* conf;      // [count] last earlier example sharing a feature (-1: none; t itself: must run alone)
+  int count;
+};
+
+__global__ void seq_pack_k(const int64_t* __restrict__ ex_b, const int* __restrict__ ex_len, int count, const uint32_t* __restrict__ col,
+                           const float* __restrict__ val, int tdap, uint2* __restrict__ packed, uint32_t* __restrict__ keys,
+                           uint32_t* __restrict__ vals, int* __restrict__ conf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count * FAST_NZ) return;
+  const int t = i / FAST_NZ, u = i % FAST_NZ;
+  const bool have = u < ex_len[t];
+  const uint32_t c = have ? col[ex_b[t] + u] : 0u;
+  packed[i] = make_uint2(c, have ? __float_as_uint(val[ex_b[t] + u]) : 0u);
+  keys[i] = have ? c : 0xFFFFFFFFu;
+  vals[i] = (uint32_t)t;
+  if (tdap && have && c < (uint32_t)FAST_NZ) atomicMax(conf + t, t);  // z_w[c] is what other examples read by position
+}
+
+__global__ void seq_conf_k(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int n, int* __restrict__ conf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= 0 || i >= n) return;
+  if (keys[i] != 0xFFFFFFFFu && keys[i] == keys[i - 1]) atomicMax(conf + vals[i], (int)vals[i - 1]);  // stable sort: vals ascend inside a key
+}
+
+template <int KIND>
+__global__ __launch_bounds__(SeqWin<KIND>::NW * 64) void fm_seq_window_k(SeqArgs a, WinArgs wa, Hyper h) {
+  constexpr int NW = SeqWin<KIND>::NW;
+  constexpr int NS = SeqState<KIND>::N;
+  __shared__ double terms[NW][WIN_TERMS];
+  __shared__ double s_mult[NW], s_uw[NW], s_uv[NW];
+  __shared__ float s_y[NW];
+  __shared__ int s_cand[NW], s_need[NW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = a.k, kp = a.kp;
+  const bool k0 = h.k0 != 0, k1 = h.k1 != 0;
+  const int k8 = (k + 7) & ~7;  // the chain adds the pairwise terms eight at a time
+  // the scalar chain lives in wave 0
+  double w0 = a.scal[SC_W0], z0 = a.scal[SC_Z0], n0 = a.scal[SC_N0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
+  double t_nu = a.scal[SC_T_NU], t_delta = a.scal[SC_T_DELTA], t_h = a.scal[SC_T_H];
+
+  // this wave's candidate example of the group starting at g: its metadata is fetched one group ahead
+  struct Meta { int conf_t, conf_g, len; uint2 en; float y; };
+  auto fetch = [&](int gg) {
+    Meta mt{-1, -1, 0, make_uint2(0u, 0u), 0.f};
+    const int tt = gg + wave;
+    if (tt < wa.count) {
+      mt.conf_t = wa.conf[tt];
+      mt.conf_g = wa.conf[gg];
+      mt.len = wa.ex_len[tt];
+      mt.en = wa.packed[(size_t)tt * FAST_NZ + (lane & (FAST_NZ - 1))];
+      mt.y = wa.ex_y[tt];
+    }
+    return mt;
+  };
+  int g = 0;
+  int unfenced = 0;  // stores of the examples >= unfenced may still be in flight (no fence since)
+#ifdef FMX_SEQ_TIMING
+  unsigned long long tA = 0, tS = 0, tC = 0, tV = 0, tF = 0, nG = 0, nF = 0, t0, t1;
+#define FMX_T(acc) do { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } while (0)
+#else
+#define FMX_T(acc) do { } while (0)
+#endif
+  Meta cur = fetch(0);
+  if (lane == 0) s_cand[wave] = (wave < wa.count) && (wave == 0 || (cur.conf_t < 0 && cur.conf_g != 0));
+  __syncthreads();
+
+  while (g < wa.count) {
+#ifdef FMX_SEQ_TIMING
+    t0 = __builtin_amdgcn_s_memtime(); ++nG;
+#endif
+    int G = 0;
+    while (G < NW && s_cand[G]) ++G;  // the group: the leading candidates
+    const bool mine = wave < G;
+    const int gn = g + G;             // where the next group starts: known now, so its metadata can travel during this group
+    const Meta nxt = fetch(gn);
+
+    // ---------------------------------------------------------------- A: gathers and the terms of y_hat
+    const bool fv = lane < k;
+    const int fl = fv ? lane : 0;
+    const int len = cur.len;
+    const bool tv = lane < len;
+    const uint32_t mycol = tv ? cur.en.x : 0u;
+    const double myx = tv ? (double)__uint_as_float(cur.en.y) : 0.0;
+    double myw = 0.0, s1 = 0.0, q1 = 0.0;
+    double stw[NS > 0 ? NS : 1];
+    double vv[FAST_NZ];
+    double stv[NS > 0 ? NS : 1][FAST_NZ];
+    if (mine) {
+      myw = a.w[mycol];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) stw[j] = seq_state_ptr<KIND>(a, true, j)[mycol];
+#pragma unroll
+      for (int u = 0; u < FAST_NZ; ++u) {
+        const size_t at = (size_t)bcast(mycol, u) * kp + fl;
+        vv[u] = a.V[at];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) stv[j][u] = seq_state_ptr<KIND>(a, false, j)[at];
+      }
+#pragma unroll
+      for (int u = 0; u < FAST_NZ; ++u) {  // core/Model.h:83-97, row order
+        const double tmp = vv[u] * bcast(myx, u);
+        s1 += tmp;
+        q1 += tmp * tmp;
+      }
+      if (lane < FAST_NZ) terms[wave][lane] = (k1 ? myw : 0.0) * myx;     // w_j x_j, the linear term's addends in row order
+      if (lane < k8) terms[wave][FAST_NZ + lane] = fv ? 0.5 * (s1 * s1 - q1) : 0.0;  // core/Model.h:100, factor order
+      if (lane == 0) s_y[wave] = cur.y;
+    }
+    __syncthreads();
+    FMX_T(tA);
+
+    // ---------------------------------------------------------------- S: the scalar chain, in order
+    if (wave == 0) {
+      for (int e = 0; e < G; ++e) {
+        if constexpr (KIND == UPD_SGD_L1) { uw += h.lr * h.regw; uv += h.lr * h.regv; }  // SGD_Learner.h:92-97
+        // every lane reads the same addresses (LDS broadcast) and runs the same chain: no cross-lane traffic in the chain
+        const double* __restrict__ T = terms[e];
+        double pred = k0 ? w0 : 0.0;
+#pragma unroll
+        for (int u = 0; u < FAST_NZ; u += 8) {
+          double tt[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) tt[i] = T[u + i];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pred += tt[i];
+        }
+        for (int f = 0; f < k8; f += 8) {  // slots k..k8 hold +0.0: adding it changes nothing
+          double tt[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) tt[i] = T[FAST_NZ + f + i];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pred += tt[i];
+        }
+        const double mult = seq_grad_mult(h, pred, s_y[e]);
+        if (k0) {
+          if constexpr (KIND == UPD_TDAP) tdap_coord(mult, w0, h.alpha_w, h.egamma, n0, t_nu, t_delta, t_h, z0);
+          else if constexpr (KIND == UPD_FTRL) {
+            const double n_old = n0;
+            n0 += mult * mult;
+            const double delta = (sqrt(n0) - sqrt(n_old)) / h.alpha_w;
+            z0 += mult - delta * w0;
+          } else w0 -= h.lr * (mult + h.reg0 * w0);
+        }
+        if constexpr (KIND == UPD_FTRL) w0 = -z0 * h.alpha_w / (h.beta_w + sqrt(n0));
+        if constexpr (KIND == UPD_TDAP) w0 = -z0 / t_delta;
+        if (lane == 0) { s_mult[e] = mult; s_uw[e] = uw; s_uv[e] = uv; }
+      }
+    }
+    __syncthreads();
+    FMX_T(tS);
+
+    // ---------------------------------------------------------------- C: the example's update, from registers
+    if (mine) {
+      const double mult = s_mult[wave], euw = s_uw[wave], euv = s_uv[wave];
+      if (tv && (k1 || KIND == UPD_FTRL)) {
+        if constexpr (KIND == UPD_TDAP) {
+          const double z = coord_seq<KIND>(h, true, true, myw, myx, mult, euw, stw);
+          a.sw[mycol] = z;
+        } else {
+          coord_seq<KIND>(h, true, k1, myw, myx, mult, euw, stw);
+          a.w[mycol] = myw;
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) if (k1) seq_state_ptr<KIND>(a, true, j)[mycol] = stw[j];
+      }
+#pragma unroll
+      for (int u = 0; u < FAST_NZ; ++u) {
+        const double xu = bcast(myx, u);
+        const size_t at = (size_t)bcast(mycol, u) * kp + lane;
+        if (u < len && fv) {
+          double th = vv[u];
+          double st[NS > 0 ? NS : 1];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) st[j] = stv[j][u];
+          const double grad = s1 * xu - th * xu * xu;
+          const double z = coord_seq<KIND>(h, false, true, th, grad, mult, euv, st);
+          a.V[at] = th;
+          if constexpr (KIND == UPD_TDAP) a.sV[at] = z;
+#pragma unroll
+          for (int j = 0; j < NS; ++j) seq_state_ptr<KIND>(a, false, j)[at] = st[j];
+        }
+      }
+      if constexpr (KIND == UPD_TDAP) {  // w prox reads z_w by POSITION (TDAP_Learner.h:207); such readers/writers never share a group
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (tv) a.w[mycol] = tdap_prox(a.sw[lane], k1 ? stw[2] : a.t2w[mycol], h.l1w, h.l2w);
+      }
+    }
+
+    FMX_T(tC);
+    // ---------------------------------------------------------------- the next group: members, and whether it must wait
+    // for stores still in flight (it must iff one of its candidates shares a feature with an example stored since the
+    // last fence; otherwise its gathers overlap this group's stores)
+    const int tn = gn + wave;
+    const bool in_n = tn < wa.count;
+    if (lane == 0) {
+      s_cand[wave] = in_n && (wave == 0 || (nxt.conf_t < gn && nxt.conf_g != gn));
+      s_need[wave] = in_n && nxt.conf_t >= unfenced;
+    }
+    __syncthreads();
+    int need = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) need |= s_need[i];
+    FMX_T(tV);
+    if (need) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores done ...
+      __syncthreads();                                         // ... and everybody else's
+      unfenced = gn;
+#ifdef FMX_SEQ_TIMING
+      ++nF;
+#endif
+    }
+    FMX_T(tF);
+    g = gn;
+    cur = nxt;
+  }
+
+  if (threadIdx.x == 0) {
+    a.scal[SC_W0] = w0; a.scal[SC_Z0] = z0; a.scal[SC_N0] = n0; a.scal[SC_UW] = uw; a.scal[SC_UV] = uv;
+    a.scal[SC_T_NU] = t_nu; a.scal[SC_T_DELTA] = t_delta; a.scal[SC_T_H] = t_h;
+#ifdef FMX_SEQ_TIMING
+    printf("window kernel: %llu groups (%d examples), %llu fences; memtime ticks per group: A %.0f  S %.0f  C %.0f  vote %.0f  fence %.0f\n", nG, wa.count, nF,
+           (double)tA / nG, (double)tS / nG, (double)tC / nG, (double)tV / nG, (double)tF / nG);
+#endif
+  }
+#undef FMX_T
+}
+
+// the windowed learner applies when every row is a fast row; FMX_SEQ_WINDOW=0 in the environment keeps the one-wave kernel
+static bool window_mode(const fmx_engine* e, const fmx_matrix* m) {
+  const char* s = getenv("FMX_SEQ_WINDOW");  // read per call: the tests compare both kernels in one process
+  const bool off = s && s[0] == '0';
+  return !off && m->rows_sorted && e->k <= 64 && m->max_row_len <= FAST_NZ;
+}
+
+static int ensure_window_workspace(fmx_engine* e, int64_t cap) {
+  if (cap <= e->seq_wcap) return FMX_OK;
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
+  e->seq_packed = nullptr; e->seq_conf = nullptr; e->seq_keys = nullptr; e->seq_sort_tmp = nullptr; e->seq_wcap = 0;
+  const size_t pairs = (size_t)cap * FAST_NZ;
+  FMX_HIP(hipMalloc(&e->seq_packed, pairs * sizeof(uint2)));
+  FMX_HIP(hipMalloc(&e->seq_conf, (size_t)cap * sizeof(int)));
+  FMX_HIP(hipMalloc(&e->seq_keys, 4 * pairs * sizeof(uint32_t)));
+  size_t tb = 0;
+  uint32_t* k = e->seq_keys;
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k, k + pairs, k + 2 * pairs, k + 3 * pairs, pairs, 0, 32, e->stream));
+  FMX_HIP(hipMalloc(&e->seq_sort_tmp, tb ? tb : 16));
+  e->seq_sort_tmp_bytes = tb;
+  e->seq_wcap = cap;
+  return FMX_OK;
+}
+
+template <int KIND>
+static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa) {
+  hipLaunchKernelGGL(fm_seq_window_k<KIND>, dim3(1), dim3(SeqWin<KIND>::NW * 64), 0, e->stream, a, wa, e->hyper);
+}
+
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
   FMX_CHECK(e->k <= 64 * FI, FMX_ERR_INVALID, "sequential mode supports factor.number <= %d", 64 * FI);
   if (count <= 0) return FMX_OK;
@@ -498,12 +781,38 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
   SeqArgs a{m->row_ptr, m->col, m->val, m->y, d_order, 0, ex_b, ex_len, ex_y, e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw,
             e->dt1V, e->dt1w, e->dt2V, e->dt2w, e->dt3V, e->dt3w, e->scal,
             e->k, e->kp64, m->rows_sorted};
-  // bounded launches: a single wave walking millions of examples in one dispatch would run for seconds
+  // bounded launches: a single workgroup walking millions of examples in one dispatch would run for seconds
   const int64_t CHUNK = 1 << 16;
+  const bool windowed = window_mode(e, m);
+  if (windowed) FMX_TRY(ensure_window_workspace(e, count < CHUNK ? count : CHUNK));
   for (int64_t off = 0; off < count; off += CHUNK) {
     a.order = d_order + off;
     a.ex_b = ex_b + off; a.ex_len = ex_len + off; a.ex_y = ex_y + off;
     a.count = (count - off < CHUNK) ? count - off : CHUNK;
+    if (windowed) {
+      // the chunk's examples packed in visiting order, and for each the last earlier example of the chunk sharing a feature
+      const int cnt = (int)a.count;
+      const size_t pairs = (size_t)cnt * FAST_NZ;
+      uint32_t* keys = e->seq_keys;
+      const size_t cap_pairs = (size_t)e->seq_wcap * FAST_NZ;
+      FMX_HIP(hipMemsetAsync(e->seq_conf, 0xFF, (size_t)cnt * sizeof(int), e->stream));  // -1
+      hipLaunchKernelGGL(seq_pack_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, a.ex_b, a.ex_len, cnt, m->col, m->val,
+                         e->hyper.kind == UPD_TDAP ? 1 : 0, (uint2*)e->seq_packed, keys, keys + 2 * cap_pairs, e->seq_conf);
+      size_t tb = e->seq_sort_tmp_bytes;
+      FMX_HIP(rocprim::radix_sort_pairs(e->seq_sort_tmp, tb, keys, keys + cap_pairs, keys + 2 * cap_pairs, keys + 3 * cap_pairs, pairs, 0, 32, e->stream));
+      hipLaunchKernelGGL(seq_conf_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, keys + cap_pairs, keys + 3 * cap_pairs, (int)pairs, e->seq_conf);
+      WinArgs wa{(const uint2*)e->seq_packed, a.ex_len, a.ex_y, e->seq_conf, cnt};
+      prof_begin(e, FMX_KERNEL_SEQ);
+      switch (e->hyper.kind) {
+        case UPD_SGD_L2: launch_window_kind<UPD_SGD_L2>(e, a, wa); break;
+        case UPD_SGD_L1: launch_window_kind<UPD_SGD_L1>(e, a, wa); break;
+        case UPD_TDAP: launch_window_kind<UPD_TDAP>(e, a, wa); break;
+        default: launch_window_kind<UPD_FTRL>(e, a, wa); break;
+      }
+      prof_end(e);
+      FMX_HIP(hipGetLastError());
+      continue;
+    }
     prof_begin(e, FMX_KERNEL_SEQ);
     switch (e->hyper.kind) {
       case UPD_SGD_L2: hipLaunchKernelGGL(fm_seq_learn_k<UPD_SGD_L2>, dim3(1), dim3(64), 0, e->stream, a, e->hyper); break;

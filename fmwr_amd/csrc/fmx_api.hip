@@ -547,6 +547,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
   (void)hipFree(e->dt1V); (void)hipFree(e->dt1w); (void)hipFree(e->dt2V); (void)hipFree(e->dt2w); (void)hipFree(e->dt3V); (void)hipFree(e->dt3w);
   (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
+  (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
   if (e->stream) (void)hipStreamDestroy(e->stream);

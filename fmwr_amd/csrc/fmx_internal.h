@@ -97,6 +97,7 @@ struct fmx_matrix {
   float* y = nullptr;          // [n] or null
   int has_labels = 0;
   int rows_sorted = 0;  // every row strictly ascending in col (=> no duplicate column inside a row)
+  int max_row_len = 0;  // entries of the longest row
   // per-tile CSC ("inverted index" of each tile of rows), built lazily for one (batch_rows, tile_rows) pair.
   // A step covers batch_rows consecutive rows and is cut into tiles of at most tile_rows rows.
   int64_t batch_rows = 0;
@@ -153,6 +154,13 @@ struct fmx_engine {
   int* seq_len = nullptr;
   float* seq_y = nullptr;
   int64_t seq_cap = 0;
+  // windowed sequential learner: per example the padded (id, x) entries and the last earlier example sharing a feature
+  void* seq_packed = nullptr;     // uint2 [seq_wcap][32]
+  int32_t* seq_conf = nullptr;    // [seq_wcap]
+  uint32_t* seq_keys = nullptr;   // [4][seq_wcap * 32] sort buffers (keys in/out, values in/out)
+  void* seq_sort_tmp = nullptr;
+  size_t seq_sort_tmp_bytes = 0;
+  int64_t seq_wcap = 0;
   // workspaces (mini-batch)
   int64_t ws_rows = 0;
   int64_t tile_rows = 0;      // rows per tile (<= cfg.batch_rows)
