@@ -499,7 +499,15 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
 // (feature, example) pairs; TDAP examples holding a feature id < FAST_NZ run alone (its w prox reads z_w by POSITION, A-6).
 // Bitwise the same results as the one-wave kernel above (tests/test_gpu_seq_window.py).
 constexpr int WIN_TERMS = FAST_NZ + 64;
-template <int KIND> struct SeqWin { static constexpr int NW = (KIND == UPD_TDAP) ? 4 : 8; };  // registers: FAST_NZ x (1 + state) doubles per lane
+// Lane mapping of a wave: KL lanes per factor block (16 / 32 / 64 for k <= 16 / 32 / 64) and Q = 64 / KL blocks, block q
+// holding the nonzeros u = q, q + Q, q + 2Q ...: with k = 16 all 64 lanes gather and update (8 coordinates each instead
+// of 32 on 16 lanes), and a lane keeps FAST_NZ / Q x (1 + state) doubles in registers, which is what sets the number of
+// waves (= examples per group) a workgroup can hold.
+template <int KIND, int KL> struct SeqWin {
+  static constexpr int Q = 64 / KL;
+  static constexpr int SL = FAST_NZ / Q;  // nonzero slots per lane
+  static constexpr int NW = (KIND == UPD_TDAP && KL >= 32) ? 4 : 8;  // 256 (512) VGPRs per lane at 8 (4) waves per workgroup
+};
 
 struct WinArgs {
   const uint2* packed;  // [count][FAST_NZ] (column, x bits), idle slots (0, +0.0f)
@@ -529,9 +537,11 @@ __global__ void seq_conf_k(const uint32_t* __restrict__ keys, const uint32_t* __
   if (keys[i] != 0xFFFFFFFFu && keys[i] == keys[i - 1]) atomicMax(conf + vals[i], (int)vals[i - 1]);  // stable sort: vals ascend inside a key
 }
 
-template <int KIND>
-__global__ __launch_bounds__(SeqWin<KIND>::NW * 64) void fm_seq_window_k(SeqArgs a, WinArgs wa, Hyper h) {
-  constexpr int NW = SeqWin<KIND>::NW;
+template <int KIND, int KL>
+__global__ __launch_bounds__((SeqWin<KIND, KL>::NW * 64)) void fm_seq_window_k(SeqArgs a, WinArgs wa, Hyper h) {
+  constexpr int NW = SeqWin<KIND, KL>::NW;
+  constexpr int Q = SeqWin<KIND, KL>::Q;
+  constexpr int SL = SeqWin<KIND, KL>::SL;
   constexpr int NS = SeqState<KIND>::N;
   __shared__ double terms[NW][WIN_TERMS];
   __shared__ double s_mult[NW], s_uw[NW], s_uv[NW];
@@ -582,35 +592,42 @@ __global__ __launch_bounds__(SeqWin<KIND>::NW * 64) void fm_seq_window_k(SeqArgs
     const Meta nxt = fetch(gn);
 
     // ---------------------------------------------------------------- A: gathers and the terms of y_hat
-    const bool fv = lane < k;
-    const int fl = fv ? lane : 0;
+    const int fq = lane / KL, ff = lane % KL;  // this lane's nonzero block and factor (V side)
+    const bool fv = ff < k;
+    const int fl = fv ? ff : 0;
     const int len = cur.len;
-    const bool tv = lane < len;
+    const bool tv = lane < len;                // this lane's nonzero (w side)
     const uint32_t mycol = tv ? cur.en.x : 0u;
     const double myx = tv ? (double)__uint_as_float(cur.en.y) : 0.0;
     double myw = 0.0, s1 = 0.0, q1 = 0.0;
     double stw[NS > 0 ? NS : 1];
-    double vv[FAST_NZ];
-    double stv[NS > 0 ? NS : 1][FAST_NZ];
+    uint32_t cu[Q > 1 ? SL : 1];  // with one block the slot's column and x come straight from the owning lane (readlane)
+    double xu[Q > 1 ? SL : 1], vv[SL];
+    double stv[NS > 0 ? NS : 1][SL];
     if (mine) {
       myw = a.w[mycol];
 #pragma unroll
       for (int j = 0; j < NS; ++j) stw[j] = seq_state_ptr<KIND>(a, true, j)[mycol];
 #pragma unroll
-      for (int u = 0; u < FAST_NZ; ++u) {
-        const size_t at = (size_t)bcast(mycol, u) * kp + fl;
-        vv[u] = a.V[at];
+      for (int j = 0; j < SL; ++j) {  // slot j of this lane is nonzero u = j * Q + fq (idle slots: column 0, x = 0)
+        uint32_t cj;
+        if constexpr (Q == 1) cj = bcast(mycol, j);
+        else { cj = cu[j] = (uint32_t)__shfl((int)mycol, j * Q + fq); xu[j] = __shfl(myx, j * Q + fq); }
+        const size_t at = (size_t)cj * kp + fl;
+        vv[j] = a.V[at];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) stv[j][u] = seq_state_ptr<KIND>(a, false, j)[at];
+        for (int n = 0; n < NS; ++n) stv[n][j] = seq_state_ptr<KIND>(a, false, n)[at];
       }
 #pragma unroll
-      for (int u = 0; u < FAST_NZ; ++u) {  // core/Model.h:83-97, row order
-        const double tmp = vv[u] * bcast(myx, u);
+      for (int u = 0; u < FAST_NZ; ++u) {  // core/Model.h:83-97: every factor's sums run over the nonzeros in row order
+        double tmp;
+        if constexpr (Q == 1) tmp = vv[u] * bcast(myx, u);
+        else tmp = __shfl(vv[u / Q] * xu[u / Q], (u % Q) * KL + ff);  // from the block that holds nonzero u
         s1 += tmp;
         q1 += tmp * tmp;
       }
       if (lane < FAST_NZ) terms[wave][lane] = (k1 ? myw : 0.0) * myx;     // w_j x_j, the linear term's addends in row order
-      if (lane < k8) terms[wave][FAST_NZ + lane] = fv ? 0.5 * (s1 * s1 - q1) : 0.0;  // core/Model.h:100, factor order
+      if (lane < k8) terms[wave][FAST_NZ + lane] = fv ? 0.5 * (s1 * s1 - q1) : 0.0;  // core/Model.h:100, factor order (lanes of block 0)
       if (lane == 0) s_y[wave] = cur.y;
     }
     __syncthreads();
@@ -671,20 +688,23 @@ __global__ __launch_bounds__(SeqWin<KIND>::NW * 64) void fm_seq_window_k(SeqArgs
         for (int j = 0; j < NS; ++j) if (k1) seq_state_ptr<KIND>(a, true, j)[mycol] = stw[j];
       }
 #pragma unroll
-      for (int u = 0; u < FAST_NZ; ++u) {
-        const double xu = bcast(myx, u);
-        const size_t at = (size_t)bcast(mycol, u) * kp + lane;
-        if (u < len && fv) {
-          double th = vv[u];
+      for (int j = 0; j < SL; ++j) {
+        uint32_t cj;
+        double xj;
+        if constexpr (Q == 1) { cj = bcast(mycol, j); xj = bcast(myx, j); }
+        else { cj = cu[j]; xj = xu[j]; }
+        const size_t at = (size_t)cj * kp + ff;
+        if (j * Q + fq < len && fv) {
+          double th = vv[j];
           double st[NS > 0 ? NS : 1];
 #pragma unroll
-          for (int j = 0; j < NS; ++j) st[j] = stv[j][u];
-          const double grad = s1 * xu - th * xu * xu;
+          for (int n = 0; n < NS; ++n) st[n] = stv[n][j];
+          const double grad = s1 * xj - th * xj * xj;
           const double z = coord_seq<KIND>(h, false, true, th, grad, mult, euv, st);
           a.V[at] = th;
           if constexpr (KIND == UPD_TDAP) a.sV[at] = z;
 #pragma unroll
-          for (int j = 0; j < NS; ++j) seq_state_ptr<KIND>(a, false, j)[at] = st[j];
+          for (int n = 0; n < NS; ++n) seq_state_ptr<KIND>(a, false, n)[at] = st[n];
         }
       }
       if constexpr (KIND == UPD_TDAP) {  // w prox reads z_w by POSITION (TDAP_Learner.h:207); such readers/writers never share a group
@@ -759,7 +779,9 @@ static int ensure_window_workspace(fmx_engine* e, int64_t cap) {
 
 template <int KIND>
 static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa) {
-  hipLaunchKernelGGL(fm_seq_window_k<KIND>, dim3(1), dim3(SeqWin<KIND>::NW * 64), 0, e->stream, a, wa, e->hyper);
+  if (e->k <= 16) hipLaunchKernelGGL((fm_seq_window_k<KIND, 16>), dim3(1), dim3(SeqWin<KIND, 16>::NW * 64), 0, e->stream, a, wa, e->hyper);
+  else if (e->k <= 32) hipLaunchKernelGGL((fm_seq_window_k<KIND, 32>), dim3(1), dim3(SeqWin<KIND, 32>::NW * 64), 0, e->stream, a, wa, e->hyper);
+  else hipLaunchKernelGGL((fm_seq_window_k<KIND, 64>), dim3(1), dim3(SeqWin<KIND, 64>::NW * 64), 0, e->stream, a, wa, e->hyper);
 }
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count) {

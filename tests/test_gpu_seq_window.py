@@ -18,6 +18,11 @@ SOLVERS = {
     "tdap": dict(solver="tdap", k=6, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=1e-3, alpha_v=0.05),
     "sgd_k64_nolinear": dict(solver="sgd", k=64, k0=False, k1=False, l2_regv=1e-3, learn_rate=0.02),
     "ftrl_reg": dict(solver="ftrl", task=oracle.REGRESSION, k=16, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-4, l2_regv=1e-4),
+    # 17 <= k <= 32: two nonzero blocks of 32 lanes
+    "sgd_l1_k32": dict(solver="sgd", k=32, l1_regw=1e-3, l1_regv=5e-4, learn_rate=0.03),
+    "ftrl_k24": dict(solver="ftrl", k=24, l1_regw=1e-3, l1_regv=1e-3, l2_regw=1e-2, l2_regv=1e-2),
+    "tdap_k20": dict(solver="tdap", k=20, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=1e-3, alpha_v=0.05),
+    "tdap_k40": dict(solver="tdap", k=40, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=1e-3, alpha_v=0.05),
 }
 
 
