@@ -930,7 +930,6 @@ int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_
   FMX_CHECK(track != nullptr && track->struct_size == sizeof(fmx_track_config), FMX_ERR_INVALID, "bad fmx_track_config");
   FMX_CHECK(track->step_size > 0, FMX_ERR_INVALID, "step_size must be > 0 (use fmx_train when the tracker is off)");
   FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
-  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS, FMX_ERR_STATE, "ALS engines train through fmx_als_vsweep");
   FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
   FMX_TRY(use_device(e->cfg.device));
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
@@ -960,7 +959,22 @@ int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_
     return track_record(e, iter, score, keep);
   };
 
-  if (seq_mode(e)) {
+  if (e->cfg.solver == FMX_SOLVER_ALS) {
+    // MCMC_ALS_Learner::learn, :96-125: the tracker looks at the model at the START of iterations 0, step, 2 step, ... and of the
+    // last one (clamped predictions, or fast_pnorm for CLASSIFICATION); no convergence rule
+    if (!seq_mode(e)) { set_error("ALS runs on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL"); st = FMX_ERR_STATE; }
+    int64_t ii = -1;
+    for (int64_t it = 0; st == FMX_OK && it < max_iter; ++it) {
+      if (++ii == step) ii = 0;
+      if (ii == 0 || it == max_iter - 1) {
+        double score = 0.0;
+        st = track_eval(e, m, track->metric, d_yhat, &score);
+        if (st == FMX_OK) st = track_record(e, it, score, keep);
+      }
+      if (st == FMX_OK) st = launch_als_train(e, m, 1, 0);
+      done = it + 1;
+    }
+  } else if (seq_mode(e)) {
     std::vector<int64_t> order;
     visit_order(m->n, e->cfg.random_step, max_iter, &order);
     const int64_t count = (int64_t)order.size();

@@ -326,3 +326,17 @@ def als_learn(P, X, y, w0, w, v, max_iter, with_v=False):
     lib().fmo_als_learn(C.byref(P), C.c_uint32(X.p), C.byref(w0c), _ptr(w), _ptr(v), C.byref(X.c), _ptr(col_ptr), _ptr(row_idx), _ptr(val_t),
                         _ptr(y), C.c_int(max_iter), C.c_int(int(with_v)))
     return w0c.value, w, v
+
+
+def als_learn_traced(P, X, y, w0, w, v, max_iter, with_v=False):
+    """als_learn with the tracker on (P.trace_step > 0, P.eval_type): returns (w0, w, v, iters, evals)."""
+    col_ptr, row_idx, val_t = X.transpose()
+    row_idx = np.ascontiguousarray(row_idx); val_t = np.ascontiguousarray(val_t)
+    y = np.ascontiguousarray(y, np.float32)
+    w = _f64(w).copy(); v = _f64(v).copy()
+    w0c = C.c_double(w0)
+    cap = max_iter + 2
+    iters = np.zeros(cap, np.int64); vals = np.zeros(cap); n = C.c_int64()
+    lib().fmo_als_learn_traced(C.byref(P), C.c_uint32(X.p), C.byref(w0c), _ptr(w), _ptr(v), C.byref(X.c), _ptr(col_ptr), _ptr(row_idx), _ptr(val_t),
+                               _ptr(y), C.c_int(max_iter), C.c_int(int(with_v)), _ptr(iters), _ptr(vals), C.c_int64(cap), C.byref(n))
+    return w0c.value, w, v, iters[: n.value], vals[: n.value]

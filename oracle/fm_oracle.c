@@ -827,20 +827,54 @@ static void fmo_als_update_w(uint32_t p, double* w, const int64_t* col_ptr, cons
  * predict_batch, e = y_hat - y (:520-527), update_w0, update_w.  As shipped, update_all never calls update_v (SURVEY A-1);
  * with_v != 0 adds the V sweep (:272-354) after the w sweep, on the carried residual -- the engine's extension.
  * init() resets the solver parameters (A-7): alpha = 1, w0_mean_0 = 0, lambdas = 0, mus = 0. */
-void fmo_als_learn(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, const fmo_csr* X,
-                   const int64_t* col_ptr, const uint32_t* row_idx, const float* val_t, const float* y, int max_iter, int with_v) {
+void fmo_als_learn_traced(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, const fmo_csr* X,
+                          const int64_t* col_ptr, const uint32_t* row_idx, const float* val_t, const float* y, int max_iter, int with_v,
+                          int64_t* trace_iters, double* trace_vals, int64_t trace_cap, int64_t* trace_n) {
   double* error = (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1));
   double* v_q = (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1));
+  double* y_hat_ = (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1));
   double* zeros = (double*)calloc((size_t)(P->k ? P->k : 1), sizeof(double));
+  /* Tracker::init, core/Tracker.h:41-52 */
+  int64_t step = P->trace_step;
+  if (step > 0) {
+    const int64_t MAX_REC = 10000;
+    int64_t record_times = (int64_t)ceil(((double)max_iter - 0.5) / (double)step) + 1;
+    if (record_times > MAX_REC) step = (int64_t)((double)(max_iter + 1) / (double)MAX_REC) + 1;
+  }
+  int64_t ii = -1, tn = 0;
   for (int it = 0; it < max_iter; ++it) {
     fmo_predict_batch(P, p, *w0, w, v, X, error);
+    if (step > 0) { /* :101-125: the model at the start of the iteration */
+      ii++;
+      if (ii == step) ii = 0;
+      if (ii == 0 || it == max_iter - 1) {
+        for (int64_t i = 0; i < X->n; ++i) {
+          if (P->task == FMO_REGRESSION) {
+            double t = error[i];
+            y_hat_[i] = t < P->min_target ? P->min_target : (t > P->max_target ? P->max_target : t);
+          } else {
+            y_hat_[i] = fmo_fast_pnorm(error[i]);
+          }
+        }
+        if (tn < trace_cap) { trace_iters[tn] = it; trace_vals[tn] = fmo_evaluate(P->task, P->eval_type, y_hat_, y, X->n); }
+        tn++;
+      }
+    }
     if (P->task == FMO_REGRESSION) fmo_als_error_regression(error, y, X->n);
     else fmo_als_error_classification(error, y, X->n);
     if (P->k0) fmo_als_update_w0(P, w0, error, X->n, 1.0, 0.0);
     if (P->k1) fmo_als_update_w(p, w, col_ptr, row_idx, val_t, error, 1.0, 0.0, 0.0);
     if (with_v && P->k > 0) fmo_als_update_v(P->k, p, v, X->n, col_ptr, row_idx, val_t, error, v_q, 1.0, zeros, zeros, NULL);
   }
-  free(error); free(v_q); free(zeros);
+  if (trace_n) *trace_n = tn;
+  free(error); free(v_q); free(y_hat_); free(zeros);
+}
+
+void fmo_als_learn(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, const fmo_csr* X,
+                   const int64_t* col_ptr, const uint32_t* row_idx, const float* val_t, const float* y, int max_iter, int with_v) {
+  fmo_params Q = *P;
+  Q.trace_step = -1;
+  fmo_als_learn_traced(&Q, p, w0, w, v, X, col_ptr, row_idx, val_t, y, max_iter, with_v, NULL, NULL, 0, NULL);
 }
 
 /* ================================================================== engine semantics (not in reference)

@@ -123,3 +123,32 @@ def test_tracked_minibatch(fm):
         if done - 1 in (499, 1499, 2499, 3499, 4199):
             got.append(e2.evaluate(m, L.EVAL_LL))
     np.testing.assert_array_equal(r["evals"], got)
+
+
+@pytest.mark.parametrize("task,metric", [("regression", "RMSE"), ("classification", "LL"), ("classification", "AUC")])
+def test_als_tracker_matches_oracle(task, metric):
+    """MCMC_ALS_Learner::learn with the tracker on (:96-125): the model at the START of iterations 0, step, 2 step ... and of the
+    last one is scored -- clamped predictions for REGRESSION, the probit table for CLASSIFICATION; no convergence rule."""
+    from fmwr_amd import engine, _lib as L
+    n, p, k = 900, 70, 3
+    rp, col, val = util.random_csr(n, p, 6, seed=33)
+    y = util.labels(n, 33, task)
+    w0, w, v = util.params(p, k, 33, stdev=0.2, fp32=False)
+    ot = oracle.REGRESSION if task == "regression" else oracle.CLASSIFICATION
+    P = oracle.params(task=ot, k=k, l2_reg0=0.01, min_target=float(y.min()), max_target=float(y.max()),
+                      eval_type=getattr(oracle, metric), trace_step=3)
+    X = oracle.Matrix(rp, col, val, p)
+    r0, rw, rv, it, ev = oracle.als_learn_traced(P, X, y, w0, w, v.ravel(), 11)
+    assert list(it) == [0, 3, 6, 9, 10]
+    e = engine.Engine(p, task=L.TASK_REGRESSION if task == "regression" else L.TASK_CLASSIFICATION, solver=L.SOLVER_ALS, num_factor=k,
+                      l2_w0=0.01, mode=L.MODE_SEQUENTIAL, min_target=float(y.min()), max_target=float(y.max()))
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    r = e.train_tracked(m, 11, 3, getattr(L, "EVAL_" + metric), keep_params=True)
+    assert list(r["iters"]) == [0, 3, 6, 9, 10] and not r["convergent"] and r["done"] == 11
+    np.testing.assert_allclose(r["evals"], ev, rtol=1e-9, atol=1e-12)
+    g0, gw, gv = e.get_params()
+    assert abs(g0 - r0) < 1e-10 and util.rel_err(gw, rw) < 1e-10
+    # snapshot 0 is the untouched start model
+    s0 = r["params"][0]
+    assert s0[0] == w0 and np.array_equal(s0[1], w)
