@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("FMX_LIB_PATH") or os.path.join(_PKG, "libfmx.so")  # 
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOGPU, ERR_STATE = 0, 1, 2, 3, 4
 TASK_CLASSIFICATION, TASK_REGRESSION = 10, 20
-SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL, SOLVER_TDAP = 200, 300, 500, 600
+SOLVER_MCMC, SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL, SOLVER_TDAP = 100, 200, 300, 500, 600
 MODE_SEQUENTIAL, MODE_MINIBATCH = 0, 1
 LINK_NONE, LINK_LOGISTIC, LINK_CLAMP, LINK_PROBIT = 0, 1, 2, 3
 REDUCE_MEAN, REDUCE_SUM = 0, 1
@@ -24,7 +24,7 @@ SYMBOLS = [
     "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
     "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
     "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_grad_elem_bytes", "fmx_grad_layout", "fmx_grad_begin", "fmx_grad_chunk", "fmx_apply_chunk", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
-    "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
+    "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_mcmc_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset",
 ]
 

@@ -5,8 +5,8 @@ R/fm_solver_control.R, R/fm_track_control.R, R/fm_matrix.R -> src/FM.cpp).  R is
 same surface is mirrored here with the same names (dots -> underscores), argument meaning, defaults and error
 messages, on top of the C ABI (include/fmx.h).  The Rcpp glue a maintainer would add is in INTEGRATION.md.
 
-Outside the path: the MCMC solver (its Gibbs draws come from R's RNG); asking for it raises
-NotImplementedError.  ALS runs for REGRESSION and CLASSIFICATION (probit tables regenerated, csrc/fm_probit.h).  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
+ALS runs for REGRESSION and CLASSIFICATION (probit tables regenerated, csrc/fm_probit.h); the MCMC solver runs with its
+Gibbs draws taken from the numpy generator of fm_train(seed=...) instead of R's (same call order, include/fmx.h).  The tracker (track.control(step_size > 0), fm.track, fm.select: row f-1) runs on the device.
 """
 import warnings
 
@@ -16,7 +16,7 @@ from . import _lib as L
 from .engine import Engine, Matrix
 
 _TASKS = {"CLASSIFICATION": L.TASK_CLASSIFICATION, "REGRESSION": L.TASK_REGRESSION}
-_SOLVERS = {"SGD": L.SOLVER_SGD, "FTRL": L.SOLVER_FTRL, "ALS": L.SOLVER_ALS, "TDAP": L.SOLVER_TDAP}
+_SOLVERS = {"SGD": L.SOLVER_SGD, "FTRL": L.SOLVER_FTRL, "ALS": L.SOLVER_ALS, "TDAP": L.SOLVER_TDAP, "MCMC": L.SOLVER_MCMC}
 
 # R/fm_control.R:52-66
 MODEL_CONTROL_DEFAULT = {
@@ -85,7 +85,10 @@ def TDAP_solver(**kw):
 
 
 def MCMC_solver(**kw):
-    raise NotImplementedError("MCMC.solver is outside the accelerated path (it samples from R's RNG)")
+    """MCMC.solver() -- R/fm_solver_control.R:36-62 (its parameters are ignored by the reference too: SURVEY A-7).
+    The chain's Gamma / normal variates, which the reference takes from R's generator, are drawn here from the numpy
+    generator seeded by fm_train(seed=...), in the reference's call order (include/fmx.h: fmx_mcmc_train)."""
+    return {"solver": "MCMC", **_control_assign(ALS_SOLVER_DEFAULT, kw)}
 
 
 def solver_control(max_iter=10000, solver=None):
@@ -196,14 +199,29 @@ def _normalize_columns(normalize, p):
     return np.sort(cols).astype(np.int32)
 
 
-def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, norm_cols=None):
+def _mcmc_draws(rng, n, p, iters, k0, k1):
+    """Standard variates of one MCMC run in the reference's call order: per iteration the Gamma of update_alpha, the
+    normal of update_w0, the Gamma of update_w_lambda, the normals of update_w_mu and update_w (fmx.h: fmx_mcmc_train)."""
+    g = np.ones((iters, 2)); z = np.zeros((iters, 2 + p))
+    for it in range(iters):
+        g[it, 0] = rng.gamma((1.0 + n) / 2.0)
+        if k0:
+            z[it, 0] = rng.normal()
+        if k1:
+            g[it, 1] = rng.gamma((2.0 + p) / 2.0)
+            z[it, 1] = rng.normal()
+            z[it, 2:] = rng.normal(size=p)
+    return g, z
+
+
+def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, norm_cols=None, rng=None):
     p = data.dim[1]
     y = _check_labels(data, controls["model"]["task"])
     lo, hi = float(y.min()), float(y.max())  # src/FM.cpp:89-90
     if target_range is not None:               # src/FM.cpp:91-96 (fm.update widens the range)
         lo, hi = min(lo, target_range[0]), max(hi, target_range[1])
-    if controls["solver"]["solver"]["solver"] == "ALS":
-        mode = "sequential"  # ALS works on the fp64 tables
+    if controls["solver"]["solver"]["solver"] in ("ALS", "MCMC"):
+        mode = "sequential"  # ALS / MCMC work on the fp64 tables
     eng = _engine_for(controls, p, (lo, hi), mode, batch_rows, device)
     eng.set_params(w0, w, v)
     m = _device_matrix(data, y, device)
@@ -213,7 +231,12 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, nor
     sol = controls["solver"]["solver"]["solver"]
     track = controls["track"]
     trace, convergent = None, False
-    if track["step_size"] > 0:  # learner->tracker.step_size > 0: Learner::learn evaluates, snapshots and may stop early
+    if sol == "MCMC":  # MCMC_Learner: the tracker block of its loop is not wired (track.control is ignored for this solver)
+        hp = controls["model"]["hyper.params"]
+        iters = int(controls["solver"]["max_iter"])
+        g, z = _mcmc_draws(rng if rng is not None else np.random.default_rng(), data.dim[0], p, iters, bool(hp["keep.w0"]), bool(hp["keep.w1"]))
+        eng.mcmc_train(m, iters, g, z)
+    elif track["step_size"] > 0:  # learner->tracker.step_size > 0: Learner::learn evaluates, snapshots and may stop early
         metric = getattr(L, "EVAL_" + track["evaluate.metric"])
         r = eng.train_tracked(m, controls["solver"]["max_iter"], track["step_size"], metric, track["convergence"], keep_params=True)
         convergent = r["convergent"]
@@ -246,7 +269,7 @@ def fm_train(data, normalize=True, control=None, seed=None, mode="sequential", b
     k, p = int(hp["factor.number"]), data.dim[1]
     rng = np.random.default_rng(seed)
     v0 = rng.normal(hp["v.init_mean"], hp["v.init_stdev"], (k, p)) if k > 0 else np.zeros((0, p))
-    return _train(data, controls, 0.0, np.zeros(p), v0, None, mode, batch_rows, device, norm_cols)
+    return _train(data, controls, 0.0, np.zeros(p), v0, None, mode, batch_rows, device, norm_cols, rng=rng)
 
 
 def fm_update(object, data, normalize=True, max_iter=None, mode=None, batch_rows=None, device=None):

@@ -12,6 +12,8 @@
 // fp64 throughout, like the reference; x*x is a float product there (:314,:345) and here.
 // q and e live interleaved as one {q[r], e[r]} pair per row, so a stored nonzero costs one 16-byte gather (one line)
 // per pass instead of two.
+#include <cmath>
+
 #include "fmx_internal.h"
 #include "fm_probit.h"
 
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_w0_partial_k(const double2* __
 
 // one workgroup: finish the sum, set the new w0, leave (old - new) in partials[n_partials]
 __global__ __launch_bounds__(WG_THREADS) void als_w0_final_k(double* __restrict__ partials, int64_t n_partials, int64_t n, double* __restrict__ scal,
-                                                            double reg0, double alpha, double w0_mean_0) {
+                                                            double reg0, double alpha, double w0_mean_0, int sample, double znorm) {
   __shared__ double red[WG_THREADS];
   double acc = 0.0;
   for (int64_t i = threadIdx.x; i < n_partials; i += WG_THREADS) acc += partials[i];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_w0_final_k(double* __restrict_
   const double w0_var = 1.0 / (reg0 + alpha * (double)n);               // :169
   const double w0_mean = -(alpha * err - w0_mean_0 * reg0) * w0_var;    // :170
   const double w0_old = scal[SC_W0];
-  double w0_new = w0_mean;
+  double w0_new = sample ? w0_mean + sqrt(w0_var) * znorm : w0_mean;   // MCMC: Rf_rnorm(w0_mean, sqrt(w0_var)), :174-175
   if (isnan(w0_new) || isinf(w0_new)) w0_new = w0_old;                  // CHECK_PARAM, :180
   scal[SC_W0] = w0_new;
   partials[n_partials] = w0_old - w0_new;
@@ -201,7 +203,8 @@ __global__ void als_shift_k(double2* __restrict__ qe, int64_t n, const double* _
 // one wave per feature of the level: w sweep, :208-256 with one thread's residual
 __global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
                                                             const uint32_t* __restrict__ crow, const float* __restrict__ cval,
-                                                            double* __restrict__ w, double2* __restrict__ qe, double alpha, double lambda, double mu) {
+                                                            double* __restrict__ w, double2* __restrict__ qe, double alpha, double lambda, double mu,
+                                                            const double* __restrict__ znorm) {
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6);
   if (wid >= n_feats) return;
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __re
   }
   w_var = 1.0 / (lambda + alpha * w_var);
   w_mean = -w_var * (alpha * w_mean - mu * lambda);
-  const double w_new = bad_number(w_var) ? 0.0 : w_mean;
+  // MCMC: Rf_rnorm(w_mean, w_var), :239 -- the variance sits where a standard deviation belongs; kept
+  const double w_new = bad_number(w_var) ? 0.0 : (znorm ? w_mean + w_var * znorm[i] : w_mean);
   if (bad_number(w_new)) return;  // CHECK_PARAM: keep the old value, skip the corrections
   if (lane == 0) w[i] = w_new;
   const double w_diff = w_old - w_new;
@@ -328,7 +332,7 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, dp_y);
     if (e->hyper.k0) {
       hipLaunchKernelGGL(als_w0_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, e->scal, d_part);
-      hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, 1.0, 0.0);
+      hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, 1.0, 0.0, 0, 0.0);
       hipLaunchKernelGGL(als_shift_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, n, d_part + np);
     }
     if (e->hyper.k1) {
@@ -337,7 +341,7 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
         if (cnt == 0) continue;
         const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
         hipLaunchKernelGGL(als_w_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
-                           m->col_ptr, m->crow, m->cval, e->dw, d_qe, 1.0, 0.0, 0.0);
+                           m->col_ptr, m->crow, m->cval, e->dw, d_qe, 1.0, 0.0, 0.0, (const double*)nullptr);
       }
     }
     if (with_v && e->k > 0) v_sweep_enqueue(e, m, d_qe, 1.0, nullptr, nullptr);
@@ -347,6 +351,182 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
   (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part);
   FMX_TRY(st);
   FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "ALS training failed: %s", hipGetErrorString(err));
+  return FMX_OK;
+}
+
+// ---- the MCMC learner (MCMC_Learner: do_sample, do_multilevel; :565-576) ------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void mcmc_sumsq_partial_k(const double2* __restrict__ qe, int64_t n, double* __restrict__ partials) {
+  __shared__ double red[WG_THREADS];
+  const int64_t base = (int64_t)blockIdx.x * ALS_SLAB;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < ALS_SLAB; i += WG_THREADS) {
+    const int64_t r = base + i;
+    if (r < n) acc += qe[r].y * qe[r].y;  // update_alpha, :370-373
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = WG_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// per slab of w: sum w and sum (w - mu)^2 (update_w_lambda :423-427, update_w_mu :392-395)
+__global__ __launch_bounds__(WG_THREADS) void mcmc_wstats_partial_k(const double* __restrict__ w, int64_t p, double mu, double* __restrict__ partials) {
+  __shared__ double r1[WG_THREADS], r2[WG_THREADS];
+  const int64_t base = (int64_t)blockIdx.x * ALS_SLAB;
+  double a1 = 0.0, a2 = 0.0;
+  for (int i = threadIdx.x; i < ALS_SLAB; i += WG_THREADS) {
+    const int64_t j = base + i;
+    if (j < p) { a1 += w[j]; a2 += (w[j] - mu) * (w[j] - mu); }
+  }
+  r1[threadIdx.x] = a1; r2[threadIdx.x] = a2;
+  __syncthreads();
+  for (int off = WG_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { r1[threadIdx.x] += r1[threadIdx.x + off]; r2[threadIdx.x] += r2[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = r1[0]; partials[2 * blockIdx.x + 1] = r2[0]; }
+}
+
+// util/Random.h:20-93 on libc rand(), host side: the reference draws its truncated normals from rand(), row by row
+static double h_runif() { return rand() / ((double)RAND_MAX + 1); }
+static double h_rexp() { return -std::log(1 - h_runif()); }
+static double h_rnorm() {  // Leva's ratio-of-uniforms, Random.h:31-49
+  double u, v, abs_v, x, y, Q;
+  do {
+    do { u = h_runif(); } while (u == 0.0);
+    v = 1.7156 * (h_runif() - 0.5);
+    abs_v = v < 0 ? -v : v;
+    x = u - 0.449871;
+    y = abs_v + 0.386595;
+    Q = x * x + y * (0.19600 * y - 0.25472 * x);
+    if (Q < 0.27597) break;
+  } while ((Q > 0.27846) || ((v * v) > (-4.0 * u * u * std::log(u))));
+  return v / u;
+}
+static double h_trnorm_left(double left) {  // Random.h:52-76
+  if (left < 0.0) {
+    for (;;) { const double r = h_rnorm(); if (r >= left) return r; }
+  }
+  const double alpha_star = 0.5 * (left + std::sqrt(left * left + 4.0));
+  for (;;) {
+    const double z = h_rexp() / alpha_star + left;
+    double d = z - alpha_star;
+    d = std::exp(-(d * d) / 2);
+    const double u = h_runif();
+    if (u < d) return z;
+  }
+}
+
+// MCMC_ALS_Learner::learn + update_all for the MCMC learner, one attribute group (core/Data.h:10-26).  R's generator is
+// not available to a library: the draws the reference takes from it come pre-drawn from the caller, in call order (see
+// fmx.h).  The CLASSIFICATION residual subtracts truncated normals drawn from libc rand() row by row (:529-542), which is a
+// serial stream by construction: y_hat goes to the host, the draws are made there, the residual comes back.  V is never
+// updated, as shipped (SURVEY A-1).
+int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state) {
+  FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
+  FMX_TRY(build_full_csc(m, e->stream));
+  FMX_TRY(build_plan(m, e->stream));
+  const int64_t n = m->n;
+  const int64_t p = (int64_t)e->p;
+  const unsigned row_grid = (unsigned)((n + 255) / 256);
+  const int64_t np = (n + ALS_SLAB - 1) / ALS_SLAB, npw = (p + ALS_SLAB - 1) / ALS_SLAB;
+  const int64_t part_cap = (np > 2 * npw ? np : 2 * npw) + 1;
+  double *d_yhat = nullptr, *d_part = nullptr, *d_z = nullptr;
+  double2* d_qe = nullptr;
+  auto cleanup = [&]() { (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part); (void)hipFree(d_z); };
+  if (hipMalloc(&d_yhat, (size_t)n * sizeof(double)) != hipSuccess || hipMalloc(&d_qe, (size_t)n * sizeof(double2)) != hipSuccess ||
+      hipMalloc(&d_part, (size_t)part_cap * sizeof(double)) != hipSuccess || hipMalloc(&d_z, (size_t)p * sizeof(double)) != hipSuccess) {
+    cleanup(); set_error("out of device memory"); return FMX_ERR_HIP;
+  }
+  std::vector<double> h_part((size_t)part_cap), h_y;
+  std::vector<float> h_lab;
+  const bool cls = e->cfg.task == FMX_TASK_CLASSIFICATION;
+  if (cls) {
+    h_y.resize((size_t)n); h_lab.resize((size_t)n);
+    if (hipMemcpy(h_lab.data(), m->y, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); set_error("label download failed"); return FMX_ERR_HIP; }
+  }
+  const double alpha_0 = 1.0, gamma_0 = 1.0, beta_0 = 1.0, mu_0 = 0.0, w0_mean_0 = 0.0;  // init(), :59-90 (SURVEY A-7)
+  double alpha = 1.0, w_lambda = 0.0, w_mu = 0.0;
+  const std::vector<int64_t>& level_ptr = m->als_level_ptr;
+  const int L = (int)level_ptr.size() - 1;
+  auto bad = [](double x) { return std::isnan(x) || std::isinf(x); };
+  int st = FMX_OK;
+#define MC_HIP(call) do { if (st == FMX_OK) { hipError_t _e = (call); if (_e != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(_e)); st = FMX_ERR_HIP; } } } while (0)
+  for (int it = 0; it < max_iter && st == FMX_OK; ++it) {
+    const double* G = h_gammas + (size_t)it * 2;
+    const double* Z = h_normals + (size_t)it * (2 + (size_t)p);
+    RowsArgs a{};
+    a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = n;
+    a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
+    st = launch_rows_forward(e, a, false, true);
+    if (st != FMX_OK) break;
+    if (!cls) {
+      hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, (const double*)nullptr);
+    } else {  // calculate_error with do_sample, one thread, rows in order
+      MC_HIP(hipMemcpyAsync(h_y.data(), d_yhat, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      MC_HIP(hipStreamSynchronize(e->stream));
+      for (int64_t i = 0; i < n && st == FMX_OK; ++i) {
+        const double ev = h_y[(size_t)i];
+        h_y[(size_t)i] = (h_lab[(size_t)i] >= 0.0f) ? ev - h_trnorm_left(ev) : ev - (-h_trnorm_left(-ev));
+      }
+      MC_HIP(hipMemcpyAsync(d_yhat, h_y.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+      hipLaunchKernelGGL(als_pack_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, n, d_qe);
+    }
+    // update_alpha, :359-380
+    hipLaunchKernelGGL(mcmc_sumsq_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, d_part);
+    MC_HIP(hipMemcpyAsync(h_part.data(), d_part, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    MC_HIP(hipStreamSynchronize(e->stream));
+    if (st != FMX_OK) break;
+    {
+      double gamma_n = gamma_0;
+      for (int64_t i = 0; i < np; ++i) gamma_n += h_part[(size_t)i];
+      (void)alpha_0;
+      const double a_new = (2.0 / gamma_n) * G[0];  // Rf_rgamma((alpha_0 + n) / 2, 2 / gamma_n)
+      if (!bad(a_new)) alpha = a_new;
+    }
+    if (e->hyper.k0) {  // update_w0, :160-188
+      hipLaunchKernelGGL(als_w0_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, e->scal, d_part);
+      hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, alpha, w0_mean_0, 1, Z[0]);
+      hipLaunchKernelGGL(als_shift_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, n, d_part + np);
+    }
+    if (e->hyper.k1) {
+      hipLaunchKernelGGL(mcmc_wstats_partial_k, dim3((unsigned)npw), dim3(WG_THREADS), 0, e->stream, e->dw, p, w_mu, d_part);
+      MC_HIP(hipMemcpyAsync(h_part.data(), d_part, (size_t)npw * 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      MC_HIP(hipStreamSynchronize(e->stream));
+      if (st != FMX_OK) break;
+      double sum_w = 0.0, sum_sq = 0.0;
+      for (int64_t i = 0; i < npw; ++i) { sum_w += h_part[(size_t)(2 * i)]; sum_sq += h_part[(size_t)(2 * i + 1)]; }
+      {  // update_w_lambda, :415-445
+        const double s_ = sum_sq + beta_0 * (w_mu - mu_0) * (w_mu - mu_0) + gamma_0;
+        const double l_new = (2.0 / s_) * G[1];  // Rf_rgamma((alpha_0 + p + 1) / 2, 2 / s)
+        if (!bad(l_new)) w_lambda = l_new;
+      }
+      {  // update_w_mu, :383-412
+        const double mean = (sum_w + beta_0 * mu_0) / ((double)p + beta_0);
+        const double var = 1.0 / (((double)p + beta_0) * w_lambda);
+        const double mu_new = mean + std::sqrt(var) * Z[1];
+        if (!bad(mu_new)) w_mu = mu_new;
+      }
+      MC_HIP(hipMemcpyAsync(d_z, Z + 2, (size_t)p * sizeof(double), hipMemcpyHostToDevice, e->stream));
+      for (int l = 0; l < L; ++l) {  // update_w, :190-270
+        const int64_t cnt = level_ptr[(size_t)l + 1] - level_ptr[(size_t)l];
+        if (cnt == 0) continue;
+        const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
+        hipLaunchKernelGGL(als_w_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
+                           m->col_ptr, m->crow, m->cval, e->dw, d_qe, alpha, w_lambda, w_mu, (const double*)d_z);
+      }
+    }
+  }
+#undef MC_HIP
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  cleanup();
+  FMX_TRY(st);
+  FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "MCMC training failed: %s", hipGetErrorString(err));
+  if (h_state) { h_state[0] = alpha; h_state[1] = w_lambda; h_state[2] = w_mu; }
   return FMX_OK;
 }
 

@@ -493,7 +493,8 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->struct_size == sizeof(fmx_config), FMX_ERR_INVALID, "fmx_config size mismatch (%u vs %zu): header/library skew",
             cfg->struct_size, sizeof(fmx_config));
   FMX_CHECK(cfg->task == FMX_TASK_CLASSIFICATION || cfg->task == FMX_TASK_REGRESSION, FMX_ERR_INVALID, "unknown task...");
-  FMX_CHECK(cfg->solver == FMX_SOLVER_SGD || cfg->solver == FMX_SOLVER_FTRL || cfg->solver == FMX_SOLVER_ALS || cfg->solver == FMX_SOLVER_TDAP,
+  FMX_CHECK(cfg->solver == FMX_SOLVER_SGD || cfg->solver == FMX_SOLVER_FTRL || cfg->solver == FMX_SOLVER_ALS || cfg->solver == FMX_SOLVER_TDAP ||
+                cfg->solver == FMX_SOLVER_MCMC,
             FMX_ERR_INVALID, "Unknown solver...");  // src/FM.cpp:85
   FMX_CHECK(cfg->solver != FMX_SOLVER_TDAP || cfg->mode == FMX_MODE_SEQUENTIAL, FMX_ERR_INVALID, "the TDAP solver runs in FMX_MODE_SEQUENTIAL only");
   FMX_CHECK(cfg->num_factor >= 0 && cfg->num_factor <= 128, FMX_ERR_INVALID, "factor.number must be in 0..128 (got %d)", cfg->num_factor);
@@ -837,7 +838,7 @@ int fmx_predict_device(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t r
 int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t count) {
   FMX_TRY(check_pair(e, m));
   FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "an explicit visiting order needs FMX_MODE_SEQUENTIAL");
-  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS, FMX_ERR_STATE, "ALS engines train through fmx_als_vsweep");
+  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS && e->cfg.solver != FMX_SOLVER_MCMC, FMX_ERR_STATE, "ALS / MCMC engines train through fmx_als_train / fmx_mcmc_train");
   FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
   FMX_CHECK(count >= 0 && (count == 0 || order), FMX_ERR_INVALID, "order is NULL");
   for (int64_t i = 0; i < count; ++i) FMX_CHECK(order[i] >= 0 && order[i] < m->n, FMX_ERR_INVALID, "order[%lld]=%lld out of range", (long long)i, (long long)order[i]);
@@ -859,7 +860,7 @@ int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t 
 int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done) {
   FMX_TRY(check_pair(e, m));
   FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
-  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS, FMX_ERR_STATE, "ALS engines train through fmx_als_vsweep");
+  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS && e->cfg.solver != FMX_SOLVER_MCMC, FMX_ERR_STATE, "ALS / MCMC engines train through fmx_als_train / fmx_mcmc_train");
   FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
   if (examples_done) *examples_done = 0;
   if (max_iter == 0 || m->n == 0) return FMX_OK;
@@ -892,7 +893,7 @@ namespace fmx {
 // the evaluation block of solver/SGD_Learner.h:143-155: prediction with the task's link, then tracker.evaluate
 static int track_eval(fmx_engine* e, const fmx_matrix* m, int metric, double* d_yhat, double* score) {
   // Model::predict_prob, core/Model.h:163-180: MCMC / ALS models answer through the probit table, the others logistic
-  const int link = e->cfg.task == FMX_TASK_REGRESSION ? FMX_LINK_CLAMP : (e->cfg.solver == FMX_SOLVER_ALS ? FMX_LINK_PROBIT : FMX_LINK_LOGISTIC);
+  const int link = e->cfg.task == FMX_TASK_REGRESSION ? FMX_LINK_CLAMP : ((e->cfg.solver == FMX_SOLVER_ALS || e->cfg.solver == FMX_SOLVER_MCMC) ? FMX_LINK_PROBIT : FMX_LINK_LOGISTIC);
   FMX_TRY(forward_rows(e, m, 0, m->n, d_yhat, link));
   return evaluate_device(e, d_yhat, m->y, m->n, metric, score);
 }
@@ -1184,6 +1185,17 @@ int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v
   FMX_TRY(use_device(e->cfg.device));
   if (m->n == 0 || max_iter == 0) return FMX_OK;
   return launch_als_train(e, m, max_iter, with_v);
+}
+
+int fmx_mcmc_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double* std_gammas, const double* std_normals, double* state_out) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "MCMC runs on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  FMX_CHECK(max_iter == 0 || (std_gammas != nullptr && std_normals != nullptr), FMX_ERR_INVALID, "the pre-drawn variates are NULL");
+  FMX_TRY(use_device(e->cfg.device));
+  if (m->n == 0 || max_iter == 0) return FMX_OK;
+  return launch_mcmc_train(e, m, max_iter, std_gammas, std_normals, state_out);
 }
 
 int fmx_profile_enable(fmx_engine* e, int on) {

@@ -280,6 +280,7 @@ int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double
 int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std);
 
 int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v);
+int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state);
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu,
                       const double* d_znorm);
 

@@ -234,6 +234,15 @@ class Engine:
             L.check(L.lib().fmx_mcmc_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu), _p(z)))
         return error
 
+    def mcmc_train(self, m, max_iter, std_gammas, std_normals):
+        """MCMC learner with caller-drawn variates (fmx.h: fmx_mcmc_train); returns (alpha, w_lambda, w_mu)."""
+        g = np.ascontiguousarray(std_gammas, np.float64); z = np.ascontiguousarray(std_normals, np.float64)
+        if g.shape != (max_iter, 2) or z.shape != (max_iter, 2 + self.p):
+            raise ValueError(f"std_gammas must be ({max_iter}, 2) and std_normals ({max_iter}, {2 + self.p})")
+        state = np.zeros(3)
+        L.check(L.lib().fmx_mcmc_train(self.h, m.h, C.c_int32(max_iter), _p(g), _p(z), _p(state)))
+        return tuple(state)
+
     def als_train(self, m, max_iter, with_v=False):
         L.check(L.lib().fmx_als_train(self.h, m.h, C.c_int32(max_iter), C.c_int32(int(with_v))))
 

@@ -37,6 +37,7 @@ extern "C" {
 /* task and solver ids are the reference's (util/Macros.h:11-21) */
 #define FMX_TASK_CLASSIFICATION 10
 #define FMX_TASK_REGRESSION 20
+#define FMX_SOLVER_MCMC 100  /* util/Macros.h:17; trains through fmx_mcmc_train */
 #define FMX_SOLVER_ALS 200
 #define FMX_SOLVER_SGD 300
 #define FMX_SOLVER_FTRL 500
@@ -256,6 +257,17 @@ int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, c
  * The R-side ALS.solver parameters are overridden by learner->init() in the reference and do not enter (alpha = 1,
  * lambdas = 0).  Needs an FMX_MODE_SEQUENTIAL engine (fp64 tables). */
 int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v);
+/* MCMC_ALS_Learner::learn for the MCMC learner (solver/MCMC_ALS_Learner.h:91-156, hyper-parameter draws :359-445), one
+ * attribute group, REGRESSION and CLASSIFICATION.  The reference draws from R's generator inside the loop; a library has
+ * no access to it, so the CALLER pre-draws, in the reference's call order, per iteration:
+ *   std_gammas [max_iter][2]     standard (scale 1) Gamma variates of shape (1 + n)/2 and (1 + p + 1)/2
+ *                                (update_alpha, update_w_lambda: Rf_rgamma(a, s) == s * such a variate),
+ *   std_normals[max_iter][2 + p] standard normals for w0, w_mu and w[0..p)  (Rf_rnorm(m, s) == m + s * z).
+ * Under R:  set.seed(s); for (it in 1:max_iter) { g1 <- rgamma(1, (1+n)/2); z0 <- rnorm(1); g2 <- rgamma(1, (2+p)/2);
+ * zmu <- rnorm(1); zw <- rnorm(p) }  reproduces the reference's chain (slots of switched-off updates are not drawn).
+ * The CLASSIFICATION residual subtracts truncated normals drawn from libc rand() row by row, as the reference does
+ * (util/Random.h:20-93; one host thread).  V is never updated, as shipped (SURVEY A-1).  state_out[3]: alpha, w_lambda, w_mu. */
+int fmx_mcmc_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double* std_gammas, const double* std_normals, double* state_out);
 
 /* ---- measurement: HIP-event timing of each kernel on the engine's stream (bench.py roofline leg). */
 #define FMX_KERNEL_ROWS_FORWARD 0 /* phase 1: V-row gather + forward + grad multiplier */

@@ -328,6 +328,29 @@ def als_learn(P, X, y, w0, w, v, max_iter, with_v=False):
     return w0c.value, w, v
 
 
+def mcmc_draw_shapes(n, p):
+    """Shapes of the two standard Gamma variates an MCMC iteration consumes: (alpha_0 + n)/2, (alpha_0 + p + 1)/2 with alpha_0 = 1."""
+    return (1.0 + n) / 2.0, (1.0 + p + 1.0) / 2.0
+
+
+def mcmc_learn(P, X, y, w0, w, v, max_iter, gammas, normals, seed=None):
+    """MCMC learner (fm_oracle.c fmo_mcmc_learn): gammas [max_iter][2], normals [max_iter][2 + p] pre-drawn standard
+    variates; seed seeds libc rand() for the CLASSIFICATION residual.  Returns (w0, w, v, (alpha, w_lambda, w_mu))."""
+    col_ptr, row_idx, val_t = X.transpose()
+    row_idx = np.ascontiguousarray(row_idx); val_t = np.ascontiguousarray(val_t)
+    y = np.ascontiguousarray(y, np.float32)
+    w = _f64(w).copy(); v = _f64(v).copy()
+    gammas = np.ascontiguousarray(gammas, np.float64); normals = np.ascontiguousarray(normals, np.float64)
+    assert gammas.shape == (max_iter, 2) and normals.shape == (max_iter, 2 + X.p)
+    w0c = C.c_double(w0)
+    state = np.zeros(3)
+    if seed is not None:
+        lib().fmo_srand(C.c_uint(seed))
+    lib().fmo_mcmc_learn(C.byref(P), C.c_uint32(X.p), C.byref(w0c), _ptr(w), _ptr(v), C.byref(X.c), _ptr(col_ptr), _ptr(row_idx), _ptr(val_t),
+                         _ptr(y), C.c_int(max_iter), _ptr(gammas), _ptr(normals), _ptr(state))
+    return w0c.value, w, v, tuple(state)
+
+
 def als_learn_traced(P, X, y, w0, w, v, max_iter, with_v=False):
     """als_learn with the tracker on (P.trace_step > 0, P.eval_type): returns (w0, w, v, iters, evals)."""
     col_ptr, row_idx, val_t = X.transpose()

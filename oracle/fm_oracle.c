@@ -786,12 +786,14 @@ void fmo_als_update_v(int k, uint32_t p, double* v, int64_t n, const int64_t* co
 }
 
 /* solver/MCMC_ALS_Learner.h:162-188 update_w0, ALS branch (do_sample == false; alpha = alpha_0). */
-static void fmo_als_update_w0(const fmo_params* P, double* w0, double* error, int64_t n, double alpha, double w0_mean_0) {
+/* znorm == NULL: the ALS branch; else the MCMC branch, Rf_rnorm(w0_mean, sqrt(w0_var)) (:174-175) with the standard normal
+ * *znorm pre-drawn by the caller */
+static void fmo_als_update_w0(const fmo_params* P, double* w0, double* error, int64_t n, double alpha, double w0_mean_0, const double* znorm) {
   double err = 0;
   for (int64_t i = 0; i < n; ++i) err += error[i] - *w0;
   double w0_var = (double)1.0 / (P->l2_reg0 + alpha * n);
   double w0_mean = -(alpha * err - w0_mean_0 * P->l2_reg0) * w0_var;
-  double w0_old = *w0, w0_new = w0_mean;
+  double w0_old = *w0, w0_new = znorm ? w0_mean + sqrt(w0_var) * *znorm : w0_mean;
   if (fmo_bad(w0_new)) w0_new = w0_old; /* CHECK_PARAM */
   *w0 = w0_new;
   double diff_w0 = w0_old - w0_new;
@@ -800,8 +802,10 @@ static void fmo_als_update_w0(const fmo_params* P, double* w0, double* error, in
 
 /* solver/MCMC_ALS_Learner.h:190-270 update_w, ALS branch, nthreads == 1 (the exact, sequential form: with one thread
  * the per-thread residual copy IS the residual).  w_lambda / w_mu: the one attribute group's values (0 for ALS, :73-76,:400-405). */
+/* znorm != NULL: the MCMC branch, TMP(w) = Rf_rnorm(w_mean, w_var) (:239 -- the VARIANCE is passed where a standard deviation
+ * belongs; kept), i.e. w_mean + w_var * znorm[i] */
 static void fmo_als_update_w(uint32_t p, double* w, const int64_t* col_ptr, const uint32_t* row_idx, const float* val_t,
-                             double* error, double alpha, double w_lambda, double w_mu) {
+                             double* error, double alpha, double w_lambda, double w_mu, const double* znorm) {
   for (uint32_t i = 0; i < p; ++i) {
     double w_mean = 0.0, w_var = 0.0;
     double w_old = w[i], w_ = w[i];
@@ -813,7 +817,7 @@ static void fmo_als_update_w(uint32_t p, double* w, const int64_t* col_ptr, cons
     }
     w_var = (double)1.0 / (w_lambda + alpha * w_var);
     w_mean = -w_var * (alpha * w_mean - w_mu * w_lambda);
-    if (fmo_bad(w_var)) w_ = 0.0; else w_ = w_mean;
+    if (fmo_bad(w_var)) w_ = 0.0; else w_ = znorm ? w_mean + w_var * znorm[i] : w_mean;
     if (fmo_bad(w_)) { w_ = w_old; update_err = 0; }
     w[i] = w_;
     if (update_err) {
@@ -862,8 +866,8 @@ void fmo_als_learn_traced(const fmo_params* P, uint32_t p, double* w0, double* w
     }
     if (P->task == FMO_REGRESSION) fmo_als_error_regression(error, y, X->n);
     else fmo_als_error_classification(error, y, X->n);
-    if (P->k0) fmo_als_update_w0(P, w0, error, X->n, 1.0, 0.0);
-    if (P->k1) fmo_als_update_w(p, w, col_ptr, row_idx, val_t, error, 1.0, 0.0, 0.0);
+    if (P->k0) fmo_als_update_w0(P, w0, error, X->n, 1.0, 0.0, NULL);
+    if (P->k1) fmo_als_update_w(p, w, col_ptr, row_idx, val_t, error, 1.0, 0.0, 0.0, NULL);
     if (with_v && P->k > 0) fmo_als_update_v(P->k, p, v, X->n, col_ptr, row_idx, val_t, error, v_q, 1.0, zeros, zeros, NULL);
   }
   if (trace_n) *trace_n = tn;
@@ -875,6 +879,97 @@ void fmo_als_learn(const fmo_params* P, uint32_t p, double* w0, double* w, doubl
   fmo_params Q = *P;
   Q.trace_step = -1;
   fmo_als_learn_traced(&Q, p, w0, w, v, X, col_ptr, row_idx, val_t, y, max_iter, with_v, NULL, NULL, 0, NULL);
+}
+
+/* ---------------------------------------------------------------- the MCMC learner (do_sample, do_multilevel; :565-576)
+ * util/Random.h:20-93 on libc rand(): uniform, exponential, Leva's ratio-of-uniforms normal, truncated normals. */
+static double fmo_fast_rexp(void) { return -log(1 - fmo_fast_runif()); }  /* fmo_fast_runif: above, with random_select */
+static double fmo_fast_rnorm(void) {
+  double u, v, abs_v, x, y, Q;
+  do {
+    do { u = fmo_fast_runif(); } while (u == 0.0);
+    v = 1.7156 * (fmo_fast_runif() - 0.5);
+    abs_v = v < 0 ? -v : v;
+    x = u - 0.449871;
+    y = abs_v + 0.386595;
+    Q = x * x + y * (0.19600 * y - 0.25472 * x);
+    if (Q < 0.27597) break;
+  } while ((Q > 0.27846) || ((v * v) > (-4.0 * u * u * log(u))));
+  return v / u;
+}
+double fmo_fast_trnorm_left(double left) {
+  if (left < 0.0) {
+    for (;;) { double res = fmo_fast_rnorm(); if (res >= left) return res; }
+  }
+  double alpha_star = 0.5 * (left + sqrt(left * left + 4.0));
+  for (;;) {
+    double z = fmo_fast_rexp() / alpha_star + left;
+    double d = z - alpha_star;
+    d = exp(-(d * d) / 2);
+    double u = fmo_fast_runif();
+    if (u < d) return z;
+  }
+}
+double fmo_fast_trnorm_right(double right) { return -fmo_fast_trnorm_left(-right); }
+
+/* calculate_error, CLASSIFICATION with do_sample (:529-542), one thread: rows in order, draws from libc rand() */
+void fmo_mcmc_error_classification(double* error, const float* y, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    double e = error[i];
+    if (y[i] >= 0.0f) error[i] -= 0.0 + 1.0 * fmo_fast_trnorm_left((e - 0.0) / 1.0);   /* fast_trnorm_left(e, 0, 1), Random.h:78-81 */
+    else error[i] -= 0.0 + 1.0 * fmo_fast_trnorm_right((e - 0.0) / 1.0);
+  }
+}
+
+/* MCMC_ALS_Learner::learn + update_all for the MCMC learner (:91-156, :359-445), one attribute group, one thread.
+ * R's generator is not available: the draws the reference takes from it are supplied by the caller, pre-drawn in call
+ * order -- per iteration  gammas[2]  = standard (scale 1) Gamma variates of shape (alpha_0 + n)/2 and (alpha_0 + p + 1)/2
+ * (Rf_rgamma(a, s) is s times such a variate) and  normals[2 + p] = standard normals for w0, w_mu and w[0..p)
+ * (Rf_rnorm(m, s) is m + s z).  Slots of updates that are switched off (k0, k1) are skipped, not consumed.
+ * The CLASSIFICATION residual draws truncated normals from libc rand(), as the reference does.  As shipped, V is never
+ * updated (SURVEY A-1).  state[3] returns alpha, w_lambda, w_mu after the last iteration.
+ * init() (:59-90): alpha_0 = gamma_0 = beta_0 = 1, mu_0 = 0, alpha = 1, w0_mean_0 = 0, w_lambda = w_mu = 0. */
+void fmo_mcmc_learn(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, const fmo_csr* X,
+                    const int64_t* col_ptr, const uint32_t* row_idx, const float* val_t, const float* y, int max_iter,
+                    const double* gammas, const double* normals, double* state) {
+  const double alpha_0 = 1.0, gamma_0 = 1.0, beta_0 = 1.0, mu_0 = 0.0, w0_mean_0 = 0.0;
+  double alpha = 1.0, w_lambda = 0.0, w_mu = 0.0;
+  double* error = (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1));
+  for (int it = 0; it < max_iter; ++it) {
+    const double* G = gammas + (size_t)it * 2;
+    const double* Z = normals + (size_t)it * (2 + (size_t)p);
+    fmo_predict_batch(P, p, *w0, w, v, X, error);
+    if (P->task == FMO_REGRESSION) fmo_als_error_regression(error, y, X->n);
+    else fmo_mcmc_error_classification(error, y, X->n);
+    { /* update_alpha, :359-380 */
+      double alpha_n = alpha_0 + (double)X->n, gamma_n = gamma_0;
+      for (int64_t i = 0; i < X->n; ++i) gamma_n += error[i] * error[i];
+      double a_new = (2.0 / gamma_n) * G[0]; /* Rf_rgamma(alpha_n / 2, 2 / gamma_n) */
+      (void)alpha_n;
+      if (!fmo_bad(a_new)) alpha = a_new;
+    }
+    if (P->k0) fmo_als_update_w0(P, w0, error, X->n, alpha, w0_mean_0, &Z[0]);
+    if (P->k1) {
+      { /* update_w_lambda, :415-445 */
+        double s = 0.0;
+        for (uint32_t i = 0; i < p; ++i) s += (w[i] - w_mu) * (w[i] - w_mu);
+        s += beta_0 * (w_mu - mu_0) * (w_mu - mu_0) + gamma_0;
+        double l_new = (2.0 / s) * G[1]; /* Rf_rgamma((alpha_0 + p + 1) / 2, 2 / s) */
+        if (!fmo_bad(l_new)) w_lambda = l_new;
+      }
+      { /* update_w_mu, :383-412 */
+        double m = 0.0;
+        for (uint32_t i = 0; i < p; ++i) m += w[i];
+        m = (m + beta_0 * mu_0) / ((double)p + beta_0);
+        double var = (double)1.0 / (((double)p + beta_0) * w_lambda);
+        double mu_new = m + sqrt(var) * Z[1];
+        if (!fmo_bad(mu_new)) w_mu = mu_new;
+      }
+      fmo_als_update_w(p, w, col_ptr, row_idx, val_t, error, alpha, w_lambda, w_mu, Z + 2);
+    }
+  }
+  if (state) { state[0] = alpha; state[1] = w_lambda; state[2] = w_mu; }
+  free(error);
 }
 
 /* ================================================================== engine semantics (not in reference)

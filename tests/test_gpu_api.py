@@ -72,8 +72,8 @@ def test_update_warm_start_and_errors():
         fm.predict(fit)
     with pytest.raises(ValueError, match="not the same"):
         fm.fm_update(fit, fm.fm_matrix(X[:, :100], rating), normalize=False)
-    with pytest.raises(NotImplementedError):
-        fm.solver_control(solver=fm.MCMC_solver())
+    with pytest.warns(UserWarning, match="maximum number of iteratorions"):
+        assert fm.solver_control(solver=fm.MCMC_solver())["max_iter"] == 100
     assert fm.solver_control()["solver"]["solver"] == "TDAP"  # the reference's default (R/fm_solver_control.R:22)
 
 
@@ -212,3 +212,27 @@ def test_als_classification_through_the_api_uses_the_probit_tables():
     ref = oracle.predict_batch(P, Xo, r0, rw, rv, prob="probit")
     np.testing.assert_allclose(prob, ref, rtol=0, atol=1e-9)
     assert np.mean((prob >= 0.5) == (y > 0)) > 0.93
+
+
+def test_mcmc_solver_through_the_api():
+    """MCMC.solver: the chain's variates come from the generator seeded by fm_train(seed=) in the reference's call order;
+    the same variates fed to the oracle's restatement give the same chain."""
+    import fmwr_amd as fm
+    from fmwr_amd.api import _mcmc_draws
+    rng = np.random.default_rng(31)
+    n, p, k = 2500, 40, 2
+    X = sp.random(n, p, density=0.15, format="csr", random_state=31, data_rvs=lambda s: rng.normal(0, 1, s)); X.sort_indices()
+    wt = rng.normal(0, 1, p)
+    y = X @ wt + 0.5 + rng.normal(0, 0.2, n)
+    data = fm.fm_matrix(X, y)
+    ctl = [fm.model_control("REGRESSION", **{"factor.number": k}), fm.solver_control(max_iter=25, solver=fm.MCMC_solver())]
+    fit = fm.fm_train(data, normalize=False, control=ctl, seed=9)
+    g = np.random.default_rng(9)
+    v0 = g.normal(0.0, 0.01, (k, p))
+    gam, z = _mcmc_draws(g, n, p, 25, True, True)
+    P = oracle.params(task=oracle.REGRESSION, k=k, min_target=float(y.min()), max_target=float(y.max()))
+    r0, rw, rv, st = oracle.mcmc_learn(P, oracle.Matrix(X.indptr, X.indices, X.data, p), y.astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 25, gam, z)
+    assert abs(fit["Model"]["w0"] - r0) < 1e-9 and np.max(np.abs(fit["Model"]["w"] - rw)) < 1e-9
+    assert np.max(np.abs(fit["Model"]["w"] - wt)) < 0.1 and abs(fit["Model"]["w0"] - 0.5) < 0.1  # the posterior sits on the truth
+    pred = fm.predict(fit, data, normalize=False)
+    assert np.mean((pred - y) ** 2) < 0.1 * np.var(y)

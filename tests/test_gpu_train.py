@@ -611,3 +611,41 @@ def test_chunked_exchange_equals_the_split_step(fm, name, reduce, wide):
         assert h0 == r0 and np.array_equal(hw, rw) and np.array_equal(hv, rv), chunks
     with pytest.raises(L.FmxError, match="fmx_grad_begin"):
         engine.Engine(p, exchange_chunks=2, **base).grad_chunk(m, 0)
+
+
+@pytest.mark.parametrize("task", ["regression", "classification"])
+@pytest.mark.parametrize("flags", [(True, True), (False, True), (True, False)], ids=["w0+w", "w only", "w0 only"])
+def test_mcmc_learner_matches_oracle(fm, task, flags):
+    """MCMC_Learner (do_sample, do_multilevel): alpha ~ Gamma, w0 ~ N, w_lambda ~ Gamma, w_mu ~ N, w_i ~ N(mean, var) with
+    the caller's pre-drawn standard variates; CLASSIFICATION subtracts truncated normals drawn from libc rand() row by row
+    (same seed => same stream in the oracle and in the engine's host step)."""
+    engine, L = fm
+    n, p, k = 1100, 60, 3
+    k0, k1 = flags
+    rp, col, val = util.random_csr(n, p, 6, seed=71, empty_rows=True)
+    y = util.labels(n, 71, task)
+    w0, w, v = util.params(p, k, 71, stdev=0.2, fp32=False)
+    iters = 6
+    rng = np.random.default_rng(71)
+    a1, a2 = oracle.mcmc_draw_shapes(n, p)
+    G = np.stack([rng.gamma(a1, 1.0, iters), rng.gamma(a2, 1.0, iters)], 1)
+    Z = rng.normal(0, 1, (iters, 2 + p))
+    ot = oracle.REGRESSION if task == "regression" else oracle.CLASSIFICATION
+    P = oracle.params(task=ot, k=k, k0=k0, k1=k1, l2_reg0=0.05, min_target=float(y.min()), max_target=float(y.max()))
+    X = oracle.Matrix(rp, col, val, p)
+    r0, rw, rv, rst = oracle.mcmc_learn(P, X, y, w0, w, v.ravel(), iters, G, Z, seed=123)
+    e = engine.Engine(p, task=L.TASK_REGRESSION if task == "regression" else L.TASK_CLASSIFICATION, solver=L.SOLVER_MCMC, num_factor=k,
+                      keep_w0=int(k0), keep_w1=int(k1), l2_w0=0.05, mode=L.MODE_SEQUENTIAL, min_target=float(y.min()), max_target=float(y.max()))
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    oracle.lib().fmo_srand(123)  # libc rand() is process-wide: the engine's host step continues from this seed
+    st = e.mcmc_train(m, iters, G, Z)
+    g0, gw, gv = e.get_params()
+    assert abs(g0 - r0) < 1e-9 and util.rel_err(gw, rw) < 1e-9 and np.array_equal(gv, v)
+    np.testing.assert_allclose(st, rst, rtol=1e-9)
+    if task == "classification":  # predictions of an MCMC model go through the probit table
+        prob = e.predict(m, L.LINK_PROBIT)
+        np.testing.assert_allclose(prob, oracle.predict_batch(P, X, r0, rw, rv, prob="probit"), rtol=0, atol=1e-9)
+        assert abs(e.evaluate(m, L.EVAL_LL) - oracle.evaluate(ot, oracle.LL, prob, y)) < 1e-9
+    with pytest.raises(L.FmxError, match="fmx_mcmc_train"):
+        e.train(m, 10)

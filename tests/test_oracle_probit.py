@@ -88,3 +88,34 @@ def test_als_classification_residual_and_learning():
     # one iteration by hand: e = -dpnorm(-yhat) for y >= 0, dpnorm(yhat) otherwise, at the start (yhat = 0): -/+ 0.7978845608
     e0 = oracle.fast_dpnorm([0.0])[0]
     assert abs(e0 - np.sqrt(2 / np.pi)) < 1e-11
+
+
+def test_mcmc_learner_restatement_recovers_a_linear_model():
+    """fmo_mcmc_learn (MCMC_Learner with caller-drawn variates): on y = w.x + w0 + noise the chain settles on the truth and
+    alpha on 1/noise^2; the same variates give the same chain; CLASSIFICATION (truncated normals from libc rand()) separates."""
+    from tests import util
+    n, p, k = 800, 50, 3
+    rp, col, val = util.random_csr(n, p, 6, seed=3)
+    X = oracle.Matrix(rp, col, val, p)
+    rng = np.random.default_rng(0)
+    wt = rng.normal(0, 1, p)
+    y = (oracle.predict_batch(oracle.params(k=0), X, 0.3, wt, np.zeros(0)) + rng.normal(0, 0.1, n)).astype(np.float32)
+    it = 30
+    a1, a2 = oracle.mcmc_draw_shapes(n, p)
+    assert (a1, a2) == ((1 + n) / 2, (2 + p) / 2)
+    G = np.stack([rng.gamma(a1, 1.0, it), rng.gamma(a2, 1.0, it)], 1)
+    Z = rng.normal(0, 1, (it, 2 + p))
+    v0 = rng.normal(0, 0.01, (k, p)).ravel()
+    P = oracle.params(task=oracle.REGRESSION, k=k, min_target=float(y.min()), max_target=float(y.max()))
+    w0, w, v, st = oracle.mcmc_learn(P, X, y, 0.0, np.zeros(p), v0, it, G, Z)
+    assert np.max(np.abs(w - wt)) < 0.05 and abs(w0 - 0.3) < 0.05 and 50 < st[0] < 200   # alpha ~ 1 / 0.1^2
+    assert np.array_equal(v, v0)                                                          # V is never updated (SURVEY A-1)
+    again = oracle.mcmc_learn(P, X, y, 0.0, np.zeros(p), v0, it, G, Z)
+    assert again[0] == w0 and np.array_equal(again[1], w)
+    ycls = np.where(y > np.median(y), 1, -1).astype(np.float32)
+    Pc = oracle.params(task=oracle.CLASSIFICATION, k=k)
+    c0, cw, cv, _ = oracle.mcmc_learn(Pc, X, ycls, 0.0, np.zeros(p), v0, it, G, Z, seed=5)
+    prob = oracle.predict_batch(Pc, X, c0, cw, cv, prob="probit")
+    assert np.mean((prob >= 0.5) == (ycls > 0)) > 0.93
+    d0, dw, _, _ = oracle.mcmc_learn(Pc, X, ycls, 0.0, np.zeros(p), v0, it, G, Z, seed=5)
+    assert d0 == c0 and np.array_equal(dw, cw)                                            # same rand() seed, same chain
