@@ -23,12 +23,15 @@ SOLVERS = {
     "ftrl_k24": dict(solver="ftrl", k=24, l1_regw=1e-3, l1_regv=1e-3, l2_regw=1e-2, l2_regv=1e-2),
     "tdap_k20": dict(solver="tdap", k=20, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=1e-3, alpha_v=0.05),
     "tdap_k40": dict(solver="tdap", k=40, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=1e-3, alpha_v=0.05),
+    # no factors at all, and a single one
+    "sgd_k0": dict(solver="sgd", k=0, l2_regw=1e-3, l2_reg0=1e-3, learn_rate=0.05),
+    "ftrl_k1": dict(solver="ftrl", k=1, l1_regw=1e-3, l1_regv=1e-3, l2_regw=1e-2, l2_regv=1e-2),
 }
 
 
 def _run(name, c, p, n, nnz, iters, random_step=1, window=True):
     from fmwr_amd import engine, _lib as L
-    rp, col, val = util.random_csr(n, p, nnz, seed=len(name) + p, empty_rows=True)
+    rp, col, val = util.random_csr(n, p, nnz, seed=len(name) + p, empty_rows=True, max_nnz=32)  # rows of the register-resident path
     task = c.get("task", oracle.CLASSIFICATION)
     y = util.labels(n, 5, "classification" if task == oracle.CLASSIFICATION else "regression")
     kw = {k: v for k, v in c.items() if k != "solver"}
@@ -52,9 +55,10 @@ def _run(name, c, p, n, nnz, iters, random_step=1, window=True):
 
 
 @pytest.mark.parametrize("name", list(SOLVERS))
-@pytest.mark.parametrize("p,nnz", [(40, 6), (3000, 12), (200000, 30)])
+@pytest.mark.parametrize("p,nnz", [(40, 6), (3000, 12), (200000, 30), (5000, 32)])
 def test_windowed_learner_is_bitwise_the_one_wave_learner(name, p, nnz):
-    """p = 40: every example conflicts with its neighbour (groups of one); p = 3000: mixed; p = 200000: groups mostly full."""
+    """p = 40: every example conflicts with its neighbour (groups of one); p = 3000: mixed; p = 200000: groups mostly full;
+    (5000, 32): most rows are clipped to exactly the 32 entries the register-resident path holds."""
     c = SOLVERS[name]
     n = 1500
     a, ctx = _run(name, c, p, n, nnz, 2 * n + 11, window=True)

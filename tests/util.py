@@ -2,11 +2,11 @@
 import numpy as np
 
 
-def random_csr(n, p, mean_nnz, seed, empty_rows=True, values="normal"):
+def random_csr(n, p, mean_nnz, seed, empty_rows=True, values="normal", max_nnz=None):
     """Ragged CSR: row lengths ~ Poisson(mean_nnz) clipped to [0, p] (some rows empty), columns sorted and
     distinct inside a row, float32 values."""
     rng = np.random.default_rng(seed)
-    lens = rng.poisson(mean_nnz, n).clip(0 if empty_rows else 1, p)
+    lens = rng.poisson(mean_nnz, n).clip(0 if empty_rows else 1, p if max_nnz is None else min(p, max_nnz))
     if empty_rows and n > 3:
         lens[rng.integers(0, n, max(1, n // 50))] = 0
         lens[rng.integers(0, n, max(1, n // 50))] = 1  # single-nnz rows: pairwise gradient is identically 0
