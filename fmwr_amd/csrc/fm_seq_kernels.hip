@@ -496,39 +496,45 @@ __global__ __launch_bounds__(64) void fm_seq_learn_k(SeqArgs a, Hyper h) {
 //   C  every wave applies its example's update from its registers.
 // A group ends at the first example that shares a feature with an earlier member (it then reads what that member wrote).
 // `conf[t]`, the last earlier example of the launch sharing a feature with t, comes from a stable sort of the launch's
-// (feature, example) pairs; TDAP examples holding a feature id < FAST_NZ run alone (its w prox reads z_w by POSITION, A-6).
+// (feature, example) pairs; TDAP examples holding a feature id < NZ run alone (its w prox reads z_w by POSITION, A-6).
 // Bitwise the same results as the one-wave kernel above (tests/test_gpu_seq_window.py).
-constexpr int WIN_TERMS = FAST_NZ + 64;
+// NZ, the entries a row may hold, is 32, or 64 when k <= 32 (rows of 33..64 entries, e.g. Criteo's 39: the lane layout below
+// keeps NZ / Q slots per lane, so the longer rows still fit the registers).
+constexpr int WIN_NZ_MAX = 64;
 // Lane mapping of a wave: KL lanes per factor block (16 / 32 / 64 for k <= 16 / 32 / 64) and Q = 64 / KL blocks, block q
 // holding the nonzeros u = q, q + Q, q + 2Q ...: with k = 16 all 64 lanes gather and update (8 coordinates each instead
-// of 32 on 16 lanes), and a lane keeps FAST_NZ / Q x (1 + state) doubles in registers, which is what sets the number of
+// of 32 on 16 lanes), and a lane keeps NZ / Q x (1 + state) doubles in registers, which is what sets the number of
 // waves (= examples per group) a workgroup can hold.
-template <int KIND, int KL> struct SeqWin {
+template <int KIND, int KL, int NZ> struct SeqWin {
   static constexpr int Q = 64 / KL;
-  static constexpr int SL = FAST_NZ / Q;  // nonzero slots per lane
-  static constexpr int NW = (KIND == UPD_TDAP && KL >= 32) ? 4 : 8;  // 256 (512) VGPRs per lane at 8 (4) waves per workgroup
+  static constexpr int SL = NZ / Q;  // nonzero slots per lane
+  static constexpr int TERMS = NZ + 64;
+  // 256 (512) VGPRs per lane at 8 (4) waves per workgroup; a lane holds SL x (1 + state) doubles of parameters, with
+  // several blocks also SL columns and x values, on top of ~120 registers of everything else
+  static constexpr int REGS = 2 * SL * (1 + SeqState<KIND>::N) + (Q > 1 ? 3 * SL : 0) + 120;
+  static constexpr int NW = REGS > 270 ? 4 : 8;
 };
 
 struct WinArgs {
-  const uint2* packed;  // [count][FAST_NZ] (column, x bits), idle slots (0, +0.0f)
+  const uint2* packed;  // [count][NZ] (column, x bits), idle slots (0, +0.0f)
   const int* ex_len;
   const float* ex_y;
   const int* conf;      // [count] last earlier example sharing a feature (-1: none; t itself: must run alone)
   int count;
 };
 
-__global__ void seq_pack_k(const int64_t* __restrict__ ex_b, const int* __restrict__ ex_len, int count, const uint32_t* __restrict__ col,
+__global__ void seq_pack_k(const int64_t* __restrict__ ex_b, const int* __restrict__ ex_len, int count, int nz, const uint32_t* __restrict__ col,
                            const float* __restrict__ val, int tdap, uint2* __restrict__ packed, uint32_t* __restrict__ keys,
                            uint32_t* __restrict__ vals, int* __restrict__ conf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count * FAST_NZ) return;
-  const int t = i / FAST_NZ, u = i % FAST_NZ;
+  if (i >= count * nz) return;
+  const int t = i / nz, u = i % nz;
   const bool have = u < ex_len[t];
   const uint32_t c = have ? col[ex_b[t] + u] : 0u;
   packed[i] = make_uint2(c, have ? __float_as_uint(val[ex_b[t] + u]) : 0u);
   keys[i] = have ? c : 0xFFFFFFFFu;
   vals[i] = (uint32_t)t;
-  if (tdap && have && c < (uint32_t)FAST_NZ) atomicMax(conf + t, t);  // z_w[c] is what other examples read by position
+  if (tdap && have && c < (uint32_t)nz) atomicMax(conf + t, t);  // z_w[c] is what other examples read by position
 }
 
 __global__ void seq_conf_k(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int n, int* __restrict__ conf) {
@@ -537,11 +543,12 @@ __global__ void seq_conf_k(const uint32_t* __restrict__ keys, const uint32_t* __
   if (keys[i] != 0xFFFFFFFFu && keys[i] == keys[i - 1]) atomicMax(conf + vals[i], (int)vals[i - 1]);  // stable sort: vals ascend inside a key
 }
 
-template <int KIND, int KL>
-__global__ __launch_bounds__((SeqWin<KIND, KL>::NW * 64)) void fm_seq_window_k(SeqArgs a, WinArgs wa, Hyper h) {
-  constexpr int NW = SeqWin<KIND, KL>::NW;
-  constexpr int Q = SeqWin<KIND, KL>::Q;
-  constexpr int SL = SeqWin<KIND, KL>::SL;
+template <int KIND, int KL, int NZ>
+__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window_k(SeqArgs a, WinArgs wa, Hyper h) {
+  constexpr int NW = SeqWin<KIND, KL, NZ>::NW;
+  constexpr int Q = SeqWin<KIND, KL, NZ>::Q;
+  constexpr int SL = SeqWin<KIND, KL, NZ>::SL;
+  constexpr int WIN_TERMS = SeqWin<KIND, KL, NZ>::TERMS;
   constexpr int NS = SeqState<KIND>::N;
   __shared__ double terms[NW][WIN_TERMS];
   __shared__ double s_mult[NW], s_uw[NW], s_uv[NW];
@@ -564,7 +571,7 @@ __global__ __launch_bounds__((SeqWin<KIND, KL>::NW * 64)) void fm_seq_window_k(S
       mt.conf_t = wa.conf[tt];
       mt.conf_g = wa.conf[gg];
       mt.len = wa.ex_len[tt];
-      mt.en = wa.packed[(size_t)tt * FAST_NZ + (lane & (FAST_NZ - 1))];
+      mt.en = wa.packed[(size_t)tt * NZ + (lane & (NZ - 1))];
       mt.y = wa.ex_y[tt];
     }
     return mt;
@@ -619,15 +626,15 @@ __global__ __launch_bounds__((SeqWin<KIND, KL>::NW * 64)) void fm_seq_window_k(S
         for (int n = 0; n < NS; ++n) stv[n][j] = seq_state_ptr<KIND>(a, false, n)[at];
       }
 #pragma unroll
-      for (int u = 0; u < FAST_NZ; ++u) {  // core/Model.h:83-97: every factor's sums run over the nonzeros in row order
+      for (int u = 0; u < NZ; ++u) {  // core/Model.h:83-97: every factor's sums run over the nonzeros in row order
         double tmp;
         if constexpr (Q == 1) tmp = vv[u] * bcast(myx, u);
         else tmp = __shfl(vv[u / Q] * xu[u / Q], (u % Q) * KL + ff);  // from the block that holds nonzero u
         s1 += tmp;
         q1 += tmp * tmp;
       }
-      if (lane < FAST_NZ) terms[wave][lane] = (k1 ? myw : 0.0) * myx;     // w_j x_j, the linear term's addends in row order
-      if (lane < k8) terms[wave][FAST_NZ + lane] = fv ? 0.5 * (s1 * s1 - q1) : 0.0;  // core/Model.h:100, factor order (lanes of block 0)
+      if (lane < NZ) terms[wave][lane] = (k1 ? myw : 0.0) * myx;     // w_j x_j, the linear term's addends in row order
+      if (lane < k8) terms[wave][NZ + lane] = fv ? 0.5 * (s1 * s1 - q1) : 0.0;  // core/Model.h:100, factor order (lanes of block 0)
       if (lane == 0) s_y[wave] = cur.y;
     }
     __syncthreads();
@@ -641,7 +648,7 @@ __global__ __launch_bounds__((SeqWin<KIND, KL>::NW * 64)) void fm_seq_window_k(S
         const double* __restrict__ T = terms[e];
         double pred = k0 ? w0 : 0.0;
 #pragma unroll
-        for (int u = 0; u < FAST_NZ; u += 8) {
+        for (int u = 0; u < NZ; u += 8) {
           double tt[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) tt[i] = T[u + i];
@@ -651,7 +658,7 @@ __global__ __launch_bounds__((SeqWin<KIND, KL>::NW * 64)) void fm_seq_window_k(S
         for (int f = 0; f < k8; f += 8) {  // slots k..k8 hold +0.0: adding it changes nothing
           double tt[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) tt[i] = T[FAST_NZ + f + i];
+          for (int i = 0; i < 8; ++i) tt[i] = T[NZ + f + i];
 #pragma unroll
           for (int i = 0; i < 8; ++i) pred += tt[i];
         }
@@ -753,10 +760,14 @@ __global__ __launch_bounds__((SeqWin<KIND, KL>::NW * 64)) void fm_seq_window_k(S
 }
 
 // the windowed learner applies when every row is a fast row; FMX_SEQ_WINDOW=0 in the environment keeps the one-wave kernel
-static bool window_mode(const fmx_engine* e, const fmx_matrix* m) {
+// entries per packed row (32 or 64), or 0: the one-wave kernel
+static int window_mode(const fmx_engine* e, const fmx_matrix* m) {
   const char* s = getenv("FMX_SEQ_WINDOW");  // read per call: the tests compare both kernels in one process
   const bool off = s && s[0] == '0';
-  return !off && m->rows_sorted && e->k <= 64 && m->max_row_len <= FAST_NZ;
+  if (off || !m->rows_sorted || e->k > 64) return 0;
+  if (m->max_row_len <= 32) return 32;
+  if (m->max_row_len <= 64 && e->k <= 32) return 64;
+  return 0;
 }
 
 static int ensure_window_workspace(fmx_engine* e, int64_t cap) {
@@ -764,7 +775,7 @@ static int ensure_window_workspace(fmx_engine* e, int64_t cap) {
   FMX_HIP(hipStreamSynchronize(e->stream));
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   e->seq_packed = nullptr; e->seq_conf = nullptr; e->seq_keys = nullptr; e->seq_sort_tmp = nullptr; e->seq_wcap = 0;
-  const size_t pairs = (size_t)cap * FAST_NZ;
+  const size_t pairs = (size_t)cap * WIN_NZ_MAX;
   FMX_HIP(hipMalloc(&e->seq_packed, pairs * sizeof(uint2)));
   FMX_HIP(hipMalloc(&e->seq_conf, (size_t)cap * sizeof(int)));
   FMX_HIP(hipMalloc(&e->seq_keys, 4 * pairs * sizeof(uint32_t)));
@@ -778,10 +789,12 @@ static int ensure_window_workspace(fmx_engine* e, int64_t cap) {
 }
 
 template <int KIND>
-static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa) {
-  if (e->k <= 16) hipLaunchKernelGGL((fm_seq_window_k<KIND, 16>), dim3(1), dim3(SeqWin<KIND, 16>::NW * 64), 0, e->stream, a, wa, e->hyper);
-  else if (e->k <= 32) hipLaunchKernelGGL((fm_seq_window_k<KIND, 32>), dim3(1), dim3(SeqWin<KIND, 32>::NW * 64), 0, e->stream, a, wa, e->hyper);
-  else hipLaunchKernelGGL((fm_seq_window_k<KIND, 64>), dim3(1), dim3(SeqWin<KIND, 64>::NW * 64), 0, e->stream, a, wa, e->hyper);
+static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa, int nz) {
+#define FMX_WIN(KL, NZ) hipLaunchKernelGGL((fm_seq_window_k<KIND, KL, NZ>), dim3(1), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, a, wa, e->hyper)
+  if (e->k <= 16) { if (nz == 32) FMX_WIN(16, 32); else FMX_WIN(16, 64); }
+  else if (e->k <= 32) { if (nz == 32) FMX_WIN(32, 32); else FMX_WIN(32, 64); }
+  else FMX_WIN(64, 32);
+#undef FMX_WIN
 }
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
@@ -805,7 +818,8 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
             e->k, e->kp64, m->rows_sorted};
   // bounded launches: a single workgroup walking millions of examples in one dispatch would run for seconds
   const int64_t CHUNK = 1 << 16;
-  const bool windowed = window_mode(e, m);
+  const int nz = window_mode(e, m);
+  const bool windowed = nz > 0;
   if (windowed) FMX_TRY(ensure_window_workspace(e, count < CHUNK ? count : CHUNK));
   for (int64_t off = 0; off < count; off += CHUNK) {
     a.order = d_order + off;
@@ -814,11 +828,11 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
     if (windowed) {
       // the chunk's examples packed in visiting order, and for each the last earlier example of the chunk sharing a feature
       const int cnt = (int)a.count;
-      const size_t pairs = (size_t)cnt * FAST_NZ;
+      const size_t pairs = (size_t)cnt * nz;
       uint32_t* keys = e->seq_keys;
-      const size_t cap_pairs = (size_t)e->seq_wcap * FAST_NZ;
+      const size_t cap_pairs = (size_t)e->seq_wcap * WIN_NZ_MAX;
       FMX_HIP(hipMemsetAsync(e->seq_conf, 0xFF, (size_t)cnt * sizeof(int), e->stream));  // -1
-      hipLaunchKernelGGL(seq_pack_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, a.ex_b, a.ex_len, cnt, m->col, m->val,
+      hipLaunchKernelGGL(seq_pack_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, a.ex_b, a.ex_len, cnt, nz, m->col, m->val,
                          e->hyper.kind == UPD_TDAP ? 1 : 0, (uint2*)e->seq_packed, keys, keys + 2 * cap_pairs, e->seq_conf);
       size_t tb = e->seq_sort_tmp_bytes;
       FMX_HIP(rocprim::radix_sort_pairs(e->seq_sort_tmp, tb, keys, keys + cap_pairs, keys + 2 * cap_pairs, keys + 3 * cap_pairs, pairs, 0, 32, e->stream));
@@ -826,10 +840,10 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
       WinArgs wa{(const uint2*)e->seq_packed, a.ex_len, a.ex_y, e->seq_conf, cnt};
       prof_begin(e, FMX_KERNEL_SEQ);
       switch (e->hyper.kind) {
-        case UPD_SGD_L2: launch_window_kind<UPD_SGD_L2>(e, a, wa); break;
-        case UPD_SGD_L1: launch_window_kind<UPD_SGD_L1>(e, a, wa); break;
-        case UPD_TDAP: launch_window_kind<UPD_TDAP>(e, a, wa); break;
-        default: launch_window_kind<UPD_FTRL>(e, a, wa); break;
+        case UPD_SGD_L2: launch_window_kind<UPD_SGD_L2>(e, a, wa, nz); break;
+        case UPD_SGD_L1: launch_window_kind<UPD_SGD_L1>(e, a, wa, nz); break;
+        case UPD_TDAP: launch_window_kind<UPD_TDAP>(e, a, wa, nz); break;
+        default: launch_window_kind<UPD_FTRL>(e, a, wa, nz); break;
       }
       prof_end(e);
       FMX_HIP(hipGetLastError());

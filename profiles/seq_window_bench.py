@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from fmwr_amd import _lib as L, engine
-n, p, z, k = 2_000_000, 1_000_000, 30, int(os.environ.get("SEQ_K", "16"))
+n, p, z, k = 2_000_000, 1_000_000, int(os.environ.get("SEQ_Z", "30")), int(os.environ.get("SEQ_K", "16"))
 m = engine.Matrix.synthetic(n, p, z, 20240001)
 v0 = np.random.default_rng(1).normal(0, 0.01, (k, p))
 order = np.arange(1, 400_001, dtype=np.int64)

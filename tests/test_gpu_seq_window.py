@@ -29,9 +29,9 @@ SOLVERS = {
 }
 
 
-def _run(name, c, p, n, nnz, iters, random_step=1, window=True):
+def _run(name, c, p, n, nnz, iters, random_step=1, window=True, max_nnz=32):
     from fmwr_amd import engine, _lib as L
-    rp, col, val = util.random_csr(n, p, nnz, seed=len(name) + p, empty_rows=True, max_nnz=32)  # rows of the register-resident path
+    rp, col, val = util.random_csr(n, p, nnz, seed=len(name) + p, empty_rows=True, max_nnz=max_nnz)  # rows of the register-resident path
     task = c.get("task", oracle.CLASSIFICATION)
     y = util.labels(n, 5, "classification" if task == oracle.CLASSIFICATION else "regression")
     kw = {k: v for k, v in c.items() if k != "solver"}
@@ -68,6 +68,23 @@ def test_windowed_learner_is_bitwise_the_one_wave_learner(name, p, nnz):
     X = oracle.Matrix(rp, col, val, p)
     learn = {"sgd": oracle.sgd_learn, "ftrl": oracle.ftrl_learn, "tdap": oracle.tdap_learn}[c["solver"]]
     ref = learn(P, X, y, w0, w, v.ravel(), len(order), order=order)
+    assert abs(a[0] - ref["w0"]) < 1e-11 and util.rel_err(a[1], ref["w"]) < 1e-11
+    if P.k:
+        assert util.rel_err(a[2], ref["v"].reshape(P.k, p)) < 1e-11
+
+
+@pytest.mark.parametrize("name", [n for n, c in SOLVERS.items() if c["k"] <= 32])
+def test_rows_of_33_to_64_entries_use_the_wide_layout(name):
+    """k <= 32 and rows of up to 64 entries (Criteo's 39 fall here): 64 packed slots per example."""
+    c = SOLVERS[name]
+    n, p = 1200, 30000
+    a, ctx = _run(name, c, p, n, 45, 2 * n + 7, window=True, max_nnz=64)
+    b, _ = _run(name, c, p, n, 45, 2 * n + 7, window=False, max_nnz=64)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    P, rp, col, val, y, w0, w, v, order = ctx
+    assert np.diff(rp).max() > 40
+    learn = {"sgd": oracle.sgd_learn, "ftrl": oracle.ftrl_learn, "tdap": oracle.tdap_learn}[c["solver"]]
+    ref = learn(P, oracle.Matrix(rp, col, val, p), y, w0, w, v.ravel(), len(order), order=order)
     assert abs(a[0] - ref["w0"]) < 1e-11 and util.rel_err(a[1], ref["w"]) < 1e-11
     if P.k:
         assert util.rel_err(a[2], ref["v"].reshape(P.k, p)) < 1e-11
