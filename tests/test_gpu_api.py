@@ -236,3 +236,39 @@ def test_mcmc_solver_through_the_api():
     assert np.max(np.abs(fit["Model"]["w"] - wt)) < 0.1 and abs(fit["Model"]["w0"] - 0.5) < 0.1  # the posterior sits on the truth
     pred = fm.predict(fit, data, normalize=False)
     assert np.mean((pred - y) ** 2) < 0.1 * np.var(y)
+
+
+def test_c_abi_argument_checks_for_the_newer_entry_points():
+    """Misuse of the step / exchange / MCMC entry points is refused with a message, never a fault."""
+    from fmwr_amd import engine, _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    n, p = 300, 40
+    X = sp.random(n, p, density=0.2, format="csr", random_state=1, data_rvs=lambda s: rng.normal(0, 1, s)); X.sort_indices()
+    y = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    m = engine.Matrix.from_csr(X.indptr.astype(np.int64), X.indices.astype(np.uint32), X.data.astype(np.float32), p, y.astype(np.float32))
+    seq = engine.Engine(p, num_factor=2, mode=L.MODE_SEQUENTIAL)
+    mb = engine.Engine(p, num_factor=2, mode=L.MODE_MINIBATCH, batch_rows=100, exchange_chunks=2)
+    with pytest.raises(L.FmxError, match="MINIBATCH"):
+        seq.grad_begin(m, 0)
+    with pytest.raises(L.FmxError, match="MINIBATCH"):
+        seq.grad_layout()
+    with pytest.raises(L.FmxError, match="out of range"):
+        mb.grad_begin(m, 99)
+    mb.grad_begin(m, 0)
+    with pytest.raises(L.FmxError, match="out of range"):
+        mb.grad_chunk(m, 5)
+    with pytest.raises(L.FmxError, match="out of range"):
+        mb.apply_chunk(-1, 0, True)
+    with pytest.raises(L.FmxError, match="FMX_MODE_SEQUENTIAL"):
+        mb.als_train(m, 1)
+    mc = engine.Engine(p, num_factor=2, solver=L.SOLVER_MCMC, task=L.TASK_REGRESSION, mode=L.MODE_SEQUENTIAL)
+    with pytest.raises(ValueError, match="std_gammas"):
+        mc.mcmc_train(m, 2, np.ones((2, 2)), np.zeros((2, 3)))
+    assert L.lib().fmx_mcmc_train(mc.h, m.h, C.c_int32(2), None, None, None) == L.ERR_INVALID
+    with pytest.raises(L.FmxError, match="unknown link"):
+        seq.predict(m, 7)
+    with pytest.raises(L.FmxError, match="Unknown solver"):
+        engine.Engine(p, solver=400)
+    with pytest.raises(L.FmxError, match="TDAP solver runs in FMX_MODE_SEQUENTIAL"):
+        engine.Engine(p, solver=L.SOLVER_TDAP, mode=L.MODE_MINIBATCH)
