@@ -44,8 +44,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
-    ap.add_argument("--exchange-chunks", type=int, default=8,
-                    help="N > 1: blocks of features the exchange is pipelined in (1: one all-reduce of the whole buffer per step)")
+    ap.add_argument("--exchange-chunks", type=int, default=0,
+                    help="N > 1: blocks of features the exchange is pipelined in (1: one all-reduce of the whole buffer per step; "
+                         "0: 8 blocks on 2 GPUs, where the single xGMI link is the bound and finer blocks hide more of it, 4 otherwise, "
+                         "where the extra launches of finer blocks cost more than they hide: profiles/r01_split_bench.json)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--cpu-rows", type=int, default=5_000_000, help="rows of the CPU-baseline sample (0: skip)")
     return ap.parse_args()
@@ -161,7 +163,7 @@ def main():
     e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=solver, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
                       l1_w1=1e-4 if args.solver == "ftrl" else 0.0, l1_v=1e-4 if args.solver == "ftrl" else 0.0,
                       mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=args.tile_rows, device=local_rank, keep_w1=0 if args.no_linear else 1,
-                      state_fp64=int(args.state_fp64), exchange_chunks=args.exchange_chunks if world > 1 else 0)
+                      state_fp64=int(args.state_fp64), exchange_chunks=(args.exchange_chunks or (8 if world == 2 else 4)) if world > 1 else 0)
     v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
     e.set_params(0.0, None, v0.astype(np.float64))
     nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work
