@@ -2,7 +2,8 @@
  * fmx.h -- C ABI of the MI355X-native Factorization Machine engine (libfmx.so).
  *
  * This is the drop-in boundary for ONE path of evanwang1990/FMwR: the degree-2 FM forward and the
- * SGD / FTRL-Proximal training step (plus the ALS V-column sweep).  It replaces what the Rcpp entry
+ * SGD / FTRL-Proximal / TDAP training step, plus the ALS / MCMC learners (V-column sweep, w0 / w loops,
+ * probit tables) and the tracker that call the same forward.  It replaces what the Rcpp entry
  * points FM() / FMPredict() do between unmarshalling the R lists and marshalling the result
  * (reference src/FM.cpp:7-173, :177-214), i.e. the seam
  *
