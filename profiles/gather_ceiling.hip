@@ -80,5 +80,42 @@ int main() {
     }
     CK(hipFree(table)); CK(hipFree(side));
   }
+  // Two gather kernels at once on two streams (a 64 MB and a 16 MB table: phase 1 of one tile beside phase 2 of another):
+  // does the memory system serve more random rows in total than one kernel draws alone?
+  {
+    const uint32_t rows_a = 64u * 1024 * 1024 / 64, rows_b = 16u * 1024 * 1024 / 64;
+    float4 *ta, *tb, *out_b; float* side; uint32_t* idx_b;
+    CK(hipMalloc(&ta, (size_t)rows_a * 64)); CK(hipMalloc(&tb, (size_t)rows_b * 64)); CK(hipMalloc(&side, (size_t)rows_a * 4));
+    CK(hipMalloc(&out_b, n_out * 4 * sizeof(float4))); CK(hipMalloc(&idx_b, n_idx * sizeof(uint32_t)));
+    CK(hipMemset(ta, 0, (size_t)rows_a * 64)); CK(hipMemset(tb, 0, (size_t)rows_b * 64));
+    uint64_t x = 1234567ull;
+    for (int64_t i = 0; i < n_idx; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = (uint32_t)((x >> 11) % rows_a); }
+    CK(hipMemcpy(idx, h.data(), n_idx * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (int64_t i = 0; i < n_idx; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = (uint32_t)((x >> 11) % rows_b); }
+    CK(hipMemcpy(idx_b, h.data(), n_idx * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    const dim3 grid((unsigned)((n_out * 4 + 255) / 256)), block(256);
+    auto run = [&](bool concurrent, int reps) {
+      CK(hipDeviceSynchronize());
+      hipEvent_t a, b;
+      CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      CK(hipEventRecord(a, s1));
+      for (int i = 0; i < reps; ++i) {
+        hipLaunchKernelGGL((gather_k<4, false>), grid, block, 0, s1, ta, side, idx, per_out, n_out, out);
+        hipLaunchKernelGGL((gather_k<4, false>), grid, block, 0, concurrent ? s2 : s1, tb, side, idx_b, per_out, n_out, out_b);
+      }
+      CK(hipStreamSynchronize(s2));
+      CK(hipEventRecord(b, s1));
+      CK(hipEventSynchronize(b));
+      float ms = 0.f;
+      CK(hipEventElapsedTime(&ms, a, b));
+      return ms / reps;
+    };
+    run(false, 5); run(true, 5);
+    const float serial = run(false, 40), conc = run(true, 40);
+    printf("64 MB + 16 MB tables, one launch each: back to back %.4f ms, on two streams %.4f ms (%.1f G rows/s in total)\n", serial, conc,
+           2.0 * n_idx / (conc * 1e-3) / 1e9);
+  }
   return 0;
 }
