@@ -38,16 +38,15 @@ __global__ void unpack_entries_k(const uint64_t* __restrict__ packed, int64_t cn
   vals[i] = __uint_as_float((uint32_t)v);
 }
 
+// Offsets of the per-feature lists from the sorted columns: the last entry of a run of equal columns knows where the run
+// ends (ptr[col + 1] = its index + 1, everything else 0); a running maximum then carries each end over the features that
+// have no entry.  Two passes over the p + 1 offsets instead of a binary search per feature (33 M searches in a 10 M-entry
+// tile cost 0.64 ms at configs[3]'s shape; this costs 0.1 ms).
 template <typename OffT>
-__global__ void feature_offsets_k(const uint32_t* __restrict__ sorted_cols, int64_t cnt, uint32_t p, OffT* __restrict__ ptr) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > (int64_t)p) return;
-  int64_t lo = 0, hi = cnt;  // lower_bound(sorted_cols, j)
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)sorted_cols[mid] < j) lo = mid + 1; else hi = mid;
-  }
-  ptr[j] = (OffT)lo;
+__global__ void run_ends_k(const uint32_t* __restrict__ sorted_cols, int64_t cnt, OffT* __restrict__ ptr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  if (i == cnt - 1 || sorted_cols[i + 1] != sorted_cols[i]) ptr[(size_t)sorted_cols[i] + 1] = (OffT)(i + 1);
 }
 
 __global__ void gather_i64_k(const int64_t* __restrict__ src, int64_t stride, int64_t n, int64_t count, int64_t* __restrict__ dst) {
@@ -68,8 +67,10 @@ struct SortScratch {
   uint64_t *vals_in = nullptr, *vals_out = nullptr;
   void* temp = nullptr;
   size_t temp_bytes = 0;
+  void* scan_temp = nullptr;  // running-maximum pass over the p + 1 offsets
+  size_t scan_bytes = 0;
   ~SortScratch() {
-    (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(temp);
+    (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(temp); (void)hipFree(scan_temp);
   }
 };
 
@@ -93,7 +94,20 @@ static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r
     FMX_HIP(rocprim::radix_sort_pairs(s.temp, s.temp_bytes, m->col + base, s.keys_out, s.vals_in, s.vals_out, (size_t)cnt, 0, bits, stream));
     hipLaunchKernelGGL(unpack_entries_k, dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, stream, s.vals_out, cnt, out_rows, out_vals);
   }
-  hipLaunchKernelGGL((feature_offsets_k<OffT>), dim3((unsigned)(((int64_t)m->p + 1 + T - 1) / T)), dim3(T), 0, stream, s.keys_out, cnt, m->p, out_ptr);
+  const size_t np1 = (size_t)m->p + 1;
+  FMX_HIP(hipMemsetAsync(out_ptr, 0, np1 * sizeof(OffT), stream));
+  if (cnt > 0) hipLaunchKernelGGL((run_ends_k<OffT>), dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, stream, s.keys_out, cnt, out_ptr);
+  size_t need = 0;
+  FMX_HIP(rocprim::inclusive_scan(nullptr, need, out_ptr, out_ptr, np1, rocprim::maximum<OffT>(), stream));
+  if (need < 16) need = 16;  // a null scratch pointer would mean "size query"
+  if (need > s.scan_bytes) {
+    FMX_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(s.scan_temp); s.scan_temp = nullptr; s.scan_bytes = 0;
+    FMX_HIP(hipMalloc(&s.scan_temp, need));
+    s.scan_bytes = need;
+  }
+  need = s.scan_bytes;
+  FMX_HIP(rocprim::inclusive_scan(s.scan_temp, need, out_ptr, out_ptr, np1, rocprim::maximum<OffT>(), stream));
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
