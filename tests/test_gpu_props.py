@@ -131,3 +131,61 @@ def test_full_size_training_is_reproducible_and_lr0_is_identity(fm, big):
     e.sync()
     w0, w, v = e.get_params()
     assert w0 == 0.5 and np.all(w == 0) and np.array_equal(v, v0)
+
+
+def test_full_size_tiling_and_exchange_forms_agree(fm, big):
+    """At full size: a 1 048 576-row step cut into 4 or 2 tiles, run fused, through the grad/apply split, and through the
+    pipelined split (8 blocks) -- the same step.  Splits are bitwise equal to each other; tile counts and the fused form
+    differ only in the association of the tile sums (fp32 exchange buffer)."""
+    engine, L = fm
+    v0 = np.random.default_rng(5).normal(0, 0.01, (K, P)).astype(np.float32).astype(np.float64)
+    kw = dict(num_factor=K, mode=L.MODE_MINIBATCH, batch_rows=1 << 20, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4)
+    def run(form, **extra):
+        e = engine.Engine(P, **dict(kw, **extra)); e.set_params(0.0, None, v0)
+        for b in (0, 3):
+            if form == "fused":
+                e.step(big, b)
+            elif form == "split":
+                e.grad(big, b); e.apply(0)
+            else:
+                e.grad_begin(big, b)
+                nc = e.grad_layout()[0]
+                for c in range(nc):
+                    e.grad_chunk(big, c)
+                for c in range(nc):
+                    e.apply_chunk(c, 0, c == nc - 1)
+        e.sync()
+        return e.get_params()
+    fused4 = run("fused")
+    fused2 = run("fused", tile_rows=1 << 19)
+    split = run("split")
+    chunked = run("chunked", exchange_chunks=8)
+    split8 = run("split", exchange_chunks=8)
+    assert chunked[0] == split8[0] and np.array_equal(chunked[1], split8[1]) and np.array_equal(chunked[2], split8[2])
+    scale = np.max(np.abs(fused4[2]))
+    for other in (fused2, split, chunked):
+        assert np.max(np.abs(other[2] - fused4[2])) < 2e-6 * scale
+        assert np.max(np.abs(other[1] - fused4[1])) < 2e-6 * max(np.max(np.abs(fused4[1])), 1e-6)
+        assert abs(other[0] - fused4[0]) < 1e-9
+
+
+def test_full_size_sequential_window_equals_one_wave(fm, big):
+    """The reference's algorithm over 150 000 examples of the full-size matrix (random strides 1..3): the windowed kernel
+    (groups of ~8 feature-disjoint examples) and the strictly serial one-wave kernel give bitwise the same model."""
+    import os
+    engine, L = fm
+    import oracle
+    order = oracle.visit_order(N, 3, 150_000, seed=11)
+    v0 = np.random.default_rng(6).normal(0, 0.01, (K, P))
+    out = []
+    for win in ("1", "0"):
+        os.environ["FMX_SEQ_WINDOW"] = win
+        try:
+            e = engine.Engine(P, solver=L.SOLVER_FTRL, num_factor=K, l1_w1=1e-4, l1_v=1e-4, l2_w1=1e-4, l2_v=1e-4, mode=L.MODE_SEQUENTIAL)
+            e.set_params(0.0, None, v0)
+            e.train_order(big, order)
+            out.append(e.get_params())
+        finally:
+            os.environ.pop("FMX_SEQ_WINDOW", None)
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.any(out[0][2] != v0)
