@@ -67,3 +67,106 @@ def test_als_update_v_decreases_squared_error():
     fresh = oracle.predict_batch(P, X, w0, w, v1) - y
     # (only to ~1e-7: the reference squares x in FLOAT, `val_ * val_`, MCMC_ALS_Learner.h:314,345, and the oracle keeps that)
     np.testing.assert_allclose(e1, fresh, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent pins ("what's weak" 1): the reference holds no golden vectors for the solvers, so the oracle's
+# gradient and update formulas are additionally checked against quantities that need NO restatement of the reference:
+# the loss itself (finite differences of -log sigma(y*y_hat) / 0.5*(y_hat - y)^2 through an O(z^2) pairwise forward that
+# never uses the sum-of-squares trick) and the closed-form FTRL-Proximal minimiser.
+
+def _pairwise_forward(w0, w, v, c, x):
+    """y_hat = w0 + sum_i w_i x_i + sum_{a<b} <v_a, v_b> x_a x_b, straight from the FM model definition."""
+    out = w0 + float(np.dot(w[c], x))
+    for a in range(len(c)):
+        for b in range(a + 1, len(c)):
+            out += float(np.dot(v[:, c[a]], v[:, c[b]])) * x[a] * x[b]
+    return out
+
+
+def _loss(task, y_hat, y):
+    if task == oracle.CLASSIFICATION:
+        return float(np.log1p(np.exp(-y * y_hat)))  # -log sigma(y * y_hat)
+    return 0.5 * (y_hat - y) ** 2
+
+
+def test_gradient_matches_finite_differences_of_the_loss():
+    """mult * x (w), mult * (s_f x - v x^2) (V) and mult (w0) of SGD_Learner.h:102-131 ARE dL/dtheta: central differences
+    of the loss through the pairwise forward agree to 1e-7 relative for every coordinate of every row."""
+    n, p, k = 25, 18, 5
+    rp, col, val = util.random_csr(n, p, 6, seed=11, empty_rows=True)
+    w0, w, v = util.params(p, k, seed=11, stdev=0.3, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    h = 1e-6
+    for task in (oracle.CLASSIFICATION, oracle.REGRESSION):
+        y = util.labels(n, 11, "classification" if task == oracle.CLASSIFICATION else "regression")
+        # wide target range: the regression clamp (A-12) is the identity here, so the loss is smooth
+        P = oracle.params(task=task, k=k, min_target=-1e9, max_target=1e9)
+        for i in range(n):
+            c = col[rp[i]:rp[i + 1]].astype(int); x = val[rp[i]:rp[i + 1]].astype(np.float64)
+            acc = oracle.batch_sums(P, X, y, w0, w, v.ravel(), i, i + 1)
+            f = lambda w0_, w_, v_: _loss(task, _pairwise_forward(w0_, w_, v_, c, x), float(y[i]))
+            fd0 = (f(w0 + h, w, v) - f(w0 - h, w, v)) / (2 * h)
+            assert abs(fd0 - acc["G0"]) <= 1e-7 * max(1.0, abs(fd0))
+            Gv = acc["Gv"].reshape(k, p)
+            for j in set(c.tolist()):
+                wp, wm = w.copy(), w.copy(); wp[j] += h; wm[j] -= h
+                fd = (f(w0, wp, v) - f(w0, wm, v)) / (2 * h)
+                assert abs(fd - acc["Gw"][j]) <= 1e-7 * max(1.0, abs(fd)), (task, i, j)
+                for fct in range(k):
+                    vp, vm = v.copy(), v.copy(); vp[fct, j] += h; vm[fct, j] -= h
+                    fd = (f(w0, w, vp) - f(w0, w, vm)) / (2 * h)
+                    assert abs(fd - Gv[fct, j]) <= 1e-7 * max(1.0, abs(fd)), (task, i, j, fct)
+            # coordinates the row does not hold get no gradient
+            untouched = np.setdiff1d(np.arange(p), c)
+            assert np.all(acc["Gw"][untouched] == 0.0) and np.all(Gv[:, untouched] == 0.0)
+
+
+def test_sgd_step_is_gradient_step_plus_lazy_l2():
+    """One oracle SGD example step == theta - lr*grad, then theta *= (1 - lr*reg) on the touched coordinates only
+    (SGD_Learner.h:106-135), with grad from the finite-difference-checked sums above."""
+    n, p, k = 12, 15, 3
+    rp, col, val = util.random_csr(n, p, 5, seed=12, empty_rows=False)
+    y = util.labels(n, 12)
+    w0, w, v = util.params(p, k, seed=12, stdev=0.2, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    lr, rw, rv, r0 = 0.07, 3e-3, 5e-3, 2e-3
+    P = oracle.params(k=k, learn_rate=lr, l2_regw=rw, l2_regv=rv, l2_reg0=r0)
+    for i in range(1, n):
+        acc = oracle.batch_sums(P, X, y, w0, w, v.ravel(), i, i + 1)
+        ref = oracle.sgd_learn(P, X, y, w0, w, v.ravel(), 1, order=np.array([i]))
+        c = np.unique(col[rp[i]:rp[i + 1]].astype(int))
+        w_exp = w.copy(); w_exp[c] = (w[c] - lr * acc["Gw"][c]); w_exp[c] -= lr * rw * w_exp[c]
+        v_exp = v.copy(); g = acc["Gv"].reshape(k, p)
+        v_exp[:, c] = v[:, c] - lr * g[:, c]; v_exp[:, c] -= lr * rv * v_exp[:, c]
+        assert abs(ref["w0"] - (w0 - lr * (acc["G0"] + r0 * w0))) < 1e-15
+        np.testing.assert_allclose(ref["w"], w_exp, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(ref["v"].reshape(k, p), v_exp, rtol=0, atol=1e-15)
+
+
+def test_ftrl_prox_is_the_argmin_of_its_objective():
+    """FTRL_Learner.h:177-182: theta* = argmin_t  z*t + 0.5*((beta + sqrt(n))/alpha + l2)*t^2 + l1*|t|  -- checked by brute
+    force on a grid around the closed form (McMahan et al. 2013, eq. 3), after one oracle FTRL example step."""
+    n, p, k = 8, 10, 2
+    rp, col, val = util.random_csr(n, p, 4, seed=13, empty_rows=False)
+    y = util.labels(n, 13)
+    w0, w, v = util.params(p, k, seed=13, stdev=0.4, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    a, b, l1, l2 = 0.3, 0.7, 0.02, 0.05
+    P = oracle.params(k=k, alpha_w=a, alpha_v=a, beta_w=b, beta_v=b, l1_regw=l1, l1_regv=l1, l2_regw=l2, l2_regv=l2)
+    i = 3
+    acc = oracle.batch_sums(P, X, y, w0, w, v.ravel(), i, i + 1)
+    ref = oracle.ftrl_learn(P, X, y, w0, w, v.ravel(), 1, order=np.array([i]))
+    c = np.unique(col[rp[i]:rp[i + 1]].astype(int))
+    g = acc["Gv"].reshape(k, p)
+    for j in c:
+        for fct in range(k):
+            nn = g[fct, j] ** 2                      # n after the first touch (n_old = 0)
+            z = g[fct, j] - v[fct, j] * np.sqrt(nn) / a  # z += g - sigma*theta, sigma = (sqrt(n_new) - 0)/alpha
+            curv = (b + np.sqrt(nn)) / a + l2
+            got = ref["v"].reshape(k, p)[fct, j]
+            obj = lambda t: z * t + 0.5 * curv * t * t + l1 * abs(t)
+            grid = got + np.linspace(-1e-3, 1e-3, 2001)
+            assert obj(got) <= np.min([obj(t) for t in grid]) + 1e-15
+            if abs(z) <= l1:
+                assert got == 0.0
