@@ -245,6 +245,17 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_
 // `sin` (the step's start state) and only this function writes `sout`; the host flips the two after the launch.
 // mode: SCALAR_FUSED reduce + update, SCALAR_PUBLISH reduce only -> exchange-buffer tail, SCALAR_FROM_TAIL update from the
 // (all-reduced) tail.
+// The row count travels in the exchange tail as two parts, rows = hi * 4096 + lo: each part (and its sum over the ranks)
+// stays far below 2^24, so an fp32 all-reduce(sum) carries global batches of up to 2^36 rows exactly.
+template <typename ST>
+__device__ __forceinline__ void tail_put_rows(ST* gtail, double rows) {
+  const double hi = floor(rows / 4096.0);
+  gtail[2] = (ST)hi;
+  gtail[3] = (ST)(rows - hi * 4096.0);
+}
+template <typename ST>
+__device__ __forceinline__ double tail_get_rows(const ST* gtail) { return (double)gtail[2] * 4096.0 + (double)gtail[3]; }
+
 template <typename ST>
 __device__ __forceinline__ void scalar_update(const double* __restrict__ partials, int64_t n_partials, const double* sin,
                                               double* sout, ST* gtail, const Hyper& h, double rows, int mode,
@@ -262,8 +273,8 @@ __device__ __forceinline__ void scalar_update(const double* __restrict__ partial
   }
   if (threadIdx.x != 0) return;
   g0 = sg[0]; q0 = sq[0];
-  if (phase == 1) { gtail[0] = (ST)g0; gtail[1] = (ST)q0; gtail[2] = (ST)rows; gtail[3] = (ST)0; return; }
-  if (phase == 2) { g0 = gtail[0]; q0 = gtail[1]; if (rows <= 0.0) rows = gtail[2]; }
+  if (phase == 1) { gtail[0] = (ST)g0; gtail[1] = (ST)q0; tail_put_rows(gtail, rows); return; }
+  if (phase == 2) { g0 = gtail[0]; q0 = gtail[1]; if (rows <= 0.0) rows = tail_get_rows(gtail); }
   for (int i = 0; i < SC_COUNT; ++i) sout[i] = sin[i];
   sout[SC_G0] = g0; sout[SC_Q0] = q0;
   if (h.mean && rows > 0.0) {  // FMX_REDUCE_MEAN: w0 occurs in every example -> one step with the batch-mean multiplier
@@ -305,8 +316,17 @@ struct ColsTables {
   int has_q;
   uint32_t gb_feats;         // features per exchange-buffer block
   int64_t gb_block_elems;    // elements per block
-  int64_t gb_tail;           // element offset of the tail  // exchange buffer carries the sum-of-squares planes (FTRL with FMX_REDUCE_SUM only)
+  ST* gtail;                 // the 4-element tail {sum mult, sum mult^2, rows hi, rows lo}: end of gbuf, or the compact exchange's own
+  ST* crec;                  // compact exchange: one record per occurring feature (see record layout below)
+  int rec_elems;             // elements per record
 };
+
+// Compact exchange record of one occurring feature (fmx_grad_compact): G[KP] | (has_q: Q[KP]) | Gw | Qw | cnt | id.
+// The id travels as a bit pattern (a collective that only moves bytes keeps it; records are all-gathered, never summed).
+__device__ __forceinline__ float id_to_elem(uint32_t id, float) { return __uint_as_float(id); }
+__device__ __forceinline__ double id_to_elem(uint32_t id, double) { return __longlong_as_double((long long)id); }
+__device__ __forceinline__ uint32_t elem_to_id(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint32_t elem_to_id(double v) { return (uint32_t)__double_as_longlong(v); }
 
 // solver/SGD_Learner.h:195-204
 __device__ __forceinline__ void apply_penalty(double& theta, double u, double& q) {
@@ -390,7 +410,7 @@ __device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const V
 // kernel (short lists) and the long-list finisher.  Called by every lane of the feature's group; lig == 0 handles w.
 template <typename ST, int LPR, int KIND>
 __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, const ColsTables<ST>& T, int64_t j, int lig, const double* vf,
-                                            CoordSums& s, double rows) {
+                                            CoordSums& s, double rows, int64_t ci = 0) {
   using vec_t = typename Slice<ST>::vec;
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
@@ -428,6 +448,18 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
         gCN[r] = (ST)s.cnt;
         if (NEED_Q && T.has_q) gQW[r] = (ST)s.Qw;
       }
+    }
+  }
+  if (a.store_compact) {  // record ci of the compact exchange: the sums of one occurring feature
+    ST* rec = T.crec + (size_t)ci * T.rec_elems;
+    *reinterpret_cast<vec_t*>(rec + lig * VEC) = slice_make(s.G, ST());
+    const int qo = (NEED_Q && T.has_q) ? KP : 0;
+    if (qo) *reinterpret_cast<vec_t*>(rec + KP + lig * VEC) = slice_make(s.Q, ST());
+    if (lig == 0) {
+      rec[KP + qo] = (ST)s.Gw;
+      rec[KP + qo + 1] = (ST)(qo ? s.Qw : 0.0);
+      rec[KP + qo + 2] = (ST)s.cnt;
+      rec[KP + qo + 3] = id_to_elem((uint32_t)j, ST());
     }
   }
   // untouched coordinates keep their value (lazy regularisation, SURVEY A-10)
@@ -493,7 +525,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
 
 template <typename ST, int LPR>
 __device__ __forceinline__ ST* exchange_tail(const ColsTables<ST>& T) {
-  return T.gbuf ? T.gbuf + T.gb_tail : nullptr;
+  return T.gtail;
 }
 
 // Main phase-2 kernel: one group of LPR lanes per feature list.  Lists longer than a.long_min entries (heavy hitters of a
@@ -581,9 +613,9 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   }
   ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
-  if (a.apply && a.load_gbuf && rows <= 0.0) rows = gtail[2];  // the global row count travelled in the reduced buffer
+  if (a.apply && a.load_gbuf && rows <= 0.0) rows = tail_get_rows(gtail);  // the global row count travelled in the reduced buffer
 
-  if (have) cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
+  if (have) cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows, I0 + gid);
 
   if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
     scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
@@ -697,8 +729,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
   if (sub != 0) return;
   ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
-  if (a.apply && a.load_gbuf && rows <= 0.0) rows = gtail[2];
-  cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
+  if (a.apply && a.load_gbuf && rows <= 0.0) rows = tail_get_rows(gtail);
+  cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows, la.lpos ? (int64_t)la.lpos[i] : j);
 }
 
 template <typename ST, int KIND>
@@ -739,28 +771,177 @@ static int launch_cols_state(fmx_engine* e, const ColsArgs& a, const LongArgs& l
   }
 }
 
+template <typename ST>
+static ColsTables<ST> cols_tables(fmx_engine* e, const ColsArgs& a, int has_q) {
+  constexpr bool W = sizeof(ST) == 8;
+  ColsTables<ST> T{};
+  T.V = (ST*)(W ? (void*)e->dV : (void*)e->V); T.w = (ST*)(W ? (void*)e->dw : (void*)e->w);
+  T.sV = (ST*)(W ? (void*)e->dsV : (void*)e->sV); T.sw = (ST*)(W ? (void*)e->dsw : (void*)e->sw);
+  T.nV = (ST*)(W ? (void*)e->dnV : (void*)e->nV); T.nw = (ST*)(W ? (void*)e->dnw : (void*)e->nw);
+  const int kp = W ? e->kp64 : e->kp32;
+  T.S = (const ST*)e->S + (size_t)a.s_row0 * kp;
+  T.amul = (const ST*)e->amul + a.s_row0;
+  T.scal = e->scal; T.scal_out = e->scal_next; T.partials = e->partials; T.n_partials = a.n_partials;
+  T.gbuf = (ST*)e->gbuf; T.p = (uint32_t)e->p; T.has_q = has_q;
+  T.gb_feats = (uint32_t)e->gb_feats; T.gb_block_elems = e->gb_block_elems;
+  // the tail lives at the end of the dense exchange buffer, or alone for the compact exchange (no p-sized buffer there)
+  T.gtail = a.compact_tail ? (ST*)e->ctail : (e->gbuf ? (ST*)e->gbuf + e->gb_blocks * e->gb_block_elems : nullptr);
+  T.crec = (ST*)e->crec;
+  T.rec_elems = e->rec_elems;
+  return T;
+}
+
 int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) {
   ColsArgs a = a_in;
   if (a.f1 == 0 && a.f0 == 0) a.f1 = (uint32_t)e->p;  // the whole feature range
   FMX_CHECK(a.f0 <= a.f1 && a.f1 <= e->p && !(a.tfeat && (a.f0 != 0 || a.f1 != e->p)), FMX_ERR_INVALID, "bad feature range [%u, %u)", a.f0, a.f1);
-  FMX_CHECK(!(a.load_gbuf || a.store_gbuf || a.scalar == SCALAR_PUBLISH || a.scalar == SCALAR_FROM_TAIL) || e->gbuf != nullptr,
+  FMX_CHECK(!(a.load_gbuf || a.store_gbuf || ((a.scalar == SCALAR_PUBLISH || a.scalar == SCALAR_FROM_TAIL) && !a.compact_tail)) || e->gbuf != nullptr,
             FMX_ERR_STATE, "exchange buffer not allocated");
+  FMX_CHECK(!(a.store_compact || a.compact_tail) || (e->ctail != nullptr && (!a.store_compact || e->crec != nullptr)), FMX_ERR_STATE, "compact exchange buffers not allocated");
   const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
   if (mb_wide(e)) {
-    ColsTables<double> T{e->dV, e->dw, e->dsV, e->dsw, e->dnV, e->dnw, (const double*)e->S + (size_t)a.s_row0 * e->kp64,
-                         (const double*)e->amul + a.s_row0, e->scal, e->scal_next, e->partials, a.n_partials, (double*)e->gbuf, (uint32_t)e->p, has_q,
-                         (uint32_t)e->gb_feats, e->gb_block_elems, e->gb_blocks * e->gb_block_elems};
+    ColsTables<double> T = cols_tables<double>(e, a, has_q);
     st = launch_cols_state<double>(e, a, la, T);
   } else {
-    ColsTables<float> T{e->V, e->w, e->sV, e->sw, e->nV, e->nw, (const float*)e->S + (size_t)a.s_row0 * e->kp32,
-                        (const float*)e->amul + a.s_row0, e->scal, e->scal_next, e->partials, a.n_partials, (float*)e->gbuf, (uint32_t)e->p, has_q,
-                        (uint32_t)e->gb_feats, e->gb_block_elems, e->gb_blocks * e->gb_block_elems};
+    ColsTables<float> T = cols_tables<float>(e, a, has_q);
     st = launch_cols_state<float>(e, a, la, T);
   }
   prof_end(e);
   if (st == FMX_OK && (a.scalar == SCALAR_FUSED || a.scalar == SCALAR_FROM_TAIL)) std::swap(e->scal, e->scal_next);  // the kernel wrote the next step's scalars
+  return st;
+}
+
+// ------------------------------------------------------------------------------------------------ compact exchange
+// The update half of a step whose gradient sums arrive as RECORDS (one per feature per rank that saw the feature) instead of
+// the dense p-sized buffer: the records of all ranks, concatenated in rank order, have been stably sorted by feature id
+// (fm_ingest.hip: merge_records), so list i holds the positions of feature rfeat[i]'s records in ascending rank order.  One
+// lane group per feature adds them in that order -- the same sums, in the same order, as the dense all-reduce of two ranks --
+// and finishes the feature through cols_finish() like every other phase-2 path.
+struct RecArgs {
+  const void* recs;        // all parts; record r at recs + r * rec_elems
+  const uint32_t* pos;     // [total] record positions sorted by (feature, part)
+  const uint32_t* roff;    // [n + 1] list offsets into pos
+  const uint32_t* rfeat;   // [n] feature ids, ascending
+  const uint32_t* d_n;     // device: number of lists
+};
+
+template <typename ST, int LPR, int KIND>
+__global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, ColsArgs a, Hyper h, ColsTables<ST> T) {
+  using vec_t = typename Slice<ST>::vec;
+  constexpr int VEC = Slice<ST>::N;
+  constexpr int KP = LPR * VEC;
+  constexpr int FPW = WG_THREADS / LPR;
+  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  __shared__ double red_g[WG_THREADS], red_q[WG_THREADS];
+  const int gid = threadIdx.x / LPR, lig = threadIdx.x % LPR;
+  const int64_t n = (int64_t)*r.d_n;
+  const int64_t i = (int64_t)blockIdx.x * FPW + gid;
+  ST* gtail = exchange_tail<ST, LPR>(T);
+  if (i < n) {
+    const int64_t j = r.rfeat[i];
+    double vf[VEC];
+    slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
+    const int qo = (NEED_Q && T.has_q) ? KP : 0;
+    const ST* recs = reinterpret_cast<const ST*>(r.recs);
+    // The parts are added in the exchange's element type, in rank order: exactly what an all-reduce(sum) of the dense buffer
+    // does with two ranks (one addition per element), so both forms of the exchange give the same bits.
+    ST aG[VEC], aQ[VEC], aGw = (ST)0, aQw = (ST)0, aC = (ST)0;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { aG[q] = (ST)0; aQ[q] = (ST)0; }
+    for (uint32_t t = r.roff[i]; t < r.roff[i + 1]; ++t) {
+      const ST* rec = recs + (size_t)r.pos[t] * T.rec_elems;
+      double g[VEC];
+      slice_get(*reinterpret_cast<const vec_t*>(rec + lig * VEC), g);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) aG[q] = aG[q] + (ST)g[q];
+      if (qo) {
+        slice_get(*reinterpret_cast<const vec_t*>(rec + KP + lig * VEC), g);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) aQ[q] = aQ[q] + (ST)g[q];
+      }
+      aGw = aGw + rec[KP + qo];
+      if (qo) aQw = aQw + rec[KP + qo + 1];
+      aC = aC + rec[KP + qo + 2];
+    }
+    CoordSums s;
+    sums_zero(s);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { s.G[q] = (double)aG[q]; s.Q[q] = (double)aQ[q]; }
+    s.Gw = (double)aGw; s.Qw = (double)aQw; s.cnt = (double)aC;
+    double rows = a.global_rows;
+    if (rows <= 0.0) rows = tail_get_rows(gtail);
+    cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
+  }
+  if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
+    scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
+}
+
+// sort keys of the concatenated parts: linear index i -> (part, local record) -> key = the record's feature id, value = its position
+template <typename ST>
+__global__ void record_keys_k(const ST* __restrict__ recs, int rec_elems, int id_at, const int64_t* __restrict__ prefix, int n_parts,
+                              int64_t stride, int64_t total, uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int part = 0;
+  while (part + 1 < n_parts && prefix[part + 1] <= i) ++part;
+  const int64_t at = (int64_t)part * stride + (i - prefix[part]);
+  keys[i] = elem_to_id(recs[(size_t)at * rec_elems + id_at]);
+  pos[i] = (uint32_t)at;
+}
+
+int launch_record_keys(fmx_engine* e, const void* recs, const int64_t* d_prefix, int n_parts, int64_t stride, int64_t total, uint32_t* keys, uint32_t* pos) {
+  if (total <= 0) return FMX_OK;
+  const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
+  const int id_at = mb_kp(e) * (1 + has_q) + 3;
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  if (mb_wide(e)) hipLaunchKernelGGL((record_keys_k<double>), g, b, 0, e->stream, (const double*)recs, e->rec_elems, id_at, d_prefix, n_parts, stride, total, keys, pos);
+  else hipLaunchKernelGGL((record_keys_k<float>), g, b, 0, e->stream, (const float*)recs, e->rec_elems, id_at, d_prefix, n_parts, stride, total, keys, pos);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+template <typename ST, int KIND>
+static int launch_records_kind(fmx_engine* e, const RecArgs& r, const ColsArgs& a, const ColsTables<ST>& T, int64_t max_lists) {
+  const int lpr = mb_lpr(e);
+  const int fpw = WG_THREADS / lpr;
+  const int64_t grid = max_lists > 0 ? (max_lists + fpw - 1) / fpw : 1;  // the list count is on the device: surplus workgroups leave at once
+  FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "apply_records: grid too large");
+  dim3 g((unsigned)grid), b(WG_THREADS);
+#define FMX_REC_CASE(L) case L: hipLaunchKernelGGL((fm_apply_records_k<ST, L, KIND>), g, b, 0, e->stream, r, a, e->hyper, T); break;
+  switch (lpr) {
+    FMX_REC_CASE(1) FMX_REC_CASE(2) FMX_REC_CASE(4) FMX_REC_CASE(8) FMX_REC_CASE(16) FMX_REC_CASE(32) FMX_REC_CASE(64)
+    default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", mb_kp(e));
+  }
+#undef FMX_REC_CASE
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+template <typename ST>
+static int launch_records_state(fmx_engine* e, const RecArgs& r, const ColsArgs& a, int64_t max_lists) {
+  const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
+  const ColsTables<ST> T = cols_tables<ST>(e, a, has_q);
+  switch (e->hyper.kind) {
+    case UPD_SGD_L2: return launch_records_kind<ST, UPD_SGD_L2>(e, r, a, T, max_lists);
+    case UPD_SGD_L1: return launch_records_kind<ST, UPD_SGD_L1>(e, r, a, T, max_lists);
+    default: return launch_records_kind<ST, UPD_FTRL>(e, r, a, T, max_lists);
+  }
+}
+
+int launch_apply_records(fmx_engine* e, const void* recs, const uint32_t* pos, const uint32_t* roff, const uint32_t* rfeat, const uint32_t* d_n,
+                         int64_t max_lists, int64_t global_rows) {
+  RecArgs r{recs, pos, roff, rfeat, d_n};
+  ColsArgs a{};
+  a.apply = 1;
+  a.scalar = SCALAR_FROM_TAIL;
+  a.compact_tail = 1;
+  a.global_rows = (double)global_rows;
+  prof_begin(e, FMX_KERNEL_COLS_UPDATE);
+  const int st = mb_wide(e) ? launch_records_state<double>(e, r, a, max_lists) : launch_records_state<float>(e, r, a, max_lists);
+  prof_end(e);
+  if (st == FMX_OK) std::swap(e->scal, e->scal_next);
   return st;
 }
 

@@ -84,7 +84,8 @@ static int sort_scratch_alloc(SortScratch& s, int64_t max_cnt, int bits, hipStre
   return FMX_OK;
 }
 
-// sort entries [base, base+cnt) of rows [r0, r0+nrows) by column (stable => rows stay ascending per column)
+// sort entries [base, base+cnt) of rows [r0, r0+nrows) by column (stable => rows stay ascending per column), then the
+// per-feature offsets of the whole range (the full CSC of the ALS sweep)
 template <typename OffT>
 static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r0, int64_t nrows, int64_t base, int64_t cnt,
                         uint32_t* out_rows, float* out_vals, OffT* out_ptr, hipStream_t stream) {
@@ -112,25 +113,227 @@ static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r
   return FMX_OK;
 }
 
-// flags[j] = feature j has at least one entry in the tile
-__global__ void touched_flags_k(const uint32_t* __restrict__ bptr, uint32_t p, uint8_t* __restrict__ flags) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < (int64_t)p) flags[j] = bptr[j + 1] > bptr[j];
+// ------------------------------------------------------------------------------------------------ tile plans
+// Everything below runs on the device without a host round trip, so that a streamed tile can be planned on one stream
+// while the previous tile trains on another (fmx_train_stream); the three counts are read back once per tile.
+
+// head[i] = entry i starts a new feature's run in the sorted columns
+__global__ void head_flags_k(const uint32_t* __restrict__ keys, int64_t cnt, uint8_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt) flags[i] = (i == 0) || (keys[i] != keys[i - 1]);
 }
 
-__global__ void max_list_len_k(const uint32_t* __restrict__ bptr, uint32_t p, uint32_t long_min, uint32_t* __restrict__ out) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < (int64_t)p) {
-    const uint32_t len = bptr[j + 1] - bptr[j];
-    if (len > long_min) atomicMax(out, len);
+// sparse directory: the run starts are in soff[0 .. n); add the ids and the end marker
+__global__ void lists_finish_k(const uint32_t* __restrict__ keys, uint32_t* __restrict__ soff, const uint32_t* __restrict__ dcounts,
+                               uint32_t cnt, uint32_t* __restrict__ feat) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = dcounts[0];
+  if (i < (int64_t)n) feat[i] = keys[soff[i]];
+  else if (i == (int64_t)n) soff[i] = cnt;
+}
+
+// flags[i] = list i holds more than long_min entries (lists beyond the directory's end: 0)
+__global__ void long_flags_k(const uint32_t* __restrict__ off, const uint32_t* __restrict__ dcount, uint32_t n_fixed, uint32_t n_max,
+                             uint32_t long_min, uint8_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_max) return;
+  const uint32_t n = dcount ? *dcount : n_fixed;
+  flags[i] = (i < (int64_t)n) && (off[i + 1] - off[i] > long_min);
+}
+
+__global__ void long_nseg_k(const uint32_t* __restrict__ off, const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ dcounts,
+                            uint32_t cap_long, uint32_t* __restrict__ nseg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > (int64_t)cap_long) return;
+  uint32_t v = 0;
+  if (i < (int64_t)dcounts[1]) { const uint32_t l = lpos[i]; v = (off[l + 1] - off[l] + LIST_SEG - 1) / LIST_SEG; }
+  nseg[i] = v;
+}
+
+// one thread per long list: its feature id and its segments
+__global__ void long_segments_k(const uint32_t* __restrict__ off, const uint32_t* __restrict__ feat, const uint32_t* __restrict__ lpos,
+                                const uint32_t* __restrict__ lseg_ptr, uint32_t* __restrict__ dcounts, uint32_t* __restrict__ lfeat,
+                                uint32_t* __restrict__ seg_list, uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_end) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_long = dcounts[1];
+  if (i == 0) dcounts[2] = lseg_ptr[n_long];
+  if (i >= (int64_t)n_long) return;
+  const uint32_t l = lpos[i];
+  lfeat[i] = feat ? feat[l] : l;
+  uint32_t sg = lseg_ptr[i];
+  for (uint32_t b = off[l]; b < off[l + 1]; b += LIST_SEG, ++sg) {
+    seg_list[sg] = (uint32_t)i;
+    seg_begin[sg] = b;
+    seg_end[sg] = b + LIST_SEG < off[l + 1] ? b + LIST_SEG : off[l + 1];
   }
 }
 
-__global__ void touched_offsets_k(const uint32_t* __restrict__ bptr, const uint32_t* __restrict__ tfeat, uint32_t n, uint32_t end,
-                                  uint32_t* __restrict__ toff) {
+// dense directory from a sparse one (no re-sort): off[feat[i] + 1] = soff[i + 1], then the running maximum
+__global__ void scatter_ends_k(const uint32_t* __restrict__ feat, const uint32_t* __restrict__ soff, uint32_t n, uint32_t* __restrict__ off) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (int64_t)n) toff[i] = bptr[tfeat[i]];
-  else if (i == (int64_t)n) toff[i] = end;
+  if (i < (int64_t)n) off[(size_t)feat[i] + 1] = soff[i + 1];
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void plan_free(fmx_matrix::TilePlan& t) {
+  (void)hipFree(t.pool);
+  if (t.off && !t.off_in_pool) (void)hipFree(t.off);
+  t = fmx_matrix::TilePlan{};
+}
+
+// one allocation holding every array of a plan for a tile of at most cap_cnt entries
+int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense) {
+  const uint32_t lm = list_long_min();
+  t.cap_lists = dense ? 0u : (uint32_t)((int64_t)p < cap_cnt ? (int64_t)p : cap_cnt);
+  t.cap_long = (uint32_t)(cap_cnt / ((int64_t)lm + 1) + 1);
+  t.cap_seg = (uint32_t)(cap_cnt / LIST_SEG + t.cap_long + 1);
+  size_t at = 0;
+  auto take = [&](size_t count) { const size_t o = at; at = align_up(at + count * sizeof(uint32_t), 256); return o; };
+  const size_t o_cnt = take(4);
+  const size_t o_off = dense ? take((size_t)p + 1) : 0;
+  const size_t o_feat = dense ? 0 : take(t.cap_lists ? t.cap_lists : 1);
+  const size_t o_soff = dense ? 0 : take((size_t)t.cap_lists + 1);
+  const size_t o_lfeat = take(t.cap_long), o_lpos = take(t.cap_long), o_lseg = take((size_t)t.cap_long + 2);
+  const size_t o_sl = take(t.cap_seg), o_sb = take(t.cap_seg), o_se = take(t.cap_seg);
+  FMX_HIP(hipMalloc(&t.pool, at));
+  char* b = (char*)t.pool;
+  t.dcounts = (uint32_t*)(b + o_cnt);
+  t.off = dense ? (uint32_t*)(b + o_off) : nullptr;
+  t.off_in_pool = dense ? 1 : 0;
+  t.feat = dense ? nullptr : (uint32_t*)(b + o_feat);
+  t.soff = dense ? nullptr : (uint32_t*)(b + o_soff);
+  t.lfeat = (uint32_t*)(b + o_lfeat); t.lpos = (uint32_t*)(b + o_lpos); t.lseg_ptr = (uint32_t*)(b + o_lseg);
+  t.seg_list = (uint32_t*)(b + o_sl); t.seg_begin = (uint32_t*)(b + o_sb); t.seg_end = (uint32_t*)(b + o_se);
+  return FMX_OK;
+}
+
+PlanWorkspace::~PlanWorkspace() {
+  (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(sort_temp); (void)hipFree(flags);
+  (void)hipFree(nseg); (void)hipFree(prim_temp);
+}
+
+int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
+  if (cnt <= max_cnt && p_ == p && keys_out) return FMX_OK;
+  FMX_HIP(hipStreamSynchronize(stream));
+  (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(sort_temp); (void)hipFree(flags);
+  (void)hipFree(nseg); (void)hipFree(prim_temp);
+  keys_out = nullptr; vals_in = vals_out = nullptr; sort_temp = nullptr; flags = nullptr; nseg = nullptr; prim_temp = nullptr;
+  max_cnt = 0;
+  const size_t m = (size_t)(cnt > 0 ? cnt : 1);
+  bits = col_bits(p_);
+  FMX_HIP(hipMalloc(&keys_out, m * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&vals_in, m * sizeof(uint64_t)));
+  FMX_HIP(hipMalloc(&vals_out, m * sizeof(uint64_t)));
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, keys_out, vals_in, vals_out, m, 0, bits, stream));
+  FMX_HIP(hipMalloc(&sort_temp, sort_bytes ? sort_bytes : 16));
+  const size_t nflag = m > (size_t)p_ ? m : (size_t)p_;
+  FMX_HIP(hipMalloc(&flags, nflag));
+  const size_t cap_long = m / ((size_t)list_long_min() + 1) + 1;
+  FMX_HIP(hipMalloc(&nseg, (cap_long + 2) * sizeof(uint32_t)));
+  // scratch of the device primitives: the largest of select over nflag items, max-scan over p + 1, sum-scan over cap_long + 1
+  size_t b1 = 0, b2 = 0, b3 = 0;
+  rocprim::counting_iterator<uint32_t> ids(0);
+  FMX_HIP(rocprim::select(nullptr, b1, ids, flags, (uint32_t*)nullptr, (uint32_t*)nullptr, nflag, stream));
+  FMX_HIP(rocprim::inclusive_scan(nullptr, b2, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)p_ + 1, rocprim::maximum<uint32_t>(), stream));
+  FMX_HIP(rocprim::exclusive_scan(nullptr, b3, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, cap_long + 1, rocprim::plus<uint32_t>(), stream));
+  prim_bytes = b1 > b2 ? b1 : b2;
+  if (b3 > prim_bytes) prim_bytes = b3;
+  if (prim_bytes < 16) prim_bytes = 16;
+  FMX_HIP(hipMalloc(&prim_temp, prim_bytes));
+  max_cnt = (int64_t)m;
+  p = p_;
+  return FMX_OK;
+}
+
+// Plan one tile: entries [t.base, t.base + t.cnt) of rows [t.r0, t.r0 + t.nrows), CSR arrays given explicitly (a streamed
+// tile has its own).  Enqueues on `stream`, never waits for it; t must come from plan_alloc with room for t.cnt entries.
+int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
+               uint32_t* brow, float* bval, hipStream_t stream) {
+  const int T = 256;
+  const int64_t cnt = t.cnt;
+  FMX_CHECK(cnt <= ws.max_cnt && p == ws.p, FMX_ERR_STATE, "plan workspace too small");
+  FMX_CHECK(cnt < (1LL << 32), FMX_ERR_INVALID, "a tile holds %lld nonzeros; at most 2^32-1 are supported (lower tile_rows)", (long long)cnt);
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + T - 1) / T)); };
+  if (cnt > 0) {
+    hipLaunchKernelGGL(pack_entries_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, ws.vals_in);
+    FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, ws.sort_bytes, col + t.base, ws.keys_out, ws.vals_in, ws.vals_out, (size_t)cnt, 0, ws.bits, stream));
+    hipLaunchKernelGGL(unpack_entries_k, grid(cnt), dim3(T), 0, stream, ws.vals_out, cnt, brow + t.base, bval + t.base);
+  }
+  FMX_HIP(hipMemsetAsync(t.dcounts, 0, 4 * sizeof(uint32_t), stream));
+  rocprim::counting_iterator<uint32_t> ids(0);
+  size_t tb = ws.prim_bytes;
+  const uint32_t* off;
+  uint32_t n_max;
+  if (t.off_in_pool) {  // dense directory
+    FMX_HIP(hipMemsetAsync(t.off, 0, ((size_t)p + 1) * sizeof(uint32_t), stream));
+    if (cnt > 0) hipLaunchKernelGGL((run_ends_k<uint32_t>), grid(cnt), dim3(T), 0, stream, ws.keys_out, cnt, t.off);
+    FMX_HIP(rocprim::inclusive_scan(ws.prim_temp, tb, t.off, t.off, (size_t)p + 1, rocprim::maximum<uint32_t>(), stream));
+    off = t.off; n_max = p;
+  } else {              // sparse directory: run starts -> soff, ids -> feat
+    if (cnt > 0) {
+      hipLaunchKernelGGL(head_flags_k, grid(cnt), dim3(T), 0, stream, ws.keys_out, cnt, ws.flags);
+      FMX_HIP(rocprim::select(ws.prim_temp, tb, ids, ws.flags, t.soff, t.dcounts, (size_t)cnt, stream));
+    }
+    hipLaunchKernelGGL(lists_finish_k, grid((int64_t)t.cap_lists + 1), dim3(T), 0, stream, ws.keys_out, t.soff, t.dcounts, (uint32_t)cnt, t.feat);
+    off = t.soff; n_max = t.cap_lists;
+  }
+  // long lists
+  if (cnt > (int64_t)list_long_min() && n_max > 0) {
+    hipLaunchKernelGGL(long_flags_k, grid(n_max), dim3(T), 0, stream, off, t.off_in_pool ? (const uint32_t*)nullptr : t.dcounts, p, n_max, list_long_min(), ws.flags);
+    tb = ws.prim_bytes;
+    FMX_HIP(rocprim::select(ws.prim_temp, tb, ids, ws.flags, t.lpos, t.dcounts + 1, (size_t)n_max, stream));
+    hipLaunchKernelGGL(long_nseg_k, grid((int64_t)t.cap_long + 1), dim3(T), 0, stream, off, t.lpos, t.dcounts, t.cap_long, ws.nseg);
+    tb = ws.prim_bytes;
+    FMX_HIP(rocprim::exclusive_scan(ws.prim_temp, tb, ws.nseg, t.lseg_ptr, 0u, (size_t)t.cap_long + 1, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(long_segments_k, grid(t.cap_long), dim3(T), 0, stream, off, t.off_in_pool ? (const uint32_t*)nullptr : t.feat, t.lpos, t.lseg_ptr, t.dcounts,
+                       t.lfeat, t.seg_list, t.seg_begin, t.seg_end);
+  }
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// the counts the builder left on the device -> host fields (the caller has waited for the stream)
+void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h) {
+  t.n_lists = t.off_in_pool ? p : h[0];
+  t.n_long = h[1];
+  t.n_seg = h[2];
+}
+
+// a dense directory for a tile planned with the sparse one (launches that walk the dense exchange buffer visit every feature)
+int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream) {
+  fmx_matrix::TilePlan& t = m->plans[(size_t)tile];
+  if (t.off) return FMX_OK;
+  const size_t np1 = (size_t)m->p + 1;
+  uint32_t* off = nullptr;
+  FMX_HIP(hipMalloc(&off, np1 * sizeof(uint32_t)));
+  void* tmp = nullptr;
+  size_t need = 0;
+  auto body = [&]() -> int {
+    FMX_HIP(hipMemsetAsync(off, 0, np1 * sizeof(uint32_t), stream));
+    if (t.n_lists > 0) hipLaunchKernelGGL(scatter_ends_k, dim3((t.n_lists + 255) / 256), dim3(256), 0, stream, t.feat, t.soff, t.n_lists, off);
+    FMX_HIP(rocprim::inclusive_scan(nullptr, need, off, off, np1, rocprim::maximum<uint32_t>(), stream));
+    FMX_HIP(hipMalloc(&tmp, need ? need : 16));
+    FMX_HIP(rocprim::inclusive_scan(tmp, need, off, off, np1, rocprim::maximum<uint32_t>(), stream));
+    FMX_HIP(hipStreamSynchronize(stream));
+    return FMX_OK;
+  };
+  const int st = body();
+  (void)hipFree(tmp);
+  if (st != FMX_OK) { (void)hipFree(off); return st; }
+  t.off = off;
+  t.off_in_pool = 0;
+  return FMX_OK;
+}
+
+void drop_plans(fmx_matrix* m) {
+  for (auto& t : m->plans) plan_free(t);
+  m->plans.clear();
+  m->step_first_tile.clear();
+  (void)hipFree(m->brow); (void)hipFree(m->bval);
+  m->brow = nullptr; m->bval = nullptr;
+  m->batch_rows = 0; m->tile_rows = 0; m->n_batches = 0; m->max_long_seg = 0; m->max_tile_cnt = 0;
+  m->plan_generation++;
 }
 
 __global__ void gather_rows_k(const int64_t* __restrict__ src, const int64_t* __restrict__ rows, int64_t count, int64_t* __restrict__ dst) {
@@ -138,161 +341,166 @@ __global__ void gather_rows_k(const int64_t* __restrict__ src, const int64_t* __
   if (i < count) dst[i] = src[rows[i]];
 }
 
+// Plans of every tile of the matrix for steps of batch_rows rows cut into tiles of at most tile_rows rows.  Built into
+// locals and committed to the matrix only when everything succeeded: a failure (out of memory is the expected one: the
+// sorted copy is as large as the matrix) leaves the matrix without plans, and the next call starts over.
 int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream) {
   FMX_CHECK(batch_rows > 0 && tile_rows > 0, FMX_ERR_INVALID, "batch_rows and tile_rows must be positive");
-  if (m->batch_rows == batch_rows && m->tile_rows == tile_rows && m->bptr) return FMX_OK;
+  if (m->batch_rows == batch_rows && m->tile_rows == tile_rows && !m->plans.empty()) return FMX_OK;
   FMX_HIP(hipSetDevice(m->device));
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff);
-  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->tfeat = nullptr; m->toff = nullptr;
+  drop_plans(m);
   // steps of batch_rows rows, each cut into tiles of at most tile_rows rows
   const int64_t nb = (m->n + batch_rows - 1) / batch_rows;
-  m->batch_rows = batch_rows;
-  m->tile_rows = tile_rows;
-  m->n_batches = nb;
-  m->tile_start.clear();
-  m->step_first_tile.assign((size_t)nb + 1, 0);
+  std::vector<int64_t> tile_start, step_first((size_t)nb + 1, 0);
   for (int64_t s = 0; s < nb; ++s) {
-    m->step_first_tile[(size_t)s] = (int64_t)m->tile_start.size();
+    step_first[(size_t)s] = (int64_t)tile_start.size();
     const int64_t end = (s + 1) * batch_rows < m->n ? (s + 1) * batch_rows : m->n;
-    for (int64_t r = s * batch_rows; r < end; r += tile_rows) m->tile_start.push_back(r);
+    for (int64_t r = s * batch_rows; r < end; r += tile_rows) tile_start.push_back(r);
   }
-  m->step_first_tile[(size_t)nb] = (int64_t)m->tile_start.size();
-  m->tile_start.push_back(m->n);
-  const int64_t nt = (int64_t)m->tile_start.size() - 1;
+  step_first[(size_t)nb] = (int64_t)tile_start.size();
+  tile_start.push_back(m->n);
+  const int64_t nt = (int64_t)tile_start.size() - 1;
+
+  struct Locals {  // released unless committed
+    std::vector<fmx_matrix::TilePlan> plans;
+    uint32_t* brow = nullptr; float* bval = nullptr;
+    int64_t *d_rows = nullptr, *d_ptr = nullptr;
+    uint32_t* h_counts = nullptr;
+    ~Locals() {
+      for (auto& t : plans) plan_free(t);
+      (void)hipFree(brow); (void)hipFree(bval); (void)hipFree(d_rows); (void)hipFree(d_ptr);
+      if (h_counts) (void)hipHostFree(h_counts);
+    }
+  } L;
   // row_ptr at the tile boundaries -> host
-  m->h_row_ptr_batches.assign((size_t)nt + 1, 0);
-  {
-    int64_t *d_rows = nullptr, *d = nullptr;
-    FMX_HIP(hipMalloc(&d_rows, ((size_t)nt + 1) * sizeof(int64_t)));
-    FMX_HIP(hipMalloc(&d, ((size_t)nt + 1) * sizeof(int64_t)));
-    FMX_HIP(hipMemcpyAsync(d_rows, m->tile_start.data(), ((size_t)nt + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(gather_rows_k, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), 0, stream, m->row_ptr, d_rows, nt + 1, d);
-    FMX_HIP(hipMemcpyAsync(m->h_row_ptr_batches.data(), d, ((size_t)nt + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FMX_HIP(hipStreamSynchronize(stream));
-    FMX_HIP(hipFree(d)); FMX_HIP(hipFree(d_rows));
-  }
+  std::vector<int64_t> h_ptr((size_t)nt + 1, 0);
+  FMX_HIP(hipMalloc(&L.d_rows, ((size_t)nt + 1) * sizeof(int64_t)));
+  FMX_HIP(hipMalloc(&L.d_ptr, ((size_t)nt + 1) * sizeof(int64_t)));
+  FMX_HIP(hipMemcpyAsync(L.d_rows, tile_start.data(), ((size_t)nt + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(gather_rows_k, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), 0, stream, m->row_ptr, L.d_rows, nt + 1, L.d_ptr);
+  FMX_HIP(hipMemcpyAsync(h_ptr.data(), L.d_ptr, ((size_t)nt + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  FMX_HIP(hipStreamSynchronize(stream));
   int64_t max_cnt = 0;
   for (int64_t t = 0; t < nt; ++t) {
-    const int64_t c = m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t];
+    const int64_t c = h_ptr[(size_t)t + 1] - h_ptr[(size_t)t];
     FMX_CHECK(c < (1LL << 32), FMX_ERR_INVALID, "a tile holds %lld nonzeros; at most 2^32-1 are supported (lower tile_rows)", (long long)c);
     if (c > max_cnt) max_cnt = c;
   }
-  FMX_HIP(hipMalloc(&m->bptr, (size_t)(nt > 0 ? nt : 1) * ((size_t)m->p + 1) * sizeof(uint32_t)));
-  FMX_HIP(hipMalloc(&m->brow, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(uint32_t)));
-  FMX_HIP(hipMalloc(&m->bval, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(float)));
-  const int bits = col_bits(m->p);
-  SortScratch s;
-  FMX_TRY(sort_scratch_alloc(s, max_cnt, bits, stream));
+  if (const char* f = getenv("FMX_TEST_FAIL_PLAN_BUILD")) {  // tests: an allocation failure halfway leaves no half-built cache
+    if (atoi(f) > 0) { setenv("FMX_TEST_FAIL_PLAN_BUILD", "0", 1); set_error("plan build failed (FMX_TEST_FAIL_PLAN_BUILD)"); return FMX_ERR_HIP; }
+  }
+  FMX_HIP(hipMalloc(&L.brow, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&L.bval, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(float)));
+  FMX_HIP(hipHostMalloc(&L.h_counts, (size_t)(nt > 0 ? nt : 1) * 4 * sizeof(uint32_t)));
+  PlanWorkspace ws;
+  FMX_TRY(ws.reserve(max_cnt, m->p, stream));
+  L.plans.resize((size_t)nt);
   for (int64_t t = 0; t < nt; ++t) {
-    const int64_t r0 = m->tile_start[(size_t)t];
-    const int64_t nrows = m->tile_start[(size_t)t + 1] - r0;
-    const int64_t base = m->h_row_ptr_batches[t], cnt = m->h_row_ptr_batches[t + 1] - base;
-    FMX_TRY(csc_of_range<uint32_t>(m, s, bits, r0, nrows, base, cnt, m->brow + base, m->bval + base,
-                                   m->bptr + (size_t)t * ((size_t)m->p + 1), stream));
-  }
-  // Long lists (heavy hitters of a skewed feature distribution): per tile the features whose list exceeds list_long_min() entries,
-  // each cut into segments of LIST_SEG entries (fm_batch_kernels.hip walks a segment with one wave).
-  (void)hipFree(m->lplan); m->lplan = nullptr;
-  m->long_tiles.assign((size_t)nt, fmx_matrix::LongTile{0, 0, 0, 0, 0, 0, 0});
-  m->max_long_seg = 0;
-  {
-    uint32_t* d_max = nullptr;
-    FMX_HIP(hipMalloc(&d_max, sizeof(uint32_t)));
-    std::vector<uint32_t> plan;  // all tiles: lfeat | lseg_ptr | seg_feat | seg_begin | seg_end
-    std::vector<uint32_t> hb((size_t)m->p + 1);
-    for (int64_t t = 0; t < nt; ++t) {
-      const uint32_t* tb = m->bptr + (size_t)t * ((size_t)m->p + 1);
-      uint32_t h = 0;
-      FMX_HIP(hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream));
-      hipLaunchKernelGGL(max_list_len_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream, tb, m->p, list_long_min(), d_max);
-      FMX_HIP(hipMemcpyAsync(&h, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      FMX_HIP(hipStreamSynchronize(stream));
-      if (h == 0) continue;  // no list above list_long_min() in this tile
-      FMX_HIP(hipMemcpy(hb.data(), tb, hb.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-      std::vector<uint32_t> lfeat, lseg{0}, sfeat, sbeg, send;
-      for (uint32_t j = 0; j < m->p; ++j) {
-        const uint32_t len = hb[j + 1] - hb[j];
-        if (len <= list_long_min()) continue;
-        const uint32_t li = (uint32_t)lfeat.size();
-        lfeat.push_back(j);
-        for (uint32_t b = hb[j]; b < hb[j + 1]; b += LIST_SEG) {
-          sfeat.push_back(li);
-          sbeg.push_back(b);
-          send.push_back(b + LIST_SEG < hb[j + 1] ? b + LIST_SEG : hb[j + 1]);
-        }
-        lseg.push_back((uint32_t)sfeat.size());
-      }
-      auto& lt = m->long_tiles[(size_t)t];
-      lt.n_long = (int64_t)lfeat.size(); lt.n_seg = (int64_t)sfeat.size();
-      lt.off_lfeat = (int64_t)plan.size(); plan.insert(plan.end(), lfeat.begin(), lfeat.end());
-      lt.off_lseg = (int64_t)plan.size(); plan.insert(plan.end(), lseg.begin(), lseg.end());
-      lt.off_sfeat = (int64_t)plan.size(); plan.insert(plan.end(), sfeat.begin(), sfeat.end());
-      lt.off_sbeg = (int64_t)plan.size(); plan.insert(plan.end(), sbeg.begin(), sbeg.end());
-      lt.off_send = (int64_t)plan.size(); plan.insert(plan.end(), send.begin(), send.end());
-      if (lt.n_seg > m->max_long_seg) m->max_long_seg = lt.n_seg;
-    }
-    (void)hipFree(d_max);
-    if (!plan.empty()) {
-      FMX_HIP(hipMalloc(&m->lplan, plan.size() * sizeof(uint32_t)));
-      FMX_HIP(hipMemcpy(m->lplan, plan.data(), plan.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-  }
-
-  // Sparse tiles: when fewer than half the features occur in a tile (few entries, or a skewed feature distribution whose
-  // entries pile up on few features), the per-feature walk should skip the rest: keep the ascending list of the features
-  // that do occur, with a compact copy of their entry offsets.
-  m->tfeat_ptr.assign((size_t)nt + 1, 0);
-  {
-    uint8_t* d_flags = nullptr;
-    uint32_t* d_count = nullptr;
-    void* d_tmp = nullptr;
-    size_t tmp_bytes = 0, tb2 = 0;
-    FMX_HIP(hipMalloc(&d_flags, (size_t)m->p));
-    FMX_HIP(hipMalloc(&d_count, sizeof(uint32_t)));
-    rocprim::counting_iterator<uint32_t> ids(0);
-    auto flags32 = rocprim::make_transform_iterator(d_flags, [] __device__(uint8_t v) { return (uint32_t)v; });
-    FMX_HIP(rocprim::select(nullptr, tmp_bytes, ids, d_flags, (uint32_t*)nullptr, d_count, (size_t)m->p, stream));
-    FMX_HIP(rocprim::reduce(nullptr, tb2, flags32, d_count, (uint32_t)0, (size_t)m->p, rocprim::plus<uint32_t>(), stream));
-    if (tb2 > tmp_bytes) tmp_bytes = tb2;
-    FMX_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    // pass 1: how many features occur in each tile
-    std::vector<uint32_t> occ((size_t)nt, 0);
-    int64_t total = 0;
-    for (int64_t t = 0; t < nt; ++t) {
-      const int64_t cnt = m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t];
-      if (cnt >= (int64_t)m->p * 4) continue;  // dense enough that (almost) every feature occurs: not worth counting
-      hipLaunchKernelGGL(touched_flags_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream,
-                         m->bptr + (size_t)t * ((size_t)m->p + 1), m->p, d_flags);
-      FMX_HIP(rocprim::reduce(d_tmp, tmp_bytes, flags32, d_count, (uint32_t)0, (size_t)m->p, rocprim::plus<uint32_t>(), stream));
-      uint32_t h = 0;
-      FMX_HIP(hipMemcpyAsync(&h, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      FMX_HIP(hipStreamSynchronize(stream));
-      if ((int64_t)h * 2 < (int64_t)m->p) { occ[(size_t)t] = h; total += h; }
-    }
-    // pass 2: the lists
-    if (total > 0) {
-      FMX_HIP(hipMalloc(&m->tfeat, (size_t)total * sizeof(uint32_t)));
-      FMX_HIP(hipMalloc(&m->toff, ((size_t)total + (size_t)nt) * sizeof(uint32_t)));
-    }
-    int64_t at = 0;
-    for (int64_t t = 0; t < nt; ++t) {
-      m->tfeat_ptr[(size_t)t] = at;
-      if (occ[(size_t)t] == 0) continue;
-      hipLaunchKernelGGL(touched_flags_k, dim3((unsigned)(((int64_t)m->p + 255) / 256)), dim3(256), 0, stream,
-                         m->bptr + (size_t)t * ((size_t)m->p + 1), m->p, d_flags);
-      FMX_HIP(rocprim::select(d_tmp, tmp_bytes, ids, d_flags, m->tfeat + at, d_count, (size_t)m->p, stream));
-      const uint32_t h = occ[(size_t)t];
-      const uint32_t entries = (uint32_t)(m->h_row_ptr_batches[t + 1] - m->h_row_ptr_batches[t]);
-      hipLaunchKernelGGL(touched_offsets_k, dim3((unsigned)((h + 1 + 255) / 256)), dim3(256), 0, stream,
-                         m->bptr + (size_t)t * ((size_t)m->p + 1), m->tfeat + at, h, entries, m->toff + at + t);
-      at += h;
-    }
-    m->tfeat_ptr[(size_t)nt] = at;
-    FMX_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(d_flags); (void)hipFree(d_count); (void)hipFree(d_tmp);
+    fmx_matrix::TilePlan& pl = L.plans[(size_t)t];
+    const int64_t base = h_ptr[(size_t)t], cnt = h_ptr[(size_t)t + 1] - base;
+    // a tile with at least as many entries as features touches most of them: one list per feature; otherwise only the
+    // occurring features get a list (p = 33 M against 10 M entries per tile at configs[3]: no p-sized array per tile)
+    FMX_TRY(plan_alloc(pl, m->p, cnt, cnt >= (int64_t)m->p));
+    pl.r0 = tile_start[(size_t)t]; pl.nrows = tile_start[(size_t)t + 1] - pl.r0; pl.base = base; pl.cnt = cnt;
+    FMX_TRY(plan_build(pl, ws, m->p, m->row_ptr, m->col, m->val, L.brow, L.bval, stream));
+    FMX_HIP(hipMemcpyAsync(L.h_counts + 4 * t, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   }
   FMX_HIP(hipStreamSynchronize(stream));
+  int64_t max_seg = 0;
+  for (int64_t t = 0; t < nt; ++t) {
+    plan_set_counts(L.plans[(size_t)t], m->p, L.h_counts + 4 * t);
+    if ((int64_t)L.plans[(size_t)t].n_seg > max_seg) max_seg = L.plans[(size_t)t].n_seg;
+  }
+  // commit
+  m->plans.swap(L.plans);
+  m->brow = L.brow; L.brow = nullptr;
+  m->bval = L.bval; L.bval = nullptr;
+  m->step_first_tile.swap(step_first);
+  m->batch_rows = batch_rows; m->tile_rows = tile_rows; m->n_batches = nb;
+  m->max_long_seg = max_seg; m->max_tile_cnt = max_cnt;
+  m->plan_generation++;
   return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ compact exchange: merge
+// The records of all ranks (part r = counts[r] records starting at record r * stride) are put in feature order without
+// moving them: a stable sort of (feature id, position) pairs keeps the parts of one feature in rank order, a select of the
+// run heads gives one list per feature.  Results stay in the engine's MergeWs for launch_apply_records().
+struct MergeWs {
+  int64_t cap = 0;
+  int n_parts_cap = 0;
+  uint32_t *keys_in = nullptr, *keys_out = nullptr, *pos_in = nullptr, *pos_out = nullptr, *roff = nullptr, *rfeat = nullptr, *dcount = nullptr;
+  uint8_t* flags = nullptr;
+  int64_t* d_prefix = nullptr;
+  void* sort_temp = nullptr; size_t sort_bytes = 0;
+  void* sel_temp = nullptr; size_t sel_bytes = 0;
+};
+
+void merge_ws_free(MergeWs* w) {
+  if (!w) return;
+  (void)hipFree(w->keys_in); (void)hipFree(w->keys_out); (void)hipFree(w->pos_in); (void)hipFree(w->pos_out); (void)hipFree(w->roff);
+  (void)hipFree(w->rfeat); (void)hipFree(w->dcount); (void)hipFree(w->flags); (void)hipFree(w->d_prefix); (void)hipFree(w->sort_temp); (void)hipFree(w->sel_temp);
+  delete w;
+}
+
+static int merge_ws_reserve(fmx_engine* e, int64_t total, int n_parts) {
+  if (!e->merge) e->merge = new MergeWs();
+  MergeWs& w = *e->merge;
+  if (total <= w.cap && n_parts <= w.n_parts_cap) return FMX_OK;
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  MergeWs* old = e->merge;
+  e->merge = new MergeWs();
+  merge_ws_free(old);
+  MergeWs& n = *e->merge;
+  const size_t m = (size_t)(total > 0 ? total : 1) * 5 / 4 + 64;  // some headroom: the total changes a little from step to step
+  FMX_HIP(hipMalloc(&n.keys_in, m * 4)); FMX_HIP(hipMalloc(&n.keys_out, m * 4));
+  FMX_HIP(hipMalloc(&n.pos_in, m * 4)); FMX_HIP(hipMalloc(&n.pos_out, m * 4));
+  FMX_HIP(hipMalloc(&n.roff, (m + 1) * 4)); FMX_HIP(hipMalloc(&n.rfeat, m * 4));
+  FMX_HIP(hipMalloc(&n.dcount, 16)); FMX_HIP(hipMalloc(&n.flags, m));
+  FMX_HIP(hipMalloc(&n.d_prefix, ((size_t)n_parts + 1) * sizeof(int64_t)));
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, n.sort_bytes, n.keys_in, n.keys_out, n.pos_in, n.pos_out, m, 0, 32, e->stream));
+  FMX_HIP(hipMalloc(&n.sort_temp, n.sort_bytes ? n.sort_bytes : 16));
+  rocprim::counting_iterator<uint32_t> ids(0);
+  FMX_HIP(rocprim::select(nullptr, n.sel_bytes, ids, n.flags, n.roff, n.dcount, m, e->stream));
+  FMX_HIP(hipMalloc(&n.sel_temp, n.sel_bytes ? n.sel_bytes : 16));
+  n.cap = (int64_t)m;
+  n.n_parts_cap = n_parts;
+  return FMX_OK;
+}
+
+int merge_records(fmx_engine* e, const void* recs, const int64_t* counts, int n_parts, int64_t stride, int64_t* total_out) {
+  std::vector<int64_t> prefix((size_t)n_parts + 1, 0);
+  for (int r = 0; r < n_parts; ++r) {
+    FMX_CHECK(counts[r] >= 0 && counts[r] <= stride, FMX_ERR_INVALID, "part %d holds %lld records, stride is %lld", r, (long long)counts[r], (long long)stride);
+    prefix[(size_t)r + 1] = prefix[(size_t)r] + counts[r];
+  }
+  const int64_t total = prefix[(size_t)n_parts];
+  FMX_CHECK((int64_t)n_parts * stride < (1LL << 32), FMX_ERR_INVALID, "more than 2^32 record slots");
+  FMX_TRY(merge_ws_reserve(e, total, n_parts));
+  MergeWs& w = *e->merge;
+  *total_out = total;
+  FMX_HIP(hipMemsetAsync(w.dcount, 0, 16, e->stream));
+  if (total == 0) return FMX_OK;
+  // (the prefix is small and pageable: the copy is staged by the runtime before the call returns)
+  FMX_HIP(hipMemcpyAsync(w.d_prefix, prefix.data(), prefix.size() * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+  FMX_TRY(launch_record_keys(e, recs, w.d_prefix, n_parts, stride, total, w.keys_in, w.pos_in));
+  const int bits = col_bits((uint32_t)e->p);
+  size_t tb = w.sort_bytes;
+  FMX_HIP(rocprim::radix_sort_pairs(w.sort_temp, tb, w.keys_in, w.keys_out, w.pos_in, w.pos_out, (size_t)total, 0, bits, e->stream));
+  const int T = 256;
+  hipLaunchKernelGGL(head_flags_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, e->stream, w.keys_out, total, w.flags);
+  rocprim::counting_iterator<uint32_t> ids(0);
+  tb = w.sel_bytes;
+  FMX_HIP(rocprim::select(w.sel_temp, tb, ids, w.flags, w.roff, w.dcount, (size_t)total, e->stream));
+  hipLaunchKernelGGL(lists_finish_k, dim3((unsigned)((total + 1 + T - 1) / T)), dim3(T), 0, e->stream, w.keys_out, w.roff, w.dcount, (uint32_t)total, w.rfeat);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// what launch_apply_records needs from the merge
+void merge_result(const fmx_engine* e, const uint32_t** pos, const uint32_t** roff, const uint32_t** rfeat, const uint32_t** d_n) {
+  const MergeWs& w = *e->merge;
+  *pos = w.pos_out; *roff = w.roff; *rfeat = w.rfeat; *d_n = w.dcount;
 }
 
 int build_full_csc(fmx_matrix* m, hipStream_t stream) {
@@ -418,10 +626,9 @@ __global__ void normalize_apply_k(int64_t nnz, const uint32_t* __restrict__ col,
 
 // the cached inverted indices hold copies of the values: drop them so they are rebuilt from the new values
 static void drop_value_caches(fmx_matrix* m) {
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff); (void)hipFree(m->lplan);
+  drop_plans(m);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
-  m->bptr = nullptr; m->brow = nullptr; m->bval = nullptr; m->tfeat = nullptr; m->toff = nullptr; m->lplan = nullptr; m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
-  m->batch_rows = 0; m->tile_rows = 0;
+  m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
 }
 
 int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double* h_std) {

@@ -189,7 +189,7 @@ static void visit_order(int64_t n, int random_step, int64_t max_iter, std::vecto
 static void free_matrix(fmx_matrix* m) {
   if (!m) return;
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
-  (void)hipFree(m->bptr); (void)hipFree(m->brow); (void)hipFree(m->bval); (void)hipFree(m->tfeat); (void)hipFree(m->toff); (void)hipFree(m->lplan);
+  drop_plans(m);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats);
   delete m;
 }
@@ -293,9 +293,10 @@ static int step_tiles(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_
   int64_t left = rows_limit > 0 ? rows_limit : (int64_t)1 << 62;
   int64_t total = 0;
   for (int64_t t = m->step_first_tile[(size_t)batch]; t < m->step_first_tile[(size_t)batch + 1] && left > 0; ++t) {
-    int64_t nrows = m->tile_start[(size_t)t + 1] - m->tile_start[(size_t)t];
+    const auto& pl = m->plans[(size_t)t];
+    int64_t nrows = pl.nrows;
     if (nrows > left) nrows = left;
-    out->push_back({t, m->tile_start[(size_t)t], nrows});
+    out->push_back({t, pl.r0, nrows});
     left -= nrows;
     total += nrows;
   }
@@ -318,21 +319,29 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t pa
   return launch_rows_forward(e, a, true, mb_wide(e));
 }
 
-static ColsArgs cols_args(fmx_matrix* m, const TileRun& t) {
-  const int64_t base = m->h_row_ptr_batches[(size_t)t.tile];
+// phase-2 arguments of a tile.  sparse_ok: the launch touches no dense exchange buffer, so it may walk only the lists of
+// the features that occur in the tile; otherwise it walks one list per feature (a dense directory is made on first use).
+static int cols_args(fmx_engine* e, fmx_matrix* m, const TileRun& t, bool sparse_ok, ColsArgs* out) {
+  const auto& pl = m->plans[(size_t)t.tile];
   ColsArgs c{};
-  c.bptr = m->bptr + (size_t)t.tile * ((size_t)m->p + 1);
-  c.brow = m->brow + base;
-  c.bval = m->bval + base;
+  c.brow = m->brow + pl.base;
+  c.bval = m->bval + pl.base;
   c.rows_active = (uint32_t)t.nrows;
   c.walk = 1;
-  return c;
+  if (pl.feat && sparse_ok) {
+    c.tfeat = pl.feat; c.toff = pl.soff; c.n_tfeat = pl.n_lists;
+  } else {
+    if (!pl.off) FMX_TRY(plan_ensure_dense(m, t.tile, e->stream));
+    c.bptr = m->plans[(size_t)t.tile].off;
+  }
+  *out = c;
+  return FMX_OK;
 }
 
 // heavy hitters of a tile: the long-list plan and its partial-sum buffer
 static int long_args(fmx_engine* e, fmx_matrix* m, int64_t tile, LongArgs* la, ColsArgs* c) {
-  if (m->long_tiles.empty() || m->long_tiles[(size_t)tile].n_long <= 0) return FMX_OK;
-  const auto& lt = m->long_tiles[(size_t)tile];
+  const auto& pl = m->plans[(size_t)tile];
+  if (pl.n_long == 0) return FMX_OK;
   const int64_t need = m->max_long_seg * (2 * (int64_t)mb_kp(e) + 4);
   if (need > e->long_partial_cap) {
     FMX_HIP(hipStreamSynchronize(e->stream));
@@ -340,8 +349,7 @@ static int long_args(fmx_engine* e, fmx_matrix* m, int64_t tile, LongArgs* la, C
     FMX_HIP(hipMalloc(&e->long_partial, (size_t)need * sizeof(double)));
     e->long_partial_cap = need;
   }
-  *la = LongArgs{m->lplan + lt.off_lfeat, m->lplan + lt.off_lseg, m->lplan + lt.off_sfeat, m->lplan + lt.off_sbeg, m->lplan + lt.off_send,
-                 e->long_partial, lt.n_long, lt.n_seg};
+  *la = LongArgs{pl.lfeat, pl.lpos, pl.lseg_ptr, pl.seg_list, pl.seg_begin, pl.seg_end, e->long_partial, (int64_t)pl.n_long, (int64_t)pl.n_seg};
   c->long_min = list_long_min();
   return FMX_OK;
 }
@@ -364,7 +372,10 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
     FMX_TRY(rows_phase(e, m, tiles[i], partials, &np));
     partials += np;
     const bool last = i + 1 == tiles.size();
-    ColsArgs c = cols_args(m, tiles[i]);
+    // a tile that is a whole fused step walks only the features occurring in it (the exchange buffer is dense: tiles
+    // that read or write it visit every feature)
+    ColsArgs c{};
+    FMX_TRY(cols_args(e, m, tiles[i], single && finish_local, &c));
     c.load_gbuf = i > 0;
     c.store_gbuf = !(last && finish_local);
     c.apply = last && finish_local;
@@ -373,14 +384,6 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
     c.global_rows = (double)step_rows;
     LongArgs la{};
     FMX_TRY(long_args(e, m, tiles[i].tile, &la, &c));
-    // a sparse tile that is a whole fused step walks only the features occurring in it (the exchange buffer is dense:
-    // tiles that read or write it visit every feature)
-    const int64_t tl = m->tfeat_ptr.empty() ? 0 : m->tfeat_ptr[(size_t)tiles[i].tile + 1] - m->tfeat_ptr[(size_t)tiles[i].tile];
-    if (single && finish_local && tl > 0) {
-      c.tfeat = m->tfeat + m->tfeat_ptr[(size_t)tiles[i].tile];
-      c.toff = m->toff + m->tfeat_ptr[(size_t)tiles[i].tile] + tiles[i].tile;
-      c.n_tfeat = (uint32_t)tl;
-    }
     FMX_TRY(launch_cols_update(e, c, la));
   }
   return FMX_OK;
@@ -408,6 +411,7 @@ static int grad_begin(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_
   e->open_rows = step_rows;
   e->open_partials = partials;
   e->open_matrix = m;
+  e->open_generation = m->plan_generation;
   // the tail {sum mult, sum mult^2, rows, 0} is known after phase 1: publish it now so that it can travel first
   ColsArgs c{};
   c.f0 = c.f1 = (uint32_t)e->p;  // no features: workgroup 0's scalar work only
@@ -419,6 +423,9 @@ static int grad_begin(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_
 
 static int grad_block(fmx_engine* e, fmx_matrix* m, int64_t block) {
   FMX_CHECK(e->open_matrix == m && m != nullptr, FMX_ERR_STATE, "fmx_grad_chunk needs a preceding fmx_grad_begin on the same matrix");
+  // the open step holds tile indices into the matrix's plans: another engine's tiling, fmx_matrix_scales / _normalize or a
+  // failed rebuild since fmx_grad_begin replaced them
+  FMX_CHECK(e->open_generation == m->plan_generation, FMX_ERR_STATE, "the matrix's tile plans changed since fmx_grad_begin (another tiling, or scales / normalize): begin the step again");
   FMX_CHECK(block >= 0 && block < e->gb_blocks, FMX_ERR_INVALID, "chunk %lld out of range (0..%lld)", (long long)block, (long long)e->gb_blocks - 1);
   const uint32_t f0 = (uint32_t)(block * e->gb_feats);
   const uint32_t f1 = (uint32_t)(((block + 1) * e->gb_feats < (int64_t)e->p) ? (block + 1) * e->gb_feats : (int64_t)e->p);
@@ -430,7 +437,8 @@ static int grad_block(fmx_engine* e, fmx_matrix* m, int64_t block) {
   for (size_t i = 0; i < e->open_tiles.size(); ++i) {
     const auto& ot = e->open_tiles[i];
     const TileRun t{ot.tile, ot.r0, ot.nrows};
-    ColsArgs c = cols_args(m, t);
+    ColsArgs c{};
+    FMX_TRY(cols_args(e, m, t, false, &c));
     c.f0 = f0; c.f1 = f1;
     c.s_row0 = ot.s_row0;
     c.load_gbuf = i > 0;
@@ -456,6 +464,55 @@ static int apply_block(fmx_engine* e, int64_t block, int64_t global_rows, bool l
   c.global_rows = (double)global_rows;
   if (last) e->open_matrix = nullptr;
   return launch_cols_update(e, c, LongArgs{});
+}
+
+// ---- compact exchange: steps of ONE sparse tile publish a record per occurring feature instead of the dense buffer -----
+static int ensure_compact(fmx_engine* e, int64_t cap) {
+  const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
+  e->rec_elems = mb_kp(e) * (has_q ? 2 : 1) + 4;
+  if (!e->ctail) {
+    FMX_HIP(hipMalloc(&e->ctail, 4 * mb_elem(e)));
+    FMX_HIP(hipMemset(e->ctail, 0, 4 * mb_elem(e)));
+  }
+  if (cap > e->crec_cap) {
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->crec); e->crec = nullptr; e->crec_cap = 0;
+    FMX_HIP(hipMalloc(&e->crec, (size_t)cap * e->rec_elems * mb_elem(e)));
+    e->crec_cap = cap;
+  }
+  return FMX_OK;
+}
+
+// most records one step of this matrix can publish
+static int64_t compact_capacity(const fmx_matrix* m) {
+  int64_t cap = 1;
+  for (const auto& pl : m->plans) { const int64_t c = pl.feat ? (int64_t)pl.cap_lists : (int64_t)m->p; if (c > cap) cap = c; }
+  return cap;
+}
+
+static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
+  std::vector<TileRun> tiles;
+  int64_t step_rows = 0;
+  FMX_TRY(step_tiles(e, m, batch, rows_limit, &tiles, &step_rows));
+  FMX_CHECK(tiles.size() <= 1, FMX_ERR_STATE, "the compact exchange needs steps of one tile (batch_rows <= tile_rows)");
+  if (tiles.empty()) tiles.push_back({m->step_first_tile[(size_t)batch], 0, 0});  // an empty share publishes no record, but its tail
+  const auto& pl = m->plans[(size_t)tiles[0].tile];
+  FMX_CHECK(pl.feat != nullptr, FMX_ERR_STATE, "the compact exchange needs sparse tiles (fewer entries than features per tile); use fmx_grad for dense ones");
+  FMX_TRY(ensure_compact(e, compact_capacity(m)));
+  int64_t np = 0;
+  FMX_TRY(rows_phase(e, m, tiles[0], 0, &np));
+  ColsArgs c{};
+  FMX_TRY(cols_args(e, m, tiles[0], true, &c));
+  c.store_compact = 1;
+  c.compact_tail = 1;
+  c.scalar = SCALAR_PUBLISH;
+  c.n_partials = np;
+  c.global_rows = (double)step_rows;
+  LongArgs la{};
+  FMX_TRY(long_args(e, m, tiles[0].tile, &la, &c));
+  e->crec_count = pl.dcounts;  // n_lists as the plan builder left it on the device
+  e->crec_n = (int64_t)pl.n_lists;
+  return launch_cols_update(e, c, la);
 }
 
 }  // namespace fmx
@@ -551,6 +608,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FMX_OK;
@@ -1127,6 +1185,65 @@ int fmx_apply(fmx_engine* e, int64_t global_rows) {
   c.scalar = SCALAR_FROM_TAIL;
   c.global_rows = (double)global_rows;
   return launch_cols_update(e, c, LongArgs{});
+}
+
+int fmx_compact_info(fmx_engine* e, fmx_matrix* m, int64_t* record_elems, int64_t* capacity, int32_t* usable) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "the compact exchange exists only in FMX_MODE_MINIBATCH");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, effective_tile_rows(e), e->stream));
+  const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
+  bool ok = !m->plans.empty();
+  for (int64_t s = 0; s < m->n_batches && ok; ++s) ok = m->step_first_tile[(size_t)s + 1] - m->step_first_tile[(size_t)s] <= 1;
+  for (const auto& pl : m->plans) ok = ok && pl.feat != nullptr;
+  if (record_elems) *record_elems = mb_kp(e) * (has_q ? 2 : 1) + 4;
+  if (capacity) *capacity = compact_capacity(m);
+  if (usable) *usable = ok ? 1 : 0;
+  return FMX_OK;
+}
+
+int fmx_compact_count(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t* n_records) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!seq_mode(e) && n_records != nullptr, FMX_ERR_STATE, "the compact exchange exists only in FMX_MODE_MINIBATCH");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, effective_tile_rows(e), e->stream));
+  FMX_CHECK(batch >= 0 && batch < m->n_batches, FMX_ERR_INVALID, "batch %lld out of range", (long long)batch);
+  const int64_t t0 = m->step_first_tile[(size_t)batch], t1 = m->step_first_tile[(size_t)batch + 1];
+  FMX_CHECK(t1 - t0 <= 1 && (t1 == t0 || m->plans[(size_t)t0].feat), FMX_ERR_STATE, "step %lld is not one sparse tile", (long long)batch);
+  *n_records = t1 > t0 ? (int64_t)m->plans[(size_t)t0].n_lists : 0;
+  return FMX_OK;
+}
+
+int fmx_compact_reserve(fmx_engine* e, int64_t capacity) {
+  FMX_CHECK(e != nullptr && !seq_mode(e) && capacity >= 0, FMX_ERR_INVALID, "bad argument");
+  FMX_TRY(use_device(e->cfg.device));
+  return ensure_compact(e, capacity > 0 ? capacity : 1);
+}
+
+int fmx_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
+  FMX_TRY(check_pair(e, m));
+  FMX_TRY(use_device(e->cfg.device));
+  return grad_compact(e, m, batch, rows_limit);
+}
+
+int fmx_compact_records(fmx_engine* e, void** dev_records, int64_t* n_records, void** dev_tail) {
+  FMX_CHECK(e != nullptr && e->ctail != nullptr, FMX_ERR_STATE, "fmx_compact_records needs a preceding fmx_grad_compact (or fmx_compact_reserve)");
+  if (dev_records) *dev_records = e->crec;
+  if (n_records) *n_records = e->crec_n;
+  if (dev_tail) *dev_tail = e->ctail;
+  return FMX_OK;
+}
+
+int fmx_apply_compact(fmx_engine* e, const void* dev_records, const int64_t* counts, int32_t n_parts, int64_t stride_records, int64_t global_rows) {
+  FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "fmx_apply_compact needs a mini-batch engine");
+  FMX_CHECK(e->ctail != nullptr, FMX_ERR_STATE, "fmx_apply_compact needs a preceding fmx_grad_compact");
+  FMX_CHECK(counts != nullptr && n_parts >= 1 && stride_records >= 0 && (dev_records != nullptr || stride_records == 0), FMX_ERR_INVALID, "bad record parts");
+  FMX_TRY(use_device(e->cfg.device));
+  int64_t total = 0;
+  FMX_TRY(merge_records(e, dev_records, counts, n_parts, stride_records, &total));
+  const uint32_t *pos, *roff, *rfeat, *d_n;
+  merge_result(e, &pos, &roff, &rfeat, &d_n);
+  return launch_apply_records(e, dev_records, pos, roff, rfeat, d_n, total, global_rows);
 }
 
 int fmx_sync(fmx_engine* e) {

@@ -86,6 +86,8 @@ inline int pad_factor(int k, int vec) {
 
 }  // namespace fmx
 
+namespace fmx { struct MergeWs; }
+
 struct fmx_matrix {
   int device = 0;
   int64_t n = 0;
@@ -98,30 +100,47 @@ struct fmx_matrix {
   int has_labels = 0;
   int rows_sorted = 0;  // every row strictly ascending in col (=> no duplicate column inside a row)
   int max_row_len = 0;  // entries of the longest row
-  // per-tile CSC ("inverted index" of each tile of rows), built lazily for one (batch_rows, tile_rows) pair.
+  // Per-tile inverted index ("plan"), built lazily on the device for one (batch_rows, tile_rows) pair (fm_ingest.hip).
   // A step covers batch_rows consecutive rows and is cut into tiles of at most tile_rows rows.
   int64_t batch_rows = 0;
   int64_t tile_rows = 0;
   int64_t n_batches = 0;                 // steps
-  std::vector<int64_t> tile_start;       // [n_tiles+1] first row of every tile
   std::vector<int64_t> step_first_tile;  // [n_batches+1]
-  uint32_t* bptr = nullptr;  // [n_tiles][p+1] offsets relative to row_ptr[tile_start[t]]
-  // sparse tiles (far fewer entries than features): the ascending ids of the features that occur in the tile
-  // long lists per tile (plan built at ingest; empty for data without heavy hitters)
-  uint32_t* lplan = nullptr;               // one allocation: per tile lfeat | lseg_ptr | seg_feat | seg_begin | seg_end
-  struct LongTile { int64_t off_lfeat, off_lseg, off_sfeat, off_sbeg, off_send, n_long, n_seg; };
-  std::vector<LongTile> long_tiles;        // [n_tiles]
-  int64_t max_long_seg = 0;                // largest n_seg over the tiles (sizes the partial buffer)
-  uint32_t* tfeat = nullptr;               // concatenated over the tiles that have a list
-  uint32_t* toff = nullptr;                // their entry offsets (bptr[tfeat[i]]), one extra end marker per tile: at tfeat_ptr[t] + t
-  std::vector<int64_t> tfeat_ptr;          // [n_tiles+1] into tfeat; an empty range = no list (dense walk over all p)
-  uint32_t* brow = nullptr;  // [nnz] row index local to the tile
-  float* bval = nullptr;     // [nnz]
+  // One tile: its entries sorted by feature (stable: rows ascending inside a feature's list), the lists' offsets, and the
+  // plan for lists too long for one lane group.  Two list directories exist:
+  //   dense : off[p + 1], list i belongs to feature i            (tiles with at least as many entries as features, and
+  //                                                                on demand for the launches that walk the dense exchange buffer)
+  //   sparse: feat[n_lists] ascending ids of the features that occur + soff[n_lists + 1]   (tiles with fewer entries than features)
+  struct TilePlan {
+    int64_t r0 = 0, nrows = 0;     // rows [r0, r0 + nrows) of the matrix
+    int64_t base = 0, cnt = 0;     // entries [base, base + cnt) of the CSR; brow / bval of the tile start at base
+    uint32_t* off = nullptr;       // dense directory [p + 1] (entry offsets relative to base), or null
+    uint32_t* feat = nullptr;      // sparse directory: ids [n_lists] ...
+    uint32_t* soff = nullptr;      // ... and offsets [n_lists + 1], or null
+    uint32_t n_lists = 0;          // occurring features (sparse directory)
+    uint32_t cap_lists = 0;        // capacity of feat / soff - 1
+    // long lists (more than list_long_min() entries): cut into segments of LIST_SEG entries
+    uint32_t* lfeat = nullptr;     // [n_long] feature ids, ascending
+    uint32_t* lpos = nullptr;      // [n_long] their index in the sparse directory (== lfeat without one)
+    uint32_t* lseg_ptr = nullptr;  // [n_long + 1] segments of each long list
+    uint32_t* seg_list = nullptr;  // [n_seg] index into lfeat
+    uint32_t* seg_begin = nullptr; // [n_seg] entry range of the segment (offsets relative to base)
+    uint32_t* seg_end = nullptr;
+    uint32_t n_long = 0, n_seg = 0, cap_long = 0, cap_seg = 0;
+    uint32_t* dcounts = nullptr;   // device copy of {n_lists, n_long, n_seg} as the builder wrote them
+    void* pool = nullptr;          // one allocation behind all the arrays above
+    int off_in_pool = 0;           // the dense directory is the tile's primary one (part of pool); 0 with off != null: added on demand
+  };
+  std::vector<TilePlan> plans;   // [n_tiles]
+  uint64_t plan_generation = 0;  // bumped whenever the plans are rebuilt or dropped: engines holding an open step compare it
+  int64_t max_long_seg = 0;      // largest n_seg over the tiles (sizes the partial buffer)
+  int64_t max_tile_cnt = 0;      // most entries in one tile
+  uint32_t* brow = nullptr;      // [nnz] row index local to the tile
+  float* bval = nullptr;         // [nnz]
   // CSC of the whole matrix (ALS sweep), built lazily
   int64_t* col_ptr = nullptr;  // [p+1]
   uint32_t* crow = nullptr;    // [nnz]
   float* cval = nullptr;       // [nnz]
-  std::vector<int64_t> h_row_ptr_batches;  // host copy of row_ptr at the tile boundaries
   // ALS level plan (features ordered by (level, index)), built lazily
   uint32_t* als_feats = nullptr;
   std::vector<int64_t> als_level_ptr;
@@ -171,6 +190,14 @@ struct fmx_engine {
   double* probit = nullptr;        // [PN_POINTS + 1 | DP_POINTS + 1] probit tables (fm_probit.h), uploaded on first use
   double* long_partial = nullptr;  // segment sums of the long lists
   int64_t long_partial_cap = 0;
+  // compact exchange (steps of one sparse tile): records of the occurring features instead of a p-sized buffer
+  void* crec = nullptr;       // [crec_cap][rec_elems] this rank's records (element type = state type)
+  int64_t crec_cap = 0;
+  int rec_elems = 0;          // kp * (1 + has_q) + 4
+  void* ctail = nullptr;      // [4] {sum mult, sum mult^2, rows hi, rows lo}
+  uint32_t* crec_count = nullptr;  // device: records written by the last fmx_grad_compact (points into the tile plan)
+  int64_t crec_n = 0;              // the same count on the host (the plan builder read it back)
+  fmx::MergeWs* merge = nullptr;   // scratch of fmx_apply_compact
   void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
   int64_t gbuf_floats = 0;    // its element count
   // Layout of the exchange buffer: blocks of gb_feats features, each block GV[F][kp] | GW[F] | CNT[F] (| QV[F][kp] | QW[F]),
@@ -183,6 +210,7 @@ struct fmx_engine {
   int64_t open_rows = 0;
   int64_t open_partials = 0;
   fmx_matrix* open_matrix = nullptr;
+  uint64_t open_generation = 0;  // the matrix's plan_generation at fmx_grad_begin
   // tracker (core/Tracker.h): records of the last fmx_train_tracked
   struct Snapshot { double w0; std::vector<double> w, v; };
   std::vector<int64_t> trace_iters;
@@ -250,10 +278,13 @@ struct ColsArgs {
   double global_rows;    // rows of the whole step (all tiles; all ranks when known), <= 0: take it from the buffer tail
   uint32_t f0, f1;       // dense walk over the features [f0, f1) only (f1 == 0: all p): one chunk of the chunked exchange
   int64_t s_row0;        // row of the S / multiplier workspace where this tile's rows start (0 unless a whole step is resident)
+  int store_compact;     // compact exchange: write one record per occurring feature (sparse walk only)
+  int compact_tail;      // the scalar tail is the compact exchange's own 4 elements, not the end of the dense buffer
 };
 // long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
 struct LongArgs {
   const uint32_t* lfeat;      // [n_long] feature ids, ascending
+  const uint32_t* lpos;       // [n_long] index of each in the tile's sparse directory (compact records)
   const uint32_t* lseg_ptr;   // [n_long+1] segments of each long feature
   const uint32_t* seg_feat;   // [n_seg] index into lfeat
   const uint32_t* seg_begin;  // [n_seg] entry range of the segment (offsets like bptr)
@@ -268,10 +299,44 @@ inline uint32_t list_long_min() {
 }
 constexpr uint32_t LIST_SEG = 1024;  // entries per segment (one wave)
 int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la);
+// compact exchange (fm_batch_kernels.hip; the merge itself is in fm_ingest.hip)
+int launch_record_keys(fmx_engine* e, const void* recs, const int64_t* d_prefix, int n_parts, int64_t stride, int64_t total, uint32_t* keys, uint32_t* pos);
+int launch_apply_records(fmx_engine* e, const void* recs, const uint32_t* pos, const uint32_t* roff, const uint32_t* rfeat, const uint32_t* d_n,
+                         int64_t max_lists, int64_t global_rows);
+struct MergeWs;
+int merge_records(fmx_engine* e, const void* recs, const int64_t* counts, int n_parts, int64_t stride, int64_t* total_out);
+void merge_ws_free(MergeWs* w);
+void merge_result(const fmx_engine* e, const uint32_t** pos, const uint32_t** roff, const uint32_t** rfeat, const uint32_t** d_n);
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count);
 
 // ingest
+// scratch of the plan builder, sized for tiles of up to max_cnt entries over p features (grow-only)
+struct PlanWorkspace {
+  int64_t max_cnt = 0;
+  uint32_t p = 0;
+  int bits = 0;
+  uint32_t* keys_out = nullptr;
+  uint64_t *vals_in = nullptr, *vals_out = nullptr;
+  void* sort_temp = nullptr;
+  size_t sort_bytes = 0;
+  uint8_t* flags = nullptr;
+  uint32_t* nseg = nullptr;
+  void* prim_temp = nullptr;
+  size_t prim_bytes = 0;
+  int reserve(int64_t cnt, uint32_t p, hipStream_t stream);
+  PlanWorkspace() = default;
+  PlanWorkspace(const PlanWorkspace&) = delete;
+  PlanWorkspace& operator=(const PlanWorkspace&) = delete;
+  ~PlanWorkspace();
+};
+int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense);
+void plan_free(fmx_matrix::TilePlan& t);
+int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
+               uint32_t* brow, float* bval, hipStream_t stream);
+void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h);
+int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream);
+void drop_plans(fmx_matrix* m);
 int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream);
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);

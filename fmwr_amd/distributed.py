@@ -69,13 +69,42 @@ class _DevBuf:
 class EngineStepper:
     """The product stepper: fmx_grad / fmx_grad_buffer / fmx_apply on one GPU (and their chunked forms)."""
 
-    def __init__(self, engine, matrix, device):
+    def __init__(self, engine, matrix, device, dense=True):
+        """dense=False: the dense exchange buffer ((kp + 2) * p elements: 4.5 GB at p = 33 M, k = 32) is not allocated until a
+        dense step asks for it -- a driver that only uses the compact exchange never pays for it."""
         self.e, self.m = engine, matrix
         self.device = torch.device("cuda", device)
-        ptr, n = engine.grad_buffer()
-        self.buf = torch.as_tensor(_DevBuf(ptr, n, engine.grad_elem_bytes()), device=self.device)
         self.stream = torch.cuda.ExternalStream(engine.stream(), device=self.device)
-        self.n_chunks, self.chunk_features, self.chunk_elems, self.tail_offset = engine.grad_layout()
+        self._buf = None
+        if dense:
+            self._dense()
+
+    def _dense(self):
+        if self._buf is None:
+            ptr, n = self.e.grad_buffer()
+            self._buf = torch.as_tensor(_DevBuf(ptr, n, self.e.grad_elem_bytes()), device=self.device)
+            self._layout = self.e.grad_layout()
+        return self._buf
+
+    @property
+    def buf(self):
+        return self._dense()
+
+    @property
+    def n_chunks(self):
+        self._dense(); return self._layout[0]
+
+    @property
+    def chunk_features(self):
+        self._dense(); return self._layout[1]
+
+    @property
+    def chunk_elems(self):
+        self._dense(); return self._layout[2]
+
+    @property
+    def tail_offset(self):
+        self._dense(); return self._layout[3]
 
     def grad(self, batch, rows_limit=0):
         self.e.grad(self.m, batch, rows_limit)
@@ -105,6 +134,40 @@ class EngineStepper:
     def apply_chunk(self, c, last):
         self.e.apply_chunk(c, 0, last)
 
+    # compact exchange (steps of one sparse tile: records of the occurring features instead of the dense buffer)
+    def compact_usable(self):
+        self.rec_elems, self.rec_cap, ok = self.e.compact_info(self.m)
+        return ok
+
+    def compact_counts(self):
+        """records each of this rank's steps publishes (known from ingest)"""
+        return [self.e.compact_count(self.m, b) for b in range(self.e.num_batches(self.m))]
+
+    def compact_reserve(self, cap):
+        self.e.compact_reserve(cap)
+        ptr, _, tail = self.e.compact_records()
+        eb = self.e.grad_elem_bytes()
+        self.rec = torch.as_tensor(_DevBuf(ptr, cap * self.rec_elems, eb), device=self.device).view(cap, self.rec_elems)
+        self.ctail = torch.as_tensor(_DevBuf(tail, 4, eb), device=self.device)
+
+    def grad_compact(self, batch, rows_limit=0):
+        self.e.grad_compact(self.m, batch, rows_limit)
+
+    def compact_tail(self):
+        return self.ctail
+
+    def compact_send(self, n):
+        return self.rec[:n]
+
+    def compact_recv(self, world, n):
+        need = world * n * self.rec_elems
+        if getattr(self, "_recv", None) is None or self._recv.numel() < need:
+            self._recv = torch.empty(max(need, 1), dtype=self.rec.dtype, device=self.device)
+        return self._recv[:need].view(world * n, self.rec_elems)
+
+    def apply_compact(self, recv, counts, stride):
+        self.e.apply_compact(recv.data_ptr(), counts, stride, 0)  # the global row count travelled in the tail
+
 
 class DataParallel:
     """step(batch): local gradient sums -> all-reduce(sum) -> identical update on every replica.
@@ -114,10 +177,62 @@ class DataParallel:
     issued asynchronously, so the exchange of block c travels while block c+1 is being summed, and the update of block
     c runs while block c+1 is still travelling.  Same sums, same order, same result as the unchunked step."""
 
-    def __init__(self, stepper, group=None):
+    def __init__(self, stepper, group=None, exchange="dense"):
         self.s = stepper
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchange = exchange
+        if exchange == "compact":
+            self._init_compact()
+        elif exchange != "dense":
+            raise ValueError("exchange must be 'dense' or 'compact'")
+
+    # ---- compact exchange: all-gather of (feature id, sums) records of the features that occur in the step ---------------
+    def _init_compact(self):
+        """Every rank's record count per step is known from ingest: exchange the tables once, so that no step needs a host
+        round trip to size its all-gather.  Falls back to the dense exchange if any rank's tiles are not sparse single-tile steps."""
+        s = self.s
+        ok = torch.tensor([1 if s.compact_usable() else 0], dtype=torch.int64, device=s.device)
+        if self.world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            self.exchange = "dense"
+            return
+        mine = torch.tensor(s.compact_counts(), dtype=torch.int64, device=s.device)
+        nb = torch.tensor([mine.numel()], dtype=torch.int64, device=s.device)
+        if self.world > 1:
+            dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=self.group)
+        pad = torch.zeros(int(nb.item()), dtype=torch.int64, device=s.device)
+        pad[:mine.numel()] = mine
+        table = [torch.zeros_like(pad) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(table, pad, group=self.group)
+        else:
+            table = [pad]
+        self.counts = torch.stack(table).cpu().numpy()       # [world][steps]
+        self.max_records = int(self.counts.max()) if self.counts.size else 0
+        s.compact_reserve(max(self.max_records, 1))           # every rank sends slices of the same length
+        self.bytes_per_step = []                              # filled as steps run: what the step moved per rank
+
+    def _step_compact(self, batch, rows_limit):
+        s = self.s
+        counts = self.counts[:, batch]
+        n = int(counts.max())
+        with s.comm_context():
+            s.grad_compact(batch, rows_limit)
+            if self.world > 1:
+                dist.all_reduce(s.compact_tail(), op=dist.ReduceOp.SUM, group=self.group)
+                recv = s.compact_recv(self.world, n)
+                if n > 0:
+                    send = s.compact_send(n)
+                    try:
+                        dist.all_gather_into_tensor(recv, send, group=self.group)
+                    except (RuntimeError, NotImplementedError):  # a backend without the flat form (gloo with device tensors)
+                        dist.all_gather(list(recv.view(self.world, n, -1).unbind(0)), send.contiguous(), group=self.group)
+            else:
+                recv = s.compact_send(n)
+            s.apply_compact(recv, counts, n)
+        self.last_exchange_bytes = int(self.world * n * s.rec_elems * recv.element_size()) if n > 0 else 0
 
     def _reduce(self, t):
         if self.world > 1:
@@ -125,7 +240,10 @@ class DataParallel:
         return None
 
     def step(self, batch, rows_limit=0):
+        if self.exchange == "compact":
+            return self._step_compact(batch, rows_limit)
         chunks = getattr(self.s, "n_chunks", 1)
+        self.last_exchange_bytes = int(self.s.buffer().numel() * self.s.buffer().element_size())
         if chunks <= 1:
             self.s.grad(batch, rows_limit)
             if self.world > 1:

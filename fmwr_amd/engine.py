@@ -209,6 +209,33 @@ class Engine:
     def apply_chunk(self, chunk, global_rows=0, last=False):
         L.check(L.lib().fmx_apply_chunk(self.h, C.c_int64(chunk), C.c_int64(global_rows), C.c_int32(int(last))))
 
+    def compact_info(self, m):
+        """(record_elems, capacity, usable) of the compact exchange for this matrix (builds its tile plans)."""
+        a, b, u = C.c_int64(), C.c_int64(), C.c_int32()
+        L.check(L.lib().fmx_compact_info(self.h, m.h, C.byref(a), C.byref(b), C.byref(u)))
+        return a.value, b.value, bool(u.value)
+
+    def compact_count(self, m, batch):
+        n = C.c_int64()
+        L.check(L.lib().fmx_compact_count(self.h, m.h, C.c_int64(batch), C.byref(n)))
+        return n.value
+
+    def compact_reserve(self, capacity):
+        L.check(L.lib().fmx_compact_reserve(self.h, C.c_int64(capacity)))
+
+    def grad_compact(self, m, batch, rows_limit=0):
+        L.check(L.lib().fmx_grad_compact(self.h, m.h, C.c_int64(batch), C.c_int64(rows_limit)))
+
+    def compact_records(self):
+        """(device pointer of the records, record count, device pointer of the 4-element tail)."""
+        r, n, t = C.c_void_p(), C.c_int64(), C.c_void_p()
+        L.check(L.lib().fmx_compact_records(self.h, C.byref(r), C.byref(n), C.byref(t)))
+        return r.value, n.value, t.value
+
+    def apply_compact(self, dev_records, counts, stride, global_rows=0):
+        counts = np.ascontiguousarray(counts, np.int64)
+        L.check(L.lib().fmx_apply_compact(self.h, C.c_void_p(dev_records), _p(counts), C.c_int32(len(counts)), C.c_int64(stride), C.c_int64(global_rows)))
+
     def apply(self, global_rows):
         L.check(L.lib().fmx_apply(self.h, C.c_int64(global_rows)))
 

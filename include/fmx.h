@@ -91,7 +91,8 @@ typedef struct fmx_config {
   double gamma;            /* TDAP.solver(gamma = 1e-4): decay rate (alpha_w, alpha_v shared with FTRL) */
   int64_t tile_rows;       /* 0: default.  A step of batch_rows rows is processed in tiles of at most this many
                               rows (parameters frozen across the tiles, sums accumulated): keeps the per-tile
-                              tables cache resident for large batches.  Does not change any result.           */
+                              tables cache resident for large batches.  Same result up to the rounding of the
+                              partial sums to the state type between tiles (fp32 unless state_fp64).           */
   int32_t state_fp64;      /* mini-batch mode: 0 = fp32 parameter/optimizer tables (default, half the HBM traffic),
                               1 = the fp64 tables of the sequential mode (the reference's precision; per-row sums and
                               the exchange buffer become fp64 too)                                               */
@@ -221,7 +222,7 @@ int fmx_grad_buffer(fmx_engine* e, void** dev_ptr, int64_t* n_floats);
 int fmx_grad_elem_bytes(const fmx_engine* e, int32_t* bytes);
 /* Pipelined form of the same split (cfg.exchange_chunks > 1).  The buffer is n_chunks blocks of chunk_elems elements,
  * block c holding the sums of features [c*chunk_features, (c+1)*chunk_features), followed at tail_offset by 4 elements
- * {sum of multipliers, sum of their squares, rows, 0}:
+ * {sum of multipliers, sum of their squares, rows / 4096, rows % 4096} (two parts so that an fp32 sum over the ranks stays exact):
  *   fmx_grad_begin          forward of the whole step (all its tiles), writes the tail        -> all-reduce the tail
  *   fmx_grad_chunk(c)       gradient sums of block c over all tiles                            -> all-reduce block c (async)
  *   fmx_apply_chunk(c,..)   update of block c's features from the reduced block; `last` != 0 on the final call of the
@@ -234,6 +235,24 @@ int fmx_apply_chunk(fmx_engine* e, int64_t chunk, int64_t global_rows, int32_t l
 /* ... and the update from the (reduced) buffer; global_rows = rows of the whole global batch, or <= 0 to take the
  * count that travelled in the buffer's tail (each rank's fmx_grad wrote its own row count there; the all-reduce summed them). */
 int fmx_apply(fmx_engine* e, int64_t global_rows);
+/* ---- compact exchange (SURVEY 8(e) "collective sizing", BASELINE.json configs[3]: p = 33 M, k = 32 -> a dense buffer of 4.5 GB
+ * per step).  When a step is one tile holding fewer entries than there are features (fmx_compact_info says `usable`), the
+ * gradient sums of the features that OCCUR in the step are published as records instead:
+ *     record = G[kp] | (Q[kp]: FTRL with FMX_REDUCE_SUM) | Gw | Qw | cnt | feature id      (record_elems elements, fp32 or fp64)
+ * in ascending feature order, plus a 4-element tail {sum of multipliers, sum of squares, rows / 4096, rows % 4096}.
+ *   fmx_grad_compact      forward + gradient sums of the step -> this rank's records and tail (enqueued)
+ *   fmx_compact_records   device pointers of the records / the tail, and the record count (known on the host from ingest)
+ *   -- the driver all-reduces the tail (sum) and all-gathers the records (padded to the largest count) --
+ *   fmx_apply_compact     the gathered parts (part r: counts[r] records starting at record r * stride_records) are merged by
+ *                         feature id, a feature's parts added in rank order, and the update is applied once per feature.
+ * Two ranks give bitwise the result of the dense fmx_grad / all-reduce / fmx_apply step (tests/test_gpu_distributed.py). */
+int fmx_compact_info(fmx_engine* e, fmx_matrix* m, int64_t* record_elems, int64_t* capacity, int32_t* usable);
+int fmx_compact_count(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t* n_records); /* records step `batch` publishes */
+int fmx_compact_reserve(fmx_engine* e, int64_t capacity); /* room for `capacity` records (>= every rank's own capacity) */
+int fmx_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit);
+int fmx_compact_records(fmx_engine* e, void** dev_records, int64_t* n_records, void** dev_tail);
+int fmx_apply_compact(fmx_engine* e, const void* dev_records, const int64_t* counts, int32_t n_parts, int64_t stride_records,
+                      int64_t global_rows);
 int fmx_sync(fmx_engine* e);
 /* the hipStream_t the engine launches on (as void*), so a caller can order its own work after it */
 int fmx_stream(fmx_engine* e, void** stream);

@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -83,7 +84,7 @@ class OracleStepper:
         b = self.buf.numpy().astype(np.float64)
         t = self.lay.tail
         full = dict(G0=b[t], Q0=b[t + 1], Gw=acc["Gw"], cw=acc["cw"], Qw=acc["Qw"], Gv=acc["Gv"].T.ravel().copy(), Qv=acc["Qv"].T.ravel().copy())
-        (oracle.sgd_apply_sums if self.solver == "sgd" else oracle.ftrl_apply_sums)(self.P, P_FEAT, self.st, b[t + 2], full)
+        (oracle.sgd_apply_sums if self.solver == "sgd" else oracle.ftrl_apply_sums)(self.P, P_FEAT, self.st, b[t + 2] * 4096.0 + b[t + 3], full)
 
     @staticmethod
     def _empty():
@@ -109,7 +110,7 @@ class OracleStepper:
     def grad_begin(self, batch, rows_limit=0):
         self.acc, rows = self._sums(batch)
         t = self.lay.tail
-        self.buf.numpy()[t:t + 4] = [self.acc["G0"], self.acc["Q0"], rows, 0.0]
+        self.buf.numpy()[t:t + 4] = [self.acc["G0"], self.acc["Q0"], rows // 4096, rows % 4096]  # the row count travels in two parts
         self.reduced = self._empty()
 
     def grad_chunk(self, c):
@@ -128,12 +129,73 @@ class OracleStepper:
             self._finish(self.reduced)  # the oracle applies all coordinates at once; coordinates are independent
 
 
-def _worker(rank, world, port, solver, out_dir, chunks):
+    # compact interface: one record per occurring feature, G[K] | (Q[K]) | Gw | Qw | cnt | id (bit pattern), ascending ids
+    device = torch.device("cpu")
+
+    def compact_usable(self):
+        self.rec_elems = K * (2 if self.lay.has_q else 1) + 4
+        return True
+
+    def compact_counts(self):
+        nb = -(-(self.r1 - self.r0) // B_LOCAL)
+        return [int(np.count_nonzero(self._sums(b)[0]["cw"])) for b in range(nb)]
+
+    def compact_reserve(self, cap):
+        self.rec = torch.zeros(cap, self.rec_elems, dtype=torch.float32)
+        self.ctail = torch.zeros(4, dtype=torch.float32)
+
+    def grad_compact(self, batch, rows_limit=0):
+        acc, rows = self._sums(batch)
+        ids = np.flatnonzero(acc["cw"]).astype(np.uint32)
+        r = self.rec.numpy()
+        q = K if self.lay.has_q else 0
+        r[:len(ids), :K] = acc["Gv"].reshape(K, P_FEAT).T[ids]
+        if q:
+            r[:len(ids), K:2 * K] = acc["Qv"].reshape(K, P_FEAT).T[ids]
+        r[:len(ids), K + q] = acc["Gw"][ids]
+        r[:len(ids), K + q + 1] = acc["Qw"][ids] if q else 0.0
+        r[:len(ids), K + q + 2] = acc["cw"][ids]
+        r[:len(ids), K + q + 3] = ids.view(np.float32)
+        self.ctail.numpy()[:] = [acc["G0"], acc["Q0"], rows // 4096, rows % 4096]
+
+    def compact_tail(self):
+        return self.ctail
+
+    def compact_send(self, n):
+        return self.rec[:n]
+
+    def compact_recv(self, world, n):
+        self._recv = torch.zeros(world * n, self.rec_elems, dtype=torch.float32)
+        return self._recv
+
+    def apply_compact(self, recv, counts, stride):
+        """merge by feature id; a feature's parts are added in rank order, in the buffer's element type (fp32), exactly as an
+        all-reduce(sum) of the dense buffer adds two ranks"""
+        r = recv.numpy()
+        q = K if self.lay.has_q else 0
+        red = {key: val.astype(np.float32) for key, val in self._empty().items()}
+        for part, cnt in enumerate(counts):
+            blk = r[part * stride:part * stride + int(cnt)]
+            ids = np.ascontiguousarray(blk[:, K + q + 3]).view(np.uint32)
+            red["Gv"][ids] = red["Gv"][ids] + blk[:, :K]
+            if q:
+                red["Qv"][ids] = red["Qv"][ids] + blk[:, K:2 * K]
+                red["Qw"][ids] = red["Qw"][ids] + blk[:, K + q + 1]
+            red["Gw"][ids] = red["Gw"][ids] + blk[:, K + q]
+            red["cw"][ids] = red["cw"][ids] + blk[:, K + q + 2]
+        red = {key: val.astype(np.float64) for key, val in red.items()}
+        b = self.ctail.numpy().astype(np.float64)
+        full = dict(G0=b[0], Q0=b[1], Gw=red["Gw"], cw=red["cw"], Qw=red["Qw"], Gv=red["Gv"].T.ravel().copy(), Qv=red["Qv"].T.ravel().copy())
+        (oracle.sgd_apply_sums if self.solver == "sgd" else oracle.ftrl_apply_sums)(self.P, P_FEAT, self.st, b[2] * 4096.0 + b[3], full)
+
+
+def _worker(rank, world, port, solver, out_dir, chunks, exchange="dense"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fmwr_amd.distributed import DataParallel, shard_rows
     stepper = OracleStepper(solver, shard_rows(N, rank, world), _problem(), chunks)
-    dp = DataParallel(stepper)
+    dp = DataParallel(stepper, exchange=exchange)
+    assert dp.exchange == exchange
     for s in range(STEPS):
         dp.step(s % 4)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), w0=stepper.st["w0"].value, w=stepper.st["w"], v=stepper.st["v"])
@@ -167,9 +229,9 @@ def _expected(solver, world):
     return st
 
 
-def _run(solver, tmp_path, chunks=1):
+def _run(solver, tmp_path, chunks=1, exchange="dense"):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), solver, str(tmp_path), chunks), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), solver, str(tmp_path), chunks, exchange), nprocs=world, join=True)
     exp = _expected(solver, world)
     got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     # replicas are bit-identical ...
@@ -193,6 +255,21 @@ def test_data_parallel_pipelined_exchange_world2(tmp_path):
     """exchange_chunks > 1: tail first, then one asynchronous all-reduce per block of features (2 blocks of 64 features)."""
     _run("sgd", tmp_path, chunks=2)
     _run("ftrl", tmp_path, chunks=2)
+
+
+@pytest.mark.parametrize("solver", ["sgd", "ftrl"])
+def test_compact_exchange_is_bitwise_the_dense_all_reduce_world2(tmp_path, solver):
+    """The touched-row exchange (all-gather of one record per occurring feature, merged in rank order) against the dense
+    all-reduce of the (k + 2) * p buffer: the same parameters bit for bit on both replicas, for SGD (MEAN) and FTRL (SUM,
+    which also exchanges the sums of squares)."""
+    d = tmp_path / "dense"; c = tmp_path / "compact"
+    d.mkdir(); c.mkdir()
+    _run(solver, d)
+    _run(solver, c, exchange="compact")
+    for r in range(2):
+        a, b = np.load(d / f"rank{r}.npz"), np.load(c / f"rank{r}.npz")
+        for key in ("w0", "w", "v"):
+            np.testing.assert_array_equal(a[key], b[key])
 
 
 def test_grad_layout_blocks():

@@ -272,3 +272,33 @@ def test_c_abi_argument_checks_for_the_newer_entry_points():
         engine.Engine(p, solver=400)
     with pytest.raises(L.FmxError, match="TDAP solver runs in FMX_MODE_SEQUENTIAL"):
         engine.Engine(p, solver=L.SOLVER_TDAP, mode=L.MODE_MINIBATCH)
+
+
+def test_failed_plan_build_leaves_no_half_built_cache(monkeypatch):
+    """a failure while the per-tile plans are being built (out of memory is the expected one) must not leave a
+    cache that the next call takes for valid.  The builder commits to the matrix only at the end; a forced failure is
+    followed by a clean retry with the same results as an undisturbed run."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k = 600, 90, 4
+    rp, col, val = util.random_csr(n, p, 6, seed=5)
+    y = util.labels(n, 5)
+    w0, w, v = util.params(p, k, 5)
+    kw = dict(num_factor=k, learn_rate=0.05, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=128)
+    ref = engine.Engine(p, **kw); ref.set_params(w0, w, v)
+    mref = engine.Matrix.from_csr(rp, col, val, p, y)
+    for s in range(4):
+        ref.step(mref, s)
+    ref.sync()
+    e = engine.Engine(p, **kw); e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    monkeypatch.setenv("FMX_TEST_FAIL_PLAN_BUILD", "1")
+    with pytest.raises(L.FmxError, match="plan build failed"):
+        e.step(m, 0)
+    with pytest.raises(L.FmxError):      # nothing was cached: asking for a step of a plan-less matrix fails again only if the build does
+        monkeypatch.setenv("FMX_TEST_FAIL_PLAN_BUILD", "1")
+        e.num_batches(m)
+    for s in range(4):                   # the flag cleared itself: the retry builds everything and trains
+        e.step(m, s)
+    e.sync()
+    a, b = ref.get_params(), e.get_params()
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

@@ -94,3 +94,69 @@ def test_bench_multirank_path_runs(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch_rows"] == 65536 and d["config"]["tile_rows"] == 32768
+
+
+COMPACT_WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from fmwr_amd import _lib as L, engine
+from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+solver, out, wide, reduce = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
+# far more features than entries per step (the regime of BASELINE.json configs[3]): every tile is sparse
+n, p, z, k, B = 24000, 300000, 12, 8, 3000
+r0, r1 = shard_rows(n, rank, world)
+rng = np.random.default_rng(100 + rank)
+rows = []
+for r in range(r1 - r0):   # two heavy hitters (long lists) + cold features, some shared between the ranks
+    hot = [j for j, q in ((5, 0.9), (70000, 0.4)) if rng.random() < q]
+    rows.append(np.unique(np.concatenate([hot, rng.integers(0, 4000, 3), rng.integers(4000, p, z - 3)])).astype(np.uint32))
+rp = np.zeros(len(rows) + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+col = np.concatenate(rows); val = rng.normal(0, 1, len(col)).astype(np.float32)
+y = np.where(rng.random(len(rows)) < 0.5, -1.0, 1.0).astype(np.float32)
+kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD if solver.startswith("sgd") else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05,
+          l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver != "sgd" else 0.0, l1_w1=1e-4 if solver == "sgd_l1" else 0.0,
+          mode=L.MODE_MINIBATCH, batch_rows=B // world, state_fp64=wide, batch_reduce=L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM)
+v0 = np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+res = {}
+for exchange in ("dense", "compact"):
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    e = engine.Engine(p, **kw)
+    e.set_params(0.0, None, v0)
+    dp = DataParallel(EngineStepper(e, m, 0, dense=(exchange == "dense")), exchange=exchange)
+    assert dp.exchange == exchange, dp.exchange
+    nb = e.num_batches(m)
+    moved = 0
+    for s in range(7):
+        dp.step(s % nb, rows_limit=(B // world - 100) if s == 3 else 0)   # one truncated step
+        moved += dp.last_exchange_bytes
+    e.sync()
+    res[exchange] = e.get_params() + (moved,)
+a, b = res["dense"], res["compact"]
+assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), "compact exchange differs from the dense all-reduce"
+assert np.any(a[2] != v0)
+if rank == 0:
+    np.savez(out, w0=b[0], w=b[1], v=b[2], dense_bytes=a[3], compact_bytes=b[3])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("solver,wide,reduce", [("sgd", 0, "mean"), ("sgd_l1", 0, "sum"), ("ftrl", 0, "sum"), ("ftrl", 1, "mean")])
+def test_compact_exchange_equals_dense_all_reduce_two_ranks(tmp_path, solver, wide, reduce):
+    """configs[3]'s exchange: p >> entries per step, so each rank publishes one record per OCCURRING feature (all-gather,
+    merged in rank order) instead of all-reducing the (kp + 2) * p buffer.  Two ranks on one GPU through gloo: both forms
+    leave bitwise the same parameters (asserted inside the workers, heavy hitters and a truncated step included), and the
+    compact form moves a small fraction of the bytes."""
+    script = tmp_path / "worker.py"
+    script.write_text(COMPACT_WORKER)
+    out = tmp_path / "dp.npz"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", str(script), ROOT, solver, str(out), str(wide), reduce], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    assert got["compact_bytes"] * 5 < got["dense_bytes"]
+    assert np.all(np.isfinite(got["v"]))
