@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- examples/sec of the FM SGD hot path on the BASELINE.json workload.
+"""bench.py -- examples/sec of the FM training hot path on the BASELINE.json workload.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # configs[1]: 10M x 1M, 30 nnz/row, k = 16, SGD
+    python bench.py --solver ftrl --factors 64               # configs[2]: same matrix, k = 64, FTRL (l1 + l2)
 
-A "step" is one synchronous mini-batch SGD step (forward + gradient sums + update) over `--batch-rows` rows PER GPU of
-the synthetic 10M x 1M, 30 nnz/row, k=16 workload (BASELINE.json configs[1]); the matrix is generated on the device
-and is resident in HBM before the timed region.  The engine cuts a step into tiles of <= 262144 rows (two kernel
-launches per tile: fm_rows_forward, fm_cols_update) with the parameters frozen across the tiles.  N > 1: one process per GPU (torch.distributed / RCCL), each rank
-owns a contiguous row range, computes its gradient sums, the (k+2)*p buffer is all-reduced, every replica applies the
-same update ("scaling": "weak": per-GPU rows per step are fixed).
+A "step" is one synchronous mini-batch step (forward + gradient sums + update) over `--batch-rows` rows PER GPU of the
+synthetic matrix; the matrix is generated on the device and is resident in HBM before the timed region.  The engine cuts
+a step into tiles (two kernel launches per tile: fm_rows_forward, fm_cols_update) with the parameters frozen across the
+tiles.  N > 1: one process per GPU (torch.distributed / RCCL), each rank owns a contiguous row range, computes its gradient
+sums, exchanges them (dense: the (k+2)*p buffer is all-reduced in pipelined blocks; compact: records of the occurring
+features are all-gathered), every replica applies the same update ("scaling": "weak": per-GPU rows per step are fixed).
 
-Rank 0 prints ONE JSON line: metric/value (whole-job examples/s), the dominant kernel's roofline (HIP-event timed on
-the engine's stream inside the timed region) and, at N == 1, the oracle's serial reference-order SGD timed on the
-host on a bounded sample of the same rows ("cpu_baseline").
+Rank 0 prints ONE JSON line.  `value` is whole-job examples/s of the timed steps.  `roofline` prices the step in SURVEY
+8(d)'s algorithmic bytes (the headline `frac`) and each of the two kernels on its own bytes and HIP-event time, next to the
+measured ceiling of the access pattern (`ceiling_frac`).  At N == 1 the same line also carries what `value` leaves out:
+`end_to_end` (with the one-off per-tile CSC build), `value_fp64_state`, `small_batch`, `sequential_exact` (the mode the
+reference-parity claim is made in) and the oracle timed on the host (`cpu_baseline`).
 """
 import argparse
 import json
@@ -36,38 +39,54 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows of the whole synthetic matrix")
     ap.add_argument("--features", type=int, default=1_000_000)
     ap.add_argument("--nnz", type=int, default=30)
-    ap.add_argument("--factors", type=int, default=16)
+    ap.add_argument("--factors", type=int, default=0, help="0: 16 for sgd (configs[1]), 64 for ftrl (configs[2])")
     ap.add_argument("--batch-rows", type=int, default=1_048_576,
-                    help="mini-batch rows per GPU per step (processed in cache-resident tiles of <= 262144 rows)")
-    ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144)")
+                    help="mini-batch rows per GPU per step (processed in cache-resident tiles)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144; 524288 for k > 32)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
+    ap.add_argument("--exchange", choices=["auto", "dense", "compact"], default="auto",
+                    help="N > 1: dense = all-reduce of the (k+2)*p buffer; compact = all-gather of the occurring features' records "
+                         "(steps of one sparse tile); auto = compact where usable")
     ap.add_argument("--exchange-chunks", type=int, default=0,
-                    help="N > 1: blocks of features the exchange is pipelined in (1: one all-reduce of the whole buffer per step; "
+                    help="N > 1, dense: blocks of features the exchange is pipelined in (1: one all-reduce of the whole buffer per step; "
                          "0: 8 blocks on 2 GPUs, where the single xGMI link is the bound and finer blocks hide more of it, 4 otherwise, "
                          "where the extra launches of finer blocks cost more than they hide: profiles/r01_split_bench.json)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
-    ap.add_argument("--cpu-rows", type=int, default=5_000_000, help="rows of the CPU-baseline sample (0: skip)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (0: skip; -1: 5M for sgd, 60K for ftrl k=64)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp64 state, small batches, sequential mode, ceilings)")
+    a = ap.parse_args()
+    if a.factors == 0:
+        a.factors = 16 if a.solver == "sgd" else 64
+    if a.cpu_rows < 0:
+        a.cpu_rows = 5_000_000 if a.solver == "sgd" else max(20_000, 4_000_000 // a.factors)
+    return a
 
 
-def algorithmic_bytes(z, k, p, rows, e=4):
+def algorithmic_bytes(z, k, p, rows, e=4, ftrl=False):
     """Per-launch algorithmic HBM bytes of the two hot kernels and of the SURVEY 8(d) fused step; e = bytes per state
-    element (4: the fp32 state SURVEY 8(d) prices; 8 with --state-fp64)."""
-    rows_fwd = rows * (z * (4 + 4 + e + e * k) + 8 + 4 + e * k + e)   # idx,val,w,V row | row_ptr, y, S row, mult
-    cols_upd = rows * z * (4 + 4 + e + e * k) + p * (4 + 2 * e * k + 2 * e)  # row,val,mult,S row | bptr, V RMW, w RMW
-    survey_step = rows * (z * (8 + 2 * e + 2 * e * k) + 12)
+    element (4: the fp32 state SURVEY 8(d) prices; 8 with --state-fp64).  FTRL keeps three tables per parameter (theta, z, n)."""
+    t = 3 if ftrl else 1
+    rows_fwd = rows * (z * (4 + 4 + e + e * k) + 8 + 4 + e * k + e)                  # idx,val,w,V row | row_ptr, y, S row, mult
+    cols_upd = rows * z * (4 + 4 + e + e * k) + p * (4 + t * 2 * e * k + t * 2 * e)  # row,val,mult,S row | offsets, table RMWs
+    survey_step = rows * (z * (8 + t * 2 * e + t * 2 * e * k) + 12)                  # SGD z(16+8k)+12, FTRL z(32+24k)+12 at e = 4
     return rows_fwd, cols_upd, survey_step
 
 
+def effective_tile(B, k, tile_rows):
+    want = tile_rows or (524_288 if k > 32 else 262_144)  # fmx_api.hip effective_tile_rows()
+    tiles = -(-B // want)
+    return -(-B // tiles)
+
+
 def pmc_traffic(kernel, args):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r*_pmc_summary.json,
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/r*_pmc_summary*.json,
     made by profiles/pmc_run.sh with the SAME workload arguments), or None.  bench.py cannot run rocprofv3 on itself."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
@@ -75,9 +94,11 @@ def pmc_traffic(kernel, args):
         a = d.get("_bench_args", [])
         def opt(name, default):
             return int(a[a.index(name) + 1]) if name in a else default
-        same = (-(-opt("--batch-rows", 1_048_576) // -(-opt("--batch-rows", 1_048_576) // 262_144)) == -(-args.batch_rows // -(-args.batch_rows // 262_144)) and opt("--factors", 16) == args.factors and opt("--features", 1_000_000) == args.features
-                and opt("--rows", 10_000_000) == args.rows and opt("--nnz", 30) == args.nnz and ("ftrl" in a) == (args.solver == "ftrl")
-                and ("--state-fp64" in a) == bool(args.state_fp64))
+        solver = "ftrl" if "ftrl" in a else "sgd"
+        k = opt("--factors", 16 if solver == "sgd" else 64)
+        same = (effective_tile(opt("--batch-rows", 1_048_576), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
+                and k == args.factors and opt("--features", 1_000_000) == args.features and opt("--rows", 10_000_000) == args.rows
+                and opt("--nnz", 30) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64))
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
             best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f))
     return best
@@ -95,21 +116,33 @@ def host_cpu_share():
     return max(1, min(n, 16))
 
 
+def oracle_params(args):
+    import oracle
+    if args.solver == "sgd":
+        return oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
+    return oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-4, l2_regv=1e-4)
+
+
 def cpu_baseline(m, args, v0):
-    """Oracle (reference-order serial SGD, one core) on the first cpu_rows rows of the same matrix."""
+    """Oracle (the reference's serial learner, one core) on the first cpu_rows rows of the same matrix."""
     import oracle
     n = min(args.cpu_rows, m.n)
     rp, col, val, y = m.export(0, n)
     X = oracle.Matrix(rp, col, val, args.features)
-    P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
+    P = oracle_params(args)
     w = np.zeros(args.features)
     v = np.ascontiguousarray(v0.astype(np.float64))  # [k][p] factor-major, the reference's layout
     oracle.lib()
     t0 = time.perf_counter()
-    done = oracle.sgd_pass(P, X, y, 0.0, w, v.ravel())
+    if args.solver == "sgd":
+        done = oracle.sgd_pass(P, X, y, 0.0, w, v.ravel())
+    else:
+        done = oracle.ftrl_learn(P, X, y, 0.0, w, v.ravel(), n - 1)["iters"]
     dt = time.perf_counter() - t0
     out = {"value": done / dt, "unit": "examples/s", "cores": 1, "kind": "port",
-           "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial pass ({dt:.1f} s)"}
+           "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial {args.solver.upper()} pass ({dt:.1f} s)"}
+    if args.solver != "sgd":
+        return out
     # SURVEY 8(d) item ii, reported beside it: what all host cores give.  The reference has no parallel training, so the
     # yardstick is its example step run lock-free over row ranges (Hogwild); its forward is OpenMP over rows as shipped.
     threads = min(oracle.omp_threads(), host_cpu_share())
@@ -123,6 +156,85 @@ def cpu_baseline(m, args, v0):
     dt_f = time.perf_counter() - t0
     out["all_cores"] = {"cores": threads, "hogwild_examples_per_s": done / dt_h, "forward_rows_per_s": n / dt_f,
                         "sample": f"rows 0..{n - 1}, one lock-free OpenMP pass ({dt_h:.1f} s) and one OpenMP forward ({dt_f:.1f} s)"}
+    return out
+
+
+def engine_kwargs(args, L, B, local_rank, world, **over):
+    ftrl = args.solver == "ftrl"
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_FTRL if ftrl else L.SOLVER_SGD, num_factor=args.factors, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
+              l1_w1=1e-4 if ftrl else 0.0, l1_v=1e-4 if ftrl else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=args.tile_rows, device=local_rank,
+              keep_w1=0 if args.no_linear else 1, state_fp64=int(args.state_fp64),
+              exchange_chunks=(args.exchange_chunks or (8 if world == 2 else 4)) if world > 1 else 0)
+    kw.update(over)
+    return kw
+
+
+def timed_steps(e, m, nb, steps, warmup):
+    for i in range(warmup):
+        e.step(m, i % nb)
+    e.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        e.step(m, (warmup + i) % nb)
+    e.sync()
+    return time.perf_counter() - t0
+
+
+def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows):
+    """What `value` does not say; every figure is measured here, on this GPU, in this run."""
+    out = {}
+    z, k, p = args.nnz, args.factors, args.features
+    n = m.n
+    # one-off ingest amortised over the reference's default run length (2 passes, R/fm_train.R:92) and over one pass
+    out["end_to_end"] = {"csc_build_s": csc_build_s, "one_epoch_examples_per_s": n / (csc_build_s + n / value),
+                         "two_epochs_examples_per_s": 2 * n / (csc_build_s + 2 * n / value),
+                         "note": "per-tile CSC build of the whole matrix (device radix sort, once per matrix) + training passes at `value`"}
+    # the access pattern's ceiling at each kernel's own table: random rows of kp*e bytes from V (phase 1) and from S (phase 2)
+    eb = 8 if args.state_fp64 else 4
+    kp = 4
+    while kp < k:
+        kp *= 2
+    row_bytes = min(256, max(16, kp * eb))
+    lines = (kp * eb) // row_bytes  # rows wider than 256 B are fetched as several 256-B pieces
+    ceil = {}
+    for name, table in (("fm_rows_forward", p * kp * eb), ("fm_cols_update", tile_rows * kp * eb)):
+        r = engine.measure_gather(table, row_bytes, n_groups=tile_rows, per_group=32, in_flight=4, reps=20, device=0) / max(lines, 1)
+        got = tile_rows * z / (kernels[name][1] * 1e-3) if kernels[name][1] > 0 else 0.0
+        ceil[name] = {"table_MB": table / 1e6, "row_bytes": kp * eb, "ceiling_rows_per_s": r, "kernel_rows_per_s": got, "ceiling_frac": got / r if r else None}
+    out["gather_ceiling"] = ceil
+    if args.state_fp64:
+        return out
+    # the reference's precision in the throughput mode
+    e64 = engine.Engine(p, **engine_kwargs(args, L, min(args.batch_rows, n), 0, 1, state_fp64=1))
+    e64.set_params(0.0, None, v0.astype(np.float64))
+    nb = max(1, n // min(args.batch_rows, n))
+    dt = timed_steps(e64, m, nb, max(4, args.steps // 2), 2)
+    out["value_fp64_state"] = min(args.batch_rows, n) * max(4, args.steps // 2) / dt
+    e64.close()
+    # small steps (latency-bound: two dependent launches per step) on the first 2M rows
+    sub_n = min(n, 2_000_000)
+    sub = engine.Matrix.synthetic(sub_n, p, z, args.seed, row_offset=0)
+    small = {}
+    for B in (4096, 16384):
+        es = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
+        es.set_params(0.0, None, v0.astype(np.float64))
+        nbs = es.num_batches(sub)
+        steps = 300 if B == 4096 else 150
+        small[str(B)] = B * steps / timed_steps(es, sub, nbs - 1, steps, 20)
+        es.close()
+    out["small_batch"] = dict(small, unit="examples/s", note="same engine, batch_rows = 4096 / 16384 (one fused tile per step)")
+    # the mode the reference-parity claim is made in: the reference's own algorithm, one example per update, fp64
+    seq = engine.Engine(p, **engine_kwargs(args, L, 1, 0, 1, mode=L.MODE_SEQUENTIAL, state_fp64=0, tile_rows=0))
+    seq.set_params(0.0, None, v0.astype(np.float64))
+    cnt = 200_000 if args.solver == "sgd" else 60_000
+    seq.train(sub, 20_000)
+    t0 = time.perf_counter()
+    done = seq.train(sub, cnt)
+    out["sequential_exact"] = {"value": done / (time.perf_counter() - t0), "unit": "examples/s",
+                               "note": "FMX_MODE_SEQUENTIAL: the reference's per-example algorithm in its visiting order (fp64 state); "
+                                       "1e-5-on-V parity with the reference CPU path is asserted in THIS mode; `value` is the mini-batch mode"}
+    seq.close()
+    sub.close()
     return out
 
 
@@ -154,29 +266,36 @@ def main():
             dist.init_process_group(args.backend)
 
     z, k, p = args.nnz, args.factors, args.features
+    ftrl = args.solver == "ftrl"
     from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows
     r0, r1 = shard_rows(args.rows, rank, world)
     n_local = r1 - r0
     B = min(args.batch_rows, args.rows // world)
     m = engine.Matrix.synthetic(n_local, p, z, args.seed, row_offset=r0, device=local_rank)
-    solver = L.SOLVER_SGD if args.solver == "sgd" else L.SOLVER_FTRL
-    e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=solver, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
-                      l1_w1=1e-4 if args.solver == "ftrl" else 0.0, l1_v=1e-4 if args.solver == "ftrl" else 0.0,
-                      mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=args.tile_rows, device=local_rank, keep_w1=0 if args.no_linear else 1,
-                      state_fp64=int(args.state_fp64), exchange_chunks=(args.exchange_chunks or (8 if world == 2 else 4)) if world > 1 else 0)
+    e = engine.Engine(p, **engine_kwargs(args, L, B, local_rank, world))
     v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
     e.set_params(0.0, None, v0.astype(np.float64))
     nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work
-    e.num_batches(m)              # builds the per-batch CSC (ingest, not timed)
+    e.sync()
+    t_ing = time.perf_counter()
+    e.num_batches(m)              # builds the per-tile CSC (ingest: not in the timed region; reported as end_to_end)
+    e.sync()
+    csc_build_s = time.perf_counter() - t_ing
 
-    dp = DataParallel(EngineStepper(e, m, local_rank)) if world > 1 else None
+    dp = None
+    if world > 1:
+        want = args.exchange
+        st = EngineStepper(e, m, local_rank, dense=(want == "dense"))
+        dp = DataParallel(st, exchange="dense" if want == "dense" else "compact")
+        if want == "compact" and dp.exchange != "compact":
+            raise SystemExit("--exchange compact needs steps of one sparse tile on every rank")
 
     def one_step(i):
         b = i % nb_full
         if world == 1:
             e.step(m, b)      # fused: forward -> w0 step -> gradient sums + update
         else:
-            dp.step(b)        # forward -> per feature block: gradient sums -> RCCL all-reduce (async) -> update
+            dp.step(b)        # forward -> gradient sums -> RCCL exchange -> update
 
     def fence():
         e.sync()
@@ -226,11 +345,10 @@ def main():
         value = rows_step * args.steps / dt
         fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
         upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
-        tiles = -(-B // (args.tile_rows or (524_288 if k > 32 else 262_144)))  # fmx_api.hip effective_tile_rows()
-        tile_rows = -(-B // tiles)
+        tile_rows = effective_tile(B, k, args.tile_rows)
         eb = 8 if args.state_fp64 else 4
-        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p, tile_rows, eb)   # per LAUNCH: one tile
-        b_step = algorithmic_bytes(z, k, p, B, eb)[2]
+        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p, tile_rows, eb, ftrl)   # per LAUNCH: one tile
+        b_step = algorithmic_bytes(z, k, p, B, eb, ftrl)[2]
         kernels = {
             "fm_rows_forward": (b_fwd, fwd_ms / max(fwd_n, 1)),
             "fm_cols_update": (b_upd, upd_ms / max(upd_n, 1)),
@@ -238,28 +356,41 @@ def main():
         # N > 1: phase 2 runs as one launch per (feature block, tile) plus the per-block updates, so only phase 1 keeps the
         # one-launch-per-tile byte count the roofline line is defined on
         dom = max(kernels, key=lambda name: kernels[name][1]) if world == 1 else "fm_rows_forward"
-        dbytes, dms = kernels[dom]
-        achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-        traffic = pmc_traffic(dom, args) if world == 1 else None
+        per_kernel = {}
+        for name, (nbytes, ms) in kernels.items():
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tr = pmc_traffic(name, args) if world == 1 else None
+            per_kernel[name] = {"algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                "traffic": tr[0] if tr else None, "traffic_source": f"profiles/{tr[1]}" if tr else None}
+        step_gbs = b_step / (dt / args.steps) / 1e9   # per GPU: B rows of this rank per step
+        traffic = per_kernel[dom]["traffic"]
         out = {
             "metric": "training examples/sec, 10Mx1M sparse FM SGD", "value": value, "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.state_fp64 else "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch "
-                                   f"(BASELINE.json configs[{1 if args.solver == 'sgd' else 2}])",
+                                   f"(BASELINE.json configs[{2 if ftrl else 1}])",
                        "batch_rows_per_gpu": B, "tile_rows": tile_rows, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
-                       "state": ("fp64" if args.state_fp64 else "fp32") + " V[p][k] + w[p], fp64 accumulation", "parallelism": f"dp{world}",
-                       **({"exchange": f"all-reduce(sum) of {e.grad_buffer()[1] * e.grad_elem_bytes() / 1e6:.1f} MB per step in {e.grad_layout()[0]} pipelined blocks"} if world > 1 else {})},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                         "traffic_source": (f"profiles/{traffic[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB per launch, separate --pmc passes; "
+                       "batch_reduce": "mean gradient per coordinate per step (FMX_REDUCE_MEAN)",
+                       "state": ("fp64" if args.state_fp64 else "fp32") + " V[p][k] + w[p]" + (" + z, n" if ftrl else "") + ", fp64 accumulation",
+                       "parallelism": f"dp{world}",
+                       **({"exchange": (f"all-reduce(sum) of {e.grad_buffer()[1] * e.grad_elem_bytes() / 1e6:.1f} MB per step in {e.grad_layout()[0]} pipelined blocks"
+                                        if dp.exchange == "dense" else
+                                        f"all-gather of the occurring features' records: {dp.last_exchange_bytes / 1e6:.1f} MB received per rank per step")} if world > 1 else {})},
+            # headline: the whole step priced in SURVEY 8(d)'s algorithmic bytes (SGD z(16+8k)+12, FTRL z(32+24k)+12 per example),
+            # i.e. value x bytes/example / 8 TB/s per GPU; the two kernels on their own bytes and HIP-event times are in `kernels`
+            "roofline": {"bound": "hbm", "kernel": "step = fm_rows_forward + fm_cols_update per tile", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (f"{per_kernel[dom]['traffic_source']}: (FETCH_SIZE*2 + WRITE_SIZE) KiB per launch of {dom}, separate --pmc passes; "
                                             "upper bound, see DESIGN.md section 6") if traffic else None,
-                         "algorithmic_bytes_per_launch": dbytes, "avg_launch_ms": dms,
-                         "kernels_ms": {name: kv[1] for name, kv in kernels.items()},
-                         "step_algorithmic_GBps": b_step / (dt / args.steps) / 1e9 / world},
+                         "algorithmic_bytes_per_example": b_step / B, "dominant_kernel": dom, "kernels": per_kernel},
         }
         if fwd_rate is not None:
             out["forward_rows_per_s"] = fwd_rate
+        if world == 1 and not args.no_extras:
+            out.update(side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows))
+            for name, c in out["gather_ceiling"].items():
+                out["roofline"]["kernels"][name]["ceiling_frac"] = c["ceiling_frac"]
         if world == 1 and args.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(m, args, v0)
         print(json.dumps(out), flush=True)

@@ -576,6 +576,64 @@ int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offs
   return FMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ parameter tables
+// V0 ~ N(mean, stdev) drawn on the device (Philox4x32-10 keyed by (seed; feature, factor / 2), Box-Muller in fp64): for
+// synthetic workloads whose V does not fit a host round trip comfortably (p = 33 M, k = 32: 8.4 GB of doubles).  It is NOT the
+// reference's generator (Rf_rnorm, util/Dmatrix.h:143-146): parity runs pass V0 through fmx_set_params.
+template <typename T>
+__global__ void init_normal_k(T* __restrict__ V, uint64_t p, int k, int kp, uint64_t seed, double mean, double stdev) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = (k + 1) / 2;
+  if (t >= (int64_t)p * half) return;
+  const uint64_t j = (uint64_t)(t / half);
+  const int f = (int)(t - (int64_t)j * half) * 2;
+  const Philox ph = philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), (uint32_t)(f >> 1), 0x56u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const double u1 = ((double)ph.c[0] + 1.0) / 4294967296.0, u2 = (double)ph.c[1] / 4294967296.0;
+  const double r = sqrt(-2.0 * log(u1)), a = 6.283185307179586476925 * u2;
+  V[j * kp + f] = (T)(mean + stdev * r * cos(a));
+  if (f + 1 < k) V[j * kp + f + 1] = (T)(mean + stdev * r * sin(a));
+}
+
+int init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev) {
+  const int64_t total = (int64_t)e->p * ((e->k + 1) / 2);
+  if (total == 0) return FMX_OK;
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  if (wide_state(e)) hipLaunchKernelGGL((init_normal_k<double>), g, b, 0, e->stream, e->dV, e->p, e->k, e->kp64, seed, mean, stdev);
+  else hipLaunchKernelGGL((init_normal_k<float>), g, b, 0, e->stream, e->V, e->p, e->k, e->kp32, seed, mean, stdev);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// rows of (w, V) picked by feature id <-> a dense [n][k] / [n] pair of double buffers
+template <typename T, bool SET>
+__global__ void rows_copy_k(T* __restrict__ V, T* __restrict__ w, int k, int kp, const uint32_t* __restrict__ ids, int64_t n, double* __restrict__ bw,
+                            double* __restrict__ bv) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kk = k + 1;
+  if (t >= n * kk) return;
+  const int64_t i = t / kk;
+  const int f = (int)(t - i * kk);
+  const size_t j = ids[i];
+  if (f == k) { if (SET) w[j] = (T)bw[i]; else bw[i] = (double)w[j]; }
+  else if (SET) V[j * kp + f] = (T)bv[i * k + f];
+  else bv[i * k + f] = (double)V[j * kp + f];
+}
+
+int rows_copy(fmx_engine* e, const uint32_t* d_ids, int64_t n, double* d_w, double* d_v, bool set) {
+  const int64_t total = n * (e->k + 1);
+  if (total == 0) return FMX_OK;
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  if (wide_state(e)) {
+    if (set) hipLaunchKernelGGL((rows_copy_k<double, true>), g, b, 0, e->stream, e->dV, e->dw, e->k, e->kp64, d_ids, n, d_w, d_v);
+    else hipLaunchKernelGGL((rows_copy_k<double, false>), g, b, 0, e->stream, e->dV, e->dw, e->k, e->kp64, d_ids, n, d_w, d_v);
+  } else {
+    if (set) hipLaunchKernelGGL((rows_copy_k<float, true>), g, b, 0, e->stream, e->V, e->w, e->k, e->kp32, d_ids, n, d_w, d_v);
+    else hipLaunchKernelGGL((rows_copy_k<float, false>), g, b, 0, e->stream, e->V, e->w, e->k, e->kp32, d_ids, n, d_w, d_v);
+  }
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ scales / normalize
 // Column sums in the reference run over the entries in storage order, i.e. ascending row inside a column: the full CSC
 // gives exactly that order, so the sums (hence every scaled float) are bit-identical to util/Smatrix.h:104-111.

@@ -1,0 +1,103 @@
+// Measurement aids behind the C ABI (include/fmx.h, "measurement" section).  Nothing here is on the product path.
+//
+// fmx_measure_gather: the rate at which the memory system serves uniformly random table rows -- the access pattern of
+// fm_rows_forward (V rows by column id) and fm_cols_update (S rows by row id) with everything else stripped away: the row
+// ids are generated in registers (an integer hash of the fetch number: no index stream, no side table), LPR = row_bytes / 16
+// lanes fetch one row as one contiguous segment, `in_flight` rows are outstanding per lane, every group sums `per_group`
+// rows and writes one row.  bench.py divides a kernel's rows/s by this figure at the kernel's own table size and row
+// width ("ceiling_frac"): how much of what the hardware gives this access pattern the kernel really gets.
+#include <hip/hip_runtime.h>
+
+#include "fmx_internal.h"
+
+namespace fmx {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // a full-avalanche integer hash (lowbias32)
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+template <int LPR, int U>
+__global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __restrict__ table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt,
+                                                             float4* __restrict__ out) {
+  const int64_t g = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) / LPR;
+  const int lig = threadIdx.x % LPR;
+  if (g >= n_groups) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t base = (uint32_t)g * (uint32_t)per_group + salt;
+  for (int t = 0; t < per_group; t += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // multiply-shift maps the hash onto [0, rows) without a division
+      const uint32_t r = (uint32_t)(((uint64_t)mix32(base + (uint32_t)(t + u)) * rows) >> 32);
+      v[u] = table[(size_t)r * LPR + lig];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  out[g * LPR + lig] = acc;
+}
+
+template <int LPR>
+static void launch_probe(int in_flight, dim3 g, dim3 b, hipStream_t s, const float4* table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt, float4* out) {
+  if (in_flight >= 8) hipLaunchKernelGGL((gather_probe_k<LPR, 8>), g, b, 0, s, table, rows, per_group, n_groups, salt, out);
+  else hipLaunchKernelGGL((gather_probe_k<LPR, 4>), g, b, 0, s, table, rows, per_group, n_groups, salt, out);
+}
+
+}  // namespace fmx
+
+using namespace fmx;
+
+extern "C" int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight, int32_t reps,
+                                  double* rows_per_s) {
+  FMX_CHECK(rows_per_s != nullptr, FMX_ERR_INVALID, "rows_per_s is NULL");
+  FMX_CHECK(row_bytes == 16 || row_bytes == 32 || row_bytes == 64 || row_bytes == 128 || row_bytes == 256, FMX_ERR_INVALID, "row_bytes must be 16..256, a power of two");
+  FMX_CHECK(table_bytes >= row_bytes && table_bytes / row_bytes < (1LL << 32) && n_groups > 0 && per_group > 0 && per_group % 8 == 0 && reps > 0, FMX_ERR_INVALID,
+            "bad probe geometry (per_group must be a multiple of 8)");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device available; libfmx has no CPU fallback"); return FMX_ERR_NOGPU; }
+  FMX_CHECK(device >= 0 && device < count, FMX_ERR_INVALID, "device %d out of range", device);
+  FMX_HIP(hipSetDevice(device));
+  const int lpr = row_bytes / 16;
+  const uint32_t rows = (uint32_t)(table_bytes / row_bytes);
+  float4 *table = nullptr, *out = nullptr;
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  int st = FMX_OK;
+  auto body = [&]() -> int {
+    FMX_HIP(hipMalloc(&table, (size_t)rows * row_bytes));
+    FMX_HIP(hipMalloc(&out, (size_t)n_groups * row_bytes));
+    FMX_HIP(hipMemset(table, 0, (size_t)rows * row_bytes));
+    FMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    FMX_HIP(hipEventCreate(&a)); FMX_HIP(hipEventCreate(&b));
+    FMX_HIP(hipDeviceSynchronize());
+    const int64_t threads = n_groups * lpr;
+    const dim3 g((unsigned)((threads + WG_THREADS - 1) / WG_THREADS)), blk(WG_THREADS);
+    auto launch = [&](uint32_t salt) {
+      switch (lpr) {
+        case 1: launch_probe<1>(in_flight, g, blk, s, table, rows, per_group, n_groups, salt, out); break;
+        case 2: launch_probe<2>(in_flight, g, blk, s, table, rows, per_group, n_groups, salt, out); break;
+        case 4: launch_probe<4>(in_flight, g, blk, s, table, rows, per_group, n_groups, salt, out); break;
+        case 8: launch_probe<8>(in_flight, g, blk, s, table, rows, per_group, n_groups, salt, out); break;
+        default: launch_probe<16>(in_flight, g, blk, s, table, rows, per_group, n_groups, salt, out); break;
+      }
+    };
+    for (int i = 0; i < 3; ++i) launch(0x9e3779b9u * (uint32_t)i);
+    FMX_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < reps; ++i) launch(0x85ebca6bu * (uint32_t)(i + 7));  // other rows every launch
+    FMX_HIP(hipEventRecord(b, s));
+    FMX_HIP(hipEventSynchronize(b));
+    FMX_HIP(hipGetLastError());
+    float ms = 0.f;
+    FMX_HIP(hipEventElapsedTime(&ms, a, b));
+    *rows_per_s = (double)n_groups * per_group * reps / ((double)ms * 1e-3);
+    return FMX_OK;
+  };
+  st = body();
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  if (s) (void)hipStreamDestroy(s);
+  (void)hipFree(table); (void)hipFree(out);
+  return st;
+}

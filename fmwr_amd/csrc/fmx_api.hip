@@ -498,7 +498,9 @@ static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t row
   if (tiles.empty()) tiles.push_back({m->step_first_tile[(size_t)batch], 0, 0});  // an empty share publishes no record, but its tail
   const auto& pl = m->plans[(size_t)tiles[0].tile];
   FMX_CHECK(pl.feat != nullptr, FMX_ERR_STATE, "the compact exchange needs sparse tiles (fewer entries than features per tile); use fmx_grad for dense ones");
-  FMX_TRY(ensure_compact(e, compact_capacity(m)));
+  // room for this step's records; grows only when a step needs more than was reserved (fmx_compact_reserve: the pointer a
+  // driver holds stays valid as long as it reserved enough)
+  FMX_TRY(ensure_compact(e, (int64_t)pl.n_lists > 0 ? (int64_t)pl.n_lists : 1));
   int64_t np = 0;
   FMX_TRY(rows_phase(e, m, tiles[0], 0, &np));
   ColsArgs c{};
@@ -623,19 +625,31 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
   FMX_HIP(hipMemcpy(e->scal + SC_W0, &w0, sizeof(double), hipMemcpyHostToDevice));
   if (wide_state(e)) {
     const int kp = e->kp64;
-    std::vector<double> hv(p * kp, 0.0);
-    if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = v[f + j * (size_t)k];
-    FMX_HIP(hipMemcpy(e->dV, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (v) {
+      std::vector<double> hv(p * kp, 0.0);
+      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = v[f + j * (size_t)k];
+      FMX_HIP(hipMemcpy(e->dV, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+      FMX_HIP(hipMemset(e->dV, 0, p * kp * sizeof(double)));  // no p-sized host buffer for "zeros" (p = 33 M: 8.4 GB)
+    }
     if (w) FMX_HIP(hipMemcpy(e->dw, w, p * sizeof(double), hipMemcpyHostToDevice));
     else FMX_HIP(hipMemset(e->dw, 0, p * sizeof(double)));
   } else {
     const int kp = e->kp32;
-    std::vector<float> hv(p * kp, 0.f);
-    if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = (float)v[f + j * (size_t)k];
-    FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
-    std::vector<float> hw(p, 0.f);
-    if (w) for (size_t j = 0; j < p; ++j) hw[j] = (float)w[j];
-    FMX_HIP(hipMemcpy(e->w, hw.data(), p * sizeof(float), hipMemcpyHostToDevice));
+    if (v) {
+      std::vector<float> hv(p * kp, 0.f);
+      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = (float)v[f + j * (size_t)k];
+      FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+      FMX_HIP(hipMemset(e->V, 0, p * kp * sizeof(float)));
+    }
+    if (w) {
+      std::vector<float> hw(p);
+      for (size_t j = 0; j < p; ++j) hw[j] = (float)w[j];
+      FMX_HIP(hipMemcpy(e->w, hw.data(), p * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+      FMX_HIP(hipMemset(e->w, 0, p * sizeof(float)));
+    }
   }
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   FMX_TRY(reset_optimizer_state(e));  // learner->init() zeroes q/u (SGD_Learner.h:61-69) and z/n (FTRL_Learner.h:50-55)
@@ -672,6 +686,53 @@ int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v) {
     }
   }
   return FMX_OK;
+}
+
+int fmx_init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(fmx_set_params(e, 0.0, nullptr, nullptr));  // w0 = 0, w = 0 (core/Model.h:63-72), optimizer state reset
+  FMX_TRY(init_normal(e, seed, mean, stdev));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  return FMX_OK;
+}
+
+static int rows_io(fmx_engine* e, const uint32_t* ids, int64_t n, double* w, double* v, bool set) {
+  FMX_CHECK(e != nullptr && n >= 0 && (n == 0 || ids), FMX_ERR_INVALID, "bad argument");
+  for (int64_t i = 0; i < n; ++i) FMX_CHECK((uint64_t)ids[i] < e->p, FMX_ERR_INVALID, "feature id %u out of range", ids[i]);
+  FMX_TRY(use_device(e->cfg.device));
+  if (n == 0) return FMX_OK;
+  uint32_t* d_ids = nullptr; double *d_w = nullptr, *d_v = nullptr;
+  const size_t kk = (size_t)(e->k > 0 ? e->k : 1);
+  int st = FMX_OK;
+  auto body = [&]() -> int {
+    FMX_HIP(hipMalloc(&d_ids, (size_t)n * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&d_w, (size_t)n * sizeof(double)));
+    FMX_HIP(hipMalloc(&d_v, (size_t)n * kk * sizeof(double)));
+    FMX_HIP(hipMemcpy(d_ids, ids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (set) {
+      // a NULL part keeps the rows' current values: read them first
+      FMX_TRY(rows_copy(e, d_ids, n, d_w, d_v, false));
+      FMX_HIP(hipStreamSynchronize(e->stream));
+      if (w) FMX_HIP(hipMemcpy(d_w, w, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      if (v && e->k > 0) FMX_HIP(hipMemcpy(d_v, v, (size_t)n * kk * sizeof(double), hipMemcpyHostToDevice));
+    }
+    FMX_TRY(rows_copy(e, d_ids, n, d_w, d_v, set));
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    if (!set) {
+      if (w) FMX_HIP(hipMemcpy(w, d_w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+      if (v && e->k > 0) FMX_HIP(hipMemcpy(v, d_v, (size_t)n * kk * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return FMX_OK;
+  };
+  st = body();
+  (void)hipFree(d_ids); (void)hipFree(d_w); (void)hipFree(d_v);
+  return st;
+}
+
+int fmx_get_rows(fmx_engine* e, const uint32_t* ids, int64_t n, double* w, double* v) { return rows_io(e, ids, n, w, v, false); }
+int fmx_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* w, const double* v) {
+  return rows_io(e, ids, n, const_cast<double*>(w), const_cast<double*>(v), true);
 }
 
 namespace fmx {

@@ -341,6 +341,8 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int check_rows_sorted(fmx_matrix* m);
+int init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev);
+int rows_copy(fmx_engine* e, const uint32_t* d_ids, int64_t n, double* d_w, double* d_v, bool set);
 int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double* h_std);
 int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std);
 

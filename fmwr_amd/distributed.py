@@ -211,7 +211,9 @@ class DataParallel:
             table = [pad]
         self.counts = torch.stack(table).cpu().numpy()       # [world][steps]
         self.max_records = int(self.counts.max()) if self.counts.size else 0
-        s.compact_reserve(max(self.max_records, 1))           # every rank sends slices of the same length
+        # every rank sends slices of the same length (the largest count of the step): reserve the global maximum once, so
+        # that the engine never has to move its record buffer (the tensor view below points into it)
+        s.compact_reserve(max(self.max_records, 1))
         self.bytes_per_step = []                              # filled as steps run: what the step moved per rank
 
     def _step_compact(self, batch, rows_limit):

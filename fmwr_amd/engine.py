@@ -93,6 +93,14 @@ class Matrix:
             pass
 
 
+def measure_gather(table_bytes, row_bytes, n_groups=262_144, per_group=32, in_flight=4, reps=30, device=0):
+    """rows/s the memory system serves for uniformly random rows of `row_bytes` from a `table_bytes` table (fmx_measure_gather)."""
+    out = C.c_double()
+    L.check(L.lib().fmx_measure_gather(C.c_int(device), C.c_int64(table_bytes), C.c_int32(row_bytes), C.c_int64(n_groups), C.c_int32(per_group),
+                                       C.c_int32(in_flight), C.c_int32(reps), C.byref(out)))
+    return out.value
+
+
 class Engine:
     """Parameters + optimizer state on one GPU (fmx_engine*)."""
 
@@ -128,6 +136,23 @@ class Engine:
         L.check(L.lib().fmx_get_params(self.h, C.byref(w0), _p(w), _p(vv)))
         v = vv[: self.k * self.p].reshape(self.p, self.k).T.copy()
         return w0.value, w, v
+
+    def init_normal(self, seed, mean=0.0, stdev=0.01):
+        """w0 = 0, w = 0, V ~ N(mean, stdev) drawn on the device (synthetic workloads; not R's generator)."""
+        L.check(L.lib().fmx_init_normal(self.h, C.c_uint64(seed), C.c_double(mean), C.c_double(stdev)))
+
+    def get_rows(self, ids):
+        """(w[n], v[k][n]) of the listed features."""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        w = np.zeros(max(len(ids), 1)); vv = np.zeros(max(len(ids) * self.k, 1))
+        L.check(L.lib().fmx_get_rows(self.h, _p(ids), C.c_int64(len(ids)), _p(w), _p(vv)))
+        return w[: len(ids)], vv[: len(ids) * self.k].reshape(len(ids), self.k).T.copy()
+
+    def set_rows(self, ids, w=None, v=None):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        w = None if w is None else np.ascontiguousarray(w, np.float64)
+        vv = None if v is None else np.ascontiguousarray(np.asarray(v, np.float64).T).ravel()
+        L.check(L.lib().fmx_set_rows(self.h, _p(ids), C.c_int64(len(ids)), _p(w), _p(vv)))
 
     def save(self, path):
         L.check(L.lib().fmx_engine_save(self.h, str(path).encode()))

@@ -122,6 +122,16 @@ int fmx_engine_destroy(fmx_engine* e);
 int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v);
 int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v);
 
+/* Sparse access to the parameters (p = 33 M, k = 32 is 8.4 GB of doubles: a full fmx_get_params is the wrong tool there):
+ * rows of the features ids[0..n): w -> w[i], V -> v[f + i*k] (the same k x n column-major shape as fmx_set_params).
+ * fmx_set_rows leaves every other row and the optimizer state alone; a NULL w or v keeps that part of the rows. */
+int fmx_get_rows(fmx_engine* e, const uint32_t* ids, int64_t n, double* w, double* v);
+int fmx_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* w, const double* v);
+/* w0 = 0, w = 0, V ~ N(mean, stdev) drawn ON THE DEVICE (Philox4x32-10 keyed by seed, feature and factor pair; Box-Muller):
+ * the shape of Model::init (core/Model.h:63-72) for synthetic workloads too large to stage through the host.  It is not R's
+ * generator: runs that must reproduce the reference draw V0 in the glue and pass it to fmx_set_params. */
+int fmx_init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev);
+
 /* ---- checkpoint (the reference keeps a model only as an R list and drops the optimizer state on fm.update):
  * parameters AND optimizer state (SGD-L1 q/u, FTRL z/n, TDAP u/nu/delta/h/z) to a file and back.  The loading engine must
  * have the same feature count, factor count, solver kind and mode.  Format: 64-byte header ("FMX1", version, shape),
@@ -300,6 +310,12 @@ int fmx_mcmc_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double*
 int fmx_profile_enable(fmx_engine* e, int on);
 int fmx_profile_get(fmx_engine* e, int kernel, double* total_ms, int64_t* launches);
 int fmx_profile_reset(fmx_engine* e);
+/* What the memory system gives the hot kernels' access pattern and nothing else: uniformly random rows of row_bytes bytes
+ * (16..256, a power of two) from a table of table_bytes bytes; ids are generated in registers, row_bytes / 16 lanes fetch a row,
+ * in_flight (4 or 8) rows outstanding per lane, n_groups lane groups each summing per_group rows, `reps` launches timed with
+ * HIP events.  bench.py reports kernel rows/s divided by this figure as "ceiling_frac". */
+int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight,
+                       int32_t reps, double* rows_per_s);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@ import pytest
 import scipy.sparse as sp
 
 import oracle
+from tests import util
 
 pytestmark = pytest.mark.gpu
 

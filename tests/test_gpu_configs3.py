@@ -1,0 +1,73 @@
+"""BASELINE.json configs[3] at its real feature shape: p = 33 M features, k = 32, 39 nnz/row (13 always-present "dense"
+features + 26 skewed categorical ones), mini-batch SGD.  The oracle cannot hold k x p doubles, and does not have to: a
+step only reads and writes the rows of the features that occur, so it runs on the problem restricted to those features
+(ids remapped order-preservingly, which keeps every row's entry order and every feature's list order), starting from
+the very V0 rows the engine holds (fmx_init_normal draws them on the device; fmx_get_rows reads them back)."""
+import numpy as np
+import pytest
+
+import oracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+P_FULL, K, Z = 33_000_000, 32, 39
+
+
+def _criteo_shaped(n, seed):
+    rng = np.random.default_rng(seed)
+    dense = np.tile(np.arange(13, dtype=np.int64), (n, 1))
+    cat = 13 + np.floor((P_FULL - 13) * rng.random((n, 60)) ** 3).astype(np.int64)   # skewed towards small ids: collisions between rows
+    rows = []
+    for r in range(n):
+        u = np.unique(cat[r])[:26]
+        rows.append(np.concatenate([dense[r], u]))
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows).astype(np.uint32)
+    val = np.where(col < 13, rng.random(len(col)), 1.0).astype(np.float32)   # dense features carry a value, categorical ones are one-hot
+    y = np.where(rng.random(n) < 0.5, -1.0, 1.0).astype(np.float32)
+    return rp, col, val, y
+
+
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_configs3_shape_minibatch_matches_oracle_on_the_touched_features(reduce):
+    from fmwr_amd import _lib as L, engine
+    n, B = 6144, 2048
+    rp, col, val, y = _criteo_shaped(n, 33)
+    lr = 0.01 if reduce == "sum" else 0.05
+    e = engine.Engine(P_FULL, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=K, learn_rate=lr, l2_w1=1e-4, l2_v=1e-4,
+                      mode=L.MODE_MINIBATCH, batch_rows=B, batch_reduce=L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM)
+    e.init_normal(20240001, 0.0, 0.01)
+    touched = np.unique(col)
+    assert 13 < len(touched) < n * Z and touched[-1] > 30_000_000
+    w_t, v_t = e.get_rows(touched)
+    assert np.all(w_t == 0.0) and abs(np.std(v_t) - 0.01) < 2e-4 and abs(np.mean(v_t)) < 1e-4   # N(0, 0.01) as asked
+    rng = np.random.default_rng(1)
+    other = np.setdiff1d(rng.integers(0, P_FULL, 5000).astype(np.uint32), touched)
+    w_o, v_o = e.get_rows(other)
+    m = engine.Matrix.from_csr(rp, col, val, P_FULL, y)
+    rec_elems, cap, usable = e.compact_info(m)
+    assert usable and rec_elems == K + 4 and cap <= B * Z     # sparse single-tile steps: no p-sized array per tile
+    # the oracle on the restricted problem
+    pc = len(touched)
+    colc = np.searchsorted(touched, col).astype(np.uint32)
+    P = oracle.params(task=oracle.CLASSIFICATION, k=K, l2_regw=1e-4, l2_regv=1e-4, learn_rate=lr, batch_mean=(reduce == "mean"))
+    mb = oracle.SgdMinibatch(P, oracle.Matrix(rp, colc, val, pc), y, 0.0, w_t, v_t.ravel())
+    for s in range(5):
+        b = s % (n // B)
+        mb.step(b * B, (b + 1) * B)
+        e.step(m, b)
+    e.sync()
+    g_w, g_v = e.get_rows(touched)
+    assert util.rel_err(g_v, mb.v.reshape(K, pc)) < 1e-5 and util.rel_err(g_w, mb.w) < 1e-5
+    w0 = e.get_rows(touched[:1])  # (w0 travels with get_params only; read it through a 1-row predict instead)
+    one = engine.Matrix.from_csr(np.array([0, 0], np.int64), np.zeros(0, np.uint32), np.zeros(0, np.float32), P_FULL)
+    assert abs(e.predict(one)[0] - mb.w0.value) < 1e-6 * max(1.0, abs(mb.w0.value))
+    # features that never occurred keep their rows bit for bit (lazy regularisation, SURVEY A-10)
+    w_o2, v_o2 = e.get_rows(other)
+    assert np.array_equal(w_o, w_o2) and np.array_equal(v_o, v_o2)
+    # forward at this shape against the oracle on the restricted problem
+    out = e.predict(m)
+    ref = oracle.predict_batch(P, oracle.Matrix(rp, colc, val, pc), mb.w0.value, mb.w, mb.v)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+    assert np.array_equal(np.sign(out[np.abs(ref) > 1e-4]), np.sign(ref[np.abs(ref) > 1e-4]))

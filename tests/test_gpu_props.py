@@ -189,3 +189,75 @@ def test_full_size_sequential_window_equals_one_wave(fm, big):
             os.environ.pop("FMX_SEQ_WINDOW", None)
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert np.any(out[0][2] != v0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] at FULL size: 10M x 1M, k = 64, FTRL (l1 + l2).  Properties that need no CPU pass over the matrix.
+K2 = 64
+FTRL2 = dict(alpha_w=0.1, alpha_v=0.1, beta_w=1.0, beta_v=1.0, l1_w1=1e-4, l1_v=1e-4, l2_w1=1e-4, l2_v=1e-4)
+
+
+def test_configs2_full_size_first_ftrl_step_against_host_counts(fm, big):
+    """From w = 0, V = 0, z = n = 0 every example has y_hat = 0 and multiplier -y/2, so one SUM-mode FTRL step has a closed
+    form per feature (FTRL_Learner.h:88-98, :172-183 with the batch sums): G_j = -1/2 * sum of the labels of the batch rows
+    holding j, n_j = c_j / 4, z_j = G_j, w_j = prox(z_j, n_j); w0 likewise from all rows; V stays 0 (s_f = 0, v = 0).
+    Checked on a full and on the ragged last batch against a host bincount of the exported rows."""
+    engine, L = fm
+    e = engine.Engine(P, solver=L.SOLVER_FTRL, num_factor=K2, mode=L.MODE_MINIBATCH, batch_rows=B, batch_reduce=L.REDUCE_SUM, **FTRL2)
+    nb = e.num_batches(big)
+    a, b_, l1, l2 = FTRL2["alpha_w"], FTRL2["beta_w"], FTRL2["l1_w1"], FTRL2["l2_w1"]
+    for batch in (1, nb - 1):
+        e.set_params(0.0, None, None)
+        e.step(big, batch)
+        e.sync()
+        w0, w, v = e.get_params()
+        r0 = batch * B
+        rp, col, val, y = big.export(r0, min(r0 + B, N))
+        yy = y.astype(np.float64)
+        G0, n0 = -0.5 * yy.sum(), 0.25 * len(yy)
+        assert abs(w0 - (-G0 * a / (b_ + np.sqrt(n0)))) < 1e-15
+        G = -0.5 * np.bincount(col, weights=np.repeat(yy, Z), minlength=P)
+        c = np.bincount(col, minlength=P).astype(np.float64)
+        want = np.where(np.abs(G) <= l1, 0.0, -(G - np.sign(G) * l1) / ((b_ + np.sqrt(0.25 * c)) / a + l2))
+        np.testing.assert_allclose(w, want, rtol=0, atol=2e-7)   # fp32 state
+        assert np.all(w[c == 0] == 0.0) and np.all(v == 0.0)
+
+
+def test_configs2_full_size_l1_threshold_zeroes_exactly_the_touched_rows(fm, big):
+    """With an l1 weight no |z| can exceed, the prox sets every coordinate it touches to exactly 0 and leaves the rest alone
+    (FTRL_Learner.h:177,194): after one step V is 0 on precisely the features that occur in the batch -- the per-tile
+    inverted index at full size, k = 64, against the exported rows."""
+    engine, L = fm
+    v0 = np.random.default_rng(8).normal(0, 0.01, (K2, P)).astype(np.float32).astype(np.float64)
+    e = engine.Engine(P, solver=L.SOLVER_FTRL, num_factor=K2, mode=L.MODE_MINIBATCH, batch_rows=65_536, **dict(FTRL2, l1_v=1e9, l1_w1=1e9))
+    e.set_params(0.0, None, v0)
+    e.step(big, 5)
+    e.sync()
+    _, w, v = e.get_params()
+    rp, col, val, y = big.export(5 * 65_536, 6 * 65_536)
+    touched = np.zeros(P, bool); touched[col] = True
+    assert 0.5 < touched.mean() < 0.95
+    assert np.all(v[:, touched] == 0.0) and np.array_equal(v[:, ~touched], v0[:, ~touched])
+
+
+def test_configs2_full_size_ftrl_is_reproducible_and_forms_agree(fm, big):
+    """k = 64 FTRL, 524 288-row steps (the engine's tile size at this width): two runs bit for bit; the fused step, the
+    grad/apply split and 2 tiles per step agree up to the fp32 rounding of the sums between tiles."""
+    engine, L = fm
+    v0 = np.random.default_rng(9).normal(0, 0.01, (K2, P)).astype(np.float32).astype(np.float64)
+    def run(form, **extra):
+        e = engine.Engine(P, solver=L.SOLVER_FTRL, num_factor=K2, mode=L.MODE_MINIBATCH, batch_rows=524_288, **dict(FTRL2, **extra))
+        e.set_params(0.0, None, v0)
+        for b in (0, 2, 4):
+            if form == "fused":
+                e.step(big, b)
+            else:
+                e.grad(big, b); e.apply(0)
+        e.sync()
+        return e.get_params()
+    a, b_, c, d = run("fused"), run("fused"), run("split"), run("fused", tile_rows=262_144)
+    assert a[0] == b_[0] and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])
+    assert np.all(np.isfinite(a[2])) and np.any(a[2] != v0)
+    scale = np.max(np.abs(a[2]))
+    for other in (c, d):
+        assert np.max(np.abs(other[2] - a[2])) < 5e-6 * scale and abs(other[0] - a[0]) < 1e-8

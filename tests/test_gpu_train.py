@@ -649,3 +649,64 @@ def test_mcmc_learner_matches_oracle(fm, task, flags):
         assert abs(e.evaluate(m, L.EVAL_LL) - oracle.evaluate(ot, oracle.LL, prob, y)) < 1e-9
     with pytest.raises(L.FmxError, match="fmx_mcmc_train"):
         e.train(m, 10)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2]: k = 64, FTRL (l1 + l2), ~30 nnz/row -- the configuration's own shape, reduced in rows and
+# features to what the oracle walks in seconds (reference: solver/FTRL_Learner.h:64-202).
+def _configs2_problem(n=2400, p=4000, seed=64):
+    rp, col, val = util.random_csr(n, p, 30, seed=seed, empty_rows=False, max_nnz=64)
+    y = util.labels(n, seed)
+    P = oracle.params(task=oracle.CLASSIFICATION, k=64, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-4, l2_regv=1e-4, alpha_w=0.1, alpha_v=0.1, beta_w=1.0, beta_v=1.0)
+    w0, w, v = util.params(p, 64, seed, stdev=0.01, fp32=True)   # V0 ~ N(0, 0.01)
+    return rp, col, val, y, P, w0, w, v
+
+
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+@pytest.mark.parametrize("wide", [0, 1], ids=["fp32", "fp64"])
+def test_configs2_ftrl_k64_minibatch_matches_oracle(fm, wide, reduce):
+    """Mini-batch FTRL at k = 64 (256-byte fp32 rows, 16 lanes per list) against the oracle's fp64 restatement: 1e-5 on V
+    with fp32 state, 1e-11 with the reference's fp64 state; 8 steps of 300 rows, wrapping once."""
+    engine, L = fm
+    rp, col, val, y, P, w0, w, v = _configs2_problem()
+    n, p, B = len(rp) - 1, 4000, 400
+    P.batch_mean = int(reduce == "mean")
+    mb = oracle.FtrlMinibatch(P, oracle.Matrix(rp, col, val, p), y, w0, w, v.ravel())
+    e = engine.Engine(p, task=P.task, solver=L.SOLVER_FTRL, num_factor=64, l1_w1=P.l1_regw, l1_v=P.l1_regv, l2_w1=P.l2_regw, l2_v=P.l2_regv,
+                      mode=L.MODE_MINIBATCH, batch_rows=B, state_fp64=wide, batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    nb = n // B
+    for s in range(8):
+        b0 = (s % nb) * B
+        mb.step(b0, b0 + B)
+        e.step(m, s % nb)
+    e.sync()
+    g0, gw, gv = e.get_params()
+    tol = 1e-11 if wide else V_RTOL
+    rv = mb.v.reshape(64, p)
+    assert util.rel_err(gv, rv) < tol and util.rel_err(gw, mb.w) < tol and abs(g0 - mb.w0.value) < tol * max(1.0, abs(mb.w0.value))
+    if wide:
+        assert np.array_equal(gv == 0.0, rv == 0.0)  # the l1 threshold zeroes the same coordinates
+    out = e.predict(m)
+    refp = oracle.predict_batch(P, oracle.Matrix(rp, col, val, p), mb.w0.value, mb.w, mb.v)
+    big = np.abs(refp) > 1e-4  # sign bit-exact wherever the prediction is not within rounding of zero
+    assert np.array_equal(np.sign(out[big]), np.sign(refp[big]))
+
+
+def test_configs2_ftrl_k64_sequential_matches_oracle(fm):
+    """The reference's FTRL learner itself at k = 64 (one lane per factor fills the wave): 1e-11 against the oracle over a
+    pass and a half, prediction signs bit-exact."""
+    engine, L = fm
+    rp, col, val, y, P, w0, w, v = _configs2_problem(n=1500)
+    n, p = len(rp) - 1, 4000
+    X = oracle.Matrix(rp, col, val, p)
+    iters = n + n // 2
+    ref = oracle.ftrl_learn(P, X, y, w0, w, v.ravel(), iters)
+    e = engine.Engine(p, task=P.task, solver=L.SOLVER_FTRL, num_factor=64, l1_w1=P.l1_regw, l1_v=P.l1_regv, l2_w1=P.l2_regw, l2_v=P.l2_regv, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert e.train(m, iters) == iters
+    g0, gw, gv = e.get_params()
+    assert util.rel_err(gv, ref["v"].reshape(64, p)) < 1e-11 and util.rel_err(gw, ref["w"]) < 1e-11 and abs(g0 - ref["w0"]) < 1e-11
+    assert np.array_equal(np.sign(e.predict(m)), np.sign(oracle.predict_batch(P, X, ref["w0"], ref["w"], ref["v"])))
