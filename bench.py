@@ -116,20 +116,16 @@ def host_cpu_share():
     return max(1, min(n, 16))
 
 
-def oracle_params(args):
-    import oracle
-    if args.solver == "sgd":
-        return oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
-    return oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-4, l2_regv=1e-4)
-
-
 def cpu_baseline(m, args, v0):
     """Oracle (the reference's serial learner, one core) on the first cpu_rows rows of the same matrix."""
     import oracle
     n = min(args.cpu_rows, m.n)
     rp, col, val, y = m.export(0, n)
     X = oracle.Matrix(rp, col, val, args.features)
-    P = oracle_params(args)
+    if args.solver == "sgd":
+        P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
+    else:
+        P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-4, l2_regv=1e-4)
     w = np.zeros(args.features)
     v = np.ascontiguousarray(v0.astype(np.float64))  # [k][p] factor-major, the reference's layout
     oracle.lib()
