@@ -283,7 +283,21 @@ __device__ __forceinline__ void scalar_update(const double* __restrict__ partial
     rows = 1.0;
   }
   const double w0 = sin[SC_W0];
-  if (h.kind == UPD_FTRL) {
+  if (h.kind == UPD_TDAP) {  // solver/TDAP_Learner.h:96-106, :192 with the batch sums
+    double u = sin[SC_N0], nu = sin[SC_T_NU], dl = sin[SC_T_DELTA], hh = sin[SC_T_H], z0 = sin[SC_Z0];
+    if (h.k0) {
+      const double u_new = u + q0;
+      nu += g0;
+      const double sigma = (sqrt(u_new) - sqrt(u)) / h.alpha_w;
+      const double age = rows == 1.0 ? h.egamma : exp(-h.gamma * rows);
+      dl = age * (dl + sigma);
+      hh = age * (hh + sigma * w0);
+      u = u_new;
+      z0 = nu - hh;
+    }
+    sout[SC_N0] = u; sout[SC_T_NU] = nu; sout[SC_T_DELTA] = dl; sout[SC_T_H] = hh; sout[SC_Z0] = z0;
+    sout[SC_W0] = -z0 / dl;
+  } else if (h.kind == UPD_FTRL) {
     double z0 = sin[SC_Z0], n0 = sin[SC_N0];
     if (h.k0) {  // solver/FTRL_Learner.h:80-86 with the batch sums G0, Q0
       const double n_new = n0 + q0;
@@ -305,6 +319,7 @@ __device__ __forceinline__ void scalar_update(const double* __restrict__ partial
 template <typename ST>
 struct ColsTables {
   ST *V, *w, *sV, *sw, *nV, *nw;
+  ST *t1V, *t1w, *t2V, *t2w, *t3V, *t3w;  // TDAP: nu, delta, h (u in nV / nw, z in sV / sw: the sequential learner's tables)
   const ST* S;
   const ST* amul;
   const double* scal;   // this step's start scalars (read-only during the step)
@@ -374,6 +389,30 @@ __device__ __forceinline__ double coord_update(const Hyper& h, bool is_w, double
   }
 }
 
+// Mini-batch TDAP coordinate (oracle: fmo_tdap_apply_sums; at one occurrence it is solver/TDAP_Learner.h:97-105 / :115-126 /
+// :134-141 followed by calculate_param :208-213 / :222-229): state u, nu, delta, h, z in/out, returns the new value.
+template <typename ST>
+__device__ __forceinline__ double tdap_update(const Hyper& h, bool is_w, double theta, double G, double Q, double cnt, ST& su, ST& snu, ST& sdl,
+                                              ST& sh, ST& sz, bool keep) {
+  const double alpha = is_w ? h.alpha_w : h.alpha_v;
+  const double l1 = is_w ? h.l1w : h.l1v, l2 = is_w ? h.l2w : h.l2v;
+  if (keep) {
+    const double u_old = su;
+    const double u = u_old + Q;
+    const double nu = (double)snu + G;
+    const double sigma = (sqrt(u) - sqrt(u_old)) / alpha;
+    const double age = cnt == 1.0 ? h.egamma : exp(-h.gamma * cnt);  // one decay per occurrence
+    const double dl = age * ((double)sdl + sigma);
+    const double hh = age * ((double)sh + sigma * theta);
+    su = (ST)u; snu = (ST)nu; sdl = (ST)dl; sh = (ST)hh;
+    sz = (ST)((double)snu - (double)sh);  // z = nu - h from the STORED values: what a reload of the state gives
+  }
+  const double z = sz;
+  if (fabs(z) <= l1) return 0.0;
+  const double sign = z < 0.0 ? -1.0 : 1.0;
+  return -(z - sign * l1) / ((double)sdl + l2);
+}
+
 // One (feature, lane-slice) worth of batch sums: the lane's factors (4 of an fp32 table, 2 of an fp64 one) plus the
 // feature's linear term
 struct CoordSums {
@@ -414,7 +453,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
   using vec_t = typename Slice<ST>::vec;
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
-  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
   // exchange buffer: blocks of F features, each GV [F][KP] | GW [F] | CNT [F] | (has_q: QV [F][KP] | QW [F]); then tail[4]
   const size_t at = (size_t)j * KP + lig * VEC;  // in the parameter tables
   if (a.load_gbuf || a.store_gbuf) {
@@ -487,6 +526,30 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
     u_w = T.scal[SC_UW] + r * (h.lr * h.regw);
     u_v = T.scal[SC_UV] + r * (h.lr * h.regv);
   }
+  if constexpr (KIND == UPD_TDAP) {
+    ST* const tabs[5] = {T.nV, T.t1V, T.t2V, T.t3V, T.sV};  // u, nu, delta, h, z
+    ST st[5][VEC];
+    double t5[VEC];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      slice_get(*reinterpret_cast<const vec_t*>(tabs[q] + at), t5);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) st[q][i] = (ST)t5[i];
+    }
+    double outv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) outv[i] = tdap_update<ST>(h, false, vf[i], s.G[i], s.Q[i], cnt, st[0][i], st[1][i], st[2][i], st[3][i], st[4][i], true);
+    *reinterpret_cast<vec_t*>(T.V + at) = slice_make(outv, ST());
+#pragma unroll
+    for (int q = 0; q < 5; ++q) *reinterpret_cast<vec_t*>(tabs[q] + at) = slice_make(st[q], ST());
+    if (lig == 0) {  // like FTRL, TDAP recomputes w on every touched column even with keep.w1 off (TDAP_Learner.h:203-214)
+      ST u = T.nw[j], nu = T.t1w[j], dl = T.t2w[j], hh = T.t3w[j], z = T.sw[j];
+      const double wn = tdap_update<ST>(h, true, (double)T.w[j], s.Gw, s.Qw, cnt, u, nu, dl, hh, z, h.k1 != 0);
+      T.w[j] = (ST)wn;
+      T.nw[j] = u; T.t1w[j] = nu; T.t2w[j] = dl; T.t3w[j] = hh; T.sw[j] = z;
+    }
+    return;
+  }
   double tmp[VEC];
   ST sa_[VEC], sb_[VEC];
 #pragma unroll
@@ -536,7 +599,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr int FPW = WG_THREADS / LPR;  // features (lists) per workgroup
-  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
   __shared__ uint2 stage[STAGE_ENTRIES];
   __shared__ double red_g[WG_THREADS], red_q[WG_THREADS];
   __shared__ unsigned long long wg_next;
@@ -698,7 +761,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr int NSUB = 64 / LPR;
-  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * (WG_THREADS / 64) + (threadIdx.x >> 6);
   if (i >= la.n_long) return;
@@ -743,7 +806,7 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   dim3 g((unsigned)grid), b(WG_THREADS);
   const bool lng = a.walk && la.n_long > 0;
   dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + (WG_THREADS / 64) - 1) / (WG_THREADS / 64)));
-  constexpr bool NQ = (KIND == UPD_FTRL);
+  constexpr bool NQ = (KIND == UPD_FTRL || KIND == UPD_TDAP);
 #define FMX_COLS_CASE(L)                                                                                        \
   case L:                                                                                                       \
     hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                     \
@@ -767,6 +830,7 @@ static int launch_cols_state(fmx_engine* e, const ColsArgs& a, const LongArgs& l
   switch (e->hyper.kind) {
     case UPD_SGD_L2: return launch_cols_kind<ST, UPD_SGD_L2>(e, a, la, T);
     case UPD_SGD_L1: return launch_cols_kind<ST, UPD_SGD_L1>(e, a, la, T);
+    case UPD_TDAP: return launch_cols_kind<ST, UPD_TDAP>(e, a, la, T);
     default: return launch_cols_kind<ST, UPD_FTRL>(e, a, la, T);
   }
 }
@@ -778,6 +842,9 @@ static ColsTables<ST> cols_tables(fmx_engine* e, const ColsArgs& a, int has_q) {
   T.V = (ST*)(W ? (void*)e->dV : (void*)e->V); T.w = (ST*)(W ? (void*)e->dw : (void*)e->w);
   T.sV = (ST*)(W ? (void*)e->dsV : (void*)e->sV); T.sw = (ST*)(W ? (void*)e->dsw : (void*)e->sw);
   T.nV = (ST*)(W ? (void*)e->dnV : (void*)e->nV); T.nw = (ST*)(W ? (void*)e->dnw : (void*)e->nw);
+  T.t1V = (ST*)(W ? (void*)e->dt1V : (void*)e->t1V); T.t1w = (ST*)(W ? (void*)e->dt1w : (void*)e->t1w);
+  T.t2V = (ST*)(W ? (void*)e->dt2V : (void*)e->t2V); T.t2w = (ST*)(W ? (void*)e->dt2w : (void*)e->t2w);
+  T.t3V = (ST*)(W ? (void*)e->dt3V : (void*)e->t3V); T.t3w = (ST*)(W ? (void*)e->dt3w : (void*)e->t3w);
   const int kp = W ? e->kp64 : e->kp32;
   T.S = (const ST*)e->S + (size_t)a.s_row0 * kp;
   T.amul = (const ST*)e->amul + a.s_row0;
@@ -798,7 +865,7 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
   FMX_CHECK(!(a.load_gbuf || a.store_gbuf || ((a.scalar == SCALAR_PUBLISH || a.scalar == SCALAR_FROM_TAIL) && !a.compact_tail)) || e->gbuf != nullptr,
             FMX_ERR_STATE, "exchange buffer not allocated");
   FMX_CHECK(!(a.store_compact || a.compact_tail) || (e->ctail != nullptr && (!a.store_compact || e->crec != nullptr)), FMX_ERR_STATE, "compact exchange buffers not allocated");
-  const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
+  const int has_q = exchange_has_q(e) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
   if (mb_wide(e)) {
@@ -833,7 +900,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, Cols
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr int FPW = WG_THREADS / LPR;
-  constexpr bool NEED_Q = (KIND == UPD_FTRL);
+  constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
   __shared__ double red_g[WG_THREADS], red_q[WG_THREADS];
   const int gid = threadIdx.x / LPR, lig = threadIdx.x % LPR;
   const int64_t n = (int64_t)*r.d_n;
@@ -893,7 +960,7 @@ __global__ void record_keys_k(const ST* __restrict__ recs, int rec_elems, int id
 
 int launch_record_keys(fmx_engine* e, const void* recs, const int64_t* d_prefix, int n_parts, int64_t stride, int64_t total, uint32_t* keys, uint32_t* pos) {
   if (total <= 0) return FMX_OK;
-  const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
+  const int has_q = exchange_has_q(e) ? 1 : 0;
   const int id_at = mb_kp(e) * (1 + has_q) + 3;
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   if (mb_wide(e)) hipLaunchKernelGGL((record_keys_k<double>), g, b, 0, e->stream, (const double*)recs, e->rec_elems, id_at, d_prefix, n_parts, stride, total, keys, pos);
@@ -921,11 +988,12 @@ static int launch_records_kind(fmx_engine* e, const RecArgs& r, const ColsArgs& 
 
 template <typename ST>
 static int launch_records_state(fmx_engine* e, const RecArgs& r, const ColsArgs& a, int64_t max_lists) {
-  const int has_q = (e->hyper.kind == UPD_FTRL && !e->hyper.mean) ? 1 : 0;
+  const int has_q = exchange_has_q(e) ? 1 : 0;
   const ColsTables<ST> T = cols_tables<ST>(e, a, has_q);
   switch (e->hyper.kind) {
     case UPD_SGD_L2: return launch_records_kind<ST, UPD_SGD_L2>(e, r, a, T, max_lists);
     case UPD_SGD_L1: return launch_records_kind<ST, UPD_SGD_L1>(e, r, a, T, max_lists);
+    case UPD_TDAP: return launch_records_kind<ST, UPD_TDAP>(e, r, a, T, max_lists);
     default: return launch_records_kind<ST, UPD_FTRL>(e, r, a, T, max_lists);
   }
 }

@@ -88,6 +88,7 @@ static int make_hyper(const fmx_config& c, Hyper* h) {
   h->min_t = c.min_target; h->max_t = c.max_target;
   h->mean = (c.batch_reduce == FMX_REDUCE_MEAN);
   h->egamma = std::exp(-c.gamma);  // solver/TDAP_Learner.h:83
+  h->gamma = c.gamma;
   if (c.solver == FMX_SOLVER_FTRL || c.solver == FMX_SOLVER_TDAP) {
     h->kind = c.solver == FMX_SOLVER_FTRL ? UPD_FTRL : UPD_TDAP;
     h->regw = 0; h->regv = 0;
@@ -122,6 +123,8 @@ static int reset_optimizer_state(fmx_engine* e) {
   if (e->sw) FMX_HIP(hipMemset(e->sw, 0, p * sizeof(float)));
   if (e->nV) FMX_HIP(hipMemset(e->nV, 0, p * e->kp32 * sizeof(float)));
   if (e->nw) FMX_HIP(hipMemset(e->nw, 0, p * sizeof(float)));
+  for (float* t : {e->t1V, e->t2V, e->t3V}) if (t) FMX_HIP(hipMemset(t, 0, p * e->kp32 * sizeof(float)));
+  for (float* t : {e->t1w, e->t2w, e->t3w}) if (t) FMX_HIP(hipMemset(t, 0, p * sizeof(float)));
   if (e->dsV) FMX_HIP(hipMemset(e->dsV, 0, p * e->kp64 * sizeof(double)));
   if (e->dsw) FMX_HIP(hipMemset(e->dsw, 0, p * sizeof(double)));
   if (e->dnV) FMX_HIP(hipMemset(e->dnV, 0, p * e->kp64 * sizeof(double)));
@@ -152,7 +155,7 @@ static int ensure_gbuf(fmx_engine* e) {
   if (e->gbuf) return FMX_OK;
   // blocks of F features: GV [F][kp] | GW [F] | CNT [F] | (QV [F][kp] | QW [F]: only FTRL with FMX_REDUCE_SUM needs
   // sum(g^2)); then tail[4].  One block holding all p features unless cfg.exchange_chunks > 1.
-  const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
+  const bool has_q = exchange_has_q(e);
   const int64_t chunks = e->cfg.exchange_chunks > 1 ? e->cfg.exchange_chunks : 1;
   const int64_t per = ((int64_t)e->p + chunks - 1) / chunks;
   e->gb_feats = chunks > 1 ? (per + 63) / 64 * 64 : ((int64_t)e->p + 3) / 4 * 4;  // keeps every plane 16-byte aligned
@@ -468,7 +471,7 @@ static int apply_block(fmx_engine* e, int64_t block, int64_t global_rows, bool l
 
 // ---- compact exchange: steps of ONE sparse tile publish a record per occurring feature instead of the dense buffer -----
 static int ensure_compact(fmx_engine* e, int64_t cap) {
-  const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
+  const bool has_q = exchange_has_q(e);
   e->rec_elems = mb_kp(e) * (has_q ? 2 : 1) + 4;
   if (!e->ctail) {
     FMX_HIP(hipMalloc(&e->ctail, 4 * mb_elem(e)));
@@ -555,7 +558,6 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->solver == FMX_SOLVER_SGD || cfg->solver == FMX_SOLVER_FTRL || cfg->solver == FMX_SOLVER_ALS || cfg->solver == FMX_SOLVER_TDAP ||
                 cfg->solver == FMX_SOLVER_MCMC,
             FMX_ERR_INVALID, "Unknown solver...");  // src/FM.cpp:85
-  FMX_CHECK(cfg->solver != FMX_SOLVER_TDAP || cfg->mode == FMX_MODE_SEQUENTIAL, FMX_ERR_INVALID, "the TDAP solver runs in FMX_MODE_SEQUENTIAL only");
   FMX_CHECK(cfg->num_factor >= 0 && cfg->num_factor <= 128, FMX_ERR_INVALID, "factor.number must be in 0..128 (got %d)", cfg->num_factor);
   FMX_CHECK(cfg->mode == FMX_MODE_SEQUENTIAL || cfg->mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID, "unknown mode %d", cfg->mode);
   FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
@@ -580,7 +582,12 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
     FMX_TRY(dev_alloc_zero(&e->V, p * e->kp32));
     FMX_TRY(dev_alloc_zero(&e->w, p));
     if (e->hyper.kind != UPD_SGD_L2) { FMX_TRY(dev_alloc_zero(&e->sV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->sw, p)); }
-    if (e->hyper.kind == UPD_FTRL) { FMX_TRY(dev_alloc_zero(&e->nV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->nw, p)); }
+    if (e->hyper.kind == UPD_FTRL || e->hyper.kind == UPD_TDAP) { FMX_TRY(dev_alloc_zero(&e->nV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->nw, p)); }
+    if (e->hyper.kind == UPD_TDAP) {
+      FMX_TRY(dev_alloc_zero(&e->t1V, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->t1w, p));
+      FMX_TRY(dev_alloc_zero(&e->t2V, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->t2w, p));
+      FMX_TRY(dev_alloc_zero(&e->t3V, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->t3w, p));
+    }
   } else {
     FMX_TRY(dev_alloc_zero(&e->dV, p * e->kp64));
     FMX_TRY(dev_alloc_zero(&e->dw, p));
@@ -604,6 +611,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   for (auto& pr : e->prof_pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
   (void)hipFree(e->scal_base);
   (void)hipFree(e->V); (void)hipFree(e->w); (void)hipFree(e->sV); (void)hipFree(e->sw); (void)hipFree(e->nV); (void)hipFree(e->nw);
+  (void)hipFree(e->t1V); (void)hipFree(e->t1w); (void)hipFree(e->t2V); (void)hipFree(e->t2w); (void)hipFree(e->t3V); (void)hipFree(e->t3w);
   (void)hipFree(e->dV); (void)hipFree(e->dw); (void)hipFree(e->dsV); (void)hipFree(e->dsw); (void)hipFree(e->dnV); (void)hipFree(e->dnw);
   (void)hipFree(e->dt1V); (void)hipFree(e->dt1w); (void)hipFree(e->dt2V); (void)hipFree(e->dt2w); (void)hipFree(e->dt3V); (void)hipFree(e->dt3w);
   (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
@@ -754,6 +762,9 @@ static void ckpt_tables(fmx_engine* e, std::vector<std::pair<void*, size_t>>* ou
   add(e->V, p * e->kp32 * sizeof(float)); add(e->w, p * sizeof(float));
   add(e->sV, p * e->kp32 * sizeof(float)); add(e->sw, p * sizeof(float));
   add(e->nV, p * e->kp32 * sizeof(float)); add(e->nw, p * sizeof(float));
+  add(e->t1V, p * e->kp32 * sizeof(float)); add(e->t1w, p * sizeof(float));
+  add(e->t2V, p * e->kp32 * sizeof(float)); add(e->t2w, p * sizeof(float));
+  add(e->t3V, p * e->kp32 * sizeof(float)); add(e->t3w, p * sizeof(float));
   add(e->dV, p * e->kp64 * sizeof(double)); add(e->dw, p * sizeof(double));
   add(e->dsV, p * e->kp64 * sizeof(double)); add(e->dsw, p * sizeof(double));
   add(e->dnV, p * e->kp64 * sizeof(double)); add(e->dnw, p * sizeof(double));
@@ -1253,7 +1264,7 @@ int fmx_compact_info(fmx_engine* e, fmx_matrix* m, int64_t* record_elems, int64_
   FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "the compact exchange exists only in FMX_MODE_MINIBATCH");
   FMX_TRY(use_device(e->cfg.device));
   FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, effective_tile_rows(e), e->stream));
-  const bool has_q = e->hyper.kind == UPD_FTRL && !e->hyper.mean;
+  const bool has_q = exchange_has_q(e);
   bool ok = !m->plans.empty();
   for (int64_t s = 0; s < m->n_batches && ok; ++s) ok = m->step_first_tile[(size_t)s + 1] - m->step_first_tile[(size_t)s] <= 1;
   for (const auto& pl : m->plans) ok = ok && pl.feat != nullptr;

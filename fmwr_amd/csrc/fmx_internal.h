@@ -43,7 +43,7 @@ enum UpdateKind : int {
   UPD_SGD_L2 = 0,  // solver/SGD_Learner.h:119,135 (lazy L2 on touched coordinates)
   UPD_SGD_L1 = 1,  // solver/SGD_Learner.h:195-204 (cumulative penalty)
   UPD_FTRL = 2,    // solver/FTRL_Learner.h:158-202
-  UPD_TDAP = 3,    // solver/TDAP_Learner.h:79-233 (sequential mode only)
+  UPD_TDAP = 3,    // solver/TDAP_Learner.h:79-233
 };
 
 // hyper-parameters as the kernels consume them (passed by value)
@@ -56,6 +56,7 @@ struct Hyper {
   double alpha_w, alpha_v, beta_w, beta_v;
   double min_t, max_t;
   double egamma;                    // TDAP: exp(-gamma)
+  double gamma;                     // TDAP: the decay rate itself (mini-batch: exp(-gamma * occurrences))
   double decay_w, decay_v;          // 1 - lr*reg (SGD lazy L2, one touch)
   double log_decay_w, log_decay_v;  // log of the above, for c touches: exp(c * log)
 };
@@ -160,7 +161,10 @@ struct fmx_engine {
   // mini-batch fp32 state (cfg.state_fp64 == 0): tables are [p][kp32]
   float *V = nullptr, *w = nullptr;
   float *sV = nullptr, *sw = nullptr;    // q (SGD-L1) or z (FTRL)
-  float *nV = nullptr, *nw = nullptr;    // n (FTRL)
+  float *nV = nullptr, *nw = nullptr;    // n (FTRL), u (TDAP)
+  float *t1V = nullptr, *t1w = nullptr;  // TDAP nu
+  float *t2V = nullptr, *t2w = nullptr;  // TDAP delta
+  float *t3V = nullptr, *t3w = nullptr;  // TDAP h
   // fp64 state (sequential mode, or mini-batch mode with cfg.state_fp64): tables are [p][kp64]
   double *dV = nullptr, *dw = nullptr;
   double *dsV = nullptr, *dsw = nullptr;
@@ -233,6 +237,8 @@ inline bool wide_state(const fmx_engine* e) { return e->cfg.mode == FMX_MODE_SEQ
 inline int mb_kp(const fmx_engine* e) { return mb_wide(e) ? e->kp64 : e->kp32; }        // padded factor count of the mini-batch tables
 inline int mb_lpr(const fmx_engine* e) { return mb_wide(e) ? e->kp64 / 2 : e->kp32 / 4; } // lanes per row / per feature list (16 B each)
 inline size_t mb_elem(const fmx_engine* e) { return mb_wide(e) ? sizeof(double) : sizeof(float); }
+// the exchange carries the sums of squared gradients too: solvers with an accumulated-square state, when the batch is SUMMED
+inline bool exchange_has_q(const fmx_engine* e) { return (e->hyper.kind == UPD_FTRL || e->hyper.kind == UPD_TDAP) && !e->hyper.mean; }
 
 // ---- launchers implemented in the kernel translation units -------------------------------------------------
 struct RowsArgs {

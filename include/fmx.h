@@ -42,7 +42,7 @@ extern "C" {
 #define FMX_SOLVER_ALS 200
 #define FMX_SOLVER_SGD 300
 #define FMX_SOLVER_FTRL 500
-#define FMX_SOLVER_TDAP 600 /* FMX_MODE_SEQUENTIAL only */
+#define FMX_SOLVER_TDAP 600
 
 /* FMX_MODE_SEQUENTIAL: the reference's algorithm as is -- one example per update, visited in the
  *   reference's order (solver/SGD_Learner.h:86-88), fp64 state.  The parity mode.

@@ -238,6 +238,21 @@ class FtrlMinibatch:
                                       _ptr(self.zn0), _ptr(self.z_w), _ptr(self.n_w), _ptr(self.z_v), _ptr(self.n_v))
 
 
+class TdapMinibatch:
+    """Mini-batch TDAP (fm_oracle.c fmo_tdap_minibatch_step): state u, nu, delta, h, z per parameter."""
+
+    def __init__(self, P, X, y, w0, w, v):
+        self.P, self.X = P, X
+        self.y = np.ascontiguousarray(y, np.float32)
+        self.w0 = C.c_double(w0); self.w = _f64(w).copy(); self.v = _f64(v).copy()
+        p, k = max(X.p, 1), max(P.k, 1)
+        self.s0 = np.zeros(5); self.sw = np.zeros(5 * p); self.sv = np.zeros(5 * k * p)
+
+    def step(self, b0, b1):
+        lib().fmo_tdap_minibatch_step(C.byref(self.P), C.c_uint32(self.X.p), C.byref(self.w0), _ptr(self.w), _ptr(self.v), C.byref(self.X.c),
+                                      _ptr(self.y), C.c_int64(b0), C.c_int64(b1), _ptr(self.s0), _ptr(self.sw), _ptr(self.sv))
+
+
 def als_update_v(k, X, v, error, alpha=1.0, v_lambda=None, v_mu=None, znorm=None):
     """solver/MCMC_ALS_Learner.h:272-354; znorm ([k][p] standard normals) switches to the MCMC draw; returns (v_new, error_end, v_q_end)."""
     col_ptr, row_idx, val_t = X.transpose()

@@ -1123,6 +1123,87 @@ void fmo_ftrl_minibatch_step(const fmo_params* P, uint32_t p, double* w0, double
   free(Gw); free(Qw); free(cw); free(Gv); free(Qv);
 }
 
+/* Mini-batch TDAP (engine semantics; the reference's TDAP is strictly per example, solver/TDAP_Learner.h:79-233).
+ * Per touched coordinate, with the batch sums G, Q and c occurrences and theta the batch-start value:
+ *     u' = u + Q;  nu += G;  sigma = (sqrt(u') - sqrt(u)) / alpha          (the per-example sigmas telescope, like FTRL's)
+ *     delta = e^(-gamma c) (delta + sigma);  h = e^(-gamma c) (h + sigma theta);  z = nu - h
+ *     theta = |z| <= l1 ? 0 : -(z - sgn(z) l1) / (delta + l2)
+ * i.e. the batch's accumulated sigma enters at once and the coordinate then ages by its c touches; with batch_mean the
+ * sums first become ONE pseudo-example (G/c, (G/c)^2, c = 1; w0: c = B).  At batch size 1 this is TDAP_Learner.h:97-141 and
+ * :189-233 coordinate for coordinate -- except that w's prox reads the feature's OWN z: the shipped code indexes z_w by the
+ * entry's position inside the current row (:207, SURVEY A-6), which has no meaning for a feature summed over a batch (the
+ * V loop, :220-231, indexes correctly).  The sequential mode keeps the shipped indexing.
+ * state: s0[5] = {u, nu, delta, h, z} of w0; sw [5][p]; sv [5][k][p] (planes in that order). */
+void fmo_tdap_apply_sums(const fmo_params* P, uint32_t p, double* w0, double* w, double* v, double B, double G0, double Q0,
+                         const double* Gw, const double* Qw, const double* cw, const double* Gv, const double* Qv,
+                         double* s0, double* sw, double* sv) {
+  int k = P->k;
+  size_t pp = p ? p : 1, kp = (size_t)(k ? k : 1) * pp;
+  const int mean = P->batch_mean;
+  const double gamma = P->gamma;
+  if (P->k0) {
+    double c = B;
+    if (mean && B > 0.0) { G0 /= B; Q0 = G0 * G0; c = 1.0; }
+    double u_old = s0[0];
+    s0[0] += Q0; s0[1] += G0;
+    double sigma = (sqrt(s0[0]) - sqrt(u_old)) / P->alpha_w;
+    double age = exp(-gamma * c);
+    s0[2] = age * (s0[2] + sigma);
+    s0[3] = age * (s0[3] + sigma * *w0);
+    s0[4] = s0[1] - s0[3];
+  }
+  *w0 = -s0[4] / s0[2]; /* TDAP_Learner.h:192 (no l1/l2 on w0) */
+  for (uint32_t j = 0; j < p; ++j) {
+    if (cw[j] == 0.0) continue;
+    const double c = mean ? 1.0 : cw[j];
+    const double inv = mean ? 1.0 / cw[j] : 1.0;
+    const double age = exp(-gamma * c);
+    if (P->k1) {
+      double *u = &sw[j], *nu = &sw[pp + j], *dl = &sw[2 * pp + j], *h = &sw[3 * pp + j], *z = &sw[4 * pp + j];
+      const double g = Gw[j] * inv, qq = mean ? g * g : Qw[j];
+      double u_old = *u;
+      *u += qq; *nu += g;
+      double sigma = (sqrt(*u) - sqrt(u_old)) / P->alpha_w;
+      *dl = age * (*dl + sigma);
+      *h = age * (*h + sigma * w[j]);
+      *z = *nu - *h;
+    }
+    {
+      double z = sw[4 * pp + j];
+      if (fabs(z) <= P->l1_regw) w[j] = 0.0;
+      else { double sign = z < 0.0 ? -1.0 : 1.0; w[j] = -(z - sign * P->l1_regw) / (sw[2 * pp + j] + P->l2_regw); }
+    }
+    for (int f = 0; f < k; ++f) {
+      size_t at = (size_t)f * p + j;
+      double *u = &sv[at], *nu = &sv[kp + at], *dl = &sv[2 * kp + at], *h = &sv[3 * kp + at], *z = &sv[4 * kp + at];
+      const double g = Gv[at] * inv, qq = mean ? g * g : Qv[at];
+      double u_old = *u;
+      *u += qq; *nu += g;
+      double sigma = (sqrt(*u) - sqrt(u_old)) / P->alpha_v;
+      *dl = age * (*dl + sigma);
+      *h = age * (*h + sigma * v[at]);
+      *z = *nu - *h;
+      if (fabs(*z) <= P->l1_regv) v[at] = 0.0;
+      else { double sign = *z < 0.0 ? -1.0 : 1.0; v[at] = -(*z - sign * P->l1_regv) / (*dl + P->l2_regv); }
+    }
+  }
+}
+
+void fmo_tdap_minibatch_step(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,
+                             const fmo_csr* X, const float* y, int64_t b0, int64_t b1, double* s0, double* sw, double* sv) {
+  int k = P->k;
+  size_t kp = (size_t)(k ? k : 1) * (p ? p : 1);
+  double* Gw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* Qw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* cw = (double*)calloc(p ? p : 1, sizeof(double));
+  double* Gv = (double*)calloc(kp, sizeof(double));
+  double* Qv = (double*)calloc(kp, sizeof(double));
+  double G0, Q0;
+  fmo_batch_sums(P, p, *w0, w, v, X, y, b0, b1, &G0, &Q0, Gw, Qw, cw, Gv, Qv);
+  fmo_tdap_apply_sums(P, p, w0, w, v, (double)(b1 - b0), G0, Q0, Gw, Qw, cw, Gv, Qv, s0, sw, sv);
+  free(Gw); free(Qw); free(cw); free(Gv); free(Qv);
+}
+
 /* Timed CPU baseline helper for bench.py: reference-order serial SGD over rows 1..n-1
  * (random_step == 1), no tracker.  Same code path as fmo_sgd_learn. */
 int64_t fmo_sgd_pass(const fmo_params* P, uint32_t p, double* w0, double* w, double* v,

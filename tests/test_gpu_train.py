@@ -125,8 +125,6 @@ def test_sequential_tdap_matches_oracle(fm, task):
     assert e.train(m, iters) == iters
     g0, gw, gv = e.get_params()
     assert util.rel_err(gv, ref["v"].reshape(P.k, p)) < 1e-10 and util.rel_err(gw, ref["w"]) < 1e-10 and abs(g0 - ref["w0"]) < 1e-10
-    with pytest.raises(L.FmxError, match="SEQUENTIAL only"):
-        engine.Engine(p, solver=L.SOLVER_TDAP, mode=L.MODE_MINIBATCH)
 
 
 def test_sequential_random_step(fm):
@@ -710,3 +708,75 @@ def test_configs2_ftrl_k64_sequential_matches_oracle(fm):
     g0, gw, gv = e.get_params()
     assert util.rel_err(gv, ref["v"].reshape(64, p)) < 1e-11 and util.rel_err(gw, ref["w"]) < 1e-11 and abs(g0 - ref["w0"]) < 1e-11
     assert np.array_equal(np.sign(e.predict(m)), np.sign(oracle.predict_batch(P, X, ref["w0"], ref["w"], ref["v"])))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mini-batch TDAP (the reference's DEFAULT solver, R/fm_solver_control.R:22; solver/TDAP_Learner.h:79-233) -- defined in the
+# oracle (fmo_tdap_apply_sums), equal to the reference's example step at batch size 1 where the shipped z_w[position]
+# indexing (A-6) is invisible.
+def _tdap_problem(task, n=1500, p=260, k=6, seed=91, heavy=False):
+    rng = np.random.default_rng(seed)
+    rp, col, val = util.random_csr(n, p, 9, seed=seed)
+    if heavy:  # two heavy hitters: long lists
+        rows = []
+        for r in range(n):
+            hot = [j for j, q in ((1, 0.9), (40, 0.5)) if rng.random() < q]
+            rows.append(np.unique(np.concatenate([hot, col[rp[r]:rp[r + 1]]])).astype(np.uint32))
+        rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+        col = np.concatenate(rows); val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, seed, "classification" if task == oracle.CLASSIFICATION else "regression")
+    P = oracle.params(task=task, k=k, l1_regw=1e-3, l1_regv=5e-4, l2_regw=1e-2, l2_regv=1e-2, alpha_w=0.1, alpha_v=0.05, gamma=3e-3,
+                      min_target=float(y.min()), max_target=float(y.max()))
+    w0, w, v = util.params(p, k, seed, fp32=True)
+    return rp, col, val, y, P, w0, w, v
+
+
+def _tdap_engine(fm, p, P, **kw):
+    engine, L = fm
+    return engine.Engine(p, task=P.task, solver=L.SOLVER_TDAP, num_factor=P.k, keep_w0=P.k0, keep_w1=P.k1, l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv,
+                         l2_v=P.l2_regv, alpha_w=P.alpha_w, alpha_v=P.alpha_v, gamma=P.gamma, min_target=P.min_target, max_target=P.max_target,
+                         batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM, **kw)
+
+
+@pytest.mark.parametrize("wide", [0, 1], ids=["fp32", "fp64"])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+@pytest.mark.parametrize("task", [oracle.CLASSIFICATION, oracle.REGRESSION])
+def test_minibatch_tdap_matches_oracle(fm, task, reduce, wide):
+    engine, L = fm
+    rp, col, val, y, P, w0, w, v = _tdap_problem(task, heavy=True)
+    n, p = len(rp) - 1, 260
+    P.batch_mean = int(reduce == "mean")
+    X = oracle.Matrix(rp, col, val, p)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    tol = 1e-11 if wide else 2e-5
+    for B, tile, split in ((257, 0, False), (500, 200, False), (500, 0, True)):   # fused; 3 tiles per step; grad / apply through the buffer
+        mb = oracle.TdapMinibatch(P, X, y, w0, w, v.ravel())
+        e = _tdap_engine(fm, p, P, mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=tile, state_fp64=wide)
+        e.set_params(w0, w, v)
+        nb = -(-n // B)
+        for s in range(nb + 2):
+            b = s % nb
+            mb.step(b * B, min((b + 1) * B, n))
+            if split:
+                e.grad(m, b); e.apply(0)
+            else:
+                e.step(m, b)
+        e.sync()
+        g0, gw, gv = e.get_params()
+        assert util.rel_err(gv, mb.v.reshape(P.k, p)) < tol and util.rel_err(gw, mb.w) < tol and abs(g0 - mb.w0.value) < tol * max(1.0, abs(mb.w0.value)), (B, tile, split)
+
+
+def test_minibatch_tdap_at_batch_one_is_the_reference_learner(fm):
+    """fp64 state, one row per step, linear term off (so that the shipped z_w[position] read, A-6, has nothing to read):
+    the mini-batch kernels reproduce the reference's TDAP learner (the oracle's sequential restatement) to 1e-12."""
+    engine, L = fm
+    rp, col, val, y, P, w0, w, v = _tdap_problem(oracle.CLASSIFICATION, n=300)
+    P.k1 = 0
+    n, p = len(rp) - 1, 260
+    ref = oracle.tdap_learn(P, oracle.Matrix(rp, col, val, p), y, w0, w, v.ravel(), n, order=np.arange(n))
+    e = _tdap_engine(fm, p, P, mode=L.MODE_MINIBATCH, batch_rows=1, state_fp64=1)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    e.train(m, n)
+    g0, gw, gv = e.get_params()
+    assert util.rel_err(gv, ref["v"].reshape(P.k, p)) < 1e-12 and abs(g0 - ref["w0"]) < 1e-12 and np.array_equal(gw, ref["w"])

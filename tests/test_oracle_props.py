@@ -170,3 +170,48 @@ def test_ftrl_prox_is_the_argmin_of_its_objective():
             assert obj(got) <= np.min([obj(t) for t in grid]) + 1e-15
             if abs(z) <= l1:
                 assert got == 0.0
+
+
+def test_tdap_minibatch_reduces_to_the_reference_step():
+    """Mini-batch TDAP (defined in the oracle) at batch size 1 against the reference's TDAP learner
+    (TDAP_Learner.h:79-233).  The shipped w prox reads z_w by the entry's POSITION in the row (A-6); the mini-batch form reads
+    the feature's own z, so the two agree exactly where position == column (rows holding columns 0..len-1) and, for any rows,
+    when the linear term is off; both reductions."""
+    k = 4
+    # (a) rows whose entry at position i is column i: the indexing bug is invisible
+    rng = np.random.default_rng(5)
+    n, p = 120, 12
+    lens = rng.integers(2, p + 1, n)
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum(lens)
+    col = np.concatenate([np.arange(m) for m in lens]).astype(np.uint32)
+    val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, 5)
+    w0, w, v = util.params(p, k, 5, stdev=0.2, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(k=k, l1_regw=1e-3, l1_regv=5e-4, l2_regw=1e-2, l2_regv=1e-2, alpha_w=0.1, alpha_v=0.05, gamma=3e-3)
+    ref = oracle.tdap_learn(P, X, y, w0, w, v.ravel(), n, order=np.arange(n))
+    for mean in (0, 1):
+        P.batch_mean = mean
+        mb = oracle.TdapMinibatch(P, X, y, w0, w, v.ravel())
+        for i in range(n):
+            mb.step(i, i + 1)
+        assert util.rel_err(mb.v, ref["v"]) < 1e-13 and util.rel_err(mb.w, ref["w"]) < 1e-13 and abs(mb.w0.value - ref["w0"]) < 1e-13
+    # (b) arbitrary rows, linear term off (w is then zeroed on touch by both, V and w0 follow the same formulas)
+    n, p = 150, 200
+    rp, col, val = util.random_csr(n, p, 8, seed=6)
+    y = util.labels(n, 6)
+    w0, w, v = util.params(p, k, 6, stdev=0.2, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(k=k, k1=False, l1_regv=5e-4, l2_regv=1e-2, alpha_v=0.05, gamma=3e-3)
+    ref = oracle.tdap_learn(P, X, y, w0, w, v.ravel(), n, order=np.arange(n))
+    mb = oracle.TdapMinibatch(P, X, y, w0, w, v.ravel())
+    for i in range(n):
+        mb.step(i, i + 1)
+    assert util.rel_err(mb.v, ref["v"]) < 1e-13 and abs(mb.w0.value - ref["w0"]) < 1e-13 and np.array_equal(mb.w, ref["w"])
+    # a batch holding a feature c times ages it c times: e^(-gamma c)
+    P = oracle.params(k=1, gamma=0.5, batch_mean=False)
+    Xd = oracle.Matrix(np.arange(4) * 1, np.zeros(3, np.uint32), np.ones(3, np.float32), 1)
+    mb = oracle.TdapMinibatch(P, Xd, np.ones(3, np.float32), 0.0, np.zeros(1), np.zeros(1))
+    mb.step(0, 3)
+    sigma = np.sqrt(mb.sw[0]) / P.alpha_w
+    assert abs(mb.sw[2] - np.exp(-1.5) * sigma) < 1e-15   # delta of w[0] after one step of c = 3 touches
