@@ -55,13 +55,13 @@ def parse():
                          "0: 8 blocks on 2 GPUs, where the single xGMI link is the bound and finer blocks hide more of it, 4 otherwise, "
                          "where the extra launches of finer blocks cost more than they hide: profiles/r01_split_bench.json)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
-    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (0: skip; -1: 5M for sgd, 60K for ftrl k=64)")
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (0: skip; -1: 5M for sgd, 250K for ftrl k=64: 10-20 s of one core either way)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp64 state, small batches, sequential mode, ceilings)")
     a = ap.parse_args()
     if a.factors == 0:
         a.factors = 16 if a.solver == "sgd" else 64
     if a.cpu_rows < 0:
-        a.cpu_rows = 5_000_000 if a.solver == "sgd" else max(20_000, 4_000_000 // a.factors)
+        a.cpu_rows = 5_000_000 if a.solver == "sgd" else max(20_000, 16_000_000 // a.factors)
     return a
 
 

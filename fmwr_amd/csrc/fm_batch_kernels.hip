@@ -56,6 +56,31 @@ __device__ __forceinline__ double2 gather_row(const double* p) {
 #endif
 }
 
+// Bounds-checked gathers through a buffer descriptor (raw_buffer_load): an offset at or beyond the descriptor's size
+// returns zeros WITHOUT a memory request, so the padding slots of a short list cost nothing -- with flat loads every slot of
+// the unrolled batch is a request, and lists average 8 entries against batches of 4 (measured: a quarter of phase 2's requests).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t BUF_SKIP = 0x80000000u;  // beyond any table the buffer path is used for (< 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_row(__amdgpu_buffer_rsrc_t r, uint32_t off, float) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ double2 buf_row(__amdgpu_buffer_rsrc_t r, uint32_t off, double) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+__device__ __forceinline__ float buf_elem(__amdgpu_buffer_rsrc_t r, uint32_t off, float) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ double buf_elem(__amdgpu_buffer_rsrc_t r, uint32_t off, double) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+
 template <typename T> struct Slice;
 template <> struct Slice<float> { using vec = float4; static constexpr int N = 4; };
 template <> struct Slice<double> { using vec = double2; static constexpr int N = 2; };
@@ -332,6 +357,7 @@ struct ColsTables {
   uint32_t gb_feats;         // features per exchange-buffer block
   int64_t gb_block_elems;    // elements per block
   ST* gtail;                 // the 4-element tail {sum mult, sum mult^2, rows hi, rows lo}: end of gbuf, or the compact exchange's own
+  int64_t s_rows;            // rows of S / amul reachable from the pointers above (sizes the buffer descriptors)
   ST* crec;                  // compact exchange: one record per occurring feature (see record layout below)
   int rec_elems;             // elements per record
 };
@@ -630,6 +656,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
     if (have) { ta = off[I0 + gid]; tb = off[I0 + gid + 1]; }
     if (a.long_min > 0 && tb - ta > (int64_t)a.long_min) { have = false; ta = tb = 0; }  // a long list: not ours
     const ST* __restrict__ St = T.S + lig * VEC;
+    const __amdgpu_buffer_rsrc_t s_rsrc = table_rsrc(T.S, a.buf_gather ? (uint32_t)(T.s_rows * (KP * sizeof(ST))) : 0u);
+    const __amdgpu_buffer_rsrc_t a_rsrc = table_rsrc(T.amul, a.buf_gather ? (uint32_t)(T.s_rows * sizeof(ST)) : 0u);
     int64_t c0 = lo;
     while (c0 < hi) {
       if (a.long_min > 0) {
@@ -661,10 +689,18 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
         }
         vec_t sv[FMX_U];
         ST av[FMX_U];
+        if (a.buf_gather) {  // wave-uniform: padding slots issue no request
 #pragma unroll
-        for (int u = 0; u < FMX_U; ++u) {
-          sv[u] = gather_row(St + (size_t)en[u].x * KP);
-          av[u] = T.amul[en[u].x];
+          for (int u = 0; u < FMX_U; ++u) {
+            sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
+            av[u] = buf_elem(a_rsrc, ok[u] ? en[u].x * (uint32_t)sizeof(ST) : BUF_SKIP, ST());
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < FMX_U; ++u) {
+            sv[u] = gather_row(St + (size_t)en[u].x * KP);
+            av[u] = T.amul[en[u].x];
+          }
         }
 #pragma unroll
         for (int u = 0; u < FMX_U; ++u)  // occurrences in row order
@@ -848,6 +884,7 @@ static ColsTables<ST> cols_tables(fmx_engine* e, const ColsArgs& a, int has_q) {
   const int kp = W ? e->kp64 : e->kp32;
   T.S = (const ST*)e->S + (size_t)a.s_row0 * kp;
   T.amul = (const ST*)e->amul + a.s_row0;
+  T.s_rows = e->ws_rows - a.s_row0;
   T.scal = e->scal; T.scal_out = e->scal_next; T.partials = e->partials; T.n_partials = a.n_partials;
   T.gbuf = (ST*)e->gbuf; T.p = (uint32_t)e->p; T.has_q = has_q;
   T.gb_feats = (uint32_t)e->gb_feats; T.gb_block_elems = e->gb_block_elems;
@@ -866,6 +903,10 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
             FMX_ERR_STATE, "exchange buffer not allocated");
   FMX_CHECK(!(a.store_compact || a.compact_tail) || (e->ctail != nullptr && (!a.store_compact || e->crec != nullptr)), FMX_ERR_STATE, "compact exchange buffers not allocated");
   const int has_q = exchange_has_q(e) ? 1 : 0;
+  // gathers of S rows / multipliers go through bounds-checked buffer descriptors while the workspace stays below 2 GiB
+  // (FMX_BUF_GATHER=0 in the environment switches back to flat loads: tuning only)
+  static const bool buf_ok = [] { const char* v = getenv("FMX_BUF_GATHER"); return !(v && v[0] == '0'); }();
+  a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
   if (mb_wide(e)) {

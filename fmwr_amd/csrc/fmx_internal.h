@@ -286,6 +286,7 @@ struct ColsArgs {
   int64_t s_row0;        // row of the S / multiplier workspace where this tile's rows start (0 unless a whole step is resident)
   int store_compact;     // compact exchange: write one record per occurring feature (sparse walk only)
   int compact_tail;      // the scalar tail is the compact exchange's own 4 elements, not the end of the dense buffer
+  int buf_gather;        // set by the launcher: S rows / multipliers are gathered through buffer descriptors (padding slots issue no request)
 };
 // long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
 struct LongArgs {

@@ -17,10 +17,11 @@ P_FULL, K, Z = 33_000_000, 32, 39
 def _criteo_shaped(n, seed):
     rng = np.random.default_rng(seed)
     dense = np.tile(np.arange(13, dtype=np.int64), (n, 1))
-    cat = 13 + np.floor((P_FULL - 13) * rng.random((n, 60)) ** 3).astype(np.int64)   # skewed towards small ids: collisions between rows
+    cat = 13 + np.floor((P_FULL - 13) * rng.random((n, 40)) ** 2).astype(np.int64)   # skewed towards small ids: collisions between rows
     rows = []
     for r in range(n):
-        u = np.unique(cat[r])[:26]
+        u = np.unique(cat[r])
+        u = np.sort(rng.choice(u, 26, replace=False))
         rows.append(np.concatenate([dense[r], u]))
     rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
     col = np.concatenate(rows).astype(np.uint32)
