@@ -21,11 +21,11 @@ KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3
 # every symbol include/fmx.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
     "fmx_last_error", "fmx_config_default", "fmx_engine_create", "fmx_engine_destroy", "fmx_set_params",
-    "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_destroy",
+    "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_synthetic_fields", "fmx_train_stream", "fmx_matrix_destroy",
     "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
     "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_grad_elem_bytes", "fmx_grad_layout", "fmx_grad_begin", "fmx_grad_chunk", "fmx_apply_chunk", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
     "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_mcmc_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
-    "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset", "fmx_measure_gather",
+    "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset", "fmx_measure_gather", "fmx_measure_gather_occ",
     "fmx_get_rows", "fmx_set_rows", "fmx_init_normal", "fmx_compact_info", "fmx_compact_count", "fmx_compact_reserve", "fmx_grad_compact", "fmx_compact_records", "fmx_apply_compact",
 ]
 
@@ -42,6 +42,11 @@ class Config(C.Structure):
         ("device", C.c_int32), ("batch_reduce", C.c_int32), ("gamma", C.c_double), ("tile_rows", C.c_int64),
         ("state_fp64", C.c_int32), ("exchange_chunks", C.c_int32),
     ]
+
+
+class FieldsSpec(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_dense", C.c_int32), ("n_fields", C.c_int32), ("reserved", C.c_int32),
+                ("field_vocab", C.c_void_p), ("skew", C.c_double), ("seed", C.c_uint64)]
 
 
 class TrackConfig(C.Structure):

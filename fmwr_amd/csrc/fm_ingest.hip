@@ -563,16 +563,59 @@ __global__ void synth_rows_k(int64_t n, int32_t z, uint64_t seed, int64_t row_of
   }
 }
 
-int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offset) {
+// enqueue the generator for rows [row_offset, row_offset + n) on `stream` (no wait)
+int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream) {
   const int T = 256;
-  const int64_t total = m->n * z;
+  const int64_t total = n * z;
   if (total > 0)
-    hipLaunchKernelGGL(synth_entries_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, nullptr, m->n, m->p, z, seed, row_offset, m->col, m->val);
-  hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((m->n + 1 + T - 1) / T)), dim3(T), 0, nullptr, m->n, z, seed, row_offset, m->row_ptr, m->y);
+    hipLaunchKernelGGL(synth_entries_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, stream, n, m->p, z, seed, row_offset, m->col, m->val);
+  hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((n + 1 + T - 1) / T)), dim3(T), 0, stream, n, z, seed, row_offset, m->row_ptr, m->y);
   FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offset) {
+  FMX_TRY(generate_synthetic_async(m, m->n, z, seed, row_offset, nullptr));
   FMX_HIP(hipDeviceSynchronize());
   m->rows_sorted = 1;  // strata are disjoint and ascending
   m->max_row_len = z;
+  return FMX_OK;
+}
+
+// Criteo-shaped rows (SURVEY 8(d), configs[3]: "13 dense-ish + 26 categorical"): entry i < n_dense is feature i with a value
+// in [0, 1); entry n_dense + f is one feature of categorical field f, whose ids occupy [base[f], base[f] + vocab[f]): the id
+// inside the field is floor(vocab * u^skew), u uniform -- skew = 1 is uniform, larger values pile the mass on a field's first
+// ids (a power-law head like real click logs: a few values of a field occur in most rows, most values almost never).
+// One-hot value 1.  Philox keyed by (seed; global row, entry / 4) like the uniform generator: shard independent.
+__global__ void synth_fields_k(int64_t n, FieldSpec fs, uint64_t seed, int64_t row_offset, uint32_t* __restrict__ col, float* __restrict__ val) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int z = fs.n_dense + fs.n_fields;
+  if (t >= n * z) return;
+  const int64_t r = t / z;
+  const uint32_t i = (uint32_t)(t - r * z);
+  const uint64_t g = (uint64_t)(row_offset + r);
+  const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), i >> 2, 0xF1E1D5u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const double u = (double)ph.c[i & 3] / 4294967296.0;
+  if ((int)i < fs.n_dense) {
+    col[t] = i;
+    val[t] = (float)u;
+  } else {
+    const int f = (int)i - fs.n_dense;
+    const double x = fs.skew == 1.0 ? u : pow(u, fs.skew);
+    uint32_t id = (uint32_t)(x * (double)fs.vocab[f]);
+    if (id >= fs.vocab[f]) id = fs.vocab[f] - 1;
+    col[t] = fs.base[f] + id;
+    val[t] = 1.0f;
+  }
+}
+
+int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream) {
+  const int T = 256;
+  const int z = fs.n_dense + fs.n_fields;
+  const int64_t total = n * z;
+  if (total > 0) hipLaunchKernelGGL(synth_fields_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, stream, n, fs, seed, row_offset, m->col, m->val);
+  hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((n + 1 + T - 1) / T)), dim3(T), 0, stream, n, z, seed, row_offset, m->row_ptr, m->y);
+  FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 

@@ -20,6 +20,8 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // a full-avalanche int
 template <int LPR, int U>
 __global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __restrict__ table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt,
                                                              float4* __restrict__ out) {
+  extern __shared__ char occupancy_pad[];  // dynamic LDS only limits how many workgroups share a CU (fmx_measure_gather_occ)
+  (void)occupancy_pad;
   const int64_t g = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) / LPR;
   const int lig = threadIdx.x % LPR;
   if (g >= n_groups) return;
@@ -39,15 +41,30 @@ __global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __res
   out[g * LPR + lig] = acc;
 }
 
+static int g_probe_lds = 0;  // bytes of dynamic LDS per workgroup (0: none): 160 KiB / this = workgroups per CU
+
 template <int LPR>
 static void launch_probe(int in_flight, dim3 g, dim3 b, hipStream_t s, const float4* table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt, float4* out) {
-  if (in_flight >= 8) hipLaunchKernelGGL((gather_probe_k<LPR, 8>), g, b, 0, s, table, rows, per_group, n_groups, salt, out);
-  else hipLaunchKernelGGL((gather_probe_k<LPR, 4>), g, b, 0, s, table, rows, per_group, n_groups, salt, out);
+  if (in_flight >= 8) hipLaunchKernelGGL((gather_probe_k<LPR, 8>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out);
+  else hipLaunchKernelGGL((gather_probe_k<LPR, 4>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out);
 }
 
 }  // namespace fmx
 
 using namespace fmx;
+
+// tuning aid: the same probe with `lds_bytes` of dynamic LDS per workgroup, i.e. at most 160 KiB / lds_bytes workgroups per CU --
+// how many requests in flight the ceiling needs
+extern "C" int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight, int32_t reps,
+                                  double* rows_per_s);
+extern "C" int fmx_measure_gather_occ(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight, int32_t reps,
+                                      int32_t lds_bytes, double* rows_per_s) {
+  FMX_CHECK(lds_bytes >= 0 && lds_bytes <= 64 * 1024, FMX_ERR_INVALID, "lds_bytes must be in 0..65536");
+  g_probe_lds = lds_bytes;
+  const int st = fmx_measure_gather(device, table_bytes, row_bytes, n_groups, per_group, in_flight, reps, rows_per_s);
+  g_probe_lds = 0;
+  return st;
+}
 
 extern "C" int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight, int32_t reps,
                                   double* rows_per_s) {

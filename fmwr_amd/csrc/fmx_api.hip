@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <memory>
 
 #include "fmx_internal.h"
@@ -896,6 +897,43 @@ int fmx_matrix_synthetic(int device, int64_t n, uint32_t p, int32_t nnz_per_row,
   return FMX_OK;
 }
 
+static int fields_from_spec(const fmx_fields_spec* spec, FieldSpec* fs, uint64_t* p_out) {
+  FMX_CHECK(spec != nullptr && spec->struct_size == sizeof(fmx_fields_spec), FMX_ERR_INVALID, "bad fmx_fields_spec");
+  FMX_CHECK(spec->n_dense >= 0 && spec->n_fields >= 0 && spec->n_fields <= FMX_MAX_FIELDS && spec->n_dense + spec->n_fields >= 1, FMX_ERR_INVALID,
+            "need 0 <= n_fields <= %d and at least one entry per row", FMX_MAX_FIELDS);
+  FMX_CHECK(spec->n_fields == 0 || spec->field_vocab != nullptr, FMX_ERR_INVALID, "field_vocab is NULL");
+  FMX_CHECK(spec->skew >= 1.0, FMX_ERR_INVALID, "skew must be >= 1");
+  fs->n_dense = spec->n_dense; fs->n_fields = spec->n_fields; fs->skew = spec->skew;
+  uint64_t at = (uint64_t)spec->n_dense;
+  for (int f = 0; f < spec->n_fields; ++f) {
+    FMX_CHECK(spec->field_vocab[f] >= 1, FMX_ERR_INVALID, "field %d has an empty vocabulary", f);
+    fs->base[f] = (uint32_t)at; fs->vocab[f] = spec->field_vocab[f];
+    at += spec->field_vocab[f];
+    FMX_CHECK(at < (1ull << 32), FMX_ERR_INVALID, "more than 2^32-1 features");
+  }
+  *p_out = at;
+  return FMX_OK;
+}
+
+int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* spec, int64_t row_offset, fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FieldSpec fs{};
+  uint64_t p = 0;
+  FMX_TRY(fields_from_spec(spec, &fs, &p));
+  FMX_CHECK(n >= 0, FMX_ERR_INVALID, "negative size");
+  const int z = fs.n_dense + fs.n_fields;
+  fmx_matrix* m = nullptr;
+  FMX_TRY(alloc_matrix(device, n, (uint32_t)p, n * z, true, &m));
+  int st = generate_fields_async(m, n, fs, spec->seed, row_offset, nullptr);
+  if (st == FMX_OK && hipDeviceSynchronize() != hipSuccess) { set_error("generator failed"); st = FMX_ERR_HIP; }
+  if (st != FMX_OK) { free_matrix(m); return st; }
+  m->rows_sorted = 1;
+  m->max_row_len = z;
+  *out = m;
+  return FMX_OK;
+}
+
 int fmx_matrix_destroy(fmx_matrix* m) {
   if (m) (void)hipSetDevice(m->device);
   free_matrix(m);
@@ -1014,6 +1052,107 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
   }
   FMX_TRY(fmx_sync(e));
   if (examples_done) *examples_done = done;
+  return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ streamed training
+int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
+                     int64_t* examples_done, double* ingest_wait_s) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "streamed training runs in FMX_MODE_MINIBATCH");
+  FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS && e->cfg.solver != FMX_SOLVER_MCMC, FMX_ERR_STATE, "ALS / MCMC engines train through fmx_als_train / fmx_mcmc_train");
+  FMX_CHECK(total_rows >= 0, FMX_ERR_INVALID, "total_rows must be >= 0");
+  if (examples_done) *examples_done = 0;
+  if (ingest_wait_s) *ingest_wait_s = 0.0;
+  FieldSpec fs{};
+  uint64_t p = e->p;
+  int z = nnz_per_row;
+  if (spec) {
+    FMX_TRY(fields_from_spec(spec, &fs, &p));
+    seed = spec->seed;
+    z = fs.n_dense + fs.n_fields;
+  } else {
+    FMX_CHECK(nnz_per_row >= 1 && (uint64_t)nnz_per_row <= e->p, FMX_ERR_INVALID, "need 1 <= nnz_per_row <= p");
+  }
+  FMX_CHECK(p == e->p, FMX_ERR_INVALID, "number of input's features is not correct...");
+  const int64_t B = e->cfg.batch_rows;
+  FMX_CHECK(B <= effective_tile_rows(e), FMX_ERR_STATE, "streamed training needs steps of one tile (batch_rows <= %lld)", (long long)effective_tile_rows(e));
+  FMX_TRY(use_device(e->cfg.device));
+  if (total_rows == 0) return FMX_OK;
+
+  // two slots: while slot s trains on the engine's stream, the other one is generated and planned on the ingest stream
+  struct Slot { fmx_matrix* m = nullptr; hipEvent_t ingested = nullptr, trained = nullptr; uint32_t* h_counts = nullptr; int used = 0; };
+  struct Ctx {
+    Slot slot[2];
+    hipStream_t ingest = nullptr;
+    PlanWorkspace ws;
+    ~Ctx() {
+      for (auto& s : slot) {
+        if (s.ingested) (void)hipEventDestroy(s.ingested);
+        if (s.trained) (void)hipEventDestroy(s.trained);
+        if (s.h_counts) (void)hipHostFree(s.h_counts);
+        free_matrix(s.m);
+      }
+      if (ingest) (void)hipStreamDestroy(ingest);
+    }
+  } C;
+  const int64_t cap_cnt = B * z;
+  FMX_HIP(hipStreamCreateWithFlags(&C.ingest, hipStreamNonBlocking));
+  FMX_TRY(C.ws.reserve(cap_cnt, (uint32_t)p, C.ingest));
+  for (auto& s : C.slot) {
+    FMX_TRY(alloc_matrix(e->cfg.device, B, (uint32_t)p, cap_cnt, true, &s.m));
+    s.m->rows_sorted = 1; s.m->max_row_len = z;
+    FMX_HIP(hipMalloc(&s.m->brow, (size_t)cap_cnt * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&s.m->bval, (size_t)cap_cnt * sizeof(float)));
+    s.m->plans.resize(1);
+    FMX_TRY(plan_alloc(s.m->plans[0], (uint32_t)p, cap_cnt, cap_cnt >= (int64_t)p));
+    s.m->step_first_tile = {0, 1};
+    s.m->n_batches = 1; s.m->batch_rows = B; s.m->tile_rows = effective_tile_rows(e);   // build_batch_csc sees a finished cache
+    FMX_HIP(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
+    FMX_HIP(hipEventCreateWithFlags(&s.trained, hipEventDisableTiming));
+    FMX_HIP(hipHostMalloc(&s.h_counts, 4 * sizeof(uint32_t)));
+  }
+  FMX_HIP(hipDeviceSynchronize());
+  const int64_t steps = (total_rows + B - 1) / B;
+  auto ingest = [&](int64_t t) -> int {
+    Slot& s = C.slot[t & 1];
+    fmx_matrix* m = s.m;
+    const int64_t rows = (t + 1) * B <= total_rows ? B : total_rows - t * B;
+    if (s.used) FMX_HIP(hipStreamWaitEvent(C.ingest, s.trained, 0));  // the slot's previous step must have finished with its arrays
+    m->n = rows; m->nnz = rows * z;
+    if (spec) FMX_TRY(generate_fields_async(m, rows, fs, seed, row_offset + t * B, C.ingest));
+    else FMX_TRY(generate_synthetic_async(m, rows, z, seed, row_offset + t * B, C.ingest));
+    auto& pl = m->plans[0];
+    pl.r0 = 0; pl.nrows = rows; pl.base = 0; pl.cnt = rows * z;
+    FMX_TRY(plan_build(pl, C.ws, (uint32_t)p, m->row_ptr, m->col, m->val, m->brow, m->bval, C.ingest));
+    FMX_HIP(hipMemcpyAsync(s.h_counts, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, C.ingest));
+    FMX_HIP(hipEventRecord(s.ingested, C.ingest));
+    s.used = 1;
+    return FMX_OK;
+  };
+  double waited = 0.0;
+  int64_t done = 0;
+  FMX_TRY(ingest(0));
+  for (int64_t t = 0; t < steps; ++t) {
+    Slot& s = C.slot[t & 1];
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    FMX_HIP(hipEventSynchronize(s.ingested));  // the host needs the tile's counts (launch sizes); the engine's stream keeps running meanwhile
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    waited += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    plan_set_counts(s.m->plans[0], (uint32_t)p, s.h_counts);
+    s.m->max_long_seg = s.m->plans[0].n_seg;
+    s.m->plan_generation++;
+    FMX_HIP(hipStreamWaitEvent(e->stream, s.ingested, 0));
+    FMX_TRY(run_step(e, s.m, 0, 0, true));
+    FMX_HIP(hipEventRecord(s.trained, e->stream));
+    done += s.m->n;
+    if (t + 1 < steps) FMX_TRY(ingest(t + 1));  // overlaps the step just enqueued
+  }
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  FMX_HIP(hipStreamSynchronize(C.ingest));
+  if (examples_done) *examples_done = done;
+  if (ingest_wait_s) *ingest_wait_s = waited;
   return FMX_OK;
 }
 

@@ -347,6 +347,14 @@ void drop_plans(fmx_matrix* m);
 int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream);
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
+int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream);
+constexpr int FMX_MAX_FIELDS = 64;
+struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)
+  int n_dense, n_fields;
+  double skew;
+  uint32_t base[FMX_MAX_FIELDS], vocab[FMX_MAX_FIELDS];
+};
+int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream);
 int check_rows_sorted(fmx_matrix* m);
 int init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev);
 int rows_copy(fmx_engine* e, const uint32_t* d_ids, int64_t n, double* d_w, double* d_v, bool set);

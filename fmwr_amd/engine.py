@@ -10,6 +10,20 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def fields_spec(n_dense, field_vocab, skew, seed):
+    """(fmx_fields_spec, the numpy array it points to -- keep it alive for the call)."""
+    vocab = np.ascontiguousarray(field_vocab, np.uint32)
+    spec = L.FieldsSpec(C.sizeof(L.FieldsSpec), int(n_dense), len(vocab), 0, vocab.ctypes.data, float(skew), int(seed))
+    return spec, vocab
+
+
+# BASELINE.json configs[3]: 13 dense + 26 categorical fields, 33 000 000 features in all.  Vocabulary sizes follow the spread
+# of the Criteo click logs' 26 categorical columns (a few fields of millions of values, many of a handful).
+CRITEO_VOCAB = [9_900_000, 7_900_000, 6_700_000, 4_900_000, 2_200_000, 590_000, 400_000, 250_000, 72404, 39_000, 17_000, 12_000, 7_400, 7_100,
+                2_200, 1_500, 980, 160, 110, 63, 36, 14, 10, 4, 3, 3]
+assert 13 + sum(CRITEO_VOCAB) == 33_000_000
+
+
 class Matrix:
     """A device-resident fm.matrix (fmx_matrix*)."""
 
@@ -55,6 +69,14 @@ class Matrix:
         h = C.c_void_p()
         L.check(L.lib().fmx_matrix_synthetic(C.c_int(device), C.c_int64(n), C.c_uint32(p), C.c_int32(nnz_per_row), C.c_uint64(seed),
                                              C.c_int64(row_offset), C.byref(h)))
+        return cls._wrap(h)
+
+    @classmethod
+    def synthetic_fields(cls, n, n_dense, field_vocab, skew, seed, row_offset=0, device=0):
+        """Criteo-shaped rows: n_dense always-present features + one feature of each categorical field (fmx_matrix_synthetic_fields)."""
+        spec, keep = fields_spec(n_dense, field_vocab, skew, seed)
+        h = C.c_void_p()
+        L.check(L.lib().fmx_matrix_synthetic_fields(C.c_int(device), C.c_int64(n), C.byref(spec), C.c_int64(row_offset), C.byref(h)))
         return cls._wrap(h)
 
     def scales(self, norm_columns):
@@ -169,6 +191,17 @@ class Engine:
         done = C.c_int64()
         L.check(L.lib().fmx_train(self.h, m.h, C.c_int64(max_iter), C.byref(done)))
         return done.value
+
+    def train_stream(self, total_rows, nnz_per_row=0, seed=0, row_offset=0, fields=None):
+        """Streamed training on generated rows (fmx_train_stream); fields = (n_dense, field_vocab, skew) for the Criteo-shaped
+        stream.  Returns (examples done, host seconds spent waiting for ingest)."""
+        done, wait = C.c_int64(), C.c_double()
+        spec = None
+        if fields is not None:
+            spec, keep = fields_spec(fields[0], fields[1], fields[2], seed)
+        L.check(L.lib().fmx_train_stream(self.h, C.byref(spec) if spec is not None else None, C.c_int32(nnz_per_row), C.c_uint64(seed), C.c_int64(row_offset),
+                                         C.c_int64(total_rows), C.byref(done), C.byref(wait)))
+        return done.value, wait.value
 
     def train_tracked(self, m, max_iter, step_size, metric=L.EVAL_LL, convergence=1e-4, keep_params=True):
         """Learner::learn with the tracker on; returns dict(done, convergent, iters, evals[, params])."""

@@ -155,6 +155,21 @@ int fmx_matrix_from_csr(int device, int64_t n, uint32_t p, const int64_t* row_pt
  * label +-1.  Shard-independent: a rank asks for its own row range. */
 int fmx_matrix_synthetic(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed,
                          int64_t row_offset, fmx_matrix** out);
+/* Criteo-shaped synthetic rows (BASELINE.json configs[3]): n_dense always-present features (ids
+ * 0..n_dense-1, value in [0,1)) followed by one one-hot feature from each of n_fields categorical fields (<= 64); field f owns
+ * the next field_vocab[f] ids, the id inside a field is floor(vocab * u^skew) with u uniform (skew = 1: uniform; larger: a
+ * power-law head, as in click logs).  Number of features = n_dense + sum(field_vocab); every row holds n_dense + n_fields
+ * entries, ascending.  Keyed by (seed, global row id) like fmx_matrix_synthetic. */
+typedef struct fmx_fields_spec {
+  uint32_t struct_size;  /* = sizeof(fmx_fields_spec) */
+  int32_t n_dense;
+  int32_t n_fields;
+  int32_t reserved;
+  const uint32_t* field_vocab; /* [n_fields] */
+  double skew;
+  uint64_t seed;
+} fmx_fields_spec;
+int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* spec, int64_t row_offset, fmx_matrix** out);
 int fmx_matrix_destroy(fmx_matrix* m);
 int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz);
 /* Copy rows [r0, r1) back to the host (row_ptr is rebased to 0); any pointer may be NULL. */
@@ -180,6 +195,15 @@ int fmx_predict(fmx_engine* e, const fmx_matrix* m, double* out, int link);
 int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
 /* Same, but with an explicit visiting order (row ids, SEQUENTIAL mode only). */
 int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t count);
+
+/* Streamed training (BASELINE.json configs[3]: 4e9 rows x 33 M features do not fit the reference's uint32 offsets,
+ * util/Smatrix.h:10-17, nor any memory): the rows [row_offset, row_offset + total_rows) of a synthetic stream are produced
+ * step by step -- batch_rows rows are generated, their inverted index is built ON A SECOND STREAM while the previous step
+ * trains, each step is trained on once and dropped.  spec == NULL: the uniform generator of fmx_matrix_synthetic with
+ * nnz_per_row entries; otherwise the Criteo-shaped one (nnz_per_row ignored).  Needs batch_rows <= the tile size (one tile per
+ * step).  ingest_wait_s (may be NULL): host seconds spent waiting for a tile's index, i.e. what the overlap did not hide. */
+int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset,
+                     int64_t total_rows, int64_t* examples_done, double* ingest_wait_s);
 
 /* ---- tracker (core/Tracker.h, the evaluation blocks of solver/SGD_Learner.h:140-176 and FTRL_Learner.h:118-154) */
 
@@ -316,6 +340,9 @@ int fmx_profile_reset(fmx_engine* e);
  * HIP events.  bench.py reports kernel rows/s divided by this figure as "ceiling_frac". */
 int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight,
                        int32_t reps, double* rows_per_s);
+/* the same probe held to at most 160 KiB / lds_bytes workgroups per CU: how many requests in flight the ceiling needs */
+int fmx_measure_gather_occ(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight,
+                           int32_t reps, int32_t lds_bytes, double* rows_per_s);
 
 #ifdef __cplusplus
 }

@@ -271,8 +271,20 @@ def test_c_abi_argument_checks_for_the_newer_entry_points():
         seq.predict(m, 7)
     with pytest.raises(L.FmxError, match="Unknown solver"):
         engine.Engine(p, solver=400)
-    with pytest.raises(L.FmxError, match="TDAP solver runs in FMX_MODE_SEQUENTIAL"):
-        engine.Engine(p, solver=L.SOLVER_TDAP, mode=L.MODE_MINIBATCH)
+    engine.Engine(p, solver=L.SOLVER_TDAP, mode=L.MODE_MINIBATCH).close()   # mini-batch TDAP exists since round 2
+    # compact exchange: only for steps of one sparse tile; streamed training: mini-batch engines, one tile per step
+    with pytest.raises(L.FmxError, match="sparse"):
+        mb.grad_compact(m, 0)                       # 300 x 40 with 20 % density: more entries than features per tile
+    with pytest.raises(L.FmxError, match="MINIBATCH"):
+        seq.compact_info(m)
+    with pytest.raises(L.FmxError, match="MINIBATCH"):
+        seq.train_stream(1000, nnz_per_row=3)
+    with pytest.raises(L.FmxError, match="nnz_per_row"):
+        mb.train_stream(1000, nnz_per_row=0)
+    with pytest.raises(L.FmxError, match="features is not correct"):
+        mb.train_stream(1000, seed=1, fields=(2, [5, 7], 1.0))   # 2 + 12 features, the engine has 40
+    with pytest.raises(L.FmxError, match="out of range"):
+        mb.get_rows([p])
 
 
 def test_failed_plan_build_leaves_no_half_built_cache(monkeypatch):

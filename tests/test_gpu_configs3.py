@@ -72,3 +72,52 @@ def test_configs3_shape_minibatch_matches_oracle_on_the_touched_features(reduce)
     ref = oracle.predict_batch(P, oracle.Matrix(rp, colc, val, pc), mb.w0.value, mb.w, mb.v)
     np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
     assert np.array_equal(np.sign(out[np.abs(ref) > 1e-4]), np.sign(ref[np.abs(ref) > 1e-4]))
+
+
+def test_streamed_training_equals_resident_training():
+    """fmx_train_stream (rows generated step by step, each step's inverted index built on a second stream while the previous
+    step trains, nothing kept) against the same rows trained from a resident matrix: bit for bit, for the uniform and for the
+    Criteo-shaped generator, sparse and dense tiles, a ragged last step."""
+    from fmwr_amd import _lib as L, engine
+    vocab = [50_000, 20_000, 3_000, 400, 30, 4]
+    cases = [dict(p=200_000, z=12, fields=None, B=3000),          # sparse tiles: 36 000 entries against 200 000 features
+             dict(p=4_000, z=12, fields=None, B=3000),            # dense tiles
+             dict(p=3 + sum(vocab), z=9, fields=(3, vocab, 2.5), B=2500)]   # heavy hitters: dense features and the small fields
+    for c in cases:
+        n = 4 * c["B"] + 777
+        kw = dict(num_factor=8, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=c["B"])
+        v0 = np.random.default_rng(2).normal(0, 0.05, (8, c["p"])).astype(np.float32).astype(np.float64)
+        a = engine.Engine(c["p"], **kw); a.set_params(0.0, None, v0)
+        if c["fields"] is None:
+            m = engine.Matrix.synthetic(n, c["p"], c["z"], 77, row_offset=1000)
+            done, _ = (lambda e: e.train_stream(n, nnz_per_row=c["z"], seed=77, row_offset=1000))(a)
+        else:
+            m = engine.Matrix.synthetic_fields(n, c["fields"][0], c["fields"][1], c["fields"][2], 77, row_offset=1000)
+            done, _ = a.train_stream(n, seed=77, row_offset=1000, fields=c["fields"])
+        assert done == n and m.p == c["p"]
+        b = engine.Engine(c["p"], **kw); b.set_params(0.0, None, v0)
+        assert b.train(m, n) == n
+        pa, pb = a.get_params(), b.get_params()
+        assert pa[0] == pb[0] and np.array_equal(pa[1], pb[1]) and np.array_equal(pa[2], pb[2])
+        assert np.any(pa[2] != v0)
+
+
+def test_fields_generator_shape():
+    from fmwr_amd import engine
+    vocab = [1000, 50, 7, 2]
+    m = engine.Matrix.synthetic_fields(20_000, 3, vocab, 3.0, 5)
+    rp, col, val, y = m.export()
+    z = 3 + len(vocab)
+    assert m.p == 3 + sum(vocab) and np.array_equal(rp, np.arange(20_001) * z)
+    c = col.reshape(-1, z).astype(np.int64)
+    assert np.all(np.diff(c, axis=1) > 0) and np.array_equal(c[:, :3], np.tile(np.arange(3), (20_000, 1)))
+    base = 3 + np.concatenate([[0], np.cumsum(vocab)[:-1]])
+    for f, v in enumerate(vocab):
+        ids = c[:, 3 + f] - base[f]
+        assert ids.min() >= 0 and ids.max() < v
+    ids0 = c[:, 3] - base[0]
+    assert np.mean(ids0 < 10) > 0.15          # skew 3: P(id < 1 % of the field) = 0.01^(1/3) = 0.215
+    v = val.reshape(-1, z)
+    assert np.all(v[:, 3:] == 1.0) and 0.45 < v[:, :3].mean() < 0.55 and set(np.unique(y)) == {-1.0, 1.0}
+    part = engine.Matrix.synthetic_fields(500, 3, vocab, 3.0, 5, row_offset=19_500).export()   # shard independent
+    assert np.array_equal(part[1], col[19_500 * z:]) and np.array_equal(part[3], y[19_500:])
