@@ -1,0 +1,357 @@
+// N GPUs behind the C ABI: cfg.n_gpus > 1 makes fmx_train() a synchronous data-parallel run over N replicas driven by ONE host
+// thread, so that the reference's single R process (src/FM.cpp:59,97 plumb `nthreads`; here it is `n_gpus`) scales without any
+// other runtime.  The reference has no counterpart; BASELINE.json's north_star prescribes the scheme:
+// rows shard contiguously by rank, every replica holds the full (w0, w, V), one all-reduce(sum) of the gradient-sum buffer per
+// step, every replica applies the identical update.
+//
+//   exchange on distinct devices : RCCL (ncclCommInitAll, one grouped ncclAllReduce per step, enqueued on each engine's own
+//                                  stream: no host synchronisation inside a step).  librccl is loaded on first use with
+//                                  dlopen -- libfmx.so has no link-time dependency on it, and a process that brought its own
+//                                  copy (a PyTorch wheel does) keeps using that one.
+//   exchange on ONE device       : cfg.gpus_share_device = 1 places all replicas on cfg.device (rehearsal / tests on a one-GPU
+//                                  box): a kernel adds the N buffers in rank order and writes the sum back to each.
+//
+// Shards are cut from the caller's matrix on the device (peer copies + a row_ptr rebase), cached per matrix.
+#include <dlfcn.h>
+
+#include <hip/hip_runtime.h>
+
+#include "fmx_internal.h"
+
+namespace fmx {
+
+// ---- the handful of RCCL entry points, resolved at run time ---------------------------------------------------------------
+typedef void* rcclComm_t;
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(rcclComm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(rcclComm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int RCCL_SUM = 0, RCCL_FLOAT32 = 7, RCCL_FLOAT64 = 8;  // ncclRedOp_t / ncclDataType_t values of nccl.h (rccl.h)
+
+static Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.lib ? &r : nullptr;
+  tried = true;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.lib) break;
+  }
+  if (!r.lib) return nullptr;
+  r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
+  return &r;
+}
+
+#define FMX_RCCL(call)                                                                                               \
+  do {                                                                                                               \
+    const int _r = (call);                                                                                           \
+    if (_r != 0) {                                                                                                   \
+      Rccl* _l = rccl();                                                                                             \
+      fmx::set_error("%s failed: %s", #call, _l && _l->GetErrorString ? _l->GetErrorString(_r) : "rccl error");       \
+      return FMX_ERR_HIP;                                                                                            \
+    }                                                                                                                \
+  } while (0)
+
+// ---- exchange among replicas that share one device: sum in rank order, written back to every buffer ------------------------
+constexpr int GROUP_MAX = 16;
+struct BufList { void* b[GROUP_MAX]; int n; };
+
+template <typename ST>
+__global__ void sum_buffers_k(BufList bl, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  ST acc = reinterpret_cast<const ST*>(bl.b[0])[i];
+  for (int r = 1; r < bl.n; ++r) acc = acc + reinterpret_cast<const ST*>(bl.b[r])[i];  // rank order, in the buffer's own type (what an all-reduce does)
+  for (int r = 0; r < bl.n; ++r) reinterpret_cast<ST*>(bl.b[r])[i] = acc;
+}
+
+__global__ void rebase_rows_k(const int64_t* __restrict__ src, int64_t r0, int64_t n, int64_t base, int64_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) dst[i] = src[r0 + i] - base;
+}
+
+struct Group {
+  int n = 0;
+  std::vector<fmx_engine*> rep;   // rep[0] is the caller's handle
+  std::vector<int> dev;
+  bool shared = false;
+  std::vector<rcclComm_t> comm;   // distinct devices
+  hipStream_t xs = nullptr;       // shared device: the exchange stream
+  std::vector<hipEvent_t> ready;  // per replica: gradient sums written
+  hipEvent_t summed = nullptr;
+  // shards of the last matrix trained on
+  const fmx_matrix* src = nullptr;
+  int64_t src_n = 0, src_nnz = 0;
+  uint64_t src_values = 0;
+  std::vector<fmx_matrix*> shard;
+};
+
+static void free_shards(Group* g) {
+  for (size_t r = 0; r < g->shard.size(); ++r)
+    if (g->shard[r]) { (void)hipSetDevice(g->dev[r]); fmx_matrix_destroy(g->shard[r]); }
+  g->shard.clear();
+  g->src = nullptr;
+}
+
+void group_destroy(fmx_engine* e) {
+  Group* g = e->group;
+  if (!g) return;
+  free_shards(g);
+  Rccl* l = rccl();
+  for (rcclComm_t c : g->comm) if (c && l) (void)l->CommDestroy(c);
+  (void)hipSetDevice(e->cfg.device);
+  for (hipEvent_t ev : g->ready) if (ev) (void)hipEventDestroy(ev);
+  if (g->summed) (void)hipEventDestroy(g->summed);
+  if (g->xs) (void)hipStreamDestroy(g->xs);
+  for (int r = 1; r < g->n; ++r) fmx_engine_destroy(g->rep[(size_t)r]);
+  delete g;
+  e->group = nullptr;
+}
+
+int group_create(fmx_engine* e) {
+  const int n = e->cfg.n_gpus;
+  FMX_CHECK(n >= 2 && n <= GROUP_MAX, FMX_ERR_INVALID, "n_gpus must be in 1..%d", GROUP_MAX);
+  FMX_CHECK(e->cfg.mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID,
+            "n_gpus > 1 needs FMX_MODE_MINIBATCH: the reference's per-example algorithm does not shard (every example depends on the one before)");
+  FMX_CHECK(e->cfg.solver == FMX_SOLVER_SGD || e->cfg.solver == FMX_SOLVER_FTRL || e->cfg.solver == FMX_SOLVER_TDAP, FMX_ERR_INVALID,
+            "n_gpus > 1 trains SGD / FTRL / TDAP engines (the ALS / MCMC sweeps run as replicas only)");
+  Group* g = new Group();
+  e->group = g;
+  g->n = n;
+  g->shared = e->cfg.gpus_share_device != 0;
+  g->rep.assign((size_t)n, nullptr);
+  g->rep[0] = e;
+  int count = 0;
+  FMX_HIP(hipGetDeviceCount(&count));
+  for (int r = 0; r < n; ++r) g->dev.push_back(g->shared ? e->cfg.device : e->cfg.device + r);
+  FMX_CHECK(g->dev.back() < count, FMX_ERR_INVALID, "n_gpus = %d starting at device %d, but only %d devices are visible", n, e->cfg.device, count);
+  for (int r = 1; r < n; ++r) {
+    fmx_config c = e->cfg;
+    c.n_gpus = 1;
+    c.device = g->dev[(size_t)r];
+    FMX_TRY(fmx_engine_create(&c, e->p, &g->rep[(size_t)r]));
+  }
+  g->ready.assign((size_t)n, nullptr);
+  if (g->shared) {
+    FMX_HIP(hipSetDevice(e->cfg.device));
+    FMX_HIP(hipStreamCreateWithFlags(&g->xs, hipStreamNonBlocking));
+    FMX_HIP(hipEventCreateWithFlags(&g->summed, hipEventDisableTiming));
+    for (int r = 0; r < n; ++r) FMX_HIP(hipEventCreateWithFlags(&g->ready[(size_t)r], hipEventDisableTiming));
+  } else {
+    Rccl* l = rccl();
+    FMX_CHECK(l != nullptr, FMX_ERR_STATE, "n_gpus > 1 on distinct devices needs librccl.so (not found by dlopen)");
+    g->comm.assign((size_t)n, nullptr);
+    FMX_RCCL(l->CommInitAll(g->comm.data(), n, g->dev.data()));
+  }
+  FMX_HIP(hipSetDevice(e->cfg.device));
+  return FMX_OK;
+}
+
+int group_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
+  Group* g = e->group;
+  for (int r = 1; r < g->n; ++r) FMX_TRY(fmx_set_params(g->rep[(size_t)r], w0, w, v));
+  return use_device_public(e->cfg.device);
+}
+
+// rows [r0, r1) of src as a matrix of its own on device `dev`
+static int cut_shard(const fmx_matrix* src, int64_t r0, int64_t r1, int dev, fmx_matrix** out) {
+  FMX_HIP(hipSetDevice(src->device));
+  int64_t ends[2] = {0, 0};
+  FMX_HIP(hipMemcpy(&ends[0], src->row_ptr + r0, sizeof(int64_t), hipMemcpyDeviceToHost));
+  FMX_HIP(hipMemcpy(&ends[1], src->row_ptr + r1, sizeof(int64_t), hipMemcpyDeviceToHost));
+  const int64_t base = ends[0], cnt = ends[1] - ends[0], n = r1 - r0;
+  fmx_matrix* m = nullptr;
+  FMX_TRY(alloc_matrix_public(dev, n, src->p, cnt, src->has_labels != 0, &m));
+  auto body = [&]() -> int {
+    FMX_HIP(hipSetDevice(dev));
+    if (dev == src->device) {
+      hipLaunchKernelGGL(rebase_rows_k, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, nullptr, src->row_ptr, r0, n, base, m->row_ptr);
+    } else {  // the source's row_ptr is on another device: stage the slice, then rebase in place
+      FMX_HIP(hipMemcpyPeer(m->row_ptr, dev, src->row_ptr + r0, src->device, ((size_t)n + 1) * sizeof(int64_t)));
+      hipLaunchKernelGGL(rebase_rows_k, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, (int64_t)0, n, base, m->row_ptr);
+    }
+    if (cnt > 0) {
+      FMX_HIP(hipMemcpyPeer(m->col, dev, src->col + base, src->device, (size_t)cnt * sizeof(uint32_t)));
+      FMX_HIP(hipMemcpyPeer(m->val, dev, src->val + base, src->device, (size_t)cnt * sizeof(float)));
+    }
+    if (n > 0) FMX_HIP(hipMemcpyPeer(m->y, dev, src->y + r0, src->device, (size_t)n * sizeof(float)));
+    FMX_HIP(hipGetLastError());
+    FMX_HIP(hipDeviceSynchronize());
+    return FMX_OK;
+  };
+  const int st = body();
+  if (st != FMX_OK) { fmx_matrix_destroy(m); return st; }
+  m->rows_sorted = src->rows_sorted;
+  m->max_row_len = src->max_row_len;
+  *out = m;
+  return FMX_OK;
+}
+
+static int ensure_shards(Group* g, const fmx_matrix* m) {
+  if (g->src == m && g->src_n == m->n && g->src_nnz == m->nnz && g->src_values == m->value_generation && !g->shard.empty()) return FMX_OK;
+  free_shards(g);
+  g->shard.assign((size_t)g->n, nullptr);
+  for (int r = 0; r < g->n; ++r) {
+    const int64_t r0 = (m->n * r) / g->n, r1 = (m->n * (r + 1)) / g->n;  // rank r gets rows [r n / N, (r + 1) n / N)
+    FMX_TRY(cut_shard(m, r0, r1, g->dev[(size_t)r], &g->shard[(size_t)r]));
+  }
+  g->src = m; g->src_n = m->n; g->src_nnz = m->nnz; g->src_values = m->value_generation;
+  return FMX_OK;
+}
+
+// one all-reduce(sum) of every replica's exchange buffer, ordered after its gradient kernels and before its update
+static int exchange(Group* g) {
+  void* buf[GROUP_MAX];
+  int64_t count = 0;
+  for (int r = 0; r < g->n; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_TRY(fmx_grad_buffer(g->rep[(size_t)r], &buf[r], &count));
+  }
+  const bool wide = mb_wide(g->rep[0]);
+  if (!g->shared) {
+    Rccl* l = rccl();
+    FMX_RCCL(l->GroupStart());
+    for (int r = 0; r < g->n; ++r)
+      FMX_RCCL(l->AllReduce(buf[r], buf[r], (size_t)count, wide ? RCCL_FLOAT64 : RCCL_FLOAT32, RCCL_SUM, g->comm[(size_t)r], g->rep[(size_t)r]->stream));
+    FMX_RCCL(l->GroupEnd());
+    return FMX_OK;
+  }
+  FMX_HIP(hipSetDevice(g->dev[0]));
+  BufList bl{};
+  bl.n = g->n;
+  for (int r = 0; r < g->n; ++r) {
+    bl.b[r] = buf[r];
+    FMX_HIP(hipEventRecord(g->ready[(size_t)r], g->rep[(size_t)r]->stream));
+    FMX_HIP(hipStreamWaitEvent(g->xs, g->ready[(size_t)r], 0));
+  }
+  const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+  if (wide) hipLaunchKernelGGL((sum_buffers_k<double>), grid, block, 0, g->xs, bl, count);
+  else hipLaunchKernelGGL((sum_buffers_k<float>), grid, block, 0, g->xs, bl, count);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipEventRecord(g->summed, g->xs));
+  for (int r = 0; r < g->n; ++r) FMX_HIP(hipStreamWaitEvent(g->rep[(size_t)r]->stream, g->summed, 0));
+  return FMX_OK;
+}
+
+// Learner::learn over N replicas: global step s = local batch (s mod nb) of every shard; max_iter counts examples of the
+// whole job, the last step is truncated rank by rank (lower ranks first).
+int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done) {
+  Group* g = e->group;
+  FMX_TRY(ensure_shards(g, m));
+  // fp32 exchange: counts travel as floats -- exact while every per-feature occurrence count of a global batch stays below 2^24
+  FMX_CHECK(mb_wide(e) || e->cfg.batch_rows * g->n < (1LL << 24), FMX_ERR_INVALID,
+            "batch_rows * n_gpus must stay below 2^24 with fp32 state (occurrence counts are exchanged as floats); use state_fp64 or smaller batches");
+  std::vector<int64_t> nb((size_t)g->n, 0);
+  int64_t nb_min = -1;
+  for (int r = 0; r < g->n; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_TRY(fmx_num_batches(g->rep[(size_t)r], g->shard[(size_t)r], &nb[(size_t)r]));
+    if (nb_min < 0 || nb[(size_t)r] < nb_min) nb_min = nb[(size_t)r];
+  }
+  FMX_CHECK(nb_min >= 1, FMX_ERR_INVALID, "a shard is empty: fewer rows than GPUs");
+  int64_t done = 0;
+  for (int64_t s = 0; done < max_iter; ++s) {
+    int64_t left = max_iter - done;
+    for (int r = 0; r < g->n; ++r) {
+      const fmx_matrix* sh = g->shard[(size_t)r];
+      const int64_t b = s % nb[(size_t)r];  // shards differ by at most one row: their batch counts agree except for a ragged tail
+      const int64_t b0 = b * e->cfg.batch_rows;
+      int64_t rows = b0 + e->cfg.batch_rows <= sh->n ? e->cfg.batch_rows : sh->n - b0;
+      if (rows > left) rows = left;
+      FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+      // rows == 0 can only happen on the truncated last step: fmx_grad then publishes zeros (rows_limit < 0 is not a thing: pass 0 rows as an empty share)
+      if (rows > 0) FMX_TRY(fmx_grad(g->rep[(size_t)r], g->shard[(size_t)r], b, rows));
+      else FMX_TRY(group_grad_empty(g->rep[(size_t)r], g->shard[(size_t)r], b));
+      left -= rows;
+      done += rows;
+    }
+    FMX_TRY(exchange(g));
+    for (int r = 0; r < g->n; ++r) {
+      FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+      FMX_TRY(fmx_apply(g->rep[(size_t)r], 0));  // the global row count travelled in the buffer's tail
+    }
+  }
+  for (int r = 0; r < g->n; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_TRY(fmx_sync(g->rep[(size_t)r]));
+  }
+  FMX_HIP(hipSetDevice(e->cfg.device));
+  if (examples_done) *examples_done = done;
+  return FMX_OK;
+}
+
+// RCCL smoke test on the devices this process sees (n ranks on devices 0..n-1): all-reduce of a small buffer, checked.  Lets a
+// one-GPU box prove that librccl loads, that the entry points have the signatures assumed above and that the enum values are
+// right (n = 1: the collective is a copy).
+int group_rccl_selftest(int n, double* max_err) {
+  Rccl* l = rccl();
+  FMX_CHECK(l != nullptr, FMX_ERR_STATE, "librccl.so not found by dlopen");
+  int count = 0;
+  FMX_HIP(hipGetDeviceCount(&count));
+  FMX_CHECK(n >= 1 && n <= count && n <= GROUP_MAX, FMX_ERR_INVALID, "need 1 <= n <= visible devices (%d)", count);
+  std::vector<int> dev((size_t)n);
+  std::vector<rcclComm_t> comm((size_t)n, nullptr);
+  std::vector<float*> f((size_t)n, nullptr);
+  std::vector<double*> d((size_t)n, nullptr);
+  std::vector<hipStream_t> st((size_t)n, nullptr);
+  for (int r = 0; r < n; ++r) dev[(size_t)r] = r;
+  const int N = 1000;
+  int rc = FMX_OK;
+  auto body = [&]() -> int {
+    FMX_RCCL(l->CommInitAll(comm.data(), n, dev.data()));
+    std::vector<float> hf(N);
+    std::vector<double> hd(N);
+    for (int r = 0; r < n; ++r) {
+      FMX_HIP(hipSetDevice(r));
+      FMX_HIP(hipStreamCreateWithFlags(&st[(size_t)r], hipStreamNonBlocking));
+      FMX_HIP(hipMalloc(&f[(size_t)r], N * sizeof(float)));
+      FMX_HIP(hipMalloc(&d[(size_t)r], N * sizeof(double)));
+      for (int i = 0; i < N; ++i) { hf[(size_t)i] = (float)(i + 1) * (float)(r + 1); hd[(size_t)i] = (double)(i + 1) * 1e-3 * (double)(r + 1); }
+      FMX_HIP(hipMemcpy(f[(size_t)r], hf.data(), N * sizeof(float), hipMemcpyHostToDevice));
+      FMX_HIP(hipMemcpy(d[(size_t)r], hd.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    }
+    FMX_RCCL(l->GroupStart());
+    for (int r = 0; r < n; ++r) {
+      FMX_RCCL(l->AllReduce(f[(size_t)r], f[(size_t)r], (size_t)N, RCCL_FLOAT32, RCCL_SUM, comm[(size_t)r], st[(size_t)r]));
+      FMX_RCCL(l->AllReduce(d[(size_t)r], d[(size_t)r], (size_t)N, RCCL_FLOAT64, RCCL_SUM, comm[(size_t)r], st[(size_t)r]));
+    }
+    FMX_RCCL(l->GroupEnd());
+    double err = 0.0;
+    const double tri = (double)n * (n + 1) / 2.0;
+    for (int r = 0; r < n; ++r) {
+      FMX_HIP(hipSetDevice(r));
+      FMX_HIP(hipStreamSynchronize(st[(size_t)r]));
+      FMX_HIP(hipMemcpy(hf.data(), f[(size_t)r], N * sizeof(float), hipMemcpyDeviceToHost));
+      FMX_HIP(hipMemcpy(hd.data(), d[(size_t)r], N * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < N; ++i) {
+        const double e1 = fabs((double)hf[(size_t)i] - (double)(i + 1) * tri), e2 = fabs(hd[(size_t)i] - (double)(i + 1) * 1e-3 * tri) * 1e6;
+        if (e1 > err) err = e1;
+        if (e2 > err) err = e2;
+      }
+    }
+    if (max_err) *max_err = err;
+    return FMX_OK;
+  };
+  rc = body();
+  for (int r = 0; r < n; ++r) {
+    (void)hipSetDevice(r);
+    (void)hipFree(f[(size_t)r]); (void)hipFree(d[(size_t)r]);
+    if (st[(size_t)r]) (void)hipStreamDestroy(st[(size_t)r]);
+    if (comm[(size_t)r]) (void)l->CommDestroy(comm[(size_t)r]);
+  }
+  (void)hipSetDevice(0);
+  return rc;
+}
+
+}  // namespace fmx

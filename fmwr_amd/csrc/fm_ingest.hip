@@ -728,6 +728,7 @@ __global__ void normalize_apply_k(int64_t nnz, const uint32_t* __restrict__ col,
 // the cached inverted indices hold copies of the values: drop them so they are rebuilt from the new values
 static void drop_value_caches(fmx_matrix* m) {
   drop_plans(m);
+  m->value_generation++;
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
   m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
 }

@@ -360,10 +360,11 @@ static int long_args(fmx_engine* e, fmx_matrix* m, int64_t tile, LongArgs* la, C
 
 // run the tiles of one step: every tile accumulates; `finish_local` applies the update after the last tile (single GPU),
 // otherwise the sums (and the partial-sum tail) are left in the exchange buffer for the all-reduce
-static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, bool finish_local) {
+static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, bool finish_local, bool empty_share = false) {
   std::vector<TileRun> tiles;
   int64_t step_rows = 0;
   FMX_TRY(step_tiles(e, m, batch, rows_limit, &tiles, &step_rows));
+  if (empty_share) { tiles.clear(); step_rows = 0; }
   if (tiles.empty()) {
     if (finish_local) return FMX_OK;
     tiles.push_back({m->step_first_tile[(size_t)batch], 0, 0});  // an empty share still has to publish zeros
@@ -521,6 +522,11 @@ static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t row
   return launch_cols_update(e, c, la);
 }
 
+int use_device_public(int device) { return use_device(device); }
+int alloc_matrix_public(int device, int64_t n, uint32_t p, int64_t nnz, bool labels, fmx_matrix** out) { return alloc_matrix(device, n, p, nnz, labels, out); }
+// a replica whose share of a (truncated) step is empty still publishes zeros and its tail
+int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch) { return run_step(e, m, batch, 0, false, true); }
+
 }  // namespace fmx
 
 using namespace fmx;
@@ -546,6 +552,7 @@ int fmx_config_default(fmx_config* cfg) {
   cfg->device = 0;
   cfg->batch_reduce = FMX_REDUCE_MEAN;
   cfg->gamma = 1e-4;                    // R/fm_solver_control.R:134-139
+  cfg->n_gpus = 1;                      // options("FM.threads") defaults to 1 too (R/fm_set_threads.R:19-22)
   return FMX_OK;
 }
 
@@ -562,6 +569,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->num_factor >= 0 && cfg->num_factor <= 128, FMX_ERR_INVALID, "factor.number must be in 0..128 (got %d)", cfg->num_factor);
   FMX_CHECK(cfg->mode == FMX_MODE_SEQUENTIAL || cfg->mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID, "unknown mode %d", cfg->mode);
   FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
+  FMX_CHECK(cfg->n_gpus >= 0, FMX_ERR_INVALID, "n_gpus must be >= 0");
   FMX_CHECK(cfg->batch_reduce == FMX_REDUCE_MEAN || cfg->batch_reduce == FMX_REDUCE_SUM, FMX_ERR_INVALID, "unknown batch_reduce %d", cfg->batch_reduce);
   FMX_CHECK(num_features > 0 && num_features < (1ull << 32), FMX_ERR_INVALID, "number of features must be in 1..2^32-1");
   if (cfg->mode == FMX_MODE_MINIBATCH) FMX_CHECK(cfg->batch_rows >= 1 && cfg->tile_rows >= 0, FMX_ERR_INVALID, "batch_rows must be >= 1 and tile_rows >= 0");
@@ -601,12 +609,14 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
     }
   }
   FMX_HIP(hipDeviceSynchronize());  // the zero fills ran on the null stream; the engine stream does not wait for it
+  if (cfg->n_gpus > 1) FMX_TRY(group_create(e.get()));  // (a failure destroys what was built: the unique_ptr's deleter)
   *out = e.release();
   return FMX_OK;
 }
 
 int fmx_engine_destroy(fmx_engine* e) {
   if (!e) return FMX_OK;
+  group_destroy(e);
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto& pr : e->prof_pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
@@ -663,6 +673,7 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   FMX_TRY(reset_optimizer_state(e));  // learner->init() zeroes q/u (SGD_Learner.h:61-69) and z/n (FTRL_Learner.h:50-55)
   FMX_HIP(hipDeviceSynchronize());
+  if (e->group) FMX_TRY(group_set_params(e, w0, w, v));
   return FMX_OK;
 }
 
@@ -1032,6 +1043,7 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
   FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
   if (examples_done) *examples_done = 0;
   if (max_iter == 0 || m->n == 0) return FMX_OK;
+  if (e->group) return group_train(e, m, max_iter, examples_done);
   if (seq_mode(e)) {
     std::vector<int64_t> order;
     visit_order(m->n, e->cfg.random_step, max_iter, &order);
@@ -1201,6 +1213,7 @@ int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_
   FMX_CHECK(track->step_size > 0, FMX_ERR_INVALID, "step_size must be > 0 (use fmx_train when the tracker is off)");
   FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
   FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  FMX_CHECK(e->group == nullptr, FMX_ERR_STATE, "the tracker runs on one GPU (n_gpus > 1: train with fmx_train, evaluate with fmx_evaluate)");
   FMX_TRY(use_device(e->cfg.device));
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   if (examples_done) *examples_done = 0;
@@ -1525,6 +1538,8 @@ int fmx_mcmc_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double*
   if (m->n == 0 || max_iter == 0) return FMX_OK;
   return launch_mcmc_train(e, m, max_iter, std_gammas, std_normals, state_out);
 }
+
+int fmx_rccl_selftest(int32_t n, double* max_err) { return group_rccl_selftest(n, max_err); }
 
 int fmx_profile_enable(fmx_engine* e, int on) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");

@@ -87,7 +87,7 @@ inline int pad_factor(int k, int vec) {
 
 }  // namespace fmx
 
-namespace fmx { struct MergeWs; }
+namespace fmx { struct MergeWs; struct Group; }
 
 struct fmx_matrix {
   int device = 0;
@@ -133,6 +133,7 @@ struct fmx_matrix {
     int off_in_pool = 0;           // the dense directory is the tile's primary one (part of pool); 0 with off != null: added on demand
   };
   std::vector<TilePlan> plans;   // [n_tiles]
+  uint64_t value_generation = 0; // bumped when the stored values change (scales / normalize): cached copies elsewhere are stale
   uint64_t plan_generation = 0;  // bumped whenever the plans are rebuilt or dropped: engines holding an open step compare it
   int64_t max_long_seg = 0;      // largest n_seg over the tiles (sizes the partial buffer)
   int64_t max_tile_cnt = 0;      // most entries in one tile
@@ -202,6 +203,7 @@ struct fmx_engine {
   uint32_t* crec_count = nullptr;  // device: records written by the last fmx_grad_compact (points into the tile plan)
   int64_t crec_n = 0;              // the same count on the host (the plan builder read it back)
   fmx::MergeWs* merge = nullptr;   // scratch of fmx_apply_compact
+  fmx::Group* group = nullptr;     // cfg.n_gpus > 1: the other replicas and the exchange between them (fm_group.hip)
   void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
   int64_t gbuf_floats = 0;    // its element count
   // Layout of the exchange buffer: blocks of gb_feats features, each block GV[F][kp] | GW[F] | CNT[F] (| QV[F][kp] | QW[F]),
@@ -367,6 +369,16 @@ int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q
                       const double* d_znorm);
 
 int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);
+
+// N GPUs behind one handle (fm_group.hip)
+int group_create(fmx_engine* e);
+void group_destroy(fmx_engine* e);
+int group_set_params(fmx_engine* e, double w0, const double* w, const double* v);
+int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
+int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch);
+int group_rccl_selftest(int n, double* max_err);
+int use_device_public(int device);
+int alloc_matrix_public(int device, int64_t n, uint32_t p, int64_t nnz, bool labels, fmx_matrix** out);
 
 // profiling helpers
 void prof_begin(fmx_engine* e, int kernel);

@@ -99,6 +99,12 @@ typedef struct fmx_config {
   int32_t exchange_chunks; /* 0/1: the exchange buffer is one block.  n > 1: it is laid out in n blocks of consecutive
                               features so that a multi-GPU driver can pipeline the exchange (fmx_grad_begin/_chunk/
                               _apply_chunk): the all-reduce of one block overlaps the gradient sums of the next.   */
+  int32_t n_gpus;          /* 0/1: one GPU.  N > 1 (FMX_MODE_MINIBATCH): fmx_train shards the matrix's rows over the devices
+                              device .. device+N-1, one replica each, and all-reduces the gradient sums between steps with
+                              RCCL -- what the reference's `nthreads` (options("FM.threads"), src/FM.cpp:59,97) becomes
+                              here.  batch_rows stays "rows per step per GPU".  fmx_get_params / fmx_predict use replica 0. */
+  int32_t gpus_share_device; /* 1: all N replicas live on `device` and exchange through a device kernel instead of RCCL
+                              (rehearsals and tests on a one-GPU box; same sums, same order of ranks)                  */
 } fmx_config;
 
 typedef struct fmx_engine fmx_engine; /* parameters + optimizer state on one GPU */
@@ -334,6 +340,9 @@ int fmx_mcmc_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double*
 int fmx_profile_enable(fmx_engine* e, int on);
 int fmx_profile_get(fmx_engine* e, int kernel, double* total_ms, int64_t* launches);
 int fmx_profile_reset(fmx_engine* e);
+/* RCCL smoke test for cfg.n_gpus > 1: loads librccl, ncclCommInitAll over devices 0..n-1, one grouped fp32 and fp64
+ * all-reduce(sum) of 1000 elements per rank on per-device streams, checked against the closed form; max_err = largest deviation. */
+int fmx_rccl_selftest(int32_t n, double* max_err);
 /* What the memory system gives the hot kernels' access pattern and nothing else: uniformly random rows of row_bytes bytes
  * (16..256, a power of two) from a table of table_bytes bytes; ids are generated in registers, row_bytes / 16 lanes fetch a row,
  * in_flight (4 or 8) rows outstanding per lane, n_groups lane groups each summing per_group rows, `reps` launches timed with

