@@ -535,6 +535,15 @@ extern "C" {
 
 const char* fmx_last_error(void) { return g_error.c_str(); }
 
+int fmx_device_count(int32_t* count) {
+  FMX_CHECK(count != nullptr, FMX_ERR_INVALID, "count is NULL");
+  int c = 0;
+  const hipError_t err = hipGetDeviceCount(&c);
+  *count = (err == hipSuccess) ? c : 0;
+  if (err != hipSuccess || c <= 0) { set_error("no HIP device available (%s); libfmx has no CPU fallback", err == hipSuccess ? "device count 0" : hipGetErrorString(err)); return FMX_ERR_NOGPU; }
+  return FMX_OK;
+}
+
 int fmx_config_default(fmx_config* cfg) {
   FMX_CHECK(cfg != nullptr, FMX_ERR_INVALID, "cfg is NULL");
   memset(cfg, 0, sizeof(*cfg));
@@ -942,6 +951,15 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
   m->rows_sorted = 1;
   m->max_row_len = z;
   *out = m;
+  return FMX_OK;
+}
+
+int fmx_matrix_set_labels(fmx_matrix* m, const float* y) {
+  FMX_CHECK(m != nullptr && (y != nullptr || m->n == 0), FMX_ERR_INVALID, "NULL argument");
+  FMX_TRY(use_device(m->device));
+  if (m->n > 0) FMX_HIP(hipMemcpy(m->y, y, (size_t)m->n * sizeof(float), hipMemcpyHostToDevice));
+  m->has_labels = 1;
+  m->value_generation++;
   return FMX_OK;
 }
 

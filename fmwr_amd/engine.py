@@ -79,6 +79,12 @@ class Matrix:
         L.check(L.lib().fmx_matrix_synthetic_fields(C.c_int(device), C.c_int64(n), C.byref(spec), C.c_int64(row_offset), C.byref(h)))
         return cls._wrap(h)
 
+    def set_labels(self, y):
+        y = np.ascontiguousarray(y, np.float32)
+        if len(y) != self.n:
+            raise ValueError("target's length is not equal the number of cases...")
+        L.check(L.lib().fmx_matrix_set_labels(self.h, _p(y)))
+
     def scales(self, norm_columns):
         """SMatrix::scales: z-score the listed columns in place; returns (mean[p], std[p])."""
         nc = np.ascontiguousarray(norm_columns, np.int32)

@@ -113,6 +113,9 @@ typedef struct fmx_matrix fmx_matrix; /* a device-resident fm.matrix (CSR + labe
 /* Message of the last failing call on this thread ("" if none). */
 const char* fmx_last_error(void);
 
+/* Number of HIP devices this process sees (what cfg.n_gpus may count up to); FMX_ERR_NOGPU without one. */
+int fmx_device_count(int32_t* count);
+
 /* Fill *cfg with the reference's defaults (R/fm_control.R:52-66, R/fm_solver_control.R:91-115). */
 int fmx_config_default(fmx_config* cfg);
 
@@ -176,6 +179,8 @@ typedef struct fmx_fields_spec {
   uint64_t seed;
 } fmx_fields_spec;
 int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* spec, int64_t row_offset, fmx_matrix** out);
+/* Replace the labels of a device-resident matrix (y: f32[n] on the host): e.g. labels planted from a known model. */
+int fmx_matrix_set_labels(fmx_matrix* m, const float* y);
 int fmx_matrix_destroy(fmx_matrix* m);
 int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz);
 /* Copy rows [r0, r1) back to the host (row_ptr is rebased to 0); any pointer may be NULL. */

@@ -81,9 +81,10 @@ def test_rccl_loads_and_all_reduces_on_the_visible_devices():
     """librccl is resolved with dlopen on first use: the entry points, the enum values for sum / fp32 / fp64 and the grouped
     per-device-stream call pattern of fm_group.hip against a closed form.  One device here (the collective is then a copy);
     the driver's 8-GPU node runs the same code with n = 8."""
-    import torch
     from fmwr_amd import _lib as L
-    n = max(1, min(torch.cuda.device_count(), 8))
+    cnt = C.c_int32()
+    L.check(L.lib().fmx_device_count(C.byref(cnt)))   # (no torch here: importing it AFTER libfmx.so would bring a second HIP runtime)
+    n = max(1, min(cnt.value, 8))
     err = C.c_double(-1.0)
     L.check(L.lib().fmx_rccl_selftest(C.c_int32(n), C.byref(err)))
     assert 0.0 <= err.value < 1e-3
