@@ -114,11 +114,71 @@ __device__ __forceinline__ double link_apply(const Hyper& h, double y_hat, int l
 
 // coalesced copy of `cnt` (id, x) entries starting at absolute offset c0 into LDS
 __device__ __forceinline__ void stage_entries(uint2* stage, const uint32_t* __restrict__ ids,
-                                              const float* __restrict__ xs, int64_t c0, int cnt) {
+                                              const float* __restrict__ xs, int64_t c0, int cnt, int unit) {
   // (non-temporal loads for these read-once streams were tried: phase 1 1.7 % slower, the forward-only pass 2 % faster)
-  for (int i = threadIdx.x; i < cnt; i += WG_THREADS)
-    stage[i] = make_uint2(ids[c0 + i], __float_as_uint(xs[c0 + i]));
+  if (unit) {  // one-hot data: half the stream
+    for (int i = threadIdx.x; i < cnt; i += WG_THREADS) stage[i] = make_uint2(ids[c0 + i], 0x3f800000u);
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += WG_THREADS) stage[i] = make_uint2(ids[c0 + i], __float_as_uint(xs[c0 + i]));
+  }
 }
+
+// ---- the gradient multiplier travels INSIDE the S row (fp32 tables) ------------------------------------------------------
+// Phase 2 needs, per entry, the row's factor sums (an S row: one request) and the row's multiplier (4 bytes from a side table:
+// a second request, measured at 11 % of phase 2).  The multiplier is therefore folded into the S row itself:
+//   EMBED_PAD  (k < kp): the row has padding slots; slot kp - 1 carries the multiplier as is.
+//   EMBED_BITS (k == kp >= 16): its 32 bits replace the lowest mantissa bit(s) of the row's floats -- 2 bits of each of 16
+//              floats, 1 bit of each of 32 (for kp = 64: of the first 32) -- after rounding the float to that width; S is an
+//              intermediate of the step, the factor sums keep 22 or 23 mantissa bits (relative 2.4e-7 / 1.2e-7, against the
+//              1e-5 the fp32 state is held to), the multiplier keeps all of its bits.
+// The side table is still written (long lists and the fp64 tables read it).
+enum EmbedMode : int { EMBED_NONE = 0, EMBED_PAD = 1, EMBED_BITS = 2 };
+__host__ __device__ inline int embed_mode(int k, int kp, bool fp32) { return !fp32 ? EMBED_NONE : (k < kp ? EMBED_PAD : (kp >= 16 ? EMBED_BITS : EMBED_NONE)); }
+
+template <int LPR>
+__device__ __forceinline__ float4 embed_store(float4 v, int lig, float mult, int mode) {
+  constexpr int KP = LPR * 4;
+  if (mode == EMBED_PAD) {
+    if (lig == LPR - 1) v.w = mult;
+  } else if (mode == EMBED_BITS) {
+    constexpr int B = KP == 16 ? 2 : 1;              // bits per float
+    constexpr uint32_t MASK = (1u << B) - 1u, HALF = 1u << (B - 1);
+    if (KP < 64 || lig < 8) {
+      const uint32_t m = __float_as_uint(mult);
+      const int p0 = B * (lig * 4);
+      uint32_t u;
+      u = ((__float_as_uint(v.x) + HALF) & ~MASK) | ((m >> (p0)) & MASK); v.x = __uint_as_float(u);
+      u = ((__float_as_uint(v.y) + HALF) & ~MASK) | ((m >> (p0 + B)) & MASK); v.y = __uint_as_float(u);
+      u = ((__float_as_uint(v.z) + HALF) & ~MASK) | ((m >> (p0 + 2 * B)) & MASK); v.z = __uint_as_float(u);
+      u = ((__float_as_uint(v.w) + HALF) & ~MASK) | ((m >> (p0 + 3 * B)) & MASK); v.w = __uint_as_float(u);
+    }
+  }
+  return v;
+}
+
+// the inverse, on a gathered slice: returns the multiplier to every lane of the group and leaves the pure factor sums in v
+template <int LPR>
+__device__ __forceinline__ float embed_take(float4& v, int lig, int mode) {
+  constexpr int KP = LPR * 4;
+  if (mode == EMBED_PAD) {
+    const float m = __shfl(v.w, (int)(threadIdx.x & 63) - lig + (LPR - 1));
+    if (lig == LPR - 1) v.w = 0.f;
+    return m;
+  }
+  constexpr int B = KP == 16 ? 2 : 1;
+  constexpr uint32_t MASK = (1u << B) - 1u;
+  uint32_t part = 0;
+  if (KP < 64 || lig < 8) {
+    const int p0 = B * (lig * 4);
+    const uint32_t ux = __float_as_uint(v.x), uy = __float_as_uint(v.y), uz = __float_as_uint(v.z), uw = __float_as_uint(v.w);
+    part = ((ux & MASK) << p0) | ((uy & MASK) << (p0 + B)) | ((uz & MASK) << (p0 + 2 * B)) | ((uw & MASK) << (p0 + 3 * B));
+    v.x = __uint_as_float(ux & ~MASK); v.y = __uint_as_float(uy & ~MASK); v.z = __uint_as_float(uz & ~MASK); v.w = __uint_as_float(uw & ~MASK);
+  }
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) part |= (uint32_t)__shfl_xor((int)part, off);
+  return __uint_as_float(part);
+}
+__device__ __forceinline__ double embed_take_none(double2&, int, int) { return 0.0; }
 
 // ------------------------------------------------------------------------------------------------ phase 1
 template <typename T, int LPR, bool TRAIN>
@@ -155,7 +215,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
 
   for (int64_t c0 = lo; c0 < hi; c0 += STAGE_ENTRIES) {
     const int cnt = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
-    stage_entries(stage, a.col, a.val, c0, cnt);
+    stage_entries(stage, a.col, a.val, c0, cnt, a.unit);
     __syncthreads();
     const int64_t b = ta > c0 ? ta : c0;
     const int64_t e = tb < c0 + cnt ? tb : c0 + cnt;
@@ -200,7 +260,9 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
     double mult = 0.0;
     if (have) {
       mult = grad_mult(h, y_hat, a.y[a.r0 + row]);
-      *reinterpret_cast<vec_t*>(reinterpret_cast<T*>(a.S) + (size_t)row * KP + lig * VEC) = slice_make(s, T());
+      vec_t srow = slice_make(s, T());
+      if constexpr (sizeof(T) == 4) srow = embed_store<LPR>(srow, lig, (float)mult, a.embed);  // the multiplier rides in the S row
+      *reinterpret_cast<vec_t*>(reinterpret_cast<T*>(a.S) + (size_t)row * KP + lig * VEC) = srow;
       if (lig == 0) reinterpret_cast<T*>(a.amul)[row] = (T)mult;
     }
     if (lig == 0) red[gid] = mult;
@@ -240,7 +302,10 @@ static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
   return FMX_OK;
 }
 
-int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables) {
+int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp64_tables) {
+  RowsArgs a = a_in;
+  static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
+  a.embed = (train && embed_ok) ? embed_mode(e->k, fp64_tables ? e->kp64 : e->kp32, !fp64_tables) : EMBED_NONE;  // the same rule as launch_cols_update
   prof_begin(e, FMX_KERNEL_ROWS_FORWARD);
   int st = FMX_OK;
   if (train) {
@@ -675,7 +740,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
       const int64_t b = ta > c0 ? ta : c0;
       const int64_t e = tb < c0 + cn ? tb : c0 + cn;
-      stage_entries(stage, a.brow, a.bval, c0, cn);
+      stage_entries(stage, a.brow, a.bval, c0, cn, a.unit);
       __syncthreads();
       for (int64_t t = b; t < e; t += FMX_U) {
         const int o = (int)(t - c0);
@@ -691,15 +756,27 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
         ST av[FMX_U];
         if (a.buf_gather) {  // wave-uniform: padding slots issue no request
 #pragma unroll
-          for (int u = 0; u < FMX_U; ++u) {
-            sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
-            av[u] = buf_elem(a_rsrc, ok[u] ? en[u].x * (uint32_t)sizeof(ST) : BUF_SKIP, ST());
+          for (int u = 0; u < FMX_U; ++u) sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
+          if (a.embed) {
+            if constexpr (sizeof(ST) == 4) {
+#pragma unroll
+              for (int u = 0; u < FMX_U; ++u) av[u] = embed_take<LPR>(sv[u], lig, a.embed);
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < FMX_U; ++u) av[u] = buf_elem(a_rsrc, ok[u] ? en[u].x * (uint32_t)sizeof(ST) : BUF_SKIP, ST());
           }
         } else {
 #pragma unroll
           for (int u = 0; u < FMX_U; ++u) {
             sv[u] = gather_row(St + (size_t)en[u].x * KP);
             av[u] = T.amul[en[u].x];
+          }
+          if constexpr (sizeof(ST) == 4) {
+            if (a.embed) {
+#pragma unroll
+              for (int u = 0; u < FMX_U; ++u) (void)embed_take<LPR>(sv[u], lig, a.embed);  // strip the embedded bits; the side table gave the multiplier
+            }
           }
         }
 #pragma unroll
@@ -754,7 +831,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
       const int64_t tt = t + (int64_t)u * NSUB;
       const bool in = tt < tb;
       r[u] = in ? a.brow[tt] : 0xFFFFFFFFu;
-      x[u] = in ? a.bval[tt] : 0.f;
+      x[u] = in ? (a.unit ? 1.0f : a.bval[tt]) : 0.f;
       ok[u] = r[u] < a.rows_active;
       if (!ok[u]) r[u] = 0;
     }
@@ -764,6 +841,12 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
     for (int u = 0; u < FMX_U; ++u) {
       sv[u] = gather_row(St + (size_t)r[u] * KP);
       av[u] = T.amul[r[u]];
+    }
+    if constexpr (sizeof(ST) == 4) {
+      if (a.embed) {
+#pragma unroll
+        for (int u = 0; u < FMX_U; ++u) (void)embed_take<LPR>(sv[u], lig, a.embed);
+      }
     }
 #pragma unroll
     for (int u = 0; u < FMX_U; ++u)
@@ -906,6 +989,8 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
   // gathers of S rows / multipliers go through bounds-checked buffer descriptors while the workspace stays below 2 GiB
   // (FMX_BUF_GATHER=0 in the environment switches back to flat loads: tuning only)
   static const bool buf_ok = [] { const char* v = getenv("FMX_BUF_GATHER"); return !(v && v[0] == '0'); }();
+  static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
+  a.embed = embed_ok ? embed_mode(e->k, mb_kp(e), !mb_wide(e)) : EMBED_NONE;
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;

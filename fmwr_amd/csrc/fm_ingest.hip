@@ -579,6 +579,7 @@ int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offs
   FMX_HIP(hipDeviceSynchronize());
   m->rows_sorted = 1;  // strata are disjoint and ascending
   m->max_row_len = z;
+  { const char* v = getenv("FMX_UNIT_VALUES"); m->unit_values = !(v && v[0] == '0'); }  // the generator writes 1.0f everywhere
   return FMX_OK;
 }
 
@@ -752,7 +753,7 @@ int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double
   FMX_HIP(hipMemcpy(h_std, d_std, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
   (void)hipFree(d_mean); (void)hipFree(d_std); (void)hipFree(d_listed);
   drop_value_caches(m);
-  return FMX_OK;
+  return check_rows_sorted(m);  // the values changed: is the matrix still one-hot?
 }
 
 int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std) {
@@ -767,30 +768,38 @@ int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std) {
   FMX_HIP(hipDeviceSynchronize());
   (void)hipFree(d_mean); (void)hipFree(d_std);
   drop_value_caches(m);
-  return FMX_OK;
+  return check_rows_sorted(m);
 }
 
 // ------------------------------------------------------------------------------------------------ sortedness
-__global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int* __restrict__ out) {
+__global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t n,
+                              int* __restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  int bad = 0;
-  for (int64_t t = row_ptr[r]; t + 1 < row_ptr[r + 1]; ++t) bad |= (col[t] >= col[t + 1]);
+  int bad = 0, other = 0;
+  for (int64_t t = row_ptr[r]; t < row_ptr[r + 1]; ++t) {
+    if (t + 1 < row_ptr[r + 1]) bad |= (col[t] >= col[t + 1]);
+    other |= (val[t] != 1.0f);
+  }
   if (bad) out[0] = 1;
+  if (other) out[2] = 1;
   const int64_t len = row_ptr[r + 1] - row_ptr[r];
   atomicMax(out + 1, (int)(len > 0x7fffffff ? 0x7fffffff : len));  // longest row
 }
 
 int check_rows_sorted(fmx_matrix* m) {
   int* d = nullptr;
-  int h[2] = {0, 0};
-  FMX_HIP(hipMalloc(&d, 2 * sizeof(int)));
-  FMX_HIP(hipMemset(d, 0, 2 * sizeof(int)));
-  if (m->n > 0) hipLaunchKernelGGL(rows_sorted_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->n, d);
-  FMX_HIP(hipMemcpy(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost));
+  int h[3] = {0, 0, 0};
+  FMX_HIP(hipMalloc(&d, 3 * sizeof(int)));
+  FMX_HIP(hipMemset(d, 0, 3 * sizeof(int)));
+  if (m->n > 0) hipLaunchKernelGGL(rows_sorted_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->val, m->n, d);
+  FMX_HIP(hipMemcpy(h, d, 3 * sizeof(int), hipMemcpyDeviceToHost));
   FMX_HIP(hipFree(d));
   m->rows_sorted = !h[0];
   m->max_row_len = h[1];
+  // FMX_UNIT_VALUES=0 in the environment keeps the general path (tuning / A-B runs only)
+  static const bool allow = [] { const char* v = getenv("FMX_UNIT_VALUES"); return !(v && v[0] == '0'); }();
+  m->unit_values = (allow && !h[2]) ? 1 : 0;
   return FMX_OK;
 }
 

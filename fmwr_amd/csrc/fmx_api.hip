@@ -245,6 +245,7 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
   a.yhat = d_out;
   a.link = link;
   a.pn_y = e->probit;
+  a.unit = m->unit_values;
   FMX_TRY(launch_rows_forward(e, a, false, wide_state(e)));
   return FMX_OK;
 }
@@ -318,6 +319,7 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t pa
   a.S = (char*)e->S + (size_t)s_row0 * mb_kp(e) * mb_elem(e);
   a.amul = (char*)e->amul + (size_t)s_row0 * mb_elem(e);
   a.partials = e->partials + 2 * partial_offset;
+  a.unit = m->unit_values;
   const int rpw = WG_THREADS / mb_lpr(e);
   *n_partials = (t.nrows + rpw - 1) / rpw;
   return launch_rows_forward(e, a, true, mb_wide(e));
@@ -332,6 +334,7 @@ static int cols_args(fmx_engine* e, fmx_matrix* m, const TileRun& t, bool sparse
   c.bval = m->bval + pl.base;
   c.rows_active = (uint32_t)t.nrows;
   c.walk = 1;
+  c.unit = m->unit_values;
   if (pl.feat && sparse_ok) {
     c.tfeat = pl.feat; c.toff = pl.soff; c.n_tfeat = pl.n_lists;
   } else {
@@ -1132,6 +1135,7 @@ int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per
   for (auto& s : C.slot) {
     FMX_TRY(alloc_matrix(e->cfg.device, B, (uint32_t)p, cap_cnt, true, &s.m));
     s.m->rows_sorted = 1; s.m->max_row_len = z;
+    s.m->unit_values = spec ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
     FMX_HIP(hipMalloc(&s.m->brow, (size_t)cap_cnt * sizeof(uint32_t)));
     FMX_HIP(hipMalloc(&s.m->bval, (size_t)cap_cnt * sizeof(float)));
     s.m->plans.resize(1);

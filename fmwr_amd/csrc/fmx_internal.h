@@ -100,6 +100,7 @@ struct fmx_matrix {
   float* y = nullptr;          // [n] or null
   int has_labels = 0;
   int rows_sorted = 0;  // every row strictly ascending in col (=> no duplicate column inside a row)
+  int unit_values = 0;  // every stored value is exactly 1.0f (one-hot data): the kernels then never read the value arrays
   int max_row_len = 0;  // entries of the longest row
   // Per-tile inverted index ("plan"), built lazily on the device for one (batch_rows, tile_rows) pair (fm_ingest.hip).
   // A step covers batch_rows consecutive rows and is cut into tiles of at most tile_rows rows.
@@ -260,6 +261,8 @@ struct RowsArgs {
   double* qout;         // [nrows][kp64] (predict, fp64 tables) per-row factor sums, or null
   const double* pn_y;   // fast_pnorm table (FMX_LINK_PROBIT)
   int link;
+  int unit;             // every value is 1.0f: a.val is not read
+  int embed;            // EmbedMode: how the multiplier is folded into the S row (set by the launcher)
 };
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
 int ensure_probit(fmx_engine* e);  // builds and uploads the probit tables (fm_probit.h) on first use
@@ -288,6 +291,8 @@ struct ColsArgs {
   int64_t s_row0;        // row of the S / multiplier workspace where this tile's rows start (0 unless a whole step is resident)
   int store_compact;     // compact exchange: write one record per occurring feature (sparse walk only)
   int compact_tail;      // the scalar tail is the compact exchange's own 4 elements, not the end of the dense buffer
+  int unit;              // every value of the tile is 1.0f: bval is not read
+  int embed;             // EmbedMode of the S rows (set by the launcher; must match phase 1's)
   int buf_gather;        // set by the launcher: S rows / multipliers are gathered through buffer descriptors (padding slots issue no request)
 };
 // long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
