@@ -133,7 +133,13 @@ __device__ __forceinline__ void stage_entries(uint2* stage, const uint32_t* __re
 //              1e-5 the fp32 state is held to), the multiplier keeps all of its bits.
 // The side table is still written (long lists and the fp64 tables read it).
 enum EmbedMode : int { EMBED_NONE = 0, EMBED_PAD = 1, EMBED_BITS = 2 };
-__host__ __device__ inline int embed_mode(int k, int kp, bool fp32) { return !fp32 ? EMBED_NONE : (k < kp ? EMBED_PAD : (kp >= 16 ? EMBED_BITS : EMBED_NONE)); }
+// (kp = 64: measured SLOWER -- 0.95 against 0.76 ms per tile for FTRL k = 64: a 256-byte row is four sectors, the side request is
+// a fifth of the traffic instead of half, and the bits have to be collected over 16 lanes; FMX_EMBED_MAX_KP overrides for A/B runs)
+inline int embed_max_kp() { static const int v = [] { const char* s = getenv("FMX_EMBED_MAX_KP"); return s ? atoi(s) : 32; }(); return v; }
+inline int embed_mode(int k, int kp, bool fp32) {
+  if (!fp32 || kp > embed_max_kp()) return EMBED_NONE;
+  return k < kp ? EMBED_PAD : (kp >= 16 ? EMBED_BITS : EMBED_NONE);
+}
 
 template <int LPR>
 __device__ __forceinline__ float4 embed_store(float4 v, int lig, float mult, int mode) {
