@@ -15,16 +15,17 @@ SOLVER_MCMC, SOLVER_ALS, SOLVER_SGD, SOLVER_FTRL, SOLVER_TDAP = 100, 200, 300, 5
 MODE_SEQUENTIAL, MODE_MINIBATCH = 0, 1
 LINK_NONE, LINK_LOGISTIC, LINK_CLAMP, LINK_PROBIT = 0, 1, 2, 3
 REDUCE_MEAN, REDUCE_SUM = 0, 1
+COLUMNS_UNIFORM, COLUMNS_ZIPF = 1, 2
 EVAL_LL, EVAL_AUC, EVAL_ACC, EVAL_RMSE, EVAL_MSE, EVAL_MAE = 0, 111, 222, 333, 444, 555
 KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3
 
 # every symbol include/fmx.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
     "fmx_last_error", "fmx_device_count", "fmx_config_default", "fmx_engine_create", "fmx_engine_destroy", "fmx_set_params",
-    "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_synthetic_fields", "fmx_train_stream", "fmx_matrix_set_labels", "fmx_matrix_destroy",
+    "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_synthetic_fields", "fmx_matrix_synthetic_iid", "fmx_train_stream", "fmx_matrix_set_labels", "fmx_matrix_destroy",
     "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
     "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_grad_elem_bytes", "fmx_grad_layout", "fmx_grad_begin", "fmx_grad_chunk", "fmx_apply_chunk", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
-    "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_mcmc_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
+    "fmx_als_plan_info", "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_mcmc_train", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset", "fmx_measure_gather", "fmx_measure_gather_occ", "fmx_rccl_selftest",
     "fmx_get_rows", "fmx_set_rows", "fmx_init_normal", "fmx_compact_info", "fmx_compact_count", "fmx_compact_reserve", "fmx_grad_compact", "fmx_compact_records", "fmx_apply_compact",
 ]

@@ -240,15 +240,21 @@ static int build_plan(fmx_matrix* m, hipStream_t stream) {
   FMX_HIP(hipMalloc(&d_level, (size_t)p * sizeof(int)));
   FMX_HIP(hipMalloc(&d_changed, sizeof(int)));
   FMX_HIP(hipMemsetAsync(d_level, 0, (size_t)p * sizeof(int), stream));
-  int rounds = 0;
+  // monotone relaxation to the fixed point; every sweep propagates along whole rows, so the count of sweeps is far below
+  // the number of levels.  The "changed" flag is read back once per CHECK sweeps (a host round trip per sweep would cost more
+  // than the sweep on matrices with deep level chains: i.i.d. or Zipf columns instead of one column per field).
+  const int CHECK = 8;
+  int64_t sweeps = 0;
   for (;;) {
     int h = 0;
     FMX_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
-    if (m->n > 0) hipLaunchKernelGGL(level_relax_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->n, d_level, d_changed);
+    for (int q = 0; q < CHECK; ++q)
+      if (m->n > 0) hipLaunchKernelGGL(level_relax_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->n, d_level, d_changed);
     FMX_HIP(hipMemcpyAsync(&h, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
     FMX_HIP(hipStreamSynchronize(stream));
     if (!h) break;
-    FMX_CHECK(++rounds <= (int64_t)p + 1, FMX_ERR_STATE, "level scheduling did not converge");
+    sweeps += CHECK;
+    FMX_CHECK(sweeps <= (int64_t)p + CHECK, FMX_ERR_STATE, "level scheduling did not converge");
   }
   std::vector<int> level(p);
   FMX_HIP(hipMemcpy(level.data(), d_level, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));
@@ -301,6 +307,17 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
 // (e = y_hat - y, or the probit-table ratio for CLASSIFICATION, :520-562), the w0
 // update, the w sweep; with_v adds the V sweep the shipped update_all leaves out (SURVEY A-1).  init() fixes alpha = 1,
 // w0_mean_0 = 0 and all lambda / mu = 0 (A-7), so the R-side solver parameters do not enter.
+int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest) {
+  FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
+  FMX_TRY(build_plan(m, e->stream));
+  const int64_t L = (int64_t)m->als_level_ptr.size() - 1;
+  int64_t big = 0;
+  for (int64_t l = 0; l < L; ++l) { const int64_t c = m->als_level_ptr[(size_t)l + 1] - m->als_level_ptr[(size_t)l]; if (c > big) big = c; }
+  if (levels) *levels = L;
+  if (largest) *largest = big;
+  return FMX_OK;
+}
+
 int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
   const double* dp_y = nullptr;

@@ -133,9 +133,10 @@ __device__ __forceinline__ void stage_entries(uint2* stage, const uint32_t* __re
 //              1e-5 the fp32 state is held to), the multiplier keeps all of its bits.
 // The side table is still written (long lists and the fp64 tables read it).
 enum EmbedMode : int { EMBED_NONE = 0, EMBED_PAD = 1, EMBED_BITS = 2 };
-// (kp = 64: measured SLOWER -- 0.95 against 0.76 ms per tile for FTRL k = 64: a 256-byte row is four sectors, the side request is
-// a fifth of the traffic instead of half, and the bits have to be collected over 16 lanes; FMX_EMBED_MAX_KP overrides for A/B runs)
-inline int embed_max_kp() { static const int v = [] { const char* s = getenv("FMX_EMBED_MAX_KP"); return s ? atoi(s) : 32; }(); return v; }
+// Measured (profiles/r02_embed_ab.txt): kp = 16 phase 2 0.1633 -> 0.1583 ms per tile; kp = 32 0.231 -> 0.281 and kp = 64 0.750 -> 0.895
+// (SLOWER: a 128- or 256-byte row is two to four sectors, the side request a third to a fifth of the traffic instead of half, and the
+// bits have to be collected over 8 or 16 lanes).  So: rows of 64 bytes only; FMX_EMBED_MAX_KP overrides for A/B runs.
+inline int embed_max_kp() { static const int v = [] { const char* s = getenv("FMX_EMBED_MAX_KP"); return s ? atoi(s) : 16; }(); return v; }
 inline int embed_mode(int k, int kp, bool fp32) {
   if (!fp32 || kp > embed_max_kp()) return EMBED_NONE;
   return k < kp ? EMBED_PAD : (kp >= 16 ? EMBED_BITS : EMBED_NONE);

@@ -583,6 +583,47 @@ int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offs
   return FMX_OK;
 }
 
+// SURVEY 8(d)'s other column laws: nnz columns drawn i.i.d. over [0, p) -- uniform (kind 1), or Zipf-like with exponent s (kind 2:
+// rank = ((p^(1-s) - 1) u + 1)^(1/(1-s)) - 1, the inverse CDF of the continuous power law on [1, p]; "s = 1.05 for conflict
+// stress") -- then sorted inside the row; a repeated column is bumped to the next free id so that rows stay strictly
+// ascending (what a dgCMatrix row is).  One thread per row (z <= 64), Philox keyed by (seed; global row, entry / 4).
+constexpr int SYNTH_MAX_Z = 64;
+__global__ void synth_iid_rows_k(int64_t n, uint32_t p, int32_t z, uint64_t seed, int64_t row_offset, int kind, double s_exp, uint32_t* __restrict__ col,
+                                 float* __restrict__ val) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t g = (uint64_t)(row_offset + r);
+  uint32_t c[SYNTH_MAX_Z];
+  const double a = 1.0 - s_exp, top = pow((double)p, a) - 1.0;
+  for (int i = 0; i < z; i += 4) {
+    const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(i >> 2), 0x11Du, (uint32_t)seed, (uint32_t)(seed >> 32));
+    for (int q = 0; q < 4 && i + q < z; ++q) {
+      const double u = (double)ph.c[q] / 4294967296.0;
+      double x;
+      if (kind == 1) x = u * (double)p;
+      else x = pow(top * u + 1.0, 1.0 / a) - 1.0;
+      uint32_t id = (uint32_t)x;
+      if (id >= p) id = p - 1;
+      // insertion into the sorted prefix
+      int j = i + q;
+      while (j > 0 && c[j - 1] > id) { c[j] = c[j - 1]; --j; }
+      c[j] = id;
+    }
+  }
+  // strictly ascending: bump repeats upwards, then pull an overflow at the top back down
+  for (int i = 1; i < z; ++i) if (c[i] <= c[i - 1]) c[i] = c[i - 1] + 1;
+  if (c[z - 1] >= p) { c[z - 1] = p - 1; for (int i = z - 2; i >= 0 && c[i] >= c[i + 1]; --i) c[i] = c[i + 1] - 1; }
+  for (int i = 0; i < z; ++i) { col[r * z + i] = c[i]; val[r * z + i] = 1.0f; }
+}
+
+int generate_iid_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, int kind, double s_exp, hipStream_t stream) {
+  const int T = 128;
+  if (n > 0) hipLaunchKernelGGL(synth_iid_rows_k, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, stream, n, m->p, z, seed, row_offset, kind, s_exp, m->col, m->val);
+  hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, n, z, seed, row_offset, m->row_ptr, m->y);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
 // Criteo-shaped rows (SURVEY 8(d), configs[3]: "13 dense-ish + 26 categorical"): entry i < n_dense is feature i with a value
 // in [0, 1); entry n_dense + f is one feature of categorical field f, whose ids occupy [base[f], base[f] + vocab[f]): the id
 // inside the field is floor(vocab * u^skew), u uniform -- skew = 1 is uniform, larger values pile the mass on a field's first

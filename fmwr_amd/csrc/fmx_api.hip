@@ -957,6 +957,24 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
   return FMX_OK;
 }
 
+int fmx_matrix_synthetic_iid(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int32_t law, double zipf_s,
+                             fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(n >= 0 && nnz_per_row >= 1 && nnz_per_row <= 64 && (uint32_t)nnz_per_row <= p, FMX_ERR_INVALID, "need 1 <= nnz_per_row <= min(64, p)");
+  FMX_CHECK(law == FMX_COLUMNS_UNIFORM || (law == FMX_COLUMNS_ZIPF && zipf_s > 1.0), FMX_ERR_INVALID, "law must be FMX_COLUMNS_UNIFORM, or FMX_COLUMNS_ZIPF with zipf_s > 1");
+  fmx_matrix* m = nullptr;
+  FMX_TRY(alloc_matrix(device, n, p, n * nnz_per_row, true, &m));
+  int st = generate_iid_async(m, n, nnz_per_row, seed, row_offset, law, zipf_s, nullptr);
+  if (st == FMX_OK && hipDeviceSynchronize() != hipSuccess) { set_error("generator failed"); st = FMX_ERR_HIP; }
+  if (st != FMX_OK) { free_matrix(m); return st; }
+  m->rows_sorted = 1;
+  m->max_row_len = nnz_per_row;
+  { const char* v = getenv("FMX_UNIT_VALUES"); m->unit_values = !(v && v[0] == '0'); }
+  *out = m;
+  return FMX_OK;
+}
+
 int fmx_matrix_set_labels(fmx_matrix* m, const float* y) {
   FMX_CHECK(m != nullptr && (y != nullptr || m->n == 0), FMX_ERR_INVALID, "NULL argument");
   FMX_TRY(use_device(m->device));
@@ -1538,6 +1556,12 @@ int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, c
                     const double* std_normals) {
   FMX_CHECK(std_normals != nullptr, FMX_ERR_INVALID, "std_normals is NULL (use fmx_als_vsweep for the ALS form)");
   return vsweep_impl(e, m, error, alpha, v_lambda, v_mu, std_normals);
+}
+
+int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level) {
+  FMX_TRY(check_pair(e, m));
+  FMX_TRY(use_device(e->cfg.device));
+  return als_plan_info(e, m, levels, largest_level);
 }
 
 int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v) {

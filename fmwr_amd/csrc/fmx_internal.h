@@ -355,6 +355,7 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream);
+int generate_iid_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, int kind, double s_exp, hipStream_t stream);
 constexpr int FMX_MAX_FIELDS = 64;
 struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)
   int n_dense, n_fields;
@@ -369,6 +370,7 @@ int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double
 int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std);
 
 int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v);
+int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest);
 int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state);
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu,
                       const double* d_znorm);

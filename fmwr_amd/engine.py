@@ -72,6 +72,14 @@ class Matrix:
         return cls._wrap(h)
 
     @classmethod
+    def synthetic_iid(cls, n, p, nnz_per_row, seed, law=L.COLUMNS_UNIFORM, zipf_s=1.05, row_offset=0, device=0):
+        """i.i.d. columns (uniform or Zipf), sorted inside the row (fmx_matrix_synthetic_iid)."""
+        h = C.c_void_p()
+        L.check(L.lib().fmx_matrix_synthetic_iid(C.c_int(device), C.c_int64(n), C.c_uint32(p), C.c_int32(nnz_per_row), C.c_uint64(seed), C.c_int64(row_offset),
+                                                 C.c_int32(law), C.c_double(zipf_s), C.byref(h)))
+        return cls._wrap(h)
+
+    @classmethod
     def synthetic_fields(cls, n, n_dense, field_vocab, skew, seed, row_offset=0, device=0):
         """Criteo-shaped rows: n_dense always-present features + one feature of each categorical field (fmx_matrix_synthetic_fields)."""
         spec, keep = fields_spec(n_dense, field_vocab, skew, seed)

@@ -181,6 +181,13 @@ typedef struct fmx_fields_spec {
 int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* spec, int64_t row_offset, fmx_matrix** out);
 /* Replace the labels of a device-resident matrix (y: f32[n] on the host): e.g. labels planted from a known model. */
 int fmx_matrix_set_labels(fmx_matrix* m, const float* y);
+/* SURVEY 8(d)'s other column laws (fmx_matrix_synthetic draws one column per stratum of [0, p)): nnz_per_row (<= 64) columns
+ * i.i.d. over [0, p), sorted inside the row, repeats bumped to the next id.  law = FMX_COLUMNS_UNIFORM, or FMX_COLUMNS_ZIPF with
+ * exponent `zipf_s` > 1 (1.05: a few features occur in most rows). */
+#define FMX_COLUMNS_UNIFORM 1
+#define FMX_COLUMNS_ZIPF 2
+int fmx_matrix_synthetic_iid(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int32_t law,
+                             double zipf_s, fmx_matrix** out);
 int fmx_matrix_destroy(fmx_matrix* m);
 int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz);
 /* Copy rows [r0, r1) back to the host (row_ptr is rebased to 0); any pointer may be NULL. */
@@ -315,6 +322,10 @@ int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, co
  * caller, who passes their current values in v_lambda / v_mu. */
 int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda,
                     const double* v_mu, const double* std_normals);
+
+/* The exact sweeps process the features in LEVELS (features of a level share no row, levels in ascending order reproduce the
+ * reference's index-order Gauss-Seidel): how many levels this matrix needs, and the size of the largest. */
+int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
  * w0 update (:162-188); w sweep (:190-270, the exact one-thread form) }.  As shipped the reference never sweeps V (its
