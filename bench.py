@@ -40,8 +40,11 @@ def parse():
     ap.add_argument("--features", type=int, default=1_000_000)
     ap.add_argument("--nnz", type=int, default=30)
     ap.add_argument("--factors", type=int, default=0, help="0: 16 for sgd (configs[1]), 64 for ftrl (configs[2])")
-    ap.add_argument("--batch-rows", type=int, default=1_048_576,
-                    help="mini-batch rows per GPU per step (processed in cache-resident tiles)")
+    ap.add_argument("--batch-rows", type=int, default=0,
+                    help="mini-batch rows per GPU per step (processed in cache-resident tiles).  0: 262144 on one GPU -- the largest step "
+                         "that learns per example like a 4096-row one at the reference's learning rate on this workload (a coordinate then "
+                         "occurs ~8 times per step; profiles/r02_learning_*.txt) -- and 1048576 per GPU for N > 1, where the step must be "
+                         "long enough to hide the exchange of the 72 MB buffer (the global batch is N times larger either way)")
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144; 524288 for k > 32)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
@@ -58,6 +61,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (0: skip; -1: 5M for sgd, 250K for ftrl k=64: 10-20 s of one core either way)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp64 state, small batches, sequential mode, ceilings)")
     a = ap.parse_args()
+    if a.batch_rows == 0:
+        a.batch_rows = 262_144 if a.gpus == 1 else 1_048_576
     if a.factors == 0:
         a.factors = 16 if a.solver == "sgd" else 64
     if a.cpu_rows < 0:
@@ -96,7 +101,7 @@ def pmc_traffic(kernel, args):
             return int(a[a.index(name) + 1]) if name in a else default
         solver = "ftrl" if "ftrl" in a else "sgd"
         k = opt("--factors", 16 if solver == "sgd" else 64)
-        same = (effective_tile(opt("--batch-rows", 1_048_576), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
+        same = (effective_tile(opt("--batch-rows", 262_144), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
                 and k == args.factors and opt("--features", 1_000_000) == args.features and opt("--rows", 10_000_000) == args.rows
                 and opt("--nnz", 30) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64))
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:

@@ -232,19 +232,120 @@ __global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __re
   for (int64_t t = b + lane; t < e; t += 64) qe[crow[t]].y -= (double)cval[t] * w_diff;
 }
 
+// ---- heavy columns and the approximate (grouped) sweep -----------------------------------------------------------------------
+// als_sweep_k is the general form of the two kernels above: T threads own one feature (a wave, or a whole workgroup for
+// columns of more than ALS_HEAVY entries: a Zipf head feature holds millions, and one wave walking it serialises the level),
+// W picks the w update (:208-256) or the V update (:303-350), APPROX the grouped form:
+//
+// When a matrix needs far more levels than it has entries per row (i.i.d. or Zipf columns: thousands of levels of a few
+// hundred features each -- the exact schedule is then a chain of thousands of dependent launches per factor), the sweeps can
+// run in the reference's OWN approximate parallel form instead (solver/MCMC_ALS_Learner.h:200-268: every OpenMP thread sweeps
+// its features against a private copy of the residual, the copies are merged afterwards).  Here every feature of a GROUP is
+// such a thread: all of them read the (q, e) of the group's start, each takes its exact coordinate step against that snapshot,
+// and the corrections are merged into the next snapshot by atomic adds.  Groups = the largest position a feature takes in any
+// of its rows (for one-column-per-field data that IS the exact level, and the grouped sweep equals the exact one); groups run
+// in ascending order.  cfg.als_max_levels switches it on; results are then reproducible up to the order of the atomic adds.
+constexpr int ALS_HEAVY = 4096;
+
+template <bool W, bool APPROX, int T>
+__global__ __launch_bounds__(WG_THREADS) void als_sweep_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
+                                                          const uint32_t* __restrict__ crow, const float* __restrict__ cval, double* __restrict__ P, int kp,
+                                                          int f, const double2* qe_old, double2* qe_new, double alpha, double lambda, double mu,
+                                                          const double* __restrict__ znorm) {
+  __shared__ double red[2][WG_THREADS / 64];
+  const int tid = threadIdx.x % T;
+  const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) / T);
+  if (wid >= n_feats) return;  // (T == 256: the whole workgroup leaves together)
+  const uint32_t i = feats[wid];
+  const int64_t b = col_ptr[i], e = col_ptr[i + 1];
+  const size_t at = W ? (size_t)i : (size_t)i * kp + f;
+  const double old = P[at];
+  double mean = 0.0, var = 0.0;
+  constexpr int UN = 4;
+  for (int64_t t0 = b + tid; t0 < e; t0 += (int64_t)T * UN) {
+    float x[UN]; double2 c[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t t = t0 + (int64_t)u * T;
+      const bool in = t < e;
+      x[u] = in ? cval[t] : 0.f;
+      c[u] = in ? qe_old[crow[t]] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (W) { const double xd = (double)x[u]; mean += c[u].y * xd - old * xd * xd; var += xd * xd; }
+      else { const float xx = x[u] * x[u]; const double h = (double)x[u] * c[u].x - (double)xx * old; mean += h * c[u].y; var += h * h; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mean += __shfl_xor(mean, off); var += __shfl_xor(var, off); }
+  if (T > 64) {
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = mean; red[1][wv] = var; }
+    __syncthreads();
+    mean = 0.0; var = 0.0;
+    for (int q = 0; q < WG_THREADS / 64; ++q) { mean += red[0][q]; var += red[1][q]; }
+  }
+  double nv;
+  if (W) {
+    var = 1.0 / (lambda + alpha * var);
+    mean = -var * (alpha * mean - mu * lambda);
+    nv = bad_number(var) ? 0.0 : (znorm ? mean + var * znorm[i] : mean);      // (the variance as Rf_rnorm's sd: :239, kept)
+  } else {
+    mean -= old * var;
+    var = 1.0 / (lambda + alpha * var);
+    mean = -var * (alpha * mean - mu * lambda);
+    nv = bad_number(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[i] : mean);
+  }
+  if (bad_number(nv)) return;  // CHECK_PARAM
+  if (tid == 0) P[at] = nv;
+  const double diff = old - nv;
+  for (int64_t t0 = b + tid; t0 < e; t0 += (int64_t)T * UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t t = t0 + (int64_t)u * T;
+      if (t >= e) continue;
+      const float x = cval[t];
+      const uint32_t r = crow[t];
+      const double2 c = qe_old[r];
+      double dq, de;
+      if (W) { dq = 0.0; de = (double)x * diff; }
+      else { const float xx = x * x; const double h = (double)x * c.x - (double)xx * old; dq = (double)x * diff; de = h * diff; }
+      if (APPROX) {
+        double* dst = reinterpret_cast<double*>(qe_new + r);
+        if (!W) unsafeAtomicAdd(dst, -dq);
+        unsafeAtomicAdd(dst + 1, -de);
+      } else {
+        qe_new[r] = make_double2(c.x - dq, c.y - de);
+      }
+    }
+  }
+}
+
+// largest position (0-based) each feature takes inside a row: the groups of the approximate sweep
+__global__ void als_maxpos_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int* __restrict__ level) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t b = row_ptr[r];
+  for (int64_t t = b; t < row_ptr[r + 1]; ++t) atomicMax(&level[col[t]], (int)(t - b));
+}
+
 // the level plan depends on the matrix only: built once, kept in the fmx_matrix
-static int build_plan(fmx_matrix* m, hipStream_t stream) {
-  if (m->als_feats) return FMX_OK;
+static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
+  if (m->als_feats && m->als_plan_cap == max_levels) return FMX_OK;
+  (void)hipFree(m->als_feats); m->als_feats = nullptr;
+  (void)hipFree(m->als_heavy); m->als_heavy = nullptr;
   const uint32_t p = m->p;
   int *d_level = nullptr, *d_changed = nullptr;
   FMX_HIP(hipMalloc(&d_level, (size_t)p * sizeof(int)));
   FMX_HIP(hipMalloc(&d_changed, sizeof(int)));
   FMX_HIP(hipMemsetAsync(d_level, 0, (size_t)p * sizeof(int), stream));
-  // monotone relaxation to the fixed point; every sweep propagates along whole rows, so the count of sweeps is far below
-  // the number of levels.  The "changed" flag is read back once per CHECK sweeps (a host round trip per sweep would cost more
-  // than the sweep on matrices with deep level chains: i.i.d. or Zipf columns instead of one column per field).
+  // monotone relaxation to the fixed point; every sweep propagates along whole rows.  The "changed" flag is read back once per
+  // CHECK sweeps.  max_levels > 0: give up after that many sweeps (a deep chain: i.i.d. or Zipf columns) and fall back to the
+  // grouped sweep, whose groups need one pass.
   const int CHECK = 8;
   int64_t sweeps = 0;
+  bool approx = false;
   for (;;) {
     int h = 0;
     FMX_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
@@ -254,30 +355,99 @@ static int build_plan(fmx_matrix* m, hipStream_t stream) {
     FMX_HIP(hipStreamSynchronize(stream));
     if (!h) break;
     sweeps += CHECK;
+    if (max_levels > 0 && sweeps >= max_levels) { approx = true; break; }
     FMX_CHECK(sweeps <= (int64_t)p + CHECK, FMX_ERR_STATE, "level scheduling did not converge");
   }
   std::vector<int> level(p);
   FMX_HIP(hipMemcpy(level.data(), d_level, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));
+  if (!approx && max_levels > 0) {  // converged, but with more levels than asked for?
+    int L = 0;
+    for (uint32_t j = 0; j < p; ++j) if (level[j] + 1 > L) L = level[j] + 1;
+    approx = L > max_levels;
+  }
+  if (approx) {
+    FMX_HIP(hipMemsetAsync(d_level, 0, (size_t)p * sizeof(int), stream));
+    if (m->n > 0) hipLaunchKernelGGL(als_maxpos_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->n, d_level);
+    FMX_HIP(hipMemcpyAsync(level.data(), d_level, (size_t)p * sizeof(int), hipMemcpyDeviceToHost, stream));
+    FMX_HIP(hipStreamSynchronize(stream));
+  }
   (void)hipFree(d_level); (void)hipFree(d_changed);
+  std::vector<int64_t> cp((size_t)p + 1);
+  FMX_HIP(hipMemcpy(cp.data(), m->col_ptr, cp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
   int L = 0;
   for (uint32_t j = 0; j < p; ++j) if (level[j] + 1 > L) L = level[j] + 1;
+  // per level: the light features (one wave each) and the heavy ones (one workgroup each), ascending index inside a level
+  std::vector<std::vector<uint32_t>> light((size_t)L), heavy((size_t)L);
+  for (uint32_t j = 0; j < p; ++j) (cp[(size_t)j + 1] - cp[(size_t)j] > ALS_HEAVY ? heavy : light)[(size_t)level[j]].push_back(j);
+  std::vector<uint32_t> fl, fh;
   m->als_level_ptr.assign((size_t)L + 1, 0);
-  for (uint32_t j = 0; j < p; ++j) m->als_level_ptr[(size_t)level[j] + 1]++;
-  for (int l = 0; l < L; ++l) m->als_level_ptr[(size_t)l + 1] += m->als_level_ptr[(size_t)l];
-  std::vector<uint32_t> feats(p);
-  std::vector<int64_t> cur(m->als_level_ptr.begin(), m->als_level_ptr.end() - 1);
-  for (uint32_t j = 0; j < p; ++j) feats[(size_t)cur[(size_t)level[j]]++] = j;  // ascending index inside a level
-  FMX_HIP(hipMalloc(&m->als_feats, (size_t)p * sizeof(uint32_t)));
-  FMX_HIP(hipMemcpy(m->als_feats, feats.data(), (size_t)p * sizeof(uint32_t), hipMemcpyHostToDevice));
+  m->als_heavy_ptr.assign((size_t)L + 1, 0);
+  for (int l = 0; l < L; ++l) {
+    fl.insert(fl.end(), light[(size_t)l].begin(), light[(size_t)l].end());
+    fh.insert(fh.end(), heavy[(size_t)l].begin(), heavy[(size_t)l].end());
+    m->als_level_ptr[(size_t)l + 1] = (int64_t)fl.size();
+    m->als_heavy_ptr[(size_t)l + 1] = (int64_t)fh.size();
+  }
+  FMX_HIP(hipMalloc(&m->als_feats, (fl.size() ? fl.size() : 1) * sizeof(uint32_t)));
+  if (!fl.empty()) FMX_HIP(hipMemcpy(m->als_feats, fl.data(), fl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  FMX_HIP(hipMalloc(&m->als_heavy, (fh.size() ? fh.size() : 1) * sizeof(uint32_t)));
+  if (!fh.empty()) FMX_HIP(hipMemcpy(m->als_heavy, fh.data(), fh.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  m->als_approx = approx ? 1 : 0;
+  m->als_plan_cap = max_levels;
+  m->als_level_of.assign(level.begin(), level.end());
   return FMX_OK;
+}
+
+// One pass over all features of the plan for the w sweep (W) or factor f of the V sweep: levels (exact) or groups (approximate)
+// in ascending order.  qe_new: second (q, e) array of the approximate form (the merged corrections land there; it is copied
+// over the snapshot after every group), unused by the exact form.
+template <bool W>
+static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2* d_qe_new, int f, double alpha, double lambda, double mu, const double* d_znorm) {
+  const std::vector<int64_t>& lp = m->als_level_ptr;
+  const std::vector<int64_t>& hp = m->als_heavy_ptr;
+  const int L = (int)lp.size() - 1;
+  double* P = W ? e->dw : e->dV;
+  for (int l = 0; l < L; ++l) {
+    const int64_t cnt = lp[(size_t)l + 1] - lp[(size_t)l], hcnt = hp[(size_t)l + 1] - hp[(size_t)l];
+    if (cnt + hcnt == 0) continue;
+    const uint32_t* lf = m->als_feats + lp[(size_t)l];
+    const uint32_t* hf = m->als_heavy + hp[(size_t)l];
+    const dim3 gl((unsigned)((cnt * 64 + WG_THREADS - 1) / WG_THREADS)), gh((unsigned)hcnt), blk(WG_THREADS);
+    if (!m->als_approx) {
+      if (cnt > 0) {
+        if (W) hipLaunchKernelGGL(als_w_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dw, d_qe, alpha, lambda, mu, d_znorm);
+        else hipLaunchKernelGGL(als_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_qe, alpha, lambda, mu, d_znorm);
+      }
+      // (a heavy feature shares rows with nearly everything: it is alone in its level, or with a few other heavy ones)
+      if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
+                                       (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
+    } else {
+      if (cnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, 64>), gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
+                                      (const double2*)d_qe, d_qe_new, alpha, lambda, mu, d_znorm);
+      if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
+                                       (const double2*)d_qe, d_qe_new, alpha, lambda, mu, d_znorm);
+      (void)hipMemcpyAsync(d_qe, d_qe_new, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);  // the next group's snapshot
+    }
+  }
+}
+
+// the approximate form's second (q, e) array: allocated on first use, kept in the engine
+static double2* approx_buffer(fmx_engine* e, fmx_matrix* m) {
+  if (!m->als_approx) return nullptr;
+  if (e->als_qe_new_rows < m->n) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(e->als_qe_new); e->als_qe_new = nullptr; e->als_qe_new_rows = 0;
+    if (hipMalloc(&e->als_qe_new, (size_t)m->n * sizeof(double2)) != hipSuccess) return nullptr;
+    e->als_qe_new_rows = m->n;
+  }
+  return reinterpret_cast<double2*>(e->als_qe_new);
 }
 
 // V sweep over all factors on the interleaved (q, e) pairs
 static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu,
                             const double* d_znorm = nullptr) {
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
-  const std::vector<int64_t>& level_ptr = m->als_level_ptr;
-  const int L = (int)level_ptr.size() - 1;
+  double2* d_qe_new = approx_buffer(e, m);
   // q_f = X v_f only depends on column f of V, which no other factor's sweep touches: all k of them come out of ONE
   // row-gather pass (the forward kernel on the fp64 tables) instead of one gather per nonzero per factor
   double* d_Q = nullptr;
@@ -291,14 +461,8 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
     if (d_Q) hipLaunchKernelGGL(als_q_pick_k, dim3(row_grid), dim3(256), 0, e->stream, d_Q, e->kp64, f, m->n, d_qe);
     else hipLaunchKernelGGL(als_q_init_k, dim3(row_grid), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_qe);
     const double lambda = h_lambda ? h_lambda[f] : 0.0, mu = h_mu ? h_mu[f] : 0.0;
-    for (int l = 0; l < L; ++l) {
-      const int64_t cnt = level_ptr[(size_t)l + 1] - level_ptr[(size_t)l];
-      if (cnt == 0) continue;
-      const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
-      hipLaunchKernelGGL(als_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
-                         m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_qe, alpha, lambda, mu,
-                         d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
-    }
+    if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);  // q changed: resynchronise the pair
+    sweep_features<false>(e, m, d_qe, d_qe_new, f, alpha, lambda, mu, d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
   }
   if (d_Q) { (void)hipStreamSynchronize(e->stream); (void)hipFree(d_Q); }
 }
@@ -307,14 +471,20 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
 // (e = y_hat - y, or the probit-table ratio for CLASSIFICATION, :520-562), the w0
 // update, the w sweep; with_v adds the V sweep the shipped update_all leaves out (SURVEY A-1).  init() fixes alpha = 1,
 // w0_mean_0 = 0 and all lambda / mu = 0 (A-7), so the R-side solver parameters do not enter.
-int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest) {
+int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest, int32_t* approx, int32_t* level_of) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
-  FMX_TRY(build_plan(m, e->stream));
+  FMX_TRY(build_full_csc(m, e->stream));
+  FMX_TRY(build_plan(m, e->stream, e->cfg.als_max_levels));
   const int64_t L = (int64_t)m->als_level_ptr.size() - 1;
   int64_t big = 0;
-  for (int64_t l = 0; l < L; ++l) { const int64_t c = m->als_level_ptr[(size_t)l + 1] - m->als_level_ptr[(size_t)l]; if (c > big) big = c; }
+  for (int64_t l = 0; l < L; ++l) {
+    const int64_t c = m->als_level_ptr[(size_t)l + 1] - m->als_level_ptr[(size_t)l] + m->als_heavy_ptr[(size_t)l + 1] - m->als_heavy_ptr[(size_t)l];
+    if (c > big) big = c;
+  }
   if (levels) *levels = L;
   if (largest) *largest = big;
+  if (approx) *approx = m->als_approx;
+  if (level_of) for (size_t j = 0; j < m->als_level_of.size(); ++j) level_of[j] = m->als_level_of[j];
   return FMX_OK;
 }
 
@@ -326,7 +496,7 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     dp_y = e->probit + PN_POINTS + 1;
   }
   FMX_TRY(build_full_csc(m, e->stream));
-  FMX_TRY(build_plan(m, e->stream));
+  FMX_TRY(build_plan(m, e->stream, e->cfg.als_max_levels));
   const int64_t n = m->n;
   const unsigned row_grid = (unsigned)((n + 255) / 256);
   const int64_t np = (n + ALS_SLAB - 1) / ALS_SLAB;
@@ -337,8 +507,6 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part);
     set_error("out of device memory"); return FMX_ERR_HIP;
   }
-  const std::vector<int64_t>& level_ptr = m->als_level_ptr;
-  const int L = (int)level_ptr.size() - 1;
   int st = FMX_OK;
   for (int it = 0; it < max_iter && st == FMX_OK; ++it) {
     RowsArgs a{};
@@ -353,13 +521,9 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
       hipLaunchKernelGGL(als_shift_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, n, d_part + np);
     }
     if (e->hyper.k1) {
-      for (int l = 0; l < L; ++l) {
-        const int64_t cnt = level_ptr[(size_t)l + 1] - level_ptr[(size_t)l];
-        if (cnt == 0) continue;
-        const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
-        hipLaunchKernelGGL(als_w_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
-                           m->col_ptr, m->crow, m->cval, e->dw, d_qe, 1.0, 0.0, 0.0, (const double*)nullptr);
-      }
+      double2* d_qe_new = approx_buffer(e, m);
+      if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);
+      sweep_features<true>(e, m, d_qe, d_qe_new, 0, 1.0, 0.0, 0.0, nullptr);
     }
     if (with_v && e->k > 0) v_sweep_enqueue(e, m, d_qe, 1.0, nullptr, nullptr);
   }
@@ -445,7 +609,7 @@ static double h_trnorm_left(double left) {  // Random.h:52-76
 int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
   FMX_TRY(build_full_csc(m, e->stream));
-  FMX_TRY(build_plan(m, e->stream));
+  FMX_TRY(build_plan(m, e->stream, e->cfg.als_max_levels));
   const int64_t n = m->n;
   const int64_t p = (int64_t)e->p;
   const unsigned row_grid = (unsigned)((n + 255) / 256);
@@ -467,8 +631,6 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
   }
   const double alpha_0 = 1.0, gamma_0 = 1.0, beta_0 = 1.0, mu_0 = 0.0, w0_mean_0 = 0.0;  // init(), :59-90 (SURVEY A-7)
   double alpha = 1.0, w_lambda = 0.0, w_mu = 0.0;
-  const std::vector<int64_t>& level_ptr = m->als_level_ptr;
-  const int L = (int)level_ptr.size() - 1;
   auto bad = [](double x) { return std::isnan(x) || std::isinf(x); };
   int st = FMX_OK;
 #define MC_HIP(call) do { if (st == FMX_OK) { hipError_t _e = (call); if (_e != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(_e)); st = FMX_ERR_HIP; } } } while (0)
@@ -528,12 +690,10 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
         if (!bad(mu_new)) w_mu = mu_new;
       }
       MC_HIP(hipMemcpyAsync(d_z, Z + 2, (size_t)p * sizeof(double), hipMemcpyHostToDevice, e->stream));
-      for (int l = 0; l < L; ++l) {  // update_w, :190-270
-        const int64_t cnt = level_ptr[(size_t)l + 1] - level_ptr[(size_t)l];
-        if (cnt == 0) continue;
-        const int64_t grid = (cnt * 64 + WG_THREADS - 1) / WG_THREADS;
-        hipLaunchKernelGGL(als_w_level_k, dim3((unsigned)grid), dim3(WG_THREADS), 0, e->stream, m->als_feats + level_ptr[(size_t)l], (int)cnt,
-                           m->col_ptr, m->crow, m->cval, e->dw, d_qe, alpha, w_lambda, w_mu, (const double*)d_z);
+      {  // update_w, :190-270
+        double2* d_qe_new = approx_buffer(e, m);
+        if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);
+        sweep_features<true>(e, m, d_qe, d_qe_new, 0, alpha, w_lambda, w_mu, (const double*)d_z);
       }
     }
   }
@@ -551,7 +711,7 @@ int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q
                       const double* d_znorm) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweep needs every row's columns strictly ascending (as R's dgCMatrix rows are)");
   FMX_TRY(build_full_csc(m, e->stream));
-  FMX_TRY(build_plan(m, e->stream));
+  FMX_TRY(build_plan(m, e->stream, e->cfg.als_max_levels));
   double2* d_qe = reinterpret_cast<double2*>(d_qe_raw);
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   hipLaunchKernelGGL(als_pack_k, dim3(row_grid), dim3(256), 0, e->stream, d_error, m->n, d_qe);

@@ -16,18 +16,29 @@
 namespace fmx {
 
 // ------------------------------------------------------------------------------------------------ CSC builders
-__global__ void pack_entries_k(const int64_t* __restrict__ row_ptr, const float* __restrict__ val, int64_t r0, int64_t nrows,
-                               int64_t base, int64_t cnt, uint64_t* __restrict__ packed) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cnt) return;
-  const int64_t t = base + i;
-  // row of entry t: last r in [r0, r0+nrows) with row_ptr[r] <= t
+// row of entry t: last r in [r0, r0+nrows) with row_ptr[r] <= t (rows of one fixed length: a division)
+__device__ __forceinline__ uint32_t entry_row(const int64_t* __restrict__ row_ptr, int64_t r0, int64_t nrows, int64_t base, int64_t t, int fixed_len) {
+  if (fixed_len > 0) return (uint32_t)((t - base) / fixed_len);
   int64_t lo = r0, hi = r0 + nrows;
   while (hi - lo > 1) {
     const int64_t mid = (lo + hi) >> 1;
     if (row_ptr[mid] <= t) lo = mid; else hi = mid;
   }
-  packed[i] = ((uint64_t)(uint32_t)(lo - r0) << 32) | (uint64_t)__float_as_uint(val[t]);
+  return (uint32_t)(lo - r0);
+}
+
+__global__ void pack_entries_k(const int64_t* __restrict__ row_ptr, const float* __restrict__ val, int64_t r0, int64_t nrows,
+                               int64_t base, int64_t cnt, uint64_t* __restrict__ packed, int fixed_len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const int64_t t = base + i;
+  packed[i] = ((uint64_t)entry_row(row_ptr, r0, nrows, base, t, fixed_len) << 32) | (uint64_t)__float_as_uint(val[t]);
+}
+
+// one-hot matrices: the payload is the row alone (the values are never read)
+__global__ void pack_rows_k(const int64_t* __restrict__ row_ptr, int64_t r0, int64_t nrows, int64_t base, int64_t cnt, uint32_t* __restrict__ rows, int fixed_len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt) rows[i] = entry_row(row_ptr, r0, nrows, base, base + i, fixed_len);
 }
 
 __global__ void unpack_entries_k(const uint64_t* __restrict__ packed, int64_t cnt, uint32_t* __restrict__ rows, float* __restrict__ vals) {
@@ -91,7 +102,7 @@ static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r
                         uint32_t* out_rows, float* out_vals, OffT* out_ptr, hipStream_t stream) {
   const int T = 256;
   if (cnt > 0) {
-    hipLaunchKernelGGL(pack_entries_k, dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, stream, m->row_ptr, m->val, r0, nrows, base, cnt, s.vals_in);
+    hipLaunchKernelGGL(pack_entries_k, dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, stream, m->row_ptr, m->val, r0, nrows, base, cnt, s.vals_in, 0);
     FMX_HIP(rocprim::radix_sort_pairs(s.temp, s.temp_bytes, m->col + base, s.keys_out, s.vals_in, s.vals_out, (size_t)cnt, 0, bits, stream));
     hipLaunchKernelGGL(unpack_entries_k, dim3((unsigned)((cnt + T - 1) / T)), dim3(T), 0, stream, s.vals_out, cnt, out_rows, out_vals);
   }
@@ -226,6 +237,11 @@ int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
   FMX_HIP(hipMalloc(&vals_in, m * sizeof(uint64_t)));
   FMX_HIP(hipMalloc(&vals_out, m * sizeof(uint64_t)));
   FMX_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, keys_out, vals_in, vals_out, m, 0, bits, stream));
+  {
+    size_t b32 = 0;  // the (u32, u32) sort of one-hot matrices
+    FMX_HIP(rocprim::radix_sort_pairs(nullptr, b32, (const uint32_t*)nullptr, keys_out, (uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, bits, stream));
+    if (b32 > sort_bytes) sort_bytes = b32;
+  }
   FMX_HIP(hipMalloc(&sort_temp, sort_bytes ? sort_bytes : 16));
   const size_t nflag = m > (size_t)p_ ? m : (size_t)p_;
   FMX_HIP(hipMalloc(&flags, nflag));
@@ -249,14 +265,21 @@ int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
 // Plan one tile: entries [t.base, t.base + t.cnt) of rows [t.r0, t.r0 + t.nrows), CSR arrays given explicitly (a streamed
 // tile has its own).  Enqueues on `stream`, never waits for it; t must come from plan_alloc with room for t.cnt entries.
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
-               uint32_t* brow, float* bval, hipStream_t stream) {
+               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len) {
   const int T = 256;
   const int64_t cnt = t.cnt;
   FMX_CHECK(cnt <= ws.max_cnt && p == ws.p, FMX_ERR_STATE, "plan workspace too small");
   FMX_CHECK(cnt < (1LL << 32), FMX_ERR_INVALID, "a tile holds %lld nonzeros; at most 2^32-1 are supported (lower tile_rows)", (long long)cnt);
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + T - 1) / T)); };
-  if (cnt > 0) {
-    hipLaunchKernelGGL(pack_entries_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, ws.vals_in);
+  if (cnt > 0 && unit_values) {
+    // one-hot values: sort (column, row) pairs straight into brow -- 8 bytes per entry and pass instead of 12, no unpack pass;
+    // bval is never read for such a matrix
+    uint32_t* rows32 = reinterpret_cast<uint32_t*>(ws.vals_in);
+    hipLaunchKernelGGL(pack_rows_k, grid(cnt), dim3(T), 0, stream, row_ptr, t.r0, t.nrows, t.base, cnt, rows32, fixed_row_len);
+    size_t tb32 = ws.sort_bytes;  // sized for the (u32, u64) sort of the same length: the (u32, u32) one needs no more
+    FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, tb32, col + t.base, ws.keys_out, rows32, brow + t.base, (size_t)cnt, 0, ws.bits, stream));
+  } else if (cnt > 0) {
+    hipLaunchKernelGGL(pack_entries_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, ws.vals_in, fixed_row_len);
     FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, ws.sort_bytes, col + t.base, ws.keys_out, ws.vals_in, ws.vals_out, (size_t)cnt, 0, ws.bits, stream));
     hipLaunchKernelGGL(unpack_entries_k, grid(cnt), dim3(T), 0, stream, ws.vals_out, cnt, brow + t.base, bval + t.base);
   }
@@ -402,7 +425,7 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     // occurring features get a list (p = 33 M against 10 M entries per tile at configs[3]: no p-sized array per tile)
     FMX_TRY(plan_alloc(pl, m->p, cnt, cnt >= (int64_t)m->p));
     pl.r0 = tile_start[(size_t)t]; pl.nrows = tile_start[(size_t)t + 1] - pl.r0; pl.base = base; pl.cnt = cnt;
-    FMX_TRY(plan_build(pl, ws, m->p, m->row_ptr, m->col, m->val, L.brow, L.bval, stream));
+    FMX_TRY(plan_build(pl, ws, m->p, m->row_ptr, m->col, m->val, L.brow, L.bval, stream, m->unit_values, m->fixed_row_len));
     FMX_HIP(hipMemcpyAsync(L.h_counts + 4 * t, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   }
   FMX_HIP(hipStreamSynchronize(stream));
@@ -579,6 +602,7 @@ int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offs
   FMX_HIP(hipDeviceSynchronize());
   m->rows_sorted = 1;  // strata are disjoint and ascending
   m->max_row_len = z;
+  m->fixed_row_len = z;
   { const char* v = getenv("FMX_UNIT_VALUES"); m->unit_values = !(v && v[0] == '0'); }  // the generator writes 1.0f everywhere
   return FMX_OK;
 }
@@ -826,21 +850,24 @@ __global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_
   if (other) out[2] = 1;
   const int64_t len = row_ptr[r + 1] - row_ptr[r];
   atomicMax(out + 1, (int)(len > 0x7fffffff ? 0x7fffffff : len));  // longest row
+  atomicMax(out + 3, (int)(len > 0x7fffffff ? 0 : 0x7fffffff - (int)len));  // shortest row (as a maximum of the complement)
 }
 
 int check_rows_sorted(fmx_matrix* m) {
   int* d = nullptr;
-  int h[3] = {0, 0, 0};
-  FMX_HIP(hipMalloc(&d, 3 * sizeof(int)));
-  FMX_HIP(hipMemset(d, 0, 3 * sizeof(int)));
+  int h[4] = {0, 0, 0, 0};
+  FMX_HIP(hipMalloc(&d, 4 * sizeof(int)));
+  FMX_HIP(hipMemset(d, 0, 4 * sizeof(int)));
   if (m->n > 0) hipLaunchKernelGGL(rows_sorted_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->val, m->n, d);
-  FMX_HIP(hipMemcpy(h, d, 3 * sizeof(int), hipMemcpyDeviceToHost));
+  FMX_HIP(hipMemcpy(h, d, 4 * sizeof(int), hipMemcpyDeviceToHost));
   FMX_HIP(hipFree(d));
   m->rows_sorted = !h[0];
   m->max_row_len = h[1];
   // FMX_UNIT_VALUES=0 in the environment keeps the general path (tuning / A-B runs only)
   static const bool allow = [] { const char* v = getenv("FMX_UNIT_VALUES"); return !(v && v[0] == '0'); }();
   m->unit_values = (allow && !h[2]) ? 1 : 0;
+  const int shortest = 0x7fffffff - h[3];
+  m->fixed_row_len = (m->n > 0 && shortest == h[1] && h[1] > 0) ? h[1] : 0;  // every row holds the same number of entries
   return FMX_OK;
 }
 

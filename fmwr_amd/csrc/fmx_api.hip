@@ -194,7 +194,7 @@ static void free_matrix(fmx_matrix* m) {
   if (!m) return;
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
   drop_plans(m);
-  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats);
+  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats); (void)hipFree(m->als_heavy);
   delete m;
 }
 
@@ -582,6 +582,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->mode == FMX_MODE_SEQUENTIAL || cfg->mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID, "unknown mode %d", cfg->mode);
   FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
   FMX_CHECK(cfg->n_gpus >= 0, FMX_ERR_INVALID, "n_gpus must be >= 0");
+  FMX_CHECK(cfg->als_max_levels >= 0, FMX_ERR_INVALID, "als_max_levels must be >= 0");
   FMX_CHECK(cfg->batch_reduce == FMX_REDUCE_MEAN || cfg->batch_reduce == FMX_REDUCE_SUM, FMX_ERR_INVALID, "unknown batch_reduce %d", cfg->batch_reduce);
   FMX_CHECK(num_features > 0 && num_features < (1ull << 32), FMX_ERR_INVALID, "number of features must be in 1..2^32-1");
   if (cfg->mode == FMX_MODE_MINIBATCH) FMX_CHECK(cfg->batch_rows >= 1 && cfg->tile_rows >= 0, FMX_ERR_INVALID, "batch_rows must be >= 1 and tile_rows >= 0");
@@ -641,7 +642,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FMX_OK;
@@ -953,6 +954,8 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
   if (st != FMX_OK) { free_matrix(m); return st; }
   m->rows_sorted = 1;
   m->max_row_len = z;
+  m->fixed_row_len = z;
+  m->unit_values = (fs.n_dense == 0) ? 1 : 0;  // the dense features carry values in [0, 1)
   *out = m;
   return FMX_OK;
 }
@@ -970,6 +973,7 @@ int fmx_matrix_synthetic_iid(int device, int64_t n, uint32_t p, int32_t nnz_per_
   if (st != FMX_OK) { free_matrix(m); return st; }
   m->rows_sorted = 1;
   m->max_row_len = nnz_per_row;
+  m->fixed_row_len = nnz_per_row;
   { const char* v = getenv("FMX_UNIT_VALUES"); m->unit_values = !(v && v[0] == '0'); }
   *out = m;
   return FMX_OK;
@@ -1152,8 +1156,8 @@ int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per
   FMX_TRY(C.ws.reserve(cap_cnt, (uint32_t)p, C.ingest));
   for (auto& s : C.slot) {
     FMX_TRY(alloc_matrix(e->cfg.device, B, (uint32_t)p, cap_cnt, true, &s.m));
-    s.m->rows_sorted = 1; s.m->max_row_len = z;
-    s.m->unit_values = spec ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
+    s.m->rows_sorted = 1; s.m->max_row_len = z; s.m->fixed_row_len = z;
+    s.m->unit_values = (spec && fs.n_dense > 0) ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
     FMX_HIP(hipMalloc(&s.m->brow, (size_t)cap_cnt * sizeof(uint32_t)));
     FMX_HIP(hipMalloc(&s.m->bval, (size_t)cap_cnt * sizeof(float)));
     s.m->plans.resize(1);
@@ -1176,7 +1180,7 @@ int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per
     else FMX_TRY(generate_synthetic_async(m, rows, z, seed, row_offset + t * B, C.ingest));
     auto& pl = m->plans[0];
     pl.r0 = 0; pl.nrows = rows; pl.base = 0; pl.cnt = rows * z;
-    FMX_TRY(plan_build(pl, C.ws, (uint32_t)p, m->row_ptr, m->col, m->val, m->brow, m->bval, C.ingest));
+    FMX_TRY(plan_build(pl, C.ws, (uint32_t)p, m->row_ptr, m->col, m->val, m->brow, m->bval, C.ingest, m->unit_values, z));
     FMX_HIP(hipMemcpyAsync(s.h_counts, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, C.ingest));
     FMX_HIP(hipEventRecord(s.ingested, C.ingest));
     s.used = 1;
@@ -1558,10 +1562,11 @@ int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, c
   return vsweep_impl(e, m, error, alpha, v_lambda, v_mu, std_normals);
 }
 
-int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level) {
+int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level, int32_t* approximate, int32_t* level_of_feature) {
   FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweeps run on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
   FMX_TRY(use_device(e->cfg.device));
-  return als_plan_info(e, m, levels, largest_level);
+  return als_plan_info(e, m, levels, largest_level, approximate, level_of_feature);
 }
 
 int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v) {

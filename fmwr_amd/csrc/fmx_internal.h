@@ -100,6 +100,7 @@ struct fmx_matrix {
   float* y = nullptr;          // [n] or null
   int has_labels = 0;
   int rows_sorted = 0;  // every row strictly ascending in col (=> no duplicate column inside a row)
+  int fixed_row_len = 0; // > 0: every row holds exactly this many entries (row of an entry = a division, not a search)
   int unit_values = 0;  // every stored value is exactly 1.0f (one-hot data): the kernels then never read the value arrays
   int max_row_len = 0;  // entries of the longest row
   // Per-tile inverted index ("plan"), built lazily on the device for one (batch_rows, tile_rows) pair (fm_ingest.hip).
@@ -145,8 +146,13 @@ struct fmx_matrix {
   uint32_t* crow = nullptr;    // [nnz]
   float* cval = nullptr;       // [nnz]
   // ALS level plan (features ordered by (level, index)), built lazily
-  uint32_t* als_feats = nullptr;
+  uint32_t* als_feats = nullptr;        // light features (one wave each), ordered by (level, index)
   std::vector<int64_t> als_level_ptr;
+  uint32_t* als_heavy = nullptr;        // features with long columns (one workgroup each), same order
+  std::vector<int64_t> als_heavy_ptr;
+  std::vector<int32_t> als_level_of;    // [p] level (exact plan) or group (approximate plan) of every feature
+  int als_approx = 0;                   // the plan holds the groups of the approximate sweep, not exact levels
+  int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
 };
 
 struct fmx_engine {
@@ -204,6 +210,8 @@ struct fmx_engine {
   uint32_t* crec_count = nullptr;  // device: records written by the last fmx_grad_compact (points into the tile plan)
   int64_t crec_n = 0;              // the same count on the host (the plan builder read it back)
   fmx::MergeWs* merge = nullptr;   // scratch of fmx_apply_compact
+  void* als_qe_new = nullptr;      // second (q, e) array of the approximate ALS sweep
+  int64_t als_qe_new_rows = 0;
   fmx::Group* group = nullptr;     // cfg.n_gpus > 1: the other replicas and the exchange between them (fm_group.hip)
   void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
   int64_t gbuf_floats = 0;    // its element count
@@ -347,7 +355,7 @@ struct PlanWorkspace {
 int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense);
 void plan_free(fmx_matrix::TilePlan& t);
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
-               uint32_t* brow, float* bval, hipStream_t stream);
+               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len);
 void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h);
 int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream);
 void drop_plans(fmx_matrix* m);
@@ -370,7 +378,7 @@ int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double
 int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std);
 
 int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v);
-int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest);
+int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest, int32_t* approx, int32_t* level_of);
 int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state);
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu,
                       const double* d_znorm);

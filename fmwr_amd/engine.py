@@ -342,6 +342,13 @@ class Engine:
         L.check(L.lib().fmx_mcmc_train(self.h, m.h, C.c_int32(max_iter), _p(g), _p(z), _p(state)))
         return tuple(state)
 
+    def als_plan(self, m):
+        """(levels or groups, size of the largest, approximate?, level / group of every feature) of the ALS sweeps on this matrix."""
+        lv, big, ap = C.c_int64(), C.c_int64(), C.c_int32()
+        lof = np.zeros(max(self.p, 1), np.int32)
+        L.check(L.lib().fmx_als_plan_info(self.h, m.h, C.byref(lv), C.byref(big), C.byref(ap), _p(lof)))
+        return lv.value, big.value, bool(ap.value), lof[: self.p]
+
     def als_train(self, m, max_iter, with_v=False):
         L.check(L.lib().fmx_als_train(self.h, m.h, C.c_int32(max_iter), C.c_int32(int(with_v))))
 

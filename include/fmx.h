@@ -103,6 +103,13 @@ typedef struct fmx_config {
                               device .. device+N-1, one replica each, and all-reduces the gradient sums between steps with
                               RCCL -- what the reference's `nthreads` (options("FM.threads"), src/FM.cpp:59,97) becomes
                               here.  batch_rows stays "rows per step per GPU".  fmx_get_params / fmx_predict use replica 0. */
+  int32_t als_max_levels;  /* ALS / MCMC sweeps.  0: always the exact schedule (levels of row-disjoint features, the reference's
+                              index-order Gauss-Seidel reproduced).  L > 0: a matrix that needs more than L levels -- i.i.d. or
+                              Zipf columns need thousands, each a dependent launch -- is swept in the reference's own approximate
+                              parallel form instead (solver/MCMC_ALS_Learner.h:200-268): the features of a group step against the
+                              same snapshot of the residual, corrections are merged; groups = largest position of a feature in
+                              its rows.  For one-column-per-field data both forms coincide.                                  */
+  int32_t reserved0;
   int32_t gpus_share_device; /* 1: all N replicas live on `device` and exchange through a device kernel instead of RCCL
                               (rehearsals and tests on a one-GPU box; same sums, same order of ranks)                  */
 } fmx_config;
@@ -324,8 +331,10 @@ int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, c
                     const double* v_mu, const double* std_normals);
 
 /* The exact sweeps process the features in LEVELS (features of a level share no row, levels in ascending order reproduce the
- * reference's index-order Gauss-Seidel): how many levels this matrix needs, and the size of the largest. */
-int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level);
+ * reference's index-order Gauss-Seidel): how many levels (or, with cfg.als_max_levels exceeded, groups of the approximate
+ * form: `approximate` = 1) this matrix needs, the size of the largest, and every feature's level / group. */
+int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level, int32_t* approximate,
+                      int32_t* level_of_feature /* [p] or NULL */);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
  * w0 update (:162-188); w sweep (:190-270, the exact one-thread form) }.  As shipped the reference never sweeps V (its

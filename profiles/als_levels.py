@@ -14,8 +14,8 @@ for name, make in (("stratified (one column per stratum)", lambda: engine.Matrix
     e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
     e.set_params(0.0, None, np.random.default_rng(1).normal(0, 0.01, (k, p)))
     t = time.perf_counter()
-    lv, big = C.c_int64(), C.c_int64()
-    L.check(L.lib().fmx_als_plan_info(e.h, m.h, C.byref(lv), C.byref(big)))
+    lv, big, ap = C.c_int64(), C.c_int64(), C.c_int32()
+    L.check(L.lib().fmx_als_plan_info(e.h, m.h, C.byref(lv), C.byref(big), C.byref(ap), None))
     t_plan = time.perf_counter() - t
     err = np.zeros(n)
     t = time.perf_counter(); e.als_vsweep(m, err); t1 = time.perf_counter() - t      # includes the CSC build and the residual's two PCIe trips

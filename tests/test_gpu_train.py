@@ -780,3 +780,108 @@ def test_minibatch_tdap_at_batch_one_is_the_reference_learner(fm):
     e.train(m, n)
     g0, gw, gv = e.get_params()
     assert util.rel_err(gv, ref["v"].reshape(P.k, p)) < 1e-12 and abs(g0 - ref["w0"]) < 1e-12 and np.array_equal(gw, ref["w"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ALS / MCMC sweeps on matrices whose columns do NOT come one per field
+def _numpy_grouped_vsweep(k, p, rp, col, val, v, err, group_of, alpha=1.0):
+    """The approximate sweep restated: per factor q = X v_f; groups ascending; every feature of a group takes its exact
+    coordinate step (MCMC_ALS_Learner.h:303-334) against the (q, e) of the group's start, the corrections (:341-350) are
+    merged afterwards.  v: [k][p]."""
+    n = len(rp) - 1
+    v = v.copy(); e = err.copy()
+    rows_of = np.repeat(np.arange(n), np.diff(rp))
+    x = val.astype(np.float64); xx = (val * val).astype(np.float64)   # x*x is a float product in the reference (:314)
+    for f in range(k):
+        q = np.zeros(n); np.add.at(q, rows_of, x * v[f, col])
+        for g in range(int(group_of.max()) + 1):
+            sel = np.flatnonzero(group_of[col] == g)
+            if len(sel) == 0:
+                continue
+            c = col[sel]; r = rows_of[sel]
+            h = x[sel] * q[r] - xx[sel] * v[f, c]
+            mean = np.zeros(p); var = np.zeros(p)
+            np.add.at(mean, c, h * e[r]); np.add.at(var, c, h * h)
+            feats = np.unique(c)
+            mean[feats] -= v[f, feats] * var[feats]
+            vv = 1.0 / (alpha * var[feats])
+            new = -vv * (alpha * mean[feats])
+            new = np.where(np.isfinite(vv), new, 0.0)
+            diff = np.zeros(p); diff[feats] = v[f, feats] - new
+            v[f, feats] = new
+            np.subtract.at(q, r, x[sel] * diff[c]); np.subtract.at(e, r, h * diff[c])
+    return v, e
+
+
+def test_als_approximate_grouped_sweep(fm):
+    """cfg.als_max_levels: a matrix with i.i.d. columns needs hundreds of levels even at this size; with the cap the sweep
+    runs in groups (largest position of a feature in its rows), every group against one snapshot.  Checked against a numpy
+    restatement of exactly that; and on one-column-per-field data the grouped sweep IS the exact one."""
+    engine, L = fm
+    rng = np.random.default_rng(12)
+    n, p, z, k = 3000, 500, 8, 3
+    cols = np.sort(np.stack([rng.choice(p, z, replace=False) for _ in range(n)]), axis=1)
+    rp = np.arange(n + 1, dtype=np.int64) * z
+    col = cols.astype(np.uint32).ravel(); val = rng.normal(0, 1, n * z).astype(np.float32)
+    y = util.labels(n, 12, "regression")
+    w0, w, v = util.params(p, k, 12, stdev=0.3, fp32=False)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    err0 = oracle.predict_batch(P, oracle.Matrix(rp, col, val, p), w0, w, v.ravel()) - y
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    exact = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+    levels, _, approx, _ = exact.als_plan(m)
+    assert not approx and levels > 4 * z                      # a deep chain
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=16)
+    e.set_params(w0, w, v)
+    m2 = engine.Matrix.from_csr(rp, col, val, p, y)
+    groups, _, approx, group_of = e.als_plan(m2)
+    want = np.zeros(p, np.int64); np.maximum.at(want, col.astype(np.int64), np.tile(np.arange(z), n))
+    assert approx and groups == z and np.array_equal(group_of, want)
+    gerr = e.als_vsweep(m2, err0)
+    rv, rerr = _numpy_grouped_vsweep(k, p, rp, col.astype(np.int64), val, v, err0, group_of.astype(np.int64))
+    assert util.rel_err(e.get_params()[2], rv) < 1e-9 and util.rel_err(gerr, rerr) < 1e-9
+    assert np.sum(gerr ** 2) < np.sum(err0 ** 2)              # still a descent step on this data
+    # field-structured data: groups == exact levels, both forms give the same sweep
+    fields, width = 6, 50
+    pf = fields * width
+    colf = (rng.integers(0, width, (n, fields)) + np.arange(fields)[None, :] * width).astype(np.uint32).ravel()
+    rpf = np.arange(n + 1, dtype=np.int64) * fields
+    valf = rng.normal(0, 1, n * fields).astype(np.float32)
+    w0f, wf, vf = util.params(pf, k, 13, stdev=0.3, fp32=False)
+    errf = oracle.predict_batch(P, oracle.Matrix(rpf, colf, valf, pf), w0f, wf, vf.ravel()) - y
+    outs = []
+    for cap in (0, 3):                                         # exact; approximate (6 levels > 3)
+        ee = engine.Engine(pf, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=cap)
+        ee.set_params(w0f, wf, vf)
+        mm = engine.Matrix.from_csr(rpf, colf, valf, pf, y)
+        assert ee.als_plan(mm)[2] == (cap > 0)
+        outs.append((ee.als_vsweep(mm, errf), ee.get_params()[2]))
+    assert util.rel_err(outs[1][1], outs[0][1]) < 1e-12 and util.rel_err(outs[1][0], outs[0][0]) < 1e-12
+
+
+def test_als_heavy_columns_match_oracle(fm):
+    """A feature that occurs in (almost) every row has a column of thousands of entries: it is swept by a whole workgroup
+    (als_sweep_k) instead of one wave; exact schedule, against the oracle."""
+    engine, L = fm
+    rng = np.random.default_rng(14)
+    n, p, k = 9000, 120, 3
+    rows = [np.unique(np.concatenate([[0] if rng.random() < 0.97 else [], [1] if rng.random() < 0.6 else [], rng.choice(np.arange(2, p), 4, replace=False)])) for _ in range(n)]
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows).astype(np.uint32); val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, 14, "regression")
+    w0, w, v = util.params(p, k, 14, stdev=0.3, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    gerr = e.als_vsweep(m, err0)
+    assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    r0, rw, rvv = oracle.als_learn(P, X, y, w0, w, v.ravel(), 2, with_v=True)     # the learner's w sweep takes the same path
+    e2 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+    e2.set_params(w0, w, v)
+    e2.als_train(m, 2, with_v=True)
+    g0, gw, gv = e2.get_params()
+    assert abs(g0 - r0) < 1e-10 and util.rel_err(gw, rw) < 1e-10 and util.rel_err(gv, rvv.reshape(k, p)) < 1e-10
