@@ -1140,6 +1140,7 @@ int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per
   struct Ctx {
     Slot slot[2];
     hipStream_t ingest = nullptr;
+    bool own_stream = true;
     PlanWorkspace ws;
     ~Ctx() {
       for (auto& s : slot) {
@@ -1148,11 +1149,18 @@ int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per
         if (s.h_counts) (void)hipHostFree(s.h_counts);
         free_matrix(s.m);
       }
-      if (ingest) (void)hipStreamDestroy(ingest);
+      if (ingest && own_stream) (void)hipStreamDestroy(ingest);
     }
   } C;
   const int64_t cap_cnt = B * z;
-  FMX_HIP(hipStreamCreateWithFlags(&C.ingest, hipStreamNonBlocking));
+  // Where the next step's tile is generated and planned: on a second stream beside the running step (FMX_STREAM_OVERLAP=1), or
+  // on the engine's own stream right behind it (default).  Measured at configs[3]'s shape (profiles/r02_stream.txt): side by
+  // side both get slower than back to back -- the sort's streaming passes push the step's gather tables (S: 33 MB) out of the
+  // Infinity Cache -- and the overlapped form loses 15-20 % end to end; in both forms the host only waits for the tile's
+  // three counts, one step ahead of the GPU.
+  static const bool overlap = [] { const char* v = getenv("FMX_STREAM_OVERLAP"); return v && v[0] == '1'; }();
+  if (overlap) FMX_HIP(hipStreamCreateWithFlags(&C.ingest, hipStreamNonBlocking));
+  else { C.ingest = e->stream; C.own_stream = false; }
   FMX_TRY(C.ws.reserve(cap_cnt, (uint32_t)p, C.ingest));
   for (auto& s : C.slot) {
     FMX_TRY(alloc_matrix(e->cfg.device, B, (uint32_t)p, cap_cnt, true, &s.m));

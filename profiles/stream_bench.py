@@ -1,4 +1,5 @@
-"""configs[3] shape on ONE GPU: p = 33 M, 39 nnz/row, k = 32, SGD, 262 144-row steps.
+"""(FMX_STREAM_OVERLAP=1 in the environment: ingest on a second stream beside the running step; default: behind it on the same stream)
+configs[3] shape on ONE GPU: p = 33 M, 39 nnz/row, k = 32, SGD, 262 144-row steps.
   resident : 8 M rows stay in HBM, their tile plans are built once (timed separately), steps run over them;
   streamed : fmx_train_stream -- every step's rows are generated and planned on a second stream while the previous step
              trains, trained on once and dropped (what a 4e9-row job does per GPU); the rate includes generation and ingest.
