@@ -243,8 +243,8 @@ __global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __re
 // its features against a private copy of the residual, the copies are merged afterwards).  Here every feature of a GROUP is
 // such a thread: all of them read the (q, e) of the group's start, each takes its exact coordinate step against that snapshot,
 // and the corrections are merged into the next snapshot by atomic adds.  Groups = the largest position a feature takes in any
-// of its rows (for one-column-per-field data that IS the exact level, and the grouped sweep equals the exact one); groups run
-// in ascending order.  cfg.als_max_levels switches it on; results are then reproducible up to the order of the atomic adds.
+// of its rows (for one-column-per-field data that IS the exact level, and the grouped sweep equals the exact one), after the
+// features with long columns, which are stepped one by one first (see build_plan); groups run in ascending order.  cfg.als_max_levels switches it on; results are then reproducible up to the order of the atomic adds.
 constexpr int ALS_HEAVY = 4096;
 
 template <bool W, bool APPROX, int T>
@@ -374,6 +374,18 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   (void)hipFree(d_level); (void)hipFree(d_changed);
   std::vector<int64_t> cp((size_t)p + 1);
   FMX_HIP(hipMemcpy(cp.data(), m->col_ptr, cp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (approx) {
+    // Features with long columns meet almost every row, and each other: stepping them against one snapshot overshoots (measured:
+    // a Zipf(1.05) matrix diverges within two sweeps).  They go FIRST, one group each, in index order -- an exact Gauss-Seidel
+    // pass over the heavy features -- and the many rare features follow in their position groups.
+    int H = 0;
+    for (uint32_t j = 0; j < p; ++j) if (cp[(size_t)j + 1] - cp[(size_t)j] > ALS_HEAVY) ++H;
+    int h_at = 0;
+    for (uint32_t j = 0; j < p; ++j) {
+      if (cp[(size_t)j + 1] - cp[(size_t)j] > ALS_HEAVY) level[j] = h_at++;
+      else level[j] += H;
+    }
+  }
   int L = 0;
   for (uint32_t j = 0; j < p; ++j) if (level[j] + 1 > L) L = level[j] + 1;
   // per level: the light features (one wave each) and the heavy ones (one workgroup each), ascending index inside a level
@@ -407,6 +419,7 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
   const std::vector<int64_t>& hp = m->als_heavy_ptr;
   const int L = (int)lp.size() - 1;
   double* P = W ? e->dw : e->dV;
+  bool synced = true;  // approximate form: d_qe_new holds what d_qe holds (the caller copied it)
   for (int l = 0; l < L; ++l) {
     const int64_t cnt = lp[(size_t)l + 1] - lp[(size_t)l], hcnt = hp[(size_t)l + 1] - hp[(size_t)l];
     if (cnt + hcnt == 0) continue;
@@ -421,7 +434,15 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
       // (a heavy feature shares rows with nearly everything: it is alone in its level, or with a few other heavy ones)
       if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
                                        (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
+    } else if (cnt + hcnt == 1) {
+      // a group of one: its step against "the snapshot" is the exact step -- in place, no merge (the heavy features' pass)
+      if (hcnt) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, 1, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
+                                   (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
+      else hipLaunchKernelGGL((als_sweep_k<W, false, 64>), gl, blk, 0, e->stream, lf, 1, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
+                              (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
+      synced = false;
     } else {
+      if (!synced) { (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream); synced = true; }
       if (cnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, 64>), gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
                                       (const double2*)d_qe, d_qe_new, alpha, lambda, mu, d_znorm);
       if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,

@@ -879,6 +879,15 @@ def test_als_heavy_columns_match_oracle(fm):
     m = engine.Matrix.from_csr(rp, col, val, p, y)
     gerr = e.als_vsweep(m, err0)
     assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    # the approximate form on the same matrix: the two heavy features are stepped first, one by one, the rest in position groups
+    ea = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=4)
+    ea.set_params(w0, w, v)
+    ma = engine.Matrix.from_csr(rp, col, val, p, y)
+    groups, _, approx, group_of = ea.als_plan(ma)
+    assert approx and group_of[0] == 0 and group_of[1] == 1 and group_of[2:].min() >= 2
+    aerr = ea.als_vsweep(ma, err0)
+    nv, nerr = _numpy_grouped_vsweep(k, p, rp, col.astype(np.int64), val, v, err0, group_of.astype(np.int64))
+    assert util.rel_err(ea.get_params()[2], nv) < 1e-9 and util.rel_err(aerr, nerr) < 1e-9 and np.sum(aerr ** 2) < np.sum(err0 ** 2)
     r0, rw, rvv = oracle.als_learn(P, X, y, w0, w, v.ravel(), 2, with_v=True)     # the learner's w sweep takes the same path
     e2 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
     e2.set_params(w0, w, v)
