@@ -691,11 +691,10 @@ __device__ __forceinline__ ST* exchange_tail(const ColsTables<ST>& T) {
 
 // Main phase-2 kernel: one group of LPR lanes per feature list.  Lists longer than a.long_min entries (heavy hitters of a
 // skewed feature distribution) are left to the long-list kernels below; walking them with one group would serialise the tile.
-#ifndef FMX_COLS_WAVES
-#define FMX_COLS_WAVES 1  // minimum waves per SIMD asked of the register allocator (tuning: 6 caps the kernel at 80 VGPRs, 8 at 64)
-#endif
+// (88-90 VGPRs: 5 workgroups per CU.  Asking the register allocator for 6 waves per SIMD spills to scratch -- phase 2 0.16 -> 0.31 ms per
+// tile -- and 4 or 8 or 16 gathers in flight per lane (FMX_U) change nothing or lose: profiles/r02_small_batch.txt, r02_ab.txt.)
 template <typename ST, int LPR, int KIND>
-__global__ __launch_bounds__(WG_THREADS, FMX_COLS_WAVES) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables<ST> T) {
+__global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables<ST> T) {
   using vec_t = typename Slice<ST>::vec;
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
