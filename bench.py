@@ -41,10 +41,10 @@ def parse():
     ap.add_argument("--nnz", type=int, default=30)
     ap.add_argument("--factors", type=int, default=0, help="0: 16 for sgd (configs[1]), 64 for ftrl (configs[2])")
     ap.add_argument("--batch-rows", type=int, default=0,
-                    help="mini-batch rows per GPU per step (processed in cache-resident tiles).  0: 262144 on one GPU -- the largest step "
+                    help="mini-batch rows per GPU per step (processed in cache-resident tiles).  0: SGD on one GPU 262144 -- the largest step "
                          "that learns per example like a 4096-row one at the reference's learning rate on this workload (a coordinate then "
-                         "occurs ~8 times per step; profiles/r02_learning_*.txt) -- and 1048576 per GPU for N > 1, where the step must be "
-                         "long enough to hide the exchange of the 72 MB buffer (the global batch is N times larger either way)")
+                         "occurs ~8 times per step; profiles/r02_learning_*.txt) -- and 1048576 per GPU for FTRL and for N > 1, where the step "
+                         "must be long enough to hide the exchange of the 72 MB buffer (the global batch is N times larger either way)")
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144; 524288 for k > 32)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--seed", type=int, default=20240001)
@@ -62,7 +62,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp64 state, small batches, sequential mode, ceilings)")
     a = ap.parse_args()
     if a.batch_rows == 0:
-        a.batch_rows = 262_144 if a.gpus == 1 else 1_048_576
+        # SGD, one GPU: 262144 (a coordinate occurs ~8 times per step: learns per example like 4096-row steps at the reference's
+        # learning rate).  FTRL: 1048576 -- its per-coordinate adaptive step keeps learning at ~100 occurrences per step (the fastest
+        # configuration of profiles/r02_learning_ftrl.txt), and the three-table sweep per tile wants the larger 524288-row tiles.
+        a.batch_rows = 262_144 if (a.gpus == 1 and a.solver == "sgd") else 1_048_576
     if a.factors == 0:
         a.factors = 16 if a.solver == "sgd" else 64
     if a.cpu_rows < 0:
