@@ -312,9 +312,11 @@ def main():
         one_step(i)
     fence()
     e.profile_reset()
-    # HIP events around every 16th launch of each kernel, on the engine's stream, inside the timed region (an event pair is a
-    # serialisation point on the stream: timing every launch costs ~5 % of the throughput it is there to explain)
-    e.profile(16)
+    # HIP events around every 15th launch of each kernel, on the engine's stream, inside the timed region (an event pair is a
+    # serialisation point on the stream: timing every launch costs ~5 % of the throughput it is there to explain; an ODD period,
+    # so that the samples walk through the tiles of a multi-tile step -- the first tile of a step only stores its sums, the last
+    # one also applies the update: sampling every 16th launch of a 2-tile step saw only one of the two)
+    e.profile(15)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
