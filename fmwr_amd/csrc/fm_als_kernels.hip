@@ -627,7 +627,7 @@ static double h_trnorm_left(double left) {  // Random.h:52-76
 // fmx.h).  The CLASSIFICATION residual subtracts truncated normals drawn from libc rand() row by row (:529-542), which is a
 // serial stream by construction: y_hat goes to the host, the draws are made there, the residual comes back.  V is never
 // updated, as shipped (SURVEY A-1).
-int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state) {
+int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state, const double* h_state_in) {
   FMX_CHECK(m->rows_sorted, FMX_ERR_INVALID, "the ALS sweeps need every row's columns strictly ascending (as R's dgCMatrix rows are)");
   FMX_TRY(build_full_csc(m, e->stream));
   FMX_TRY(build_plan(m, e->stream, e->cfg.als_max_levels));
@@ -652,6 +652,7 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
   }
   const double alpha_0 = 1.0, gamma_0 = 1.0, beta_0 = 1.0, mu_0 = 0.0, w0_mean_0 = 0.0;  // init(), :59-90 (SURVEY A-7)
   double alpha = 1.0, w_lambda = 0.0, w_mu = 0.0;
+  if (h_state_in) { alpha = h_state_in[0]; w_lambda = h_state_in[1]; w_mu = h_state_in[2]; }  // a chain continued (fmx_mcmc_train_from)
   auto bad = [](double x) { return std::isnan(x) || std::isinf(x); };
   int st = FMX_OK;
 #define MC_HIP(call) do { if (st == FMX_OK) { hipError_t _e = (call); if (_e != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(_e)); st = FMX_ERR_HIP; } } } while (0)
@@ -726,6 +727,61 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
   FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "MCMC training failed: %s", hipGetErrorString(err));
   if (h_state) { h_state[0] = alpha; h_state[1] = w_lambda; h_state[2] = w_mu; }
   return FMX_OK;
+}
+
+// per slab of features: sum (v_fj - mu)^2 of factor f (update_v_lambda, :489-493)
+__global__ __launch_bounds__(WG_THREADS) void mcmc_vstats_partial_k(const double* __restrict__ V, int kp, int f, int64_t p, double mu, double* __restrict__ partials) {
+  __shared__ double red[WG_THREADS];
+  const int64_t base = (int64_t)blockIdx.x * ALS_SLAB;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < ALS_SLAB; i += WG_THREADS) {
+    const int64_t j = base + i;
+    if (j < p) { const double d = V[(size_t)j * kp + f] - mu; a += d * d; }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int off = WG_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// update_v_lambda + update_v_mu (solver/MCMC_ALS_Learner.h:448-517), one attribute group; the O(p k) sums run on the device,
+// the k scalar draws on the host (the caller's standard variates).  Shipped indexing of update_v_mu kept (A-8).
+int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_normals, double* v_lambda, double* v_mu, int sample) {
+  const int64_t p = (int64_t)e->p;
+  const int k = e->k;
+  if (k == 0) return FMX_OK;
+  const int64_t npw = (p + ALS_SLAB - 1) / ALS_SLAB;
+  double* d_part = nullptr;
+  FMX_HIP(hipMalloc(&d_part, (size_t)npw * sizeof(double)));
+  std::vector<double> h_part((size_t)npw), v0((size_t)e->kp64);
+  const double alpha_0 = 1.0, gamma_0 = 1.0, beta_0 = 1.0, mu_0 = 0.0;
+  auto bad = [](double x) { return std::isnan(x) || std::isinf(x); };
+  int st = FMX_OK;
+  for (int f = 0; f < k && st == FMX_OK; ++f) {
+    hipLaunchKernelGGL(mcmc_vstats_partial_k, dim3((unsigned)npw), dim3(WG_THREADS), 0, e->stream, e->dV, e->kp64, f, p, v_mu[f], d_part);
+    if (hipMemcpyAsync(h_part.data(), d_part, (size_t)npw * sizeof(double), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) { set_error("v statistics failed"); st = FMX_ERR_HIP; break; }
+    double g = 0.0;
+    for (int64_t i = 0; i < npw; ++i) g += h_part[(size_t)i];
+    g += beta_0 * (v_mu[f] - mu_0) * (v_mu[f] - mu_0) + gamma_0;
+    const double a = alpha_0 + (double)p + 1.0;
+    const double l_new = sample ? (2.0 / g) * h_gammas[f] : a / g;
+    if (!bad(l_new)) v_lambda[f] = l_new;
+  }
+  if (st == FMX_OK && hipMemcpy(v0.data(), e->dV, (size_t)e->kp64 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { set_error("download of V row 0 failed"); st = FMX_ERR_HIP; }
+  for (int f = 0; f < k && st == FMX_OK; ++f) {
+    double m = 0.0;
+    for (int64_t i = 0; i < p; ++i) m += v0[(size_t)f];  // sic: sum over i of v(f, attr_group[i]) = v(f, 0), p times (:462)
+    m = (m + beta_0 * mu_0) / ((double)p + beta_0);
+    const double var = 1.0 / (((double)p + beta_0) * v_lambda[f]);
+    const double mu_new = sample ? m + std::sqrt(var) * h_normals[f] : m;
+    if (!bad(mu_new)) v_mu[f] = mu_new;
+  }
+  (void)hipFree(d_part);
+  return st;
 }
 
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_qe_raw, double alpha, const double* h_lambda, const double* h_mu,

@@ -176,19 +176,38 @@ static uint32_t random_select(int n) {
   return (uint32_t)((rand() / ((double)RAND_MAX + 1)) * n + 1);
 }
 
-static void visit_order(int64_t n, int random_step, int64_t max_iter, std::vector<int64_t>* out) {
-  out->clear();
-  out->reserve((size_t)max_iter);
+// Resumable form of the loop `for(;;) for (i = random_select(step); i < n; i += random_select(step))`: next(count) appends the
+// next `count` visited rows, drawing from libc rand() exactly as many times and in the same order as the reference does, so
+// a long run can be produced (uploaded, trained on) in bounded pieces instead of one max_iter-sized array.
+struct VisitOrder {
+  int64_t n;
+  int step;
+  uint64_t i = 0;
+  bool in_pass = false;
   int idle = 0;
-  while ((int64_t)out->size() < max_iter) {
-    const size_t before = out->size();
-    for (uint64_t i = random_select(random_step); i < (uint64_t)n; i += random_select(random_step)) {
-      out->push_back((int64_t)i);
-      if ((int64_t)out->size() >= max_iter) break;
+  VisitOrder(int64_t n_, int step_) : n(n_), step(step_) {}
+  // false when nothing can ever be visited (n <= 1)
+  bool pending = false;  // the stride after the last visited row is drawn only when the next row is asked for (the reference
+                         // leaves its loop by `break` BEFORE the increment: the libc stream must not run one draw ahead)
+  bool next(int64_t count, std::vector<int64_t>* out) {
+    out->clear();
+    out->reserve((size_t)count);
+    size_t pass_start = 0;
+    while ((int64_t)out->size() < count) {
+      if (!in_pass) { i = random_select(step); in_pass = true; pending = false; pass_start = out->size(); }
+      else if (pending) { i += random_select(step); pending = false; }
+      if (i < (uint64_t)n) {
+        out->push_back((int64_t)i);
+        pending = true;
+        idle = 0;
+      } else {
+        in_pass = false;  // the pass ended: the outer for(;;) starts the next one with a fresh first stride
+        if (out->size() == pass_start && ++idle > 1000) return false;
+      }
     }
-    if (out->size() == before && ++idle > 1000) break;  // n <= 1: nothing can ever be visited
+    return true;
   }
-}
+};
 
 static void free_matrix(fmx_matrix* m) {
   if (!m) return;
@@ -1088,10 +1107,20 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
   if (max_iter == 0 || m->n == 0) return FMX_OK;
   if (e->group) return group_train(e, m, max_iter, examples_done);
   if (seq_mode(e)) {
+    // the visiting order is produced, uploaded and trained on in pieces: host and device memory stay bounded however many
+    // examples max_iter asks for (the reference counts examples, not passes)
+    const int64_t PIECE = 1 << 22;
+    VisitOrder vo(m->n, e->cfg.random_step);
     std::vector<int64_t> order;
-    visit_order(m->n, e->cfg.random_step, max_iter, &order);
-    FMX_TRY(fmx_train_order(e, m, order.data(), (int64_t)order.size()));
-    if (examples_done) *examples_done = (int64_t)order.size();
+    int64_t done = 0;
+    while (done < max_iter) {
+      const int64_t want = max_iter - done < PIECE ? max_iter - done : PIECE;
+      const bool alive = vo.next(want, &order);
+      if (!order.empty()) FMX_TRY(fmx_train_order(e, m, order.data(), (int64_t)order.size()));
+      done += (int64_t)order.size();
+      if (!alive) break;
+    }
+    if (examples_done) *examples_done = done;
     return FMX_OK;
   }
   int64_t nb = 0;
@@ -1311,7 +1340,7 @@ int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_
     }
   } else if (seq_mode(e)) {
     std::vector<int64_t> order;
-    visit_order(m->n, e->cfg.random_step, max_iter, &order);
+    { VisitOrder vo(m->n, e->cfg.random_step); (void)vo.next(max_iter, &order); }  // (the tracker's record points index into the whole order)
     const int64_t count = (int64_t)order.size();
     if (count > 0) {
       if (hipMalloc(&d_order, (size_t)count * sizeof(int64_t)) != hipSuccess ||
@@ -1596,6 +1625,27 @@ int fmx_mcmc_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double*
   FMX_TRY(use_device(e->cfg.device));
   if (m->n == 0 || max_iter == 0) return FMX_OK;
   return launch_mcmc_train(e, m, max_iter, std_gammas, std_normals, state_out);
+}
+
+int fmx_mcmc_train_from(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double* std_gammas, const double* std_normals, double* state_io) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "MCMC runs on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(state_io != nullptr, FMX_ERR_INVALID, "state_io is NULL (use fmx_mcmc_train to start a chain)");
+  FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  FMX_CHECK(max_iter == 0 || (std_gammas != nullptr && std_normals != nullptr), FMX_ERR_INVALID, "the pre-drawn variates are NULL");
+  FMX_TRY(use_device(e->cfg.device));
+  if (m->n == 0 || max_iter == 0) return FMX_OK;
+  const double in[3] = {state_io[0], state_io[1], state_io[2]};
+  return launch_mcmc_train(e, m, max_iter, std_gammas, std_normals, state_io, in);
+}
+
+int fmx_mcmc_v_hyper(fmx_engine* e, const double* std_gammas, const double* std_normals, double* v_lambda, double* v_mu, int32_t sample) {
+  FMX_CHECK(e != nullptr && v_lambda != nullptr && v_mu != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "MCMC / ALS run on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(!sample || (std_gammas != nullptr && std_normals != nullptr), FMX_ERR_INVALID, "the pre-drawn variates are NULL");
+  FMX_TRY(use_device(e->cfg.device));
+  return launch_mcmc_v_hyper(e, std_gammas, std_normals, v_lambda, v_mu, sample);
 }
 
 int fmx_rccl_selftest(int32_t n, double* max_err) { return group_rccl_selftest(n, max_err); }

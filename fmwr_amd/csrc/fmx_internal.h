@@ -379,7 +379,8 @@ int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std);
 
 int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v);
 int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest, int32_t* approx, int32_t* level_of);
-int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state);
+int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* h_gammas, const double* h_normals, double* h_state, const double* h_state_in = nullptr);
+int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_normals, double* v_lambda, double* v_mu, int sample);
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu,
                       const double* d_znorm);
 

@@ -342,6 +342,22 @@ class Engine:
         L.check(L.lib().fmx_mcmc_train(self.h, m.h, C.c_int32(max_iter), _p(g), _p(z), _p(state)))
         return tuple(state)
 
+    def mcmc_train_from(self, m, max_iter, std_gammas, std_normals, state):
+        """the chain continued from state = (alpha, w_lambda, w_mu); returns the new state"""
+        g = np.ascontiguousarray(std_gammas, np.float64); z = np.ascontiguousarray(std_normals, np.float64)
+        st = np.ascontiguousarray(state, np.float64).copy()
+        L.check(L.lib().fmx_mcmc_train_from(self.h, m.h, C.c_int32(max_iter), _p(g), _p(z), _p(st)))
+        return tuple(st)
+
+    def mcmc_v_hyper(self, v_lambda, v_mu, std_gammas=None, std_normals=None):
+        """update_v_lambda + update_v_mu; variates given: the MCMC draws, else the ALS means.  Returns (v_lambda, v_mu)."""
+        lam = np.ascontiguousarray(v_lambda, np.float64).copy(); mu = np.ascontiguousarray(v_mu, np.float64).copy()
+        sample = std_gammas is not None
+        g = None if not sample else np.ascontiguousarray(std_gammas, np.float64)
+        z = None if not sample else np.ascontiguousarray(std_normals, np.float64)
+        L.check(L.lib().fmx_mcmc_v_hyper(self.h, _p(g), _p(z), _p(lam), _p(mu), C.c_int32(int(sample))))
+        return lam, mu
+
     def als_plan(self, m):
         """(levels or groups, size of the largest, approximate?, level / group of every feature) of the ALS sweeps on this matrix."""
         lv, big, ap = C.c_int64(), C.c_int64(), C.c_int32()

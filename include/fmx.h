@@ -354,6 +354,17 @@ int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v
  * (util/Random.h:20-93; one host thread).  V is never updated, as shipped (SURVEY A-1).  state_out[3]: alpha, w_lambda, w_mu. */
 int fmx_mcmc_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double* std_gammas, const double* std_normals, double* state_out);
 
+/* The same chain continued: state_io[3] = {alpha, w_lambda, w_mu} on entry (what an earlier call returned) and on return.  Lets the
+ * caller interleave evaluations with iterations -- the tracker block of MCMC_ALS_Learner::learn (:96-125) is, per record point,
+ * fmx_evaluate(...) followed by fmx_mcmc_train_from(e, m, 1, gammas + 2*it, normals + (2+p)*it, state). */
+int fmx_mcmc_train_from(fmx_engine* e, fmx_matrix* m, int32_t max_iter, const double* std_gammas, const double* std_normals, double* state_io);
+/* V hyper-priors of the MCMC / ALS learners: update_v_lambda then update_v_mu (solver/MCMC_ALS_Learner.h:448-517; in the shipped
+ * code their caller is commented out together with the V sweep, :151-155), one attribute group.  v_lambda, v_mu: f64[k] in/out
+ * (what fmx_mcmc_vsweep / fmx_als_vsweep take).  sample != 0 (MCMC): std_gammas[k] standard Gamma variates of shape (2 + p)/2,
+ * std_normals[k] standard normals, in factor order -- under R: g <- rgamma(k, (2+p)/2); z <- rnorm(k).  sample == 0 (ALS): the
+ * means, no variates.  The shipped update_v_mu sums v(f, attr_group[i]) instead of v(f, i) (:462): kept. */
+int fmx_mcmc_v_hyper(fmx_engine* e, const double* std_gammas, const double* std_normals, double* v_lambda, double* v_mu, int32_t sample);
+
 /* ---- measurement: HIP-event timing of each kernel on the engine's stream (bench.py roofline leg). */
 #define FMX_KERNEL_ROWS_FORWARD 0 /* phase 1: V-row gather + forward + grad multiplier */
 #define FMX_KERNEL_COLS_UPDATE 1  /* phase 2: per-feature gradient sums + update */

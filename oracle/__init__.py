@@ -366,6 +366,13 @@ def mcmc_learn(P, X, y, w0, w, v, max_iter, gammas, normals, seed=None):
     return w0c.value, w, v, tuple(state)
 
 
+def mcmc_v_hyper(k, p, v, std_gammas, std_normals, v_lambda, v_mu, sample=True):
+    """update_v_lambda + update_v_mu (fm_oracle.c fmo_mcmc_v_hyper); returns (v_lambda, v_mu)."""
+    lam = _f64(v_lambda).copy(); mu = _f64(v_mu).copy()
+    lib().fmo_mcmc_v_hyper(C.c_int(k), C.c_uint32(p), _ptr(_f64(v)), _ptr(_f64(std_gammas)), _ptr(_f64(std_normals)), _ptr(lam), _ptr(mu), C.c_int(int(sample)))
+    return lam, mu
+
+
 def als_learn_traced(P, X, y, w0, w, v, max_iter, with_v=False):
     """als_learn with the tracker on (P.trace_step > 0, P.eval_type): returns (w0, w, v, iters, evals)."""
     col_ptr, row_idx, val_t = X.transpose()

@@ -934,6 +934,7 @@ void fmo_mcmc_learn(const fmo_params* P, uint32_t p, double* w0, double* w, doub
                     const double* gammas, const double* normals, double* state) {
   const double alpha_0 = 1.0, gamma_0 = 1.0, beta_0 = 1.0, mu_0 = 0.0, w0_mean_0 = 0.0;
   double alpha = 1.0, w_lambda = 0.0, w_mu = 0.0;
+  if (state && state[0] > 0.0) { alpha = state[0]; w_lambda = state[1]; w_mu = state[2]; } /* resume (engine semantics: fmx_mcmc_train_from) */
   double* error = (double*)malloc(sizeof(double) * (size_t)(X->n ? X->n : 1));
   for (int it = 0; it < max_iter; ++it) {
     const double* G = gammas + (size_t)it * 2;
@@ -970,6 +971,32 @@ void fmo_mcmc_learn(const fmo_params* P, uint32_t p, double* w0, double* w, doub
   }
   if (state) { state[0] = alpha; state[1] = w_lambda; state[2] = w_mu; }
   free(error);
+}
+
+/* solver/MCMC_ALS_Learner.h:448-517 update_v_lambda + update_v_mu (called in that order by the update_all block the shipped
+ * code comments out, :151-155; SURVEY A-1), one attribute group, do_multilevel.  sample != 0: the MCMC learner with the
+ * caller's standard variates (std_gammas[f]: shape (alpha_0 + p + 1)/2, scale 1; std_normals[f]); sample == 0: the ALS
+ * learner's means.  Shipped indexing kept: update_v_mu sums v(f, attr_group[i]) -- with one group that is p times v(f, 0),
+ * not the sum over the features (:462, SURVEY A-8).  init(): alpha_0 = gamma_0 = beta_0 = 1, mu_0 = 0.  v is [k][p]. */
+void fmo_mcmc_v_hyper(int k, uint32_t p, const double* v, const double* std_gammas, const double* std_normals, double* v_lambda, double* v_mu,
+                      int sample) {
+  const double alpha_0 = 1.0, gamma_0 = 1.0, beta_0 = 1.0, mu_0 = 0.0;
+  for (int f = 0; f < k; ++f) { /* update_v_lambda, :482-517 */
+    double g = 0.0;
+    for (uint32_t i = 0; i < p; ++i) g += (v[(size_t)f * p + i] - v_mu[f]) * (v[(size_t)f * p + i] - v_mu[f]);
+    g += beta_0 * (v_mu[f] - mu_0) * (v_mu[f] - mu_0) + gamma_0;
+    const double a = alpha_0 + (double)p + 1.0;
+    const double l_new = sample ? (2.0 / g) * std_gammas[f] : a / g; /* Rf_rgamma(a / 2, 2 / g) */
+    if (!fmo_bad(l_new)) v_lambda[f] = l_new;
+  }
+  for (int f = 0; f < k; ++f) { /* update_v_mu, :448-479 */
+    double m = 0.0;
+    for (uint32_t i = 0; i < p; ++i) m += v[(size_t)f * p + 0]; /* sic: v(f, attr_group[i]) with attr_group[i] == 0 */
+    m = (m + beta_0 * mu_0) / ((double)p + beta_0);
+    const double var = (double)1.0 / (((double)p + beta_0) * v_lambda[f]);
+    const double mu_new = sample ? m + sqrt(var) * std_normals[f] : m;
+    if (!fmo_bad(mu_new)) v_mu[f] = mu_new;
+  }
 }
 
 /* ================================================================== engine semantics (not in reference)

@@ -894,3 +894,60 @@ def test_als_heavy_columns_match_oracle(fm):
     e2.als_train(m, 2, with_v=True)
     g0, gw, gv = e2.get_params()
     assert abs(g0 - r0) < 1e-10 and util.rel_err(gw, rw) < 1e-10 and util.rel_err(gv, rvv.reshape(k, p)) < 1e-10
+
+
+def test_mcmc_v_hyper_priors_and_the_tracker_loop(fm):
+    """f-4 completed: (1) update_v_lambda + update_v_mu (MCMC_ALS_Learner.h:448-517; shipped v(f, attr_group[i]) indexing kept)
+    against the oracle, MCMC draws and ALS means; one full Gibbs step over V as the commented-out block of update_all would run
+    it: hyper-priors, then the sweep with them.  (2) the MCMC chain continued call by call (fmx_mcmc_train_from) equals the
+    one-shot chain, which is what the tracker block of learn() (:96-125) needs: evaluate, one iteration, evaluate, ..."""
+    engine, L = fm
+    n, fields, width, k = 1500, 5, 30, 4
+    p = fields * width
+    rng = np.random.default_rng(91)
+    rp = np.arange(n + 1, dtype=np.int64) * fields
+    col = (rng.integers(0, width, (n, fields)) + np.arange(fields)[None, :] * width).astype(np.uint32).ravel()
+    val = rng.normal(0, 1, n * fields).astype(np.float32)
+    y = util.labels(n, 91, "regression")
+    w0, w, v = util.params(p, k, 91, stdev=0.3, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL, min_target=float(y.min()), max_target=float(y.max()))
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    lam0 = np.full(k, 0.5); mu0 = np.linspace(-0.1, 0.1, k)
+    g = rng.gamma((2.0 + p) / 2.0, 1.0, k); z = rng.normal(0, 1, k)
+    for sample in (True, False):
+        rl, rm = oracle.mcmc_v_hyper(k, p, v.ravel(), g, z, lam0, mu0, sample=sample)
+        gl, gm = e.mcmc_v_hyper(lam0, mu0, g, z) if sample else e.mcmc_v_hyper(lam0, mu0)
+        np.testing.assert_allclose(gl, rl, rtol=1e-11); np.testing.assert_allclose(gm, rm, rtol=1e-11, atol=1e-15)
+    # a Gibbs step over V: hyper-priors, then the sweep under them
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    zn = rng.normal(0, 1, (k, p))
+    rl, rm = oracle.mcmc_v_hyper(k, p, v.ravel(), g, z, lam0, mu0)
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=0.8, v_lambda=rl, v_mu=rm, znorm=zn.ravel())
+    gl, gm = e.mcmc_v_hyper(lam0, mu0, g, z)
+    gerr = e.als_vsweep(m, err0, alpha=0.8, v_lambda=gl, v_mu=gm, std_normals=zn)
+    assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    # (2) the chain in pieces, with an evaluation before every iteration (Tracker: metric of the model at the START of the iteration)
+    iters = 5
+    a1, a2 = oracle.mcmc_draw_shapes(n, p)
+    G = np.stack([rng.gamma(a1, 1.0, iters), rng.gamma(a2, 1.0, iters)], 1)
+    Z = rng.normal(0, 1, (iters, 2 + p))
+    one = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL, min_target=float(y.min()), max_target=float(y.max()))
+    one.set_params(w0, w, v)
+    st_one = one.mcmc_train(m, iters, G, Z)
+    step = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL, min_target=float(y.min()), max_target=float(y.max()))
+    step.set_params(w0, w, v)
+    trace = [step.evaluate(m, L.EVAL_RMSE)]
+    st = step.mcmc_train(m, 1, G[:1], Z[:1])
+    for it in range(1, iters):
+        trace.append(step.evaluate(m, L.EVAL_RMSE))
+        st = step.mcmc_train_from(m, 1, G[it:it + 1], Z[it:it + 1], st)
+    a, b = one.get_params(), step.get_params()
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and st == st_one
+    r0, rw, rvv, rst = oracle.mcmc_learn(P, X, y, w0, w, v.ravel(), iters, G, Z)
+    np.testing.assert_allclose(st, rst, rtol=1e-9)
+    # the first record is the start model's clamped RMSE (:103-111), from the oracle's forward
+    yh = np.clip(oracle.predict_batch(P, X, w0, w, v.ravel()), y.min(), y.max())
+    assert abs(trace[0] - oracle.evaluate(oracle.REGRESSION, oracle.RMSE, yh, y)) < 1e-9 and len(trace) == iters
