@@ -547,7 +547,7 @@ __device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const V
 // kernel (short lists) and the long-list finisher.  Called by every lane of the feature's group; lig == 0 handles w.
 template <typename ST, int LPR, int KIND>
 __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, const ColsTables<ST>& T, int64_t j, int lig, const double* vf,
-                                            CoordSums& s, double rows, int64_t ci = 0) {
+                                            CoordSums& s, double rows, int64_t ci = 0, const ST* w_pre = nullptr) {
   using vec_t = typename Slice<ST>::vec;
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
@@ -642,7 +642,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
     for (int q = 0; q < 5; ++q) *reinterpret_cast<vec_t*>(tabs[q] + at) = slice_make(st[q], ST());
     if (lig == 0) {  // like FTRL, TDAP recomputes w on every touched column even with keep.w1 off (TDAP_Learner.h:203-214)
       ST u = T.nw[j], nu = T.t1w[j], dl = T.t2w[j], hh = T.t3w[j], z = T.sw[j];
-      const double wn = tdap_update<ST>(h, true, (double)T.w[j], s.Gw, s.Qw, cnt, u, nu, dl, hh, z, h.k1 != 0);
+      const double wn = tdap_update<ST>(h, true, (double)(w_pre ? *w_pre : T.w[j]), s.Gw, s.Qw, cnt, u, nu, dl, hh, z, h.k1 != 0);
       T.w[j] = (ST)wn;
       T.nw[j] = u; T.t1w[j] = nu; T.t2w[j] = dl; T.t3w[j] = hh; T.sw[j] = z;
     }
@@ -676,7 +676,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
       ST wa = (ST)0, wb = (ST)0;
       if constexpr (KIND != UPD_SGD_L2) wa = T.sw[j];
       if constexpr (KIND == UPD_FTRL) wb = T.nw[j];
-      const double wn = coord_update<KIND, ST>(h, true, (double)T.w[j], s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
+      const double wn = coord_update<KIND, ST>(h, true, (double)(w_pre ? *w_pre : T.w[j]), s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
       T.w[j] = (ST)wn;
       if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
       if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
@@ -721,6 +721,9 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
 #pragma unroll
   for (int i = 0; i < VEC; ++i) vf[i] = 0.0;
   if (have) slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
+  // w_j is needed only after the walk: ask for it now, beside the V row, instead of paying its round trip at the end
+  ST w_pre = (ST)0;
+  if (have && lig == 0 && a.apply) w_pre = T.w[j];
   CoordSums s;
   sums_zero(s);
 
@@ -732,75 +735,93 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
     const ST* __restrict__ St = T.S + lig * VEC;
     const __amdgpu_buffer_rsrc_t s_rsrc = table_rsrc(T.S, a.buf_gather ? (uint32_t)(T.s_rows * (KP * sizeof(ST))) : 0u);
     const __amdgpu_buffer_rsrc_t a_rsrc = table_rsrc(T.amul, a.buf_gather ? (uint32_t)(T.s_rows * sizeof(ST)) : 0u);
-    int64_t c0 = lo;
-    while (c0 < hi) {
-      if (a.long_min > 0) {
-        // The entries of long lists lie between those of this workgroup's short lists (one heavy hitter can hold 10^5 of
-        // them): jump straight to the first entry that a short list still needs.
-        if (tid == 0) wg_next = ~0ull;
-        __syncthreads();
-        if (tb > c0) atomicMin(&wg_next, (unsigned long long)(ta > c0 ? ta : c0));
-        __syncthreads();
-        const unsigned long long nx = wg_next;
-        __syncthreads();
-        if (nx == ~0ull) break;
-        c0 = (int64_t)nx;
+    // one batch of FMX_U entries of this group's list: gather the S rows (and multipliers), add the occurrences in row order
+    auto take = [&](uint2 (&en)[FMX_U]) {
+      bool ok[FMX_U];
+#pragma unroll
+      for (int u = 0; u < FMX_U; ++u) {
+        ok[u] = en[u].x < a.rows_active;  // truncated batch: rows beyond the limit do not take part (padding slots: 0xFFFFFFFF)
+        if (!ok[u]) en[u].x = 0;
       }
-      const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
-      const int64_t b = ta > c0 ? ta : c0;
-      const int64_t e = tb < c0 + cn ? tb : c0 + cn;
-      stage_entries(stage, a.brow, a.bval, c0, cn, a.unit);
-      __syncthreads();
-      for (int64_t t = b; t < e; t += FMX_U) {
-        const int o = (int)(t - c0);
-        uint2 en[FMX_U];
-        bool ok[FMX_U];
+      vec_t sv[FMX_U];
+      ST av[FMX_U];
+      if (a.buf_gather) {  // wave-uniform: padding slots issue no request
 #pragma unroll
-        for (int u = 0; u < FMX_U; ++u) {
-          en[u] = (t + u < e) ? stage[o + u] : make_uint2(0xFFFFFFFFu, 0u);
-          ok[u] = en[u].x < a.rows_active;  // truncated batch: rows beyond the limit do not take part
-          if (!ok[u]) en[u].x = 0;
-        }
-        vec_t sv[FMX_U];
-        ST av[FMX_U];
-        if (a.buf_gather) {  // wave-uniform: padding slots issue no request
+        for (int u = 0; u < FMX_U; ++u) sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
+        if (a.embed) {
+          if constexpr (sizeof(ST) == 4) {
 #pragma unroll
-          for (int u = 0; u < FMX_U; ++u) sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
-          if (a.embed) {
-            if constexpr (sizeof(ST) == 4) {
-#pragma unroll
-              for (int u = 0; u < FMX_U; ++u) av[u] = embed_take<LPR>(sv[u], lig, a.embed);
-            }
-          } else {
-#pragma unroll
-            for (int u = 0; u < FMX_U; ++u) av[u] = buf_elem(a_rsrc, ok[u] ? en[u].x * (uint32_t)sizeof(ST) : BUF_SKIP, ST());
+            for (int u = 0; u < FMX_U; ++u) av[u] = embed_take<LPR>(sv[u], lig, a.embed);
           }
         } else {
 #pragma unroll
-          for (int u = 0; u < FMX_U; ++u) {
-            sv[u] = gather_row(St + (size_t)en[u].x * KP);
-            av[u] = T.amul[en[u].x];
-          }
-          if constexpr (sizeof(ST) == 4) {
-            if (a.embed) {
+          for (int u = 0; u < FMX_U; ++u) av[u] = buf_elem(a_rsrc, ok[u] ? en[u].x * (uint32_t)sizeof(ST) : BUF_SKIP, ST());
+        }
+      } else {
 #pragma unroll
-              for (int u = 0; u < FMX_U; ++u) (void)embed_take<LPR>(sv[u], lig, a.embed);  // strip the embedded bits; the side table gave the multiplier
-            }
+        for (int u = 0; u < FMX_U; ++u) {
+          sv[u] = gather_row(St + (size_t)en[u].x * KP);
+          av[u] = T.amul[en[u].x];
+        }
+        if constexpr (sizeof(ST) == 4) {
+          if (a.embed) {
+#pragma unroll
+            for (int u = 0; u < FMX_U; ++u) (void)embed_take<LPR>(sv[u], lig, a.embed);  // strip the embedded bits; the side table gave the multiplier
           }
         }
-#pragma unroll
-        for (int u = 0; u < FMX_U; ++u)  // occurrences in row order
-          if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(en[u].y));
       }
-      __syncthreads();
-      c0 += STAGE_ENTRIES;
+#pragma unroll
+      for (int u = 0; u < FMX_U; ++u)  // occurrences in row order
+        if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(en[u].y));
+    };
+    if (a.direct) {
+      // Sparse tiles (lists of one or two entries): every group reads its own entries straight from memory -- neighbouring groups
+      // read neighbouring addresses, so the loads coalesce by themselves -- and the workgroup never meets at a barrier: one
+      // dependent round trip fewer per list, in a regime that is nothing but dependent round trips.
+      for (int64_t t = ta; t < tb; t += FMX_U) {
+        uint2 en[FMX_U];
+#pragma unroll
+        for (int u = 0; u < FMX_U; ++u)
+          en[u] = (t + u < tb) ? make_uint2(a.brow[t + u], a.unit ? 0x3f800000u : __float_as_uint(a.bval[t + u])) : make_uint2(0xFFFFFFFFu, 0u);
+        take(en);
+      }
+    } else {
+      int64_t c0 = lo;
+      while (c0 < hi) {
+        if (a.long_min > 0) {
+          // The entries of long lists lie between those of this workgroup's short lists (one heavy hitter can hold 10^5 of
+          // them): jump straight to the first entry that a short list still needs.
+          if (tid == 0) wg_next = ~0ull;
+          __syncthreads();
+          if (tb > c0) atomicMin(&wg_next, (unsigned long long)(ta > c0 ? ta : c0));
+          __syncthreads();
+          const unsigned long long nx = wg_next;
+          __syncthreads();
+          if (nx == ~0ull) break;
+          c0 = (int64_t)nx;
+        }
+        const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
+        const int64_t b = ta > c0 ? ta : c0;
+        const int64_t e = tb < c0 + cn ? tb : c0 + cn;
+        stage_entries(stage, a.brow, a.bval, c0, cn, a.unit);
+        __syncthreads();
+        for (int64_t t = b; t < e; t += FMX_U) {
+          const int o = (int)(t - c0);
+          uint2 en[FMX_U];
+#pragma unroll
+          for (int u = 0; u < FMX_U; ++u) en[u] = (t + u < e) ? stage[o + u] : make_uint2(0xFFFFFFFFu, 0u);
+          take(en);
+        }
+        __syncthreads();
+        c0 += STAGE_ENTRIES;
+      }
     }
   }
   ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
   if (a.apply && a.load_gbuf && rows <= 0.0) rows = tail_get_rows(gtail);  // the global row count travelled in the reduced buffer
 
-  if (have) cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows, I0 + gid);
+  if (have) cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows, I0 + gid, &w_pre);
 
   if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
     scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
@@ -1000,6 +1021,8 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
   static const bool buf_ok = [] { const char* v = getenv("FMX_BUF_GATHER"); return !(v && v[0] == '0'); }();
   static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
   a.embed = embed_ok ? embed_mode(e->k, mb_kp(e), !mb_wide(e)) : EMBED_NONE;
+  static const bool direct_ok = [] { const char* v = getenv("FMX_DIRECT_LISTS"); return !(v && v[0] == '0'); }();
+  a.direct = (direct_ok && a.walk && a.tfeat && a.n_tfeat > 0 && a.list_entries < 4 * (int64_t)a.n_tfeat) ? 1 : 0;  // sparse tile, lists of < 4 entries on average
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;

@@ -300,6 +300,8 @@ struct ColsArgs {
   int store_compact;     // compact exchange: write one record per occurring feature (sparse walk only)
   int compact_tail;      // the scalar tail is the compact exchange's own 4 elements, not the end of the dense buffer
   int unit;              // every value of the tile is 1.0f: bval is not read
+  int direct;            // set by the launcher: every group reads its list's entries itself (sparse tiles), no LDS staging
+  int64_t list_entries;  // entries of the tile (sparse walk: decides `direct`)
   int embed;             // EmbedMode of the S rows (set by the launcher; must match phase 1's)
   int buf_gather;        // set by the launcher: S rows / multipliers are gathered through buffer descriptors (padding slots issue no request)
 };
