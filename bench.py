@@ -47,6 +47,10 @@ def parse():
                          "must be long enough to hide the exchange of the 72 MB buffer (the global batch is N times larger either way)")
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144; 524288 for k > 32)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
+    ap.add_argument("--workload", choices=["uniform", "criteo"], default="uniform",
+                    help="uniform: BASELINE.json configs[1] / [2] (one column per stratum).  criteo: configs[3]'s shape -- 33 M features, 39 nnz/row "
+                         "(13 dense + 26 categorical fields with power-law heads), k = 32, 262144-row steps of one sparse tile; --rows rows resident "
+                         "per GPU (default 8 M); N > 1 exchanges the occurring features' records (compact exchange)")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
@@ -61,6 +65,13 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (0: skip; -1: 5M for sgd, 250K for ftrl k=64: 10-20 s of one core either way)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp64 state, small batches, sequential mode, ceilings)")
     a = ap.parse_args()
+    if a.workload == "criteo":
+        a.features, a.nnz = 33_000_000, 39
+        a.factors = a.factors or 32
+        a.batch_rows = a.batch_rows or 262_144
+        if a.rows == 10_000_000:
+            a.rows = 8_000_000 * a.gpus
+        a.no_extras, a.cpu_rows = True, 0
     if a.batch_rows == 0:
         # SGD, one GPU: 262144 (a coordinate occurs ~8 times per step: learns per example like 4096-row steps at the reference's
         # learning rate).  FTRL: 1048576 -- its per-coordinate adaptive step keeps learning at ~100 occurrences per step (the fastest
@@ -275,10 +286,18 @@ def main():
     r0, r1 = shard_rows(args.rows, rank, world)
     n_local = r1 - r0
     B = min(args.batch_rows, args.rows // world)
-    m = engine.Matrix.synthetic(n_local, p, z, args.seed, row_offset=r0, device=local_rank)
+    criteo = args.workload == "criteo"
+    if criteo:
+        m = engine.Matrix.synthetic_fields(n_local, 13, engine.CRITEO_VOCAB, 3.0, args.seed, row_offset=r0, device=local_rank)
+    else:
+        m = engine.Matrix.synthetic(n_local, p, z, args.seed, row_offset=r0, device=local_rank)
     e = engine.Engine(p, **engine_kwargs(args, L, B, local_rank, world))
-    v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
-    e.set_params(0.0, None, v0.astype(np.float64))
+    if criteo:
+        v0 = None
+        e.init_normal(args.seed, 0.0, 0.01)  # drawn on the device (k x p doubles would be 8.4 GB through the host); same on every replica
+    else:
+        v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p)).astype(np.float32)  # same V0 on every replica
+        e.set_params(0.0, None, v0.astype(np.float64))
     nb_full = max(1, n_local // B)  # ragged tail batch left out so every step does the same work
     e.sync()
     t_ing = time.perf_counter()
@@ -342,7 +361,11 @@ def main():
         e.sync()
         fwd_rate = 3 * n_local / (time.perf_counter() - t1)
 
-    w0, _, vv = e.get_params()
+    if criteo:
+        _, vv = e.get_rows(np.arange(0, p, max(1, p // 100_000), dtype=np.uint32))
+        w0 = 0.0
+    else:
+        w0, _, vv = e.get_params()
     if not (np.isfinite(w0) and np.all(np.isfinite(vv))):
         raise SystemExit("non-finite parameters after the timed region")
 
@@ -371,11 +394,14 @@ def main():
         step_gbs = b_step / (dt / args.steps) / 1e9   # per GPU: B rows of this rank per step
         traffic = per_kernel[dom]["traffic"]
         out = {
-            "metric": "training examples/sec, 10Mx1M sparse FM SGD", "value": value, "unit": "examples/s",
+            "metric": "training examples/sec, 10Mx1M sparse FM SGD" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
+            "value": value, "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.state_fp64 else "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch "
-                                   f"(BASELINE.json configs[{2 if ftrl else 1}])",
+            "config": {"workload": (f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch "
+                                    f"(BASELINE.json configs[{2 if ftrl else 1}])") if not criteo else
+                                   (f"Criteo-shaped synthetic {args.rows}x{p} resident ({z} nnz/row: 13 dense + 26 categorical fields, skew 3), k={k}, "
+                                    f"{args.solver.upper()} mini-batch (BASELINE.json configs[3]'s shape; its 4e9 rows are streamed: fmx_train_stream)"),
                        "batch_rows_per_gpu": B, "tile_rows": tile_rows, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
                        "batch_reduce": "mean gradient per coordinate per step (FMX_REDUCE_MEAN)",
                        "state": ("fp64" if args.state_fp64 else "fp32") + " V[p][k] + w[p]" + (" + z, n" if ftrl else "") + ", fp64 accumulation",

@@ -80,7 +80,7 @@ TDAP_SOLVER_DEFAULT = {"gamma": 1e-4, "alpha_w": 0.1, "alpha_v": 0.1, "random_st
 
 
 def TDAP_solver(**kw):
-    """TDAP.solver() -- R/fm_solver_control.R:141-155 (row f-3; runs in mode="sequential" only)."""
+    """TDAP.solver() -- R/fm_solver_control.R:141-155 (row f-3; sequential mode = the shipped algorithm; mode="minibatch" = the mini-batch form defined in DESIGN.md section 4)."""
     return {"solver": "TDAP", **_control_assign(TDAP_SOLVER_DEFAULT, kw)}
 
 
@@ -231,11 +231,24 @@ def _train(data, controls, w0, w, v, target_range, mode, batch_rows, device, nor
     sol = controls["solver"]["solver"]["solver"]
     track = controls["track"]
     trace, convergent = None, False
-    if sol == "MCMC":  # MCMC_Learner: the tracker block of its loop is not wired (track.control is ignored for this solver)
+    if sol == "MCMC":
         hp = controls["model"]["hyper.params"]
         iters = int(controls["solver"]["max_iter"])
         g, z = _mcmc_draws(rng if rng is not None else np.random.default_rng(), data.dim[0], p, iters, bool(hp["keep.w0"]), bool(hp["keep.w1"]))
-        eng.mcmc_train(m, iters, g, z)
+        if track["step_size"] > 0 and iters > 0:
+            # the tracker block of MCMC_ALS_Learner::learn (:96-125): the model at the START of iterations 0, step, 2 step, ... and of
+            # the last one is scored (clamped predictions / fast_pnorm) and snapshotted; the chain continues call by call
+            metric = getattr(L, "EVAL_" + track["evaluate.metric"])
+            idx, evals, snaps, state, ii = [], [], [], None, -1
+            for it in range(iters):
+                ii = 0 if ii + 1 == track["step_size"] else ii + 1
+                if ii == 0 or it == iters - 1:
+                    idx.append(it); evals.append(eng.evaluate(m, metric))
+                    a, b, c = eng.get_params(); snaps.append({"w0": a, "w": b, "v": c})
+                state = eng.mcmc_train(m, 1, g[it:it + 1], z[it:it + 1]) if state is None else eng.mcmc_train_from(m, 1, g[it:it + 1], z[it:it + 1], state)
+            trace = {"trace": [np.asarray(idx)] + snaps, "evaluation.train": np.asarray(evals)}
+        else:
+            eng.mcmc_train(m, iters, g, z)
     elif track["step_size"] > 0:  # learner->tracker.step_size > 0: Learner::learn evaluates, snapshots and may stop early
         metric = getattr(L, "EVAL_" + track["evaluate.metric"])
         r = eng.train_tracked(m, controls["solver"]["max_iter"], track["step_size"], metric, track["convergence"], keep_params=True)

@@ -237,6 +237,18 @@ def test_mcmc_solver_through_the_api():
     assert np.max(np.abs(fit["Model"]["w"] - wt)) < 0.1 and abs(fit["Model"]["w0"] - 0.5) < 0.1  # the posterior sits on the truth
     pred = fm.predict(fit, data, normalize=False)
     assert np.mean((pred - y) ** 2) < 0.1 * np.var(y)
+    # with track.control the loop's tracker block runs (MCMC_ALS_Learner::learn :96-125): same chain, plus the RMSE of the model
+    # at the START of iterations 0, 10, 20 and of the last one, with their snapshots; fm.select can pick from them
+    ctl_t = ctl + [fm.track_control(step_size=10, evaluate_metric="RMSE")]
+    fit_t = fm.fm_train(data, normalize=False, control=ctl_t, seed=9)
+    assert fit_t["Model"]["w0"] == fit["Model"]["w0"] and np.array_equal(fit_t["Model"]["w"], fit["Model"]["w"])
+    tr = fit_t["Trace"]
+    assert list(tr["trace"][0]) == [0, 10, 20, 24] and len(tr["trace"]) == 5
+    ev = tr["evaluation.train"]
+    assert ev[0] > ev[1] > ev[-1] * 0.5 and ev[-1] < 0.5 * ev[0]          # the chain moves to the data
+    assert tr["trace"][1]["w0"] == 0.0 and np.all(tr["trace"][1]["w"] == 0.0)   # record 0 is the initial model
+    r10, rw10, _, _ = oracle.mcmc_learn(P, oracle.Matrix(X.indptr, X.indices, X.data, p), y.astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 10, gam[:10], z[:10])
+    assert abs(tr["trace"][2]["w0"] - r10) < 1e-9 and np.max(np.abs(tr["trace"][2]["w"] - rw10)) < 1e-9  # the snapshot before iteration 10
 
 
 def test_c_abi_argument_checks_for_the_newer_entry_points():

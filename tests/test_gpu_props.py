@@ -261,3 +261,20 @@ def test_configs2_full_size_ftrl_is_reproducible_and_forms_agree(fm, big):
     scale = np.max(np.abs(a[2]))
     for other in (c, d):
         assert np.max(np.abs(other[2] - a[2])) < 5e-6 * scale and abs(other[0] - a[0]) < 1e-8
+
+
+def test_iid_generators_rows_are_strictly_ascending_and_follow_their_law(fm):
+    """SURVEY 8(d)'s i.i.d. column laws (fmx_matrix_synthetic_iid): rows strictly ascending and in range, labels as the other
+    generators', shard independent; uniform columns are flat over [0, p), Zipf(1.05) columns pile up on the first ids."""
+    engine, L = fm
+    n, p, z = 20_000, 50_000, 30
+    for law, s_exp in ((L.COLUMNS_UNIFORM, 1.05), (L.COLUMNS_ZIPF, 1.05)):
+        m = engine.Matrix.synthetic_iid(n, p, z, 9, law, s_exp)
+        rp, col, val, y = m.export()
+        c = col.reshape(n, z).astype(np.int64)
+        assert np.array_equal(rp, np.arange(n + 1) * z) and c.min() >= 0 and c.max() < p
+        assert np.all(np.diff(c, axis=1) > 0) and np.all(val == 1.0) and set(np.unique(y)) == {-1.0, 1.0}
+        head = np.mean(c < p // 100)
+        assert (0.005 < head < 0.02) if law == L.COLUMNS_UNIFORM else head > 0.4
+        part = engine.Matrix.synthetic_iid(1000, p, z, 9, law, s_exp, row_offset=n - 1000).export()
+        assert np.array_equal(part[1], col[(n - 1000) * z:]) and np.array_equal(part[3], y[n - 1000:])
