@@ -376,7 +376,9 @@ def main():
         upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
         tile_rows = effective_tile(B, k, args.tile_rows)
         eb = 8 if args.state_fp64 else 4
-        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p, tile_rows, eb, ftrl)   # per LAUNCH: one tile
+        # per LAUNCH: one tile.  A sparse tile's phase 2 visits only the features that occur in it (their count is known from ingest)
+        p_walk = int(np.mean([e.compact_count(m, b) for b in range(min(nb_full, 8))])) if criteo else p
+        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p_walk, tile_rows, eb, ftrl)
         b_step = algorithmic_bytes(z, k, p, B, eb, ftrl)[2]
         kernels = {
             "fm_rows_forward": (b_fwd, fwd_ms / max(fwd_n, 1)),
@@ -402,6 +404,7 @@ def main():
                                     f"(BASELINE.json configs[{2 if ftrl else 1}])") if not criteo else
                                    (f"Criteo-shaped synthetic {args.rows}x{p} resident ({z} nnz/row: 13 dense + 26 categorical fields, skew 3), k={k}, "
                                     f"{args.solver.upper()} mini-batch (BASELINE.json configs[3]'s shape; its 4e9 rows are streamed: fmx_train_stream)"),
+                       **({"features_occurring_per_step": p_walk} if criteo else {}),
                        "batch_rows_per_gpu": B, "tile_rows": tile_rows, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
                        "batch_reduce": "mean gradient per coordinate per step (FMX_REDUCE_MEAN)",
                        "state": ("fp64" if args.state_fp64 else "fp32") + " V[p][k] + w[p]" + (" + z, n" if ftrl else "") + ", fp64 accumulation",
