@@ -27,6 +27,7 @@ struct Rccl {
   int (*CommInitAll)(rcclComm_t*, int, const int*) = nullptr;
   int (*CommDestroy)(rcclComm_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -46,10 +47,11 @@ static Rccl* rccl() {
   r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
   r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
   r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
   r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-  if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
+  if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.GroupStart || !r.GroupEnd) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
   return &r;
 }
 
@@ -95,6 +97,9 @@ struct Group {
   int64_t src_n = 0, src_nnz = 0;
   uint64_t src_values = 0;
   std::vector<fmx_matrix*> shard;
+  // compact exchange (steps of one sparse tile): every replica's gather buffer [N][stride][record]
+  std::vector<void*> gath;
+  int64_t gath_records = 0;
 };
 
 static void free_shards(Group* g) {
@@ -108,6 +113,7 @@ void group_destroy(fmx_engine* e) {
   Group* g = e->group;
   if (!g) return;
   free_shards(g);
+  for (size_t r = 0; r < g->gath.size(); ++r) if (g->gath[r]) { (void)hipSetDevice(g->dev[r]); (void)hipFree(g->gath[r]); }
   Rccl* l = rccl();
   for (rcclComm_t c : g->comm) if (c && l) (void)l->CommDestroy(c);
   (void)hipSetDevice(e->cfg.device);
@@ -156,6 +162,12 @@ int group_create(fmx_engine* e) {
   }
   FMX_HIP(hipSetDevice(e->cfg.device));
   return FMX_OK;
+}
+
+int group_load(fmx_engine* e, const char* path) {
+  Group* g = e->group;
+  for (int r = 1; r < g->n; ++r) FMX_TRY(fmx_engine_load(g->rep[(size_t)r], path));
+  return use_device_public(e->cfg.device);
 }
 
 int group_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
@@ -246,6 +258,88 @@ static int exchange(Group* g) {
   return FMX_OK;
 }
 
+// ---- compact exchange inside the group (steps of one sparse tile: p >> entries per step, BASELINE.json configs[3]) -------------
+// all-reduce of the 4-element tails, all-gather of the records (padded to the step's largest count), fmx_apply_compact on every
+// replica: the same protocol fmwr_amd/distributed.py runs between processes
+static int exchange_compact(Group* g, const std::vector<int64_t>& counts, int64_t stride) {
+  const bool wide = mb_wide(g->rep[0]);
+  const size_t eb = wide ? 8 : 4;
+  const int64_t rec = g->rep[0]->rec_elems;
+  void *recs[GROUP_MAX], *tails[GROUP_MAX];
+  for (int r = 0; r < g->n; ++r) {
+    int64_t n = 0;
+    FMX_TRY(fmx_compact_records(g->rep[(size_t)r], &recs[r], &n, &tails[r]));
+  }
+  if (!g->shared) {
+    Rccl* l = rccl();
+    FMX_RCCL(l->GroupStart());
+    for (int r = 0; r < g->n; ++r) {
+      FMX_RCCL(l->AllReduce(tails[r], tails[r], 4, wide ? RCCL_FLOAT64 : RCCL_FLOAT32, RCCL_SUM, g->comm[(size_t)r], g->rep[(size_t)r]->stream));
+      if (stride > 0)
+        FMX_RCCL(l->AllGather(recs[r], g->gath[(size_t)r], (size_t)(stride * rec), wide ? RCCL_FLOAT64 : RCCL_FLOAT32, g->comm[(size_t)r], g->rep[(size_t)r]->stream));
+    }
+    FMX_RCCL(l->GroupEnd());
+  } else {
+    FMX_HIP(hipSetDevice(g->dev[0]));
+    BufList bl{};
+    bl.n = g->n;
+    for (int r = 0; r < g->n; ++r) {
+      bl.b[r] = tails[r];
+      FMX_HIP(hipEventRecord(g->ready[(size_t)r], g->rep[(size_t)r]->stream));
+      FMX_HIP(hipStreamWaitEvent(g->xs, g->ready[(size_t)r], 0));
+    }
+    if (wide) hipLaunchKernelGGL((sum_buffers_k<double>), dim3(1), dim3(256), 0, g->xs, bl, (int64_t)4);
+    else hipLaunchKernelGGL((sum_buffers_k<float>), dim3(1), dim3(256), 0, g->xs, bl, (int64_t)4);
+    FMX_HIP(hipGetLastError());
+    for (int dst = 0; dst < g->n && stride > 0; ++dst)
+      for (int src = 0; src < g->n; ++src)
+        if (counts[(size_t)src] > 0)
+          FMX_HIP(hipMemcpyAsync((char*)g->gath[(size_t)dst] + (size_t)src * stride * rec * eb, recs[src], (size_t)counts[(size_t)src] * rec * eb, hipMemcpyDeviceToDevice, g->xs));
+    FMX_HIP(hipEventRecord(g->summed, g->xs));
+    for (int r = 0; r < g->n; ++r) FMX_HIP(hipStreamWaitEvent(g->rep[(size_t)r]->stream, g->summed, 0));
+  }
+  for (int r = 0; r < g->n; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_TRY(fmx_apply_compact(g->rep[(size_t)r], g->gath[(size_t)r], counts.data(), g->n, stride, 0));
+  }
+  return FMX_OK;
+}
+
+// every replica's steps are single sparse tiles?  then reserve the record buffers and the gather buffers once
+static int prepare_compact(Group* g, bool* usable) {
+  const char* v = getenv("FMX_GROUP_EXCHANGE");  // "dense": tests and A/B runs (read at every fmx_train)
+  const bool allow = !(v && v[0] == 'd');
+  *usable = false;
+  if (!allow) return FMX_OK;
+  int64_t max_n = 0, rec = 0;
+  for (int r = 0; r < g->n; ++r) {
+    int64_t cap = 0; int32_t ok = 0;
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_TRY(fmx_compact_info(g->rep[(size_t)r], g->shard[(size_t)r], &rec, &cap, &ok));
+    if (!ok) return FMX_OK;
+    int64_t nb = 0;
+    FMX_TRY(fmx_num_batches(g->rep[(size_t)r], g->shard[(size_t)r], &nb));
+    for (int64_t b = 0; b < nb; ++b) {
+      int64_t n = 0;
+      FMX_TRY(fmx_compact_count(g->rep[(size_t)r], g->shard[(size_t)r], b, &n));
+      if (n > max_n) max_n = n;
+    }
+  }
+  const size_t eb = mb_wide(g->rep[0]) ? 8 : 4;
+  if (g->gath.empty()) g->gath.assign((size_t)g->n, nullptr);
+  for (int r = 0; r < g->n; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_TRY(fmx_compact_reserve(g->rep[(size_t)r], max_n > 0 ? max_n : 1));  // slices of the step's largest count are sent from every replica
+    if (max_n > g->gath_records || !g->gath[(size_t)r]) {
+      (void)hipFree(g->gath[(size_t)r]); g->gath[(size_t)r] = nullptr;
+      FMX_HIP(hipMalloc(&g->gath[(size_t)r], (size_t)g->n * (size_t)(max_n > 0 ? max_n : 1) * (size_t)rec * eb));
+    }
+  }
+  if (max_n > g->gath_records) g->gath_records = max_n;
+  *usable = true;
+  return FMX_OK;
+}
+
 // Learner::learn over N replicas: global step s = local batch (s mod nb) of every shard; max_iter counts examples of the
 // whole job, the last step is truncated rank by rank (lower ranks first).
 int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done) {
@@ -262,9 +356,13 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
     if (nb_min < 0 || nb[(size_t)r] < nb_min) nb_min = nb[(size_t)r];
   }
   FMX_CHECK(nb_min >= 1, FMX_ERR_INVALID, "a shard is empty: fewer rows than GPUs");
+  bool compact = false;
+  FMX_TRY(prepare_compact(g, &compact));
+  std::vector<int64_t> counts((size_t)g->n, 0);
   int64_t done = 0;
   for (int64_t s = 0; done < max_iter; ++s) {
     int64_t left = max_iter - done;
+    int64_t stride = 0;
     for (int r = 0; r < g->n; ++r) {
       const fmx_matrix* sh = g->shard[(size_t)r];
       const int64_t b = s % nb[(size_t)r];  // shards differ by at most one row: their batch counts agree except for a ragged tail
@@ -272,16 +370,27 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
       int64_t rows = b0 + e->cfg.batch_rows <= sh->n ? e->cfg.batch_rows : sh->n - b0;
       if (rows > left) rows = left;
       FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
-      // rows == 0 can only happen on the truncated last step: fmx_grad then publishes zeros (rows_limit < 0 is not a thing: pass 0 rows as an empty share)
-      if (rows > 0) FMX_TRY(fmx_grad(g->rep[(size_t)r], g->shard[(size_t)r], b, rows));
-      else FMX_TRY(group_grad_empty(g->rep[(size_t)r], g->shard[(size_t)r], b));
+      if (compact) {
+        // an empty share (the truncated last step) still publishes its records with zero counts, and its tail
+        FMX_TRY(group_grad_compact(g->rep[(size_t)r], g->shard[(size_t)r], b, rows));
+        FMX_TRY(fmx_compact_count(g->rep[(size_t)r], g->shard[(size_t)r], b, &counts[(size_t)r]));
+        if (counts[(size_t)r] > stride) stride = counts[(size_t)r];
+      } else if (rows > 0) {
+        FMX_TRY(fmx_grad(g->rep[(size_t)r], g->shard[(size_t)r], b, rows));
+      } else {
+        FMX_TRY(group_grad_empty(g->rep[(size_t)r], g->shard[(size_t)r], b));  // publishes zeros
+      }
       left -= rows;
       done += rows;
     }
-    FMX_TRY(exchange(g));
-    for (int r = 0; r < g->n; ++r) {
-      FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
-      FMX_TRY(fmx_apply(g->rep[(size_t)r], 0));  // the global row count travelled in the buffer's tail
+    if (compact) {
+      FMX_TRY(exchange_compact(g, counts, stride));
+    } else {
+      FMX_TRY(exchange(g));
+      for (int r = 0; r < g->n; ++r) {
+        FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+        FMX_TRY(fmx_apply(g->rep[(size_t)r], 0));  // the global row count travelled in the buffer's tail
+      }
     }
   }
   for (int r = 0; r < g->n; ++r) {

@@ -518,10 +518,11 @@ static int64_t compact_capacity(const fmx_matrix* m) {
   return cap;
 }
 
-static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
+static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, bool empty_share = false) {
   std::vector<TileRun> tiles;
   int64_t step_rows = 0;
   FMX_TRY(step_tiles(e, m, batch, rows_limit, &tiles, &step_rows));
+  if (empty_share) { tiles.clear(); step_rows = 0; }
   FMX_CHECK(tiles.size() <= 1, FMX_ERR_STATE, "the compact exchange needs steps of one tile (batch_rows <= tile_rows)");
   if (tiles.empty()) tiles.push_back({m->step_first_tile[(size_t)batch], 0, 0});  // an empty share publishes no record, but its tail
   const auto& pl = m->plans[(size_t)tiles[0].tile];
@@ -549,6 +550,8 @@ int use_device_public(int device) { return use_device(device); }
 int alloc_matrix_public(int device, int64_t n, uint32_t p, int64_t nnz, bool labels, fmx_matrix** out) { return alloc_matrix(device, n, p, nnz, labels, out); }
 // a replica whose share of a (truncated) step is empty still publishes zeros and its tail
 int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch) { return run_step(e, m, batch, 0, false, true); }
+// rows == 0: an empty share (records with zero counts, a zero tail)
+int group_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows) { return grad_compact(e, m, batch, rows, rows <= 0); }
 
 }  // namespace fmx
 
@@ -882,6 +885,7 @@ int fmx_engine_load(fmx_engine* e, const char* path) {
   FMX_CHECK(ok, FMX_ERR_INVALID, "reading %s failed (truncated?)", path);
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   FMX_HIP(hipDeviceSynchronize());
+  if (e->group) FMX_TRY(group_load(e, path));  // every replica resumes from the same file
   return FMX_OK;
 }
 
@@ -1145,6 +1149,7 @@ int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per
                      int64_t* examples_done, double* ingest_wait_s) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "streamed training runs in FMX_MODE_MINIBATCH");
+  FMX_CHECK(e->group == nullptr, FMX_ERR_STATE, "streamed training runs on one GPU per handle (n_gpus > 1: one stream per process, see fmwr_amd/distributed.py)");
   FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS && e->cfg.solver != FMX_SOLVER_MCMC, FMX_ERR_STATE, "ALS / MCMC engines train through fmx_als_train / fmx_mcmc_train");
   FMX_CHECK(total_rows >= 0, FMX_ERR_INVALID, "total_rows must be >= 0");
   if (examples_done) *examples_done = 0;

@@ -392,8 +392,10 @@ int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64
 int group_create(fmx_engine* e);
 void group_destroy(fmx_engine* e);
 int group_set_params(fmx_engine* e, double w0, const double* w, const double* v);
+int group_load(fmx_engine* e, const char* path);
 int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
 int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch);
+int group_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows);
 int group_rccl_selftest(int n, double* max_err);
 int use_device_public(int device);
 int alloc_matrix_public(int device, int64_t n, uint32_t p, int64_t nnz, bool labels, fmx_matrix** out);

@@ -88,3 +88,40 @@ def test_rccl_loads_and_all_reduces_on_the_visible_devices():
     err = C.c_double(-1.0)
     L.check(L.lib().fmx_rccl_selftest(C.c_int32(n), C.byref(err)))
     assert 0.0 <= err.value < 1e-3
+
+
+def test_group_compact_exchange_for_sparse_tiles_is_bitwise_the_dense_one(monkeypatch):
+    """n_gpus = 2 on a matrix with far more features than entries per step: the group exchanges the occurring features' records
+    (all-reduce of the tails, all-gather of the records, fmx_apply_compact) instead of the (kp + 2) * p buffer -- bitwise the dense
+    form (FMX_GROUP_EXCHANGE=dense forces it), heavy hitters and a truncated last step included; and equal to one GPU on the
+    global batches."""
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(21)
+    n, p, z, k, B = 9000, 150_000, 10, 8, 1500
+    rows = []
+    for r in range(n):
+        hot = [j for j, q in ((3, 0.9), (60_000, 0.5)) if rng.random() < q]
+        rows.append(np.unique(np.concatenate([hot, rng.integers(0, 3000, 3), rng.integers(3000, p, z - 3)])).astype(np.uint32))
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows); val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, 21)
+    v0 = np.random.default_rng(2).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+    total = 3 * 2 * B + 700          # three full global steps and a truncated one (rank 0: 700 rows, rank 1: none)
+    out = {}
+    for form in ("compact", "dense"):
+        if form == "dense":
+            monkeypatch.setenv("FMX_GROUP_EXCHANGE", "dense")
+        res = {}
+        for solver in ("sgd", "ftrl"):
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            g = engine.Engine(p, solver=L.SOLVER_SGD if solver == "sgd" else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3,
+                              l1_v=1e-4 if solver == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B, n_gpus=2, gpus_share_device=1,
+                              batch_reduce=L.REDUCE_MEAN if solver == "sgd" else L.REDUCE_SUM)
+            g.set_params(0.0, None, v0)
+            assert g.train(m, total) == total
+            res[solver] = g.get_params()
+        out[form] = res
+    for solver in ("sgd", "ftrl"):
+        a, b = out["compact"][solver], out["dense"][solver]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.any(a[2] != v0)
