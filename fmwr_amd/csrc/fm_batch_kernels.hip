@@ -116,10 +116,21 @@ __device__ __forceinline__ double link_apply(const Hyper& h, double y_hat, int l
 __device__ __forceinline__ void stage_entries(uint2* stage, const uint32_t* __restrict__ ids,
                                               const float* __restrict__ xs, int64_t c0, int cnt, int unit) {
   // (non-temporal loads for these read-once streams were tried: phase 1 1.7 % slower, the forward-only pass 2 % faster)
-  if (unit) {  // one-hot data: half the stream
-    for (int i = threadIdx.x; i < cnt; i += WG_THREADS) stage[i] = make_uint2(ids[c0 + i], 0x3f800000u);
-  } else {
-    for (int i = threadIdx.x; i < cnt; i += WG_THREADS) stage[i] = make_uint2(ids[c0 + i], __float_as_uint(xs[c0 + i]));
+  // All of a thread's loads are issued before the first LDS store: a chunk is up to 8 entries per thread, and a plain
+  // load -> store loop pays one memory round trip PER ENTRY when nothing else hides it (small steps: 16 workgroups on the chip).
+  constexpr int PER = STAGE_ENTRIES / WG_THREADS;
+  uint32_t id[PER], xb[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = threadIdx.x + u * WG_THREADS;
+    const bool in = i < cnt;
+    id[u] = in ? ids[c0 + i] : 0u;
+    xb[u] = unit ? 0x3f800000u : (in ? __float_as_uint(xs[c0 + i]) : 0u);  // one-hot data: half the stream
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = threadIdx.x + u * WG_THREADS;
+    if (i < cnt) stage[i] = make_uint2(id[u], xb[u]);
   }
 }
 
