@@ -30,6 +30,16 @@
 #ifndef FMX_U
 #define FMX_U 4  // row gathers kept in flight per lane
 #endif
+// Phase 1 keeps fewer in flight when the chip is full: a step large enough for the 256-thread workgroups runs at the gather
+// ceiling with ONE entry (its V row and its w) outstanding per lane group -- the waves on a CU supply the parallelism, and
+// more per wave only lengthens the queues (measured at configs[1]: 1 -> 0.147 ms per tile, 4 -> 0.164).  A small step is the
+// opposite: a handful of waves per CU, every round a bare memory round trip, so it keeps four.
+#ifndef FMX_U_LARGE
+#define FMX_U_LARGE 4
+#endif
+#ifndef FMX_U_SMALL
+#define FMX_U_SMALL 4
+#endif
 
 namespace fmx {
 
@@ -113,23 +123,30 @@ __device__ __forceinline__ double link_apply(const Hyper& h, double y_hat, int l
 }
 
 // coalesced copy of `cnt` (id, x) entries starting at absolute offset c0 into LDS
+template <bool BATCHED, int WGT = WG_THREADS>
 __device__ __forceinline__ void stage_entries(uint2* stage, const uint32_t* __restrict__ ids,
                                               const float* __restrict__ xs, int64_t c0, int cnt, int unit) {
   // (non-temporal loads for these read-once streams were tried: phase 1 1.7 % slower, the forward-only pass 2 % faster)
   // All of a thread's loads are issued before the first LDS store: a chunk is up to 8 entries per thread, and a plain
   // load -> store loop pays one memory round trip PER ENTRY when nothing else hides it (small steps: 16 workgroups on the chip).
-  constexpr int PER = STAGE_ENTRIES / WG_THREADS;
+  // Phase 2 keeps the plain loop: its state variants (FTRL) are register-bound and lose 19 % to the eight extra pairs.
+  if constexpr (!BATCHED) {
+    for (int i = threadIdx.x; i < cnt; i += WGT)
+      stage[i] = make_uint2(ids[c0 + i], unit ? 0x3f800000u : __float_as_uint(xs[c0 + i]));
+    return;
+  }
+  constexpr int PER = STAGE_ENTRIES / WG_THREADS  /* a chunk is PER * WGT entries */;
   uint32_t id[PER], xb[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int i = threadIdx.x + u * WG_THREADS;
+    const int i = threadIdx.x + u * WGT;
     const bool in = i < cnt;
     id[u] = in ? ids[c0 + i] : 0u;
     xb[u] = unit ? 0x3f800000u : (in ? __float_as_uint(xs[c0 + i]) : 0u);  // one-hot data: half the stream
   }
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int i = threadIdx.x + u * WG_THREADS;
+    const int i = threadIdx.x + u * WGT;
     if (i < cnt) stage[i] = make_uint2(id[u], xb[u]);
   }
 }
@@ -198,16 +215,31 @@ __device__ __forceinline__ float embed_take(float4& v, int lig, int mode) {
 }
 __device__ __forceinline__ double embed_take_none(double2&, int, int) { return 0.0; }
 
+// Diagnostic build only (-DFMX_TRACE, profiles/trace_rows_forward.py): 100 MHz stamps from one workgroup of phase 1.  The product
+// build compiles none of it.
+#ifdef FMX_TRACE
+__device__ unsigned long long fmx_trace_buf[16];
+#define FMX_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) fmx_trace_buf[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int fmx_debug_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fmx_trace_buf), sizeof(fmx_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#else
+#define FMX_STAMP(i)
+#endif
+
 // ------------------------------------------------------------------------------------------------ phase 1
-template <typename T, int LPR, bool TRAIN>
-__global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hyper h) {
+template <typename T, int LPR, bool TRAIN, int WGT>
+__global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
   using vec_t = typename Slice<T>::vec;
   constexpr int VEC = Slice<T>::N;
   constexpr int KP = LPR * VEC;
-  constexpr int RPW = WG_THREADS / LPR;  // rows (lists) per workgroup
-  __shared__ uint2 stage[STAGE_ENTRIES];
+  constexpr int RPW = WGT / LPR;  // rows (lists) per workgroup
+  constexpr int CHUNK = STAGE_ENTRIES / WG_THREADS * WGT;  // entries staged at a time
+  constexpr int RU = WGT == 64 ? FMX_U_SMALL : FMX_U_LARGE;  // entries whose gathers are in flight together, per lane group
+  __shared__ uint2 stage[CHUNK + RU];  // + RU: the gather rounds read whole groups of RU entries
   __shared__ double red[TRAIN ? RPW : 1];
 
+  FMX_STAMP(0);
   const int tid = threadIdx.x;
   const int gid = tid / LPR;
   const int lig = tid % LPR;
@@ -223,7 +255,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
     tb = a.row_ptr[a.r0 + row + 1];
   }
   const T* __restrict__ Vt = reinterpret_cast<const T*>(a.V) + lig * VEC;
-  const T* __restrict__ wt = reinterpret_cast<const T*>(a.w);
+  const T* __restrict__ wt = a.w ? reinterpret_cast<const T*>(a.w) : reinterpret_cast<const T*>(a.V);  // always readable
   const bool k1 = h.k1 != 0;
 
   double s[VEC], q[VEC];
@@ -231,29 +263,42 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
   for (int i = 0; i < VEC; ++i) { s[i] = 0.0; q[i] = 0.0; }
   double lin = h.k0 ? a.scal[SC_W0] : 0.0;  // core/Model.h:77-78
 
-  for (int64_t c0 = lo; c0 < hi; c0 += STAGE_ENTRIES) {
-    const int cnt = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
-    stage_entries(stage, a.col, a.val, c0, cnt, a.unit);
+  for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
+    const int cnt = (hi - c0 < CHUNK) ? (int)(hi - c0) : CHUNK;
+    FMX_STAMP(1);
+    stage_entries<true, WGT>(stage, a.col, a.val, c0, cnt, a.unit);
     __syncthreads();
+    FMX_STAMP(2);
     const int64_t b = ta > c0 ? ta : c0;
     const int64_t e = tb < c0 + cnt ? tb : c0 + cnt;
-    for (int64_t t = b; t < e; t += FMX_U) {
+    for (int64_t t = b; t < e; t += RU) {
       const int o = (int)(t - c0);
-      uint2 en[FMX_U];
-      en[0] = stage[o];
+      // Straight-line on purpose: every LDS read, then every gather, then the arithmetic.  A `cond ? load : constant` here
+      // compiles to a branch around the load with a wait for ALL outstanding loads at the join -- the rounds of one wave
+      // then cost one memory round trip per ENTRY instead of one per RU entries (seen in the ISA; 17 of a small step's
+      // 20 us).  So: read past the row's end (the stage array is padded), select afterwards; w is read even when the
+      // model has no linear term (wt then points at valid memory) and dropped by the select below.
+      uint2 en[RU];
 #pragma unroll
-      for (int u = 1; u < FMX_U; ++u) en[u] = (t + u < e) ? stage[o + u] : make_uint2(en[0].x, 0u);  // x = +0.0f pads
-      vec_t vv[FMX_U];
-      T wv[FMX_U];
+      for (int u = 0; u < RU; ++u) en[u] = stage[o + u];
 #pragma unroll
-      for (int u = 0; u < FMX_U; ++u) {
+      for (int u = 1; u < RU; ++u)
+        if (t + u >= e) en[u] = make_uint2(en[0].x, 0u);  // x = +0.0f pads
+      vec_t vv[RU];
+      T wv[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
         vv[u] = gather_row(Vt + (size_t)en[u].x * KP);
-        wv[u] = k1 ? wt[en[u].x] : (T)0;
+        wv[u] = wt[en[u].x];
+        if constexpr (WGT != 64) {
+          // large steps over a cache-sized table: let these land before the next entry's requests go out (see FMX_U_LARGE above)
+          if (a.serial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       }
 #pragma unroll
-      for (int u = 0; u < FMX_U; ++u) {  // nonzeros in row order: same association as core/Model.h:83-97
+      for (int u = 0; u < RU; ++u) {  // nonzeros in row order: same association as core/Model.h:83-97
         const double x = (double)__uint_as_float(en[u].y);
-        lin += (double)wv[u] * x;
+        if (k1) lin += (double)wv[u] * x;
         double vf[VEC];
         slice_get(vv[u], vf);
 #pragma unroll
@@ -264,7 +309,9 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
         }
       }
     }
+    FMX_STAMP(3);
     __syncthreads();
+    FMX_STAMP(4);
   }
 
   double pair = 0.0;
@@ -283,14 +330,17 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
       *reinterpret_cast<vec_t*>(reinterpret_cast<T*>(a.S) + (size_t)row * KP + lig * VEC) = srow;
       if (lig == 0) reinterpret_cast<T*>(a.amul)[row] = (T)mult;
     }
+    FMX_STAMP(5);
     if (lig == 0) red[gid] = mult;
     __syncthreads();
+    FMX_STAMP(6);
     if (tid == 0) {  // fixed-order partial sums for the w0 step
       double g0 = 0.0, q0 = 0.0;
       for (int i = 0; i < RPW; ++i) { g0 += red[i]; q0 += red[i] * red[i]; }
       a.partials[2 * (size_t)blockIdx.x] = g0;
       a.partials[2 * (size_t)blockIdx.x + 1] = q0;
     }
+    FMX_STAMP(7);
   } else {
     if (have && lig == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link, a.pn_y);
     if constexpr (sizeof(T) == 8) {  // fp64 tables: optionally the per-row factor sums q[row][f] = sum_j x_j v_jf (ALS sweeps)
@@ -299,17 +349,17 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_k(RowsArgs a, Hype
   }
 }
 
-template <typename T, bool TRAIN>
+template <typename T, bool TRAIN, int WGT>
 static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
   constexpr int VEC = Slice<T>::N;
   const int lpr = kp / VEC;
-  const int rpw = WG_THREADS / lpr;
+  const int rpw = WGT / lpr;
   const int64_t grid = (a.nrows + rpw - 1) / rpw;
   if (grid == 0) return FMX_OK;
   FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "rows_forward: grid too large (%lld)", (long long)grid);
-  dim3 g((unsigned)grid), b(WG_THREADS);
-#define FMX_ROWS_CASE(L)                                                                              \
-  case L: hipLaunchKernelGGL((fm_rows_forward_k<T, L, TRAIN>), g, b, 0, e->stream, a, e->hyper); break;
+  dim3 g((unsigned)grid), b(WGT);
+#define FMX_ROWS_CASE(L)                                                                                   \
+  case L: hipLaunchKernelGGL((fm_rows_forward_k<T, L, TRAIN, WGT>), g, b, 0, e->stream, a, e->hyper); break;
   switch (lpr) {
     FMX_ROWS_CASE(1) FMX_ROWS_CASE(2) FMX_ROWS_CASE(4) FMX_ROWS_CASE(8)
     FMX_ROWS_CASE(16) FMX_ROWS_CASE(32) FMX_ROWS_CASE(64)
@@ -319,15 +369,57 @@ static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
+template <typename T, bool TRAIN>
+static int launch_rows_w(fmx_engine* e, const RowsArgs& a, int kp) {
+  return a.wg_threads == 64 ? launch_rows_t<T, TRAIN, 64>(e, a, kp) : launch_rows_t<T, TRAIN, WG_THREADS>(e, a, kp);
+}
 
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp64_tables) {
   RowsArgs a = a_in;
   static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
+  static const int force = [] { const char* v = getenv("FMX_ROWS_SERIAL"); return v ? atoi(v) : -1; }();
+  RowsTune& tu = e->rows_tune;
+  const bool wide = a.wg_threads != 64;
+  int trial = -1;  // index of this launch among the timed ones
+  a.serial = 1;
+  if (force >= 0) {
+    a.serial = force;
+  } else {
+    const int64_t key = a.unit ? 1 : 0;
+    if (train && wide && a.nrows >= RowsTune::MIN_ROWS && key != tu.key) { tu.key = key; tu.decided = -1; tu.launches = 0; }
+    if (tu.decided >= 0) {
+      a.serial = tu.decided;
+    } else if (train && wide && a.nrows >= RowsTune::MIN_ROWS) {
+      if (!tu.events) {
+        bool ok = true;
+        for (auto& ev : tu.ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+        FMX_CHECK(ok, FMX_ERR_HIP, "rows_forward: could not create the tuning events");
+        tu.events = true;
+      }
+      trial = tu.launches++;
+      a.serial = trial % 2 == 0 ? 1 : 0;
+      FMX_HIP(hipEventRecord(tu.ev[2 * trial], e->stream));
+    }
+  }
   a.embed = (train && embed_ok) ? embed_mode(e->k, fp64_tables ? e->kp64 : e->kp32, !fp64_tables) : EMBED_NONE;  // the same rule as launch_cols_update
   prof_begin(e, FMX_KERNEL_ROWS_FORWARD);
   int st = FMX_OK;
   if (train) {
-    st = fp64_tables ? launch_rows_t<double, true>(e, a, e->kp64) : launch_rows_t<float, true>(e, a, e->kp32);
+    st = fp64_tables ? launch_rows_w<double, true>(e, a, e->kp64) : launch_rows_w<float, true>(e, a, e->kp32);
+    if (trial >= 0 && st == FMX_OK) {
+      FMX_HIP(hipEventRecord(tu.ev[2 * trial + 1], e->stream));
+      if (tu.launches == RowsTune::TRIALS) {  // the one wait of the measurement
+        FMX_HIP(hipEventSynchronize(tu.ev[2 * trial + 1]));
+        double ms[2] = {0.0, 0.0};
+        for (int i = 2; i < RowsTune::TRIALS; ++i) {
+          float t = 0.f;
+          FMX_HIP(hipEventElapsedTime(&t, tu.ev[2 * i], tu.ev[2 * i + 1]));
+          ms[i % 2 == 0 ? 1 : 0] += t;
+        }
+        tu.ms[0] = ms[0]; tu.ms[1] = ms[1];
+        tu.decided = ms[1] <= ms[0] ? 1 : 0;
+      }
+    }
   } else {
     // Forward-only passes over many rows go out as launches of 262 144 rows: measured at configs[1]
     // (profiles/forward_probe.py) such launches run at 0.58 ns/row, 1 M-row launches at 0.69, 4 M-row launches at 0.75 --
@@ -340,7 +432,8 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
       s.nrows = a.nrows - off < SLAB ? a.nrows - off : SLAB;
       if (a.yhat) s.yhat = a.yhat + off;
       if (a.qout) s.qout = a.qout + (size_t)off * kp;
-      st = fp64_tables ? launch_rows_t<double, false>(e, s, kp) : launch_rows_t<float, false>(e, s, kp);
+      s.wg_threads = rows_wg_threads(a.nrows, kp / (fp64_tables ? 2 : 4));
+      st = fp64_tables ? launch_rows_w<double, false>(e, s, kp) : launch_rows_w<float, false>(e, s, kp);
     }
   }
   prof_end(e);
@@ -814,7 +907,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
         const int cn = (hi - c0 < STAGE_ENTRIES) ? (int)(hi - c0) : STAGE_ENTRIES;
         const int64_t b = ta > c0 ? ta : c0;
         const int64_t e = tb < c0 + cn ? tb : c0 + cn;
-        stage_entries(stage, a.brow, a.bval, c0, cn, a.unit);
+        stage_entries<false>(stage, a.brow, a.bval, c0, cn, a.unit);
         __syncthreads();
         for (int64_t t = b; t < e; t += FMX_U) {
           const int o = (int)(t - c0);

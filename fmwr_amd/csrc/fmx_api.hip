@@ -139,7 +139,8 @@ static int reset_optimizer_state(fmx_engine* e) {
 // partial sums for one step; grow-only
 static int ensure_workspace(fmx_engine* e, int64_t s_rows, int64_t step_rows, int64_t tiles_per_step) {
   const int rpw = WG_THREADS / mb_lpr(e);
-  const int64_t partials = (step_rows + rpw - 1) / rpw + (tiles_per_step > 0 ? tiles_per_step : 1) + 8;  // sum over tiles of ceil(rows_t / rpw)
+  // sum over tiles of ceil(rows_t / rpw); a small step's one-wave workgroups (rows_wg_threads) write at most 2048 of them
+  const int64_t partials = (step_rows + rpw - 1) / rpw + (tiles_per_step > 0 ? tiles_per_step : 1) + 8 + 2048;
   if (s_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(e->stream));
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
@@ -328,7 +329,7 @@ static int step_tiles(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_
   return FMX_OK;
 }
 
-static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t partial_offset, int64_t* n_partials, int64_t s_row0 = 0) {
+static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t step_rows, int64_t partial_offset, int64_t* n_partials, int64_t s_row0 = 0) {
   RowsArgs a{};
   a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = m->y;
   a.r0 = t.r0; a.nrows = t.nrows;
@@ -339,7 +340,8 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t pa
   a.amul = (char*)e->amul + (size_t)s_row0 * mb_elem(e);
   a.partials = e->partials + 2 * partial_offset;
   a.unit = m->unit_values;
-  const int rpw = WG_THREADS / mb_lpr(e);
+  a.wg_threads = rows_wg_threads(step_rows, mb_lpr(e));
+  const int rpw = a.wg_threads / mb_lpr(e);
   *n_partials = (t.nrows + rpw - 1) / rpw;
   return launch_rows_forward(e, a, true, mb_wide(e));
 }
@@ -397,7 +399,7 @@ static int run_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_li
   int64_t partials = 0;
   for (size_t i = 0; i < tiles.size(); ++i) {
     int64_t np = 0;
-    FMX_TRY(rows_phase(e, m, tiles[i], partials, &np));
+    FMX_TRY(rows_phase(e, m, tiles[i], step_rows, partials, &np));
     partials += np;
     const bool last = i + 1 == tiles.size();
     // a tile that is a whole fused step walks only the features occurring in it (the exchange buffer is dense: tiles
@@ -431,7 +433,7 @@ static int grad_begin(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_
   int64_t partials = 0, s_row0 = 0;
   for (const TileRun& t : tiles) {
     int64_t np = 0;
-    FMX_TRY(rows_phase(e, m, t, partials, &np, s_row0));
+    FMX_TRY(rows_phase(e, m, t, step_rows, partials, &np, s_row0));
     partials += np;
     e->open_tiles.push_back({t.tile, t.r0, t.nrows, s_row0});
     s_row0 += t.nrows;
@@ -531,7 +533,7 @@ static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t row
   // driver holds stays valid as long as it reserved enough)
   FMX_TRY(ensure_compact(e, (int64_t)pl.n_lists > 0 ? (int64_t)pl.n_lists : 1));
   int64_t np = 0;
-  FMX_TRY(rows_phase(e, m, tiles[0], 0, &np));
+  FMX_TRY(rows_phase(e, m, tiles[0], step_rows, 0, &np));
   ColsArgs c{};
   FMX_TRY(cols_args(e, m, tiles[0], true, &c));
   c.store_compact = 1;
@@ -656,6 +658,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto& pr : e->prof_pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
+  if (e->rows_tune.events) for (auto& ev : e->rows_tune.ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->scal_base);
   (void)hipFree(e->V); (void)hipFree(e->w); (void)hipFree(e->sV); (void)hipFree(e->sw); (void)hipFree(e->nV); (void)hipFree(e->nw);
   (void)hipFree(e->t1V); (void)hipFree(e->t1w); (void)hipFree(e->t2V); (void)hipFree(e->t2w); (void)hipFree(e->t3V); (void)hipFree(e->t3w);
@@ -1669,6 +1672,14 @@ int fmx_profile_get(fmx_engine* e, int kernel, double* total_ms, int64_t* launch
   FMX_TRY(prof_collect(e));
   if (total_ms) *total_ms = e->prof_ms[kernel];
   if (launches) *launches = e->prof_n[kernel];
+  return FMX_OK;
+}
+
+int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double* ms_pipelined) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  if (serial) *serial = e->rows_tune.decided;
+  if (ms_serial) *ms_serial = e->rows_tune.ms[1];
+  if (ms_pipelined) *ms_pipelined = e->rows_tune.ms[0];
   return FMX_OK;
 }
 

@@ -155,6 +155,23 @@ struct fmx_matrix {
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
 };
 
+// Phase 1 of a LARGE step has two schedules that compute the same bits: `serial` (one entry's V row and w outstanding per lane
+// group, the next entry's requests go out when they have landed) and pipelined (four entries' requests out together).
+// Which is faster is a property of the DATA: serial wins where the gathers miss (uniform columns: 0.146 against 0.196 ms per
+// tile at configs[1], and still ahead at p = 16M), pipelined where they hit (Criteo-shaped skew: 0.137 against 0.196).  So
+// the engine times both on its own first large launches -- TRIALS launches alternate, the first two are thrown away -- and
+// keeps the faster one for that tile shape; FMX_ROWS_SERIAL=0/1 pins it.  Results do not depend on the choice.
+struct RowsTune {
+  static constexpr int TRIALS = 14;
+  static constexpr int64_t MIN_ROWS = 65536;  // launches this large are timed; smaller wide launches follow the decision
+  int decided = -1;          // -1: still measuring
+  int launches = 0;
+  int64_t key = -1;          // one-hot data or not: the other kind measures again
+  hipEvent_t ev[2 * TRIALS] = {};
+  bool events = false;
+  double ms[2] = {0, 0};     // kept for fmx_rows_tune_info
+};
+
 struct fmx_engine {
   fmx_config cfg{};
   fmx::Hyper hyper{};
@@ -238,6 +255,7 @@ struct fmx_engine {
   double prof_ms[FMX_KERNEL_COUNT] = {0};
   int64_t prof_n[FMX_KERNEL_COUNT] = {0};
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+  RowsTune rows_tune;   // phase 1's request cadence for large steps, measured on this engine's own first launches
 };
 
 namespace fmx {
@@ -271,7 +289,18 @@ struct RowsArgs {
   int link;
   int unit;             // every value is 1.0f: a.val is not read
   int embed;            // EmbedMode: how the multiplier is folded into the S row (set by the launcher)
+  int wg_threads;       // 64: one-wave workgroups (rows_wg_threads); anything else: WG_THREADS
+  int serial;           // large steps: one entry's requests outstanding per lane group at a time (set by the launcher)
 };
+// Small steps.  A CU sustains about 240 random 64-byte rows per microsecond whatever runs on it (its miss queue; the
+// gather probe shows the same rate at 2 and at 8 workgroups per CU), so a phase 1 of fewer than one 256-thread workgroup
+// per CU is bound by the FEW CUs it occupies: in-kernel stamps at batch_rows = 1024 show 17 of its 20 us in the four
+// dependent gather rounds of 16 workgroups (profiles/r02_small_batch.txt).  Such a step goes out as one-WAVE workgroups, four times
+// the CUs.  The choice is made from the STEP's row count, never the tile's: a workgroup's partial sum for the w0 step
+// covers wg_threads / lpr rows, so the association of that sum -- and with it the last bits of w0 -- stays a function of
+// the step alone.
+constexpr size_t FMX_SERIAL_TABLE_MAX = 1ull << 30;
+inline int rows_wg_threads(int64_t step_rows, int lpr) { return step_rows * lpr < 512LL * WG_THREADS ? 64 : WG_THREADS; }
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
 int ensure_probit(fmx_engine* e);  // builds and uploads the probit tables (fm_probit.h) on first use
 

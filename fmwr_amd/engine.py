@@ -380,6 +380,12 @@ class Engine:
         L.check(L.lib().fmx_profile_get(self.h, C.c_int(kernel), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def rows_tune(self):
+        """(serial, ms_serial, ms_pipelined): phase 1's schedule for large steps as this engine measured it (fmx_rows_tune_info)."""
+        d, a, b = C.c_int32(), C.c_double(), C.c_double()
+        L.check(L.lib().fmx_rows_tune_info(self.h, C.byref(d), C.byref(a), C.byref(b)))
+        return d.value, a.value, b.value
+
     def close(self):
         if self.h:
             L.lib().fmx_engine_destroy(self.h)

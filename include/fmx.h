@@ -376,6 +376,10 @@ int fmx_mcmc_v_hyper(fmx_engine* e, const double* std_gammas, const double* std_
 int fmx_profile_enable(fmx_engine* e, int on);
 int fmx_profile_get(fmx_engine* e, int kernel, double* total_ms, int64_t* launches);
 int fmx_profile_reset(fmx_engine* e);
+/* Phase 1's request schedule for large steps (>= 65536 rows per launch), which the engine picks by timing its own first 14
+ * such launches: *serial = 1 one entry's requests outstanding per lane group, 0 four entries', -1 not decided yet;
+ * ms_serial / ms_pipelined = the six timed launches of each.  The choice never changes a result.  FMX_ROWS_SERIAL=0/1 pins it. */
+int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double* ms_pipelined);
 /* RCCL smoke test for cfg.n_gpus > 1: loads librccl, ncclCommInitAll over devices 0..n-1, one grouped fp32 and fp64
  * all-reduce(sum) of 1000 elements per rank on per-device streams, checked against the closed form; max_err = largest deviation. */
 int fmx_rccl_selftest(int32_t n, double* max_err);
