@@ -804,7 +804,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   constexpr int KP = LPR * VEC;
   constexpr int FPW = WG_THREADS / LPR;  // features (lists) per workgroup
   constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
-  __shared__ uint2 stage[STAGE_ENTRIES];
+  __shared__ uint2 stage[STAGE_ENTRIES + FMX_U];
   __shared__ double red_g[WG_THREADS], red_q[WG_THREADS];
   __shared__ unsigned long long wg_next;
 
@@ -815,26 +815,38 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   const int64_t n_lists = a.tfeat ? (int64_t)a.n_tfeat : (int64_t)a.f1;
   const int64_t I0 = (a.tfeat ? 0 : (int64_t)a.f0) + (int64_t)blockIdx.x * FPW;
   const int64_t I1 = (I0 + FPW < n_lists) ? I0 + FPW : n_lists;
+  if (I0 >= n_lists) {  // a launch without lists: only workgroup 0 exists, for the w0 step (nothing below may be read)
+    if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
+      scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, exchange_tail<ST, LPR>(T), h, a.global_rows, a.scalar, red_g, red_q);
+    return;
+  }
   bool have = I0 + gid < n_lists;
-  const int64_t j = !have ? 0 : (a.tfeat ? (int64_t)a.tfeat[I0 + gid] : I0 + gid);
+  // Every load below is unconditional, on an index clamped into the workgroup's own range, and its value is selected afterwards.
+  // A load inside `if (have)` (or `cond ? load : constant`) compiles to a branch with a wait for everything outstanding at the
+  // join, and the front of this kernel used to be a chain of such waits: feature id -> V row -> w -> list offsets -> entries
+  // -> S rows, six dependent round trips where the data dependences ask for three (ids and offsets; V row, w and entries; S rows).
+  const int64_t idx = have ? I0 + gid : I0;
   // list offsets: the dense per-feature array, or its compact copy for the occurring features (their entries are
   // contiguous: the features between them have none)
   const uint32_t* __restrict__ off = a.tfeat ? a.toff : a.bptr;
-
-  double vf[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) vf[i] = 0.0;
-  if (have) slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
+  uint32_t off_a = 0, off_b = 0;
+  int64_t j = idx;
+  if (a.tfeat) {  // one join, one wait: the id and both offsets travel together
+    j = (int64_t)a.tfeat[idx];
+    off_a = a.toff[idx]; off_b = a.toff[idx + 1];
+  } else if (a.walk) {
+    off_a = a.bptr[idx]; off_b = a.bptr[idx + 1];
+  }
+  const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC);
   // w_j is needed only after the walk: ask for it now, beside the V row, instead of paying its round trip at the end
-  ST w_pre = (ST)0;
-  if (have && lig == 0 && a.apply) w_pre = T.w[j];
+  ST w_pre = T.w[j];
   CoordSums s;
   sums_zero(s);
+  double vf[VEC];
 
   if (a.walk) {
     const int64_t lo = off[I0], hi = off[I1];
-    int64_t ta = 0, tb = 0;
-    if (have) { ta = off[I0 + gid]; tb = off[I0 + gid + 1]; }
+    int64_t ta = have ? (int64_t)off_a : 0, tb = have ? (int64_t)off_b : 0;
     if (a.long_min > 0 && tb - ta > (int64_t)a.long_min) { have = false; ta = tb = 0; }  // a long list: not ours
     const ST* __restrict__ St = T.S + lig * VEC;
     const __amdgpu_buffer_rsrc_t s_rsrc = table_rsrc(T.S, a.buf_gather ? (uint32_t)(T.s_rows * (KP * sizeof(ST))) : 0u);
@@ -874,6 +886,9 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
           }
         }
       }
+      // the V row is first needed HERE (converted per batch: four conversions, and the wait for it falls after this batch's
+      // gathers have gone out instead of before the first entry is read)
+      slice_get(v_raw, vf);
 #pragma unroll
       for (int u = 0; u < FMX_U; ++u)  // occurrences in row order
         if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(en[u].y));
@@ -882,12 +897,30 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       // Sparse tiles (lists of one or two entries): every group reads its own entries straight from memory -- neighbouring groups
       // read neighbouring addresses, so the loads coalesce by themselves -- and the workgroup never meets at a barrier: one
       // dependent round trip fewer per list, in a regime that is nothing but dependent round trips.
-      for (int64_t t = ta; t < tb; t += FMX_U) {
-        uint2 en[FMX_U];
+      if (a.unit) {
+        for (int64_t t = ta; t < tb; t += FMX_U) {
+          uint32_t r[FMX_U];
 #pragma unroll
-        for (int u = 0; u < FMX_U; ++u)
-          en[u] = (t + u < tb) ? make_uint2(a.brow[t + u], a.unit ? 0x3f800000u : __float_as_uint(a.bval[t + u])) : make_uint2(0xFFFFFFFFu, 0u);
-        take(en);
+          for (int u = 0; u < FMX_U; ++u) r[u] = a.brow[t + u < tb ? t + u : t];
+          uint2 en[FMX_U];
+#pragma unroll
+          for (int u = 0; u < FMX_U; ++u) en[u] = make_uint2(t + u < tb ? r[u] : 0xFFFFFFFFu, 0x3f800000u);
+          take(en);
+        }
+      } else {
+        for (int64_t t = ta; t < tb; t += FMX_U) {
+          uint32_t r[FMX_U], x[FMX_U];
+#pragma unroll
+          for (int u = 0; u < FMX_U; ++u) {
+            const int64_t tt = t + u < tb ? t + u : t;
+            r[u] = a.brow[tt];
+            x[u] = __float_as_uint(a.bval[tt]);
+          }
+          uint2 en[FMX_U];
+#pragma unroll
+          for (int u = 0; u < FMX_U; ++u) en[u] = make_uint2(t + u < tb ? r[u] : 0xFFFFFFFFu, x[u]);
+          take(en);
+        }
       }
     } else {
       int64_t c0 = lo;
@@ -913,7 +946,10 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
           const int o = (int)(t - c0);
           uint2 en[FMX_U];
 #pragma unroll
-          for (int u = 0; u < FMX_U; ++u) en[u] = (t + u < e) ? stage[o + u] : make_uint2(0xFFFFFFFFu, 0u);
+          for (int u = 0; u < FMX_U; ++u) {  // the array is padded: read first, select afterwards
+            const uint2 v = stage[o + u];
+            en[u] = make_uint2(t + u < e ? v.x : 0xFFFFFFFFu, v.y);
+          }
           take(en);
         }
         __syncthreads();
@@ -921,6 +957,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       }
     }
   }
+  slice_get(v_raw, vf);
   ST* gtail = exchange_tail<ST, LPR>(T);
   double rows = a.global_rows;
   if (a.apply && a.load_gbuf && rows <= 0.0) rows = tail_get_rows(gtail);  // the global row count travelled in the reduced buffer
