@@ -557,23 +557,25 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = a.k, kp = a.kp;
   const bool k0 = h.k0 != 0, k1 = h.k1 != 0;
-  const int k8 = (k + 7) & ~7;  // the chain adds the pairwise terms eight at a time
+  const int k16 = (k + 15) & ~15;  // the chain adds the pairwise terms sixteen at a time (two eights)
   // the scalar chain lives in wave 0
   double w0 = a.scal[SC_W0], z0 = a.scal[SC_Z0], n0 = a.scal[SC_N0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
   double t_nu = a.scal[SC_T_NU], t_delta = a.scal[SC_T_DELTA], t_h = a.scal[SC_T_H];
 
   // this wave's candidate example of the group starting at g: its metadata is fetched one group ahead
+  // Loaded unconditionally, on indices clamped into the piece: a wave past the end carries the last example's metadata, and every use
+  // below is guarded by its own range test anyway.  (Inside `if (tt < count)` the loads sat behind a branch whose join waits for
+  // them -- the "one group ahead" fetch was a round trip in FRONT of every group's gathers instead of one hidden behind them.)
   struct Meta { int conf_t, conf_g, len; uint2 en; float y; };
   auto fetch = [&](int gg) {
-    Meta mt{-1, -1, 0, make_uint2(0u, 0u), 0.f};
-    const int tt = gg + wave;
-    if (tt < wa.count) {
-      mt.conf_t = wa.conf[tt];
-      mt.conf_g = wa.conf[gg];
-      mt.len = wa.ex_len[tt];
-      mt.en = wa.packed[(size_t)tt * NZ + (lane & (NZ - 1))];
-      mt.y = wa.ex_y[tt];
-    }
+    Meta mt;
+    const int last = wa.count - 1;
+    const int tt = gg + wave < last ? gg + wave : last;
+    mt.conf_t = wa.conf[tt];
+    mt.conf_g = wa.conf[gg < last ? gg : last];
+    mt.len = wa.ex_len[tt];
+    mt.en = wa.packed[(size_t)tt * NZ + (lane & (NZ - 1))];
+    mt.y = wa.ex_y[tt];
     return mt;
   };
   int g = 0;
@@ -592,8 +594,15 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window
 #ifdef FMX_SEQ_TIMING
     t0 = __builtin_amdgcn_s_memtime(); ++nG;
 #endif
-    int G = 0;
-    while (G < NW && s_cand[G]) ++G;  // the group: the leading candidates
+    int G = 0;  // the group: the leading candidates (all flags read at once: an early-exit loop is NW dependent LDS round trips)
+    {
+      int c[NW];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) c[i] = s_cand[i];
+      bool run = true;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) { run = run && c[i] != 0; G += run ? 1 : 0; }
+    }
     const bool mine = wave < G;
     const int gn = g + G;             // where the next group starts: known now, so its metadata can travel during this group
     const Meta nxt = fetch(gn);
@@ -634,7 +643,7 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window
         q1 += tmp * tmp;
       }
       if (lane < NZ) terms[wave][lane] = (k1 ? myw : 0.0) * myx;     // w_j x_j, the linear term's addends in row order
-      if (lane < k8) terms[wave][NZ + lane] = fv ? 0.5 * (s1 * s1 - q1) : 0.0;  // core/Model.h:100, factor order (lanes of block 0)
+      if (lane < k16) terms[wave][NZ + lane] = fv ? 0.5 * (s1 * s1 - q1) : 0.0;  // core/Model.h:100, factor order (lanes of block 0)
       if (lane == 0) s_y[wave] = cur.y;
     }
     __syncthreads();
@@ -642,26 +651,33 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window
 
     // ---------------------------------------------------------------- S: the scalar chain, in order
     if (wave == 0) {
+      double cb0[8], cb1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cb0[i] = terms[0][i];
       for (int e = 0; e < G; ++e) {
         if constexpr (KIND == UPD_SGD_L1) { uw += h.lr * h.regw; uv += h.lr * h.regv; }  // SGD_Learner.h:92-97
-        // every lane reads the same addresses (LDS broadcast) and runs the same chain: no cross-lane traffic in the chain
+        // every lane reads the same addresses (LDS broadcast) and runs the same chain: no cross-lane traffic in the chain.
+        // The addends arrive eight at a time and in PAIRS of eights (k16: the factor slots are zero-filled to a multiple of 16),
+        // each eight requested before the eight in front of it are added, the next example's first eight before this example's
+        // multiplier is computed: the additions are the serial floor of the mode, the LDS latency need not be.  Same additions,
+        // same order (+0.0 addends change nothing).
         const double* __restrict__ T = terms[e];
         double pred = k0 ? w0 : 0.0;
+        auto pair = [&](const double* __restrict__ second, const double* __restrict__ after) {
 #pragma unroll
-        for (int u = 0; u < NZ; u += 8) {
-          double tt[8];
+          for (int i = 0; i < 8; ++i) cb1[i] = second[i];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) tt[i] = T[u + i];
+          for (int i = 0; i < 8; ++i) pred += cb0[i];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) pred += tt[i];
-        }
-        for (int f = 0; f < k8; f += 8) {  // slots k..k8 hold +0.0: adding it changes nothing
-          double tt[8];
+          for (int i = 0; i < 8; ++i) cb0[i] = after[i];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) tt[i] = T[NZ + f + i];
+          for (int i = 0; i < 8; ++i) pred += cb1[i];
+        };
+        const double* __restrict__ nextT = terms[e + 1 < G ? e + 1 : e];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) pred += tt[i];
-        }
+        for (int u = 0; u < NZ; u += 16)  // the linear term's addends; the last `after` is the first factor eight (k = 0: there is none)
+          pair(T + u + 8, (u + 16 < NZ || k16 > 0) ? T + u + 16 : nextT);
+        for (int f = 0; f < k16; f += 16) pair(T + NZ + f + 8, f + 16 < k16 ? T + NZ + f + 16 : nextT);
         const double mult = seq_grad_mult(h, pred, s_y[e]);
         if (k0) {
           if constexpr (KIND == UPD_TDAP) tdap_coord(mult, w0, h.alpha_w, h.egamma, n0, t_nu, t_delta, t_h, z0);
