@@ -775,6 +775,216 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window
 #undef FMX_T
 }
 
+// ---- pipelined windowed learner ---------------------------------------------------------------------------------------
+// fm_seq_window_k runs A, S and C of a group one after the other: while wave 0 walks the chain (S, about half of a group's time)
+// the other waves wait, and while they gather (A, a third) the chain waits.  Here wave 0 does nothing but the chain, waves
+// 1..NW-1 each own one example of a group, and the groups are software-pipelined: in step j
+//     the chain wave runs        S(g_{j-1});
+//     a worker wave runs         C(g_{j-2})  ->  A(g_j)  ->  its vote on joining g_{j+1}  ->  release fence;
+// one barrier ends the step.  A worker therefore holds the parameters of TWO examples (g_{j-1}'s wait for their multiplier
+// while g_j's are gathered): two register sets, used alternately, and every LDS buffer exists twice (step parity).
+// What may be gathered early: A(g_{j+1}) runs in step j+1, when the stores of g_{j-1} (same step) and g_j (one step later)
+// have not happened.  Candidate t joins g_{j+1} iff the candidates before it did and conf[t] < start(g_{j-1}): its last
+// earlier conflict was stored in step j at the latest and fenced before that step's barrier (C comes first in a step, so
+// the fence at the end finds those stores long complete).  If the FIRST candidate fails, g_{j+1} is empty -- a bubble; two
+// steps later the pipeline has drained up to it and it passes (conf[t] < t).  The examples, their order, the arithmetic
+// and its association are those of fm_seq_window_k; results are bitwise the one-wave kernel's (tests/test_gpu_seq_window.py).
+// Not for TDAP (its w prox reads z_w by position, A-6: neighbours may not overlap at all).
+template <int KIND, int KL, int NZ>
+__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_pipe_k(SeqArgs a, WinArgs wa, Hyper h) {
+  static_assert(KIND != UPD_TDAP, "TDAP keeps fm_seq_window_k");
+  constexpr int NW = SeqWin<KIND, KL, NZ>::NW, W = NW - 1;
+  constexpr int Q = SeqWin<KIND, KL, NZ>::Q;
+  constexpr int SL = SeqWin<KIND, KL, NZ>::SL;
+  constexpr int WIN_TERMS = SeqWin<KIND, KL, NZ>::TERMS;
+  constexpr int NS = SeqState<KIND>::N;
+  constexpr int NS1 = NS > 0 ? NS : 1, QN = Q > 1 ? SL : 1;
+  __shared__ double terms[2][W][WIN_TERMS];
+  __shared__ double s_mult[2][W], s_uw[2][W], s_uv[2][W];
+  __shared__ float s_y[2][W];
+  __shared__ int s_cand[2][W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ww = wave > 0 ? wave - 1 : 0;  // worker index (the chain wave computes with 0 and discards)
+  const bool worker = wave > 0;
+  const int k = a.k, kp = a.kp;
+  const bool k0 = h.k0 != 0, k1 = h.k1 != 0;
+  const int k16 = (k + 15) & ~15;
+  double w0 = a.scal[SC_W0], z0 = a.scal[SC_Z0], n0 = a.scal[SC_N0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
+  const int fq = lane / KL, ff = lane % KL;  // this lane's nonzero block and factor (V side)
+  const bool fv = ff < k;
+  const int fl = fv ? ff : 0;
+
+  struct Meta { int conf_t, len; uint2 en; float y; };
+  auto fetch = [&](int start) {  // unconditional loads on a clamped index: every use is guarded by its own range test
+    Meta mt;
+    const int last = wa.count - 1;
+    const int tt = start + ww < last ? start + ww : last;
+    mt.conf_t = wa.conf[tt];
+    mt.len = wa.ex_len[tt];
+    mt.en = wa.packed[(size_t)tt * NZ + (lane & (NZ - 1))];
+    mt.y = wa.ex_y[tt];
+    return mt;
+  };
+  auto leading = [&](const int* c) {
+    int v[W], G = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = c[i];
+    bool run = true;
+#pragma unroll
+    for (int i = 0; i < W; ++i) { run = run && v[i] != 0; G += run ? 1 : 0; }
+    return G;
+  };
+  // a worker's example: everything C needs later
+  struct Held {
+    bool mine;
+    int len;
+    uint32_t mycol;
+    double myx, myw, s1;
+    double stw[NS1];
+    double vv[SL];
+    double stv[NS1][SL];
+  };  // (the slots' columns and x values are re-read from the owning lanes in C: two shuffles instead of three registers per slot, held twice)
+
+  // ------------------------------------------------------------------ A: gathers and the terms of y_hat (as fm_seq_window_k)
+  auto phaseA = [&](Held& R, const Meta& mt, int par) {
+    R.len = mt.len;
+    const bool tv = lane < R.len;
+    R.mycol = tv ? mt.en.x : 0u;
+    R.myx = tv ? (double)__uint_as_float(mt.en.y) : 0.0;
+    double q1 = 0.0;
+    double xu[QN];
+    R.s1 = 0.0;
+    R.myw = a.w[R.mycol];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) R.stw[j] = seq_state_ptr<KIND>(a, true, j)[R.mycol];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      uint32_t cj;
+      if constexpr (Q == 1) cj = bcast(R.mycol, j);
+      else { cj = (uint32_t)__shfl((int)R.mycol, j * Q + fq); xu[j] = __shfl(R.myx, j * Q + fq); }
+      const size_t at = (size_t)cj * kp + fl;
+      R.vv[j] = a.V[at];
+#pragma unroll
+      for (int n = 0; n < NS; ++n) R.stv[n][j] = seq_state_ptr<KIND>(a, false, n)[at];
+    }
+#pragma unroll
+    for (int u = 0; u < NZ; ++u) {  // core/Model.h:83-97
+      double tmp;
+      if constexpr (Q == 1) tmp = R.vv[u] * bcast(R.myx, u);
+      else tmp = __shfl(R.vv[u / Q] * xu[u / Q], (u % Q) * KL + ff);
+      R.s1 += tmp;
+      q1 += tmp * tmp;
+    }
+    if (lane < NZ) terms[par][ww][lane] = (k1 ? R.myw : 0.0) * R.myx;
+    if (lane < k16) terms[par][ww][NZ + lane] = fv ? 0.5 * (R.s1 * R.s1 - q1) : 0.0;  // core/Model.h:100
+    if (lane == 0) s_y[par][ww] = mt.y;
+  };
+
+  // ------------------------------------------------------------------ C: the example's update, from registers
+  auto phaseC = [&](Held& R, int par) {
+    const double mult = s_mult[par][ww], euw = s_uw[par][ww], euv = s_uv[par][ww];
+    const bool tv = lane < R.len;
+    if (tv && (k1 || KIND == UPD_FTRL)) {
+      coord_seq<KIND>(h, true, k1, R.myw, R.myx, mult, euw, R.stw);
+      a.w[R.mycol] = R.myw;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) if (k1) seq_state_ptr<KIND>(a, true, j)[R.mycol] = R.stw[j];
+    }
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      uint32_t cj;
+      double xj;
+      if constexpr (Q == 1) { cj = bcast(R.mycol, j); xj = bcast(R.myx, j); }
+      else { cj = (uint32_t)__shfl((int)R.mycol, j * Q + fq); xj = __shfl(R.myx, j * Q + fq); }
+      const size_t at = (size_t)cj * kp + ff;
+      if (j * Q + fq < R.len && fv) {
+        double th = R.vv[j];
+        double st[NS1];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) st[n] = R.stv[n][j];
+        const double grad = R.s1 * xj - th * xj * xj;
+        coord_seq<KIND>(h, false, true, th, grad, mult, euv, st);
+        a.V[at] = th;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) seq_state_ptr<KIND>(a, false, n)[at] = st[n];
+      }
+    }
+  };
+
+  // ------------------------------------------------------------------ S: the scalar chain of one group, in order (as fm_seq_window_k)
+  auto chain = [&](int par, int G) {
+    double cb0[8], cb1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cb0[i] = terms[par][0][i];
+    for (int e = 0; e < G; ++e) {
+      if constexpr (KIND == UPD_SGD_L1) { uw += h.lr * h.regw; uv += h.lr * h.regv; }  // SGD_Learner.h:92-97
+      const double* __restrict__ T = terms[par][e];
+      double pred = k0 ? w0 : 0.0;
+      auto pair = [&](const double* __restrict__ second, const double* __restrict__ after) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cb1[i] = second[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pred += cb0[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cb0[i] = after[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pred += cb1[i];
+      };
+      const double* __restrict__ nextT = terms[par][e + 1 < G ? e + 1 : e];
+#pragma unroll
+      for (int u = 0; u < NZ; u += 16) pair(T + u + 8, (u + 16 < NZ || k16 > 0) ? T + u + 16 : nextT);
+      for (int f = 0; f < k16; f += 16) pair(T + NZ + f + 8, f + 16 < k16 ? T + NZ + f + 16 : nextT);
+      const double mult = seq_grad_mult(h, pred, s_y[par][e]);
+      if (k0) {
+        if constexpr (KIND == UPD_FTRL) {
+          const double n_old = n0;
+          n0 += mult * mult;
+          const double delta = (sqrt(n0) - sqrt(n_old)) / h.alpha_w;
+          z0 += mult - delta * w0;
+        } else w0 -= h.lr * (mult + h.reg0 * w0);
+      }
+      if constexpr (KIND == UPD_FTRL) w0 = -z0 * h.alpha_w / (h.beta_w + sqrt(n0));
+      if (lane == 0) { s_mult[par][e] = mult; s_uw[par][e] = uw; s_uv[par][e] = uv; }
+    }
+  };
+
+  // pipeline state, the same in every wave: starts of g_{j-1} and g_j, sizes of g_{j-2}, g_{j-1}, g_j
+  int stS = 0, stA = 0, szC = 0, szS = 0, szA = 0;
+  Meta cur = fetch(0);
+  if (worker && lane == 0) s_cand[1][ww] = (ww < wa.count) && cur.conf_t < 0;  // g_0: examples without an earlier conflict
+  __syncthreads();
+  szA = leading(s_cand[1]);
+
+  Held R0, R1;
+  R0.mine = false; R1.mine = false;
+  // one step; returns true when nothing is left in flight
+  auto step = [&](Held& R, int par) {
+    const int stN = stA + szA;  // where g_{j+1} starts: its metadata travels behind this step's work
+    const Meta nxt = fetch(stN);
+    if (!worker) {
+      if (szS > 0) chain(par ^ 1, szS);
+    } else {
+      if (R.mine) phaseC(R, par);   // g_{j-2}: this set, this parity
+      R.mine = ww < szA;
+      if (R.mine) phaseA(R, cur, par);
+      if (lane == 0) s_cand[par][ww] = (stN + ww < wa.count) && nxt.conf_t < stS;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this step's stores (issued first) before the barrier
+    }
+    __syncthreads();
+    const int szN = leading(s_cand[par]);
+    szC = szS; stS = stA; szS = szA; stA = stN; szA = szN; cur = nxt;
+    return stA >= wa.count && szA == 0 && szS == 0 && szC == 0;
+  };
+  for (;;) {
+    if (step(R0, 0)) break;
+    if (step(R1, 1)) break;
+  }
+
+  if (threadIdx.x == 0) {
+    a.scal[SC_W0] = w0; a.scal[SC_Z0] = z0; a.scal[SC_N0] = n0; a.scal[SC_UW] = uw; a.scal[SC_UV] = uv;
+  }
+}
+
 // the windowed learner applies when every row is a fast row; FMX_SEQ_WINDOW=0 in the environment keeps the one-wave kernel
 // entries per packed row (32 or 64), or 0: the one-wave kernel
 static int window_mode(const fmx_engine* e, const fmx_matrix* m) {
@@ -804,8 +1014,34 @@ static int ensure_window_workspace(fmx_engine* e, int64_t cap) {
   return FMX_OK;
 }
 
+// Which shapes take the pipelined kernel: measured (profiles/r02_seq_window.txt).  Two register sets fit 256 VGPRs without scratch for
+// SGD-L2 at k <= 32 and SGD-L1 at k <= 16 with rows of <= 32 entries; the other shapes spill (llvm's .private_seg_size: 32 B to
+// 768 B per lane) and still win while the spill is small next to what the overlap hides: SGD-L2 everywhere (1.2-1.6x),
+// SGD-L1 and FTRL at k <= 16 (1.3-1.5x); at k > 16 those two lose or tie and keep fm_seq_window_k.
+// FMX_SEQ_WINDOW=1 keeps the unpipelined windowed kernel everywhere, =2 pipelines every non-TDAP shape (tests compare all forms,
+// profiles/seq_window_bench.py measures them); read per call.
+template <int KIND, int KL, int NZ> struct PipeFits {
+  static constexpr bool value = KIND == UPD_SGD_L2 || ((KIND == UPD_SGD_L1 || KIND == UPD_FTRL) && KL == 16);
+};
+static int pipe_mode() {
+  const char* s = getenv("FMX_SEQ_WINDOW");
+  return !s ? 1 : (s[0] == '1' ? 0 : (s[0] == '2' ? 2 : 1));  // 0 never, 1 where it fits, 2 always
+}
+
 template <int KIND>
 static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa, int nz) {
+  if constexpr (KIND != UPD_TDAP) {
+    const int pm = pipe_mode();
+#define FMX_PIPE(KL, NZ)                                                                                                                            \
+  if (pm == 2 || (pm == 1 && PipeFits<KIND, KL, NZ>::value)) {                                                                                      \
+    hipLaunchKernelGGL((fm_seq_pipe_k<KIND, KL, NZ>), dim3(1), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, a, wa, e->hyper);                   \
+    return;                                                                                                                                         \
+  }
+    if (e->k <= 16) { if (nz == 32) { FMX_PIPE(16, 32) } else { FMX_PIPE(16, 64) } }
+    else if (e->k <= 32) { if (nz == 32) { FMX_PIPE(32, 32) } else { FMX_PIPE(32, 64) } }
+    else { FMX_PIPE(64, 32) }
+#undef FMX_PIPE
+  }
 #define FMX_WIN(KL, NZ) hipLaunchKernelGGL((fm_seq_window_k<KIND, KL, NZ>), dim3(1), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, a, wa, e->hyper)
   if (e->k <= 16) { if (nz == 32) FMX_WIN(16, 32); else FMX_WIN(16, 64); }
   else if (e->k <= 32) { if (nz == 32) FMX_WIN(32, 32); else FMX_WIN(32, 64); }

@@ -38,7 +38,7 @@ def _run(name, c, p, n, nnz, iters, random_step=1, window=True, max_nnz=32):
     P = oracle.params(min_target=float(y.min()), max_target=float(y.max()), random_step=random_step, **kw)
     w0, w, v = util.params(p, P.k, 3, fp32=False)
     solver = {"sgd": L.SOLVER_SGD, "ftrl": L.SOLVER_FTRL, "tdap": L.SOLVER_TDAP}[c["solver"]]
-    os.environ["FMX_SEQ_WINDOW"] = "1" if window else "0"
+    os.environ["FMX_SEQ_WINDOW"] = {True: "1", False: "0"}.get(window, window)  # "2": the pipelined kernel on every non-TDAP shape
     try:
         e = engine.Engine(p, task=P.task, solver=solver, num_factor=P.k, keep_w0=P.k0, keep_w1=P.k1, l2_w0=P.l2_reg0, l1_w1=P.l1_regw,
                           l2_w1=P.l2_regw, l1_v=P.l1_regv, l2_v=P.l2_regv, learn_rate=P.learn_rate, alpha_w=P.alpha_w, alpha_v=P.alpha_v,
@@ -64,6 +64,9 @@ def test_windowed_learner_is_bitwise_the_one_wave_learner(name, p, nnz):
     a, ctx = _run(name, c, p, n, nnz, 2 * n + 11, window=True)
     b, _ = _run(name, c, p, n, nnz, 2 * n + 11, window=False)
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    if c["solver"] != "tdap":  # the pipelined kernel (groups overlapped: chain of one group beside the gathers of the next)
+        d, _ = _run(name, c, p, n, nnz, 2 * n + 11, window="2")
+        assert d[0] == b[0] and np.array_equal(d[1], b[1]) and np.array_equal(d[2], b[2])
     P, rp, col, val, y, w0, w, v, order = ctx
     X = oracle.Matrix(rp, col, val, p)
     learn = {"sgd": oracle.sgd_learn, "ftrl": oracle.ftrl_learn, "tdap": oracle.tdap_learn}[c["solver"]]
@@ -81,6 +84,9 @@ def test_rows_of_33_to_64_entries_use_the_wide_layout(name):
     a, ctx = _run(name, c, p, n, 45, 2 * n + 7, window=True, max_nnz=64)
     b, _ = _run(name, c, p, n, 45, 2 * n + 7, window=False, max_nnz=64)
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    if c["solver"] != "tdap":
+        d, _ = _run(name, c, p, n, 45, 2 * n + 7, window="2", max_nnz=64)
+        assert d[0] == b[0] and np.array_equal(d[1], b[1]) and np.array_equal(d[2], b[2])
     P, rp, col, val, y, w0, w, v, order = ctx
     assert np.diff(rp).max() > 40
     learn = {"sgd": oracle.sgd_learn, "ftrl": oracle.ftrl_learn, "tdap": oracle.tdap_learn}[c["solver"]]
@@ -96,6 +102,8 @@ def test_windowed_learner_with_random_strides_and_many_chunks():
     a, ctx = _run("strides", c, 50000, 60000, 8, 150000, random_step=3, window=True)
     b, _ = _run("strides", c, 50000, 60000, 8, 150000, random_step=3, window=False)
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    d, _ = _run("strides", c, 50000, 60000, 8, 150000, random_step=3, window="2")
+    assert d[0] == b[0] and np.array_equal(d[1], b[1]) and np.array_equal(d[2], b[2])
 
 
 def test_rows_longer_than_the_fast_path_keep_the_one_wave_kernel():
@@ -148,3 +156,6 @@ def test_fuzz_windowed_equals_one_wave(seed):
     # (TDAP with keep.w0 off leaves w0 = -0/0 = NaN, in the reference too: TDAP_Learner.h:192)
     same = lambda x, y: np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
     assert same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2]), (c, p, n, nnz, max_nnz, rstep)
+    if c["solver"] != "tdap":
+        d, _ = _run("fuzz%d" % seed, c, p, n, nnz, iters, random_step=rstep, window="2", max_nnz=max_nnz)
+        assert same(d[0], b[0]) and same(d[1], b[1]) and same(d[2], b[2]), ("pipelined", c, p, n, nnz, max_nnz, rstep)
