@@ -17,14 +17,15 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     order = oracle.visit_order(n, 1 + rep % 3, 120_000, seed=rep)
     v0 = np.random.default_rng(rep).normal(0, 0.01, (k, p))
     out = []
-    for win in ("1", "0"):
+    for win in ("1", "0", "2"):  # windowed; one wave; windowed + pipelined groups (not for TDAP: "2" falls back to windowed there)
         os.environ["FMX_SEQ_WINDOW"] = win
         e = engine.Engine(p, solver=solver, num_factor=k, learn_rate=0.02, mode=L.MODE_SEQUENTIAL, **kw)
         e.set_params(0.0, None, v0)
         e.train_order(m, order)
         out.append(e.get_params())
         del e
-    same = all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) for a, b in zip(out[0], out[1]))
+    same = all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) and np.array_equal(np.asarray(c), np.asarray(b), equal_nan=True)
+               for a, b, c in zip(out[0], out[1], out[2]))
     bad += not same
     print(f"rep {rep:3d} k={k:2d} solver={solver} stride={1 + rep % 3}: {'same' if same else 'MISMATCH'}", flush=True)
 print(f"{bad} mismatches in {rep + 1} runs, {time.time() - t0:.0f} s")
