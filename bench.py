@@ -45,7 +45,7 @@ def parse():
                          "that learns per example like a 4096-row one at the reference's learning rate on this workload (a coordinate then "
                          "occurs ~8 times per step; profiles/r02_learning_*.txt) -- and 1048576 per GPU for FTRL and for N > 1, where the step "
                          "must be long enough to hide the exchange of the 72 MB buffer (the global batch is N times larger either way)")
-    ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 262144; 524288 for k > 32)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 524288; 262144 for k <= 8)")
     ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
     ap.add_argument("--workload", choices=["uniform", "criteo"], default="uniform",
                     help="uniform: BASELINE.json configs[1] / [2] (one column per stratum).  criteo: configs[3]'s shape -- 33 M features, 39 nnz/row "
@@ -95,7 +95,7 @@ def algorithmic_bytes(z, k, p, rows, e=4, ftrl=False):
 
 
 def effective_tile(B, k, tile_rows):
-    want = tile_rows or (524_288 if k > 32 else 262_144)  # fmx_api.hip effective_tile_rows()
+    want = tile_rows or (524_288 if k > 8 else 262_144)  # fmx_api.hip effective_tile_rows(): kp32 >= 16
     tiles = -(-B // want)
     return -(-B // tiles)
 
@@ -383,7 +383,8 @@ def main():
         tile_rows = effective_tile(B, k, args.tile_rows)
         eb = 8 if args.state_fp64 else 4
         # per LAUNCH: one tile.  A sparse tile's phase 2 visits only the features that occur in it (their count is known from ingest)
-        p_walk = int(np.mean([e.compact_count(m, b) for b in range(min(nb_full, 8))])) if criteo else p
+        sparse_tiles = world == 1 and tile_rows >= B and e.compact_info(m)[2]
+        p_walk = int(np.mean([e.compact_count(m, b) for b in range(min(nb_full, 8))])) if (criteo or sparse_tiles) else p
         b_fwd, b_upd, _ = algorithmic_bytes(z, k, p_walk, tile_rows, eb, ftrl)
         b_step = algorithmic_bytes(z, k, p, B, eb, ftrl)[2]
         kernels = {
@@ -410,7 +411,7 @@ def main():
                                     f"(BASELINE.json configs[{2 if ftrl else 1}])") if not criteo else
                                    (f"Criteo-shaped synthetic {args.rows}x{p} resident ({z} nnz/row: 13 dense + 26 categorical fields, skew 3), k={k}, "
                                     f"{args.solver.upper()} mini-batch (BASELINE.json configs[3]'s shape; its 4e9 rows are streamed: fmx_train_stream)"),
-                       **({"features_occurring_per_step": p_walk} if criteo else {}),
+                       **({"features_occurring_per_step": p_walk} if (criteo or sparse_tiles) else {}),
                        "batch_rows_per_gpu": B, "tile_rows": tile_rows, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
                        "batch_reduce": "mean gradient per coordinate per step (FMX_REDUCE_MEAN)",
                        "state": ("fp64" if args.state_fp64 else "fp32") + " V[p][k] + w[p]" + (" + z, n" if ftrl else "") + ", fp64 accumulation",

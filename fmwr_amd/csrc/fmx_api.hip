@@ -291,9 +291,10 @@ int ensure_probit(fmx_engine* e) {
 
 // rows-per-tile actually used: a step of batch_rows rows is cut into ceil(batch_rows / tile) equal-ish tiles
 static int64_t effective_tile_rows(const fmx_engine* e) {
-  // measured optimum (profiles/r01_sweep_batch.txt, r01_sweep_tile.txt): 262144 rows up to k = 32 (S = tile x 64..128 B stays
-  // in the Infinity Cache next to V), 524288 for wider rows where the per-tile sweep over all p features weighs more
-  const int64_t want = e->cfg.tile_rows > 0 ? e->cfg.tile_rows : (e->kp32 >= 64 ? 524288 : 262144);
+  // measured optimum (profiles/r02_sweep_tile.txt, 1M-row steps at configs[1]'s shape): 524288 rows from k = 16 up (k = 16: 865 ->
+  // 910 M ex/s against 262144-row tiles, k = 32: 583 -> 651; the per-tile sweep over all p features is paid half as often), 262144
+  // below (k = 8: 990 against 891 -- the rows are 32 bytes and the tile's S table is what has to stay cached); 1048576 loses everywhere
+  const int64_t want = e->cfg.tile_rows > 0 ? e->cfg.tile_rows : (e->kp32 >= 16 ? 524288 : 262144);
   if (e->cfg.batch_rows <= want) return e->cfg.batch_rows;
   const int64_t tiles = (e->cfg.batch_rows + want - 1) / want;
   return (e->cfg.batch_rows + tiles - 1) / tiles;

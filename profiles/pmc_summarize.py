@@ -12,7 +12,7 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        if "fm_rows_forward" in name and "true>" in name: kn = "fm_rows_forward"            # the training launch (one tile)
+        if "fm_rows_forward" in name and ", true" in name: kn = "fm_rows_forward"           # the training launch (one tile): <T, LPR, TRAIN = true, WGT>
         elif "fm_rows_forward" in name: kn = "fm_rows_forward_predict"                      # bench's forward-only pass (all rows)
         elif "fm_cols_update" in name: kn = "fm_cols_update"
         elif "fm_scalar" in name: kn = "fm_scalar_update"

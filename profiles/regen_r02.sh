@@ -7,8 +7,20 @@ rm -rf $O; mkdir -p $O
 python3 bench.py > $O/bench_sgd.json 2> $O/bench_sgd.err; echo "bench sgd rc=$?"
 python3 bench.py --solver ftrl > $O/bench_ftrl.json 2> $O/bench_ftrl.err; echo "bench ftrl rc=$?"
 python3 bench.py --batch-rows 1048576 --no-extras --cpu-rows 0 > $O/bench_sgd_1m.json 2>/dev/null; echo "bench sgd 1M rc=$?"
+python3 bench.py --workload criteo --no-extras --cpu-rows 0 > $O/bench_criteo.json 2> $O/bench_criteo.err; echo "bench criteo rc=$?"
+# Under the profilers phase 1 runs the schedule the engine settles on in the plain runs above (serial at both configs: see
+# config.rows_forward_schedule in the bench lines), pinned, so that the per-kernel averages are of ONE form -- without the pin the
+# first 14 large launches alternate between the two forms and pull rocprof's average 3-4 % above the settled launches.
+export FMX_ROWS_SERIAL=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sgd -- python3 bench.py --cpu-rows 0 --no-extras > $O/bench_sgd_under_rocprof.json 2> $O/rocprof_sgd.err; echo "rocprof sgd rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ftrl -- python3 bench.py --solver ftrl --cpu-rows 0 --no-extras > $O/bench_ftrl_under_rocprof.json 2> $O/rocprof_ftrl.err; echo "rocprof ftrl rc=$?"
 bash profiles/pmc_run.sh $O/pmc_sgd --no-extras > $O/pmc_sgd.log 2>&1; echo "pmc sgd rc=$?"
 bash profiles/pmc_run.sh $O/pmc_ftrl --solver ftrl --no-extras > $O/pmc_ftrl.log 2>&1; echo "pmc ftrl rc=$?"
+unset FMX_ROWS_SERIAL
+python3 profiles/sweep.py --factors 4,8,16,32,64,128 > $O/sweep_k.txt 2>&1
+python3 profiles/sweep.py --features 250000,1000000,4000000,16000000,33000000 > $O/sweep_features.txt 2>&1
+python3 profiles/sweep.py --batch-rows 65536,262144,524288,1048576,2097152 > $O/sweep_batch.txt 2>&1
+python3 profiles/sweep.py --tile-rows 65536,131072,262144,524288 --batch-rows 1048576 > $O/sweep_tile.txt 2>&1
+timeout -k 10 300 python3 profiles/stream_bench.py > $O/stream.txt 2>&1
+python3 profiles/small_batch_probe.py 1024 4096 16384 65536 > $O/small_batch.txt 2>&1
 find $O -name "*kernel_stats.csv" | head
