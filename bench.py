@@ -115,7 +115,7 @@ def pmc_traffic(kernel, args):
             return int(a[a.index(name) + 1]) if name in a else default
         solver = "ftrl" if "ftrl" in a else "sgd"
         k = opt("--factors", 16 if solver == "sgd" else 64)
-        same = (effective_tile(opt("--batch-rows", 262_144), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
+        same = (effective_tile(opt("--batch-rows", 262_144 if solver == "sgd" else 1_048_576), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
                 and k == args.factors and opt("--features", 1_000_000) == args.features and opt("--rows", 10_000_000) == args.rows
                 and opt("--nnz", 30) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64))
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
