@@ -34,6 +34,10 @@
 // ceiling with ONE entry (its V row and its w) outstanding per lane group -- the waves on a CU supply the parallelism, and
 // more per wave only lengthens the queues (measured at configs[1]: 1 -> 0.147 ms per tile, 4 -> 0.164).  A small step is the
 // opposite: a handful of waves per CU, every round a bare memory round trip, so it keeps four.
+// waves per SIMD the lean sparse form of phase 2 is compiled for (register budget 512 / this)
+#ifndef FMX_SPARSE_WAVES
+#define FMX_SPARSE_WAVES 4
+#endif
 #ifndef FMX_U_LARGE
 #define FMX_U_LARGE 4
 #endif
@@ -649,7 +653,7 @@ __device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const V
 
 // What happens to a feature's sums: [+ the exchange buffer's] -> [publish] -> [apply the update].  Shared by the main
 // kernel (short lists) and the long-list finisher.  Called by every lane of the feature's group; lig == 0 handles w.
-template <typename ST, int LPR, int KIND>
+template <typename ST, int LPR, int KIND, bool GBUF = true>
 __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, const ColsTables<ST>& T, int64_t j, int lig, const double* vf,
                                             CoordSums& s, double rows, int64_t ci = 0, const ST* w_pre = nullptr) {
   using vec_t = typename Slice<ST>::vec;
@@ -658,7 +662,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
   constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
   // exchange buffer: blocks of F features, each GV [F][KP] | GW [F] | CNT [F] | (has_q: QV [F][KP] | QW [F]); then tail[4]
   const size_t at = (size_t)j * KP + lig * VEC;  // in the parameter tables
-  if (a.load_gbuf || a.store_gbuf) {
+  if (GBUF && (a.load_gbuf || a.store_gbuf)) {
     const uint32_t F = T.gb_feats;
     const uint32_t blk = (uint32_t)j / F, r = (uint32_t)j - blk * F;
     ST* gGV = T.gbuf + (size_t)blk * T.gb_block_elems;
@@ -797,14 +801,17 @@ __device__ __forceinline__ ST* exchange_tail(const ColsTables<ST>& T) {
 // skewed feature distribution) are left to the long-list kernels below; walking them with one group would serialise the tile.
 // (88-90 VGPRs: 5 workgroups per CU.  Asking the register allocator for 6 waves per SIMD spills to scratch -- phase 2 0.16 -> 0.31 ms per
 // tile -- and 4 or 8 or 16 gathers in flight per lane (FMX_U) change nothing or lose: profiles/r02_small_batch.txt, r02_ab.txt.)
-template <typename ST, int LPR, int KIND>
-__global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables<ST> T) {
+// SPARSE: the lean form for a sparse tile walked list by list (a.direct) with no dense exchange buffer in play -- no staging
+// array, no exchange-buffer code; fewer registers and 4 KB of LDS, so more workgroups per CU.  That walk is latency x occupancy
+// bound (three dependent memory rounds per list, lists of one to four entries), not byte bound: DESIGN.md section 6.1.
+template <typename ST, int LPR, int KIND, bool SPARSE = false>
+__global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables<ST> T) {
   using vec_t = typename Slice<ST>::vec;
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
   constexpr int FPW = WG_THREADS / LPR;  // features (lists) per workgroup
   constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
-  __shared__ uint2 stage[STAGE_ENTRIES + FMX_U];
+  __shared__ uint2 stage[SPARSE ? 1 : STAGE_ENTRIES + FMX_U];
   __shared__ double red_g[WG_THREADS], red_q[WG_THREADS];
   __shared__ unsigned long long wg_next;
 
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   const uint32_t* __restrict__ off = a.tfeat ? a.toff : a.bptr;
   uint32_t off_a = 0, off_b = 0;
   int64_t j = idx;
-  if (a.tfeat) {  // one join, one wait: the id and both offsets travel together
+  if (SPARSE || a.tfeat) {  // one join, one wait: the id and both offsets travel together
     j = (int64_t)a.tfeat[idx];
     off_a = a.toff[idx]; off_b = a.toff[idx + 1];
   } else if (a.walk) {
@@ -844,8 +851,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   sums_zero(s);
   double vf[VEC];
 
-  if (a.walk) {
-    const int64_t lo = off[I0], hi = off[I1];
+  if (SPARSE || a.walk) {
+    const int64_t lo = SPARSE ? 0 : off[I0], hi = SPARSE ? 0 : off[I1];
     int64_t ta = have ? (int64_t)off_a : 0, tb = have ? (int64_t)off_b : 0;
     if (a.long_min > 0 && tb - ta > (int64_t)a.long_min) { have = false; ta = tb = 0; }  // a long list: not ours
     const ST* __restrict__ St = T.S + lig * VEC;
@@ -893,7 +900,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
       for (int u = 0; u < FMX_U; ++u)  // occurrences in row order
         if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(en[u].y));
     };
-    if (a.direct) {
+    if (SPARSE || a.direct) {
       // Sparse tiles (lists of one or two entries): every group reads its own entries straight from memory -- neighbouring groups
       // read neighbouring addresses, so the loads coalesce by themselves -- and the workgroup never meets at a barrier: one
       // dependent round trip fewer per list, in a regime that is nothing but dependent round trips.
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
           take(en);
         }
       }
-    } else {
+    } else if constexpr (!SPARSE) {
       int64_t c0 = lo;
       while (c0 < hi) {
         if (a.long_min > 0) {
@@ -962,7 +969,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_update_k(ColsArgs a, Hyper
   double rows = a.global_rows;
   if (a.apply && a.load_gbuf && rows <= 0.0) rows = tail_get_rows(gtail);  // the global row count travelled in the reduced buffer
 
-  if (have) cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows, I0 + gid, &w_pre);
+  if (have) cols_finish<ST, LPR, KIND, !SPARSE>(a, h, T, j, lig, vf, s, rows, I0 + gid, &w_pre);
 
   if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
     scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
@@ -1097,9 +1104,11 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   const bool lng = a.walk && la.n_long > 0;
   dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + (WG_THREADS / 64) - 1) / (WG_THREADS / 64)));
   constexpr bool NQ = (KIND == UPD_FTRL || KIND == UPD_TDAP);
+  const bool sparse_form = a.direct && a.tfeat && !a.load_gbuf && !a.store_gbuf;
 #define FMX_COLS_CASE(L)                                                                                        \
   case L:                                                                                                       \
-    hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                     \
+    if (sparse_form) hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND, true>), g, b, 0, e->stream, a, e->hyper, T); \
+    else hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                \
     if (lng) {                                                                                                  \
       hipLaunchKernelGGL((fm_cols_long_partial_k<ST, L, NQ>), g1, b, 0, e->stream, la, a, T);                   \
       hipLaunchKernelGGL((fm_cols_long_finish_k<ST, L, KIND>), g2, b, 0, e->stream, la, a, e->hyper, T);        \
@@ -1163,7 +1172,11 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
   static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
   a.embed = embed_ok ? embed_mode(e->k, mb_kp(e), !mb_wide(e)) : EMBED_NONE;
   static const bool direct_ok = [] { const char* v = getenv("FMX_DIRECT_LISTS"); return !(v && v[0] == '0'); }();
-  a.direct = (direct_ok && a.walk && a.tfeat && a.n_tfeat > 0 && a.list_entries < 4 * (int64_t)a.n_tfeat) ? 1 : 0;  // sparse tile, lists of < 4 entries on average
+  // Measured on the Criteo shape (six entries per occurring feature, heads in the long-list kernels): walking the lists straight from
+  // memory 0.42 ms per step against 0.59 through the LDS staging with its barriers and its skip-the-long-lists handshake
+  // (profiles/r02_direct_lists.txt); FMX_DIRECT_MAX_AVG overrides the bound for A/B runs.
+  static const int direct_avg = [] { const char* v = getenv("FMX_DIRECT_MAX_AVG"); return v && atoi(v) > 0 ? atoi(v) : 16; }();
+  a.direct = (direct_ok && a.walk && a.tfeat && a.n_tfeat > 0 && a.list_entries < direct_avg * (int64_t)a.n_tfeat) ? 1 : 0;  // sparse tile, short lists on average
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
