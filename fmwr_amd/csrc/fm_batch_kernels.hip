@@ -838,9 +838,13 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
   const uint32_t* __restrict__ off = a.tfeat ? a.toff : a.bptr;
   uint32_t off_a = 0, off_b = 0;
   int64_t j = idx;
+  uint32_t row0 = 0, x0 = 0x3f800000u;  // SPARSE: the list's first entry, inline in the directory
   if (SPARSE || a.tfeat) {  // one join, one wait: the id and both offsets travel together
     j = (int64_t)a.tfeat[idx];
     off_a = a.toff[idx]; off_b = a.toff[idx + 1];
+    if constexpr (SPARSE) {
+      if (a.inline0) { row0 = a.trow0[idx]; x0 = a.tval0[idx]; }
+    }
   } else if (a.walk) {
     off_a = a.bptr[idx]; off_b = a.bptr[idx + 1];
   }
@@ -900,12 +904,75 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
       for (int u = 0; u < FMX_U; ++u)  // occurrences in row order
         if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(en[u].y));
     };
+    // the same, one entry at a time (the lean form's first batch)
+    auto issue1 = [&](uint32_t row, bool ok, vec_t& sv, ST& av) {
+      if (a.buf_gather) {
+        sv = buf_row(s_rsrc, ok ? row * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
+        av = buf_elem(a_rsrc, (ok && !a.embed) ? row * (uint32_t)sizeof(ST) : BUF_SKIP, ST());  // embedded: no request goes out
+      } else {
+        sv = gather_row(St + (size_t)(ok ? row : 0u) * KP);
+        av = T.amul[ok ? row : 0u];
+      }
+    };
+    auto fin1 = [&](vec_t& sv, ST& av) {
+      if constexpr (sizeof(ST) == 4) {
+        if (a.embed) {
+          const float m = embed_take<LPR>(sv, lig, a.embed);
+          if (a.buf_gather) av = m;
+        }
+      }
+    };
+    int64_t t_first = ta;  // where the list-by-list loops below start
+    if (SPARSE && a.inline0) {
+      // Round 2 of the list: next to its V row and w goes out the S row of its FIRST entry -- whose row number came inline with the
+      // directory -- and the reads of entries 1..3: the first gathers overlap the V row's fetch.  Same additions, same order.
+      // Measured (profiles/r02_direct_lists.txt): Criteo shape (six entries per list) 0.425 -> 0.385 ms per step; tiles of one-entry
+      // lists (uniform 33 M features) LOSE 2-6 % -- they are bound by the rate of random requests, not by rounds, and the
+      // earlier gather only deepens the queues (section 6.2's finding again) -- so the launcher asks for it from two entries
+      // per list on average.
+      const bool ok0 = ta < tb && row0 < a.rows_active;
+      vec_t sv0;
+      ST av0;
+      issue1(row0, ok0, sv0, av0);
+      uint32_t r[FMX_U], x[FMX_U];
+#pragma unroll
+      for (int u = 1; u < FMX_U; ++u) { r[u] = 0u; x[u] = 0x3f800000u; }
+      // (loads under a branch: its join waits for this round's requests -- which is what the next line does anyway; a wave of
+      // one-entry lists skips the block)
+      if (tb - ta > 1) {
+#pragma unroll
+        for (int u = 1; u < FMX_U; ++u) r[u] = a.brow[ta + u < tb ? ta + u : ta];
+        if (!a.unit) {
+#pragma unroll
+          for (int u = 1; u < FMX_U; ++u) x[u] = __float_as_uint(a.bval[ta + u < tb ? ta + u : ta]);
+        }
+      }
+      fin1(sv0, av0);
+      slice_get(v_raw, vf);
+      if (ok0) sums_add<NEED_Q>(s, vf, sv0, av0, __uint_as_float(x0));
+      if (tb - ta > 1) {
+        vec_t sv[FMX_U];
+        ST av[FMX_U];
+        bool ok[FMX_U];
+#pragma unroll
+        for (int u = 1; u < FMX_U; ++u) {
+          ok[u] = ta + u < tb && r[u] < a.rows_active;
+          issue1(r[u], ok[u], sv[u], av[u]);
+        }
+#pragma unroll
+        for (int u = 1; u < FMX_U; ++u) fin1(sv[u], av[u]);
+#pragma unroll
+        for (int u = 1; u < FMX_U; ++u)
+          if (ok[u]) sums_add<NEED_Q>(s, vf, sv[u], av[u], __uint_as_float(x[u]));
+      }
+      t_first = ta + FMX_U;
+    }
     if (SPARSE || a.direct) {
       // Sparse tiles (lists of one or two entries): every group reads its own entries straight from memory -- neighbouring groups
       // read neighbouring addresses, so the loads coalesce by themselves -- and the workgroup never meets at a barrier: one
       // dependent round trip fewer per list, in a regime that is nothing but dependent round trips.
       if (a.unit) {
-        for (int64_t t = ta; t < tb; t += FMX_U) {
+        for (int64_t t = t_first; t < tb; t += FMX_U) {
           uint32_t r[FMX_U];
 #pragma unroll
           for (int u = 0; u < FMX_U; ++u) r[u] = a.brow[t + u < tb ? t + u : t];
@@ -915,7 +982,7 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
           take(en);
         }
       } else {
-        for (int64_t t = ta; t < tb; t += FMX_U) {
+        for (int64_t t = t_first; t < tb; t += FMX_U) {
           uint32_t r[FMX_U], x[FMX_U];
 #pragma unroll
           for (int u = 0; u < FMX_U; ++u) {
@@ -1177,6 +1244,7 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
   // (profiles/r02_direct_lists.txt); FMX_DIRECT_MAX_AVG overrides the bound for A/B runs.
   static const int direct_avg = [] { const char* v = getenv("FMX_DIRECT_MAX_AVG"); return v && atoi(v) > 0 ? atoi(v) : 16; }();
   a.direct = (direct_ok && a.walk && a.tfeat && a.n_tfeat > 0 && a.list_entries < direct_avg * (int64_t)a.n_tfeat) ? 1 : 0;  // sparse tile, short lists on average
+  a.inline0 = (a.direct && a.trow0 && a.list_entries >= 2 * (int64_t)a.n_tfeat) ? 1 : 0;
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;

@@ -135,12 +135,17 @@ __global__ void head_flags_k(const uint32_t* __restrict__ keys, int64_t cnt, uin
 }
 
 // sparse directory: the run starts are in soff[0 .. n); add the ids and the end marker
+// (a tile plan also gets each list's first entry inline: row0 / val0, from the sorted entries; the record merge passes nulls)
 __global__ void lists_finish_k(const uint32_t* __restrict__ keys, uint32_t* __restrict__ soff, const uint32_t* __restrict__ dcounts,
-                               uint32_t cnt, uint32_t* __restrict__ feat) {
+                               uint32_t cnt, uint32_t* __restrict__ feat, const uint32_t* __restrict__ brow = nullptr,
+                               const float* __restrict__ bval = nullptr, uint32_t* __restrict__ row0 = nullptr, uint32_t* __restrict__ val0 = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = dcounts[0];
-  if (i < (int64_t)n) feat[i] = keys[soff[i]];
-  else if (i == (int64_t)n) soff[i] = cnt;
+  if (i < (int64_t)n) {
+    const uint32_t o = soff[i];
+    feat[i] = keys[o];
+    if (row0) { row0[i] = brow[o]; val0[i] = bval ? __float_as_uint(bval[o]) : 0x3f800000u; }
+  } else if (i == (int64_t)n) soff[i] = cnt;
 }
 
 // flags[i] = list i holds more than long_min entries (lists beyond the directory's end: 0)
@@ -205,6 +210,7 @@ int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense)
   const size_t o_off = dense ? take((size_t)p + 1) : 0;
   const size_t o_feat = dense ? 0 : take(t.cap_lists ? t.cap_lists : 1);
   const size_t o_soff = dense ? 0 : take((size_t)t.cap_lists + 1);
+  const size_t o_row0 = dense ? 0 : take(t.cap_lists ? t.cap_lists : 1), o_val0 = dense ? 0 : take(t.cap_lists ? t.cap_lists : 1);
   const size_t o_lfeat = take(t.cap_long), o_lpos = take(t.cap_long), o_lseg = take((size_t)t.cap_long + 2);
   const size_t o_sl = take(t.cap_seg), o_sb = take(t.cap_seg), o_se = take(t.cap_seg);
   FMX_HIP(hipMalloc(&t.pool, at));
@@ -214,6 +220,8 @@ int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense)
   t.off_in_pool = dense ? 1 : 0;
   t.feat = dense ? nullptr : (uint32_t*)(b + o_feat);
   t.soff = dense ? nullptr : (uint32_t*)(b + o_soff);
+  t.row0 = dense ? nullptr : (uint32_t*)(b + o_row0);
+  t.val0 = dense ? nullptr : (uint32_t*)(b + o_val0);
   t.lfeat = (uint32_t*)(b + o_lfeat); t.lpos = (uint32_t*)(b + o_lpos); t.lseg_ptr = (uint32_t*)(b + o_lseg);
   t.seg_list = (uint32_t*)(b + o_sl); t.seg_begin = (uint32_t*)(b + o_sb); t.seg_end = (uint32_t*)(b + o_se);
   return FMX_OK;
@@ -298,7 +306,8 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
       hipLaunchKernelGGL(head_flags_k, grid(cnt), dim3(T), 0, stream, ws.keys_out, cnt, ws.flags);
       FMX_HIP(rocprim::select(ws.prim_temp, tb, ids, ws.flags, t.soff, t.dcounts, (size_t)cnt, stream));
     }
-    hipLaunchKernelGGL(lists_finish_k, grid((int64_t)t.cap_lists + 1), dim3(T), 0, stream, ws.keys_out, t.soff, t.dcounts, (uint32_t)cnt, t.feat);
+    hipLaunchKernelGGL(lists_finish_k, grid((int64_t)t.cap_lists + 1), dim3(T), 0, stream, ws.keys_out, t.soff, t.dcounts, (uint32_t)cnt, t.feat,
+                       (const uint32_t*)(brow + t.base), unit_values ? (const float*)nullptr : (const float*)(bval + t.base), t.row0, t.val0);
     off = t.soff; n_max = t.cap_lists;
   }
   // long lists

@@ -359,6 +359,7 @@ static int cols_args(fmx_engine* e, fmx_matrix* m, const TileRun& t, bool sparse
   c.unit = m->unit_values;
   if (pl.feat && sparse_ok) {
     c.tfeat = pl.feat; c.toff = pl.soff; c.n_tfeat = pl.n_lists;
+    c.trow0 = pl.row0; c.tval0 = pl.val0;
     c.list_entries = pl.cnt;
   } else {
     if (!pl.off) FMX_TRY(plan_ensure_dense(m, t.tile, e->stream));

@@ -120,6 +120,8 @@ struct fmx_matrix {
     uint32_t* off = nullptr;       // dense directory [p + 1] (entry offsets relative to base), or null
     uint32_t* feat = nullptr;      // sparse directory: ids [n_lists] ...
     uint32_t* soff = nullptr;      // ... and offsets [n_lists + 1], or null
+    uint32_t* row0 = nullptr;      // ... and each list's FIRST entry inline (row, value bits): a one-entry list needs no trip to brow/bval
+    uint32_t* val0 = nullptr;
     uint32_t n_lists = 0;          // occurring features (sparse directory)
     uint32_t cap_lists = 0;        // capacity of feat / soff - 1
     // long lists (more than list_long_min() entries): cut into segments of LIST_SEG entries
@@ -317,6 +319,9 @@ struct ColsArgs {
   const uint32_t* tfeat; // ids of the features occurring in the tile (ascending), or null: walk all p features
   const uint32_t* toff;  // [n_tfeat+1] entry offsets of those features (compact copy of bptr)
   uint32_t n_tfeat;
+  const uint32_t* trow0; // [n_tfeat] first entry of each list, inline (row; value bits)
+  const uint32_t* tval0;
+  int inline0;           // the lean form gathers a list's first S row beside its V row (set by the launcher)
   int walk;              // accumulate this tile's sums from S / amul
   int load_gbuf;         // add the sums already in the exchange buffer (earlier tiles, or the all-reduced global sums)
   int store_gbuf;        // write the sums back to the exchange buffer
