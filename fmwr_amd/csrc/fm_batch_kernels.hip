@@ -1067,17 +1067,31 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   CoordSums s;
   sums_zero(s);
   const ST* __restrict__ St = T.S + lig * VEC;
+  // unconditional loads on clamped indices, values selected afterwards (a `cond ? load : constant` costs a wait per entry: the
+  // segment of a wave is ONE dependent chain, and this kernel's duration is that chain's -- 0.13 ms per step on the Criteo shape
+  // with eight serialised reads per round, section 6.2)
   for (int64_t t = ta + sub; t < tb; t += (int64_t)NSUB * FMX_U) {
-    uint32_t r[FMX_U];
+    uint32_t r[FMX_U], xb[FMX_U];
     float x[FMX_U];
     bool ok[FMX_U];
 #pragma unroll
     for (int u = 0; u < FMX_U; ++u) {
       const int64_t tt = t + (int64_t)u * NSUB;
-      const bool in = tt < tb;
-      r[u] = in ? a.brow[tt] : 0xFFFFFFFFu;
-      x[u] = in ? (a.unit ? 1.0f : a.bval[tt]) : 0.f;
-      ok[u] = r[u] < a.rows_active;
+      r[u] = a.brow[tt < tb ? tt : t];
+      xb[u] = 0x3f800000u;
+    }
+    if (!a.unit) {  // (the join of this branch waits for the round's reads: what the next lines need anyway)
+#pragma unroll
+      for (int u = 0; u < FMX_U; ++u) {
+        const int64_t tt = t + (int64_t)u * NSUB;
+        xb[u] = __float_as_uint(a.bval[tt < tb ? tt : t]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < FMX_U; ++u) {
+      const bool in = t + (int64_t)u * NSUB < tb;
+      x[u] = in ? __uint_as_float(xb[u]) : 0.f;
+      ok[u] = in && r[u] < a.rows_active;
       if (!ok[u]) r[u] = 0;
     }
     vec_t sv[FMX_U];
