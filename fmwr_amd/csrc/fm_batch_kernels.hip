@@ -1301,9 +1301,12 @@ __global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, Cols
   const int64_t i = (int64_t)blockIdx.x * FPW + gid;
   ST* gtail = exchange_tail<ST, LPR>(T);
   if (i < n) {
+    // Three dependent rounds -- {feature id, list bounds} -> {V row, w, record positions} -> {records} -- with every load of a round
+    // issued before the first one is used (the plain loop paid two rounds per PART on top of the V row's own: section 6.2).
     const int64_t j = r.rfeat[i];
-    double vf[VEC];
-    slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
+    const uint32_t t0 = r.roff[i], t1 = r.roff[i + 1];
+    const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC);
+    const ST w_pre = T.w[j];
     const int qo = (NEED_Q && T.has_q) ? KP : 0;
     const ST* recs = reinterpret_cast<const ST*>(r.recs);
     // The parts are added in the exchange's element type, in rank order: exactly what an all-reduce(sum) of the dense buffer
@@ -1311,21 +1314,42 @@ __global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, Cols
     ST aG[VEC], aQ[VEC], aGw = (ST)0, aQw = (ST)0, aC = (ST)0;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { aG[q] = (ST)0; aQ[q] = (ST)0; }
-    for (uint32_t t = r.roff[i]; t < r.roff[i + 1]; ++t) {
-      const ST* rec = recs + (size_t)r.pos[t] * T.rec_elems;
-      double g[VEC];
-      slice_get(*reinterpret_cast<const vec_t*>(rec + lig * VEC), g);
+    constexpr int RU = 4;  // parts per round
+    for (uint32_t t = t0; t < t1; t += RU) {
+      uint32_t pp[RU];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) aG[q] = aG[q] + (ST)g[q];
-      if (qo) {
-        slice_get(*reinterpret_cast<const vec_t*>(rec + KP + lig * VEC), g);
+      for (int u = 0; u < RU; ++u) pp[u] = r.pos[t + u < t1 ? t + u : t];
+      vec_t gv[RU], qv[RU];
+      ST gw[RU], qw[RU], gc[RU];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) aQ[q] = aQ[q] + (ST)g[q];
+      for (int u = 0; u < RU; ++u) {
+        const ST* rec = recs + (size_t)pp[u] * T.rec_elems;
+        gv[u] = *reinterpret_cast<const vec_t*>(rec + lig * VEC);
+        qv[u] = *reinterpret_cast<const vec_t*>(rec + qo + lig * VEC);  // qo == 0: the same slice again (not used)
+        gw[u] = rec[KP + qo];
+        qw[u] = rec[KP + qo + 1];
+        gc[u] = rec[KP + qo + 2];
       }
-      aGw = aGw + rec[KP + qo];
-      if (qo) aQw = aQw + rec[KP + qo + 1];
-      aC = aC + rec[KP + qo + 2];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        if (t + u < t1) {
+          double g[VEC];
+          slice_get(gv[u], g);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) aG[q] = aG[q] + (ST)g[q];
+          if (qo) {
+            slice_get(qv[u], g);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) aQ[q] = aQ[q] + (ST)g[q];
+            aQw = aQw + qw[u];
+          }
+          aGw = aGw + gw[u];
+          aC = aC + gc[u];
+        }
+      }
     }
+    double vf[VEC];
+    slice_get(v_raw, vf);
     CoordSums s;
     sums_zero(s);
 #pragma unroll
@@ -1333,7 +1357,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, Cols
     s.Gw = (double)aGw; s.Qw = (double)aQw; s.cnt = (double)aC;
     double rows = a.global_rows;
     if (rows <= 0.0) rows = tail_get_rows(gtail);
-    cols_finish<ST, LPR, KIND>(a, h, T, j, lig, vf, s, rows);
+    cols_finish<ST, LPR, KIND, false>(a, h, T, j, lig, vf, s, rows, 0, &w_pre);
   }
   if (blockIdx.x == 0 && a.scalar != SCALAR_NONE)
     scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
