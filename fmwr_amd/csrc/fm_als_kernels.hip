@@ -86,14 +86,28 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
   float kx[ALS_KEEP];
   uint32_t kr[ALS_KEEP];
   double2 kc[ALS_KEEP];
+  // :310-317, entries lane, lane+64, ...  Loads are unconditional on a clamped index and selected afterwards: `in ? cval[t] : 0`
+  // compiles to a branch with a wait at its join, i.e. three dependent round trips PER SLOT instead of two for all of them
+  // (DESIGN.md section 6.2).  Slots 0-1 (128 entries: every column of one-column-per-field data) always, slots 2.. only for longer columns.
+  auto load_slots = [&](int s0, int s1) {
 #pragma unroll
-  for (int s = 0; s < ALS_KEEP; ++s) {  // :310-317, entries lane, lane+64, ... (independent gathers: all in flight together)
-    const int64_t t = b + lane + 64 * s;
-    const bool in = t < e;
-    kx[s] = in ? cval[t] : 0.f;
-    kr[s] = in ? crow[t] : 0u;
-    kc[s] = in ? qe[kr[s]] : make_double2(0.0, 0.0);
-  }
+    for (int s = s0; s < s1; ++s) {
+      const int64_t t = b + lane + 64 * s;
+      const int64_t tc = t < e ? t : 0;
+      kx[s] = cval[tc];
+      kr[s] = crow[tc];
+    }
+#pragma unroll
+    for (int s = s0; s < s1; ++s) kc[s] = qe[kr[s]];
+#pragma unroll
+    for (int s = s0; s < s1; ++s) {
+      if (b + lane + 64 * s >= e) { kx[s] = 0.f; kc[s] = make_double2(0.0, 0.0); }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < ALS_KEEP; ++s) { kx[s] = 0.f; kr[s] = 0u; kc[s] = make_double2(0.0, 0.0); }
+  load_slots(0, 2);
+  if (e - b > 128) load_slots(2, ALS_KEEP);
 #pragma unroll
   for (int s = 0; s < ALS_KEEP; ++s) {
     const float xx = kx[s] * kx[s];
@@ -212,10 +226,21 @@ __global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __re
   const int64_t b = col_ptr[i], e = col_ptr[i + 1];
   const double w_old = w[i];
   double w_mean = 0.0, w_var = 0.0;
-  for (int64_t t = b + lane; t < e; t += 64) {
-    const double x = (double)cval[t];
-    w_mean += qe[crow[t]].y * x - w_old * x * x;
-    w_var += x * x;
+  constexpr int WU = 2;  // entries per lane whose reads are in flight together (unconditional, clamped: see als_level_k)
+  for (int64_t t0 = b + lane; t0 < e; t0 += 64 * WU) {
+    float xs[WU]; uint32_t rs[WU]; double es[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) { const int64_t t = t0 + 64 * u, tc = t < e ? t : t0; xs[u] = cval[tc]; rs[u] = crow[tc]; }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) es[u] = qe[rs[u]].y;
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {  // same additions, same order as one entry per iteration
+      if (t0 + 64 * u < e) {
+        const double x = (double)xs[u];
+        w_mean += es[u] * x - w_old * x * x;
+        w_var += x * x;
+      }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -229,7 +254,16 @@ __global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __re
   if (bad_number(w_new)) return;  // CHECK_PARAM: keep the old value, skip the corrections
   if (lane == 0) w[i] = w_new;
   const double w_diff = w_old - w_new;
-  for (int64_t t = b + lane; t < e; t += 64) qe[crow[t]].y -= (double)cval[t] * w_diff;
+  for (int64_t t0 = b + lane; t0 < e; t0 += 64 * WU) {
+    float xs[WU]; uint32_t rs[WU]; double es[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) { const int64_t t = t0 + 64 * u, tc = t < e ? t : t0; xs[u] = cval[tc]; rs[u] = crow[tc]; }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) es[u] = qe[rs[u]].y;
+#pragma unroll
+    for (int u = 0; u < WU; ++u)
+      if (t0 + 64 * u < e) qe[rs[u]].y = es[u] - (double)xs[u] * w_diff;
+  }
 }
 
 // ---- heavy columns and the approximate (grouped) sweep -----------------------------------------------------------------------
@@ -264,13 +298,18 @@ __global__ __launch_bounds__(WG_THREADS) void als_sweep_k(const uint32_t* __rest
   constexpr int UN = 4;
   for (int64_t t0 = b + tid; t0 < e; t0 += (int64_t)T * UN) {
     float x[UN]; double2 c[UN];
+    uint32_t rr[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int64_t t = t0 + (int64_t)u * T;
-      const bool in = t < e;
-      x[u] = in ? cval[t] : 0.f;
-      c[u] = in ? qe_old[crow[t]] : make_double2(0.0, 0.0);
+    for (int u = 0; u < UN; ++u) {  // unconditional on a clamped index, selected afterwards (see als_level_k)
+      const int64_t t = t0 + (int64_t)u * T, tc = t < e ? t : t0;
+      x[u] = cval[tc];
+      rr[u] = crow[tc];
     }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) c[u] = qe_old[rr[u]];
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (t0 + (int64_t)u * T >= e) { x[u] = 0.f; c[u] = make_double2(0.0, 0.0); }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       if (W) { const double xd = (double)x[u]; mean += c[u].y * xd - old * xd * xd; var += xd * xd; }
@@ -301,13 +340,18 @@ __global__ __launch_bounds__(WG_THREADS) void als_sweep_k(const uint32_t* __rest
   if (tid == 0) P[at] = nv;
   const double diff = old - nv;
   for (int64_t t0 = b + tid; t0 < e; t0 += (int64_t)T * UN) {
+    float xs[UN]; uint32_t rs[UN]; double2 cs[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { const int64_t t = t0 + (int64_t)u * T, tc = t < e ? t : t0; xs[u] = cval[tc]; rs[u] = crow[tc]; }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) cs[u] = qe_old[rs[u]];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int64_t t = t0 + (int64_t)u * T;
       if (t >= e) continue;
-      const float x = cval[t];
-      const uint32_t r = crow[t];
-      const double2 c = qe_old[r];
+      const float x = xs[u];
+      const uint32_t r = rs[u];
+      const double2 c = cs[u];
       double dq, de;
       if (W) { dq = 0.0; de = (double)x * diff; }
       else { const float xx = x * x; const double h = (double)x * c.x - (double)xx * old; dq = (double)x * diff; de = h * diff; }
