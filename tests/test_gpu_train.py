@@ -951,3 +951,48 @@ def test_mcmc_v_hyper_priors_and_the_tracker_loop(fm):
     # the first record is the start model's clamped RMSE (:103-111), from the oracle's forward
     yh = np.clip(oracle.predict_batch(P, X, w0, w, v.ravel()), y.min(), y.max())
     assert abs(trace[0] - oracle.evaluate(oracle.REGRESSION, oracle.RMSE, yh, y)) < 1e-9 and len(trace) == iters
+
+
+@pytest.mark.parametrize("law", ["iid", "ragged", "fields", "heavy"])
+def test_als_levels_by_frontier_walk_equal_the_relaxation_and_a_host_restatement(fm, law):
+    """The level of a feature (its place in the exact ALS schedule) = the longest chain of row predecessors.  The frontier
+    walk (default), the round-1 relaxation (FMX_ALS_LEVELS=relax) and a plain host loop must agree on every feature,
+    including features that never occur (level 0), empty rows and rows of different lengths."""
+    import os
+    engine, L = fm
+    rng = np.random.default_rng({"iid": 1, "ragged": 2, "fields": 3, "heavy": 4}[law])
+    n, p = 4000, 700
+    if law == "heavy":       # columns of more than 16 384 entries are walked by the whole grid (level_heavy_k): features 3 and 40 sit in every row
+        n = 18000
+        cols = [np.unique(np.concatenate([[3, 40], rng.choice(p - 50, 5, replace=False)])) for _ in range(n)]
+    elif law == "fields":
+        fields, width = 7, 100
+        cols = [np.sort(rng.integers(0, width, fields) + np.arange(fields) * width) for _ in range(n)]
+    else:
+        lens = np.full(n, 9) if law == "iid" else rng.integers(0, 14, n)
+        cols = [np.sort(rng.choice(p - 50, int(q), replace=False)) for q in lens]      # the last 50 features never occur
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    col = np.concatenate(cols).astype(np.uint32)
+    val = rng.normal(0, 1, len(col)).astype(np.float32)
+    want = np.zeros(p, np.int64)
+    order = np.argsort(col, kind="stable")                 # features ascending: a feature's predecessors are all smaller
+    row_of = np.repeat(np.arange(n), np.diff(rp))
+    run = np.full(n, -1, np.int64)                         # level of the row's latest placed entry
+    for j in np.unique(col):
+        rows = row_of[order[np.searchsorted(col[order], j, "left"):np.searchsorted(col[order], j, "right")]]
+        want[j] = run[rows].max() + 1
+        run[rows] = want[j]
+    got = {}
+    for form in ("frontier", "relax"):
+        os.environ["FMX_ALS_LEVELS"] = form
+        try:
+            m = engine.Matrix.from_csr(rp, col, val, p, np.zeros(n, np.float32))
+            e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=2, mode=L.MODE_SEQUENTIAL)
+            levels, _, approx, lof = e.als_plan(m)
+            got[form] = (levels, approx, lof.astype(np.int64))
+            e.close(); m.close()
+        finally:
+            os.environ.pop("FMX_ALS_LEVELS", None)
+    assert not got["frontier"][1] and not got["relax"][1]
+    assert np.array_equal(got["frontier"][2], want) and np.array_equal(got["relax"][2], want)
+    assert got["frontier"][0] == got["relax"][0] == want.max() + 1
