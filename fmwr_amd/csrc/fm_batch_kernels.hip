@@ -839,13 +839,13 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
   uint32_t off_a = 0, off_b = 0;
   int64_t j = idx;
   uint32_t row0 = 0, x0 = 0x3f800000u;  // SPARSE: the list's first entry, inline in the directory
-  if (SPARSE || a.tfeat) {  // one join, one wait: the id and both offsets travel together
+  if (a.tfeat) {  // one join, one wait: the id and both offsets travel together
     j = (int64_t)a.tfeat[idx];
     off_a = a.toff[idx]; off_b = a.toff[idx + 1];
     if constexpr (SPARSE) {
       if (a.inline0) { row0 = a.trow0[idx]; x0 = a.tval0[idx]; }
     }
-  } else if (a.walk) {
+  } else if (SPARSE || a.walk) {
     off_a = a.bptr[idx]; off_b = a.bptr[idx + 1];
   }
   const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC);
@@ -1185,7 +1185,7 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   const bool lng = a.walk && la.n_long > 0;
   dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + (WG_THREADS / 64) - 1) / (WG_THREADS / 64)));
   constexpr bool NQ = (KIND == UPD_FTRL || KIND == UPD_TDAP);
-  const bool sparse_form = a.direct && a.tfeat && !a.load_gbuf && !a.store_gbuf;
+  const bool sparse_form = a.direct && !a.load_gbuf && !a.store_gbuf;
 #define FMX_COLS_CASE(L)                                                                                        \
   case L:                                                                                                       \
     if (sparse_form) hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND, true>), g, b, 0, e->stream, a, e->hyper, T); \
@@ -1258,6 +1258,11 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
   // (profiles/r02_direct_lists.txt); FMX_DIRECT_MAX_AVG overrides the bound for A/B runs.
   static const int direct_avg = [] { const char* v = getenv("FMX_DIRECT_MAX_AVG"); return v && atoi(v) > 0 ? atoi(v) : 16; }();
   a.direct = (direct_ok && a.walk && a.tfeat && a.n_tfeat > 0 && a.list_entries < direct_avg * (int64_t)a.n_tfeat) ? 1 : 0;  // sparse tile, short lists on average
+  {  // the list-by-list form over a DENSE directory too, for steps that touch no exchange buffer (no staging, no barriers): small
+     // but consistent at configs[1]'s shapes (profiles/r02_direct_lists.txt: phase 2 -1 % ... -7 %); FMX_DIRECT_DENSE=0 switches it off
+    static const bool dense_direct = [] { const char* v = getenv("FMX_DIRECT_DENSE"); return !(v && v[0] == '0'); }();
+    if (dense_direct && direct_ok && a.walk && !a.tfeat && !a.load_gbuf && !a.store_gbuf && a.f0 == 0 && a.f1 == e->p) a.direct = 1;
+  }
   a.inline0 = (a.direct && a.trow0 && a.list_entries >= 2 * (int64_t)a.n_tfeat) ? 1 : 0;
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
