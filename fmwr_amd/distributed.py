@@ -18,6 +18,8 @@ if _L._lib is not None and "torch" not in sys.modules:
     raise ImportError("fmwr_amd.distributed (or torch) must be imported before the first fmwr_amd call: libfmx.so is already "
                       "loaded with the system HIP runtime and torch would bring a second one")
 
+import os
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -181,6 +183,9 @@ class DataParallel:
         self.s = stepper
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # FMX_DP_FORCE_COLLECTIVES=1: issue every collective even with one rank (they are identities then) -- lets the real backend
+        # (RCCL) run the whole exchange on a one-GPU box: tests/test_gpu_distributed.py
+        self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get("FMX_DP_FORCE_COLLECTIVES") == "1")
         self.exchange = exchange
         if exchange == "compact":
             self._init_compact()
@@ -193,19 +198,19 @@ class DataParallel:
         round trip to size its all-gather.  Falls back to the dense exchange if any rank's tiles are not sparse single-tile steps."""
         s = self.s
         ok = torch.tensor([1 if s.compact_usable() else 0], dtype=torch.int64, device=s.device)
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) == 0:
             self.exchange = "dense"
             return
         mine = torch.tensor(s.compact_counts(), dtype=torch.int64, device=s.device)
         nb = torch.tensor([mine.numel()], dtype=torch.int64, device=s.device)
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=self.group)
         pad = torch.zeros(int(nb.item()), dtype=torch.int64, device=s.device)
         pad[:mine.numel()] = mine
         table = [torch.zeros_like(pad) for _ in range(self.world)]
-        if self.world > 1:
+        if self.collective:
             dist.all_gather(table, pad, group=self.group)
         else:
             table = [pad]
@@ -222,7 +227,7 @@ class DataParallel:
         n = int(counts.max())
         with s.comm_context():
             s.grad_compact(batch, rows_limit)
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(s.compact_tail(), op=dist.ReduceOp.SUM, group=self.group)
                 recv = s.compact_recv(self.world, n)
                 if n > 0:
@@ -237,7 +242,7 @@ class DataParallel:
         self.last_exchange_bytes = int(self.world * n * s.rec_elems * recv.element_size()) if n > 0 else 0
 
     def _reduce(self, t):
-        if self.world > 1:
+        if self.collective:
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
@@ -248,7 +253,7 @@ class DataParallel:
         self.last_exchange_bytes = int(self.s.buffer().numel() * self.s.buffer().element_size())
         if chunks <= 1:
             self.s.grad(batch, rows_limit)
-            if self.world > 1:
+            if self.collective:
                 with self.s.comm_context():
                     dist.all_reduce(self.s.buffer(), op=dist.ReduceOp.SUM, group=self.group)
             self.s.apply()

@@ -160,3 +160,55 @@ def test_compact_exchange_equals_dense_all_reduce_two_ranks(tmp_path, solver, wi
     got = np.load(out)
     assert got["compact_bytes"] * 5 < got["dense_bytes"]
     assert np.all(np.isfinite(got["v"]))
+
+
+RCCL_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from fmwr_amd import _lib as L, engine
+from fmwr_amd.distributed import DataParallel, EngineStepper
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))     # RCCL, one rank: every collective really runs
+mode = sys.argv[2]
+if mode == "dense":
+    n, p, z, k, B = 40000, 5000, 10, 16, 4000
+    m = engine.Matrix.synthetic(n, p, z, 7, device=0)
+    kw = dict(exchange_chunks=3)
+else:
+    n, p, z, k, B = 6000, 400000, 12, 8, 2000                          # entries per step < features: sparse tiles, compact exchange
+    m = engine.Matrix.synthetic(n, p, z, 7, device=0)
+    kw = {}
+mk = lambda **extra: engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_FTRL, num_factor=k, l1_v=1e-4, l2_w1=1e-3, l2_v=1e-3,
+                                   mode=L.MODE_MINIBATCH, batch_rows=B, **extra)
+v0 = np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+def run(force):
+    os.environ["FMX_DP_FORCE_COLLECTIVES"] = "1" if force else "0"
+    e = mk(**kw); e.set_params(0.0, None, v0)
+    st = EngineStepper(e, m, 0, dense=(mode == "dense"))
+    dp = DataParallel(st, exchange=mode)
+    assert dp.exchange == mode and dp.collective == force
+    for s in range(6):
+        dp.step(s % e.num_batches(m))
+    e.sync(); torch.cuda.synchronize()
+    return e.get_params()
+a, b = run(True), run(False)      # through RCCL (identities with one rank) / the same step with the collectives left out
+same = a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+print("RCCL_WORLD1", mode, "bitwise" if same else "DIFFERENT", flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if same else 3)
+'''
+
+
+@pytest.mark.parametrize("mode", ["dense", "compact"])
+def test_the_rccl_backend_itself_runs_the_exchange_world1(tmp_path, mode):
+    """The N > 1 drivers' plumbing on the REAL backend: torch.distributed "nccl" (= RCCL) with one rank on the one GPU.  The tensors
+    made from the engine's device pointers, the engine's stream as a torch ExternalStream, the asynchronous chunked all-reduce and
+    the padded all-gather of records all execute (FMX_DP_FORCE_COLLECTIVES=1); with one rank they are identities, so the result must
+    be bitwise that of the same steps with the collectives left out."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", str(script), ROOT, mode], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "bitwise" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])
