@@ -33,7 +33,7 @@
 // Phase 1 keeps fewer in flight when the chip is full: a step large enough for the 256-thread workgroups runs at the gather
 // ceiling with ONE entry (its V row and its w) outstanding per lane group -- the waves on a CU supply the parallelism, and
 // more per wave only lengthens the queues (measured at configs[1]: 1 -> 0.147 ms per tile, 4 -> 0.164).  A small step is the
-// opposite: a handful of waves per CU, every round a bare memory round trip, so it keeps four.
+// opposite: a handful of waves per CU, every round a bare memory round trip, so it keeps eight.
 // waves per SIMD the lean sparse form of phase 2 is compiled for (register budget 512 / this)
 #ifndef FMX_SPARSE_WAVES
 #define FMX_SPARSE_WAVES 4
@@ -42,7 +42,7 @@
 #define FMX_U_LARGE 4
 #endif
 #ifndef FMX_U_SMALL
-#define FMX_U_SMALL 4
+#define FMX_U_SMALL 8  // (4 / 8 / 16: 16.0 / 14.5 / 14.1 us per 1 024-row step, 21.9 / 21.4 / 21.2 at 4 096, equal at 16 384, 56.0 / 56.7 / 58.0 at 24 576)
 #endif
 
 namespace fmx {
@@ -1263,7 +1263,7 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
     static const bool dense_direct = [] { const char* v = getenv("FMX_DIRECT_DENSE"); return !(v && v[0] == '0'); }();
     if (dense_direct && direct_ok && a.walk && !a.tfeat && !a.load_gbuf && !a.store_gbuf && a.f0 == 0 && a.f1 == e->p) a.direct = 1;
   }
-  a.inline0 = (a.direct && a.trow0 && a.list_entries >= 2 * (int64_t)a.n_tfeat) ? 1 : 0;
+  a.inline0 = (a.direct && a.trow0 && a.list_entries >= 2 * (int64_t)a.n_tfeat) ? 1 : 0;  // (small launches of one-entry lists do not gain either)
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
