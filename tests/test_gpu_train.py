@@ -22,9 +22,9 @@ def fm():
     return engine, _lib
 
 
-def _engine(fm, p, P, solver, mode, batch_rows=64):
+def _engine(fm, p, P, solver, mode, batch_rows=64, **extra):
     engine, L = fm
-    return engine.Engine(p, batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM, task=P.task, solver=solver, num_factor=P.k, keep_w0=P.k0, keep_w1=P.k1, l2_w0=P.l2_reg0,
+    return engine.Engine(p, **extra, batch_reduce=L.REDUCE_MEAN if P.batch_mean else L.REDUCE_SUM, task=P.task, solver=solver, num_factor=P.k, keep_w0=P.k0, keep_w1=P.k1, l2_w0=P.l2_reg0,
                          l1_w1=P.l1_regw, l2_w1=P.l2_regw, l1_v=P.l1_regv, l2_v=P.l2_regv, learn_rate=P.learn_rate,
                          alpha_w=P.alpha_w, alpha_v=P.alpha_v, beta_w=P.beta_w, beta_v=P.beta_v, random_step=P.random_step,
                          mode=mode, batch_rows=batch_rows, min_target=P.min_target, max_target=P.max_target)
@@ -996,3 +996,57 @@ def test_als_levels_by_frontier_walk_equal_the_relaxation_and_a_host_restatement
     assert not got["frontier"][1] and not got["relax"][1]
     assert np.array_equal(got["frontier"][2], want) and np.array_equal(got["relax"][2], want)
     assert got["frontier"][0] == got["relax"][0] == want.max() + 1
+
+
+@pytest.mark.parametrize("wide", [0, 1], ids=["fp32", "fp64"])
+@pytest.mark.parametrize("one_hot", [False, True], ids=["values", "one-hot"])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+@pytest.mark.parametrize("name", ["sgd_l2_cls", "sgd_l1_cls", "ftrl_l1l2_cls"])
+def test_sparse_tiles_with_lists_of_a_few_entries(fm, name, reduce, one_hot, wide):
+    """The Criteo regime in small: fewer entries per step than features (sparse directory), but the features that occur are
+    drawn from a small pool, so their lists hold 2..16 entries on average -- the lean list-by-list form of phase 2 WITH the
+    list's first entry inline in the directory (its S row gathered beside the V row) -- plus one feature in almost every row
+    (a long list inside the sparse tile) and a ragged last step.  fp32 state against the fp64 oracle at 1e-5, fp64 state at 1e-11."""
+    engine, L = fm
+    c = next(x for x in CASES if x["name"] == name)
+    rng = np.random.default_rng(sum(map(ord, name)) + int(one_hot))
+    n, p, batch, z = 7000, 50000, 3000, 12                       # 36 000 entries per step < 50 000 features
+    pool = np.sort(rng.choice(np.arange(50, p), 5000, replace=False))
+    rows = []
+    for _ in range(n):
+        own = rng.choice(pool, z - 1, replace=False)
+        rows.append(np.sort(np.concatenate([[7] if rng.random() < 0.95 else [pool[0]], own])).astype(np.int64))
+        rows[-1] = np.unique(rows[-1])
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows).astype(np.uint32)
+    val = np.ones(len(col), np.float32) if one_hot else rng.normal(0, 1, len(col)).astype(np.float32)
+    seed = 31
+    y = util.labels(n, seed, "classification")
+    kw = {k: v for k, v in c.items() if k not in ("name", "solver")}
+    P = oracle.params(min_target=float(y.min()), max_target=float(y.max()), **kw)
+    P.batch_mean = int(reduce == "mean")
+    if reduce == "sum":
+        P.learn_rate = P.learn_rate / 40.0                       # feature 7 sums ~2 850 gradients per step
+    w0, w, v = util.params(p, P.k, seed, fp32=True)
+    X = oracle.Matrix(rp, col, val, p)
+    mb = (oracle.SgdMinibatch if c["solver"] == "sgd" else oracle.FtrlMinibatch)(P, X, y, w0, w, v.ravel())
+    e = _engine(fm, p, P, L.SOLVER_SGD if c["solver"] == "sgd" else L.SOLVER_FTRL, L.MODE_MINIBATCH, batch_rows=batch, state_fp64=wide)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    tol = 1e-11 if wide else V_RTOL
+    info = e.compact_info(m)
+    assert info[2], "the tiles of this matrix must be sparse (fewer entries than features)"
+    lists = e.compact_count(m, 0)
+    assert 2 * lists <= batch * z < 16 * lists, (lists, batch * z)   # the regime this test is about
+    nb = -(-n // batch)
+    for s in range(nb + 2):
+        b = s % nb
+        mb.step(b * batch, min((b + 1) * batch, n))
+        e.step(m, b)
+    e.sync()
+    g0, gw, gv = e.get_params()
+    rv = mb.v.reshape(P.k, p)
+    assert util.rel_err(gv, rv) < tol, util.rel_err(gv, rv)
+    assert util.rel_err(gw, mb.w) < tol and abs(g0 - mb.w0.value) < tol * max(1.0, abs(mb.w0.value))
+    touched = np.zeros(p, bool); touched[col] = True
+    assert np.array_equal(gv[:, ~touched], v[:, ~touched].astype(np.float32).astype(np.float64))   # features that never occur are not written
