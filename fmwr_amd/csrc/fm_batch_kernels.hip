@@ -760,15 +760,22 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
   ST sa_[VEC], sb_[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { sa_[i] = (ST)0; sb_[i] = (ST)0; }
+  // every state element of the coordinate is requested in ONE round -- the V side's and, by every lane of the group (same address:
+  // one request), the w side's, which used to be read behind `if (lig == 0)` after the V stores: a second dependent round trip
+  ST wa = (ST)0, wb = (ST)0;
   if constexpr (KIND != UPD_SGD_L2) {
-    slice_get(*reinterpret_cast<const vec_t*>(T.sV + at), tmp);
+    const vec_t raw_a = *reinterpret_cast<const vec_t*>(T.sV + at);
+    wa = T.sw[j];
+    if constexpr (KIND == UPD_FTRL) {
+      const vec_t raw_b = *reinterpret_cast<const vec_t*>(T.nV + at);
+      wb = T.nw[j];
+      slice_get(raw_b, tmp);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) sb_[i] = (ST)tmp[i];
+    }
+    slice_get(raw_a, tmp);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) sa_[i] = (ST)tmp[i];
-  }
-  if constexpr (KIND == UPD_FTRL) {
-    slice_get(*reinterpret_cast<const vec_t*>(T.nV + at), tmp);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) sb_[i] = (ST)tmp[i];
   }
   double out[VEC];
 #pragma unroll
@@ -781,9 +788,6 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
     // FTRL recomputes w on every touched column even when keep.w1 is off (FTRL_Learner.h:172-183); SGD skips (:111)
     const bool k1 = h.k1 != 0;
     if (k1 || KIND == UPD_FTRL) {
-      ST wa = (ST)0, wb = (ST)0;
-      if constexpr (KIND != UPD_SGD_L2) wa = T.sw[j];
-      if constexpr (KIND == UPD_FTRL) wb = T.nw[j];
       const double wn = coord_update<KIND, ST>(h, true, (double)(w_pre ? *w_pre : T.w[j]), s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
       T.w[j] = (ST)wn;
       if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
