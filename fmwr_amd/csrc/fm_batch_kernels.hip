@@ -383,51 +383,56 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
   static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
   static const int force = [] { const char* v = getenv("FMX_ROWS_SERIAL"); return v ? atoi(v) : -1; }();
   RowsTune& tu = e->rows_tune;
-  const bool wide = a.wg_threads != 64;
-  int trial = -1;  // index of this launch among the timed ones
-  a.serial = 1;
-  if (force >= 0) {
-    a.serial = force;
-  } else {
-    const int64_t key = a.unit ? 1 : 0;
-    if (train && wide && a.nrows >= RowsTune::MIN_ROWS && key != tu.key) { tu.key = key; tu.decided = -1; tu.launches = 0; }
-    if (tu.decided >= 0) {
-      a.serial = tu.decided;
-    } else if (train && wide && a.nrows >= RowsTune::MIN_ROWS) {
-      if (!tu.events) {
-        bool ok = true;
-        for (auto& ev : tu.ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
-        FMX_CHECK(ok, FMX_ERR_HIP, "rows_forward: could not create the tuning events");
-        tu.events = true;
-      }
-      trial = tu.launches++;
-      a.serial = trial % 2 == 0 ? 1 : 0;
-      FMX_HIP(hipEventRecord(tu.ev[2 * trial], e->stream));
+  // The schedule of one wide launch of `nrows` rows (RowsTune): pinned, decided, or -- for a large launch while the engine is still
+  // measuring -- this launch's turn in the alternation; *trial is then its index and the launch is bracketed by two events.
+  auto pick = [&](const RowsArgs& r, int* serial, int* trial) -> int {
+    *trial = -1;
+    *serial = 1;
+    if (force >= 0) { *serial = force; return FMX_OK; }
+    const bool timed = r.wg_threads != 64 && r.nrows >= RowsTune::MIN_ROWS;
+    const int64_t key = r.unit ? 1 : 0;
+    if (timed && key != tu.key) { tu.key = key; tu.decided = -1; tu.launches = 0; }
+    if (tu.decided >= 0) { *serial = tu.decided; return FMX_OK; }
+    if (!timed) return FMX_OK;
+    if (!tu.events) {
+      bool ok = true;
+      for (auto& ev : tu.ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+      FMX_CHECK(ok, FMX_ERR_HIP, "rows_forward: could not create the tuning events");
+      tu.events = true;
     }
-  }
+    *trial = tu.launches++;
+    *serial = *trial % 2 == 0 ? 1 : 0;
+    FMX_HIP(hipEventRecord(tu.ev[2 * *trial], e->stream));
+    return FMX_OK;
+  };
+  auto done = [&](int trial) -> int {
+    if (trial < 0) return FMX_OK;
+    FMX_HIP(hipEventRecord(tu.ev[2 * trial + 1], e->stream));
+    if (tu.launches == RowsTune::TRIALS) {  // the one wait of the measurement
+      FMX_HIP(hipEventSynchronize(tu.ev[2 * trial + 1]));
+      double ms[2] = {0.0, 0.0};
+      for (int i = 2; i < RowsTune::TRIALS; ++i) {
+        float t = 0.f;
+        FMX_HIP(hipEventElapsedTime(&t, tu.ev[2 * i], tu.ev[2 * i + 1]));
+        ms[i % 2 == 0 ? 1 : 0] += t;
+      }
+      tu.ms[0] = ms[0]; tu.ms[1] = ms[1];
+      tu.decided = ms[1] <= ms[0] ? 1 : 0;
+    }
+    return FMX_OK;
+  };
   a.embed = (train && embed_ok) ? embed_mode(e->k, fp64_tables ? e->kp64 : e->kp32, !fp64_tables) : EMBED_NONE;  // the same rule as launch_cols_update
   prof_begin(e, FMX_KERNEL_ROWS_FORWARD);
   int st = FMX_OK;
   if (train) {
+    int trial;
+    FMX_TRY(pick(a, &a.serial, &trial));
     st = fp64_tables ? launch_rows_w<double, true>(e, a, e->kp64) : launch_rows_w<float, true>(e, a, e->kp32);
-    if (trial >= 0 && st == FMX_OK) {
-      FMX_HIP(hipEventRecord(tu.ev[2 * trial + 1], e->stream));
-      if (tu.launches == RowsTune::TRIALS) {  // the one wait of the measurement
-        FMX_HIP(hipEventSynchronize(tu.ev[2 * trial + 1]));
-        double ms[2] = {0.0, 0.0};
-        for (int i = 2; i < RowsTune::TRIALS; ++i) {
-          float t = 0.f;
-          FMX_HIP(hipEventElapsedTime(&t, tu.ev[2 * i], tu.ev[2 * i + 1]));
-          ms[i % 2 == 0 ? 1 : 0] += t;
-        }
-        tu.ms[0] = ms[0]; tu.ms[1] = ms[1];
-        tu.decided = ms[1] <= ms[0] ? 1 : 0;
-      }
-    }
+    if (st == FMX_OK) st = done(trial);
   } else {
     // Forward-only passes over many rows go out as launches of 262 144 rows: measured at configs[1]
     // (profiles/forward_probe.py) such launches run at 0.58 ns/row, 1 M-row launches at 0.69, 4 M-row launches at 0.75 --
-    // the same optimum as the training tiles.
+    // the same optimum as the training tiles.  (A forward-only process measures its schedule on these launches.)
     const int64_t SLAB = 1 << 18;
     const int kp = fp64_tables ? e->kp64 : e->kp32;
     for (int64_t off = 0; off < a.nrows && st == FMX_OK; off += SLAB) {
@@ -437,7 +442,10 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
       if (a.yhat) s.yhat = a.yhat + off;
       if (a.qout) s.qout = a.qout + (size_t)off * kp;
       s.wg_threads = rows_wg_threads(a.nrows, kp / (fp64_tables ? 2 : 4));
+      int trial;
+      FMX_TRY(pick(s, &s.serial, &trial));
       st = fp64_tables ? launch_rows_w<double, false>(e, s, kp) : launch_rows_w<float, false>(e, s, kp);
+      if (st == FMX_OK) st = done(trial);
     }
   }
   prof_end(e);
