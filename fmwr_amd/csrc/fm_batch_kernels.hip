@@ -935,7 +935,7 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
       }
     };
     int64_t t_first = ta;  // where the list-by-list loops below start
-    if (SPARSE && a.inline0) {
+    if constexpr (SPARSE) if (a.inline0) {
       // Round 2 of the list: next to its V row and w goes out the S row of its FIRST entry -- whose row number came inline with the
       // directory -- and the reads of entries 1..3: the first gathers overlap the V row's fetch.  Same additions, same order.
       // Measured (profiles/r02_direct_lists.txt): Criteo shape (six entries per list) 0.425 -> 0.385 ms per step; tiles of one-entry
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
       }
       t_first = ta + FMX_U;
     }
-    if (SPARSE || a.direct) {
+    if constexpr (SPARSE) {  // (the launcher picks this instantiation whenever a.direct is set)
       // Sparse tiles (lists of one or two entries): every group reads its own entries straight from memory -- neighbouring groups
       // read neighbouring addresses, so the loads coalesce by themselves -- and the workgroup never meets at a barrier: one
       // dependent round trip fewer per list, in a regime that is nothing but dependent round trips.
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
           take(en);
         }
       }
-    } else if constexpr (!SPARSE) {
+    } else {
       int64_t c0 = lo;
       while (c0 < hi) {
         if (a.long_min > 0) {
