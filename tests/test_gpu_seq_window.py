@@ -22,6 +22,7 @@ SOLVERS = {
     "sgd_l1_k32": dict(solver="sgd", k=32, l1_regw=1e-3, l1_regv=5e-4, learn_rate=0.03),
     "ftrl_k24": dict(solver="ftrl", k=24, l1_regw=1e-3, l1_regv=1e-3, l2_regw=1e-2, l2_regv=1e-2),
     "tdap_k20": dict(solver="tdap", k=20, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=1e-3, alpha_v=0.05),
+    "ftrl_k40": dict(solver="ftrl", k=40, l1_regw=1e-3, l1_regv=1e-3, l2_regw=1e-2, l2_regv=1e-2),   # four waves per workgroup: three workers in the pipelined form
     "tdap_k40": dict(solver="tdap", k=40, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-2, l2_regv=1e-2, gamma=1e-3, alpha_v=0.05),
     # no factors at all, and a single one
     "sgd_k0": dict(solver="sgd", k=0, l2_regw=1e-3, l2_reg0=1e-3, learn_rate=0.05),
