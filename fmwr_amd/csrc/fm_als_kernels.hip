@@ -437,6 +437,115 @@ __global__ __launch_bounds__(WG_THREADS) void als_sweep_k(const uint32_t* __rest
   }
 }
 
+// ---- very long columns, exact form: one column over MANY workgroups -----------------------------------------------------------
+// A Zipf head feature holds a million entries; one workgroup walking it is milliseconds per pass, and such features sit in
+// thousands of consecutive levels (a dependent chain of launches).  Columns of more than ALS_SPLIT (16 384) entries are therefore cut
+// into segments of ALS_SPLIT_SEG entries: als_vh_partial_k sums a segment (the first pass of als_sweep_k), als_vh_value_k adds
+// a feature's segment sums in segment order and takes the coordinate step, als_vh_apply_k applies the rank-1 corrections
+// segment by segment.  Features of one level share no row, so the segments of a level never write the same (q, e).  Fixed
+// geometry, fixed order: reproducible; the association of the two sums differs from the one-workgroup form (oracle parity 1e-10).
+constexpr int64_t ALS_SPLIT = 16384, ALS_SPLIT_SEG = 8192;  // (65536 / 16384: Zipf exact sweep 4.0 s; one workgroup per column: 6.7 s)
+
+template <bool W>
+__global__ __launch_bounds__(WG_THREADS) void als_vh_partial_k(const uint32_t* __restrict__ vh, const uint32_t* __restrict__ seg_feat,
+                                                               const int64_t* __restrict__ seg_b, const int64_t* __restrict__ seg_e, int64_t seg0,
+                                                               const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
+                                                               const float* __restrict__ cval, const double* __restrict__ P, int kp, int f,
+                                                               const double2* __restrict__ qe, double* __restrict__ partial) {
+  __shared__ double red[2][WG_THREADS / 64];
+  const int64_t sg = seg0 + blockIdx.x;
+  const uint32_t i = vh[seg_feat[sg]];
+  const int64_t b = col_ptr[i] + seg_b[sg], e = col_ptr[i] + seg_e[sg];
+  const double old = P[W ? (size_t)i : (size_t)i * kp + f];
+  double mean = 0.0, var = 0.0;
+  constexpr int UN = 4;
+  for (int64_t t0 = b + threadIdx.x; t0 < e; t0 += (int64_t)WG_THREADS * UN) {
+    float x[UN]; uint32_t rr[UN]; double2 c[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { const int64_t t = t0 + (int64_t)u * WG_THREADS, tc = t < e ? t : t0; x[u] = cval[tc]; rr[u] = crow[tc]; }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) c[u] = qe[rr[u]];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (t0 + (int64_t)u * WG_THREADS >= e) continue;
+      if (W) { const double xd = (double)x[u]; mean += c[u].y * xd - old * xd * xd; var += xd * xd; }
+      else { const float xx = x[u] * x[u]; const double h = (double)x[u] * c[u].x - (double)xx * old; mean += h * c[u].y; var += h * h; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mean += __shfl_xor(mean, off); var += __shfl_xor(var, off); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = mean; red[1][wv] = var; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ms = 0.0, vs = 0.0;
+    for (int q = 0; q < WG_THREADS / 64; ++q) { ms += red[0][q]; vs += red[1][q]; }
+    partial[2 * sg] = ms; partial[2 * sg + 1] = vs;
+  }
+}
+
+template <bool W>
+__global__ void als_vh_value_k(const uint32_t* __restrict__ vh, const uint32_t* __restrict__ seg_first, int64_t h0, int n, const double* __restrict__ partial,
+                               double* __restrict__ P, int kp, int f, double alpha, double lambda, double mu, const double* __restrict__ znorm,
+                               double* __restrict__ v_old, double* __restrict__ v_diff) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int64_t hx = h0 + q;
+  const uint32_t i = vh[hx];
+  const size_t at = W ? (size_t)i : (size_t)i * kp + f;
+  const double old = P[at];
+  double mean = 0.0, var = 0.0;
+  for (uint32_t sg = seg_first[hx]; sg < seg_first[hx + 1]; ++sg) { mean += partial[2 * (size_t)sg]; var += partial[2 * (size_t)sg + 1]; }
+  double nv;
+  if (W) {
+    var = 1.0 / (lambda + alpha * var);
+    mean = -var * (alpha * mean - mu * lambda);
+    nv = bad_number(var) ? 0.0 : (znorm ? mean + var * znorm[i] : mean);      // (the variance as Rf_rnorm's sd: :239, kept)
+  } else {
+    mean -= old * var;
+    var = 1.0 / (lambda + alpha * var);
+    mean = -var * (alpha * mean - mu * lambda);
+    nv = bad_number(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[i] : mean);
+  }
+  v_old[hx] = old;
+  if (bad_number(nv)) { v_diff[hx] = 0.0; return; }  // CHECK_PARAM: keep the old value, no corrections
+  P[at] = nv;
+  v_diff[hx] = old - nv;
+}
+
+template <bool W>
+__global__ __launch_bounds__(WG_THREADS) void als_vh_apply_k(const uint32_t* __restrict__ vh, const uint32_t* __restrict__ seg_feat,
+                                                             const int64_t* __restrict__ seg_b, const int64_t* __restrict__ seg_e, int64_t seg0,
+                                                             const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
+                                                             const float* __restrict__ cval, const double* __restrict__ v_old,
+                                                             const double* __restrict__ v_diff, double2* __restrict__ qe) {
+  const int64_t sg = seg0 + blockIdx.x;
+  const uint32_t hx = seg_feat[sg];
+  const double diff = v_diff[hx];
+  if (diff == 0.0) return;  // nothing moves (or CHECK_PARAM refused the step)
+  const uint32_t i = vh[hx];
+  const double old = v_old[hx];
+  const int64_t b = col_ptr[i] + seg_b[sg], e = col_ptr[i] + seg_e[sg];
+  constexpr int UN = 4;
+  for (int64_t t0 = b + threadIdx.x; t0 < e; t0 += (int64_t)WG_THREADS * UN) {
+    float xs[UN]; uint32_t rs[UN]; double2 cs[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { const int64_t t = t0 + (int64_t)u * WG_THREADS, tc = t < e ? t : t0; xs[u] = cval[tc]; rs[u] = crow[tc]; }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) cs[u] = qe[rs[u]];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (t0 + (int64_t)u * WG_THREADS >= e) continue;
+      const float x = xs[u];
+      const double2 c = cs[u];
+      double dq, de;
+      if (W) { dq = 0.0; de = (double)x * diff; }
+      else { const float xx = x * x; const double h = (double)x * c.x - (double)xx * old; dq = (double)x * diff; de = h * diff; }
+      qe[rs[u]] = make_double2(c.x - dq, c.y - de);
+    }
+  }
+}
+
 // largest position (0-based) each feature takes inside a row: the groups of the approximate sweep
 __global__ void als_maxpos_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int* __restrict__ level) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -450,6 +559,9 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   if (m->als_feats && m->als_plan_cap == max_levels) return FMX_OK;
   (void)hipFree(m->als_feats); m->als_feats = nullptr;
   (void)hipFree(m->als_heavy); m->als_heavy = nullptr;
+  (void)hipFree(m->als_vh); (void)hipFree(m->als_vh_seg0); (void)hipFree(m->als_vseg_feat); (void)hipFree(m->als_vseg_b); (void)hipFree(m->als_vseg_e); (void)hipFree(m->als_vh_work);
+  m->als_vh = nullptr; m->als_vh_seg0 = nullptr; m->als_vseg_feat = nullptr; m->als_vseg_b = nullptr; m->als_vseg_e = nullptr; m->als_vh_work = nullptr;
+  m->als_n_vh = 0; m->als_n_vseg = 0;
   const uint32_t p = m->p;
   int *d_level = nullptr, *d_changed = nullptr;
   FMX_HIP(hipMalloc(&d_level, (size_t)p * sizeof(int)));
@@ -555,22 +667,57 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   }
   int L = 0;
   for (uint32_t j = 0; j < p; ++j) if (level[j] + 1 > L) L = level[j] + 1;
-  // per level: the light features (one wave each) and the heavy ones (one workgroup each), ascending index inside a level
-  std::vector<std::vector<uint32_t>> light((size_t)L), heavy((size_t)L);
-  for (uint32_t j = 0; j < p; ++j) (cp[(size_t)j + 1] - cp[(size_t)j] > ALS_HEAVY ? heavy : light)[(size_t)level[j]].push_back(j);
-  std::vector<uint32_t> fl, fh;
+  // per level: the light features (one wave each), the heavy ones (one workgroup each) and -- exact plan only -- the very long
+  // columns, cut into segments (one workgroup per segment: als_vh_*_k); ascending index inside a level
+  const char* split_env = getenv("FMX_ALS_SPLIT");  // read per call: the tests compare the two forms
+  const bool split_ok = !(split_env && split_env[0] == '0');
+  std::vector<std::vector<uint32_t>> light((size_t)L), heavy((size_t)L), vheavy((size_t)L);
+  for (uint32_t j = 0; j < p; ++j) {
+    const int64_t len = cp[(size_t)j + 1] - cp[(size_t)j];
+    (len > ALS_SPLIT && !approx && split_ok ? vheavy : len > ALS_HEAVY ? heavy : light)[(size_t)level[j]].push_back(j);
+  }
+  std::vector<uint32_t> fl, fh, fv, seg_first(1, 0u), seg_feat;
+  std::vector<int64_t> seg_b, seg_e;
   m->als_level_ptr.assign((size_t)L + 1, 0);
   m->als_heavy_ptr.assign((size_t)L + 1, 0);
+  m->als_vh_ptr.assign((size_t)L + 1, 0);
+  m->als_vseg_ptr.assign((size_t)L + 1, 0);
   for (int l = 0; l < L; ++l) {
     fl.insert(fl.end(), light[(size_t)l].begin(), light[(size_t)l].end());
     fh.insert(fh.end(), heavy[(size_t)l].begin(), heavy[(size_t)l].end());
+    for (uint32_t j : vheavy[(size_t)l]) {
+      const int64_t len = cp[(size_t)j + 1] - cp[(size_t)j];
+      for (int64_t b = 0; b < len; b += ALS_SPLIT_SEG) {
+        seg_feat.push_back((uint32_t)fv.size());
+        seg_b.push_back(b);
+        seg_e.push_back(b + ALS_SPLIT_SEG < len ? b + ALS_SPLIT_SEG : len);
+      }
+      fv.push_back(j);
+      seg_first.push_back((uint32_t)seg_feat.size());
+    }
     m->als_level_ptr[(size_t)l + 1] = (int64_t)fl.size();
     m->als_heavy_ptr[(size_t)l + 1] = (int64_t)fh.size();
+    m->als_vh_ptr[(size_t)l + 1] = (int64_t)fv.size();
+    m->als_vseg_ptr[(size_t)l + 1] = (int64_t)seg_feat.size();
   }
   FMX_HIP(hipMalloc(&m->als_feats, (fl.size() ? fl.size() : 1) * sizeof(uint32_t)));
   if (!fl.empty()) FMX_HIP(hipMemcpy(m->als_feats, fl.data(), fl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   FMX_HIP(hipMalloc(&m->als_heavy, (fh.size() ? fh.size() : 1) * sizeof(uint32_t)));
   if (!fh.empty()) FMX_HIP(hipMemcpy(m->als_heavy, fh.data(), fh.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  m->als_n_vh = (int64_t)fv.size(); m->als_n_vseg = (int64_t)seg_feat.size();
+  if (!fv.empty()) {
+    FMX_HIP(hipMalloc(&m->als_vh, fv.size() * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&m->als_vh_seg0, seg_first.size() * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&m->als_vseg_feat, seg_feat.size() * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&m->als_vseg_b, seg_b.size() * sizeof(int64_t)));
+    FMX_HIP(hipMalloc(&m->als_vseg_e, seg_e.size() * sizeof(int64_t)));
+    FMX_HIP(hipMalloc(&m->als_vh_work, (2 * seg_feat.size() + 2 * fv.size()) * sizeof(double)));
+    FMX_HIP(hipMemcpy(m->als_vh, fv.data(), fv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FMX_HIP(hipMemcpy(m->als_vh_seg0, seg_first.data(), seg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FMX_HIP(hipMemcpy(m->als_vseg_feat, seg_feat.data(), seg_feat.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FMX_HIP(hipMemcpy(m->als_vseg_b, seg_b.data(), seg_b.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    FMX_HIP(hipMemcpy(m->als_vseg_e, seg_e.data(), seg_e.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  }
   m->als_approx = approx ? 1 : 0;
   m->als_plan_cap = max_levels;
   m->als_level_of.assign(level.begin(), level.end());
@@ -589,7 +736,8 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
   bool synced = true;  // approximate form: d_qe_new holds what d_qe holds (the caller copied it)
   for (int l = 0; l < L; ++l) {
     const int64_t cnt = lp[(size_t)l + 1] - lp[(size_t)l], hcnt = hp[(size_t)l + 1] - hp[(size_t)l];
-    if (cnt + hcnt == 0) continue;
+    const int64_t vcnt = m->als_vh_ptr.empty() ? 0 : m->als_vh_ptr[(size_t)l + 1] - m->als_vh_ptr[(size_t)l];  // (the approximate plan has none)
+    if (cnt + hcnt + vcnt == 0) continue;
     const uint32_t* lf = m->als_feats + lp[(size_t)l];
     const uint32_t* hf = m->als_heavy + hp[(size_t)l];
     const dim3 gl((unsigned)((cnt * 64 + WG_THREADS - 1) / WG_THREADS)), gh((unsigned)hcnt), blk(WG_THREADS);
@@ -601,6 +749,18 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
       // (a heavy feature shares rows with nearly everything: it is alone in its level, or with a few other heavy ones)
       if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
                                        (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
+      if (vcnt > 0) {  // the very long columns of the level, over many workgroups each
+        const int64_t v0 = m->als_vh_ptr[(size_t)l], s0 = m->als_vseg_ptr[(size_t)l], ns = m->als_vseg_ptr[(size_t)l + 1] - s0;
+        double* partial = m->als_vh_work;
+        double* v_old = m->als_vh_work + 2 * m->als_n_vseg;
+        double* v_diff = v_old + m->als_n_vh;
+        hipLaunchKernelGGL((als_vh_partial_k<W>), dim3((unsigned)ns), blk, 0, e->stream, m->als_vh, m->als_vseg_feat, m->als_vseg_b, m->als_vseg_e, s0, m->col_ptr,
+                           m->crow, m->cval, (const double*)P, e->kp64, f, (const double2*)d_qe, partial);
+        hipLaunchKernelGGL((als_vh_value_k<W>), dim3((unsigned)((vcnt + 63) / 64)), dim3(64), 0, e->stream, m->als_vh, m->als_vh_seg0, v0, (int)vcnt, (const double*)partial, P,
+                           e->kp64, f, alpha, lambda, mu, d_znorm, v_old, v_diff);
+        hipLaunchKernelGGL((als_vh_apply_k<W>), dim3((unsigned)ns), blk, 0, e->stream, m->als_vh, m->als_vseg_feat, m->als_vseg_b, m->als_vseg_e, s0, m->col_ptr,
+                           m->crow, m->cval, (const double*)v_old, (const double*)v_diff, d_qe);
+      }
     } else if (cnt + hcnt == 1) {
       // a group of one: its step against "the snapshot" is the exact step -- in place, no merge (the heavy features' pass)
       if (hcnt) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, 1, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
@@ -666,7 +826,8 @@ int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* larges
   const int64_t L = (int64_t)m->als_level_ptr.size() - 1;
   int64_t big = 0;
   for (int64_t l = 0; l < L; ++l) {
-    const int64_t c = m->als_level_ptr[(size_t)l + 1] - m->als_level_ptr[(size_t)l] + m->als_heavy_ptr[(size_t)l + 1] - m->als_heavy_ptr[(size_t)l];
+    const int64_t c = m->als_level_ptr[(size_t)l + 1] - m->als_level_ptr[(size_t)l] + m->als_heavy_ptr[(size_t)l + 1] - m->als_heavy_ptr[(size_t)l] +
+                      (m->als_vh_ptr.empty() ? 0 : m->als_vh_ptr[(size_t)l + 1] - m->als_vh_ptr[(size_t)l]);
     if (c > big) big = c;
   }
   if (levels) *levels = L;

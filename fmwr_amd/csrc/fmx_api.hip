@@ -215,6 +215,7 @@ static void free_matrix(fmx_matrix* m) {
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
   drop_plans(m);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats); (void)hipFree(m->als_heavy);
+  (void)hipFree(m->als_vh); (void)hipFree(m->als_vh_seg0); (void)hipFree(m->als_vseg_feat); (void)hipFree(m->als_vseg_b); (void)hipFree(m->als_vseg_e); (void)hipFree(m->als_vh_work);
   delete m;
 }
 

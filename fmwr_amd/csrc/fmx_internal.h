@@ -152,6 +152,15 @@ struct fmx_matrix {
   std::vector<int64_t> als_level_ptr;
   uint32_t* als_heavy = nullptr;        // features with long columns (one workgroup each), same order
   std::vector<int64_t> als_heavy_ptr;
+  // exact plan: columns of more than ALS_SPLIT entries are cut into segments walked by one workgroup each (fm_als_kernels.hip)
+  uint32_t* als_vh = nullptr;           // such features, ordered by (level, index); vh_seg0[i]..vh_seg0[i+1]: their segments
+  uint32_t* als_vh_seg0 = nullptr;
+  uint32_t* als_vseg_feat = nullptr;    // per segment: index into als_vh, entry range inside the column
+  int64_t* als_vseg_b = nullptr;
+  int64_t* als_vseg_e = nullptr;
+  double* als_vh_work = nullptr;        // [2 * n_vseg] partial sums | [n_vh] old value | [n_vh] difference
+  int64_t als_n_vh = 0, als_n_vseg = 0;
+  std::vector<int64_t> als_vh_ptr, als_vseg_ptr;   // per level
   std::vector<int32_t> als_level_of;    // [p] level (exact plan) or group (approximate plan) of every feature
   int als_approx = 0;                   // the plan holds the groups of the approximate sweep, not exact levels
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for

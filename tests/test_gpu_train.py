@@ -1050,3 +1050,46 @@ def test_sparse_tiles_with_lists_of_a_few_entries(fm, name, reduce, one_hot, wid
     assert util.rel_err(gw, mb.w) < tol and abs(g0 - mb.w0.value) < tol * max(1.0, abs(mb.w0.value))
     touched = np.zeros(p, bool); touched[col] = True
     assert np.array_equal(gv[:, ~touched], v[:, ~touched].astype(np.float32).astype(np.float64))   # features that never occur are not written
+
+
+def test_als_very_long_columns_are_split_over_workgroups(fm):
+    """Columns of more than 65 536 entries (two features that sit in almost every one of 80 000 rows) are cut into segments swept by
+    one workgroup each (als_vh_*_k): V sweep and the full ALS learner (w0, w and V sweeps) against the oracle, and against the
+    one-workgroup-per-column form (FMX_ALS_SPLIT=0)."""
+    import os
+    engine, L = fm
+    rng = np.random.default_rng(15)
+    n, p, k = 80000, 60, 2
+    a = rng.random(n) < 0.97
+    b = rng.random(n) < 0.9
+    others = rng.integers(2, p, (n, 3))
+    rows = [np.unique(np.concatenate([[0] if a[i] else [], [1] if b[i] else [], others[i]])) for i in range(n)]
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows).astype(np.uint32); val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, 15, "regression")
+    w0, w, v = util.params(p, k, 15, stdev=0.3, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    assert np.bincount(col, minlength=p)[:2].min() > 65536
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0)
+    r0, rw, rvv = oracle.als_learn(P, X, y, w0, w, v.ravel(), 2, with_v=True)
+    got = {}
+    for split in ("1", "0"):
+        os.environ["FMX_ALS_SPLIT"] = split
+        try:
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+            e.set_params(w0, w, v)
+            gerr = e.als_vsweep(m, err0)
+            gv = e.get_params()[2]
+            e2 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+            e2.set_params(w0, w, v)
+            e2.als_train(m, 2, with_v=True)
+            got[split] = (gv, gerr, e2.get_params())
+        finally:
+            os.environ.pop("FMX_ALS_SPLIT", None)
+    for split in ("1", "0"):
+        gv, gerr, (g0, gw, gvv) = got[split]
+        assert util.rel_err(gv, rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10, split
+        assert abs(g0 - r0) < 1e-10 and util.rel_err(gw, rw) < 1e-10 and util.rel_err(gvv, rvv.reshape(k, p)) < 1e-10, split
