@@ -232,20 +232,25 @@ extern "C" int fmx_debug_trace(unsigned long long* out) {
 #endif
 
 // ------------------------------------------------------------------------------------------------ phase 1
-template <typename T, int LPR, bool TRAIN, int WGT>
+// SPLIT > 1 (the smallest steps, one-wave workgroups): SPLIT lane groups share a row, group `sub` taking its entries sub, sub + SPLIT,
+// ... -- a 30-entry row is then ONE round of eight gathers per group instead of four -- and the partial sums meet in a fixed
+// butterfly ((0+1)+(2+3)).  Deterministic; the association of a row's sums then differs from the large-step form by design
+// (both are inside the 1e-5 bar and the fp64-state 1e-11 one: the sums are fp64).
+template <typename T, int LPR, bool TRAIN, int WGT, int SPLIT = 1>
 __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
   using vec_t = typename Slice<T>::vec;
   constexpr int VEC = Slice<T>::N;
   constexpr int KP = LPR * VEC;
-  constexpr int RPW = WGT / LPR;  // rows (lists) per workgroup
+  constexpr int RPW = WGT / (LPR * SPLIT);  // rows (lists) per workgroup
   constexpr int CHUNK = STAGE_ENTRIES / WG_THREADS * WGT;  // entries staged at a time
   constexpr int RU = WGT == 64 ? FMX_U_SMALL : FMX_U_LARGE;  // entries whose gathers are in flight together, per lane group
-  __shared__ uint2 stage[CHUNK + RU];  // + RU: the gather rounds read whole groups of RU entries
+  __shared__ uint2 stage[CHUNK + RU * SPLIT];  // + RU * SPLIT: the gather rounds read whole groups of RU entries
   __shared__ double red[TRAIN ? RPW : 1];
 
   FMX_STAMP(0);
   const int tid = threadIdx.x;
-  const int gid = tid / LPR;
+  const int gid = (tid / LPR) / SPLIT;  // row of the workgroup
+  const int sub = (tid / LPR) % SPLIT;  // this lane group's part of the row
   const int lig = tid % LPR;
   const int64_t R0 = (int64_t)blockIdx.x * RPW;
   const int64_t R1 = (R0 + RPW < a.nrows) ? R0 + RPW : a.nrows;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
   double s[VEC], q[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { s[i] = 0.0; q[i] = 0.0; }
-  double lin = h.k0 ? a.scal[SC_W0] : 0.0;  // core/Model.h:77-78
+  double lin = (h.k0 && sub == 0) ? a.scal[SC_W0] : 0.0;  // core/Model.h:77-78
 
   for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
     const int cnt = (hi - c0 < CHUNK) ? (int)(hi - c0) : CHUNK;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
     FMX_STAMP(2);
     const int64_t b = ta > c0 ? ta : c0;
     const int64_t e = tb < c0 + cnt ? tb : c0 + cnt;
-    for (int64_t t = b; t < e; t += RU) {
+    for (int64_t t = b + sub; t < e; t += RU * SPLIT) {
       const int o = (int)(t - c0);
       // Straight-line on purpose: every LDS read, then every gather, then the arithmetic.  A `cond ? load : constant` here
       // compiles to a branch around the load with a wait for ALL outstanding loads at the join -- the rounds of one wave
@@ -284,10 +289,10 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
       // model has no linear term (wt then points at valid memory) and dropped by the select below.
       uint2 en[RU];
 #pragma unroll
-      for (int u = 0; u < RU; ++u) en[u] = stage[o + u];
+      for (int u = 0; u < RU; ++u) en[u] = stage[o + u * SPLIT];
 #pragma unroll
       for (int u = 1; u < RU; ++u)
-        if (t + u >= e) en[u] = make_uint2(en[0].x, 0u);  // x = +0.0f pads
+        if (t + u * SPLIT >= e) en[u] = make_uint2(en[0].x, 0u);  // x = +0.0f pads
       vec_t vv[RU];
       T wv[RU];
 #pragma unroll
@@ -318,6 +323,14 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
     FMX_STAMP(4);
   }
 
+  if constexpr (SPLIT > 1) {  // the row's SPLIT parts, in a fixed order
+#pragma unroll
+    for (int off = LPR; off < LPR * SPLIT; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s[i] += __shfl_xor(s[i], off); q[i] += __shfl_xor(q[i], off); }
+      lin += __shfl_xor(lin, off);
+    }
+  }
   double pair = 0.0;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) pair += 0.5 * (s[i] * s[i] - q[i]);  // core/Model.h:100
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
 
   if constexpr (TRAIN) {
     double mult = 0.0;
-    if (have) {
+    if (have && sub == 0) {
       mult = grad_mult(h, y_hat, a.y[a.r0 + row]);
       vec_t srow = slice_make(s, T());
       if constexpr (sizeof(T) == 4) srow = embed_store<LPR>(srow, lig, (float)mult, a.embed);  // the multiplier rides in the S row
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
       if (lig == 0) reinterpret_cast<T*>(a.amul)[row] = (T)mult;
     }
     FMX_STAMP(5);
-    if (lig == 0) red[gid] = mult;
+    if (lig == 0 && sub == 0) red[gid] = mult;
     __syncthreads();
     FMX_STAMP(6);
     if (tid == 0) {  // fixed-order partial sums for the w0 step
@@ -346,24 +359,27 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
     }
     FMX_STAMP(7);
   } else {
-    if (have && lig == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link, a.pn_y);
+    if (have && lig == 0 && sub == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link, a.pn_y);
     if constexpr (sizeof(T) == 8) {  // fp64 tables: optionally the per-row factor sums q[row][f] = sum_j x_j v_jf (ALS sweeps)
-      if (have && a.qout) *reinterpret_cast<double2*>(a.qout + (size_t)row * KP + lig * VEC) = make_double2(s[0], s[1]);
+      if (have && sub == 0 && a.qout) *reinterpret_cast<double2*>(a.qout + (size_t)row * KP + lig * VEC) = make_double2(s[0], s[1]);
     }
   }
 }
 
-template <typename T, bool TRAIN, int WGT>
+template <typename T, bool TRAIN, int WGT, int SPLIT>
 static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
   constexpr int VEC = Slice<T>::N;
   const int lpr = kp / VEC;
-  const int rpw = WGT / lpr;
+  const int rpw = WGT / (lpr * SPLIT);
+  FMX_CHECK(rpw >= 1, FMX_ERR_INVALID, "rows_forward: %d lane groups of %d lanes do not fit %d threads", SPLIT, lpr, WGT);
   const int64_t grid = (a.nrows + rpw - 1) / rpw;
   if (grid == 0) return FMX_OK;
   FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "rows_forward: grid too large (%lld)", (long long)grid);
   dim3 g((unsigned)grid), b(WGT);
-#define FMX_ROWS_CASE(L)                                                                                   \
-  case L: hipLaunchKernelGGL((fm_rows_forward_k<T, L, TRAIN, WGT>), g, b, 0, e->stream, a, e->hyper); break;
+#define FMX_ROWS_CASE(L)                                                                                          \
+  case L:                                                                                                         \
+    if constexpr (L * SPLIT <= WGT) hipLaunchKernelGGL((fm_rows_forward_k<T, L, TRAIN, WGT, SPLIT>), g, b, 0, e->stream, a, e->hyper); \
+    break;
   switch (lpr) {
     FMX_ROWS_CASE(1) FMX_ROWS_CASE(2) FMX_ROWS_CASE(4) FMX_ROWS_CASE(8)
     FMX_ROWS_CASE(16) FMX_ROWS_CASE(32) FMX_ROWS_CASE(64)
@@ -375,7 +391,8 @@ static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
 }
 template <typename T, bool TRAIN>
 static int launch_rows_w(fmx_engine* e, const RowsArgs& a, int kp) {
-  return a.wg_threads == 64 ? launch_rows_t<T, TRAIN, 64>(e, a, kp) : launch_rows_t<T, TRAIN, WG_THREADS>(e, a, kp);
+  if (a.wg_threads == 64) return a.split == 4 ? launch_rows_t<T, TRAIN, 64, 4>(e, a, kp) : launch_rows_t<T, TRAIN, 64, 1>(e, a, kp);
+  return launch_rows_t<T, TRAIN, WG_THREADS, 1>(e, a, kp);
 }
 
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp64_tables) {
@@ -442,6 +459,7 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
       if (a.yhat) s.yhat = a.yhat + off;
       if (a.qout) s.qout = a.qout + (size_t)off * kp;
       s.wg_threads = rows_wg_threads(a.nrows, kp / (fp64_tables ? 2 : 4));
+      s.split = rows_split(a.nrows, kp / (fp64_tables ? 2 : 4));
       int trial;
       FMX_TRY(pick(s, &s.serial, &trial));
       st = fp64_tables ? launch_rows_w<double, false>(e, s, kp) : launch_rows_w<float, false>(e, s, kp);

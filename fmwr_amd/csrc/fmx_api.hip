@@ -139,8 +139,8 @@ static int reset_optimizer_state(fmx_engine* e) {
 // partial sums for one step; grow-only
 static int ensure_workspace(fmx_engine* e, int64_t s_rows, int64_t step_rows, int64_t tiles_per_step) {
   const int rpw = WG_THREADS / mb_lpr(e);
-  // sum over tiles of ceil(rows_t / rpw); a small step's one-wave workgroups (rows_wg_threads) write at most 2048 of them
-  const int64_t partials = (step_rows + rpw - 1) / rpw + (tiles_per_step > 0 ? tiles_per_step : 1) + 8 + 2048;
+  // sum over tiles of ceil(rows_t / rpw); a small step's one-wave workgroups (rows_wg_threads) write at most 2048 of them (4096 with four lane groups per row)
+  const int64_t partials = (step_rows + rpw - 1) / rpw + (tiles_per_step > 0 ? tiles_per_step : 1) + 8 + 4096;
   if (s_rows <= e->ws_rows && partials <= e->ws_partials) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(e->stream));
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials);
@@ -343,7 +343,8 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t st
   a.partials = e->partials + 2 * partial_offset;
   a.unit = m->unit_values;
   a.wg_threads = rows_wg_threads(step_rows, mb_lpr(e));
-  const int rpw = a.wg_threads / mb_lpr(e);
+  a.split = rows_split(step_rows, mb_lpr(e));
+  const int rpw = a.wg_threads / (mb_lpr(e) * (a.wg_threads == 64 && a.split == 4 ? 4 : 1));
   *n_partials = (t.nrows + rpw - 1) / rpw;
   return launch_rows_forward(e, a, true, mb_wide(e));
 }

@@ -301,6 +301,7 @@ struct RowsArgs {
   int unit;             // every value is 1.0f: a.val is not read
   int embed;            // EmbedMode: how the multiplier is folded into the S row (set by the launcher)
   int wg_threads;       // 64: one-wave workgroups (rows_wg_threads); anything else: WG_THREADS
+  int split;            // 4: four lane groups share a row (rows_split; one-wave workgroups only); anything else: one
   int serial;           // large steps: one entry's requests outstanding per lane group at a time (set by the launcher)
 };
 // Small steps.  A CU sustains about 240 random 64-byte rows per microsecond whatever runs on it (its miss queue; the
@@ -312,6 +313,9 @@ struct RowsArgs {
 // the step alone.
 constexpr size_t FMX_SERIAL_TABLE_MAX = 1ull << 30;
 inline int rows_wg_threads(int64_t step_rows, int lpr) { return step_rows * lpr < 512LL * WG_THREADS ? 64 : WG_THREADS; }
+// ... and the smallest steps (fewer than 1024 one-wave workgroups) spread every row over four lane groups: four times the waves again,
+// and a 30-entry row is one gather round per group instead of four.  Also decided from the STEP's row count.
+inline int rows_split(int64_t step_rows, int lpr) { return (lpr <= 16 && step_rows * lpr < 1024LL * 64) ? 4 : 1; }
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
 int ensure_probit(fmx_engine* e);  // builds and uploads the probit tables (fm_probit.h) on first use
 
