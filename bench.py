@@ -46,7 +46,9 @@ def parse():
                          "occurs ~8 times per step; profiles/r02_learning_*.txt) -- and 1048576 per GPU for FTRL and for N > 1, where the step "
                          "must be long enough to hide the exchange of the 72 MB buffer (the global batch is N times larger either way)")
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 524288; 262144 for k <= 8)")
-    ap.add_argument("--solver", choices=["sgd", "ftrl"], default="sgd")
+    ap.add_argument("--solver", choices=["sgd", "ftrl", "als", "mcmc"], default="sgd",
+                    help="als / mcmc: BASELINE.json configs[4], the V-column sweep of MCMC_ALS_Learner::update_v over the same matrix (k = 16); a step is "
+                         "one sweep of all k factors over all rows (mcmc: the Gibbs draw with device-resident standard normals; als: the mean)")
     ap.add_argument("--workload", choices=["uniform", "criteo"], default="uniform",
                     help="uniform: BASELINE.json configs[1] / [2] (one column per stratum).  criteo: configs[3]'s shape -- 33 M features, 39 nnz/row "
                          "(13 dense + 26 categorical fields with power-law heads), k = 32, 262144-row steps of one sparse tile; --rows rows resident "
@@ -72,6 +74,13 @@ def parse():
         if a.rows == 10_000_000:
             a.rows = 8_000_000 * a.gpus
         a.no_extras, a.cpu_rows = True, 0
+    if a.solver in ("als", "mcmc"):
+        a.factors = a.factors or 16
+        if a.steps == 40 and a.warmup == 5:   # the defaults are sized for 0.3 ms steps; a sweep of 16 factors over 3e8 entries is ~0.2 s
+            a.steps, a.warmup = 5, 1
+        if a.cpu_rows < 0:
+            a.cpu_rows = 200_000
+        return a
     if a.batch_rows == 0:
         # SGD, one GPU: 262144 (a coordinate occurs ~8 times per step: learns per example like 4096-row steps at the reference's
         # learning rate).  FTRL: 1048576 -- its per-coordinate adaptive step keeps learning at ~100 occurrences per step (the fastest
@@ -253,6 +262,115 @@ def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_
     return out
 
 
+def main_sweep(args, rank, local_rank, world):
+    """configs[4]: the ALS / Gibbs V sweep (MCMC_ALS_Learner::update_v, solver/MCMC_ALS_Learner.h:272-354).  The sweep does not
+    shard (a feature's step reads the residual of every row that holds it; DESIGN.md section 7: replicas only), so N > 1 runs N
+    independent replicas, each on its own 10 M-row range of the stream, and `value` adds them up."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from fmwr_amd import _lib as L
+    from fmwr_amd import engine
+    z, k, p, n = args.nnz, args.factors, args.features, args.rows
+    gibbs = args.solver == "mcmc"
+    dev = torch.device("cuda", local_rank)
+    m = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=rank * n, device=local_rank)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank)
+    e.init_normal(args.seed, 0.0, 0.01)          # SURVEY 8(d): V0 ~ N(0, 0.01), w0 = w = 0
+    t0 = time.perf_counter()
+    levels, largest, approx, _ = e.als_plan(m)   # CSC of the whole matrix + the level plan: ingest, outside the timed region
+    plan_s = time.perf_counter() - t0
+    d_err = torch.empty(n, dtype=torch.float64, device=dev)
+    L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(n), C.c_void_p(d_err.data_ptr()), C.c_int(L.LINK_NONE)))
+    e.sync()
+    for r0 in range(0, n, 2_000_000):            # e = y_hat - y (calculate_error, REGRESSION, :520-527); labels +-1 from the generator
+        r1 = min(n, r0 + 2_000_000)
+        yy = np.zeros(r1 - r0, np.float32)
+        L.check(L.lib().fmx_matrix_export(m.h, C.c_int64(r0), C.c_int64(r1), None, None, None, yy.ctypes.data_as(C.c_void_p)))
+        d_err[r0:r1] -= torch.from_numpy(yy).to(dev, torch.float64)
+    d_z = torch.randn(k, p, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(args.seed)) if gibbs else None
+    lam = np.full(k, 1.0) if gibbs else None     # MCMC: a proper prior precision (the ALS learner's init() leaves lambda = 0, SURVEY A-7)
+    torch.cuda.synchronize()
+    ss0 = float((d_err * d_err).sum().item())
+
+    def sweep():
+        e.vsweep_device(m, d_err.data_ptr(), alpha=1.0, v_lambda=lam, dev_std_normals=d_z.data_ptr() if gibbs else None)
+
+    def fence():
+        e.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sweep()
+    fence()
+    e.profile_reset()
+    e.profile(7)     # HIP events around every 7th level launch, on the engine's stream, inside the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sweep()
+    fence()
+    dt = time.perf_counter() - t0
+    e.profile(0)
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ss1 = float((d_err * d_err).sum().item())
+    if not np.isfinite(ss1) or (not gibbs and not ss1 < ss0):
+        raise SystemExit(f"the sweeps did not reduce the residual: {ss0} -> {ss1}")
+    if rank != 0:
+        return
+    nnz = n * z
+    lvl_ms, lvl_n = e.profile_get(L.KERNEL_ALS_SWEEP)
+    fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
+    per_launch_ms = lvl_ms / max(lvl_n, 1)
+    launches = levels * k
+    b_launch = 40.0 * nnz / levels               # SURVEY 8(d): 40 B per stored nonzero per factor; one launch = one level of one factor
+    gbs = b_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    step_gbs = 40.0 * nnz * k / (dt / args.steps) / 1e9
+    out = {
+        "metric": "V-sweep examples/sec, 10Mx1M sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
+        "value": world * n * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic {n}x{p}, {z} nnz/row, k={k}, {'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
+                               f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
+                   "levels": levels, "largest_level": largest, "approximate": bool(approx), "launches_per_step": launches,
+                   "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
+                   "parallelism": f"replicas{world}" if world > 1 else "dp1"},
+        "roofline": {"bound": "hbm", "kernel": "als_level_k (one level of one factor)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": per_launch_ms, "timed_launches": lvl_n,
+                     "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                              "note": "40 B x nnz x k over the whole sweep's wall time (includes the one forward pass that builds q for all factors and the per-factor q picks)"},
+                     "q_build_forward_ms": fwd_ms / max(fwd_n, 1) if fwd_n else None},
+    }
+    if not args.no_extras:
+        # the access pattern's own ceiling: random 16-byte (q, e) pairs from the n-row table; a level reads AND writes one per entry
+        r = engine.measure_gather(n * 16, 16, n_groups=262_144, per_group=64, in_flight=4, reps=20, device=local_rank)
+        got = (nnz / levels) / (per_launch_ms * 1e-3) if per_launch_ms > 0 else 0.0
+        out["roofline"]["gather_ceiling"] = {"table_MB": n * 16 / 1e6, "row_bytes": 16, "ceiling_rows_per_s": r, "kernel_entries_per_s": got,
+                                             "ceiling_frac": got / r if r else None,
+                                             "note": "entries per second of als_level_k (each entry: one 16-B gather and one 16-B scatter of its row's (q, e)) over the measured rate of random 16-B gathers"}
+    if args.cpu_rows > 0:
+        import oracle
+        rs = min(args.cpu_rows, n)
+        rp, col, val, y = m.export(0, rs)
+        X = oracle.Matrix(rp, col, val, p)
+        v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p))
+        err = np.random.default_rng(args.seed + 1).normal(0.0, 1.0, rs)
+        oracle.lib()
+        zz = np.random.default_rng(args.seed + 2).normal(0.0, 1.0, k * p) if gibbs else None
+        t0 = time.perf_counter()
+        oracle.als_update_v(k, X, v0.ravel(), err, alpha=1.0, v_lambda=lam, znorm=zz)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": rs / dtc, "unit": "examples/s", "cores": 1, "kind": "port",
+                               "sample": f"one reference-order update_v sweep (k = {k}) over rows 0..{rs - 1} of the same matrix ({dtc:.1f} s incl. its transpose)"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -280,6 +398,12 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.solver in ("als", "mcmc"):
+        main_sweep(args, rank, local_rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     z, k, p = args.nnz, args.factors, args.features
     ftrl = args.solver == "ftrl"
     from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows

@@ -17,7 +17,7 @@ LINK_NONE, LINK_LOGISTIC, LINK_CLAMP, LINK_PROBIT = 0, 1, 2, 3
 REDUCE_MEAN, REDUCE_SUM = 0, 1
 COLUMNS_UNIFORM, COLUMNS_ZIPF = 1, 2
 EVAL_LL, EVAL_AUC, EVAL_ACC, EVAL_RMSE, EVAL_MSE, EVAL_MAE = 0, 111, 222, 333, 444, 555
-KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ = 0, 1, 2, 3
+KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ, KERNEL_ALS_SWEEP = 0, 1, 2, 3, 4
 
 # every symbol include/fmx.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = [
@@ -28,6 +28,7 @@ SYMBOLS = [
     "fmx_als_plan_info", "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_mcmc_train", "fmx_mcmc_train_from", "fmx_mcmc_v_hyper", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset", "fmx_rows_tune_info", "fmx_measure_gather", "fmx_measure_gather_occ", "fmx_rccl_selftest",
     "fmx_get_rows", "fmx_set_rows", "fmx_init_normal", "fmx_compact_info", "fmx_compact_count", "fmx_compact_reserve", "fmx_grad_compact", "fmx_compact_records", "fmx_apply_compact",
+    "fmx_debug_fail_next_plan_build", "fmx_vsweep_device",
 ]
 
 

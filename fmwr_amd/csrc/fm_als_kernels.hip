@@ -741,6 +741,8 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
     const uint32_t* lf = m->als_feats + lp[(size_t)l];
     const uint32_t* hf = m->als_heavy + hp[(size_t)l];
     const dim3 gl((unsigned)((cnt * 64 + WG_THREADS - 1) / WG_THREADS)), gh((unsigned)hcnt), blk(WG_THREADS);
+    prof_begin(e, FMX_KERNEL_ALS_SWEEP);  // one level (or group) of one factor: the unit bench.py --solver als prices
+    struct ProfEnd { fmx_engine* e; ~ProfEnd() { prof_end(e); } } prof_guard{e};
     if (!m->als_approx) {
       if (cnt > 0) {
         if (W) hipLaunchKernelGGL(als_w_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dw, d_qe, alpha, lambda, mu, d_znorm);
@@ -797,13 +799,25 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   double2* d_qe_new = approx_buffer(e, m);
   // q_f = X v_f only depends on column f of V, which no other factor's sweep touches: all k of them come out of ONE
-  // row-gather pass (the forward kernel on the fp64 tables) instead of one gather per nonzero per factor
+  // row-gather pass (the forward kernel on the fp64 tables) instead of one gather per nonzero per factor.  The n x kp table lives
+  // in the engine (grow-only): a sweep allocates nothing once the first one has run.
   double* d_Q = nullptr;
-  if (hipMalloc(&d_Q, (size_t)m->n * e->kp64 * sizeof(double)) == hipSuccess) {
+  {
+    const size_t need = (size_t)m->n * e->kp64;
+    if (e->als_Q_elems < need) {
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipFree(e->als_Q); e->als_Q = nullptr; e->als_Q_elems = 0;
+      if (hipMalloc(&e->als_Q, need * sizeof(double)) == hipSuccess) e->als_Q_elems = need;
+      else (void)hipGetLastError();  // no room for the table: fall back to one gather pass per factor
+    }
+    d_Q = e->als_Q;
+  }
+  if (d_Q) {
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
     a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.link = FMX_LINK_NONE;
-    if (launch_rows_forward(e, a, false, true) != FMX_OK) { (void)hipFree(d_Q); d_Q = nullptr; }
+    a.unit = m->unit_values;
+    if (launch_rows_forward(e, a, false, true) != FMX_OK) d_Q = nullptr;
   }
   for (int f = 0; f < e->k; ++f) {
     if (d_Q) hipLaunchKernelGGL(als_q_pick_k, dim3(row_grid), dim3(256), 0, e->stream, d_Q, e->kp64, f, m->n, d_qe);
@@ -812,7 +826,6 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
     if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);  // q changed: resynchronise the pair
     sweep_features<false>(e, m, d_qe, d_qe_new, f, alpha, lambda, mu, d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
   }
-  if (d_Q) { (void)hipStreamSynchronize(e->stream); (void)hipFree(d_Q); }
 }
 
 // MCMC_ALS_Learner::learn for the ALS learner (:91-156): per iteration a fresh forward, the residual of the task
@@ -1110,6 +1123,23 @@ int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_n
   }
   (void)hipFree(d_part);
   return st;
+}
+
+// (q, e) pairs of the device-resident sweep: kept in the engine, grow-only
+static double2* sweep_pairs(fmx_engine* e, int64_t n) {
+  if (e->als_qe_rows < n) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(e->als_qe); e->als_qe = nullptr; e->als_qe_rows = 0;
+    if (hipMalloc(&e->als_qe, (size_t)n * sizeof(double2)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    e->als_qe_rows = n;
+  }
+  return reinterpret_cast<double2*>(e->als_qe);
+}
+
+int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm) {
+  double2* qe = sweep_pairs(e, m->n);
+  FMX_CHECK(qe != nullptr, FMX_ERR_HIP, "out of device memory");
+  return launch_als_vsweep(e, m, d_error, reinterpret_cast<double*>(qe), alpha, h_lambda, h_mu, d_znorm);
 }
 
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_qe_raw, double alpha, const double* h_lambda, const double* h_mu,

@@ -408,7 +408,12 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
     if (force >= 0) { *serial = force; return FMX_OK; }
     const bool timed = r.wg_threads != 64 && r.nrows >= RowsTune::MIN_ROWS;
     const int64_t key = r.unit ? 1 : 0;
-    if (timed && key != tu.key) { tu.key = key; tu.decided = -1; tu.launches = 0; }
+    if (timed && key != tu.key) {
+      // the other kind of data measures again; a half-measured set of events is drained first so that no slot is re-recorded
+      // while an earlier recording of it is still pending on the stream
+      if (tu.events && tu.launches > 0 && tu.decided < 0) FMX_HIP(hipStreamSynchronize(e->stream));
+      tu.key = key; tu.decided = -1; tu.launches = 0;
+    }
     if (tu.decided >= 0) { *serial = tu.decided; return FMX_OK; }
     if (!timed) return FMX_OK;
     if (!tu.events) {
@@ -417,15 +422,21 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
       FMX_CHECK(ok, FMX_ERR_HIP, "rows_forward: could not create the tuning events");
       tu.events = true;
     }
+    if (tu.launches >= RowsTune::TRIALS) {  // every trial slot is used up and nothing was decided (a timed launch failed on the way): stop measuring
+      tu.decided = 1;
+      return FMX_OK;
+    }
     *trial = tu.launches++;
     *serial = *trial % 2 == 0 ? 1 : 0;
     FMX_HIP(hipEventRecord(tu.ev[2 * *trial], e->stream));
     return FMX_OK;
   };
+  // closes trial `trial` (also when its launch failed: the slot's second event is recorded either way, so a later decision never
+  // reads a half-recorded pair)
   auto done = [&](int trial) -> int {
     if (trial < 0) return FMX_OK;
     FMX_HIP(hipEventRecord(tu.ev[2 * trial + 1], e->stream));
-    if (tu.launches == RowsTune::TRIALS) {  // the one wait of the measurement
+    if (tu.launches >= RowsTune::TRIALS && tu.decided < 0) {  // the one wait of the measurement
       FMX_HIP(hipEventSynchronize(tu.ev[2 * trial + 1]));
       double ms[2] = {0.0, 0.0};
       for (int i = 2; i < RowsTune::TRIALS; ++i) {
@@ -445,7 +456,7 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
     int trial;
     FMX_TRY(pick(a, &a.serial, &trial));
     st = fp64_tables ? launch_rows_w<double, true>(e, a, e->kp64) : launch_rows_w<float, true>(e, a, e->kp32);
-    if (st == FMX_OK) st = done(trial);
+    { const int st2 = done(trial); if (st == FMX_OK) st = st2; }
   } else {
     // Forward-only passes over many rows go out as launches of 262 144 rows: measured at configs[1]
     // (profiles/forward_probe.py) such launches run at 0.58 ns/row, 1 M-row launches at 0.69, 4 M-row launches at 0.75 --
@@ -463,7 +474,7 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
       int trial;
       FMX_TRY(pick(s, &s.serial, &trial));
       st = fp64_tables ? launch_rows_w<double, false>(e, s, kp) : launch_rows_w<float, false>(e, s, kp);
-      if (st == FMX_OK) st = done(trial);
+      { const int st2 = done(trial); if (st == FMX_OK) st = st2; }
     }
   }
   prof_end(e);
@@ -1398,26 +1409,28 @@ __global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, Cols
     scalar_update(T.partials, T.n_partials, T.scal, T.scal_out, gtail, h, a.global_rows, a.scalar, red_g, red_q);
 }
 
-// sort keys of the concatenated parts: linear index i -> (part, local record) -> key = the record's feature id, value = its position
+// sort keys of the concatenated parts: linear index i -> (part, local record) -> key = the record's feature id, value = its position.
+// The parts' prefix sums (and where each part starts in the buffer) travel BY VALUE in the kernel arguments: no pageable host
+// buffer behind an asynchronous copy, and no host-synchronous staging inside a step.
 template <typename ST>
-__global__ void record_keys_k(const ST* __restrict__ recs, int rec_elems, int id_at, const int64_t* __restrict__ prefix, int n_parts,
-                              int64_t stride, int64_t total, uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+__global__ void record_keys_k(const ST* __restrict__ recs, int rec_elems, int id_at, RecParts parts, int64_t total, uint32_t* __restrict__ keys,
+                              uint32_t* __restrict__ pos) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int part = 0;
-  while (part + 1 < n_parts && prefix[part + 1] <= i) ++part;
-  const int64_t at = (int64_t)part * stride + (i - prefix[part]);
+  while (part + 1 < parts.n && parts.prefix[part + 1] <= i) ++part;
+  const int64_t at = parts.start[part] + (i - parts.prefix[part]);
   keys[i] = elem_to_id(recs[(size_t)at * rec_elems + id_at]);
   pos[i] = (uint32_t)at;
 }
 
-int launch_record_keys(fmx_engine* e, const void* recs, const int64_t* d_prefix, int n_parts, int64_t stride, int64_t total, uint32_t* keys, uint32_t* pos) {
+int launch_record_keys(fmx_engine* e, const void* recs, const RecParts& parts, int64_t total, uint32_t* keys, uint32_t* pos) {
   if (total <= 0) return FMX_OK;
   const int has_q = exchange_has_q(e) ? 1 : 0;
   const int id_at = mb_kp(e) * (1 + has_q) + 3;
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
-  if (mb_wide(e)) hipLaunchKernelGGL((record_keys_k<double>), g, b, 0, e->stream, (const double*)recs, e->rec_elems, id_at, d_prefix, n_parts, stride, total, keys, pos);
-  else hipLaunchKernelGGL((record_keys_k<float>), g, b, 0, e->stream, (const float*)recs, e->rec_elems, id_at, d_prefix, n_parts, stride, total, keys, pos);
+  if (mb_wide(e)) hipLaunchKernelGGL((record_keys_k<double>), g, b, 0, e->stream, (const double*)recs, e->rec_elems, id_at, parts, total, keys, pos);
+  else hipLaunchKernelGGL((record_keys_k<float>), g, b, 0, e->stream, (const float*)recs, e->rec_elems, id_at, parts, total, keys, pos);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

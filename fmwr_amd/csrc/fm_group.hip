@@ -93,20 +93,23 @@ struct Group {
   std::vector<hipEvent_t> ready;  // per replica: gradient sums written
   hipEvent_t summed = nullptr;
   // shards of the last matrix trained on
-  const fmx_matrix* src = nullptr;
-  int64_t src_n = 0, src_nnz = 0;
+  uint64_t src_uid = 0;  // fmx_matrix::uid of the matrix the shards were cut from (0: none); an address can be reused, a uid is not
   uint64_t src_values = 0;
   std::vector<fmx_matrix*> shard;
   // compact exchange (steps of one sparse tile): every replica's gather buffer [N][stride][record]
   std::vector<void*> gath;
   int64_t gath_records = 0;
+  bool busy = false;  // group_train is driving the replicas: the step-level entry points are its own calls, not a caller's
 };
+
+// A group handle reached from outside group_train: the step-level mutators would change replica 0 alone
+bool group_outside(const fmx_engine* e) { return e->group != nullptr && !e->group->busy; }
 
 static void free_shards(Group* g) {
   for (size_t r = 0; r < g->shard.size(); ++r)
     if (g->shard[r]) { (void)hipSetDevice(g->dev[r]); fmx_matrix_destroy(g->shard[r]); }
   g->shard.clear();
-  g->src = nullptr;
+  g->src_uid = 0;
 }
 
 void group_destroy(fmx_engine* e) {
@@ -176,6 +179,19 @@ int group_set_params(fmx_engine* e, double w0, const double* w, const double* v)
   return use_device_public(e->cfg.device);
 }
 
+// the same draw (seed, feature, factor pair) on every other replica: V0 must be identical everywhere or the replicas never agree
+int group_init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev) {
+  Group* g = e->group;
+  for (int r = 1; r < g->n; ++r) FMX_TRY(fmx_init_normal(g->rep[(size_t)r], seed, mean, stdev));
+  return use_device_public(e->cfg.device);
+}
+
+int group_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* w, const double* v) {
+  Group* g = e->group;
+  for (int r = 1; r < g->n; ++r) FMX_TRY(fmx_set_rows(g->rep[(size_t)r], ids, n, w, v));
+  return use_device_public(e->cfg.device);
+}
+
 // rows [r0, r1) of src as a matrix of its own on device `dev`
 static int cut_shard(const fmx_matrix* src, int64_t r0, int64_t r1, int dev, fmx_matrix** out) {
   FMX_HIP(hipSetDevice(src->device));
@@ -213,14 +229,14 @@ static int cut_shard(const fmx_matrix* src, int64_t r0, int64_t r1, int dev, fmx
 }
 
 static int ensure_shards(Group* g, const fmx_matrix* m) {
-  if (g->src == m && g->src_n == m->n && g->src_nnz == m->nnz && g->src_values == m->value_generation && !g->shard.empty()) return FMX_OK;
+  if (g->src_uid == m->uid && g->src_values == m->value_generation && !g->shard.empty()) return FMX_OK;
   free_shards(g);
   g->shard.assign((size_t)g->n, nullptr);
   for (int r = 0; r < g->n; ++r) {
     const int64_t r0 = (m->n * r) / g->n, r1 = (m->n * (r + 1)) / g->n;  // rank r gets rows [r n / N, (r + 1) n / N)
     FMX_TRY(cut_shard(m, r0, r1, g->dev[(size_t)r], &g->shard[(size_t)r]));
   }
-  g->src = m; g->src_n = m->n; g->src_nnz = m->nnz; g->src_values = m->value_generation;
+  g->src_uid = m->uid; g->src_values = m->value_generation;
   return FMX_OK;
 }
 
@@ -344,6 +360,7 @@ static int prepare_compact(Group* g, bool* usable) {
 // whole job, the last step is truncated rank by rank (lower ranks first).
 int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done) {
   Group* g = e->group;
+  struct Busy { Group* g; explicit Busy(Group* g_) : g(g_) { g->busy = true; } ~Busy() { g->busy = false; } } busy(g);
   FMX_TRY(ensure_shards(g, m));
   // fp32 exchange: counts travel as floats -- exact while every per-feature occurrence count of a global batch stays below 2^24
   FMX_CHECK(mb_wide(e) || e->cfg.batch_rows * g->n < (1LL << 24), FMX_ERR_INVALID,

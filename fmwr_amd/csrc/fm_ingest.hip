@@ -7,6 +7,7 @@
 //   * the strictly-ascending-rows check the sequential learner uses.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
 
 #include <rocprim/rocprim.hpp>
@@ -14,6 +15,10 @@
 #include "fmx_internal.h"
 
 namespace fmx {
+
+// fault injection for tests/test_gpu_api.py: the next build_batch_csc fails once (no environment access from inside the library)
+static std::atomic<int> g_fail_next_plan_build{0};
+void debug_fail_next_plan_build() { g_fail_next_plan_build.store(1); }
 
 // ------------------------------------------------------------------------------------------------ CSC builders
 // row of entry t: last r in [r0, r0+nrows) with row_ptr[r] <= t (rows of one fixed length: a division)
@@ -418,9 +423,8 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     FMX_CHECK(c < (1LL << 32), FMX_ERR_INVALID, "a tile holds %lld nonzeros; at most 2^32-1 are supported (lower tile_rows)", (long long)c);
     if (c > max_cnt) max_cnt = c;
   }
-  if (const char* f = getenv("FMX_TEST_FAIL_PLAN_BUILD")) {  // tests: an allocation failure halfway leaves no half-built cache
-    if (atoi(f) > 0) { setenv("FMX_TEST_FAIL_PLAN_BUILD", "0", 1); set_error("plan build failed (FMX_TEST_FAIL_PLAN_BUILD)"); return FMX_ERR_HIP; }
-  }
+  // tests: an allocation failure halfway must leave no half-built cache (armed by fmx_debug_fail_next_plan_build; one shot)
+  if (g_fail_next_plan_build.exchange(0) > 0) { set_error("plan build failed (fmx_debug_fail_next_plan_build)"); return FMX_ERR_HIP; }
   FMX_HIP(hipMalloc(&L.brow, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(uint32_t)));
   FMX_HIP(hipMalloc(&L.bval, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(float)));
   FMX_HIP(hipHostMalloc(&L.h_counts, (size_t)(nt > 0 ? nt : 1) * 4 * sizeof(uint32_t)));
@@ -463,7 +467,6 @@ struct MergeWs {
   int n_parts_cap = 0;
   uint32_t *keys_in = nullptr, *keys_out = nullptr, *pos_in = nullptr, *pos_out = nullptr, *roff = nullptr, *rfeat = nullptr, *dcount = nullptr;
   uint8_t* flags = nullptr;
-  int64_t* d_prefix = nullptr;
   void* sort_temp = nullptr; size_t sort_bytes = 0;
   void* sel_temp = nullptr; size_t sel_bytes = 0;
 };
@@ -471,7 +474,7 @@ struct MergeWs {
 void merge_ws_free(MergeWs* w) {
   if (!w) return;
   (void)hipFree(w->keys_in); (void)hipFree(w->keys_out); (void)hipFree(w->pos_in); (void)hipFree(w->pos_out); (void)hipFree(w->roff);
-  (void)hipFree(w->rfeat); (void)hipFree(w->dcount); (void)hipFree(w->flags); (void)hipFree(w->d_prefix); (void)hipFree(w->sort_temp); (void)hipFree(w->sel_temp);
+  (void)hipFree(w->rfeat); (void)hipFree(w->dcount); (void)hipFree(w->flags); (void)hipFree(w->sort_temp); (void)hipFree(w->sel_temp);
   delete w;
 }
 
@@ -489,7 +492,6 @@ static int merge_ws_reserve(fmx_engine* e, int64_t total, int n_parts) {
   FMX_HIP(hipMalloc(&n.pos_in, m * 4)); FMX_HIP(hipMalloc(&n.pos_out, m * 4));
   FMX_HIP(hipMalloc(&n.roff, (m + 1) * 4)); FMX_HIP(hipMalloc(&n.rfeat, m * 4));
   FMX_HIP(hipMalloc(&n.dcount, 16)); FMX_HIP(hipMalloc(&n.flags, m));
-  FMX_HIP(hipMalloc(&n.d_prefix, ((size_t)n_parts + 1) * sizeof(int64_t)));
   FMX_HIP(rocprim::radix_sort_pairs(nullptr, n.sort_bytes, n.keys_in, n.keys_out, n.pos_in, n.pos_out, m, 0, 32, e->stream));
   FMX_HIP(hipMalloc(&n.sort_temp, n.sort_bytes ? n.sort_bytes : 16));
   rocprim::counting_iterator<uint32_t> ids(0);
@@ -500,22 +502,26 @@ static int merge_ws_reserve(fmx_engine* e, int64_t total, int n_parts) {
   return FMX_OK;
 }
 
-int merge_records(fmx_engine* e, const void* recs, const int64_t* counts, int n_parts, int64_t stride, int64_t* total_out) {
-  std::vector<int64_t> prefix((size_t)n_parts + 1, 0);
+int merge_records(fmx_engine* e, const void* recs, const int64_t* counts, const int64_t* starts, int n_parts, int64_t stride, int64_t* total_out) {
+  FMX_CHECK(n_parts >= 1 && n_parts <= REC_PARTS_MAX, FMX_ERR_INVALID, "1..%d record parts are supported (got %d)", REC_PARTS_MAX, n_parts);
+  RecParts parts{};
+  parts.n = n_parts;
+  int64_t top = 0;
   for (int r = 0; r < n_parts; ++r) {
-    FMX_CHECK(counts[r] >= 0 && counts[r] <= stride, FMX_ERR_INVALID, "part %d holds %lld records, stride is %lld", r, (long long)counts[r], (long long)stride);
-    prefix[(size_t)r + 1] = prefix[(size_t)r] + counts[r];
+    FMX_CHECK(counts[r] >= 0 && (starts != nullptr || counts[r] <= stride), FMX_ERR_INVALID, "part %d holds %lld records, stride is %lld", r, (long long)counts[r], (long long)stride);
+    parts.prefix[r + 1] = parts.prefix[r] + counts[r];
+    parts.start[r] = starts ? starts[r] : (int64_t)r * stride;
+    FMX_CHECK(parts.start[r] >= 0, FMX_ERR_INVALID, "part %d starts at a negative record", r);
+    if (parts.start[r] + counts[r] > top) top = parts.start[r] + counts[r];
   }
-  const int64_t total = prefix[(size_t)n_parts];
-  FMX_CHECK((int64_t)n_parts * stride < (1LL << 32), FMX_ERR_INVALID, "more than 2^32 record slots");
+  const int64_t total = parts.prefix[n_parts];
+  FMX_CHECK(top < (1LL << 32), FMX_ERR_INVALID, "more than 2^32 record slots");
   FMX_TRY(merge_ws_reserve(e, total, n_parts));
   MergeWs& w = *e->merge;
   *total_out = total;
   FMX_HIP(hipMemsetAsync(w.dcount, 0, 16, e->stream));
   if (total == 0) return FMX_OK;
-  // (the prefix is small and pageable: the copy is staged by the runtime before the call returns)
-  FMX_HIP(hipMemcpyAsync(w.d_prefix, prefix.data(), prefix.size() * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
-  FMX_TRY(launch_record_keys(e, recs, w.d_prefix, n_parts, stride, total, w.keys_in, w.pos_in));
+  FMX_TRY(launch_record_keys(e, recs, parts, total, w.keys_in, w.pos_in));
   const int bits = col_bits((uint32_t)e->p);
   size_t tb = w.sort_bytes;
   FMX_HIP(rocprim::radix_sort_pairs(w.sort_temp, tb, w.keys_in, w.keys_out, w.pos_in, w.pos_out, (size_t)total, 0, bits, e->stream));

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <atomic>
 #include <memory>
 
 #include "fmx_internal.h"
@@ -225,6 +226,8 @@ static int alloc_matrix(int device, int64_t n, uint32_t p, int64_t nnz, bool lab
   FMX_CHECK(n >= 0 && nnz >= 0, FMX_ERR_INVALID, "negative size");
   FMX_TRY(use_device(device));
   std::unique_ptr<fmx_matrix, void (*)(fmx_matrix*)> m(new fmx_matrix(), free_matrix);
+  static std::atomic<uint64_t> next_uid{1};
+  m->uid = next_uid.fetch_add(1);
   m->device = device; m->n = n; m->p = p; m->nnz = nnz; m->has_labels = labels;
   FMX_HIP(hipMalloc(&m->row_ptr, ((size_t)n + 1) * sizeof(int64_t)));
   // one spare entry, like the reference's over-read guard (SURVEY A-13); keeps zero-nnz matrices allocatable too
@@ -672,7 +675,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FMX_OK;
@@ -757,6 +760,7 @@ int fmx_init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev) {
   FMX_TRY(fmx_set_params(e, 0.0, nullptr, nullptr));  // w0 = 0, w = 0 (core/Model.h:63-72), optimizer state reset
   FMX_TRY(init_normal(e, seed, mean, stdev));
   FMX_HIP(hipStreamSynchronize(e->stream));
+  if (e->group) FMX_TRY(group_init_normal(e, seed, mean, stdev));  // the same V0 on every replica
   return FMX_OK;
 }
 
@@ -795,7 +799,9 @@ static int rows_io(fmx_engine* e, const uint32_t* ids, int64_t n, double* w, dou
 
 int fmx_get_rows(fmx_engine* e, const uint32_t* ids, int64_t n, double* w, double* v) { return rows_io(e, ids, n, w, v, false); }
 int fmx_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* w, const double* v) {
-  return rows_io(e, ids, n, const_cast<double*>(w), const_cast<double*>(v), true);
+  FMX_TRY(rows_io(e, ids, n, const_cast<double*>(w), const_cast<double*>(v), true));
+  if (e->group) FMX_TRY(group_set_rows(e, ids, n, w, v));  // every replica holds the full model
+  return FMX_OK;
 }
 
 namespace fmx {
@@ -1443,12 +1449,14 @@ int fmx_num_batches(fmx_engine* e, fmx_matrix* m, int64_t* n_batches) {
 
 int fmx_step(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_TRY(use_device(e->cfg.device));
   return run_step(e, m, batch, rows_limit, true);
 }
 
 int fmx_grad(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_TRY(use_device(e->cfg.device));
   return run_step(e, m, batch, rows_limit, false);
 }
@@ -1477,18 +1485,21 @@ int fmx_grad_layout(fmx_engine* e, int64_t* n_chunks, int64_t* chunk_features, i
 
 int fmx_grad_begin(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_TRY(use_device(e->cfg.device));
   return grad_begin(e, m, batch, rows_limit);
 }
 
 int fmx_grad_chunk(fmx_engine* e, fmx_matrix* m, int64_t chunk) {
   FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_TRY(use_device(e->cfg.device));
   return grad_block(e, m, chunk);
 }
 
 int fmx_apply_chunk(fmx_engine* e, int64_t chunk, int64_t global_rows, int32_t last) {
   FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "fmx_apply_chunk needs a mini-batch engine");
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_TRY(use_device(e->cfg.device));
   return apply_block(e, chunk, global_rows, last != 0);
 }
@@ -1502,6 +1513,7 @@ int fmx_grad_elem_bytes(const fmx_engine* e, int32_t* bytes) {
 int fmx_apply(fmx_engine* e, int64_t global_rows) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_CHECK(!seq_mode(e) && e->gbuf, FMX_ERR_STATE, "fmx_apply needs a preceding fmx_grad");
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_TRY(use_device(e->cfg.device));
   ColsArgs c{};
   c.load_gbuf = 1;
@@ -1546,6 +1558,7 @@ int fmx_compact_reserve(fmx_engine* e, int64_t capacity) {
 
 int fmx_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit) {
   FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_TRY(use_device(e->cfg.device));
   return grad_compact(e, m, batch, rows_limit);
 }
@@ -1560,11 +1573,12 @@ int fmx_compact_records(fmx_engine* e, void** dev_records, int64_t* n_records, v
 
 int fmx_apply_compact(fmx_engine* e, const void* dev_records, const int64_t* counts, int32_t n_parts, int64_t stride_records, int64_t global_rows) {
   FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "fmx_apply_compact needs a mini-batch engine");
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): the step-level calls would change replica 0 alone; train it with fmx_train", e->cfg.n_gpus);
   FMX_CHECK(e->ctail != nullptr, FMX_ERR_STATE, "fmx_apply_compact needs a preceding fmx_grad_compact");
   FMX_CHECK(counts != nullptr && n_parts >= 1 && stride_records >= 0 && (dev_records != nullptr || stride_records == 0), FMX_ERR_INVALID, "bad record parts");
   FMX_TRY(use_device(e->cfg.device));
   int64_t total = 0;
-  FMX_TRY(merge_records(e, dev_records, counts, n_parts, stride_records, &total));
+  FMX_TRY(merge_records(e, dev_records, counts, nullptr, n_parts, stride_records, &total));
   const uint32_t *pos, *roff, *rfeat, *d_n;
   merge_result(e, &pos, &roff, &rfeat, &d_n);
   return launch_apply_records(e, dev_records, pos, roff, rfeat, d_n, total, global_rows);
@@ -1618,6 +1632,15 @@ int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, c
   return vsweep_impl(e, m, error, alpha, v_lambda, v_mu, std_normals);
 }
 
+int fmx_vsweep_device(fmx_engine* e, fmx_matrix* m, void* dev_error_f64, double alpha, const double* v_lambda, const double* v_mu, const void* dev_std_normals_f64) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweep runs on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(dev_error_f64 != nullptr || m->n == 0, FMX_ERR_INVALID, "dev_error_f64 is NULL");
+  FMX_TRY(use_device(e->cfg.device));
+  if (m->n == 0 || e->k == 0) return FMX_OK;
+  return launch_als_vsweep_device(e, m, (double*)dev_error_f64, alpha, v_lambda, v_mu, (const double*)dev_std_normals_f64);
+}
+
 int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level, int32_t* approximate, int32_t* level_of_feature) {
   FMX_TRY(check_pair(e, m));
   FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweeps run on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
@@ -1668,6 +1691,8 @@ int fmx_mcmc_v_hyper(fmx_engine* e, const double* std_gammas, const double* std_
 }
 
 int fmx_rccl_selftest(int32_t n, double* max_err) { return group_rccl_selftest(n, max_err); }
+
+int fmx_debug_fail_next_plan_build(void) { debug_fail_next_plan_build(); return FMX_OK; }
 
 int fmx_profile_enable(fmx_engine* e, int on) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");

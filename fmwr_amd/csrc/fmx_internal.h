@@ -90,6 +90,7 @@ inline int pad_factor(int k, int vec) {
 namespace fmx { struct MergeWs; struct Group; }
 
 struct fmx_matrix {
+  uint64_t uid = 0;  // process-unique, never reused (caches keyed on a matrix compare this, not its address)
   int device = 0;
   int64_t n = 0;
   uint32_t p = 0;
@@ -240,6 +241,10 @@ struct fmx_engine {
   fmx::MergeWs* merge = nullptr;   // scratch of fmx_apply_compact
   void* als_qe_new = nullptr;      // second (q, e) array of the approximate ALS sweep
   int64_t als_qe_new_rows = 0;
+  double* als_Q = nullptr;         // q of every factor, [n][kp64], made by one forward pass per V sweep (grow-only)
+  size_t als_Q_elems = 0;
+  void* als_qe = nullptr;          // (q, e) pairs of fmx_vsweep_device (grow-only)
+  int64_t als_qe_rows = 0;
   fmx::Group* group = nullptr;     // cfg.n_gpus > 1: the other replicas and the exchange between them (fm_group.hip)
   void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
   int64_t gbuf_floats = 0;    // its element count
@@ -371,11 +376,15 @@ inline uint32_t list_long_min() {
 constexpr uint32_t LIST_SEG = 1024;  // entries per segment (one wave)
 int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la);
 // compact exchange (fm_batch_kernels.hip; the merge itself is in fm_ingest.hip)
-int launch_record_keys(fmx_engine* e, const void* recs, const int64_t* d_prefix, int n_parts, int64_t stride, int64_t total, uint32_t* keys, uint32_t* pos);
+// the parts of a record buffer: part r holds prefix[r + 1] - prefix[r] records starting at record start[r] (kernel argument, by value)
+constexpr int REC_PARTS_MAX = 64;
+struct RecParts { int n; int64_t prefix[REC_PARTS_MAX + 1]; int64_t start[REC_PARTS_MAX]; };
+int launch_record_keys(fmx_engine* e, const void* recs, const RecParts& parts, int64_t total, uint32_t* keys, uint32_t* pos);
 int launch_apply_records(fmx_engine* e, const void* recs, const uint32_t* pos, const uint32_t* roff, const uint32_t* rfeat, const uint32_t* d_n,
                          int64_t max_lists, int64_t global_rows);
 struct MergeWs;
-int merge_records(fmx_engine* e, const void* recs, const int64_t* counts, int n_parts, int64_t stride, int64_t* total_out);
+// part r: counts[r] records starting at record starts[r] (starts == nullptr: at r * stride)
+int merge_records(fmx_engine* e, const void* recs, const int64_t* counts, const int64_t* starts, int n_parts, int64_t stride, int64_t* total_out);
 void merge_ws_free(MergeWs* w);
 void merge_result(const fmx_engine* e, const uint32_t** pos, const uint32_t** roff, const uint32_t** rfeat, const uint32_t** d_n);
 
@@ -409,6 +418,7 @@ void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h);
 int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream);
 void drop_plans(fmx_matrix* m);
 int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream);
+void debug_fail_next_plan_build();
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream);
@@ -432,6 +442,7 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
 int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_normals, double* v_lambda, double* v_mu, int sample);
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu,
                       const double* d_znorm);
+int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 
 int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);
 
@@ -439,6 +450,9 @@ int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64
 int group_create(fmx_engine* e);
 void group_destroy(fmx_engine* e);
 int group_set_params(fmx_engine* e, double w0, const double* w, const double* v);
+int group_init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev);
+int group_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* w, const double* v);
+bool group_outside(const fmx_engine* e);  // a cfg.n_gpus > 1 handle called from outside fmx_train
 int group_load(fmx_engine* e, const char* path);
 int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
 int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch);

@@ -333,6 +333,13 @@ class Engine:
             L.check(L.lib().fmx_mcmc_vsweep(self.h, m.h, _p(error), C.c_double(alpha), _p(lam), _p(mu), _p(z)))
         return error
 
+    def vsweep_device(self, m, dev_error, alpha=1.0, v_lambda=None, v_mu=None, dev_std_normals=None):
+        """ALS (dev_std_normals None) or MCMC V sweep on a residual that lives on the device (fmx_vsweep_device); pointers are ints."""
+        lam = None if v_lambda is None else np.ascontiguousarray(v_lambda, np.float64)
+        mu = None if v_mu is None else np.ascontiguousarray(v_mu, np.float64)
+        L.check(L.lib().fmx_vsweep_device(self.h, m.h, C.c_void_p(dev_error), C.c_double(alpha), _p(lam), _p(mu),
+                                          C.c_void_p(dev_std_normals) if dev_std_normals else None))
+
     def mcmc_train(self, m, max_iter, std_gammas, std_normals):
         """MCMC learner with caller-drawn variates (fmx.h: fmx_mcmc_train); returns (alpha, w_lambda, w_mu)."""
         g = np.ascontiguousarray(std_gammas, np.float64); z = np.ascontiguousarray(std_normals, np.float64)

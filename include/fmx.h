@@ -330,6 +330,12 @@ int fmx_als_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, co
 int fmx_mcmc_vsweep(fmx_engine* e, fmx_matrix* m, double* error, double alpha, const double* v_lambda,
                     const double* v_mu, const double* std_normals);
 
+/* Both sweeps with the residual RESIDENT on the engine's device (what a learner's loop and bench.py --solver als / mcmc use: no
+ * host transfer per sweep): dev_error_f64 f64[n], updated in place; dev_std_normals_f64 f64[k][p] (element (f, j) at f*p + j) or
+ * NULL for the ALS form.  v_lambda / v_mu stay host pointers (k scalars).  Returns when the sweep has finished. */
+int fmx_vsweep_device(fmx_engine* e, fmx_matrix* m, void* dev_error_f64, double alpha, const double* v_lambda, const double* v_mu,
+                      const void* dev_std_normals_f64);
+
 /* The exact sweeps process the features in LEVELS (features of a level share no row, levels in ascending order reproduce the
  * reference's index-order Gauss-Seidel): how many levels (or, with cfg.als_max_levels exceeded, groups of the approximate
  * form: `approximate` = 1) this matrix needs, the size of the largest, and every feature's level / group. */
@@ -370,6 +376,7 @@ int fmx_mcmc_v_hyper(fmx_engine* e, const double* std_gammas, const double* std_
 #define FMX_KERNEL_COLS_UPDATE 1  /* phase 2: per-feature gradient sums + update */
 #define FMX_KERNEL_SCALAR 2       /* w0 reduction/update */
 #define FMX_KERNEL_SEQ 3          /* sequential-exact learner */
+#define FMX_KERNEL_ALS_SWEEP 4    /* one level (or group) of one factor of an ALS / MCMC sweep: als_level_k and its heavy-column forms */
 #define FMX_KERNEL_COUNT 8
 /* on == 0: off; on == n > 0: time every n-th launch of each kernel (n = 1: all; sampling keeps the events' own cost,
  * a few microseconds of stream time per timed launch, out of the measured throughput). */
@@ -392,6 +399,11 @@ int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64
 /* the same probe held to at most 160 KiB / lds_bytes workgroups per CU: how many requests in flight the ceiling needs */
 int fmx_measure_gather_occ(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight,
                            int32_t reps, int32_t lds_bytes, double* rows_per_s);
+
+/* ---- test hook (tests/test_gpu_api.py): the next per-tile plan build of this process fails once with FMX_ERR_HIP, as an
+ * allocation failure halfway would -- checks that a failed build leaves no half-built cache behind.  One shot; never armed by
+ * the library itself. */
+int fmx_debug_fail_next_plan_build(void);
 
 #ifdef __cplusplus
 }

@@ -316,11 +316,11 @@ def test_failed_plan_build_leaves_no_half_built_cache(monkeypatch):
     ref.sync()
     e = engine.Engine(p, **kw); e.set_params(w0, w, v)
     m = engine.Matrix.from_csr(rp, col, val, p, y)
-    monkeypatch.setenv("FMX_TEST_FAIL_PLAN_BUILD", "1")
+    L.check(L.lib().fmx_debug_fail_next_plan_build())
     with pytest.raises(L.FmxError, match="plan build failed"):
         e.step(m, 0)
     with pytest.raises(L.FmxError):      # nothing was cached: asking for a step of a plan-less matrix fails again only if the build does
-        monkeypatch.setenv("FMX_TEST_FAIL_PLAN_BUILD", "1")
+        L.check(L.lib().fmx_debug_fail_next_plan_build())
         e.num_batches(m)
     for s in range(4):                   # the flag cleared itself: the retry builds everything and trains
         e.step(m, s)

@@ -1,0 +1,199 @@
+"""BASELINE.json configs[4]: "Synthetic 10M x 1M, k=16, MCMC.solver Gibbs sweep over V columns" -- the V sweep of
+MCMC_ALS_Learner::update_v (solver/MCMC_ALS_Learner.h:272-354) at the config's own shape.
+
+  * parity vs the oracle at k = 16, 30 entries per row, on the engine's own generators (one column per stratum: what bench.py
+    --solver als trains on; i.i.d. uniform sorted columns: SURVEY 8(d)'s law), ALS and Gibbs forms, 1e-10.  k = 16 selects
+    kp64 = 16: the padded layout and the stride of the all-factor q table that no k <= 6 case touches;
+  * at the full 10 M x 1 M size, properties that need no CPU pass: the stratified matrix plans into exactly 30 levels, the
+    residual's sum of squares falls strictly over two sweeps, two runs agree bit for bit, and columns cut into segments over many
+    workgroups give the sums of the uncut form;
+  * the device-resident entry (fmx_vsweep_device) equals the host-pointer one.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+K, Z = 16, 30
+
+
+def _problem(engine, L, law, n, p, seed, values):
+    if law == "stratified":
+        m = engine.Matrix.synthetic(n, p, Z, seed)
+    else:
+        m = engine.Matrix.synthetic_iid(n, p, Z, seed, law=L.COLUMNS_UNIFORM)
+    rp, col, val, _ = m.export()
+    assert np.all(np.diff(rp) == Z)
+    if values == "normal":   # SURVEY 8(d)'s variant: real values instead of the one-hot 1.0
+        val = np.random.default_rng(seed).normal(0, 1, len(val)).astype(np.float32)
+    y = util.labels(n, seed, "regression")
+    m.close()
+    return rp, col, val, y
+
+
+@pytest.mark.parametrize("values", ["ones", "normal"])
+@pytest.mark.parametrize("law", ["stratified", "iid"])
+def test_configs4_als_vsweep_k16_matches_oracle(law, values):
+    from fmwr_amd import _lib as L, engine
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, law, n, p, 41, values)
+    w0, w, v = util.params(p, K, 17, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    lam = np.linspace(0.0, 0.4, K); mu = np.linspace(-0.05, 0.05, K)
+    rv, rerr, _ = oracle.als_update_v(K, X, v.ravel(), err0, alpha=1.2, v_lambda=lam, v_mu=mu)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    levels, _, approx, _ = e.als_plan(m)
+    assert not approx and (levels == Z if law == "stratified" else levels > Z)
+    gerr = e.als_vsweep(m, err0, alpha=1.2, v_lambda=lam, v_mu=mu)
+    gv = e.get_params()[2]
+    assert util.rel_err(gv, rv.reshape(K, p)) < 1e-10
+    assert util.rel_err(gerr, rerr) < 1e-10
+    assert np.sum(gerr ** 2) < np.sum(err0 ** 2)
+
+
+@pytest.mark.parametrize("law", ["stratified", "iid"])
+def test_configs4_gibbs_vsweep_k16_matches_oracle(law):
+    """The MCMC form (do_sample, :329-331) with the caller's standard normals in the reference's (f, j) draw order."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, law, n, p, 43, "ones")
+    w0, w, v = util.params(p, K, 19, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    lam = np.full(K, 2.0); mu = np.linspace(-0.02, 0.02, K)
+    z = np.random.default_rng(5).normal(0, 1, (K, p))
+    rv, rerr, _ = oracle.als_update_v(K, X, v.ravel(), err0, alpha=0.8, v_lambda=lam, v_mu=mu, znorm=z.ravel())
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=K, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    gerr = e.als_vsweep(m, err0, alpha=0.8, v_lambda=lam, v_mu=mu, std_normals=z)
+    gv = e.get_params()[2]
+    assert util.rel_err(gv, rv.reshape(K, p)) < 1e-10
+    assert util.rel_err(gerr, rerr) < 1e-10
+
+
+def test_configs4_device_resident_sweep_equals_the_host_pointer_one():
+    from fmwr_amd import _lib as L, engine
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 47, "ones")
+    w0, w, v = util.params(p, K, 23, stdev=0.1, fp32=False)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    z = np.random.default_rng(6).normal(0, 1, (K, p))
+    lam = np.full(K, 1.0)
+    out = {}
+    for form in ("host", "device"):
+        for gibbs in (False, True):
+            e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=K, mode=L.MODE_SEQUENTIAL)
+            e.set_params(w0, w, v)
+            err0 = e.predict(m) - y
+            if form == "host":
+                err = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam, std_normals=z if gibbs else None)
+            else:
+                d_err = util.DevBuf.from_numpy(err0)
+                d_z = util.DevBuf.from_numpy(z)
+                e.vsweep_device(m, d_err.ptr.value, alpha=1.0, v_lambda=lam, dev_std_normals=d_z.ptr.value if gibbs else None)
+                err = d_err.numpy()
+            out[(form, gibbs)] = (err, e.get_params()[2])
+    for gibbs in (False, True):
+        assert np.array_equal(out[("host", gibbs)][0], out[("device", gibbs)][0])
+        assert np.array_equal(out[("host", gibbs)][1], out[("device", gibbs)][1])
+
+
+# ---- the config's own size ---------------------------------------------------------------------------------------------------
+N, P, SEED = 10_000_000, 1_000_000, 20240001
+
+
+def _sumsq(buf):
+    a = buf.numpy()
+    return float(np.dot(a, a))
+
+
+def _labels(L, m, n):
+    """the generator's labels through fmx_matrix_export, in slabs (no host pass over the matrix's entries)"""
+    lab = np.zeros(n, np.float64)
+    step = 2_000_000
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        yy = np.zeros(r1 - r0, np.float32)
+        L.check(L.lib().fmx_matrix_export(m.h, C.c_int64(r0), C.c_int64(r1), None, None, None, yy.ctypes.data_as(C.c_void_p)))
+        lab[r0:r1] = yy
+    return lab
+
+
+def test_configs4_full_size_levels_descent_and_reproducibility():
+    """10 M x 1 M, k = 16, the stratified generator bench.py trains on: 30 levels (one per stratum), the residual falls strictly
+    over two ALS sweeps, and a second engine reproduces V and the residual bit for bit."""
+    from fmwr_amd import _lib as L, engine
+    m = engine.Matrix.synthetic(N, P, Z, SEED)
+    res = []
+    for run in range(2):
+        e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.init_normal(SEED, 0.0, 0.1)
+        if run == 0:
+            levels, largest, approx, lof = e.als_plan(m)
+            assert levels == Z and not approx
+            # one level per stratum: feature j sits in stratum j * Z // P (the generator's bounds are (i * P) // Z)
+            bounds = (np.arange(Z + 1, dtype=np.int64) * P) // Z
+            want = np.searchsorted(bounds, np.arange(P), side="right") - 1
+            assert np.array_equal(lof, want.astype(np.int32))
+            assert largest == int(np.max(np.diff(bounds)))
+        d_err = util.DevBuf(N)
+        L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(N), d_err.ptr, C.c_int(L.LINK_NONE)))
+        e.sync()
+        err0 = d_err.numpy() - _labels(L, m, N)     # calculate_error, REGRESSION: e = y_hat - y (:520-527)
+        d_err.upload(err0)
+        s0 = float(np.dot(err0, err0))
+        e.vsweep_device(m, d_err.ptr.value, alpha=1.0)
+        s1 = _sumsq(d_err)
+        e.vsweep_device(m, d_err.ptr.value, alpha=1.0)
+        s2 = _sumsq(d_err)
+        assert s2 < s1 < s0, (s0, s1, s2)
+        ids = np.arange(0, P, 997, dtype=np.uint32)
+        res.append((d_err.numpy(), e.get_rows(ids)[1], (s0, s1, s2)))
+        e.close(); d_err.free()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    m.close()
+
+
+def test_configs4_full_size_split_columns_equal_the_unsplit_form(monkeypatch):
+    """10 M rows x 1 M features in 30 one-hot fields of which four are tiny (3 to 40 values: columns of 0.25 M to 3.3 M entries,
+    cut into segments over many workgroups, fm_als_kernels.hip als_vh_*): the same levels, and the sums of the uncut form to
+    1e-10 (the partial sums associate differently)."""
+    from fmwr_amd import _lib as L, engine
+    small = [3, 7, 16, 40]
+    big = (P - sum(small)) // 26
+    vocab = [big] * 25 + [P - sum(small) - 25 * big] + small
+    assert sum(vocab) == P and len(vocab) == Z
+    m = engine.Matrix.synthetic_fields(N, 0, vocab, 1.0, SEED)
+    out = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_SPLIT", split)
+        mm = m if split == "1" else engine.Matrix.synthetic_fields(N, 0, vocab, 1.0, SEED)   # the plan is cached per matrix
+        e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.init_normal(SEED, 0.0, 0.1)
+        levels, _, approx, _ = e.als_plan(mm)
+        assert levels == Z and not approx
+        d_err = util.DevBuf(N)
+        L.check(L.lib().fmx_predict_device(e.h, mm.h, C.c_int64(0), C.c_int64(N), d_err.ptr, C.c_int(L.LINK_NONE)))
+        e.sync()
+        s0 = _sumsq(d_err)                       # residual against y = 0: the sweep drives y_hat towards 0
+        e.vsweep_device(mm, d_err.ptr.value, alpha=1.0)
+        s1 = _sumsq(d_err)
+        assert s1 < s0
+        ids = np.concatenate([np.arange(0, P, 1009), np.arange(P - sum(small), P)]).astype(np.uint32)
+        out.append((d_err.numpy(), e.get_rows(ids)[1]))
+        e.close(); d_err.free()
+        if mm is not m:
+            mm.close()
+    assert util.rel_err(out[0][0], out[1][0]) < 1e-10 and util.rel_err(out[0][1], out[1][1]) < 1e-10
+    m.close()

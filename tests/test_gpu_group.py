@@ -125,3 +125,59 @@ def test_group_compact_exchange_for_sparse_tiles_is_bitwise_the_dense_one(monkey
         a, b = out["compact"][solver], out["dense"][solver]
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert np.any(a[2] != v0)
+
+
+def test_group_handle_init_normal_set_rows_and_step_level_refusals():
+    """on an n_gpus > 1 handle every entry point that changes the model reaches EVERY replica (fmx_init_normal drew V on
+    replica 0 alone: the replicas then applied identical updates to different parameters and never agreed), and the step-level
+    mutators -- which would move replica 0 alone -- are refused from outside fmx_train."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k, B = 8000, 700, 8, 500
+    rp, col, val = util.random_csr(n, p, 8, seed=6, empty_rows=False)
+    y = util.labels(n, 6)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, state_fp64=1)
+    g = engine.Engine(p, batch_rows=B, n_gpus=2, gpus_share_device=1, **kw)
+    g.init_normal(77, 0.0, 0.1)
+    ids = np.array([3, 50, 699], np.uint32)
+    rows_w = np.array([0.5, -0.25, 0.125]); rows_v = np.arange(3 * k, dtype=np.float64).reshape(k, 3) * 1e-2
+    g.set_rows(ids, rows_w, rows_v)
+    steps = 6
+    assert g.train(m, steps * B * 2) == steps * B * 2
+    one_m, nb = _interleaved(engine, m, 2, B)
+    e = engine.Engine(p, batch_rows=2 * B, **kw)
+    e.init_normal(77, 0.0, 0.1)
+    e.set_rows(ids, rows_w, rows_v)
+    for s in range(steps):
+        e.step(one_m, s % nb)
+    e.sync()
+    a, b = g.get_params(), e.get_params()
+    assert util.rel_err(a[2], b[2]) < 1e-11 and util.rel_err(a[1], b[1]) < 1e-11 and abs(a[0] - b[0]) < 1e-11
+    for call in (lambda: g.step(m, 0), lambda: g.grad(m, 0), lambda: g.apply(0), lambda: g.grad_begin(m, 0), lambda: g.grad_compact(m, 0)):
+        with pytest.raises(L.FmxError, match="drives 2 GPUs"):
+            call()
+
+
+def test_group_shard_cache_is_keyed_by_the_matrix_not_its_address():
+    """a destroyed matrix's address is reused by the next one of the same shape; the cached shards must not be."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k, B = 4000, 300, 4, 250
+    w0, w, v = util.params(p, k, 9)
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, learn_rate=0.05, mode=L.MODE_MINIBATCH, state_fp64=1)
+    g = engine.Engine(p, batch_rows=B, n_gpus=2, gpus_share_device=1, **kw)
+    results = []
+    for seed in (1, 2):
+        rp, col, val = util.random_csr(n, p, 6, seed=seed, empty_rows=False, max_nnz=12)
+        # same n; pad/truncate to the same nnz so that (address, n, nnz) could all coincide
+        y = util.labels(n, seed)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        g.set_params(w0, w, v)
+        g.train(m, 4 * B * 2)
+        one_m, nb = _interleaved(engine, m, 2, B)
+        e = engine.Engine(p, batch_rows=2 * B, **kw)
+        e.set_params(w0, w, v)
+        for s in range(4):
+            e.step(one_m, s % nb)
+        e.sync()
+        assert util.rel_err(g.get_params()[2], e.get_params()[2]) < 1e-11
+        m.close()   # the next matrix may land on the same address

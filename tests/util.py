@@ -46,3 +46,57 @@ def rel_err(a, b):
     d = np.max(np.abs(a - b)) if a.size else 0.0
     s = np.max(np.abs(b)) if b.size else 0.0
     return d / s if s > 0 else d
+
+
+class DevBuf:
+    """A device buffer of float64 through the HIP runtime libfmx.so is linked against (ctypes; no torch: importing torch AFTER
+    libfmx.so brings a second HIP runtime into the process, see fmwr_amd/distributed.py)."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes as C
+            from fmwr_amd import _lib
+            _lib.lib()  # libfmx.so first: its libamdhip64.so.7 is then the one dlopen hands back
+            cls._hip = C.CDLL("libamdhip64.so.7")
+        return cls._hip
+
+    def __init__(self, n, dtype=np.float64):
+        import ctypes as C
+        self.n, self.dtype = int(n), np.dtype(dtype)
+        self.ptr = C.c_void_p()
+        rc = self.hip().hipMalloc(C.byref(self.ptr), C.c_size_t(max(1, self.n) * self.dtype.itemsize))
+        if rc != 0:
+            raise MemoryError(f"hipMalloc failed ({rc})")
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.size, a.dtype)
+        b.upload(a)
+        return b
+
+    def upload(self, a, offset=0):
+        import ctypes as C
+        a = np.ascontiguousarray(a, self.dtype)
+        rc = self.hip().hipMemcpy(C.c_void_p(self.ptr.value + offset * self.dtype.itemsize), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), C.c_int(1))
+        assert rc == 0, rc
+
+    def numpy(self):
+        import ctypes as C
+        out = np.empty(self.n, self.dtype)
+        rc = self.hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, C.c_size_t(out.nbytes), C.c_int(2))
+        assert rc == 0, rc
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip().hipFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
