@@ -56,13 +56,20 @@ def parse():
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
-    ap.add_argument("--exchange", choices=["auto", "dense", "compact"], default="auto",
+    ap.add_argument("--exchange", choices=["auto", "dense", "compact", "owner"], default="auto",
                     help="N > 1: dense = all-reduce of the (k+2)*p buffer; compact = all-gather of the occurring features' records "
-                         "(steps of one sparse tile); auto = compact where usable")
+                         "(steps of one sparse tile); owner = the records go to the rank that owns the feature (id mod N), which updates its slice and "
+                         "hands current rows to whoever reads them next (SURVEY 8(e)(ii)); auto = compact where usable, owner with --stream")
+    ap.add_argument("--stream", action="store_true",
+                    help="--workload criteo: every step's rows are generated and planned on the fly (fmx_source; BASELINE.json configs[3]: the 4e9-row matrix never "
+                         "exists), rank r streaming its own row range; N > 1 exchanges per step (--exchange owner | compact)")
     ap.add_argument("--exchange-chunks", type=int, default=0,
                     help="N > 1, dense: blocks of features the exchange is pipelined in (1: one all-reduce of the whole buffer per step; "
                          "0: 8 blocks on 2 GPUs, where the single xGMI link is the bound and finer blocks hide more of it, 4 otherwise, "
                          "where the extra launches of finer blocks cost more than they hide: profiles/r01_split_bench.json)")
+    ap.add_argument("--in-library", action="store_true",
+                    help="drive the N GPUs from ONE process through cfg.n_gpus (fm_group.hip: N replicas behind one handle, RCCL by dlopen) instead of one "
+                         "process per GPU: `python bench.py --gpus N --in-library`, no torch.distributed.run.  N = 1 is fmx_train's own loop and must equal the default line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (0: skip; -1: 5M for sgd, 250K for ftrl k=64: 10-20 s of one core either way)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp64 state, small batches, sequential mode, ceilings)")
@@ -371,14 +378,146 @@ def main_sweep(args, rank, local_rank, world):
     print(json.dumps(out), flush=True)
 
 
+def main_stream(args, rank, local_rank, world):
+    """configs[3] as ONE N-GPU job: p = 33 M, k = 32, Criteo-shaped rows streamed (generated, planned, trained on once, dropped), rank r
+    its own row range, per step: pull current rows -> gradient sums -> records to their owners -> update (fmwr_amd/distributed.py)."""
+    import torch
+    import torch.distributed as dist
+    from fmwr_amd import _lib as L
+    from fmwr_amd import engine
+    from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows, train_stream
+    z, k, p, B = args.nnz, args.factors, args.features, args.batch_rows
+    tune = 16 if B >= 65536 else 0
+    total = (tune + args.warmup + args.steps) * B * world
+    r0, r1 = shard_rows(total, rank, world)
+    e = engine.Engine(p, **engine_kwargs(args, L, B, local_rank, world, exchange_chunks=0))
+    e.init_normal(args.seed, 0.0, 0.01)
+    exchange = "owner" if args.exchange in ("auto", "owner") else args.exchange
+    dp = DataParallel(EngineStepper(e, None, local_rank, dense=False), exchange=exchange) if world > 1 else None
+    src = e.source(r1 - r0, seed=args.seed, row_offset=r0, fields=(13, engine.CRITEO_VOCAB, 3.0))
+
+    def run(steps):
+        if world > 1:
+            return train_stream(dp, src, steps=steps)
+        done = 0
+        for _ in range(steps):
+            m = src.next()
+            e.step(m, 0)
+            done += m.n
+        return done
+
+    def fence():
+        e.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(tune + args.warmup)
+    fence()
+    if dp is not None and exchange == "owner":
+        dp.bytes_sent.clear()
+    e.profile_reset()
+    e.profile(15)
+    t0 = time.perf_counter()
+    done = run(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    e.profile(0)
+    wait = src.close()
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    _, vv = e.get_rows(np.arange(rank, p, max(1, p // 100_000) * world, dtype=np.uint32))   # rows this rank owns (id mod N)
+    if not np.all(np.isfinite(vv)):
+        raise SystemExit("non-finite parameters after the timed region")
+    moved = None
+    if dp is not None and exchange == "owner":
+        mine = torch.tensor([float(np.mean(dp.bytes_sent)), float(np.max(dp.bytes_sent))], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        moved = {"bytes_sent_per_step_per_rank_mean": float(torch.stack(allr)[:, 0].mean().item()), "bytes_sent_per_step_per_rank_max": float(torch.stack(allr)[:, 1].max().item())}
+    elif dp is not None:
+        moved = {"bytes_received_per_step_per_rank": dp.last_exchange_bytes}
+    if rank != 0:
+        return
+    fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
+    upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
+    b_step = algorithmic_bytes(z, k, p, B, 4, False)[2]
+    step_gbs = b_step / (dt / args.steps) / 1e9
+    print(json.dumps({
+        "metric": "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD, streamed (configs[3])",
+        "value": B * world * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Criteo-shaped synthetic STREAM, {p} features ({z} nnz/row: 13 dense + 26 categorical fields, skew 3), k={k}, SGD mini-batch: every step's "
+                               f"{B} rows per GPU are generated, planned and trained on once (BASELINE.json configs[3]; its 4e9 rows = {4_000_000_000 // (B * world)} such steps)",
+                   "batch_rows_per_gpu": B, "global_batch_rows": B * world, "parallelism": f"dp{world}",
+                   "ingest_wait_s": wait,
+                   **({"exchange": dict(form=exchange + (": records all-to-all to the owner (id mod N), owner update, rows pulled back on demand" if exchange == "owner" else ""), **moved)} if moved else {})},
+        "roofline": {"bound": "hbm", "kernel": "step = generate + plan + fm_rows_forward + fm_cols_update (+ exchange)", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": step_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_example": b_step / B,
+                     "kernels": {"fm_rows_forward": {"avg_launch_ms": fwd_ms / max(fwd_n, 1)}, "fm_cols_update": {"avg_launch_ms": upd_ms / max(upd_n, 1)}},
+                     "note": "per GPU: SURVEY 8(d) step bytes over the wall time of a streamed global step (ingest and exchange included)"},
+    }), flush=True)
+
+
+def main_in_library(args):
+    """The other N-GPU driver: ONE process, cfg.n_gpus = N (fm_group.hip cuts the matrix into per-device shards, runs every replica's
+    gradient sums on its own stream, one grouped RCCL all-reduce -- or the all-gather of records for sparse tiles -- per step).  The
+    timed region is one fmx_train call of exactly `steps` global steps; the line carries the same metric / config keys as the
+    process-per-GPU driver so that a SCALE run can compare the two."""
+    import torch  # noqa: F401  (imported first: libfmx.so then binds to the HIP runtime torch carries; see fmwr_amd/distributed.py)
+    from fmwr_amd import _lib as L
+    from fmwr_amd import engine
+    N = args.gpus
+    z, k, p = args.nnz, args.factors, args.features
+    criteo = args.workload == "criteo"
+    ftrl = args.solver == "ftrl"
+    B = min(args.batch_rows, args.rows // N)
+    share = os.environ.get("FMX_BENCH_SHARED_DEVICE") == "1"
+    if criteo:
+        m = engine.Matrix.synthetic_fields(args.rows, 13, engine.CRITEO_VOCAB, 3.0, args.seed)
+    else:
+        m = engine.Matrix.synthetic(args.rows, p, z, args.seed)
+    e = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1, n_gpus=N, gpus_share_device=int(share and N > 1), exchange_chunks=0))
+    e.init_normal(args.seed, 0.0, 0.01)
+    per_step = B * N
+    e.train(m, per_step * (args.warmup + (16 if B >= 65536 else 0)))   # shards, plans, phase 1's schedule trials: all outside the timed region
+    t0 = time.perf_counter()
+    done = e.train(m, per_step * args.steps)
+    dt = time.perf_counter() - t0
+    assert done == per_step * args.steps
+    _, vv = e.get_rows(np.arange(0, p, max(1, p // 100_000), dtype=np.uint32))
+    if not np.all(np.isfinite(vv)):
+        raise SystemExit("non-finite parameters after the timed region")
+    b_step = algorithmic_bytes(z, k, p, B, 4, ftrl)[2]
+    step_gbs = b_step / (dt / args.steps) / 1e9
+    print(json.dumps({
+        "metric": "training examples/sec, 10Mx1M sparse FM SGD" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
+        "value": done / dt, "unit": "examples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch (BASELINE.json configs[{3 if criteo else (2 if ftrl else 1)}]{' shape, resident rows' if criteo else ''})",
+                   "driver": "in-library: one process, cfg.n_gpus replicas behind one C-ABI handle (fm_group.hip)" + (" on ONE device (rehearsal)" if share and N > 1 else ""),
+                   "batch_rows_per_gpu": B, "global_batch_rows": per_step, "parallelism": f"dp{N}"},
+        "roofline": {"bound": "hbm", "kernel": "step = fm_rows_forward + fm_cols_update per tile", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": step_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_example": b_step / B,
+                     "note": "per GPU, SURVEY 8(d) bytes over the wall time of a global step (exchange included for N > 1)"},
+    }), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.in_library:
+        if world != 1:
+            raise SystemExit("--in-library is one process for all GPUs: start it without torch.distributed.run")
+        return main_in_library(args)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+            raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU), or pass --in-library")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -398,8 +537,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    if args.solver in ("als", "mcmc"):
-        main_sweep(args, rank, local_rank, world)
+    if args.solver in ("als", "mcmc") or args.stream:
+        if args.stream and args.workload != "criteo":
+            raise SystemExit("--stream needs --workload criteo")
+        (main_stream if args.stream else main_sweep)(args, rank, local_rank, world)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -433,7 +574,7 @@ def main():
     if world > 1:
         want = args.exchange
         st = EngineStepper(e, m, local_rank, dense=(want == "dense"))
-        dp = DataParallel(st, exchange="dense" if want == "dense" else "compact")
+        dp = DataParallel(st, exchange={"dense": "dense", "owner": "owner"}.get(want, "compact"))
         if want == "compact" and dp.exchange != "compact":
             raise SystemExit("--exchange compact needs steps of one sparse tile on every rank")
 
@@ -543,7 +684,9 @@ def main():
                        "parallelism": f"dp{world}",
                        **({"exchange": (f"all-reduce(sum) of {e.grad_buffer()[1] * e.grad_elem_bytes() / 1e6:.1f} MB per step in {e.grad_layout()[0]} pipelined blocks"
                                         if dp.exchange == "dense" else
-                                        f"all-gather of the occurring features' records: {dp.last_exchange_bytes / 1e6:.1f} MB received per rank per step")} if world > 1 else {})},
+                                        (f"owner-sharded: records all-to-all to the owner (id mod N), rows pulled back: {np.mean(dp.bytes_sent) / 1e6:.1f} MB sent per rank per step"
+                                         if dp.exchange == "owner" else
+                                         f"all-gather of the occurring features' records: {dp.last_exchange_bytes / 1e6:.1f} MB received per rank per step"))} if world > 1 else {})},
             # headline: the whole step priced in SURVEY 8(d)'s algorithmic bytes (SGD z(16+8k)+12, FTRL z(32+24k)+12 per example),
             # i.e. value x bytes/example / 8 TB/s per GPU; the two kernels on their own bytes and HIP-event times are in `kernels`
             "roofline": {"bound": "hbm", "kernel": "step = fm_rows_forward + fm_cols_update per tile", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

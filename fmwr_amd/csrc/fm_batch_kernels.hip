@@ -733,7 +733,9 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
     }
   }
   if (a.store_compact) {  // record ci of the compact exchange: the sums of one occurring feature
-    ST* rec = T.crec + (size_t)ci * T.rec_elems;
+    // owner-sharded exchange: the record goes to the list's slot in owner-major order (the part for owner o is then one slice)
+    const size_t slot = a.rec_pos ? (size_t)a.rec_pos[ci] : (size_t)ci;
+    ST* rec = T.crec + slot * T.rec_elems;
     *reinterpret_cast<vec_t*>(rec + lig * VEC) = slice_make(s.G, ST());
     const int qo = (NEED_Q && T.has_q) ? KP : 0;
     if (qo) *reinterpret_cast<vec_t*>(rec + KP + lig * VEC) = slice_make(s.Q, ST());

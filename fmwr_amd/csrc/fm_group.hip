@@ -321,6 +321,23 @@ static int exchange_compact(Group* g, const std::vector<int64_t>& counts, int64_
   return FMX_OK;
 }
 
+// every replica's gather buffer holds N parts of `stride` records
+static int ensure_gath(Group* g, int64_t stride) {
+  const size_t eb = mb_wide(g->rep[0]) ? 8 : 4;
+  const int64_t rec = g->rep[0]->rec_elems;
+  if (g->gath.empty()) g->gath.assign((size_t)g->n, nullptr);
+  if (stride <= g->gath_records && g->gath[0]) return FMX_OK;
+  const int64_t want = stride + stride / 8 + 1;  // some headroom: the count moves a little from step to step
+  for (int r = 0; r < g->n; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_HIP(hipStreamSynchronize(g->rep[(size_t)r]->stream));
+    (void)hipFree(g->gath[(size_t)r]); g->gath[(size_t)r] = nullptr;
+    FMX_HIP(hipMalloc(&g->gath[(size_t)r], (size_t)g->n * (size_t)want * (size_t)rec * eb));
+  }
+  g->gath_records = want;
+  return FMX_OK;
+}
+
 // every replica's steps are single sparse tiles?  then reserve the record buffers and the gather buffers once
 static int prepare_compact(Group* g, bool* usable) {
   const char* v = getenv("FMX_GROUP_EXCHANGE");  // "dense": tests and A/B runs (read at every fmx_train)
@@ -417,6 +434,86 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
   FMX_HIP(hipSetDevice(e->cfg.device));
   if (examples_done) *examples_done = done;
   return FMX_OK;
+}
+
+// fmx_train_stream over N replicas: replica r streams rows [r T / N, (r + 1) T / N) of the caller's range -- the generators are keyed
+// by the global row id, so a shard is just another row_offset -- plans each of its steps on its own device and the replicas
+// exchange per step as in group_train: the records of the occurring features when the steps are sparse tiles (configs[3]:
+// 33 M features against 10 M entries per step), the dense buffer otherwise.  A replica whose range ends a step early publishes
+// an empty share.
+int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
+                       int64_t* examples_done, double* ingest_wait_s) {
+  Group* g = e->group;
+  struct Busy { Group* g; explicit Busy(Group* g_) : g(g_) { g->busy = true; } ~Busy() { g->busy = false; } } busy(g);
+  FMX_CHECK(total_rows >= 0, FMX_ERR_INVALID, "total_rows must be >= 0");
+  FMX_CHECK(mb_wide(e) || e->cfg.batch_rows * g->n < (1LL << 24), FMX_ERR_INVALID,
+            "batch_rows * n_gpus must stay below 2^24 with fp32 state (occurrence counts are exchanged as floats); use state_fp64 or smaller batches");
+  if (total_rows == 0) return FMX_OK;
+  const int N = g->n;
+  std::vector<fmx_source*> S((size_t)N, nullptr);
+  std::vector<fmx_matrix*> last((size_t)N, nullptr);
+  std::vector<int64_t> counts((size_t)N, 0);
+  int64_t done = 0;
+  double waited = 0.0;
+  auto body = [&]() -> int {
+    int64_t steps = 0;
+    for (int r = 0; r < N; ++r) {
+      const int64_t r0 = (total_rows * r) / N, r1 = (total_rows * (r + 1)) / N;
+      FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+      FMX_TRY(fmx_source_open(g->rep[(size_t)r], spec, nnz_per_row, seed, row_offset + r0, r1 - r0, &S[(size_t)r]));
+      const int64_t st = (r1 - r0 + e->cfg.batch_rows - 1) / e->cfg.batch_rows;
+      if (st > steps) steps = st;
+    }
+    FMX_CHECK(total_rows >= N, FMX_ERR_INVALID, "a shard is empty: fewer rows than GPUs");
+    for (int64_t s = 0; s < steps; ++s) {
+      int64_t stride = 0;
+      bool compact = false;
+      for (int r = 0; r < N; ++r) {
+        fmx_engine* rep = g->rep[(size_t)r];
+        fmx_matrix* m = nullptr;
+        int64_t rows = 0;
+        FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+        FMX_TRY(fmx_source_next(S[(size_t)r], &m, &rows));
+        if (m) last[(size_t)r] = m; else m = last[(size_t)r];
+        FMX_CHECK(m != nullptr, FMX_ERR_STATE, "a replica has no step to share");
+        const char* v = getenv("FMX_GROUP_EXCHANGE");
+        compact = m->plans[0].feat != nullptr && !(v && v[0] == 'd');
+        if (compact) {
+          FMX_TRY(group_grad_compact(rep, m, 0, rows));  // rows == 0: the shard ended a step early -- zero counts, an empty tail
+          counts[(size_t)r] = (int64_t)m->plans[0].n_lists;
+          if (counts[(size_t)r] > stride) stride = counts[(size_t)r];
+        } else if (rows > 0) {
+          FMX_TRY(fmx_grad(rep, m, 0, 0));
+        } else {
+          FMX_TRY(group_grad_empty(rep, m, 0));
+        }
+        done += rows;
+      }
+      if (compact) {
+        FMX_TRY(ensure_gath(g, stride > 0 ? stride : 1));
+        FMX_TRY(exchange_compact(g, counts, stride));
+      } else {
+        FMX_TRY(exchange(g));
+        for (int r = 0; r < N; ++r) {
+          FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+          FMX_TRY(fmx_apply(g->rep[(size_t)r], 0));
+        }
+      }
+    }
+    return FMX_OK;
+  };
+  int st = body();
+  for (int r = 0; r < N; ++r) {
+    (void)hipSetDevice(g->dev[(size_t)r]);
+    double w = 0.0;
+    const int st2 = fmx_source_close(S[(size_t)r], &w);
+    if (st == FMX_OK) st = st2;
+    if (w > waited) waited = w;
+  }
+  (void)hipSetDevice(e->cfg.device);
+  if (examples_done) *examples_done = done;
+  if (ingest_wait_s) *ingest_wait_s = waited;
+  return st;
 }
 
 // RCCL smoke test on the devices this process sees (n ranks on devices 0..n-1): all-reduce of a small buffer, checked.  Lets a

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 #include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
 
 #include <rocprim/rocprim.hpp>
@@ -199,6 +200,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 void plan_free(fmx_matrix::TilePlan& t) {
   (void)hipFree(t.pool);
+  (void)hipFree(t.own_pool);
   if (t.off && !t.off_in_pool) (void)hipFree(t.off);
   t = fmx_matrix::TilePlan{};
 }
@@ -360,6 +362,134 @@ int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream) {
   if (st != FMX_OK) { (void)hipFree(off); return st; }
   t.off = off;
   t.off_in_pool = 0;
+  return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ owner-major order of a directory
+// Owner-sharded exchange: feature j belongs to rank j mod N.  A rank's records (and the ids it asks the owners
+// for) travel in owner-major order, so that the part for owner o is ONE contiguous slice -- no packing pass per step.  The order
+// is a stable partition of the tile's ascending directory by (id mod N): ids stay ascending inside an owner's slice, which is
+// what keeps the owner's merge (stable sort by id over the parts in rank order) equal to the all-gather form's.
+OwnerWorkspace::~OwnerWorkspace() { (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(idx_in); (void)hipFree(idx_out); (void)hipFree(temp); }
+
+int OwnerWorkspace::reserve(uint32_t n, hipStream_t stream) {
+  if (n <= cap && keys_in) return FMX_OK;
+  FMX_HIP(hipStreamSynchronize(stream));
+  (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(idx_in); (void)hipFree(idx_out); (void)hipFree(temp);
+  keys_in = keys_out = idx_in = idx_out = nullptr; temp = nullptr; cap = 0;
+  const size_t m = n ? n : 1;
+  FMX_HIP(hipMalloc(&keys_in, m * 4)); FMX_HIP(hipMalloc(&keys_out, m * 4)); FMX_HIP(hipMalloc(&idx_in, m * 4)); FMX_HIP(hipMalloc(&idx_out, m * 4));
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, idx_out, m, 0, 5, stream));
+  FMX_HIP(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+  cap = (uint32_t)m;
+  return FMX_OK;
+}
+
+int plan_owner_alloc(fmx_matrix::TilePlan& t, uint32_t cap_lists) {
+  if (t.own_pool && t.own_cap >= cap_lists) return FMX_OK;
+  (void)hipFree(t.own_pool); t.own_pool = nullptr; t.own_cap = 0; t.own_n = 0;
+  const size_t c = cap_lists ? cap_lists : 1;
+  const size_t b_counts = align_up((OWNERS_MAX + 2) * sizeof(uint32_t), 256), b_arr = align_up(c * sizeof(uint32_t), 256);
+  FMX_HIP(hipMalloc(&t.own_pool, b_counts + 2 * b_arr));
+  char* b = (char*)t.own_pool;
+  t.own_counts = (uint32_t*)b;
+  t.own_pos = (uint32_t*)(b + b_counts);
+  t.own_ids = (uint32_t*)(b + b_counts + b_arr);
+  t.own_cap = (uint32_t)c;
+  return FMX_OK;
+}
+
+__global__ void owner_keys_k(const uint32_t* __restrict__ feat, const uint32_t* __restrict__ dcounts, uint32_t n_sort, uint32_t n_owners,
+                             uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_sort) return;
+  keys[i] = i < (int64_t)dcounts[0] ? feat[i] % n_owners : n_owners;  // slots beyond the directory's end sort behind every owner
+  idx[i] = (uint32_t)i;
+}
+
+// sorted keys -> counts per owner (n_owners + 1 threads: the first position of each key value), positions and ids
+__global__ void owner_finish_k(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ order, const uint32_t* __restrict__ feat,
+                               const uint32_t* __restrict__ dcounts, uint32_t n_sort, uint32_t n_owners, uint32_t* __restrict__ counts,
+                               uint32_t* __restrict__ pos, uint32_t* __restrict__ ids) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = dcounts[0] < n_sort ? dcounts[0] : n_sort;
+  if (j < (int64_t)n) {
+    const uint32_t i = order[j];
+    pos[i] = (uint32_t)j;
+    ids[j] = feat[i];
+  }
+  if (j <= (int64_t)n_owners) {  // owner j's slice starts at the first sorted key >= j; counts[j] = start(j + 1) - start(j)
+    auto lower = [&](uint32_t key) {
+      uint32_t lo = 0, hi = n;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+      return lo;
+    };
+    if (j < (int64_t)n_owners) counts[j] = lower((uint32_t)j + 1) - lower((uint32_t)j);
+    else counts[j] = n;  // total, behind the per-owner counts
+  }
+}
+
+int plan_owner_build(fmx_matrix::TilePlan& t, OwnerWorkspace& ws, int n_owners, uint32_t n_sort, hipStream_t stream) {
+  FMX_CHECK(n_owners >= 1 && n_owners <= OWNERS_MAX, FMX_ERR_INVALID, "1..%d owners are supported (got %d)", OWNERS_MAX, n_owners);
+  FMX_CHECK(t.feat != nullptr, FMX_ERR_STATE, "the owner-sharded exchange needs a sparse tile (fewer entries than features)");
+  FMX_CHECK(t.own_pool != nullptr && n_sort <= t.own_cap && n_sort <= ws.cap, FMX_ERR_STATE, "owner plan: arrays too small");
+  const int T = 256;
+  FMX_HIP(hipMemsetAsync(t.own_counts, 0, (OWNERS_MAX + 2) * sizeof(uint32_t), stream));
+  if (n_sort > 0) {
+    hipLaunchKernelGGL(owner_keys_k, dim3((n_sort + T - 1) / T), dim3(T), 0, stream, t.feat, t.dcounts, n_sort, (uint32_t)n_owners, ws.keys_in, ws.idx_in);
+    size_t tb = ws.temp_bytes;
+    int bits = 1;
+    while ((1 << bits) <= n_owners) ++bits;  // keys 0 .. n_owners
+    FMX_HIP(rocprim::radix_sort_pairs(ws.temp, tb, ws.keys_in, ws.keys_out, ws.idx_in, ws.idx_out, (size_t)n_sort, 0, bits, stream));
+  }
+  const uint32_t g = (n_sort > (uint32_t)n_owners + 1 ? n_sort : (uint32_t)n_owners + 1);
+  hipLaunchKernelGGL(owner_finish_k, dim3((g + T - 1) / T), dim3(T), 0, stream, ws.keys_out, ws.idx_out, t.feat, t.dcounts, n_sort, (uint32_t)n_owners, t.own_counts,
+                     t.own_pos, t.own_ids);
+  FMX_HIP(hipGetLastError());
+  t.own_n = n_owners;
+  return FMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ rows <-> packed buffer
+// What an owner sends back for a pulled feature, and what the asking rank stores: the V row and w in the STATE's element type,
+// [kp | w 0 0 0] per feature (16-byte aligned rows).  Optimizer state never travels: it lives with the owner.
+template <typename T, int VEC, bool UNPACK>
+__global__ void rows_pack_k(T* __restrict__ V, T* __restrict__ w, int kp, const uint32_t* __restrict__ ids, int64_t n, T* __restrict__ rows) {
+  const int lpr = kp / VEC + 1;  // the row's slices, then the w slice
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * lpr) return;
+  const int64_t i = t / lpr;
+  const int s = (int)(t - i * lpr);
+  const size_t j = ids[i];
+  T* row = rows + (size_t)i * (kp + 4);
+  using vec_t = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
+  if (s < kp / VEC) {
+    vec_t* a = reinterpret_cast<vec_t*>(V + j * kp + s * VEC);
+    vec_t* b = reinterpret_cast<vec_t*>(row + s * VEC);
+    if (UNPACK) *a = *b; else *b = *a;
+  } else if (UNPACK) {
+    w[j] = row[kp];
+  } else {
+    row[kp] = w[j];
+    for (int q = 1; q < 4; ++q) row[kp + q] = (T)0;
+  }
+}
+
+int rows_pack(fmx_engine* e, const uint32_t* d_ids, int64_t n, void* d_rows, bool unpack) {
+  if (n <= 0) return FMX_OK;
+  const int kp = mb_kp(e);
+  if (mb_wide(e)) {
+    const int64_t total = n * (kp / 2 + 1);
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
+    if (unpack) hipLaunchKernelGGL((rows_pack_k<double, 2, true>), g, b, 0, e->stream, e->dV, e->dw, kp, d_ids, n, (double*)d_rows);
+    else hipLaunchKernelGGL((rows_pack_k<double, 2, false>), g, b, 0, e->stream, e->dV, e->dw, kp, d_ids, n, (double*)d_rows);
+  } else {
+    const int64_t total = n * (kp / 4 + 1);
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
+    if (unpack) hipLaunchKernelGGL((rows_pack_k<float, 4, true>), g, b, 0, e->stream, e->V, e->w, kp, d_ids, n, (float*)d_rows);
+    else hipLaunchKernelGGL((rows_pack_k<float, 4, false>), g, b, 0, e->stream, e->V, e->w, kp, d_ids, n, (float*)d_rows);
+  }
+  FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 

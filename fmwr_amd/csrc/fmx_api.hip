@@ -211,7 +211,7 @@ struct VisitOrder {
   }
 };
 
-static void free_matrix(fmx_matrix* m) {
+void free_matrix(fmx_matrix* m) {
   if (!m) return;
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
   drop_plans(m);
@@ -527,6 +527,22 @@ static int64_t compact_capacity(const fmx_matrix* m) {
   return cap;
 }
 
+// the owner-major order of a resident tile, built on first use (a streamed tile's comes with its ingest: fmx_source_open)
+static int ensure_owner_plan(fmx_engine* e, fmx_matrix* m, int64_t tile) {
+  auto& pl = m->plans[(size_t)tile];
+  if (pl.own_n == e->owner_parts) return FMX_OK;
+  FMX_CHECK(pl.feat != nullptr, FMX_ERR_STATE, "the owner-sharded exchange needs sparse tiles (fewer entries than features per tile)");
+  OwnerWorkspace ws;
+  FMX_TRY(ws.reserve(pl.n_lists, e->stream));
+  FMX_TRY(plan_owner_alloc(pl, pl.n_lists));
+  FMX_TRY(plan_owner_build(pl, ws, e->owner_parts, pl.n_lists, e->stream));
+  uint32_t h[OWNERS_MAX + 2];
+  FMX_HIP(hipMemcpyAsync(h, pl.own_counts, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  FMX_HIP(hipStreamSynchronize(e->stream));  // (also keeps the workspace alive until the sort has run)
+  for (int o = 0; o <= OWNERS_MAX; ++o) pl.own_counts_h[o] = h[o];
+  return FMX_OK;
+}
+
 static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_limit, bool empty_share = false) {
   std::vector<TileRun> tiles;
   int64_t step_rows = 0;
@@ -548,6 +564,10 @@ static int grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t row
   c.scalar = SCALAR_PUBLISH;
   c.n_partials = np;
   c.global_rows = (double)step_rows;
+  if (e->owner_parts > 1) {  // owner-sharded exchange: records in owner-major order
+    FMX_TRY(ensure_owner_plan(e, m, tiles[0].tile));
+    c.rec_pos = m->plans[(size_t)tiles[0].tile].own_pos;
+  }
   LongArgs la{};
   FMX_TRY(long_args(e, m, tiles[0].tile, &la, &c));
   e->crec_count = pl.dcounts;  // n_lists as the plan builder left it on the device
@@ -1158,120 +1178,191 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
 }
 
 // ------------------------------------------------------------------------------------------------ streamed training
-int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
-                     int64_t* examples_done, double* ingest_wait_s) {
+// A stream of training steps over generated rows (BASELINE.json configs[3]: 4e9 rows never exist at once).  Three slots, ingest two
+// steps ahead: the engine's stream then holds  plan(t+1) | train(t) | plan(t+2) | train(t+1) ...  and the counts the host waits
+// for (a tile's launch sizes) belong to a plan that finished BEFORE the step now running -- with two slots the host waited for
+// plan(t+1) behind train(t) and the GPU idled from the end of that plan until the host had woken up and enqueued train(t+1).
+// Measured (profiles/r02_stream.txt): uniform columns 107 -> 113 M examples/s.
+//
+// Where the next step's tile is generated and planned: on a second stream beside the running step (FMX_STREAM_OVERLAP=1), or on
+// the engine's own stream right behind it (default).  Measured at configs[3]'s shape: side by side both get slower than back to
+// back -- the sort's streaming passes push the step's gather tables (S: 33 MB) out of the Infinity Cache -- and the overlapped
+// form loses 15-20 % end to end; in both forms the host only waits for the tile's counts, one step ahead of the GPU.
+struct fmx_source {
+  static constexpr int NSLOT = 3;
+  struct Slot { fmx_matrix* m = nullptr; hipEvent_t ingested = nullptr, trained = nullptr; uint32_t* h_counts = nullptr; int used = 0; };
+  fmx_engine* e = nullptr;
+  Slot slot[NSLOT];
+  hipStream_t ingest = nullptr;
+  bool own_stream = false;
+  fmx::PlanWorkspace ws;
+  fmx::OwnerWorkspace ows;
+  bool has_spec = false;
+  fmx::FieldSpec fs{};
+  int z = 0;
+  uint64_t seed = 0, p = 0;
+  int64_t row_offset = 0, total_rows = 0, B = 0, steps = 0;
+  int64_t next_t = 0;       // step the next fmx_source_next hands out
+  int64_t ingested_to = 0;  // steps whose ingest has been enqueued
+  int owners = 0;
+  double waited = 0.0;
+  ~fmx_source() {
+    for (auto& s : slot) {
+      if (s.ingested) (void)hipEventDestroy(s.ingested);
+      if (s.trained) (void)hipEventDestroy(s.trained);
+      if (s.h_counts) (void)hipHostFree(s.h_counts);
+      fmx::free_matrix(s.m);
+    }
+    if (ingest && own_stream) (void)hipStreamDestroy(ingest);
+  }
+};
+
+namespace fmx {
+
+constexpr int STREAM_COUNTS = 4 + OWNERS_MAX + 2;  // a tile's {n_lists, n_long, n_seg, -} and its lists per owner (+ total)
+
+static int stream_ingest(fmx_source* S, int64_t t) {
+  fmx_source::Slot& s = S->slot[t % fmx_source::NSLOT];
+  fmx_matrix* m = s.m;
+  const int64_t rows = (t + 1) * S->B <= S->total_rows ? S->B : S->total_rows - t * S->B;
+  if (s.used) FMX_HIP(hipStreamWaitEvent(S->ingest, s.trained, 0));  // the slot's previous step must have finished with its arrays
+  m->n = rows; m->nnz = rows * S->z;
+  if (S->has_spec) FMX_TRY(generate_fields_async(m, rows, S->fs, S->seed, S->row_offset + t * S->B, S->ingest));
+  else FMX_TRY(generate_synthetic_async(m, rows, S->z, S->seed, S->row_offset + t * S->B, S->ingest));
+  auto& pl = m->plans[0];
+  pl.r0 = 0; pl.nrows = rows; pl.base = 0; pl.cnt = rows * S->z;
+  FMX_TRY(plan_build(pl, S->ws, (uint32_t)S->p, m->row_ptr, m->col, m->val, m->brow, m->bval, S->ingest, m->unit_values, S->z));
+  FMX_HIP(hipMemcpyAsync(s.h_counts, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->ingest));
+  if (S->owners > 1 && pl.feat) {  // the owner-major order of the tile's lists: the count is still on the device, so the whole directory is sorted
+    FMX_TRY(plan_owner_build(pl, S->ows, S->owners, pl.own_cap, S->ingest));
+    FMX_HIP(hipMemcpyAsync(s.h_counts + 4, pl.own_counts, (OWNERS_MAX + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, S->ingest));
+  }
+  FMX_HIP(hipEventRecord(s.ingested, S->ingest));
+  s.used = 1;
+  return FMX_OK;
+}
+
+}  // namespace fmx
+
+int fmx_source_open(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows, fmx_source** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_CHECK(!seq_mode(e), FMX_ERR_STATE, "streamed training runs in FMX_MODE_MINIBATCH");
-  FMX_CHECK(e->group == nullptr, FMX_ERR_STATE, "streamed training runs on one GPU per handle (n_gpus > 1: one stream per process, see fmwr_amd/distributed.py)");
   FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS && e->cfg.solver != FMX_SOLVER_MCMC, FMX_ERR_STATE, "ALS / MCMC engines train through fmx_als_train / fmx_mcmc_train");
-  FMX_CHECK(total_rows >= 0, FMX_ERR_INVALID, "total_rows must be >= 0");
-  if (examples_done) *examples_done = 0;
-  if (ingest_wait_s) *ingest_wait_s = 0.0;
-  FieldSpec fs{};
-  uint64_t p = e->p;
-  int z = nnz_per_row;
+  FMX_CHECK(total_rows >= 0 && row_offset >= 0, FMX_ERR_INVALID, "total_rows and row_offset must be >= 0");
+  std::unique_ptr<fmx_source> S(new fmx_source());
+  S->e = e;
+  S->p = e->p;
+  S->z = nnz_per_row;
+  S->seed = seed;
   if (spec) {
-    FMX_TRY(fields_from_spec(spec, &fs, &p));
-    seed = spec->seed;
-    z = fs.n_dense + fs.n_fields;
+    FMX_TRY(fields_from_spec(spec, &S->fs, &S->p));
+    S->has_spec = true;
+    S->seed = spec->seed;
+    S->z = S->fs.n_dense + S->fs.n_fields;
   } else {
     FMX_CHECK(nnz_per_row >= 1 && (uint64_t)nnz_per_row <= e->p, FMX_ERR_INVALID, "need 1 <= nnz_per_row <= p");
   }
-  FMX_CHECK(p == e->p, FMX_ERR_INVALID, "number of input's features is not correct...");
+  FMX_CHECK(S->p == e->p, FMX_ERR_INVALID, "number of input's features is not correct...");
   const int64_t B = e->cfg.batch_rows;
   FMX_CHECK(B <= effective_tile_rows(e), FMX_ERR_STATE, "streamed training needs steps of one tile (batch_rows <= %lld)", (long long)effective_tile_rows(e));
   FMX_TRY(use_device(e->cfg.device));
-  if (total_rows == 0) return FMX_OK;
-
-  // Three slots, ingest two steps ahead: the stream then holds  plan(t+1) | train(t) | plan(t+2) | train(t+1) ...  and the counts the
-  // host waits for (a tile's launch sizes) belong to a plan that finished BEFORE the step now running -- with two slots the host
-  // waited for plan(t+1) behind train(t) and the GPU idled from the end of that plan until the host had woken up and enqueued
-  // train(t+1).  Measured (profiles/r02_stream.txt): uniform columns 107 -> 113 M examples/s, Criteo shape unchanged at 157 (there
-  // the GPU time itself -- generate 0.1 + plan 0.72 + train 0.74 ms per step -- is what is left).
-  constexpr int NSLOT = 3;
-  struct Slot { fmx_matrix* m = nullptr; hipEvent_t ingested = nullptr, trained = nullptr; uint32_t* h_counts = nullptr; int used = 0; };
-  struct Ctx {
-    Slot slot[NSLOT];
-    hipStream_t ingest = nullptr;
-    bool own_stream = true;
-    PlanWorkspace ws;
-    ~Ctx() {
-      for (auto& s : slot) {
-        if (s.ingested) (void)hipEventDestroy(s.ingested);
-        if (s.trained) (void)hipEventDestroy(s.trained);
-        if (s.h_counts) (void)hipHostFree(s.h_counts);
-        free_matrix(s.m);
-      }
-      if (ingest && own_stream) (void)hipStreamDestroy(ingest);
-    }
-  } C;
-  const int64_t cap_cnt = B * z;
-  // Where the next step's tile is generated and planned: on a second stream beside the running step (FMX_STREAM_OVERLAP=1), or
-  // on the engine's own stream right behind it (default).  Measured at configs[3]'s shape (profiles/r02_stream.txt): side by
-  // side both get slower than back to back -- the sort's streaming passes push the step's gather tables (S: 33 MB) out of the
-  // Infinity Cache -- and the overlapped form loses 15-20 % end to end; in both forms the host only waits for the tile's
-  // three counts, one step ahead of the GPU.
+  S->B = B; S->row_offset = row_offset; S->total_rows = total_rows; S->steps = (total_rows + B - 1) / B;
+  S->owners = e->owner_parts;
+  const int64_t cap_cnt = B * S->z;
   static const bool overlap = [] { const char* v = getenv("FMX_STREAM_OVERLAP"); return v && v[0] == '1'; }();
-  if (overlap) FMX_HIP(hipStreamCreateWithFlags(&C.ingest, hipStreamNonBlocking));
-  else { C.ingest = e->stream; C.own_stream = false; }
-  FMX_TRY(C.ws.reserve(cap_cnt, (uint32_t)p, C.ingest));
-  for (auto& s : C.slot) {
-    FMX_TRY(alloc_matrix(e->cfg.device, B, (uint32_t)p, cap_cnt, true, &s.m));
-    s.m->rows_sorted = 1; s.m->max_row_len = z; s.m->fixed_row_len = z;
-    s.m->unit_values = (spec && fs.n_dense > 0) ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
+  if (overlap) { FMX_HIP(hipStreamCreateWithFlags(&S->ingest, hipStreamNonBlocking)); S->own_stream = true; }
+  else S->ingest = e->stream;
+  FMX_TRY(S->ws.reserve(cap_cnt, (uint32_t)S->p, S->ingest));
+  const bool dense = cap_cnt >= (int64_t)S->p;
+  for (auto& s : S->slot) {
+    FMX_TRY(alloc_matrix(e->cfg.device, B, (uint32_t)S->p, cap_cnt, true, &s.m));
+    s.m->rows_sorted = 1; s.m->max_row_len = S->z; s.m->fixed_row_len = S->z;
+    s.m->unit_values = (S->has_spec && S->fs.n_dense > 0) ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
     FMX_HIP(hipMalloc(&s.m->brow, (size_t)cap_cnt * sizeof(uint32_t)));
     FMX_HIP(hipMalloc(&s.m->bval, (size_t)cap_cnt * sizeof(float)));
     s.m->plans.resize(1);
-    FMX_TRY(plan_alloc(s.m->plans[0], (uint32_t)p, cap_cnt, cap_cnt >= (int64_t)p));
+    FMX_TRY(plan_alloc(s.m->plans[0], (uint32_t)S->p, cap_cnt, dense));
+    if (S->owners > 1 && !dense) FMX_TRY(plan_owner_alloc(s.m->plans[0], s.m->plans[0].cap_lists));
     s.m->step_first_tile = {0, 1};
     s.m->n_batches = 1; s.m->batch_rows = B; s.m->tile_rows = effective_tile_rows(e);   // build_batch_csc sees a finished cache
     FMX_HIP(hipEventCreateWithFlags(&s.ingested, hipEventDisableTiming));
     FMX_HIP(hipEventCreateWithFlags(&s.trained, hipEventDisableTiming));
-    FMX_HIP(hipHostMalloc(&s.h_counts, 4 * sizeof(uint32_t)));
+    FMX_HIP(hipHostMalloc(&s.h_counts, STREAM_COUNTS * sizeof(uint32_t)));
+    memset(s.h_counts, 0, STREAM_COUNTS * sizeof(uint32_t));
   }
+  if (S->owners > 1 && !dense) FMX_TRY(S->ows.reserve(S->slot[0].m->plans[0].cap_lists, S->ingest));
   FMX_HIP(hipDeviceSynchronize());
-  const int64_t steps = (total_rows + B - 1) / B;
-  auto ingest = [&](int64_t t) -> int {
-    Slot& s = C.slot[t % NSLOT];
-    fmx_matrix* m = s.m;
-    const int64_t rows = (t + 1) * B <= total_rows ? B : total_rows - t * B;
-    if (s.used) FMX_HIP(hipStreamWaitEvent(C.ingest, s.trained, 0));  // the slot's previous step must have finished with its arrays
-    m->n = rows; m->nnz = rows * z;
-    if (spec) FMX_TRY(generate_fields_async(m, rows, fs, seed, row_offset + t * B, C.ingest));
-    else FMX_TRY(generate_synthetic_async(m, rows, z, seed, row_offset + t * B, C.ingest));
-    auto& pl = m->plans[0];
-    pl.r0 = 0; pl.nrows = rows; pl.base = 0; pl.cnt = rows * z;
-    FMX_TRY(plan_build(pl, C.ws, (uint32_t)p, m->row_ptr, m->col, m->val, m->brow, m->bval, C.ingest, m->unit_values, z));
-    FMX_HIP(hipMemcpyAsync(s.h_counts, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, C.ingest));
-    FMX_HIP(hipEventRecord(s.ingested, C.ingest));
-    s.used = 1;
-    return FMX_OK;
-  };
-  double waited = 0.0;
-  int64_t done = 0;
-  FMX_TRY(ingest(0));
-  if (steps > 1) FMX_TRY(ingest(1));
-  for (int64_t t = 0; t < steps; ++t) {
-    Slot& s = C.slot[t % NSLOT];
-    timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    FMX_HIP(hipEventSynchronize(s.ingested));  // the host needs the tile's counts (launch sizes); the engine's stream keeps running meanwhile
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    waited += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-    plan_set_counts(s.m->plans[0], (uint32_t)p, s.h_counts);
-    s.m->max_long_seg = s.m->plans[0].n_seg;
-    s.m->plan_generation++;
-    FMX_HIP(hipStreamWaitEvent(e->stream, s.ingested, 0));
-    FMX_TRY(run_step(e, s.m, 0, 0, true));
-    FMX_HIP(hipEventRecord(s.trained, e->stream));
-    done += s.m->n;
-    if (t + 2 < steps) FMX_TRY(ingest(t + 2));  // queued behind the step just enqueued; its slot's previous step (t - 1) is ahead of both
-  }
-  FMX_HIP(hipStreamSynchronize(e->stream));
-  FMX_HIP(hipStreamSynchronize(C.ingest));
-  if (examples_done) *examples_done = done;
-  if (ingest_wait_s) *ingest_wait_s = waited;
+  for (int64_t t = 0; t < 2 && t < S->steps; ++t) { FMX_TRY(stream_ingest(S.get(), t)); S->ingested_to = t + 1; }
+  *out = S.release();
   return FMX_OK;
+}
+
+int fmx_source_next(fmx_source* S, fmx_matrix** step_matrix, int64_t* rows) {
+  FMX_CHECK(S != nullptr && step_matrix != nullptr, FMX_ERR_INVALID, "NULL argument");
+  fmx_engine* e = S->e;
+  FMX_TRY(use_device(e->cfg.device));
+  *step_matrix = nullptr;
+  if (rows) *rows = 0;
+  const int64_t t = S->next_t;
+  if (t > 0) {
+    // everything the caller enqueued for step t - 1 (its gradient kernels read the slot's arrays) is on the engine's stream by now
+    FMX_HIP(hipEventRecord(S->slot[(t - 1) % fmx_source::NSLOT].trained, e->stream));
+    if (S->ingested_to < S->steps && S->ingested_to <= t + 1) { FMX_TRY(stream_ingest(S, S->ingested_to)); S->ingested_to++; }
+  }
+  if (t >= S->steps) return FMX_OK;
+  fmx_source::Slot& s = S->slot[t % fmx_source::NSLOT];
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  FMX_HIP(hipEventSynchronize(s.ingested));  // the host needs the tile's counts (launch sizes); the engine's stream keeps running meanwhile
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  S->waited += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  auto& pl = s.m->plans[0];
+  plan_set_counts(pl, (uint32_t)S->p, s.h_counts);
+  if (pl.own_n > 0) for (int o = 0; o <= OWNERS_MAX; ++o) pl.own_counts_h[o] = s.h_counts[4 + o];
+  s.m->max_long_seg = pl.n_seg;
+  s.m->plan_generation++;
+  FMX_HIP(hipStreamWaitEvent(e->stream, s.ingested, 0));
+  *step_matrix = s.m;
+  if (rows) *rows = s.m->n;
+  S->next_t = t + 1;
+  return FMX_OK;
+}
+
+int fmx_source_close(fmx_source* S, double* ingest_wait_s) {
+  if (!S) return FMX_OK;
+  (void)hipSetDevice(S->e->cfg.device);
+  hipError_t e1 = hipStreamSynchronize(S->e->stream), e2 = S->ingest ? hipStreamSynchronize(S->ingest) : hipSuccess;
+  if (ingest_wait_s) *ingest_wait_s = S->waited;
+  delete S;
+  FMX_CHECK(e1 == hipSuccess && e2 == hipSuccess, FMX_ERR_HIP, "a streamed step failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  return FMX_OK;
+}
+
+int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
+                     int64_t* examples_done, double* ingest_wait_s) {
+  if (examples_done) *examples_done = 0;
+  if (ingest_wait_s) *ingest_wait_s = 0.0;
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  if (e->group) return group_train_stream(e, spec, nnz_per_row, seed, row_offset, total_rows, examples_done, ingest_wait_s);
+  fmx_source* S = nullptr;
+  FMX_TRY(fmx_source_open(e, spec, nnz_per_row, seed, row_offset, total_rows, &S));
+  int64_t done = 0;
+  int st = FMX_OK;
+  for (;;) {
+    fmx_matrix* m = nullptr;
+    int64_t rows = 0;
+    st = fmx_source_next(S, &m, &rows);
+    if (st != FMX_OK || m == nullptr) break;
+    st = run_step(e, m, 0, 0, true);
+    if (st != FMX_OK) break;
+    done += rows;
+  }
+  const int st2 = fmx_source_close(S, ingest_wait_s);
+  if (st == FMX_OK) st = st2;
+  if (examples_done) *examples_done = done;
+  return st;
 }
 
 // ------------------------------------------------------------------------------------------------ tracker
@@ -1582,6 +1673,60 @@ int fmx_apply_compact(fmx_engine* e, const void* dev_records, const int64_t* cou
   const uint32_t *pos, *roff, *rfeat, *d_n;
   merge_result(e, &pos, &roff, &rfeat, &d_n);
   return launch_apply_records(e, dev_records, pos, roff, rfeat, d_n, total, global_rows);
+}
+
+int fmx_apply_compact_parts(fmx_engine* e, const void* dev_records, const int64_t* counts, const int64_t* starts, int32_t n_parts, int64_t global_rows) {
+  FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "fmx_apply_compact_parts needs a mini-batch engine");
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): train it with fmx_train", e->cfg.n_gpus);
+  FMX_CHECK(e->ctail != nullptr, FMX_ERR_STATE, "fmx_apply_compact_parts needs a preceding fmx_grad_compact");
+  FMX_CHECK(counts != nullptr && starts != nullptr && n_parts >= 1, FMX_ERR_INVALID, "bad record parts");
+  FMX_TRY(use_device(e->cfg.device));
+  int64_t total = 0;
+  for (int r = 0; r < n_parts; ++r) total += counts[r];
+  FMX_CHECK(dev_records != nullptr || total == 0, FMX_ERR_INVALID, "dev_records is NULL");
+  FMX_TRY(merge_records(e, dev_records, counts, starts, n_parts, 0, &total));
+  const uint32_t *pos, *roff, *rfeat, *d_n;
+  merge_result(e, &pos, &roff, &rfeat, &d_n);
+  return launch_apply_records(e, dev_records, pos, roff, rfeat, d_n, total, global_rows);
+}
+
+int fmx_owner_configure(fmx_engine* e, int32_t n_owners, int32_t rank) {
+  FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "the owner-sharded exchange exists only in FMX_MODE_MINIBATCH");
+  FMX_CHECK(n_owners >= 1 && n_owners <= OWNERS_MAX && rank >= 0 && rank < n_owners, FMX_ERR_INVALID, "need 1 <= n_owners <= %d and 0 <= rank < n_owners", OWNERS_MAX);
+  e->owner_parts = n_owners > 1 ? n_owners : 0;
+  e->owner_rank = rank;
+  return FMX_OK;
+}
+
+int fmx_owner_info(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t* counts, void** dev_ids) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(!seq_mode(e) && e->owner_parts > 1, FMX_ERR_STATE, "fmx_owner_info needs fmx_owner_configure(n_owners > 1) on a mini-batch engine");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(build_batch_csc(m, e->cfg.batch_rows, effective_tile_rows(e), e->stream));
+  FMX_CHECK(batch >= 0 && batch < m->n_batches, FMX_ERR_INVALID, "batch %lld out of range", (long long)batch);
+  const int64_t t0 = m->step_first_tile[(size_t)batch], t1 = m->step_first_tile[(size_t)batch + 1];
+  FMX_CHECK(t1 - t0 == 1 && m->plans[(size_t)t0].feat, FMX_ERR_STATE, "step %lld is not one sparse tile", (long long)batch);
+  FMX_TRY(ensure_owner_plan(e, m, t0));
+  const auto& pl = m->plans[(size_t)t0];
+  if (counts) for (int o = 0; o < e->owner_parts; ++o) counts[o] = pl.own_counts_h[o];
+  if (dev_ids) *dev_ids = pl.own_ids;
+  return FMX_OK;
+}
+
+int fmx_rows_pack(fmx_engine* e, const void* dev_ids_u32, int64_t n, void* dev_rows, int64_t* row_elems) {
+  FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "fmx_rows_pack needs a mini-batch engine");
+  FMX_CHECK(n >= 0 && (n == 0 || (dev_ids_u32 && dev_rows)), FMX_ERR_INVALID, "bad argument");
+  FMX_TRY(use_device(e->cfg.device));
+  if (row_elems) *row_elems = mb_kp(e) + 4;
+  return rows_pack(e, (const uint32_t*)dev_ids_u32, n, dev_rows, false);
+}
+
+int fmx_rows_unpack(fmx_engine* e, const void* dev_ids_u32, int64_t n, const void* dev_rows) {
+  FMX_CHECK(e != nullptr && !seq_mode(e), FMX_ERR_STATE, "fmx_rows_unpack needs a mini-batch engine");
+  FMX_CHECK(!group_outside(e), FMX_ERR_STATE, "this handle drives %d GPUs (cfg.n_gpus): train it with fmx_train", e->cfg.n_gpus);
+  FMX_CHECK(n >= 0 && (n == 0 || (dev_ids_u32 && dev_rows)), FMX_ERR_INVALID, "bad argument");
+  FMX_TRY(use_device(e->cfg.device));
+  return rows_pack(e, (const uint32_t*)dev_ids_u32, n, const_cast<void*>(dev_rows), true);
 }
 
 int fmx_sync(fmx_engine* e) {

@@ -77,6 +77,7 @@ enum Scalar : int {
 };
 
 constexpr int WG_THREADS = 256;
+constexpr int OWNERS_MAX = 16;       // ranks of the owner-sharded exchange (one node: 8)
 constexpr int STAGE_ENTRIES = 2048;  // (id, x) pairs staged in LDS per chunk: 16 KiB
 
 inline int pad_factor(int k, int vec) {
@@ -136,6 +137,15 @@ struct fmx_matrix {
     uint32_t* dcounts = nullptr;   // device copy of {n_lists, n_long, n_seg} as the builder wrote them
     void* pool = nullptr;          // one allocation behind all the arrays above
     int off_in_pool = 0;           // the dense directory is the tile's primary one (part of pool); 0 with off != null: added on demand
+    // owner-sharded exchange (sparse tiles): the tile's lists in OWNER-MAJOR order, owner of feature j = j mod own_n, ids ascending
+    // inside an owner's segment (a stable partition of the ascending directory).  Built by plan_owner_build.
+    int own_n = 0;                 // owners the permutation was built for (0: not built)
+    uint32_t* own_pos = nullptr;   // [n_lists] record slot of list i (its position in owner-major order)
+    uint32_t* own_ids = nullptr;   // [n_lists] feature ids in owner-major order: segment o holds the ids this rank asks owner o for
+    uint32_t* own_counts = nullptr;// device [OWNERS_MAX + 1] lists per owner (the last slot: the sentinel padding)
+    int64_t own_counts_h[17] = {0};// the same on the host once read back
+    void* own_pool = nullptr;      // one allocation behind the three arrays
+    uint32_t own_cap = 0;          // lists the arrays have room for
   };
   std::vector<TilePlan> plans;   // [n_tiles]
   uint64_t value_generation = 0; // bumped when the stored values change (scales / normalize): cached copies elsewhere are stale
@@ -238,6 +248,8 @@ struct fmx_engine {
   void* ctail = nullptr;      // [4] {sum mult, sum mult^2, rows hi, rows lo}
   uint32_t* crec_count = nullptr;  // device: records written by the last fmx_grad_compact (points into the tile plan)
   int64_t crec_n = 0;              // the same count on the host (the plan builder read it back)
+  int owner_parts = 0;             // > 1: fmx_grad_compact writes its records owner-major for this many owners (fmx_owner_configure)
+  int owner_rank = 0;
   fmx::MergeWs* merge = nullptr;   // scratch of fmx_apply_compact
   void* als_qe_new = nullptr;      // second (q, e) array of the approximate ALS sweep
   int64_t als_qe_new_rows = 0;
@@ -350,6 +362,7 @@ struct ColsArgs {
   uint32_t f0, f1;       // dense walk over the features [f0, f1) only (f1 == 0: all p): one chunk of the chunked exchange
   int64_t s_row0;        // row of the S / multiplier workspace where this tile's rows start (0 unless a whole step is resident)
   int store_compact;     // compact exchange: write one record per occurring feature (sparse walk only)
+  const uint32_t* rec_pos; // ... at slot rec_pos[list] instead of slot `list` (owner-major records), or null
   int compact_tail;      // the scalar tail is the compact exchange's own 4 elements, not the end of the dense buffer
   int unit;              // every value of the tile is 1.0f: bval is not read
   int direct;            // set by the launcher: every group reads its list's entries itself (sparse tiles), no LDS staging
@@ -416,6 +429,24 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
                uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len);
 void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h);
 int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream);
+// scratch of the owner partition (a 4-bit radix sort of the directory), grow-only
+struct OwnerWorkspace {
+  uint32_t cap = 0;
+  uint32_t *keys_in = nullptr, *keys_out = nullptr, *idx_in = nullptr, *idx_out = nullptr;
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+  int reserve(uint32_t n, hipStream_t stream);
+  OwnerWorkspace() = default;
+  OwnerWorkspace(const OwnerWorkspace&) = delete;
+  OwnerWorkspace& operator=(const OwnerWorkspace&) = delete;
+  ~OwnerWorkspace();
+};
+// Owner-major order of tile t's sparse directory for n_owners owners; n_sort lists are sorted (the host's n_lists, or the
+// directory's capacity while the count is still on the device: slots beyond dcounts[0] sort last).  Enqueues only.
+int plan_owner_alloc(fmx_matrix::TilePlan& t, uint32_t cap_lists);
+int plan_owner_build(fmx_matrix::TilePlan& t, OwnerWorkspace& ws, int n_owners, uint32_t n_sort, hipStream_t stream);
+// rows (V row | w | 0 0 0) of the listed features <-> a packed buffer [n][kp + 4] in the state's element type
+int rows_pack(fmx_engine* e, const uint32_t* d_ids, int64_t n, void* d_rows, bool unpack);
 void drop_plans(fmx_matrix* m);
 int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream);
 void debug_fail_next_plan_build();
@@ -455,6 +486,9 @@ int group_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* 
 bool group_outside(const fmx_engine* e);  // a cfg.n_gpus > 1 handle called from outside fmx_train
 int group_load(fmx_engine* e, const char* path);
 int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
+int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
+                       int64_t* examples_done, double* ingest_wait_s);
+void free_matrix(fmx_matrix* m);
 int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch);
 int group_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows);
 int group_rccl_selftest(int n, double* max_err);

@@ -129,6 +129,45 @@ class Matrix:
             pass
 
 
+class Source:
+    """fmx_source: generated rows handed out one step at a time (each a Matrix of one batch, owned by the source)."""
+
+    def __init__(self, engine, total_rows, nnz_per_row=0, seed=0, row_offset=0, fields=None):
+        spec = None
+        if fields is not None:
+            spec, self._keep = fields_spec(fields[0], fields[1], fields[2], seed)
+        self.h = C.c_void_p()
+        L.check(L.lib().fmx_source_open(engine.h, C.byref(spec) if spec is not None else None, C.c_int32(nnz_per_row), C.c_uint64(seed), C.c_int64(row_offset),
+                                        C.c_int64(total_rows), C.byref(self.h)))
+        self.batch_rows = int(engine.cfg.batch_rows)
+        self.steps = -(-int(total_rows) // self.batch_rows)
+
+    def next(self):
+        """the next step's Matrix (a borrowed handle: never close it) or None at the end"""
+        mh, rows = C.c_void_p(), C.c_int64()
+        L.check(L.lib().fmx_source_next(self.h, C.byref(mh), C.byref(rows)))
+        if not mh.value:
+            return None
+        m = Matrix._wrap(mh)
+        m.close = lambda: None   # owned by the source
+        m.__dict__["_borrowed"] = True
+        return m
+
+    def close(self):
+        """waits for the engine's stream; returns the host seconds spent waiting for tiles' counts"""
+        wait = C.c_double()
+        if self.h:
+            L.check(L.lib().fmx_source_close(self.h, C.byref(wait)))
+            self.h = None
+        return wait.value
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def measure_gather(table_bytes, row_bytes, n_groups=262_144, per_group=32, in_flight=4, reps=30, device=0):
     """rows/s the memory system serves for uniformly random rows of `row_bytes` from a `table_bytes` table (fmx_measure_gather)."""
     out = C.c_double()
@@ -151,6 +190,13 @@ class Engine:
         self.k = int(cfg.num_factor)
         self.h = C.c_void_p()
         L.check(L.lib().fmx_engine_create(C.byref(cfg), C.c_uint64(self.p), C.byref(self.h)))
+
+    def k_padded(self):
+        """padded factor count of the mini-batch tables (4 * 2^m floats, or 2 * 2^m doubles with state_fp64)"""
+        kp = 2 if self.cfg.state_fp64 else 4
+        while kp < self.k:
+            kp *= 2
+        return kp
 
     def set_params(self, w0=0.0, w=None, v=None):
         """v: (k, p) array as R holds it (k x p matrix); stored column-major for the ABI."""
@@ -310,6 +356,35 @@ class Engine:
 
     def apply(self, global_rows):
         L.check(L.lib().fmx_apply(self.h, C.c_int64(global_rows)))
+
+    def apply_compact_parts(self, dev_records, counts, starts, global_rows=0):
+        """parts at explicit record positions (what an uneven all-to-all leaves): fmx_apply_compact_parts"""
+        counts = np.ascontiguousarray(counts, np.int64); starts = np.ascontiguousarray(starts, np.int64)
+        L.check(L.lib().fmx_apply_compact_parts(self.h, C.c_void_p(dev_records), _p(counts), _p(starts), C.c_int32(len(counts)), C.c_int64(global_rows)))
+
+    # owner-sharded exchange (include/fmx.h: feature j belongs to rank j mod N)
+    def owner_configure(self, n_owners, rank):
+        L.check(L.lib().fmx_owner_configure(self.h, C.c_int32(n_owners), C.c_int32(rank)))
+        self._owners = n_owners
+
+    def owner_info(self, m, batch=0):
+        """(counts[n_owners], device pointer of the step's ids in owner-major order)"""
+        counts = np.zeros(self._owners, np.int64)
+        ids = C.c_void_p()
+        L.check(L.lib().fmx_owner_info(self.h, m.h, C.c_int64(batch), _p(counts), C.byref(ids)))
+        return counts, ids.value
+
+    def rows_pack(self, dev_ids, n, dev_rows):
+        re = C.c_int64()
+        L.check(L.lib().fmx_rows_pack(self.h, C.c_void_p(dev_ids), C.c_int64(n), C.c_void_p(dev_rows), C.byref(re)))
+        return re.value
+
+    def rows_unpack(self, dev_ids, n, dev_rows):
+        L.check(L.lib().fmx_rows_unpack(self.h, C.c_void_p(dev_ids), C.c_int64(n), C.c_void_p(dev_rows)))
+
+    def source(self, total_rows, nnz_per_row=0, seed=0, row_offset=0, fields=None):
+        """A streamed source of steps over generated rows (fmx_source_open): iterate with Source.next()."""
+        return Source(self, total_rows, nnz_per_row, seed, row_offset, fields)
 
     def sync(self):
         L.check(L.lib().fmx_sync(self.h))

@@ -223,12 +223,28 @@ int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t 
 
 /* Streamed training (BASELINE.json configs[3]: 4e9 rows x 33 M features do not fit the reference's uint32 offsets,
  * util/Smatrix.h:10-17, nor any memory): the rows [row_offset, row_offset + total_rows) of a synthetic stream are produced
- * step by step -- batch_rows rows are generated, their inverted index is built ON A SECOND STREAM while the previous step
- * trains, each step is trained on once and dropped.  spec == NULL: the uniform generator of fmx_matrix_synthetic with
- * nnz_per_row entries; otherwise the Criteo-shaped one (nnz_per_row ignored).  Needs batch_rows <= the tile size (one tile per
- * step).  ingest_wait_s (may be NULL): host seconds spent waiting for a tile's index, i.e. what the overlap did not hide. */
+ * step by step -- batch_rows rows are generated and their inverted index is built two steps ahead of the step that trains on
+ * them (behind it on the engine's stream: measured faster than a second stream beside it); each step is trained
+ * on once and dropped.  spec == NULL: the uniform generator of fmx_matrix_synthetic with nnz_per_row entries; otherwise the
+ * Criteo-shaped one (nnz_per_row ignored).  Needs batch_rows <= the tile size (one tile per step).  ingest_wait_s (may be
+ * NULL): host seconds spent waiting for a tile's counts.  On a cfg.n_gpus > 1 handle replica r streams rows
+ * [r T / N, (r + 1) T / N) of the range on its own device and the replicas exchange per step (records of the occurring features
+ * for sparse tiles, the dense buffer otherwise). */
 int fmx_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset,
                      int64_t total_rows, int64_t* examples_done, double* ingest_wait_s);
+
+/* The same stream step by step, for a driver that exchanges between the gradient sums and the update of every step (one process
+ * per GPU: fmwr_amd/distributed.py; rank r opens rows [r T / N, (r + 1) T / N) -- the generators are keyed by the global row id).
+ *   fmx_source_open   generates and plans the first two steps (enqueued on the engine's stream)
+ *   fmx_source_next   hands out the next step as a matrix of ONE batch (step index 0 for fmx_step / fmx_grad / fmx_grad_compact /
+ *                     fmx_owner_info ...), valid until the call after the next one; waits (host) only for that tile's counts, and
+ *                     enqueues the generation and planning of the step after the next.  *step_matrix == NULL at the end.
+ *   fmx_source_close  waits for the engine's stream and frees the stream; ingest_wait_s as above. */
+typedef struct fmx_source fmx_source;
+int fmx_source_open(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
+                    fmx_source** out);
+int fmx_source_next(fmx_source* s, fmx_matrix** step_matrix, int64_t* rows);
+int fmx_source_close(fmx_source* s, double* ingest_wait_s);
 
 /* ---- tracker (core/Tracker.h, the evaluation blocks of solver/SGD_Learner.h:140-176 and FTRL_Learner.h:118-154) */
 
@@ -312,6 +328,33 @@ int fmx_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows_l
 int fmx_compact_records(fmx_engine* e, void** dev_records, int64_t* n_records, void** dev_tail);
 int fmx_apply_compact(fmx_engine* e, const void* dev_records, const int64_t* counts, int32_t n_parts, int64_t stride_records,
                       int64_t global_rows);
+/* The parts of fmx_apply_compact at explicit positions: part r holds counts[r] records starting at record starts[r] of the buffer
+ * (what an all-to-all with uneven splits leaves behind). */
+int fmx_apply_compact_parts(fmx_engine* e, const void* dev_records, const int64_t* counts, const int64_t* starts, int32_t n_parts,
+                            int64_t global_rows);
+
+/* ---- owner-sharded exchange (SURVEY 8(e) option (ii), BASELINE.json configs[3] on N GPUs).  Feature j BELONGS to rank j mod N: the
+ * owner holds its current (V row, w) and its optimizer state; the other ranks hold copies that are refreshed when a step needs
+ * them.  Per step, on every rank (the collectives are the driver's: fmwr_amd/distributed.py):
+ *     ids    = the step's occurring features in owner-major order, counts[o] of them owned by rank o     (fmx_owner_info)
+ *     pull   : all-to-all of the ids to their owners; an owner packs the rows asked for (fmx_rows_pack), all-to-all back,
+ *              the asking rank stores them (fmx_rows_unpack): every row the step reads is the owner's current one
+ *     sums   : fmx_grad_compact -- with fmx_owner_configure(N > 1) its records come out in the same owner-major order, so the
+ *              part for owner o is one contiguous slice
+ *     push   : all-to-all of the record slices to their owners (+ all-reduce of the 4-element tail)
+ *     update : fmx_apply_compact_parts on the received parts: a feature's parts are added in rank order and the update is applied
+ *              once, by its owner.
+ * Per rank and step this moves about 2 x (N-1)/N x records instead of the all-gather's N x records, and equals it bit for bit
+ * (the same additions in the same order).  w0 and the other scalars stay replicated (the tail is all-reduced).  After training,
+ * a rank's copy of a feature it does not own is as old as the last step of its own that used it. */
+int fmx_owner_configure(fmx_engine* e, int32_t n_owners, int32_t rank);
+/* counts: i64[n_owners] records of step `batch` per owner; *dev_ids: u32[sum(counts)] the ids in owner-major order (device; valid
+ * until the matrix's plans change, for a streamed step until the call after the next fmx_source_next) */
+int fmx_owner_info(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t* counts, void** dev_ids);
+/* (V row | w 0 0 0) of n features in the state's element type: row_elems = kp + 4 elements per feature (device buffers) */
+int fmx_rows_pack(fmx_engine* e, const void* dev_ids_u32, int64_t n, void* dev_rows, int64_t* row_elems);
+int fmx_rows_unpack(fmx_engine* e, const void* dev_ids_u32, int64_t n, const void* dev_rows);
+
 int fmx_sync(fmx_engine* e);
 /* the hipStream_t the engine launches on (as void*), so a caller can order its own work after it */
 int fmx_stream(fmx_engine* e, void** stream);

@@ -147,6 +147,8 @@ class OracleStepper:
     def grad_compact(self, batch, rows_limit=0):
         acc, rows = self._sums(batch)
         ids = np.flatnonzero(acc["cw"]).astype(np.uint32)
+        if getattr(self, "world", 1) > 1:
+            ids = ids[np.argsort(ids % self.world, kind="stable")]   # owner-major records
         r = self.rec.numpy()
         q = K if self.lay.has_q else 0
         r[:len(ids), :K] = acc["Gv"].reshape(K, P_FEAT).T[ids]
@@ -189,15 +191,99 @@ class OracleStepper:
         (oracle.sgd_apply_sums if self.solver == "sgd" else oracle.ftrl_apply_sums)(self.P, P_FEAT, self.st, b[2] * 4096.0 + b[3], full)
 
 
+    # owner-sharded exchange (include/fmx.h): feature j belongs to rank j mod N; records and ids travel in owner-major order (a stable
+    # partition of the ascending ids), rows come back in the STATE's type (fp64 here, like the oracle's state)
+    m = object()   # "a resident matrix": the per-step counts are known up front
+
+    def num_batches(self):
+        return -(-(self.r1 - self.r0) // B_LOCAL)
+
+    def owner_configure(self, world, rank):
+        self.world, self.rank = world, rank
+
+    def owner_usable(self):
+        return self.compact_usable()
+
+    def _owner_order(self, batch):
+        ids = np.flatnonzero(self._sums(batch)[0]["cw"]).astype(np.uint32)
+        order = np.argsort(ids % self.world, kind="stable")
+        return ids, order
+
+    def owner_counts(self, batch):
+        ids, _ = self._owner_order(batch)
+        return np.bincount(ids % self.world, minlength=self.world).astype(np.int64)
+
+    def owner_ids(self, batch, n):
+        ids, order = self._owner_order(batch)
+        assert n == len(ids)
+        return torch.from_numpy(ids[order].astype(np.int32))
+
+    def state_dtype(self):
+        return torch.float64
+
+    def ids_buffer(self, n):
+        return torch.zeros(n, dtype=torch.int32)
+
+    def rows_buffer(self, which, n):
+        return torch.zeros(n, K + 4, dtype=torch.float64)
+
+    def rows_pack(self, ids, out):
+        j = ids.numpy().astype(np.int64)
+        o = out.numpy()
+        o[:, :K] = self.st["v"].reshape(K, P_FEAT)[:, j].T
+        o[:, K] = self.st["w"][j]
+        o[:, K + 1:] = 0.0
+
+    def rows_unpack(self, ids, rows):
+        j = ids.numpy().astype(np.int64)
+        r = rows.numpy()
+        self.st["v"].reshape(K, P_FEAT)[:, j] = r[:, :K].T
+        self.st["w"][j] = r[:, K]
+
+    def records_view(self, n):
+        return self.rec[:n]
+
+    def records_buffer(self, n):
+        return torch.zeros(n, self.rec_elems, dtype=torch.float32)
+
+    def apply_parts(self, recv, counts, starts):
+        """the owner's merge: parts at explicit positions, added in rank order in the buffer's element type"""
+        r = recv.numpy()
+        q = K if self.lay.has_q else 0
+        red = {key: val.astype(np.float32) for key, val in self._empty().items()}
+        for cnt, st0 in zip(counts, starts):
+            blk = r[int(st0):int(st0) + int(cnt)]
+            ids = np.ascontiguousarray(blk[:, K + q + 3]).view(np.uint32)
+            assert np.all(ids % self.world == self.rank) and np.all(np.diff(ids.astype(np.int64)) > 0)
+            red["Gv"][ids] = red["Gv"][ids] + blk[:, :K]
+            if q:
+                red["Qv"][ids] = red["Qv"][ids] + blk[:, K:2 * K]
+                red["Qw"][ids] = red["Qw"][ids] + blk[:, K + q + 1]
+            red["Gw"][ids] = red["Gw"][ids] + blk[:, K + q]
+            red["cw"][ids] = red["cw"][ids] + blk[:, K + q + 2]
+        red = {key: val.astype(np.float64) for key, val in red.items()}
+        b = self.ctail.numpy().astype(np.float64)
+        full = dict(G0=b[0], Q0=b[1], Gw=red["Gw"], cw=red["cw"], Qw=red["Qw"], Gv=red["Gv"].T.ravel().copy(), Qv=red["Qv"].T.ravel().copy())
+        (oracle.sgd_apply_sums if self.solver == "sgd" else oracle.ftrl_apply_sums)(self.P, P_FEAT, self.st, b[2] * 4096.0 + b[3], full)
+
+
 def _worker(rank, world, port, solver, out_dir, chunks, exchange="dense"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fmwr_amd.distributed import DataParallel, shard_rows
     stepper = OracleStepper(solver, shard_rows(N, rank, world), _problem(), chunks)
+    if exchange == "owner":
+        stepper.compact_usable(); stepper.compact_reserve(P_FEAT)
     dp = DataParallel(stepper, exchange=exchange)
     assert dp.exchange == exchange
     for s in range(STEPS):
-        dp.step(s % 4)
+        dp.step(s % (4 if world == 2 else 3))
+    if exchange == "owner":
+        assert len(dp.bytes_sent) == STEPS and all(b > 0 for b in dp.bytes_sent)
+        mine_before = {key: np.array(stepper.st[key]).copy() for key in ("w", "v")}
+        dp.pull_all(P_FEAT)   # refresh the copies of the features other ranks own
+        own = np.arange(rank, P_FEAT, world)
+        assert np.array_equal(mine_before["w"][own], stepper.st["w"][own])   # the owner's rows are never overwritten by anyone else's
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), w0=stepper.st["w0"].value, w=stepper.st["w"], v=stepper.st["v"])
     dist.barrier()
     dist.destroy_process_group()
@@ -219,7 +305,7 @@ def _expected(solver, world):
         acc, rows = None, 0
         for r in range(world):
             r0, r1 = shard_rows(N, r, world)
-            b0 = r0 + (s % 4) * B_LOCAL; b1 = min(b0 + B_LOCAL, r1)
+            b0 = r0 + (s % (4 if world == 2 else 3)) * B_LOCAL; b1 = min(b0 + B_LOCAL, r1)
             acc = oracle.batch_sums(P, X, y, st["w0"].value, st["w"], st["v"], b0, b1, acc)
             rows += b1 - b0
         if solver == "sgd":
@@ -229,14 +315,14 @@ def _expected(solver, world):
     return st
 
 
-def _run(solver, tmp_path, chunks=1, exchange="dense"):
-    world = 2
+def _run(solver, tmp_path, chunks=1, exchange="dense", world=2):
     mp.spawn(_worker, args=(world, _free_port(), solver, str(tmp_path), chunks, exchange), nprocs=world, join=True)
     exp = _expected(solver, world)
     got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     # replicas are bit-identical ...
-    for key in ("w0", "w", "v"):
-        np.testing.assert_array_equal(got[0][key], got[1][key])
+    for r in range(1, world):
+        for key in ("w0", "w", "v"):
+            np.testing.assert_array_equal(got[0][key], got[r][key])
     # ... and equal the single-process result up to the fp32 rounding of the exchanged sums
     assert util.rel_err(got[0]["v"], exp["v"]) < 1e-5
     assert util.rel_err(got[0]["w"], exp["w"]) < 1e-5
@@ -270,6 +356,38 @@ def test_compact_exchange_is_bitwise_the_dense_all_reduce_world2(tmp_path, solve
         a, b = np.load(d / f"rank{r}.npz"), np.load(c / f"rank{r}.npz")
         for key in ("w0", "w", "v"):
             np.testing.assert_array_equal(a[key], b[key])
+
+
+@pytest.mark.parametrize("solver", ["sgd", "ftrl"])
+def test_owner_sharded_exchange_is_bitwise_the_dense_all_reduce_world2(tmp_path, solver):
+    """records routed to the rank that owns the feature (id mod N), the owner adds the parts in rank order and
+    updates its slice, current rows are pulled by whoever reads them next.  With two ranks the additions are those of the dense
+    all-reduce: the same parameters bit for bit (every rank, after a final pull of the rows it does not own)."""
+    d = tmp_path / "dense"; o = tmp_path / "owner"
+    d.mkdir(); o.mkdir()
+    _run(solver, d)
+    _run(solver, o, exchange="owner")
+    for r in range(2):
+        a, b = np.load(d / f"rank{r}.npz"), np.load(o / f"rank{r}.npz")
+        for key in ("w0", "w", "v"):
+            np.testing.assert_array_equal(a[key], b[key])
+
+
+@pytest.mark.parametrize("solver", ["sgd", "ftrl"])
+def test_owner_sharded_exchange_world3_equals_the_all_gather_form(tmp_path, solver):
+    """Three ranks: a feature's parts are added in rank order by its owner, exactly as every replica adds them after the all-gather
+    of records (bitwise).  The dense all-reduce of three ranks adds in the ring's order, which no exchange of records can
+    reproduce bit for bit (fp32 addition does not associate): against it the bar is the fp32 rounding of the sums."""
+    c = tmp_path / "compact"; o = tmp_path / "owner"; d = tmp_path / "dense"
+    c.mkdir(); o.mkdir(); d.mkdir()
+    _run(solver, c, exchange="compact", world=3)
+    _run(solver, o, exchange="owner", world=3)
+    _run(solver, d, world=3)
+    for r in range(3):
+        a, b, dd = np.load(c / f"rank{r}.npz"), np.load(o / f"rank{r}.npz"), np.load(d / f"rank{r}.npz")
+        for key in ("w0", "w", "v"):
+            np.testing.assert_array_equal(a[key], b[key])
+        assert util.rel_err(b["v"], dd["v"]) < 1e-6 and util.rel_err(b["w"], dd["w"]) < 1e-6
 
 
 def test_grad_layout_blocks():

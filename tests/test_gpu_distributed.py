@@ -212,3 +212,140 @@ def test_the_rccl_backend_itself_runs_the_exchange_world1(tmp_path, mode):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                         "--master-port", "29519", str(script), ROOT, mode], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "bitwise" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])
+
+
+OWNER_WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from fmwr_amd import _lib as L, engine
+from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows, train_stream
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+solver, out, wide, reduce, mode = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], sys.argv[6]
+kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD if solver.startswith("sgd") else L.SOLVER_FTRL, learn_rate=0.05,
+          l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver != "sgd" else 0.0, l1_w1=1e-4 if solver == "sgd_l1" else 0.0,
+          mode=L.MODE_MINIBATCH, state_fp64=wide, batch_reduce=L.REDUCE_MEAN if reduce == "mean" else L.REDUCE_SUM)
+res = {}
+if mode == "resident":
+    # far more features than entries per step (BASELINE.json configs[3]'s regime): every tile is sparse; heavy hitters (long lists)
+    n, p, z, k, B = 24000, 300000, 12, 8, 3000
+    r0, r1 = shard_rows(n, rank, world)
+    rng = np.random.default_rng(100 + rank)
+    rows = []
+    for r in range(r1 - r0):
+        hot = [j for j, q in ((5, 0.9), (70000, 0.4), (70001, 0.3)) if rng.random() < q]
+        rows.append(np.unique(np.concatenate([hot, rng.integers(0, 4000, 3), rng.integers(4000, p, z - 3)])).astype(np.uint32))
+    rp = np.zeros(len(rows) + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows); val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = np.where(rng.random(len(rows)) < 0.5, -1.0, 1.0).astype(np.float32)
+    v0 = np.random.default_rng(1).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+    for exchange in ("dense", "compact", "owner"):
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        e = engine.Engine(p, num_factor=k, batch_rows=B // world, **kw)
+        e.set_params(0.0, None, v0)
+        dp = DataParallel(EngineStepper(e, m, 0, dense=(exchange == "dense")), exchange=exchange)
+        assert dp.exchange == exchange, dp.exchange
+        nb = e.num_batches(m)
+        moved = 0
+        for s in range(7):
+            dp.step(s % nb, rows_limit=(B // world - 100) if s == 3 else 0)   # one truncated step
+            moved += dp.last_exchange_bytes
+        if exchange == "owner":
+            dp.pull_all(p)          # refresh the copies of the rows other ranks own
+        e.sync()
+        res[exchange] = e.get_params() + (moved,)
+else:
+    # streamed steps (fmx_source): Criteo-shaped fields, every rank its own row range of the stream
+    vocab = [60000, 30000, 9000, 700, 40, 5]
+    p, k, B, steps = 6 + sum(vocab), 8, 2048, 5
+    total = steps * B * world - 300              # the last global step is ragged
+    r0, r1 = shard_rows(total, rank, world)
+    for exchange in ("compact", "owner"):
+        e = engine.Engine(p, num_factor=k, batch_rows=B, **kw)
+        e.init_normal(11, 0.0, 0.05)
+        dp = DataParallel(EngineStepper(e, None, 0, dense=False), exchange=exchange)
+        src = e.source(r1 - r0, seed=3, row_offset=r0, fields=(6, vocab, 2.0))
+        done = train_stream(dp, src)
+        assert done == r1 - r0
+        src.close()
+        if exchange == "owner":
+            dp.pull_all(p)
+        e.sync()
+        res[exchange] = e.get_params() + (sum(dp.bytes_sent) if exchange == "owner" else 0,)
+    res["dense"] = res["compact"]
+a, c, o = res["dense"], res["compact"], res["owner"]
+same = lambda x, y: x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+assert same(c, o), "owner-sharded exchange differs from the all-gather of records"
+if world == 2:
+    assert same(a, o), "owner-sharded exchange differs from the dense all-reduce"
+if rank == 0:
+    np.savez(out, w0=o[0], w=o[1], v=o[2], dense_bytes=a[3], compact_bytes=c[3], owner_bytes=o[3])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,solver,wide,reduce,mode", [
+    (2, "sgd", 0, "mean", "resident"), (2, "sgd_l1", 0, "sum", "resident"), (2, "ftrl", 0, "sum", "resident"), (2, "ftrl", 1, "mean", "resident"),
+    (3, "sgd", 0, "mean", "resident"), (3, "ftrl", 0, "sum", "resident"),
+    (2, "sgd", 0, "mean", "stream"), (3, "ftrl", 0, "sum", "stream")])
+def test_owner_sharded_exchange_on_the_gpu(tmp_path, world, solver, wide, reduce, mode):
+    """SURVEY 8(e)(ii) / VERDICT r2 items 1-2: records routed to the rank that owns the feature (id mod N), the owner adds a
+    feature's parts in rank order and applies the update to ITS slice, the rows a step reads are pulled from their owners first.
+    Ranks on one GPU through gloo.  Bitwise the all-gather form for any N (the same additions in the same order) and bitwise the dense
+    all-reduce for N = 2 (asserted inside the workers; heavy hitters, a truncated step, three solvers, fp64 state).  mode = stream:
+    every step is a streamed tile (fmx_source) of the rank's own row range -- configs[3] as one N-GPU job."""
+    script = tmp_path / "worker.py"
+    script.write_text(OWNER_WORKER)
+    out = tmp_path / "dp.npz"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", "29521", str(script), ROOT, solver, str(out), str(wide), reduce, mode], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = np.load(out)
+    assert np.all(np.isfinite(got["v"])) and got["owner_bytes"] > 0
+    if mode == "resident":
+        assert got["owner_bytes"] < got["compact_bytes"] or world == 2   # 2 x (N-1)/N x records against N x records
+
+
+def test_streamed_training_with_n_gpus_behind_one_handle(tmp_path):
+    """fmx_train_stream on a cfg.n_gpus = 2 handle (replicas on one device): replica r streams its own half of the row range, the
+    replicas exchange the occurring features' records per step; equal to the dense form bit for bit, and to ONE engine that
+    trains on the interleaved global batches to fp32 rounding."""
+    from fmwr_amd import _lib as L, engine
+    vocab = [50000, 20000, 5000, 300, 20]
+    p, k, B, steps = 4 + sum(vocab), 8, 1024, 4
+    total = steps * B * 2
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH)
+    res = {}
+    for form in ("compact", "dense"):
+        os.environ["FMX_GROUP_EXCHANGE"] = form
+        try:
+            g = engine.Engine(p, batch_rows=B, n_gpus=2, gpus_share_device=1, **kw)
+            g.init_normal(5, 0.0, 0.05)
+            done, _ = g.train_stream(total, seed=9, fields=(4, vocab, 2.0))
+            assert done == total
+            res[form] = g.get_params()
+        finally:
+            os.environ.pop("FMX_GROUP_EXCHANGE", None)
+    a, b = res["compact"], res["dense"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    # one engine on the interleaved global batches: global step s = rows of replica 0's step s, then replica 1's
+    halves = [engine.Matrix.synthetic_fields(total // 2, 4, vocab, 2.0, 9, row_offset=r * (total // 2)) for r in range(2)]
+    parts = [h.export() for h in halves]
+    rp = [0]; col = []; val = []; y = []
+    for s in range(steps):
+        for (rpi, ci, vi, yi) in parts:
+            lo, hi = s * B, (s + 1) * B
+            col.append(ci[rpi[lo]:rpi[hi]]); val.append(vi[rpi[lo]:rpi[hi]]); y.append(yi[lo:hi])
+            rp.extend((rpi[lo + 1:hi + 1] - rpi[lo] + rp[-1]).tolist())
+    one = engine.Matrix.from_csr(np.array(rp, np.int64), np.concatenate(col), np.concatenate(val), p, np.concatenate(y))
+    e = engine.Engine(p, batch_rows=2 * B, **kw)
+    e.init_normal(5, 0.0, 0.05)
+    for s in range(steps):
+        e.step(one, s)
+    e.sync()
+    c = e.get_params()
+    from tests import util
+    assert util.rel_err(a[2], c[2]) < 1e-5 and util.rel_err(a[1], c[1]) < 1e-5 and abs(a[0] - c[0]) < 1e-5
