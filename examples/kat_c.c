@@ -54,5 +54,46 @@ int main(void) {
   for (int i = 0; i < N; ++i) printf("p%d %.17g\n", i, prob[i]);
   CHECK(fmx_matrix_destroy(m));
   CHECK(fmx_engine_destroy(e));
+
+  /* The multi-GPU entry from C: cfg.n_gpus = 2 (what options("FM.threads") = 2 becomes, src/FM.cpp:59,97) with both replicas on
+   * one device (gpus_share_device: a one-GPU box).  fmx_train cuts the 6 rows into two shards of 3; a global step is 2 rows of
+   * each shard.  The same steps on ONE engine are the rows in the order 0 1 3 4 | 2 5 with 4 rows per step. */
+  {
+    fmx_config g;
+    CHECK(fmx_config_default(&g));
+    g.task = FMX_TASK_CLASSIFICATION; g.solver = FMX_SOLVER_SGD; g.num_factor = K;
+    g.l2_w1 = 0.01; g.l2_v = 0.02; g.learn_rate = 0.05;
+    g.mode = FMX_MODE_MINIBATCH; g.state_fp64 = 1; g.min_target = -1.0; g.max_target = 1.0;
+    const int perm[N] = {0, 1, 3, 4, 2, 5};
+    double value2[12], labels2[N]; int32_t col2[12], size2[N];
+    int start[N], at = 0;
+    for (int i = 0, t = 0; i < N; ++i) { start[i] = t; t += row_size[i]; }
+    for (int i = 0; i < N; ++i) {
+      const int r = perm[i];
+      size2[i] = row_size[r]; labels2[i] = labels[r];
+      for (int q = 0; q < row_size[r]; ++q, ++at) { value2[at] = value[start[r] + q]; col2[at] = col_idx[start[r] + q]; }
+    }
+    for (int form = 0; form < 2; ++form) {
+      fmx_config cc = g;
+      cc.n_gpus = form == 0 ? 2 : 1; cc.gpus_share_device = form == 0 ? 1 : 0;
+      cc.batch_rows = form == 0 ? 2 : 4;                     /* rows per step PER GPU */
+      fmx_engine* ge = NULL; fmx_matrix* gm = NULL;
+      CHECK(fmx_engine_create(&cc, P, &ge));
+      if (form == 0) CHECK(fmx_matrix_from_rlist(0, N, P, 12, value, col_idx, row_size, labels, &gm));
+      else CHECK(fmx_matrix_from_rlist(0, N, P, 12, value2, col2, size2, labels2, &gm));
+      double zero[P] = {0};
+      CHECK(fmx_set_params(ge, 0.0, zero, v_kxp));
+      int64_t gdone = 0;
+      CHECK(fmx_train(ge, gm, 18, &gdone));                  /* three passes */
+      double gw0 = 0.0, gw[P], gv[K * P];
+      CHECK(fmx_get_params(ge, &gw0, gw, gv));
+      printf("g%d_examples %lld\ng%d_w0 %.17g\n", cc.n_gpus, (long long)gdone, cc.n_gpus, gw0);
+      for (int j = 0; j < P; ++j) printf("g%d_lin%d %.17g\n", cc.n_gpus, j, gw[j]);
+      for (int j = 0; j < K * P; ++j) printf("g%d_v%d %.17g\n", cc.n_gpus, j, gv[j]);
+      if (form == 0 && fmx_step(ge, gm, 0, 0) == FMX_OK) { fprintf(stderr, "fmx_step on an n_gpus = 2 handle must be refused\n"); return 1; }
+      CHECK(fmx_matrix_destroy(gm));
+      CHECK(fmx_engine_destroy(ge));
+    }
+  }
   return 0;
 }

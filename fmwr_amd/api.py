@@ -285,9 +285,12 @@ def fm_train(data, normalize=True, control=None, seed=None, mode="sequential", b
     return _train(data, controls, 0.0, np.zeros(p), v0, None, mode, batch_rows, device, norm_cols, rng=rng)
 
 
-def fm_update(object, data, normalize=True, max_iter=None, mode=None, batch_rows=None, device=None):
+def fm_update(object, data, normalize=True, max_iter=None, mode=None, batch_rows=None, device=None, rng=None):
     """fm.update() -- R/fm_update.R:18-135: continue training from a fitted FM with the controls stored on it.
-    Optimizer state (FTRL z/n, SGD q/u) is NOT carried over, exactly as in the reference."""
+    Optimizer state (FTRL z/n, SGD q/u) is NOT carried over, exactly as in the reference.
+    rng: a numpy Generator standing in for R's global stream.  The reference calls fm.init() -- k*p normal draws -- BEFORE the
+    warm start overwrites them (src/FM.cpp:64 precedes :66-72), so an update consumes k*p normals too: they are drawn from
+    `rng` and discarded here, which leaves the stream where the reference leaves it (examples/FM_glue.cpp does the same in R)."""
     if not isinstance(object, dict) or object.get("class") != "FM":
         raise TypeError("object must be a FM object")
     if not isinstance(data, FmMatrix):
@@ -318,9 +321,12 @@ def fm_update(object, data, normalize=True, max_iter=None, mode=None, batch_rows
     if max_iter is not None:
         controls["solver"]["max_iter"] = int(max_iter)
     eng = object.get("engine", {})
+    if rng is not None:
+        hp = controls["model"]["hyper.params"]
+        rng.normal(hp["v.init_mean"], hp["v.init_stdev"], (int(hp["factor.number"]), p))   # Model::init's draws, discarded (src/FM.cpp:64)
     fit = _train(data, controls, mdl["w0"], mdl["w"], mdl["v"], object["Scales"]["target.range"],
                  mode or eng.get("mode", "sequential"), batch_rows or eng.get("batch_rows", 65536),
-                 eng.get("device", 0) if device is None else device, norm_cols)
+                 eng.get("device", 0) if device is None else device, norm_cols, **({"rng": rng} if rng is not None else {}))
     if object.get("Trace") is not None and fit.get("Trace") is not None:  # R/fm_update.R:125-133: traces are concatenated
         old, new = object["Trace"], fit["Trace"]
         idx = np.concatenate([np.asarray(old["trace"][0]), np.asarray(new["trace"][0]) + np.asarray(old["trace"][0])[-1]])

@@ -1319,6 +1319,9 @@ int fmx_source_next(fmx_source* S, fmx_matrix** step_matrix, int64_t* rows) {
   clock_gettime(CLOCK_MONOTONIC, &t1);
   S->waited += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   auto& pl = s.m->plans[0];
+  // a dense directory added on demand for the slot's PREVIOUS tile (a launch that walked the dense exchange buffer) describes that
+  // tile, not this one: drop it, plan_ensure_dense makes the new one if a launch asks again
+  if (pl.off && !pl.off_in_pool) { (void)hipFree(pl.off); pl.off = nullptr; }
   plan_set_counts(pl, (uint32_t)S->p, s.h_counts);
   if (pl.own_n > 0) for (int o = 0; o <= OWNERS_MAX; ++o) pl.own_counts_h[o] = s.h_counts[4 + o];
   s.m->max_long_seg = pl.n_seg;

@@ -43,3 +43,9 @@ def test_c_caller_reproduces_the_reference_known_answers(tmp_path):
     assert abs(float(out["ll"]) - kat.SGD_LL[-1]) < 5e-10
     prob = np.array([float(out["p%d" % i]) for i in range(6)])
     assert np.all((prob > 0) & (prob < 1))
+    # the multi-GPU entry from C: n_gpus = 2 (both replicas on this device) equals one engine on the interleaved global batches
+    assert int(out["g2_examples"]) == 18 and int(out["g1_examples"]) == 18
+    keys = ["w0"] + ["lin%d" % j for j in range(5)] + ["v%d" % j for j in range(15)]
+    a = np.array([float(out["g2_" + key]) for key in keys]); b = np.array([float(out["g1_" + key]) for key in keys])
+    assert np.max(np.abs(a - b)) < 1e-12
+    assert np.any(a[1:6] != 0.0)
