@@ -86,7 +86,7 @@ def parse():
         if a.steps == 40 and a.warmup == 5:   # the defaults are sized for 0.3 ms steps; a sweep of 16 factors over 3e8 entries is ~0.2 s
             a.steps, a.warmup = 5, 1
         if a.cpu_rows < 0:
-            a.cpu_rows = 200_000
+            a.cpu_rows = 4_000_000   # ~10-20 s of one core
         return a
     if a.batch_rows == 0:
         # SGD, one GPU: 262144 (a coordinate occurs ~8 times per step: learns per example like 4096-row steps at the reference's
@@ -157,6 +157,17 @@ def cpu_baseline(m, args, v0):
     n = min(args.cpu_rows, m.n)
     rp, col, val, y = m.export(0, n)
     X = oracle.Matrix(rp, col, val, args.features)
+    if args.solver in ("als", "mcmc"):   # configs[4]: one reference-order update_v sweep (MCMC_ALS_Learner.h:272-354) over a row sample
+        k, p, gibbs = args.factors, args.features, args.solver == "mcmc"
+        vv = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p))
+        err = np.random.default_rng(args.seed + 1).normal(0.0, 1.0, n)
+        zz = np.random.default_rng(args.seed + 2).normal(0.0, 1.0, k * p) if gibbs else None
+        oracle.lib()
+        t0 = time.perf_counter()
+        oracle.als_update_v(k, X, vv.ravel(), err, alpha=1.0, v_lambda=np.full(k, 1.0) if gibbs else None, znorm=zz)
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "examples/s", "cores": 1, "kind": "port",
+                "sample": f"one reference-order update_v sweep (k = {k}{', Gibbs draws' if gibbs else ''}) over rows 0..{n - 1} of the same matrix ({dt:.1f} s incl. its transpose)"}
     if args.solver == "sgd":
         P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
     else:
@@ -362,19 +373,7 @@ def main_sweep(args, rank, local_rank, world):
                                              "ceiling_frac": got / r if r else None,
                                              "note": "entries per second of als_level_k (each entry: one 16-B gather and one 16-B scatter of its row's (q, e)) over the measured rate of random 16-B gathers"}
     if args.cpu_rows > 0:
-        import oracle
-        rs = min(args.cpu_rows, n)
-        rp, col, val, y = m.export(0, rs)
-        X = oracle.Matrix(rp, col, val, p)
-        v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p))
-        err = np.random.default_rng(args.seed + 1).normal(0.0, 1.0, rs)
-        oracle.lib()
-        zz = np.random.default_rng(args.seed + 2).normal(0.0, 1.0, k * p) if gibbs else None
-        t0 = time.perf_counter()
-        oracle.als_update_v(k, X, v0.ravel(), err, alpha=1.0, v_lambda=lam, znorm=zz)
-        dtc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": rs / dtc, "unit": "examples/s", "cores": 1, "kind": "port",
-                               "sample": f"one reference-order update_v sweep (k = {k}) over rows 0..{rs - 1} of the same matrix ({dtc:.1f} s incl. its transpose)"}
+        out["cpu_baseline"] = cpu_baseline(m, args, None)
     print(json.dumps(out), flush=True)
 
 

@@ -140,13 +140,27 @@ __global__ void als_unpack_k(const double2* __restrict__ qe, int64_t n, double* 
 
 __device__ __forceinline__ bool bad_number(double x) { return isnan(x) || isinf(x); }
 
+// What changes from factor to factor (and from call to call) in a sweep: it lives in device memory and every sweep kernel reads it from
+// there, so that the launches of one factor's sweep are IDENTICAL for every factor and every call -- a deep-level plan (i.i.d.
+// columns: 8 155 dependent launches per factor) is then captured once as a HIP graph and replayed (sweep_graph below).
+struct SweepDyn {
+  int f, pad;
+  double alpha, lambda, mu;
+  const double* znorm;   // this factor's (or w's) standard normals, or null: the ALS mean
+};
+__global__ void als_set_dyn_k(SweepDyn* d, int f, double alpha, double lambda, double mu, const double* znorm) {
+  d->f = f; d->pad = 0; d->alpha = alpha; d->lambda = lambda; d->mu = mu; d->znorm = znorm;
+}
+
 // one wave per feature of the level.  The first ALS_KEEP entries per lane (512 per wave: almost every column) stay in
 // registers between the two passes, so the rank-1 correction pass does not gather q/e again.
 constexpr int ALS_KEEP = 8;
 __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
                                                           const uint32_t* __restrict__ crow, const float* __restrict__ cval,
-                                                          double* __restrict__ V, int kp, int f, double2* __restrict__ qe,
-                                                          double alpha, double lambda, double mu, const double* __restrict__ znorm) {
+                                                          double* __restrict__ V, int kp, const SweepDyn* __restrict__ dyn, double2* __restrict__ qe) {
+  const int f = dyn->f;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6);
   if (wid >= n_feats) return;
@@ -288,8 +302,9 @@ __global__ void als_shift_k(double2* __restrict__ qe, int64_t n, const double* _
 // one wave per feature of the level: w sweep, :208-256 with one thread's residual
 __global__ __launch_bounds__(WG_THREADS) void als_w_level_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
                                                             const uint32_t* __restrict__ crow, const float* __restrict__ cval,
-                                                            double* __restrict__ w, double2* __restrict__ qe, double alpha, double lambda, double mu,
-                                                            const double* __restrict__ znorm) {
+                                                            double* __restrict__ w, double2* __restrict__ qe, const SweepDyn* __restrict__ dyn) {
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6);
   if (wid >= n_feats) return;
@@ -355,8 +370,10 @@ constexpr int ALS_HEAVY = 4096;
 template <bool W, bool APPROX, int T>
 __global__ __launch_bounds__(WG_THREADS) void als_sweep_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr,
                                                           const uint32_t* __restrict__ crow, const float* __restrict__ cval, double* __restrict__ P, int kp,
-                                                          int f, const double2* qe_old, double2* qe_new, double alpha, double lambda, double mu,
-                                                          const double* __restrict__ znorm) {
+                                                          const SweepDyn* __restrict__ dyn, const double2* qe_old, double2* qe_new) {
+  const int f = dyn->f;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
   __shared__ double red[2][WG_THREADS / 64];
   const int tid = threadIdx.x % T;
   const int wid = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) / T);
@@ -450,8 +467,9 @@ template <bool W>
 __global__ __launch_bounds__(WG_THREADS) void als_vh_partial_k(const uint32_t* __restrict__ vh, const uint32_t* __restrict__ seg_feat,
                                                                const int64_t* __restrict__ seg_b, const int64_t* __restrict__ seg_e, int64_t seg0,
                                                                const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
-                                                               const float* __restrict__ cval, const double* __restrict__ P, int kp, int f,
-                                                               const double2* __restrict__ qe, double* __restrict__ partial) {
+                                                               const float* __restrict__ cval, const double* __restrict__ P, int kp,
+                                                               const SweepDyn* __restrict__ dyn, const double2* __restrict__ qe, double* __restrict__ partial) {
+  const int f = dyn->f;
   __shared__ double red[2][WG_THREADS / 64];
   const int64_t sg = seg0 + blockIdx.x;
   const uint32_t i = vh[seg_feat[sg]];
@@ -486,8 +504,10 @@ __global__ __launch_bounds__(WG_THREADS) void als_vh_partial_k(const uint32_t* _
 
 template <bool W>
 __global__ void als_vh_value_k(const uint32_t* __restrict__ vh, const uint32_t* __restrict__ seg_first, int64_t h0, int n, const double* __restrict__ partial,
-                               double* __restrict__ P, int kp, int f, double alpha, double lambda, double mu, const double* __restrict__ znorm,
-                               double* __restrict__ v_old, double* __restrict__ v_diff) {
+                               double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, double* __restrict__ v_old, double* __restrict__ v_diff) {
+  const int f = dyn->f;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   const int64_t hx = h0 + q;
@@ -556,6 +576,7 @@ __global__ void als_maxpos_k(const int64_t* __restrict__ row_ptr, const uint32_t
 
 // the level plan depends on the matrix only: built once, kept in the fmx_matrix
 static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
+  if (m->als_force_exact) max_levels = 0;  // an approximate sweep of this matrix raised the residual once: exact from then on
   if (m->als_feats && m->als_plan_cap == max_levels) return FMX_OK;
   (void)hipFree(m->als_feats); m->als_feats = nullptr;
   (void)hipFree(m->als_heavy); m->als_heavy = nullptr;
@@ -724,11 +745,11 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   return FMX_OK;
 }
 
-// One pass over all features of the plan for the w sweep (W) or factor f of the V sweep: levels (exact) or groups (approximate)
-// in ascending order.  qe_new: second (q, e) array of the approximate form (the merged corrections land there; it is copied
-// over the snapshot after every group), unused by the exact form.
+// One pass over all features of the plan for the w sweep (W) or one factor of the V sweep: levels (exact) or groups (approximate)
+// in ascending order; the factor, alpha, lambda, mu and the normals come from *dyn (device).  qe_new: second (q, e) array of the
+// approximate form (the merged corrections land there; it is copied over the snapshot after every group), unused by the exact form.
 template <bool W>
-static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2* d_qe_new, int f, double alpha, double lambda, double mu, const double* d_znorm) {
+static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2* d_qe_new, const SweepDyn* dyn, bool profile = true) {
   const std::vector<int64_t>& lp = m->als_level_ptr;
   const std::vector<int64_t>& hp = m->als_heavy_ptr;
   const int L = (int)lp.size() - 1;
@@ -741,44 +762,116 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
     const uint32_t* lf = m->als_feats + lp[(size_t)l];
     const uint32_t* hf = m->als_heavy + hp[(size_t)l];
     const dim3 gl((unsigned)((cnt * 64 + WG_THREADS - 1) / WG_THREADS)), gh((unsigned)hcnt), blk(WG_THREADS);
-    prof_begin(e, FMX_KERNEL_ALS_SWEEP);  // one level (or group) of one factor: the unit bench.py --solver als prices
-    struct ProfEnd { fmx_engine* e; ~ProfEnd() { prof_end(e); } } prof_guard{e};
+    struct ProfEnd { fmx_engine* e; bool on; ~ProfEnd() { if (on) prof_end(e); } } prof_guard{e, profile};
+    if (profile) prof_begin(e, FMX_KERNEL_ALS_SWEEP);  // one level (or group) of one factor: the unit bench.py --solver als prices
     if (!m->als_approx) {
       if (cnt > 0) {
-        if (W) hipLaunchKernelGGL(als_w_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dw, d_qe, alpha, lambda, mu, d_znorm);
-        else hipLaunchKernelGGL(als_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dV, e->kp64, f, d_qe, alpha, lambda, mu, d_znorm);
+        if (W) hipLaunchKernelGGL(als_w_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dw, d_qe, dyn);
+        else hipLaunchKernelGGL(als_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dV, e->kp64, dyn, d_qe);
       }
       // (a heavy feature shares rows with nearly everything: it is alone in its level, or with a few other heavy ones)
-      if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
-                                       (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
+      if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, dyn,
+                                       (const double2*)d_qe, d_qe);
       if (vcnt > 0) {  // the very long columns of the level, over many workgroups each
         const int64_t v0 = m->als_vh_ptr[(size_t)l], s0 = m->als_vseg_ptr[(size_t)l], ns = m->als_vseg_ptr[(size_t)l + 1] - s0;
         double* partial = m->als_vh_work;
         double* v_old = m->als_vh_work + 2 * m->als_n_vseg;
         double* v_diff = v_old + m->als_n_vh;
         hipLaunchKernelGGL((als_vh_partial_k<W>), dim3((unsigned)ns), blk, 0, e->stream, m->als_vh, m->als_vseg_feat, m->als_vseg_b, m->als_vseg_e, s0, m->col_ptr,
-                           m->crow, m->cval, (const double*)P, e->kp64, f, (const double2*)d_qe, partial);
+                           m->crow, m->cval, (const double*)P, e->kp64, dyn, (const double2*)d_qe, partial);
         hipLaunchKernelGGL((als_vh_value_k<W>), dim3((unsigned)((vcnt + 63) / 64)), dim3(64), 0, e->stream, m->als_vh, m->als_vh_seg0, v0, (int)vcnt, (const double*)partial, P,
-                           e->kp64, f, alpha, lambda, mu, d_znorm, v_old, v_diff);
+                           e->kp64, dyn, v_old, v_diff);
         hipLaunchKernelGGL((als_vh_apply_k<W>), dim3((unsigned)ns), blk, 0, e->stream, m->als_vh, m->als_vseg_feat, m->als_vseg_b, m->als_vseg_e, s0, m->col_ptr,
                            m->crow, m->cval, (const double*)v_old, (const double*)v_diff, d_qe);
       }
     } else if (cnt + hcnt == 1) {
       // a group of one: its step against "the snapshot" is the exact step -- in place, no merge (the heavy features' pass)
-      if (hcnt) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, 1, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
-                                   (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
-      else hipLaunchKernelGGL((als_sweep_k<W, false, 64>), gl, blk, 0, e->stream, lf, 1, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
-                              (const double2*)d_qe, d_qe, alpha, lambda, mu, d_znorm);
+      if (hcnt) hipLaunchKernelGGL((als_sweep_k<W, false, WG_THREADS>), gh, blk, 0, e->stream, hf, 1, m->col_ptr, m->crow, m->cval, P, e->kp64, dyn,
+                                   (const double2*)d_qe, d_qe);
+      else hipLaunchKernelGGL((als_sweep_k<W, false, 64>), gl, blk, 0, e->stream, lf, 1, m->col_ptr, m->crow, m->cval, P, e->kp64, dyn,
+                              (const double2*)d_qe, d_qe);
       synced = false;
     } else {
       if (!synced) { (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream); synced = true; }
-      if (cnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, 64>), gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
-                                      (const double2*)d_qe, d_qe_new, alpha, lambda, mu, d_znorm);
-      if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, f,
-                                       (const double2*)d_qe, d_qe_new, alpha, lambda, mu, d_znorm);
+      if (cnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, 64>), gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, P, e->kp64, dyn,
+                                      (const double2*)d_qe, d_qe_new);
+      if (hcnt > 0) hipLaunchKernelGGL((als_sweep_k<W, true, WG_THREADS>), gh, blk, 0, e->stream, hf, (int)hcnt, m->col_ptr, m->crow, m->cval, P, e->kp64, dyn,
+                                       (const double2*)d_qe, d_qe_new);
       (void)hipMemcpyAsync(d_qe, d_qe_new, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);  // the next group's snapshot
     }
   }
+}
+
+// the device struct the sweep kernels read their per-factor values from
+static SweepDyn* sweep_dyn(fmx_engine* e) {
+  if (!e->als_dyn && hipMalloc(&e->als_dyn, sizeof(SweepDyn)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return reinterpret_cast<SweepDyn*>(e->als_dyn);
+}
+static void set_dyn(fmx_engine* e, SweepDyn* dyn, int f, double alpha, double lambda, double mu, const double* znorm) {
+  hipLaunchKernelGGL(als_set_dyn_k, dim3(1), dim3(1), 0, e->stream, dyn, f, alpha, lambda, mu, znorm);
+}
+
+// ---- deep plans as a HIP graph ---------------------------------------------------------------------------------------------------
+// An exact plan over i.i.d. columns has thousands of levels of a few hundred features (4 M x 1 M, 30 per row: 8 155 levels): one
+// sweep of one factor is 8 155 dependent launches of a microsecond each, and eager launches cost the host 3-4 us apiece -- the sweep
+// is HOST-bound (0.65 s for 16 factors = 5 us per level; a same-stream kernel boundary is 1.5 us on the device).  Since every
+// launch of a factor's sweep is identical for all factors and calls (SweepDyn), the sequence is captured ONCE per (plan, buffers)
+// and replayed: the device walks it at its own pace.  Plans of fewer than ALS_GRAPH_MIN_LEVELS levels stay eager (nothing to win,
+// and their level launches are what bench.py times).  FMX_ALS_GRAPH=0/1 overrides.  Same kernels, same order: same bits.
+constexpr int ALS_GRAPH_MIN_LEVELS = 256;
+struct AlsGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  uint64_t matrix_uid = 0;
+  const void *qe = nullptr, *feats = nullptr;
+  int plan_cap = -2, levels = 0;
+};
+void als_graph_free(void* p) {
+  AlsGraph* g = reinterpret_cast<AlsGraph*>(p);
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+template <bool W>
+static bool sweep_graph_wanted(const fmx_matrix* m) {
+  if (m->als_approx) return false;
+  const char* v = getenv("FMX_ALS_GRAPH");
+  if (v) return v[0] == '1';
+  return (int)m->als_level_ptr.size() - 1 >= ALS_GRAPH_MIN_LEVELS;
+}
+// the replayable form of sweep_features<W>(e, m, d_qe, nullptr, dyn): null when capture is not possible (the caller then launches eagerly)
+template <bool W>
+static hipGraphExec_t sweep_graph(fmx_engine* e, fmx_matrix* m, double2* d_qe, const SweepDyn* dyn) {
+  void*& slot = W ? e->als_graph_w : e->als_graph_v;
+  AlsGraph* g = reinterpret_cast<AlsGraph*>(slot);
+  const int L = (int)m->als_level_ptr.size() - 1;
+  if (g && g->exec && g->matrix_uid == m->uid && g->qe == d_qe && g->feats == m->als_feats && g->plan_cap == m->als_plan_cap && g->levels == L) return g->exec;
+  als_graph_free(g);
+  slot = nullptr;
+  g = new AlsGraph();
+  if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); delete g; return nullptr; }
+  sweep_features<W>(e, m, d_qe, nullptr, dyn, /*profile=*/false);
+  if (hipStreamEndCapture(e->stream, &g->graph) != hipSuccess || g->graph == nullptr ||
+      hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    als_graph_free(g);
+    return nullptr;
+  }
+  g->matrix_uid = m->uid; g->qe = d_qe; g->feats = m->als_feats; g->plan_cap = m->als_plan_cap; g->levels = L;
+  slot = g;
+  return g->exec;
+}
+
+// one sweep of the w coordinates or of one factor, by replay when the plan is deep
+template <bool W>
+static void sweep_once(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2* d_qe_new, SweepDyn* dyn) {
+  if (sweep_graph_wanted<W>(m)) {
+    hipGraphExec_t x = sweep_graph<W>(e, m, d_qe, dyn);
+    if (x && hipGraphLaunch(x, e->stream) == hipSuccess) return;
+    (void)hipGetLastError();
+  }
+  sweep_features<W>(e, m, d_qe, d_qe_new, dyn);
 }
 
 // the approximate form's second (q, e) array: allocated on first use, kept in the engine
@@ -793,11 +886,28 @@ static double2* approx_buffer(fmx_engine* e, fmx_matrix* m) {
   return reinterpret_cast<double2*>(e->als_qe_new);
 }
 
+// sum of e^2 over the rows: partial sums on the device (mcmc_sumsq_partial_k), the rest on the host
+static int residual_sumsq(fmx_engine* e, const double2* d_qe, int64_t n, double* out);
+
+// (q, e) pairs of a learner's loop or a device-resident sweep: kept in the engine, grow-only (a stable address: the replayed graphs
+// of deep plans are captured against it)
+static double2* sweep_pairs(fmx_engine* e, int64_t n) {
+  if (e->als_qe_rows < n) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(e->als_qe); e->als_qe = nullptr; e->als_qe_rows = 0;
+    if (hipMalloc(&e->als_qe, (size_t)n * sizeof(double2)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    e->als_qe_rows = n;
+  }
+  return reinterpret_cast<double2*>(e->als_qe);
+}
+
 // V sweep over all factors on the interleaved (q, e) pairs
-static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu,
-                            const double* d_znorm = nullptr) {
+static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu,
+                           const double* d_znorm = nullptr) {
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   double2* d_qe_new = approx_buffer(e, m);
+  SweepDyn* dyn = sweep_dyn(e);
+  FMX_CHECK(dyn != nullptr, FMX_ERR_HIP, "out of device memory");
   // q_f = X v_f only depends on column f of V, which no other factor's sweep touches: all k of them come out of ONE
   // row-gather pass (the forward kernel on the fp64 tables) instead of one gather per nonzero per factor.  The n x kp table lives
   // in the engine (grow-only): a sweep allocates nothing once the first one has run.
@@ -815,7 +925,7 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
   if (d_Q) {
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
-    a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.link = FMX_LINK_NONE;
+    a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.link = FMX_LINK_NONE;
     a.unit = m->unit_values;
     if (launch_rows_forward(e, a, false, true) != FMX_OK) d_Q = nullptr;
   }
@@ -824,8 +934,82 @@ static void v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double 
     else hipLaunchKernelGGL(als_q_init_k, dim3(row_grid), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_qe);
     const double lambda = h_lambda ? h_lambda[f] : 0.0, mu = h_mu ? h_mu[f] : 0.0;
     if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);  // q changed: resynchronise the pair
-    sweep_features<false>(e, m, d_qe, d_qe_new, f, alpha, lambda, mu, d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
+    set_dyn(e, dyn, f, alpha, lambda, mu, d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
+    sweep_once<false>(e, m, d_qe, d_qe_new, dyn);
   }
+  return FMX_OK;
+}
+
+// ---- the approximate form, guarded ------------------------------------------------------------------------------------------------
+// Features of a group step against ONE snapshot of the residual; correlated features then overshoot together, and on Zipf columns
+// the sweep diverges (sum e^2 1e6 -> 1e22 in one sweep, profiles/r02_als_levels.txt).  So an approximate sweep is run under a guard:
+// V (or w) and the residual are kept aside, the sweep runs, and if the residual's sum of squares went UP (ALS: at all; MCMC, whose
+// draws add variance of their own: tenfold, or not finite) everything is put back, the matrix is marked exact-only and the sweep
+// is run again through the exact level schedule.  cfg.als_max_levels is therefore a request, not a risk.
+struct ApproxGuard {
+  fmx_engine* e; fmx_matrix* m; double2* d_qe; bool w; bool gibbs;
+  double ss0 = 0.0;
+  bool armed = false;
+  int begin() {
+    if (!m->als_approx) return FMX_OK;
+    const size_t pv = w ? (size_t)e->p : (size_t)e->p * e->kp64;
+    const size_t need = pv + 2 * (size_t)m->n;
+    if (e->als_backup_elems < need) {
+      FMX_HIP(hipStreamSynchronize(e->stream));
+      (void)hipFree(e->als_backup); e->als_backup = nullptr; e->als_backup_elems = 0;
+      FMX_HIP(hipMalloc(&e->als_backup, need * sizeof(double)));
+      e->als_backup_elems = need;
+    }
+    FMX_TRY(residual_sumsq(e, d_qe, m->n, &ss0));
+    FMX_HIP(hipMemcpyAsync(e->als_backup, w ? e->dw : e->dV, pv * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    FMX_HIP(hipMemcpyAsync(e->als_backup + pv, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream));
+    armed = true;
+    return FMX_OK;
+  }
+  // *redo = true: the state was put back and the plan is exact now -- run the sweep again
+  int end(bool* redo) {
+    *redo = false;
+    if (!armed) return FMX_OK;
+    double ss1 = 0.0;
+    FMX_TRY(residual_sumsq(e, d_qe, m->n, &ss1));
+    const bool bad = !(ss1 == ss1) || std::isinf(ss1) || ss1 > ss0 * (gibbs ? 10.0 : 1.0 + 1e-12);
+    if (!bad) return FMX_OK;
+    const size_t pv = w ? (size_t)e->p : (size_t)e->p * e->kp64;
+    FMX_HIP(hipMemcpyAsync(w ? e->dw : e->dV, e->als_backup, pv * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    FMX_HIP(hipMemcpyAsync(d_qe, e->als_backup + pv, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream));
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    m->als_force_exact = 1;
+    FMX_TRY(build_plan(m, e->stream, 0));
+    *redo = true;
+    return FMX_OK;
+  }
+};
+
+static int v_sweep_guarded(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm = nullptr) {
+  ApproxGuard g{e, m, d_qe, false, d_znorm != nullptr};
+  FMX_TRY(g.begin());
+  FMX_TRY(v_sweep_enqueue(e, m, d_qe, alpha, h_lambda, h_mu, d_znorm));
+  bool redo = false;
+  FMX_TRY(g.end(&redo));
+  if (redo) FMX_TRY(v_sweep_enqueue(e, m, d_qe, alpha, h_lambda, h_mu, d_znorm));
+  return FMX_OK;
+}
+
+static int w_sweep_guarded(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, double lambda, double mu, const double* d_znorm) {
+  SweepDyn* dyn = sweep_dyn(e);
+  FMX_CHECK(dyn != nullptr, FMX_ERR_HIP, "out of device memory");
+  ApproxGuard g{e, m, d_qe, true, d_znorm != nullptr};
+  FMX_TRY(g.begin());
+  for (int pass = 0; pass < 2; ++pass) {
+    double2* d_qe_new = approx_buffer(e, m);
+    if (d_qe_new) FMX_HIP(hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream));
+    set_dyn(e, dyn, 0, alpha, lambda, mu, d_znorm);
+    sweep_once<true>(e, m, d_qe, d_qe_new, dyn);
+    bool redo = false;
+    if (pass == 0) FMX_TRY(g.end(&redo));
+    if (!redo) break;
+  }
+  return FMX_OK;
 }
 
 // MCMC_ALS_Learner::learn for the ALS learner (:91-156): per iteration a fresh forward, the residual of the task
@@ -863,17 +1047,18 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
   const unsigned row_grid = (unsigned)((n + 255) / 256);
   const int64_t np = (n + ALS_SLAB - 1) / ALS_SLAB;
   double *d_yhat = nullptr, *d_part = nullptr;
-  double2* d_qe = nullptr;
+  double2* d_qe = sweep_pairs(e, n);
+  FMX_CHECK(d_qe != nullptr, FMX_ERR_HIP, "out of device memory");
   FMX_HIP(hipMalloc(&d_yhat, (size_t)n * sizeof(double)));
-  if (hipMalloc(&d_qe, (size_t)n * sizeof(double2)) != hipSuccess || hipMalloc(&d_part, ((size_t)np + 1) * sizeof(double)) != hipSuccess) {
-    (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part);
+  if (hipMalloc(&d_part, ((size_t)np + 1) * sizeof(double)) != hipSuccess) {
+    (void)hipFree(d_yhat); (void)hipFree(d_part);
     set_error("out of device memory"); return FMX_ERR_HIP;
   }
   int st = FMX_OK;
   for (int it = 0; it < max_iter && st == FMX_OK; ++it) {
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = n;
-    a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
+    a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
     st = launch_rows_forward(e, a, false, true);  // fm->predict_batch(train, train_err), :100
     if (st != FMX_OK) break;
     hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, dp_y);
@@ -882,16 +1067,12 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
       hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, 1.0, 0.0, 0, 0.0);
       hipLaunchKernelGGL(als_shift_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, n, d_part + np);
     }
-    if (e->hyper.k1) {
-      double2* d_qe_new = approx_buffer(e, m);
-      if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);
-      sweep_features<true>(e, m, d_qe, d_qe_new, 0, 1.0, 0.0, 0.0, nullptr);
-    }
-    if (with_v && e->k > 0) v_sweep_enqueue(e, m, d_qe, 1.0, nullptr, nullptr);
+    if (e->hyper.k1 && st == FMX_OK) st = w_sweep_guarded(e, m, d_qe, 1.0, 0.0, 0.0, nullptr);
+    if (with_v && e->k > 0 && st == FMX_OK) st = v_sweep_guarded(e, m, d_qe, 1.0, nullptr, nullptr);
   }
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-  (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part);
+  (void)hipFree(d_yhat); (void)hipFree(d_part);
   FMX_TRY(st);
   FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "ALS training failed: %s", hipGetErrorString(err));
   return FMX_OK;
@@ -913,6 +1094,24 @@ __global__ __launch_bounds__(WG_THREADS) void mcmc_sumsq_partial_k(const double2
     __syncthreads();
   }
   if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+static int residual_sumsq(fmx_engine* e, const double2* d_qe, int64_t n, double* out) {
+  const int64_t np = (n + ALS_SLAB - 1) / ALS_SLAB;
+  double* d_part = nullptr;
+  FMX_HIP(hipMalloc(&d_part, (size_t)(np > 0 ? np : 1) * sizeof(double)));
+  std::vector<double> h((size_t)np);
+  int st = FMX_OK;
+  if (np > 0) {
+    hipLaunchKernelGGL(mcmc_sumsq_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, d_part);
+    if (hipMemcpyAsync(h.data(), d_part, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) { set_error("residual sum of squares failed"); st = FMX_ERR_HIP; }
+  }
+  (void)hipFree(d_part);
+  double s = 0.0;
+  for (double v : h) s += v;
+  *out = s;
+  return st;
 }
 
 // per slab of w: sum w and sum (w - mu)^2 (update_w_lambda :423-427, update_w_mu :392-395)
@@ -978,9 +1177,10 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
   const int64_t np = (n + ALS_SLAB - 1) / ALS_SLAB, npw = (p + ALS_SLAB - 1) / ALS_SLAB;
   const int64_t part_cap = (np > 2 * npw ? np : 2 * npw) + 1;
   double *d_yhat = nullptr, *d_part = nullptr, *d_z = nullptr;
-  double2* d_qe = nullptr;
-  auto cleanup = [&]() { (void)hipFree(d_yhat); (void)hipFree(d_qe); (void)hipFree(d_part); (void)hipFree(d_z); };
-  if (hipMalloc(&d_yhat, (size_t)n * sizeof(double)) != hipSuccess || hipMalloc(&d_qe, (size_t)n * sizeof(double2)) != hipSuccess ||
+  double2* d_qe = sweep_pairs(e, n);
+  FMX_CHECK(d_qe != nullptr, FMX_ERR_HIP, "out of device memory");
+  auto cleanup = [&]() { (void)hipFree(d_yhat); (void)hipFree(d_part); (void)hipFree(d_z); };
+  if (hipMalloc(&d_yhat, (size_t)n * sizeof(double)) != hipSuccess ||
       hipMalloc(&d_part, (size_t)part_cap * sizeof(double)) != hipSuccess || hipMalloc(&d_z, (size_t)p * sizeof(double)) != hipSuccess) {
     cleanup(); set_error("out of device memory"); return FMX_ERR_HIP;
   }
@@ -1002,7 +1202,7 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
     const double* Z = h_normals + (size_t)it * (2 + (size_t)p);
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = n;
-    a.V = e->dV; a.w = e->dw; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
+    a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
     st = launch_rows_forward(e, a, false, true);
     if (st != FMX_OK) break;
     if (!cls) {
@@ -1053,11 +1253,7 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
         if (!bad(mu_new)) w_mu = mu_new;
       }
       MC_HIP(hipMemcpyAsync(d_z, Z + 2, (size_t)p * sizeof(double), hipMemcpyHostToDevice, e->stream));
-      {  // update_w, :190-270
-        double2* d_qe_new = approx_buffer(e, m);
-        if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);
-        sweep_features<true>(e, m, d_qe, d_qe_new, 0, alpha, w_lambda, w_mu, (const double*)d_z);
-      }
+      if (st == FMX_OK) st = w_sweep_guarded(e, m, d_qe, alpha, w_lambda, w_mu, (const double*)d_z);  // update_w, :190-270
     }
   }
 #undef MC_HIP
@@ -1125,17 +1321,6 @@ int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_n
   return st;
 }
 
-// (q, e) pairs of the device-resident sweep: kept in the engine, grow-only
-static double2* sweep_pairs(fmx_engine* e, int64_t n) {
-  if (e->als_qe_rows < n) {
-    (void)hipStreamSynchronize(e->stream);
-    (void)hipFree(e->als_qe); e->als_qe = nullptr; e->als_qe_rows = 0;
-    if (hipMalloc(&e->als_qe, (size_t)n * sizeof(double2)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    e->als_qe_rows = n;
-  }
-  return reinterpret_cast<double2*>(e->als_qe);
-}
-
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm) {
   double2* qe = sweep_pairs(e, m->n);
   FMX_CHECK(qe != nullptr, FMX_ERR_HIP, "out of device memory");
@@ -1150,7 +1335,7 @@ int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q
   double2* d_qe = reinterpret_cast<double2*>(d_qe_raw);
   const unsigned row_grid = (unsigned)((m->n + 255) / 256);
   hipLaunchKernelGGL(als_pack_k, dim3(row_grid), dim3(256), 0, e->stream, d_error, m->n, d_qe);
-  v_sweep_enqueue(e, m, d_qe, alpha, h_lambda, h_mu, d_znorm);
+  FMX_TRY(v_sweep_guarded(e, m, d_qe, alpha, h_lambda, h_mu, d_znorm));
   hipLaunchKernelGGL(als_unpack_k, dim3(row_grid), dim3(256), 0, e->stream, d_qe, m->n, d_error);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(e->stream);

@@ -297,8 +297,8 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
       T wv[RU];
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
-        vv[u] = gather_row(Vt + (size_t)en[u].x * KP);
-        wv[u] = wt[en[u].x];
+        vv[u] = gather_row(Vt + (size_t)en[u].x * a.vs);
+        wv[u] = wt[(size_t)en[u].x * a.ws];  // (w-in-row layout: the same 128-byte line as the V row)
         if constexpr (WGT != 64) {
           // large steps over a cache-sized table: let these land before the next entry's requests go out (see FMX_U_LARGE above)
           if (a.serial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -397,6 +397,7 @@ static int launch_rows_w(fmx_engine* e, const RowsArgs& a, int kp) {
 
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp64_tables) {
   RowsArgs a = a_in;
+  FMX_CHECK(a.vs >= (fp64_tables ? e->kp64 : e->kp32) && a.ws >= 1, FMX_ERR_STATE, "rows_forward: table strides not set (%d, %d)", a.vs, a.ws);
   static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
   static const int force = [] { const char* v = getenv("FMX_ROWS_SERIAL"); return v ? atoi(v) : -1; }();
   RowsTune& tu = e->rows_tune;
@@ -577,6 +578,8 @@ struct ColsTables {
   int64_t s_rows;            // rows of S / amul reachable from the pointers above (sizes the buffer descriptors)
   ST* crec;                  // compact exchange: one record per occurring feature (see record layout below)
   int rec_elems;             // elements per record
+  int w_full;                // w-in-row layout: store the row's whole second half with w (see store_w)
+  int vs, ws;                // V rows lie vs elements apart, feature j's w is w[j * ws] (fmx_internal.h: w_in_row); the STATE tables keep stride KP
 };
 
 // Compact exchange record of one occurring feature (fmx_grad_compact): G[KP] | (has_q: Q[KP]) | Gw | Qw | cnt | id.
@@ -688,6 +691,21 @@ __device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const V
   }
 }
 
+// Store of the updated linear weight.  Separate w table (ws == 1): lane 0 stores the word.  w-in-row layout (ws > 1): the row's
+// second half -- slot KP = w, the rest padding -- is stored WHOLE, every lane of the group its 16-byte slice of it: a 4-byte store
+// into an otherwise clean 64-byte sector is a partial write (the memory side has to read, merge and re-encode the sector: ECC), a full
+// sector is a plain write.  Measured at p = 16 M, k = 16 (profiles/r03_wir_ab.txt).  full == 0: the 4-byte store (A/B runs).
+template <typename ST, int VEC>
+__device__ __forceinline__ void store_w(ST* wbase, size_t at_w, int ws, int lig, double wn, int full) {
+  using vec_t = typename Slice<ST>::vec;
+  if (ws > 1 && full) {
+    double sl[4] = {lig == 0 ? wn : 0.0, 0.0, 0.0, 0.0};
+    *reinterpret_cast<vec_t*>(wbase + at_w + lig * VEC) = slice_make(sl, ST());
+  } else if (lig == 0) {
+    wbase[at_w] = (ST)wn;
+  }
+}
+
 // What happens to a feature's sums: [+ the exchange buffer's] -> [publish] -> [apply the update].  Shared by the main
 // kernel (short lists) and the long-list finisher.  Called by every lane of the feature's group; lig == 0 handles w.
 template <typename ST, int LPR, int KIND, bool GBUF = true>
@@ -698,7 +716,9 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
   constexpr int KP = LPR * VEC;
   constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
   // exchange buffer: blocks of F features, each GV [F][KP] | GW [F] | CNT [F] | (has_q: QV [F][KP] | QW [F]); then tail[4]
-  const size_t at = (size_t)j * KP + lig * VEC;  // in the parameter tables
+  const size_t at = (size_t)j * KP + lig * VEC;    // in the optimizer-state tables
+  const size_t at_v = (size_t)j * T.vs + lig * VEC;  // in the V table
+  const size_t at_w = (size_t)j * T.ws;              // in the w table (or the V row's w slot)
   if (GBUF && (a.load_gbuf || a.store_gbuf)) {
     const uint32_t F = T.gb_feats;
     const uint32_t blk = (uint32_t)j / F, r = (uint32_t)j - blk * F;
@@ -784,15 +804,16 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
     double outv[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) outv[i] = tdap_update<ST>(h, false, vf[i], s.G[i], s.Q[i], cnt, st[0][i], st[1][i], st[2][i], st[3][i], st[4][i], true);
-    *reinterpret_cast<vec_t*>(T.V + at) = slice_make(outv, ST());
+    *reinterpret_cast<vec_t*>(T.V + at_v) = slice_make(outv, ST());
 #pragma unroll
     for (int q = 0; q < 5; ++q) *reinterpret_cast<vec_t*>(tabs[q] + at) = slice_make(st[q], ST());
+    double wn = 0.0;
     if (lig == 0) {  // like FTRL, TDAP recomputes w on every touched column even with keep.w1 off (TDAP_Learner.h:203-214)
       ST u = T.nw[j], nu = T.t1w[j], dl = T.t2w[j], hh = T.t3w[j], z = T.sw[j];
-      const double wn = tdap_update<ST>(h, true, (double)(w_pre ? *w_pre : T.w[j]), s.Gw, s.Qw, cnt, u, nu, dl, hh, z, h.k1 != 0);
-      T.w[j] = (ST)wn;
+      wn = tdap_update<ST>(h, true, (double)(w_pre ? *w_pre : T.w[at_w]), s.Gw, s.Qw, cnt, u, nu, dl, hh, z, h.k1 != 0);
       T.nw[j] = u; T.t1w[j] = nu; T.t2w[j] = dl; T.t3w[j] = hh; T.sw[j] = z;
     }
+    store_w<ST, VEC>(T.w, at_w, T.ws, lig, wn, T.w_full);
     return;
   }
   double tmp[VEC];
@@ -820,18 +841,19 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
 #pragma unroll
   for (int i = 0; i < VEC; ++i)
     out[i] = coord_update<KIND, ST>(h, false, vf[i], s.G[i], s.Q[i], cnt, decay_v, u_v, sa_[i], sb_[i], true);
-  *reinterpret_cast<vec_t*>(T.V + at) = slice_make(out, ST());
+  *reinterpret_cast<vec_t*>(T.V + at_v) = slice_make(out, ST());
   if constexpr (KIND != UPD_SGD_L2) *reinterpret_cast<vec_t*>(T.sV + at) = slice_make(sa_, ST());
   if constexpr (KIND == UPD_FTRL) *reinterpret_cast<vec_t*>(T.nV + at) = slice_make(sb_, ST());
-  if (lig == 0) {
-    // FTRL recomputes w on every touched column even when keep.w1 is off (FTRL_Learner.h:172-183); SGD skips (:111)
-    const bool k1 = h.k1 != 0;
-    if (k1 || KIND == UPD_FTRL) {
-      const double wn = coord_update<KIND, ST>(h, true, (double)(w_pre ? *w_pre : T.w[j]), s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
-      T.w[j] = (ST)wn;
+  // FTRL recomputes w on every touched column even when keep.w1 is off (FTRL_Learner.h:172-183); SGD skips (:111)
+  const bool k1 = h.k1 != 0;
+  if (k1 || KIND == UPD_FTRL) {
+    double wn = 0.0;
+    if (lig == 0) {
+      wn = coord_update<KIND, ST>(h, true, (double)(w_pre ? *w_pre : T.w[at_w]), s.Gw, s.Qw, cnt, decay_w, u_w, wa, wb, k1);
       if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
       if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
     }
+    store_w<ST, VEC>(T.w, at_w, T.ws, lig, wn, T.w_full);
   }
 }
 
@@ -891,9 +913,9 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
   } else if (SPARSE || a.walk) {
     off_a = a.bptr[idx]; off_b = a.bptr[idx + 1];
   }
-  const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC);
+  const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + (size_t)j * T.vs + lig * VEC);
   // w_j is needed only after the walk: ask for it now, beside the V row, instead of paying its round trip at the end
-  ST w_pre = T.w[j];
+  ST w_pre = T.w[(size_t)j * T.ws];
   CoordSums s;
   sums_zero(s);
   double vf[VEC];
@@ -1106,7 +1128,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   if (j < (int64_t)a.f0 || j >= (int64_t)a.f1) return;  // not in this launch's feature range (uniform over the wave)
   const int64_t ta = la.seg_begin[seg], tb = la.seg_end[seg];
   double vf[VEC];
-  slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
+  slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * T.vs + lig * VEC), vf);
   CoordSums s;
   sums_zero(s);
   const ST* __restrict__ St = T.S + lig * VEC;
@@ -1190,7 +1212,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
   const int64_t j = la.lfeat[i];
   if (j < (int64_t)a.f0 || j >= (int64_t)a.f1) return;
   double vf[VEC];
-  slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC), vf);
+  slice_get(*reinterpret_cast<const vec_t*>(T.V + (size_t)j * T.vs + lig * VEC), vf);
   CoordSums s;
   sums_zero(s);
   for (uint32_t sg = la.lseg_ptr[i] + sub; sg < la.lseg_ptr[i + 1]; sg += NSUB) {
@@ -1262,7 +1284,8 @@ template <typename ST>
 static ColsTables<ST> cols_tables(fmx_engine* e, const ColsArgs& a, int has_q) {
   constexpr bool W = sizeof(ST) == 8;
   ColsTables<ST> T{};
-  T.V = (ST*)(W ? (void*)e->dV : (void*)e->V); T.w = (ST*)(W ? (void*)e->dw : (void*)e->w);
+  T.V = (ST*)mb_vbase(e); T.w = (ST*)mb_wbase(e); T.vs = mb_vstride(e); T.ws = mb_wstride(e);
+  { static const bool full = [] { const char* v = getenv("FMX_WIR_FULL_STORE"); return !(v && v[0] == '0'); }(); T.w_full = full ? 1 : 0; }
   T.sV = (ST*)(W ? (void*)e->dsV : (void*)e->sV); T.sw = (ST*)(W ? (void*)e->dsw : (void*)e->sw);
   T.nV = (ST*)(W ? (void*)e->dnV : (void*)e->nV); T.nw = (ST*)(W ? (void*)e->dnw : (void*)e->nw);
   T.t1V = (ST*)(W ? (void*)e->dt1V : (void*)e->t1V); T.t1w = (ST*)(W ? (void*)e->dt1w : (void*)e->t1w);
@@ -1353,8 +1376,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, Cols
     // issued before the first one is used (the plain loop paid two rounds per PART on top of the V row's own: section 6.2).
     const int64_t j = r.rfeat[i];
     const uint32_t t0 = r.roff[i], t1 = r.roff[i + 1];
-    const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + (size_t)j * KP + lig * VEC);
-    const ST w_pre = T.w[j];
+    const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + (size_t)j * T.vs + lig * VEC);
+    const ST w_pre = T.w[(size_t)j * T.ws];
     const int qo = (NEED_Q && T.has_q) ? KP : 0;
     const ST* recs = reinterpret_cast<const ST*>(r.recs);
     // The parts are added in the exchange's element type, in rank order: exactly what an all-reduce(sum) of the dense buffer

@@ -454,7 +454,7 @@ int plan_owner_build(fmx_matrix::TilePlan& t, OwnerWorkspace& ws, int n_owners, 
 // What an owner sends back for a pulled feature, and what the asking rank stores: the V row and w in the STATE's element type,
 // [kp | w 0 0 0] per feature (16-byte aligned rows).  Optimizer state never travels: it lives with the owner.
 template <typename T, int VEC, bool UNPACK>
-__global__ void rows_pack_k(T* __restrict__ V, T* __restrict__ w, int kp, const uint32_t* __restrict__ ids, int64_t n, T* __restrict__ rows) {
+__global__ void rows_pack_k(T* __restrict__ V, T* __restrict__ w, int kp, int vs, int ws, const uint32_t* __restrict__ ids, int64_t n, T* __restrict__ rows) {
   const int lpr = kp / VEC + 1;  // the row's slices, then the w slice
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * lpr) return;
@@ -464,13 +464,13 @@ __global__ void rows_pack_k(T* __restrict__ V, T* __restrict__ w, int kp, const 
   T* row = rows + (size_t)i * (kp + 4);
   using vec_t = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
   if (s < kp / VEC) {
-    vec_t* a = reinterpret_cast<vec_t*>(V + j * kp + s * VEC);
+    vec_t* a = reinterpret_cast<vec_t*>(V + j * vs + s * VEC);
     vec_t* b = reinterpret_cast<vec_t*>(row + s * VEC);
     if (UNPACK) *a = *b; else *b = *a;
   } else if (UNPACK) {
-    w[j] = row[kp];
+    w[j * ws] = row[kp];
   } else {
-    row[kp] = w[j];
+    row[kp] = w[j * ws];
     for (int q = 1; q < 4; ++q) row[kp + q] = (T)0;
   }
 }
@@ -481,13 +481,14 @@ int rows_pack(fmx_engine* e, const uint32_t* d_ids, int64_t n, void* d_rows, boo
   if (mb_wide(e)) {
     const int64_t total = n * (kp / 2 + 1);
     const dim3 g((unsigned)((total + 255) / 256)), b(256);
-    if (unpack) hipLaunchKernelGGL((rows_pack_k<double, 2, true>), g, b, 0, e->stream, e->dV, e->dw, kp, d_ids, n, (double*)d_rows);
-    else hipLaunchKernelGGL((rows_pack_k<double, 2, false>), g, b, 0, e->stream, e->dV, e->dw, kp, d_ids, n, (double*)d_rows);
+    if (unpack) hipLaunchKernelGGL((rows_pack_k<double, 2, true>), g, b, 0, e->stream, e->dV, e->dw, kp, kp, 1, d_ids, n, (double*)d_rows);
+    else hipLaunchKernelGGL((rows_pack_k<double, 2, false>), g, b, 0, e->stream, e->dV, e->dw, kp, kp, 1, d_ids, n, (double*)d_rows);
   } else {
     const int64_t total = n * (kp / 4 + 1);
     const dim3 g((unsigned)((total + 255) / 256)), b(256);
-    if (unpack) hipLaunchKernelGGL((rows_pack_k<float, 4, true>), g, b, 0, e->stream, e->V, e->w, kp, d_ids, n, (float*)d_rows);
-    else hipLaunchKernelGGL((rows_pack_k<float, 4, false>), g, b, 0, e->stream, e->V, e->w, kp, d_ids, n, (float*)d_rows);
+    float* wb = (float*)mb_wbase(e);
+    if (unpack) hipLaunchKernelGGL((rows_pack_k<float, 4, true>), g, b, 0, e->stream, e->V, wb, kp, mb_vstride(e), mb_wstride(e), d_ids, n, (float*)d_rows);
+    else hipLaunchKernelGGL((rows_pack_k<float, 4, false>), g, b, 0, e->stream, e->V, wb, kp, mb_vstride(e), mb_wstride(e), d_ids, n, (float*)d_rows);
   }
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -853,14 +854,14 @@ int init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev) {
   if (total == 0) return FMX_OK;
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   if (wide_state(e)) hipLaunchKernelGGL((init_normal_k<double>), g, b, 0, e->stream, e->dV, e->p, e->k, e->kp64, seed, mean, stdev);
-  else hipLaunchKernelGGL((init_normal_k<float>), g, b, 0, e->stream, e->V, e->p, e->k, e->kp32, seed, mean, stdev);
+  else hipLaunchKernelGGL((init_normal_k<float>), g, b, 0, e->stream, e->V, e->p, e->k, e->vstride32, seed, mean, stdev);  // (kp = the row stride)
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 
 // rows of (w, V) picked by feature id <-> a dense [n][k] / [n] pair of double buffers
 template <typename T, bool SET>
-__global__ void rows_copy_k(T* __restrict__ V, T* __restrict__ w, int k, int kp, const uint32_t* __restrict__ ids, int64_t n, double* __restrict__ bw,
+__global__ void rows_copy_k(T* __restrict__ V, T* __restrict__ w, int k, int kp, int ws, const uint32_t* __restrict__ ids, int64_t n, double* __restrict__ bw,
                             double* __restrict__ bv) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int kk = k + 1;
@@ -868,7 +869,7 @@ __global__ void rows_copy_k(T* __restrict__ V, T* __restrict__ w, int k, int kp,
   const int64_t i = t / kk;
   const int f = (int)(t - i * kk);
   const size_t j = ids[i];
-  if (f == k) { if (SET) w[j] = (T)bw[i]; else bw[i] = (double)w[j]; }
+  if (f == k) { if (SET) w[j * ws] = (T)bw[i]; else bw[i] = (double)w[j * ws]; }
   else if (SET) V[j * kp + f] = (T)bv[i * k + f];
   else bv[i * k + f] = (double)V[j * kp + f];
 }
@@ -878,11 +879,12 @@ int rows_copy(fmx_engine* e, const uint32_t* d_ids, int64_t n, double* d_w, doub
   if (total == 0) return FMX_OK;
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   if (wide_state(e)) {
-    if (set) hipLaunchKernelGGL((rows_copy_k<double, true>), g, b, 0, e->stream, e->dV, e->dw, e->k, e->kp64, d_ids, n, d_w, d_v);
-    else hipLaunchKernelGGL((rows_copy_k<double, false>), g, b, 0, e->stream, e->dV, e->dw, e->k, e->kp64, d_ids, n, d_w, d_v);
+    if (set) hipLaunchKernelGGL((rows_copy_k<double, true>), g, b, 0, e->stream, e->dV, e->dw, e->k, e->kp64, 1, d_ids, n, d_w, d_v);
+    else hipLaunchKernelGGL((rows_copy_k<double, false>), g, b, 0, e->stream, e->dV, e->dw, e->k, e->kp64, 1, d_ids, n, d_w, d_v);
   } else {
-    if (set) hipLaunchKernelGGL((rows_copy_k<float, true>), g, b, 0, e->stream, e->V, e->w, e->k, e->kp32, d_ids, n, d_w, d_v);
-    else hipLaunchKernelGGL((rows_copy_k<float, false>), g, b, 0, e->stream, e->V, e->w, e->k, e->kp32, d_ids, n, d_w, d_v);
+    float* wb = (float*)mb_wbase(e);   // (kp = the row stride)
+    if (set) hipLaunchKernelGGL((rows_copy_k<float, true>), g, b, 0, e->stream, e->V, wb, e->k, e->vstride32, mb_wstride(e), d_ids, n, d_w, d_v);
+    else hipLaunchKernelGGL((rows_copy_k<float, false>), g, b, 0, e->stream, e->V, wb, e->k, e->vstride32, mb_wstride(e), d_ids, n, d_w, d_v);
   }
   FMX_HIP(hipGetLastError());
   return FMX_OK;

@@ -263,8 +263,8 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
   RowsArgs a{};  // launch_rows_forward cuts the range into launches of 262 144 rows
   a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = nullptr;
   a.r0 = r0; a.nrows = r1 - r0;
-  a.V = wide_state(e) ? (const void*)e->dV : (const void*)e->V;
-  a.w = wide_state(e) ? (const void*)e->dw : (const void*)e->w;
+  if (wide_state(e)) { a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; }
+  else { a.V = e->V; a.w = mb_wbase(e); a.vs = e->vstride32; a.ws = mb_wstride(e); }
   a.scal = e->scal;
   a.yhat = d_out;
   a.link = link;
@@ -338,8 +338,7 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t st
   RowsArgs a{};
   a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.y = m->y;
   a.r0 = t.r0; a.nrows = t.nrows;
-  a.V = mb_wide(e) ? (const void*)e->dV : (const void*)e->V;
-  a.w = mb_wide(e) ? (const void*)e->dw : (const void*)e->w;
+  a.V = mb_vbase(e); a.w = mb_wbase(e); a.vs = mb_vstride(e); a.ws = mb_wstride(e);
   a.scal = e->scal;
   a.S = (char*)e->S + (size_t)s_row0 * mb_kp(e) * mb_elem(e);
   a.amul = (char*)e->amul + (size_t)s_row0 * mb_elem(e);
@@ -653,8 +652,14 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   e->scal_next = e->scal_base + SC_COUNT;
   const size_t p = (size_t)e->p;
   if (cfg->mode == FMX_MODE_MINIBATCH && !cfg->state_fp64) {
-    FMX_TRY(dev_alloc_zero(&e->V, p * e->kp32));
-    FMX_TRY(dev_alloc_zero(&e->w, p));
+    {  // layout of the V / w tables (fmx_internal.h: w_in_row)
+      const char* v = getenv("FMX_W_IN_ROW");
+      const bool want = v ? v[0] == '1' : num_features >= 8000000ull;
+      e->w_in_row = (want && e->kp32 <= 16 && e->k > 0) ? 1 : 0;
+      e->vstride32 = e->w_in_row ? 2 * e->kp32 : e->kp32;
+    }
+    FMX_TRY(dev_alloc_zero(&e->V, p * e->vstride32));
+    if (!e->w_in_row) FMX_TRY(dev_alloc_zero(&e->w, p));
     if (e->hyper.kind != UPD_SGD_L2) { FMX_TRY(dev_alloc_zero(&e->sV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->sw, p)); }
     if (e->hyper.kind == UPD_FTRL || e->hyper.kind == UPD_TDAP) { FMX_TRY(dev_alloc_zero(&e->nV, p * e->kp32)); FMX_TRY(dev_alloc_zero(&e->nw, p)); }
     if (e->hyper.kind == UPD_TDAP) {
@@ -695,7 +700,8 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup);
+  als_graph_free(e->als_graph_w); als_graph_free(e->als_graph_v);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FMX_OK;
@@ -720,20 +726,31 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
     if (w) FMX_HIP(hipMemcpy(e->dw, w, p * sizeof(double), hipMemcpyHostToDevice));
     else FMX_HIP(hipMemset(e->dw, 0, p * sizeof(double)));
   } else {
-    const int kp = e->kp32;
-    if (v) {
-      std::vector<float> hv(p * kp, 0.f);
-      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = (float)v[f + j * (size_t)k];
-      FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int vs = e->vstride32, kp = e->kp32;
+    if (e->w_in_row) {  // V row and w travel in one table
+      if (v || w) {
+        std::vector<float> hv(p * vs, 0.f);
+        if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * vs + f] = (float)v[f + j * (size_t)k];
+        if (w) for (size_t j = 0; j < p; ++j) hv[j * vs + kp] = (float)w[j];
+        FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+      } else {
+        FMX_HIP(hipMemset(e->V, 0, p * vs * sizeof(float)));
+      }
     } else {
-      FMX_HIP(hipMemset(e->V, 0, p * kp * sizeof(float)));
-    }
-    if (w) {
-      std::vector<float> hw(p);
-      for (size_t j = 0; j < p; ++j) hw[j] = (float)w[j];
-      FMX_HIP(hipMemcpy(e->w, hw.data(), p * sizeof(float), hipMemcpyHostToDevice));
-    } else {
-      FMX_HIP(hipMemset(e->w, 0, p * sizeof(float)));
+      if (v) {
+        std::vector<float> hv(p * kp, 0.f);
+        for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = (float)v[f + j * (size_t)k];
+        FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+      } else {
+        FMX_HIP(hipMemset(e->V, 0, p * kp * sizeof(float)));
+      }
+      if (w) {
+        std::vector<float> hw(p);
+        for (size_t j = 0; j < p; ++j) hw[j] = (float)w[j];
+        FMX_HIP(hipMemcpy(e->w, hw.data(), p * sizeof(float), hipMemcpyHostToDevice));
+      } else {
+        FMX_HIP(hipMemset(e->w, 0, p * sizeof(float)));
+      }
     }
   }
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
@@ -759,16 +776,25 @@ int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v) {
       for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * kp + f];
     }
   } else {
-    if (w) {
-      std::vector<float> hw(p);
-      FMX_HIP(hipMemcpy(hw.data(), e->w, p * sizeof(float), hipMemcpyDeviceToHost));
-      for (size_t j = 0; j < p; ++j) w[j] = hw[j];
-    }
-    if (v && k > 0) {
-      const int kp = e->kp32;
-      std::vector<float> hv(p * kp);
-      FMX_HIP(hipMemcpy(hv.data(), e->V, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
-      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * kp + f];
+    const int vs = e->vstride32, kp = e->kp32;
+    if (e->w_in_row) {
+      if (w || (v && k > 0)) {
+        std::vector<float> hv(p * vs);
+        FMX_HIP(hipMemcpy(hv.data(), e->V, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (w) for (size_t j = 0; j < p; ++j) w[j] = hv[j * vs + kp];
+        if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * vs + f];
+      }
+    } else {
+      if (w) {
+        std::vector<float> hw(p);
+        FMX_HIP(hipMemcpy(hw.data(), e->w, p * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < p; ++j) w[j] = hw[j];
+      }
+      if (v && k > 0) {
+        std::vector<float> hv(p * kp);
+        FMX_HIP(hipMemcpy(hv.data(), e->V, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * kp + f];
+      }
     }
   }
   return FMX_OK;
@@ -840,7 +866,7 @@ static_assert(sizeof(CkptHeader) == 64, "checkpoint header is 64 bytes");
 static void ckpt_tables(fmx_engine* e, std::vector<std::pair<void*, size_t>>* out) {
   const size_t p = (size_t)e->p;
   auto add = [&](void* ptr, size_t bytes) { if (ptr) out->push_back({ptr, bytes}); };
-  add(e->V, p * e->kp32 * sizeof(float)); add(e->w, p * sizeof(float));
+  add(e->V, p * (e->vstride32 ? e->vstride32 : e->kp32) * sizeof(float)); add(e->w, p * sizeof(float));  // (w-in-row layout: no separate w table)
   add(e->sV, p * e->kp32 * sizeof(float)); add(e->sw, p * sizeof(float));
   add(e->nV, p * e->kp32 * sizeof(float)); add(e->nw, p * sizeof(float));
   add(e->t1V, p * e->kp32 * sizeof(float)); add(e->t1w, p * sizeof(float));
@@ -860,6 +886,7 @@ static CkptHeader ckpt_header(const fmx_engine* e) {
   h.version = 1; h.p = e->p; h.k = e->k; h.kp = wide_state(e) ? e->kp64 : e->kp32; h.mode = e->cfg.mode; h.kind = e->hyper.kind;
   h.scalars = SC_COUNT;
   h.reserved[0] = mb_wide(e) ? 1u : 0u;  // mini-batch state kept in the fp64 tables
+  h.reserved[1] = e->w_in_row ? 1u : 0u;  // V rows carry w (the tables are stored as they lie on the device)
   return h;
 }
 
@@ -898,7 +925,7 @@ int fmx_engine_load(fmx_engine* e, const char* path) {
   bool ok = fread(&h, sizeof(h), 1, f) == 1;
   if (!ok || memcmp(h.magic, "FMX1", 4) != 0 || h.version != 1) { fclose(f); set_error("%s is not an fmx checkpoint", path); return FMX_ERR_INVALID; }
   if (h.p != want.p || h.k != want.k || h.kp != want.kp || h.mode != want.mode || h.kind != want.kind || h.scalars != want.scalars ||
-      h.reserved[0] != want.reserved[0]) {
+      h.reserved[0] != want.reserved[0] || h.reserved[1] != want.reserved[1]) {
     fclose(f);
     set_error("checkpoint shape (p=%llu k=%d mode=%d kind=%d) does not match the engine (p=%llu k=%d mode=%d kind=%d)", (unsigned long long)h.p, h.k, h.mode,
               h.kind, (unsigned long long)want.p, want.k, want.mode, want.kind);
@@ -1752,21 +1779,21 @@ static int vsweep_impl(fmx_engine* e, fmx_matrix* m, double* error, double alpha
   FMX_CHECK(error != nullptr || m->n == 0, FMX_ERR_INVALID, "error is NULL");
   FMX_TRY(use_device(e->cfg.device));
   if (m->n == 0 || e->k == 0) return FMX_OK;
-  double *d_err = nullptr, *d_q = nullptr, *d_z = nullptr;
+  double *d_err = nullptr, *d_z = nullptr;
   const size_t bytes = (size_t)m->n * sizeof(double);
   const size_t zbytes = (size_t)e->k * (size_t)e->p * sizeof(double);
   FMX_HIP(hipMalloc(&d_err, bytes));
-  if (hipMalloc(&d_q, 2 * bytes) != hipSuccess || (std_normals && hipMalloc(&d_z, zbytes) != hipSuccess)) {  // interleaved (q, e) pairs
-    (void)hipFree(d_err); (void)hipFree(d_q);
+  if (std_normals && hipMalloc(&d_z, zbytes) != hipSuccess) {
+    (void)hipFree(d_err);
     set_error("out of device memory");
     return FMX_ERR_HIP;
   }
   int st = FMX_OK;
   if (hipMemcpy(d_err, error, bytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the residual failed"); st = FMX_ERR_HIP; }
   if (st == FMX_OK && std_normals && hipMemcpy(d_z, std_normals, zbytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the normal draws failed"); st = FMX_ERR_HIP; }
-  if (st == FMX_OK) st = launch_als_vsweep(e, m, d_err, d_q, alpha, v_lambda, v_mu, d_z);
+  if (st == FMX_OK) st = launch_als_vsweep_device(e, m, d_err, alpha, v_lambda, v_mu, d_z);  // the (q, e) pairs live in the engine
   if (st == FMX_OK && hipMemcpy(error, d_err, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("download of the residual failed"); st = FMX_ERR_HIP; }
-  (void)hipFree(d_err); (void)hipFree(d_q); (void)hipFree(d_z);
+  (void)hipFree(d_err); (void)hipFree(d_z);
   return st;
 }
 

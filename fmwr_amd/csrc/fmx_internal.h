@@ -174,6 +174,7 @@ struct fmx_matrix {
   std::vector<int64_t> als_vh_ptr, als_vseg_ptr;   // per level
   std::vector<int32_t> als_level_of;    // [p] level (exact plan) or group (approximate plan) of every feature
   int als_approx = 0;                   // the plan holds the groups of the approximate sweep, not exact levels
+  int als_force_exact = 0;              // an approximate sweep raised the residual on this matrix: only exact plans from now on
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
 };
 
@@ -200,6 +201,14 @@ struct fmx_engine {
   uint64_t p = 0;
   int k = 0;
   int kp32 = 0;  // padded factor count of the fp32 tables (multiple of 4)
+  // fp32 mini-batch tables, "w in the row" layout: V rows lie vstride32 floats apart; with w_in_row = 1 the stride is 2 * kp32 and
+  // the feature's linear weight sits in slot kp32 of its own row (V[16] | w | ... in ONE 128-byte line for k = 16), e->w is null.
+  // Out of the caches a nonzero then costs one memory request instead of two (V row + w: measured at p = 16 M, 14.8 M of the
+  // 15.7 M fabric reads of a phase-1 launch were those two misses per nonzero, profiles/r03_pmc_summary_p16m.json), and phase 2's
+  // sparse walk touches one line per feature.  Chosen at engine creation (p >= 8 M and kp32 <= 16; FMX_W_IN_ROW=0/1 overrides):
+  // cache-resident tables gain nothing and a dense phase-2 sweep would stream twice the bytes.
+  int vstride32 = 0;
+  int w_in_row = 0;
   int kp64 = 0;  // padded factor count of the fp64 tables (multiple of 2)
   hipStream_t stream = nullptr;
   double* scal = nullptr;       // [SC_COUNT] current scalars (one half of scal_base)
@@ -255,8 +264,12 @@ struct fmx_engine {
   int64_t als_qe_new_rows = 0;
   double* als_Q = nullptr;         // q of every factor, [n][kp64], made by one forward pass per V sweep (grow-only)
   size_t als_Q_elems = 0;
-  void* als_qe = nullptr;          // (q, e) pairs of fmx_vsweep_device (grow-only)
+  void* als_qe = nullptr;          // (q, e) pairs of the learners' loops and of fmx_vsweep_device (grow-only)
   int64_t als_qe_rows = 0;
+  void* als_dyn = nullptr;         // device struct the sweep kernels read factor / alpha / lambda / mu / normals from (fm_als_kernels.hip)
+  void *als_graph_w = nullptr, *als_graph_v = nullptr;  // deep exact plans replayed as HIP graphs (AlsGraph)
+  double* als_backup = nullptr;    // what an approximate sweep is rolled back to when it raises the residual
+  size_t als_backup_elems = 0;
   fmx::Group* group = nullptr;     // cfg.n_gpus > 1: the other replicas and the exchange between them (fm_group.hip)
   void* gbuf = nullptr;       // multi-GPU exchange buffer (element type = state type)
   int64_t gbuf_floats = 0;    // its element count
@@ -294,6 +307,12 @@ inline bool wide_state(const fmx_engine* e) { return e->cfg.mode == FMX_MODE_SEQ
 inline int mb_kp(const fmx_engine* e) { return mb_wide(e) ? e->kp64 : e->kp32; }        // padded factor count of the mini-batch tables
 inline int mb_lpr(const fmx_engine* e) { return mb_wide(e) ? e->kp64 / 2 : e->kp32 / 4; } // lanes per row / per feature list (16 B each)
 inline size_t mb_elem(const fmx_engine* e) { return mb_wide(e) ? sizeof(double) : sizeof(float); }
+// where the mini-batch kernels find V rows and w: element stride between consecutive features' V rows, the address of feature 0's w,
+// and the element stride between consecutive features' w
+inline int mb_vstride(const fmx_engine* e) { return mb_wide(e) ? e->kp64 : e->vstride32; }
+inline void* mb_vbase(const fmx_engine* e) { return mb_wide(e) ? (void*)e->dV : (void*)e->V; }
+inline void* mb_wbase(const fmx_engine* e) { return mb_wide(e) ? (void*)e->dw : (e->w_in_row ? (void*)(e->V + e->kp32) : (void*)e->w); }
+inline int mb_wstride(const fmx_engine* e) { return (!mb_wide(e) && e->w_in_row) ? e->vstride32 : 1; }
 // the exchange carries the sums of squared gradients too: solvers with an accumulated-square state, when the batch is SUMMED
 inline bool exchange_has_q(const fmx_engine* e) { return (e->hyper.kind == UPD_FTRL || e->hyper.kind == UPD_TDAP) && !e->hyper.mean; }
 
@@ -305,8 +324,9 @@ struct RowsArgs {
   const float* y;       // may be null when !train
   int64_t r0;           // first row (global index into the matrix)
   int64_t nrows;        // rows to process
-  const void* V;        // [p][kp] float or double
-  const void* w;        // [p]
+  const void* V;        // [p][vs] float or double: the first kp elements of a row are the factors
+  const void* w;        // feature j's linear weight at w[j * ws]
+  int vs, ws;           // element strides (kp and 1, or the w-in-row layout's 2 kp and 2 kp)
   const double* scal;
   void* S;              // [nrows][kp]   (train) element type of the tables
   void* amul;           // [nrows]       (train)
@@ -473,6 +493,7 @@ int launch_mcmc_train(fmx_engine* e, fmx_matrix* m, int max_iter, const double* 
 int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_normals, double* v_lambda, double* v_mu, int sample);
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu,
                       const double* d_znorm);
+void als_graph_free(void* g);
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 
 int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);

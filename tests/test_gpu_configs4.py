@@ -197,3 +197,61 @@ def test_configs4_full_size_split_columns_equal_the_unsplit_form(monkeypatch):
             mm.close()
     assert util.rel_err(out[0][0], out[1][0]) < 1e-10 and util.rel_err(out[0][1], out[1][1]) < 1e-10
     m.close()
+
+
+def test_an_approximate_sweep_that_raises_the_residual_falls_back_to_the_exact_schedule():
+    """cfg.als_max_levels asks for the grouped (approximate) form; five features that always occur together and land in one group
+    step against the same snapshot and overshoot fivefold -- the residual's sum of squares goes UP.  The engine notices, puts V and the
+    residual back, marks the matrix exact-only and runs the sweep through the level schedule: the caller gets the exact sweep's result
+    (the approximate form used to return 1e22 silently on Zipf columns)."""
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(3)
+    S = [1000, 1001, 1002, 1003, 1004]
+    rows = [np.array(S, np.uint32) for _ in range(1500)]
+    for s in S:                                                    # "lift" rows: every feature of S takes position 4 somewhere -> one group
+        rows += [np.array([10, 11, 12, 13, s], np.uint32) for _ in range(40)]
+    order = rng.permutation(len(rows))
+    rows = [rows[i] for i in order]
+    n, p, k = len(rows), 1100, 4
+    rp = np.arange(n + 1, dtype=np.int64) * 5
+    col = np.concatenate(rows); val = np.ones(len(col), np.float32)
+    y = util.labels(n, 3, "regression")
+    w0, w, v = util.params(p, k, 3, stdev=0.3, fp32=False)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=2)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    groups, _, approx, group_of = e.als_plan(m)
+    assert approx and len(set(group_of[S])) == 1                   # the approximate plan, S in one group
+    gerr = e.als_vsweep(m, err0)
+    assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    assert np.sum(gerr ** 2) < np.sum(err0 ** 2)
+    assert not e.als_plan(m)[2]                                    # exact from now on
+
+
+def test_deep_plans_replayed_as_a_graph_equal_the_eager_launches(monkeypatch):
+    """i.i.d. columns: hundreds of levels of a few features.  The level launches of one factor are captured once as a HIP graph and
+    replayed per factor (fm_als_kernels.hip: sweep_graph); FMX_ALS_GRAPH=0 launches them eagerly.  Same kernels, same order: same bits,
+    ALS and Gibbs forms, two sweeps (the second replays the first's graph)."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "iid", n, p, 51, "normal")
+    w0, w, v = util.params(p, K, 29, stdev=0.1, fp32=False)
+    z = np.random.default_rng(8).normal(0, 1, (K, p))
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_GRAPH", flag)
+        for gibbs in (False, True):
+            e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=K, mode=L.MODE_SEQUENTIAL)
+            e.set_params(w0, w, v)
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            err = e.predict(m) - y
+            lam = np.full(K, 1.5)
+            err = e.als_vsweep(m, err, alpha=1.1, v_lambda=lam, std_normals=z if gibbs else None)
+            err = e.als_vsweep(m, err, alpha=0.9, v_lambda=lam, std_normals=z if gibbs else None)
+            out[(flag, gibbs)] = (err, e.get_params()[2])
+    for gibbs in (False, True):
+        assert np.array_equal(out[("1", gibbs)][0], out[("0", gibbs)][0]) and np.array_equal(out[("1", gibbs)][1], out[("0", gibbs)][1])

@@ -859,6 +859,50 @@ def test_als_approximate_grouped_sweep(fm):
     assert util.rel_err(outs[1][1], outs[0][1]) < 1e-12 and util.rel_err(outs[1][0], outs[0][0]) < 1e-12
 
 
+def test_als_approximate_sweep_against_a_dense_least_squares_restatement(fm):
+    """An independent pin for the grouped (approximate) sweep: nothing entry-wise, no CSC walk -- per factor and group, every feature
+    of the group takes the minimiser of its own one-dimensional regularised least-squares problem against the group's residual
+    snapshot (np.linalg.lstsq on the stacked system [sqrt(alpha) h; sqrt(lambda)] d = -[sqrt(alpha) e; sqrt(lambda) (v - mu)], with
+    h = d y_hat / d v_jf = x_j (q - x_j v_jf) from DENSE matrices), then the snapshot moves by the linearised corrections
+    (q += X_G d, e += H d).  The statement of the method (solver/MCMC_ALS_Learner.h:200-268 with one "thread" per feature of a
+    group), not a transcription of the kernel."""
+    engine, L = fm
+    rng = np.random.default_rng(33)
+    n, p, z, k = 400, 60, 5, 3
+    cols = np.sort(np.stack([rng.choice(p, z, replace=False) for _ in range(n)]), axis=1)
+    rp = np.arange(n + 1, dtype=np.int64) * z
+    col = cols.astype(np.uint32).ravel(); val = rng.normal(0, 1, n * z).astype(np.float32)
+    y = util.labels(n, 33, "regression")
+    w0, w, v = util.params(p, k, 33, stdev=0.3, fp32=False)
+    alpha, lam, mu = 1.3, np.array([0.5, 0.0, 2.0]), np.array([0.05, -0.1, 0.0])
+    Xd = np.zeros((n, p)); Xd[np.repeat(np.arange(n), z), col.astype(np.int64)] = val.astype(np.float64)
+    e_res = (w0 + Xd @ w + 0.5 * (((Xd @ v.T) ** 2).sum(1) - ((Xd ** 2) @ (v.T ** 2)).sum(1))) - y    # e = y_hat - y, dense
+    eng = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=4)
+    eng.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    groups, _, approx, group_of = eng.als_plan(m)
+    assert approx and groups == z
+    got_err = eng.als_vsweep(m, e_res, alpha=alpha, v_lambda=lam, v_mu=mu)
+    got_v = eng.get_params()[2]
+    V = v.copy(); e = e_res.copy()
+    for f in range(k):
+        q = Xd @ V[f]
+        for g in range(groups):
+            G = np.flatnonzero(group_of == g)
+            G = G[(Xd[:, G] != 0).any(0)]                      # features that never occur keep their value (an empty column: no step)
+            H = Xd[:, G] * q[:, None] - (Xd[:, G].astype(np.float32) ** 2).astype(np.float64) * V[f, G][None, :]   # x*x is a float product (:314)
+            d = np.zeros(len(G))
+            for a_, j in enumerate(G):
+                A = np.concatenate([np.sqrt(alpha) * H[:, a_], [np.sqrt(lam[f])]])[:, None]
+                b = -np.concatenate([np.sqrt(alpha) * e, [np.sqrt(lam[f]) * (V[f, j] - mu[f])]])
+                d[a_] = np.linalg.lstsq(A, b, rcond=None)[0][0]
+            V[f, G] += d
+            q += Xd[:, G] @ d
+            e += H @ d
+    assert util.rel_err(got_v, V) < 1e-9 and util.rel_err(got_err, e) < 1e-9
+    assert np.any(np.abs(got_v - v) > 1e-3)
+
+
 def test_als_heavy_columns_match_oracle(fm):
     """A feature that occurs in (almost) every row has a column of thousands of entries: it is swept by a whole workgroup
     (als_sweep_k) instead of one wave; exact schedule, against the oracle."""

@@ -215,3 +215,86 @@ def test_tdap_minibatch_reduces_to_the_reference_step():
     mb.step(0, 3)
     sigma = np.sqrt(mb.sw[0]) / P.alpha_w
     assert abs(mb.sw[2] - np.exp(-1.5) * sigma) < 1e-15   # delta of w[0] after one step of c = 3 touches
+
+
+# ---- independent pins for the mini-batch TDAP semantics (fmo_tdap_apply_sums): no reference-held vector exists for it, so it is
+# checked against things that need no restatement of its own -----------------------------------------------------------------------
+def _tdap_coord_c_times(gs, theta, alpha, gamma, state=(0.0, 0.0, 0.0, 0.0)):
+    """c applications of the reference's per-example coordinate accumulation (solver/TDAP_Learner.h:97-105) with the parameter FROZEN at
+    theta -- written here from the source text, in numpy, independently of the oracle's C."""
+    u, nu, delta, h = state
+    for g in gs:
+        u_old = u
+        u = u + g * g
+        nu = nu + g
+        sigma = (np.sqrt(u) - np.sqrt(u_old)) / alpha
+        delta = np.exp(-gamma) * (delta + sigma)
+        h = np.exp(-gamma) * (h + sigma * theta)
+    return u, nu, delta, h
+
+
+def test_minibatch_tdap_on_feature_disjoint_rows_is_the_sequential_learner():
+    """Rows that share no feature, no w0 and no linear term: an example's step then touches nothing any other example reads, so
+    processing the batch at once (SUM: every coordinate occurs once) must equal the reference's sequential learner -- which the
+    Appendix-B known answers pin -- on the same rows."""
+    rng = np.random.default_rng(7)
+    n, z, k = 40, 5, 4
+    p = n * z
+    col = rng.permutation(p).astype(np.uint32).reshape(n, z)
+    col.sort(axis=1)
+    rp = np.arange(n + 1, dtype=np.int64) * z
+    val = rng.normal(0, 1, n * z).astype(np.float32)
+    y = util.labels(n, 7)
+    _, w, v = util.params(p, k, 7, stdev=0.2, fp32=False)
+    X = oracle.Matrix(rp, col.ravel(), val, p)
+    for task in (oracle.CLASSIFICATION, oracle.REGRESSION):
+        P = oracle.params(task=task, k=k, k0=False, k1=False, l1_regv=1e-3, l2_regv=1e-2, gamma=1e-3, batch_mean=False)
+        ref = oracle.tdap_learn(P, X, y, 0.0, w, v.ravel(), n, order=np.arange(n))
+        mb = oracle.TdapMinibatch(P, X, y, 0.0, w, v.ravel())
+        mb.step(0, n)
+        assert util.rel_err(mb.v, ref["v"]) < 1e-13
+        assert np.any(mb.v != v.ravel())
+
+
+def test_minibatch_tdap_with_c_occurrences_against_c_frozen_reference_steps():
+    """One feature occurring c times in the batch (k = 0, no w0: the gradients are mult_i * x_i at the frozen w).  Against c
+    applications of the reference's coordinate accumulation with frozen gradients (restated above from the source text): u and nu are
+    exact (the sigmas telescope); delta and h are exact at gamma = 0 and differ by at most gamma * c * |accumulated sigma| otherwise
+    (the batch enters its whole sigma before ageing c times: first order in gamma * c)."""
+    rng = np.random.default_rng(9)
+    c, p, j = 7, 3, 1
+    x = rng.normal(0, 1, c).astype(np.float32)
+    y = np.where(rng.random(c) < 0.5, -1.0, 1.0).astype(np.float32)
+    rp = np.arange(c + 1, dtype=np.int64)
+    col = np.full(c, j, np.uint32)
+    X = oracle.Matrix(rp, col, x, p)
+    theta = 0.3
+    w = np.zeros(p); w[j] = theta
+    xd, yd = x.astype(np.float64), y.astype(np.float64)
+    mult = -yd * (1.0 - 1.0 / (1.0 + np.exp(-yd * (theta * xd))))          # calculate_grad_mult, CLASSIFICATION (TDAP_Learner.h:235-246)
+    gs = mult * xd
+    for gamma in (0.0, 1e-3, 5e-2):
+        P = oracle.params(k=0, k0=False, k1=True, l1_regw=1e-4, l2_regw=1e-2, alpha_w=0.1, gamma=gamma, batch_mean=False)
+        mb = oracle.TdapMinibatch(P, X, y, 0.0, w, np.zeros(1))
+        mb.step(0, c)
+        u, nu, delta, h, zz = (mb.sw[q * p + j] for q in range(5))
+        ru, rnu, rdelta, rh = _tdap_coord_c_times(gs, theta, 0.1, gamma)
+        assert abs(u - ru) < 1e-15 * max(1.0, ru) and abs(nu - rnu) < 1e-15 * max(1.0, abs(rnu))
+        sigma_total = np.sqrt(ru) / 0.1
+        bound = gamma * c * sigma_total * max(1.0, abs(theta)) + 1e-14
+        assert abs(delta - rdelta) <= bound and abs(h - rh) <= bound
+        if gamma == 0.0:
+            assert abs(delta - rdelta) < 1e-13 and abs(h - rh) < 1e-13
+        assert abs(zz - (nu - h)) < 1e-15
+        # the prox on the batch's own state: TDAP_Learner.h:208-213
+        want = 0.0 if abs(zz) <= 1e-4 else -(zz - np.sign(zz) * 1e-4) / (delta + 1e-2)
+        assert abs(mb.w[j] - want) < 1e-14
+        # ... and a coordinate that does not occur keeps its value and its state
+        assert mb.w[0] == 0.0 and mb.sw[0] == 0.0
+    # MEAN: the c occurrences become one pseudo-example with the mean gradient
+    P = oracle.params(k=0, k0=False, k1=True, alpha_w=0.1, gamma=1e-3, batch_mean=True)
+    mb = oracle.TdapMinibatch(P, X, y, 0.0, w, np.zeros(1))
+    mb.step(0, c)
+    ru, rnu, rdelta, rh = _tdap_coord_c_times([gs.mean()], theta, 0.1, 1e-3)
+    got = [mb.sw[q * p + j] for q in range(4)]
+    assert np.allclose(got, [ru, rnu, rdelta, rh], rtol=1e-14, atol=1e-16)
