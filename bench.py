@@ -110,6 +110,13 @@ def algorithmic_bytes(z, k, p, rows, e=4, ftrl=False):
     return rows_fwd, cols_upd, survey_step
 
 
+def tile_kp(k):
+    kp = 4
+    while kp < k:
+        kp *= 2
+    return kp
+
+
 def effective_tile(B, k, tile_rows):
     want = tile_rows or (524_288 if k > 8 else 262_144)  # fmx_api.hip effective_tile_rows(): kp32 >= 16
     tiles = -(-B // want)
@@ -222,28 +229,71 @@ def timed_steps(e, m, nb, steps, warmup):
     return time.perf_counter() - t0
 
 
+def gather_ceilings(args, engine, kernels, tile_rows, v_row_elems=None, sparse_lists=0):
+    """The access pattern's own ceiling at each kernel's table, measured in this run (fmx_measure_gather: uniformly random rows, ids
+    generated in registers): rows of the V table for phase 1 (in the w-in-row layout a row is the whole 2 * kp-float line), rows of the
+    tile's S table for phase 2.  `ceiling_frac` = the kernel's row gathers per second over that rate."""
+    z, k, p = args.nnz, args.factors, args.features
+    eb = 8 if args.state_fp64 else 4
+    kp = 4
+    while kp < k:
+        kp *= 2
+    ceil = {}
+    for name, elems, table_rows in (("fm_rows_forward", v_row_elems or kp, p), ("fm_cols_update", kp, tile_rows)):
+        row_bytes = min(256, max(16, elems * eb))
+        lines = max((elems * eb) // row_bytes, 1)  # rows wider than 256 B are fetched as several 256-B pieces
+        r = engine.measure_gather(table_rows * elems * eb, row_bytes, n_groups=tile_rows, per_group=32, in_flight=4, reps=20, device=0) / lines
+        got = tile_rows * z / (kernels[name][1] * 1e-3) if kernels[name][1] > 0 else 0.0
+        ceil[name] = {"table_MB": table_rows * elems * eb / 1e6, "row_bytes": elems * eb, "ceiling_rows_per_s": r, "kernel_rows_per_s": got, "ceiling_frac": got / r if r else None}
+    if sparse_lists > 0 and kernels["fm_cols_update"][1] > 0:
+        # A sparse tile's phase 2 is not only S-row gathers: per occurring feature it reads one random row of the V table and writes it back.
+        # Its floor is the sum of its parts at their own measured random-row rates (writes priced like reads): the S gathers from the tile's
+        # table, two random V-table rows per list.
+        rv, rs = ceil["fm_rows_forward"]["ceiling_rows_per_s"], ceil["fm_cols_update"]["ceiling_rows_per_s"]
+        floor_ms = (tile_rows * z / rs + 2.0 * sparse_lists / rv) * 1e3
+        c = ceil["fm_cols_update"]
+        c["s_row_gather_frac"] = c["ceiling_frac"]
+        c["parts_floor_ms"] = floor_ms
+        c["ceiling_frac"] = floor_ms / kernels["fm_cols_update"][1]
+        c["note"] = (f"sparse tile: {sparse_lists} lists; floor = entries / (S-table random-row rate) + 2 x lists / (V-table random-row rate), both measured here; "
+                     "ceiling_frac = floor / measured launch time")
+    return ceil
+
+
 def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows):
     """What `value` does not say; every figure is measured here, on this GPU, in this run."""
     out = {}
     z, k, p = args.nnz, args.factors, args.features
     n = m.n
-    # one-off ingest amortised over the reference's default run length (2 passes, R/fm_train.R:92) and over one pass
-    out["end_to_end"] = {"csc_build_s": csc_build_s, "one_epoch_examples_per_s": n / (csc_build_s + n / value),
-                         "two_epochs_examples_per_s": 2 * n / (csc_build_s + 2 * n / value),
-                         "note": "per-tile CSC build of the whole matrix (device radix sort, once per matrix) + training passes at `value`"}
-    # the access pattern's ceiling at each kernel's own table: random rows of kp*e bytes from V (phase 1) and from S (phase 2)
-    eb = 8 if args.state_fp64 else 4
-    kp = 4
-    while kp < k:
-        kp *= 2
-    row_bytes = min(256, max(16, kp * eb))
-    lines = (kp * eb) // row_bytes  # rows wider than 256 B are fetched as several 256-B pieces
-    ceil = {}
-    for name, table in (("fm_rows_forward", p * kp * eb), ("fm_cols_update", tile_rows * kp * eb)):
-        r = engine.measure_gather(table, row_bytes, n_groups=tile_rows, per_group=32, in_flight=4, reps=20, device=0) / max(lines, 1)
-        got = tile_rows * z / (kernels[name][1] * 1e-3) if kernels[name][1] > 0 else 0.0
-        ceil[name] = {"table_MB": table / 1e6, "row_bytes": kp * eb, "ceiling_rows_per_s": r, "kernel_rows_per_s": got, "ceiling_frac": got / r if r else None}
-    out["gather_ceiling"] = ceil
+    # MEASURED, not computed: a fresh matrix and a fresh engine, the clock around { per-tile plan build of the whole matrix + one full
+    # pass over its rows } (the reference's default run is two passes, R/fm_train.R:92: the second pass costs n / value more)
+    B = min(args.batch_rows, n)
+    m2 = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=0)
+    e2 = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
+    e2.set_params(0.0, None, v0.astype(np.float64))
+    e2.sync()
+    t0 = time.perf_counter()
+    nb2 = e2.num_batches(m2)
+    e2.sync()
+    t_plan = time.perf_counter() - t0
+    for b in range(nb2):
+        e2.step(m2, b)
+    e2.sync()
+    t_all = time.perf_counter() - t0
+    out["end_to_end"] = {"measured": True, "plan_build_s": t_plan, "plan_and_one_pass_s": t_all, "one_epoch_examples_per_s": n / t_all,
+                         "two_epochs_examples_per_s": 2 * n / (t_all + n / value), "first_plan_build_s_of_the_bench_matrix": csc_build_s,
+                         "note": "wall clock around the per-tile plan build of the 10 M-row matrix (device radix sort, once per matrix) plus ONE pass over all its rows, "
+                                 "the last ragged step and phase 1's 14 schedule-trial launches included; two passes = that + n / value"}
+    e2.close(); m2.close()
+    # SURVEY 8(d)'s column law: i.i.d. uniform columns, sorted inside the row (the headline matrix draws one column per stratum)
+    mi = engine.Matrix.synthetic_iid(n, p, z, args.seed)
+    ei = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
+    ei.set_params(0.0, None, v0.astype(np.float64))
+    nbi = max(1, n // B)
+    timed_steps(ei, mi, nbi, 16, 2)   # schedule trials
+    out["value_iid_uniform"] = {"value": B * args.steps / timed_steps(ei, mi, nbi, args.steps, 2), "unit": "examples/s",
+                                "note": "the same configuration on fmx_matrix_synthetic_iid (columns i.i.d. uniform over [0, p), sorted inside the row: SURVEY 8(d)'s generator)"}
+    ei.close(); mi.close()
     if args.state_fp64:
         return out
     # the reference's precision in the throughput mode
@@ -696,10 +746,32 @@ def main():
         }
         if fwd_rate is not None:
             out["forward_rows_per_s"] = fwd_rate
-        if world == 1 and not args.no_extras:
-            out.update(side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows))
+        if world == 1:
+            # every line carries the measured ceiling of its own access pattern
+            v_row = 2 * tile_kp(k) if (e.w_in_row() and not args.state_fp64) else None
+            out["gather_ceiling"] = gather_ceilings(args, engine, kernels, tile_rows, v_row, p_walk if (criteo or sparse_tiles) else 0)
             for name, c in out["gather_ceiling"].items():
                 out["roofline"]["kernels"][name]["ceiling_frac"] = c["ceiling_frac"]
+        # A fraction above 1 says the bytes priced are not the bytes moved: the step's `frac` then switches to the
+        # design's own algorithmic bytes (what the two kernels have to move per step) and the SURVEY 8(d) figure stays beside it
+        rf = out["roofline"]
+        tiles_per_step = -(-B // tile_rows)
+        design_step = tiles_per_step * (b_fwd + b_upd)
+        rf["design_bytes_per_example"] = design_step / B
+        if rf["frac"] > 1.0:
+            rf["survey_priced_frac"] = rf["frac"]
+            rf["frac"] = design_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
+            rf["achieved"] = design_step / (dt / args.steps) / 1e9
+            rf["frac_note"] = ("SURVEY 8(d) prices a read-modify-write of theta, z, n per OCCURRENCE (the reference's per-example loop); the two-phase design touches "
+                               "them once per feature per tile, so the step moves design_bytes_per_example, not algorithmic_bytes_per_example: `frac` is on the former")
+        for name, kk in rf["kernels"].items():
+            if kk["frac"] > 1.0:
+                kk["hbm_priced_frac"] = kk["frac"]
+                kk["frac"] = kk.get("ceiling_frac")
+                kk["frac_note"] = ("the rows this kernel gathers are served by L2 / the Infinity Cache (skewed columns: the heads are re-read on-die), so its algorithmic "
+                                   "bytes over the HBM peak exceed 1; `frac` is the kernel's row rate over the measured random-row ceiling of its table instead")
+        if world == 1 and not args.no_extras:
+            out.update(side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows))
         if world == 1 and args.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(m, args, v0)
         print(json.dumps(out), flush=True)

@@ -29,7 +29,7 @@ SYMBOLS = [
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset", "fmx_rows_tune_info", "fmx_measure_gather", "fmx_measure_gather_occ", "fmx_rccl_selftest",
     "fmx_get_rows", "fmx_set_rows", "fmx_init_normal", "fmx_compact_info", "fmx_compact_count", "fmx_compact_reserve", "fmx_grad_compact", "fmx_compact_records", "fmx_apply_compact",
     "fmx_debug_fail_next_plan_build", "fmx_vsweep_device", "fmx_source_open", "fmx_source_next", "fmx_source_close",
-    "fmx_apply_compact_parts", "fmx_owner_configure", "fmx_owner_info", "fmx_rows_pack", "fmx_rows_unpack",
+    "fmx_apply_compact_parts", "fmx_layout_info", "fmx_owner_configure", "fmx_owner_info", "fmx_rows_pack", "fmx_rows_unpack",
 ]
 
 

@@ -13,6 +13,7 @@
 // q and e live interleaved as one {q[r], e[r]} pair per row, so a stored nonzero costs one 16-byte gather (one line)
 // per pass instead of two.
 #include <cmath>
+#include <ctime>
 
 #include "fmx_internal.h"
 #include "fm_probit.h"
@@ -816,9 +817,13 @@ static void set_dyn(fmx_engine* e, SweepDyn* dyn, int f, double alpha, double la
 // sweep of one factor is 8 155 dependent launches of a microsecond each, and eager launches cost the host 3-4 us apiece -- the sweep
 // is HOST-bound (0.65 s for 16 factors = 5 us per level; a same-stream kernel boundary is 1.5 us on the device).  Since every
 // launch of a factor's sweep is identical for all factors and calls (SweepDyn), the sequence is captured ONCE per (plan, buffers)
-// and replayed: the device walks it at its own pace.  Plans of fewer than ALS_GRAPH_MIN_LEVELS levels stay eager (nothing to win,
-// and their level launches are what bench.py times).  FMX_ALS_GRAPH=0/1 overrides.  Same kernels, same order: same bits.
-constexpr int ALS_GRAPH_MIN_LEVELS = 256;
+// and replayed: the device walks it at its own pace.  Same kernels, same order: same bits (tests/test_gpu_configs4.py).
+// MEASURED (profiles/r03_als_graph_probe.txt): 8 155 nodes capture and instantiate in 13 ms, and the replayed sweep takes the SAME
+// 0.655 s as the eager one -- the sweep was never host-bound: the host enqueues a launch in 3.5 us, a level takes 5 us on the device
+// (its wave's chain of four dependent memory rounds: feature id -> column bounds -> entries -> (q, e) pairs), so the host runs
+// ahead either way.  The replay is therefore OFF unless FMX_ALS_GRAPH=1 asks for it; the record stays as the answer to "would a
+// graph (or a persistent level loop, whose grid barrier costs more than the 1.5 us kernel boundary) help": no.
+constexpr int ALS_GRAPH_MIN_LEVELS = 64;
 struct AlsGraph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -837,8 +842,7 @@ template <bool W>
 static bool sweep_graph_wanted(const fmx_matrix* m) {
   if (m->als_approx) return false;
   const char* v = getenv("FMX_ALS_GRAPH");
-  if (v) return v[0] == '1';
-  return (int)m->als_level_ptr.size() - 1 >= ALS_GRAPH_MIN_LEVELS;
+  return v && v[0] == '1' && (int)m->als_level_ptr.size() - 1 >= ALS_GRAPH_MIN_LEVELS;
 }
 // the replayable form of sweep_features<W>(e, m, d_qe, nullptr, dyn): null when capture is not possible (the caller then launches eagerly)
 template <bool W>
@@ -850,13 +854,29 @@ static hipGraphExec_t sweep_graph(fmx_engine* e, fmx_matrix* m, double2* d_qe, c
   als_graph_free(g);
   slot = nullptr;
   g = new AlsGraph();
-  if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); delete g; return nullptr; }
+  const bool verbose = getenv("FMX_ALS_GRAPH_VERBOSE") != nullptr;
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  hipError_t err = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+  if (err != hipSuccess) {
+    if (verbose) fprintf(stderr, "fmx: als graph: begin capture failed: %s\n", hipGetErrorString(err));
+    (void)hipGetLastError(); delete g; return nullptr;
+  }
   sweep_features<W>(e, m, d_qe, nullptr, dyn, /*profile=*/false);
-  if (hipStreamEndCapture(e->stream, &g->graph) != hipSuccess || g->graph == nullptr ||
-      hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+  err = hipStreamEndCapture(e->stream, &g->graph);
+  if (err == hipSuccess && g->graph != nullptr) err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (err != hipSuccess || g->graph == nullptr) {
+    if (verbose) fprintf(stderr, "fmx: als graph: capture / instantiate failed: %s\n", hipGetErrorString(err));
     (void)hipGetLastError();
     als_graph_free(g);
     return nullptr;
+  }
+  if (verbose) {
+    size_t nodes = 0;
+    (void)hipGraphGetNodes(g->graph, nullptr, &nodes);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    fprintf(stderr, "fmx: als graph (%s sweep): %zu nodes for %d levels, captured and instantiated in %.1f ms\n", W ? "w" : "V", nodes, L,
+            1e3 * ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec)));
   }
   g->matrix_uid = m->uid; g->qe = d_qe; g->feats = m->als_feats; g->plan_cap = m->als_plan_cap; g->levels = L;
   slot = g;

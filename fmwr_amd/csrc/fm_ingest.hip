@@ -73,6 +73,20 @@ __global__ void gather_i64_k(const int64_t* __restrict__ src, int64_t stride, in
   dst[i] = src[at < n ? at : n];
 }
 
+// The (column, row) pair sort of one-hot tiles: rocprim's tuned default for gfx950 sorts 8 bits per pass -- 25 bits of column id
+// (33 M features) are then FOUR passes, the last one for a single bit.  Nine bits per pass make it three.
+using PairSort9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 9,
+                                                                                 rocprim::block_radix_rank_algorithm::match>>;
+static bool nine_bit_passes(int bits) {
+  static const bool ok = [] { const char* v = getenv("FMX_SORT9"); return !(v && v[0] == '0'); }();
+  return ok && (bits + 8) / 9 < (bits + 7) / 8;
+}
+static hipError_t sort_pairs_u32(void* temp, size_t& bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits, hipStream_t stream) {
+  if (nine_bit_passes(bits)) return rocprim::radix_sort_pairs<PairSort9>(temp, bytes, kin, kout, vin, vout, n, 0, bits, stream);
+  return rocprim::radix_sort_pairs(temp, bytes, kin, kout, vin, vout, n, 0, bits, stream);
+}
+
 static int col_bits(uint32_t p) {
   int bits = 1;
   while (bits < 32 && (1ull << bits) < (uint64_t)p) ++bits;
@@ -138,6 +152,166 @@ static int csc_of_range(const fmx_matrix* m, SortScratch& s, int bits, int64_t r
 __global__ void head_flags_k(const uint32_t* __restrict__ keys, int64_t cnt, uint8_t* __restrict__ flags) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < cnt) flags[i] = (i == 0) || (keys[i] != keys[i - 1]);
+}
+
+// ---- ordered compaction without a flag array: which indices of [0, n) satisfy a predicate, in ascending order -------------------------
+// (rocprim::select over a byte-flag array cost 86 us per call at 10.2 M items -- two calls per streamed tile, a seventh of the step:
+// profiles/r03_stream_trace.txt.)  Three small launches: every block counts the hits among its CP_CHUNK consecutive indices, one block
+// scans the block counts, every block writes its hits behind its offset.  The predicate is evaluated twice instead of being stored.
+// n may live on the device (n_dev): blocks beyond it leave at once.
+constexpr int CP_THREADS = 256, CP_PER = 16, CP_CHUNK = CP_THREADS * CP_PER;
+struct HeadPred {   // index i starts a run of equal keys
+  const uint32_t* keys;
+  __device__ bool operator()(uint32_t i) const { return i == 0 || keys[i] != keys[i - 1]; }
+};
+struct LongPred {   // list i holds more than long_min entries
+  const uint32_t* off;
+  uint32_t long_min;
+  __device__ bool operator()(uint32_t i) const { return off[i + 1] - off[i] > long_min; }
+};
+template <typename Pred>
+__global__ __launch_bounds__(CP_THREADS) void compact_count_k(Pred pred, uint32_t n_fixed, const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ blk) {
+  __shared__ uint32_t red[CP_THREADS];
+  const uint32_t n = n_dev ? *n_dev : n_fixed;
+  const uint32_t b0 = blockIdx.x * CP_CHUNK;
+  uint32_t c = 0;
+  if (b0 < n) {
+    const uint32_t i0 = b0 + threadIdx.x * CP_PER;
+#pragma unroll
+    for (int u = 0; u < CP_PER; ++u) { const uint32_t i = i0 + u; if (i < n && pred(i)) ++c; }
+  }
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = CP_THREADS / 2; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) blk[blockIdx.x] = red[0];
+}
+// exclusive scan of the block counts in place (one block), total -> *total
+__global__ __launch_bounds__(1024) void compact_scan_k(uint32_t* __restrict__ blk, uint32_t n_blocks, uint32_t* __restrict__ total) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (n_blocks + 1023) / 1024;
+  const uint32_t b = threadIdx.x * per, e = b + per < n_blocks ? b + per : n_blocks;
+  uint32_t s = 0;
+  for (uint32_t i = b; i < e; ++i) s += blk[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan of the thread sums
+    const uint32_t v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (uint32_t i = b; i < e; ++i) { const uint32_t c = blk[i]; blk[i] = run; run += c; }
+  if (threadIdx.x == 1023) *total = part[1023];
+}
+// Emit(position, index) is called for every hit, positions ascending with the index
+template <typename Pred, typename Emit>
+__global__ __launch_bounds__(CP_THREADS) void compact_write_k(Pred pred, Emit emit, uint32_t n_fixed, const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ blk) {
+  __shared__ uint32_t sc[CP_THREADS];
+  const uint32_t n = n_dev ? *n_dev : n_fixed;
+  const uint32_t b0 = blockIdx.x * CP_CHUNK;
+  if (b0 >= n) return;
+  const uint32_t i0 = b0 + threadIdx.x * CP_PER;
+  uint32_t hit = 0, c = 0;
+#pragma unroll
+  for (int u = 0; u < CP_PER; ++u) { const uint32_t i = i0 + u; if (i < n && pred(i)) { hit |= 1u << u; ++c; } }
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < CP_THREADS; off <<= 1) {
+    const uint32_t v = (int)threadIdx.x >= off ? sc[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t pos = blk[blockIdx.x] + sc[threadIdx.x] - c;
+#pragma unroll
+  for (int u = 0; u < CP_PER; ++u) if (hit & (1u << u)) emit(pos++, i0 + u);
+}
+// The run heads of the sorted columns, specialised: the chunk's keys are staged through LDS with coalesced loads (a thread reading its
+// 16 consecutive keys straight from memory strides the wave over 4 KiB: 143 us per 10.2 M-entry tile against 25 us for the count).
+__global__ __launch_bounds__(CP_THREADS) void heads_count_k(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ blk) {
+  __shared__ uint32_t red[CP_THREADS];
+  const uint32_t b0 = blockIdx.x * CP_CHUNK;
+  uint32_t c = 0;
+#pragma unroll
+  for (int u = 0; u < CP_PER; ++u) {   // any order will do for a count: consecutive threads read consecutive keys
+    const uint32_t i = b0 + u * CP_THREADS + threadIdx.x;
+    if (i < n && (i == 0 || keys[i] != keys[i - 1])) ++c;
+  }
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = CP_THREADS / 2; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) blk[blockIdx.x] = red[0];
+}
+struct HeadEmit;
+__global__ __launch_bounds__(CP_THREADS) void heads_write_k(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ blk, uint32_t* __restrict__ soff,
+                                                            uint32_t* __restrict__ feat, const uint32_t* __restrict__ brow, const float* __restrict__ bval,
+                                                            uint32_t* __restrict__ row0, uint32_t* __restrict__ val0) {
+  __shared__ uint32_t sk[CP_THREADS * (CP_PER + 1) + 1];   // thread t's keys at sk[t * 17 + 1 + u] (the odd stride keeps the banks apart), sk[0] = the key before the chunk
+  __shared__ uint32_t sc[CP_THREADS];
+  const uint32_t b0 = blockIdx.x * CP_CHUNK;
+  if (b0 >= n) return;
+#pragma unroll
+  for (int u = 0; u < CP_PER; ++u) {
+    const uint32_t l = u * CP_THREADS + threadIdx.x, i = b0 + l;
+    if (i < n) sk[(l / CP_PER) * (CP_PER + 1) + 1 + (l % CP_PER)] = keys[i];
+  }
+  if (threadIdx.x == 0) sk[0] = b0 > 0 ? keys[b0 - 1] : 0u;
+  __syncthreads();
+  const uint32_t base = threadIdx.x * (CP_PER + 1) + 1;
+  uint32_t prev = threadIdx.x == 0 ? sk[0] : sk[base - 2];   // the previous thread's last key
+  uint32_t hit = 0, c = 0;
+#pragma unroll
+  for (int u = 0; u < CP_PER; ++u) {
+    const uint32_t i = b0 + threadIdx.x * CP_PER + u;
+    const uint32_t kk = sk[base + u];
+    if (i < n && (i == 0 || kk != prev)) { hit |= 1u << u; ++c; }
+    prev = kk;
+  }
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < CP_THREADS; off <<= 1) {
+    const uint32_t v = (int)threadIdx.x >= off ? sc[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t pos = blk[blockIdx.x] + sc[threadIdx.x] - c;
+#pragma unroll
+  for (int u = 0; u < CP_PER; ++u) {
+    if (hit & (1u << u)) {
+      const uint32_t i = b0 + threadIdx.x * CP_PER + u;
+      soff[pos] = i;
+      feat[pos] = sk[base + u];
+      if (row0) { row0[pos] = brow[i]; val0[pos] = bval ? __float_as_uint(bval[i]) : 0x3f800000u; }
+      ++pos;
+    }
+  }
+}
+
+struct HeadEmit {   // a run head: the list's start, its feature id and (tile plans) its first entry inline; the last hit also closes the directory
+  const uint32_t* keys; uint32_t* soff; uint32_t* feat; const uint32_t* brow; const float* bval; uint32_t* row0; uint32_t* val0;
+  __device__ void operator()(uint32_t pos, uint32_t i) const {
+    soff[pos] = i;
+    feat[pos] = keys[i];
+    if (row0) { row0[pos] = brow[i]; val0[pos] = bval ? __float_as_uint(bval[i]) : 0x3f800000u; }
+  }
+};
+struct LongEmit {
+  uint32_t* lpos;
+  __device__ void operator()(uint32_t pos, uint32_t i) const { lpos[pos] = i; }
+};
+__global__ void close_directory_k(uint32_t* __restrict__ soff, const uint32_t* __restrict__ n_lists, uint32_t cnt) { soff[*n_lists] = cnt; }
+
+template <typename Pred, typename Emit>
+static int compact_indices(Pred pred, Emit emit, uint32_t n_max, const uint32_t* n_dev, uint32_t* blk, uint32_t* total, hipStream_t stream) {
+  if (n_max == 0) { FMX_HIP(hipMemsetAsync(total, 0, sizeof(uint32_t), stream)); return FMX_OK; }
+  const uint32_t nb = (n_max + CP_CHUNK - 1) / CP_CHUNK;
+  hipLaunchKernelGGL((compact_count_k<Pred>), dim3(nb), dim3(CP_THREADS), 0, stream, pred, n_max, n_dev, blk);
+  hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, stream, blk, nb, total);
+  hipLaunchKernelGGL((compact_write_k<Pred, Emit>), dim3(nb), dim3(CP_THREADS), 0, stream, pred, emit, n_max, n_dev, (const uint32_t*)blk);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
 }
 
 // sparse directory: the run starts are in soff[0 .. n); add the ids and the end marker
@@ -236,15 +410,15 @@ int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense)
 
 PlanWorkspace::~PlanWorkspace() {
   (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(sort_temp); (void)hipFree(flags);
-  (void)hipFree(nseg); (void)hipFree(prim_temp);
+  (void)hipFree(nseg); (void)hipFree(prim_temp); (void)hipFree(blk);
 }
 
 int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
   if (cnt <= max_cnt && p_ == p && keys_out) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(stream));
   (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(sort_temp); (void)hipFree(flags);
-  (void)hipFree(nseg); (void)hipFree(prim_temp);
-  keys_out = nullptr; vals_in = vals_out = nullptr; sort_temp = nullptr; flags = nullptr; nseg = nullptr; prim_temp = nullptr;
+  (void)hipFree(nseg); (void)hipFree(prim_temp); (void)hipFree(blk);
+  keys_out = nullptr; vals_in = vals_out = nullptr; sort_temp = nullptr; flags = nullptr; nseg = nullptr; prim_temp = nullptr; blk = nullptr;
   max_cnt = 0;
   const size_t m = (size_t)(cnt > 0 ? cnt : 1);
   bits = col_bits(p_);
@@ -254,7 +428,7 @@ int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
   FMX_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, keys_out, vals_in, vals_out, m, 0, bits, stream));
   {
     size_t b32 = 0;  // the (u32, u32) sort of one-hot matrices
-    FMX_HIP(rocprim::radix_sort_pairs(nullptr, b32, (const uint32_t*)nullptr, keys_out, (uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, bits, stream));
+    FMX_HIP(sort_pairs_u32(nullptr, b32, (const uint32_t*)nullptr, keys_out, (const uint32_t*)nullptr, (uint32_t*)nullptr, m, bits, stream));
     if (b32 > sort_bytes) sort_bytes = b32;
   }
   FMX_HIP(hipMalloc(&sort_temp, sort_bytes ? sort_bytes : 16));
@@ -262,6 +436,7 @@ int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
   FMX_HIP(hipMalloc(&flags, nflag));
   const size_t cap_long = m / ((size_t)list_long_min() + 1) + 1;
   FMX_HIP(hipMalloc(&nseg, (cap_long + 2) * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&blk, (nflag / CP_CHUNK + 2) * sizeof(uint32_t)));
   // scratch of the device primitives: the largest of select over nflag items, max-scan over p + 1, sum-scan over cap_long + 1
   size_t b1 = 0, b2 = 0, b3 = 0;
   rocprim::counting_iterator<uint32_t> ids(0);
@@ -277,22 +452,73 @@ int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
   return FMX_OK;
 }
 
+// ---- field-structured rows (fmx_matrix::dense_prefix): split instead of sort ------------------------------------------------------
+// Every row is [dense columns 0..d-1 with real values | one one-hot entry per categorical field].  The sorted order of the tile then
+// starts with the d dense columns' lists, each simply the rows in order -- written directly, no sort -- and only the one-hot part
+// (z - d of z entries per row, values all 1) goes through the radix sort, as (column, row) u32 pairs: a third fewer entries at
+// 8 instead of 12 bytes per entry and pass.  One workgroup transposes FS_ROWS rows through LDS so that every output stream is
+// written in contiguous runs.
+constexpr int FS_ROWS = 64;
+__global__ __launch_bounds__(256) void fields_split_k(const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t nrows, int z, int d,
+                                                      uint32_t* __restrict__ keys_sorted, uint32_t* __restrict__ brow, float* __restrict__ bval,
+                                                      uint32_t* __restrict__ keys_in, uint32_t* __restrict__ rows_in) {
+  __shared__ uint32_t s_col[FS_ROWS * 64];
+  __shared__ float s_val[FS_ROWS * 64];
+  const int64_t R0 = (int64_t)blockIdx.x * FS_ROWS;
+  const int rows = (int)(nrows - R0 < FS_ROWS ? nrows - R0 : FS_ROWS);
+  const int cnt = rows * z;
+  for (int i = threadIdx.x; i < cnt; i += 256) { s_col[i] = col[R0 * z + i]; s_val[i] = val[R0 * z + i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < d * rows; i += 256) {   // dense column c: entries [c * nrows, (c + 1) * nrows) of the sorted order
+    const int c = i / rows, r = i - c * rows;
+    const int64_t at = (int64_t)c * nrows + R0 + r;
+    keys_sorted[at] = s_col[r * z + c];
+    brow[at] = (uint32_t)(R0 + r);
+    bval[at] = s_val[r * z + c];
+  }
+  const int zc = z - d;
+  for (int i = threadIdx.x; i < zc * rows; i += 256) {  // the one-hot part, row-major, compacted
+    const int r = i / zc, c = i - r * zc;
+    const int64_t at = R0 * zc + i;
+    keys_in[at] = s_col[r * z + d + c];
+    rows_in[at] = (uint32_t)(R0 + r);
+  }
+}
+
+__global__ void fill_ones_k(float* __restrict__ x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = 1.0f;
+}
+
 // Plan one tile: entries [t.base, t.base + t.cnt) of rows [t.r0, t.r0 + t.nrows), CSR arrays given explicitly (a streamed
 // tile has its own).  Enqueues on `stream`, never waits for it; t must come from plan_alloc with room for t.cnt entries.
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
-               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len) {
+               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix) {
   const int T = 256;
   const int64_t cnt = t.cnt;
   FMX_CHECK(cnt <= ws.max_cnt && p == ws.p, FMX_ERR_STATE, "plan workspace too small");
   FMX_CHECK(cnt < (1LL << 32), FMX_ERR_INVALID, "a tile holds %lld nonzeros; at most 2^32-1 are supported (lower tile_rows)", (long long)cnt);
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + T - 1) / T)); };
-  if (cnt > 0 && unit_values) {
+  const char* split_env = getenv("FMX_FIELDS_SPLIT");  // read per build: the tests compare both forms
+  const bool split_ok = !(split_env && split_env[0] == '0');
+  if (cnt > 0 && split_ok && !unit_values && dense_prefix > 0 && fixed_row_len > dense_prefix && fixed_row_len <= 64 &&
+      cnt == t.nrows * (int64_t)fixed_row_len) {
+    const int z = fixed_row_len, d = dense_prefix;
+    const int64_t n_dense = t.nrows * d, n_cat = cnt - n_dense;
+    uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws.vals_in);          // the u64 payload buffer holds both u32 inputs of the pair sort
+    uint32_t* rows_in = keys_in + n_cat;
+    hipLaunchKernelGGL(fields_split_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, val + t.base, t.nrows, z, d,
+                       ws.keys_out, brow + t.base, bval + t.base, keys_in, rows_in);
+    size_t tb32 = ws.sort_bytes;
+    FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, keys_in, ws.keys_out + n_dense, rows_in, brow + t.base + n_dense, (size_t)n_cat, ws.bits, stream));
+    hipLaunchKernelGGL(fill_ones_k, grid(n_cat), dim3(T), 0, stream, bval + t.base + n_dense, n_cat);
+  } else if (cnt > 0 && unit_values) {
     // one-hot values: sort (column, row) pairs straight into brow -- 8 bytes per entry and pass instead of 12, no unpack pass;
     // bval is never read for such a matrix
     uint32_t* rows32 = reinterpret_cast<uint32_t*>(ws.vals_in);
     hipLaunchKernelGGL(pack_rows_k, grid(cnt), dim3(T), 0, stream, row_ptr, t.r0, t.nrows, t.base, cnt, rows32, fixed_row_len);
     size_t tb32 = ws.sort_bytes;  // sized for the (u32, u64) sort of the same length: the (u32, u32) one needs no more
-    FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, tb32, col + t.base, ws.keys_out, rows32, brow + t.base, (size_t)cnt, 0, ws.bits, stream));
+    FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, col + t.base, ws.keys_out, rows32, brow + t.base, (size_t)cnt, ws.bits, stream));
   } else if (cnt > 0) {
     hipLaunchKernelGGL(pack_entries_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, ws.vals_in, fixed_row_len);
     FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, ws.sort_bytes, col + t.base, ws.keys_out, ws.vals_in, ws.vals_out, (size_t)cnt, 0, ws.bits, stream));
@@ -309,19 +535,22 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
     FMX_HIP(rocprim::inclusive_scan(ws.prim_temp, tb, t.off, t.off, (size_t)p + 1, rocprim::maximum<uint32_t>(), stream));
     off = t.off; n_max = p;
   } else {              // sparse directory: run starts -> soff, ids -> feat
+    // run heads of the sorted columns -> list starts, ids, first entries (one ordered compaction; dcounts[0] = the number of lists)
     if (cnt > 0) {
-      hipLaunchKernelGGL(head_flags_k, grid(cnt), dim3(T), 0, stream, ws.keys_out, cnt, ws.flags);
-      FMX_HIP(rocprim::select(ws.prim_temp, tb, ids, ws.flags, t.soff, t.dcounts, (size_t)cnt, stream));
+      const uint32_t nb = ((uint32_t)cnt + CP_CHUNK - 1) / CP_CHUNK;
+      hipLaunchKernelGGL(heads_count_k, dim3(nb), dim3(CP_THREADS), 0, stream, ws.keys_out, (uint32_t)cnt, ws.blk);
+      hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, stream, ws.blk, nb, t.dcounts);
+      hipLaunchKernelGGL(heads_write_k, dim3(nb), dim3(CP_THREADS), 0, stream, ws.keys_out, (uint32_t)cnt, (const uint32_t*)ws.blk, t.soff, t.feat,
+                         (const uint32_t*)(brow + t.base), unit_values ? (const float*)nullptr : (const float*)(bval + t.base), t.row0, t.val0);
     }
-    hipLaunchKernelGGL(lists_finish_k, grid((int64_t)t.cap_lists + 1), dim3(T), 0, stream, ws.keys_out, t.soff, t.dcounts, (uint32_t)cnt, t.feat,
-                       (const uint32_t*)(brow + t.base), unit_values ? (const float*)nullptr : (const float*)(bval + t.base), t.row0, t.val0);
+    hipLaunchKernelGGL(close_directory_k, dim3(1), dim3(1), 0, stream, t.soff, (const uint32_t*)t.dcounts, (uint32_t)cnt);
     off = t.soff; n_max = t.cap_lists;
   }
   // long lists
   if (cnt > (int64_t)list_long_min() && n_max > 0) {
-    hipLaunchKernelGGL(long_flags_k, grid(n_max), dim3(T), 0, stream, off, t.off_in_pool ? (const uint32_t*)nullptr : t.dcounts, p, n_max, list_long_min(), ws.flags);
-    tb = ws.prim_bytes;
-    FMX_HIP(rocprim::select(ws.prim_temp, tb, ids, ws.flags, t.lpos, t.dcounts + 1, (size_t)n_max, stream));
+    // lists longer than long_min, ascending (dense directory: among all p features; sparse: among the dcounts[0] lists)
+    FMX_TRY(compact_indices(LongPred{off, list_long_min()}, LongEmit{t.lpos}, t.off_in_pool ? p : n_max, t.off_in_pool ? (const uint32_t*)nullptr : (const uint32_t*)t.dcounts,
+                            ws.blk, t.dcounts + 1, stream));
     hipLaunchKernelGGL(long_nseg_k, grid((int64_t)t.cap_long + 1), dim3(T), 0, stream, off, t.lpos, t.dcounts, t.cap_long, ws.nseg);
     tb = ws.prim_bytes;
     FMX_HIP(rocprim::exclusive_scan(ws.prim_temp, tb, ws.nseg, t.lseg_ptr, 0u, (size_t)t.cap_long + 1, rocprim::plus<uint32_t>(), stream));
@@ -569,7 +798,7 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     // occurring features get a list (p = 33 M against 10 M entries per tile at configs[3]: no p-sized array per tile)
     FMX_TRY(plan_alloc(pl, m->p, cnt, cnt >= (int64_t)m->p));
     pl.r0 = tile_start[(size_t)t]; pl.nrows = tile_start[(size_t)t + 1] - pl.r0; pl.base = base; pl.cnt = cnt;
-    FMX_TRY(plan_build(pl, ws, m->p, m->row_ptr, m->col, m->val, L.brow, L.bval, stream, m->unit_values, m->fixed_row_len));
+    FMX_TRY(plan_build(pl, ws, m->p, m->row_ptr, m->col, m->val, L.brow, L.bval, stream, m->unit_values, m->fixed_row_len, m->dense_prefix));
     FMX_HIP(hipMemcpyAsync(L.h_counts + 4 * t, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   }
   FMX_HIP(hipStreamSynchronize(stream));
@@ -813,7 +1042,8 @@ __global__ void synth_fields_k(int64_t n, FieldSpec fs, uint64_t seed, int64_t r
     val[t] = (float)u;
   } else {
     const int f = (int)i - fs.n_dense;
-    const double x = fs.skew == 1.0 ? u : pow(u, fs.skew);
+    // (small integer exponents by multiplication: pow() in fp64 was most of this kernel's 98 us per 262 144-row tile)
+    const double x = fs.skew == 1.0 ? u : fs.skew == 2.0 ? u * u : fs.skew == 3.0 ? u * u * u : pow(u, fs.skew);
     uint32_t id = (uint32_t)(x * (double)fs.vocab[f]);
     if (id >= fs.vocab[f]) id = fs.vocab[f] - 1;
     col[t] = fs.base[f] + id;
@@ -1010,6 +1240,7 @@ int check_rows_sorted(fmx_matrix* m) {
   FMX_HIP(hipFree(d));
   m->rows_sorted = !h[0];
   m->max_row_len = h[1];
+  m->dense_prefix = 0;  // (only the field generator vouches for it; changed values may have broken it)
   // FMX_UNIT_VALUES=0 in the environment keeps the general path (tuning / A-B runs only)
   static const bool allow = [] { const char* v = getenv("FMX_UNIT_VALUES"); return !(v && v[0] == '0'); }();
   m->unit_values = (allow && !h[2]) ? 1 : 0;

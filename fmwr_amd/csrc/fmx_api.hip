@@ -361,6 +361,11 @@ static int cols_args(fmx_engine* e, fmx_matrix* m, const TileRun& t, bool sparse
   c.rows_active = (uint32_t)t.nrows;
   c.walk = 1;
   c.unit = m->unit_values;
+  // dense-prefix features of a field-structured tile: long lists of exactly nrows entries each, in row order (plan_build's split path)
+  if (m->dense_prefix > 0 && m->fixed_row_len > m->dense_prefix && !m->unit_values && pl.nrows > (int64_t)list_long_min() &&
+      pl.cnt == pl.nrows * (int64_t)m->fixed_row_len) {
+    c.pre_val = m->val + pl.base; c.pre_z = m->fixed_row_len; c.pre_d = m->dense_prefix; c.pre_rows = (uint32_t)pl.nrows;
+  }
   if (pl.feat && sparse_ok) {
     c.tfeat = pl.feat; c.toff = pl.soff; c.n_tfeat = pl.n_lists;
     c.trow0 = pl.row0; c.tval0 = pl.val0;
@@ -654,7 +659,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   if (cfg->mode == FMX_MODE_MINIBATCH && !cfg->state_fp64) {
     {  // layout of the V / w tables (fmx_internal.h: w_in_row)
       const char* v = getenv("FMX_W_IN_ROW");
-      const bool want = v ? v[0] == '1' : num_features >= 8000000ull;
+      const bool want = v ? v[0] == '1' : num_features >= 3000000ull;  // measured (profiles/r03_wir_ab.txt): 1 M features -0.4 %, 4 M +8 %, 16 M +6 %, 33 M +6 %
       e->w_in_row = (want && e->kp32 <= 16 && e->k > 0) ? 1 : 0;
       e->vstride32 = e->w_in_row ? 2 * e->kp32 : e->kp32;
     }
@@ -1040,6 +1045,7 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
   m->max_row_len = z;
   m->fixed_row_len = z;
   m->unit_values = (fs.n_dense == 0) ? 1 : 0;  // the dense features carry values in [0, 1)
+  m->dense_prefix = fs.n_dense;
   *out = m;
   return FMX_OK;
 }
@@ -1258,7 +1264,7 @@ static int stream_ingest(fmx_source* S, int64_t t) {
   else FMX_TRY(generate_synthetic_async(m, rows, S->z, S->seed, S->row_offset + t * S->B, S->ingest));
   auto& pl = m->plans[0];
   pl.r0 = 0; pl.nrows = rows; pl.base = 0; pl.cnt = rows * S->z;
-  FMX_TRY(plan_build(pl, S->ws, (uint32_t)S->p, m->row_ptr, m->col, m->val, m->brow, m->bval, S->ingest, m->unit_values, S->z));
+  FMX_TRY(plan_build(pl, S->ws, (uint32_t)S->p, m->row_ptr, m->col, m->val, m->brow, m->bval, S->ingest, m->unit_values, S->z, m->dense_prefix));
   FMX_HIP(hipMemcpyAsync(s.h_counts, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->ingest));
   if (S->owners > 1 && pl.feat) {  // the owner-major order of the tile's lists: the count is still on the device, so the whole directory is sorted
     FMX_TRY(plan_owner_build(pl, S->ows, S->owners, pl.own_cap, S->ingest));
@@ -1307,6 +1313,7 @@ int fmx_source_open(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_
     FMX_TRY(alloc_matrix(e->cfg.device, B, (uint32_t)S->p, cap_cnt, true, &s.m));
     s.m->rows_sorted = 1; s.m->max_row_len = S->z; s.m->fixed_row_len = S->z;
     s.m->unit_values = (S->has_spec && S->fs.n_dense > 0) ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
+    s.m->dense_prefix = S->has_spec ? S->fs.n_dense : 0;
     FMX_HIP(hipMalloc(&s.m->brow, (size_t)cap_cnt * sizeof(uint32_t)));
     FMX_HIP(hipMalloc(&s.m->bval, (size_t)cap_cnt * sizeof(float)));
     s.m->plans.resize(1);
@@ -1890,6 +1897,13 @@ int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double
   if (serial) *serial = e->rows_tune.decided;
   if (ms_serial) *ms_serial = e->rows_tune.ms[1];
   if (ms_pipelined) *ms_pipelined = e->rows_tune.ms[0];
+  return FMX_OK;
+}
+
+int fmx_layout_info(fmx_engine* e, int32_t* v_row_stride, int32_t* w_in_row) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  if (v_row_stride) *v_row_stride = wide_state(e) ? e->kp64 : e->vstride32;
+  if (w_in_row) *w_in_row = (!wide_state(e) && e->w_in_row) ? 1 : 0;
   return FMX_OK;
 }
 

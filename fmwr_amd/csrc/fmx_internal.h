@@ -104,6 +104,9 @@ struct fmx_matrix {
   int rows_sorted = 0;  // every row strictly ascending in col (=> no duplicate column inside a row)
   int fixed_row_len = 0; // > 0: every row holds exactly this many entries (row of an entry = a division, not a search)
   int unit_values = 0;  // every stored value is exactly 1.0f (one-hot data): the kernels then never read the value arrays
+  int dense_prefix = 0; // > 0 (with fixed_row_len): every row STARTS with the columns 0 .. dense_prefix-1 (always-present features with real
+                        // values) and every other stored value is exactly 1.0f -- Criteo-shaped rows.  The plan builder then sorts only the
+                        // one-hot part, as (column, row) pairs: the dense columns' lists are the rows in order (plan_build)
   int max_row_len = 0;  // entries of the longest row
   // Per-tile inverted index ("plan"), built lazily on the device for one (batch_rows, tile_rows) pair (fm_ingest.hip).
   // A step covers batch_rows consecutive rows and is cut into tiles of at most tile_rows rows.
@@ -205,7 +208,7 @@ struct fmx_engine {
   // the feature's linear weight sits in slot kp32 of its own row (V[16] | w | ... in ONE 128-byte line for k = 16), e->w is null.
   // Out of the caches a nonzero then costs one memory request instead of two (V row + w: measured at p = 16 M, 14.8 M of the
   // 15.7 M fabric reads of a phase-1 launch were those two misses per nonzero, profiles/r03_pmc_summary_p16m.json), and phase 2's
-  // sparse walk touches one line per feature.  Chosen at engine creation (p >= 8 M and kp32 <= 16; FMX_W_IN_ROW=0/1 overrides):
+  // sparse walk touches one line per feature.  Chosen at engine creation (p >= 3 M and kp32 <= 16; FMX_W_IN_ROW=0/1 overrides):
   // cache-resident tables gain nothing and a dense phase-2 sweep would stream twice the bytes.
   int vstride32 = 0;
   int w_in_row = 0;
@@ -326,7 +329,8 @@ struct RowsArgs {
   int64_t nrows;        // rows to process
   const void* V;        // [p][vs] float or double: the first kp elements of a row are the factors
   const void* w;        // feature j's linear weight at w[j * ws]
-  int vs, ws;           // element strides (kp and 1, or the w-in-row layout's 2 kp and 2 kp)
+  int vs, ws;           // element strides (kp and 1, or the w-in-row layout's 2 kp and 2 kp): powers of two
+  int vsh, wsh;         // their log2 (set by launch_rows_forward: the kernels shift instead of multiplying)
   const double* scal;
   void* S;              // [nrows][kp]   (train) element type of the tables
   void* amul;           // [nrows]       (train)
@@ -389,6 +393,11 @@ struct ColsArgs {
   int64_t list_entries;  // entries of the tile (sparse walk: decides `direct`)
   int embed;             // EmbedMode of the S rows (set by the launcher; must match phase 1's)
   int buf_gather;        // set by the launcher: S rows / multipliers are gathered through buffer descriptors (padding slots issue no request)
+  // field-structured tiles (fmx_matrix::dense_prefix): the first pre_d features occur in EVERY row of the tile, entry j of row r holding
+  // feature j -- their sums come from ONE pass over the S rows (fm_cols_prefix_k) instead of one long list each
+  const float* pre_val;  // the tile's CSR values, row 0 of the tile first (row-major, pre_z per row); null: no prefix pass
+  int pre_z, pre_d;
+  uint32_t pre_rows;     // rows of the tile
 };
 // long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
 struct LongArgs {
@@ -400,6 +409,7 @@ struct LongArgs {
   const uint32_t* seg_end;
   double* partial;            // [n_seg][2*kp+4] segment sums
   int64_t n_long, n_seg;
+  int64_t seg0;               // fm_cols_long_partial_k starts at this segment (the ones before it belong to the dense-prefix kernel)
 };
 // a list of more than this many entries is a long list (FMX_LONG_MIN in the environment overrides it: tuning only)
 inline uint32_t list_long_min() {
@@ -435,6 +445,7 @@ struct PlanWorkspace {
   size_t sort_bytes = 0;
   uint8_t* flags = nullptr;
   uint32_t* nseg = nullptr;
+  uint32_t* blk = nullptr;   // block counts of the ordered compactions (fm_ingest.hip: compact_indices)
   void* prim_temp = nullptr;
   size_t prim_bytes = 0;
   int reserve(int64_t cnt, uint32_t p, hipStream_t stream);
@@ -446,7 +457,7 @@ struct PlanWorkspace {
 int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense);
 void plan_free(fmx_matrix::TilePlan& t);
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
-               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len);
+               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix = 0);
 void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h);
 int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream);
 // scratch of the owner partition (a 4-bit radix sort of the directory), grow-only

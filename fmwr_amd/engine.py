@@ -462,6 +462,12 @@ class Engine:
         L.check(L.lib().fmx_profile_get(self.h, C.c_int(kernel), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def w_in_row(self):
+        """True when the fp32 tables use the w-in-row layout (fmx_layout_info)."""
+        a, b = C.c_int32(), C.c_int32()
+        L.check(L.lib().fmx_layout_info(self.h, C.byref(a), C.byref(b)))
+        return bool(b.value)
+
     def rows_tune(self):
         """(serial, ms_serial, ms_pipelined): phase 1's schedule for large steps as this engine measured it (fmx_rows_tune_info)."""
         d, a, b = C.c_int32(), C.c_double(), C.c_double()

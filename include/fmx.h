@@ -430,6 +430,10 @@ int fmx_profile_reset(fmx_engine* e);
  * such launches: *serial = 1 one entry's requests outstanding per lane group, 0 four entries', -1 not decided yet;
  * ms_serial / ms_pipelined = the six timed launches of each.  The choice never changes a result.  FMX_ROWS_SERIAL=0/1 pins it. */
 int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double* ms_pipelined);
+/* How the engine laid out its parameter tables: elements between consecutive features' V rows, and whether a feature's linear weight
+ * sits inside its V row (fp32 mini-batch tables of at most 16 padded factors, from 3 M features up: out of the caches a nonzero then
+ * costs one memory request instead of two; FMX_W_IN_ROW=0/1 in the environment overrides).  Never changes a result. */
+int fmx_layout_info(fmx_engine* e, int32_t* v_row_stride, int32_t* w_in_row);
 /* RCCL smoke test for cfg.n_gpus > 1: loads librccl, ncclCommInitAll over devices 0..n-1, one grouped fp32 and fp64
  * all-reduce(sum) of 1000 elements per rank on per-device streams, checked against the closed form; max_err = largest deviation. */
 int fmx_rccl_selftest(int32_t n, double* max_err);

@@ -75,8 +75,8 @@ def test_configs3_shape_minibatch_matches_oracle_on_the_touched_features(reduce)
 
 
 def test_streamed_training_equals_resident_training():
-    """fmx_train_stream (rows generated step by step, each step's inverted index built on a second stream while the previous
-    step trains, nothing kept) against the same rows trained from a resident matrix: bit for bit, for the uniform and for the
+    """fmx_train_stream (rows generated step by step, each step's inverted index built two steps ahead of the step that trains on
+    it, nothing kept) against the same rows trained from a resident matrix: bit for bit, for the uniform and for the
     Criteo-shaped generator, sparse and dense tiles, a ragged last step."""
     from fmwr_amd import _lib as L, engine
     vocab = [50_000, 20_000, 3_000, 400, 30, 4]
@@ -100,6 +100,49 @@ def test_streamed_training_equals_resident_training():
         pa, pb = a.get_params(), b.get_params()
         assert pa[0] == pb[0] and np.array_equal(pa[1], pb[1]) and np.array_equal(pa[2], pb[2])
         assert np.any(pa[2] != v0)
+
+
+def test_field_structured_plan_equals_the_general_sort(monkeypatch):
+    """Criteo-shaped rows (dense columns first, then one one-hot entry per field): the plan builder writes the dense columns' lists
+    directly and sorts only the one-hot part as (column, row) pairs (fm_ingest.hip: fields_split_k); FMX_FIELDS_SPLIT=0 sends the
+    whole tile through the general (column, row, value) sort.  Same plan: the same training bit for bit -- resident tiles (several per
+    matrix, a ragged last one) and streamed ones, and from a CSR upload of the same rows (which the builder does not recognise as
+    field-structured: the general path again)."""
+    from fmwr_amd import _lib as L, engine
+    vocab = [40_000, 9_000, 700, 40, 5, 3]
+    n, B, k = 4 * 2048 + 500, 2048, 8
+    p = 4 + sum(vocab)
+    kw = dict(num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
+    v0 = np.random.default_rng(4).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FMX_FIELDS_SPLIT", flag)
+        m = engine.Matrix.synthetic_fields(n, 4, vocab, 2.5, 31)
+        e = engine.Engine(p, **kw); e.set_params(0.0, None, v0)
+        assert e.train(m, n + 3 * B) == n + 3 * B
+        s = engine.Engine(p, **kw); s.set_params(0.0, None, v0)
+        assert s.train_stream(n, seed=31, fields=(4, vocab, 2.5))[0] == n
+        res[flag] = (e.get_params(), s.get_params())
+    monkeypatch.setenv("FMX_FIELDS_SPLIT", "1")
+    rp, col, val, y = engine.Matrix.synthetic_fields(n, 4, vocab, 2.5, 31).export()
+    u = engine.Engine(p, **kw); u.set_params(0.0, None, v0)
+    assert u.train(engine.Matrix.from_csr(rp, col, val, p, y), n + 3 * B) == n + 3 * B
+    same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert same(res["1"][0], res["0"][0]) and same(res["1"][1], res["0"][1]) and same(res["1"][0], u.get_params())
+    assert np.any(res["1"][0][2] != v0)
+    # the dense columns' sums from ONE pass over the S rows (fm_cols_prefix_k) against one long list each: the same partial sums in
+    # the same order, so the same bits -- SGD and FTRL (which also sums the squares), k = 8 and k = 16, a truncated step
+    for solver, k2 in ((L.SOLVER_SGD, 16), (L.SOLVER_FTRL, 8)):
+        out = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("FMX_PREFIX_PASS", flag)
+            m = engine.Matrix.synthetic_fields(n, 4, vocab, 2.5, 31)
+            e = engine.Engine(p, solver=solver, num_factor=k2, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver == L.SOLVER_FTRL else 0.0,
+                              mode=L.MODE_MINIBATCH, batch_rows=B, batch_reduce=L.REDUCE_SUM if solver == L.SOLVER_FTRL else L.REDUCE_MEAN)
+            e.init_normal(7, 0.0, 0.05)
+            assert e.train(m, n + B + 700) == n + B + 700
+            out.append(e.get_params())
+        assert same(out[0], out[1])
 
 
 def test_fields_generator_shape():
