@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   constexpr int KP = LPR * VEC;
   constexpr int NSUB = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const int64_t seg = la.seg0 + (int64_t)blockIdx.x * (WG_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t seg = (int64_t)blockIdx.x * (WG_THREADS / 64) + (threadIdx.x >> 6);
   if (seg >= la.n_seg) return;
   const int sub = lane / LPR, lig = lane % LPR;
   const int64_t j = la.lfeat[la.seg_feat[seg]];
@@ -1199,88 +1199,6 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   }
 }
 
-// ---- dense-prefix features of field-structured tiles --------------------------------------------------------------------------------
-// Criteo-shaped rows start with d always-present features (fmx_matrix::dense_prefix): each of them is a "long list" holding EVERY row of
-// the tile in order, and walking them one list at a time reads the whole S table d times (13 x 33 MB per 262 144-row step: 0.116 ms of
-// a 0.51 ms step).  Here one wave takes one LIST_SEG-row segment for DCH features AT ONCE: a row's S slice and multiplier are loaded
-// once, its d values come straight from the CSR row, and the wave leaves the same per-segment partial sums fm_cols_long_partial_k
-// would have left -- same rows per lane group, same order, same butterfly: bit for bit -- so fm_cols_long_finish_k finishes the
-// features as before.  Segment (feature j, rows [1024 s, ...)) is partial j * segs + s: the dense features are the first long lists.
-template <typename ST, int LPR, bool NEED_Q, int DCH>
-__global__ __launch_bounds__(WG_THREADS) void fm_cols_prefix_k(LongArgs la, ColsArgs a, ColsTables<ST> T, int d0, int dn, uint32_t segs) {
-  using vec_t = typename Slice<ST>::vec;
-  constexpr int VEC = Slice<ST>::N;
-  constexpr int KP = LPR * VEC;
-  constexpr int NSUB = 64 / LPR;
-  const int lane = threadIdx.x & 63;
-  const uint32_t sg = blockIdx.x * (WG_THREADS / 64) + (threadIdx.x >> 6);
-  if (sg >= segs) return;
-  const int sub = lane / LPR, lig = lane % LPR;
-  const int64_t ta = (int64_t)sg * LIST_SEG;
-  const int64_t tb = ta + LIST_SEG < (int64_t)a.pre_rows ? ta + LIST_SEG : (int64_t)a.pre_rows;
-  double vf[DCH][VEC];
-  CoordSums s[DCH];
-#pragma unroll
-  for (int q = 0; q < DCH; ++q) {
-    const int j = d0 + (q < dn ? q : 0);
-    slice_get(*reinterpret_cast<const vec_t*>(T.V + ((size_t)j << T.vsh) + lig * VEC), vf[q]);
-    sums_zero(s[q]);
-  }
-  const ST* __restrict__ St = T.S + lig * VEC;
-  for (int64_t t = ta + sub; t < tb; t += (int64_t)NSUB * FMX_U) {
-    vec_t sv[FMX_U];
-    ST av[FMX_U];
-    float x[FMX_U][DCH];
-    bool ok[FMX_U];
-#pragma unroll
-    for (int u = 0; u < FMX_U; ++u) {
-      const int64_t r = t + (int64_t)u * NSUB;
-      const bool in = r < tb;
-      ok[u] = in && (uint32_t)r < a.rows_active;
-      const size_t rr = ok[u] ? (size_t)r : 0;
-      sv[u] = gather_row(St + rr * KP);
-      av[u] = T.amul[rr];
-      const float* xr = a.pre_val + rr * (size_t)a.pre_z + d0;
-#pragma unroll
-      for (int q = 0; q < DCH; ++q) x[u][q] = xr[q < dn ? q : 0];
-    }
-    if constexpr (sizeof(ST) == 4) {
-      if (a.embed) {
-#pragma unroll
-        for (int u = 0; u < FMX_U; ++u) (void)embed_take<LPR>(sv[u], lig, a.embed);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < FMX_U; ++u) {
-      if (ok[u]) {
-#pragma unroll
-        for (int q = 0; q < DCH; ++q) sums_add<NEED_Q>(s[q], vf[q], sv[u], av[u], x[u][q]);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < DCH; ++q) {
-    if (q >= dn) break;
-#pragma unroll
-    for (int o = 32; o >= LPR; o >>= 1) {   // the same fixed butterfly over the lane groups as fm_cols_long_partial_k
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        s[q].G[i] += __shfl_xor(s[q].G[i], o);
-        if (NEED_Q) s[q].Q[i] += __shfl_xor(s[q].Q[i], o);
-      }
-      s[q].Gw += __shfl_xor(s[q].Gw, o);
-      if (NEED_Q) s[q].Qw += __shfl_xor(s[q].Qw, o);
-      s[q].cnt += __shfl_xor(s[q].cnt, o);
-    }
-    if (sub == 0) {
-      double* out = la.partial + ((size_t)(d0 + q) * segs + sg) * LONG_STRIDE(KP);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { out[lig * VEC + i] = s[q].G[i]; out[KP + lig * VEC + i] = s[q].Q[i]; }
-      if (lig == 0) { out[2 * KP] = s[q].Gw; out[2 * KP + 1] = s[q].Qw; out[2 * KP + 2] = s[q].cnt; }
-    }
-  }
-}
-
 // one WAVE per long feature: its lane groups add the feature's segment sums strided (a heavy hitter has hundreds of
 // segments), a fixed butterfly combines them, group 0 finishes the feature
 template <typename ST, int LPR, int KIND>
@@ -1334,27 +1252,18 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   dim3 g((unsigned)grid), b(WG_THREADS);
   const bool lng = a.walk && la.n_long > 0;
   constexpr bool NQ = (KIND == UPD_FTRL || KIND == UPD_TDAP);
-  constexpr int DCH = 7;  // dense-prefix features per pass over the S rows (registers: DCH x (2 VEC + 3) fp64 accumulators per lane)
-  // the dense-prefix pass takes the first pre_d long lists (whole feature range only: a chunked launch walks them the general way)
-  const char* prefix_env = getenv("FMX_PREFIX_PASS");  // read per launch: the tests compare both forms
-  const bool prefix_ok = !(prefix_env && prefix_env[0] == '0');
-  const uint32_t pre_segs = (a.pre_rows + LIST_SEG - 1) / LIST_SEG;
-  const bool pre = lng && prefix_ok && a.pre_val && a.pre_d > 0 && a.f0 == 0 && a.f1 == e->p && (int64_t)a.pre_d <= la.n_long &&
-                   (int64_t)a.pre_d * pre_segs <= la.n_seg;
-  LongArgs la1 = la;
-  la1.seg0 = pre ? (int64_t)a.pre_d * pre_segs : 0;
-  const int64_t rest = la.n_seg - la1.seg0;
-  dim3 g1((unsigned)((rest + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + (WG_THREADS / 64) - 1) / (WG_THREADS / 64)));
-  dim3 g0((pre_segs + (WG_THREADS / 64) - 1) / (WG_THREADS / 64));
+  // (Tried and removed, profiles/r03_prefix_pass.txt: the d always-present features of Criteo-shaped rows summed by ONE pass over the S
+  // rows instead of one long list each.  Their lists cost only 22 us of fm_cols_long_partial_k's 116 per 262 144-row step -- the S
+  // table is cache resident and 13 x 256 one-wave segments fill the chip -- while the single pass has 256 segments' worth of waves
+  // and 150 live accumulators per lane: 133 us.  The heads of the categorical fields are what the long-list kernels spend their time on.)
+  dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + (WG_THREADS / 64) - 1) / (WG_THREADS / 64)));
   const bool sparse_form = a.direct && !a.load_gbuf && !a.store_gbuf;
 #define FMX_COLS_CASE(L)                                                                                        \
   case L:                                                                                                       \
     if (sparse_form) hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND, true>), g, b, 0, e->stream, a, e->hyper, T); \
     else hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                \
     if (lng) {                                                                                                  \
-      if (pre) for (int d0 = 0; d0 < a.pre_d; d0 += DCH)                                                        \
-        hipLaunchKernelGGL((fm_cols_prefix_k<ST, L, NQ, DCH>), g0, b, 0, e->stream, la, a, T, d0, a.pre_d - d0 < DCH ? a.pre_d - d0 : DCH, pre_segs); \
-      if (rest > 0) hipLaunchKernelGGL((fm_cols_long_partial_k<ST, L, NQ>), g1, b, 0, e->stream, la1, a, T);    \
+      hipLaunchKernelGGL((fm_cols_long_partial_k<ST, L, NQ>), g1, b, 0, e->stream, la, a, T);                   \
       hipLaunchKernelGGL((fm_cols_long_finish_k<ST, L, KIND>), g2, b, 0, e->stream, la, a, e->hyper, T);        \
     }                                                                                                           \
     break;

@@ -247,14 +247,22 @@ struct HeadEmit;
 __global__ __launch_bounds__(CP_THREADS) void heads_write_k(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ blk, uint32_t* __restrict__ soff,
                                                             uint32_t* __restrict__ feat, const uint32_t* __restrict__ brow, const float* __restrict__ bval,
                                                             uint32_t* __restrict__ row0, uint32_t* __restrict__ val0) {
-  __shared__ uint32_t sk[CP_THREADS * (CP_PER + 1) + 1];   // thread t's keys at sk[t * 17 + 1 + u] (the odd stride keeps the banks apart), sk[0] = the key before the chunk
+  // thread t's entries at [t * 17 + 1 + u] (the odd stride keeps the banks apart); sk[0] = the key before the chunk.  The rows and
+  // values of the chunk are staged the same way: a head's first entry is then an LDS read, not a 4-byte gather per list
+  __shared__ uint32_t sk[CP_THREADS * (CP_PER + 1) + 1];
+  __shared__ uint32_t sr[CP_THREADS * (CP_PER + 1) + 1];
+  __shared__ uint32_t sx[CP_THREADS * (CP_PER + 1) + 1];
   __shared__ uint32_t sc[CP_THREADS];
   const uint32_t b0 = blockIdx.x * CP_CHUNK;
   if (b0 >= n) return;
 #pragma unroll
   for (int u = 0; u < CP_PER; ++u) {
     const uint32_t l = u * CP_THREADS + threadIdx.x, i = b0 + l;
-    if (i < n) sk[(l / CP_PER) * (CP_PER + 1) + 1 + (l % CP_PER)] = keys[i];
+    if (i < n) {
+      const uint32_t at = (l / CP_PER) * (CP_PER + 1) + 1 + (l % CP_PER);
+      sk[at] = keys[i];
+      if (row0) { sr[at] = brow[i]; sx[at] = bval ? __float_as_uint(bval[i]) : 0x3f800000u; }
+    }
   }
   if (threadIdx.x == 0) sk[0] = b0 > 0 ? keys[b0 - 1] : 0u;
   __syncthreads();
@@ -280,10 +288,9 @@ __global__ __launch_bounds__(CP_THREADS) void heads_write_k(const uint32_t* __re
 #pragma unroll
   for (int u = 0; u < CP_PER; ++u) {
     if (hit & (1u << u)) {
-      const uint32_t i = b0 + threadIdx.x * CP_PER + u;
-      soff[pos] = i;
+      soff[pos] = b0 + threadIdx.x * CP_PER + u;
       feat[pos] = sk[base + u];
-      if (row0) { row0[pos] = brow[i]; val0[pos] = bval ? __float_as_uint(bval[i]) : 0x3f800000u; }
+      if (row0) { row0[pos] = sr[base + u]; val0[pos] = sx[base + u]; }
       ++pos;
     }
   }

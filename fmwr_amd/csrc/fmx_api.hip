@@ -361,11 +361,6 @@ static int cols_args(fmx_engine* e, fmx_matrix* m, const TileRun& t, bool sparse
   c.rows_active = (uint32_t)t.nrows;
   c.walk = 1;
   c.unit = m->unit_values;
-  // dense-prefix features of a field-structured tile: long lists of exactly nrows entries each, in row order (plan_build's split path)
-  if (m->dense_prefix > 0 && m->fixed_row_len > m->dense_prefix && !m->unit_values && pl.nrows > (int64_t)list_long_min() &&
-      pl.cnt == pl.nrows * (int64_t)m->fixed_row_len) {
-    c.pre_val = m->val + pl.base; c.pre_z = m->fixed_row_len; c.pre_d = m->dense_prefix; c.pre_rows = (uint32_t)pl.nrows;
-  }
   if (pl.feat && sparse_ok) {
     c.tfeat = pl.feat; c.toff = pl.soff; c.n_tfeat = pl.n_lists;
     c.trow0 = pl.row0; c.tval0 = pl.val0;

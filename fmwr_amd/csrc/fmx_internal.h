@@ -393,11 +393,6 @@ struct ColsArgs {
   int64_t list_entries;  // entries of the tile (sparse walk: decides `direct`)
   int embed;             // EmbedMode of the S rows (set by the launcher; must match phase 1's)
   int buf_gather;        // set by the launcher: S rows / multipliers are gathered through buffer descriptors (padding slots issue no request)
-  // field-structured tiles (fmx_matrix::dense_prefix): the first pre_d features occur in EVERY row of the tile, entry j of row r holding
-  // feature j -- their sums come from ONE pass over the S rows (fm_cols_prefix_k) instead of one long list each
-  const float* pre_val;  // the tile's CSR values, row 0 of the tile first (row-major, pre_z per row); null: no prefix pass
-  int pre_z, pre_d;
-  uint32_t pre_rows;     // rows of the tile
 };
 // long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
 struct LongArgs {
@@ -409,7 +404,6 @@ struct LongArgs {
   const uint32_t* seg_end;
   double* partial;            // [n_seg][2*kp+4] segment sums
   int64_t n_long, n_seg;
-  int64_t seg0;               // fm_cols_long_partial_k starts at this segment (the ones before it belong to the dense-prefix kernel)
 };
 // a list of more than this many entries is a long list (FMX_LONG_MIN in the environment overrides it: tuning only)
 inline uint32_t list_long_min() {

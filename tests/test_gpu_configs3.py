@@ -130,19 +130,6 @@ def test_field_structured_plan_equals_the_general_sort(monkeypatch):
     same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert same(res["1"][0], res["0"][0]) and same(res["1"][1], res["0"][1]) and same(res["1"][0], u.get_params())
     assert np.any(res["1"][0][2] != v0)
-    # the dense columns' sums from ONE pass over the S rows (fm_cols_prefix_k) against one long list each: the same partial sums in
-    # the same order, so the same bits -- SGD and FTRL (which also sums the squares), k = 8 and k = 16, a truncated step
-    for solver, k2 in ((L.SOLVER_SGD, 16), (L.SOLVER_FTRL, 8)):
-        out = []
-        for flag in ("1", "0"):
-            monkeypatch.setenv("FMX_PREFIX_PASS", flag)
-            m = engine.Matrix.synthetic_fields(n, 4, vocab, 2.5, 31)
-            e = engine.Engine(p, solver=solver, num_factor=k2, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, l1_v=1e-4 if solver == L.SOLVER_FTRL else 0.0,
-                              mode=L.MODE_MINIBATCH, batch_rows=B, batch_reduce=L.REDUCE_SUM if solver == L.SOLVER_FTRL else L.REDUCE_MEAN)
-            e.init_normal(7, 0.0, 0.05)
-            assert e.train(m, n + B + 700) == n + B + 700
-            out.append(e.get_params())
-        assert same(out[0], out[1])
 
 
 def test_fields_generator_shape():

@@ -302,6 +302,8 @@ def test_owner_sharded_exchange_on_the_gpu(tmp_path, world, solver, wide, reduce
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", "29521", str(script), ROOT, solver, str(out), str(wide), reduce, mode], capture_output=True, text=True, env=env, timeout=600)
+    if r.returncode != 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):   # pytest clips long assertion messages: keep the workers' own words
+        open(os.path.join(ROOT, "gpurun_out", f"fail_owner_{world}_{solver}_{mode}.txt"), "w").write(r.stdout + "\n==== stderr ====\n" + r.stderr)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     got = np.load(out)
     assert np.all(np.isfinite(got["v"])) and got["owner_bytes"] > 0
