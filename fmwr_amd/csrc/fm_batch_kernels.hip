@@ -38,6 +38,12 @@
 #ifndef FMX_SPARSE_WAVES
 #define FMX_SPARSE_WAVES 4
 #endif
+// ... and the fp32 dense-tile form: its FTRL / TDAP instances sit at 127-133 VGPRs, on the edge between 4 and 3 waves per SIMD, and which
+// side they fall on changed with unrelated edits (round 3: FTRL k = 64 went 0.94 -> 1.08 ms per tile at 3).  Pinned at 4; the few
+// registers over go to scratch outside the entry loop.
+#ifndef FMX_DENSE_WAVES
+#define FMX_DENSE_WAVES 4
+#endif
 #ifndef FMX_U_LARGE
 #define FMX_U_LARGE 4
 #endif
@@ -98,6 +104,17 @@ __device__ __forceinline__ double buf_elem(__amdgpu_buffer_rsrc_t r, uint32_t of
 template <typename T> struct Slice;
 template <> struct Slice<float> { using vec = float4; static constexpr int N = 4; };
 template <> struct Slice<double> { using vec = double2; static constexpr int N = 2; };
+
+// Table strides, as shifts.  The w-in-row layout (fmx_internal.h: w_in_row) exists for fp32 rows of at most 16 padded factors (LPR <= 4)
+// only: there the shifts are launch arguments.  Everywhere else -- fp64 tables, wider rows -- they are the compile-time ones (rows KP
+// apart, w a table of its own), so that those kernels keep the registers they had before the layout existed: the wide-row kernels are
+// register-bound, and two more VGPRs took the FTRL k = 64 kernel from 4 to 3 waves per SIMD (0.94 -> 1.08 ms per tile, round 3).
+template <typename ST, int LPR> struct RowStride {
+  static constexpr bool DYN = sizeof(ST) == 4 && LPR <= 4;
+  static constexpr int KSH = __builtin_ctz((unsigned)(LPR * Slice<ST>::N));
+  static __device__ __forceinline__ int v(int vsh) { if constexpr (DYN) return vsh; else return KSH; }
+  static __device__ __forceinline__ int w(int wsh) { if constexpr (DYN) return wsh; else return 0; }
+};
 
 __device__ __forceinline__ void slice_get(const float4& v, double* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 __device__ __forceinline__ void slice_get(const double2& v, double* o) { o[0] = v.x; o[1] = v.y; }
@@ -297,8 +314,8 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
       T wv[RU];
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
-        vv[u] = gather_row(Vt + ((size_t)en[u].x << a.vsh));
-        wv[u] = wt[(size_t)en[u].x << a.wsh];  // (w-in-row layout: the same 128-byte line as the V row)
+        vv[u] = gather_row(Vt + ((size_t)en[u].x << RowStride<T, LPR>::v(a.vsh)));
+        wv[u] = wt[(size_t)en[u].x << RowStride<T, LPR>::w(a.wsh)];  // (w-in-row layout: the same 128-byte line as the V row)
         if constexpr (WGT != 64) {
           // large steps over a cache-sized table: let these land before the next entry's requests go out (see FMX_U_LARGE above)
           if (a.serial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -399,6 +416,11 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
   RowsArgs a = a_in;
   FMX_CHECK(a.vs >= (fp64_tables ? e->kp64 : e->kp32) && a.ws >= 1 && (a.vs & (a.vs - 1)) == 0 && (a.ws & (a.ws - 1)) == 0, FMX_ERR_STATE,
             "rows_forward: table strides not set (%d, %d)", a.vs, a.ws);
+  {  // kernels of fp64 tables and of rows wider than 16 factors have their strides compiled in (RowStride)
+    const int kp = fp64_tables ? e->kp64 : e->kp32;
+    FMX_CHECK((!fp64_tables && kp <= 16) || (a.vs == kp && a.ws == 1), FMX_ERR_STATE, "rows_forward: strides (%d, %d) on a table of compiled strides (%d, 1)",
+              a.vs, a.ws, kp);
+  }
   a.vsh = __builtin_ctz((unsigned)a.vs); a.wsh = __builtin_ctz((unsigned)a.ws);
   static const bool embed_ok = [] { const char* v = getenv("FMX_EMBED_MULT"); return !(v && v[0] == '0'); }();
   static const int force = [] { const char* v = getenv("FMX_ROWS_SERIAL"); return v ? atoi(v) : -1; }();
@@ -698,15 +720,18 @@ __device__ __forceinline__ void sums_add(CoordSums& s, const double* vf, const V
 // second half -- slot KP = w, the rest padding -- is stored WHOLE, every lane of the group its 16-byte slice of it: a 4-byte store
 // into an otherwise clean 64-byte sector is a partial write (the memory side has to read, merge and re-encode the sector: ECC), a full
 // sector is a plain write.  Measured at p = 16 M, k = 16 (profiles/r03_wir_ab.txt).  full == 0: the 4-byte store (A/B runs).
-template <typename ST, int VEC>
+// WIR_OK = RowStride::DYN: elsewhere only the word store is compiled.
+template <typename ST, int VEC, bool WIR_OK>
 __device__ __forceinline__ void store_w(ST* wbase, size_t at_w, int ws, int lig, double wn, int full) {
   using vec_t = typename Slice<ST>::vec;
-  if (ws > 1 && full) {
-    double sl[4] = {lig == 0 ? wn : 0.0, 0.0, 0.0, 0.0};
-    *reinterpret_cast<vec_t*>(wbase + at_w + lig * VEC) = slice_make(sl, ST());
-  } else if (lig == 0) {
-    wbase[at_w] = (ST)wn;
+  if constexpr (WIR_OK) {
+    if (ws > 1 && full) {
+      double sl[4] = {lig == 0 ? wn : 0.0, 0.0, 0.0, 0.0};
+      *reinterpret_cast<vec_t*>(wbase + at_w + lig * VEC) = slice_make(sl, ST());
+      return;
+    }
   }
+  if (lig == 0) wbase[at_w] = (ST)wn;
 }
 
 // What happens to a feature's sums: [+ the exchange buffer's] -> [publish] -> [apply the update].  Shared by the main
@@ -720,8 +745,8 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
   constexpr bool NEED_Q = (KIND == UPD_FTRL || KIND == UPD_TDAP);
   // exchange buffer: blocks of F features, each GV [F][KP] | GW [F] | CNT [F] | (has_q: QV [F][KP] | QW [F]); then tail[4]
   const size_t at = (size_t)j * KP + lig * VEC;    // in the optimizer-state tables
-  const size_t at_v = ((size_t)j << T.vsh) + lig * VEC;  // in the V table
-  const size_t at_w = (size_t)j << T.wsh;                // in the w table (or the V row's w slot)
+  const size_t at_v = ((size_t)j << RowStride<ST, LPR>::v(T.vsh)) + lig * VEC;  // in the V table
+  const size_t at_w = (size_t)j << RowStride<ST, LPR>::w(T.wsh);                // in the w table (or the V row's w slot)
   if (GBUF && (a.load_gbuf || a.store_gbuf)) {
     const uint32_t F = T.gb_feats;
     const uint32_t blk = (uint32_t)j / F, r = (uint32_t)j - blk * F;
@@ -816,7 +841,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
       wn = tdap_update<ST>(h, true, (double)(w_pre ? *w_pre : T.w[at_w]), s.Gw, s.Qw, cnt, u, nu, dl, hh, z, h.k1 != 0);
       T.nw[j] = u; T.t1w[j] = nu; T.t2w[j] = dl; T.t3w[j] = hh; T.sw[j] = z;
     }
-    store_w<ST, VEC>(T.w, at_w, T.ws, lig, wn, T.w_full);
+    store_w<ST, VEC, RowStride<ST, LPR>::DYN>(T.w, at_w, T.ws, lig, wn, T.w_full);
     return;
   }
   double tmp[VEC];
@@ -856,7 +881,7 @@ __device__ __forceinline__ void cols_finish(const ColsArgs& a, const Hyper& h, c
       if constexpr (KIND != UPD_SGD_L2) T.sw[j] = wa;
       if constexpr (KIND == UPD_FTRL) T.nw[j] = wb;
     }
-    store_w<ST, VEC>(T.w, at_w, T.ws, lig, wn, T.w_full);
+    store_w<ST, VEC, RowStride<ST, LPR>::DYN>(T.w, at_w, T.ws, lig, wn, T.w_full);
   }
 }
 
@@ -873,7 +898,7 @@ __device__ __forceinline__ ST* exchange_tail(const ColsTables<ST>& T) {
 // array, no exchange-buffer code; fewer registers and 4 KB of LDS, so more workgroups per CU.  That walk is latency x occupancy
 // bound (three dependent memory rounds per list, lists of one to four entries), not byte bound: DESIGN.md section 6.1.
 template <typename ST, int LPR, int KIND, bool SPARSE = false>
-__global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables<ST> T) {
+__global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : (sizeof(ST) == 4 ? FMX_DENSE_WAVES : 1)) void fm_cols_update_k(ColsArgs a, Hyper h, ColsTables<ST> T) {
   using vec_t = typename Slice<ST>::vec;
   constexpr int VEC = Slice<ST>::N;
   constexpr int KP = LPR * VEC;
@@ -916,9 +941,9 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : 1) void fm_
   } else if (SPARSE || a.walk) {
     off_a = a.bptr[idx]; off_b = a.bptr[idx + 1];
   }
-  const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + ((size_t)j << T.vsh) + lig * VEC);
+  const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + ((size_t)j << RowStride<ST, LPR>::v(T.vsh)) + lig * VEC);
   // w_j is needed only after the walk: ask for it now, beside the V row, instead of paying its round trip at the end
-  ST w_pre = T.w[(size_t)j << T.wsh];
+  ST w_pre = T.w[(size_t)j << RowStride<ST, LPR>::w(T.wsh)];
   CoordSums s;
   sums_zero(s);
   double vf[VEC];
@@ -1131,7 +1156,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_partial_k(LongArgs la
   if (j < (int64_t)a.f0 || j >= (int64_t)a.f1) return;  // not in this launch's feature range (uniform over the wave)
   const int64_t ta = la.seg_begin[seg], tb = la.seg_end[seg];
   double vf[VEC];
-  slice_get(*reinterpret_cast<const vec_t*>(T.V + ((size_t)j << T.vsh) + lig * VEC), vf);
+  slice_get(*reinterpret_cast<const vec_t*>(T.V + ((size_t)j << RowStride<ST, LPR>::v(T.vsh)) + lig * VEC), vf);
   CoordSums s;
   sums_zero(s);
   const ST* __restrict__ St = T.S + lig * VEC;
@@ -1215,7 +1240,7 @@ __global__ __launch_bounds__(WG_THREADS) void fm_cols_long_finish_k(LongArgs la,
   const int64_t j = la.lfeat[i];
   if (j < (int64_t)a.f0 || j >= (int64_t)a.f1) return;
   double vf[VEC];
-  slice_get(*reinterpret_cast<const vec_t*>(T.V + ((size_t)j << T.vsh) + lig * VEC), vf);
+  slice_get(*reinterpret_cast<const vec_t*>(T.V + ((size_t)j << RowStride<ST, LPR>::v(T.vsh)) + lig * VEC), vf);
   CoordSums s;
   sums_zero(s);
   for (uint32_t sg = la.lseg_ptr[i] + sub; sg < la.lseg_ptr[i + 1]; sg += NSUB) {
@@ -1279,6 +1304,8 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
 
 template <typename ST>
 static int launch_cols_state(fmx_engine* e, const ColsArgs& a, const LongArgs& la, const ColsTables<ST>& T) {
+  FMX_CHECK((sizeof(ST) == 4 && e->kp32 <= 16) || (T.vs == (sizeof(ST) == 8 ? e->kp64 : e->kp32) && T.ws == 1), FMX_ERR_STATE,
+            "cols_update: strides (%d, %d) on a table of compiled strides (RowStride)", T.vs, T.ws);
   switch (e->hyper.kind) {
     case UPD_SGD_L2: return launch_cols_kind<ST, UPD_SGD_L2>(e, a, la, T);
     case UPD_SGD_L1: return launch_cols_kind<ST, UPD_SGD_L1>(e, a, la, T);
@@ -1384,8 +1411,8 @@ __global__ __launch_bounds__(WG_THREADS) void fm_apply_records_k(RecArgs r, Cols
     // issued before the first one is used (the plain loop paid two rounds per PART on top of the V row's own: section 6.2).
     const int64_t j = r.rfeat[i];
     const uint32_t t0 = r.roff[i], t1 = r.roff[i + 1];
-    const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + ((size_t)j << T.vsh) + lig * VEC);
-    const ST w_pre = T.w[(size_t)j << T.wsh];
+    const vec_t v_raw = *reinterpret_cast<const vec_t*>(T.V + ((size_t)j << RowStride<ST, LPR>::v(T.vsh)) + lig * VEC);
+    const ST w_pre = T.w[(size_t)j << RowStride<ST, LPR>::w(T.wsh)];
     const int qo = (NEED_Q && T.has_q) ? KP : 0;
     const ST* recs = reinterpret_cast<const ST*>(r.recs);
     // The parts are added in the exchange's element type, in rank order: exactly what an all-reduce(sum) of the dense buffer

@@ -75,15 +75,26 @@ __global__ void gather_i64_k(const int64_t* __restrict__ src, int64_t stride, in
 
 // The (column, row) pair sort of one-hot tiles: rocprim's tuned default for gfx950 sorts 8 bits per pass -- 25 bits of column id
 // (33 M features) are then FOUR passes, the last one for a single bit.  Nine bits per pass make it three.
+// The tuned default also sorts 16 384 items per workgroup: a 6.8 M-entry tile is then 415 workgroups on 256 CUs.  Smaller workgroups
+// (FMX_SORT_CFG = 1: 512 x 8, 2: 256 x 12 items) are compiled beside it; the default is the one measured fastest at the streamed
+// tile's size (profiles/r03_sort_cfg.txt).
+template <int BS, int IPT>
 using PairSort9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 9,
+                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<BS, IPT>, rocprim::kernel_config<BS, IPT>, 9,
                                                                                  rocprim::block_radix_rank_algorithm::match>>;
 static bool nine_bit_passes(int bits) {
   static const bool ok = [] { const char* v = getenv("FMX_SORT9"); return !(v && v[0] == '0'); }();
   return ok && (bits + 8) / 9 < (bits + 7) / 8;
 }
+static int sort_cfg() { static const int c = [] { const char* v = getenv("FMX_SORT_CFG"); return v ? atoi(v) : 0; }(); return c; }
 static hipError_t sort_pairs_u32(void* temp, size_t& bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits, hipStream_t stream) {
-  if (nine_bit_passes(bits)) return rocprim::radix_sort_pairs<PairSort9>(temp, bytes, kin, kout, vin, vout, n, 0, bits, stream);
+  if (nine_bit_passes(bits)) {
+    switch (sort_cfg()) {
+      case 1: return rocprim::radix_sort_pairs<PairSort9<512, 8>>(temp, bytes, kin, kout, vin, vout, n, 0, bits, stream);
+      case 2: return rocprim::radix_sort_pairs<PairSort9<256, 12>>(temp, bytes, kin, kout, vin, vout, n, 0, bits, stream);
+      default: return rocprim::radix_sort_pairs<PairSort9<1024, 16>>(temp, bytes, kin, kout, vin, vout, n, 0, bits, stream);
+    }
+  }
   return rocprim::radix_sort_pairs(temp, bytes, kin, kout, vin, vout, n, 0, bits, stream);
 }
 
@@ -489,6 +500,7 @@ __global__ __launch_bounds__(256) void fields_split_k(const uint32_t* __restrict
     const int64_t at = R0 * zc + i;
     keys_in[at] = s_col[r * z + d + c];
     rows_in[at] = (uint32_t)(R0 + r);
+    bval[(int64_t)d * nrows + at] = 1.0f;   // the one-hot part's values, wherever the sort puts its entries
   }
 }
 
@@ -518,7 +530,6 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
                        ws.keys_out, brow + t.base, bval + t.base, keys_in, rows_in);
     size_t tb32 = ws.sort_bytes;
     FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, keys_in, ws.keys_out + n_dense, rows_in, brow + t.base + n_dense, (size_t)n_cat, ws.bits, stream));
-    hipLaunchKernelGGL(fill_ones_k, grid(n_cat), dim3(T), 0, stream, bval + t.base + n_dense, n_cat);
   } else if (cnt > 0 && unit_values) {
     // one-hot values: sort (column, row) pairs straight into brow -- 8 bytes per entry and pass instead of 12, no unpack pass;
     // bval is never read for such a matrix

@@ -508,7 +508,11 @@ static int ensure_compact(fmx_engine* e, int64_t cap) {
   e->rec_elems = mb_kp(e) * (has_q ? 2 : 1) + 4;
   if (!e->ctail) {
     FMX_HIP(hipMalloc(&e->ctail, 4 * mb_elem(e)));
-    FMX_HIP(hipMemset(e->ctail, 0, 4 * mb_elem(e)));
+    // ON THE ENGINE'S STREAM: a null-stream memset is not ordered against a non-blocking stream, and when the first fmx_grad_compact of an
+    // engine is also the call that creates the tail (no fmx_compact_reserve before it: the owner-sharded driver), the zero fill could land
+    // AFTER the kernel had published the step's tail -- one rank then applied its first step with a zero tail (w0 = -0, found in round 3
+    // through a per-step trace of w0 across three ranks: replicas that disagree after a collective that hands everyone the same bytes)
+    FMX_HIP(hipMemsetAsync(e->ctail, 0, 4 * mb_elem(e), e->stream));
   }
   if (cap > e->crec_cap) {
     FMX_HIP(hipStreamSynchronize(e->stream));
@@ -1212,10 +1216,11 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
 // plan(t+1) behind train(t) and the GPU idled from the end of that plan until the host had woken up and enqueued train(t+1).
 // Measured (profiles/r02_stream.txt): uniform columns 107 -> 113 M examples/s.
 //
-// Where the next step's tile is generated and planned: on a second stream beside the running step (FMX_STREAM_OVERLAP=1), or on
-// the engine's own stream right behind it (default).  Measured at configs[3]'s shape: side by side both get slower than back to
-// back -- the sort's streaming passes push the step's gather tables (S: 33 MB) out of the Infinity Cache -- and the overlapped
-// form loses 15-20 % end to end; in both forms the host only waits for the tile's counts, one step ahead of the GPU.
+// Where the next step's tile is generated and planned: on a second stream beside the running step (default since round 3), or on
+// the engine's own stream right behind it (FMX_STREAM_OVERLAP=0).  Round 2 measured the overlapped form 15-20 % SLOWER at
+// configs[3]'s shape: the sort's streaming passes (10.2 M x 12 B x 4 passes) pushed the step's gather tables out of the Infinity
+// Cache.  With the field-structured plan of round 3 (6.8 M x 8 B x 3 passes, no select passes) the balance turned: 272 against
+// 257 M examples/s (profiles/r03_stream_overlap.txt).  In both forms the host only waits for the tile's counts, one step ahead.
 struct fmx_source {
   static constexpr int NSLOT = 3;
   struct Slot { fmx_matrix* m = nullptr; hipEvent_t ingested = nullptr, trained = nullptr; uint32_t* h_counts = nullptr; int used = 0; };
@@ -1299,7 +1304,7 @@ int fmx_source_open(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_
   S->B = B; S->row_offset = row_offset; S->total_rows = total_rows; S->steps = (total_rows + B - 1) / B;
   S->owners = e->owner_parts;
   const int64_t cap_cnt = B * S->z;
-  static const bool overlap = [] { const char* v = getenv("FMX_STREAM_OVERLAP"); return v && v[0] == '1'; }();
+  static const bool overlap = [] { const char* v = getenv("FMX_STREAM_OVERLAP"); return !(v && v[0] == '0'); }();
   if (overlap) { FMX_HIP(hipStreamCreateWithFlags(&S->ingest, hipStreamNonBlocking)); S->own_stream = true; }
   else S->ingest = e->stream;
   FMX_TRY(S->ws.reserve(cap_cnt, (uint32_t)S->p, S->ingest));

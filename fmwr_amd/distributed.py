@@ -470,7 +470,7 @@ class DataParallel:
                 self.s.apply_chunk(c, c == chunks - 1)
 
 
-def train_stream(dp, source, steps=None):
+def train_stream(dp, source, steps=None, on_step=None):
     """Streamed data-parallel training: every rank owns one engine.Source over ITS row range of the stream (rank r: rows
     [r T / N, (r + 1) T / N) -- the generators are keyed by the global row id), each global step is one streamed tile per rank:
     next tile -> gradient sums -> exchange -> update.  exchange = "owner" routes the occurring features' records to their owners
@@ -495,4 +495,6 @@ def train_stream(dp, source, steps=None):
             dp.step(0)
         done += m.n
         t += 1
+        if on_step is not None:
+            on_step(t)
     return done

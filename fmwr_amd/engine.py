@@ -219,6 +219,12 @@ class Engine:
         v = vv[: self.k * self.p].reshape(self.p, self.k).T.copy()
         return w0.value, w, v
 
+    def get_w0(self):
+        """the global bias alone (waits for the engine's stream; no table is copied)"""
+        w0 = C.c_double()
+        L.check(L.lib().fmx_get_params(self.h, C.byref(w0), None, None))
+        return w0.value
+
     def init_normal(self, seed, mean=0.0, stdev=0.01):
         """w0 = 0, w = 0, V ~ N(mean, stdev) drawn on the device (synthetic workloads; not R's generator)."""
         L.check(L.lib().fmx_init_normal(self.h, C.c_uint64(seed), C.c_double(mean), C.c_double(stdev)))

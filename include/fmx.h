@@ -224,7 +224,7 @@ int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t 
 /* Streamed training (BASELINE.json configs[3]: 4e9 rows x 33 M features do not fit the reference's uint32 offsets,
  * util/Smatrix.h:10-17, nor any memory): the rows [row_offset, row_offset + total_rows) of a synthetic stream are produced
  * step by step -- batch_rows rows are generated and their inverted index is built two steps ahead of the step that trains on
- * them (behind it on the engine's stream: measured faster than a second stream beside it); each step is trained
+ * them (on a second stream beside the running step; FMX_STREAM_OVERLAP=0: behind it on the engine's stream -- DESIGN.md 6.5, 6.7); each step is trained
  * on once and dropped.  spec == NULL: the uniform generator of fmx_matrix_synthetic with nnz_per_row entries; otherwise the
  * Criteo-shaped one (nnz_per_row ignored).  Needs batch_rows <= the tile size (one tile per step).  ingest_wait_s (may be
  * NULL): host seconds spent waiting for a tile's counts.  On a cfg.n_gpus > 1 handle replica r streams rows

@@ -267,7 +267,10 @@ else:
         e.init_normal(11, 0.0, 0.05)
         dp = DataParallel(EngineStepper(e, None, 0, dense=False), exchange=exchange)
         src = e.source(r1 - r0, seed=3, row_offset=r0, fields=(6, vocab, 2.0))
-        done = train_stream(dp, src)
+        trace = []
+        done = train_stream(dp, src, on_step=(lambda t: trace.append(e.get_w0())) if os.environ.get("FMX_TEST_TRACE_W0") == "1" else None)
+        if trace:
+            print(f"W0TRACE rank {rank} {exchange}: " + " ".join(f"{x!r}" for x in trace), flush=True)
         assert done == r1 - r0
         src.close()
         if exchange == "owner":
@@ -277,6 +280,11 @@ else:
     res["dense"] = res["compact"]
 a, c, o = res["dense"], res["compact"], res["owner"]
 same = lambda x, y: x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+if not same(c, o):   # say WHERE: which features (owner = id % world), how far apart
+    dw = np.flatnonzero(c[1] != o[1]); dv = np.flatnonzero(np.any(c[2] != o[2], axis=0))
+    print(f"MISMATCH rank {rank}: w0 {c[0]!r} vs {o[0]!r}; w differs at {len(dw)} ids, V at {len(dv)} ids of {p}", flush=True)
+    for j in list(dv[:12]) + list(dw[:6]):
+        print(f"  id {j} owner {j % world} dw {o[1][j] - c[1][j]:.3e} max dV {np.max(np.abs(o[2][:, j] - c[2][:, j])):.3e} v0? {bool(np.all(o[2][:, j] == 0))}", flush=True)
 assert same(c, o), "owner-sharded exchange differs from the all-gather of records"
 if world == 2:
     assert same(a, o), "owner-sharded exchange differs from the dense all-reduce"
