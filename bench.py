@@ -140,7 +140,8 @@ def pmc_traffic(kernel, args):
         k = opt("--factors", 16 if solver == "sgd" else 64)
         same = (effective_tile(opt("--batch-rows", 262_144 if solver == "sgd" else 1_048_576), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
                 and k == args.factors and opt("--features", 1_000_000) == args.features and opt("--rows", 10_000_000) == args.rows
-                and opt("--nnz", 30) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64))
+                and opt("--nnz", 30) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64)
+                and (a[a.index("--workload") + 1] if "--workload" in a else "uniform") == args.workload)
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
             best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f))
     return best
@@ -229,7 +230,7 @@ def timed_steps(e, m, nb, steps, warmup):
     return time.perf_counter() - t0
 
 
-def gather_ceilings(args, engine, kernels, tile_rows, v_row_elems=None, sparse_lists=0):
+def gather_ceilings(args, engine, kernels, tile_rows, v_row_elems=None, sparse_lists=0, skewed_matrix=None):
     """The access pattern's own ceiling at each kernel's table, measured in this run (fmx_measure_gather: uniformly random rows, ids
     generated in registers): rows of the V table for phase 1 (in the w-in-row layout a row is the whole 2 * kp-float line), rows of the
     tile's S table for phase 2.  `ceiling_frac` = the kernel's row gathers per second over that rate."""
@@ -245,6 +246,12 @@ def gather_ceilings(args, engine, kernels, tile_rows, v_row_elems=None, sparse_l
         r = engine.measure_gather(table_rows * elems * eb, row_bytes, n_groups=tile_rows, per_group=32, in_flight=4, reps=20, device=0) / lines
         got = tile_rows * z / (kernels[name][1] * 1e-3) if kernels[name][1] > 0 else 0.0
         ceil[name] = {"table_MB": table_rows * elems * eb / 1e6, "row_bytes": elems * eb, "ceiling_rows_per_s": r, "kernel_rows_per_s": got, "ceiling_frac": got / r if r else None}
+        if name == "fm_rows_forward" and skewed_matrix is not None and lines == 1:
+            # skewed columns: most V-row fetches are served on-die, and uniformly random ids are no ceiling for them.  The ceiling is the bare
+            # gather of the rows THIS matrix names (fmx_measure_gather_matrix: the tile's own column ids, a table of the same size, no arithmetic)
+            rm = max(engine.measure_gather_matrix(skewed_matrix, 0, min(tile_rows, skewed_matrix.n), table_rows, row_bytes, in_flight=u, reps=20) for u in (4, 8))
+            ceil[name].update({"uniform_ids_ceiling_rows_per_s": r, "ceiling_rows_per_s": rm, "ceiling_frac": got / rm if rm else None,
+                               "ceiling_source": "bare gather of the first tile's own column ids (4 and 8 in flight, the faster)"})
     if sparse_lists > 0 and kernels["fm_cols_update"][1] > 0:
         # A sparse tile's phase 2 is not only S-row gathers: per occurring feature it reads one random row of the V table and writes it back.
         # Its floor is the sum of its parts at their own measured random-row rates (writes priced like reads): the S gathers from the tile's
@@ -749,7 +756,7 @@ def main():
         if world == 1:
             # every line carries the measured ceiling of its own access pattern
             v_row = 2 * tile_kp(k) if (e.w_in_row() and not args.state_fp64) else None
-            out["gather_ceiling"] = gather_ceilings(args, engine, kernels, tile_rows, v_row, p_walk if (criteo or sparse_tiles) else 0)
+            out["gather_ceiling"] = gather_ceilings(args, engine, kernels, tile_rows, v_row, p_walk if (criteo or sparse_tiles) else 0, m if criteo else None)
             for name, c in out["gather_ceiling"].items():
                 out["roofline"]["kernels"][name]["ceiling_frac"] = c["ceiling_frac"]
         # A fraction above 1 says the bytes priced are not the bytes moved: the step's `frac` then switches to the
@@ -769,7 +776,7 @@ def main():
                 kk["hbm_priced_frac"] = kk["frac"]
                 kk["frac"] = kk.get("ceiling_frac")
                 kk["frac_note"] = ("the rows this kernel gathers are served by L2 / the Infinity Cache (skewed columns: the heads are re-read on-die), so its algorithmic "
-                                   "bytes over the HBM peak exceed 1; `frac` is the kernel's row rate over the measured random-row ceiling of its table instead")
+                                   "bytes over the HBM peak exceed 1; `frac` is the kernel's row rate over the measured rate of the bare gather of the same rows instead")
         if world == 1 and not args.no_extras:
             out.update(side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows))
         if world == 1 and args.cpu_rows > 0:

@@ -224,6 +224,7 @@ static int cut_shard(const fmx_matrix* src, int64_t r0, int64_t r1, int dev, fmx
   m->unit_values = src->unit_values;
   m->fixed_row_len = src->fixed_row_len;
   m->dense_prefix = src->dense_prefix;
+  m->field_base = src->field_base;
   m->max_row_len = src->max_row_len;
   *out = m;
   return FMX_OK;

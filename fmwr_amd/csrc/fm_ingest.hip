@@ -197,7 +197,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_k(Pred pred, uint32_
   if (threadIdx.x == 0) blk[blockIdx.x] = red[0];
 }
 // exclusive scan of the block counts in place (one block), total -> *total
-__global__ __launch_bounds__(1024) void compact_scan_k(uint32_t* __restrict__ blk, uint32_t n_blocks, uint32_t* __restrict__ total) {
+__global__ __launch_bounds__(1024) void compact_scan_k(uint32_t* __restrict__ blk, uint32_t n_blocks, uint32_t* __restrict__ total, uint32_t add = 0) {
   __shared__ uint32_t part[1024];
   const uint32_t per = (n_blocks + 1023) / 1024;
   const uint32_t b = threadIdx.x * per, e = b + per < n_blocks ? b + per : n_blocks;
@@ -211,9 +211,9 @@ __global__ __launch_bounds__(1024) void compact_scan_k(uint32_t* __restrict__ bl
     part[threadIdx.x] += v;
     __syncthreads();
   }
-  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  uint32_t run = (threadIdx.x ? part[threadIdx.x - 1] : 0u) + add;   // (add: hits known beforehand that take the first positions)
   for (uint32_t i = b; i < e; ++i) { const uint32_t c = blk[i]; blk[i] = run; run += c; }
-  if (threadIdx.x == 1023) *total = part[1023];
+  if (threadIdx.x == 1023) *total = part[1023] + add;
 }
 // Emit(position, index) is called for every hit, positions ascending with the index
 template <typename Pred, typename Emit>
@@ -255,54 +255,56 @@ __global__ __launch_bounds__(CP_THREADS) void heads_count_k(const uint32_t* __re
   if (threadIdx.x == 0) blk[blockIdx.x] = red[0];
 }
 struct HeadEmit;
+// The writer: thread t of the block looks at entries t, t + 256, ... of the chunk (coalesced loads, the key before an entry comes from the
+// neighbouring lane), a head's position is the block's offset + the heads of the chunk's earlier 256-entry slices and waves (a 64-value
+// scan) + the heads in lower lanes (a ballot); the head's first row and value are read only where there is a head.  (Round 3's first
+// version staged the chunk's keys, rows and values through 52 KB of LDS to give every thread 16 CONSECUTIVE entries: three workgroups per
+// CU, 60 us per 6.8 M entries where the count takes 8.)
 __global__ __launch_bounds__(CP_THREADS) void heads_write_k(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ blk, uint32_t* __restrict__ soff,
                                                             uint32_t* __restrict__ feat, const uint32_t* __restrict__ brow, const float* __restrict__ bval,
-                                                            uint32_t* __restrict__ row0, uint32_t* __restrict__ val0) {
-  // thread t's entries at [t * 17 + 1 + u] (the odd stride keeps the banks apart); sk[0] = the key before the chunk.  The rows and
-  // values of the chunk are staged the same way: a head's first entry is then an LDS read, not a 4-byte gather per list
-  __shared__ uint32_t sk[CP_THREADS * (CP_PER + 1) + 1];
-  __shared__ uint32_t sr[CP_THREADS * (CP_PER + 1) + 1];
-  __shared__ uint32_t sx[CP_THREADS * (CP_PER + 1) + 1];
-  __shared__ uint32_t sc[CP_THREADS];
+                                                            uint32_t* __restrict__ row0, uint32_t* __restrict__ val0, uint32_t first = 0) {
+  // (first: keys / brow / bval point at entry `first` of the tile -- the entries before it have their heads already)
+  constexpr int WAVES = CP_THREADS / 64;
+  static_assert(CP_PER * WAVES == 64, "the (slice, wave) counts are scanned by one wave");
+  __shared__ uint32_t wc[CP_PER * WAVES];   // heads per (slice, wave), then their exclusive prefix
   const uint32_t b0 = blockIdx.x * CP_CHUNK;
   if (b0 >= n) return;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t key[CP_PER], rank[CP_PER], hit = 0;
 #pragma unroll
   for (int u = 0; u < CP_PER; ++u) {
-    const uint32_t l = u * CP_THREADS + threadIdx.x, i = b0 + l;
-    if (i < n) {
-      const uint32_t at = (l / CP_PER) * (CP_PER + 1) + 1 + (l % CP_PER);
-      sk[at] = keys[i];
-      if (row0) { sr[at] = brow[i]; sx[at] = bval ? __float_as_uint(bval[i]) : 0x3f800000u; }
-    }
+    const uint32_t i = b0 + u * CP_THREADS + threadIdx.x;
+    key[u] = i < n ? keys[i] : 0u;
   }
-  if (threadIdx.x == 0) sk[0] = b0 > 0 ? keys[b0 - 1] : 0u;
-  __syncthreads();
-  const uint32_t base = threadIdx.x * (CP_PER + 1) + 1;
-  uint32_t prev = threadIdx.x == 0 ? sk[0] : sk[base - 2];   // the previous thread's last key
-  uint32_t hit = 0, c = 0;
 #pragma unroll
   for (int u = 0; u < CP_PER; ++u) {
-    const uint32_t i = b0 + threadIdx.x * CP_PER + u;
-    const uint32_t kk = sk[base + u];
-    if (i < n && (i == 0 || kk != prev)) { hit |= 1u << u; ++c; }
-    prev = kk;
+    const uint32_t i = b0 + u * CP_THREADS + threadIdx.x;
+    uint32_t prev = __shfl_up(key[u], 1);
+    if (lane == 0 && i > 0 && i < n) prev = keys[i - 1];
+    const bool head = i < n && (i == 0 || key[u] != prev);
+    const uint64_t bal = __ballot(head);
+    if (head) hit |= 1u << u;
+    rank[u] = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wc[u * WAVES + wave] = (uint32_t)__builtin_popcountll(bal);
   }
-  sc[threadIdx.x] = c;
   __syncthreads();
-  for (int off = 1; off < CP_THREADS; off <<= 1) {
-    const uint32_t v = (int)threadIdx.x >= off ? sc[threadIdx.x - off] : 0u;
-    __syncthreads();
-    sc[threadIdx.x] += v;
-    __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive scan of the CP_PER * WAVES = 64 counts, in (slice, wave) order
+    const uint32_t v = wc[threadIdx.x];
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if ((int)lane >= off) x += y; }
+    wc[threadIdx.x] = x - v;
   }
-  uint32_t pos = blk[blockIdx.x] + sc[threadIdx.x] - c;
+  __syncthreads();
+  const uint32_t base = blk[blockIdx.x];
 #pragma unroll
   for (int u = 0; u < CP_PER; ++u) {
     if (hit & (1u << u)) {
-      soff[pos] = b0 + threadIdx.x * CP_PER + u;
-      feat[pos] = sk[base + u];
-      if (row0) { row0[pos] = sr[base + u]; val0[pos] = sx[base + u]; }
-      ++pos;
+      const uint32_t i = b0 + u * CP_THREADS + threadIdx.x;
+      const uint32_t pos = base + wc[u * WAVES + wave] + rank[u];
+      soff[pos] = first + i;
+      feat[pos] = key[u];
+      if (row0) { row0[pos] = brow[i]; val0[pos] = bval ? __float_as_uint(bval[i]) : 0x3f800000u; }
     }
   }
 }
@@ -426,17 +428,20 @@ int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense)
   return FMX_OK;
 }
 
+// per-field sort (further down): the workspace fits blocks of at least this many entries and digit histograms of at most this size
+constexpr int FQ_TILE_MIN = 2048, FQ_NBMAX = 512;
 PlanWorkspace::~PlanWorkspace() {
   (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(sort_temp); (void)hipFree(flags);
-  (void)hipFree(nseg); (void)hipFree(prim_temp); (void)hipFree(blk);
+  (void)hipFree(nseg); (void)hipFree(prim_temp); (void)hipFree(blk); (void)hipFree(fq_counts); (void)hipFree(fq_totals);
 }
 
 int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
   if (cnt <= max_cnt && p_ == p && keys_out) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(stream));
   (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(vals_out); (void)hipFree(sort_temp); (void)hipFree(flags);
-  (void)hipFree(nseg); (void)hipFree(prim_temp); (void)hipFree(blk);
+  (void)hipFree(nseg); (void)hipFree(prim_temp); (void)hipFree(blk); (void)hipFree(fq_counts); (void)hipFree(fq_totals);
   keys_out = nullptr; vals_in = vals_out = nullptr; sort_temp = nullptr; flags = nullptr; nseg = nullptr; prim_temp = nullptr; blk = nullptr;
+  fq_counts = fq_totals = nullptr;
   max_cnt = 0;
   const size_t m = (size_t)(cnt > 0 ? cnt : 1);
   bits = col_bits(p_);
@@ -465,6 +470,10 @@ int PlanWorkspace::reserve(int64_t cnt, uint32_t p_, hipStream_t stream) {
   if (b3 > prim_bytes) prim_bytes = b3;
   if (prim_bytes < 16) prim_bytes = 16;
   FMX_HIP(hipMalloc(&prim_temp, prim_bytes));
+  // per-field sort: a digit histogram per 8192-entry block of every field (at most cnt / 8192 + one ragged block per field) and its
+  // running sums over the field's blocks (second half), digit totals per field
+  FMX_HIP(hipMalloc(&fq_counts, 2 * (m / FQ_TILE_MIN + FMX_MAX_FIELDS) * (size_t)FQ_NBMAX * sizeof(uint32_t)));
+  FMX_HIP(hipMalloc(&fq_totals, (size_t)FMX_MAX_FIELDS * FQ_NBMAX * sizeof(uint32_t)));
   max_cnt = (int64_t)m;
   p = p_;
   return FMX_OK;
@@ -504,6 +513,295 @@ __global__ __launch_bounds__(256) void fields_split_k(const uint32_t* __restrict
   }
 }
 
+// ---- per-field sort (field-structured rows whose field ranges are known: fmx_matrix::field_base) -----------------------------------------
+// Entry d + c of every row is the one value of categorical field c, an id in [base[c], base[c + 1]).  The tile's sorted order is then the
+// fields one after another, each field its n = nrows entries stably sorted by the id INSIDE the field -- 26 independent sorts of (local id,
+// row) pairs whose keys have ceil(log2 vocab_c) bits: 24 for a field of ten million values, 2 for a field of three.  One global radix sort
+// of the 25-bit column ids drags every entry through every pass (78 field-passes at the Criteo shape); sorted field by field the same tile
+// needs 52 (digits of at most 8 bits), no lookback chains, no buffer fills between passes.  An LSD pass is three launches over the fields
+// still active: count (digit histogram of every 4096-entry block), scan (a digit's blocks in order), scatter.  The scatter ranks its entries
+// with wave ballots and per-wave histograms, orders the block by digit in LDS and writes each digit's run contiguously (16 entries on
+// average when the digit is uniform: a first version that stored every entry straight from its lane, with 11-bit digits, spent its time
+// in 4-byte stores to 64 different lines per instruction -- 51 us per pass against 13 for the count that reads the same keys).  Pass 0
+// takes the row from the entry's position; a field's last pass adds base[c] back and writes straight into the plan.  Blocks of one field
+// run on ONE XCD (consecutive workgroup ids go round the eight XCDs): the next pass re-reads what this one wrote from that XCD's L2.
+struct FieldPass {  // one LSD pass (by value)
+  int n_active;                    // fields taking part
+  uint32_t n, tiles;               // entries per field, blocks per field
+  uint8_t field[FMX_MAX_FIELDS];   // active slot -> field
+  uint8_t shift[FMX_MAX_FIELDS], db[FMX_MAX_FIELDS], last[FMX_MAX_FIELDS];  // per slot: digit position and width, final pass of the field
+  uint32_t base[FMX_MAX_FIELDS];   // per slot: first column id of the field
+};
+// geometry: THREADS per block, PER entries per thread (TILE = THREADS * PER entries per block), digits of at most DBMAX bits
+template <int THREADS_, int PER_, int DBMAX_>
+struct FqCfg {
+  static constexpr int THREADS = THREADS_, PER = PER_, DBMAX = DBMAX_, TILE = THREADS_ * PER_, NBMAX = 1 << DBMAX_, WAVES = THREADS_ / 64;
+  static constexpr int DPT = NBMAX > THREADS ? NBMAX / THREADS : 1;   // digits a thread looks after
+  static_assert(TILE >= FQ_TILE_MIN && NBMAX <= FQ_NBMAX, "the workspace is sized for blocks of at least FQ_TILE_MIN entries and FQ_NBMAX digits");
+};
+__device__ __forceinline__ bool fq_block(const FieldPass& P, int* slot, uint32_t* tile) {
+  const uint32_t x = blockIdx.x & 7u, s = blockIdx.x >> 3;   // XCD, position in the XCD's queue
+  *slot = (int)(x + 8u * (s / P.tiles));
+  *tile = s % P.tiles;
+  return *slot < P.n_active;
+}
+// lanes of the wave holding the same digit (valid lanes only)
+__device__ __forceinline__ uint64_t fq_match(uint32_t d, int db, bool valid) {
+  uint64_t m = __ballot(valid);
+  for (int b = 0; b < db; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+// exclusive scan over the block's threads; ends with a barrier
+template <int WAVES>
+__device__ __forceinline__ uint32_t fq_block_scan(uint32_t v, uint32_t* wsum) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if ((int)lane >= off) x += y; }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) before += (uint32_t)w < wave ? wsum[w] : 0u;
+  __syncthreads();
+  return before + x - v;
+}
+template <typename G>
+__global__ __launch_bounds__(G::THREADS) void fq_count_k(FieldPass P, const uint32_t* __restrict__ src_keys, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[G::NBMAX];
+  int slot; uint32_t tile;
+  if (!fq_block(P, &slot, &tile)) return;
+  const int db = P.db[slot], shift = P.shift[slot];
+  const uint32_t NB = 1u << db;
+  for (uint32_t d = threadIdx.x; d < NB; d += G::THREADS) hist[d] = 0;
+  __syncthreads();
+  const uint32_t* __restrict__ k = src_keys + (size_t)P.field[slot] * P.n;
+  const uint32_t i0 = tile * G::TILE + threadIdx.x;
+  uint32_t key[G::PER];
+#pragma unroll
+  for (int c = 0; c < G::PER; ++c) { const uint32_t i = i0 + c * G::THREADS; key[c] = i < P.n ? k[i] : 0u; }
+#pragma unroll
+  for (int c = 0; c < G::PER; ++c)   // (a histogram: any order; equal digits in one instruction serialise in the LDS, a few hundred cycles at worst)
+    if (i0 + c * G::THREADS < P.n) atomicAdd(&hist[(key[c] >> shift) & (NB - 1)], 1u);
+  __syncthreads();
+  uint32_t* __restrict__ out = counts + ((size_t)slot * P.tiles + tile) * G::NBMAX;
+  for (uint32_t d = threadIdx.x; d < NB; d += G::THREADS) out[d] = hist[d];
+}
+// pre[slot][tile][d] = entries of digit d in the field's earlier blocks; totals[slot][d] = the digit's entries in the whole field
+template <typename G>
+__global__ __launch_bounds__(256) void fq_scan_k(FieldPass P, const uint32_t* __restrict__ counts, uint32_t* __restrict__ pre, uint32_t* __restrict__ totals) {
+  const int slot = blockIdx.y;
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= (1u << P.db[slot])) return;
+  const size_t at = (size_t)slot * P.tiles * G::NBMAX + d;
+  uint32_t run = 0;
+  for (uint32_t t0 = 0; t0 < P.tiles; t0 += 8) {   // eight independent loads at a time (the output is another array: nothing to wait for)
+    uint32_t v[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) v[u] = t0 + u < P.tiles ? counts[at + (size_t)(t0 + u) * G::NBMAX] : 0u;
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) { if (t0 + u < P.tiles) pre[at + (size_t)(t0 + u) * G::NBMAX] = run; run += v[u]; }
+  }
+  totals[(size_t)slot * G::NBMAX + d] = run;
+}
+template <typename G>
+__global__ __launch_bounds__(G::THREADS) void fq_scatter_k(FieldPass P, const uint32_t* __restrict__ src_keys, const uint32_t* __restrict__ src_rows,
+                                                           uint32_t* __restrict__ dst_keys, uint32_t* __restrict__ dst_rows, uint32_t* __restrict__ fin_keys,
+                                                           uint32_t* __restrict__ fin_rows, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ totals) {
+  constexpr int WAVES = G::WAVES, NBMAX = G::NBMAX, PER = G::PER, DPT = G::DPT, THREADS = G::THREADS;
+  __shared__ uint32_t whist[WAVES][NBMAX];   // entries of a digit in each wave's part of the block; then where that part starts in the ordered block
+  __shared__ uint32_t delta[NBMAX];          // ordered-block position -> position in the field's output, per digit (mod 2^32)
+  __shared__ uint32_t stage[G::TILE];        // the block ordered by digit
+  __shared__ uint32_t wsum[WAVES];
+  int slot; uint32_t tile;
+  if (!fq_block(P, &slot, &tile)) return;
+  const int db = P.db[slot], shift = P.shift[slot];
+  const uint32_t NB = 1u << db;
+  const uint32_t d0 = threadIdx.x * DPT;   // the DPT digits this thread looks after: d0 .. d0 + DPT - 1
+  uint32_t tot[DPT], pr[DPT];
+#pragma unroll
+  for (int u = 0; u < DPT; ++u) {   // (asked for before anything else: both are needed only after the ranks)
+    const bool in = d0 + u < NB;
+    tot[u] = in ? totals[(size_t)slot * NBMAX + d0 + u] : 0u;
+    pr[u] = in ? pre[((size_t)slot * P.tiles + tile) * NBMAX + d0 + u] : 0u;
+    if (in) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) whist[w][d0 + u] = 0;
+    }
+  }
+  const size_t f0 = (size_t)P.field[slot] * P.n;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t i0 = tile * G::TILE + wave * (G::TILE / WAVES) + lane;
+  uint32_t key[PER], row[PER], lp[PER];
+#pragma unroll
+  for (int c = 0; c < PER; ++c) {
+    const uint32_t i = i0 + c * 64;
+    const bool valid = i < P.n;
+    key[c] = valid ? src_keys[f0 + i] : 0u;
+    row[c] = src_rows ? (valid ? src_rows[f0 + i] : 0u) : i;   // pass 0: the entry's position IS its row
+  }
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int u = 0; u < DPT; ++u) tsum += tot[u];
+  uint32_t dbase = fq_block_scan<WAVES>(tsum, wsum);   // where digit d0 starts in the field's output
+  // ranks inside the wave's part, chunk after chunk: the lanes of a digit read its counter, the first of them moves it on
+  volatile uint32_t* wh = whist[wave];
+#pragma unroll
+  for (int c = 0; c < PER; ++c) {
+    const bool valid = i0 + c * 64 < P.n;
+    const uint32_t d = (key[c] >> shift) & (NB - 1);
+    const uint64_t m = fq_match(d, db, valid);
+    const uint32_t old = wh[valid ? d : 0u];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lane == (uint32_t)__builtin_ctzll(m)) wh[d] = old + (uint32_t)__builtin_popcountll(m);
+    __builtin_amdgcn_wave_barrier();
+    lp[c] = old + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  uint32_t cw[DPT][WAVES], bc[DPT], bsum = 0;
+#pragma unroll
+  for (int u = 0; u < DPT; ++u) {
+    bc[u] = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { cw[u][w] = d0 + u < NB ? whist[w][d0 + u] : 0u; bc[u] += cw[u][w]; }
+    bsum += bc[u];
+  }
+  uint32_t lbase = fq_block_scan<WAVES>(bsum, wsum);   // where digit d0 starts in the ordered block
+#pragma unroll
+  for (int u = 0; u < DPT; ++u) {
+    if (d0 + u < NB) {
+      uint32_t g = lbase;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) { whist[w][d0 + u] = g; g += cw[u][w]; }
+      delta[d0 + u] = dbase + pr[u] - lbase;
+    }
+    lbase += bc[u]; dbase += tot[u];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < PER; ++c) {
+    if (i0 + c * 64 < P.n) {
+      lp[c] += whist[wave][(key[c] >> shift) & (NB - 1)];
+      stage[lp[c]] = key[c];
+    }
+  }
+  __syncthreads();
+  const bool last = P.last[slot] != 0;
+  uint32_t* __restrict__ ok = (last ? fin_keys : dst_keys) + f0;
+  uint32_t* __restrict__ orow = (last ? fin_rows : dst_rows) + f0;
+  const uint32_t add = last ? P.base[slot] : 0u;
+  const uint32_t have = P.n - tile * G::TILE < (uint32_t)G::TILE ? P.n - tile * G::TILE : (uint32_t)G::TILE;
+  uint32_t dest[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t l = threadIdx.x + j * THREADS;
+    if (l < have) {
+      const uint32_t kk = stage[l];
+      dest[j] = l + delta[(kk >> shift) & (NB - 1)];
+      ok[dest[j]] = kk + add;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < PER; ++c)
+    if (i0 + c * 64 < P.n) stage[lp[c]] = row[c];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t l = threadIdx.x + j * THREADS;
+    if (l < have) orow[dest[j]] = stage[l];
+  }
+}
+// split for the per-field sort: the dense columns as in fields_split_k, the one-hot part FIELD-major with the field's base taken off
+struct FieldBases { uint32_t base[FMX_MAX_FIELDS]; };
+__global__ __launch_bounds__(256) void fields_split_local_k(const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t nrows, int z, int d, FieldBases fb,
+                                                            uint32_t* __restrict__ keys_sorted, uint32_t* __restrict__ brow, float* __restrict__ bval,
+                                                            uint32_t* __restrict__ keys_in) {
+  __shared__ uint32_t s_col[FS_ROWS * 64];
+  __shared__ float s_val[FS_ROWS * 64];
+  const int64_t R0 = (int64_t)blockIdx.x * FS_ROWS;
+  const int rows = (int)(nrows - R0 < FS_ROWS ? nrows - R0 : FS_ROWS);
+  const int cnt = rows * z;
+  for (int i = threadIdx.x; i < cnt; i += 256) { s_col[i] = col[R0 * z + i]; s_val[i] = val[R0 * z + i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < d * rows; i += 256) {
+    const int c = i / rows, r = i - c * rows;
+    const int64_t at = (int64_t)c * nrows + R0 + r;
+    keys_sorted[at] = s_col[r * z + c];
+    brow[at] = (uint32_t)(R0 + r);
+    bval[at] = s_val[r * z + c];
+  }
+  const int zc = z - d;
+  for (int i = threadIdx.x; i < zc * rows; i += 256) {
+    const int c = i / rows, r = i - c * rows;
+    const int64_t at = (int64_t)c * nrows + R0 + r;
+    keys_in[at] = s_col[r * z + d + c] - fb.base[c];
+    bval[(int64_t)d * nrows + at] = 1.0f;
+  }
+}
+// the dense columns' list heads (column c: entries [c * nrows, (c + 1) * nrows), first row 0)
+__global__ void dense_heads_k(int d, uint32_t nrows, const float* __restrict__ bval, uint32_t* __restrict__ soff, uint32_t* __restrict__ feat,
+                              uint32_t* __restrict__ row0, uint32_t* __restrict__ val0) {
+  const int c = threadIdx.x;
+  if (c < d) { soff[c] = (uint32_t)c * nrows; feat[c] = (uint32_t)c; row0[c] = 0u; val0[c] = __float_as_uint(bval[(size_t)c * nrows]); }
+}
+// A, B: ping-pong buffers of n_cat keys + n_cat rows each; fin_*: the plan's arrays at the one-hot part
+template <typename G>
+static int field_sort_g(const std::vector<uint32_t>& fbase, uint32_t n, uint32_t* a_keys, uint32_t* a_rows, uint32_t* b_keys, uint32_t* b_rows, uint32_t* fin_keys,
+                        uint32_t* fin_rows, uint32_t* counts, uint32_t* totals, hipStream_t stream) {
+  const int C = (int)fbase.size() - 1;
+  int passes[FMX_MAX_FIELDS], dbq[FMX_MAX_FIELDS], bits[FMX_MAX_FIELDS], max_passes = 0;
+  for (int c = 0; c < C; ++c) {
+    bits[c] = col_bits(fbase[(size_t)c + 1] - fbase[(size_t)c]);
+    passes[c] = (bits[c] + G::DBMAX - 1) / G::DBMAX;
+    dbq[c] = (bits[c] + passes[c] - 1) / passes[c];   // balanced digits: 17 bits = 9 + 8, not 9 + 8 + 0 or 11 + 6
+    if (passes[c] > max_passes) max_passes = passes[c];
+  }
+  const uint32_t tiles = (n + G::TILE - 1) / G::TILE;
+  uint32_t* pre = counts + ((size_t)C * tiles) * G::NBMAX;   // (the workspace holds twice the histograms' size)
+  for (int q = 0; q < max_passes; ++q) {
+    FieldPass P{};
+    P.n = n; P.tiles = tiles;
+    int db_max = 0;
+    for (int c = 0; c < C; ++c) {
+      if (passes[c] <= q) continue;
+      const int s = P.n_active++;
+      P.field[s] = (uint8_t)c; P.shift[s] = (uint8_t)(q * dbq[c]);
+      P.db[s] = (uint8_t)((bits[c] - q * dbq[c]) < dbq[c] ? (bits[c] - q * dbq[c]) : dbq[c]);
+      P.last[s] = (uint8_t)(q + 1 == passes[c]);
+      P.base[s] = fbase[(size_t)c];
+      if (P.db[s] > db_max) db_max = P.db[s];
+    }
+    const uint32_t* sk = (q & 1) ? b_keys : a_keys;
+    const uint32_t* sr = q == 0 ? nullptr : ((q & 1) ? b_rows : a_rows);
+    uint32_t* dk = (q & 1) ? a_keys : b_keys;
+    uint32_t* dr = (q & 1) ? a_rows : b_rows;
+    const dim3 grid(8u * tiles * (unsigned)((P.n_active + 7) / 8));
+    hipLaunchKernelGGL((fq_count_k<G>), grid, dim3(G::THREADS), 0, stream, P, sk, counts);
+    hipLaunchKernelGGL((fq_scan_k<G>), dim3((unsigned)(((1u << db_max) + 255) / 256), (unsigned)P.n_active), dim3(256), 0, stream, P, (const uint32_t*)counts, pre, totals);
+    hipLaunchKernelGGL((fq_scatter_k<G>), grid, dim3(G::THREADS), 0, stream, P, sk, sr, dk, dr, fin_keys, fin_rows, (const uint32_t*)pre, (const uint32_t*)totals);
+  }
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+static int field_sort(const std::vector<uint32_t>& fbase, uint32_t n, uint32_t* a_keys, uint32_t* a_rows, uint32_t* b_keys, uint32_t* b_rows, uint32_t* fin_keys,
+                      uint32_t* fin_rows, uint32_t* counts, uint32_t* totals, hipStream_t stream) {
+  // block geometry (profiles/r03_field_sort.txt: streamed Criteo shape, M examples/s): 256 x 16 entries with 8-bit digits 367, 256 x 8 / 8 bits 368,
+  // 128 x 16 / 8 bits 365, 256 x 16 / 7 bits 362, 256 x 16 / 9 bits 355, 128 x 32 / 8 bits 348, 512 x 16 / 9 bits 319, 1024 x 8 / 9 bits 314,
+  // 256 x 32 / 9 bits 303 -- small blocks win: a block is a chain of barriers, and the chip wants many of them in flight
+  static const int cfg = [] { const char* v = getenv("FMX_FQ_CFG"); return v ? atoi(v) : 1; }();
+  switch (cfg) {
+    case 0: return field_sort_g<FqCfg<512, 16, 9>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
+    case 6: return field_sort_g<FqCfg<256, 8, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
+    case 7: return field_sort_g<FqCfg<128, 16, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
+    default: return field_sort_g<FqCfg<256, 16, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
+  }
+}
+
 __global__ void fill_ones_k(float* __restrict__ x, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = 1.0f;
@@ -512,12 +810,13 @@ __global__ void fill_ones_k(float* __restrict__ x, int64_t n) {
 // Plan one tile: entries [t.base, t.base + t.cnt) of rows [t.r0, t.r0 + t.nrows), CSR arrays given explicitly (a streamed
 // tile has its own).  Enqueues on `stream`, never waits for it; t must come from plan_alloc with room for t.cnt entries.
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
-               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix) {
+               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix, const std::vector<uint32_t>* field_base) {
   const int T = 256;
   const int64_t cnt = t.cnt;
   FMX_CHECK(cnt <= ws.max_cnt && p == ws.p, FMX_ERR_STATE, "plan workspace too small");
   FMX_CHECK(cnt < (1LL << 32), FMX_ERR_INVALID, "a tile holds %lld nonzeros; at most 2^32-1 are supported (lower tile_rows)", (long long)cnt);
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + T - 1) / T)); };
+  bool field_sorted = false;
   const char* split_env = getenv("FMX_FIELDS_SPLIT");  // read per build: the tests compare both forms
   const bool split_ok = !(split_env && split_env[0] == '0');
   if (cnt > 0 && split_ok && !unit_values && dense_prefix > 0 && fixed_row_len > dense_prefix && fixed_row_len <= 64 &&
@@ -526,10 +825,22 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
     const int64_t n_dense = t.nrows * d, n_cat = cnt - n_dense;
     uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws.vals_in);          // the u64 payload buffer holds both u32 inputs of the pair sort
     uint32_t* rows_in = keys_in + n_cat;
-    hipLaunchKernelGGL(fields_split_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, val + t.base, t.nrows, z, d,
-                       ws.keys_out, brow + t.base, bval + t.base, keys_in, rows_in);
-    size_t tb32 = ws.sort_bytes;
-    FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, keys_in, ws.keys_out + n_dense, rows_in, brow + t.base + n_dense, (size_t)n_cat, ws.bits, stream));
+    const char* fq_env = getenv("FMX_FIELD_SORT");  // read per build: the tests compare the forms
+    field_sorted = field_base && (int)field_base->size() == z - d + 1 && !(fq_env && fq_env[0] == '0') && ws.fq_counts != nullptr;
+    if (field_sorted) {   // the fields' id ranges are known: 26 short sorts instead of one long one (field_sort above)
+      FieldBases fb{};
+      for (int c = 0; c < z - d; ++c) fb.base[c] = (*field_base)[(size_t)c];
+      hipLaunchKernelGGL(fields_split_local_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, val + t.base, t.nrows, z, d, fb,
+                         ws.keys_out, brow + t.base, bval + t.base, keys_in);
+      uint32_t* b_keys = reinterpret_cast<uint32_t*>(ws.vals_out);
+      FMX_TRY(field_sort(*field_base, (uint32_t)t.nrows, keys_in, rows_in, b_keys, b_keys + n_cat, ws.keys_out + n_dense, brow + t.base + n_dense, ws.fq_counts,
+                         ws.fq_totals, stream));
+    } else {
+      hipLaunchKernelGGL(fields_split_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, val + t.base, t.nrows, z, d,
+                         ws.keys_out, brow + t.base, bval + t.base, keys_in, rows_in);
+      size_t tb32 = ws.sort_bytes;
+      FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, keys_in, ws.keys_out + n_dense, rows_in, brow + t.base + n_dense, (size_t)n_cat, ws.bits, stream));
+    }
   } else if (cnt > 0 && unit_values) {
     // one-hot values: sort (column, row) pairs straight into brow -- 8 bytes per entry and pass instead of 12, no unpack pass;
     // bval is never read for such a matrix
@@ -554,12 +865,21 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
     off = t.off; n_max = p;
   } else {              // sparse directory: run starts -> soff, ids -> feat
     // run heads of the sorted columns -> list starts, ids, first entries (one ordered compaction; dcounts[0] = the number of lists)
-    if (cnt > 0) {
+    if (cnt > 0 && field_sorted) {
+      // the dense columns' heads are known (column c starts at c * nrows with row 0); only the one-hot part is searched, and its values are all 1
+      const uint32_t d = (uint32_t)dense_prefix, first = d * (uint32_t)t.nrows, n_cat = (uint32_t)cnt - first;
+      const uint32_t nb = (n_cat + CP_CHUNK - 1) / CP_CHUNK;
+      hipLaunchKernelGGL(dense_heads_k, dim3(1), dim3(64), 0, stream, (int)d, (uint32_t)t.nrows, (const float*)(bval + t.base), t.soff, t.feat, t.row0, t.val0);
+      hipLaunchKernelGGL(heads_count_k, dim3(nb), dim3(CP_THREADS), 0, stream, ws.keys_out + first, n_cat, ws.blk);
+      hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, stream, ws.blk, nb, t.dcounts, d);
+      hipLaunchKernelGGL(heads_write_k, dim3(nb), dim3(CP_THREADS), 0, stream, ws.keys_out + first, n_cat, (const uint32_t*)ws.blk, t.soff, t.feat,
+                         (const uint32_t*)(brow + t.base + first), (const float*)nullptr, t.row0, t.val0, first);
+    } else if (cnt > 0) {
       const uint32_t nb = ((uint32_t)cnt + CP_CHUNK - 1) / CP_CHUNK;
       hipLaunchKernelGGL(heads_count_k, dim3(nb), dim3(CP_THREADS), 0, stream, ws.keys_out, (uint32_t)cnt, ws.blk);
-      hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, stream, ws.blk, nb, t.dcounts);
+      hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, stream, ws.blk, nb, t.dcounts, 0u);
       hipLaunchKernelGGL(heads_write_k, dim3(nb), dim3(CP_THREADS), 0, stream, ws.keys_out, (uint32_t)cnt, (const uint32_t*)ws.blk, t.soff, t.feat,
-                         (const uint32_t*)(brow + t.base), unit_values ? (const float*)nullptr : (const float*)(bval + t.base), t.row0, t.val0);
+                         (const uint32_t*)(brow + t.base), unit_values ? (const float*)nullptr : (const float*)(bval + t.base), t.row0, t.val0, 0u);
     }
     hipLaunchKernelGGL(close_directory_k, dim3(1), dim3(1), 0, stream, t.soff, (const uint32_t*)t.dcounts, (uint32_t)cnt);
     off = t.soff; n_max = t.cap_lists;
@@ -816,7 +1136,8 @@ int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStr
     // occurring features get a list (p = 33 M against 10 M entries per tile at configs[3]: no p-sized array per tile)
     FMX_TRY(plan_alloc(pl, m->p, cnt, cnt >= (int64_t)m->p));
     pl.r0 = tile_start[(size_t)t]; pl.nrows = tile_start[(size_t)t + 1] - pl.r0; pl.base = base; pl.cnt = cnt;
-    FMX_TRY(plan_build(pl, ws, m->p, m->row_ptr, m->col, m->val, L.brow, L.bval, stream, m->unit_values, m->fixed_row_len, m->dense_prefix));
+    FMX_TRY(plan_build(pl, ws, m->p, m->row_ptr, m->col, m->val, L.brow, L.bval, stream, m->unit_values, m->fixed_row_len, m->dense_prefix,
+                       m->field_base.empty() ? nullptr : &m->field_base));
     FMX_HIP(hipMemcpyAsync(L.h_counts + 4 * t, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   }
   FMX_HIP(hipStreamSynchronize(stream));
@@ -1259,6 +1580,7 @@ int check_rows_sorted(fmx_matrix* m) {
   m->rows_sorted = !h[0];
   m->max_row_len = h[1];
   m->dense_prefix = 0;  // (only the field generator vouches for it; changed values may have broken it)
+  m->field_base.clear();
   // FMX_UNIT_VALUES=0 in the environment keeps the general path (tuning / A-B runs only)
   static const bool allow = [] { const char* v = getenv("FMX_UNIT_VALUES"); return !(v && v[0] == '0'); }();
   m->unit_values = (allow && !h[2]) ? 1 : 0;

@@ -41,6 +41,31 @@ __global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __res
   out[g * LPR + lig] = acc;
 }
 
+// The same stripped-down gather, but of the rows a MATRIX asks for: lane group g walks row r0 + g of the matrix and fetches the table row
+// of every column id in it (U outstanding per lane).  On skewed columns (the heads of Criteo-shaped fields) most of these fetches are
+// served on-die, and uniformly random ids are no ceiling for the kernel that reads them; this is.
+template <int LPR, int U>
+__global__ __launch_bounds__(WG_THREADS) void gather_matrix_k(const float4* __restrict__ table, uint32_t table_rows, const int64_t* __restrict__ row_ptr,
+                                                              const uint32_t* __restrict__ col, int64_t r0, int64_t nrows, float4* __restrict__ out) {
+  const int64_t g = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) / LPR;
+  const int lig = threadIdx.x % LPR;
+  if (g >= nrows) return;
+  const int64_t a = row_ptr[r0 + g], b = row_ptr[r0 + g + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t t = a; t < b; t += U) {
+    uint32_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = col[t + u < b ? t + u : t];
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = table[(size_t)(id[u] < table_rows ? id[u] : 0u) * LPR + lig];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (t + u < b) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  out[g * LPR + lig] = acc;
+}
+
 static int g_probe_lds = 0;  // bytes of dynamic LDS per workgroup (0: none): 160 KiB / this = workgroups per CU
 
 template <int LPR>
@@ -112,6 +137,59 @@ extern "C" int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_b
     return FMX_OK;
   };
   st = body();
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  if (s) (void)hipStreamDestroy(s);
+  (void)hipFree(table); (void)hipFree(out);
+  return st;
+}
+
+extern "C" int fmx_measure_gather_matrix(fmx_matrix* m, int64_t r0, int64_t nrows, int64_t table_rows, int32_t row_bytes, int32_t in_flight, int32_t reps,
+                                         double* rows_per_s) {
+  FMX_CHECK(m != nullptr && rows_per_s != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_CHECK(row_bytes == 16 || row_bytes == 32 || row_bytes == 64 || row_bytes == 128 || row_bytes == 256, FMX_ERR_INVALID, "row_bytes must be 16..256, a power of two");
+  FMX_CHECK(r0 >= 0 && nrows > 0 && r0 + nrows <= m->n && table_rows > 0 && table_rows < (1LL << 32) && reps > 0, FMX_ERR_INVALID, "bad probe geometry");
+  FMX_HIP(hipSetDevice(m->device));
+  const int lpr = row_bytes / 16;
+  float4 *table = nullptr, *out = nullptr;
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  auto body = [&]() -> int {
+    FMX_HIP(hipMalloc(&table, (size_t)table_rows * row_bytes));
+    FMX_HIP(hipMalloc(&out, (size_t)nrows * row_bytes));
+    FMX_HIP(hipMemset(table, 0, (size_t)table_rows * row_bytes));
+    FMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    FMX_HIP(hipEventCreate(&a)); FMX_HIP(hipEventCreate(&b));
+    FMX_HIP(hipDeviceSynchronize());
+    const dim3 g((unsigned)((nrows * lpr + WG_THREADS - 1) / WG_THREADS)), blk(WG_THREADS);
+    int64_t h_ab[2] = {0, 0};
+    FMX_HIP(hipMemcpy(&h_ab[0], m->row_ptr + r0, sizeof(int64_t), hipMemcpyDeviceToHost));
+    FMX_HIP(hipMemcpy(&h_ab[1], m->row_ptr + r0 + nrows, sizeof(int64_t), hipMemcpyDeviceToHost));
+    auto launch = [&]() {
+#define FMX_GM(L) \
+  if (in_flight >= 8) hipLaunchKernelGGL((gather_matrix_k<L, 8>), g, blk, 0, s, table, (uint32_t)table_rows, m->row_ptr, m->col, r0, nrows, out); \
+  else hipLaunchKernelGGL((gather_matrix_k<L, 4>), g, blk, 0, s, table, (uint32_t)table_rows, m->row_ptr, m->col, r0, nrows, out);
+      switch (lpr) {
+        case 1: FMX_GM(1) break;
+        case 2: FMX_GM(2) break;
+        case 4: FMX_GM(4) break;
+        case 8: FMX_GM(8) break;
+        default: FMX_GM(16) break;
+      }
+#undef FMX_GM
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    FMX_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < reps; ++i) launch();
+    FMX_HIP(hipEventRecord(b, s));
+    FMX_HIP(hipEventSynchronize(b));
+    FMX_HIP(hipGetLastError());
+    float ms = 0.f;
+    FMX_HIP(hipEventElapsedTime(&ms, a, b));
+    *rows_per_s = (double)(h_ab[1] - h_ab[0]) * reps / ((double)ms * 1e-3);
+    return FMX_OK;
+  };
+  const int st = body();
   if (a) (void)hipEventDestroy(a);
   if (b) (void)hipEventDestroy(b);
   if (s) (void)hipStreamDestroy(s);

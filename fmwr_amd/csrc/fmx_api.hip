@@ -1045,6 +1045,7 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
   m->fixed_row_len = z;
   m->unit_values = (fs.n_dense == 0) ? 1 : 0;  // the dense features carry values in [0, 1)
   m->dense_prefix = fs.n_dense;
+  if (fs.n_dense > 0) { m->field_base.assign(fs.base, fs.base + fs.n_fields); m->field_base.push_back((uint32_t)p); }
   *out = m;
   return FMX_OK;
 }
@@ -1264,7 +1265,8 @@ static int stream_ingest(fmx_source* S, int64_t t) {
   else FMX_TRY(generate_synthetic_async(m, rows, S->z, S->seed, S->row_offset + t * S->B, S->ingest));
   auto& pl = m->plans[0];
   pl.r0 = 0; pl.nrows = rows; pl.base = 0; pl.cnt = rows * S->z;
-  FMX_TRY(plan_build(pl, S->ws, (uint32_t)S->p, m->row_ptr, m->col, m->val, m->brow, m->bval, S->ingest, m->unit_values, S->z, m->dense_prefix));
+  FMX_TRY(plan_build(pl, S->ws, (uint32_t)S->p, m->row_ptr, m->col, m->val, m->brow, m->bval, S->ingest, m->unit_values, S->z, m->dense_prefix,
+                     m->field_base.empty() ? nullptr : &m->field_base));
   FMX_HIP(hipMemcpyAsync(s.h_counts, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->ingest));
   if (S->owners > 1 && pl.feat) {  // the owner-major order of the tile's lists: the count is still on the device, so the whole directory is sorted
     FMX_TRY(plan_owner_build(pl, S->ows, S->owners, pl.own_cap, S->ingest));
@@ -1314,6 +1316,7 @@ int fmx_source_open(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_
     s.m->rows_sorted = 1; s.m->max_row_len = S->z; s.m->fixed_row_len = S->z;
     s.m->unit_values = (S->has_spec && S->fs.n_dense > 0) ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
     s.m->dense_prefix = S->has_spec ? S->fs.n_dense : 0;
+    if (S->has_spec && S->fs.n_dense > 0) { s.m->field_base.assign(S->fs.base, S->fs.base + S->fs.n_fields); s.m->field_base.push_back((uint32_t)S->p); }
     FMX_HIP(hipMalloc(&s.m->brow, (size_t)cap_cnt * sizeof(uint32_t)));
     FMX_HIP(hipMalloc(&s.m->bval, (size_t)cap_cnt * sizeof(float)));
     s.m->plans.resize(1);

@@ -107,6 +107,8 @@ struct fmx_matrix {
   int dense_prefix = 0; // > 0 (with fixed_row_len): every row STARTS with the columns 0 .. dense_prefix-1 (always-present features with real
                         // values) and every other stored value is exactly 1.0f -- Criteo-shaped rows.  The plan builder then sorts only the
                         // one-hot part, as (column, row) pairs: the dense columns' lists are the rows in order (plan_build)
+  std::vector<uint32_t> field_base;  // with dense_prefix (the field generator only): entry dense_prefix + c of every row is an id of categorical field c,
+                                     // in [field_base[c], field_base[c + 1]); the last element is p.  The plan builder then sorts field by field.
   int max_row_len = 0;  // entries of the longest row
   // Per-tile inverted index ("plan"), built lazily on the device for one (batch_rows, tile_rows) pair (fm_ingest.hip).
   // A step covers batch_rows consecutive rows and is cut into tiles of at most tile_rows rows.
@@ -442,6 +444,7 @@ struct PlanWorkspace {
   uint32_t* blk = nullptr;   // block counts of the ordered compactions (fm_ingest.hip: compact_indices)
   void* prim_temp = nullptr;
   size_t prim_bytes = 0;
+  uint32_t *fq_counts = nullptr, *fq_totals = nullptr;   // per-field sort: block histograms, digit totals
   int reserve(int64_t cnt, uint32_t p, hipStream_t stream);
   PlanWorkspace() = default;
   PlanWorkspace(const PlanWorkspace&) = delete;
@@ -451,7 +454,8 @@ struct PlanWorkspace {
 int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense);
 void plan_free(fmx_matrix::TilePlan& t);
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
-               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix = 0);
+               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix = 0,
+               const std::vector<uint32_t>* field_base = nullptr);
 void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h);
 int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream);
 // scratch of the owner partition (a 4-bit radix sort of the directory), grow-only

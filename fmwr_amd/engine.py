@@ -176,6 +176,14 @@ def measure_gather(table_bytes, row_bytes, n_groups=262_144, per_group=32, in_fl
     return out.value
 
 
+def measure_gather_matrix(m, r0, nrows, table_rows, row_bytes, in_flight=4, reps=20):
+    """rows/s of the bare gather of the table rows that rows [r0, r0 + nrows) of matrix `m` name (fmx_measure_gather_matrix)."""
+    out = C.c_double()
+    L.check(L.lib().fmx_measure_gather_matrix(m.h, C.c_int64(r0), C.c_int64(nrows), C.c_int64(table_rows), C.c_int32(row_bytes), C.c_int32(in_flight),
+                                              C.c_int32(reps), C.byref(out)))
+    return out.value
+
+
 class Engine:
     """Parameters + optimizer state on one GPU (fmx_engine*)."""
 

@@ -447,6 +447,12 @@ int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64
 int fmx_measure_gather_occ(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight,
                            int32_t reps, int32_t lds_bytes, double* rows_per_s);
 
+/* the same gather driven by a MATRIX: lane group g fetches the table row of every column id of row r0 + g (rows [r0, r0 + nrows) of m) from
+ * a scratch table of table_rows rows -- phase 1's own access stream with the arithmetic stripped away.  For skewed columns (most fetches
+ * served on-die) this, not the uniformly random probe, is the ceiling bench.py divides by. */
+int fmx_measure_gather_matrix(fmx_matrix* m, int64_t r0, int64_t nrows, int64_t table_rows, int32_t row_bytes, int32_t in_flight,
+                              int32_t reps, double* rows_per_s);
+
 /* ---- test hook (tests/test_gpu_api.py): the next per-tile plan build of this process fails once with FMX_ERR_HIP, as an
  * allocation failure halfway would -- checks that a failed build leaves no half-built cache behind.  One shot; never armed by
  * the library itself. */

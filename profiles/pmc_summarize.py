@@ -9,8 +9,21 @@ from collections import defaultdict
 out = sys.argv[1]
 bench_args = sys.argv[2:]
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+# PMC_SPLIT_TILES=T: a step of T tiles launches each hot kernel T times in a fixed order (FTRL at configs[2]: the first phase-2 launch stores its
+# sums, the second adds them and applies the update); the launches are then ALSO averaged per position in the step ("..._tile0", "..._tile1"),
+# by their dispatch order within one pass.
+split = int(os.environ.get("PMC_SPLIT_TILES", "0"))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    order = {}
+    if split > 1:
+        seen = defaultdict(dict)   # short kernel name -> dispatch id -> rank
+        for row in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+            for key in ("fm_rows_forward", "fm_cols_update"):
+                if key in row["Kernel_Name"] and not (key == "fm_rows_forward" and ", true" not in row["Kernel_Name"]):
+                    seen[key].setdefault(int(row["Dispatch_Id"]), len(seen[key]))
+        order = seen
+    for row in rows:
         name = row["Kernel_Name"]
         if "fm_rows_forward" in name and ", true" in name: kn = "fm_rows_forward"           # the training launch (one tile): <T, LPR, TRAIN = true, WGT>
         elif "fm_rows_forward" in name: kn = "fm_rows_forward_predict"                      # bench's forward-only pass (all rows)
@@ -19,6 +32,13 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         else: continue
         a = acc[kn][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"]); a[1] += 1
+        if split > 1 and kn in order:
+            t = order[kn][int(row["Dispatch_Id"])] % split
+            a = acc[f"{kn}_tile{t}"][row["Counter_Name"]]
+            a[0] += float(row["Counter_Value"]); a[1] += 1
+            if "Start_Timestamp" in row and "End_Timestamp" in row:
+                a = acc[f"{kn}_tile{t}"]["duration_ns_under_pmc"]
+                a[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"]); a[1] += 1
 res = {k: {c: v[0] / v[1] for c, v in d.items()} for k, d in acc.items()}
 for k, d in res.items():
     # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced

@@ -1,0 +1,3 @@
+#!/bin/bash
+export TMPDIR=/tmp
+bash profiles/regen_r03.sh

@@ -132,6 +132,34 @@ def test_field_structured_plan_equals_the_general_sort(monkeypatch):
     assert np.any(res["1"][0][2] != v0)
 
 
+def test_per_field_sort_equals_the_pair_sort(monkeypatch):
+    """Where the fields' id ranges are known (the field generator: resident matrices and streamed sources) the one-hot part is sorted field
+    by field on ceil(log2 vocab) bits (fm_ingest.hip: field_sort) instead of as one array of 25-bit column ids; FMX_FIELD_SORT=0 keeps the
+    pair sort.  Same plan, hence the same training bit for bit: fields of one, two and three passes (vocabularies of 1 .. 5 000 000),
+    several 8192-entry blocks per field with a ragged last one, tiles shorter than a block, uniform and skewed ids."""
+    from fmwr_amd import _lib as L, engine
+    same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for vocab, skew, B, n in (([5_000_000, 300_000, 513, 512, 600, 17, 2, 1], 3.0, 5 * 4096 + 100, 2 * (5 * 4096 + 100) + 900),
+                              ([70_000, 5_000, 3], 1.0, 8192, 8192 + 4096),
+                              ([40_000, 9_000, 700, 40, 5, 3], 2.5, 1000, 3500)):
+        k, d = 4, 2
+        p = d + sum(vocab)
+        kw = dict(num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
+        v0 = np.random.default_rng(4).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("FMX_FIELD_SORT", flag)
+            m = engine.Matrix.synthetic_fields(n, d, vocab, skew, 31)
+            e = engine.Engine(p, **kw); e.set_params(0.0, None, v0)
+            assert e.train(m, n + B) == n + B
+            s = engine.Engine(p, **kw); s.set_params(0.0, None, v0)
+            assert s.train_stream(n, seed=31, fields=(d, vocab, skew))[0] == n
+            res[flag] = (e.get_params(), s.get_params())
+            e.close(); s.close(); m.close()
+        assert same(res["1"][0], res["0"][0]) and same(res["1"][1], res["0"][1])
+        assert np.any(res["1"][0][2] != v0)
+
+
 def test_fields_generator_shape():
     from fmwr_amd import engine
     vocab = [1000, 50, 7, 2]
