@@ -1,4 +1,4 @@
-"""The "w in the row" layout of the fp32 mini-batch tables (fmx_internal.h: w_in_row; chosen by itself from 8 M features up, forced
+"""The "w in the row" layout of the fp32 mini-batch tables (fmx_internal.h: w_in_row; chosen by itself from 3 M features up, forced
 here with FMX_W_IN_ROW): V rows lie 2 * kp floats apart and a feature's linear weight sits in slot kp of its own row, so that out
 of the caches a nonzero costs one memory request instead of two.  Only addresses change: every result must be BITWISE the one of
 the separate-table layout -- training through every phase-2 form (dense and sparse tiles, long lists, tiles of a step, the
