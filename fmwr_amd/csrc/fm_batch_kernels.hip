@@ -1283,11 +1283,31 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   // and 150 live accumulators per lane: 133 us.  The heads of the categorical fields are what the long-list kernels spend their time on.)
   dim3 g1((unsigned)((la.n_seg + (WG_THREADS / 64) - 1) / (WG_THREADS / 64))), g2((unsigned)((la.n_long + (WG_THREADS / 64) - 1) / (WG_THREADS / 64)));
   const bool sparse_form = a.direct && !a.load_gbuf && !a.store_gbuf;
+  // The long lists' two kernels touch other features than the main kernel (which skips every long list) and read nothing it writes: on
+  // a sparse tile they run BESIDE it, on a stream of their own.  The list-by-list walk is bound by dependent rounds x occupancy and
+  // leaves the memory system idle; the segments of the long lists stream S rows at cache bandwidth (section 6.7).  FMX_LONG_SIDE=0: one stream.
+  static const bool side_ok = [] { const char* v = getenv("FMX_LONG_SIDE"); return !(v && v[0] == '0'); }();
+  const bool side = lng && sparse_form && side_ok;
+  hipStream_t ls = e->stream;
+  if (side) {
+    if (!e->side) {
+      FMX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+      FMX_HIP(hipEventCreateWithFlags(&e->side_fork, hipEventDisableTiming));
+      FMX_HIP(hipEventCreateWithFlags(&e->side_join, hipEventDisableTiming));
+    }
+    FMX_HIP(hipEventRecord(e->side_fork, e->stream));      // everything enqueued so far (phase 1, the plan's arrival) comes first
+    FMX_HIP(hipStreamWaitEvent(e->side, e->side_fork, 0));
+    ls = e->side;
+  }
 #define FMX_COLS_CASE(L)                                                                                        \
   case L:                                                                                                       \
+    if (side) {                                                                                                 \
+      hipLaunchKernelGGL((fm_cols_long_partial_k<ST, L, NQ>), g1, b, 0, ls, la, a, T);                          \
+      hipLaunchKernelGGL((fm_cols_long_finish_k<ST, L, KIND>), g2, b, 0, ls, la, a, e->hyper, T);               \
+    }                                                                                                           \
     if (sparse_form) hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND, true>), g, b, 0, e->stream, a, e->hyper, T); \
     else hipLaunchKernelGGL((fm_cols_update_k<ST, L, KIND>), g, b, 0, e->stream, a, e->hyper, T);                \
-    if (lng) {                                                                                                  \
+    if (lng && !side) {                                                                                         \
       hipLaunchKernelGGL((fm_cols_long_partial_k<ST, L, NQ>), g1, b, 0, e->stream, la, a, T);                   \
       hipLaunchKernelGGL((fm_cols_long_finish_k<ST, L, KIND>), g2, b, 0, e->stream, la, a, e->hyper, T);        \
     }                                                                                                           \
@@ -1298,6 +1318,10 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
     default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", mb_kp(e));
   }
 #undef FMX_COLS_CASE
+  if (side) {
+    FMX_HIP(hipEventRecord(e->side_join, e->side));
+    FMX_HIP(hipStreamWaitEvent(e->stream, e->side_join, 0));
+  }
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

@@ -706,6 +706,9 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
   (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup);
   als_graph_free(e->als_graph_w); als_graph_free(e->als_graph_v);
+  if (e->side_fork) (void)hipEventDestroy(e->side_fork);
+  if (e->side_join) (void)hipEventDestroy(e->side_join);
+  if (e->side) (void)hipStreamDestroy(e->side);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FMX_OK;

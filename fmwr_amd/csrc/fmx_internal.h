@@ -216,6 +216,9 @@ struct fmx_engine {
   int w_in_row = 0;
   int kp64 = 0;  // padded factor count of the fp64 tables (multiple of 2)
   hipStream_t stream = nullptr;
+  // phase 2's long lists on a stream of their own, beside the short lists' kernel (fm_batch_kernels.hip: launch_cols_kind); made on first use
+  hipStream_t side = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
   double* scal = nullptr;       // [SC_COUNT] current scalars (one half of scal_base)
   double* scal_next = nullptr;  // the other half: written by the step's last kernel, then swapped in
   double* scal_base = nullptr;  // [2][SC_COUNT] allocation
