@@ -110,7 +110,7 @@ template <> struct Slice<double> { using vec = double2; static constexpr int N =
 // apart, w a table of its own), so that those kernels keep the registers they had before the layout existed: the wide-row kernels are
 // register-bound, and two more VGPRs took the FTRL k = 64 kernel from 4 to 3 waves per SIMD (0.94 -> 1.08 ms per tile, round 3).
 template <typename ST, int LPR> struct RowStride {
-  static constexpr bool DYN = sizeof(ST) == 4 && LPR <= 4;
+  static constexpr bool DYN = sizeof(ST) == 4 && LPR <= WIR_MAX_KP / 4;
   static constexpr int KSH = __builtin_ctz((unsigned)(LPR * Slice<ST>::N));
   static __device__ __forceinline__ int v(int vsh) { if constexpr (DYN) return vsh; else return KSH; }
   static __device__ __forceinline__ int w(int wsh) { if constexpr (DYN) return wsh; else return 0; }
@@ -418,7 +418,7 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
             "rows_forward: table strides not set (%d, %d)", a.vs, a.ws);
   {  // kernels of fp64 tables and of rows wider than 16 factors have their strides compiled in (RowStride)
     const int kp = fp64_tables ? e->kp64 : e->kp32;
-    FMX_CHECK((!fp64_tables && kp <= 16) || (a.vs == kp && a.ws == 1), FMX_ERR_STATE, "rows_forward: strides (%d, %d) on a table of compiled strides (%d, 1)",
+    FMX_CHECK((!fp64_tables && kp <= WIR_MAX_KP) || (a.vs == kp && a.ws == 1), FMX_ERR_STATE, "rows_forward: strides (%d, %d) on a table of compiled strides (%d, 1)",
               a.vs, a.ws, kp);
   }
   a.vsh = __builtin_ctz((unsigned)a.vs); a.wsh = __builtin_ctz((unsigned)a.ws);
@@ -1328,7 +1328,7 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
 
 template <typename ST>
 static int launch_cols_state(fmx_engine* e, const ColsArgs& a, const LongArgs& la, const ColsTables<ST>& T) {
-  FMX_CHECK((sizeof(ST) == 4 && e->kp32 <= 16) || (T.vs == (sizeof(ST) == 8 ? e->kp64 : e->kp32) && T.ws == 1), FMX_ERR_STATE,
+  FMX_CHECK((sizeof(ST) == 4 && e->kp32 <= WIR_MAX_KP) || (T.vs == (sizeof(ST) == 8 ? e->kp64 : e->kp32) && T.ws == 1), FMX_ERR_STATE,
             "cols_update: strides (%d, %d) on a table of compiled strides (RowStride)", T.vs, T.ws);
   switch (e->hyper.kind) {
     case UPD_SGD_L2: return launch_cols_kind<ST, UPD_SGD_L2>(e, a, la, T);

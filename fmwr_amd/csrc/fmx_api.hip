@@ -659,7 +659,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
     {  // layout of the V / w tables (fmx_internal.h: w_in_row)
       const char* v = getenv("FMX_W_IN_ROW");
       const bool want = v ? v[0] == '1' : num_features >= 3000000ull;  // measured (profiles/r03_wir_ab.txt): 1 M features -0.4 %, 4 M +8 %, 16 M +6 %, 33 M +6 %
-      e->w_in_row = (want && e->kp32 <= 16 && e->k > 0) ? 1 : 0;
+      e->w_in_row = (want && e->kp32 <= WIR_MAX_KP && e->k > 0) ? 1 : 0;
       e->vstride32 = e->w_in_row ? 2 * e->kp32 : e->kp32;
     }
     FMX_TRY(dev_alloc_zero(&e->V, p * e->vstride32));

@@ -415,6 +415,9 @@ inline uint32_t list_long_min() {
   static const uint32_t v = [] { const char* s = getenv("FMX_LONG_MIN"); const long x = s ? atol(s) : 0; return x > 0 ? (uint32_t)x : 64u; }();
   return v;
 }
+// widest fp32 row (padded factors) that can carry its w (w_in_row); the kernels of wider rows have their strides compiled in.  Tried at 32 (a 256-byte
+// row = two lines, profiles/r03_wir_ab.txt): slower everywhere -- Criteo shape 523 -> 481 M examples/s, p = 16 M, k = 32: 245 -> 214 M.
+constexpr int WIR_MAX_KP = 16;
 constexpr uint32_t LIST_SEG = 1024;  // entries per segment (one wave)
 int launch_cols_update(fmx_engine* e, const ColsArgs& a, const LongArgs& la);
 // compact exchange (fm_batch_kernels.hip; the merge itself is in fm_ingest.hip)
