@@ -1137,3 +1137,42 @@ def test_als_very_long_columns_are_split_over_workgroups(fm):
         gv, gerr, (g0, gw, gvv) = got[split]
         assert util.rel_err(gv, rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10, split
         assert abs(g0 - r0) < 1e-10 and util.rel_err(gw, rw) < 1e-10 and util.rel_err(gvv, rvv.reshape(k, p)) < 1e-10, split
+
+
+_SCHEDULE_CHILD = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, ".")
+from fmwr_amd import _lib as L, engine
+P, Z, K, N, B = 300_000, 12, int(sys.argv[1]), 3 * 70_000 + 999, 70_000
+m = engine.Matrix.synthetic_iid(N, P, Z, 20240001)
+v0 = np.random.default_rng(1).normal(0, 0.01, (K, P)).astype(np.float32).astype(np.float64)
+e = engine.Engine(P, num_factor=K, solver=L.SOLVER_SGD, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4, mode=L.MODE_MINIBATCH, batch_rows=B)
+e.set_params(0.0, None, v0)
+nb = e.num_batches(m)
+for s in range(30):          # more wide launches than the 14 the tuner times
+    e.step(m, s % nb)
+e.sync()
+w0, w, v = e.get_params()
+yh = e.predict(m, L.LINK_LOGISTIC)
+print("HASH", hashlib.sha256(v.tobytes() + w.tobytes() + np.float64(w0).tobytes() + yh.tobytes()).hexdigest(), e.rows_tune()[0])
+'''
+
+
+@pytest.mark.parametrize("k", [16, 64])
+def test_phase_1_schedules_do_not_change_a_bit(k):
+    """Phase 1 issues a row's gathers in one of two schedules -- one entry's requests at a time, or four entries in flight per lane group
+    (fm_batch_kernels.hip: RowsTune; the engine times both on its first wide launches and keeps the faster) -- and both add the row's
+    terms in the same order.  Separate processes with FMX_ROWS_SERIAL pinned either way, and one left to the engine's own choice:
+    identical parameters and predictions after 30 steps of 70 000 rows."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for name, env in (("chosen", {}), ("serial", {"FMX_ROWS_SERIAL": "1"}), ("four", {"FMX_ROWS_SERIAL": "0"})):
+        r = subprocess.run([sys.executable, "-c", _SCHEDULE_CHILD, str(k)], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()
+        seen[name] = line[1]
+        if name == "chosen":
+            assert int(line[2]) in (0, 1)      # decided after 14 timed launches
+    assert len(set(seen.values())) == 1, seen
