@@ -377,7 +377,7 @@ static int prepare_compact(Group* g, bool* usable) {
 
 // Learner::learn over N replicas: global step s = local batch (s mod nb) of every shard; max_iter counts examples of the
 // whole job, the last step is truncated rank by rank (lower ranks first).
-int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done) {
+int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done, const GroupStepHook* after_step) {
   Group* g = e->group;
   struct Busy { Group* g; explicit Busy(Group* g_) : g(g_) { g->busy = true; } ~Busy() { g->busy = false; } } busy(g);
   FMX_TRY(ensure_shards(g, m));
@@ -399,6 +399,7 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
   for (int64_t s = 0; done < max_iter; ++s) {
     int64_t left = max_iter - done;
     int64_t stride = 0;
+    const int64_t step_first = done;
     for (int r = 0; r < g->n; ++r) {
       const fmx_matrix* sh = g->shard[(size_t)r];
       const int64_t b = s % nb[(size_t)r];  // shards differ by at most one row: their batch counts agree except for a ragged tail
@@ -427,6 +428,12 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
         FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
         FMX_TRY(fmx_apply(g->rep[(size_t)r], 0));  // the global row count travelled in the buffer's tail
       }
+    }
+    if (after_step) {   // (replica 0 is the caller's handle: its tables hold the step's result, on its own stream)
+      bool stop = false;
+      FMX_HIP(hipSetDevice(e->cfg.device));
+      FMX_TRY((*after_step)(step_first, done - 1, &stop));
+      if (stop) break;
     }
   }
   for (int r = 0; r < g->n; ++r) {

@@ -1453,7 +1453,8 @@ int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_
   FMX_CHECK(track->step_size > 0, FMX_ERR_INVALID, "step_size must be > 0 (use fmx_train when the tracker is off)");
   FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
   FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
-  FMX_CHECK(e->group == nullptr, FMX_ERR_STATE, "the tracker runs on one GPU (n_gpus > 1: train with fmx_train, evaluate with fmx_evaluate)");
+  FMX_CHECK(e->group == nullptr || (e->cfg.solver != FMX_SOLVER_ALS && !seq_mode(e)), FMX_ERR_STATE,
+            "with n_gpus > 1 the tracker follows the mini-batch learners only (ALS and the sequential mode run on one GPU)");
   FMX_TRY(use_device(e->cfg.device));
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   if (examples_done) *examples_done = 0;
@@ -1520,6 +1521,19 @@ int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_
       done = pos;
       if (conv_times >= 3) { if (convergent) *convergent = 1; break; }  // SGD_Learner.h:169-172
     }
+  } else if (e->group) {
+    // N replicas behind the handle: the same record rule, applied to the example indices a GLOBAL step covers (n_gpus x batch_rows of them); the
+    // model is looked at on replica 0 -- the handle itself -- over the whole matrix
+    const GroupStepHook hook = [&](int64_t first, int64_t last, bool* stop) -> int {
+      const bool hit = (last / step) * step >= first || last == max_iter - 1;
+      if (!hit) return FMX_OK;
+      double score = 0.0;
+      FMX_TRY(track_eval(e, m, track->metric, d_yhat, &score));
+      FMX_TRY(after_eval(last, score));
+      if (conv_times >= 3) { if (convergent) *convergent = 1; *stop = true; }
+      return FMX_OK;
+    };
+    st = group_train(e, m, max_iter, &done, &hook);
   } else {
     int64_t nb = 0;
     st = fmx_num_batches(e, m, &nb);

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -521,7 +522,10 @@ int group_init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev);
 int group_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* w, const double* v);
 bool group_outside(const fmx_engine* e);  // a cfg.n_gpus > 1 handle called from outside fmx_train
 int group_load(fmx_engine* e, const char* path);
-int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
+// after_step (may be null): called after every global step with the example indices [first, last] it covered; *stop = true ends the training
+// (the tracker of fmx_train_tracked: core/Tracker.h)
+using GroupStepHook = std::function<int(int64_t first, int64_t last, bool* stop)>;
+int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done, const GroupStepHook* after_step = nullptr);
 int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
                        int64_t* examples_done, double* ingest_wait_s);
 void free_matrix(fmx_matrix* m);

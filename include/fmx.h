@@ -272,7 +272,8 @@ int fmx_evaluate(fmx_engine* e, const fmx_matrix* m, int metric, double* out);
 
 /* Learner::learn with the tracker on: as fmx_train, plus an evaluation on the training matrix after example 0,
  * step_size, 2*step_size, ... and after the last one; stops early when converged.  The trace stays in the engine
- * until the next fmx_train_tracked / fmx_set_params. */
+ * until the next fmx_train_tracked / fmx_set_params.  cfg.n_gpus > 1 (mini-batch learners): the record rule is applied to the
+ * example indices a GLOBAL step covers (n_gpus * batch_rows of them) and the model is looked at on replica 0, over all of m. */
 int fmx_train_tracked(fmx_engine* e, fmx_matrix* m, int64_t max_iter, const fmx_track_config* track,
                       int64_t* examples_done, int32_t* convergent);
 int fmx_trace_size(fmx_engine* e, int64_t* n_records);

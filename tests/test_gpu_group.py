@@ -73,8 +73,45 @@ def test_n_gpus_truncated_last_step_and_refusals():
         engine.Engine(p, num_factor=k, mode=L.MODE_SEQUENTIAL, n_gpus=2, gpus_share_device=1)
     with pytest.raises(L.FmxError, match="devices are visible"):
         engine.Engine(p, num_factor=k, mode=L.MODE_MINIBATCH, n_gpus=16)
-    with pytest.raises(L.FmxError, match="tracker runs on one GPU"):
-        g.train_tracked(m, 1000, 100)
+
+
+@pytest.mark.parametrize("solver,n_gpus", [("sgd", 2), ("ftrl", 3)])
+def test_the_tracker_follows_an_n_gpus_handle(solver, n_gpus):
+    """fmx_train_tracked on a cfg.n_gpus > 1 handle (FM(..., step_size > 0) with several threads in the reference, src/FM.cpp:97,
+    core/Tracker.h): the record rule is applied to the example indices a GLOBAL step covers and the model is looked at on replica 0.
+    Same trace -- iterations, scores, kept parameters -- as one GPU stepping through the global batches; the convergence stop too."""
+    from fmwr_amd import _lib as L, engine
+    B, nb_full = 400, 5
+    n, p, k = n_gpus * B * nb_full, 300, 4
+    rp, col, val = util.random_csr(n, p, 6, seed=14, empty_rows=False)
+    y = util.labels(n, 14)
+    w0, w, v = util.params(p, k, 14)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    kw = dict(task=L.TASK_CLASSIFICATION, solver={"sgd": L.SOLVER_SGD, "ftrl": L.SOLVER_FTRL}[solver], num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3,
+              l1_v=1e-4 if solver == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, state_fp64=1)
+    g = engine.Engine(p, batch_rows=B, n_gpus=n_gpus, gpus_share_device=1, **kw)
+    g.set_params(w0, w, v)
+    total = 2 * n + 3 * B            # two passes and a bit: the last global step is cut short
+    step = 2 * n_gpus * B + 100      # a record point inside every third global step or so
+    rg = g.train_tracked(m, total, step, L.EVAL_LL, convergence=0.0)
+    one_m, nb = _interleaved(engine, m, n_gpus, B)
+    assert nb == nb_full and one_m.n == n
+    e = engine.Engine(p, batch_rows=B * n_gpus, **kw)
+    e.set_params(w0, w, v)
+    re_ = e.train_tracked(one_m, total, step, L.EVAL_LL, convergence=0.0)
+    assert rg["done"] == re_["done"] == total and len(rg["iters"]) >= 4
+    assert np.array_equal(rg["iters"], re_["iters"])
+    np.testing.assert_allclose(rg["evals"], re_["evals"], rtol=1e-9)
+    for a, b in zip(rg["params"], re_["params"]):
+        assert abs(a[0] - b[0]) < 1e-10 and util.rel_err(a[1], b[1]) < 1e-10 and util.rel_err(a[2], b[2]) < 1e-10
+    # a loose convergence bar stops both after the same record
+    g2 = engine.Engine(p, batch_rows=B, n_gpus=n_gpus, gpus_share_device=1, **kw); g2.set_params(w0, w, v)
+    e2 = engine.Engine(p, batch_rows=B * n_gpus, **kw); e2.set_params(w0, w, v)
+    a = g2.train_tracked(m, 20 * n, n_gpus * B, L.EVAL_LL, convergence=0.5, keep_params=False)
+    b = e2.train_tracked(one_m, 20 * n, n_gpus * B, L.EVAL_LL, convergence=0.5, keep_params=False)
+    assert a["convergent"] and b["convergent"] and a["done"] == b["done"] < 20 * n and np.array_equal(a["iters"], b["iters"])
+    with pytest.raises(L.FmxError, match="MINIBATCH"):
+        engine.Engine(p, num_factor=k, mode=L.MODE_SEQUENTIAL, n_gpus=2, gpus_share_device=1)
 
 
 def test_rccl_loads_and_all_reduces_on_the_visible_devices():
