@@ -160,6 +160,29 @@ def test_per_field_sort_equals_the_pair_sort(monkeypatch):
         assert np.any(res["1"][0][2] != v0)
 
 
+def test_per_field_sort_at_the_full_configs3_shape(monkeypatch):
+    """The same comparison at BASELINE.json configs[3]'s own step: 33 M features in 13 dense + 26 categorical fields of 3 .. 9.9 M values,
+    k = 32, steps of 262 144 rows (one sparse tile of 10.2 M entries, 64 blocks per field, three sort passes for the large fields).  Three
+    streamed steps with the per-field sort and with the pair sort: the rows of the features that occur are the same bit for bit."""
+    from fmwr_amd import _lib as L, engine
+    vocab, B = engine.CRITEO_VOCAB, 262_144
+    p = 13 + sum(vocab)
+    first = engine.Matrix.synthetic_fields(40_000, 13, vocab, 3.0, 77, row_offset=0)
+    touched = np.unique(first.export()[1])
+    first.close()
+    assert len(touched) > 100_000 and touched[-1] > 30_000_000
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FMX_FIELD_SORT", flag)
+        e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=32, learn_rate=0.05, l2_w1=1e-4, l2_v=1e-4, mode=L.MODE_MINIBATCH, batch_rows=B)
+        e.init_normal(20240001, 0.0, 0.01)
+        assert e.train_stream(3 * B, seed=77, row_offset=0, fields=(13, vocab, 3.0))[0] == 3 * B
+        got[flag] = e.get_rows(touched)
+        e.close()
+    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+    assert np.any(got["1"][0] != 0.0)
+
+
 def test_fields_generator_shape():
     from fmwr_amd import engine
     vocab = [1000, 50, 7, 2]
