@@ -555,7 +555,9 @@ def main_in_library(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch (BASELINE.json configs[{3 if criteo else (2 if ftrl else 1)}]{' shape, resident rows' if criteo else ''})",
                    "driver": "in-library: one process, cfg.n_gpus replicas behind one C-ABI handle (fm_group.hip)" + (" on ONE device (rehearsal)" if share and N > 1 else ""),
-                   "batch_rows_per_gpu": B, "global_batch_rows": per_step, "parallelism": f"dp{N}"},
+                   "batch_rows_per_gpu": B, "global_batch_rows": per_step, "parallelism": f"dp{N}",
+                   **({"exchange": (os.environ.get("FMX_GROUP_EXCHANGE") or ("owner-sharded (peer copies of owner-major slices) where the steps are sparse tiles, the dense "
+                                                                             "all-reduce otherwise"))} if N > 1 else {})},
         "roofline": {"bound": "hbm", "kernel": "step = fm_rows_forward + fm_cols_update per tile", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": step_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_example": b_step / B,
                      "note": "per GPU, SURVEY 8(d) bytes over the wall time of a global step (exchange included for N > 1)"},

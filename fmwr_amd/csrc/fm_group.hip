@@ -100,6 +100,15 @@ struct Group {
   std::vector<void*> gath;
   int64_t gath_records = 0;
   bool busy = false;  // group_train is driving the replicas: the step-level entry points are its own calls, not a caller's
+  // owner-sharded exchange (exchange_owner below): per replica, grow-only
+  struct OwnerBuf {
+    void *req = nullptr, *rows_out = nullptr, *rows_in = nullptr, *parts = nullptr;   // ids asked of me, the rows I answer with, the rows I asked for, record slices sent to me
+    int64_t req_cap = 0, out_cap = 0, in_cap = 0, parts_cap = 0;                      // in ids / rows / rows / records
+  };
+  std::vector<OwnerBuf> ox;
+  std::vector<hipEvent_t> ev_ids, ev_packed, ev_grad, ev_done;   // per replica, recorded on its stream
+  bool owners_on = false;     // the replicas are configured as owners (records and ids come out owner-major)
+  bool owner_dirty = false;   // owner-sharded steps ran: a feature's tables are current at its owner (V and w also on replica 0) and nowhere else
 };
 
 // A group handle reached from outside group_train: the step-level mutators would change replica 0 alone
@@ -117,6 +126,12 @@ void group_destroy(fmx_engine* e) {
   if (!g) return;
   free_shards(g);
   for (size_t r = 0; r < g->gath.size(); ++r) if (g->gath[r]) { (void)hipSetDevice(g->dev[r]); (void)hipFree(g->gath[r]); }
+  for (size_t r = 0; r < g->ox.size(); ++r) {
+    (void)hipSetDevice(g->dev[r]);
+    (void)hipFree(g->ox[r].req); (void)hipFree(g->ox[r].rows_out); (void)hipFree(g->ox[r].rows_in); (void)hipFree(g->ox[r].parts);
+  }
+  for (auto* v : {&g->ev_ids, &g->ev_packed, &g->ev_grad, &g->ev_done})
+    for (size_t r = 0; r < v->size(); ++r) if ((*v)[r]) { (void)hipSetDevice(g->dev[r]); (void)hipEventDestroy((*v)[r]); }
   Rccl* l = rccl();
   for (rcclComm_t c : g->comm) if (c && l) (void)l->CommDestroy(c);
   (void)hipSetDevice(e->cfg.device);
@@ -323,6 +338,239 @@ static int exchange_compact(Group* g, const std::vector<int64_t>& counts, int64_
   return FMX_OK;
 }
 
+// ---- owner-sharded exchange inside the group (SURVEY 8(e) option (ii); include/fmx.h "owner-sharded exchange") -------------------------
+// Feature j belongs to replica j mod N.  One process sees every device, so the three all-to-alls of the protocol are plain peer copies of
+// contiguous slices (the plans and the records are owner-major), each enqueued on the RECEIVING replica's stream behind an event of the
+// sending one: xGMI is point to point, and so is this.  No host synchronisation inside a step.
+//   ids -> owners, rows back (pull) | fmx_grad_compact | record slices -> owners, tails all-reduced | fmx_apply_compact_parts at the owners
+// The same additions in the same order as the all-gather form: bitwise equal to it (tests/test_gpu_group.py).
+static int owner_setup(Group* g, bool on) {
+  if (on && g->ev_ids.empty()) {
+    g->ox.assign((size_t)g->n, Group::OwnerBuf());
+    for (auto* v : {&g->ev_ids, &g->ev_packed, &g->ev_grad, &g->ev_done}) {
+      v->assign((size_t)g->n, nullptr);
+      for (int r = 0; r < g->n; ++r) { FMX_HIP(hipSetDevice(g->dev[(size_t)r])); FMX_HIP(hipEventCreateWithFlags(&(*v)[(size_t)r], hipEventDisableTiming)); }
+    }
+  }
+  if (on != g->owners_on) {
+    for (int r = 0; r < g->n; ++r) { FMX_HIP(hipSetDevice(g->dev[(size_t)r])); FMX_TRY(fmx_owner_configure(g->rep[(size_t)r], on ? g->n : 1, on ? r : 0)); }
+    g->owners_on = on;
+  }
+  return FMX_OK;
+}
+
+static int owner_grow(Group* g, int r, void** buf, int64_t* cap, int64_t need, size_t unit) {
+  if (need <= *cap && *buf) return FMX_OK;
+  FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+  for (int q = 0; q < g->n; ++q) { FMX_HIP(hipSetDevice(g->dev[(size_t)q])); FMX_HIP(hipStreamSynchronize(g->rep[(size_t)q]->stream)); }  // (rare: copies in flight may read the old buffer)
+  FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+  (void)hipFree(*buf); *buf = nullptr;
+  const int64_t want = need + need / 8 + 1;
+  FMX_HIP(hipMalloc(buf, (size_t)want * unit));
+  *cap = want;
+  return FMX_OK;
+}
+
+// one global step: replica r trains rows_limit[r] rows of step batch[r] of mats[r] (0 rows: an empty share)
+static int exchange_owner(Group* g, fmx_matrix* const* mats, const int64_t* batch, const int64_t* rows) {
+  const int N = g->n;
+  const bool wide = mb_wide(g->rep[0]);
+  const size_t eb = wide ? 8 : 4;
+  const int64_t rowe = mb_kp(g->rep[0]) + 4;
+  int64_t rec = 0;
+  {  // (the engine's own rec_elems is set by its first fmx_grad_compact: a fresh streamed job has none yet)
+    int64_t cap = 0; int32_t ok = 0;
+    FMX_HIP(hipSetDevice(g->dev[0]));
+    FMX_TRY(fmx_compact_info(g->rep[0], mats[0], &rec, &cap, &ok));
+    FMX_CHECK(ok && rec > 0, FMX_ERR_STATE, "the step is not one sparse tile");
+  }
+  int64_t cnt[GROUP_MAX][GROUP_MAX];      // cnt[r][o]: lists of r's step owned by o
+  int64_t soff[GROUP_MAX][GROUP_MAX + 1];  // where owner o's slice starts in r's owner-major arrays
+  int64_t roff[GROUP_MAX][GROUP_MAX + 1];  // where r's slice starts in what owner o receives (rank order)
+  void* ids[GROUP_MAX];
+  for (int r = 0; r < N; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    FMX_TRY(fmx_owner_info(g->rep[(size_t)r], mats[r], batch[r], cnt[r], &ids[r]));
+    soff[r][0] = 0;
+    for (int o = 0; o < N; ++o) soff[r][o + 1] = soff[r][o] + cnt[r][o];
+  }
+  for (int o = 0; o < N; ++o) {
+    roff[o][0] = 0;
+    for (int r = 0; r < N; ++r) roff[o][r + 1] = roff[o][r] + cnt[r][o];
+  }
+  for (int r = 0; r < N; ++r) {
+    Group::OwnerBuf& b = g->ox[(size_t)r];
+    FMX_TRY(owner_grow(g, r, &b.req, &b.req_cap, roff[r][N], sizeof(uint32_t)));
+    FMX_TRY(owner_grow(g, r, &b.rows_out, &b.out_cap, roff[r][N], (size_t)rowe * eb));
+    FMX_TRY(owner_grow(g, r, &b.rows_in, &b.in_cap, soff[r][N], (size_t)rowe * eb));
+    FMX_TRY(owner_grow(g, r, &b.parts, &b.parts_cap, roff[r][N], (size_t)rec * eb));
+  }
+  auto copy = [&](void* dst, int ddev, const void* src, int sdev, size_t bytes, hipStream_t st) -> int {
+    if (bytes == 0) return FMX_OK;
+    if (g->dev[(size_t)ddev] == g->dev[(size_t)sdev]) FMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    else FMX_HIP(hipMemcpyPeerAsync(dst, g->dev[(size_t)ddev], src, g->dev[(size_t)sdev], bytes, st));
+    return FMX_OK;
+  };
+  // pull: ids to their owners ...
+  for (int r = 0; r < N; ++r) { FMX_HIP(hipSetDevice(g->dev[(size_t)r])); FMX_HIP(hipEventRecord(g->ev_ids[(size_t)r], g->rep[(size_t)r]->stream)); }
+  for (int o = 0; o < N; ++o) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)o]));
+    hipStream_t st = g->rep[(size_t)o]->stream;
+    for (int r = 0; r < N; ++r) {
+      if (r != o) FMX_HIP(hipStreamWaitEvent(st, g->ev_ids[(size_t)r], 0));
+      FMX_TRY(copy((uint32_t*)g->ox[(size_t)o].req + roff[o][r], o, (const uint32_t*)ids[r] + soff[r][o], r, (size_t)cnt[r][o] * sizeof(uint32_t), st));
+    }
+    int64_t re = 0;
+    FMX_TRY(fmx_rows_pack(g->rep[(size_t)o], g->ox[(size_t)o].req, roff[o][N], g->ox[(size_t)o].rows_out, &re));
+    FMX_CHECK(re == rowe, FMX_ERR_STATE, "row width changed");
+    FMX_HIP(hipEventRecord(g->ev_packed[(size_t)o], st));
+  }
+  // ... the owners' current rows back, stored; then this replica's sums
+  void *recs[GROUP_MAX], *tails[GROUP_MAX];
+  for (int r = 0; r < N; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    hipStream_t st = g->rep[(size_t)r]->stream;
+    for (int o = 0; o < N; ++o) {
+      if (o != r) FMX_HIP(hipStreamWaitEvent(st, g->ev_packed[(size_t)o], 0));
+      FMX_TRY(copy((char*)g->ox[(size_t)r].rows_in + (size_t)soff[r][o] * rowe * eb, r, (const char*)g->ox[(size_t)o].rows_out + (size_t)roff[o][r] * rowe * eb, o,
+                   (size_t)cnt[r][o] * rowe * eb, st));
+    }
+    FMX_TRY(fmx_rows_unpack(g->rep[(size_t)r], ids[r], soff[r][N], g->ox[(size_t)r].rows_in));
+    FMX_TRY(group_grad_compact(g->rep[(size_t)r], mats[r], batch[r], rows[r]));
+    int64_t n = 0;
+    FMX_TRY(fmx_compact_records(g->rep[(size_t)r], &recs[r], &n, &tails[r]));
+    FMX_CHECK(n == soff[r][N], FMX_ERR_STATE, "replica %d published %lld records, its plan lists %lld", r, (long long)n, (long long)soff[r][N]);
+    FMX_HIP(hipEventRecord(g->ev_grad[(size_t)r], st));
+  }
+  // the 4-element tails: summed over the replicas (w0's sums and the global row count)
+  if (!g->shared) {
+    Rccl* l = rccl();
+    FMX_RCCL(l->GroupStart());
+    for (int r = 0; r < N; ++r)
+      FMX_RCCL(l->AllReduce(tails[r], tails[r], 4, wide ? RCCL_FLOAT64 : RCCL_FLOAT32, RCCL_SUM, g->comm[(size_t)r], g->rep[(size_t)r]->stream));
+    FMX_RCCL(l->GroupEnd());
+  } else {
+    FMX_HIP(hipSetDevice(g->dev[0]));
+    BufList bl{};
+    bl.n = N;
+    for (int r = 0; r < N; ++r) { bl.b[r] = tails[r]; FMX_HIP(hipStreamWaitEvent(g->xs, g->ev_grad[(size_t)r], 0)); }
+    if (wide) hipLaunchKernelGGL((sum_buffers_k<double>), dim3(1), dim3(256), 0, g->xs, bl, (int64_t)4);
+    else hipLaunchKernelGGL((sum_buffers_k<float>), dim3(1), dim3(256), 0, g->xs, bl, (int64_t)4);
+    FMX_HIP(hipGetLastError());
+    FMX_HIP(hipEventRecord(g->summed, g->xs));
+    for (int r = 0; r < N; ++r) FMX_HIP(hipStreamWaitEvent(g->rep[(size_t)r]->stream, g->summed, 0));
+  }
+  // push: record slices to their owners, which add a feature's parts in rank order and update it
+  for (int o = 0; o < N; ++o) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)o]));
+    hipStream_t st = g->rep[(size_t)o]->stream;
+    int64_t counts[GROUP_MAX], starts[GROUP_MAX];
+    for (int r = 0; r < N; ++r) {
+      if (r != o) FMX_HIP(hipStreamWaitEvent(st, g->ev_grad[(size_t)r], 0));
+      FMX_TRY(copy((char*)g->ox[(size_t)o].parts + (size_t)roff[o][r] * rec * eb, o, (const char*)recs[r] + (size_t)soff[r][o] * rec * eb, r, (size_t)cnt[r][o] * rec * eb, st));
+      counts[r] = cnt[r][o]; starts[r] = roff[o][r];
+    }
+    FMX_TRY(fmx_apply_compact_parts(g->rep[(size_t)o], g->ox[(size_t)o].parts, counts, starts, N, 0));
+    FMX_HIP(hipEventRecord(g->ev_done[(size_t)o], st));
+  }
+  // nobody overwrites what a peer may still be reading (ids, rows, records of this step): every stream waits for every update
+  for (int r = 0; r < N; ++r) {
+    FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+    for (int o = 0; o < N; ++o) if (o != r) FMX_HIP(hipStreamWaitEvent(g->rep[(size_t)r]->stream, g->ev_done[(size_t)o], 0));
+  }
+  g->owner_dirty = true;
+  return FMX_OK;
+}
+
+// rows j = first, first + step, ... of a table of `row_words` 4-byte words per feature <-> a packed buffer
+__global__ void strided_rows_k(uint32_t* __restrict__ table, int64_t row_words, uint64_t first, uint64_t step, int64_t n_rows, uint32_t* __restrict__ packed, int scatter) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rows * row_words) return;
+  const int64_t i = idx / row_words, t = idx - i * row_words;
+  const size_t at = (size_t)(first + step * (uint64_t)i) * (size_t)row_words + (size_t)t;
+  if (scatter) table[at] = packed[idx]; else packed[idx] = table[at];
+}
+
+// After owner-sharded steps: the owners' rows of the listed tables to replica `to` (-1: to every replica).  params_only: V and w.
+static int owner_refresh(Group* g, int to, bool params_only) {
+  const int N = g->n;
+  const uint64_t p = g->rep[0]->p;
+  const int64_t CHUNK_BYTES = 64LL << 20;
+  std::vector<void*> stage((size_t)N, nullptr);
+  std::vector<hipEvent_t> packed((size_t)N, nullptr), taken((size_t)N, nullptr);
+  auto body = [&]() -> int {
+    for (int r = 0; r < N; ++r) {
+      FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
+      FMX_HIP(hipMalloc(&stage[(size_t)r], (size_t)CHUNK_BYTES * 2));   // first half: what I pack for a peer; second half: what a peer packed for me
+      FMX_HIP(hipEventCreateWithFlags(&packed[(size_t)r], hipEventDisableTiming));
+      FMX_HIP(hipEventCreateWithFlags(&taken[(size_t)r], hipEventDisableTiming));
+    }
+    std::vector<std::vector<std::pair<void*, size_t>>> tabs((size_t)N);
+    for (int r = 0; r < N; ++r) engine_tables(g->rep[(size_t)r], &tabs[(size_t)r], params_only);
+    for (int dst = 0; dst < N; ++dst) {
+      if (to >= 0 && dst != to) continue;
+      for (int o = 0; o < N; ++o) {
+        if (o == dst) continue;
+        const int64_t n_own = p > (uint64_t)o ? (int64_t)((p - (uint64_t)o + (uint64_t)N - 1) / (uint64_t)N) : 0;
+        for (size_t t = 0; t < tabs[(size_t)o].size(); ++t) {
+          const int64_t words = (int64_t)(tabs[(size_t)o][t].second / 4);
+          const int64_t per = CHUNK_BYTES / (words * 4) > 0 ? CHUNK_BYTES / (words * 4) : 1;
+          for (int64_t i0 = 0; i0 < n_own; i0 += per) {
+            const int64_t n = n_own - i0 < per ? n_own - i0 : per;
+            const dim3 grid((unsigned)((n * words + 255) / 256)), blk(256);
+            hipStream_t so = g->rep[(size_t)o]->stream, sd = g->rep[(size_t)dst]->stream;
+            FMX_HIP(hipSetDevice(g->dev[(size_t)o]));
+            for (int q = 0; q < N; ++q) FMX_HIP(hipStreamWaitEvent(so, taken[(size_t)q], 0));   // whatever was packed here before has left (copies run on the taker's stream)
+            hipLaunchKernelGGL(strided_rows_k, grid, blk, 0, so, (uint32_t*)tabs[(size_t)o][t].first, words, (uint64_t)o + (uint64_t)N * (uint64_t)i0, (uint64_t)N, n,
+                               (uint32_t*)stage[(size_t)o], 0);
+            FMX_HIP(hipEventRecord(packed[(size_t)o], so));
+            FMX_HIP(hipSetDevice(g->dev[(size_t)dst]));
+            FMX_HIP(hipStreamWaitEvent(sd, packed[(size_t)o], 0));
+            void* in = (char*)stage[(size_t)dst] + CHUNK_BYTES;
+            if (g->dev[(size_t)dst] == g->dev[(size_t)o]) FMX_HIP(hipMemcpyAsync(in, stage[(size_t)o], (size_t)n * words * 4, hipMemcpyDeviceToDevice, sd));
+            else FMX_HIP(hipMemcpyPeerAsync(in, g->dev[(size_t)dst], stage[(size_t)o], g->dev[(size_t)o], (size_t)n * words * 4, sd));
+            FMX_HIP(hipEventRecord(taken[(size_t)dst], sd));
+            hipLaunchKernelGGL(strided_rows_k, grid, blk, 0, sd, (uint32_t*)tabs[(size_t)dst][t].first, words, (uint64_t)o + (uint64_t)N * (uint64_t)i0, (uint64_t)N, n,
+                               (uint32_t*)in, 1);
+            FMX_HIP(hipGetLastError());
+            // (one chunk in flight per pair: the next pack into stage[o] waits for `taken`, the next copy into `in` is behind this scatter on sd)
+          }
+        }
+      }
+    }
+    for (int r = 0; r < N; ++r) { FMX_HIP(hipSetDevice(g->dev[(size_t)r])); FMX_HIP(hipStreamSynchronize(g->rep[(size_t)r]->stream)); }
+    return FMX_OK;
+  };
+  const int st = body();
+  for (int r = 0; r < N; ++r) {
+    (void)hipSetDevice(g->dev[(size_t)r]);
+    if (st != FMX_OK) (void)hipDeviceSynchronize();
+    (void)hipFree(stage[(size_t)r]);
+    if (packed[(size_t)r]) (void)hipEventDestroy(packed[(size_t)r]);
+    if (taken[(size_t)r]) (void)hipEventDestroy(taken[(size_t)r]);
+  }
+  (void)hipSetDevice(g->rep[0]->cfg.device);
+  return st;
+}
+
+int group_make_replicated(fmx_engine* e) {
+  Group* g = e->group;
+  if (!g || !g->owner_dirty) return FMX_OK;
+  FMX_TRY(owner_refresh(g, -1, false));
+  g->owner_dirty = false;
+  return FMX_OK;
+}
+
+// which exchange a training call uses: FMX_GROUP_EXCHANGE = dense | compact | owner (read at every call; default: owner-sharded wherever
+// the steps are sparse tiles and nobody looks at the model between steps)
+enum GroupMode { GM_DENSE = 0, GM_COMPACT = 1, GM_OWNER = 2 };
+static GroupMode group_mode(bool compact_usable, bool watched) {
+  const char* v = getenv("FMX_GROUP_EXCHANGE");
+  if (!compact_usable || (v && v[0] == 'd')) return GM_DENSE;
+  if ((v && v[0] == 'c') || watched) return GM_COMPACT;
+  return GM_OWNER;
+}
+
 // every replica's gather buffer holds N parts of `stride` records
 static int ensure_gath(Group* g, int64_t stride) {
   const size_t eb = mb_wide(g->rep[0]) ? 8 : 4;
@@ -394,12 +642,17 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
   FMX_CHECK(nb_min >= 1, FMX_ERR_INVALID, "a shard is empty: fewer rows than GPUs");
   bool compact = false;
   FMX_TRY(prepare_compact(g, &compact));
+  const GroupMode mode = group_mode(compact, after_step != nullptr);
+  compact = mode != GM_DENSE;
+  if (mode != GM_OWNER) FMX_TRY(group_make_replicated(e));   // the other forms apply every update on every replica: all copies must be current
+  FMX_TRY(owner_setup(g, mode == GM_OWNER));
   std::vector<int64_t> counts((size_t)g->n, 0);
   int64_t done = 0;
   for (int64_t s = 0; done < max_iter; ++s) {
     int64_t left = max_iter - done;
     int64_t stride = 0;
     const int64_t step_first = done;
+    int64_t o_batch[GROUP_MAX], o_rows[GROUP_MAX];
     for (int r = 0; r < g->n; ++r) {
       const fmx_matrix* sh = g->shard[(size_t)r];
       const int64_t b = s % nb[(size_t)r];  // shards differ by at most one row: their batch counts agree except for a ragged tail
@@ -407,7 +660,10 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
       int64_t rows = b0 + e->cfg.batch_rows <= sh->n ? e->cfg.batch_rows : sh->n - b0;
       if (rows > left) rows = left;
       FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
-      if (compact) {
+      o_batch[r] = b; o_rows[r] = rows;
+      if (mode == GM_OWNER) {
+        // (the step's kernels are enqueued by exchange_owner, behind the pull of the rows they read)
+      } else if (compact) {
         // an empty share (the truncated last step) still publishes its records with zero counts, and its tail
         FMX_TRY(group_grad_compact(g->rep[(size_t)r], g->shard[(size_t)r], b, rows));
         FMX_TRY(fmx_compact_count(g->rep[(size_t)r], g->shard[(size_t)r], b, &counts[(size_t)r]));
@@ -420,7 +676,9 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
       left -= rows;
       done += rows;
     }
-    if (compact) {
+    if (mode == GM_OWNER) {
+      FMX_TRY(exchange_owner(g, g->shard.data(), o_batch, o_rows));
+    } else if (compact) {
       FMX_TRY(exchange_compact(g, counts, stride));
     } else {
       FMX_TRY(exchange(g));
@@ -436,6 +694,7 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
       if (stop) break;
     }
   }
+  if (mode == GM_OWNER && g->owner_dirty) FMX_TRY(owner_refresh(g, 0, true));   // the handle answers fmx_get_params / fmx_predict: its V and w current again
   for (int r = 0; r < g->n; ++r) {
     FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
     FMX_TRY(fmx_sync(g->rep[(size_t)r]));
@@ -464,6 +723,11 @@ int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_p
   std::vector<int64_t> counts((size_t)N, 0);
   int64_t done = 0;
   double waited = 0.0;
+  // a streamed step is one tile: sparse (records / owners) when it holds fewer entries than there are features
+  const int64_t z_row = spec ? (int64_t)spec->n_dense + spec->n_fields : (int64_t)nnz_per_row;
+  const GroupMode mode = group_mode(e->cfg.batch_rows * z_row < (int64_t)e->p, false);
+  if (mode != GM_OWNER) FMX_TRY(group_make_replicated(e));
+  FMX_TRY(owner_setup(g, mode == GM_OWNER));   // (before the sources open: the ingest builds the owner-major order with the plan)
   auto body = [&]() -> int {
     int64_t steps = 0;
     for (int r = 0; r < N; ++r) {
@@ -477,6 +741,8 @@ int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_p
     for (int64_t s = 0; s < steps; ++s) {
       int64_t stride = 0;
       bool compact = false;
+      fmx_matrix* s_mats[GROUP_MAX];
+      int64_t s_rows[GROUP_MAX];
       for (int r = 0; r < N; ++r) {
         fmx_engine* rep = g->rep[(size_t)r];
         fmx_matrix* m = nullptr;
@@ -485,9 +751,11 @@ int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_p
         FMX_TRY(fmx_source_next(S[(size_t)r], &m, &rows));
         if (m) last[(size_t)r] = m; else m = last[(size_t)r];
         FMX_CHECK(m != nullptr, FMX_ERR_STATE, "a replica has no step to share");
-        const char* v = getenv("FMX_GROUP_EXCHANGE");
-        compact = m->plans[0].feat != nullptr && !(v && v[0] == 'd');
-        if (compact) {
+        compact = m->plans[0].feat != nullptr && mode != GM_DENSE;
+        s_mats[r] = m; s_rows[r] = rows;
+        if (compact && mode == GM_OWNER) {
+          // (enqueued by exchange_owner)
+        } else if (compact) {
           FMX_TRY(group_grad_compact(rep, m, 0, rows));  // rows == 0: the shard ended a step early -- zero counts, an empty tail
           counts[(size_t)r] = (int64_t)m->plans[0].n_lists;
           if (counts[(size_t)r] > stride) stride = counts[(size_t)r];
@@ -498,7 +766,10 @@ int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_p
         }
         done += rows;
       }
-      if (compact) {
+      if (compact && mode == GM_OWNER) {
+        int64_t zero[GROUP_MAX] = {0};
+        FMX_TRY(exchange_owner(g, s_mats, zero, s_rows));
+      } else if (compact) {
         FMX_TRY(ensure_gath(g, stride > 0 ? stride : 1));
         FMX_TRY(exchange_compact(g, counts, stride));
       } else {
@@ -512,6 +783,7 @@ int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_p
     return FMX_OK;
   };
   int st = body();
+  if (st == FMX_OK && mode == GM_OWNER && g->owner_dirty) st = owner_refresh(g, 0, true);
   for (int r = 0; r < N; ++r) {
     (void)hipSetDevice(g->dev[(size_t)r]);
     double w = 0.0;

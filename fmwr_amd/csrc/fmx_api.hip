@@ -887,6 +887,17 @@ static void ckpt_tables(fmx_engine* e, std::vector<std::pair<void*, size_t>>* ou
   add(e->dt3V, p * e->kp64 * sizeof(double)); add(e->dt3w, p * sizeof(double));
 }
 
+// every per-feature table of the engine as (base, bytes per feature); params_only: the V rows and w alone (fm_group.hip: the owner-sharded
+// exchange refreshes the copies of features a replica does not own)
+extern "C++" void engine_tables(fmx_engine* e, std::vector<std::pair<void*, size_t>>* out, bool params_only) {
+  std::vector<std::pair<void*, size_t>> all;
+  ckpt_tables(e, &all);
+  for (auto& t : all) {
+    const bool param = t.first == (void*)e->V || t.first == (void*)e->w || t.first == (void*)e->dV || t.first == (void*)e->dw;
+    if (!params_only || param) out->push_back({t.first, t.second / (size_t)(e->p ? e->p : 1)});
+  }
+}
+
 static CkptHeader ckpt_header(const fmx_engine* e) {
   CkptHeader h{};
   memcpy(h.magic, "FMX1", 4);
@@ -901,6 +912,7 @@ static CkptHeader ckpt_header(const fmx_engine* e) {
 
 int fmx_engine_save(fmx_engine* e, const char* path) {
   FMX_CHECK(e != nullptr && path != nullptr, FMX_ERR_INVALID, "NULL argument");
+  if (e->group) FMX_TRY(group_make_replicated(e));   // (after owner-sharded steps the optimizer state of a feature is current at its owner only)
   FMX_TRY(use_device(e->cfg.device));
   FMX_HIP(hipStreamSynchronize(e->stream));
   FILE* f = fopen(path, "wb");

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fmx.h"
@@ -529,6 +530,8 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
 int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int64_t total_rows,
                        int64_t* examples_done, double* ingest_wait_s);
 void free_matrix(fmx_matrix* m);
+void engine_tables(fmx_engine* e, std::vector<std::pair<void*, size_t>>* out, bool params_only);
+int group_make_replicated(fmx_engine* e);  // every replica's copy of every table current again (no-op unless owner-sharded steps ran since)
 int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch);
 int group_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows);
 int group_rccl_selftest(int n, double* max_err);

@@ -146,8 +146,7 @@ def test_group_compact_exchange_for_sparse_tiles_is_bitwise_the_dense_one(monkey
     total = 3 * 2 * B + 700          # three full global steps and a truncated one (rank 0: 700 rows, rank 1: none)
     out = {}
     for form in ("compact", "dense"):
-        if form == "dense":
-            monkeypatch.setenv("FMX_GROUP_EXCHANGE", "dense")
+        monkeypatch.setenv("FMX_GROUP_EXCHANGE", form)
         res = {}
         for solver in ("sgd", "ftrl"):
             m = engine.Matrix.from_csr(rp, col, val, p, y)
@@ -162,6 +161,70 @@ def test_group_compact_exchange_for_sparse_tiles_is_bitwise_the_dense_one(monkey
         a, b = out["compact"][solver], out["dense"][solver]
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert np.any(a[2] != v0)
+
+
+@pytest.mark.parametrize("n_gpus", [2, 3])
+def test_group_owner_sharded_exchange(monkeypatch, tmp_path, n_gpus):
+    """The default exchange of a cfg.n_gpus > 1 handle on sparse tiles: feature j belongs to replica j mod N, the step's rows are pulled
+    from their owners, record slices go to the owners by peer copies, the owner updates (fm_group.hip: exchange_owner).  Bitwise the
+    all-gather form (FMX_GROUP_EXCHANGE=compact) for SGD and FTRL, heavy hitters and a truncated last step included, resident shards and
+    streamed ones; afterwards the handle answers with current V and w, a checkpoint written from it holds every feature's current
+    optimizer state (the replicas are made whole first), and a later call in another form continues from the same state."""
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(22)
+    n, p, z, k, B = 9000, 150_000, 10, 8, 1000
+    rows = []
+    for r in range(n):
+        hot = [j for j, q in ((3, 0.9), (60_000, 0.5)) if rng.random() < q]
+        rows.append(np.unique(np.concatenate([hot, rng.integers(0, 3000, 3), rng.integers(3000, p, z - 3)])).astype(np.uint32))
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows); val = rng.normal(0, 1, len(col)).astype(np.float32)
+    y = util.labels(n, 22)
+    v0 = np.random.default_rng(2).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+    total = 2 * n_gpus * B + B + 300          # two full global steps and a truncated one (rank 0: all its rows, rank 1: 300, the others none)
+    same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    vocab = [40_000, 9_000, 700, 40, 5, 3]
+    ps = 4 + sum(vocab)
+    vs = np.random.default_rng(4).normal(0, 0.05, (k, ps)).astype(np.float32).astype(np.float64)
+    out = {}
+    for form in ("owner", "compact"):
+        monkeypatch.setenv("FMX_GROUP_EXCHANGE", form)
+        res = {}
+        for solver in ("sgd", "ftrl"):
+            kw = dict(solver=L.SOLVER_SGD if solver == "sgd" else L.SOLVER_FTRL, num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3,
+                      l1_v=1e-4 if solver == "ftrl" else 0.0, mode=L.MODE_MINIBATCH, batch_reduce=L.REDUCE_MEAN if solver == "sgd" else L.REDUCE_SUM)
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            g = engine.Engine(p, batch_rows=B, n_gpus=n_gpus, gpus_share_device=1, **kw)
+            g.set_params(0.0, None, v0)
+            assert g.train(m, total) == total
+            first = g.get_params()
+            ck = tmp_path / f"{form}_{solver}.fmx"
+            g.save(ck)                                    # (owner form: every replica is made whole before the tables are written)
+            assert g.train(m, n_gpus * B) == n_gpus * B   # and training goes on from there, in the same form
+            second = g.get_params()
+            one = engine.Engine(p, batch_rows=B, **kw)    # the checkpoint continues on ONE GPU like the handle's own next steps on the global batches
+            one.load(ck)
+            res[solver] = (first, second, one.get_params(), g.predict(m))
+            s = engine.Engine(ps, batch_rows=1500, n_gpus=n_gpus, gpus_share_device=1, **kw)
+            s.set_params(0.0, None, vs)
+            assert s.train_stream(n_gpus * 4000 + 777, seed=31, fields=(4, vocab, 2.5))[0] == n_gpus * 4000 + 777
+            res[solver + "_stream"] = s.get_params()
+            # a dense-tile matrix on the handle that has just run owner-sharded steps: the replicas are made whole, then the dense exchange runs
+            rp2, col2, val2 = util.random_csr(4000, p, 40, seed=5, empty_rows=False)
+            m2 = engine.Matrix.from_csr(rp2, col2, val2, p, util.labels(4000, 5))
+            g2 = engine.Engine(p, batch_rows=4000 // n_gpus, n_gpus=n_gpus, gpus_share_device=1, **kw)
+            g2.set_params(0.0, None, v0)
+            g2.train(m, n_gpus * B)
+            g2.train(m2, 2 * 4000)
+            res[solver + "_then_dense"] = g2.get_params()
+        out[form] = res
+    for key in out["owner"]:
+        a, b = out["owner"][key], out["compact"][key]
+        if key in ("sgd", "ftrl"):
+            assert same(a[0], b[0]) and same(a[1], b[1]) and same(a[2], b[2]) and np.array_equal(a[3], b[3]), key
+            assert same(a[0], a[2]) and np.any(a[0][2] != v0) and np.any(a[1][2] != a[0][2])
+        else:
+            assert same(a, b), key
 
 
 def test_group_handle_init_normal_set_rows_and_step_level_refusals():
