@@ -1287,8 +1287,9 @@ static int launch_cols_kind(fmx_engine* e, const ColsArgs& a, const LongArgs& la
   // a sparse tile they run BESIDE it, on a stream of their own.  The list-by-list walk is bound by dependent rounds x occupancy and
   // leaves the memory system idle; the segments of the long lists stream S rows at cache bandwidth (section 6.7).  FMX_LONG_SIDE=0: one stream.
   static const bool side_ok = [] { const char* v = getenv("FMX_LONG_SIDE"); return !(v && v[0] == '0'); }();
-  // (only where the long lists are real work: a fork and a join between two streams cost 0.14 ms per step when the side stream's kernels are a few
-  // microseconds long -- uniform columns over 250 000 features, a handful of long lists: 1 087 -> 681 M examples/s -- and nothing when they are 0.13 ms)
+  // (only where the long lists are real work: a fork and a join between two streams cost about 10 us -- profiles/probes/stream_hop.hip: 13.5 us per
+  // dependency hop against 2.5 us per kernel on one stream -- which a handful of long lists cannot earn back, and the side stream's one-off creation
+  // took 5 ms out of a 40-step timed region when the first tile with a long list came late: uniform columns over 250 000 features, 1 087 -> 681 M)
   const bool side = lng && sparse_form && side_ok && la.n_seg >= 2048;
   hipStream_t ls = e->stream;
   if (side) {
