@@ -137,10 +137,11 @@ def pmc_traffic(kernel, args):
         def opt(name, default):
             return int(a[a.index(name) + 1]) if name in a else default
         solver = "ftrl" if "ftrl" in a else "sgd"
-        k = opt("--factors", 16 if solver == "sgd" else 64)
-        same = (effective_tile(opt("--batch-rows", 262_144 if solver == "sgd" else 1_048_576), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
-                and k == args.factors and opt("--features", 1_000_000) == args.features and opt("--rows", 10_000_000) == args.rows
-                and opt("--nnz", 30) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64)
+        crit = "--workload" in a and a[a.index("--workload") + 1] == "criteo"   # (parse() resolves the Criteo shape's own defaults)
+        k = opt("--factors", 32 if crit else (16 if solver == "sgd" else 64))
+        same = (effective_tile(opt("--batch-rows", 262_144 if (solver == "sgd" or crit) else 1_048_576), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
+                and k == args.factors and (33_000_000 if crit else opt("--features", 1_000_000)) == args.features and opt("--rows", 8_000_000 if crit else 10_000_000) == args.rows
+                and (39 if crit else opt("--nnz", 30)) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64)
                 and (a[a.index("--workload") + 1] if "--workload" in a else "uniform") == args.workload)
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
             best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f))

@@ -211,7 +211,7 @@ struct fmx_engine {
   // fp32 mini-batch tables, "w in the row" layout: V rows lie vstride32 floats apart; with w_in_row = 1 the stride is 2 * kp32 and
   // the feature's linear weight sits in slot kp32 of its own row (V[16] | w | ... in ONE 128-byte line for k = 16), e->w is null.
   // Out of the caches a nonzero then costs one memory request instead of two (V row + w: measured at p = 16 M, 14.8 M of the
-  // 15.7 M fabric reads of a phase-1 launch were those two misses per nonzero, profiles/r03_pmc_summary_p16m.json), and phase 2's
+  // 15.7 M fabric reads of a phase-1 launch were those two misses per nonzero, profiles/r03_pmc_p16m_separate_tables.json), and phase 2's
   // sparse walk touches one line per feature.  Chosen at engine creation (p >= 3 M and kp32 <= 16; FMX_W_IN_ROW=0/1 overrides):
   // cache-resident tables gain nothing and a dense phase-2 sweep would stream twice the bytes.
   int vstride32 = 0;
