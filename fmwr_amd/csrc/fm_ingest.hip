@@ -1276,17 +1276,23 @@ __host__ __device__ inline Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32
 // entry i of global row g: stratum i of nnz equal-width strata of [0,p); position inside it from Philox(seed; g, i/4)[i%4]
 __global__ void synth_entries_k(int64_t n, uint32_t p, int32_t z, uint64_t seed, int64_t row_offset, uint32_t* __restrict__ col,
                                 float* __restrict__ val) {
+  // one thread per Philox block (entries 4 q .. 4 q + 3 of a row)
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * z) return;
-  const int64_t r = t / z;
-  const uint32_t i = (uint32_t)(t - r * z);
+  const int gq = (z + 3) / 4;
+  if (t >= n * gq) return;
+  const int64_t r = t / gq;
+  const uint32_t q = (uint32_t)(t - r * gq);
   const uint64_t g = (uint64_t)(row_offset + r);
-  const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), i >> 2, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const uint32_t rnd = ph.c[i & 3];
-  const uint32_t lo = (uint32_t)(((uint64_t)i * p) / (uint32_t)z);
-  const uint32_t hi = (uint32_t)(((uint64_t)(i + 1) * p) / (uint32_t)z);
-  col[t] = lo + (uint32_t)(((uint64_t)rnd * (hi - lo)) >> 32);
-  val[t] = 1.0f;
+  const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), q, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t i = 4 * q + (uint32_t)u;
+    if ((int)i >= z) break;
+    const uint32_t lo = (uint32_t)(((uint64_t)i * p) / (uint32_t)z);
+    const uint32_t hi = (uint32_t)(((uint64_t)(i + 1) * p) / (uint32_t)z);
+    col[r * z + i] = lo + (uint32_t)(((uint64_t)ph.c[u] * (hi - lo)) >> 32);
+    val[r * z + i] = 1.0f;
+  }
 }
 
 __global__ void synth_rows_k(int64_t n, int32_t z, uint64_t seed, int64_t row_offset, int64_t* __restrict__ row_ptr, float* __restrict__ y) {
@@ -1303,7 +1309,7 @@ __global__ void synth_rows_k(int64_t n, int32_t z, uint64_t seed, int64_t row_of
 // enqueue the generator for rows [row_offset, row_offset + n) on `stream` (no wait)
 int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream) {
   const int T = 256;
-  const int64_t total = n * z;
+  const int64_t total = n * ((z + 3) / 4);
   if (total > 0)
     hipLaunchKernelGGL(synth_entries_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, stream, n, m->p, z, seed, row_offset, m->col, m->val);
   hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((n + 1 + T - 1) / T)), dim3(T), 0, stream, n, z, seed, row_offset, m->row_ptr, m->y);
@@ -1368,32 +1374,40 @@ int generate_iid_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64
 // ids (a power-law head like real click logs: a few values of a field occur in most rows, most values almost never).
 // One-hot value 1.  Philox keyed by (seed; global row, entry / 4) like the uniform generator: shard independent.
 __global__ void synth_fields_k(int64_t n, FieldSpec fs, uint64_t seed, int64_t row_offset, uint32_t* __restrict__ col, float* __restrict__ val) {
+  // one thread per Philox block: entries 4 q .. 4 q + 3 of a row share the block keyed (row, q) -- four threads used to compute it each for one word
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int z = fs.n_dense + fs.n_fields;
-  if (t >= n * z) return;
-  const int64_t r = t / z;
-  const uint32_t i = (uint32_t)(t - r * z);
+  const int gq = (z + 3) / 4;
+  if (t >= n * gq) return;
+  const int64_t r = t / gq;
+  const uint32_t q = (uint32_t)(t - r * gq);
   const uint64_t g = (uint64_t)(row_offset + r);
-  const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), i >> 2, 0xF1E1D5u, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const double u = (double)ph.c[i & 3] / 4294967296.0;
-  if ((int)i < fs.n_dense) {
-    col[t] = i;
-    val[t] = (float)u;
-  } else {
-    const int f = (int)i - fs.n_dense;
-    // (small integer exponents by multiplication: pow() in fp64 was most of this kernel's 98 us per 262 144-row tile)
-    const double x = fs.skew == 1.0 ? u : fs.skew == 2.0 ? u * u : fs.skew == 3.0 ? u * u * u : pow(u, fs.skew);
-    uint32_t id = (uint32_t)(x * (double)fs.vocab[f]);
-    if (id >= fs.vocab[f]) id = fs.vocab[f] - 1;
-    col[t] = fs.base[f] + id;
-    val[t] = 1.0f;
+  const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), q, 0xF1E1D5u, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t i = 4 * q + (uint32_t)u;
+    if ((int)i >= z) break;
+    const int64_t at = r * z + i;
+    const double uu = (double)ph.c[u] / 4294967296.0;
+    if ((int)i < fs.n_dense) {
+      col[at] = i;
+      val[at] = (float)uu;
+    } else {
+      const int f = (int)i - fs.n_dense;
+      // (small integer exponents by multiplication: pow() in fp64 was most of this kernel's 98 us per 262 144-row tile)
+      const double x = fs.skew == 1.0 ? uu : fs.skew == 2.0 ? uu * uu : fs.skew == 3.0 ? uu * uu * uu : pow(uu, fs.skew);
+      uint32_t id = (uint32_t)(x * (double)fs.vocab[f]);
+      if (id >= fs.vocab[f]) id = fs.vocab[f] - 1;
+      col[at] = fs.base[f] + id;
+      val[at] = 1.0f;
+    }
   }
 }
 
 int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream) {
   const int T = 256;
   const int z = fs.n_dense + fs.n_fields;
-  const int64_t total = n * z;
+  const int64_t total = n * ((z + 3) / 4);
   if (total > 0) hipLaunchKernelGGL(synth_fields_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, stream, n, fs, seed, row_offset, m->col, m->val);
   hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((n + 1 + T - 1) / T)), dim3(T), 0, stream, n, z, seed, row_offset, m->row_ptr, m->y);
   FMX_HIP(hipGetLastError());

@@ -71,6 +71,37 @@ def test_generator_matches_numpy_philox(fm):
     np.testing.assert_array_equal(whole[3][3000:], part[3])
 
 
+def test_fields_generator_matches_numpy_philox(fm):
+    """The Criteo-shaped generator (fm_ingest.hip: synth_fields_k) against the same independent numpy Philox: entry i of row g is word i mod 4 of
+    the block keyed (g, i / 4, 0xF1E1D5); a dense feature's value is the word / 2^32 in fp32, a categorical id floor(vocab * u^skew) clamped into
+    the field, its value 1."""
+    engine, L = fm
+    vocab, d, skew, seed = [5_000_000, 70_000, 900, 17, 3, 1], 3, 3.0, 77
+    for n, off in ((4000, 0), (1000, 2 ** 33 + 5)):
+        m = engine.Matrix.synthetic_fields(n, d, vocab, skew, seed, row_offset=off)
+        rp, col, val, y = m.export()
+        z = d + len(vocab)
+        g = np.arange(off, off + n, dtype=np.uint64)
+        k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+        base = d + np.concatenate([[0], np.cumsum(vocab)[:-1]])
+        ecol = np.zeros((n, z), np.uint32); eval_ = np.ones((n, z), np.float32)
+        for blk in range((z + 3) // 4):
+            words = philox4x32_10(g & np.uint64(0xFFFFFFFF), g >> np.uint64(32), np.full(n, blk, np.uint64), np.full(n, 0xF1E1D5, np.uint64), k0, k1)
+            for j in range(4):
+                i = blk * 4 + j
+                if i >= z:
+                    break
+                u = words[j].astype(np.float64) / 4294967296.0
+                if i < d:
+                    ecol[:, i] = i; eval_[:, i] = u.astype(np.float32)
+                else:
+                    f = i - d
+                    ecol[:, i] = base[f] + np.minimum(np.floor(u * u * u * vocab[f]).astype(np.int64), vocab[f] - 1)
+        np.testing.assert_array_equal(col.reshape(n, z), ecol)
+        np.testing.assert_array_equal(val.reshape(n, z), eval_)
+        np.testing.assert_array_equal(rp, np.arange(n + 1) * z)
+
+
 def test_full_size_forward_closed_form(fm, big):
     """Every row holds exactly Z distinct features with x = 1: with w = c and every V row = a,
     y_hat = w0 + Z*c + 0.5*(Z*Z - Z)*sum(a^2) for all 10M rows."""
