@@ -720,13 +720,14 @@ __global__ __launch_bounds__(G::THREADS) void fq_scatter_k(FieldPass P, const ui
 struct FieldBases { uint32_t base[FMX_MAX_FIELDS]; };
 __global__ __launch_bounds__(256) void fields_split_local_k(const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t nrows, int z, int d, FieldBases fb,
                                                             uint32_t* __restrict__ keys_sorted, uint32_t* __restrict__ brow, float* __restrict__ bval,
-                                                            uint32_t* __restrict__ keys_in) {
+                                                            uint32_t* __restrict__ keys_in, int unit) {
+  // (unit: a one-hot matrix -- d = 0, nobody reads its value arrays)
   __shared__ uint32_t s_col[FS_ROWS * 64];
   __shared__ float s_val[FS_ROWS * 64];
   const int64_t R0 = (int64_t)blockIdx.x * FS_ROWS;
   const int rows = (int)(nrows - R0 < FS_ROWS ? nrows - R0 : FS_ROWS);
   const int cnt = rows * z;
-  for (int i = threadIdx.x; i < cnt; i += 256) { s_col[i] = col[R0 * z + i]; s_val[i] = val[R0 * z + i]; }
+  for (int i = threadIdx.x; i < cnt; i += 256) { s_col[i] = col[R0 * z + i]; if (!unit) s_val[i] = val[R0 * z + i]; }
   __syncthreads();
   for (int i = threadIdx.x; i < d * rows; i += 256) {
     const int c = i / rows, r = i - c * rows;
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256) void fields_split_local_k(const uint32_t* __re
     const int c = i / rows, r = i - c * rows;
     const int64_t at = (int64_t)c * nrows + R0 + r;
     keys_in[at] = s_col[r * z + d + c] - fb.base[c];
-    bval[(int64_t)d * nrows + at] = 1.0f;
+    if (!unit) bval[(int64_t)d * nrows + at] = 1.0f;
   }
 }
 // the dense columns' list heads (column c: entries [c * nrows, (c + 1) * nrows), first row 0)
@@ -831,7 +832,7 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
       FieldBases fb{};
       for (int c = 0; c < z - d; ++c) fb.base[c] = (*field_base)[(size_t)c];
       hipLaunchKernelGGL(fields_split_local_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, val + t.base, t.nrows, z, d, fb,
-                         ws.keys_out, brow + t.base, bval + t.base, keys_in);
+                         ws.keys_out, brow + t.base, bval + t.base, keys_in, 0);
       uint32_t* b_keys = reinterpret_cast<uint32_t*>(ws.vals_out);
       FMX_TRY(field_sort(*field_base, (uint32_t)t.nrows, keys_in, rows_in, b_keys, b_keys + n_cat, ws.keys_out + n_dense, brow + t.base + n_dense, ws.fq_counts,
                          ws.fq_totals, stream));
@@ -841,6 +842,19 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
       size_t tb32 = ws.sort_bytes;
       FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, keys_in, ws.keys_out + n_dense, rows_in, brow + t.base + n_dense, (size_t)n_cat, ws.bits, stream));
     }
+  } else if (cnt > 0 && unit_values && field_base && fixed_row_len > 0 && fixed_row_len <= FMX_MAX_FIELDS && (int)field_base->size() == fixed_row_len + 1 &&
+             cnt == t.nrows * (int64_t)fixed_row_len && !(getenv("FMX_FIELD_SORT") && getenv("FMX_FIELD_SORT")[0] == '0') && ws.fq_counts != nullptr) {
+    // one-hot rows whose entry i is an id of field i (the uniform generator: one column per stratum of [0, p)): the per-field sort with no dense part
+    const int z = fixed_row_len;
+    field_sorted = true;
+    FieldBases fb{};
+    for (int c = 0; c < z; ++c) fb.base[c] = (*field_base)[(size_t)c];
+    uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws.vals_in);
+    uint32_t* rows_in = keys_in + cnt;
+    hipLaunchKernelGGL(fields_split_local_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, (const float*)nullptr, t.nrows, z, 0, fb,
+                       ws.keys_out, brow + t.base, bval + t.base, keys_in, 1);
+    uint32_t* b_keys = reinterpret_cast<uint32_t*>(ws.vals_out);
+    FMX_TRY(field_sort(*field_base, (uint32_t)t.nrows, keys_in, rows_in, b_keys, b_keys + cnt, ws.keys_out, brow + t.base, ws.fq_counts, ws.fq_totals, stream));
   } else if (cnt > 0 && unit_values) {
     // one-hot values: sort (column, row) pairs straight into brow -- 8 bytes per entry and pass instead of 12, no unpack pass;
     // bval is never read for such a matrix
@@ -1306,6 +1320,13 @@ __global__ void synth_rows_k(int64_t n, int32_t z, uint64_t seed, int64_t row_of
   }
 }
 
+// entry i of every row of the uniform generator is a column of stratum i = [i p / z, (i + 1) p / z): field-structured rows (fmx_matrix::field_base)
+void strata_bounds(uint32_t p, int32_t z, std::vector<uint32_t>* out) {
+  out->clear();
+  if (z < 1 || z > FMX_MAX_FIELDS) return;
+  for (int i = 0; i <= z; ++i) out->push_back((uint32_t)(((uint64_t)i * p) / (uint32_t)z));
+}
+
 // enqueue the generator for rows [row_offset, row_offset + n) on `stream` (no wait)
 int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream) {
   const int T = 256;
@@ -1324,6 +1345,7 @@ int generate_synthetic(fmx_matrix* m, int32_t z, uint64_t seed, int64_t row_offs
   m->max_row_len = z;
   m->fixed_row_len = z;
   { const char* v = getenv("FMX_UNIT_VALUES"); m->unit_values = !(v && v[0] == '0'); }  // the generator writes 1.0f everywhere
+  strata_bounds(m->p, z, &m->field_base);
   return FMX_OK;
 }
 

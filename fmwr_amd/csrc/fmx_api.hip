@@ -1060,7 +1060,7 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
   m->fixed_row_len = z;
   m->unit_values = (fs.n_dense == 0) ? 1 : 0;  // the dense features carry values in [0, 1)
   m->dense_prefix = fs.n_dense;
-  if (fs.n_dense > 0) { m->field_base.assign(fs.base, fs.base + fs.n_fields); m->field_base.push_back((uint32_t)p); }
+  if (fs.n_fields > 0) { m->field_base.assign(fs.base, fs.base + fs.n_fields); m->field_base.push_back((uint32_t)p); }
   *out = m;
   return FMX_OK;
 }
@@ -1331,7 +1331,8 @@ int fmx_source_open(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_
     s.m->rows_sorted = 1; s.m->max_row_len = S->z; s.m->fixed_row_len = S->z;
     s.m->unit_values = (S->has_spec && S->fs.n_dense > 0) ? 0 : 1;  // the uniform generator writes 1.0f everywhere, the Criteo-shaped one has dense values
     s.m->dense_prefix = S->has_spec ? S->fs.n_dense : 0;
-    if (S->has_spec && S->fs.n_dense > 0) { s.m->field_base.assign(S->fs.base, S->fs.base + S->fs.n_fields); s.m->field_base.push_back((uint32_t)S->p); }
+    if (S->has_spec && S->fs.n_fields > 0) { s.m->field_base.assign(S->fs.base, S->fs.base + S->fs.n_fields); s.m->field_base.push_back((uint32_t)S->p); }
+    else if (!S->has_spec && s.m->unit_values) strata_bounds((uint32_t)S->p, (int32_t)S->z, &s.m->field_base);
     FMX_HIP(hipMalloc(&s.m->brow, (size_t)cap_cnt * sizeof(uint32_t)));
     FMX_HIP(hipMalloc(&s.m->bval, (size_t)cap_cnt * sizeof(float)));
     s.m->plans.resize(1);

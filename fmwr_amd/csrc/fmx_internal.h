@@ -109,8 +109,8 @@ struct fmx_matrix {
   int dense_prefix = 0; // > 0 (with fixed_row_len): every row STARTS with the columns 0 .. dense_prefix-1 (always-present features with real
                         // values) and every other stored value is exactly 1.0f -- Criteo-shaped rows.  The plan builder then sorts only the
                         // one-hot part, as (column, row) pairs: the dense columns' lists are the rows in order (plan_build)
-  std::vector<uint32_t> field_base;  // with dense_prefix (the field generator only): entry dense_prefix + c of every row is an id of categorical field c,
-                                     // in [field_base[c], field_base[c + 1]); the last element is p.  The plan builder then sorts field by field.
+  std::vector<uint32_t> field_base;  // the generators only: entry dense_prefix + c of every row is an id of field c, in [field_base[c], field_base[c + 1]);
+                                     // the last element is p (the uniform generator: dense_prefix = 0, field c = stratum c).  The plan builder then sorts field by field.
   int max_row_len = 0;  // entries of the longest row
   // Per-tile inverted index ("plan"), built lazily on the device for one (batch_rows, tile_rows) pair (fm_ingest.hip).
   // A step covers batch_rows consecutive rows and is cut into tiles of at most tile_rows rows.
@@ -490,6 +490,7 @@ void debug_fail_next_plan_build();
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream);
+void strata_bounds(uint32_t p, int32_t z, std::vector<uint32_t>* out);
 int generate_iid_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, int kind, double s_exp, hipStream_t stream);
 constexpr int FMX_MAX_FIELDS = 64;
 struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)

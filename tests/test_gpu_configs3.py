@@ -139,10 +139,11 @@ def test_per_field_sort_equals_the_pair_sort(monkeypatch):
     several 8192-entry blocks per field with a ragged last one, tiles shorter than a block, uniform and skewed ids."""
     from fmwr_amd import _lib as L, engine
     same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    for vocab, skew, B, n in (([5_000_000, 300_000, 513, 512, 600, 17, 2, 1], 3.0, 5 * 4096 + 100, 2 * (5 * 4096 + 100) + 900),
-                              ([70_000, 5_000, 3], 1.0, 8192, 8192 + 4096),
-                              ([40_000, 9_000, 700, 40, 5, 3], 2.5, 1000, 3500)):
-        k, d = 4, 2
+    for vocab, skew, B, n, d in (([5_000_000, 300_000, 513, 512, 600, 17, 2, 1], 3.0, 5 * 4096 + 100, 2 * (5 * 4096 + 100) + 900, 2),
+                                 ([70_000, 5_000, 3], 1.0, 8192, 8192 + 4096, 2),
+                                 ([40_000, 9_000, 700, 40, 5, 3], 2.5, 1000, 3500, 2),
+                                 ([200_000, 9_000, 700, 40, 5, 3], 2.0, 5000, 12_000, 0)):     # no dense part: one-hot rows (sparse tiles)
+        k = 4
         p = d + sum(vocab)
         kw = dict(num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
         v0 = np.random.default_rng(4).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
@@ -156,6 +157,22 @@ def test_per_field_sort_equals_the_pair_sort(monkeypatch):
             assert s.train_stream(n, seed=31, fields=(d, vocab, skew))[0] == n
             res[flag] = (e.get_params(), s.get_params())
             e.close(); s.close(); m.close()
+        assert same(res["1"][0], res["0"][0]) and same(res["1"][1], res["0"][1])
+        assert np.any(res["1"][0][2] != v0)
+    # the uniform generator: entry i of a row is a column of stratum i -- its one-hot rows are field-structured too (dense and sparse tiles)
+    for p, z, B, n in ((3_000, 12, 5000, 12_345), (400_000, 30, 6000, 20_000)):
+        k = 4
+        kw = dict(num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
+        v0 = np.random.default_rng(4).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("FMX_FIELD_SORT", flag)
+            m = engine.Matrix.synthetic(n, p, z, 31)
+            e = engine.Engine(p, **kw); e.set_params(0.0, None, v0)
+            assert e.train(m, n + B) == n + B
+            s = engine.Engine(p, **kw); s.set_params(0.0, None, v0)
+            assert s.train_stream(n, nnz_per_row=z, seed=31)[0] == n
+            res[flag] = (e.get_params(), s.get_params())
         assert same(res["1"][0], res["0"][0]) and same(res["1"][1], res["0"][1])
         assert np.any(res["1"][0][2] != v0)
 
