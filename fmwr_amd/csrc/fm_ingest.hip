@@ -1605,6 +1605,48 @@ __global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_
   atomicMax(out + 3, (int)(len > 0x7fffffff ? 0 : 0x7fffffff - (int)len));  // shortest row (as a maximum of the complement)
 }
 
+// Does every row read [columns 0 .. d-1 | one id of field c in [base[c], base[c + 1]) for c = 0 .. C-1, value 1]?
+struct FieldCheck { int d, C; uint32_t base[FMX_MAX_FIELDS + 1]; };
+__global__ void rows_fields_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t n, FieldCheck fc,
+                              int* __restrict__ bad) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t a = row_ptr[r];
+  const int z = fc.d + fc.C;
+  int wrong = row_ptr[r + 1] - a != z;
+  for (int i = 0; i < z && !wrong; ++i) {
+    const uint32_t c = col[a + i];
+    if (i < fc.d) wrong |= c != (uint32_t)i;
+    else wrong |= c < fc.base[i - fc.d] || c >= fc.base[i - fc.d + 1] || val[a + i] != 1.0f;
+  }
+  if (wrong) *bad = 1;
+}
+
+// the caller vouches for a field layout (a one-hot encoded data frame: every factor column is a contiguous range of dummy columns); checked here
+int matrix_set_fields(fmx_matrix* m, int n_dense, int n_fields, const uint32_t* base) {
+  FieldCheck fc{};
+  fc.d = n_dense; fc.C = n_fields;
+  for (int c = 0; c <= n_fields; ++c) fc.base[c] = base[c];
+  FMX_CHECK(base[0] == (uint32_t)n_dense && base[n_fields] == m->p, FMX_ERR_INVALID, "field_base must start at n_dense (%d) and end at the feature count (%u)", n_dense, m->p);
+  for (int c = 0; c < n_fields; ++c) FMX_CHECK(base[c] < base[c + 1], FMX_ERR_INVALID, "field %d is empty or out of order", c);
+  int* d = nullptr;
+  int h = 0;
+  FMX_HIP(hipSetDevice(m->device));
+  FMX_HIP(hipMalloc(&d, sizeof(int)));
+  FMX_HIP(hipMemset(d, 0, sizeof(int)));
+  if (m->n > 0) hipLaunchKernelGGL(rows_fields_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->val, m->n, fc, d);
+  FMX_HIP(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
+  FMX_HIP(hipFree(d));
+  FMX_CHECK(!h, FMX_ERR_INVALID, "the rows do not have this layout: every row must hold the %d dense columns 0..%d, then exactly one id of every field in its range, with value 1",
+            n_dense, n_dense - 1);
+  drop_plans(m);   // plans built on the general path stay valid, but the point of the call is the other builder
+  m->value_generation++;   // (shards cut from this matrix before the call do not know the layout)
+  m->dense_prefix = n_dense;
+  m->fixed_row_len = n_dense + n_fields;
+  m->field_base.assign(base, base + n_fields + 1);
+  return FMX_OK;
+}
+
 int check_rows_sorted(fmx_matrix* m) {
   int* d = nullptr;
   int h[4] = {0, 0, 0, 0};

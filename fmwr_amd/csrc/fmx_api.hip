@@ -1065,6 +1065,12 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
   return FMX_OK;
 }
 
+int fmx_matrix_set_fields(fmx_matrix* m, int32_t n_dense, int32_t n_fields, const uint32_t* field_base) {
+  FMX_CHECK(m != nullptr && field_base != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_CHECK(n_dense >= 0 && n_fields >= 1 && n_fields <= FMX_MAX_FIELDS && n_dense + n_fields <= 64, FMX_ERR_INVALID, "need n_dense >= 0, 1 <= n_fields <= %d and at most 64 entries per row", FMX_MAX_FIELDS);
+  return matrix_set_fields(m, n_dense, n_fields, field_base);
+}
+
 int fmx_matrix_synthetic_iid(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int32_t law, double zipf_s,
                              fmx_matrix** out) {
   FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");

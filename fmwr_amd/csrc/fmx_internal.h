@@ -500,6 +500,7 @@ struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)
 };
 int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream);
 int check_rows_sorted(fmx_matrix* m);
+int matrix_set_fields(fmx_matrix* m, int n_dense, int n_fields, const uint32_t* base);
 int init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev);
 int rows_copy(fmx_engine* e, const uint32_t* d_ids, int64_t n, double* d_w, double* d_v, bool set);
 int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double* h_std);

@@ -87,6 +87,12 @@ class Matrix:
         L.check(L.lib().fmx_matrix_synthetic_fields(C.c_int(device), C.c_int64(n), C.byref(spec), C.c_int64(row_offset), C.byref(h)))
         return cls._wrap(h)
 
+    def set_fields(self, n_dense, field_base):
+        """Vouch for a field layout (fmx_matrix_set_fields): n_dense always-present columns, then one id of every field c in
+        [field_base[c], field_base[c + 1]) with value 1; checked on the device."""
+        fb = np.ascontiguousarray(field_base, np.uint32)
+        L.check(L.lib().fmx_matrix_set_fields(self.h, C.c_int32(int(n_dense)), C.c_int32(len(fb) - 1), _p(fb)))
+
     def set_labels(self, y):
         y = np.ascontiguousarray(y, np.float32)
         if len(y) != self.n:

@@ -186,6 +186,13 @@ typedef struct fmx_fields_spec {
   uint64_t seed;
 } fmx_fields_spec;
 int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* spec, int64_t row_offset, fmx_matrix** out);
+/* Field-structured rows -- what fm.matrix makes of a data frame whose factor columns are one-hot encoded (R/fm_matrix.R: model.matrix keeps a
+ * factor's dummy columns together): every row holds the n_dense always-present columns 0 .. n_dense-1 (any values), then exactly ONE id of each of
+ * n_fields (<= 64) categorical fields, field c's ids lying in [field_base[c], field_base[c + 1]) with value 1 (field_base[0] = n_dense,
+ * field_base[n_fields] = the feature count).  The layout is checked on the device (FMX_ERR_INVALID if a row differs); the inverted index of a step is
+ * then built field by field -- a column's ids inside its field are sorted on ceil(log2 vocabulary) bits, the dense columns are not sorted at all --
+ * instead of by one sort of all column ids: same plan, same results, about twice the planning rate.  The generators set it themselves. */
+int fmx_matrix_set_fields(fmx_matrix* m, int32_t n_dense, int32_t n_fields, const uint32_t* field_base);
 /* Replace the labels of a device-resident matrix (y: f32[n] on the host): e.g. labels planted from a known model. */
 int fmx_matrix_set_labels(fmx_matrix* m, const float* y);
 /* SURVEY 8(d)'s other column laws (fmx_matrix_synthetic draws one column per stratum of [0, p)): nnz_per_row (<= 64) columns

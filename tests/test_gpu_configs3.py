@@ -177,6 +177,42 @@ def test_per_field_sort_equals_the_pair_sort(monkeypatch):
         assert np.any(res["1"][0][2] != v0)
 
 
+def test_a_caller_can_vouch_for_the_field_layout(monkeypatch):
+    """fmx_matrix_set_fields: rows uploaded as CSR (what fm.matrix hands over for a one-hot encoded data frame) with the field layout named by the
+    caller take the per-field plan builder like the generator's own matrices -- same training bit for bit as the general sort -- after a check on the
+    device; a layout the rows do not have is refused and leaves the matrix as it was."""
+    from fmwr_amd import _lib as L, engine
+    same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for d, vocab in ((3, [50_000, 6_000, 300, 12, 2]), (0, [90_000, 5_000, 40])):
+        n, B, k = 9000, 2500, 4
+        p = d + sum(vocab)
+        base = d + np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
+        rp, col, val, y = engine.Matrix.synthetic_fields(n, d, vocab, 2.0, 9).export()
+        kw = dict(num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
+        v0 = np.random.default_rng(4).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+        res = []
+        for fields in (False, True):
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            if fields:
+                m.set_fields(d, base)
+            e = engine.Engine(p, **kw); e.set_params(0.0, None, v0)
+            assert e.train(m, n + B) == n + B
+            res.append(e.get_params())
+        assert same(res[0], res[1]) and np.any(res[0][2] != v0)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        wrong2 = base.copy(); wrong2[1] -= 1000                  # field 0 too narrow: its larger ids are out of range
+        with pytest.raises(L.FmxError, match="do not have this layout"):
+            m.set_fields(d, wrong2)
+        with pytest.raises(L.FmxError, match="field_base must start"):
+            m.set_fields(d + 1, base)
+        col2 = col.copy(); col2[d + 1] = col2[d]                 # a row with two ids of the same field (and unsorted): refused
+        m2 = engine.Matrix.from_csr(rp, col2, val, p, y)
+        with pytest.raises(L.FmxError, match="do not have this layout"):
+            m2.set_fields(d, base)
+        e = engine.Engine(p, **kw); e.set_params(0.0, None, v0)   # the refused matrix still trains (general path)
+        assert e.train(m, B) == B
+
+
 def test_per_field_sort_at_the_full_configs3_shape(monkeypatch):
     """The same comparison at BASELINE.json configs[3]'s own step: 33 M features in 13 dense + 26 categorical fields of 3 .. 9.9 M values,
     k = 32, steps of 262 144 rows (one sparse tile of 10.2 M entries, 64 blocks per field, three sort passes for the large fields).  Three
