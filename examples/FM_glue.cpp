@@ -68,6 +68,12 @@ static fmx_matrix* matrix_from_fm_matrix(List X, SEXP labels) {   // src/FM.cpp:
   fmx_matrix* m = nullptr;
   const double* y = Rf_isNull(labels) ? nullptr : REAL(labels);
   fmx_check(fmx_matrix_from_rlist(0, dim[0], (uint32_t)dim[1], value.size(), value.begin(), col_idx.begin(), row_size.begin(), y, &m));
+  // Optional: a matrix made from a data frame with one-hot encoded factors (numeric columns first) may name its layout -- R/fm_matrix.R would pass
+  // the ranges along as X$field_base (from model.matrix's "assign" attribute) -- and the step plans are then built field by field, twice as fast:
+  //   if (X.containsElementNamed("field_base")) {
+  //     IntegerVector fb = X["field_base"];  std::vector<uint32_t> b(fb.begin(), fb.end());
+  //     if (fmx_matrix_set_fields(m, (int32_t)b[0], (int32_t)b.size() - 1, b.data()) != FMX_OK) { /* not that layout: the general path is used */ }
+  //   }
   return m;
 }
 
