@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <thread>
 #include <type_traits>
+#include <vector>
 #include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
 
 #include <rocprim/rocprim.hpp>
@@ -1586,6 +1588,153 @@ int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std) {
   (void)hipFree(d_mean); (void)hipFree(d_std);
   drop_value_caches(m);
   return check_rows_sorted(m);
+}
+
+// ------------------------------------------------------------------------------------------------ host hand-over
+// fm.matrix's arrays live in pageable host memory (R vectors): value f64, col_idx i32, row_size i32, labels f64.  They are copied as they are --
+// 64 MB pieces, a few host threads filling one pinned buffer while the other is on the wire and the piece before it is being converted -- and
+// narrowed, range-checked and prefix-summed ON THE DEVICE (util/Smatrix.h:53-60 does this in a host loop; so did round 1-3's first version:
+// 0.96 s for the 3.7 GB of the 10 M x 1 M matrix, 3.9 GB/s, thirty-five times the epoch that follows).
+namespace {
+struct Stager {
+  size_t PIECE = 64u << 20;   // (smaller for small matrices: two pinned and two device buffers of this size are made per hand-over)
+  void* pin[2] = {nullptr, nullptr};
+  void* dev[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  hipStream_t st = nullptr;
+  int threads = 1;
+  bool used[2] = {false, false};
+  int open(size_t largest_array_bytes) {
+    while (PIECE > (1u << 20) && PIECE / 2 >= largest_array_bytes) PIECE /= 2;
+    unsigned hc = std::thread::hardware_concurrency();
+    threads = hc >= 16 ? 8 : (hc >= 4 ? 4 : 1);
+    FMX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      FMX_HIP(hipHostMalloc(&pin[i], PIECE, hipHostMallocDefault));
+      FMX_HIP(hipMalloc(&dev[i], PIECE));
+      FMX_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    return FMX_OK;
+  }
+  ~Stager() {
+    if (st) (void)hipStreamSynchronize(st);
+    for (int i = 0; i < 2; ++i) { if (pin[i]) (void)hipHostFree(pin[i]); (void)hipFree(dev[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
+    if (st) (void)hipStreamDestroy(st);
+  }
+  // `count` elements of `elem` bytes from host memory; consume(device piece, index of its first element, elements in it) enqueues on st
+  template <typename F>
+  int run(const void* host, size_t elem, int64_t count, F consume) {
+    const int64_t per = (int64_t)(PIECE / elem);
+    int64_t piece = 0;
+    for (int64_t i0 = 0; i0 < count; i0 += per, ++piece) {
+      const int b = (int)(piece & 1);
+      const int64_t n = count - i0 < per ? count - i0 : per;
+      if (used[b]) FMX_HIP(hipEventSynchronize(done[b]));   // the piece that last went through this buffer has been consumed
+      const char* src = (const char*)host + (size_t)i0 * elem;
+      const size_t bytes = (size_t)n * elem;
+      if (threads > 1 && bytes >= (4u << 20)) {
+        std::vector<std::thread> pool;
+        const size_t slice = (bytes / (size_t)threads + 4095) & ~(size_t)4095;
+        for (int t = 0; t < threads; ++t) {
+          const size_t a = (size_t)t * slice;
+          if (a >= bytes) break;
+          const size_t len = a + slice < bytes ? slice : bytes - a;
+          pool.emplace_back([=] { memcpy((char*)pin[b] + a, src + a, len); });
+        }
+        for (auto& th : pool) th.join();
+      } else {
+        memcpy(pin[b], src, bytes);
+      }
+      FMX_HIP(hipMemcpyAsync(dev[b], pin[b], bytes, hipMemcpyHostToDevice, st));
+      FMX_TRY(consume(dev[b], i0, n));
+      FMX_HIP(hipEventRecord(done[b], st));
+      used[b] = true;
+    }
+    return FMX_OK;
+  }
+};
+}  // namespace
+
+__global__ void narrow_values_k(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+template <typename IN>
+__global__ void check_cols_k(const IN* __restrict__ in, uint32_t* __restrict__ out, int64_t n, uint32_t p, int64_t first, unsigned long long* __restrict__ first_bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const IN c = in[i];
+  if (c < (IN)0 || (uint64_t)c >= (uint64_t)p) atomicMin(first_bad, (unsigned long long)(first + i));
+  out[i] = (uint32_t)c;
+}
+__global__ void copy_words_k(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void sizes_to_i64_k(const int32_t* __restrict__ in, int64_t* __restrict__ out, int64_t n, int64_t first, unsigned long long* __restrict__ first_bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (in[i] < 0) atomicMin(first_bad, (unsigned long long)(first + i));
+  out[i] = (int64_t)in[i];
+}
+__global__ void rowptr_check_k(const int64_t* __restrict__ rp, int64_t n, unsigned long long* __restrict__ first_bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && rp[i + 1] < rp[i]) atomicMin(first_bad, (unsigned long long)i);
+}
+
+// the device arrays of m from host arrays: values f64 or f32, columns i32 or u32, row sizes (i32) or row offsets (i64), labels f64 or f32.
+// bad[0] = first column out of range, bad[1] = first negative row size / decreasing offset, total = what the offsets end in
+int ingest_host_arrays(fmx_matrix* m, const void* values, bool values_f64, const void* cols, bool cols_signed, const int32_t* row_size, const int64_t* row_ptr,
+                       const void* labels, bool labels_f64, uint64_t bad[2], int64_t* total) {
+  Stager S;
+  FMX_HIP(hipSetDevice(m->device));
+  FMX_HIP(hipDeviceSynchronize());   // (the matrix was allocated and zeroed through the null stream; the pieces below run on a stream of their own)
+  FMX_TRY(S.open((size_t)(m->nnz > m->n ? m->nnz : m->n + 1) * 8));
+  unsigned long long* d_bad = nullptr;
+  FMX_HIP(hipMalloc(&d_bad, 2 * sizeof(unsigned long long)));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } free_bad{d_bad};
+  FMX_HIP(hipMemsetAsync(d_bad, 0xFF, 2 * sizeof(unsigned long long), S.st));
+  const int T = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + T - 1) / T)); };
+  if (m->nnz > 0) {
+    float* val = m->val; uint32_t* col = m->col; const uint32_t p = m->p;
+    hipStream_t st = S.st;
+    if (values_f64) FMX_TRY(S.run(values, 8, m->nnz, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL(narrow_values_k, grid(n), dim3(T), 0, st, (const double*)d, val + i0, n); return FMX_OK; }));
+    else FMX_TRY(S.run(values, 4, m->nnz, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL(copy_words_k, grid(n), dim3(T), 0, st, (const uint32_t*)d, (uint32_t*)val + i0, n); return FMX_OK; }));
+    if (cols_signed) FMX_TRY(S.run(cols, 4, m->nnz, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL((check_cols_k<int32_t>), grid(n), dim3(T), 0, st, (const int32_t*)d, col + i0, n, p, i0, d_bad); return FMX_OK; }));
+    else FMX_TRY(S.run(cols, 4, m->nnz, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL((check_cols_k<uint32_t>), grid(n), dim3(T), 0, st, (const uint32_t*)d, col + i0, n, p, i0, d_bad); return FMX_OK; }));
+  }
+  if (row_size) {   // sizes -> offsets: an exclusive scan in place over [0, n], entry n = the total
+    int64_t* rp = m->row_ptr;
+    hipStream_t st = S.st;
+    FMX_HIP(hipMemsetAsync(rp + m->n, 0, sizeof(int64_t), st));
+    if (m->n > 0) FMX_TRY(S.run(row_size, 4, m->n, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL(sizes_to_i64_k, grid(n), dim3(T), 0, st, (const int32_t*)d, rp + i0, n, i0, d_bad + 1); return FMX_OK; }));
+    size_t tb = 0;
+    FMX_HIP(rocprim::exclusive_scan(nullptr, tb, rp, rp, (int64_t)0, (size_t)m->n + 1, rocprim::plus<int64_t>(), st));
+    void* tmp = nullptr;
+    FMX_HIP(hipMalloc(&tmp, tb ? tb : 16));
+    Free free_tmp{tmp};
+    FMX_HIP(rocprim::exclusive_scan(tmp, tb, rp, rp, (int64_t)0, (size_t)m->n + 1, rocprim::plus<int64_t>(), st));
+    FMX_HIP(hipStreamSynchronize(st));
+  } else {
+    int64_t* rp = m->row_ptr;
+    hipStream_t st = S.st;
+    FMX_TRY(S.run(row_ptr, 8, m->n + 1, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL(copy_words_k, grid(2 * n), dim3(T), 0, st, (const uint32_t*)d, (uint32_t*)(rp + i0), 2 * n); return FMX_OK; }));
+    if (m->n > 0) hipLaunchKernelGGL(rowptr_check_k, grid(m->n), dim3(T), 0, st, (const int64_t*)rp, m->n, d_bad + 1);
+  }
+  if (labels && m->n > 0) {
+    float* y = m->y;
+    hipStream_t st = S.st;
+    if (labels_f64) FMX_TRY(S.run(labels, 8, m->n, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL(narrow_values_k, grid(n), dim3(T), 0, st, (const double*)d, y + i0, n); return FMX_OK; }));
+    else FMX_TRY(S.run(labels, 4, m->n, [&](void* d, int64_t i0, int64_t n) { hipLaunchKernelGGL(copy_words_k, grid(n), dim3(T), 0, st, (const uint32_t*)d, (uint32_t*)y + i0, n); return FMX_OK; }));
+  }
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipStreamSynchronize(S.st));
+  unsigned long long h_bad[2];
+  FMX_HIP(hipMemcpy(h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost));
+  bad[0] = h_bad[0]; bad[1] = h_bad[1];
+  FMX_HIP(hipMemcpy(total, m->row_ptr + m->n, sizeof(int64_t), hipMemcpyDeviceToHost));
+  return FMX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ sortedness

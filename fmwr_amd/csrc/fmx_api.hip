@@ -239,16 +239,6 @@ static int alloc_matrix(int device, int64_t n, uint32_t p, int64_t nnz, bool lab
   return FMX_OK;
 }
 
-static int upload_matrix(fmx_matrix* m, const int64_t* row_ptr, const uint32_t* col, const float* val, const float* y) {
-  FMX_HIP(hipMemcpy(m->row_ptr, row_ptr, ((size_t)m->n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-  if (m->nnz) {
-    FMX_HIP(hipMemcpy(m->col, col, (size_t)m->nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FMX_HIP(hipMemcpy(m->val, val, (size_t)m->nnz * sizeof(float), hipMemcpyHostToDevice));
-  }
-  if (y && m->n) FMX_HIP(hipMemcpy(m->y, y, (size_t)m->n * sizeof(float), hipMemcpyHostToDevice));
-  return check_rows_sorted(m);
-}
-
 static int check_pair(const fmx_engine* e, const fmx_matrix* m) {
   FMX_CHECK(e && m, FMX_ERR_INVALID, "NULL handle");
   // core/Model.h:115: "number of input's features is not correct..."
@@ -974,14 +964,22 @@ int fmx_matrix_from_csr(int device, int64_t n, uint32_t p, const int64_t* row_pt
   *out = nullptr;
   FMX_CHECK(row_ptr != nullptr && n >= 0, FMX_ERR_INVALID, "row_ptr is NULL or n < 0");
   FMX_CHECK(row_ptr[0] == 0, FMX_ERR_INVALID, "row_ptr[0] must be 0");
-  for (int64_t i = 0; i < n; ++i) FMX_CHECK(row_ptr[i + 1] >= row_ptr[i], FMX_ERR_INVALID, "row_ptr decreases at row %lld", (long long)i);
   const int64_t nnz = row_ptr[n];
+  FMX_CHECK(nnz >= 0, FMX_ERR_INVALID, "row_ptr ends in a negative count");
   FMX_CHECK(nnz == 0 || (col && val), FMX_ERR_INVALID, "col/val is NULL");
-  // the reference leaves this check commented out (core/Model.h:88); on a GPU an out-of-range column is a fault, so it is enforced
-  for (int64_t t = 0; t < nnz; ++t) FMX_CHECK(col[t] < p, FMX_ERR_INVALID, "Length of x is greater then then number of attributes... (col %u at %lld, p=%u)", col[t], (long long)t, p);
   fmx_matrix* m = nullptr;
   FMX_TRY(alloc_matrix(device, n, p, nnz, y != nullptr, &m));
-  int st = upload_matrix(m, row_ptr, col, val, y);
+  // the arrays go over as they are and are checked on the device (fm_ingest.hip: ingest_host_arrays).  The reference leaves the column check
+  // commented out (core/Model.h:88); on a GPU an out-of-range column is a fault, so it is enforced
+  uint64_t bad[2] = {~0ull, ~0ull};
+  int64_t total = 0;
+  int st = ingest_host_arrays(m, val, false, col, false, nullptr, row_ptr, y, false, bad, &total);
+  if (st == FMX_OK && bad[1] != ~0ull) { set_error("row_ptr decreases at row %llu", (unsigned long long)bad[1]); st = FMX_ERR_INVALID; }
+  if (st == FMX_OK && bad[0] != ~0ull) {
+    set_error("Length of x is greater then then number of attributes... (col %u at %llu, p=%u: out of range)", col[bad[0]], (unsigned long long)bad[0], p);
+    st = FMX_ERR_INVALID;
+  }
+  if (st == FMX_OK) st = check_rows_sorted(m);
   if (st != FMX_OK) { free_matrix(m); return st; }
   *out = m;
   return FMX_OK;
@@ -993,23 +991,23 @@ int fmx_matrix_from_rlist(int device, int64_t n, uint32_t p, int64_t nnz, const 
   *out = nullptr;
   FMX_CHECK(n >= 0 && nnz >= 0 && (n == 0 || row_size), FMX_ERR_INVALID, "the length of input's row_size is not correct...");
   FMX_CHECK(nnz == 0 || (value && col_idx), FMX_ERR_INVALID, "value/col_idx is NULL");
-  // util/Smatrix.h:53-60: narrow value f64->f32, col_idx i32->u32, prefix-sum row_size into row_idx
-  std::vector<int64_t> rp((size_t)n + 1, 0);
-  for (int64_t i = 0; i < n; ++i) {
-    FMX_CHECK(row_size[i] >= 0, FMX_ERR_INVALID, "negative row_size at row %lld", (long long)i);
-    rp[(size_t)i + 1] = rp[(size_t)i] + row_size[i];
+  // util/Smatrix.h:53-60 narrows value f64 -> f32 and col_idx i32 -> u32 and prefix-sums row_size into row_idx in a host loop; here the R
+  // vectors are copied as they are and all of that happens on the device (fm_ingest.hip: ingest_host_arrays)
+  fmx_matrix* m = nullptr;
+  FMX_TRY(alloc_matrix(device, n, p, nnz, labels != nullptr, &m));
+  uint64_t bad[2] = {~0ull, ~0ull};
+  int64_t total = 0;
+  int st = ingest_host_arrays(m, value, true, col_idx, true, row_size, nullptr, labels, true, bad, &total);
+  if (st == FMX_OK && bad[1] != ~0ull) { set_error("negative row_size at row %llu", (unsigned long long)bad[1]); st = FMX_ERR_INVALID; }
+  if (st == FMX_OK && total != nnz) {
+    set_error("the length of input's row_size is not correct... (sum %lld, size %lld)", (long long)total, (long long)nnz);
+    st = FMX_ERR_INVALID;
   }
-  FMX_CHECK(rp[(size_t)n] == nnz, FMX_ERR_INVALID, "the length of input's row_size is not correct... (sum %lld, size %lld)", (long long)rp[(size_t)n], (long long)nnz);
-  std::vector<uint32_t> c((size_t)nnz);
-  std::vector<float> x((size_t)nnz);
-  for (int64_t t = 0; t < nnz; ++t) {
-    FMX_CHECK(col_idx[t] >= 0 && (uint32_t)col_idx[t] < p, FMX_ERR_INVALID, "col_idx %d out of range at %lld", col_idx[t], (long long)t);
-    c[(size_t)t] = (uint32_t)col_idx[t];
-    x[(size_t)t] = (float)value[t];
-  }
-  std::vector<float> yl;
-  if (labels) { yl.resize((size_t)n); for (int64_t i = 0; i < n; ++i) yl[(size_t)i] = (float)labels[i]; }  // util/Dvector.h:89-99
-  return fmx_matrix_from_csr(device, n, p, rp.data(), c.data(), x.data(), labels ? yl.data() : nullptr, out);
+  if (st == FMX_OK && bad[0] != ~0ull) { set_error("col_idx %d out of range at %llu", col_idx[bad[0]], (unsigned long long)bad[0]); st = FMX_ERR_INVALID; }
+  if (st == FMX_OK) st = check_rows_sorted(m);
+  if (st != FMX_OK) { free_matrix(m); return st; }
+  *out = m;
+  return FMX_OK;
 }
 
 int fmx_matrix_synthetic(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, fmx_matrix** out) {

@@ -500,6 +500,8 @@ struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)
 };
 int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream);
 int check_rows_sorted(fmx_matrix* m);
+int ingest_host_arrays(fmx_matrix* m, const void* values, bool values_f64, const void* cols, bool cols_signed, const int32_t* row_size, const int64_t* row_ptr,
+                       const void* labels, bool labels_f64, uint64_t bad[2], int64_t* total);
 int matrix_set_fields(fmx_matrix* m, int n_dense, int n_fields, const uint32_t* base);
 int init_normal(fmx_engine* e, uint64_t seed, double mean, double stdev);
 int rows_copy(fmx_engine* e, const uint32_t* d_ids, int64_t n, double* d_w, double* d_v, bool set);
