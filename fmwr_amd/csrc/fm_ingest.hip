@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -1604,8 +1605,13 @@ struct Stager {
   hipStream_t st = nullptr;
   int threads = 1;
   bool used[2] = {false, false};
+  size_t cap = 0;             // bytes of each buffer
   int open(size_t largest_array_bytes) {
+    PIECE = 64u << 20;
     while (PIECE > (1u << 20) && PIECE / 2 >= largest_array_bytes) PIECE /= 2;
+    used[0] = used[1] = false;
+    if (cap >= PIECE) return FMX_OK;   // (a kept stager: buffers, events and stream are there)
+    release();
     unsigned hc = std::thread::hardware_concurrency();
     threads = hc >= 16 ? 8 : (hc >= 4 ? 4 : 1);
     FMX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1614,12 +1620,19 @@ struct Stager {
       FMX_HIP(hipMalloc(&dev[i], PIECE));
       FMX_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     }
+    cap = PIECE;
     return FMX_OK;
   }
-  ~Stager() {
+  void release() {
     if (st) (void)hipStreamSynchronize(st);
-    for (int i = 0; i < 2; ++i) { if (pin[i]) (void)hipHostFree(pin[i]); (void)hipFree(dev[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
+    for (int i = 0; i < 2; ++i) {
+      if (pin[i]) (void)hipHostFree(pin[i]);
+      (void)hipFree(dev[i]);
+      if (done[i]) (void)hipEventDestroy(done[i]);
+      pin[i] = dev[i] = nullptr; done[i] = nullptr;
+    }
     if (st) (void)hipStreamDestroy(st);
+    st = nullptr; cap = 0;
   }
   // `count` elements of `elem` bytes from host memory; consume(device piece, index of its first element, elements in it) enqueues on st
   template <typename F>
@@ -1652,6 +1665,69 @@ struct Stager {
     }
     return FMX_OK;
   }
+  // the other way: produce(device piece, first element, elements) enqueues on st; the piece then comes down and is copied into `host`
+  template <typename F>
+  int run_down(void* host, size_t elem, int64_t count, F produce) {
+    const int64_t per = (int64_t)(PIECE / elem);
+    int64_t prev_i0 = 0, prev_n = 0;
+    int prev_b = -1;
+    auto drain = [&]() -> int {   // the previous piece: wait for its copy, hand it to the caller's array
+      if (prev_b < 0) return FMX_OK;
+      FMX_HIP(hipEventSynchronize(done[prev_b]));
+      const size_t bytes = (size_t)prev_n * elem;
+      char* dst = (char*)host + (size_t)prev_i0 * elem;
+      if (threads > 1 && bytes >= (4u << 20)) {
+        std::vector<std::thread> pool;
+        const size_t slice = (bytes / (size_t)threads + 4095) & ~(size_t)4095;
+        const char* src = (const char*)pin[prev_b];
+        for (int t = 0; t < threads; ++t) {
+          const size_t a = (size_t)t * slice;
+          if (a >= bytes) break;
+          const size_t len = a + slice < bytes ? slice : bytes - a;
+          pool.emplace_back([=] { memcpy(dst + a, src + a, len); });
+        }
+        for (auto& th : pool) th.join();
+      } else {
+        memcpy(dst, pin[prev_b], bytes);
+      }
+      return FMX_OK;
+    };
+    int64_t piece = 0;
+    for (int64_t i0 = 0; i0 < count; i0 += per, ++piece) {
+      const int b = (int)(piece & 1);
+      const int64_t n = count - i0 < per ? count - i0 : per;
+      FMX_TRY(produce(dev[b], i0, n));                       // (buffer b was drained two pieces ago)
+      FMX_HIP(hipMemcpyAsync(pin[b], dev[b], (size_t)n * elem, hipMemcpyDeviceToHost, st));
+      FMX_HIP(hipEventRecord(done[b], st));
+      FMX_TRY(drain());                                      // while this piece is produced and copied
+      prev_b = b; prev_i0 = i0; prev_n = n;
+    }
+    return drain();
+  }
+};
+// One stager per device is KEPT between calls (two pinned and two device buffers of up to 64 MB, a stream): making them costs 20-30 ms, more than
+// the hand-over of a model's parameters takes.  Never destroyed (the HIP runtime may be gone before a static's destructor runs).
+struct StagerLease {
+  Stager* s = nullptr;
+  bool kept = false;
+  explicit StagerLease(int device) {
+    static std::mutex mu;
+    static Stager* keep[64] = {};
+    static bool busy[64] = {};
+    std::lock_guard<std::mutex> g(mu);
+    if (device >= 0 && device < 64 && !busy[device]) {
+      if (!keep[device]) keep[device] = new Stager();
+      s = keep[device]; kept = true; busy[device] = true; dev_ = device; busy_ = busy;
+    } else {
+      s = new Stager();
+    }
+  }
+  ~StagerLease() {
+    if (kept) { if (s->st) (void)hipStreamSynchronize(s->st); busy_[dev_] = false; }
+    else { s->release(); delete s; }
+  }
+  int dev_ = 0;
+  bool* busy_ = nullptr;
 };
 }  // namespace
 
@@ -1682,11 +1758,100 @@ __global__ void rowptr_check_k(const int64_t* __restrict__ rp, int64_t n, unsign
   if (i < n && rp[i + 1] < rp[i]) atomicMin(first_bad, (unsigned long long)i);
 }
 
+// (w0, w, V) in R's layout -- V a k x p column-major matrix of doubles, i.e. p rows of k -- <-> the engine's tables (rows of `stride` elements)
+template <typename ST>
+__global__ void rows_from_f64_k(const double* __restrict__ in, ST* __restrict__ table, int k, int64_t stride, int64_t j0, int64_t n_elems) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_elems) return;
+  const int64_t j = i / k;
+  table[(size_t)(j0 + j) * stride + (i - j * k)] = (ST)in[i];
+}
+template <typename ST>
+__global__ void rows_to_f64_k(double* __restrict__ out, const ST* __restrict__ table, int k, int64_t stride, int64_t j0, int64_t n_elems) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_elems) return;
+  const int64_t j = i / k;
+  out[i] = (double)table[(size_t)(j0 + j) * stride + (i - j * k)];
+}
+
+// v (may be null: zeros) and w (may be null: zeros) into the tables; the padding of the rows is zeroed
+int params_to_device(fmx_engine* e, const double* w, const double* v) {
+  const int64_t p = (int64_t)e->p;
+  const int k = e->k;
+  const bool wide = wide_state(e);
+  void* V = wide ? (void*)e->dV : (void*)e->V;
+  const int64_t vs = wide ? e->kp64 : e->vstride32;
+  const size_t eb = wide ? 8 : 4;
+  FMX_HIP(hipMemset(V, 0, (size_t)p * vs * eb));   // (the w slot of a w-in-row table included)
+  void* wt = wide ? (void*)e->dw : mb_wbase(e);
+  const int64_t ws = wide ? 1 : mb_wstride(e);
+  if (!(!wide && e->w_in_row)) FMX_HIP(hipMemset(wt, 0, (size_t)p * eb));
+  FMX_HIP(hipDeviceSynchronize());
+  if (!w && !(v && k > 0)) return FMX_OK;
+  StagerLease lease(e->cfg.device);
+  Stager& S = *lease.s;
+  FMX_TRY(S.open((size_t)p * (size_t)(k > 1 ? k : 1) * 8));
+  const int T = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + T - 1) / T)); };
+  hipStream_t st = S.st;
+  if (v && k > 0) {
+    const int64_t rows_per = (int64_t)(S.PIECE / 8) / k;   // whole rows per piece
+    S.PIECE = (size_t)rows_per * k * 8;
+    FMX_TRY(S.run(v, 8, p * k, [&](void* d, int64_t i0, int64_t n) {
+      if (wide) hipLaunchKernelGGL((rows_from_f64_k<double>), grid(n), dim3(T), 0, st, (const double*)d, (double*)V, k, vs, i0 / k, n);
+      else hipLaunchKernelGGL((rows_from_f64_k<float>), grid(n), dim3(T), 0, st, (const double*)d, (float*)V, k, vs, i0 / k, n);
+      return FMX_OK; }));
+  }
+  if (w) {
+    FMX_TRY(S.run(w, 8, p, [&](void* d, int64_t i0, int64_t n) {
+      if (wide) hipLaunchKernelGGL((rows_from_f64_k<double>), grid(n), dim3(T), 0, st, (const double*)d, (double*)wt, 1, ws, i0, n);
+      else hipLaunchKernelGGL((rows_from_f64_k<float>), grid(n), dim3(T), 0, st, (const double*)d, (float*)wt, 1, ws, i0, n);
+      return FMX_OK; }));
+  }
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipStreamSynchronize(st));
+  return FMX_OK;
+}
+
+int params_from_device(fmx_engine* e, double* w, double* v) {
+  const int64_t p = (int64_t)e->p;
+  const int k = e->k;
+  if (!w && !(v && k > 0)) return FMX_OK;
+  const bool wide = wide_state(e);
+  const void* V = wide ? (const void*)e->dV : (const void*)e->V;
+  const int64_t vs = wide ? e->kp64 : e->vstride32;
+  const void* wt = wide ? (const void*)e->dw : (const void*)mb_wbase(e);
+  const int64_t ws = wide ? 1 : mb_wstride(e);
+  StagerLease lease(e->cfg.device);
+  Stager& S = *lease.s;
+  FMX_TRY(S.open((size_t)p * (size_t)(k > 1 ? k : 1) * 8));
+  const int T = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + T - 1) / T)); };
+  hipStream_t st = S.st;
+  if (v && k > 0) {
+    const int64_t rows_per = (int64_t)(S.PIECE / 8) / k;
+    S.PIECE = (size_t)rows_per * k * 8;
+    FMX_TRY(S.run_down(v, 8, p * k, [&](void* d, int64_t i0, int64_t n) {
+      if (wide) hipLaunchKernelGGL((rows_to_f64_k<double>), grid(n), dim3(T), 0, st, (double*)d, (const double*)V, k, vs, i0 / k, n);
+      else hipLaunchKernelGGL((rows_to_f64_k<float>), grid(n), dim3(T), 0, st, (double*)d, (const float*)V, k, vs, i0 / k, n);
+      return FMX_OK; }));
+  }
+  if (w) {
+    FMX_TRY(S.run_down(w, 8, p, [&](void* d, int64_t i0, int64_t n) {
+      if (wide) hipLaunchKernelGGL((rows_to_f64_k<double>), grid(n), dim3(T), 0, st, (double*)d, (const double*)wt, 1, ws, i0, n);
+      else hipLaunchKernelGGL((rows_to_f64_k<float>), grid(n), dim3(T), 0, st, (double*)d, (const float*)wt, 1, ws, i0, n);
+      return FMX_OK; }));
+  }
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
 // the device arrays of m from host arrays: values f64 or f32, columns i32 or u32, row sizes (i32) or row offsets (i64), labels f64 or f32.
 // bad[0] = first column out of range, bad[1] = first negative row size / decreasing offset, total = what the offsets end in
 int ingest_host_arrays(fmx_matrix* m, const void* values, bool values_f64, const void* cols, bool cols_signed, const int32_t* row_size, const int64_t* row_ptr,
                        const void* labels, bool labels_f64, uint64_t bad[2], int64_t* total) {
-  Stager S;
+  StagerLease lease(m->device);
+  Stager& S = *lease.s;
   FMX_HIP(hipSetDevice(m->device));
   FMX_HIP(hipDeviceSynchronize());   // (the matrix was allocated and zeroed through the null stream; the pieces below run on a stream of their own)
   FMX_TRY(S.open((size_t)(m->nnz > m->n ? m->nnz : m->n + 1) * 8));

@@ -708,48 +708,10 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_TRY(use_device(e->cfg.device));
   FMX_HIP(hipStreamSynchronize(e->stream));
-  const size_t p = (size_t)e->p;
-  const int k = e->k;
   FMX_HIP(hipMemcpy(e->scal + SC_W0, &w0, sizeof(double), hipMemcpyHostToDevice));
-  if (wide_state(e)) {
-    const int kp = e->kp64;
-    if (v) {
-      std::vector<double> hv(p * kp, 0.0);
-      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = v[f + j * (size_t)k];
-      FMX_HIP(hipMemcpy(e->dV, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice));
-    } else {
-      FMX_HIP(hipMemset(e->dV, 0, p * kp * sizeof(double)));  // no p-sized host buffer for "zeros" (p = 33 M: 8.4 GB)
-    }
-    if (w) FMX_HIP(hipMemcpy(e->dw, w, p * sizeof(double), hipMemcpyHostToDevice));
-    else FMX_HIP(hipMemset(e->dw, 0, p * sizeof(double)));
-  } else {
-    const int vs = e->vstride32, kp = e->kp32;
-    if (e->w_in_row) {  // V row and w travel in one table
-      if (v || w) {
-        std::vector<float> hv(p * vs, 0.f);
-        if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * vs + f] = (float)v[f + j * (size_t)k];
-        if (w) for (size_t j = 0; j < p; ++j) hv[j * vs + kp] = (float)w[j];
-        FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
-      } else {
-        FMX_HIP(hipMemset(e->V, 0, p * vs * sizeof(float)));
-      }
-    } else {
-      if (v) {
-        std::vector<float> hv(p * kp, 0.f);
-        for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) hv[j * kp + f] = (float)v[f + j * (size_t)k];
-        FMX_HIP(hipMemcpy(e->V, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
-      } else {
-        FMX_HIP(hipMemset(e->V, 0, p * kp * sizeof(float)));
-      }
-      if (w) {
-        std::vector<float> hw(p);
-        for (size_t j = 0; j < p; ++j) hw[j] = (float)w[j];
-        FMX_HIP(hipMemcpy(e->w, hw.data(), p * sizeof(float), hipMemcpyHostToDevice));
-      } else {
-        FMX_HIP(hipMemset(e->w, 0, p * sizeof(float)));
-      }
-    }
-  }
+  // R's vectors go over as they are (V: k x p column-major = p rows of k doubles) and are narrowed and laid out by kernels (fm_ingest.hip:
+  // params_to_device); null = zeros, with no p-sized host buffer either way (p = 33 M, k = 32: 8.4 GB of doubles)
+  FMX_TRY(params_to_device(e, w, v));
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   FMX_TRY(reset_optimizer_state(e));  // learner->init() zeroes q/u (SGD_Learner.h:61-69) and z/n (FTRL_Learner.h:50-55)
   FMX_HIP(hipDeviceSynchronize());
@@ -761,39 +723,8 @@ int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_TRY(use_device(e->cfg.device));
   FMX_HIP(hipStreamSynchronize(e->stream));
-  const size_t p = (size_t)e->p;
-  const int k = e->k;
   if (w0) FMX_HIP(hipMemcpy(w0, e->scal + SC_W0, sizeof(double), hipMemcpyDeviceToHost));
-  if (wide_state(e)) {
-    if (w) FMX_HIP(hipMemcpy(w, e->dw, p * sizeof(double), hipMemcpyDeviceToHost));
-    if (v && k > 0) {
-      const int kp = e->kp64;
-      std::vector<double> hv(p * kp);
-      FMX_HIP(hipMemcpy(hv.data(), e->dV, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
-      for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * kp + f];
-    }
-  } else {
-    const int vs = e->vstride32, kp = e->kp32;
-    if (e->w_in_row) {
-      if (w || (v && k > 0)) {
-        std::vector<float> hv(p * vs);
-        FMX_HIP(hipMemcpy(hv.data(), e->V, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
-        if (w) for (size_t j = 0; j < p; ++j) w[j] = hv[j * vs + kp];
-        if (v) for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * vs + f];
-      }
-    } else {
-      if (w) {
-        std::vector<float> hw(p);
-        FMX_HIP(hipMemcpy(hw.data(), e->w, p * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t j = 0; j < p; ++j) w[j] = hw[j];
-      }
-      if (v && k > 0) {
-        std::vector<float> hv(p * kp);
-        FMX_HIP(hipMemcpy(hv.data(), e->V, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t j = 0; j < p; ++j) for (int f = 0; f < k; ++f) v[f + j * (size_t)k] = hv[j * kp + f];
-      }
-    }
-  }
+  FMX_TRY(params_from_device(e, w, v));   // widened and packed on the device, copied down in pieces (fm_ingest.hip)
   return FMX_OK;
 }
 

@@ -500,6 +500,8 @@ struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)
 };
 int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream);
 int check_rows_sorted(fmx_matrix* m);
+int params_to_device(fmx_engine* e, const double* w, const double* v);
+int params_from_device(fmx_engine* e, double* w, double* v);
 int ingest_host_arrays(fmx_matrix* m, const void* values, bool values_f64, const void* cols, bool cols_signed, const int32_t* row_size, const int64_t* row_ptr,
                        const void* labels, bool labels_f64, uint64_t bad[2], int64_t* total);
 int matrix_set_fields(fmx_matrix* m, int n_dense, int n_fields, const uint32_t* base);
