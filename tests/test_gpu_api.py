@@ -327,3 +327,56 @@ def test_failed_plan_build_leaves_no_half_built_cache(monkeypatch):
     e.sync()
     a, b = ref.get_params(), e.get_params()
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_host_hand_over_in_pieces():
+    """fmx_matrix_from_rlist / _from_csr / fmx_set_params / fmx_get_params copy the caller's arrays as they are, in pinned pieces, and narrow / check /
+    prefix-sum them on the device (fm_ingest.hip: ingest_host_arrays, params_to_device): arrays of several pieces -- 20 M entries, a 1 M x 16 model --
+    arrive exactly (values narrowed to f32, columns, offsets, labels), a bad column or row size far into the arrays is reported at its position, and
+    the parameters make the round trip bit for bit (fp64 state) or as their f32 images."""
+    from fmwr_amd import engine, _lib as L
+    rng = np.random.default_rng(7)
+    n, z, p = 1_000_000, 20, 300_000
+    col = np.sort(rng.integers(0, p // z, (n, z)) + (np.arange(z) * (p // z))[None, :], axis=1).astype(np.int32).ravel()
+    value = rng.normal(0, 1, n * z)
+    sizes = np.full(n, z, np.int32)
+    labels = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    m = engine.Matrix.from_rlist(value, col, sizes, p, labels)
+    rp, c2, v2, y2 = m.export()
+    assert np.array_equal(rp, np.arange(n + 1, dtype=np.int64) * z) and np.array_equal(c2, col.astype(np.uint32))
+    assert np.array_equal(v2, value.astype(np.float32)) and np.array_equal(y2, labels.astype(np.float32))
+    m2 = engine.Matrix.from_csr(rp, c2, v2, p, y2)           # the CSR entry takes the same path
+    r2 = m2.export()
+    assert np.array_equal(r2[0], rp) and np.array_equal(r2[1], c2) and np.array_equal(r2[2], v2) and np.array_equal(r2[3], y2)
+    bad = col.copy(); bad[17_000_003] = p                      # far into the third piece
+    with pytest.raises(L.FmxError, match="out of range at 17000003"):
+        engine.Matrix.from_rlist(value, bad, sizes, p, labels)
+    bad_sizes = sizes.copy(); bad_sizes[900_001] = -1
+    with pytest.raises(L.FmxError, match="negative row_size at row 900001"):
+        engine.Matrix.from_rlist(value, col, bad_sizes, p, labels)
+    short = sizes.copy(); short[5] = z - 1
+    with pytest.raises(L.FmxError, match="row_size is not correct"):
+        engine.Matrix.from_rlist(value, col, short, p, labels)
+    rp_bad = rp.copy(); rp_bad[700_000] = rp_bad[700_001] + 1
+    with pytest.raises(L.FmxError, match="row_ptr decreases at row 700000"):
+        engine.Matrix.from_csr(rp_bad, c2, v2, p, y2)
+    # the model: 1 M x 16 doubles = 128 MB, three pieces of whole rows
+    P, K = 1_000_000, 16
+    w = rng.normal(0, 1, P); v = rng.normal(0, 1, (K, P))
+    for wide, layout in ((1, "0"), (0, "0"), (0, "1")):
+        import os
+        os.environ["FMX_W_IN_ROW"] = layout
+        try:
+            e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH, state_fp64=wide)
+        finally:
+            del os.environ["FMX_W_IN_ROW"]
+        e.set_params(0.25, w, v)
+        w0, gw, gv = e.get_params()
+        if wide:
+            assert w0 == 0.25 and np.array_equal(gw, w) and np.array_equal(gv, v)
+        else:
+            assert w0 == 0.25 and np.array_equal(gw, w.astype(np.float32).astype(np.float64)) and np.array_equal(gv, v.astype(np.float32).astype(np.float64))
+        e.set_params(0.0, None, None)
+        w0, gw, gv = e.get_params()
+        assert w0 == 0.0 and not gw.any() and not gv.any()
+        e.close()
