@@ -135,14 +135,15 @@ def test_field_structured_plan_equals_the_general_sort(monkeypatch):
 def test_per_field_sort_equals_the_pair_sort(monkeypatch):
     """Where the fields' id ranges are known (the field generator: resident matrices and streamed sources) the one-hot part is sorted field
     by field on ceil(log2 vocab) bits (fm_ingest.hip: field_sort) instead of as one array of 25-bit column ids; FMX_FIELD_SORT=0 keeps the
-    pair sort.  Same plan, hence the same training bit for bit: fields of one, two and three passes (vocabularies of 1 .. 5 000 000),
+    pair sort.  Same plan, hence the same training bit for bit: fields of one to four passes (vocabularies of 1 .. 20 000 000),
     several 8192-entry blocks per field with a ragged last one, tiles shorter than a block, uniform and skewed ids."""
     from fmwr_amd import _lib as L, engine
     same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     for vocab, skew, B, n, d in (([5_000_000, 300_000, 513, 512, 600, 17, 2, 1], 3.0, 5 * 4096 + 100, 2 * (5 * 4096 + 100) + 900, 2),
                                  ([70_000, 5_000, 3], 1.0, 8192, 8192 + 4096, 2),
                                  ([40_000, 9_000, 700, 40, 5, 3], 2.5, 1000, 3500, 2),
-                                 ([200_000, 9_000, 700, 40, 5, 3], 2.0, 5000, 12_000, 0)):     # no dense part: one-hot rows (sparse tiles)
+                                 ([200_000, 9_000, 700, 40, 5, 3], 2.0, 5000, 12_000, 0),      # no dense part: one-hot rows (sparse tiles)
+                                 ([20_000_000, 70_000, 3], 1.0, 9000, 20_000, 1)):             # 25 bits: four passes (the buffers change roles three times)
         k = 4
         p = d + sum(vocab)
         kw = dict(num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
