@@ -724,6 +724,10 @@ def main():
             tr = pmc_traffic(name, args) if world == 1 else None
             per_kernel[name] = {"algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
                                 "traffic": tr[0] if tr else None, "traffic_source": f"profiles/{tr[1]}" if tr else None}
+            if tr and ms > 0:
+                # the counted memory-side bytes of a launch (FETCH_SIZE x 2 + WRITE_SIZE, Infinity Cache hits included: an upper bound on HBM bytes for
+                # the cache-resident shapes, close to the bytes of whole 128-byte lines for tables that live in HBM) over this run's launch time / HBM peak
+                per_kernel[name]["traffic_frac_upper_bound"] = tr[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         step_gbs = b_step / (dt / args.steps) / 1e9   # per GPU: B rows of this rank per step
         traffic = per_kernel[dom]["traffic"]
         out = {
