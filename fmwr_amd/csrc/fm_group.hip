@@ -417,11 +417,16 @@ static int exchange_owner(Group* g, fmx_matrix* const* mats, const int64_t* batc
     FMX_HIP(hipSetDevice(g->dev[(size_t)o]));
     hipStream_t st = g->rep[(size_t)o]->stream;
     for (int r = 0; r < N; ++r) {
-      if (r != o) FMX_HIP(hipStreamWaitEvent(st, g->ev_ids[(size_t)r], 0));
+      if (r == o) continue;   // (a replica's own features are current where they are: nothing to ask, pack, send or store)
+      FMX_HIP(hipStreamWaitEvent(st, g->ev_ids[(size_t)r], 0));
       FMX_TRY(copy((uint32_t*)g->ox[(size_t)o].req + roff[o][r], o, (const uint32_t*)ids[r] + soff[r][o], r, (size_t)cnt[r][o] * sizeof(uint32_t), st));
     }
-    int64_t re = 0;
-    FMX_TRY(fmx_rows_pack(g->rep[(size_t)o], g->ox[(size_t)o].req, roff[o][N], g->ox[(size_t)o].rows_out, &re));
+    int64_t re = rowe;
+    // the rows asked for by the ranks before and after this one (its own slice lies between them and stays unpacked)
+    if (roff[o][o] > 0) FMX_TRY(fmx_rows_pack(g->rep[(size_t)o], g->ox[(size_t)o].req, roff[o][o], g->ox[(size_t)o].rows_out, &re));
+    if (roff[o][N] > roff[o][o + 1])
+      FMX_TRY(fmx_rows_pack(g->rep[(size_t)o], (const uint32_t*)g->ox[(size_t)o].req + roff[o][o + 1], roff[o][N] - roff[o][o + 1],
+                            (char*)g->ox[(size_t)o].rows_out + (size_t)roff[o][o + 1] * rowe * eb, &re));
     FMX_CHECK(re == rowe, FMX_ERR_STATE, "row width changed");
     FMX_HIP(hipEventRecord(g->ev_packed[(size_t)o], st));
   }
@@ -431,11 +436,15 @@ static int exchange_owner(Group* g, fmx_matrix* const* mats, const int64_t* batc
     FMX_HIP(hipSetDevice(g->dev[(size_t)r]));
     hipStream_t st = g->rep[(size_t)r]->stream;
     for (int o = 0; o < N; ++o) {
-      if (o != r) FMX_HIP(hipStreamWaitEvent(st, g->ev_packed[(size_t)o], 0));
+      if (o == r) continue;
+      FMX_HIP(hipStreamWaitEvent(st, g->ev_packed[(size_t)o], 0));
       FMX_TRY(copy((char*)g->ox[(size_t)r].rows_in + (size_t)soff[r][o] * rowe * eb, r, (const char*)g->ox[(size_t)o].rows_out + (size_t)roff[o][r] * rowe * eb, o,
                    (size_t)cnt[r][o] * rowe * eb, st));
     }
-    FMX_TRY(fmx_rows_unpack(g->rep[(size_t)r], ids[r], soff[r][N], g->ox[(size_t)r].rows_in));
+    if (soff[r][r] > 0) FMX_TRY(fmx_rows_unpack(g->rep[(size_t)r], ids[r], soff[r][r], g->ox[(size_t)r].rows_in));
+    if (soff[r][N] > soff[r][r + 1])
+      FMX_TRY(fmx_rows_unpack(g->rep[(size_t)r], (const uint32_t*)ids[r] + soff[r][r + 1], soff[r][N] - soff[r][r + 1],
+                              (const char*)g->ox[(size_t)r].rows_in + (size_t)soff[r][r + 1] * rowe * eb));
     FMX_TRY(group_grad_compact(g->rep[(size_t)r], mats[r], batch[r], rows[r]));
     int64_t n = 0;
     FMX_TRY(fmx_compact_records(g->rep[(size_t)r], &recs[r], &n, &tails[r]));
