@@ -400,10 +400,17 @@ class DataParallel:
             req = s.ids_buffer(n_recv)
             self._all_to_all(req, ids, recv, send)
             rows_out = s.rows_buffer("out", n_recv)
-            s.rows_pack(req, rows_out)
+            # (this rank's own features are current where they are: its own slice is neither packed nor stored -- the all-to-all carries it untouched)
+            ra, rb = int(recv[:me].sum()), int(recv[:me + 1].sum())
+            for a, b in ((0, ra), (rb, n_recv)):
+                if b > a:
+                    s.rows_pack(req[a:b], rows_out[a:b])
             rows_in = s.rows_buffer("in", n_send)
             self._all_to_all(rows_in, rows_out, send, recv)
-            s.rows_unpack(ids, rows_in)
+            sa, sb = int(send[:me].sum()), int(send[:me + 1].sum())
+            for a, b in ((0, sa), (sb, n_send)):
+                if b > a:
+                    s.rows_unpack(ids[a:b], rows_in[a:b])
             # sums -> the owners
             s.grad_compact(batch, rows_limit)
             recs = s.records_view(n_send)
