@@ -1528,22 +1528,26 @@ __global__ void scales_finish_k(uint32_t p, int64_t n, const uint8_t* __restrict
   }
 }
 
-__global__ void scales_apply_k(int64_t nnz, const uint32_t* __restrict__ col, float* __restrict__ val, const double* __restrict__ mean,
-                               const double* __restrict__ std) {
+// (mean, std) of a column travel as ONE 16-byte gather per entry (two 8-byte gathers from two tables were 8 ms for 3e8 entries: the request rate again)
+__global__ void pair_up_k(const double* __restrict__ mean, const double* __restrict__ std, uint32_t p, double2* __restrict__ ms) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < p) ms[j] = make_double2(mean[j], std[j]);
+}
+__global__ void scales_apply_k(int64_t nnz, const uint32_t* __restrict__ col, float* __restrict__ val, const double2* __restrict__ ms) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nnz) return;
+  const double2 c = ms[col[t]];
   float v = val[t];
-  v = (float)((double)v - mean[col[t]]);           // value[p] -= colSum[idx]        (:127)
-  v = (float)((double)v / (std[col[t]] + 1e-30));  // value[p] /= (colSumSqr + 1e-30) (:128)
+  v = (float)((double)v - c.x);            // value[p] -= colSum[idx]        (:127)
+  v = (float)((double)v / (c.y + 1e-30));  // value[p] /= (colSumSqr + 1e-30) (:128)
   val[t] = v;
 }
 
-__global__ void normalize_apply_k(int64_t nnz, const uint32_t* __restrict__ col, float* __restrict__ val, const double* __restrict__ mean,
-                                  const double* __restrict__ std) {
+__global__ void normalize_apply_k(int64_t nnz, const uint32_t* __restrict__ col, float* __restrict__ val, const double2* __restrict__ ms) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nnz) return;
-  const uint32_t i = col[t];
-  if (std[i] != 0) val[t] = (float)(((double)val[t] - mean[i]) / std[i]);  // util/Smatrix.h:148-150
+  const double2 c = ms[col[t]];
+  if (c.y != 0) val[t] = (float)(((double)val[t] - c.x) / c.y);  // util/Smatrix.h:148-150
 }
 
 // the cached inverted indices hold copies of the values: drop them so they are rebuilt from the new values
@@ -1567,11 +1571,14 @@ int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double
   const unsigned gp = (unsigned)(((int64_t)p + 255) / 256);
   hipLaunchKernelGGL(col_moments_k, dim3(gp), dim3(256), 0, nullptr, m->col_ptr, m->cval, p, d_mean, d_std);
   hipLaunchKernelGGL(scales_finish_k, dim3(gp), dim3(256), 0, nullptr, p, m->n, d_listed, d_mean, d_std);
-  if (m->nnz > 0) hipLaunchKernelGGL(scales_apply_k, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, nullptr, m->nnz, m->col, m->val, d_mean, d_std);
+  double2* d_ms = nullptr;
+  FMX_HIP(hipMalloc(&d_ms, (size_t)p * sizeof(double2)));
+  hipLaunchKernelGGL(pair_up_k, dim3(gp), dim3(256), 0, nullptr, (const double*)d_mean, (const double*)d_std, p, d_ms);
+  if (m->nnz > 0) hipLaunchKernelGGL(scales_apply_k, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, nullptr, m->nnz, m->col, m->val, (const double2*)d_ms);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipMemcpy(h_mean, d_mean, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
   FMX_HIP(hipMemcpy(h_std, d_std, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
-  (void)hipFree(d_mean); (void)hipFree(d_std); (void)hipFree(d_listed);
+  (void)hipFree(d_mean); (void)hipFree(d_std); (void)hipFree(d_listed); (void)hipFree(d_ms);
   drop_value_caches(m);
   return check_rows_sorted(m);  // the values changed: is the matrix still one-hot?
 }
@@ -1583,10 +1590,13 @@ int matrix_normalize(fmx_matrix* m, const double* h_mean, const double* h_std) {
   FMX_HIP(hipMalloc(&d_std, (size_t)p * sizeof(double)));
   FMX_HIP(hipMemcpy(d_mean, h_mean, (size_t)p * sizeof(double), hipMemcpyHostToDevice));
   FMX_HIP(hipMemcpy(d_std, h_std, (size_t)p * sizeof(double), hipMemcpyHostToDevice));
-  if (m->nnz > 0) hipLaunchKernelGGL(normalize_apply_k, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, nullptr, m->nnz, m->col, m->val, d_mean, d_std);
+  double2* d_ms = nullptr;
+  FMX_HIP(hipMalloc(&d_ms, (size_t)p * sizeof(double2)));
+  hipLaunchKernelGGL(pair_up_k, dim3((unsigned)(((int64_t)p + 255) / 256)), dim3(256), 0, nullptr, (const double*)d_mean, (const double*)d_std, p, d_ms);
+  if (m->nnz > 0) hipLaunchKernelGGL(normalize_apply_k, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, nullptr, m->nnz, m->col, m->val, (const double2*)d_ms);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipDeviceSynchronize());
-  (void)hipFree(d_mean); (void)hipFree(d_std);
+  (void)hipFree(d_mean); (void)hipFree(d_std); (void)hipFree(d_ms);
   drop_value_caches(m);
   return check_rows_sorted(m);
 }
@@ -1903,20 +1913,55 @@ int ingest_host_arrays(fmx_matrix* m, const void* values, bool values_f64, const
 }
 
 // ------------------------------------------------------------------------------------------------ sortedness
-__global__ void rows_sorted_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t n,
-                              int* __restrict__ out) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  int bad = 0, other = 0;
-  for (int64_t t = row_ptr[r]; t < row_ptr[r + 1]; ++t) {
-    if (t + 1 < row_ptr[r + 1]) bad |= (col[t] >= col[t + 1]);
-    other |= (val[t] != 1.0f);
+// Are the rows strictly ascending, are all values 1, how long are the rows?  One thread per ROW walking its entries was 12 ms for the 10 M x 30
+// matrix (every lane on its own 120-byte stride) -- of every hand-over, of every normalize.  Now the entries are read once, coalesced: a descent
+// col[t] >= col[t + 1] is counted wherever it occurs, the descents that are merely the seam between two rows are counted from the row offsets,
+// and the rows are sorted exactly when the two counts agree.
+constexpr int SCAN_SLOTS = 256;   // counters a scan spreads its atomics over (summed on the host)
+constexpr int ES_PER = 16;   // entries per thread: one atomic per wave and 1024 entries (every wave sees a row seam: one atomic per 64 entries on ONE address took 90 ms)
+__global__ __launch_bounds__(256) void entries_scan_k(const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t nnz, unsigned long long* __restrict__ descents,
+                                                      int* __restrict__ out) {
+  const int64_t base = (int64_t)blockIdx.x * (256 * ES_PER) + threadIdx.x;
+  unsigned down = 0;
+  bool other = false;
+#pragma unroll
+  for (int i = 0; i < ES_PER; ++i) {
+    const int64_t t = base + (int64_t)i * 256;
+    if (t < nnz) {
+      other |= val[t] != 1.0f;
+      if (t + 1 < nnz) down += col[t] >= col[t + 1];
+    }
   }
-  if (bad) out[0] = 1;
-  if (other) out[2] = 1;
-  const int64_t len = row_ptr[r + 1] - row_ptr[r];
-  atomicMax(out + 1, (int)(len > 0x7fffffff ? 0x7fffffff : len));  // longest row
-  atomicMax(out + 3, (int)(len > 0x7fffffff ? 0 : 0x7fffffff - (int)len));  // shortest row (as a maximum of the complement)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) down += __shfl_xor(down, off);
+  // (one address for every wave is a queue, not a counter: 293 K stores of `1` to out[2] after a normalize took 12 ms.  The counts go to one of
+  // SCAN_SLOTS slots, the flag is written only while it still reads 0)
+  if ((threadIdx.x & 63) == 0 && down) atomicAdd(descents + (blockIdx.x & (SCAN_SLOTS - 1)), (unsigned long long)down);
+  if (__ballot(other) && (threadIdx.x & 63) == 0 && __atomic_load_n(out + 2, __ATOMIC_RELAXED) == 0) out[2] = 1;
+}
+__global__ __launch_bounds__(256) void rows_scan_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, int64_t nnz,
+                                                   unsigned long long* __restrict__ seams, int* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool seam_down = false;
+  int longest = 0, shortest_c = 0;   // (the shortest row as a maximum of the complement)
+  if (r < n) {
+    const int64_t a = row_ptr[r], b = row_ptr[r + 1];
+    const int len = (int)(b - a > 0x7fffffff ? 0x7fffffff : b - a);
+    longest = len; shortest_c = 0x7fffffff - len;
+    if (b > a && b < nnz) seam_down = col[b - 1] >= col[b];   // this row's last entry against the next stored entry (the next non-empty row's first)
+  }
+  const unsigned long long d = __ballot(seam_down);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int a2 = __shfl_xor(longest, off), b2 = __shfl_xor(shortest_c, off);
+    longest = a2 > longest ? a2 : longest;
+    shortest_c = b2 > shortest_c ? b2 : shortest_c;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (d) atomicAdd(seams + (blockIdx.x & (SCAN_SLOTS - 1)), (unsigned long long)__builtin_popcountll(d));
+    if (longest > __atomic_load_n(out + 1, __ATOMIC_RELAXED)) atomicMax(out + 1, longest);
+    if (shortest_c > __atomic_load_n(out + 3, __ATOMIC_RELAXED)) atomicMax(out + 3, shortest_c);
+  }
 }
 
 // Does every row read [columns 0 .. d-1 | one id of field c in [base[c], base[c + 1]) for c = 0 .. C-1, value 1]?
@@ -1964,11 +2009,19 @@ int matrix_set_fields(fmx_matrix* m, int n_dense, int n_fields, const uint32_t* 
 int check_rows_sorted(fmx_matrix* m) {
   int* d = nullptr;
   int h[4] = {0, 0, 0, 0};
-  FMX_HIP(hipMalloc(&d, 4 * sizeof(int)));
-  FMX_HIP(hipMemset(d, 0, 4 * sizeof(int)));
-  if (m->n > 0) hipLaunchKernelGGL(rows_sorted_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->val, m->n, d);
+  std::vector<unsigned long long> slots(2 * SCAN_SLOTS, 0);
+  const size_t bytes = 4 * sizeof(int) + 2 * SCAN_SLOTS * sizeof(unsigned long long);
+  FMX_HIP(hipMalloc(&d, bytes));
+  FMX_HIP(hipMemset(d, 0, bytes));
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(d + 4);
+  if (m->nnz > 0) hipLaunchKernelGGL(entries_scan_k, dim3((unsigned)((m->nnz + 256 * ES_PER - 1) / (256 * ES_PER))), dim3(256), 0, nullptr, m->col, m->val, m->nnz, cnt, d);
+  if (m->n > 0) hipLaunchKernelGGL(rows_scan_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, nullptr, m->row_ptr, m->col, m->n, m->nnz, cnt + SCAN_SLOTS, d);
   FMX_HIP(hipMemcpy(h, d, 4 * sizeof(int), hipMemcpyDeviceToHost));
+  FMX_HIP(hipMemcpy(slots.data(), cnt, 2 * SCAN_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   FMX_HIP(hipFree(d));
+  unsigned long long h_cnt[2] = {0, 0};
+  for (int i = 0; i < SCAN_SLOTS; ++i) { h_cnt[0] += slots[(size_t)i]; h_cnt[1] += slots[(size_t)SCAN_SLOTS + i]; }
+  h[0] = h_cnt[0] != h_cnt[1];   // a descent inside a row
   m->rows_sorted = !h[0];
   m->max_row_len = h[1];
   m->dense_prefix = 0;  // (only the field generator vouches for it; changed values may have broken it)
