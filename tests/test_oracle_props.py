@@ -298,3 +298,40 @@ def test_minibatch_tdap_with_c_occurrences_against_c_frozen_reference_steps():
     ru, rnu, rdelta, rh = _tdap_coord_c_times([gs.mean()], theta, 0.1, 1e-3)
     got = [mb.sw[q * p + j] for q in range(4)]
     assert np.allclose(got, [ru, rnu, rdelta, rh], rtol=1e-14, atol=1e-16)
+
+
+def test_als_coordinate_update_is_the_minimiser_of_its_quadratic():
+    """An independent pin for MCMC_ALS_Learner.h:272-354 (the V sweep): y_hat is LINEAR in one v[f][j], so the regularised squared error
+    J(v) = alpha/2 sum_r (y_hat_r - y_r)^2 + lambda_f/2 (v - mu_f)^2 is a parabola in it and the ALS step must land on its vertex.  The coordinate a sweep
+    updates LAST -- the last stored feature, factor k-1 -- is still at its vertex when the sweep ends; J and its derivatives are taken by finite differences through the
+    O(z^2) pairwise forward above, which shares nothing with the sweep's cached q / e bookkeeping.  lambda, mu and alpha away from their defaults."""
+    rng = np.random.default_rng(11)
+    for seed in range(8):
+        n, p, k = 120, 25, 3
+        rp, col, val = util.random_csr(n, p, 5, seed=100 + seed, empty_rows=False)
+        y = util.labels(n, 100 + seed, "regression")
+        w0, w, v = util.params(p, k, 100 + seed, stdev=0.3, fp32=False)
+        X = oracle.Matrix(rp, col, val, p)
+        P = oracle.params(task=oracle.REGRESSION, k=k)
+        alpha, lam, mu = 1.7, rng.uniform(0.05, 2.0, k), rng.normal(0, 0.3, k)
+        e0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+        v1, _, _ = oracle.als_update_v(k, X, v.ravel(), e0, alpha=alpha, v_lambda=lam, v_mu=mu)
+        V = v1.reshape(k, p).copy()
+        j = int(np.max(col)); f = k - 1
+        rows = [r for r in range(n) if j in col[rp[r]:rp[r + 1]]]
+        assert rows
+
+        def J(x):
+            Vx = V.copy(); Vx[f, j] = x
+            s = 0.0
+            for r in rows:      # (the other rows' residuals do not depend on this coordinate)
+                c = col[rp[r]:rp[r + 1]].astype(np.int64); xv = val[rp[r]:rp[r + 1]].astype(np.float64)
+                s += (_pairwise_forward(w0, w, Vx, c, xv) - float(y[r])) ** 2
+            return 0.5 * alpha * s + 0.5 * lam[f] * (x - mu[f]) ** 2
+        x0, h = V[f, j], 1e-3
+        d1 = (J(x0 + h) - J(x0 - h)) / (2 * h)            # exact for a parabola
+        d2 = (J(x0 + h) - 2 * J(x0) + J(x0 - h)) / (h * h)
+        assert d2 > 0
+        # the distance to the vertex (1e-6: the reference squares x in FLOAT inside the sweep, MCMC_ALS_Learner.h:314, the parabola here does not)
+        assert abs(d1 / d2) < 1e-6 * max(1.0, abs(x0)), (seed, d1, d2, x0)
+        assert V[f, j] != v[f, j]
