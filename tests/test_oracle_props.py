@@ -335,3 +335,32 @@ def test_als_coordinate_update_is_the_minimiser_of_its_quadratic():
         # the distance to the vertex (1e-6: the reference squares x in FLOAT inside the sweep, MCMC_ALS_Learner.h:314, the parabola here does not)
         assert abs(d1 / d2) < 1e-6 * max(1.0, abs(x0)), (seed, d1, d2, x0)
         assert V[f, j] != v[f, j]
+
+
+def test_als_linear_sweep_ends_on_the_vertex_of_its_last_coordinate():
+    """The same pin for update_w0 / update_w (MCMC_ALS_Learner.h:162-270; init() fixes alpha = 1, lambda_w = mu_w = 0, A-7): y_hat is linear in every w_j, the ALS
+    iteration updates w0, then w_0 .. w_{p-1}; when it ends, the squared error (clamp off, regression) is stationary in the LAST stored w_j -- and NOT in w0, which
+    was stepped first and has since been overtaken (the check bites).  Finite differences through the pairwise forward."""
+    for seed in range(6):
+        n, p, k = 150, 20, 2
+        rp, col, val = util.random_csr(n, p, 4, seed=200 + seed, empty_rows=False)
+        y = util.labels(n, 200 + seed, "regression")
+        w0, w, v = util.params(p, k, 200 + seed, stdev=0.3, fp32=False)
+        X = oracle.Matrix(rp, col, val, p)
+        P = oracle.params(task=oracle.REGRESSION, k=k, min_target=-1e9, max_target=1e9)
+        w0n, wn, vn = oracle.als_learn(P, X, y, w0, w, v.ravel(), 1, with_v=False)
+        assert np.array_equal(vn, v.ravel())       # A-1: the reference's ALS never updates V
+        V = v.copy()
+        j = int(np.max(col))
+
+        def J(w0_, wj):
+            ww = wn.copy(); ww[j] = wj
+            return 0.5 * sum((_pairwise_forward(w0_, ww, V, col[rp[r]:rp[r + 1]].astype(np.int64), val[rp[r]:rp[r + 1]].astype(np.float64)) - float(y[r])) ** 2
+                             for r in range(n))
+        h = 1e-3
+        d1 = (J(w0n, wn[j] + h) - J(w0n, wn[j] - h)) / (2 * h)
+        d2 = (J(w0n, wn[j] + h) - 2 * J(w0n, wn[j]) + J(w0n, wn[j] - h)) / (h * h)
+        assert d2 > 0 and abs(d1 / d2) < 1e-6 * max(1.0, abs(wn[j])), (seed, d1, d2)
+        g0 = (J(w0n + h, wn[j]) - J(w0n - h, wn[j])) / (2 * h)
+        assert abs(g0) > 1e-3                       # w0 is no longer at its vertex
+        assert wn[j] != w[j] and w0n != w0
