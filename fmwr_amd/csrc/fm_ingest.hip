@@ -1662,7 +1662,8 @@ struct Stager {
           const size_t a = (size_t)t * slice;
           if (a >= bytes) break;
           const size_t len = a + slice < bytes ? slice : bytes - a;
-          pool.emplace_back([=] { memcpy((char*)pin[b] + a, src + a, len); });
+          try { pool.emplace_back([=] { memcpy((char*)pin[b] + a, src + a, len); }); }
+          catch (...) { memcpy((char*)pin[b] + a, src + a, len); }   // (no thread to be had: this slice is copied here)
         }
         for (auto& th : pool) th.join();
       } else {
@@ -1694,7 +1695,8 @@ struct Stager {
           const size_t a = (size_t)t * slice;
           if (a >= bytes) break;
           const size_t len = a + slice < bytes ? slice : bytes - a;
-          pool.emplace_back([=] { memcpy(dst + a, src + a, len); });
+          try { pool.emplace_back([=] { memcpy(dst + a, src + a, len); }); }
+          catch (...) { memcpy(dst + a, src + a, len); }
         }
         for (auto& th : pool) th.join();
       } else {
