@@ -1966,6 +1966,73 @@ __global__ __launch_bounds__(256) void rows_scan_k(const int64_t* __restrict__ r
   }
 }
 
+// Rows of one length z: the smallest and largest column and "some value is not 1" per POSITION in the row (z <= 64).  Positions whose ranges are
+// disjoint and ascending are fields (check_rows_sorted below).  Reduced per block in LDS; a global atomic only where it still improves the value.
+__global__ __launch_bounds__(256) void positions_scan_k(const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t nnz, int z,
+                                                        uint32_t* __restrict__ pos_min, uint32_t* __restrict__ pos_max, uint32_t* __restrict__ pos_other) {
+  __shared__ uint32_t lo[64], hi[64], ot[64];
+  if (threadIdx.x < 64) { lo[threadIdx.x] = 0xFFFFFFFFu; hi[threadIdx.x] = 0u; ot[threadIdx.x] = 0u; }
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (256 * ES_PER) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < ES_PER; ++i) {
+    const int64_t t = base + (int64_t)i * 256;
+    if (t < nnz) {
+      const int pos = (int)(t % z);
+      const uint32_t c = col[t];
+      if (c < lo[pos]) atomicMin(&lo[pos], c);
+      if (c > hi[pos]) atomicMax(&hi[pos], c);
+      if (val[t] != 1.0f && !ot[pos]) ot[pos] = 1u;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < z) {
+    const int i = threadIdx.x;
+    if (lo[i] < __atomic_load_n(pos_min + i, __ATOMIC_RELAXED)) atomicMin(pos_min + i, lo[i]);
+    if (hi[i] > __atomic_load_n(pos_max + i, __ATOMIC_RELAXED)) atomicMax(pos_max + i, hi[i]);
+    if (ot[i] && !__atomic_load_n(pos_other + i, __ATOMIC_RELAXED)) pos_other[i] = 1u;
+  }
+}
+
+// rows of one length whose entry positions have disjoint ascending column ranges ARE field-structured (fmx_matrix::field_base): the first d positions
+// that always hold column i are the dense prefix, every other position is a field and must hold value 1.  Found here for any uploaded matrix (a one-hot
+// encoded data frame, user / item ids ...), so that the per-field plan builder needs no hint; fmx_matrix_set_fields remains for callers who know the
+// vocabularies (its ranges may be wider than the ids that occur).  FMX_DETECT_FIELDS=0 switches the detection off.
+static int detect_fields(fmx_matrix* m) {
+  static const bool on = [] { const char* v = getenv("FMX_DETECT_FIELDS"); return !(v && v[0] == '0'); }();
+  const int z = m->fixed_row_len;
+  if (!on || !m->rows_sorted || z < 1 || z > 64 || m->nnz != m->n * (int64_t)z || m->nnz == 0) return FMX_OK;
+  uint32_t* d = nullptr;
+  FMX_HIP(hipMalloc(&d, 3 * 64 * sizeof(uint32_t)));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  FMX_HIP(hipMemset(d, 0xFF, 64 * sizeof(uint32_t)));
+  FMX_HIP(hipMemset(d + 64, 0, 2 * 64 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(positions_scan_k, dim3((unsigned)((m->nnz + 256 * ES_PER - 1) / (256 * ES_PER))), dim3(256), 0, nullptr, m->col, m->val, m->nnz, z, d, d + 64, d + 128);
+  uint32_t h[3 * 64];
+  FMX_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  const uint32_t *lo = h, *hi = h + 64, *other = h + 128;
+  int dn = 0;
+  while (dn < z && lo[dn] == (uint32_t)dn && hi[dn] == (uint32_t)dn) ++dn;   // always-present columns 0 .. dn-1 (any values)
+  // (a leading position that always holds column i WITH value 1 may as well be a one-value field: keep the matrix one-hot if it is)
+  if (m->unit_values) dn = 0;
+  const int C = z - dn;
+  if (C < 1 || C > FMX_MAX_FIELDS) return FMX_OK;
+  for (int c = dn; c < z; ++c) {
+    if (other[c]) return FMX_OK;                                 // a field entry with a value other than 1
+    if (c > dn && lo[c] <= hi[c - 1]) return FMX_OK;             // ranges overlap: positions are not fields
+  }
+  if (lo[dn] < (uint32_t)dn) return FMX_OK;
+  std::vector<uint32_t> base((size_t)C + 1);
+  base[0] = (uint32_t)dn;
+  for (int c = 1; c < C; ++c) base[(size_t)c] = lo[dn + c];
+  base[(size_t)C] = m->p;
+  if (hi[z - 1] >= m->p) return FMX_OK;
+  if (dn > 0 && m->unit_values) return FMX_OK;
+  m->dense_prefix = dn;
+  m->field_base = base;
+  return FMX_OK;
+}
+
 // Does every row read [columns 0 .. d-1 | one id of field c in [base[c], base[c + 1]) for c = 0 .. C-1, value 1]?
 struct FieldCheck { int d, C; uint32_t base[FMX_MAX_FIELDS + 1]; };
 __global__ void rows_fields_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t n, FieldCheck fc,
@@ -2033,7 +2100,7 @@ int check_rows_sorted(fmx_matrix* m) {
   m->unit_values = (allow && !h[2]) ? 1 : 0;
   const int shortest = 0x7fffffff - h[3];
   m->fixed_row_len = (m->n > 0 && shortest == h[1] && h[1] > 0) ? h[1] : 0;  // every row holds the same number of entries
-  return FMX_OK;
+  return detect_fields(m);
 }
 
 }  // namespace fmx

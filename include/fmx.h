@@ -191,7 +191,9 @@ int fmx_matrix_synthetic_fields(int device, int64_t n, const fmx_fields_spec* sp
  * n_fields (<= 64) categorical fields, field c's ids lying in [field_base[c], field_base[c + 1]) with value 1 (field_base[0] = n_dense,
  * field_base[n_fields] = the feature count).  The layout is checked on the device (FMX_ERR_INVALID if a row differs); the inverted index of a step is
  * then built field by field -- a column's ids inside its field are sorted on ceil(log2 vocabulary) bits, the dense columns are not sorted at all --
- * instead of by one sort of all column ids: same plan, same results, about twice the planning rate.  The generators set it themselves. */
+ * instead of by one sort of all column ids: same plan, same results, about twice the planning rate.  The generators set it themselves,
+ * and every uploaded matrix is looked at for it (rows of one length whose entry positions have disjoint ascending column ranges, values 1 outside a
+ * leading run of always-present columns): this call is for a caller who knows the vocabularies to be wider than the ids that occur, or wants the check. */
 int fmx_matrix_set_fields(fmx_matrix* m, int32_t n_dense, int32_t n_fields, const uint32_t* field_base);
 /* Replace the labels of a device-resident matrix (y: f32[n] on the host): e.g. labels planted from a known model. */
 int fmx_matrix_set_labels(fmx_matrix* m, const float* y);

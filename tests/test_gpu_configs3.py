@@ -214,6 +214,48 @@ def test_a_caller_can_vouch_for_the_field_layout(monkeypatch):
         assert e.train(m, B) == B
 
 
+def test_the_field_layout_of_uploaded_rows_is_found(monkeypatch):
+    """Rows handed over as CSR with one length and disjoint, ascending column ranges per entry position -- user id / item id pairs (BASELINE.json
+    configs[0]'s shape), a one-hot encoded data frame with numeric columns first -- are recognised as field-structured on the device (fm_ingest.hip:
+    detect_fields) and planned field by field, without a hint.  Same training bit for bit as with the pair sort (FMX_FIELD_SORT=0) and the general sort
+    (FMX_FIELDS_SPLIT=0), for ids that leave gaps in their ranges; rows whose positions overlap keep the general path and train all the same."""
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(3)
+    same = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    n, B, k = 20_000, 6000, 4
+    cases = {}
+    # (a) MovieLens-shaped: a user id in [0, 943), an item id in [943, 2625) -- the ids that occur start at 5 and 1000
+    u = rng.integers(5, 943, n); it = rng.integers(1000, 2625, n)
+    cases["user_item"] = (2625, np.stack([u, it], 1).astype(np.uint32), np.ones((n, 2), np.float32))
+    # (b) two numeric columns with values, then three factors
+    f1 = 2 + rng.integers(0, 50_000, n); f2 = 60_000 + rng.integers(0, 300, n); f3 = 70_000 + rng.integers(0, 3, n)
+    cols = np.stack([np.zeros(n), np.ones(n), f1, f2, f3], 1).astype(np.uint32)
+    vals = np.concatenate([rng.normal(0, 1, (n, 2)), np.ones((n, 3))], 1).astype(np.float32)
+    cases["frame"] = (70_003, cols, vals)
+    # (c) positions that overlap: three sorted draws from one range -- not fields
+    tri = np.sort(np.stack([rng.choice(5000, 3, replace=False) for _ in range(n)]), 1).astype(np.uint32)
+    cases["overlap"] = (5000, tri, np.ones((n, 3), np.float32))
+    y = np.where(rng.random(n) < 0.5, -1.0, 1.0).astype(np.float32)
+    for name, (p, cols, vals) in cases.items():
+        z = cols.shape[1]
+        rp = np.arange(n + 1, dtype=np.int64) * z
+        kw = dict(num_factor=k, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
+        v0 = np.random.default_rng(4).normal(0, 0.05, (k, p)).astype(np.float32).astype(np.float64)
+        res = {}
+        for env in ({}, {"FMX_FIELD_SORT": "0"}, {"FMX_FIELDS_SPLIT": "0", "FMX_FIELD_SORT": "0"}):
+            for key in ("FMX_FIELD_SORT", "FMX_FIELDS_SPLIT"):
+                monkeypatch.delenv(key, raising=False)
+            for key, value in env.items():
+                monkeypatch.setenv(key, value)
+            m = engine.Matrix.from_csr(rp, cols.ravel(), vals.ravel(), p, y)
+            e = engine.Engine(p, **kw); e.set_params(0.0, None, v0)
+            assert e.train(m, n + B) == n + B
+            res[tuple(env)] = e.get_params()
+        first = res[()]
+        assert all(same(first, r) for r in res.values()), name
+        assert np.any(first[2] != v0)
+
+
 def test_per_field_sort_at_the_full_configs3_shape(monkeypatch):
     """The same comparison at BASELINE.json configs[3]'s own step: 33 M features in 13 dense + 26 categorical fields of 3 .. 9.9 M values,
     k = 32, steps of 262 144 rows (one sparse tile of 10.2 M entries, 64 blocks per field, three sort passes for the large fields).  Three
