@@ -23,3 +23,7 @@ unset FMX_ROWS_SERIAL
 python3 profiles/sweep.py --features 250000,1000000,4000000,16000000,33000000 > $O/sweep_features.txt 2>&1
 python3 profiles/sweep.py --factors 4,8,16,32,64 > $O/sweep_k.txt 2>&1
 find $O -name "*kernel_stats.csv"
+# the boundary and the streamed steady state (round 3, later additions)
+python3 profiles/host_handover.py > $O/host_handover.json 2>/dev/null; echo "host hand-over rc=$?"
+python3 profiles/stream_steady.py > $O/stream_steady.txt 2>&1; echo "stream steady rc=$?"
+python3 profiles/soak_r03.py > $O/soak_r03.txt 2>&1; echo "soak r03 rc=$?"
