@@ -188,9 +188,29 @@ int group_load(fmx_engine* e, const char* path) {
   return use_device_public(e->cfg.device);
 }
 
+// the handle (replica 0) holds the caller's model already: the other replicas take their copy from IT, device to device (one trip over PCIe for
+// the job instead of N: 8.4 GB of doubles at configs[3]'s shape), after the same reset of optimizer state and traces that fmx_set_params does
 int group_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
+  (void)w; (void)v;
   Group* g = e->group;
-  for (int r = 1; r < g->n; ++r) FMX_TRY(fmx_set_params(g->rep[(size_t)r], w0, w, v));
+  std::vector<std::pair<void*, size_t>> src;
+  engine_tables(e, &src, true);
+  FMX_HIP(hipSetDevice(e->cfg.device));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  for (int r = 1; r < g->n; ++r) {
+    FMX_TRY(fmx_set_params(g->rep[(size_t)r], w0, nullptr, nullptr));   // zeros + the reset; then the tables themselves
+    std::vector<std::pair<void*, size_t>> dst;
+    engine_tables(g->rep[(size_t)r], &dst, true);
+    FMX_CHECK(dst.size() == src.size(), FMX_ERR_STATE, "replica %d has another table layout", r);
+    for (size_t t = 0; t < src.size(); ++t) {
+      FMX_CHECK(dst[t].second == src[t].second, FMX_ERR_STATE, "replica %d has another table layout", r);
+      const size_t bytes = src[t].second * (size_t)e->p;
+      if (g->dev[(size_t)r] == g->dev[0]) FMX_HIP(hipMemcpy(dst[t].first, src[t].first, bytes, hipMemcpyDeviceToDevice));
+      else FMX_HIP(hipMemcpyPeer(dst[t].first, g->dev[(size_t)r], src[t].first, g->dev[0], bytes));
+    }
+  }
+  FMX_HIP(hipDeviceSynchronize());
+  g->owner_dirty = false;   // every replica holds every table again
   return use_device_public(e->cfg.device);
 }
 
