@@ -380,3 +380,22 @@ def test_host_hand_over_in_pieces():
         w0, gw, gv = e.get_params()
         assert w0 == 0.0 and not gw.any() and not gv.any()
         e.close()
+
+
+def test_gather_probes_answer_and_refuse():
+    """The measurement aids behind bench.py's `ceiling_frac` (fm_measure.hip; nothing on the product path): the uniformly random probe and the one driven
+    by a matrix's own column ids return a rate; a skewed matrix's rows are served faster than uniformly random ones from the same table (its heads stay
+    on-die), which is why the skewed workload is priced against the matrix-driven probe; bad geometry is refused."""
+    from fmwr_amd import engine, _lib as L
+    vocab = engine.CRITEO_VOCAB
+    p = 13 + sum(vocab)
+    m = engine.Matrix.synthetic_fields(100_000, 13, vocab, 3.0, 5)
+    skew = engine.measure_gather_matrix(m, 0, 100_000, p, 128, in_flight=4, reps=5)
+    flat = engine.measure_gather(p * 128, 128, n_groups=100_000, per_group=40, in_flight=4, reps=5)
+    assert skew > 0 and flat > 0 and skew > 1.2 * flat, (skew, flat)
+    with pytest.raises(L.FmxError, match="row_bytes"):
+        engine.measure_gather_matrix(m, 0, 1000, p, 48)
+    with pytest.raises(L.FmxError, match="geometry"):
+        engine.measure_gather_matrix(m, 0, 200_000, p, 128)
+    with pytest.raises(L.FmxError, match="geometry"):
+        engine.measure_gather(1 << 20, 64, n_groups=1000, per_group=30)    # per_group must be a multiple of 8
