@@ -527,9 +527,12 @@ __global__ __launch_bounds__(256) void fields_split_k(const uint32_t* __restrict
 // average when the digit is uniform: a first version that stored every entry straight from its lane, with 11-bit digits, spent its time
 // in 4-byte stores to 64 different lines per instruction -- 51 us per pass against 13 for the count that reads the same keys).  Pass 0
 // takes the row from the entry's position; a field's last pass adds base[c] back and writes straight into the plan.  Blocks of one field
-// run on ONE XCD (consecutive workgroup ids go round the eight XCDs): the next pass re-reads what this one wrote from that XCD's L2.
+// run on ONE XCD (consecutive workgroup ids go round the eight XCDs) so that the next pass could re-read what this one wrote from that XCD's L2 --
+// measured against plain field-major order (FMX_FQ_PLAIN=1): no difference at the Criteo shape (383 / 386 M examples/s streamed); matrices of fewer than
+// eight fields (user id / item id pairs) take the plain order, which keeps the whole chip busy.
 struct FieldPass {  // one LSD pass (by value)
   int n_active;                    // fields taking part
+  int plain;                       // blocks in field-major order over the whole chip instead of one field per XCD at a time
   uint32_t n, tiles;               // entries per field, blocks per field
   uint8_t field[FMX_MAX_FIELDS];   // active slot -> field
   uint8_t shift[FMX_MAX_FIELDS], db[FMX_MAX_FIELDS], last[FMX_MAX_FIELDS];  // per slot: digit position and width, final pass of the field
@@ -543,6 +546,11 @@ struct FqCfg {
   static_assert(TILE >= FQ_TILE_MIN && NBMAX <= FQ_NBMAX, "the workspace is sized for blocks of at least FQ_TILE_MIN entries and FQ_NBMAX digits");
 };
 __device__ __forceinline__ bool fq_block(const FieldPass& P, int* slot, uint32_t* tile) {
+  if (P.plain) {   // fewer fields than XCDs (user id / item id pairs): field after field over the whole chip
+    *slot = (int)(blockIdx.x / P.tiles);
+    *tile = blockIdx.x % P.tiles;
+    return *slot < P.n_active;
+  }
   const uint32_t x = blockIdx.x & 7u, s = blockIdx.x >> 3;   // XCD, position in the XCD's queue
   *slot = (int)(x + 8u * (s / P.tiles));
   *tile = s % P.tiles;
@@ -784,7 +792,10 @@ static int field_sort_g(const std::vector<uint32_t>& fbase, uint32_t n, uint32_t
     const uint32_t* sr = q == 0 ? nullptr : ((q & 1) ? b_rows : a_rows);
     uint32_t* dk = (q & 1) ? a_keys : b_keys;
     uint32_t* dr = (q & 1) ? a_rows : b_rows;
-    const dim3 grid(8u * tiles * (unsigned)((P.n_active + 7) / 8));
+    static const int plain_env = [] { const char* v = getenv("FMX_FQ_PLAIN"); return v ? atoi(v) : -1; }();
+    P.plain = plain_env >= 0 ? plain_env : (P.n_active < 8 ? 1 : 0);
+    if (P.n_active < 8) P.plain = 1;
+    const dim3 grid(P.plain ? tiles * (unsigned)P.n_active : 8u * tiles * (unsigned)((P.n_active + 7) / 8));
     hipLaunchKernelGGL((fq_count_k<G>), grid, dim3(G::THREADS), 0, stream, P, sk, counts);
     hipLaunchKernelGGL((fq_scan_k<G>), dim3((unsigned)(((1u << db_max) + 255) / 256), (unsigned)P.n_active), dim3(256), 0, stream, P, (const uint32_t*)counts, pre, totals);
     hipLaunchKernelGGL((fq_scatter_k<G>), grid, dim3(G::THREADS), 0, stream, P, sk, sr, dk, dr, fin_keys, fin_rows, (const uint32_t*)pre, (const uint32_t*)totals);
