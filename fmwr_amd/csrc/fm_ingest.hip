@@ -1193,15 +1193,14 @@ struct MergeWs {
   int64_t cap = 0;
   int n_parts_cap = 0;
   uint32_t *keys_in = nullptr, *keys_out = nullptr, *pos_in = nullptr, *pos_out = nullptr, *roff = nullptr, *rfeat = nullptr, *dcount = nullptr;
-  uint8_t* flags = nullptr;
+  uint32_t* blk = nullptr;   // block counts of the ordered compaction (heads)
   void* sort_temp = nullptr; size_t sort_bytes = 0;
-  void* sel_temp = nullptr; size_t sel_bytes = 0;
 };
 
 void merge_ws_free(MergeWs* w) {
   if (!w) return;
   (void)hipFree(w->keys_in); (void)hipFree(w->keys_out); (void)hipFree(w->pos_in); (void)hipFree(w->pos_out); (void)hipFree(w->roff);
-  (void)hipFree(w->rfeat); (void)hipFree(w->dcount); (void)hipFree(w->flags); (void)hipFree(w->sort_temp); (void)hipFree(w->sel_temp);
+  (void)hipFree(w->rfeat); (void)hipFree(w->dcount); (void)hipFree(w->blk); (void)hipFree(w->sort_temp);
   delete w;
 }
 
@@ -1218,12 +1217,14 @@ static int merge_ws_reserve(fmx_engine* e, int64_t total, int n_parts) {
   FMX_HIP(hipMalloc(&n.keys_in, m * 4)); FMX_HIP(hipMalloc(&n.keys_out, m * 4));
   FMX_HIP(hipMalloc(&n.pos_in, m * 4)); FMX_HIP(hipMalloc(&n.pos_out, m * 4));
   FMX_HIP(hipMalloc(&n.roff, (m + 1) * 4)); FMX_HIP(hipMalloc(&n.rfeat, m * 4));
-  FMX_HIP(hipMalloc(&n.dcount, 16)); FMX_HIP(hipMalloc(&n.flags, m));
-  FMX_HIP(rocprim::radix_sort_pairs(nullptr, n.sort_bytes, n.keys_in, n.keys_out, n.pos_in, n.pos_out, m, 0, 32, e->stream));
+  FMX_HIP(hipMalloc(&n.dcount, 16)); FMX_HIP(hipMalloc(&n.blk, (m / CP_CHUNK + 2) * 4));
+  {  // scratch of the pair sort: the larger of the tuned nine-bit form and rocprim's default (whichever sort_pairs_u32 picks for the bit count)
+    size_t a = 0, b = 0;
+    FMX_HIP(rocprim::radix_sort_pairs(nullptr, a, n.keys_in, n.keys_out, n.pos_in, n.pos_out, m, 0, 32, e->stream));
+    FMX_HIP(sort_pairs_u32(nullptr, b, n.keys_in, n.keys_out, n.pos_in, n.pos_out, m, 25, e->stream));
+    n.sort_bytes = a > b ? a : b;
+  }
   FMX_HIP(hipMalloc(&n.sort_temp, n.sort_bytes ? n.sort_bytes : 16));
-  rocprim::counting_iterator<uint32_t> ids(0);
-  FMX_HIP(rocprim::select(nullptr, n.sel_bytes, ids, n.flags, n.roff, n.dcount, m, e->stream));
-  FMX_HIP(hipMalloc(&n.sel_temp, n.sel_bytes ? n.sel_bytes : 16));
   n.cap = (int64_t)m;
   n.n_parts_cap = n_parts;
   return FMX_OK;
@@ -1249,15 +1250,17 @@ int merge_records(fmx_engine* e, const void* recs, const int64_t* counts, const 
   FMX_HIP(hipMemsetAsync(w.dcount, 0, 16, e->stream));
   if (total == 0) return FMX_OK;
   FMX_TRY(launch_record_keys(e, recs, parts, total, w.keys_in, w.pos_in));
+  // (feature id, slot) pairs sorted by id -- stable: a feature's parts stay in rank order -- with the plan builder's pair sort (nine-bit passes where
+  // they save one) and its ordered compaction for the run heads (list starts and ids in one pass) instead of a flag array + rocprim::select + a fix-up pass
   const int bits = col_bits((uint32_t)e->p);
   size_t tb = w.sort_bytes;
-  FMX_HIP(rocprim::radix_sort_pairs(w.sort_temp, tb, w.keys_in, w.keys_out, w.pos_in, w.pos_out, (size_t)total, 0, bits, e->stream));
-  const int T = 256;
-  hipLaunchKernelGGL(head_flags_k, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, e->stream, w.keys_out, total, w.flags);
-  rocprim::counting_iterator<uint32_t> ids(0);
-  tb = w.sel_bytes;
-  FMX_HIP(rocprim::select(w.sel_temp, tb, ids, w.flags, w.roff, w.dcount, (size_t)total, e->stream));
-  hipLaunchKernelGGL(lists_finish_k, dim3((unsigned)((total + 1 + T - 1) / T)), dim3(T), 0, e->stream, w.keys_out, w.roff, w.dcount, (uint32_t)total, w.rfeat);
+  FMX_HIP(sort_pairs_u32(w.sort_temp, tb, w.keys_in, w.keys_out, w.pos_in, w.pos_out, (size_t)total, bits, e->stream));
+  const uint32_t nb = ((uint32_t)total + CP_CHUNK - 1) / CP_CHUNK;
+  hipLaunchKernelGGL(heads_count_k, dim3(nb), dim3(CP_THREADS), 0, e->stream, w.keys_out, (uint32_t)total, w.blk);
+  hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, e->stream, w.blk, nb, w.dcount, 0u);
+  hipLaunchKernelGGL(heads_write_k, dim3(nb), dim3(CP_THREADS), 0, e->stream, w.keys_out, (uint32_t)total, (const uint32_t*)w.blk, w.roff, w.rfeat,
+                     (const uint32_t*)nullptr, (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+  hipLaunchKernelGGL(close_directory_k, dim3(1), dim3(1), 0, e->stream, w.roff, (const uint32_t*)w.dcount, (uint32_t)total);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }

@@ -1,0 +1,9 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out
+timeout -k 10 900 python3 -m pytest tests/test_gpu_group.py tests/test_gpu_distributed.py tests/test_gpu_configs3.py -x -q -m gpu > $O/r3_t69.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 $O/r3_t69.log
+[ $rc -ne 0 ] && exit $rc
+export FMX_BENCH_SHARED_DEVICE=1
+for x in owner compact; do
+  FMX_GROUP_EXCHANGE=$x timeout -k 10 300 python3 bench.py --in-library --workload criteo --gpus 2 --rows 4000000 --steps 20 > $O/r3_inlib69_$x.json 2>/dev/null; echo "$x rc=$?"; cut -c100-240 $O/r3_inlib69_$x.json
+done
