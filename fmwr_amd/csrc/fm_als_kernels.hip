@@ -141,14 +141,9 @@ __global__ void als_unpack_k(const double2* __restrict__ qe, int64_t n, double* 
 
 __device__ __forceinline__ bool bad_number(double x) { return isnan(x) || isinf(x); }
 
-// What changes from factor to factor (and from call to call) in a sweep: it lives in device memory and every sweep kernel reads it from
-// there, so that the launches of one factor's sweep are IDENTICAL for every factor and every call -- a deep-level plan (i.i.d.
-// columns: 8 155 dependent launches per factor) is then captured once as a HIP graph and replayed (sweep_graph below).
-struct SweepDyn {
-  int f, pad;
-  double alpha, lambda, mu;
-  const double* znorm;   // this factor's (or w's) standard normals, or null: the ALS mean
-};
+// SweepDyn (fmx_internal.h): what changes from factor to factor (and from call to call) in a sweep lives in device memory and every sweep
+// kernel reads it from there, so that the launches of one factor's sweep are IDENTICAL for every factor and every call -- a deep-level plan
+// (i.i.d. columns: 8 155 dependent launches per factor) is then captured once as a HIP graph and replayed (sweep_graph below).
 __global__ void als_set_dyn_k(SweepDyn* d, int f, double alpha, double lambda, double mu, const double* znorm) {
   d->f = f; d->pad = 0; d->alpha = alpha; d->lambda = lambda; d->mu = mu; d->znorm = znorm;
 }
@@ -578,7 +573,11 @@ __global__ void als_maxpos_k(const int64_t* __restrict__ row_ptr, const uint32_t
 // the level plan depends on the matrix only: built once, kept in the fmx_matrix
 static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   if (m->als_force_exact) max_levels = 0;  // an approximate sweep of this matrix raised the residual once: exact from then on
-  if (m->als_feats && m->als_plan_cap == max_levels) return FMX_OK;
+  if (m->als_feats && m->als_plan_cap == max_levels) {
+    if (!m->als_tiled_tried) { m->als_tiled_tried = 1; FMX_TRY(als_tiled_build(m, stream)); }  // (the values changed since: the tiled lists hold copies)
+    return FMX_OK;
+  }
+  als_tiled_free(m); m->als_tiled_tried = 0;
   (void)hipFree(m->als_feats); m->als_feats = nullptr;
   (void)hipFree(m->als_heavy); m->als_heavy = nullptr;
   (void)hipFree(m->als_vh); (void)hipFree(m->als_vh_seg0); (void)hipFree(m->als_vseg_feat); (void)hipFree(m->als_vseg_b); (void)hipFree(m->als_vseg_e); (void)hipFree(m->als_vh_work);
@@ -743,7 +742,8 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   m->als_approx = approx ? 1 : 0;
   m->als_plan_cap = max_levels;
   m->als_level_of.assign(level.begin(), level.end());
-  return FMX_OK;
+  m->als_tiled_tried = 1;
+  return als_tiled_build(m, stream);  // wide levels of an exact plan: the row-tiled form (fm_als_tiled.hip)
 }
 
 // One pass over all features of the plan for the w sweep (W) or one factor of the V sweep: levels (exact) or groups (approximate)
@@ -765,6 +765,10 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
     const dim3 gl((unsigned)((cnt * 64 + WG_THREADS - 1) / WG_THREADS)), gh((unsigned)hcnt), blk(WG_THREADS);
     struct ProfEnd { fmx_engine* e; bool on; ~ProfEnd() { if (on) prof_end(e); } } prof_guard{e, profile};
     if (profile) prof_begin(e, FMX_KERNEL_ALS_SWEEP);  // one level (or group) of one factor: the unit bench.py --solver als prices
+    if (!m->als_approx && m->als_tiled) {
+      bool done = false;
+      if (als_tiled_level<W>(e, m, l, d_qe, dyn, &done) == FMX_OK && done) continue;
+    }
     if (!m->als_approx) {
       if (cnt > 0) {
         if (W) hipLaunchKernelGGL(als_w_level_k, gl, blk, 0, e->stream, lf, (int)cnt, m->col_ptr, m->crow, m->cval, e->dw, d_qe, dyn);

@@ -1,0 +1,391 @@
+// Row-tiled form of one level of the ALS / Gibbs sweeps (MCMC_ALS_Learner::update_v, solver/MCMC_ALS_Learner.h:283-351; update_w, :208-256).
+//
+// als_level_k (fm_als_kernels.hip) walks a feature's CSC column: per stored nonzero one random 16-byte gather AND one 16-byte scatter of the
+// row's (q, e) pair, from a table of n rows -- 160 MB at configs[4], i.e. every access a miss of the XCD's 4 MB L2, a whole line moved for
+// 16 bytes used (profiles/r04_pmc_summary_mcmc_untiled.json).  On matrices whose levels are few and wide (one column per field: the levels
+// ARE the fields) the same level is done here as three passes, none of which touches the big table at random:
+//
+//   sums   als_tile_sums_k   the rows are cut into tiles whose (q, e) slice fits an XCD's L2 (131 072 rows = 2 MB); a tile's workgroups share
+//                            one XCD (equal blockIdx % 8: placement for speed only, the result does not depend on it).  Per (tile, feature of
+//                            the level) the tile's entries of that feature -- kept sorted by feature, rows ascending: `trow`, `tval`, `toff` --
+//                            are walked by a lane group: sum h e, sum h^2 against the L2-resident slice.  One (mean, var) pair per (tile, feature).
+//   step   als_tile_step_k   per feature: the tiles' pairs added in tile order (fixed: reproducible run to run), the coordinate step of
+//                            :318-336 exactly as als_level_k takes it, V written, (v_old, v_old - v_new) left in a level-sized table.
+//   apply  als_rows_apply_k  ROW-major: row r reads the level's entry it holds (`lfi`, `lval`: level-major copies of the CSR), the 16-byte
+//                            (v_old, diff) pair of its feature (a table of one level's features: L2-resident) and streams (q, e)[r] through:
+//                            q -= x diff, e -= h diff (:341-350).  Coalesced in and out.
+//
+// Same arithmetic per entry as als_level_k; only the association of the two sums differs (lane-strided butterfly there, list order inside a
+// tile then tile order here): oracle parity 1e-10 (tests/test_gpu_configs4.py), bitwise run to run.
+#include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
+#include <memory>
+
+#include <rocprim/rocprim.hpp>
+
+#include "fmx_internal.h"
+
+namespace fmx {
+
+constexpr uint32_t TILED_NONE = 0xFFFFFFFFu;
+
+struct AlsTiled {
+  int64_t n = 0;
+  int tshift = 17;               // tile_rows = 1 << tshift
+  int n_tiles = 0;
+  int lg = 1;                    // lanes per (tile, feature) list in als_tile_sums_k
+  uint32_t n_feats = 0;          // features of the tiled levels, ordered by (level, index)
+  uint32_t max_cnt = 0;          // most features in one tiled level
+  int n_slots = 0;               // tiled levels
+  int unit = 0;
+  std::vector<int> slot_of_level;          // [L] index of the level among the tiled ones, -1: the level keeps the column-walking kernels
+  std::vector<uint32_t> lvl0, cnt;         // per slot: first feature (position in `feats`) and number of features
+  uint32_t* feats = nullptr;     // [n_feats] feature ids
+  uint32_t* lfi = nullptr;       // [n_slots][n] index (inside its level) of the feature row r holds at that level, TILED_NONE: none
+  float* lval = nullptr;         // [n_slots][n] its value (null: every value is 1.0f)
+  uint32_t* toff = nullptr;      // [n_tiles][n_feats + 1] entry offsets of the (tile, feature) lists, relative to the tile's first entry
+  int64_t* tile_base = nullptr;  // [n_tiles + 1] (device) first entry of each tile in trow / tval
+  uint32_t* trow = nullptr;      // [entries + 1] row inside the tile
+  float* tval = nullptr;         // [entries + 1] (null: unit values)
+  ~AlsTiled() {
+    (void)hipFree(feats); (void)hipFree(lfi); (void)hipFree(lval); (void)hipFree(toff); (void)hipFree(tile_base); (void)hipFree(trow); (void)hipFree(tval);
+  }
+};
+
+void als_tiled_free(fmx_matrix* m) {
+  delete reinterpret_cast<AlsTiled*>(m->als_tiled);
+  m->als_tiled = nullptr;
+}
+
+// ---- plan ------------------------------------------------------------------------------------------------------------------------------------
+// level-major copies of the CSR: for every tiled level the feature (as its index inside the level) and value each row holds there
+__global__ void tiled_rows_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t n,
+                             const int* __restrict__ slot_of_feat, const uint32_t* __restrict__ idx_in_level, uint32_t* __restrict__ lfi, float* __restrict__ lval) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int64_t t = row_ptr[r]; t < row_ptr[r + 1]; ++t) {
+    const uint32_t j = col[t];
+    const int s = slot_of_feat[j];
+    if (s < 0) continue;
+    lfi[(size_t)s * n + r] = idx_in_level[j];
+    if (lval) lval[(size_t)s * n + r] = val[t];
+  }
+}
+
+// entries of every (tile, feature) list: one wave per CSC column (rows ascending inside a column, so a tile's entries of it are one run)
+__global__ __launch_bounds__(WG_THREADS) void tiled_count_k(const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const uint32_t* __restrict__ rank_of,
+                                                            uint32_t p, int tshift, size_t nf1, uint32_t* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6;
+  if (j >= (int64_t)p) return;
+  const uint32_t k = rank_of[j];
+  if (k == TILED_NONE) return;
+  const int64_t b = col_ptr[j], e = col_ptr[j + 1];
+  for (int64_t t = b + lane; t < e; t += 64) atomicAdd(&counts[(size_t)(crow[t] >> tshift) * nf1 + k], 1u);  // (integer counts: the order of the adds does not matter)
+}
+
+__global__ __launch_bounds__(WG_THREADS) void tiled_scatter_k(const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
+                                                              const uint32_t* __restrict__ rank_of, uint32_t p, int tshift, size_t nf1,
+                                                              const uint32_t* __restrict__ toff, const int64_t* __restrict__ tile_base,
+                                                              uint32_t* __restrict__ trow, float* __restrict__ tval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6;
+  if (j >= (int64_t)p) return;
+  const uint32_t k = rank_of[j];
+  if (k == TILED_NONE) return;
+  const int64_t b = col_ptr[j], e = col_ptr[j + 1];
+  for (int64_t t = b + lane; t < e; t += 64) {
+    const uint32_t r = crow[t];
+    const uint32_t tile = r >> tshift, lo = tile << tshift;
+    int64_t a = b, z = t;  // first entry of the column whose row lies in this tile: in [b, t]
+    while (a < z) {
+      const int64_t mid = (a + z) >> 1;
+      if (crow[mid] < lo) a = mid + 1; else z = mid;
+    }
+    const int64_t dst = tile_base[tile] + (int64_t)toff[(size_t)tile * nf1 + k] + (t - a);
+    trow[dst] = r - lo;
+    if (tval) tval[dst] = cval[t];
+  }
+}
+
+__global__ void tiled_tile_base_k(const int64_t* __restrict__ row_ptr, int64_t n, int tshift, int n_tiles, int64_t* __restrict__ tile_base) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_tiles) return;
+  const int64_t r = (int64_t)t << tshift;
+  tile_base[t] = row_ptr[r < n ? r : n];
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s && *s ? atoi(s) : dflt;
+}
+
+// Which levels of the exact plan go through the tiled form, and their plan.  Called at the end of build_plan (the CSC and the levels exist).
+// A failure to allocate leaves the matrix without a tiled plan (the column-walking kernels do every level then): never an error.
+int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
+  als_tiled_free(m);
+  if (m->als_approx || m->n == 0 || m->nnz == 0) return FMX_OK;
+  // FMX_ALS_TILED: 0 never, 1 wherever a level qualifies (tests: small matrices), unset: where the (q, e) table no longer fits the L2s together
+  const int mode = env_int("FMX_ALS_TILED", -1);
+  if (mode == 0) return FMX_OK;
+  if (mode < 0 && m->n < (1 << 21)) return FMX_OK;
+  const int L = (int)m->als_level_ptr.size() - 1;
+  const uint32_t p = m->p;
+  if (L <= 0 || m->n >= (1LL << 32)) return FMX_OK;
+  // a level qualifies when every feature of it is a "light" one (at most ALS_HEAVY entries: als_heavy / als_vh hold none of the level) and it is wide
+  // enough to fill the chip; the level-major copies cost 4 (8) bytes per row and tiled level, so deep plans (thousands of narrow levels) never qualify
+  const int64_t min_feats = mode > 0 ? 1 : 2048;
+  std::vector<int> slot((size_t)L, -1);
+  int n_slots = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t c = m->als_level_ptr[(size_t)l + 1] - m->als_level_ptr[(size_t)l];
+    const int64_t h = m->als_heavy_ptr[(size_t)l + 1] - m->als_heavy_ptr[(size_t)l];
+    const int64_t v = m->als_vh_ptr.empty() ? 0 : m->als_vh_ptr[(size_t)l + 1] - m->als_vh_ptr[(size_t)l];
+    if (h == 0 && v == 0 && c >= min_feats) slot[(size_t)l] = n_slots++;
+  }
+  if (n_slots == 0 || n_slots > (mode > 0 ? 4096 : 256)) return FMX_OK;
+  if (mode < 0 && (double)n_slots * (double)m->n > 8.0 * (double)m->nnz + 1e6) return FMX_OK;   // the level-major copies would dwarf the matrix
+  std::unique_ptr<AlsTiled> T(new AlsTiled());
+  T->n = m->n;
+  int rows_want = env_int("FMX_ALS_TILE_ROWS", 131072);
+  int ts = 4;
+  while ((1 << (ts + 1)) <= rows_want && ts < 24) ++ts;
+  T->tshift = ts;
+  T->n_tiles = (int)((m->n + (1LL << ts) - 1) >> ts);
+  T->lg = env_int("FMX_ALS_TILE_LG", 1);
+  if (T->lg != 1 && T->lg != 2 && T->lg != 4 && T->lg != 8) T->lg = 1;
+  T->unit = m->unit_values;
+  T->n_slots = n_slots;
+  T->slot_of_level = slot;
+  // features of the tiled levels by (level, index): als_feats already holds the light features in that order
+  std::vector<uint32_t> all_light((size_t)m->als_level_ptr[(size_t)L]);
+  if (!all_light.empty()) FMX_HIP(hipMemcpy(all_light.data(), m->als_feats, all_light.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> feats, rank_of((size_t)p, TILED_NONE), idx_in((size_t)p, 0u);
+  std::vector<int> slot_of_feat((size_t)p, -1);
+  T->lvl0.assign((size_t)n_slots, 0u); T->cnt.assign((size_t)n_slots, 0u);
+  for (int l = 0; l < L; ++l) {
+    const int s = slot[(size_t)l];
+    if (s < 0) continue;
+    T->lvl0[(size_t)s] = (uint32_t)feats.size();
+    for (int64_t q = m->als_level_ptr[(size_t)l]; q < m->als_level_ptr[(size_t)l + 1]; ++q) {
+      const uint32_t j = all_light[(size_t)q];
+      idx_in[j] = (uint32_t)(feats.size() - T->lvl0[(size_t)s]);
+      rank_of[j] = (uint32_t)feats.size();
+      slot_of_feat[j] = s;
+      feats.push_back(j);
+    }
+    T->cnt[(size_t)s] = (uint32_t)(feats.size() - T->lvl0[(size_t)s]);
+    if (T->cnt[(size_t)s] > T->max_cnt) T->max_cnt = T->cnt[(size_t)s];
+  }
+  T->n_feats = (uint32_t)feats.size();
+  const size_t nf1 = (size_t)T->n_feats + 1;
+  if ((double)nf1 * T->n_tiles * 4.0 > 4e9) return FMX_OK;   // directories of more than 4 GB: smaller tiles than this matrix wants
+  struct Tmp {
+    uint32_t *rank_of = nullptr, *idx_in = nullptr, *counts = nullptr;
+    int* slot_of_feat = nullptr;
+    void* scan = nullptr;
+    ~Tmp() { (void)hipFree(rank_of); (void)hipFree(idx_in); (void)hipFree(counts); (void)hipFree(slot_of_feat); (void)hipFree(scan); }
+  } w;
+  auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
+  const size_t sn = (size_t)n_slots * (size_t)m->n;
+  if (!ok(hipMalloc(&w.rank_of, (size_t)p * 4)) || !ok(hipMalloc(&w.idx_in, (size_t)p * 4)) || !ok(hipMalloc(&w.slot_of_feat, (size_t)p * 4)) ||
+      !ok(hipMalloc(&w.counts, nf1 * T->n_tiles * 4)) || !ok(hipMalloc(&T->feats, (size_t)(T->n_feats ? T->n_feats : 1) * 4)) ||
+      !ok(hipMalloc(&T->lfi, sn * 4)) || (!T->unit && !ok(hipMalloc(&T->lval, sn * 4))) || !ok(hipMalloc(&T->toff, nf1 * T->n_tiles * 4)) ||
+      !ok(hipMalloc(&T->tile_base, ((size_t)T->n_tiles + 1) * 8)) || !ok(hipMalloc(&T->trow, ((size_t)m->nnz + 1) * 4)) ||
+      (!T->unit && !ok(hipMalloc(&T->tval, ((size_t)m->nnz + 1) * 4))))
+    return FMX_OK;
+  FMX_HIP(hipMemcpyAsync(w.rank_of, rank_of.data(), (size_t)p * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemcpyAsync(w.idx_in, idx_in.data(), (size_t)p * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemcpyAsync(w.slot_of_feat, slot_of_feat.data(), (size_t)p * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemcpyAsync(T->feats, feats.data(), (size_t)T->n_feats * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemsetAsync(T->lfi, 0xFF, sn * 4, stream));
+  FMX_HIP(hipMemsetAsync(w.counts, 0, nf1 * T->n_tiles * 4, stream));
+  FMX_HIP(hipMemsetAsync(T->trow, 0, ((size_t)m->nnz + 1) * 4, stream));
+  if (T->tval) FMX_HIP(hipMemsetAsync(T->tval, 0, ((size_t)m->nnz + 1) * 4, stream));
+  hipLaunchKernelGGL(tiled_rows_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->val, m->n, w.slot_of_feat, w.idx_in, T->lfi, T->lval);
+  hipLaunchKernelGGL(tiled_tile_base_k, dim3((unsigned)(T->n_tiles / 256 + 1)), dim3(256), 0, stream, m->row_ptr, m->n, ts, T->n_tiles, T->tile_base);
+  const unsigned col_grid = (unsigned)(((int64_t)p * 64 + WG_THREADS - 1) / WG_THREADS);
+  hipLaunchKernelGGL(tiled_count_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, w.rank_of, p, ts, nf1, w.counts);
+  size_t scan_bytes = 0;
+  FMX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, w.counts, T->toff, 0u, nf1, rocprim::plus<uint32_t>(), stream));
+  if (!ok(hipMalloc(&w.scan, scan_bytes ? scan_bytes : 16))) return FMX_OK;
+  for (int t = 0; t < T->n_tiles; ++t)
+    FMX_HIP(rocprim::exclusive_scan(w.scan, scan_bytes, w.counts + (size_t)t * nf1, T->toff + (size_t)t * nf1, 0u, nf1, rocprim::plus<uint32_t>(), stream));
+  hipLaunchKernelGGL(tiled_scatter_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, m->cval, w.rank_of, p, ts, nf1, T->toff, T->tile_base, T->trow, T->tval);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipStreamSynchronize(stream));
+  m->als_tiled = T.release();
+  return FMX_OK;
+}
+
+int als_tiled_info(const fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_rows, int32_t* n_tiles) {
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (levels_tiled) *levels_tiled = T ? T->n_slots : 0;
+  if (tile_rows) *tile_rows = T ? (1LL << T->tshift) : 0;
+  if (n_tiles) *n_tiles = T ? T->n_tiles : 0;
+  return FMX_OK;
+}
+
+// ---- the sweep -------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bad_number_t(double x) { return isnan(x) || isinf(x); }
+
+// the level's current coordinates, gathered once into a level-sized vector (read coalesced by every tile's lists)
+template <bool W>
+__global__ void als_tile_prep_k(const uint32_t* __restrict__ feats, uint32_t cnt, const double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                double* __restrict__ vf) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  vf[i] = P[W ? (size_t)feats[i] : (size_t)feats[i] * kp + dyn->f];
+}
+
+// blockIdx -> (tile, chunk of the level's features): the B workgroups of a tile are consecutive in ONE XCD's share of the grid (blocks are dealt
+// round-robin over the eight XCDs, so blocks b and b + 8 share one), and an XCD works through its tiles one after the other -- the tile's
+// (q, e) slice is fetched into that L2 once and gathered from there.  Placement is for speed only.
+template <bool W, int LG, bool UNIT>
+__global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt,
+                                                              const int64_t* __restrict__ tile_base, const uint32_t* __restrict__ trow, const float* __restrict__ tval,
+                                                              const double* __restrict__ vf, const double2* __restrict__ qe, int tshift, int n_tiles, int B,
+                                                              double2* __restrict__ partial, uint32_t max_cnt) {
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int tile = (i / B) * 8 + x, chunk = i % B;
+  if (tile >= n_tiles) return;
+  constexpr int LISTS = WG_THREADS / LG;
+  const uint32_t fi = (uint32_t)chunk * LISTS + threadIdx.x / LG;
+  const int lg = threadIdx.x % LG;
+  if (fi >= cnt) return;   // (a whole lane group leaves together)
+  const uint32_t* off = toff + (size_t)tile * nf1 + lvl0 + fi;
+  const uint32_t lb = off[0], le = off[1];
+  const int64_t tb = tile_base[tile];
+  const double2* __restrict__ slice = qe + ((size_t)tile << tshift);
+  const double old = vf[fi];
+  double mean = 0.0, var = 0.0;
+  constexpr int U = 4;
+  // loads are unconditional on a clamped index, the values selected afterwards (a load under a condition is a branch whose join waits: DESIGN 6.2)
+  for (uint32_t t0 = lb + lg; t0 < le; t0 += LG * U) {
+    uint32_t rr[U]; float xs[U]; double2 c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t t = t0 + u * LG, tc = t < le ? t : t0;
+      rr[u] = trow[tb + tc];
+      xs[u] = UNIT ? 1.0f : tval[tb + tc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) c[u] = slice[rr[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t0 + u * LG >= le) continue;
+      if (W) { const double xd = (double)xs[u]; mean += c[u].y * xd - old * xd * xd; var += xd * xd; }                                       // :216-219
+      else { const float xx = xs[u] * xs[u]; const double h = (double)xs[u] * c[u].x - (double)xx * old; mean += h * c[u].y; var += h * h; }  // :310-317
+    }
+  }
+#pragma unroll
+  for (int o = LG / 2; o > 0; o >>= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }
+  if (lg == 0) partial[(size_t)tile * max_cnt + fi] = make_double2(mean, var);
+}
+
+template <bool W>
+__global__ void als_tile_step_k(const uint32_t* __restrict__ feats, uint32_t cnt, const double2* __restrict__ partial, uint32_t max_cnt, int n_tiles,
+                                double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, const double* __restrict__ vf, double2* __restrict__ vstep) {
+  const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (fi >= cnt) return;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  const uint32_t i = feats[fi];
+  double mean = 0.0, var = 0.0;
+  for (int t = 0; t < n_tiles; ++t) { const double2 s = partial[(size_t)t * max_cnt + fi]; mean += s.x; var += s.y; }
+  const double old = vf[fi];
+  double nv;
+  if (W) {
+    var = 1.0 / (lambda + alpha * var);
+    mean = -var * (alpha * mean - mu * lambda);
+    nv = bad_number_t(var) ? 0.0 : (znorm ? mean + var * znorm[i] : mean);      // (the variance as Rf_rnorm's sd: :239, kept)
+  } else {
+    mean -= old * var;                               // :318
+    var = 1.0 / (lambda + alpha * var);              // :319
+    mean = -var * (alpha * mean - mu * lambda);      // :320
+    nv = bad_number_t(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[i] : mean);
+  }
+  if (bad_number_t(nv)) { vstep[fi] = make_double2(old, nan("")); return; }  // CHECK_PARAM (:336): keep the old value; NaN tells the apply pass to skip the feature's rows
+  P[W ? (size_t)i : (size_t)i * kp + dyn->f] = nv;
+  vstep[fi] = make_double2(old, old - nv);
+}
+
+template <bool W, bool UNIT>
+__global__ __launch_bounds__(WG_THREADS) void als_rows_apply_k(const uint32_t* __restrict__ lfi, const float* __restrict__ lval, int64_t n,
+                                                               const double2* __restrict__ vstep, double2* __restrict__ qe) {
+  const int64_t r = (int64_t)blockIdx.x * WG_THREADS + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t fi = lfi[r];
+  const float x = UNIT ? 1.0f : lval[r];
+  const double2 c = qe[r];
+  const double2 s = vstep[fi == TILED_NONE ? 0u : fi];
+  if (fi == TILED_NONE || s.y != s.y) return;
+  if (W) {
+    qe[r] = make_double2(c.x, c.y - (double)x * s.y);                                         // :246-252
+  } else {
+    const float xx = x * x;
+    const double h = (double)x * c.x - (double)xx * s.x;
+    qe[r] = make_double2(c.x - (double)x * s.y, c.y - h * s.y);                               // :341-350
+  }
+}
+
+static int tile_ws(fmx_engine* e, const AlsTiled* T, double2** partial, double** vf, double2** vstep) {
+  const size_t need = ((size_t)T->n_tiles * T->max_cnt + T->max_cnt) * sizeof(double2) + (size_t)T->max_cnt * sizeof(double);
+  if (e->als_tile_ws_bytes < need) {
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->als_tile_ws); e->als_tile_ws = nullptr; e->als_tile_ws_bytes = 0;
+    FMX_HIP(hipMalloc(&e->als_tile_ws, need));
+    e->als_tile_ws_bytes = need;
+  }
+  *partial = reinterpret_cast<double2*>(e->als_tile_ws);
+  *vstep = *partial + (size_t)T->n_tiles * T->max_cnt;
+  *vf = reinterpret_cast<double*>(*vstep + T->max_cnt);
+  return FMX_OK;
+}
+
+// one level of the w sweep (W) or of one factor of the V sweep in the tiled form; *done = false: the level is not a tiled one
+template <bool W>
+int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, double2* d_qe, const SweepDyn* dyn, bool* done) {
+  *done = false;
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (!T || level >= (int)T->slot_of_level.size() || T->slot_of_level[(size_t)level] < 0) return FMX_OK;
+  const int s = T->slot_of_level[(size_t)level];
+  const uint32_t lvl0 = T->lvl0[(size_t)s], cnt = T->cnt[(size_t)s];
+  double2 *partial = nullptr, *vstep = nullptr;
+  double* vf = nullptr;
+  FMX_TRY(tile_ws(e, T, &partial, &vf, &vstep));
+  double* P = W ? e->dw : e->dV;
+  const size_t nf1 = (size_t)T->n_feats + 1;
+  const unsigned fgrid = (cnt + 255) / 256;
+  hipLaunchKernelGGL((als_tile_prep_k<W>), dim3(fgrid), dim3(256), 0, e->stream, T->feats + lvl0, cnt, (const double*)P, e->kp64, dyn, vf);
+  const int lists = WG_THREADS / T->lg;
+  const int B = (int)((cnt + lists - 1) / lists);
+  const dim3 g((unsigned)(((T->n_tiles + 7) / 8) * 8 * B)), blk(WG_THREADS);
+#define FMX_SUMS(LGv)                                                                                                                                     \
+  do {                                                                                                                                                    \
+    if (T->unit) hipLaunchKernelGGL((als_tile_sums_k<W, LGv, true>), g, blk, 0, e->stream, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, vf,     \
+                                    (const double2*)d_qe, T->tshift, T->n_tiles, B, partial, T->max_cnt);                                                  \
+    else hipLaunchKernelGGL((als_tile_sums_k<W, LGv, false>), g, blk, 0, e->stream, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, vf,            \
+                            (const double2*)d_qe, T->tshift, T->n_tiles, B, partial, T->max_cnt);                                                          \
+  } while (0)
+  switch (T->lg) {
+    case 2: FMX_SUMS(2); break;
+    case 4: FMX_SUMS(4); break;
+    case 8: FMX_SUMS(8); break;
+    default: FMX_SUMS(1); break;
+  }
+#undef FMX_SUMS
+  hipLaunchKernelGGL((als_tile_step_k<W>), dim3(fgrid), dim3(256), 0, e->stream, T->feats + lvl0, cnt, (const double2*)partial, T->max_cnt, T->n_tiles, P, e->kp64, dyn,
+                     (const double*)vf, vstep);
+  const dim3 rg((unsigned)((T->n + WG_THREADS - 1) / WG_THREADS));
+  const uint32_t* lfi = T->lfi + (size_t)s * T->n;
+  const float* lval = T->lval ? T->lval + (size_t)s * T->n : nullptr;
+  if (T->unit) hipLaunchKernelGGL((als_rows_apply_k<W, true>), rg, blk, 0, e->stream, lfi, lval, T->n, (const double2*)vstep, d_qe);
+  else hipLaunchKernelGGL((als_rows_apply_k<W, false>), rg, blk, 0, e->stream, lfi, lval, T->n, (const double2*)vstep, d_qe);
+  *done = true;
+  return FMX_OK;
+}
+template int als_tiled_level<true>(fmx_engine*, fmx_matrix*, int, double2*, const SweepDyn*, bool*);
+template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, double2*, const SweepDyn*, bool*);
+
+}  // namespace fmx

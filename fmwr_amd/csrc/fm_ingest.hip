@@ -1570,6 +1570,7 @@ static void drop_value_caches(fmx_matrix* m) {
   m->value_generation++;
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval);
   m->col_ptr = nullptr; m->crow = nullptr; m->cval = nullptr;
+  als_tiled_free(m); m->als_tiled_tried = 0;   // (its lists hold values too)
 }
 
 int matrix_scales(fmx_matrix* m, const uint8_t* h_listed, double* h_mean, double* h_std) {

@@ -217,6 +217,7 @@ void free_matrix(fmx_matrix* m) {
   drop_plans(m);
   (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats); (void)hipFree(m->als_heavy);
   (void)hipFree(m->als_vh); (void)hipFree(m->als_vh_seg0); (void)hipFree(m->als_vseg_feat); (void)hipFree(m->als_vseg_b); (void)hipFree(m->als_vseg_e); (void)hipFree(m->als_vh_work);
+  als_tiled_free(m);
   delete m;
 }
 
@@ -694,7 +695,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws);
   als_graph_free(e->als_graph_w); als_graph_free(e->als_graph_v);
   if (e->side_fork) (void)hipEventDestroy(e->side_fork);
   if (e->side_join) (void)hipEventDestroy(e->side_join);
@@ -1796,6 +1797,14 @@ int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* la
   FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweeps run on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
   FMX_TRY(use_device(e->cfg.device));
   return als_plan_info(e, m, levels, largest_level, approximate, level_of_feature);
+}
+
+int fmx_als_tiled_info(fmx_engine* e, fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_rows, int32_t* n_tiles) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweeps run on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(als_plan_info(e, m, nullptr, nullptr, nullptr, nullptr));
+  return als_tiled_info(m, levels_tiled, tile_rows, n_tiles);
 }
 
 int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v) {

@@ -183,6 +183,8 @@ struct fmx_matrix {
   int als_approx = 0;                   // the plan holds the groups of the approximate sweep, not exact levels
   int als_force_exact = 0;              // an approximate sweep raised the residual on this matrix: only exact plans from now on
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
+  void* als_tiled = nullptr;            // row-tiled form of the wide levels of an exact plan (fm_als_tiled.hip: AlsTiled), or null
+  int als_tiled_tried = 0;              // the tiled plan was built, or found not to apply, for the current plan and values
 };
 
 // Phase 1 of a LARGE step has two schedules that compute the same bits: `serial` (one entry's V row and w outstanding per lane
@@ -277,6 +279,8 @@ struct fmx_engine {
   void* als_qe = nullptr;          // (q, e) pairs of the learners' loops and of fmx_vsweep_device (grow-only)
   int64_t als_qe_rows = 0;
   void* als_dyn = nullptr;         // device struct the sweep kernels read factor / alpha / lambda / mu / normals from (fm_als_kernels.hip)
+  void* als_tile_ws = nullptr;     // tiled sweep: per (tile, feature) sums, the level's coordinates and steps (fm_als_tiled.hip; grow-only)
+  size_t als_tile_ws_bytes = 0;
   void *als_graph_w = nullptr, *als_graph_v = nullptr;  // deep exact plans replayed as HIP graphs (AlsGraph)
   double* als_backup = nullptr;    // what an approximate sweep is rolled back to when it raises the residual
   size_t als_backup_elems = 0;
@@ -517,6 +521,19 @@ int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_n
 int launch_als_vsweep(fmx_engine* e, fmx_matrix* m, double* d_error, double* d_q, double alpha, const double* h_lambda, const double* h_mu,
                       const double* d_znorm);
 void als_graph_free(void* g);
+// What changes from factor to factor (and from call to call) in a sweep: it lives in device memory and every sweep kernel reads it from
+// there, so that the launches of one factor's sweep are IDENTICAL for every factor and every call (a deep plan can then be replayed as a graph).
+struct SweepDyn {
+  int f, pad;
+  double alpha, lambda, mu;
+  const double* znorm;   // this factor's (or w's) standard normals, or null: the ALS mean
+};
+// the row-tiled form of the wide levels (fm_als_tiled.hip)
+int als_tiled_build(fmx_matrix* m, hipStream_t stream);
+void als_tiled_free(fmx_matrix* m);
+int als_tiled_info(const fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_rows, int32_t* n_tiles);
+template <bool W>
+int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, double2* d_qe, const SweepDyn* dyn, bool* done);
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 
 int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);

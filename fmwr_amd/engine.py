@@ -467,6 +467,12 @@ class Engine:
         L.check(L.lib().fmx_als_plan_info(self.h, m.h, C.byref(lv), C.byref(big), C.byref(ap), _p(lof)))
         return lv.value, big.value, bool(ap.value), lof[: self.p]
 
+    def als_tiled(self, m):
+        """(levels swept in the row-tiled form, rows per tile, tiles) for this matrix (fmx_als_tiled_info); (0, 0, 0): none."""
+        lv, tr, nt = C.c_int32(), C.c_int64(), C.c_int32()
+        L.check(L.lib().fmx_als_tiled_info(self.h, m.h, C.byref(lv), C.byref(tr), C.byref(nt)))
+        return lv.value, tr.value, nt.value
+
     def als_train(self, m, max_iter, with_v=False):
         L.check(L.lib().fmx_als_train(self.h, m.h, C.c_int32(max_iter), C.c_int32(int(with_v))))
 

@@ -394,6 +394,13 @@ int fmx_vsweep_device(fmx_engine* e, fmx_matrix* m, void* dev_error_f64, double 
  * form: `approximate` = 1) this matrix needs, the size of the largest, and every feature's level / group. */
 int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level, int32_t* approximate,
                       int32_t* level_of_feature /* [p] or NULL */);
+/* Wide levels of an exact plan (every feature of the level holds at most 4096 entries, at least 2048 features: the fields of one-column-per-
+ * field data) are swept in a ROW-TILED form on matrices of 2 M rows or more (fm_als_tiled.hip: per-tile sums against an L2-resident slice of
+ * the (q, e) pairs, the coordinate steps, a row-major correction pass) instead of walking CSC columns against the whole table.  Same
+ * arithmetic per entry; the two sums of a coordinate step associate differently (1e-10 against the column-walking form).  Reports how many
+ * levels take that form (0: none), the rows per tile and the number of tiles; builds the plan if need be.  FMX_ALS_TILED=0 / 1 in the
+ * environment forbids / forces the form wherever a level qualifies (1: any size, any width -- tests), FMX_ALS_TILE_ROWS sets the tile. */
+int fmx_als_tiled_info(fmx_engine* e, fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_rows, int32_t* n_tiles);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
  * w0 update (:162-188); w sweep (:190-270, the exact one-thread form) }.  As shipped the reference never sweeps V (its

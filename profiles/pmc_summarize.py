@@ -29,6 +29,11 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         elif "fm_rows_forward" in name: kn = "fm_rows_forward_predict"                      # bench's forward-only pass (all rows)
         elif "fm_cols_update" in name: kn = "fm_cols_update"
         elif "fm_scalar" in name: kn = "fm_scalar_update"
+        elif "als_level_k" in name: kn = "als_level"                                        # configs[4]: one level of one factor (the untiled form)
+        elif "als_tile_sums_k" in name: kn = "als_tile_sums"                                # the row-tiled form: per (tile, feature) sums ...
+        elif "als_tile_step_k" in name: kn = "als_tile_step"                                # ... the coordinate steps of the level ...
+        elif "als_rows_apply_k" in name: kn = "als_rows_apply"                              # ... and the row-major rank-1 corrections
+        elif "als_q_pick_k" in name: kn = "als_q_pick"
         else: continue
         a = acc[kn][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"]); a[1] += 1

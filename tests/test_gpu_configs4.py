@@ -82,6 +82,64 @@ def test_configs4_gibbs_vsweep_k16_matches_oracle(law):
     assert util.rel_err(gerr, rerr) < 1e-10
 
 
+@pytest.mark.parametrize("lg", [1, 4])
+@pytest.mark.parametrize("law,values,gibbs", [("stratified", "ones", False), ("stratified", "normal", True), ("iid", "normal", False), ("iid", "ones", True)])
+def test_configs4_row_tiled_sweep_matches_oracle(monkeypatch, law, values, gibbs, lg):
+    """The row-tiled form of the wide levels (fm_als_tiled.hip: per-tile sums against a slice of the (q, e) pairs, the coordinate steps, a row-major
+    correction pass), forced onto a small matrix with 4 096-row tiles (five tiles, the last one short): every level of the stratified matrix is a
+    field; the i.i.d. matrix has many narrow levels and rows that hold nothing at most of them.  ALS and Gibbs forms, one and four lanes per list."""
+    from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_TILE_ROWS", "4096")
+    monkeypatch.setenv("FMX_ALS_TILE_LG", str(lg))
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, law, n, p, 53, values)
+    w0, w, v = util.params(p, K, 31, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    lam = np.linspace(0.1, 0.5, K); mu = np.linspace(-0.05, 0.05, K)
+    z = np.random.default_rng(9).normal(0, 1, (K, p)) if gibbs else None
+    rv, rerr, _ = oracle.als_update_v(K, X, v.ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    levels = e.als_plan(m)[0]
+    tiled, tile_rows, n_tiles = e.als_tiled(m)
+    assert tile_rows == 4096 and n_tiles == 5
+    assert tiled == levels if law == "stratified" else 0 < tiled <= levels
+    gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    assert util.rel_err(e.get_params()[2], rv.reshape(K, p)) < 1e-10
+    assert util.rel_err(gerr, rerr) < 1e-10
+
+
+def test_configs4_row_tiled_learners_equal_the_column_walking_form(monkeypatch):
+    """The ALS learner's loop (w0, w sweep, V sweep) and the MCMC learner's (w0, w sweep with draws) through the tiled form and through the
+    column-walking kernels: the same sweeps, sums associated differently."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k = 12_000, 3_000, 8
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 57, "normal")
+    w0, w, v = util.params(p, k, 37, stdev=0.1, fp32=False)
+    g = np.random.default_rng(10)
+    gam = g.gamma((1 + n) / 2, 1.0, (3, 2)); nor = g.normal(0, 1, (3, 2 + p))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_TILED", mode)
+        monkeypatch.setenv("FMX_ALS_TILE_ROWS", "2048")
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        assert (e.als_tiled(m)[0] > 0) == (mode == "1")
+        e.als_train(m, 3, with_v=True)
+        e2 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL)
+        e2.set_params(w0, w, v)
+        e2.mcmc_train(m, 3, gam, nor)
+        out[mode] = (e.get_params(), e2.get_params())
+    for a, b in zip(out["1"], out["0"]):
+        assert abs(a[0] - b[0]) < 1e-10 * max(1.0, abs(b[0]))
+        assert util.rel_err(a[1], b[1]) < 1e-10 and util.rel_err(a[2], b[2]) < 1e-10
+
+
 def test_configs4_device_resident_sweep_equals_the_host_pointer_one():
     from fmwr_amd import _lib as L, engine
     n, p = 20_000, 6_000
@@ -163,6 +221,29 @@ def test_configs4_full_size_levels_descent_and_reproducibility():
         e.close(); d_err.free()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     m.close()
+
+
+def test_configs4_full_size_row_tiled_form_equals_the_column_walking_form(monkeypatch):
+    """10 M x 1 M, k = 16: the default takes the row-tiled form for all 30 levels (77 tiles of 131 072 rows); FMX_ALS_TILED=0 walks the CSC columns.
+    One Gibbs sweep each from the same start: V (sampled rows) and the residual agree to 1e-10."""
+    from fmwr_amd import _lib as L, engine
+    out = []
+    for mode in (None, "0"):
+        if mode is not None:
+            monkeypatch.setenv("FMX_ALS_TILED", mode)
+        m = engine.Matrix.synthetic(N, P, Z, SEED)
+        e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.init_normal(SEED, 0.0, 0.1)
+        tiled, tile_rows, n_tiles = e.als_tiled(m)
+        assert (tiled, tile_rows, n_tiles) == ((Z, 131072, 77) if mode is None else (0, 0, 0))
+        d_err = util.DevBuf(N)
+        L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(N), d_err.ptr, C.c_int(L.LINK_NONE)))
+        e.sync()
+        d_z = util.DevBuf.from_numpy(np.random.default_rng(12).normal(0, 1, (K, P)))
+        e.vsweep_device(m, d_err.ptr.value, alpha=1.0, v_lambda=np.full(K, 1.0), dev_std_normals=d_z.ptr.value)
+        out.append((d_err.numpy(), e.get_rows(np.arange(0, P, 499, dtype=np.uint32))[1]))
+        e.close(); d_err.free(); d_z.free(); m.close()
+    assert util.rel_err(out[0][0], out[1][0]) < 1e-10 and util.rel_err(out[0][1], out[1][1]) < 1e-10
 
 
 def test_configs4_full_size_split_columns_equal_the_unsplit_form(monkeypatch):

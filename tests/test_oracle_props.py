@@ -364,3 +364,208 @@ def test_als_linear_sweep_ends_on_the_vertex_of_its_last_coordinate():
         g0 = (J(w0n + h, wn[j]) - J(w0n - h, wn[j])) / (2 * h)
         assert abs(g0) > 1e-3                       # w0 is no longer at its vertex
         assert wn[j] != w[j] and w0n != w0
+
+
+# ---- round 4: independent pins for the branches that rested on the restatement alone --------------------------------
+
+def _tsuruoka_clip(theta_half, u, q):
+    """Tsuruoka, Tsujii & Ananiadou (ACL 2009), "SGD training for L1-regularized log-linear models with cumulative penalty", Fig. 2,
+    APPLYPENALTY: z = w; w > 0: w = max(0, w - (u + q)); w < 0: w = min(0, w + (u - q)); q += w - z.  Written from the paper."""
+    z = theta_half
+    if theta_half > 0:
+        theta = max(0.0, theta_half - (u + q))
+    elif theta_half < 0:
+        theta = min(0.0, theta_half + (u - q))
+    else:
+        theta = theta_half
+    return theta, q + (theta - z)
+
+
+def test_sgd_l1_is_tsuruokas_cumulative_penalty_on_the_finite_difference_gradient():
+    """SGD_Learner.h:92-138 in L1 mode, 300 examples in a row, against a numpy statement that shares nothing with the oracle: the gradient is the
+    central difference of the logistic loss through the O(z^2) pairwise forward, the penalty is Tsuruoka's APPLYPENALTY from the paper with the
+    budget u advanced by lr * reg once per example BEFORE the step (:93-94).  Per step: parameters agree to 1e-9 (finite-difference error);
+    exactly: the penalty never carries a coordinate across zero, |q| <= u (no coordinate has received more than the budget), untouched
+    coordinates do not move."""
+    n, p, k = 300, 14, 3
+    rp, col, val = util.random_csr(n, p, 4, seed=21, empty_rows=True)
+    y = util.labels(n, 21)
+    w0, w, v = util.params(p, k, seed=21, stdev=0.3, fp32=False)
+    lr, l1w, l1v = 0.05, 0.02, 0.01   # large enough that coordinates are clipped to exactly zero along the way
+    P = oracle.params(k=k, learn_rate=lr, l1_regw=l1w, l1_regv=l1v, l2_regw=0.5, l2_regv=0.5)  # (any L1 > 0 drops L2: SGD_Learner.h:46-51)
+    X = oracle.Matrix(rp, col, val, p)
+    mb = oracle.SgdMinibatch(P, X, y, w0, w, v.ravel())   # batch size 1 == the reference's example step (test_minibatch_semantics_...)
+    rw0, rw, rv = w0, w.copy(), v.copy()
+    qw, qv, uw, uv = np.zeros(p), np.zeros((k, p)), 0.0, 0.0
+    h = 1e-6
+    zeros_seen = 0
+    for i in range(n):
+        c = col[rp[i]:rp[i + 1]].astype(int); x = val[rp[i]:rp[i + 1]].astype(np.float64)
+        uw += lr * l1w; uv += lr * l1v
+        f = lambda a, b, d: _loss(oracle.CLASSIFICATION, _pairwise_forward(a, b, d, c, x), float(y[i]))
+        g0 = (f(rw0 + h, rw, rv) - f(rw0 - h, rw, rv)) / (2 * h)
+        gw = {}; gv = {}
+        for j in c.tolist():
+            wp, wm = rw.copy(), rw.copy(); wp[j] += h; wm[j] -= h
+            gw[j] = (f(rw0, wp, rv) - f(rw0, wm, rv)) / (2 * h)
+            for fc in range(k):
+                vp, vm = rv.copy(), rv.copy(); vp[fc, j] += h; vm[fc, j] -= h
+                gv[(fc, j)] = (f(rw0, rw, vp) - f(rw0, rw, vm)) / (2 * h)
+        rw0 = rw0 - lr * g0
+        for j in c.tolist():
+            half = rw[j] - lr * gw[j]
+            rw[j], qw[j] = _tsuruoka_clip(half, uw, qw[j])
+            assert rw[j] == 0.0 or np.sign(rw[j]) == np.sign(half)       # the penalty stops at zero
+            for fc in range(k):
+                half = rv[fc, j] - lr * gv[(fc, j)]
+                rv[fc, j], qv[fc, j] = _tsuruoka_clip(half, uv, qv[fc, j])
+        before_w, before_v = mb.w.copy(), mb.v.copy()
+        mb.step(i, i + 1)
+        untouched = np.setdiff1d(np.arange(p), c)
+        assert np.array_equal(mb.w[untouched], before_w[untouched]) and np.array_equal(mb.v.reshape(k, p)[:, untouched], before_v.reshape(k, p)[:, untouched])
+        assert abs(mb.w0.value - rw0) < 1e-9
+        np.testing.assert_allclose(mb.w, rw, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(mb.v.reshape(k, p), rv, rtol=0, atol=1e-9)
+        # Tsuruoka's invariant: the penalty a coordinate has received in total never exceeds the budget
+        assert np.all(np.abs(mb.q_w) <= mb.u[0] * (1 + 1e-12)) and np.all(np.abs(mb.q_v) <= mb.u[1] * (1 + 1e-12))
+        assert abs(mb.u[0] - uw) < 1e-15 and abs(mb.u[1] - uv) < 1e-15
+        zeros_seen += int(np.sum(mb.w[c] == 0.0)) + int(np.sum(mb.v.reshape(k, p)[:, c] == 0.0))
+        # resynchronise the reference statement (finite-difference error must not accumulate into a different clipping decision)
+        rw0, rw, rv = mb.w0.value, mb.w.copy(), mb.v.reshape(k, p).copy()
+        qw, qv = mb.q_w.copy(), mb.q_v.reshape(k, p).copy()
+    assert zeros_seen > 50   # the clipping branch was exercised, not just the shrinkage
+
+
+def test_regression_multiplier_is_the_derivative_of_the_linearly_extended_squared_loss():
+    """calculate_grad_mult, REGRESSION (SGD_Learner.h:183-186): y_hat is clamped to [min_target, max_target] BEFORE the residual.  That is the
+    derivative of phi(y_hat) = 1/2 (y - y_hat)^2 inside the range, continued LINEARLY (C^1) outside it -- checked by central differences of phi
+    on both sides of both clamps and across them, and through a whole example step whose forward lies beyond the clamp."""
+    lo, hi = -0.75, 1.25
+    P = oracle.params(task=oracle.REGRESSION, k=2, min_target=lo, max_target=hi, learn_rate=0.1)
+
+    def phi(yh, y):
+        c = min(max(yh, lo), hi)
+        return 0.5 * (y - c) ** 2 + (c - y) * (yh - c)      # the tangent at the clamp point outside the range; plain squared loss inside
+
+    h = 1e-6
+    for y in (-2.0, -0.75, 0.1, 1.25, 3.0):
+        y = float(np.float32(y))      # targets are fp32 in the reference (util/Dvector.h:89-99)
+        for yh in (-5.0, lo - 1e-3, lo + 1e-3, 0.0, 0.3, hi - 1e-3, hi + 1e-3, 7.0):
+            fd = (phi(yh + h, y) - phi(yh - h, y)) / (2 * h)
+            assert abs(oracle.grad_mult(P, yh, y)[0] - fd) < 1e-8, (y, yh)
+        # outside the range the multiplier is CONSTANT (the value at the clamp), and continuous across the clamp
+        assert oracle.grad_mult(P, hi + 10, y)[0] == oracle.grad_mult(P, hi, y)[0] == -(y - hi)
+        assert oracle.grad_mult(P, lo - 10, y)[0] == oracle.grad_mult(P, lo, y)[0] == -(y - lo)
+    # one example step with the forward far above the clamp: every coordinate moves by lr * (hi - y) * d y_hat / d theta
+    p, k = 6, 2
+    rp = np.array([0, 0, 3], np.int64); col = np.array([0, 2, 5], np.uint32); val = np.array([1.5, -2.0, 0.5], np.float32)
+    yy = np.array([0.0, 0.4], np.float32)
+    w0, w, v = 4.0, np.linspace(-0.2, 0.3, p), np.random.default_rng(5).normal(0, 0.3, (k, p))
+    X = oracle.Matrix(rp, col, val, p)
+    c = col.astype(int); x = val.astype(np.float64)
+    assert _pairwise_forward(w0, w, v, c, x) > hi + 1.0
+    ref = oracle.sgd_learn(P, X, yy, w0, w, v.ravel(), 1, order=np.array([1]))
+    mult = hi - float(np.float32(0.4))
+    f = lambda a, b, d: _pairwise_forward(a, b, d, c, x)
+    assert abs(ref["w0"] - (w0 - 0.1 * mult)) < 1e-12
+    for j in c.tolist():
+        wp, wm = w.copy(), w.copy(); wp[j] += h; wm[j] -= h
+        assert abs(ref["w"][j] - (w[j] - 0.1 * mult * (f(w0, wp, v) - f(w0, wm, v)) / (2 * h))) < 1e-8
+        for fc in range(k):
+            vp, vm = v.copy(), v.copy(); vp[fc, j] += h; vm[fc, j] -= h
+            assert abs(ref["v"].reshape(k, p)[fc, j] - (v[fc, j] - 0.1 * mult * (f(w0, w, vp) - f(w0, w, vm)) / (2 * h))) < 1e-8
+
+
+# glibc's rand() (TYPE_3 additive feedback generator, r[i] = r[i-3] + r[i-31]) after srand(1): the sequence every glibc prints,
+# e.g. in the rand(3) discussion of "1804289383" as the first value of an unseeded program
+GLIBC_RAND_SEED1 = [1804289383, 846930886, 1681692777, 1714636915, 1957747793, 424238335, 719885386, 1649760492, 596516649, 1189641421]
+
+
+def test_random_select_on_glibc_rand_known_values():
+    """util/Random.h:20-24,126-132: random_select(n) = (uint)(rand() / (RAND_MAX + 1.0) * n + 1), n == 1 -> 1 without a draw; the strides of
+    SGD_Learner.h:86-88 come from libc rand(), which the reference never seeds (SURVEY A-4) -- glibc then behaves as after srand(1).  Pinned to
+    glibc's published first values (RAND_MAX = 2^31 - 1), not to anything the oracle computes."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    L = oracle.lib()
+    for n in (2, 7, 1000, 2_000_000_000):      # (random_select takes an int: Random.h:126)
+        L.fmo_srand(C.c_uint(1))
+        got = [int(L.fmo_random_select(C.c_uint32(n))) for _ in GLIBC_RAND_SEED1]
+        want = [int(r / 2147483648.0 * n + 1) for r in GLIBC_RAND_SEED1]
+        assert got == want and all(1 <= g <= n for g in got)
+    L.fmo_srand(C.c_uint(1))
+    assert [int(L.fmo_random_select(C.c_uint32(1))) for _ in range(3)] == [1, 1, 1]
+    assert int(L.fmo_random_select(C.c_uint32(1000))) == int(GLIBC_RAND_SEED1[0] / 2147483648.0 * 1000 + 1)   # n == 1 consumed no draw
+    # the visiting order with random_step = 3 walks those strides (i = first stride; i += stride; wrap by restarting, :86-88,:168-176)
+    order = oracle.visit_order(50, 3, 8, seed=1)
+    strides = [int(r / 2147483648.0 * 3 + 1) for r in GLIBC_RAND_SEED1]
+    assert order[0] == strides[0] and list(np.diff(order)[:3]) == strides[1:4]
+    # a process that never calls srand() gets the same stream (the reference's situation)
+    code = ("import ctypes as C, oracle; L = oracle.lib(); "
+            "print([int(L.fmo_random_select(C.c_uint32(1000))) for _ in range(5)])")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    assert eval(out.stdout.strip()) == [int(r / 2147483648.0 * 1000 + 1) for r in GLIBC_RAND_SEED1[:5]]
+
+
+def test_mcmc_hyper_draws_follow_the_published_conditional_posteriors():
+    """MCMC_ALS_Learner.h:359-517 against the conditional posteriors of Rendle, "Factorization Machines with libFM" (ACM TIST 2012, sec. 4.3,
+    hyper-parameters alpha_0 = beta_0 = gamma_0 = 1, mu_0 = 0 as init() sets them), stated in numpy/scipy:
+        alpha    ~ Gamma((alpha_0 + n) / 2, rate (gamma_0 + sum e^2) / 2)
+        lambda   ~ Gamma((alpha_0 + p + 1) / 2, rate (gamma_0 + sum (theta - mu)^2 + beta_0 (mu - mu_0)^2) / 2)
+        mu       ~ N((sum theta + beta_0 mu_0) / (p + beta_0), 1 / ((p + beta_0) lambda))
+    The library takes STANDARD variates from the caller (R's generator is not its to call), so each draw is a map of the caller's variate:
+    the map is checked exactly (to 1e-12) and the resulting samples against the posterior's moments and a Kolmogorov-Smirnov test.  The
+    shipped update_v_mu sums v(f, attr_group[i]) = v(f, 0) instead of v(f, i) (SURVEY A-8): asserted as shipped, and shown to be the ONLY
+    deviation from the published mean."""
+    from scipy import stats
+    rng = np.random.default_rng(77)
+    p, S = 40, 6000
+    row = rng.normal(0.05, 0.2, p)
+    v = np.tile(row, (S, 1))                      # S "factors" with the same coordinates: S draws from one posterior
+    shape = (1.0 + p + 1.0) / 2.0
+    G = rng.gamma(shape, 1.0, S); Z = rng.normal(0, 1, S)
+    mu_in = 0.03
+    lam, mu = oracle.mcmc_v_hyper(S, p, v.ravel(), G, Z, np.ones(S), np.full(S, mu_in))
+    rate = (1.0 + np.sum((row - mu_in) ** 2) + 1.0 * (mu_in - 0.0) ** 2) / 2.0
+    np.testing.assert_allclose(lam, G / rate, rtol=1e-12)
+    assert abs(lam.mean() - shape / rate) < 5 * np.sqrt(shape) / rate / np.sqrt(S)
+    assert abs(lam.var() - shape / rate ** 2) < 0.15 * shape / rate ** 2
+    assert stats.kstest(lam, "gamma", args=(shape, 0, 1.0 / rate)).pvalue > 1e-3
+    shipped_mean = (p * row[0] + 0.0) / (p + 1.0)                 # A-8: p times v(f, 0)
+    published_mean = (row.sum() + 0.0) / (p + 1.0)
+    assert abs(shipped_mean - published_mean) > 1e-3
+    zs = (mu - shipped_mean) * np.sqrt((p + 1.0) * lam)           # standardised with each draw's own lambda
+    np.testing.assert_allclose(zs, Z, rtol=0, atol=1e-9)
+    assert stats.kstest(zs, "norm").pvalue > 1e-3
+    # the ALS learner's form (sample = 0) takes the posterior means
+    lam0, mu0 = oracle.mcmc_v_hyper(2, p, v[:2].ravel(), None, None, np.ones(2), np.full(2, mu_in), sample=False)
+    np.testing.assert_allclose(lam0, shape / rate, rtol=1e-12)
+    np.testing.assert_allclose(mu0, shipped_mean, rtol=1e-12)
+    # alpha, w_lambda, w_mu: one iteration of the MCMC learner on a small regression problem, many variate sets
+    n, pp, k = 60, 12, 2
+    rp, col, val = util.random_csr(n, pp, 4, seed=31, empty_rows=False)
+    y = util.labels(n, 31, "regression")
+    w0, w, vv = util.params(pp, k, 31, stdev=0.2, fp32=False)
+    X = oracle.Matrix(rp, col, val, pp)
+    P = oracle.params(task=oracle.REGRESSION, k=k, min_target=-1e9, max_target=1e9)
+    e = np.array([_pairwise_forward(w0, w, vv, col[rp[i]:rp[i + 1]].astype(int), val[rp[i]:rp[i + 1]].astype(np.float64)) for i in range(n)]) - y.astype(np.float64)
+    sa, sl = oracle.mcmc_draw_shapes(n, pp)
+    assert (sa, sl) == ((1.0 + n) / 2.0, (1.0 + pp + 1.0) / 2.0)
+    T = 400
+    alphas, lams, zmu = np.zeros(T), np.zeros(T), np.zeros(T)
+    for t in range(T):
+        g = np.array([[rng.gamma(sa), rng.gamma(sl)]]); z = rng.normal(0, 1, (1, 2 + pp))
+        _, _, _, (alpha, w_lambda, w_mu) = oracle.mcmc_learn(P, X, y, w0, w, vv.ravel(), 1, g, z)
+        rate_a = (1.0 + float(np.dot(e, e))) / 2.0
+        assert abs(alpha - g[0, 0] / rate_a) < 1e-10 * alpha
+        rate_l = (1.0 + float(np.sum((w - 0.0) ** 2)) + 0.0) / 2.0          # w_mu = 0 and mu_0 = 0 on entry
+        assert abs(w_lambda - g[0, 1] / rate_l) < 1e-10 * w_lambda
+        m = (w.sum() + 0.0) / (pp + 1.0)
+        assert abs(w_mu - (m + z[0, 1] / np.sqrt((pp + 1.0) * w_lambda))) < 1e-10
+        alphas[t], lams[t], zmu[t] = alpha, w_lambda, (w_mu - m) * np.sqrt((pp + 1.0) * w_lambda)
+    assert stats.kstest(alphas, "gamma", args=(sa, 0, 1.0 / rate_a)).pvalue > 1e-3
+    assert stats.kstest(lams, "gamma", args=(sl, 0, 1.0 / rate_l)).pvalue > 1e-3
+    assert stats.kstest(zmu, "norm").pvalue > 1e-3
