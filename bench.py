@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -73,14 +73,19 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (0: skip; -1: 5M for sgd, 250K for ftrl k=64: 10-20 s of one core either way)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (fp64 state, small batches, sequential mode, ceilings)")
-    a = ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default line (configs[1], one GPU) also carries `other_configs`: short runs of configs[2], configs[3] (rows resident and streamed) and configs[4] "
+                         "in the same process, each with its value, kernel fractions and a small CPU sample; this flag leaves them out")
+    a = ap.parse_args(argv)
     if a.workload == "criteo":
         a.features, a.nnz = 33_000_000, 39
         a.factors = a.factors or 32
         a.batch_rows = a.batch_rows or 262_144
         if a.rows == 10_000_000:
             a.rows = 8_000_000 * a.gpus
-        a.no_extras, a.cpu_rows = True, 0
+        a.no_extras = True
+        if a.cpu_rows < 0:
+            a.cpu_rows = 0
     if a.solver in ("als", "mcmc"):
         a.factors = a.factors or 16
         if a.steps == 40 and a.warmup == 5:   # the defaults are sized for 0.3 ms steps; a sweep of 16 factors over 3e8 entries is ~0.2 s
@@ -148,6 +153,30 @@ def pmc_traffic(kernel, args):
     return best
 
 
+def pmc_traffic_sweep(args, tiled):
+    """configs[4]: HBM-side bytes of one level of one factor from the committed PMC summaries (profiles/r*_pmc_summary_mcmc*.json), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_mcmc*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        a = d.get("_bench_args", [])
+        if ("als" in a) != (args.solver == "als") or args.rows != 10_000_000 or args.features != 1_000_000:
+            continue
+        names = ("als_tile_sums", "als_tile_step", "als_rows_apply") if tiled else ("als_level",)
+        if all(nm in d and "traffic_bytes_per_launch" in d[nm] for nm in names) and (("als_level" in d) != tiled):
+            best = (sum(d[nm]["traffic_bytes_per_launch"] for nm in names), os.path.basename(f))
+    return best
+
+
+def e_unit(m):
+    """every stored value of the matrix is 1.0 (one-hot rows: the kernels never read the value arrays)"""
+    _, _, val, _ = m.export(0, min(m.n, 1024))
+    return bool(np.all(val == 1.0))
+
+
 def host_cpu_share():
     """Cores this process may really use: affinity mask, cgroup quota, and at most 16 (a one-GPU box's CPU share)."""
     n = len(os.sched_getaffinity(0))
@@ -165,7 +194,16 @@ def cpu_baseline(m, args, v0):
     import oracle
     n = min(args.cpu_rows, m.n)
     rp, col, val, y = m.export(0, n)
-    X = oracle.Matrix(rp, col, val, args.features)
+    p_cpu, remap_note = args.features, ""
+    if args.features > 4_000_000:
+        # configs[3]'s shape: the reference's dense k x p fp64 table would be 8.4 GB of host memory for a sample that touches a fraction of it.  The
+        # sample's columns are renumbered onto the features that occur in it (order kept: the same work per example, a smaller table -- friendlier to the
+        # CPU's caches than the real one)
+        uniq, inv = np.unique(col, return_inverse=True)
+        col, p_cpu = inv.astype(np.uint32), int(len(uniq))
+        remap_note = f"; columns renumbered onto the {p_cpu} features the sample touches"
+        v0 = np.random.default_rng(args.seed).normal(0.0, 0.01, (args.factors, p_cpu)).astype(np.float32)
+    X = oracle.Matrix(rp, col, val, p_cpu)
     if args.solver in ("als", "mcmc"):   # configs[4]: one reference-order update_v sweep (MCMC_ALS_Learner.h:272-354) over a row sample
         k, p, gibbs = args.factors, args.features, args.solver == "mcmc"
         vv = np.random.default_rng(args.seed).normal(0.0, 0.01, (k, p))
@@ -181,7 +219,7 @@ def cpu_baseline(m, args, v0):
         P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
     else:
         P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l1_regw=1e-4, l1_regv=1e-4, l2_regw=1e-4, l2_regv=1e-4)
-    w = np.zeros(args.features)
+    w = np.zeros(p_cpu)
     v = np.ascontiguousarray(v0.astype(np.float64))  # [k][p] factor-major, the reference's layout
     oracle.lib()
     t0 = time.perf_counter()
@@ -191,13 +229,13 @@ def cpu_baseline(m, args, v0):
         done = oracle.ftrl_learn(P, X, y, 0.0, w, v.ravel(), n - 1)["iters"]
     dt = time.perf_counter() - t0
     out = {"value": done / dt, "unit": "examples/s", "cores": 1, "kind": "port",
-           "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial {args.solver.upper()} pass ({dt:.1f} s)"}
-    if args.solver != "sgd":
+           "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial {args.solver.upper()} pass ({dt:.1f} s){remap_note}"}
+    if args.solver != "sgd" or remap_note or getattr(args, "cpu_one_core_only", False):
         return out
     # SURVEY 8(d) item ii, reported beside it: what all host cores give.  The reference has no parallel training, so the
     # yardstick is its example step run lock-free over row ranges (Hogwild); its forward is OpenMP over rows as shipped.
     threads = min(oracle.omp_threads(), host_cpu_share())
-    w = np.zeros(args.features)
+    w = np.zeros(p_cpu)
     v = np.ascontiguousarray(v0.astype(np.float64))
     t0 = time.perf_counter()
     done = oracle.omp_sgd_hogwild(P, X, y, 0.0, w, v.ravel(), threads)
@@ -288,10 +326,14 @@ def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_
         e2.step(m2, b)
     e2.sync()
     t_all = time.perf_counter() - t0
-    out["end_to_end"] = {"measured": True, "plan_build_s": t_plan, "plan_and_one_pass_s": t_all, "one_epoch_examples_per_s": n / t_all,
-                         "two_epochs_examples_per_s": 2 * n / (t_all + n / value), "first_plan_build_s_of_the_bench_matrix": csc_build_s,
-                         "note": "wall clock around the per-tile plan build of the 10 M-row matrix (device radix sort, once per matrix) plus ONE pass over all its rows, "
-                                 "the last ragged step and phase 1's 14 schedule-trial launches included; two passes = that + n / value"}
+    for b in range(nb2):           # the reference's default run is two passes (R/fm_train.R:92): the second one, on the same clock
+        e2.step(m2, b)
+    e2.sync()
+    t_two = time.perf_counter() - t0
+    out["end_to_end"] = {"measured": True, "plan_build_s": t_plan, "plan_and_one_pass_s": t_all, "plan_and_two_passes_s": t_two, "one_epoch_examples_per_s": n / t_all,
+                         "two_epochs_examples_per_s": 2 * n / t_two, "first_plan_build_s_of_the_bench_matrix": csc_build_s,
+                         "note": "wall clock around the per-tile plan build of the 10 M-row matrix (device sort, once per matrix) plus one pass, and plus TWO passes, over all its "
+                                 "rows -- the last ragged step and phase 1's 14 schedule-trial launches included; every figure is a measured interval of one clock"}
     e2.close(); m2.close()
     # SURVEY 8(d)'s column law: i.i.d. uniform columns, sorted inside the row (the headline matrix draws one column per stratum)
     mi = engine.Matrix.synthetic_iid(n, p, z, args.seed)
@@ -399,40 +441,57 @@ def main_sweep(args, rank, local_rank, world):
     if not np.isfinite(ss1) or (not gibbs and not ss1 < ss0):
         raise SystemExit(f"the sweeps did not reduce the residual: {ss0} -> {ss1}")
     if rank != 0:
-        return
+        return None
     nnz = n * z
     lvl_ms, lvl_n = e.profile_get(L.KERNEL_ALS_SWEEP)
     fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
     per_launch_ms = lvl_ms / max(lvl_n, 1)
     launches = levels * k
-    b_launch = 40.0 * nnz / levels               # 40 B per stored nonzero per factor; one launch = one level of one factor
+    tiled, tile_rows, n_tiles = e.als_tiled(m)
+    b_launch = 40.0 * nnz / levels               # 40 B per stored nonzero per factor; one unit = one level of one factor
     gbs = b_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
     step_gbs = 40.0 * nnz * k / (dt / args.steps) / 1e9
+    form = (f"row-tiled: als_tile_sums_k ({n_tiles} tiles of {tile_rows} rows, each tile's (q, e) slice gathered from its XCD's L2) + als_tile_step_k + als_rows_apply_k (row-major corrections)"
+            if tiled else "als_level_k (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q, e) per entry)")
     out = {
         "metric": "V-sweep examples/sec, 10Mx1M sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
         "value": world * n * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {n}x{p}, {z} nnz/row, k={k}, {'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
                                f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
-                   "levels": levels, "largest_level": largest, "approximate": bool(approx), "launches_per_step": launches,
+                   "levels": levels, "largest_level": largest, "approximate": bool(approx), "levels_per_step": launches, "levels_row_tiled": tiled,
                    "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
                    "parallelism": f"replicas{world}" if world > 1 else "dp1"},
-        "roofline": {"bound": "hbm", "kernel": "als_level_k (one level of one factor)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "one level of one factor: " + form, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": per_launch_ms, "timed_launches": lvl_n,
                      "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
-                              "note": "40 B x nnz x k over the whole sweep's wall time (includes the one forward pass that builds q for all factors and the per-factor q picks)"},
+                              "note": "40 B x nnz x k over the whole sweep's wall time (includes the one forward pass that builds q for all factors)"},
                      "q_build_forward_ms": fwd_ms / max(fwd_n, 1) if fwd_n else None},
     }
+    tr = pmc_traffic_sweep(args, bool(tiled))
+    if tr:
+        out["roofline"]["traffic"] = tr[0]
+        out["roofline"]["traffic_source"] = f"profiles/{tr[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB summed over the launches of one level, separate --pmc passes; upper bound, DESIGN.md section 6"
+    if tiled:
+        # what the three passes of a level have to move (design bytes): sums: (q, e) 16 + list entry 4 (+4 value) per nonzero, the per-tile sums out;
+        # step: the per-tile sums in; corrections: level-major index 4 (+4 value), (q, e) 16 in and 16 out per row
+        per_level_feats = largest
+        vb = 0 if e_unit(m) else 4
+        design = (nnz / levels) * (16 + 4 + vb) + 2 * n_tiles * per_level_feats * 16 + n * (4 + vb + 32)
+        out["roofline"]["design_bytes_per_launch"] = design
+        out["roofline"]["design_frac"] = design / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if per_launch_ms > 0 else None
     if not args.no_extras:
-        # the access pattern's own ceiling: random 16-byte (q, e) pairs from the n-row table; a level reads AND writes one per entry
+        # the untiled form's ceiling: random 16-byte (q, e) pairs from the n-row table; als_level_k reads AND writes one per entry.  The tiled form leaves
+        # that ceiling behind (its gathers hit the XCD's L2): entries per second over the SAME figure shows by how much
         r = engine.measure_gather(n * 16, 16, n_groups=262_144, per_group=64, in_flight=4, reps=20, device=local_rank)
         got = (nnz / levels) / (per_launch_ms * 1e-3) if per_launch_ms > 0 else 0.0
         out["roofline"]["gather_ceiling"] = {"table_MB": n * 16 / 1e6, "row_bytes": 16, "ceiling_rows_per_s": r, "kernel_entries_per_s": got,
                                              "ceiling_frac": got / r if r else None,
-                                             "note": "entries per second of als_level_k (each entry: one 16-B gather and one 16-B scatter of its row's (q, e)) over the measured rate of random 16-B gathers"}
+                                             "note": "entries per second of a level over the measured rate of random 16-B gathers from the whole (q, e) table (the untiled form does a gather AND a scatter "
+                                                     "per entry against it: at most 0.5; the row-tiled form gathers from L2-resident slices and is not bound by it)"}
     if args.cpu_rows > 0:
         out["cpu_baseline"] = cpu_baseline(m, args, None)
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def main_stream(args, rank, local_rank, world):
@@ -498,12 +557,12 @@ def main_stream(args, rank, local_rank, world):
     elif dp is not None:
         moved = {"bytes_received_per_step_per_rank": dp.last_exchange_bytes}
     if rank != 0:
-        return
+        return None
     fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
     upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
     b_step = algorithmic_bytes(z, k, p, B, 4, False)[2]
     step_gbs = b_step / (dt / args.steps) / 1e9
-    print(json.dumps({
+    return ({
         "metric": "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD, streamed (configs[3])",
         "value": B * world * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -516,7 +575,7 @@ def main_stream(args, rank, local_rank, world):
                      "frac": step_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_example": b_step / B,
                      "kernels": {"fm_rows_forward": {"avg_launch_ms": fwd_ms / max(fwd_n, 1)}, "fm_cols_update": {"avg_launch_ms": upd_ms / max(upd_n, 1)}},
                      "note": "per GPU: SURVEY 8(d) step bytes over the wall time of a streamed global step (ingest and exchange included)"},
-    }), flush=True)
+    })
 
 
 def main_in_library(args):
@@ -550,19 +609,69 @@ def main_in_library(args):
         raise SystemExit("non-finite parameters after the timed region")
     b_step = algorithmic_bytes(z, k, p, B, 4, ftrl)[2]
     step_gbs = b_step / (dt / args.steps) / 1e9
-    print(json.dumps({
+    ginfo = e.group_info()
+    return ({
         "metric": "training examples/sec, 10Mx1M sparse FM SGD" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
         "value": done / dt, "unit": "examples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch (BASELINE.json configs[{3 if criteo else (2 if ftrl else 1)}]{' shape, resident rows' if criteo else ''})",
                    "driver": "in-library: one process, cfg.n_gpus replicas behind one C-ABI handle (fm_group.hip)" + (" on ONE device (rehearsal)" if share and N > 1 else ""),
                    "batch_rows_per_gpu": B, "global_batch_rows": per_step, "parallelism": f"dp{N}",
-                   **({"exchange": (os.environ.get("FMX_GROUP_EXCHANGE") or ("owner-sharded (peer copies of owner-major slices) where the steps are sparse tiles, the dense "
-                                                                             "all-reduce otherwise"))} if N > 1 else {})},
+                   **({"exchange": (os.environ.get("FMX_GROUP_EXCHANGE") or ("steps of one sparse tile: " + ("owner-sharded (peer copies of owner-major slices)" if ginfo["sparse_exchange"] == "owner"
+                                                                                                           else "all-gather of the occurring features' records") + "; the dense all-reduce otherwise"))} if N > 1 else {})},
         "roofline": {"bound": "hbm", "kernel": "step = fm_rows_forward + fm_cols_update per tile", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": step_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_example": b_step / B,
                      "note": "per GPU, SURVEY 8(d) bytes over the wall time of a global step (exchange included for N > 1)"},
-    }), flush=True)
+        "group": ginfo,
+    })
+
+
+def compact_line(d):
+    """what `other_configs` keeps of a full bench line"""
+    if d is None:
+        return None
+    r = d.get("roofline", {})
+    keep = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
+            "workload": d["config"]["workload"],
+            "roofline": {kk: r[kk] for kk in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_note", "survey_priced_frac", "design_frac", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                                              "algorithmic_bytes_per_example", "traffic") if kk in r}}
+    if "kernels" in r:
+        keep["roofline"]["kernels"] = {name: {kk: v[kk] for kk in ("avg_launch_ms", "frac", "ceiling_frac", "hbm_priced_frac", "traffic") if kk in v} for name, v in r["kernels"].items()}
+    if "gather_ceiling" in r:
+        keep["roofline"]["ceiling_frac"] = r["gather_ceiling"].get("ceiling_frac")
+    for kk in ("cpu_baseline", "forward_rows_per_s"):
+        if kk in d:
+            keep[kk] = d[kk]
+    for kk in ("batch_rows_per_gpu", "tile_rows", "features_occurring_per_step", "levels", "levels_row_tiled", "ingest_wait_s"):
+        if kk in d["config"]:
+            keep[kk] = d["config"][kk]
+    return keep
+
+
+def other_configs(args):
+    """BASELINE.json configs[2], [3] (rows resident and streamed) and [4], each run here, in this process, right after the headline line -- the driver's
+    command (`bench.py --gpus 1 --steps K --warmup W`) witnesses all five configs.  Same code paths as `bench.py --solver ftrl`,
+    `--workload criteo [--stream]`, `--solver mcmc`; the GPU shapes are the configs' own, only the step counts and the CPU samples are short."""
+    out = {}
+    runs = [
+        ("configs[2]", ["--solver", "ftrl", "--no-extras", "--steps", "16", "--warmup", "2", "--cpu-rows", "60000"], run_minibatch),
+        ("configs[3]_resident", ["--workload", "criteo", "--steps", "30", "--warmup", "3", "--cpu-rows", "120000"], run_minibatch),
+        ("configs[3]_streamed", ["--workload", "criteo", "--stream", "--steps", "30", "--warmup", "3"], main_stream),
+        ("configs[4]", ["--solver", "mcmc", "--no-extras", "--steps", "4", "--warmup", "1", "--cpu-rows", "1000000"], main_sweep),
+    ]
+    for name, argv, fn in runs:
+        t0 = time.perf_counter()
+        try:
+            a = parse(argv + ["--seed", str(args.seed), "--no-other-configs"])
+            a.cpu_one_core_only = True
+            line = fn(a, 0, 0, 1)
+            out[name] = compact_line(line)
+            out[name]["wall_s"] = time.perf_counter() - t0
+        except BaseException as ex:   # a failing side run must not take the headline line with it
+            out[name] = {"error": f"{type(ex).__name__}: {ex}"}
+    if "configs[3]_streamed" in out and "configs[3]_resident" in out and "cpu_baseline" in out["configs[3]_resident"] and "error" not in out["configs[3]_streamed"]:
+        out["configs[3]_streamed"]["cpu_baseline"] = dict(out["configs[3]_resident"]["cpu_baseline"], note="the resident line's sample: the same workload")
+    return out
 
 
 def main():
@@ -573,7 +682,8 @@ def main():
     if args.in_library:
         if world != 1:
             raise SystemExit("--in-library is one process for all GPUs: start it without torch.distributed.run")
-        return main_in_library(args)
+        print(json.dumps(main_in_library(args)), flush=True)
+        return
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU), or pass --in-library")
@@ -581,8 +691,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from fmwr_amd import _lib as L
-    from fmwr_amd import engine
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -599,11 +707,25 @@ def main():
     if args.solver in ("als", "mcmc") or args.stream:
         if args.stream and args.workload != "criteo":
             raise SystemExit("--stream needs --workload criteo")
-        (main_stream if args.stream else main_sweep)(args, rank, local_rank, world)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        out = (main_stream if args.stream else main_sweep)(args, rank, local_rank, world)
+    else:
+        out = run_minibatch(args, rank, local_rank, world)
+        headline = args.solver == "sgd" and args.workload == "uniform" and world == 1 and not args.state_fp64
+        if out is not None and headline and not args.no_other_configs and not args.no_extras:
+            out["other_configs"] = other_configs(args)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_minibatch(args, rank, local_rank, world):
+    """configs[1] / [2] / [3] with resident rows: synchronous mini-batch steps; returns rank 0's line (None on the other ranks)."""
+    import torch
+    import torch.distributed as dist
+    from fmwr_amd import _lib as L
+    from fmwr_amd import engine
     z, k, p = args.nnz, args.factors, args.features
     ftrl = args.solver == "ftrl"
     from fmwr_amd.distributed import DataParallel, EngineStepper, shard_rows
@@ -788,10 +910,8 @@ def main():
             out.update(side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows))
         if world == 1 and args.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(m, args, v0)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -28,9 +28,13 @@ SYMBOLS = [
     "fmx_als_plan_info", "fmx_als_tiled_info", "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_mcmc_train", "fmx_mcmc_train_from", "fmx_mcmc_v_hyper", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset", "fmx_rows_tune_info", "fmx_measure_gather", "fmx_measure_gather_occ", "fmx_measure_gather_matrix", "fmx_rccl_selftest",
     "fmx_get_rows", "fmx_set_rows", "fmx_init_normal", "fmx_compact_info", "fmx_compact_count", "fmx_compact_reserve", "fmx_grad_compact", "fmx_compact_records", "fmx_apply_compact",
-    "fmx_debug_fail_next_plan_build", "fmx_vsweep_device", "fmx_source_open", "fmx_source_next", "fmx_source_close",
+    "fmx_vsweep_device", "fmx_group_info", "fmx_source_open", "fmx_source_next", "fmx_source_close",
     "fmx_apply_compact_parts", "fmx_layout_info", "fmx_owner_configure", "fmx_owner_info", "fmx_rows_pack", "fmx_rows_unpack",
 ]
+
+
+# fmwr_amd/csrc/fmx_test_hooks.h: exported for the GPU tests, not part of the C ABI
+TEST_HOOKS = ["fmx_debug_fail_next_plan_build", "fmx_debug_fail_next_comm_init"]
 
 
 class Config(C.Structure):
@@ -75,7 +79,7 @@ def lib():
                               "fmwr_amd has no CPU fallback.")
         L = C.CDLL(LIB_PATH)
         L.fmx_last_error.restype = C.c_char_p
-        for name in SYMBOLS:
+        for name in SYMBOLS + TEST_HOOKS:
             if name != "fmx_last_error":
                 getattr(L, name).restype = C.c_int
         _lib = L

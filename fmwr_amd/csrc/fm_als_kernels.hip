@@ -123,10 +123,11 @@ __global__ void als_q_init_k(const int64_t* __restrict__ row_ptr, const uint32_t
   qe[r].x = acc;
 }
 
-// q of factor f out of the all-factor table Q[n][kp] (one strided read per row instead of a gather per nonzero)
-__global__ void als_q_pick_k(const double* __restrict__ Q, int kp, int f, int64_t n, double2* __restrict__ qe) {
+// q of factor f out of the all-factor table, kept FACTOR-major (Q[kp][n]: one coalesced 8-byte read per row; the row-major table of rounds 1-3
+// cost a 128-byte line per row and factor: 1.28 GB read per pick at configs[4], 0.30 ms x 16)
+__global__ void als_q_pick_k(const double* __restrict__ Qf, int64_t n, double2* __restrict__ qe) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) qe[r].x = Q[(size_t)r * kp + f];
+  if (r < n) { const double2 c = qe[r]; qe[r] = make_double2(Qf[r], c.y); }
 }
 
 __global__ void als_pack_k(const double* __restrict__ err, int64_t n, double2* __restrict__ qe) {
@@ -767,7 +768,10 @@ static void sweep_features(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2*
     if (profile) prof_begin(e, FMX_KERNEL_ALS_SWEEP);  // one level (or group) of one factor: the unit bench.py --solver als prices
     if (!m->als_approx && m->als_tiled) {
       bool done = false;
-      if (als_tiled_level<W>(e, m, l, d_qe, dyn, &done) == FMX_OK && done) continue;
+      bool last = true;   // no later level of this sweep holds a feature?
+      for (int l2 = l + 1; l2 < L && last; ++l2)
+        last = lp[(size_t)l2 + 1] - lp[(size_t)l2] + hp[(size_t)l2 + 1] - hp[(size_t)l2] + (m->als_vh_ptr.empty() ? 0 : m->als_vh_ptr[(size_t)l2 + 1] - m->als_vh_ptr[(size_t)l2]) == 0;
+      if (als_tiled_level<W>(e, m, l, last, d_qe, dyn, &done) == FMX_OK && done) continue;
     }
     if (!m->als_approx) {
       if (cnt > 0) {
@@ -949,18 +953,27 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
   if (d_Q) {
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
-    a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.link = FMX_LINK_NONE;
+    a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.qout_t = m->n; a.link = FMX_LINK_NONE;
     a.unit = m->unit_values;
     if (launch_rows_forward(e, a, false, true) != FMX_OK) d_Q = nullptr;
   }
+  bool picked = false;   // the previous factor's last correction pass already stored this factor's q (tiled form)
+  e->als_vf_slot = -1;
   for (int f = 0; f < e->k; ++f) {
-    if (d_Q) hipLaunchKernelGGL(als_q_pick_k, dim3(row_grid), dim3(256), 0, e->stream, d_Q, e->kp64, f, m->n, d_qe);
+    if (picked) {}
+    else if (d_Q) hipLaunchKernelGGL(als_q_pick_k, dim3(row_grid), dim3(256), 0, e->stream, (const double*)(d_Q + (size_t)f * m->n), m->n, d_qe);
     else hipLaunchKernelGGL(als_q_init_k, dim3(row_grid), dim3(256), 0, e->stream, m->row_ptr, m->col, m->val, m->n, e->dV, e->kp64, f, d_qe);
     const double lambda = h_lambda ? h_lambda[f] : 0.0, mu = h_mu ? h_mu[f] : 0.0;
     if (d_qe_new) (void)hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream);  // q changed: resynchronise the pair
     set_dyn(e, dyn, f, alpha, lambda, mu, d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
+    e->als_vf_slot = -1;   // (another factor: nothing gathered ahead is valid)
+    e->als_qnext = (d_Q && f + 1 < e->k) ? d_Q + (size_t)(f + 1) * m->n : nullptr;
+    const bool offered = e->als_qnext != nullptr;
     sweep_once<false>(e, m, d_qe, d_qe_new, dyn);
+    picked = offered && e->als_qnext == nullptr;
+    e->als_qnext = nullptr;
   }
+  e->als_vf_slot = -1;
   return FMX_OK;
 }
 
@@ -970,10 +983,24 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
 // V (or w) and the residual are kept aside, the sweep runs, and if the residual's sum of squares went UP (ALS: at all; MCMC, whose
 // draws add variance of their own: tenfold, or not finite) everything is put back, the matrix is marked exact-only and the sweep
 // is run again through the exact level schedule.  cfg.als_max_levels is therefore a request, not a risk.
+// What is compared is the objective the coordinate steps descend, alpha sum e^2 + sum_f lambda_f sum_j (theta_fj - mu_f)^2, not the residual alone: with a
+// prior (lambda > 0) or a warm start beyond the regularised optimum a correct sweep lowers the objective while RAISING sum e^2, and the residual alone
+// would demote the matrix to the exact schedule for good after one benign sweep.  The demotion is visible to the caller: fmx_als_plan_info
+// reports approximate = 0 from then on.
+static int penalty_sum(fmx_engine* e, bool w, const double* h_lambda, const double* h_mu, double* out);
 struct ApproxGuard {
   fmx_engine* e; fmx_matrix* m; double2* d_qe; bool w; bool gibbs;
+  double alpha = 1.0;
+  const double *h_lambda = nullptr, *h_mu = nullptr;   // [k] (V sweep) or [1] (w sweep); null: no prior
   double ss0 = 0.0;
   bool armed = false;
+  int objective(double* out) {
+    double ss = 0.0, pen = 0.0;
+    FMX_TRY(residual_sumsq(e, d_qe, m->n, &ss));
+    FMX_TRY(penalty_sum(e, w, h_lambda, h_mu, &pen));
+    *out = alpha * ss + pen;
+    return FMX_OK;
+  }
   int begin() {
     if (!m->als_approx) return FMX_OK;
     const size_t pv = w ? (size_t)e->p : (size_t)e->p * e->kp64;
@@ -984,7 +1011,7 @@ struct ApproxGuard {
       FMX_HIP(hipMalloc(&e->als_backup, need * sizeof(double)));
       e->als_backup_elems = need;
     }
-    FMX_TRY(residual_sumsq(e, d_qe, m->n, &ss0));
+    FMX_TRY(objective(&ss0));
     FMX_HIP(hipMemcpyAsync(e->als_backup, w ? e->dw : e->dV, pv * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     FMX_HIP(hipMemcpyAsync(e->als_backup + pv, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream));
     armed = true;
@@ -995,8 +1022,8 @@ struct ApproxGuard {
     *redo = false;
     if (!armed) return FMX_OK;
     double ss1 = 0.0;
-    FMX_TRY(residual_sumsq(e, d_qe, m->n, &ss1));
-    const bool bad = !(ss1 == ss1) || std::isinf(ss1) || ss1 > ss0 * (gibbs ? 10.0 : 1.0 + 1e-12);
+    FMX_TRY(objective(&ss1));
+    const bool bad = !(ss1 == ss1) || std::isinf(ss1) || ss1 > ss0 * (gibbs ? 10.0 : 1.0 + 1e-9);
     if (!bad) return FMX_OK;
     const size_t pv = w ? (size_t)e->p : (size_t)e->p * e->kp64;
     FMX_HIP(hipMemcpyAsync(w ? e->dw : e->dV, e->als_backup, pv * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
@@ -1010,7 +1037,7 @@ struct ApproxGuard {
 };
 
 static int v_sweep_guarded(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm = nullptr) {
-  ApproxGuard g{e, m, d_qe, false, d_znorm != nullptr};
+  ApproxGuard g{e, m, d_qe, false, d_znorm != nullptr, alpha, h_lambda, h_mu};
   FMX_TRY(g.begin());
   FMX_TRY(v_sweep_enqueue(e, m, d_qe, alpha, h_lambda, h_mu, d_znorm));
   bool redo = false;
@@ -1022,13 +1049,15 @@ static int v_sweep_guarded(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
 static int w_sweep_guarded(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, double lambda, double mu, const double* d_znorm) {
   SweepDyn* dyn = sweep_dyn(e);
   FMX_CHECK(dyn != nullptr, FMX_ERR_HIP, "out of device memory");
-  ApproxGuard g{e, m, d_qe, true, d_znorm != nullptr};
+  ApproxGuard g{e, m, d_qe, true, d_znorm != nullptr, alpha, &lambda, &mu};
   FMX_TRY(g.begin());
   for (int pass = 0; pass < 2; ++pass) {
     double2* d_qe_new = approx_buffer(e, m);
     if (d_qe_new) FMX_HIP(hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream));
     set_dyn(e, dyn, 0, alpha, lambda, mu, d_znorm);
+    e->als_vf_slot = -1; e->als_qnext = nullptr;
     sweep_once<true>(e, m, d_qe, d_qe_new, dyn);
+    e->als_vf_slot = -1;
     bool redo = false;
     if (pass == 0) FMX_TRY(g.end(&redo));
     if (!redo) break;
@@ -1342,6 +1371,37 @@ int launch_mcmc_v_hyper(fmx_engine* e, const double* h_gammas, const double* h_n
     if (!bad(mu_new)) v_mu[f] = mu_new;
   }
   (void)hipFree(d_part);
+  return st;
+}
+
+// sum_f lambda_f sum_j (theta_fj - mu_f)^2 over the V table (all factors) or over w: the prior's part of the objective an ALS sweep descends
+static int penalty_sum(fmx_engine* e, bool w, const double* h_lambda, const double* h_mu, double* out) {
+  *out = 0.0;
+  if (!h_lambda) return FMX_OK;
+  const int64_t p = (int64_t)e->p;
+  const int64_t npw = (p + ALS_SLAB - 1) / ALS_SLAB;
+  const int nf = w ? 1 : e->k;
+  bool any = false;
+  for (int f = 0; f < nf; ++f) any = any || h_lambda[f] != 0.0;
+  if (!any || p == 0) return FMX_OK;
+  double* d_part = nullptr;
+  FMX_HIP(hipMalloc(&d_part, (size_t)npw * 2 * sizeof(double)));
+  std::vector<double> h((size_t)npw * 2);
+  int st = FMX_OK;
+  double total = 0.0;
+  for (int f = 0; f < nf && st == FMX_OK; ++f) {
+    if (h_lambda[f] == 0.0) continue;
+    const double mu = h_mu ? h_mu[f] : 0.0;
+    if (w) hipLaunchKernelGGL(mcmc_wstats_partial_k, dim3((unsigned)npw), dim3(WG_THREADS), 0, e->stream, e->dw, p, mu, d_part);
+    else hipLaunchKernelGGL(mcmc_vstats_partial_k, dim3((unsigned)npw), dim3(WG_THREADS), 0, e->stream, e->dV, e->kp64, f, p, mu, d_part);
+    if (hipMemcpyAsync(h.data(), d_part, (size_t)npw * (w ? 2 : 1) * sizeof(double), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) { set_error("prior term of the ALS objective failed"); st = FMX_ERR_HIP; break; }
+    double sq = 0.0;
+    for (int64_t i = 0; i < npw; ++i) sq += w ? h[(size_t)(2 * i + 1)] : h[(size_t)i];   // (w statistics: {sum w, sum (w - mu)^2} per slab)
+    total += h_lambda[f] * sq;
+  }
+  (void)hipFree(d_part);
+  *out = total;
   return st;
 }
 

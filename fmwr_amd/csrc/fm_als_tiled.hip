@@ -228,6 +228,21 @@ int als_tiled_info(const fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_row
 // ---- the sweep -------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool bad_number_t(double x) { return isnan(x) || isinf(x); }
 
+// The (q, e) pairs are the one table every pass of every level re-reads (160 MB at configs[4]: it fits the 256 MB Infinity Cache, but not next
+// to the 40 MB per level of lists, of level-major indices and of per-tile sums that are read ONCE).  Those streams are loaded non-temporally
+// so that they do not push the pairs out (NT = false: the default cache policy, for A/B: FMX_ALS_NT=0).
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+typedef double fmx_v2d __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 stream_load(const double2* p) {   // (the builtin takes native vectors, not HIP's struct)
+  if constexpr (NT) { const fmx_v2d v = __builtin_nontemporal_load(reinterpret_cast<const fmx_v2d*>(p)); return make_double2(v.x, v.y); }
+  else return *p;
+}
+
 // the level's current coordinates, gathered once into a level-sized vector (read coalesced by every tile's lists)
 template <bool W>
 __global__ void als_tile_prep_k(const uint32_t* __restrict__ feats, uint32_t cnt, const double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
@@ -240,7 +255,7 @@ __global__ void als_tile_prep_k(const uint32_t* __restrict__ feats, uint32_t cnt
 // blockIdx -> (tile, chunk of the level's features): the B workgroups of a tile are consecutive in ONE XCD's share of the grid (blocks are dealt
 // round-robin over the eight XCDs, so blocks b and b + 8 share one), and an XCD works through its tiles one after the other -- the tile's
 // (q, e) slice is fetched into that L2 once and gathered from there.  Placement is for speed only.
-template <bool W, int LG, bool UNIT>
+template <bool W, int LG, bool UNIT, bool NT>
 __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt,
                                                               const int64_t* __restrict__ tile_base, const uint32_t* __restrict__ trow, const float* __restrict__ tval,
                                                               const double* __restrict__ vf, const double2* __restrict__ qe, int tshift, int n_tiles, int B,
@@ -250,11 +265,12 @@ __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __
   const int tile = (i / B) * 8 + x, chunk = i % B;
   if (tile >= n_tiles) return;
   constexpr int LISTS = WG_THREADS / LG;
-  const uint32_t fi = (uint32_t)chunk * LISTS + threadIdx.x / LG;
+  const uint32_t fi_raw = (uint32_t)chunk * LISTS + threadIdx.x / LG;
+  const bool live = fi_raw < cnt;             // (a whole lane group is live or not)
+  const uint32_t fi = live ? fi_raw : cnt - 1;
   const int lg = threadIdx.x % LG;
-  if (fi >= cnt) return;   // (a whole lane group leaves together)
   const uint32_t* off = toff + (size_t)tile * nf1 + lvl0 + fi;
-  const uint32_t lb = off[0], le = off[1];
+  const uint32_t lb = stream_load<NT>(off), le = live ? stream_load<NT>(off + 1) : lb;
   const int64_t tb = tile_base[tile];
   const double2* __restrict__ slice = qe + ((size_t)tile << tshift);
   const double old = vf[fi];
@@ -266,8 +282,8 @@ __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t t = t0 + u * LG, tc = t < le ? t : t0;
-      rr[u] = trow[tb + tc];
-      xs[u] = UNIT ? 1.0f : tval[tb + tc];
+      rr[u] = stream_load<NT>(trow + tb + tc);
+      xs[u] = UNIT ? 1.0f : stream_load<NT>(tval + tb + tc);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) c[u] = slice[rr[u]];
@@ -280,19 +296,39 @@ __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __
   }
 #pragma unroll
   for (int o = LG / 2; o > 0; o >>= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }
-  if (lg == 0) partial[(size_t)tile * max_cnt + fi] = make_double2(mean, var);
+  if (lg == 0 && live) partial[(size_t)tile * max_cnt + fi] = make_double2(mean, var);
 }
 
-template <bool W>
-__global__ void als_tile_step_k(const uint32_t* __restrict__ feats, uint32_t cnt, const double2* __restrict__ partial, uint32_t max_cnt, int n_tiles,
-                                double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, const double* __restrict__ vf, double2* __restrict__ vstep) {
-  const uint32_t fi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (fi >= cnt) return;
+// 16 features per workgroup, 16 threads per feature: thread (tl, fl) adds the pairs of tiles tl, tl + 16, ... of feature fl in that order, the sixteen
+// part sums meet in LDS and are added in tl order -- a fixed association (reproducible), and sixteen loads in flight per feature where one thread per
+// feature walked the tiles one load at a time (24 us of a 245 us level).
+// Workgroups beyond the level's own (step_blocks) gather the coordinates of the NEXT tiled level of the sweep into the other half of the
+// coordinate buffer (features of different levels are different features: nothing this level writes is read there) -- the prep launch of that level is saved.
+template <bool W, bool NT>
+__global__ __launch_bounds__(WG_THREADS) void als_tile_step_k(const uint32_t* __restrict__ feats, uint32_t cnt, const double2* __restrict__ partial, uint32_t max_cnt, int n_tiles,
+                                                              double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, const double* __restrict__ vf,
+                                                              double2* __restrict__ vstep, unsigned step_blocks, const uint32_t* __restrict__ next_feats, uint32_t next_cnt,
+                                                              double* __restrict__ next_vf) {
+  __shared__ double2 red[16][16];
+  if (blockIdx.x >= step_blocks) {
+    const uint32_t i = (blockIdx.x - step_blocks) * WG_THREADS + threadIdx.x;
+    if (i < next_cnt) next_vf[i] = P[W ? (size_t)next_feats[i] : (size_t)next_feats[i] * kp + dyn->f];
+    return;
+  }
+  const int fl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const uint32_t fi = blockIdx.x * 16 + fl;
+  const uint32_t fc = fi < cnt ? fi : cnt - 1;
+  double mean = 0.0, var = 0.0;
+  for (int t = tl; t < n_tiles; t += 16) { const double2 s = stream_load<NT>(partial + (size_t)t * max_cnt + fc); mean += s.x; var += s.y; }
+  red[tl][fl] = make_double2(mean, var);
+  __syncthreads();
+  if (tl != 0 || fi >= cnt) return;
+  mean = 0.0; var = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { mean += red[q][fl].x; var += red[q][fl].y; }
   const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
   const double* __restrict__ znorm = dyn->znorm;
   const uint32_t i = feats[fi];
-  double mean = 0.0, var = 0.0;
-  for (int t = 0; t < n_tiles; ++t) { const double2 s = partial[(size_t)t * max_cnt + fi]; mean += s.x; var += s.y; }
   const double old = vf[fi];
   double nv;
   if (W) {
@@ -310,27 +346,43 @@ __global__ void als_tile_step_k(const uint32_t* __restrict__ feats, uint32_t cnt
   vstep[fi] = make_double2(old, old - nv);
 }
 
-template <bool W, bool UNIT>
+// R rows per thread, a workgroup's rows contiguous per r (coalesced): all of a thread's loads go out before the first is used
+// QNEXT (the LAST level of a factor's sweep): this factor's q is dead once its last correction is applied, so the pass stores the NEXT factor's q
+// (qnext[r], one coalesced double per row, from the factor-major table of all factors' q) in its place -- for EVERY row, also those the level does
+// not touch -- and the per-factor pick pass over the pairs is saved.
+template <bool W, bool UNIT, bool NT, int R, bool QNEXT>
 __global__ __launch_bounds__(WG_THREADS) void als_rows_apply_k(const uint32_t* __restrict__ lfi, const float* __restrict__ lval, int64_t n,
-                                                               const double2* __restrict__ vstep, double2* __restrict__ qe) {
-  const int64_t r = (int64_t)blockIdx.x * WG_THREADS + threadIdx.x;
-  if (r >= n) return;
-  const uint32_t fi = lfi[r];
-  const float x = UNIT ? 1.0f : lval[r];
-  const double2 c = qe[r];
-  const double2 s = vstep[fi == TILED_NONE ? 0u : fi];
-  if (fi == TILED_NONE || s.y != s.y) return;
-  if (W) {
-    qe[r] = make_double2(c.x, c.y - (double)x * s.y);                                         // :246-252
-  } else {
-    const float xx = x * x;
-    const double h = (double)x * c.x - (double)xx * s.x;
-    qe[r] = make_double2(c.x - (double)x * s.y, c.y - h * s.y);                               // :341-350
+                                                               const double2* __restrict__ vstep, double2* __restrict__ qe, const double* __restrict__ qnext) {
+  const int64_t r0 = (int64_t)blockIdx.x * (WG_THREADS * R) + threadIdx.x;
+  uint32_t fi[R]; float x[R]; double2 c[R], s[R]; double qn[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int64_t r = r0 + (int64_t)u * WG_THREADS, rc = r < n ? r : n - 1;
+    fi[u] = stream_load<NT>(lfi + rc);
+    x[u] = UNIT ? 1.0f : stream_load<NT>(lval + rc);
+    c[u] = qe[rc];
+    qn[u] = QNEXT ? stream_load<NT>(qnext + rc) : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) s[u] = vstep[fi[u] == TILED_NONE ? 0u : fi[u]];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int64_t r = r0 + (int64_t)u * WG_THREADS;
+    if (r >= n) continue;
+    const bool skip = fi[u] == TILED_NONE || s[u].y != s[u].y;
+    if (skip) { if (QNEXT) qe[r] = make_double2(qn[u], c[u].y); continue; }
+    if (W) {
+      qe[r] = make_double2(c[u].x, c[u].y - (double)x[u] * s[u].y);                           // :246-252
+    } else {
+      const float xx = x[u] * x[u];
+      const double h = (double)x[u] * c[u].x - (double)xx * s[u].x;
+      qe[r] = make_double2(QNEXT ? qn[u] : c[u].x - (double)x[u] * s[u].y, c[u].y - h * s[u].y);   // :341-350
+    }
   }
 }
 
 static int tile_ws(fmx_engine* e, const AlsTiled* T, double2** partial, double** vf, double2** vstep) {
-  const size_t need = ((size_t)T->n_tiles * T->max_cnt + T->max_cnt) * sizeof(double2) + (size_t)T->max_cnt * sizeof(double);
+  const size_t need = ((size_t)T->n_tiles * T->max_cnt + T->max_cnt) * sizeof(double2) + 2 * (size_t)T->max_cnt * sizeof(double);   // (vf: two halves)
   if (e->als_tile_ws_bytes < need) {
     FMX_HIP(hipStreamSynchronize(e->stream));
     (void)hipFree(e->als_tile_ws); e->als_tile_ws = nullptr; e->als_tile_ws_bytes = 0;
@@ -345,28 +397,37 @@ static int tile_ws(fmx_engine* e, const AlsTiled* T, double2** partial, double**
 
 // one level of the w sweep (W) or of one factor of the V sweep in the tiled form; *done = false: the level is not a tiled one
 template <bool W>
-int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, double2* d_qe, const SweepDyn* dyn, bool* done) {
+int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2* d_qe, const SweepDyn* dyn, bool* done) {
   *done = false;
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
   if (!T || level >= (int)T->slot_of_level.size() || T->slot_of_level[(size_t)level] < 0) return FMX_OK;
   const int s = T->slot_of_level[(size_t)level];
   const uint32_t lvl0 = T->lvl0[(size_t)s], cnt = T->cnt[(size_t)s];
   double2 *partial = nullptr, *vstep = nullptr;
-  double* vf = nullptr;
-  FMX_TRY(tile_ws(e, T, &partial, &vf, &vstep));
+  double* vf2 = nullptr;
+  FMX_TRY(tile_ws(e, T, &partial, &vf2, &vstep));
   double* P = W ? e->dw : e->dV;
   const size_t nf1 = (size_t)T->n_feats + 1;
-  const unsigned fgrid = (cnt + 255) / 256;
-  hipLaunchKernelGGL((als_tile_prep_k<W>), dim3(fgrid), dim3(256), 0, e->stream, T->feats + lvl0, cnt, (const double*)P, e->kp64, dyn, vf);
+  const dim3 blk(WG_THREADS);
+  // FMX_ALS_NT: bit 0 the lists of the sums pass, bit 1 the streams of the correction pass, bit 2 the per-tile sums read by the step kernel
+  static const int nt_mask = env_int("FMX_ALS_NT", 6);
+  static const int rows_per_thread = env_int("FMX_ALS_APPLY_ROWS", 4);
+  static const bool fold_prep = env_int("FMX_ALS_FOLD_PREP", 1) != 0;
+  // this level's coordinates: gathered by the previous tiled level's step kernel (its spare workgroups), or here
+  int buf = 0;
+  if (fold_prep && e->als_vf_slot == s) buf = e->als_vf_buf;
+  else hipLaunchKernelGGL((als_tile_prep_k<W>), dim3((cnt + 255) / 256), dim3(256), 0, e->stream, T->feats + lvl0, cnt, (const double*)P, e->kp64, dyn, vf2);
+  double* vf = vf2 + (size_t)buf * T->max_cnt;
   const int lists = WG_THREADS / T->lg;
   const int B = (int)((cnt + lists - 1) / lists);
-  const dim3 g((unsigned)(((T->n_tiles + 7) / 8) * 8 * B)), blk(WG_THREADS);
+  const dim3 g((unsigned)(((T->n_tiles + 7) / 8) * 8 * B));
+#define FMX_SUMS2(LGv, UNITv, NTv)                                                                                                                        \
+  hipLaunchKernelGGL((als_tile_sums_k<W, LGv, UNITv, NTv>), g, blk, 0, e->stream, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, (const double*)vf, \
+                     (const double2*)d_qe, T->tshift, T->n_tiles, B, partial, T->max_cnt)
 #define FMX_SUMS(LGv)                                                                                                                                     \
   do {                                                                                                                                                    \
-    if (T->unit) hipLaunchKernelGGL((als_tile_sums_k<W, LGv, true>), g, blk, 0, e->stream, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, vf,     \
-                                    (const double2*)d_qe, T->tshift, T->n_tiles, B, partial, T->max_cnt);                                                  \
-    else hipLaunchKernelGGL((als_tile_sums_k<W, LGv, false>), g, blk, 0, e->stream, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, vf,            \
-                            (const double2*)d_qe, T->tshift, T->n_tiles, B, partial, T->max_cnt);                                                          \
+    if (T->unit) { if (nt_mask & 1) FMX_SUMS2(LGv, true, true); else FMX_SUMS2(LGv, true, false); }                                                         \
+    else { if (nt_mask & 1) FMX_SUMS2(LGv, false, true); else FMX_SUMS2(LGv, false, false); }                                                               \
   } while (0)
   switch (T->lg) {
     case 2: FMX_SUMS(2); break;
@@ -375,17 +436,47 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, double2* d_qe, cons
     default: FMX_SUMS(1); break;
   }
 #undef FMX_SUMS
-  hipLaunchKernelGGL((als_tile_step_k<W>), dim3(fgrid), dim3(256), 0, e->stream, T->feats + lvl0, cnt, (const double2*)partial, T->max_cnt, T->n_tiles, P, e->kp64, dyn,
-                     (const double*)vf, vstep);
-  const dim3 rg((unsigned)((T->n + WG_THREADS - 1) / WG_THREADS));
+#undef FMX_SUMS2
+  // the next tiled level of this sweep, if the very next level is one (anything in between may not be skipped: it would run after the gather,
+  // which is harmless -- other features -- but keep the rule simple)
+  const uint32_t* next_feats = nullptr; uint32_t next_cnt = 0;
+  int next_slot = -1;
+  if (fold_prep && !last && level + 1 < (int)T->slot_of_level.size() && T->slot_of_level[(size_t)level + 1] >= 0) {
+    next_slot = T->slot_of_level[(size_t)level + 1];
+    next_feats = T->feats + T->lvl0[(size_t)next_slot]; next_cnt = T->cnt[(size_t)next_slot];
+  }
+  double* next_vf = vf2 + (size_t)(1 - buf) * T->max_cnt;
+  const unsigned sgrid = (cnt + 15) / 16, pgrid = (next_cnt + WG_THREADS - 1) / WG_THREADS;
+  if (nt_mask & 4) hipLaunchKernelGGL((als_tile_step_k<W, true>), dim3(sgrid + pgrid), blk, 0, e->stream, T->feats + lvl0, cnt, (const double2*)partial, T->max_cnt, T->n_tiles, P, e->kp64, dyn,
+                                      (const double*)vf, vstep, sgrid, next_feats, next_cnt, next_vf);
+  else hipLaunchKernelGGL((als_tile_step_k<W, false>), dim3(sgrid + pgrid), blk, 0, e->stream, T->feats + lvl0, cnt, (const double2*)partial, T->max_cnt, T->n_tiles, P, e->kp64, dyn,
+                          (const double*)vf, vstep, sgrid, next_feats, next_cnt, next_vf);
+  e->als_vf_slot = next_slot; e->als_vf_buf = 1 - buf;
   const uint32_t* lfi = T->lfi + (size_t)s * T->n;
   const float* lval = T->lval ? T->lval + (size_t)s * T->n : nullptr;
-  if (T->unit) hipLaunchKernelGGL((als_rows_apply_k<W, true>), rg, blk, 0, e->stream, lfi, lval, T->n, (const double2*)vstep, d_qe);
-  else hipLaunchKernelGGL((als_rows_apply_k<W, false>), rg, blk, 0, e->stream, lfi, lval, T->n, (const double2*)vstep, d_qe);
+  const double* qnext = (!W && last) ? e->als_qnext : nullptr;
+#define FMX_APPLY(UNITv, NTv, Rv, QNv)                                                                                                                    \
+  hipLaunchKernelGGL((als_rows_apply_k<W, UNITv, NTv, Rv, QNv>), dim3((unsigned)((T->n + WG_THREADS * Rv - 1) / (WG_THREADS * Rv))), blk, 0, e->stream, lfi, lval, T->n,   \
+                     (const double2*)vstep, d_qe, qnext)
+#define FMX_APPLY_Q(UNITv, NTv, Rv) do { if (qnext) FMX_APPLY(UNITv, NTv, Rv, true); else FMX_APPLY(UNITv, NTv, Rv, false); } while (0)
+#define FMX_APPLY_R(Rv)                                                                                                                                   \
+  do {                                                                                                                                                    \
+    if (T->unit) { if (nt_mask & 2) FMX_APPLY_Q(true, true, Rv); else FMX_APPLY_Q(true, false, Rv); }                                                       \
+    else { if (nt_mask & 2) FMX_APPLY_Q(false, true, Rv); else FMX_APPLY_Q(false, false, Rv); }                                                             \
+  } while (0)
+  switch (rows_per_thread) {
+    case 1: FMX_APPLY_R(1); break;
+    case 2: FMX_APPLY_R(2); break;
+    default: FMX_APPLY_R(4); break;
+  }
+#undef FMX_APPLY_R
+#undef FMX_APPLY_Q
+#undef FMX_APPLY
+  if (qnext) e->als_qnext = nullptr;   // folded: v_sweep_enqueue skips the next factor's pick
   *done = true;
   return FMX_OK;
 }
-template int als_tiled_level<true>(fmx_engine*, fmx_matrix*, int, double2*, const SweepDyn*, bool*);
-template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, double2*, const SweepDyn*, bool*);
+template int als_tiled_level<true>(fmx_engine*, fmx_matrix*, int, bool, double2*, const SweepDyn*, bool*);
+template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, bool, double2*, const SweepDyn*, bool*);
 
 }  // namespace fmx

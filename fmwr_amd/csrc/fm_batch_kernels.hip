@@ -378,7 +378,10 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
   } else {
     if (have && lig == 0 && sub == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link, a.pn_y);
     if constexpr (sizeof(T) == 8) {  // fp64 tables: optionally the per-row factor sums q[row][f] = sum_j x_j v_jf (ALS sweeps)
-      if (have && sub == 0 && a.qout) *reinterpret_cast<double2*>(a.qout + (size_t)row * KP + lig * VEC) = make_double2(s[0], s[1]);
+      if (have && sub == 0 && a.qout) {
+        if (a.qout_t > 0) { a.qout[(size_t)(lig * VEC) * a.qout_t + row] = s[0]; a.qout[(size_t)(lig * VEC + 1) * a.qout_t + row] = s[1]; }
+        else *reinterpret_cast<double2*>(a.qout + (size_t)row * KP + lig * VEC) = make_double2(s[0], s[1]);
+      }
     }
   }
 }
@@ -493,7 +496,7 @@ int launch_rows_forward(fmx_engine* e, const RowsArgs& a_in, bool train, bool fp
       s.r0 = a.r0 + off;
       s.nrows = a.nrows - off < SLAB ? a.nrows - off : SLAB;
       if (a.yhat) s.yhat = a.yhat + off;
-      if (a.qout) s.qout = a.qout + (size_t)off * kp;
+      if (a.qout) s.qout = a.qout_t > 0 ? a.qout + off : a.qout + (size_t)off * kp;
       s.wg_threads = rows_wg_threads(a.nrows, kp / (fp64_tables ? 2 : 4));
       s.split = rows_split(a.nrows, kp / (fp64_tables ? 2 : 4));
       int trial;

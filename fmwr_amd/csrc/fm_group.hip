@@ -14,6 +14,8 @@
 // Shards are cut from the caller's matrix on the device (peer copies + a row_ptr rebase), cached per matrix.
 #include <dlfcn.h>
 
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 
 #include "fmx_internal.h"
@@ -107,6 +109,9 @@ struct Group {
   };
   std::vector<OwnerBuf> ox;
   std::vector<hipEvent_t> ev_ids, ev_packed, ev_grad, ev_done;   // per replica, recorded on its stream
+  // peer access between the replicas' devices, asked for at creation (distinct devices): ordered pairs (a, b), a != b, for which device a may address device b's memory
+  // directly -- hipMemcpyPeerAsync (the shards, the owner-sharded exchange's slices, set_params) then goes over xGMI without a bounce through the host.
+  int peer_pairs = 0, peer_direct = 0;
   bool owners_on = false;     // the replicas are configured as owners (records and ids come out owner-major)
   bool owner_dirty = false;   // owner-sharded steps ran: a feature's tables are current at its owner (V and w also on replica 0) and nowhere else
 };
@@ -143,6 +148,11 @@ void group_destroy(fmx_engine* e) {
   e->group = nullptr;
 }
 
+// test hook (fmx_test_hooks.h): the next group creation fails where RCCL is initialised, after the other replicas exist -- what a failing
+// ncclCommInitAll on some device i > 0 leaves behind must be torn down by the caller's error path (fmx_engine_create's deleter -> group_destroy)
+static std::atomic<int> g_fail_next_comm_init{0};
+void debug_fail_next_comm_init() { g_fail_next_comm_init.store(1); }
+
 int group_create(fmx_engine* e) {
   const int n = e->cfg.n_gpus;
   FMX_CHECK(n >= 2 && n <= GROUP_MAX, FMX_ERR_INVALID, "n_gpus must be in 1..%d", GROUP_MAX);
@@ -167,6 +177,10 @@ int group_create(fmx_engine* e) {
     FMX_TRY(fmx_engine_create(&c, e->p, &g->rep[(size_t)r]));
   }
   g->ready.assign((size_t)n, nullptr);
+  if (g_fail_next_comm_init.exchange(0) > 0) {
+    set_error("ncclCommInitAll failed on device %d (forced: fmx_debug_fail_next_comm_init)", g->dev[(size_t)n - 1]);
+    return FMX_ERR_HIP;   // (the caller destroys the engine: group_destroy frees the replicas made above)
+  }
   if (g->shared) {
     FMX_HIP(hipSetDevice(e->cfg.device));
     FMX_HIP(hipStreamCreateWithFlags(&g->xs, hipStreamNonBlocking));
@@ -177,6 +191,20 @@ int group_create(fmx_engine* e) {
     FMX_CHECK(l != nullptr, FMX_ERR_STATE, "n_gpus > 1 on distinct devices needs librccl.so (not found by dlopen)");
     g->comm.assign((size_t)n, nullptr);
     FMX_RCCL(l->CommInitAll(g->comm.data(), n, g->dev.data()));
+    // direct peer access wherever the devices allow it (all pairs of one xGMI hive); a pair that refuses keeps working through staged copies
+    for (int a = 0; a < n; ++a) {
+      FMX_HIP(hipSetDevice(g->dev[(size_t)a]));
+      for (int b = 0; b < n; ++b) {
+        if (a == b) continue;
+        ++g->peer_pairs;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g->dev[(size_t)a], g->dev[(size_t)b]) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (!can) continue;
+        const hipError_t pe = hipDeviceEnablePeerAccess(g->dev[(size_t)b], 0);
+        if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) ++g->peer_direct;
+        (void)hipGetLastError();
+      }
+    }
   }
   FMX_HIP(hipSetDevice(e->cfg.device));
   return FMX_OK;
@@ -185,6 +213,7 @@ int group_create(fmx_engine* e) {
 int group_load(fmx_engine* e, const char* path) {
   Group* g = e->group;
   for (int r = 1; r < g->n; ++r) FMX_TRY(fmx_engine_load(g->rep[(size_t)r], path));
+  g->owner_dirty = false;   // every replica holds every table again (the file's): nothing left for an owner refresh to move
   return use_device_public(e->cfg.device);
 }
 
@@ -590,14 +619,31 @@ int group_make_replicated(fmx_engine* e) {
   return FMX_OK;
 }
 
-// which exchange a training call uses: FMX_GROUP_EXCHANGE = dense | compact | owner (read at every call; default: owner-sharded wherever
-// the steps are sparse tiles and nobody looks at the model between steps)
+// which exchange a training call uses: FMX_GROUP_EXCHANGE = dense | compact | owner (read at every call).  Steps of one sparse tile default to the
+// all-gather of records (compact).  The owner-sharded form moves fewer bytes, but between DISTINCT devices it is a protocol of peer copies ordered by
+// cross-device events in which only the owner holds a feature's current optimizer state -- a missed edge would diverge the replicas silently -- and
+// no box with two devices has run it yet (SCALE_r01..r03 skipped): there it is opt-in (FMX_GROUP_EXCHANGE=owner) until tests/test_gpu_group.py has
+// passed on 2+ GPUs.  Replicas that share one device (cfg.gpus_share_device: the rehearsal every GPU suite runs, bitwise the all-gather form) take it
+// by default, as before.  Nobody may look at the model between owner-sharded steps (`watched`: the tracker).
 enum GroupMode { GM_DENSE = 0, GM_COMPACT = 1, GM_OWNER = 2 };
-static GroupMode group_mode(bool compact_usable, bool watched) {
+static GroupMode group_mode(const Group* g, bool compact_usable, bool watched) {
   const char* v = getenv("FMX_GROUP_EXCHANGE");
   if (!compact_usable || (v && v[0] == 'd')) return GM_DENSE;
   if ((v && v[0] == 'c') || watched) return GM_COMPACT;
-  return GM_OWNER;
+  if (v && v[0] == 'o') return GM_OWNER;
+  return g->shared ? GM_OWNER : GM_COMPACT;
+}
+
+// n replicas, sharing one device or not, ordered device pairs and how many of them have direct peer access, and the exchange steps of one sparse tile
+// take by default (1: all-gather of records, 2: owner-sharded)
+int group_info(const fmx_engine* e, int32_t* n, int32_t* shared, int32_t* peer_pairs, int32_t* peer_direct, int32_t* sparse_exchange) {
+  const Group* g = e->group;
+  if (n) *n = g ? g->n : 1;
+  if (shared) *shared = g && g->shared ? 1 : 0;
+  if (peer_pairs) *peer_pairs = g ? g->peer_pairs : 0;
+  if (peer_direct) *peer_direct = g ? g->peer_direct : 0;
+  if (sparse_exchange) *sparse_exchange = g ? (int32_t)group_mode(g, true, false) : 0;
+  return FMX_OK;
 }
 
 // every replica's gather buffer holds N parts of `stride` records
@@ -671,7 +717,7 @@ int group_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* example
   FMX_CHECK(nb_min >= 1, FMX_ERR_INVALID, "a shard is empty: fewer rows than GPUs");
   bool compact = false;
   FMX_TRY(prepare_compact(g, &compact));
-  const GroupMode mode = group_mode(compact, after_step != nullptr);
+  const GroupMode mode = group_mode(g, compact, after_step != nullptr);
   compact = mode != GM_DENSE;
   if (mode != GM_OWNER) FMX_TRY(group_make_replicated(e));   // the other forms apply every update on every replica: all copies must be current
   FMX_TRY(owner_setup(g, mode == GM_OWNER));
@@ -754,7 +800,7 @@ int group_train_stream(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_p
   double waited = 0.0;
   // a streamed step is one tile: sparse (records / owners) when it holds fewer entries than there are features
   const int64_t z_row = spec ? (int64_t)spec->n_dense + spec->n_fields : (int64_t)nnz_per_row;
-  const GroupMode mode = group_mode(e->cfg.batch_rows * z_row < (int64_t)e->p, false);
+  const GroupMode mode = group_mode(g, e->cfg.batch_rows * z_row < (int64_t)e->p, false);
   if (mode != GM_OWNER) FMX_TRY(group_make_replicated(e));
   FMX_TRY(owner_setup(g, mode == GM_OWNER));   // (before the sources open: the ingest builds the owner-major order with the plan)
   auto body = [&]() -> int {

@@ -10,6 +10,7 @@
 #include <memory>
 
 #include "fmx_internal.h"
+#include "fmx_test_hooks.h"
 #include "fm_probit.h"
 
 namespace fmx {
@@ -826,8 +827,53 @@ static CkptHeader ckpt_header(const fmx_engine* e) {
   h.version = 1; h.p = e->p; h.k = e->k; h.kp = wide_state(e) ? e->kp64 : e->kp32; h.mode = e->cfg.mode; h.kind = e->hyper.kind;
   h.scalars = SC_COUNT;
   h.reserved[0] = mb_wide(e) ? 1u : 0u;  // mini-batch state kept in the fp64 tables
-  h.reserved[1] = e->w_in_row ? 1u : 0u;  // V rows carry w (the tables are stored as they lie on the device)
+  // reserved[1]: how the FILE holds the fp32 parameters.  0 (every file written since round 4): canonical -- V[p][kp] then w[p] -- whatever layout the
+  // engine keeps on the device (the w-in-row layout is a tuning choice made from p, k and FMX_W_IN_ROW at engine creation: it must not leak into the
+  // format).  1 (round-3 files of w-in-row engines): one table [p][2 kp] with w in slot kp of its row and no w table; still read, by either layout.
+  h.reserved[1] = 0u;
   return h;
+}
+
+// The fp32 parameters between the device layout and the file's.  Pieces of PIECE features: device rows are `ds` floats apart (kp, or 2 kp with w in slot kp),
+// file rows `fs` floats apart (kp canonical; 2 kp for a round-3 w-in-row file, whose w travels in the row).  w of a canonical file is a separate array.
+constexpr size_t CKPT_PIECE = 1u << 18;
+static bool ckpt_save_params32(fmx_engine* e, FILE* f) {
+  const size_t p = (size_t)e->p, kp = (size_t)e->kp32, ds = (size_t)e->vstride32;
+  std::vector<float> dev(CKPT_PIECE * ds), rows(CKPT_PIECE * kp), w(p);
+  for (size_t j0 = 0; j0 < p; j0 += CKPT_PIECE) {
+    const size_t c = p - j0 < CKPT_PIECE ? p - j0 : CKPT_PIECE;
+    if (hipMemcpy(dev.data(), e->V + j0 * ds, c * ds * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (size_t j = 0; j < c; ++j) {
+      memcpy(&rows[j * kp], &dev[j * ds], kp * sizeof(float));
+      w[j0 + j] = dev[j * ds + kp];
+    }
+    if (fwrite(rows.data(), sizeof(float), c * kp, f) != c * kp) return false;
+  }
+  return fwrite(w.data(), sizeof(float), p, f) == p;
+}
+// file_wir: the file holds rows of 2 kp floats with w inside (and no w array)
+static bool ckpt_load_params32(fmx_engine* e, FILE* f, bool file_wir) {
+  const size_t p = (size_t)e->p, kp = (size_t)e->kp32, ds = (size_t)e->vstride32, fs = file_wir ? 2 * kp : kp;
+  std::vector<float> dev(CKPT_PIECE * ds), rows(CKPT_PIECE * fs), w(p, 0.f);
+  if (!file_wir && e->w_in_row) {   // canonical file into w-in-row tables: w is needed while the rows are laid out -- it sits BEHIND them in the file
+    const long at = ftell(f);
+    if (at < 0 || fseek(f, (long)(p * kp * sizeof(float)), SEEK_CUR) != 0 || fread(w.data(), sizeof(float), p, f) != p || fseek(f, at, SEEK_SET) != 0) return false;
+  }
+  for (size_t j0 = 0; j0 < p; j0 += CKPT_PIECE) {
+    const size_t c = p - j0 < CKPT_PIECE ? p - j0 : CKPT_PIECE;
+    if (fread(rows.data(), sizeof(float), c * fs, f) != c * fs) return false;
+    std::fill(dev.begin(), dev.begin() + c * ds, 0.f);
+    for (size_t j = 0; j < c; ++j) {
+      memcpy(&dev[j * ds], &rows[j * fs], kp * sizeof(float));
+      if (file_wir) w[j0 + j] = rows[j * fs + kp];
+      if (e->w_in_row) dev[j * ds + kp] = w[j0 + j];
+    }
+    if (hipMemcpy(e->V + j0 * ds, dev.data(), c * ds * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
+  }
+  if (!file_wir && e->w_in_row) { if (fseek(f, (long)(p * sizeof(float)), SEEK_CUR) != 0) return false; }   // (w was read ahead)
+  else if (!file_wir) { if (fread(w.data(), sizeof(float), p, f) != p) return false; }
+  if (!e->w_in_row && hipMemcpy(e->w, w.data(), p * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
+  return true;
 }
 
 }  // namespace fmx
@@ -848,6 +894,7 @@ int fmx_engine_save(fmx_engine* e, const char* path) {
   std::vector<char> buf;
   for (auto& t : tabs) {
     if (!ok) break;
+    if (e->w_in_row && t.first == (void*)e->V) { ok = ckpt_save_params32(e, f); continue; }   // canonical: V[p][kp] then w[p]
     buf.resize(t.second);
     ok = hipMemcpy(buf.data(), t.first, t.second, hipMemcpyDeviceToHost) == hipSuccess && fwrite(buf.data(), 1, t.second, f) == t.second;
   }
@@ -866,12 +913,15 @@ int fmx_engine_load(fmx_engine* e, const char* path) {
   bool ok = fread(&h, sizeof(h), 1, f) == 1;
   if (!ok || memcmp(h.magic, "FMX1", 4) != 0 || h.version != 1) { fclose(f); set_error("%s is not an fmx checkpoint", path); return FMX_ERR_INVALID; }
   if (h.p != want.p || h.k != want.k || h.kp != want.kp || h.mode != want.mode || h.kind != want.kind || h.scalars != want.scalars ||
-      h.reserved[0] != want.reserved[0] || h.reserved[1] != want.reserved[1]) {
+      h.reserved[0] != want.reserved[0]) {
     fclose(f);
-    set_error("checkpoint shape (p=%llu k=%d mode=%d kind=%d) does not match the engine (p=%llu k=%d mode=%d kind=%d)", (unsigned long long)h.p, h.k, h.mode,
-              h.kind, (unsigned long long)want.p, want.k, want.mode, want.kind);
+    set_error("checkpoint shape (p=%llu k=%d padded to %d, mode=%d kind=%d, %s state) does not match the engine (p=%llu k=%d padded to %d, mode=%d kind=%d, %s state)",
+              (unsigned long long)h.p, h.k, h.kp, h.mode, h.kind, h.reserved[0] ? "fp64" : "fp32", (unsigned long long)want.p, want.k, want.kp, want.mode, want.kind,
+              want.reserved[0] ? "fp64" : "fp32");
     return FMX_ERR_INVALID;
   }
+  const bool file_wir = h.reserved[1] == 1u;   // a round-3 file of a w-in-row engine: rows of 2 kp floats, w inside, no w array
+  if (h.reserved[1] > 1u || (file_wir && e->V == nullptr)) { fclose(f); set_error("%s: unknown parameter layout %u in the checkpoint header", path, h.reserved[1]); return FMX_ERR_INVALID; }
   double scal[SC_COUNT];
   ok = fread(scal, sizeof(scal), 1, f) == 1 && hipMemcpy(e->scal, scal, sizeof(scal), hipMemcpyHostToDevice) == hipSuccess;
   std::vector<std::pair<void*, size_t>> tabs;
@@ -879,6 +929,8 @@ int fmx_engine_load(fmx_engine* e, const char* path) {
   std::vector<char> buf;
   for (auto& t : tabs) {
     if (!ok) break;
+    if (t.first == (void*)e->V && (e->w_in_row || file_wir)) { ok = ckpt_load_params32(e, f, file_wir); continue; }   // either layout on either side
+    if (t.first == (void*)e->w && file_wir) continue;                                                                 // (its w came with the rows)
     buf.resize(t.second);
     ok = fread(buf.data(), 1, t.second, f) == t.second && hipMemcpy(t.first, buf.data(), t.second, hipMemcpyHostToDevice) == hipSuccess;
   }
@@ -1852,6 +1904,11 @@ int fmx_mcmc_v_hyper(fmx_engine* e, const double* std_gammas, const double* std_
 int fmx_rccl_selftest(int32_t n, double* max_err) { return group_rccl_selftest(n, max_err); }
 
 int fmx_debug_fail_next_plan_build(void) { debug_fail_next_plan_build(); return FMX_OK; }
+int fmx_debug_fail_next_comm_init(void) { debug_fail_next_comm_init(); return FMX_OK; }
+int fmx_group_info(fmx_engine* e, int32_t* n_replicas, int32_t* share_device, int32_t* peer_pairs, int32_t* peer_pairs_direct, int32_t* sparse_exchange) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  return group_info(e, n_replicas, share_device, peer_pairs, peer_pairs_direct, sparse_exchange);
+}
 
 int fmx_profile_enable(fmx_engine* e, int on) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");

@@ -281,6 +281,9 @@ struct fmx_engine {
   void* als_dyn = nullptr;         // device struct the sweep kernels read factor / alpha / lambda / mu / normals from (fm_als_kernels.hip)
   void* als_tile_ws = nullptr;     // tiled sweep: per (tile, feature) sums, the level's coordinates and steps (fm_als_tiled.hip; grow-only)
   size_t als_tile_ws_bytes = 0;
+  const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
+                                      // finished factor's q when that level is a tiled one (it then clears this pointer: the pick kernel is not needed)
+  int als_vf_slot = -1, als_vf_buf = 0;  // tiled sweep: the tiled level whose coordinates the previous level's step kernel already gathered, and into which half
   void *als_graph_w = nullptr, *als_graph_v = nullptr;  // deep exact plans replayed as HIP graphs (AlsGraph)
   double* als_backup = nullptr;    // what an approximate sweep is rolled back to when it raises the residual
   size_t als_backup_elems = 0;
@@ -348,6 +351,7 @@ struct RowsArgs {
   double* partials;     // [grid][2]     (train)
   double* yhat;         // [nrows]       (predict) -- indexed from 0; may be null when only qout is wanted
   double* qout;         // [nrows][kp64] (predict, fp64 tables) per-row factor sums, or null
+  int64_t qout_t;       // > 0: qout is FACTOR-major, factor f of row r at qout[f * qout_t + r] (the ALS sweeps pick one factor at a time)
   const double* pn_y;   // fast_pnorm table (FMX_LINK_PROBIT)
   int link;
   int unit;             // every value is 1.0f: a.val is not read
@@ -532,8 +536,9 @@ struct SweepDyn {
 int als_tiled_build(fmx_matrix* m, hipStream_t stream);
 void als_tiled_free(fmx_matrix* m);
 int als_tiled_info(const fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_rows, int32_t* n_tiles);
+// last: no further level of this factor's sweep follows (the fold of the next factor's q, e->als_qnext, happens there)
 template <bool W>
-int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, double2* d_qe, const SweepDyn* dyn, bool* done);
+int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2* d_qe, const SweepDyn* dyn, bool* done);
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 
 int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);
@@ -558,6 +563,8 @@ int group_make_replicated(fmx_engine* e);  // every replica's copy of every tabl
 int group_grad_empty(fmx_engine* e, fmx_matrix* m, int64_t batch);
 int group_grad_compact(fmx_engine* e, fmx_matrix* m, int64_t batch, int64_t rows);
 int group_rccl_selftest(int n, double* max_err);
+int group_info(const fmx_engine* e, int32_t* n, int32_t* shared, int32_t* peer_pairs, int32_t* peer_direct, int32_t* sparse_exchange);
+void debug_fail_next_comm_init();
 int use_device_public(int device);
 int alloc_matrix_public(int device, int64_t n, uint32_t p, int64_t nnz, bool labels, fmx_matrix** out);
 

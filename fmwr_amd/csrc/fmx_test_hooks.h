@@ -1,0 +1,17 @@
+/* Test hooks of libfmx.so -- NOT part of the C ABI (include/fmx.h).  The library exports them so that the GPU tests can arm a fault through ctypes;
+ * nothing in the library or its drivers calls them, each is one-shot, and none changes a result.  Kept out of the public header on purpose. */
+#ifndef FMX_TEST_HOOKS_H_
+#define FMX_TEST_HOOKS_H_
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* the next per-tile plan build of this process fails once with FMX_ERR_HIP, as an allocation failure halfway would (tests/test_gpu_api.py:
+ * a failed build leaves no half-built cache behind) */
+int fmx_debug_fail_next_plan_build(void);
+/* the next fmx_engine_create with cfg.n_gpus > 1 fails where the communicator is initialised -- after the other replicas were created -- as
+ * ncclCommInitAll failing on a later device would (tests/test_gpu_group.py: the error path tears everything down, the next create works) */
+int fmx_debug_fail_next_comm_init(void);
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMX_TEST_HOOKS_H_ */

@@ -147,9 +147,15 @@ class Source:
                                         C.c_int64(total_rows), C.byref(self.h)))
         self.batch_rows = int(engine.cfg.batch_rows)
         self.steps = -(-int(total_rows) // self.batch_rows)
+        # fmx_source holds a raw fmx_engine* and fmx_source_close waits on that engine's stream: the engine must outlive the source.  The source keeps
+        # it alive (so `Engine(...).source(...)` and interpreter shutdown order are safe) and registers itself so that Engine.close() closes it first.
+        self._engine = engine
+        engine._sources.append(self)
 
     def next(self):
-        """the next step's Matrix (a borrowed handle: never close it) or None at the end"""
+        """the next step's Matrix (a borrowed handle: never close it; it holds the source alive) or None at the end"""
+        if not self.h:
+            raise ValueError("the source is closed")
         mh, rows = C.c_void_p(), C.c_int64()
         L.check(L.lib().fmx_source_next(self.h, C.byref(mh), C.byref(rows)))
         if not mh.value:
@@ -157,14 +163,18 @@ class Source:
         m = Matrix._wrap(mh)
         m.close = lambda: None   # owned by the source
         m.__dict__["_borrowed"] = True
+        m.__dict__["_source"] = self
         return m
 
     def close(self):
         """waits for the engine's stream; returns the host seconds spent waiting for tiles' counts"""
         wait = C.c_double()
         if self.h:
-            L.check(L.lib().fmx_source_close(self.h, C.byref(wait)))
-            self.h = None
+            h, self.h = self.h, None
+            eng, self._engine = self._engine, None
+            if eng is not None and self in eng._sources:
+                eng._sources.remove(self)
+            L.check(L.lib().fmx_source_close(h, C.byref(wait)))
         return wait.value
 
     def __del__(self):
@@ -203,6 +213,7 @@ class Engine:
         self.p = int(num_features)
         self.k = int(cfg.num_factor)
         self.h = C.c_void_p()
+        self._sources = []   # open Source objects (they point at this engine)
         L.check(L.lib().fmx_engine_create(C.byref(cfg), C.c_uint64(self.p), C.byref(self.h)))
 
     def k_padded(self):
@@ -467,6 +478,13 @@ class Engine:
         L.check(L.lib().fmx_als_plan_info(self.h, m.h, C.byref(lv), C.byref(big), C.byref(ap), _p(lof)))
         return lv.value, big.value, bool(ap.value), lof[: self.p]
 
+    def group_info(self):
+        """a cfg.n_gpus handle: replicas, shared device or not, ordered device pairs / those with direct peer access, default exchange of sparse-tile steps"""
+        v = [C.c_int32() for _ in range(5)]
+        L.check(L.lib().fmx_group_info(self.h, *[C.byref(x) for x in v]))
+        return {"replicas": v[0].value, "share_one_device": bool(v[1].value), "device_pairs": v[2].value, "device_pairs_with_direct_peer_access": v[3].value,
+                "sparse_exchange": {0: "none", 1: "compact", 2: "owner"}.get(v[4].value, str(v[4].value))}
+
     def als_tiled(self, m):
         """(levels swept in the row-tiled form, rows per tile, tiles) for this matrix (fmx_als_tiled_info); (0, 0, 0): none."""
         lv, tr, nt = C.c_int32(), C.c_int64(), C.c_int32()
@@ -502,6 +520,11 @@ class Engine:
 
     def close(self):
         if self.h:
+            for src in list(getattr(self, "_sources", [])):   # their fmx_source points at this engine: close them while it exists
+                try:
+                    src.close()
+                except Exception:
+                    pass
             L.lib().fmx_engine_destroy(self.h)
             self.h = None
 

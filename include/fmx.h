@@ -451,6 +451,12 @@ int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double
  * sits inside its V row (fp32 mini-batch tables of at most 16 padded factors, from 3 M features up: out of the caches a nonzero then
  * costs one memory request instead of two; FMX_W_IN_ROW=0/1 in the environment overrides).  Never changes a result. */
 int fmx_layout_info(fmx_engine* e, int32_t* v_row_stride, int32_t* w_in_row);
+/* A cfg.n_gpus > 1 handle: replicas, whether they share one device (rehearsal), the ordered device pairs (a, b), a != b, and for how many of them
+ * direct peer access could be enabled at creation (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess: the shards, fmx_set_params and the
+ * owner-sharded exchange move data with peer copies, which go over xGMI only then), and the exchange a step of one sparse tile takes unless
+ * FMX_GROUP_EXCHANGE says otherwise (1: all-gather of the occurring features' records; 2: owner-sharded -- the default only where the replicas share
+ * a device until a run on two or more devices has confirmed it bitwise).  A one-GPU handle reports n = 1 and zeros. */
+int fmx_group_info(fmx_engine* e, int32_t* n_replicas, int32_t* share_device, int32_t* peer_pairs, int32_t* peer_pairs_direct, int32_t* sparse_exchange);
 /* RCCL smoke test for cfg.n_gpus > 1: loads librccl, ncclCommInitAll over devices 0..n-1, one grouped fp32 and fp64
  * all-reduce(sum) of 1000 elements per rank on per-device streams, checked against the closed form; max_err = largest deviation. */
 int fmx_rccl_selftest(int32_t n, double* max_err);
@@ -469,11 +475,6 @@ int fmx_measure_gather_occ(int device, int64_t table_bytes, int32_t row_bytes, i
  * served on-die) this, not the uniformly random probe, is the ceiling bench.py divides by. */
 int fmx_measure_gather_matrix(fmx_matrix* m, int64_t r0, int64_t nrows, int64_t table_rows, int32_t row_bytes, int32_t in_flight,
                               int32_t reps, double* rows_per_s);
-
-/* ---- test hook (tests/test_gpu_api.py): the next per-tile plan build of this process fails once with FMX_ERR_HIP, as an
- * allocation failure halfway would -- checks that a failed build leaves no half-built cache behind.  One shot; never armed by
- * the library itself. */
-int fmx_debug_fail_next_plan_build(void);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,12 @@ def test_exports_every_declared_symbol():
     lib = L.lib()
     for s in declared:
         assert hasattr(lib, s), s
+    # the test hooks live in an internal header, outside the ABI: exported, but not declared to callers
+    hooks = open(os.path.join(ROOT, "fmwr_amd", "csrc", "fmx_test_hooks.h")).read()
+    hooks = set(re.findall(r"\b(fmx_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hooks, flags=re.S)))
+    assert hooks == set(L.TEST_HOOKS) and not (hooks & declared)
+    for s in hooks:
+        assert hasattr(lib, s), s
 
 
 def test_config_struct_matches_header():

@@ -399,3 +399,25 @@ def test_gather_probes_answer_and_refuse():
         engine.measure_gather_matrix(m, 0, 200_000, p, 128)
     with pytest.raises(L.FmxError, match="geometry"):
         engine.measure_gather(1 << 20, 64, n_groups=1000, per_group=30)    # per_group must be a multiple of 8
+
+
+def test_a_source_keeps_its_engine_alive_and_the_engine_closes_its_sources():
+    """fmx_source holds a raw fmx_engine* (fmx_source_close waits on that engine's stream): the Python Source keeps the Engine alive, matrices it
+    hands out keep the Source, and Engine.close() closes open sources first (`Engine(...).source(...)`, shutdown order)."""
+    import gc
+    from fmwr_amd import _lib as L, engine
+    p = 3_000
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=4, mode=L.MODE_MINIBATCH, batch_rows=512)
+    src = engine.Engine(p, **kw).source(2048, nnz_per_row=6, seed=3)     # the engine has no other reference
+    gc.collect()
+    m = src.next()
+    assert m is not None and m.n == 512 and m._source is src
+    assert src.close() >= 0.0
+    e = engine.Engine(p, **kw)
+    s2 = e.source(1024, nnz_per_row=6, seed=4)
+    assert s2.next().n == 512
+    e.close()                      # closes s2 while the engine still exists
+    assert s2.h is None
+    with pytest.raises(ValueError):
+        s2.next()
+    assert s2.close() == 0.0       # idempotent

@@ -281,3 +281,45 @@ def test_group_shard_cache_is_keyed_by_the_matrix_not_its_address():
         e.sync()
         assert util.rel_err(g.get_params()[2], e.get_params()[2]) < 1e-11
         m.close()   # the next matrix may land on the same address
+
+
+def test_group_creation_failure_is_clean_and_group_info_reports_the_links():
+    """fm_group.hip at creation: (i) a communicator that fails to initialise AFTER the other replicas exist (forced through the test hook of
+    fmwr_amd/csrc/fmx_test_hooks.h; what ncclCommInitAll failing on a later device leaves behind) makes fmx_engine_create fail with a message and
+    tears down everything it built -- the next create works and trains; (ii) fmx_group_info: replicas, shared device or not, ordered device pairs
+    and how many got direct peer access (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess at creation), and the default exchange of sparse-tile
+    steps -- owner-sharded only where the replicas share a device (the validated rehearsal), the all-gather of records between distinct devices."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k, B = 4_000, 600, 4, 250
+    rp, col, val = util.random_csr(n, p, 6, seed=5, empty_rows=False)
+    y = util.labels(n, 5)
+    w0, w, v = util.params(p, k, 5)
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, learn_rate=0.05, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=B)
+    free0 = _free_bytes()
+    for _ in range(3):
+        L.check(L.lib().fmx_debug_fail_next_comm_init())
+        with pytest.raises(L.FmxError, match="ncclCommInitAll failed"):
+            engine.Engine(p, n_gpus=3, gpus_share_device=1, **kw)
+    assert _free_bytes() >= free0 - (8 << 20)          # the replicas made before the failure were destroyed (no table of theirs is left)
+    g = engine.Engine(p, n_gpus=3, gpus_share_device=1, **kw)   # the hook was one-shot
+    info = [C.c_int32() for _ in range(5)]
+    L.check(L.lib().fmx_group_info(g.h, *[C.byref(x) for x in info]))
+    assert [x.value for x in info] == [3, 1, 0, 0, 2]           # three replicas on one device: no device pairs; sparse steps owner-sharded
+    g.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert g.train(m, 6 * B * 3) == 6 * B * 3 and np.any(g.get_params()[2] != v)
+    one = engine.Engine(p, **kw)
+    L.check(L.lib().fmx_group_info(one.h, *[C.byref(x) for x in info]))
+    assert [x.value for x in info] == [1, 0, 0, 0, 0]
+    cnt = C.c_int32()
+    L.check(L.lib().fmx_device_count(C.byref(cnt)))
+    if cnt.value >= 2:   # distinct devices: every ordered pair is asked for peer access; the default for sparse tiles is the all-gather
+        d = engine.Engine(p, n_gpus=2, **kw)
+        L.check(L.lib().fmx_group_info(d.h, *[C.byref(x) for x in info]))
+        assert [x.value for x in info][:3] == [2, 0, 2] and 0 <= info[3].value <= 2 and info[4].value == 1
+
+
+def _free_bytes():
+    free, total = C.c_size_t(), C.c_size_t()
+    assert util.DevBuf.hip().hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value

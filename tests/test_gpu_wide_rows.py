@@ -129,11 +129,60 @@ def test_row_access_device_init_and_checkpoint(monkeypatch, tmp_path):
         return a, e.get_rows(ids)
     a, b = _both(monkeypatch, run)
     assert _same(a[0], b[0]) and np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
-    # a checkpoint written in one layout is refused by an engine in the other (the tables are stored as they lie on the device)
+
+
+def test_checkpoints_are_one_format_whatever_the_device_layout(monkeypatch, tmp_path):
+    """The w-in-row layout is a tuning choice (p, k, FMX_W_IN_ROW at engine creation) and stays out of the file: both layouts write the SAME bytes
+    (V[p][kp] then w[p], then the optimizer tables), either loads the other's file and continues bit for bit, and a round-3 file of a w-in-row
+    engine (header word reserved[1] = 1: rows of 2 kp floats with w inside, no w array) is still read by both."""
+    import struct
+    from fmwr_amd import _lib as L, engine
+    n, p, k = 2000, 900, 16
+    rp, col, val = util.random_csr(n, p, 7, seed=8)
+    y = util.labels(n, 8)
+    files, finals = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FMX_W_IN_ROW", flag)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        e = _engine(engine, L, p, "ftrl", k, batch_rows=500)
+        assert e.w_in_row() == (flag == "1")
+        e.init_normal(99, 0.0, 0.1)
+        e.set_rows(np.array([0, 17, 899], np.uint32), w=np.array([0.5, -0.25, 2.0]))
+        e.train(m, 1500)
+        path = tmp_path / f"ck{flag}.fmx"
+        e.save(path)
+        files[flag] = open(path, "rb").read()
+        e.train(m, 1000)
+        finals[flag] = e.get_params()
+    assert files["0"] == files["1"]
+    assert _same(finals["0"], finals["1"])
+    # a round-3 style file: header reserved[1] = 1, first table [p][2 kp] with w in slot kp, no w table
+    raw = files["0"]
+    hdr, scal = raw[:64], raw[64:64 + 12 * 8]
+    kp = 16
+    body = raw[64 + 12 * 8:]
+    V = np.frombuffer(body[: p * kp * 4], np.float32).reshape(p, kp)
+    w = np.frombuffer(body[p * kp * 4: p * kp * 4 + p * 4], np.float32)
+    rest = body[p * kp * 4 + p * 4:]
+    wide = np.zeros((p, 2 * kp), np.float32); wide[:, :kp] = V; wide[:, kp] = w
+    words = list(struct.unpack("<4sIQiiiiI7I", hdr))
+    assert words[8] == 0 and words[9] == 0          # fp32 state, canonical layout
+    words[9] = 1
+    legacy = tmp_path / "legacy.fmx"
+    open(legacy, "wb").write(struct.pack("<4sIQiiiiI7I", *words) + scal + wide.tobytes() + rest)
+    for src in ("ck0.fmx", "ck1.fmx", "legacy.fmx"):
+        for flag in ("0", "1"):
+            monkeypatch.setenv("FMX_W_IN_ROW", flag)
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            f = _engine(engine, L, p, "ftrl", k, batch_rows=500)
+            f.load(tmp_path / src)
+            f.train(m, 1000)
+            assert _same(f.get_params(), finals["0"]), (src, flag)
+    # a file of another shape is refused, and the message names what differs
     monkeypatch.setenv("FMX_W_IN_ROW", "0")
-    f = _engine(engine, L, p, "ftrl", k, batch_rows=500)
+    g = _engine(engine, L, p, "ftrl", 8, batch_rows=500)
     with pytest.raises(L.FmxError, match="does not match"):
-        f.load(tmp_path / "ck.fmx")
+        g.load(tmp_path / "ck0.fmx")
 
 
 def test_rows_wider_than_64_bytes_keep_the_separate_tables(monkeypatch):
