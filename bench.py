@@ -44,7 +44,9 @@ def parse(argv=None):
                     help="mini-batch rows per GPU per step (processed in cache-resident tiles).  0: SGD on one GPU 262144 -- the largest step "
                          "that learns per example like a 4096-row one at the reference's learning rate on this workload (a coordinate then "
                          "occurs ~8 times per step; profiles/r02_learning_*.txt) -- and 1048576 per GPU for FTRL and for N > 1, where the step "
-                         "must be long enough to hide the exchange of the 72 MB buffer (the global batch is N times larger either way)")
+                         "must be long enough to hide the exchange of the 72 MB buffer; the SGD learning rate then follows the global batch linearly "
+                         "(learn_rate_for: profiles/r04_learning_scaling.txt shows the held-out loss per example kept up to 8.4 M rows per step), and the one-GPU "
+                         "line carries `scaling_reference`, ONE GPU at that step size")
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile (0: the engine's default, 524288; 262144 for k <= 8)")
     ap.add_argument("--solver", choices=["sgd", "ftrl", "als", "mcmc"], default="sgd",
                     help="als / mcmc: BASELINE.json configs[4], the V-column sweep of MCMC_ALS_Learner::update_v over the same matrix (k = 16); a step is "
@@ -248,9 +250,19 @@ def cpu_baseline(m, args, v0):
     return out
 
 
+LR_BASE, LR_BASE_ROWS = 0.01, 262_144
+
+
+def learn_rate_for(global_rows):
+    """SGD with the MEAN gradient per coordinate per step: the reference's learning rate (0.01) holds up to 262 144 rows per step; beyond, the step is scaled
+    LINEARLY with the global batch -- profiles/r04_learning_scaling.txt: held-out log-likelihood after three passes -0.633 at 262 144 rows / lr 0.01 and
+    -0.633 / -0.635 / -0.640 / -0.640 / -0.641 at 2x / 4x / 8x / 16x / 32x the rows with 2x ... 32x the rate (unscaled: -0.658 ... -0.691; sqrt scaling: -0.647 ... -0.681)."""
+    return LR_BASE * max(1.0, global_rows / LR_BASE_ROWS)
+
+
 def engine_kwargs(args, L, B, local_rank, world, **over):
     ftrl = args.solver == "ftrl"
-    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_FTRL if ftrl else L.SOLVER_SGD, num_factor=args.factors, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4,
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_FTRL if ftrl else L.SOLVER_SGD, num_factor=args.factors, learn_rate=learn_rate_for(B * world), l2_w1=1e-4, l2_v=1e-4,
               l1_w1=1e-4 if ftrl else 0.0, l1_v=1e-4 if ftrl else 0.0, mode=L.MODE_MINIBATCH, batch_rows=B, tile_rows=args.tile_rows, device=local_rank,
               keep_w1=0 if args.no_linear else 1, state_fp64=int(args.state_fp64),
               exchange_chunks=(args.exchange_chunks or (8 if world == 2 else 4)) if world > 1 else 0)
@@ -343,7 +355,43 @@ def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_
     timed_steps(ei, mi, nbi, 16, 2)   # schedule trials
     out["value_iid_uniform"] = {"value": B * args.steps / timed_steps(ei, mi, nbi, args.steps, 2), "unit": "examples/s",
                                 "note": "the same configuration on fmx_matrix_synthetic_iid (columns i.i.d. uniform over [0, p), sorted inside the row: SURVEY 8(d)'s generator)"}
+    ei.profile_reset(); ei.profile(5)
+    t_iid = timed_steps(ei, mi, nbi, args.steps, 0)
+    ei.profile(0)
+    iid_k = {name: ms / max(cnt, 1) for name, (ms, cnt) in (("fm_rows_forward", ei.profile_get(L.KERNEL_ROWS_FORWARD)), ("fm_cols_update", ei.profile_get(L.KERNEL_COLS_UPDATE)))}
     ei.close(); mi.close()
+    # SURVEY 8(d)'s ragged variant: row lengths Poisson(z) clipped to [1, 64], the same column law.  The kernels give every row a fixed lane group that walks
+    # the row in rounds of RU entries (padded with x = 0): what that costs against rows of exactly z entries is the ratio of the two ENTRY rates
+    mr = engine.Matrix.synthetic_ragged(n, p, float(z), args.seed)
+    er = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
+    er.set_params(0.0, None, v0.astype(np.float64))
+    nbr = max(1, n // B)
+    timed_steps(er, mr, nbr, 16, 2)   # schedule trials
+    er.profile_reset(); er.profile(5)
+    t_rag = timed_steps(er, mr, nbr, args.steps, 2)
+    er.profile(0)
+    rag_k = {name: ms / max(cnt, 1) for name, (ms, cnt) in (("fm_rows_forward", er.profile_get(L.KERNEL_ROWS_FORWARD)), ("fm_cols_update", er.profile_get(L.KERNEL_COLS_UPDATE)))}
+    mean_len = mr.nnz / mr.n
+    v_rag, v_iid = B * args.steps / t_rag, B * args.steps / t_iid
+    out["value_ragged_rows"] = {"value": v_rag, "unit": "examples/s", "nnz_per_row": {"law": f"Poisson({z}) clipped to [1, 64]", "mean": mean_len},
+                                "entries_per_s": v_rag * mean_len, "fixed_length_entries_per_s": v_iid * z, "entry_rate_vs_fixed_length_rows": (v_rag * mean_len) / (v_iid * z),
+                                "kernel_ms": rag_k, "fixed_length_kernel_ms": iid_k,
+                                "note": "fmx_matrix_synthetic_ragged against fmx_matrix_synthetic_iid (rows of exactly z entries, same column law), same engine configuration; "
+                                        "HIP events around every 5th launch"}
+    er.close(); mr.close()
+    # the like-for-like origin of a 1 -> N curve: N > 1 runs 1 048 576 rows per GPU per step (the step has to hide the exchange of the 72 MB buffer), the headline
+    # line 262 144; this is ONE GPU at the N > 1 step size, same learning-rate rule
+    Bn = 1_048_576
+    if args.solver == "sgd" and args.batch_rows != Bn and n >= 4 * Bn:
+        ms_ = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=0)
+        es_ = engine.Engine(p, **engine_kwargs(args, L, Bn, 0, 1))
+        es_.set_params(0.0, None, v0.astype(np.float64))
+        nbs_ = n // Bn
+        timed_steps(es_, ms_, nbs_, 16, 2)
+        steps_ = max(8, args.steps // 2)
+        out["scaling_reference"] = {"value": Bn * steps_ / timed_steps(es_, ms_, nbs_, steps_, 2), "unit": "examples/s", "batch_rows_per_gpu": Bn, "learn_rate": learn_rate_for(Bn),
+                                    "note": "one GPU at the per-GPU step size that `bench.py --gpus N` (N > 1) runs: divide the N-GPU values by THIS figure for a like-for-like efficiency"}
+        es_.close(); ms_.close()
     if args.state_fp64:
         return out
     # the reference's precision in the throughput mode
@@ -864,6 +912,8 @@ def run_minibatch(args, rank, local_rank, world):
                        **({"features_occurring_per_step": p_walk} if (criteo or sparse_tiles) else {}),
                        "batch_rows_per_gpu": B, "tile_rows": tile_rows, "global_batch_rows": rows_step, "rows_per_gpu": n_local,
                        "batch_reduce": "mean gradient per coordinate per step (FMX_REDUCE_MEAN)",
+                       **({} if ftrl else {"learn_rate": learn_rate_for(rows_step), "learn_rate_rule": "0.01 x max(1, global rows per step / 262144): linear scaling keeps the held-out loss per "
+                                                                                                     "example of the one-GPU step up to 32x the rows (profiles/r04_learning_scaling.txt)"}),
                        "state": ("fp64" if args.state_fp64 else "fp32") + " V[p][k] + w[p]" + (" + z, n" if ftrl else "") + ", fp64 accumulation",
                        "rows_forward_schedule": dict(zip(("serial", "ms_serial_x6", "ms_pipelined_x6"), e.rows_tune())),
                        "parallelism": f"dp{world}",

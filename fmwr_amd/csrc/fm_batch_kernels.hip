@@ -266,11 +266,31 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
 
   FMX_STAMP(0);
   const int tid = threadIdx.x;
-  const int gid = (tid / LPR) / SPLIT;  // row of the workgroup
+  int gid = (tid / LPR) / SPLIT;        // row of the workgroup
   const int sub = (tid / LPR) % SPLIT;  // this lane group's part of the row
   const int lig = tid % LPR;
   const int64_t R0 = (int64_t)blockIdx.x * RPW;
   const int64_t R1 = (R0 + RPW < a.nrows) ? R0 + RPW : a.nrows;
+  if constexpr (SPLIT == 1 && RPW > 64 / LPR) {
+    // Ragged rows (Poisson(30) clipped to [1, 64]): a wave's 64 / LPR lane groups walk their rows in lockstep rounds of RU entries, so a wave
+    // takes as many rounds as its LONGEST row -- measured 18 % of phase 1 at the survey's law (bench `value_ragged_rows`).  The workgroup's rows are dealt to
+    // its lane groups by DESCENDING length (rank by counting, RPW <= 128 lengths in LDS), so that every wave holds rows of similar length.  A row is still
+    // walked by ONE lane group, entries in row order, and every per-row result is stored under the row's own index: same bits as the identity assignment.
+    if (a.sort_rows) {
+      __shared__ int len_of[RPW];
+      __shared__ unsigned char row_at[RPW];
+      if (tid < RPW) { const int64_t r = R0 + tid; len_of[tid] = r < a.nrows ? (int)(a.row_ptr[a.r0 + r + 1] - a.row_ptr[a.r0 + r]) : -1; }
+      __syncthreads();
+      if (tid < RPW) {
+        const int mine = len_of[tid];
+        int rank = 0;
+        for (int j = 0; j < RPW; ++j) { const int o = len_of[j]; rank += (o > mine || (o == mine && j < tid)) ? 1 : 0; }
+        row_at[rank] = (unsigned char)tid;
+      }
+      __syncthreads();
+      gid = row_at[gid];
+    }
+  }
   const int64_t lo = a.row_ptr[a.r0 + R0];
   const int64_t hi = a.row_ptr[a.r0 + R1];
   const int64_t row = R0 + gid;

@@ -1274,6 +1274,10 @@ void merge_result(const fmx_engine* e, const uint32_t** pos, const uint32_t** ro
 int build_full_csc(fmx_matrix* m, hipStream_t stream) {
   if (m->col_ptr) return FMX_OK;
   FMX_CHECK(m->n < (1LL << 32), FMX_ERR_INVALID, "ALS sweep supports fewer than 2^32 rows");
+  // one sort over ALL entries and u32 row ids per column list: verified up to 3e8 entries; beyond 2^32 the whole-matrix CSC is refused, not built on trust
+  // (the mini-batch path has no whole-matrix structure: its plans are per tile -- tests/test_gpu_nnz_2p32.py)
+  FMX_CHECK(m->nnz < (1LL << 32), FMX_ERR_INVALID, "the ALS / MCMC sweeps and column scaling need the CSC of the whole matrix, which is limited to fewer than 2^32 stored entries (this one: %lld)",
+            (long long)m->nnz);
   FMX_HIP(hipSetDevice(m->device));
   FMX_HIP(hipMalloc(&m->col_ptr, ((size_t)m->p + 1) * sizeof(int64_t)));
   FMX_HIP(hipMalloc(&m->crow, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(uint32_t)));
@@ -1404,6 +1408,78 @@ int generate_iid_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64
   if (n > 0) hipLaunchKernelGGL(synth_iid_rows_k, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, stream, n, m->p, z, seed, row_offset, kind, s_exp, m->col, m->val);
   hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, n, z, seed, row_offset, m->row_ptr, m->y);
   FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// SURVEY 8(d)'s ragged variant: "nnz/row = Poisson(30) clipped to [1, 64]", columns i.i.d. uniform over [0, p), sorted inside the row (repeats bumped).
+// Lengths by inversion of the Poisson CDF on one Philox word keyed (seed; global row): shard independent like every generator here.
+__global__ void synth_ragged_len_k(int64_t n, double mean, int lo, int hi, uint64_t seed, int64_t row_offset, int64_t* __restrict__ lens) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r == n) { lens[r] = 0; return; }
+  const uint64_t g = (uint64_t)(row_offset + r);
+  const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 0x4A66EDu, 0x11Du, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const double u = ((double)ph.c[0] + 0.5) / 4294967296.0;
+  int kq = 0;
+  double term = exp(-mean), cdf = term;
+  while (u > cdf && kq < 4 * hi + 64) { ++kq; term *= mean / (double)kq; cdf += term; }
+  lens[r] = kq < lo ? lo : (kq > hi ? hi : kq);
+}
+__global__ void synth_ragged_rows_k(int64_t n, uint32_t p, uint64_t seed, int64_t row_offset, const int64_t* __restrict__ row_ptr, uint32_t* __restrict__ col,
+                                    float* __restrict__ val, float* __restrict__ y) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t g = (uint64_t)(row_offset + r);
+  const int64_t b = row_ptr[r];
+  const int z = (int)(row_ptr[r + 1] - b);
+  uint32_t c[SYNTH_MAX_Z];
+  for (int i = 0; i < z; i += 4) {
+    const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(i >> 2), 0x11Du, (uint32_t)seed, (uint32_t)(seed >> 32));
+    for (int q = 0; q < 4 && i + q < z; ++q) {
+      uint32_t id = (uint32_t)(((uint64_t)ph.c[q] * p) >> 32);
+      int j = i + q;
+      while (j > 0 && c[j - 1] > id) { c[j] = c[j - 1]; --j; }
+      c[j] = id;
+    }
+  }
+  for (int i = 1; i < z; ++i) if (c[i] <= c[i - 1]) c[i] = c[i - 1] + 1;
+  if (z > 0 && c[z - 1] >= p) { c[z - 1] = p - 1; for (int i = z - 2; i >= 0 && c[i] >= c[i + 1]; --i) c[i] = c[i + 1] - 1; }
+  for (int i = 0; i < z; ++i) { col[b + i] = c[i]; val[b + i] = 1.0f; }
+  const Philox pl = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 0xFFFFFFFFu, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  y[r] = (pl.c[0] & 1u) ? 1.0f : -1.0f;
+}
+
+int generate_ragged(int device, int64_t n, uint32_t p, double mean, int lo, int hi, uint64_t seed, int64_t row_offset, fmx_matrix** out) {
+  *out = nullptr;
+  FMX_TRY(use_device_public(device));
+  int64_t *d_len = nullptr, *d_ptr = nullptr;
+  void* d_tmp = nullptr;
+  fmx_matrix* m = nullptr;
+  auto body = [&]() -> int {
+    FMX_HIP(hipMalloc(&d_len, ((size_t)n + 1) * sizeof(int64_t)));
+    FMX_HIP(hipMalloc(&d_ptr, ((size_t)n + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(synth_ragged_len_k, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, nullptr, n, mean, lo, hi, seed, row_offset, d_len);
+    size_t bytes = 0;
+    FMX_HIP(rocprim::exclusive_scan(nullptr, bytes, d_len, d_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), nullptr));
+    FMX_HIP(hipMalloc(&d_tmp, bytes ? bytes : 16));
+    FMX_HIP(rocprim::exclusive_scan(d_tmp, bytes, d_len, d_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), nullptr));
+    int64_t total = 0;
+    FMX_HIP(hipMemcpy(&total, d_ptr + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    FMX_TRY(alloc_matrix_public(device, n, p, total, true, &m));
+    FMX_HIP(hipMemcpy(m->row_ptr, d_ptr, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice));
+    if (n > 0) hipLaunchKernelGGL(synth_ragged_rows_k, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, nullptr, n, p, seed, row_offset, (const int64_t*)m->row_ptr, m->col, m->val, m->y);
+    FMX_HIP(hipGetLastError());
+    FMX_HIP(hipDeviceSynchronize());
+    m->rows_sorted = 1;
+    m->max_row_len = hi;
+    m->fixed_row_len = 0;
+    { const char* v = getenv("FMX_UNIT_VALUES"); m->unit_values = !(v && v[0] == '0'); }
+    return FMX_OK;
+  };
+  const int st = body();
+  (void)hipFree(d_len); (void)hipFree(d_ptr); (void)hipFree(d_tmp);
+  if (st != FMX_OK) { free_matrix(m); return st; }
+  *out = m;
   return FMX_OK;
 }
 

@@ -262,6 +262,7 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
   a.link = link;
   a.pn_y = e->probit;
   a.unit = m->unit_values;
+  a.sort_rows = rows_ragged(m);
   FMX_TRY(launch_rows_forward(e, a, false, wide_state(e)));
   return FMX_OK;
 }
@@ -336,6 +337,7 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t st
   a.amul = (char*)e->amul + (size_t)s_row0 * mb_elem(e);
   a.partials = e->partials + 2 * partial_offset;
   a.unit = m->unit_values;
+  a.sort_rows = rows_ragged(m);
   a.wg_threads = rows_wg_threads(step_rows, mb_lpr(e));
   a.split = rows_split(step_rows, mb_lpr(e));
   const int rpw = a.wg_threads / (mb_lpr(e) * (a.wg_threads == 64 && a.split == 4 ? 4 : 1));
@@ -1070,6 +1072,15 @@ int fmx_matrix_synthetic_iid(int device, int64_t n, uint32_t p, int32_t nnz_per_
   { const char* v = getenv("FMX_UNIT_VALUES"); m->unit_values = !(v && v[0] == '0'); }
   *out = m;
   return FMX_OK;
+}
+
+int fmx_matrix_synthetic_ragged(int device, int64_t n, uint32_t p, double mean_nnz, int32_t min_nnz, int32_t max_nnz, uint64_t seed, int64_t row_offset,
+                                fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(n >= 0 && mean_nnz > 0.0 && mean_nnz <= 64.0 && min_nnz >= 0 && min_nnz <= max_nnz && max_nnz <= 64 && (uint32_t)max_nnz <= p, FMX_ERR_INVALID,
+            "need 0 < mean_nnz <= 64 and 0 <= min_nnz <= max_nnz <= min(64, p)");
+  return generate_ragged(device, n, p, mean_nnz, min_nnz, max_nnz, seed, row_offset, out);
 }
 
 int fmx_matrix_set_labels(fmx_matrix* m, const float* y) {

@@ -80,6 +80,14 @@ class Matrix:
         return cls._wrap(h)
 
     @classmethod
+    def synthetic_ragged(cls, n, p, mean_nnz, seed, min_nnz=1, max_nnz=64, row_offset=0, device=0):
+        """Row lengths Poisson(mean_nnz) clipped to [min_nnz, max_nnz], i.i.d. uniform sorted columns (fmx_matrix_synthetic_ragged: SURVEY 8(d)'s ragged variant)."""
+        h = C.c_void_p()
+        L.check(L.lib().fmx_matrix_synthetic_ragged(C.c_int(device), C.c_int64(n), C.c_uint32(p), C.c_double(mean_nnz), C.c_int32(min_nnz), C.c_int32(max_nnz),
+                                                    C.c_uint64(seed), C.c_int64(row_offset), C.byref(h)))
+        return cls._wrap(h)
+
+    @classmethod
     def synthetic_fields(cls, n, n_dense, field_vocab, skew, seed, row_offset=0, device=0):
         """Criteo-shaped rows: n_dense always-present features + one feature of each categorical field (fmx_matrix_synthetic_fields)."""
         spec, keep = fields_spec(n_dense, field_vocab, skew, seed)

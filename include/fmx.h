@@ -204,6 +204,10 @@ int fmx_matrix_set_labels(fmx_matrix* m, const float* y);
 #define FMX_COLUMNS_ZIPF 2
 int fmx_matrix_synthetic_iid(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, int32_t law,
                              double zipf_s, fmx_matrix** out);
+/* SURVEY 8(d)'s ragged variant: row lengths Poisson(mean_nnz) clipped to [min_nnz, max_nnz] (the survey's "Poisson(30) clipped to [1, 64]"), columns
+ * i.i.d. uniform over [0, p), sorted inside the row, repeats bumped; values 1, labels +-1; shard independent (keyed by the global row). */
+int fmx_matrix_synthetic_ragged(int device, int64_t n, uint32_t p, double mean_nnz, int32_t min_nnz, int32_t max_nnz, uint64_t seed, int64_t row_offset,
+                                fmx_matrix** out);
 int fmx_matrix_destroy(fmx_matrix* m);
 int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz);
 /* Copy rows [r0, r1) back to the host (row_ptr is rebased to 0); any pointer may be NULL. */

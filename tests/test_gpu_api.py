@@ -421,3 +421,61 @@ def test_a_source_keeps_its_engine_alive_and_the_engine_closes_its_sources():
     with pytest.raises(ValueError):
         s2.next()
     assert s2.close() == 0.0       # idempotent
+
+
+def test_the_ragged_generator_and_training_on_its_rows_against_the_oracle():
+    """fmx_matrix_synthetic_ragged (SURVEY 8(d)'s variant: row lengths Poisson(30) clipped to [1, 64]): lengths in range with the clipped law's mean, rows
+    strictly ascending, shard independent; and the hot path on such rows -- forward and three mini-batch steps -- equals the oracle on the exported rows
+    (the kernels walk a row in padded rounds of a fixed lane group: ragged lengths exercise every padding count)."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k = 6_000, 5_000, 16
+    m = engine.Matrix.synthetic_ragged(n, p, 30.0, seed=9)
+    rp, col, val, y = m.export()
+    lens = np.diff(rp)
+    assert lens.min() >= 1 and lens.max() <= 64 and abs(lens.mean() - 30.0) < 0.5 and 4.5 < lens.std() < 6.5
+    assert len(set(lens.tolist())) > 25
+    for i in range(0, n, 97):
+        c = col[rp[i]:rp[i + 1]]
+        assert np.all(np.diff(c.astype(np.int64)) > 0) and c[-1] < p
+    assert np.all(val == 1.0) and set(np.unique(y).tolist()) <= {-1.0, 1.0}
+    tail = engine.Matrix.synthetic_ragged(1_000, p, 30.0, seed=9, row_offset=5_000)     # rows 5000.. of the same stream
+    rp2, col2, _, y2 = tail.export()
+    assert np.array_equal(np.diff(rp2), lens[5_000:]) and np.array_equal(col2, col[rp[5_000]:]) and np.array_equal(y2, y[5_000:])
+    with pytest.raises(L.FmxError):
+        engine.Matrix.synthetic_ragged(10, p, 30.0, seed=1, min_nnz=5, max_nnz=80)
+    w0, w, v = util.params(p, k, 9)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.CLASSIFICATION, k=k, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.05)
+    e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, l2_w1=1e-4, l2_v=1e-4, learn_rate=0.05, mode=L.MODE_MINIBATCH, batch_rows=2_000)
+    e.set_params(w0, w, v)
+    np.testing.assert_allclose(e.predict(m), oracle.predict_batch(P, X, w0, w, v.ravel()), rtol=0, atol=1e-5)
+    e.train(m, n)
+    mb = oracle.SgdMinibatch(P, X, y, w0, w, v.ravel())
+    for b in range(0, n, 2_000):
+        mb.step(b, b + 2_000)
+    gw0, gw, gv = e.get_params()
+    assert util.rel_err(gv, mb.v.reshape(k, p)) < 1e-5 and util.rel_err(gw, mb.w) < 1e-5 and abs(gw0 - mb.w0.value) < 1e-5
+
+
+def test_dealing_rows_to_lane_groups_by_length_changes_no_bit(monkeypatch):
+    """Phase 1 on rows of differing lengths deals a workgroup's rows to its lane groups by descending length (a wave takes as many gather rounds as its longest
+    row); a row is still walked by one lane group in row order and stored under its own index: FMX_SORT_ROWS=0 (identity assignment) gives the same bits --
+    forward, S rows and w0 partial sums (through three training steps), fp32 and fp64 state, k = 8 (two lanes per row) and k = 16."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 70_000, 4_000          # >= 512 wide workgroups: the 256-thread form, 64 (or 128) rows per workgroup
+    for k, wide in ((16, 0), (8, 0), (16, 1)):
+        rp, col, val = util.random_csr(n, p, 12, seed=31 + k, empty_rows=True)
+        y = util.labels(n, 31)
+        w0, w, v = util.params(p, k, 31)
+        out = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("FMX_SORT_ROWS", flag)
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, l2_w1=1e-4, l2_v=1e-4, learn_rate=0.05, mode=L.MODE_MINIBATCH, batch_rows=n // 2,
+                              state_fp64=wide)
+            e.set_params(w0, w, v)
+            pred = e.predict(m)
+            e.train(m, n + n // 2)
+            out.append((pred, e.get_params()))
+        assert np.array_equal(out[0][0], out[1][0])
+        assert out[0][1][0] == out[1][1][0] and np.array_equal(out[0][1][1], out[1][1][1]) and np.array_equal(out[0][1][2], out[1][1][2])
