@@ -266,31 +266,11 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
 
   FMX_STAMP(0);
   const int tid = threadIdx.x;
-  int gid = (tid / LPR) / SPLIT;        // row of the workgroup
+  const int gid = (tid / LPR) / SPLIT;  // row of the workgroup
   const int sub = (tid / LPR) % SPLIT;  // this lane group's part of the row
   const int lig = tid % LPR;
   const int64_t R0 = (int64_t)blockIdx.x * RPW;
   const int64_t R1 = (R0 + RPW < a.nrows) ? R0 + RPW : a.nrows;
-  if constexpr (SPLIT == 1 && RPW > 64 / LPR) {
-    // Ragged rows (Poisson(30) clipped to [1, 64]): a wave's 64 / LPR lane groups walk their rows in lockstep rounds of RU entries, so a wave
-    // takes as many rounds as its LONGEST row -- measured 18 % of phase 1 at the survey's law (bench `value_ragged_rows`).  The workgroup's rows are dealt to
-    // its lane groups by DESCENDING length (rank by counting, RPW <= 128 lengths in LDS), so that every wave holds rows of similar length.  A row is still
-    // walked by ONE lane group, entries in row order, and every per-row result is stored under the row's own index: same bits as the identity assignment.
-    if (a.sort_rows) {
-      __shared__ int len_of[RPW];
-      __shared__ unsigned char row_at[RPW];
-      if (tid < RPW) { const int64_t r = R0 + tid; len_of[tid] = r < a.nrows ? (int)(a.row_ptr[a.r0 + r + 1] - a.row_ptr[a.r0 + r]) : -1; }
-      __syncthreads();
-      if (tid < RPW) {
-        const int mine = len_of[tid];
-        int rank = 0;
-        for (int j = 0; j < RPW; ++j) { const int o = len_of[j]; rank += (o > mine || (o == mine && j < tid)) ? 1 : 0; }
-        row_at[rank] = (unsigned char)tid;
-      }
-      __syncthreads();
-      gid = row_at[gid];
-    }
-  }
   const int64_t lo = a.row_ptr[a.r0 + R0];
   const int64_t hi = a.row_ptr[a.r0 + R1];
   const int64_t row = R0 + gid;
@@ -406,6 +386,155 @@ __global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
   }
 }
 
+// ---- phase 1 on rows of differing lengths (opt-in: FMX_ROWS_PULL=1) ---------------------------------------------------------------------
+// fm_rows_forward_k gives every lane group ONE row of its workgroup; a group idles once its row is done, and the workgroup's slot is held until its
+// longest row is.  On SURVEY 8(d)'s ragged law (row lengths Poisson(30) clipped to [1, 64]) phase 1 takes 18 % longer than on rows of exactly 30
+// entries (bench `value_ragged_rows`; profiles/r04_ragged_probe.txt: 0.169 ms per tile for lengths 30..30, 0.178 for 25..35, 0.196 for the Poisson
+// law).  Two balancing forms were built, both bit for bit the static kernel, and NEITHER pays (profiles/r04_ragged_probe2.txt):
+//   * dealing a workgroup's rows to its lane groups by descending length (every wave then holds rows of similar length): 0.1967 against 0.1943 ms --
+//     the kernel is bound by requests in flight, not by instruction issue, and a workgroup still lives as long as its longest row (removed again);
+//   * THIS kernel: the lane groups of a workgroup PULL rows from a counter (256 rows for 64 groups at k = 16), so every group walks entries until
+//     the workgroup's rows are exhausted.  Rows pulled out of order cannot use the coalesced LDS stage: lane l of a group loads entry t + l of a round
+//     itself and the group shares the round by shuffles -- two more gather-shaped instructions per round, which cost more (rows of exactly 30 entries:
+//     0.188 against 0.169 ms) than the balance returns (Poisson law: 0.221 against 0.194).  Kept opt-in with its bitwise test as the record.
+// What would pay is the flat form (a workgroup's staged entries cut evenly over the lane groups, row boundaries by ballot, a segmented combine in a fixed
+// order): not built -- it changes the association of a row's sums (the bits), for 8 % of a ragged step.
+// A row is walked by ONE lane group, entries in row order, fp64 accumulators, every per-row result stored under the row's own index; the w0 partial
+// sums keep the static kernel's granularity (GROUPS rows each, in row order).
+template <typename T, int LPR, bool TRAIN>
+__global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_dyn_k(RowsArgs a, Hyper h) {
+  using vec_t = typename Slice<T>::vec;
+  constexpr int VEC = Slice<T>::N;
+  constexpr int KP = LPR * VEC;
+  constexpr int GROUPS = WG_THREADS / LPR;   // lane groups = rows of one static workgroup = rows of one w0 partial sum
+  constexpr int RPW = 4 * GROUPS;            // rows one workgroup pulls from
+  constexpr int RU = FMX_U_LARGE;            // entries per round
+  constexpr int PER = (RU + LPR - 1) / LPR;  // entries a lane loads per round
+  __shared__ int next_row;
+  __shared__ double red[TRAIN ? RPW : 1];
+  const int tid = threadIdx.x;
+  const int grp = tid / LPR, lig = tid % LPR;
+  const int lane0 = (tid & 63) - lig;        // first lane of this group inside its wave
+  const int64_t R0 = (int64_t)blockIdx.x * RPW;
+  const int rows_here = (int)((R0 + RPW < a.nrows ? R0 + RPW : a.nrows) - R0);
+  if (tid == 0) next_row = GROUPS;
+  if (TRAIN) for (int i = tid; i < RPW; i += WG_THREADS) red[i] = 0.0;
+  __syncthreads();
+  const T* __restrict__ Vt = reinterpret_cast<const T*>(a.V) + lig * VEC;
+  const T* __restrict__ wt = a.w ? reinterpret_cast<const T*>(a.w) : reinterpret_cast<const T*>(a.V);
+  const bool k1 = h.k1 != 0;
+  const int64_t last = a.row_ptr[a.r0 + R0 + rows_here] - 1;   // last entry of the workgroup's rows (clamp for the loads past a row's end)
+  int r = grp;
+  while (r < rows_here) {
+    const int64_t ta = a.row_ptr[a.r0 + R0 + r], tb = a.row_ptr[a.r0 + R0 + r + 1];
+    double s[VEC], q[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s[i] = 0.0; q[i] = 0.0; }
+    double lin = h.k0 ? a.scal[SC_W0] : 0.0;  // core/Model.h:77-78
+    // this lane's share of a round: entries t + lig, t + lig + LPR, ... (index clamped, value selected afterwards: no load under a condition)
+    auto load_round = [&](int64_t t, uint32_t* id, uint32_t* xb) {
+#pragma unroll
+      for (int v = 0; v < PER; ++v) {
+        const int64_t at = t + lig + v * LPR;
+        const int64_t ac = at <= last ? (at >= 0 ? at : 0) : (last >= 0 ? last : 0);
+        id[v] = a.col[ac];
+        xb[v] = a.unit ? 0x3f800000u : __float_as_uint(a.val[ac]);
+      }
+    };
+    uint32_t cid[PER], cxb[PER], nid[PER], nxb[PER];
+    load_round(ta, cid, cxb);
+    for (int64_t t = ta; t < tb; t += RU) {
+      load_round(t + RU, nid, nxb);            // the next round's entries are on their way while this round gathers
+      uint2 en[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        en[u].x = (uint32_t)__shfl((int)cid[u / LPR], lane0 + (u % LPR));
+        en[u].y = (uint32_t)__shfl((int)cxb[u / LPR], lane0 + (u % LPR));
+      }
+#pragma unroll
+      for (int u = 1; u < RU; ++u)
+        if (t + u >= tb) en[u] = make_uint2(en[0].x, 0u);  // x = +0.0f pads
+      vec_t vv[RU];
+      T wv[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        vv[u] = gather_row(Vt + ((size_t)en[u].x << RowStride<T, LPR>::v(a.vsh)));
+        wv[u] = wt[(size_t)en[u].x << RowStride<T, LPR>::w(a.wsh)];
+        if (a.serial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {  // nonzeros in row order: same association as core/Model.h:83-97
+        const double x = (double)__uint_as_float(en[u].y);
+        if (k1) lin += (double)wv[u] * x;
+        double vf[VEC];
+        slice_get(vv[u], vf);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const double tmp = vf[i] * x;
+          s[i] += tmp;
+          q[i] += tmp * tmp;
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < PER; ++v) { cid[v] = nid[v]; cxb[v] = nxb[v]; }
+    }
+    double pair = 0.0;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) pair += 0.5 * (s[i] * s[i] - q[i]);  // core/Model.h:100
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) pair += __shfl_xor(pair, off);
+    const double y_hat = lin + pair;
+    const int64_t row = R0 + r;
+    if constexpr (TRAIN) {
+      const double mult = grad_mult(h, y_hat, a.y[a.r0 + row]);
+      vec_t srow = slice_make(s, T());
+      if constexpr (sizeof(T) == 4) srow = embed_store<LPR>(srow, lig, (float)mult, a.embed);
+      *reinterpret_cast<vec_t*>(reinterpret_cast<T*>(a.S) + (size_t)row * KP + lig * VEC) = srow;
+      if (lig == 0) { reinterpret_cast<T*>(a.amul)[row] = (T)mult; red[r] = mult; }
+    } else {
+      if (lig == 0 && a.yhat) a.yhat[row] = link_apply(h, y_hat, a.link, a.pn_y);
+      if constexpr (sizeof(T) == 8) {
+        if (a.qout) {
+          if (a.qout_t > 0) { a.qout[(size_t)(lig * VEC) * a.qout_t + row] = s[0]; a.qout[(size_t)(lig * VEC + 1) * a.qout_t + row] = s[1]; }
+          else *reinterpret_cast<double2*>(a.qout + (size_t)row * KP + lig * VEC) = make_double2(s[0], s[1]);
+        }
+      }
+    }
+    int nr = 0;
+    if (lig == 0) nr = atomicAdd(&next_row, 1);
+    r = __shfl(nr, lane0);
+  }
+  if constexpr (TRAIN) {
+    __syncthreads();
+    if (tid < RPW / GROUPS && tid * GROUPS < rows_here) {   // the static kernel's partial sums: GROUPS rows each, in row order
+      double g0 = 0.0, q0 = 0.0;
+      for (int i = tid * GROUPS; i < (tid + 1) * GROUPS; ++i) { g0 += red[i]; q0 += red[i] * red[i]; }
+      const size_t at = (size_t)blockIdx.x * (RPW / GROUPS) + tid;
+      a.partials[2 * at] = g0;
+      a.partials[2 * at + 1] = q0;
+    }
+  }
+}
+
+template <typename T, bool TRAIN>
+static int launch_rows_dyn(fmx_engine* e, const RowsArgs& a, int kp) {
+  constexpr int VEC = Slice<T>::N;
+  const int lpr = kp / VEC;
+  const int rpw = 4 * (WG_THREADS / lpr);
+  const int64_t grid = (a.nrows + rpw - 1) / rpw;
+  if (grid == 0) return FMX_OK;
+  FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "rows_forward: grid too large (%lld)", (long long)grid);
+  dim3 g((unsigned)grid), b(WG_THREADS);
+#define FMX_DYN_CASE(L) case L: hipLaunchKernelGGL((fm_rows_forward_dyn_k<T, L, TRAIN>), g, b, 0, e->stream, a, e->hyper); break;
+  switch (lpr) {
+    FMX_DYN_CASE(1) FMX_DYN_CASE(2) FMX_DYN_CASE(4) FMX_DYN_CASE(8) FMX_DYN_CASE(16) FMX_DYN_CASE(32) FMX_DYN_CASE(64)
+    default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", kp);
+  }
+#undef FMX_DYN_CASE
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
 template <typename T, bool TRAIN, int WGT, int SPLIT>
 static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
   constexpr int VEC = Slice<T>::N;
@@ -431,6 +560,7 @@ static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
 }
 template <typename T, bool TRAIN>
 static int launch_rows_w(fmx_engine* e, const RowsArgs& a, int kp) {
+  if (a.sort_rows && a.wg_threads != 64) return launch_rows_dyn<T, TRAIN>(e, a, kp);   // FMX_ROWS_PULL=1, rows of differing lengths, wide workgroups
   if (a.wg_threads == 64) return a.split == 4 ? launch_rows_t<T, TRAIN, 64, 4>(e, a, kp) : launch_rows_t<T, TRAIN, 64, 1>(e, a, kp);
   return launch_rows_t<T, TRAIN, WG_THREADS, 1>(e, a, kp);
 }

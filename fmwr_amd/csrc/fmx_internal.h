@@ -359,7 +359,7 @@ struct RowsArgs {
   int wg_threads;       // 64: one-wave workgroups (rows_wg_threads); anything else: WG_THREADS
   int split;            // 4: four lane groups share a row (rows_split; one-wave workgroups only); anything else: one
   int serial;           // large steps: one entry's requests outstanding per lane group at a time (set by the launcher)
-  int sort_rows;        // the rows differ in length: a workgroup deals its rows to its lane groups by descending length (same bits; fm_rows_forward_k)
+  int sort_rows;        // FMX_ROWS_PULL=1 on a matrix of differing row lengths: wide launches take fm_rows_forward_dyn_k (lane groups pull rows; same bits, measured slower)
 };
 // Small steps.  A CU sustains about 240 random 64-byte rows per microsecond whatever runs on it (its miss queue; the
 // gather probe shows the same rate at 2 and at 8 workgroups per CU), so a phase 1 of fewer than one 256-thread workgroup
@@ -373,10 +373,11 @@ inline int rows_wg_threads(int64_t step_rows, int lpr) { return step_rows * lpr 
 // ... and the smallest steps (fewer than 1024 one-wave workgroups) spread every row over four lane groups: four times the waves again,
 // and a 30-entry row is one gather round per group instead of four.  Also decided from the STEP's row count.
 inline int rows_split(int64_t step_rows, int lpr) { return (lpr <= 16 && step_rows * lpr < 1024LL * 64) ? 4 : 1; }
-// rows of differing lengths: phase 1 deals a workgroup's rows to its lane groups by descending length (FMX_SORT_ROWS=0: never, for A/B; same bits either way)
+// rows of differing lengths: FMX_ROWS_PULL=1 sends wide launches through fm_rows_forward_dyn_k (lane groups pull rows instead of owning one each).  Same bits as
+// the static kernel; measured SLOWER on SURVEY 8(d)'s Poisson law (0.221 against 0.194 ms per 262 144-row tile, profiles/r04_ragged_probe2.txt), hence opt-in.
 inline int rows_ragged(const fmx_matrix* m) {
-  const char* s = getenv("FMX_SORT_ROWS");   // (read per call: the tests compare the two forms)
-  return (!(s && s[0] == '0') && m->fixed_row_len == 0 && m->n > 0) ? 1 : 0;
+  const char* s = getenv("FMX_ROWS_PULL");   // (read per call: the tests compare the two forms)
+  return (s && s[0] == '1' && m->fixed_row_len == 0 && m->n > 0) ? 1 : 0;
 }
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
 int ensure_probit(fmx_engine* e);  // builds and uploads the probit tables (fm_probit.h) on first use
