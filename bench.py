@@ -705,7 +705,7 @@ def other_configs(args):
         ("configs[2]", ["--solver", "ftrl", "--no-extras", "--steps", "16", "--warmup", "2", "--cpu-rows", "60000"], run_minibatch),
         ("configs[3]_resident", ["--workload", "criteo", "--steps", "30", "--warmup", "3", "--cpu-rows", "120000"], run_minibatch),
         ("configs[3]_streamed", ["--workload", "criteo", "--stream", "--steps", "30", "--warmup", "3"], main_stream),
-        ("configs[4]", ["--solver", "mcmc", "--no-extras", "--steps", "4", "--warmup", "1", "--cpu-rows", "1000000"], main_sweep),
+        ("configs[4]", ["--solver", "mcmc", "--no-extras", "--steps", "4", "--warmup", "1", "--cpu-rows", "2000000"], main_sweep),
     ]
     for name, argv, fn in runs:
         t0 = time.perf_counter()
