@@ -644,7 +644,7 @@ def main_in_library(args):
         m = engine.Matrix.synthetic_fields(args.rows, 13, engine.CRITEO_VOCAB, 3.0, args.seed)
     else:
         m = engine.Matrix.synthetic(args.rows, p, z, args.seed)
-    e = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1, n_gpus=N, gpus_share_device=int(share and N > 1), exchange_chunks=0))
+    e = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1, n_gpus=N, gpus_share_device=int(share and N > 1), exchange_chunks=0, learn_rate=learn_rate_for(B * N)))
     e.init_normal(args.seed, 0.0, 0.01)
     per_step = B * N
     e.train(m, per_step * (args.warmup + (16 if B >= 65536 else 0)))   # shards, plans, phase 1's schedule trials: all outside the timed region
@@ -665,6 +665,7 @@ def main_in_library(args):
         "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch (BASELINE.json configs[{3 if criteo else (2 if ftrl else 1)}]{' shape, resident rows' if criteo else ''})",
                    "driver": "in-library: one process, cfg.n_gpus replicas behind one C-ABI handle (fm_group.hip)" + (" on ONE device (rehearsal)" if share and N > 1 else ""),
                    "batch_rows_per_gpu": B, "global_batch_rows": per_step, "parallelism": f"dp{N}",
+                   **({} if ftrl else {"learn_rate": learn_rate_for(per_step)}),
                    **({"exchange": (os.environ.get("FMX_GROUP_EXCHANGE") or ("steps of one sparse tile: " + ("owner-sharded (peer copies of owner-major slices)" if ginfo["sparse_exchange"] == "owner"
                                                                                                            else "all-gather of the occurring features' records") + "; the dense all-reduce otherwise"))} if N > 1 else {})},
         "roofline": {"bound": "hbm", "kernel": "step = fm_rows_forward + fm_cols_update per tile", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

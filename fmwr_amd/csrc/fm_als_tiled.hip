@@ -255,7 +255,7 @@ __global__ void als_tile_prep_k(const uint32_t* __restrict__ feats, uint32_t cnt
 // blockIdx -> (tile, chunk of the level's features): the B workgroups of a tile are consecutive in ONE XCD's share of the grid (blocks are dealt
 // round-robin over the eight XCDs, so blocks b and b + 8 share one), and an XCD works through its tiles one after the other -- the tile's
 // (q, e) slice is fetched into that L2 once and gathered from there.  Placement is for speed only.
-template <bool W, int LG, bool UNIT, bool NT>
+template <bool W, int LG, bool UNIT, bool NT, int U>
 __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt,
                                                               const int64_t* __restrict__ tile_base, const uint32_t* __restrict__ trow, const float* __restrict__ tval,
                                                               const double* __restrict__ vf, const double2* __restrict__ qe, int tshift, int n_tiles, int B,
@@ -275,7 +275,6 @@ __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __
   const double2* __restrict__ slice = qe + ((size_t)tile << tshift);
   const double old = vf[fi];
   double mean = 0.0, var = 0.0;
-  constexpr int U = 4;
   // loads are unconditional on a clamped index, the values selected afterwards (a load under a condition is a branch whose join waits: DESIGN 6.2)
   for (uint32_t t0 = lb + lg; t0 < le; t0 += LG * U) {
     uint32_t rr[U]; float xs[U]; double2 c[U];
@@ -411,8 +410,9 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
   const dim3 blk(WG_THREADS);
   // FMX_ALS_NT: bit 0 the lists of the sums pass, bit 1 the streams of the correction pass, bit 2 the per-tile sums read by the step kernel
   static const int nt_mask = env_int("FMX_ALS_NT", 6);
-  static const int rows_per_thread = env_int("FMX_ALS_APPLY_ROWS", 4);
+  static const int rows_per_thread = env_int("FMX_ALS_APPLY_ROWS", 8);
   static const bool fold_prep = env_int("FMX_ALS_FOLD_PREP", 1) != 0;
+  static const int sums_u = env_int("FMX_ALS_SUMS_U", 4);
   // this level's coordinates: gathered by the previous tiled level's step kernel (its spare workgroups), or here
   int buf = 0;
   if (fold_prep && e->als_vf_slot == s) buf = e->als_vf_buf;
@@ -421,9 +421,10 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
   const int lists = WG_THREADS / T->lg;
   const int B = (int)((cnt + lists - 1) / lists);
   const dim3 g((unsigned)(((T->n_tiles + 7) / 8) * 8 * B));
-#define FMX_SUMS2(LGv, UNITv, NTv)                                                                                                                        \
-  hipLaunchKernelGGL((als_tile_sums_k<W, LGv, UNITv, NTv>), g, blk, 0, e->stream, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, (const double*)vf, \
+#define FMX_SUMS3(LGv, UNITv, NTv, Uv)                                                                                                                    \
+  hipLaunchKernelGGL((als_tile_sums_k<W, LGv, UNITv, NTv, Uv>), g, blk, 0, e->stream, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, (const double*)vf, \
                      (const double2*)d_qe, T->tshift, T->n_tiles, B, partial, T->max_cnt)
+#define FMX_SUMS2(LGv, UNITv, NTv) do { if (sums_u == 8) FMX_SUMS3(LGv, UNITv, NTv, 8); else FMX_SUMS3(LGv, UNITv, NTv, 4); } while (0)
 #define FMX_SUMS(LGv)                                                                                                                                     \
   do {                                                                                                                                                    \
     if (T->unit) { if (nt_mask & 1) FMX_SUMS2(LGv, true, true); else FMX_SUMS2(LGv, true, false); }                                                         \
@@ -437,6 +438,7 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
   }
 #undef FMX_SUMS
 #undef FMX_SUMS2
+#undef FMX_SUMS3
   // the next tiled level of this sweep, if the very next level is one (anything in between may not be skipped: it would run after the gather,
   // which is harmless -- other features -- but keep the rule simple)
   const uint32_t* next_feats = nullptr; uint32_t next_cnt = 0;
@@ -467,7 +469,8 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
   switch (rows_per_thread) {
     case 1: FMX_APPLY_R(1); break;
     case 2: FMX_APPLY_R(2); break;
-    default: FMX_APPLY_R(4); break;
+    case 4: FMX_APPLY_R(4); break;
+    default: FMX_APPLY_R(8); break;
   }
 #undef FMX_APPLY_R
 #undef FMX_APPLY_Q

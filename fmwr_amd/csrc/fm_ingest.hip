@@ -762,9 +762,11 @@ __global__ void dense_heads_k(int d, uint32_t nrows, const float* __restrict__ b
   if (c < d) { soff[c] = (uint32_t)c * nrows; feat[c] = (uint32_t)c; row0[c] = 0u; val0[c] = __float_as_uint(bval[(size_t)c * nrows]); }
 }
 // A, B: ping-pong buffers of n_cat keys + n_cat rows each; fin_*: the plan's arrays at the one-hot part
+// keys0 / rows0 (optional): where the FIRST pass reads its keys and rows (a read-only source -- the matrix's own column array -- and rows that are not the
+// entries' positions: the one-"field" sort of a tile without a field layout); the ping-pong buffers are then only written from pass 0 on
 template <typename G>
 static int field_sort_g(const std::vector<uint32_t>& fbase, uint32_t n, uint32_t* a_keys, uint32_t* a_rows, uint32_t* b_keys, uint32_t* b_rows, uint32_t* fin_keys,
-                        uint32_t* fin_rows, uint32_t* counts, uint32_t* totals, hipStream_t stream) {
+                        uint32_t* fin_rows, uint32_t* counts, uint32_t* totals, hipStream_t stream, const uint32_t* keys0 = nullptr, const uint32_t* rows0 = nullptr) {
   const int C = (int)fbase.size() - 1;
   int passes[FMX_MAX_FIELDS], dbq[FMX_MAX_FIELDS], bits[FMX_MAX_FIELDS], max_passes = 0;
   for (int c = 0; c < C; ++c) {
@@ -788,8 +790,8 @@ static int field_sort_g(const std::vector<uint32_t>& fbase, uint32_t n, uint32_t
       P.base[s] = fbase[(size_t)c];
       if (P.db[s] > db_max) db_max = P.db[s];
     }
-    const uint32_t* sk = (q & 1) ? b_keys : a_keys;
-    const uint32_t* sr = q == 0 ? nullptr : ((q & 1) ? b_rows : a_rows);
+    const uint32_t* sk = (q == 0 && keys0) ? keys0 : ((q & 1) ? b_keys : a_keys);
+    const uint32_t* sr = q == 0 ? rows0 : ((q & 1) ? b_rows : a_rows);
     uint32_t* dk = (q & 1) ? a_keys : b_keys;
     uint32_t* dr = (q & 1) ? a_rows : b_rows;
     static const int plain_env = [] { const char* v = getenv("FMX_FQ_PLAIN"); return v ? atoi(v) : -1; }();
@@ -804,16 +806,16 @@ static int field_sort_g(const std::vector<uint32_t>& fbase, uint32_t n, uint32_t
   return FMX_OK;
 }
 static int field_sort(const std::vector<uint32_t>& fbase, uint32_t n, uint32_t* a_keys, uint32_t* a_rows, uint32_t* b_keys, uint32_t* b_rows, uint32_t* fin_keys,
-                      uint32_t* fin_rows, uint32_t* counts, uint32_t* totals, hipStream_t stream) {
+                      uint32_t* fin_rows, uint32_t* counts, uint32_t* totals, hipStream_t stream, const uint32_t* keys0 = nullptr, const uint32_t* rows0 = nullptr) {
   // block geometry (profiles/r03_field_sort.txt: streamed Criteo shape, M examples/s): 256 x 16 entries with 8-bit digits 367, 256 x 8 / 8 bits 368,
   // 128 x 16 / 8 bits 365, 256 x 16 / 7 bits 362, 256 x 16 / 9 bits 355, 128 x 32 / 8 bits 348, 512 x 16 / 9 bits 319, 1024 x 8 / 9 bits 314,
   // 256 x 32 / 9 bits 303 -- small blocks win: a block is a chain of barriers, and the chip wants many of them in flight
   static const int cfg = [] { const char* v = getenv("FMX_FQ_CFG"); return v ? atoi(v) : 1; }();
   switch (cfg) {
-    case 0: return field_sort_g<FqCfg<512, 16, 9>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
-    case 6: return field_sort_g<FqCfg<256, 8, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
-    case 7: return field_sort_g<FqCfg<128, 16, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
-    default: return field_sort_g<FqCfg<256, 16, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream);
+    case 0: return field_sort_g<FqCfg<512, 16, 9>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream, keys0, rows0);
+    case 6: return field_sort_g<FqCfg<256, 8, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream, keys0, rows0);
+    case 7: return field_sort_g<FqCfg<128, 16, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream, keys0, rows0);
+    default: return field_sort_g<FqCfg<256, 16, 8>>(fbase, n, a_keys, a_rows, b_keys, b_rows, fin_keys, fin_rows, counts, totals, stream, keys0, rows0);
   }
 }
 
@@ -874,8 +876,19 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
     // bval is never read for such a matrix
     uint32_t* rows32 = reinterpret_cast<uint32_t*>(ws.vals_in);
     hipLaunchKernelGGL(pack_rows_k, grid(cnt), dim3(T), 0, stream, row_ptr, t.r0, t.nrows, t.base, cnt, rows32, fixed_row_len);
-    size_t tb32 = ws.sort_bytes;  // sized for the (u32, u64) sort of the same length: the (u32, u32) one needs no more
-    FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, col + t.base, ws.keys_out, rows32, brow + t.base, (size_t)cnt, ws.bits, stream));
+    const char* ps_env = getenv("FMX_PAIR_SORT");  // read per build (the tests compare the two): "rocprim" keeps the library's onesweep sort
+    if (!(ps_env && ps_env[0] == 'r') && ws.fq_counts != nullptr) {
+      // [r4] the hand-written LSD sort of the per-field plans, run as ONE "field" [0, p) over the tile's cnt entries (block histograms, a digit's blocks scanned in
+      // order, blocks ordered by digit in LDS and written as runs): the first pass reads the matrix's own column array and the rows just packed, the last one
+      // writes the sorted columns and rows straight into the plan.  Stable, so rows stay ascending inside a list: the same plan, bit for bit, as the library sort.
+      const std::vector<uint32_t> one{0u, p};
+      uint32_t* a_keys = rows32 + cnt;                                  // (the u64 payload buffers hold two u32 arrays each)
+      uint32_t* b_keys = reinterpret_cast<uint32_t*>(ws.vals_out);
+      FMX_TRY(field_sort(one, (uint32_t)cnt, a_keys, rows32, b_keys, b_keys + cnt, ws.keys_out, brow + t.base, ws.fq_counts, ws.fq_totals, stream, col + t.base, rows32));
+    } else {
+      size_t tb32 = ws.sort_bytes;  // sized for the (u32, u64) sort of the same length: the (u32, u32) one needs no more
+      FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, col + t.base, ws.keys_out, rows32, brow + t.base, (size_t)cnt, ws.bits, stream));
+    }
   } else if (cnt > 0) {
     hipLaunchKernelGGL(pack_entries_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, ws.vals_in, fixed_row_len);
     FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, ws.sort_bytes, col + t.base, ws.keys_out, ws.vals_in, ws.vals_out, (size_t)cnt, 0, ws.bits, stream));

@@ -480,3 +480,23 @@ def test_lane_groups_pulling_rows_changes_no_bit(monkeypatch):
             out.append((pred, e.get_params()))
         assert np.array_equal(out[0][0], out[1][0]), (k, wide)
         assert out[0][1][0] == out[1][1][0] and np.array_equal(out[0][1][1], out[1][1][1]) and np.array_equal(out[0][1][2], out[1][1][2]), (k, wide)
+
+
+@pytest.mark.parametrize("p,n,z", [(3_000, 30_000, 9), (1_000_000, 300_000, 30), (20_000_000, 120_000, 12), (200, 5_000, 6)])
+def test_the_hand_written_pair_sort_builds_the_library_sorts_plan(monkeypatch, p, n, z):
+    """One-hot tiles without a field layout (ragged rows, i.i.d. columns) are sorted by (column, row) with the hand-written LSD sort of the per-field plans run as ONE
+    field [0, p) (fm_ingest.hip: plan_build; FMX_PAIR_SORT=rocprim keeps the library's onesweep sort).  Both are stable, so the plans are the same and training on
+    them gives the same bits: 12-bit ids (two passes), 20-bit (three), 25-bit (four), 8-bit (one pass, straight into the plan); dense and sparse tiles; ragged rows."""
+    from fmwr_amd import _lib as L, engine
+    k = 8
+    out = []
+    for flag in ("hand", "rocprim"):
+        monkeypatch.setenv("FMX_PAIR_SORT", flag)
+        m = engine.Matrix.synthetic_ragged(n, p, float(z), seed=5, min_nnz=1, max_nnz=min(64, p))
+        e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_FTRL, num_factor=k, l1_w1=1e-4, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=max(1000, n // 3))
+        e.init_normal(3, 0.0, 0.05)
+        assert e.train(m, n) == n
+        ids = np.arange(0, p, max(1, p // 5000), dtype=np.uint32)
+        out.append(e.get_rows(ids))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.any(out[0][1] != 0.0)
