@@ -50,6 +50,16 @@ __global__ void pack_rows_k(const int64_t* __restrict__ row_ptr, int64_t r0, int
   if (i < cnt) rows[i] = entry_row(row_ptr, r0, nrows, base, base + i, fixed_len);
 }
 
+// sorted positions (parked, as raw bits, in the value array) -> the entries' rows and values
+__global__ void gather_sorted_k(const int64_t* __restrict__ row_ptr, const float* __restrict__ val, int64_t r0, int64_t nrows, int64_t base, int64_t cnt,
+                                uint32_t* __restrict__ rows, float* vals, int fixed_len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const int64_t t = base + (int64_t)__float_as_uint(vals[i]);
+  rows[i] = entry_row(row_ptr, r0, nrows, base, t, fixed_len);
+  vals[i] = val[t];
+}
+
 __global__ void unpack_entries_k(const uint64_t* __restrict__ packed, int64_t cnt, uint32_t* __restrict__ rows, float* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cnt) return;
@@ -876,11 +886,15 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
     // bval is never read for such a matrix
     uint32_t* rows32 = reinterpret_cast<uint32_t*>(ws.vals_in);
     hipLaunchKernelGGL(pack_rows_k, grid(cnt), dim3(T), 0, stream, row_ptr, t.r0, t.nrows, t.base, cnt, rows32, fixed_row_len);
-    const char* ps_env = getenv("FMX_PAIR_SORT");  // read per build (the tests compare the two): "rocprim" keeps the library's onesweep sort
-    if (!(ps_env && ps_env[0] == 'r') && ws.fq_counts != nullptr) {
+    const char* ps_env = getenv("FMX_PAIR_SORT");  // read per build (the tests compare the two): "hand" takes the hand-written sort below
+    if (ps_env && ps_env[0] == 'h' && ws.fq_counts != nullptr) {
       // [r4] the hand-written LSD sort of the per-field plans, run as ONE "field" [0, p) over the tile's cnt entries (block histograms, a digit's blocks scanned in
       // order, blocks ordered by digit in LDS and written as runs): the first pass reads the matrix's own column array and the rows just packed, the last one
-      // writes the sorted columns and rows straight into the plan.  Stable, so rows stay ascending inside a list: the same plan, bit for bit, as the library sort.
+      // writes the sorted columns and rows straight into the plan.  Stable, so rows stay ascending inside a list: the same plan, bit for bit, as the library sort
+      // (tests/test_gpu_api.py).  MEASURED (profiles/r04_pair_sort.txt): 24.2 against 12.9 ms for the 39 tiles of a 10 M x 1 M matrix of i.i.d. columns, 28.0 against
+      // 16.4 ms on ragged rows -- with one field there is nothing to run side by side, every pass reads the keys twice (count, then scatter) where the library's
+      // onesweep reads them once and chains its blocks by lookback; the streamed rate does not move (144.7 M examples/s either way: phase 2 bounds it).  So the
+      // library's sort stays the default for tiles WITHOUT a field layout, and this form is opt-in (FMX_PAIR_SORT=hand); tiles with one keep the per-field sort.
       const std::vector<uint32_t> one{0u, p};
       uint32_t* a_keys = rows32 + cnt;                                  // (the u64 payload buffers hold two u32 arrays each)
       uint32_t* b_keys = reinterpret_cast<uint32_t*>(ws.vals_out);
@@ -890,9 +904,21 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
       FMX_HIP(sort_pairs_u32(ws.sort_temp, tb32, col + t.base, ws.keys_out, rows32, brow + t.base, (size_t)cnt, ws.bits, stream));
     }
   } else if (cnt > 0) {
-    hipLaunchKernelGGL(pack_entries_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, ws.vals_in, fixed_row_len);
-    FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, ws.sort_bytes, col + t.base, ws.keys_out, ws.vals_in, ws.vals_out, (size_t)cnt, 0, ws.bits, stream));
-    hipLaunchKernelGGL(unpack_entries_k, grid(cnt), dim3(T), 0, stream, ws.vals_out, cnt, brow + t.base, bval + t.base);
+    const char* ps_env = getenv("FMX_PAIR_SORT");
+    if (ps_env && ps_env[0] == 'h' && ws.fq_counts != nullptr) {
+      // [r4] real values (opt-in like the one-hot form above): the same hand-written sort on (column, POSITION in the tile) -- pass 0 takes the position for the row by itself -- with the sorted
+      // positions parked in the plan's value array; one gather then turns a position into the entry's row and value (12 bytes per entry and pass before: a u64 payload)
+      const std::vector<uint32_t> one{0u, p};
+      uint32_t* a_keys = reinterpret_cast<uint32_t*>(ws.vals_in);
+      uint32_t* b_keys = reinterpret_cast<uint32_t*>(ws.vals_out);
+      uint32_t* pos = reinterpret_cast<uint32_t*>(bval + t.base);
+      FMX_TRY(field_sort(one, (uint32_t)cnt, a_keys, a_keys + cnt, b_keys, b_keys + cnt, ws.keys_out, pos, ws.fq_counts, ws.fq_totals, stream, col + t.base, nullptr));
+      hipLaunchKernelGGL(gather_sorted_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, brow + t.base, bval + t.base, fixed_row_len);
+    } else {
+      hipLaunchKernelGGL(pack_entries_k, grid(cnt), dim3(T), 0, stream, row_ptr, val, t.r0, t.nrows, t.base, cnt, ws.vals_in, fixed_row_len);
+      FMX_HIP(rocprim::radix_sort_pairs(ws.sort_temp, ws.sort_bytes, col + t.base, ws.keys_out, ws.vals_in, ws.vals_out, (size_t)cnt, 0, ws.bits, stream));
+      hipLaunchKernelGGL(unpack_entries_k, grid(cnt), dim3(T), 0, stream, ws.vals_out, cnt, brow + t.base, bval + t.base);
+    }
   }
   FMX_HIP(hipMemsetAsync(t.dcounts, 0, 4 * sizeof(uint32_t), stream));
   rocprim::counting_iterator<uint32_t> ids(0);

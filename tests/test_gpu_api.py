@@ -484,9 +484,10 @@ def test_lane_groups_pulling_rows_changes_no_bit(monkeypatch):
 
 @pytest.mark.parametrize("p,n,z", [(3_000, 30_000, 9), (1_000_000, 300_000, 30), (20_000_000, 120_000, 12), (200, 5_000, 6)])
 def test_the_hand_written_pair_sort_builds_the_library_sorts_plan(monkeypatch, p, n, z):
-    """One-hot tiles without a field layout (ragged rows, i.i.d. columns) are sorted by (column, row) with the hand-written LSD sort of the per-field plans run as ONE
-    field [0, p) (fm_ingest.hip: plan_build; FMX_PAIR_SORT=rocprim keeps the library's onesweep sort).  Both are stable, so the plans are the same and training on
-    them gives the same bits: 12-bit ids (two passes), 20-bit (three), 25-bit (four), 8-bit (one pass, straight into the plan); dense and sparse tiles; ragged rows."""
+    """Tiles without a field layout (ragged rows, i.i.d. columns) are sorted by (column, row) by the library's onesweep sort; FMX_PAIR_SORT=hand takes the hand-written
+    LSD sort of the per-field plans run as ONE field [0, p) instead (fm_ingest.hip: plan_build; measured 1.9 x slower on tile-sized sorts, hence opt-in).  Both are
+    stable, so the plans are the same and training on them gives the same bits: 12-bit ids (two passes), 20-bit (three), 25-bit (four), 8-bit (one pass, straight
+    into the plan); dense and sparse tiles; ragged rows; one-hot rows and rows with real values (sorted as (column, position), rows and values gathered afterwards)."""
     from fmwr_amd import _lib as L, engine
     k = 8
     out = []
@@ -500,3 +501,17 @@ def test_the_hand_written_pair_sort_builds_the_library_sorts_plan(monkeypatch, p
         out.append(e.get_rows(ids))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.any(out[0][1] != 0.0)
+    if p > 100_000:
+        return
+    # real values: (column, position) sorted by hand, rows and values gathered afterwards -- against the library's sort of a 64-bit payload
+    rp, col, val = util.random_csr(n, p, z, seed=6, empty_rows=True)
+    y = util.labels(n, 6)
+    out = []
+    for flag in ("hand", "rocprim"):
+        monkeypatch.setenv("FMX_PAIR_SORT", flag)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, l2_v=1e-3, learn_rate=0.05, mode=L.MODE_MINIBATCH, batch_rows=max(1000, n // 3))
+        e.init_normal(3, 0.0, 0.05)
+        assert e.train(m, n) == n
+        out.append(e.get_params())
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
