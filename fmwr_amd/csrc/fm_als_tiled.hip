@@ -27,6 +27,7 @@
 namespace fmx {
 
 constexpr uint32_t TILED_NONE = 0xFFFFFFFFu;
+constexpr int TILED_SLOT = 8;   // rows of a (tile, feature) list kept inline (lists average 3.9 entries at 131 072-row tiles of configs[4]; 98 % hold at most 8)
 
 struct AlsTiled {
   int64_t n = 0;
@@ -40,7 +41,11 @@ struct AlsTiled {
   std::vector<int> slot_of_level;          // [L] index of the level among the tiled ones, -1: the level keeps the column-walking kernels
   std::vector<uint32_t> lvl0, cnt;         // per slot: first feature (position in `feats`) and number of features
   uint32_t* feats = nullptr;     // [n_feats] feature ids
-  uint32_t* lfi = nullptr;       // [n_slots][n] index (inside its level) of the feature row r holds at that level, TILED_NONE: none
+  void* lfi = nullptr;           // [n_slots][n] index (inside its level) of the feature row r holds at that level (u16 when every level has fewer than 65 535
+                                 // features -- lfi16 -- else u32), all ones: none
+  int lfi16 = 0;
+  uint32_t* tslot = nullptr;     // [n_tiles][n_feats][SLOT] the first SLOT rows of every (tile, feature) list INLINE (all ones: no entry): a list's rows arrive with one
+  float* tvslot = nullptr;       // coalesced load instead of offsets -> rows (two dependent loads); lists longer than SLOT continue in trow / tval behind toff
   float* lval = nullptr;         // [n_slots][n] its value (null: every value is 1.0f)
   uint32_t* toff = nullptr;      // [n_tiles][n_feats + 1] entry offsets of the (tile, feature) lists, relative to the tile's first entry
   int64_t* tile_base = nullptr;  // [n_tiles + 1] (device) first entry of each tile in trow / tval
@@ -48,6 +53,7 @@ struct AlsTiled {
   float* tval = nullptr;         // [entries + 1] (null: unit values)
   ~AlsTiled() {
     (void)hipFree(feats); (void)hipFree(lfi); (void)hipFree(lval); (void)hipFree(toff); (void)hipFree(tile_base); (void)hipFree(trow); (void)hipFree(tval);
+    (void)hipFree(tslot); (void)hipFree(tvslot);
   }
 };
 
@@ -58,15 +64,16 @@ void als_tiled_free(fmx_matrix* m) {
 
 // ---- plan ------------------------------------------------------------------------------------------------------------------------------------
 // level-major copies of the CSR: for every tiled level the feature (as its index inside the level) and value each row holds there
+template <typename IT>
 __global__ void tiled_rows_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val, int64_t n,
-                             const int* __restrict__ slot_of_feat, const uint32_t* __restrict__ idx_in_level, uint32_t* __restrict__ lfi, float* __restrict__ lval) {
+                             const int* __restrict__ slot_of_feat, const uint32_t* __restrict__ idx_in_level, IT* __restrict__ lfi, float* __restrict__ lval) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   for (int64_t t = row_ptr[r]; t < row_ptr[r + 1]; ++t) {
     const uint32_t j = col[t];
     const int s = slot_of_feat[j];
     if (s < 0) continue;
-    lfi[(size_t)s * n + r] = idx_in_level[j];
+    lfi[(size_t)s * n + r] = (IT)idx_in_level[j];
     if (lval) lval[(size_t)s * n + r] = val[t];
   }
 }
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(WG_THREADS) void tiled_count_k(const int64_t* __res
 __global__ __launch_bounds__(WG_THREADS) void tiled_scatter_k(const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
                                                               const uint32_t* __restrict__ rank_of, uint32_t p, int tshift, size_t nf1,
                                                               const uint32_t* __restrict__ toff, const int64_t* __restrict__ tile_base,
-                                                              uint32_t* __restrict__ trow, float* __restrict__ tval) {
+                                                              uint32_t* __restrict__ trow, float* __restrict__ tval, uint32_t* __restrict__ tslot, float* __restrict__ tvslot) {
   const int lane = threadIdx.x & 63;
   const int64_t j = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6;
   if (j >= (int64_t)p) return;
@@ -104,6 +111,11 @@ __global__ __launch_bounds__(WG_THREADS) void tiled_scatter_k(const int64_t* __r
     const int64_t dst = tile_base[tile] + (int64_t)toff[(size_t)tile * nf1 + k] + (t - a);
     trow[dst] = r - lo;
     if (tval) tval[dst] = cval[t];
+    if (tslot && t - a < TILED_SLOT) {   // the list's first rows, inline
+      const size_t at = ((size_t)tile * (nf1 - 1) + k) * TILED_SLOT + (size_t)(t - a);
+      tslot[at] = r - lo;
+      if (tvslot) tvslot[at] = cval[t];
+    }
   }
 }
 
@@ -187,9 +199,11 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   } w;
   auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
   const size_t sn = (size_t)n_slots * (size_t)m->n;
+  T->lfi16 = T->max_cnt < 0xFFFFu ? 1 : 0;
+  const size_t isz = T->lfi16 ? 2 : 4;
   if (!ok(hipMalloc(&w.rank_of, (size_t)p * 4)) || !ok(hipMalloc(&w.idx_in, (size_t)p * 4)) || !ok(hipMalloc(&w.slot_of_feat, (size_t)p * 4)) ||
       !ok(hipMalloc(&w.counts, nf1 * T->n_tiles * 4)) || !ok(hipMalloc(&T->feats, (size_t)(T->n_feats ? T->n_feats : 1) * 4)) ||
-      !ok(hipMalloc(&T->lfi, sn * 4)) || (!T->unit && !ok(hipMalloc(&T->lval, sn * 4))) || !ok(hipMalloc(&T->toff, nf1 * T->n_tiles * 4)) ||
+      !ok(hipMalloc(&T->lfi, sn * isz)) || (!T->unit && !ok(hipMalloc(&T->lval, sn * 4))) || !ok(hipMalloc(&T->toff, nf1 * T->n_tiles * 4)) ||
       !ok(hipMalloc(&T->tile_base, ((size_t)T->n_tiles + 1) * 8)) || !ok(hipMalloc(&T->trow, ((size_t)m->nnz + 1) * 4)) ||
       (!T->unit && !ok(hipMalloc(&T->tval, ((size_t)m->nnz + 1) * 4))))
     return FMX_OK;
@@ -197,11 +211,22 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   FMX_HIP(hipMemcpyAsync(w.idx_in, idx_in.data(), (size_t)p * 4, hipMemcpyHostToDevice, stream));
   FMX_HIP(hipMemcpyAsync(w.slot_of_feat, slot_of_feat.data(), (size_t)p * 4, hipMemcpyHostToDevice, stream));
   FMX_HIP(hipMemcpyAsync(T->feats, feats.data(), (size_t)T->n_feats * 4, hipMemcpyHostToDevice, stream));
-  FMX_HIP(hipMemsetAsync(T->lfi, 0xFF, sn * 4, stream));
+  FMX_HIP(hipMemsetAsync(T->lfi, 0xFF, sn * isz, stream));
+  // inline slots (FMX_ALS_SLOTS=0: none): worth their 32 bytes per list where lists are short -- on average at most 0.6 SLOT entries
+  const size_t n_lists = (size_t)T->n_feats * (size_t)T->n_tiles;
+  if (env_int("FMX_ALS_SLOTS", 1) != 0 && T->lg == 1 && (mode > 0 || (double)m->nnz <= 0.6 * TILED_SLOT * (double)n_lists) && n_lists * TILED_SLOT * 4 < ((size_t)12 << 30)) {
+    if (ok(hipMalloc(&T->tslot, n_lists * TILED_SLOT * 4)) && (T->unit || ok(hipMalloc(&T->tvslot, n_lists * TILED_SLOT * 4)))) {
+      FMX_HIP(hipMemsetAsync(T->tslot, 0xFF, n_lists * TILED_SLOT * 4, stream));
+      if (T->tvslot) FMX_HIP(hipMemsetAsync(T->tvslot, 0, n_lists * TILED_SLOT * 4, stream));
+    } else { (void)hipFree(T->tslot); T->tslot = nullptr; (void)hipFree(T->tvslot); T->tvslot = nullptr; }
+  }
   FMX_HIP(hipMemsetAsync(w.counts, 0, nf1 * T->n_tiles * 4, stream));
   FMX_HIP(hipMemsetAsync(T->trow, 0, ((size_t)m->nnz + 1) * 4, stream));
   if (T->tval) FMX_HIP(hipMemsetAsync(T->tval, 0, ((size_t)m->nnz + 1) * 4, stream));
-  hipLaunchKernelGGL(tiled_rows_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->val, m->n, w.slot_of_feat, w.idx_in, T->lfi, T->lval);
+  if (T->lfi16) hipLaunchKernelGGL((tiled_rows_k<uint16_t>), dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->val, m->n, w.slot_of_feat, w.idx_in,
+                                   reinterpret_cast<uint16_t*>(T->lfi), T->lval);
+  else hipLaunchKernelGGL((tiled_rows_k<uint32_t>), dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->val, m->n, w.slot_of_feat, w.idx_in,
+                          reinterpret_cast<uint32_t*>(T->lfi), T->lval);
   hipLaunchKernelGGL(tiled_tile_base_k, dim3((unsigned)(T->n_tiles / 256 + 1)), dim3(256), 0, stream, m->row_ptr, m->n, ts, T->n_tiles, T->tile_base);
   const unsigned col_grid = (unsigned)(((int64_t)p * 64 + WG_THREADS - 1) / WG_THREADS);
   hipLaunchKernelGGL(tiled_count_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, w.rank_of, p, ts, nf1, w.counts);
@@ -210,7 +235,8 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   if (!ok(hipMalloc(&w.scan, scan_bytes ? scan_bytes : 16))) return FMX_OK;
   for (int t = 0; t < T->n_tiles; ++t)
     FMX_HIP(rocprim::exclusive_scan(w.scan, scan_bytes, w.counts + (size_t)t * nf1, T->toff + (size_t)t * nf1, 0u, nf1, rocprim::plus<uint32_t>(), stream));
-  hipLaunchKernelGGL(tiled_scatter_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, m->cval, w.rank_of, p, ts, nf1, T->toff, T->tile_base, T->trow, T->tval);
+  hipLaunchKernelGGL(tiled_scatter_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, m->cval, w.rank_of, p, ts, nf1, T->toff, T->tile_base, T->trow, T->tval,
+                     T->tslot, T->tvslot);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipStreamSynchronize(stream));
   m->als_tiled = T.release();
@@ -298,6 +324,62 @@ __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __
   if (lg == 0 && live) partial[(size_t)tile * max_cnt + fi] = make_double2(mean, var);
 }
 
+// The sums pass with the lists' first rows INLINE: thread fi loads its list's TILED_SLOT rows as two 16-byte loads (neighbouring threads read neighbouring
+// 32 bytes: coalesced), then all its gathers go out at once through a buffer descriptor over the tile's slice -- an empty slot's offset lies beyond the
+// descriptor and issues no request.  Two dependent rounds instead of three (offsets -> rows -> pairs), eight gathers in flight per thread instead of four.
+// A list longer than the slots (its last slot is taken) continues behind the offsets in trow / tval.  Entries are added in list order, as in als_tile_sums_k.
+typedef unsigned int tiled_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 tiled_buf_pair(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  const tiled_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+template <bool W, bool UNIT>
+__global__ __launch_bounds__(WG_THREADS) void als_tile_sums_slot_k(const uint32_t* __restrict__ tslot, const float* __restrict__ tvslot, const uint32_t* __restrict__ toff, size_t nf1,
+                                                                   uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base, const uint32_t* __restrict__ trow,
+                                                                   const float* __restrict__ tval, const double* __restrict__ vf, const double2* __restrict__ qe, int tshift,
+                                                                   int n_tiles, int B, int64_t n, double2* __restrict__ partial, uint32_t max_cnt) {
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int tile = (i / B) * 8 + x, chunk = i % B;
+  if (tile >= n_tiles) return;
+  const uint32_t fi_raw = (uint32_t)chunk * WG_THREADS + threadIdx.x;
+  const bool live = fi_raw < cnt;
+  const uint32_t fi = live ? fi_raw : cnt - 1;
+  const size_t list = (size_t)tile * (nf1 - 1) + lvl0 + fi;
+  const uint4 s0 = *reinterpret_cast<const uint4*>(tslot + list * TILED_SLOT), s1 = *reinterpret_cast<const uint4*>(tslot + list * TILED_SLOT + 4);
+  float4 x0 = make_float4(1.f, 1.f, 1.f, 1.f), x1 = x0;
+  if (!UNIT) { x0 = *reinterpret_cast<const float4*>(tvslot + list * TILED_SLOT); x1 = *reinterpret_cast<const float4*>(tvslot + list * TILED_SLOT + 4); }
+  const int64_t r0 = (int64_t)tile << tshift;
+  const int64_t rows = (r0 + ((int64_t)1 << tshift) < n ? r0 + ((int64_t)1 << tshift) : n) - r0;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(qe + r0), 0, (int)(rows * 16), 0x00020000);
+  const double old = vf[fi];
+  const uint32_t rr[TILED_SLOT] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  const float xs[TILED_SLOT] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  double2 c[TILED_SLOT];
+#pragma unroll
+  for (int q = 0; q < TILED_SLOT; ++q) c[q] = tiled_buf_pair(rs, (rr[q] == TILED_NONE || !live) ? 0x80000000u : rr[q] * 16u);
+  double mean = 0.0, var = 0.0;
+#pragma unroll
+  for (int q = 0; q < TILED_SLOT; ++q) {
+    if (rr[q] == TILED_NONE) continue;
+    if (W) { const double xd = (double)xs[q]; mean += c[q].y * xd - old * xd * xd; var += xd * xd; }
+    else { const float xx = xs[q] * xs[q]; const double h = (double)xs[q] * c[q].x - (double)xx * old; mean += h * c[q].y; var += h * h; }
+  }
+  if (rr[TILED_SLOT - 1] != TILED_NONE && live) {   // a longer list: entries TILED_SLOT.. behind the offsets (rare: 2 % of the lists at configs[4])
+    const uint32_t* off = toff + (size_t)tile * nf1 + lvl0 + fi;
+    const uint32_t le = off[1];
+    const int64_t tb = tile_base[tile];
+    const double2* __restrict__ slice = qe + r0;
+    for (uint32_t t = off[0] + TILED_SLOT; t < le; ++t) {
+      const float xv = UNIT ? 1.0f : tval[tb + t];
+      const double2 cc = slice[trow[tb + t]];
+      if (W) { const double xd = (double)xv; mean += cc.y * xd - old * xd * xd; var += xd * xd; }
+      else { const float xx = xv * xv; const double h = (double)xv * cc.x - (double)xx * old; mean += h * cc.y; var += h * h; }
+    }
+  }
+  if (live) partial[(size_t)tile * max_cnt + fi] = make_double2(mean, var);
+}
+
 // 16 features per workgroup, 16 threads per feature: thread (tl, fl) adds the pairs of tiles tl, tl + 16, ... of feature fl in that order, the sixteen
 // part sums meet in LDS and are added in tl order -- a fixed association (reproducible), and sixteen loads in flight per feature where one thread per
 // feature walked the tiles one load at a time (24 us of a 245 us level).
@@ -349,15 +431,15 @@ __global__ __launch_bounds__(WG_THREADS) void als_tile_step_k(const uint32_t* __
 // QNEXT (the LAST level of a factor's sweep): this factor's q is dead once its last correction is applied, so the pass stores the NEXT factor's q
 // (qnext[r], one coalesced double per row, from the factor-major table of all factors' q) in its place -- for EVERY row, also those the level does
 // not touch -- and the per-factor pick pass over the pairs is saved.
-template <bool W, bool UNIT, bool NT, int R, bool QNEXT>
-__global__ __launch_bounds__(WG_THREADS) void als_rows_apply_k(const uint32_t* __restrict__ lfi, const float* __restrict__ lval, int64_t n,
+template <bool W, bool UNIT, bool NT, int R, bool QNEXT, typename IT>
+__global__ __launch_bounds__(WG_THREADS) void als_rows_apply_k(const IT* __restrict__ lfi, const float* __restrict__ lval, int64_t n,
                                                                const double2* __restrict__ vstep, double2* __restrict__ qe, const double* __restrict__ qnext) {
   const int64_t r0 = (int64_t)blockIdx.x * (WG_THREADS * R) + threadIdx.x;
   uint32_t fi[R]; float x[R]; double2 c[R], s[R]; double qn[R];
 #pragma unroll
   for (int u = 0; u < R; ++u) {
     const int64_t r = r0 + (int64_t)u * WG_THREADS, rc = r < n ? r : n - 1;
-    fi[u] = stream_load<NT>(lfi + rc);
+    { const IT raw = stream_load<NT>(lfi + rc); fi[u] = raw == (IT)~(IT)0 ? TILED_NONE : (uint32_t)raw; }
     x[u] = UNIT ? 1.0f : stream_load<NT>(lval + rc);
     c[u] = qe[rc];
     qn[u] = QNEXT ? stream_load<NT>(qnext + rc) : 0.0;
@@ -430,6 +512,12 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
     if (T->unit) { if (nt_mask & 1) FMX_SUMS2(LGv, true, true); else FMX_SUMS2(LGv, true, false); }                                                         \
     else { if (nt_mask & 1) FMX_SUMS2(LGv, false, true); else FMX_SUMS2(LGv, false, false); }                                                               \
   } while (0)
+  if (T->tslot) {   // the lists' first rows inline (one lane per list)
+    if (T->unit) hipLaunchKernelGGL((als_tile_sums_slot_k<W, true>), g, blk, 0, e->stream, T->tslot, T->tvslot, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, (const double*)vf,
+                                    (const double2*)d_qe, T->tshift, T->n_tiles, B, T->n, partial, T->max_cnt);
+    else hipLaunchKernelGGL((als_tile_sums_slot_k<W, false>), g, blk, 0, e->stream, T->tslot, T->tvslot, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, (const double*)vf,
+                            (const double2*)d_qe, T->tshift, T->n_tiles, B, T->n, partial, T->max_cnt);
+  } else
   switch (T->lg) {
     case 2: FMX_SUMS(2); break;
     case 4: FMX_SUMS(4); break;
@@ -454,12 +542,16 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
   else hipLaunchKernelGGL((als_tile_step_k<W, false>), dim3(sgrid + pgrid), blk, 0, e->stream, T->feats + lvl0, cnt, (const double2*)partial, T->max_cnt, T->n_tiles, P, e->kp64, dyn,
                           (const double*)vf, vstep, sgrid, next_feats, next_cnt, next_vf);
   e->als_vf_slot = next_slot; e->als_vf_buf = 1 - buf;
-  const uint32_t* lfi = T->lfi + (size_t)s * T->n;
+  const uint32_t* lfi32 = T->lfi16 ? nullptr : reinterpret_cast<const uint32_t*>(T->lfi) + (size_t)s * T->n;
+  const uint16_t* lfi16 = T->lfi16 ? reinterpret_cast<const uint16_t*>(T->lfi) + (size_t)s * T->n : nullptr;
   const float* lval = T->lval ? T->lval + (size_t)s * T->n : nullptr;
   const double* qnext = (!W && last) ? e->als_qnext : nullptr;
 #define FMX_APPLY(UNITv, NTv, Rv, QNv)                                                                                                                    \
-  hipLaunchKernelGGL((als_rows_apply_k<W, UNITv, NTv, Rv, QNv>), dim3((unsigned)((T->n + WG_THREADS * Rv - 1) / (WG_THREADS * Rv))), blk, 0, e->stream, lfi, lval, T->n,   \
-                     (const double2*)vstep, d_qe, qnext)
+  do {                                                                                                                                                    \
+    const dim3 ag((unsigned)((T->n + WG_THREADS * Rv - 1) / (WG_THREADS * Rv)));                                                                            \
+    if (lfi16) hipLaunchKernelGGL((als_rows_apply_k<W, UNITv, NTv, Rv, QNv, uint16_t>), ag, blk, 0, e->stream, lfi16, lval, T->n, (const double2*)vstep, d_qe, qnext); \
+    else hipLaunchKernelGGL((als_rows_apply_k<W, UNITv, NTv, Rv, QNv, uint32_t>), ag, blk, 0, e->stream, lfi32, lval, T->n, (const double2*)vstep, d_qe, qnext);       \
+  } while (0)
 #define FMX_APPLY_Q(UNITv, NTv, Rv) do { if (qnext) FMX_APPLY(UNITv, NTv, Rv, true); else FMX_APPLY(UNITv, NTv, Rv, false); } while (0)
 #define FMX_APPLY_R(Rv)                                                                                                                                   \
   do {                                                                                                                                                    \
