@@ -27,7 +27,6 @@
 namespace fmx {
 
 constexpr uint32_t TILED_NONE = 0xFFFFFFFFu;
-constexpr int TILED_SLOT = 8;   // rows of a (tile, feature) list kept inline (lists average 3.9 entries at 131 072-row tiles of configs[4]; 98 % hold at most 8)
 
 struct AlsTiled {
   int64_t n = 0;
@@ -44,8 +43,6 @@ struct AlsTiled {
   void* lfi = nullptr;           // [n_slots][n] index (inside its level) of the feature row r holds at that level (u16 when every level has fewer than 65 535
                                  // features -- lfi16 -- else u32), all ones: none
   int lfi16 = 0;
-  uint32_t* tslot = nullptr;     // [n_tiles][n_feats][SLOT] the first SLOT rows of every (tile, feature) list INLINE (all ones: no entry): a list's rows arrive with one
-  float* tvslot = nullptr;       // coalesced load instead of offsets -> rows (two dependent loads); lists longer than SLOT continue in trow / tval behind toff
   float* lval = nullptr;         // [n_slots][n] its value (null: every value is 1.0f)
   uint32_t* toff = nullptr;      // [n_tiles][n_feats + 1] entry offsets of the (tile, feature) lists, relative to the tile's first entry
   int64_t* tile_base = nullptr;  // [n_tiles + 1] (device) first entry of each tile in trow / tval
@@ -53,7 +50,6 @@ struct AlsTiled {
   float* tval = nullptr;         // [entries + 1] (null: unit values)
   ~AlsTiled() {
     (void)hipFree(feats); (void)hipFree(lfi); (void)hipFree(lval); (void)hipFree(toff); (void)hipFree(tile_base); (void)hipFree(trow); (void)hipFree(tval);
-    (void)hipFree(tslot); (void)hipFree(tvslot);
   }
 };
 
@@ -93,7 +89,7 @@ __global__ __launch_bounds__(WG_THREADS) void tiled_count_k(const int64_t* __res
 __global__ __launch_bounds__(WG_THREADS) void tiled_scatter_k(const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
                                                               const uint32_t* __restrict__ rank_of, uint32_t p, int tshift, size_t nf1,
                                                               const uint32_t* __restrict__ toff, const int64_t* __restrict__ tile_base,
-                                                              uint32_t* __restrict__ trow, float* __restrict__ tval, uint32_t* __restrict__ tslot, float* __restrict__ tvslot) {
+                                                              uint32_t* __restrict__ trow, float* __restrict__ tval) {
   const int lane = threadIdx.x & 63;
   const int64_t j = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6;
   if (j >= (int64_t)p) return;
@@ -111,11 +107,6 @@ __global__ __launch_bounds__(WG_THREADS) void tiled_scatter_k(const int64_t* __r
     const int64_t dst = tile_base[tile] + (int64_t)toff[(size_t)tile * nf1 + k] + (t - a);
     trow[dst] = r - lo;
     if (tval) tval[dst] = cval[t];
-    if (tslot && t - a < TILED_SLOT) {   // the list's first rows, inline
-      const size_t at = ((size_t)tile * (nf1 - 1) + k) * TILED_SLOT + (size_t)(t - a);
-      tslot[at] = r - lo;
-      if (tvslot) tvslot[at] = cval[t];
-    }
   }
 }
 
@@ -212,14 +203,6 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   FMX_HIP(hipMemcpyAsync(w.slot_of_feat, slot_of_feat.data(), (size_t)p * 4, hipMemcpyHostToDevice, stream));
   FMX_HIP(hipMemcpyAsync(T->feats, feats.data(), (size_t)T->n_feats * 4, hipMemcpyHostToDevice, stream));
   FMX_HIP(hipMemsetAsync(T->lfi, 0xFF, sn * isz, stream));
-  // inline slots (FMX_ALS_SLOTS=0: none): worth their 32 bytes per list where lists are short -- on average at most 0.6 SLOT entries
-  const size_t n_lists = (size_t)T->n_feats * (size_t)T->n_tiles;
-  if (env_int("FMX_ALS_SLOTS", 1) != 0 && T->lg == 1 && (mode > 0 || (double)m->nnz <= 0.6 * TILED_SLOT * (double)n_lists) && n_lists * TILED_SLOT * 4 < ((size_t)12 << 30)) {
-    if (ok(hipMalloc(&T->tslot, n_lists * TILED_SLOT * 4)) && (T->unit || ok(hipMalloc(&T->tvslot, n_lists * TILED_SLOT * 4)))) {
-      FMX_HIP(hipMemsetAsync(T->tslot, 0xFF, n_lists * TILED_SLOT * 4, stream));
-      if (T->tvslot) FMX_HIP(hipMemsetAsync(T->tvslot, 0, n_lists * TILED_SLOT * 4, stream));
-    } else { (void)hipFree(T->tslot); T->tslot = nullptr; (void)hipFree(T->tvslot); T->tvslot = nullptr; }
-  }
   FMX_HIP(hipMemsetAsync(w.counts, 0, nf1 * T->n_tiles * 4, stream));
   FMX_HIP(hipMemsetAsync(T->trow, 0, ((size_t)m->nnz + 1) * 4, stream));
   if (T->tval) FMX_HIP(hipMemsetAsync(T->tval, 0, ((size_t)m->nnz + 1) * 4, stream));
@@ -235,8 +218,7 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   if (!ok(hipMalloc(&w.scan, scan_bytes ? scan_bytes : 16))) return FMX_OK;
   for (int t = 0; t < T->n_tiles; ++t)
     FMX_HIP(rocprim::exclusive_scan(w.scan, scan_bytes, w.counts + (size_t)t * nf1, T->toff + (size_t)t * nf1, 0u, nf1, rocprim::plus<uint32_t>(), stream));
-  hipLaunchKernelGGL(tiled_scatter_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, m->cval, w.rank_of, p, ts, nf1, T->toff, T->tile_base, T->trow, T->tval,
-                     T->tslot, T->tvslot);
+  hipLaunchKernelGGL(tiled_scatter_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, m->cval, w.rank_of, p, ts, nf1, T->toff, T->tile_base, T->trow, T->tval);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipStreamSynchronize(stream));
   m->als_tiled = T.release();
@@ -322,62 +304,6 @@ __global__ __launch_bounds__(WG_THREADS) void als_tile_sums_k(const uint32_t* __
 #pragma unroll
   for (int o = LG / 2; o > 0; o >>= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }
   if (lg == 0 && live) partial[(size_t)tile * max_cnt + fi] = make_double2(mean, var);
-}
-
-// The sums pass with the lists' first rows INLINE: thread fi loads its list's TILED_SLOT rows as two 16-byte loads (neighbouring threads read neighbouring
-// 32 bytes: coalesced), then all its gathers go out at once through a buffer descriptor over the tile's slice -- an empty slot's offset lies beyond the
-// descriptor and issues no request.  Two dependent rounds instead of three (offsets -> rows -> pairs), eight gathers in flight per thread instead of four.
-// A list longer than the slots (its last slot is taken) continues behind the offsets in trow / tval.  Entries are added in list order, as in als_tile_sums_k.
-typedef unsigned int tiled_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double2 tiled_buf_pair(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-  const tiled_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
-}
-template <bool W, bool UNIT>
-__global__ __launch_bounds__(WG_THREADS) void als_tile_sums_slot_k(const uint32_t* __restrict__ tslot, const float* __restrict__ tvslot, const uint32_t* __restrict__ toff, size_t nf1,
-                                                                   uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base, const uint32_t* __restrict__ trow,
-                                                                   const float* __restrict__ tval, const double* __restrict__ vf, const double2* __restrict__ qe, int tshift,
-                                                                   int n_tiles, int B, int64_t n, double2* __restrict__ partial, uint32_t max_cnt) {
-  const int b = blockIdx.x;
-  const int x = b & 7, i = b >> 3;
-  const int tile = (i / B) * 8 + x, chunk = i % B;
-  if (tile >= n_tiles) return;
-  const uint32_t fi_raw = (uint32_t)chunk * WG_THREADS + threadIdx.x;
-  const bool live = fi_raw < cnt;
-  const uint32_t fi = live ? fi_raw : cnt - 1;
-  const size_t list = (size_t)tile * (nf1 - 1) + lvl0 + fi;
-  const uint4 s0 = *reinterpret_cast<const uint4*>(tslot + list * TILED_SLOT), s1 = *reinterpret_cast<const uint4*>(tslot + list * TILED_SLOT + 4);
-  float4 x0 = make_float4(1.f, 1.f, 1.f, 1.f), x1 = x0;
-  if (!UNIT) { x0 = *reinterpret_cast<const float4*>(tvslot + list * TILED_SLOT); x1 = *reinterpret_cast<const float4*>(tvslot + list * TILED_SLOT + 4); }
-  const int64_t r0 = (int64_t)tile << tshift;
-  const int64_t rows = (r0 + ((int64_t)1 << tshift) < n ? r0 + ((int64_t)1 << tshift) : n) - r0;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(qe + r0), 0, (int)(rows * 16), 0x00020000);
-  const double old = vf[fi];
-  const uint32_t rr[TILED_SLOT] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-  const float xs[TILED_SLOT] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-  double2 c[TILED_SLOT];
-#pragma unroll
-  for (int q = 0; q < TILED_SLOT; ++q) c[q] = tiled_buf_pair(rs, (rr[q] == TILED_NONE || !live) ? 0x80000000u : rr[q] * 16u);
-  double mean = 0.0, var = 0.0;
-#pragma unroll
-  for (int q = 0; q < TILED_SLOT; ++q) {
-    if (rr[q] == TILED_NONE) continue;
-    if (W) { const double xd = (double)xs[q]; mean += c[q].y * xd - old * xd * xd; var += xd * xd; }
-    else { const float xx = xs[q] * xs[q]; const double h = (double)xs[q] * c[q].x - (double)xx * old; mean += h * c[q].y; var += h * h; }
-  }
-  if (rr[TILED_SLOT - 1] != TILED_NONE && live) {   // a longer list: entries TILED_SLOT.. behind the offsets (rare: 2 % of the lists at configs[4])
-    const uint32_t* off = toff + (size_t)tile * nf1 + lvl0 + fi;
-    const uint32_t le = off[1];
-    const int64_t tb = tile_base[tile];
-    const double2* __restrict__ slice = qe + r0;
-    for (uint32_t t = off[0] + TILED_SLOT; t < le; ++t) {
-      const float xv = UNIT ? 1.0f : tval[tb + t];
-      const double2 cc = slice[trow[tb + t]];
-      if (W) { const double xd = (double)xv; mean += cc.y * xd - old * xd * xd; var += xd * xd; }
-      else { const float xx = xv * xv; const double h = (double)xv * cc.x - (double)xx * old; mean += h * cc.y; var += h * h; }
-    }
-  }
-  if (live) partial[(size_t)tile * max_cnt + fi] = make_double2(mean, var);
 }
 
 // 16 features per workgroup, 16 threads per feature: thread (tl, fl) adds the pairs of tiles tl, tl + 16, ... of feature fl in that order, the sixteen
@@ -512,12 +438,6 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
     if (T->unit) { if (nt_mask & 1) FMX_SUMS2(LGv, true, true); else FMX_SUMS2(LGv, true, false); }                                                         \
     else { if (nt_mask & 1) FMX_SUMS2(LGv, false, true); else FMX_SUMS2(LGv, false, false); }                                                               \
   } while (0)
-  if (T->tslot) {   // the lists' first rows inline (one lane per list)
-    if (T->unit) hipLaunchKernelGGL((als_tile_sums_slot_k<W, true>), g, blk, 0, e->stream, T->tslot, T->tvslot, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, (const double*)vf,
-                                    (const double2*)d_qe, T->tshift, T->n_tiles, B, T->n, partial, T->max_cnt);
-    else hipLaunchKernelGGL((als_tile_sums_slot_k<W, false>), g, blk, 0, e->stream, T->tslot, T->tvslot, T->toff, nf1, lvl0, cnt, T->tile_base, T->trow, T->tval, (const double*)vf,
-                            (const double2*)d_qe, T->tshift, T->n_tiles, B, T->n, partial, T->max_cnt);
-  } else
   switch (T->lg) {
     case 2: FMX_SUMS(2); break;
     case 4: FMX_SUMS(4); break;
