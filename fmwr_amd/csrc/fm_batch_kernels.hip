@@ -253,8 +253,13 @@ extern "C" int fmx_debug_trace(unsigned long long* out) {
 // ... -- a 30-entry row is then ONE round of eight gathers per group instead of four -- and the partial sums meet in a fixed
 // butterfly ((0+1)+(2+3)).  Deterministic; the association of a row's sums then differs from the large-step form by design
 // (both are inside the 1e-5 bar and the fp64-state 1e-11 one: the sums are fp64).
+#ifndef FMX_ROWS_WAVES
+#define FMX_ROWS_WAVES_ATTR
+#else
+#define FMX_ROWS_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(FMX_ROWS_WAVES, FMX_ROWS_WAVES)))
+#endif
 template <typename T, int LPR, bool TRAIN, int WGT, int SPLIT = 1>
-__global__ __launch_bounds__(WGT) void fm_rows_forward_k(RowsArgs a, Hyper h) {
+__global__ __launch_bounds__(WGT) FMX_ROWS_WAVES_ATTR void fm_rows_forward_k(RowsArgs a, Hyper h) {
   using vec_t = typename Slice<T>::vec;
   constexpr int VEC = Slice<T>::N;
   constexpr int KP = LPR * VEC;
@@ -516,6 +521,212 @@ __global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_dyn_k(RowsArgs a, 
   }
 }
 
+// ---- phase 1, flat form (opt-in: FMX_ROWS_FLAT=1): the entries of a block of rows as ONE stream, cut evenly over the lane groups ------------------------
+// (north_star: "entries of a workgroup's rows as one stream ... row boundaries ... segmented combine"; the reference's loop is core/Model.h:83-97.)
+// The static kernel gives lane group g row g of its block: on SURVEY 8(d)'s ragged law (Poisson(30) clipped to [1, 64]) the groups idle for 30 % of the
+// block's life and phase 1 takes 18 % longer than on rows of exactly 30 entries.  Here the block's staged entries [0, cnt) are cut into G equal ranges;
+// group g walks range g whatever rows it crosses, in rounds of RU gathers like the static kernel, and leaves one PIECE (the factor sums of a run of one
+// row's entries) per row it touches in LDS: the FIRST piece of its range under its own index (it may continue a row that an earlier group began), every
+// later piece -- which starts its row -- under the row's index.  After a barrier group g adds up the pieces of row g in entry order (the piece that starts
+// the row, then the first pieces of the following groups while they still belong to it) and finishes the row exactly as the static kernel does.  No
+// atomics; the order is fixed by the matrix.
+//   * A row's sums associate differently from the static kernel's one sequential sum (pieces are summed first): same 1e-5 / 1e-11 bars against the
+//     oracle, other last bits -- so the form could only be chosen per MATRIX by a rule on its row lengths, never by timing.
+//   * The blocks are those of the MATRIX (rows b * G .. b * G + G - 1, whatever row the launch starts on) and a block is always cut as a whole, so a
+//     row's bits depend on the matrix alone -- not on the launch, tile, step, rank share or schedule that reaches it.  A launch that starts or ends
+//     inside a block walks the whole block and stores only its own rows.
+// MEASURED (profiles/r04_ragged_forms.txt) and therefore NOT the default: perfectly balanced, and slower -- 0.218 against 0.193 ms per 262 144-row tile on
+// the Poisson law, 0.217 against 0.172 on lengths 25..35, and equal (0.162) only where every range is exactly one row.  With its boundary handling switched
+// off entirely it is as slow: the cost is not the pieces.  What the static kernel has and this walk gives up is that the lane groups of a wave sit at the
+// same position of their column-sorted rows, so one gather instruction's rows come from one narrow band of the table (one column per stratum 0.149 ms,
+// i.i.d. sorted columns 0.162, ragged rows 0.193, no common position 0.217).  The same record holds five more forms that were tried and removed: one-wave
+// workgroups on large steps, two entries outstanding per lane group, no LDS stage at all, 4 / 6 / 8 waves per SIMD, and phase 1 without its w requests
+// (which changes nothing: the second request per nonzero is free under the serial schedule).
+template <typename T, int LPR, bool TRAIN>
+__global__ __launch_bounds__(WG_THREADS) void fm_rows_forward_flat_k(RowsArgs a, Hyper h) {
+  using vec_t = typename Slice<T>::vec;
+  constexpr int VEC = Slice<T>::N;
+  constexpr int KP = LPR * VEC;
+  constexpr int G = WG_THREADS / LPR;  // lane groups = rows of a block
+  constexpr int CHUNK = STAGE_ENTRIES;
+  constexpr int RU = FMX_U_LARGE;
+  constexpr int NP = VEC + 1;          // a piece, per lane: VEC factor sums and the lane's part of sum (v x)^2
+  __shared__ uint2 stage[CHUNK + RU];
+  __shared__ double piece[2][NP][WG_THREADS];  // [0][.][g * LPR + lane]: group g's first piece of the chunk; [1][.][r * LPR + lane]: the piece that starts row r
+  __shared__ double plin[2][G];                // the pieces' linear parts
+  __shared__ int rp[G + 1];                    // the block's row offsets, relative to its first entry
+  __shared__ double red[TRAIN ? G : 1];
+
+  const int tid = threadIdx.x;
+  const int grp = tid / LPR, lig = tid % LPR;
+  const int64_t G0 = (a.r0 / G + (int64_t)blockIdx.x) * G;  // the block's first row, in the matrix
+  const int64_t G1 = G0 + G < a.nmat ? G0 + G : a.nmat;
+  const int rows_here = (int)(G1 - G0);
+  const int64_t lo = a.row_ptr[G0], hi = a.row_ptr[G1];
+  for (int i = tid; i <= G; i += WG_THREADS) rp[i] = (int)(a.row_ptr[G0 + (i < rows_here ? i : rows_here)] - lo);
+  const int64_t row = G0 + grp;          // the row this lane group finishes
+  const int64_t lr = row - a.r0;         // ... and its index in the launch
+  const bool have = grp < rows_here && lr >= 0 && lr < a.nrows;
+  const T* __restrict__ Vt = reinterpret_cast<const T*>(a.V) + lig * VEC;
+  const T* __restrict__ wt = a.w ? reinterpret_cast<const T*>(a.w) : reinterpret_cast<const T*>(a.V);  // always readable
+  const bool k1 = h.k1 != 0;
+
+  double s[VEC], qs = 0.0;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.0;
+  double lin = h.k0 ? a.scal[SC_W0] : 0.0;  // core/Model.h:77-78
+
+  for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
+    const int cnt = (hi - c0 < CHUNK) ? (int)(hi - c0) : CHUNK;
+    stage_entries<true>(stage, a.col, a.val, c0, cnt, a.unit);
+    __syncthreads();  // (the first one also publishes rp)
+    const int base = (int)(c0 - lo);
+    const int per = (cnt + G - 1) / G;
+    const int p0 = grp * per;
+    const int p1 = p0 + per < cnt ? p0 + per : cnt;
+    if (p0 < p1) {
+      int r = 0;
+      {  // the row holding entry p0: the last r with rp[r] <= base + p0 (rp[0] = 0 <= it < rp[rows_here])
+        int hi_i = rows_here;
+        const int x = base + p0;
+        while (hi_i - r > 1) {
+          const int mid = (r + hi_i) >> 1;
+          if (rp[mid] <= x) r = mid; else hi_i = mid;
+        }
+      }
+      int rend = rp[r + 1] - base;  // where row r ends, in chunk positions
+      int slot = grp;               // where the running piece goes: this group's first piece under the group's index ...
+      int kind = 0;
+      double ps[VEC], pq = 0.0, pl = 0.0;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) ps[i] = 0.0;
+      for (int t = p0; t < p1; t += RU) {
+        // straight-line as in fm_rows_forward_k: every LDS read, every gather, then the arithmetic (no load under a condition)
+        uint2 en[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) en[u] = stage[t + u];
+#pragma unroll
+        for (int u = 1; u < RU; ++u)
+          if (t + u >= p1) en[u] = make_uint2(en[0].x, 0u);
+        vec_t vv[RU];
+        T wv[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          vv[u] = gather_row(Vt + ((size_t)en[u].x << RowStride<T, LPR>::v(a.vsh)));
+          wv[u] = wt[(size_t)en[u].x << RowStride<T, LPR>::w(a.wsh)];
+          if (a.serial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          if (t + u < p1) {
+            if (t + u >= rend) {  // row r ends before this entry: its piece is complete
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) { piece[kind][i][slot * LPR + lig] = ps[i]; ps[i] = 0.0; }
+              piece[kind][VEC][slot * LPR + lig] = pq;
+              if (lig == 0) plin[kind][slot] = pl;
+              pq = 0.0; pl = 0.0;
+              do { ++r; rend = rp[r + 1] - base; } while (t + u >= rend);  // (rows without entries are passed over)
+              slot = r; kind = 1;   // ... every later one starts its row: under the row's index
+            }
+            const double x = (double)__uint_as_float(en[u].y);
+            if (k1) pl += (double)wv[u] * x;
+            double vf[VEC];
+            slice_get(vv[u], vf);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const double tmp = vf[i] * x;
+              ps[i] += tmp;
+              pq += tmp * tmp;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) piece[kind][i][slot * LPR + lig] = ps[i];
+      piece[kind][VEC][slot * LPR + lig] = pq;
+      if (lig == 0) plin[kind][slot] = pl;
+    }
+    __syncthreads();
+    if (grp < rows_here) {  // the pieces of row grp inside this chunk, in entry order
+      const int b = rp[grp] - base > 0 ? rp[grp] - base : 0;
+      const int e = rp[grp + 1] - base < cnt ? rp[grp + 1] - base : cnt;
+      if (b < e) {
+        int g = b / per;
+        const int gB = (e - 1) / per;
+        if (b > g * per) {  // the row starts inside group g's range: that piece lies under the row's index
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) s[i] += piece[1][i][grp * LPR + lig];
+          qs += piece[1][VEC][grp * LPR + lig];
+          lin += plin[1][grp];
+          ++g;
+        }
+        for (; g <= gB; ++g) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) s[i] += piece[0][i][g * LPR + lig];
+          qs += piece[0][VEC][g * LPR + lig];
+          lin += plin[0][g];
+        }
+      }
+    }
+    // (no barrier here: the next chunk's staging writes `stage` only, and its pieces are written after its own first barrier)
+  }
+
+  double pair = 0.0;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) pair += s[i] * s[i];
+  pair = 0.5 * (pair - qs);  // core/Model.h:100
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) pair += __shfl_xor(pair, off);
+  const double y_hat = lin + pair;
+
+  if constexpr (TRAIN) {
+    double mult = 0.0;
+    if (have) {
+      mult = grad_mult(h, y_hat, a.y[row]);
+      vec_t srow = slice_make(s, T());
+      if constexpr (sizeof(T) == 4) srow = embed_store<LPR>(srow, lig, (float)mult, a.embed);
+      *reinterpret_cast<vec_t*>(reinterpret_cast<T*>(a.S) + (size_t)lr * KP + lig * VEC) = srow;
+      if (lig == 0) reinterpret_cast<T*>(a.amul)[lr] = (T)mult;
+    }
+    if (lig == 0) red[grp] = mult;
+    __syncthreads();
+    if (tid == 0) {  // fixed-order partial sums for the w0 step (rows of the block that are not the launch's count as zero)
+      double g0 = 0.0, q0 = 0.0;
+      for (int i = 0; i < G; ++i) { g0 += red[i]; q0 += red[i] * red[i]; }
+      a.partials[2 * (size_t)blockIdx.x] = g0;
+      a.partials[2 * (size_t)blockIdx.x + 1] = q0;
+    }
+  } else {
+    if (have && lig == 0 && a.yhat) a.yhat[lr] = link_apply(h, y_hat, a.link, a.pn_y);
+    if constexpr (sizeof(T) == 8) {
+      if (have && a.qout) {
+        if (a.qout_t > 0) { a.qout[(size_t)(lig * VEC) * a.qout_t + lr] = s[0]; a.qout[(size_t)(lig * VEC + 1) * a.qout_t + lr] = s[1]; }
+        else *reinterpret_cast<double2*>(a.qout + (size_t)lr * KP + lig * VEC) = make_double2(s[0], s[1]);
+      }
+    }
+  }
+}
+
+template <typename T, bool TRAIN>
+static int launch_rows_flat(fmx_engine* e, const RowsArgs& a, int kp) {
+  constexpr int VEC = Slice<T>::N;
+  const int lpr = kp / VEC;
+  const int64_t grid = rows_flat_blocks(a.r0, a.nrows, WG_THREADS / lpr);
+  if (grid == 0) return FMX_OK;
+  FMX_CHECK(grid < (1LL << 31), FMX_ERR_INVALID, "rows_forward: grid too large (%lld)", (long long)grid);
+  FMX_CHECK(a.nmat >= a.r0 + a.nrows, FMX_ERR_STATE, "rows_forward (flat): the matrix has %lld rows, the launch ends at %lld", (long long)a.nmat,
+            (long long)(a.r0 + a.nrows));
+  dim3 g((unsigned)grid), b(WG_THREADS);
+#define FMX_FLAT_CASE(L) case L: hipLaunchKernelGGL((fm_rows_forward_flat_k<T, L, TRAIN>), g, b, 0, e->stream, a, e->hyper); break;
+  switch (lpr) {
+    FMX_FLAT_CASE(1) FMX_FLAT_CASE(2) FMX_FLAT_CASE(4) FMX_FLAT_CASE(8) FMX_FLAT_CASE(16) FMX_FLAT_CASE(32) FMX_FLAT_CASE(64)
+    default: FMX_CHECK(false, FMX_ERR_INVALID, "unsupported padded factor count %d", kp);
+  }
+#undef FMX_FLAT_CASE
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
 template <typename T, bool TRAIN>
 static int launch_rows_dyn(fmx_engine* e, const RowsArgs& a, int kp) {
   constexpr int VEC = Slice<T>::N;
@@ -561,6 +772,7 @@ static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
 template <typename T, bool TRAIN>
 static int launch_rows_w(fmx_engine* e, const RowsArgs& a, int kp) {
   if (a.sort_rows && a.wg_threads != 64) return launch_rows_dyn<T, TRAIN>(e, a, kp);   // FMX_ROWS_PULL=1, rows of differing lengths, wide workgroups
+  if (a.flat == 1 && a.wg_threads != 64) return launch_rows_flat<T, TRAIN>(e, a, kp);      // rows of differing lengths (rows_flat), wide workgroups
   if (a.wg_threads == 64) return a.split == 4 ? launch_rows_t<T, TRAIN, 64, 4>(e, a, kp) : launch_rows_t<T, TRAIN, 64, 1>(e, a, kp);
   return launch_rows_t<T, TRAIN, WG_THREADS, 1>(e, a, kp);
 }

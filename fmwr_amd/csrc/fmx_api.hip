@@ -263,6 +263,7 @@ static int forward_rows(fmx_engine* e, const fmx_matrix* m, int64_t r0, int64_t 
   a.pn_y = e->probit;
   a.unit = m->unit_values;
   a.sort_rows = rows_ragged(m);
+  a.flat = rows_flat(m); a.nmat = m->n;
   FMX_TRY(launch_rows_forward(e, a, false, wide_state(e)));
   return FMX_OK;
 }
@@ -340,8 +341,9 @@ static int rows_phase(fmx_engine* e, fmx_matrix* m, const TileRun& t, int64_t st
   a.sort_rows = rows_ragged(m);
   a.wg_threads = rows_wg_threads(step_rows, mb_lpr(e));
   a.split = rows_split(step_rows, mb_lpr(e));
+  a.flat = rows_flat(m); a.nmat = m->n;
   const int rpw = a.wg_threads / (mb_lpr(e) * (a.wg_threads == 64 && a.split == 4 ? 4 : 1));
-  *n_partials = (t.nrows + rpw - 1) / rpw;
+  *n_partials = (a.flat == 1 && !a.sort_rows && a.wg_threads != 64) ? rows_flat_blocks(t.r0, t.nrows, rpw) : (t.nrows + rpw - 1) / rpw;
   return launch_rows_forward(e, a, true, mb_wide(e));
 }
 
@@ -1942,6 +1944,12 @@ int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double
   if (serial) *serial = e->rows_tune.decided;
   if (ms_serial) *ms_serial = e->rows_tune.ms[1];
   if (ms_pipelined) *ms_pipelined = e->rows_tune.ms[0];
+  return FMX_OK;
+}
+
+int fmx_matrix_rows_form(const fmx_matrix* m, int32_t* form) {
+  FMX_CHECK(m != nullptr && form != nullptr, FMX_ERR_INVALID, "NULL matrix or output");
+  *form = rows_ragged(m) ? 2 : (rows_flat(m) ? 1 : 0);
   return FMX_OK;
 }
 

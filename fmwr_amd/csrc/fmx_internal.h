@@ -359,6 +359,8 @@ struct RowsArgs {
   int wg_threads;       // 64: one-wave workgroups (rows_wg_threads); anything else: WG_THREADS
   int split;            // 4: four lane groups share a row (rows_split; one-wave workgroups only); anything else: one
   int serial;           // large steps: one entry's requests outstanding per lane group at a time (set by the launcher)
+  int flat;             // 1: wide launches take fm_rows_forward_flat_k (rows_flat: FMX_ROWS_FLAT=1 on a matrix whose rows differ in length); nmat must be set
+  int64_t nmat;         // rows of the matrix (the flat form cuts the MATRIX's blocks of rows, whole)
   int sort_rows;        // FMX_ROWS_PULL=1 on a matrix of differing row lengths: wide launches take fm_rows_forward_dyn_k (lane groups pull rows; same bits, measured slower)
 };
 // Small steps.  A CU sustains about 240 random 64-byte rows per microsecond whatever runs on it (its miss queue; the
@@ -379,6 +381,21 @@ inline int rows_ragged(const fmx_matrix* m) {
   const char* s = getenv("FMX_ROWS_PULL");   // (read per call: the tests compare the two forms)
   return (s && s[0] == '1' && m->fixed_row_len == 0 && m->n > 0) ? 1 : 0;
 }
+// The flat form of phase 1 (fm_rows_forward_flat_k) on matrices whose rows differ in length: opt-in, FMX_ROWS_FLAT=1 (read per call: the tests compare the
+// forms).  It changes the association of a row's sums (not the bars they are held to), so it could only ever be chosen by a rule on the MATRIX, never by a
+// measurement -- and it is MEASURED SLOWER than one lane group per row on every row-length law tried (profiles/r04_ragged_forms.txt: Poisson(30) in [1, 64]
+// 0.218 against 0.193 ms per 262 144-row tile, lengths 25..35 0.217 against 0.172), although it is perfectly balanced: what phase 1 lives on is that the lane
+// groups of a wave sit at the SAME position of their column-sorted rows, so that the rows one gather instruction fetches lie in one narrow band of the table
+// (one column per stratum 0.149 ms, i.i.d. sorted columns 0.162, ragged rows 0.193, the flat walk -- no common position at all -- 0.217).  The pull kernel
+// (FMX_ROWS_PULL=1) goes first.
+inline int rows_flat(const fmx_matrix* m) {
+  if (m->fixed_row_len != 0 || m->n <= 0 || m->nnz <= 0) return 0;
+  if ((int64_t)m->max_row_len * WG_THREADS >= (1LL << 31)) return 0;  // a block's entries are counted in 32 bits
+  const char* s = getenv("FMX_ROWS_FLAT");
+  return (s && s[0] == '1') ? 1 : 0;
+}
+// workgroups (= w0 partial sums) of a flat launch: the matrix's blocks of `g` rows that rows [r0, r0 + nrows) touch
+inline int64_t rows_flat_blocks(int64_t r0, int64_t nrows, int g) { return nrows > 0 ? (r0 + nrows - 1) / g - r0 / g + 1 : 0; }
 int launch_rows_forward(fmx_engine* e, const RowsArgs& a, bool train, bool fp64_tables);
 int ensure_probit(fmx_engine* e);  // builds and uploads the probit tables (fm_probit.h) on first use
 

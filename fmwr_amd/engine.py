@@ -121,6 +121,12 @@ class Matrix:
             raise ValueError("the length of scale:mean or scale:std is not equal")  # util/Smatrix.h:143-145
         L.check(L.lib().fmx_matrix_normalize(self.h, _p(mean), _p(std)))
 
+    def rows_form(self):
+        """0 / 1 / 2: the form of phase 1 that large steps take on this matrix (fmx_matrix_rows_form: per-row lane groups, flat, pulled)."""
+        f = C.c_int32()
+        L.check(L.lib().fmx_matrix_rows_form(self.h, C.byref(f)))
+        return f.value
+
     def export(self, r0=0, r1=None):
         """rows [r0, r1) -> (row_ptr, col, val, y) numpy arrays (row_ptr rebased to 0)."""
         r1 = self.n if r1 is None else r1

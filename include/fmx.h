@@ -451,6 +451,12 @@ int fmx_profile_reset(fmx_engine* e);
  * such launches: *serial = 1 one entry's requests outstanding per lane group, 0 four entries', -1 not decided yet;
  * ms_serial / ms_pipelined = the six timed launches of each.  The choice never changes a result.  FMX_ROWS_SERIAL=0/1 pins it. */
 int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double* ms_pipelined);
+/* Which form of phase 1 large steps (and large forward passes) take on this matrix: 0 one lane group per row (the product form), 1 the flat form
+ * (FMX_ROWS_FLAT=1 on rows of differing lengths: the entries of a block of rows as one stream cut evenly over the lane groups, a row's pieces combined in
+ * entry order; replaces the per-row loop of core/Model.h:83-97), 2 lane groups pulling rows (FMX_ROWS_PULL=1).  Forms 1 and 2 are measurement records
+ * (both slower, profiles/r04_ragged_forms.txt); form 1 associates a row's sums differently from forms 0 and 2 (same parity bars, other last bits) and
+ * under it a row's bits still depend on the matrix alone. */
+int fmx_matrix_rows_form(const fmx_matrix* m, int32_t* form);
 /* How the engine laid out its parameter tables: elements between consecutive features' V rows, and whether a feature's linear weight
  * sits inside its V row (fp32 mini-batch tables of at most 16 padded factors, from 3 M features up: out of the caches a nonzero then
  * costs one memory request instead of two; FMX_W_IN_ROW=0/1 in the environment overrides).  Never changes a result. */

@@ -469,6 +469,7 @@ def test_lane_groups_pulling_rows_changes_no_bit(monkeypatch):
         y = util.labels(n, 31)
         w0, w, v = util.params(p, k, 31)
         out = []
+        monkeypatch.delenv("FMX_ROWS_FLAT", raising=False)     # (the flat form associates differently: tests/test_gpu_flat_rows.py)
         for flag in ("1", "0"):
             monkeypatch.setenv("FMX_ROWS_PULL", flag)
             m = engine.Matrix.from_csr(rp, col, val, p, y)
