@@ -1332,7 +1332,10 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : (sizeof(ST)
       ST av[FMX_U];
       if (a.buf_gather) {  // wave-uniform: padding slots issue no request
 #pragma unroll
-        for (int u = 0; u < FMX_U; ++u) sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
+        for (int u = 0; u < FMX_U; ++u) {
+          sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
+          if (a.cols_serial == 1 || (a.cols_serial == 2 && (u & 1))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EXPERIMENT
+        }
         if (a.embed) {
           if constexpr (sizeof(ST) == 4) {
 #pragma unroll
@@ -1757,6 +1760,7 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
     if (dense_direct && direct_ok && a.walk && !a.tfeat && !a.load_gbuf && !a.store_gbuf && a.f0 == 0 && a.f1 == e->p) a.direct = 1;
   }
   a.inline0 = (a.direct && a.trow0 && a.list_entries >= 2 * (int64_t)a.n_tfeat) ? 1 : 0;  // (small launches of one-entry lists do not gain either)
+  { const char* cs = getenv("FMX_COLS_SERIAL"); a.cols_serial = cs ? atoi(cs) : 0; }   // EXPERIMENT
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;
