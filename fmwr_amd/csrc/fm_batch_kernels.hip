@@ -1258,7 +1258,8 @@ __device__ __forceinline__ ST* exchange_tail(const ColsTables<ST>& T) {
 // Main phase-2 kernel: one group of LPR lanes per feature list.  Lists longer than a.long_min entries (heavy hitters of a
 // skewed feature distribution) are left to the long-list kernels below; walking them with one group would serialise the tile.
 // (88-90 VGPRs: 5 workgroups per CU.  Asking the register allocator for 6 waves per SIMD spills to scratch -- phase 2 0.16 -> 0.31 ms per
-// tile -- and 4 or 8 or 16 gathers in flight per lane (FMX_U) change nothing or lose: profiles/r02_small_batch.txt, r02_ab.txt.)
+// tile -- and 4 or 8 or 16 gathers in flight per lane (FMX_U) change nothing or lose: profiles/r02_small_batch.txt, r02_ab.txt; ONE or TWO S rows
+// outstanding per lane group -- phase 1's winning schedule -- lose here: 0.200 / 0.171 against 0.153 ms per tile, profiles/r04_ragged_forms.txt section 9.)
 // SPARSE: the lean form for a sparse tile walked list by list (a.direct) with no dense exchange buffer in play -- no staging
 // array, no exchange-buffer code; fewer registers and 4 KB of LDS, so more workgroups per CU.  That walk is latency x occupancy
 // bound (three dependent memory rounds per list, lists of one to four entries), not byte bound: DESIGN.md section 6.1.
@@ -1332,10 +1333,7 @@ __global__ __launch_bounds__(WG_THREADS, SPARSE ? FMX_SPARSE_WAVES : (sizeof(ST)
       ST av[FMX_U];
       if (a.buf_gather) {  // wave-uniform: padding slots issue no request
 #pragma unroll
-        for (int u = 0; u < FMX_U; ++u) {
-          sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
-          if (a.cols_serial == 1 || (a.cols_serial == 2 && (u & 1))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EXPERIMENT
-        }
+        for (int u = 0; u < FMX_U; ++u) sv[u] = buf_row(s_rsrc, ok[u] ? en[u].x * (uint32_t)(KP * sizeof(ST)) + (uint32_t)(lig * 16) : BUF_SKIP, ST());
         if (a.embed) {
           if constexpr (sizeof(ST) == 4) {
 #pragma unroll
@@ -1760,7 +1758,6 @@ int launch_cols_update(fmx_engine* e, const ColsArgs& a_in, const LongArgs& la) 
     if (dense_direct && direct_ok && a.walk && !a.tfeat && !a.load_gbuf && !a.store_gbuf && a.f0 == 0 && a.f1 == e->p) a.direct = 1;
   }
   a.inline0 = (a.direct && a.trow0 && a.list_entries >= 2 * (int64_t)a.n_tfeat) ? 1 : 0;  // (small launches of one-entry lists do not gain either)
-  { const char* cs = getenv("FMX_COLS_SERIAL"); a.cols_serial = cs ? atoi(cs) : 0; }   // EXPERIMENT
   a.buf_gather = (buf_ok && a.walk && (int64_t)(e->ws_rows - a.s_row0) * mb_kp(e) * (int64_t)mb_elem(e) < (1LL << 31)) ? 1 : 0;
   prof_begin(e, FMX_KERNEL_COLS_UPDATE);
   int st;

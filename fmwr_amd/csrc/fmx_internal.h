@@ -431,7 +431,6 @@ struct ColsArgs {
   int direct;            // set by the launcher: every group reads its list's entries itself (sparse tiles), no LDS staging
   int64_t list_entries;  // entries of the tile (sparse walk: decides `direct`)
   int embed;             // EmbedMode of the S rows (set by the launcher; must match phase 1's)
-  int cols_serial;       // EXPERIMENT: 1 / 2: one / two S rows outstanding per lane group
   int buf_gather;        // set by the launcher: S rows / multipliers are gathered through buffer descriptors (padding slots issue no request)
 };
 // long lists of one tile (heavy-hitter features): cut into segments, see fm_batch_kernels.hip
