@@ -151,7 +151,7 @@ def pmc_traffic(kernel, args):
                 and (39 if crit else opt("--nnz", 30)) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64)
                 and (a[a.index("--workload") + 1] if "--workload" in a else "uniform") == args.workload)
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
-            best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f))
+            best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f), d[kernel].get("fabric_bytes_per_launch"), d[kernel].get("fabric_reads_128B_frac"))
     return best
 
 
@@ -899,6 +899,11 @@ def run_minibatch(args, rank, local_rank, world):
                 # the counted memory-side bytes of a launch (FETCH_SIZE x 2 + WRITE_SIZE, Infinity Cache hits included: an upper bound on HBM bytes for
                 # the cache-resident shapes, close to the bytes of whole 128-byte lines for tables that live in HBM) over this run's launch time / HBM peak
                 per_kernel[name]["traffic_frac_upper_bound"] = tr[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if tr[2]:
+                    # the L2's fabric reads counted by size (128 x TCC_EA0_RDREQ_128B + 64 x ..._64B + 32 x ..._32B) + WRITE_SIZE: on gfx950 every miss fetches a whole
+                    # 128-byte line (profiles/r04_gather_granularity.txt), so a random 64-byte row costs 128 bytes of fabric bandwidth -- this is what the launch
+                    # really moved, over this run's launch time / HBM peak
+                    per_kernel[name]["fabric"] = {"bytes_per_launch": tr[2], "frac": tr[2] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "reads_of_128B_frac": tr[3], "source": f"profiles/{tr[1]}"}
         step_gbs = b_step / (dt / args.steps) / 1e9   # per GPU: B rows of this rank per step
         traffic = per_kernel[dom]["traffic"]
         out = {
@@ -928,9 +933,16 @@ def run_minibatch(args, rank, local_rank, world):
             "roofline": {"bound": "hbm", "kernel": "step = fm_rows_forward + fm_cols_update per tile", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (f"{per_kernel[dom]['traffic_source']}: (FETCH_SIZE*2 + WRITE_SIZE) KiB per launch of {dom}, separate --pmc passes; "
-                                            "upper bound, see DESIGN.md section 6") if traffic else None,
+                                            "an upper bound by the guide's rule, EXACT here: every fabric read of these kernels is a 128-byte line "
+                                            "(TCC_EA0_RDREQ_128B / TCC_EA0_RDREQ = 1.00 in the same summary; DESIGN.md section 6.8)") if traffic else None,
                          "algorithmic_bytes_per_example": b_step / B, "dominant_kernel": dom, "kernels": per_kernel},
         }
+        if world == 1 and all("fabric" in v for v in per_kernel.values()):
+            fb = sum(v["fabric"]["bytes_per_launch"] for v in per_kernel.values()) * (rows_step / tile_rows if tile_rows else 1)
+            out["roofline"]["fabric"] = {"bytes_per_step": fb, "frac": fb / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "line_bytes": 128,
+                                         "note": "what the step's launches really move across the fabric (the L2's reads counted by size + writes, PMC) over the step time / HBM peak: "
+                                                 "a miss fetches a whole 128-byte line, so the random 64-byte rows of k = 16 fp32 tables cost twice their algorithmic bytes and `frac` on "
+                                                 "algorithmic bytes cannot pass 0.5 on the gather-bound part (DESIGN.md section 6.8)"}
         if fwd_rate is not None:
             out["forward_rows_per_s"] = fwd_rate
         if world == 1:

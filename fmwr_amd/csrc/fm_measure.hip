@@ -17,9 +17,26 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // a full-avalanche int
   return x;
 }
 
+template <int AUX>
+__device__ __forceinline__ float4 probe_load_aux(const float4* base, uint32_t bytes, uint32_t off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base), 0, (int)bytes, 0x00020000);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// mode 0: a plain load; 1: non-temporal (nt); 2: system scope (sc0 sc1); 3: both -- what a miss then fetches from the fabric is read off the TCC_EA0_RDREQ_* counters
+__device__ __forceinline__ float4 probe_load(const float4* base, uint32_t bytes, uint32_t off, int mode) {
+  if (mode == 1) return probe_load_aux<2>(base, bytes, off);
+  if (mode == 2) return probe_load_aux<17>(base, bytes, off);
+  if (mode == 3) return probe_load_aux<19>(base, bytes, off);
+  return probe_load_aux<0>(base, bytes, off);
+}
+
+static int g_probe_mode = 0;   // FMX_PROBE_LOAD (0..3, see probe_load); FMX_PROBE_UNCACHED=1: the table is allocated hipDeviceMallocUncached
+
 template <int LPR, int U>
 __global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __restrict__ table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt,
-                                                             float4* __restrict__ out) {
+                                                             float4* __restrict__ out, int mode = 0) {
   extern __shared__ char occupancy_pad[];  // dynamic LDS only limits how many workgroups share a CU (fmx_measure_gather_occ)
   (void)occupancy_pad;
   const int64_t g = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) / LPR;
@@ -33,7 +50,7 @@ __global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __res
     for (int u = 0; u < U; ++u) {
       // multiply-shift maps the hash onto [0, rows) without a division
       const uint32_t r = (uint32_t)(((uint64_t)mix32(base + (uint32_t)(t + u)) * rows) >> 32);
-      v[u] = table[(size_t)r * LPR + lig];
+      v[u] = mode ? probe_load(table, rows * (uint32_t)(LPR * 16), (r * LPR + lig) * 16u, mode) : table[(size_t)r * LPR + lig];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
@@ -70,8 +87,8 @@ static int g_probe_lds = 0;  // bytes of dynamic LDS per workgroup (0: none): 16
 
 template <int LPR>
 static void launch_probe(int in_flight, dim3 g, dim3 b, hipStream_t s, const float4* table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt, float4* out) {
-  if (in_flight >= 8) hipLaunchKernelGGL((gather_probe_k<LPR, 8>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out);
-  else hipLaunchKernelGGL((gather_probe_k<LPR, 4>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out);
+  if (in_flight >= 8) hipLaunchKernelGGL((gather_probe_k<LPR, 8>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode);
+  else hipLaunchKernelGGL((gather_probe_k<LPR, 4>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode);
 }
 
 }  // namespace fmx
@@ -108,7 +125,10 @@ extern "C" int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_b
   hipEvent_t a = nullptr, b = nullptr;
   int st = FMX_OK;
   auto body = [&]() -> int {
-    FMX_HIP(hipMalloc(&table, (size_t)rows * row_bytes));
+    { const char* v = getenv("FMX_PROBE_LOAD"); g_probe_mode = v ? atoi(v) : 0; }
+    { const char* v = getenv("FMX_PROBE_UNCACHED");
+      if (v && v[0] == '1') FMX_HIP(hipExtMallocWithFlags((void**)&table, (size_t)rows * row_bytes, hipDeviceMallocUncached));
+      else FMX_HIP(hipMalloc(&table, (size_t)rows * row_bytes)); }
     FMX_HIP(hipMalloc(&out, (size_t)n_groups * row_bytes));
     FMX_HIP(hipMemset(table, 0, (size_t)rows * row_bytes));
     FMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));

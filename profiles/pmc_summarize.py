@@ -56,6 +56,16 @@ for k, d in res.items():
     if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d["TCC_MISS_sum"], 1)
 for k, d in res.items():
+    # The L2's reads from the fabric by SIZE (round 4: profiles/r04_gather_granularity.txt -- on gfx950 a miss fetches a whole 128-byte line whatever the load
+    # asked for and whatever its cache policy, so a random 64-byte row costs 128 bytes of fabric bandwidth): exact read bytes instead of the x2 bound.
+    if "TCC_EA0_RDREQ_128B_sum" in d and "TCC_EA0_RDREQ_sum" in d:
+        r128, r64, r32 = d["TCC_EA0_RDREQ_128B_sum"], d.get("TCC_EA0_RDREQ_64B_sum", 0.0), d.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        other = max(d["TCC_EA0_RDREQ_sum"] - r128 - r64 - r32, 0.0)
+        d["fabric_read_bytes"] = 128 * r128 + 64 * (r64 + other) + 32 * r32
+        d["fabric_reads_128B_frac"] = r128 / max(d["TCC_EA0_RDREQ_sum"], 1.0)
+        if "write_bytes" in d:
+            d["fabric_bytes_per_launch"] = d["fabric_read_bytes"] + d["write_bytes"]
+for k, d in res.items():
     if "fetch_bytes_x2" in d and "write_bytes" in d:
         # the figure bench.py quotes as roofline.traffic: guide's gfx950 correction (x2 on FETCH_SIZE) applied to every
         # read request -- an UPPER bound here, because only part of the reads are wide coalesced streams
