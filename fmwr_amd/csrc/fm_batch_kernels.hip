@@ -772,7 +772,7 @@ static int launch_rows_t(fmx_engine* e, const RowsArgs& a, int kp) {
 template <typename T, bool TRAIN>
 static int launch_rows_w(fmx_engine* e, const RowsArgs& a, int kp) {
   if (a.sort_rows && a.wg_threads != 64) return launch_rows_dyn<T, TRAIN>(e, a, kp);   // FMX_ROWS_PULL=1, rows of differing lengths, wide workgroups
-  if (a.flat == 1 && a.wg_threads != 64) return launch_rows_flat<T, TRAIN>(e, a, kp);      // rows of differing lengths (rows_flat), wide workgroups
+  if (a.flat == 1 && a.wg_threads != 64) return launch_rows_flat<T, TRAIN>(e, a, kp);      // FMX_ROWS_FLAT=1, rows of differing lengths (rows_flat), wide workgroups
   if (a.wg_threads == 64) return a.split == 4 ? launch_rows_t<T, TRAIN, 64, 4>(e, a, kp) : launch_rows_t<T, TRAIN, 64, 1>(e, a, kp);
   return launch_rows_t<T, TRAIN, WG_THREADS, 1>(e, a, kp);
 }

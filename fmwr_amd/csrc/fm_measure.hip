@@ -32,11 +32,12 @@ __device__ __forceinline__ float4 probe_load(const float4* base, uint32_t bytes,
   return probe_load_aux<0>(base, bytes, off);
 }
 
-static int g_probe_mode = 0;   // FMX_PROBE_LOAD (0..3, see probe_load); FMX_PROBE_UNCACHED=1: the table is allocated hipDeviceMallocUncached
+static int g_probe_mode = 0;
+static const float* g_probe_side = nullptr;   // FMX_PROBE_LOAD (0..3, see probe_load); FMX_PROBE_UNCACHED=1: the table is allocated hipDeviceMallocUncached
 
 template <int LPR, int U>
 __global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __restrict__ table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt,
-                                                             float4* __restrict__ out, int mode = 0) {
+                                                             float4* __restrict__ out, int mode = 0, const float* __restrict__ side = nullptr) {
   extern __shared__ char occupancy_pad[];  // dynamic LDS only limits how many workgroups share a CU (fmx_measure_gather_occ)
   (void)occupancy_pad;
   const int64_t g = ((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) / LPR;
@@ -46,12 +47,19 @@ __global__ __launch_bounds__(WG_THREADS) void gather_probe_k(const float4* __res
   const uint32_t base = (uint32_t)g * (uint32_t)per_group + salt;
   for (int t = 0; t < per_group; t += U) {
     float4 v[U];
+    float sv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // multiply-shift maps the hash onto [0, rows) without a division
-      const uint32_t r = (uint32_t)(((uint64_t)mix32(base + (uint32_t)(t + u)) * rows) >> 32);
-      v[u] = mode ? probe_load(table, rows * (uint32_t)(LPR * 16), (r * LPR + lig) * 16u, mode) : table[(size_t)r * LPR + lig];
+      uint32_t r = (uint32_t)(((uint64_t)mix32(base + (uint32_t)(t + u)) * rows) >> 32);
+      // FMX_PROBE_STRATA=1 (mode bit 2): fetch t + u of every group comes from stratum t + u of the table (rows / per_group rows wide) -- the order in which
+      // phase 1 walks column-sorted rows of one column per stratum: every group of the chip is then in the same narrow band of the table at the same step
+      if (mode & 4) { const uint32_t w = rows / (uint32_t)per_group; r = (uint32_t)(t + u) * w + (uint32_t)(((uint64_t)mix32(base + (uint32_t)(t + u)) * w) >> 32); }
+      v[u] = (mode & 3) ? probe_load(table, rows * (uint32_t)(LPR * 16), (r * LPR + lig) * 16u, mode & 3) : table[(size_t)r * LPR + lig];
+      sv[u] = side ? side[r] : 0.f;   // FMX_PROBE_SIDE=1: a 4-byte word of a second table under the same id, as phase 1 reads w beside the V row
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc.x += sv[u];
 #pragma unroll
     for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
   }
@@ -87,8 +95,10 @@ static int g_probe_lds = 0;  // bytes of dynamic LDS per workgroup (0: none): 16
 
 template <int LPR>
 static void launch_probe(int in_flight, dim3 g, dim3 b, hipStream_t s, const float4* table, uint32_t rows, int per_group, int64_t n_groups, uint32_t salt, float4* out) {
-  if (in_flight >= 8) hipLaunchKernelGGL((gather_probe_k<LPR, 8>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode);
-  else hipLaunchKernelGGL((gather_probe_k<LPR, 4>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode);
+  if (in_flight >= 8) hipLaunchKernelGGL((gather_probe_k<LPR, 8>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode, g_probe_side);
+  else if (in_flight >= 4) hipLaunchKernelGGL((gather_probe_k<LPR, 4>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode, g_probe_side);
+  else if (in_flight >= 2) hipLaunchKernelGGL((gather_probe_k<LPR, 2>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode, g_probe_side);
+  else hipLaunchKernelGGL((gather_probe_k<LPR, 1>), g, b, g_probe_lds, s, table, rows, per_group, n_groups, salt, out, g_probe_mode, g_probe_side);
 }
 
 }  // namespace fmx
@@ -121,16 +131,21 @@ extern "C" int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_b
   const int lpr = row_bytes / 16;
   const uint32_t rows = (uint32_t)(table_bytes / row_bytes);
   float4 *table = nullptr, *out = nullptr;
+  float* side = nullptr;
   hipStream_t s = nullptr;
   hipEvent_t a = nullptr, b = nullptr;
   int st = FMX_OK;
   auto body = [&]() -> int {
     { const char* v = getenv("FMX_PROBE_LOAD"); g_probe_mode = v ? atoi(v) : 0; }
+    { const char* v = getenv("FMX_PROBE_STRATA"); if (v && v[0] == '1') g_probe_mode |= 4; }
     { const char* v = getenv("FMX_PROBE_UNCACHED");
       if (v && v[0] == '1') FMX_HIP(hipExtMallocWithFlags((void**)&table, (size_t)rows * row_bytes, hipDeviceMallocUncached));
       else FMX_HIP(hipMalloc(&table, (size_t)rows * row_bytes)); }
     FMX_HIP(hipMalloc(&out, (size_t)n_groups * row_bytes));
     FMX_HIP(hipMemset(table, 0, (size_t)rows * row_bytes));
+    { const char* v = getenv("FMX_PROBE_SIDE");
+      if (v && v[0] == '1') { FMX_HIP(hipMalloc(&side, (size_t)rows * sizeof(float))); FMX_HIP(hipMemset(side, 0, (size_t)rows * sizeof(float))); } }
+    g_probe_side = side;
     FMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     FMX_HIP(hipEventCreate(&a)); FMX_HIP(hipEventCreate(&b));
     FMX_HIP(hipDeviceSynchronize());
@@ -160,7 +175,8 @@ extern "C" int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_b
   if (a) (void)hipEventDestroy(a);
   if (b) (void)hipEventDestroy(b);
   if (s) (void)hipStreamDestroy(s);
-  (void)hipFree(table); (void)hipFree(out);
+  (void)hipFree(table); (void)hipFree(out); (void)hipFree(side);
+  g_probe_side = nullptr;
   return st;
 }
 
@@ -188,7 +204,8 @@ extern "C" int fmx_measure_gather_matrix(fmx_matrix* m, int64_t r0, int64_t nrow
     auto launch = [&]() {
 #define FMX_GM(L) \
   if (in_flight >= 8) hipLaunchKernelGGL((gather_matrix_k<L, 8>), g, blk, 0, s, table, (uint32_t)table_rows, m->row_ptr, m->col, r0, nrows, out); \
-  else hipLaunchKernelGGL((gather_matrix_k<L, 4>), g, blk, 0, s, table, (uint32_t)table_rows, m->row_ptr, m->col, r0, nrows, out);
+  else if (in_flight >= 4) hipLaunchKernelGGL((gather_matrix_k<L, 4>), g, blk, 0, s, table, (uint32_t)table_rows, m->row_ptr, m->col, r0, nrows, out); \
+  else hipLaunchKernelGGL((gather_matrix_k<L, 1>), g, blk, 0, s, table, (uint32_t)table_rows, m->row_ptr, m->col, r0, nrows, out);
       switch (lpr) {
         case 1: FMX_GM(1) break;
         case 2: FMX_GM(2) break;

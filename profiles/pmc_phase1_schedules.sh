@@ -13,10 +13,16 @@ run() {  # tag, then the environment and command
       rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/$tag/pass$i -- python3 profiles/probes/ragged_probe.py $PROBE_ARGS > $OUT/$tag.pass$i.log 2>&1 )
   done
 }
+if [ -n "$PMC_PHASE1_ONLY_LEAN" ]; then
+PROBE_ARGS="30 30 strata 16" run strata_serial FMX_ROWS_SERIAL=1
+PROBE_ARGS="30 30 strata 16" run strata_lean FMX_ROWS_SERIAL=2
+PROBE_ARGS="30 30 strata 16" run strata_pipelined FMX_ROWS_SERIAL=0
+else
 PROBE_ARGS="30 30 iid 16"   run iid_serial FMX_ROWS_SERIAL=1
 PROBE_ARGS="30 30 iid 16"   run iid_pipelined FMX_ROWS_SERIAL=0
 PROBE_ARGS="1 64 ragged 16" run ragged_static_serial FMX_ROWS_SERIAL=1 FMX_ROWS_FLAT=0
 PROBE_ARGS="1 64 ragged 16" run ragged_flat_serial FMX_ROWS_SERIAL=1 FMX_ROWS_FLAT=1
+fi
 python3 - $OUT <<'PY'
 import csv, glob, os, sys, json
 from collections import defaultdict

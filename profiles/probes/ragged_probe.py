@@ -1,11 +1,12 @@
 """Phase 1 on rows of differing lengths at configs[1]'s shape: the static kernel (one lane group per row), the flat form (fm_rows_forward_flat_k) and
-the pulled form, per row-length law.  usage: ragged_probe.py MIN MAX ragged|iid K   (environment: FMX_ROWS_FLAT, FMX_ROWS_PULL, FMX_ROWS_SERIAL)"""
+the pulled form, per row-length law.  usage: ragged_probe.py MIN MAX ragged|iid|strata K   (environment: FMX_ROWS_FLAT, FMX_ROWS_PULL, FMX_ROWS_SERIAL)"""
 import os, sys, time
 sys.path.insert(0, ".")
 from fmwr_amd import _lib as L, engine
 n, p, z, B = 10_000_000, 1_000_000, 30, 262_144
 lo, hi, kind, k = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
-m = engine.Matrix.synthetic_ragged(n, p, float(z), 20240001, min_nnz=lo, max_nnz=hi) if kind == "ragged" else engine.Matrix.synthetic_iid(n, p, z, 20240001)
+m = (engine.Matrix.synthetic_ragged(n, p, float(z), 20240001, min_nnz=lo, max_nnz=hi) if kind == "ragged" else
+     engine.Matrix.synthetic(n, p, z, 20240001) if kind == "strata" else engine.Matrix.synthetic_iid(n, p, z, 20240001))
 e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4, mode=L.MODE_MINIBATCH, batch_rows=B)
 e.init_normal(1, 0.0, 0.01)
 nb = n // B
