@@ -998,6 +998,51 @@ int fmx_matrix_from_rlist(int device, int64_t n, uint32_t p, int64_t nnz, const 
   return FMX_OK;
 }
 
+int fmx_matrix_from_dgc(int device, int64_t nrow, uint32_t ncol, int64_t nnz, const double* x, const int32_t* i, const int32_t* p, const double* labels,
+                        fmx_matrix** out) {
+  FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMX_CHECK(nrow >= 0 && nnz >= 0 && p != nullptr, FMX_ERR_INVALID, "negative size or NULL column pointers");
+  FMX_CHECK(nnz == 0 || (x && i), FMX_ERR_INVALID, "x/i is NULL");
+  FMX_CHECK(nrow < (1LL << 32) && nnz < (1LL << 32), FMX_ERR_INVALID, "a dgCMatrix is transposed by one device sort over all its entries: fewer than 2^32 rows and stored entries (this one: %lld, %lld)",
+            (long long)nrow, (long long)nnz);
+  FMX_CHECK(p[0] == 0, FMX_ERR_INVALID, "p[0] must be 0");
+  std::vector<int32_t> col_size((size_t)ncol);
+  for (uint32_t j = 0; j < ncol; ++j) {
+    FMX_CHECK(p[j + 1] >= p[j], FMX_ERR_INVALID, "the column pointers decrease at column %u", j);
+    col_size[j] = p[j + 1] - p[j];
+  }
+  FMX_CHECK((int64_t)p[ncol] == nnz, FMX_ERR_INVALID, "the column pointers end at %d, not at the number of stored entries (%lld)", p[ncol], (long long)nnz);
+  // The slots ARE the row-major arrays of the TRANSPOSE (its rows = the columns): ingest that (the same device path as fmx_matrix_from_rlist), build its
+  // column-major form with the whole-matrix sort of the ALS path -- which is the row-major form of the matrix itself, columns ascending inside a row
+  // because the sort is stable -- and move it into a matrix of its own.
+  fmx_matrix* t = nullptr;
+  FMX_TRY(alloc_matrix(device, (int64_t)ncol, (uint32_t)nrow, nnz, false, &t));
+  std::unique_ptr<fmx_matrix, void (*)(fmx_matrix*)> tg(t, free_matrix);
+  uint64_t bad[2] = {~0ull, ~0ull};
+  int64_t total = 0;
+  FMX_TRY(ingest_host_arrays(t, x, true, i, true, col_size.data(), nullptr, nullptr, true, bad, &total));
+  FMX_CHECK(bad[0] == ~0ull, FMX_ERR_INVALID, "row index %d out of range at entry %llu (%lld rows)", i[bad[0]], (unsigned long long)bad[0], (long long)nrow);
+  FMX_TRY(build_full_csc(t, nullptr));
+  fmx_matrix* m = nullptr;
+  FMX_TRY(alloc_matrix(device, nrow, ncol, nnz, labels != nullptr, &m));
+  std::unique_ptr<fmx_matrix, void (*)(fmx_matrix*)> mg(m, free_matrix);
+  FMX_HIP(hipMemcpy(m->row_ptr, t->col_ptr, ((size_t)nrow + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice));
+  if (nnz > 0) {
+    FMX_HIP(hipMemcpy(m->col, t->crow, (size_t)nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    FMX_HIP(hipMemcpy(m->val, t->cval, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice));
+  }
+  tg.reset();
+  if (labels && nrow > 0) {
+    std::vector<float> y((size_t)nrow);
+    for (int64_t r = 0; r < nrow; ++r) y[(size_t)r] = (float)labels[r];  // util/Smatrix.h narrows the same way (DVector<float>::assign)
+    FMX_HIP(hipMemcpy(m->y, y.data(), (size_t)nrow * sizeof(float), hipMemcpyHostToDevice));
+  }
+  FMX_TRY(check_rows_sorted(m));
+  *out = mg.release();
+  return FMX_OK;
+}
+
 int fmx_matrix_synthetic(int device, int64_t n, uint32_t p, int32_t nnz_per_row, uint64_t seed, int64_t row_offset, fmx_matrix** out) {
   FMX_CHECK(out != nullptr, FMX_ERR_INVALID, "out is NULL");
   *out = nullptr;

@@ -65,6 +65,20 @@ class Matrix:
         return cls._wrap(h)
 
     @classmethod
+    def from_dgc(cls, x, i, p, nrow, ncol, labels=None, device=0):
+        """A dgCMatrix's slots as they lie in R (x, i = 0-based row indices, p = column pointers): transposed to rows on the device (fmx_matrix_from_dgc;
+        R/fm_matrix.R:26-33 does it with Matrix::t on the host).  scipy: `c = scipy.sparse.csc_matrix(...); from_dgc(c.data, c.indices, c.indptr, *c.shape)`."""
+        x = np.ascontiguousarray(x, np.float64)
+        i = np.ascontiguousarray(i, np.int32)
+        p = np.ascontiguousarray(p, np.int32)
+        if len(p) != ncol + 1:
+            raise ValueError("p must hold ncol + 1 column pointers")
+        labels = None if labels is None else np.ascontiguousarray(labels, np.float64)
+        h = C.c_void_p()
+        L.check(L.lib().fmx_matrix_from_dgc(C.c_int(device), C.c_int64(nrow), C.c_uint32(ncol), C.c_int64(len(x)), _p(x), _p(i), _p(p), _p(labels), C.byref(h)))
+        return cls._wrap(h)
+
+    @classmethod
     def synthetic(cls, n, p, nnz_per_row, seed, row_offset=0, device=0):
         h = C.c_void_p()
         L.check(L.lib().fmx_matrix_synthetic(C.c_int(device), C.c_int64(n), C.c_uint32(p), C.c_int32(nnz_per_row), C.c_uint64(seed),

@@ -163,6 +163,12 @@ int fmx_engine_load(fmx_engine* e, const char* path);
 int fmx_matrix_from_rlist(int device, int64_t n, uint32_t p, int64_t nnz, const double* value,
                           const int32_t* col_idx, const int32_t* row_size, const double* labels,
                           fmx_matrix** out);
+/* A dgCMatrix as it lies in R (Matrix package slots: x f64[nnz], i i32[nnz] 0-based ROW indices, p i32[ncol + 1] column pointers, Dim = (nrow, ncol)).
+ * R/fm_matrix.R:26-33 transposes it on the host first (`Matrix::t(data)`, then the list above); here the slots go over as they are and the transposition
+ * is a device sort by row (stable: the columns of a row come out ascending).  Row indices out of range, decreasing pointers and a pointer total other than nnz
+ * are refused; nrow and nnz must be below 2^32 (one sort over all entries).  labels may be NULL. */
+int fmx_matrix_from_dgc(int device, int64_t nrow, uint32_t ncol, int64_t nnz, const double* x, const int32_t* i, const int32_t* p, const double* labels,
+                        fmx_matrix** out);
 /* Plain CSR: row_ptr i64[n+1], col u32[nnz], val f32[nnz], y f32[n] or NULL. */
 int fmx_matrix_from_csr(int device, int64_t n, uint32_t p, const int64_t* row_ptr, const uint32_t* col,
                         const float* val, const float* y, fmx_matrix** out);

@@ -516,3 +516,61 @@ def test_the_hand_written_pair_sort_builds_the_library_sorts_plan(monkeypatch, p
         assert e.train(m, n) == n
         out.append(e.get_params())
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_a_dgcmatrix_is_transposed_on_the_device():
+    """fmx_matrix_from_dgc: the slots of a dgCMatrix (x, 0-based row indices, column pointers) handed over as they lie in R; R/fm_matrix.R:26-33 transposes on the
+    host (Matrix::t) and passes the row-major list.  The device transposition gives the matrix fmx_matrix_from_rlist builds from the transposed list -- offsets,
+    columns (ascending inside a row), float32 values, labels -- and the same predictions bit for bit; empty rows and empty columns, one-hot values (found on the
+    device), a field layout (found on the device), a column whose rows are not ascending (not a valid dgCMatrix, still transposed: the sort is stable), and the
+    refusals: row index out of range, decreasing pointers, a pointer total other than nnz."""
+    import scipy.sparse as sp
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(5)
+    nrow, ncol, k = 30_000, 1_500, 8
+    dense_rows = sp.random(nrow, ncol, density=0.004, format="csr", random_state=7, dtype=np.float64)
+    dense_rows.data = rng.normal(0, 1, dense_rows.nnz)
+    dense_rows[17] = 0; dense_rows[:, 40] = 0; dense_rows.eliminate_zeros()          # an empty row, an empty column
+    csr = dense_rows.tocsr(); csr.sort_indices()
+    csc = csr.tocsc(); csc.sort_indices()
+    y = util.labels(nrow, 5).astype(np.float64)
+    a = engine.Matrix.from_dgc(csc.data, csc.indices, csc.indptr, nrow, ncol, labels=y)
+    b = engine.Matrix.from_rlist(csr.data, csr.indices, np.diff(csr.indptr), ncol, labels=y)
+    ea, eb = a.export(), b.export()
+    for u, v in zip(ea, eb):
+        assert np.array_equal(u, v)
+    assert (a.n, a.p, a.nnz) == (nrow, ncol, csr.nnz)
+    w0, w, v = util.params(ncol, k, 5)
+    e = engine.Engine(ncol, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, learn_rate=0.05, mode=L.MODE_MINIBATCH, batch_rows=8_192)
+    e.set_params(w0, w, v)
+    assert np.array_equal(e.predict(a), e.predict(b))
+    e.train(a, nrow)
+    pa = e.get_params()
+    e.set_params(w0, w, v)
+    e.train(b, nrow)
+    pb = e.get_params()
+    assert pa[0] == pb[0] and np.array_equal(pa[1], pb[1]) and np.array_equal(pa[2], pb[2])
+    # one-hot rows with a field layout: three factor columns of a data frame, one dummy column of each per row
+    f = np.stack([rng.integers(0, 50, 4_000), 50 + rng.integers(0, 200, 4_000), 250 + rng.integers(0, 30, 4_000)], axis=1)
+    oh = sp.csr_matrix((np.ones(12_000), f.ravel(), np.arange(0, 12_001, 3)), shape=(4_000, 280)).tocsc(); oh.sort_indices()
+    c = engine.Matrix.from_dgc(oh.data, oh.indices, oh.indptr, 4_000, 280)
+    rp, col, val, _ = c.export()
+    assert np.array_equal(np.diff(rp), np.full(4_000, 3)) and np.array_equal(col.reshape(-1, 3), f) and np.all(val == 1.0)
+    # rows of a column out of order: the transposition does not depend on it
+    x2, i2 = csc.data.copy(), csc.indices.copy()
+    j = int(np.argmax(np.diff(csc.indptr) >= 3)); s0 = csc.indptr[j]
+    x2[s0], x2[s0 + 2] = x2[s0 + 2], x2[s0]; i2[s0], i2[s0 + 2] = i2[s0 + 2], i2[s0]
+    d = engine.Matrix.from_dgc(x2, i2, csc.indptr, nrow, ncol)
+    for u, v in zip(d.export()[:3], ea[:3]):
+        assert np.array_equal(u, v)
+    # refusals
+    bad_i = csc.indices.copy(); bad_i[5] = nrow
+    with pytest.raises(L.FmxError, match="out of range"):
+        engine.Matrix.from_dgc(csc.data, bad_i, csc.indptr, nrow, ncol)
+    bad_p = csc.indptr.copy(); bad_p[10] = bad_p[9] - 1 if bad_p[9] > 0 else bad_p[11] + 1
+    with pytest.raises(L.FmxError, match="decrease"):
+        engine.Matrix.from_dgc(csc.data, csc.indices, bad_p, nrow, ncol)
+    with pytest.raises(L.FmxError, match="stored entries"):
+        engine.Matrix.from_dgc(csc.data[:-1], csc.indices[:-1], csc.indptr, nrow, ncol)
+    empty = engine.Matrix.from_dgc(np.zeros(0), np.zeros(0, np.int32), np.zeros(ncol + 1, np.int32), 10, ncol)
+    assert (empty.n, empty.nnz) == (10, 0)
