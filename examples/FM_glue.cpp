@@ -64,9 +64,17 @@ static fmx_config config_from_controls(List fm_controls, List solver_controls, d
 }
 
 static fmx_matrix* matrix_from_fm_matrix(List X, SEXP labels) {   // src/FM.cpp:31-44, util/Smatrix.h:44-61
-  NumericVector value = X["value"]; IntegerVector col_idx = X["col_idx"], row_size = X["row_size"], dim = X["dim"];
+  NumericVector value = X["value"]; IntegerVector col_idx = X["col_idx"], dim = X["dim"];
   fmx_matrix* m = nullptr;
   const double* y = Rf_isNull(labels) ? nullptr : REAL(labels);
+  if (X.containsElementNamed("col_ptr")) {
+    // a dgCMatrix's own slots (x, i, p: R/fm_matrix.R keeping them instead of calling Matrix::t): col_idx then holds ROW indices and the
+    // rows are made on the device
+    IntegerVector col_ptr = X["col_ptr"];
+    fmx_check(fmx_matrix_from_dgc(0, dim[0], (uint32_t)dim[1], value.size(), value.begin(), col_idx.begin(), col_ptr.begin(), y, &m));
+    return m;
+  }
+  IntegerVector row_size = X["row_size"];
   fmx_check(fmx_matrix_from_rlist(0, dim[0], (uint32_t)dim[1], value.size(), value.begin(), col_idx.begin(), row_size.begin(), y, &m));
   // Optional: a matrix made from a data frame with one-hot encoded factors (numeric columns first) may name its layout -- R/fm_matrix.R would pass
   // the ranges along as X$field_base (from model.matrix's "assign" attribute) -- and the step plans are then built field by field, twice as fast:

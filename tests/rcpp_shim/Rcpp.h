@@ -94,6 +94,7 @@ class List {
   Proxy operator[](long index) const;
   Proxy operator[](int index) const;
   Proxy attr(const char* name) const;
+  bool containsElementNamed(const char* name) const;
   long size() const;
 };
 
