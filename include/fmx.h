@@ -478,8 +478,11 @@ int fmx_group_info(fmx_engine* e, int32_t* n_replicas, int32_t* share_device, in
 int fmx_rccl_selftest(int32_t n, double* max_err);
 /* What the memory system gives the hot kernels' access pattern and nothing else: uniformly random rows of row_bytes bytes
  * (16..256, a power of two) from a table of table_bytes bytes; ids are generated in registers, row_bytes / 16 lanes fetch a row,
- * in_flight (4 or 8) rows outstanding per lane, n_groups lane groups each summing per_group rows, `reps` launches timed with
- * HIP events.  bench.py reports kernel rows/s divided by this figure as "ceiling_frac". */
+ * in_flight (1, 2, 4 or 8) rows outstanding per lane, n_groups lane groups each summing per_group rows, `reps` launches timed with
+ * HIP events.  bench.py reports kernel rows/s divided by this figure as "ceiling_frac".  Environment switches of the probe (measurement only; profiles/
+ * r04_gather_granularity.txt, r04_phase1_l2.txt): FMX_PROBE_STRATA=1 fetch j of every lane group comes from stratum j of the table (the order in which phase 1 walks
+ * rows of one column per stratum); FMX_PROBE_SIDE=1 a 4-byte word of a second table under the same id beside every row (phase 1's w); FMX_PROBE_LOAD=1/2/3 non-temporal /
+ * system-scope / both buffer loads; FMX_PROBE_UNCACHED=1 the table in hipDeviceMallocUncached memory. */
 int fmx_measure_gather(int device, int64_t table_bytes, int32_t row_bytes, int64_t n_groups, int32_t per_group, int32_t in_flight,
                        int32_t reps, double* rows_per_s);
 /* the same probe held to at most 160 KiB / lds_bytes workgroups per CU: how many requests in flight the ceiling needs */
