@@ -17,4 +17,5 @@ unset FMX_ROWS_SERIAL
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mcmc -- python3 bench.py --solver mcmc --cpu-rows 0 --no-extras > $O/bench_mcmc_under_rocprof.json 2> $O/rocprof_mcmc.err; echo "rocprof mcmc rc=$?"
 bash profiles/pmc_run.sh $O/pmc_mcmc --solver mcmc --no-extras --steps 2 --warmup 1 > $O/pmc_mcmc.log 2>&1; echo "pmc mcmc rc=$?"
 FMX_ROWS_SERIAL=1 bash profiles/pmc_run.sh $O/pmc_sgd --no-extras > $O/pmc_sgd.log 2>&1; echo "pmc sgd rc=$?"
+python3 profiles/soak_r04.py > $O/soak_r04.txt 2>&1; echo "soak r04 rc=$?"
 find $O -name "*kernel_stats.csv"
