@@ -128,6 +128,19 @@ def fm_matrix(data, labels=None, feature_names=None):
             raise ValueError("is.numeric(labels) is not TRUE")
         if np.any(np.isnan(labels)):
             raise ValueError("!any(is.na(labels)) is not TRUE")
+    if sp.issparse(data) and data.format == "csc":
+        # a dgCMatrix's own slots: R/fm_matrix.R:26-33 transposes on the host (Matrix::t); the slots go over as they are and the device transposes
+        # (fmx_matrix_from_dgc; examples/FM_glue.cpp takes the same branch on the "col_ptr" element)
+        n, p = data.shape
+        if labels is not None and len(labels) != n:
+            raise ValueError("length(labels) == nrow(data) is not TRUE")
+        if feature_names is None:
+            feature_names = [f"V{j + 1}" for j in range(p)]
+        elif len(feature_names) != p:
+            raise ValueError("ncol(data) == length(feature_names) is not TRUE")
+        features = {"value": data.data.astype(np.float64), "col_idx": data.indices.astype(np.int32), "col_ptr": data.indptr.astype(np.int32),
+                    "dim": (n, p), "size": int(data.nnz)}
+        return FmMatrix(features, labels, list(feature_names))
     X = data.tocsr() if sp.issparse(data) else sp.csr_matrix(np.asarray(data, np.float64))
     X.sort_indices()
     n, p = X.shape
@@ -144,6 +157,8 @@ def fm_matrix(data, labels=None, feature_names=None):
 
 def _device_matrix(data, labels, device):
     f = data.features
+    if "col_ptr" in f:
+        return Matrix.from_dgc(f["value"], f["col_idx"], f["col_ptr"], f["dim"][0], f["dim"][1], labels, device=device)
     return Matrix.from_rlist(f["value"], f["col_idx"], f["row_size"], f["dim"][1], labels, device=device)
 
 

@@ -574,3 +574,13 @@ def test_a_dgcmatrix_is_transposed_on_the_device():
         engine.Matrix.from_dgc(csc.data[:-1], csc.indices[:-1], csc.indptr, nrow, ncol)
     empty = engine.Matrix.from_dgc(np.zeros(0), np.zeros(0, np.int32), np.zeros(ncol + 1, np.int32), 10, ncol)
     assert (empty.n, empty.nnz) == (10, 0)
+    # the R-facing surface: fm.matrix on a column-major sparse matrix keeps its slots, training gives the model of the row-major hand-over
+    import fmwr_amd as fm
+    small, ys = csr[:3_000], np.where(y[:3_000] > 0, 1.0, 0.0)
+    ctl = [fm.model_control("CLASSIFICATION", **{"factor.number": 4}), fm.solver_control(max_iter=2_000, solver=fm.SGD_solver(learn_rate=0.02))]
+    da, db = fm.fm_matrix(small.tocsc(), ys), fm.fm_matrix(small.tocsr(), ys)
+    assert "col_ptr" in da.features and "row_size" in db.features
+    fa = fm.fm_train(da, normalize=False, control=ctl, seed=3, mode="sequential")
+    fb = fm.fm_train(db, normalize=False, control=ctl, seed=3, mode="sequential")
+    assert np.array_equal(fa["Model"]["v"], fb["Model"]["v"]) and fa["Model"]["w0"] == fb["Model"]["w0"]
+    assert np.array_equal(fm.predict(fa, da, normalize=False), fm.predict(fb, db, normalize=False))
