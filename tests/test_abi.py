@@ -55,6 +55,27 @@ def test_fails_loudly_without_gpu():
     assert b"no HIP device" in L.lib().fmx_last_error() or st == L.ERR_HIP
 
 
+def test_dgc_hand_over_checks_its_pointers_on_the_host_and_needs_a_device_for_the_rest():
+    """fmx_matrix_from_dgc (the dgCMatrix slots of R/fm_matrix.R:6-43, untransposed): the column pointers are checked before anything touches a device --
+    p[0], monotonicity, the total -- and a well-formed matrix then fails for want of a GPU, it is never transposed on the host."""
+    import numpy as np
+    L = _lib()
+    x = np.array([1.0, 2.0, 3.0]); i = np.array([0, 2, 1], np.int32)
+    h = C.c_void_p()
+
+    def call(p, nnz=3):
+        p = np.asarray(p, np.int32)
+        return L.lib().fmx_matrix_from_dgc(C.c_int(0), C.c_int64(3), C.c_uint32(2), C.c_int64(nnz), x.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p),
+                                           p.ctypes.data_as(C.c_void_p), None, C.byref(h))
+    assert call([1, 2, 3]) == L.ERR_INVALID and b"p[0]" in L.lib().fmx_last_error()
+    assert call([0, 2, 1]) == L.ERR_INVALID and b"decrease at column 1" in L.lib().fmx_last_error()
+    assert call([0, 2, 2]) == L.ERR_INVALID and b"stored entries" in L.lib().fmx_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        st = call([0, 2, 3])
+        assert st != L.OK and not h.value
+
+
 def test_product_never_touches_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
     pkg = os.path.join(ROOT, "fmwr_amd")
