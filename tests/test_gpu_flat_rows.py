@@ -128,3 +128,37 @@ def test_a_rows_bits_depend_on_the_matrix_alone(monkeypatch):
     e4.step(m, 1)
     p2 = e4.get_params()
     assert p1[0] == p2[0] and np.array_equal(p1[2], p2[2]) and np.any(p1[2] != v)
+
+
+def test_rows_longer_than_a_stage_and_a_lane_groups_range(monkeypatch):
+    """Rows of thousands of entries among short ones: a row then spans several stage chunks (2 048 entries) and the ranges of many lane groups, a chunk can lie
+    wholly inside one row, and its pieces are added up over chunks -- flat = static to rounding (forward and one step), k = 16 and k = 64, rows of no entries beside
+    the long ones."""
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(3)
+    n, p = 36_000, 6_000
+    lens = rng.poisson(25, n)
+    lens[rng.integers(0, n, 400)] = 0
+    heavy = rng.integers(0, n, 60)
+    lens[heavy] = rng.integers(2_100, 5_900, 60)
+    lens[heavy[:5] + 1 - (heavy[:5] == n - 1)] = 0          # an empty row right behind a long one
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum(lens)
+    col = np.zeros(int(rp[-1]), np.uint32)
+    for r in range(n):
+        col[rp[r]:rp[r + 1]] = np.sort(rng.choice(p, int(lens[r]), replace=False))
+    val = rng.normal(0, 0.05, len(col)).astype(np.float32)
+    y = util.labels(n, 3)
+    for k in (16, 64):
+        w0, w, v = util.params(p, k, 3, stdev=0.02)
+        out = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("FMX_ROWS_FLAT", flag)
+            m = engine.Matrix.from_csr(rp, col, val, p, y)
+            e = _engine(L, engine, p, k, batch_rows=n)
+            e.set_params(w0, w, v)
+            pred = e.predict(m)
+            e.step(m, 0)
+            out.append((pred, e.get_params()))
+        scale = np.max(np.abs(out[1][0]))
+        assert np.max(np.abs(out[0][0] - out[1][0])) <= 1e-12 * scale and not np.array_equal(out[0][0], out[1][0])
+        assert util.rel_err(out[0][1][2], out[1][1][2]) <= 2e-6 and util.rel_err(out[0][1][1], out[1][1][1]) <= 2e-6
