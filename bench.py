@@ -55,6 +55,11 @@ def parse(argv=None):
                     help="uniform: BASELINE.json configs[1] / [2] (one column per stratum).  criteo: configs[3]'s shape -- 33 M features, 39 nnz/row "
                          "(13 dense + 26 categorical fields with power-law heads), k = 32, 262144-row steps of one sparse tile; --rows rows resident "
                          "per GPU (default 8 M); N > 1 exchanges the occurring features' records (compact exchange)")
+    ap.add_argument("--columns", choices=["iid", "stratified", "zipf"], default="iid",
+                    help="--workload uniform: the column law of the synthetic rows.  iid: SURVEY 8(d)'s primary law, columns i.i.d. uniform over [0, p), sorted inside the "
+                         "row (fmx_matrix_synthetic_iid) -- the headline; stratified: one column per stratum of [0, p) (fmx_matrix_synthetic: what rounds 1-4 quoted `value` on, "
+                         "kept in the line as `value_stratified_columns`); zipf: SURVEY 8(d)'s conflict-stress variant, exponent 1.05")
+    ap.add_argument("--real-values", action="store_true", help="SURVEY 8(d)'s value variant: val ~ U(0,1) instead of 1 (fmx_matrix_synthetic_values): the kernels then read the value arrays")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
     ap.add_argument("--no-linear", action="store_true", help="experiment: keep.w1 = FALSE (no w gathers)")
@@ -107,13 +112,16 @@ def parse(argv=None):
     return a
 
 
-def algorithmic_bytes(z, k, p, rows, e=4, ftrl=False):
+def algorithmic_bytes(z, k, p, rows, e=4, ftrl=False, unit=False):
     """Per-launch algorithmic HBM bytes of the two hot kernels and of the SURVEY 8(d) fused step; e = bytes per state
-    element (4: the fp32 state SURVEY 8(d) prices; 8 with --state-fp64).  FTRL keeps three tables per parameter (theta, z, n)."""
+    element (4: the fp32 state SURVEY 8(d) prices; 8 with --state-fp64).  FTRL keeps three tables per parameter (theta, z, n).
+    unit: every stored value is 1.0f -- the kernels never read the value arrays (RowsArgs.unit / ColsArgs.unit), so the 4-byte value
+    stream is NOT priced: neither in the two kernels' own bytes nor in the survey's fused step (its 8 B of (idx, val) per nonzero become 4)."""
     t = 3 if ftrl else 1
-    rows_fwd = rows * (z * (4 + 4 + e + e * k) + 8 + 4 + e * k + e)                  # idx,val,w,V row | row_ptr, y, S row, mult
-    cols_upd = rows * z * (4 + 4 + e + e * k) + p * (4 + t * 2 * e * k + t * 2 * e)  # row,val,mult,S row | offsets, table RMWs
-    survey_step = rows * (z * (8 + t * 2 * e + t * 2 * e * k) + 12)                  # SGD z(16+8k)+12, FTRL z(32+24k)+12 at e = 4
+    vb = 0 if unit else 4
+    rows_fwd = rows * (z * (4 + vb + e + e * k) + 8 + 4 + e * k + e)                  # idx,val,w,V row | row_ptr, y, S row, mult
+    cols_upd = rows * z * (4 + vb + e + e * k) + p * (4 + t * 2 * e * k + t * 2 * e)  # row,val,mult,S row | offsets, table RMWs
+    survey_step = rows * (z * (4 + vb + t * 2 * e + t * 2 * e * k) + 12)              # SGD z(16+8k)+12, FTRL z(32+24k)+12 at e = 4, values read
     return rows_fwd, cols_upd, survey_step
 
 
@@ -149,7 +157,9 @@ def pmc_traffic(kernel, args):
         same = (effective_tile(opt("--batch-rows", 262_144 if (solver == "sgd" or crit) else 1_048_576), k, opt("--tile-rows", 0)) == effective_tile(args.batch_rows, args.factors, args.tile_rows)
                 and k == args.factors and (33_000_000 if crit else opt("--features", 1_000_000)) == args.features and opt("--rows", 8_000_000 if crit else 10_000_000) == args.rows
                 and (39 if crit else opt("--nnz", 30)) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64)
-                and (a[a.index("--workload") + 1] if "--workload" in a else "uniform") == args.workload)
+                and (a[a.index("--workload") + 1] if "--workload" in a else "uniform") == args.workload
+                # summaries made before --columns existed (rounds 1-4) ran the stratified generator
+                and (crit or (a[a.index("--columns") + 1] if "--columns" in a else "stratified") == args.columns) and ("--real-values" in a) == bool(args.real_values))
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
             best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f), d[kernel].get("fabric_bytes_per_launch"), d[kernel].get("fabric_reads_128B_frac"))
     return best
@@ -177,6 +187,36 @@ def e_unit(m):
     """every stored value of the matrix is 1.0 (one-hot rows: the kernels never read the value arrays)"""
     _, _, val, _ = m.export(0, min(m.n, 1024))
     return bool(np.all(val == 1.0))
+
+
+def cpu_model():
+    """model string of the host CPU the cpu_baseline legs ran on ("state core count and CPU model")"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+COLUMN_LAWS = {"iid": "columns i.i.d. uniform over [0, p), sorted inside the row (SURVEY 8(d)'s primary law; fmx_matrix_synthetic_iid)",
+               "stratified": "one column per stratum of [0, p) (fmx_matrix_synthetic)",
+               "zipf": "columns i.i.d. Zipf s = 1.05 over [0, p), sorted inside the row (SURVEY 8(d)'s conflict-stress variant)"}
+
+
+def make_matrix(engine, L, args, n, row_offset=0, device=0, columns=None, real_values=None):
+    """rows [row_offset, row_offset + n) of the uniform workload's stream under a column law / value law (defaults: the run's own)"""
+    columns = columns or args.columns
+    if columns == "stratified":
+        m = engine.Matrix.synthetic(n, args.features, args.nnz, args.seed, row_offset=row_offset, device=device)
+    else:
+        m = engine.Matrix.synthetic_iid(n, args.features, args.nnz, args.seed, law=L.COLUMNS_ZIPF if columns == "zipf" else L.COLUMNS_UNIFORM, zipf_s=1.05,
+                                        row_offset=row_offset, device=device)
+    if args.real_values if real_values is None else real_values:
+        m.synthetic_values(args.seed, row_offset)
+    return m
 
 
 def host_cpu_share():
@@ -215,7 +255,7 @@ def cpu_baseline(m, args, v0):
         t0 = time.perf_counter()
         oracle.als_update_v(k, X, vv.ravel(), err, alpha=1.0, v_lambda=np.full(k, 1.0) if gibbs else None, znorm=zz)
         dt = time.perf_counter() - t0
-        return {"value": n / dt, "unit": "examples/s", "cores": 1, "kind": "port",
+        return {"value": n / dt, "unit": "examples/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
                 "sample": f"one reference-order update_v sweep (k = {k}{', Gibbs draws' if gibbs else ''}) over rows 0..{n - 1} of the same matrix ({dt:.1f} s incl. its transpose)"}
     if args.solver == "sgd":
         P = oracle.params(task=oracle.CLASSIFICATION, k=args.factors, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01)
@@ -230,7 +270,7 @@ def cpu_baseline(m, args, v0):
     else:
         done = oracle.ftrl_learn(P, X, y, 0.0, w, v.ravel(), n - 1)["iters"]
     dt = time.perf_counter() - t0
-    out = {"value": done / dt, "unit": "examples/s", "cores": 1, "kind": "port",
+    out = {"value": done / dt, "unit": "examples/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
            "sample": f"rows 1..{n - 1} of the same matrix, one reference-order serial {args.solver.upper()} pass ({dt:.1f} s){remap_note}"}
     if args.solver != "sgd" or remap_note or getattr(args, "cpu_one_core_only", False):
         return out
@@ -245,7 +285,7 @@ def cpu_baseline(m, args, v0):
     t0 = time.perf_counter()
     oracle.omp_predict_batch(P, X, 0.0, w, v.ravel(), threads)
     dt_f = time.perf_counter() - t0
-    out["all_cores"] = {"cores": threads, "hogwild_examples_per_s": done / dt_h, "forward_rows_per_s": n / dt_f,
+    out["all_cores"] = {"cores": threads, "cpu_model": cpu_model(), "hogwild_examples_per_s": done / dt_h, "forward_rows_per_s": n / dt_f,
                         "sample": f"rows 0..{n - 1}, one lock-free OpenMP pass ({dt_h:.1f} s) and one OpenMP forward ({dt_f:.1f} s)"}
     return out
 
@@ -318,15 +358,77 @@ def gather_ceilings(args, engine, kernels, tile_rows, v_row_elems=None, sparse_l
     return ceil
 
 
+def kernel_ms(e, L):
+    return {name: ms / max(cnt, 1) for name, (ms, cnt) in (("fm_rows_forward", e.profile_get(L.KERNEL_ROWS_FORWARD)), ("fm_cols_update", e.profile_get(L.KERNEL_COLS_UPDATE)))}
+
+
+def timed_variant(args, L, engine, m, v0, B, steps, **over):
+    """`steps` timed steps of the run's engine configuration on another matrix (schedule trials and warmup outside): value, HIP-event kernel times"""
+    e = engine.Engine(m.p, **engine_kwargs(args, L, B, 0, 1, **over))
+    e.set_params(0.0, None, v0.astype(np.float64))
+    nb = max(1, m.n // B)
+    timed_steps(e, m, nb, 16, 2)   # schedule trials
+    e.profile_reset(); e.profile(5)
+    dt = timed_steps(e, m, nb, steps, 2)
+    e.profile(0)
+    km = kernel_ms(e, L)
+    e.close()
+    return B * steps / dt, km
+
+
+def time_to_quality(args, L, engine, v0):
+    """One line that ties throughput to learning (core/Evaluation.h:80-89's log-likelihood, held out): labels planted from a hidden FM of the workload's own
+    shape, every learner from the same start, one pass each; what the examples/s of each mode buy in loss."""
+    n, p, z, k = args.rows, args.features, args.nnz, args.factors
+    n_test = 1_000_000
+    rng = np.random.default_rng(11)
+    train = make_matrix(engine, L, args, n, 0)
+    test = make_matrix(engine, L, args, n_test, n)
+    pe = engine.Engine(p, num_factor=k, mode=L.MODE_MINIBATCH)
+    pe.set_params(0.1, rng.normal(0, 0.35, p), rng.normal(0, 0.12, (k, p)))
+
+    def plant(m):
+        prob = 1.0 / (1.0 + np.exp(-pe.predict(m)))
+        y = np.where(rng.random(m.n) < prob, 1.0, -1.0).astype(np.float32)
+        m.set_labels(y)
+        return float(np.mean(np.where(y > 0, np.log(prob + 1e-20), np.log(1 - prob + 1e-20))))
+
+    plant(train)
+    ll_star = plant(test)
+    pe.close()
+    out = {"planted_model_held_out_ll": ll_star, "coin_flip_ll": float(-np.log(2.0)), "train_rows": n, "held_out_rows": n_test,
+           "note": "labels planted from a hidden FM (w ~ N(0, 0.35), V ~ N(0, 0.12), w0 = 0.1) on the workload's own shape; every learner starts from the bench's V0, "
+                   "lr 0.01, L2 1e-5; held-out log-likelihood per example (core/Evaluation.h:80-89) after `examples` training examples and `wall_s` seconds of training "
+                   "(plan build included).  The sequential learner is the reference's algorithm (fp64, its visiting order); the mini-batch learners take one MEAN-gradient "
+                   "step per coordinate per batch, so they need more examples for the same loss and far fewer seconds",
+           "learners": {}}
+    runs = [("minibatch_262144", dict(mode=L.MODE_MINIBATCH, batch_rows=262_144), n), ("minibatch_65536", dict(mode=L.MODE_MINIBATCH, batch_rows=65_536), n),
+            ("minibatch_4096", dict(mode=L.MODE_MINIBATCH, batch_rows=4096), 2_000_000), ("sequential_exact", dict(mode=L.MODE_SEQUENTIAL), 2_000_000)]
+    for name, kw, count in runs:
+        e = engine.Engine(p, task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, learn_rate=0.01, l2_w1=1e-5, l2_v=1e-5, **kw)
+        e.set_params(0.0, None, v0.astype(np.float64))
+        e.sync()
+        t0 = time.perf_counter()
+        done = e.train(train, count)
+        e.sync()
+        dt = time.perf_counter() - t0
+        out["learners"][name] = {"examples": int(done), "wall_s": dt, "held_out_ll": e.evaluate(test, L.EVAL_LL) / n_test}
+        e.close()
+    train.close(); test.close()
+    return out
+
+
 def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_rows):
     """What `value` does not say; every figure is measured here, on this GPU, in this run."""
     out = {}
     z, k, p = args.nnz, args.factors, args.features
     n = m.n
+    ftrl = args.solver == "ftrl"
+    eb = 8 if args.state_fp64 else 4
     # MEASURED, not computed: a fresh matrix and a fresh engine, the clock around { per-tile plan build of the whole matrix + one full
     # pass over its rows } (the reference's default run is two passes, R/fm_train.R:92: the second pass costs n / value more)
     B = min(args.batch_rows, n)
-    m2 = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=0)
+    m2 = make_matrix(engine, L, args, n, 0)
     e2 = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
     e2.set_params(0.0, None, v0.astype(np.float64))
     e2.sync()
@@ -347,63 +449,64 @@ def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_
                          "note": "wall clock around the per-tile plan build of the 10 M-row matrix (device sort, once per matrix) plus one pass, and plus TWO passes, over all its "
                                  "rows -- the last ragged step and phase 1's 14 schedule-trial launches included; every figure is a measured interval of one clock"}
     e2.close(); m2.close()
-    # SURVEY 8(d)'s column law: i.i.d. uniform columns, sorted inside the row (the headline matrix draws one column per stratum)
-    mi = engine.Matrix.synthetic_iid(n, p, z, args.seed)
-    ei = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
-    ei.set_params(0.0, None, v0.astype(np.float64))
-    nbi = max(1, n // B)
-    timed_steps(ei, mi, nbi, 16, 2)   # schedule trials
-    out["value_iid_uniform"] = {"value": B * args.steps / timed_steps(ei, mi, nbi, args.steps, 2), "unit": "examples/s",
-                                "note": "the same configuration on fmx_matrix_synthetic_iid (columns i.i.d. uniform over [0, p), sorted inside the row: SURVEY 8(d)'s generator)"}
-    ei.profile_reset(); ei.profile(5)
-    t_iid = timed_steps(ei, mi, nbi, args.steps, 0)
-    ei.profile(0)
-    iid_k = {name: ms / max(cnt, 1) for name, (ms, cnt) in (("fm_rows_forward", ei.profile_get(L.KERNEL_ROWS_FORWARD)), ("fm_cols_update", ei.profile_get(L.KERNEL_COLS_UPDATE)))}
-    ei.close(); mi.close()
-    # SURVEY 8(d)'s ragged variant: row lengths Poisson(z) clipped to [1, 64], the same column law.  The kernels give every row a fixed lane group that walks
+    # the other column law (rounds 1-4 quoted `value` on the stratified generator; SURVEY 8(d)'s primary law is i.i.d. uniform)
+    other = "stratified" if args.columns != "stratified" else "iid"
+    mo = make_matrix(engine, L, args, n, 0, columns=other)
+    v_o, k_o = timed_variant(args, L, engine, mo, v0, B, args.steps)
+    mo.close()
+    out["value_stratified_columns" if other == "stratified" else "value_iid_uniform"] = {
+        "value": v_o, "unit": "examples/s", "kernel_ms": k_o, "columns": COLUMN_LAWS[other],
+        "note": "the same configuration on the other column law; HIP events around every 5th launch"}
+    # SURVEY 8(d)'s value variant: val ~ U(0,1).  The kernels then read the value arrays in both phases (4 bytes per nonzero each) and multiply; priced on the full
+    # survey bytes (z(16+8k)+12)
+    mv = make_matrix(engine, L, args, n, 0, real_values=True)
+    v_v, k_v = timed_variant(args, L, engine, mv, v0, B, args.steps)
+    mv.close()
+    bf, bu, bs = algorithmic_bytes(z, k, p, tile_rows, eb, ftrl, unit=False)
+    out["value_real_values"] = {
+        "value": v_v, "unit": "examples/s", "kernel_ms": k_v,
+        "roofline": {"algorithmic_bytes_per_example": bs / tile_rows, "frac": v_v * bs / tile_rows / 1e9 / HBM_PEAK_GBS,
+                     "kernels": {"fm_rows_forward": {"frac": bf / (k_v["fm_rows_forward"] * 1e-3) / 1e9 / HBM_PEAK_GBS if k_v["fm_rows_forward"] > 0 else None},
+                                 "fm_cols_update": {"frac": bu / (k_v["fm_cols_update"] * 1e-3) / 1e9 / HBM_PEAK_GBS if k_v["fm_cols_update"] > 0 else None}}},
+        "note": "the same rows with val ~ U(0,1) (fmx_matrix_synthetic_values; util/Smatrix.h:44-61: the reference's values are real floats): both kernels stream the "
+                "value arrays and the plan is built by the general sort; every other bench matrix is one-hot, where they skip that stream"}
+    # SURVEY 8(d)'s conflict-stress variant: Zipf s = 1.05 columns (a few features occur in most rows: phase 2's long lists, phase 1's re-read heads)
+    if args.columns != "zipf":
+        mz = make_matrix(engine, L, args, n, 0, columns="zipf")
+        v_z, k_z = timed_variant(args, L, engine, mz, v0, B, args.steps)
+        mz.close()
+        out["value_zipf_columns"] = {"value": v_z, "unit": "examples/s", "kernel_ms": k_z, "columns": COLUMN_LAWS["zipf"],
+                                     "note": "the same configuration on Zipf columns: the head features' lists take the long-list kernels (segments of 1024 entries on a side stream)"}
+    # SURVEY 8(d)'s ragged variant: row lengths Poisson(z) clipped to [1, 64], i.i.d. uniform columns.  The kernels give every row a fixed lane group that walks
     # the row in rounds of RU entries (padded with x = 0): what that costs against rows of exactly z entries is the ratio of the two ENTRY rates
     mr = engine.Matrix.synthetic_ragged(n, p, float(z), args.seed)
-    er = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
-    er.set_params(0.0, None, v0.astype(np.float64))
-    nbr = max(1, n // B)
-    timed_steps(er, mr, nbr, 16, 2)   # schedule trials
-    er.profile_reset(); er.profile(5)
-    t_rag = timed_steps(er, mr, nbr, args.steps, 2)
-    er.profile(0)
-    rag_k = {name: ms / max(cnt, 1) for name, (ms, cnt) in (("fm_rows_forward", er.profile_get(L.KERNEL_ROWS_FORWARD)), ("fm_cols_update", er.profile_get(L.KERNEL_COLS_UPDATE)))}
+    v_rag, rag_k = timed_variant(args, L, engine, mr, v0, B, args.steps)
     mean_len = mr.nnz / mr.n
-    v_rag, v_iid = B * args.steps / t_rag, B * args.steps / t_iid
-    out["value_ragged_rows"] = {"value": v_rag, "unit": "examples/s", "nnz_per_row": {"law": f"Poisson({z}) clipped to [1, 64]", "mean": mean_len},
-                                "entries_per_s": v_rag * mean_len, "fixed_length_entries_per_s": v_iid * z, "entry_rate_vs_fixed_length_rows": (v_rag * mean_len) / (v_iid * z),
-                                "kernel_ms": rag_k, "fixed_length_kernel_ms": iid_k,
-                                "note": "fmx_matrix_synthetic_ragged against fmx_matrix_synthetic_iid (rows of exactly z entries, same column law), same engine configuration; "
-                                        "HIP events around every 5th launch"}
-    er.close(); mr.close()
+    mr.close()
+    if args.columns == "iid":
+        v_iid, iid_k = value, {name: ms for name, (_, ms) in kernels.items()}
+    else:
+        v_iid, iid_k = (v_o, k_o) if other == "iid" else (None, None)
+    if v_iid:
+        out["value_ragged_rows"] = {"value": v_rag, "unit": "examples/s", "nnz_per_row": {"law": f"Poisson({z}) clipped to [1, 64]", "mean": mean_len},
+                                    "entries_per_s": v_rag * mean_len, "fixed_length_entries_per_s": v_iid * z, "entry_rate_vs_fixed_length_rows": (v_rag * mean_len) / (v_iid * z),
+                                    "kernel_ms": rag_k, "fixed_length_kernel_ms": iid_k,
+                                    "note": "fmx_matrix_synthetic_ragged against fmx_matrix_synthetic_iid (rows of exactly z entries, same column law), same engine configuration; "
+                                            "HIP events around every 5th launch"}
     # the like-for-like origin of a 1 -> N curve: N > 1 runs 1 048 576 rows per GPU per step (the step has to hide the exchange of the 72 MB buffer), the headline
     # line 262 144; this is ONE GPU at the N > 1 step size, same learning-rate rule
     Bn = 1_048_576
     if args.solver == "sgd" and args.batch_rows != Bn and n >= 4 * Bn:
-        ms_ = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=0)
-        es_ = engine.Engine(p, **engine_kwargs(args, L, Bn, 0, 1))
-        es_.set_params(0.0, None, v0.astype(np.float64))
-        nbs_ = n // Bn
-        timed_steps(es_, ms_, nbs_, 16, 2)
-        steps_ = max(8, args.steps // 2)
-        out["scaling_reference"] = {"value": Bn * steps_ / timed_steps(es_, ms_, nbs_, steps_, 2), "unit": "examples/s", "batch_rows_per_gpu": Bn, "learn_rate": learn_rate_for(Bn),
+        ms_ = make_matrix(engine, L, args, n, 0)
+        v_s, _ = timed_variant(args, L, engine, ms_, v0, Bn, max(8, args.steps // 2), learn_rate=learn_rate_for(Bn))
+        ms_.close()
+        out["scaling_reference"] = {"value": v_s, "unit": "examples/s", "batch_rows_per_gpu": Bn, "learn_rate": learn_rate_for(Bn),
                                     "note": "one GPU at the per-GPU step size that `bench.py --gpus N` (N > 1) runs: divide the N-GPU values by THIS figure for a like-for-like efficiency"}
-        es_.close(); ms_.close()
     if args.state_fp64:
         return out
-    # the reference's precision in the throughput mode
-    e64 = engine.Engine(p, **engine_kwargs(args, L, min(args.batch_rows, n), 0, 1, state_fp64=1))
-    e64.set_params(0.0, None, v0.astype(np.float64))
-    nb = max(1, n // min(args.batch_rows, n))
-    dt = timed_steps(e64, m, nb, max(4, args.steps // 2), 2)
-    out["value_fp64_state"] = min(args.batch_rows, n) * max(4, args.steps // 2) / dt
-    e64.close()
     # small steps (latency-bound: two dependent launches per step) on the first 2M rows
     sub_n = min(n, 2_000_000)
-    sub = engine.Matrix.synthetic(sub_n, p, z, args.seed, row_offset=0)
+    sub = make_matrix(engine, L, args, sub_n, 0)
     small = {}
     for B in (4096, 16384):
         es = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1))
@@ -425,6 +528,11 @@ def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_
                                        "1e-5-on-V parity with the reference CPU path is asserted in THIS mode; `value` is the mini-batch mode"}
     seq.close()
     sub.close()
+    if args.solver == "sgd":
+        try:
+            out["time_to_quality"] = time_to_quality(args, L, engine, v0)
+        except BaseException as ex:   # a side measurement must not take the line with it
+            out["time_to_quality"] = {"error": f"{type(ex).__name__}: {ex}"}
     return out
 
 
@@ -505,7 +613,9 @@ def main_sweep(args, rank, local_rank, world):
         "metric": "V-sweep examples/sec, 10Mx1M sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
         "value": world * n * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic {n}x{p}, {z} nnz/row, k={k}, {'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
+        "config": {"workload": f"synthetic {n}x{p}, {z} nnz/row, one column per stratum of [0, p) (fmx_matrix_synthetic: one-column-per-field data, the shape whose exact level "
+                               f"schedule is {z} levels; i.i.d. columns need thousands of dependent levels and take the approximate groups instead), k={k}, "
+                               f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
                                f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
                    "levels": levels, "largest_level": largest, "approximate": bool(approx), "levels_per_step": launches, "levels_row_tiled": tiled,
                    "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
@@ -609,20 +719,29 @@ def main_stream(args, rank, local_rank, world):
     fwd_ms, fwd_n = e.profile_get(L.KERNEL_ROWS_FORWARD)
     upd_ms, upd_n = e.profile_get(L.KERNEL_COLS_UPDATE)
     b_step = algorithmic_bytes(z, k, p, B, 4, False)[2]
-    step_gbs = b_step / (dt / args.steps) / 1e9
+    ms_step = dt / args.steps * 1e3
+    step_gbs = b_step / (ms_step * 1e-3) / 1e9
+    # a streamed step is ONE tile: one launch of each training kernel per step.  The roofline is priced on those two (HIP events on the engine's stream, every 15th
+    # launch); generation and planning of the steps ahead run on a second stream beside them and are reported on their own
+    k_ms = fwd_ms / max(fwd_n, 1) + upd_ms / max(upd_n, 1)
+    k_gbs = b_step / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     return ({
         "metric": "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD, streamed (configs[3])",
         "value": B * world * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Criteo-shaped synthetic STREAM, {p} features ({z} nnz/row: 13 dense + 26 categorical fields, skew 3), k={k}, SGD mini-batch: every step's "
                                f"{B} rows per GPU are generated, planned and trained on once (BASELINE.json configs[3]; its 4e9 rows = {4_000_000_000 // (B * world)} such steps)",
                    "batch_rows_per_gpu": B, "global_batch_rows": B * world, "parallelism": f"dp{world}",
                    "ingest_wait_s": wait,
                    **({"exchange": dict(form=exchange + (": records all-to-all to the owner (id mod N), owner update, rows pulled back on demand" if exchange == "owner" else ""), **moved)} if moved else {})},
-        "roofline": {"bound": "hbm", "kernel": "step = generate + plan + fm_rows_forward + fm_cols_update (+ exchange)", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": step_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_example": b_step / B,
+        "roofline": {"bound": "hbm", "kernel": "fm_rows_forward + fm_cols_update of a streamed step (one tile: one launch each)", "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": k_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_example": b_step / B, "avg_launch_ms": k_ms,
                      "kernels": {"fm_rows_forward": {"avg_launch_ms": fwd_ms / max(fwd_n, 1)}, "fm_cols_update": {"avg_launch_ms": upd_ms / max(upd_n, 1)}},
-                     "note": "per GPU: SURVEY 8(d) step bytes over the wall time of a streamed global step (ingest and exchange included)"},
+                     "note": "per GPU: SURVEY 8(d) step bytes over the two training kernels' HIP-event times (they run beside the ingest stream, so their times include what its "
+                             "traffic costs them)"},
+        "ingest": {"ms_per_step_beyond_training_kernels": ms_step - k_ms, "step_frac_with_ingest" + ("_and_exchange" if world > 1 else ""): step_gbs / HBM_PEAK_GBS,
+                   "note": "generate + split + per-field sort + directory of the step after next, on a second stream; what the step's wall time holds beyond its two "
+                           "training kernels is ingest that did not hide" + (" plus the exchange" if world > 1 else "")},
     })
 
 
@@ -643,7 +762,7 @@ def main_in_library(args):
     if criteo:
         m = engine.Matrix.synthetic_fields(args.rows, 13, engine.CRITEO_VOCAB, 3.0, args.seed)
     else:
-        m = engine.Matrix.synthetic(args.rows, p, z, args.seed)
+        m = make_matrix(engine, L, args, args.rows, 0)
     e = engine.Engine(p, **engine_kwargs(args, L, B, 0, 1, n_gpus=N, gpus_share_device=int(share and N > 1), exchange_chunks=0, learn_rate=learn_rate_for(B * N)))
     e.init_normal(args.seed, 0.0, 0.01)
     per_step = B * N
@@ -655,14 +774,14 @@ def main_in_library(args):
     _, vv = e.get_rows(np.arange(0, p, max(1, p // 100_000), dtype=np.uint32))
     if not np.all(np.isfinite(vv)):
         raise SystemExit("non-finite parameters after the timed region")
-    b_step = algorithmic_bytes(z, k, p, B, 4, ftrl)[2]
+    b_step = algorithmic_bytes(z, k, p, B, 4, ftrl, unit=e_unit(m))[2]
     step_gbs = b_step / (dt / args.steps) / 1e9
     ginfo = e.group_info()
     return ({
-        "metric": "training examples/sec, 10Mx1M sparse FM SGD" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
+        "metric": f"training examples/sec, 10Mx1M sparse FM {args.solver.upper()}" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
         "value": done / dt, "unit": "examples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch (BASELINE.json configs[{3 if criteo else (2 if ftrl else 1)}]{' shape, resident rows' if criteo else ''})",
+        "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, {'Criteo-shaped fields' if criteo else COLUMN_LAWS[args.columns]}, k={k}, {args.solver.upper()} mini-batch (BASELINE.json configs[{3 if criteo else (2 if ftrl else 1)}]{' shape, resident rows' if criteo else ''})",
                    "driver": "in-library: one process, cfg.n_gpus replicas behind one C-ABI handle (fm_group.hip)" + (" on ONE device (rehearsal)" if share and N > 1 else ""),
                    "batch_rows_per_gpu": B, "global_batch_rows": per_step, "parallelism": f"dp{N}",
                    **({} if ftrl else {"learn_rate": learn_rate_for(per_step)}),
@@ -682,13 +801,13 @@ def compact_line(d):
     r = d.get("roofline", {})
     keep = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
             "workload": d["config"]["workload"],
-            "roofline": {kk: r[kk] for kk in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_note", "survey_priced_frac", "design_frac", "avg_launch_ms", "algorithmic_bytes_per_launch",
+            "roofline": {kk: r[kk] for kk in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_note", "frac_with_unread_values", "fabric", "survey_priced_frac", "design_frac", "avg_launch_ms", "algorithmic_bytes_per_launch",
                                               "algorithmic_bytes_per_example", "traffic") if kk in r}}
     if "kernels" in r:
-        keep["roofline"]["kernels"] = {name: {kk: v[kk] for kk in ("avg_launch_ms", "frac", "ceiling_frac", "hbm_priced_frac", "traffic") if kk in v} for name, v in r["kernels"].items()}
+        keep["roofline"]["kernels"] = {name: {kk: v[kk] for kk in ("avg_launch_ms", "frac", "ceiling_frac", "hbm_priced_frac", "traffic", "fabric") if kk in v} for name, v in r["kernels"].items()}
     if "gather_ceiling" in r:
         keep["roofline"]["ceiling_frac"] = r["gather_ceiling"].get("ceiling_frac")
-    for kk in ("cpu_baseline", "forward_rows_per_s"):
+    for kk in ("cpu_baseline", "forward_rows_per_s", "ingest"):
         if kk in d:
             keep[kk] = d[kk]
     for kk in ("batch_rows_per_gpu", "tile_rows", "features_occurring_per_step", "levels", "levels_row_tiled", "ingest_wait_s"):
@@ -703,6 +822,7 @@ def other_configs(args):
     `--workload criteo [--stream]`, `--solver mcmc`; the GPU shapes are the configs' own, only the step counts and the CPU samples are short."""
     out = {}
     runs = [
+        ("configs[1]_fp64_state", ["--state-fp64", "--no-extras", "--steps", "20", "--warmup", "3", "--cpu-rows", "0"], run_minibatch),
         ("configs[2]", ["--solver", "ftrl", "--no-extras", "--steps", "16", "--warmup", "2", "--cpu-rows", "60000"], run_minibatch),
         ("configs[3]_resident", ["--workload", "criteo", "--steps", "30", "--warmup", "3", "--cpu-rows", "120000"], run_minibatch),
         ("configs[3]_streamed", ["--workload", "criteo", "--stream", "--steps", "30", "--warmup", "3"], main_stream),
@@ -711,7 +831,7 @@ def other_configs(args):
     for name, argv, fn in runs:
         t0 = time.perf_counter()
         try:
-            a = parse(argv + ["--seed", str(args.seed), "--no-other-configs"])
+            a = parse(argv + ["--seed", str(args.seed), "--columns", args.columns, "--no-other-configs"])
             a.cpu_one_core_only = True
             line = fn(a, 0, 0, 1)
             out[name] = compact_line(line)
@@ -721,6 +841,22 @@ def other_configs(args):
     if "configs[3]_streamed" in out and "configs[3]_resident" in out and "cpu_baseline" in out["configs[3]_resident"] and "error" not in out["configs[3]_streamed"]:
         out["configs[3]_streamed"]["cpu_baseline"] = dict(out["configs[3]_resident"]["cpu_baseline"], note="the resident line's sample: the same workload")
     return out
+
+
+def launch_ranks(n):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process;
+    its stdout (rank 0's ONE JSON line) and stderr pass through, its return code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -734,8 +870,10 @@ def main():
         print(json.dumps(main_in_library(args)), flush=True)
         return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU), or pass --in-library")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N ...` without a launcher: start one rank per GPU as CHILD processes (torch.distributed.run) and relay their output.  This
+            # process has imported neither torch nor the HIP library and never touches a GPU; nothing is exec'd.
+            raise SystemExit(launch_ranks(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -785,7 +923,7 @@ def run_minibatch(args, rank, local_rank, world):
     if criteo:
         m = engine.Matrix.synthetic_fields(n_local, 13, engine.CRITEO_VOCAB, 3.0, args.seed, row_offset=r0, device=local_rank)
     else:
-        m = engine.Matrix.synthetic(n_local, p, z, args.seed, row_offset=r0, device=local_rank)
+        m = make_matrix(engine, L, args, n_local, r0, local_rank)
     e = engine.Engine(p, **engine_kwargs(args, L, B, local_rank, world))
     if criteo:
         v0 = None
@@ -880,8 +1018,11 @@ def run_minibatch(args, rank, local_rank, world):
         # per LAUNCH: one tile.  A sparse tile's phase 2 visits only the features that occur in it (their count is known from ingest)
         sparse_tiles = world == 1 and tile_rows >= B and e.compact_info(m)[2]
         p_walk = int(np.mean([e.compact_count(m, b) for b in range(min(nb_full, 8))])) if (criteo or sparse_tiles) else p
-        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p_walk, tile_rows, eb, ftrl)
-        b_step = algorithmic_bytes(z, k, p, B, eb, ftrl)[2]
+        # one-hot rows: the kernels never read the value arrays, and those bytes are not priced; Criteo-shaped rows carry 13 real values of 39
+        unit = e_unit(m) and not criteo
+        b_fwd, b_upd, _ = algorithmic_bytes(z, k, p_walk, tile_rows, eb, ftrl, unit)
+        b_step = algorithmic_bytes(z, k, p, B, eb, ftrl, unit)[2]
+        b_step_with_values = algorithmic_bytes(z, k, p, B, eb, ftrl, False)[2]
         kernels = {
             "fm_rows_forward": (b_fwd, fwd_ms / max(fwd_n, 1)),
             "fm_cols_update": (b_upd, upd_ms / max(upd_n, 1)),
@@ -907,12 +1048,12 @@ def run_minibatch(args, rank, local_rank, world):
         step_gbs = b_step / (dt / args.steps) / 1e9   # per GPU: B rows of this rank per step
         traffic = per_kernel[dom]["traffic"]
         out = {
-            "metric": "training examples/sec, 10Mx1M sparse FM SGD" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
+            "metric": f"training examples/sec, 10Mx1M sparse FM {args.solver.upper()}" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
             "value": value, "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.state_fp64 else "f32", "data": "synthetic",
-            "config": {"workload": (f"synthetic {args.rows}x{p}, {z} nnz/row, k={k}, {args.solver.upper()} mini-batch "
-                                    f"(BASELINE.json configs[{2 if ftrl else 1}])") if not criteo else
+            "config": {"workload": (f"synthetic {args.rows}x{p}, {z} nnz/row, {COLUMN_LAWS[args.columns]}, values {'U(0,1)' if args.real_values else '1'}, k={k}, "
+                                    f"{args.solver.upper()} mini-batch (BASELINE.json configs[{2 if ftrl else 1}]{', fp64 parameter state: the reference precision' if args.state_fp64 else ''})") if not criteo else
                                    (f"Criteo-shaped synthetic {args.rows}x{p} resident ({z} nnz/row: 13 dense + 26 categorical fields, skew 3), k={k}, "
                                     f"{args.solver.upper()} mini-batch (BASELINE.json configs[3]'s shape; its 4e9 rows are streamed: fmx_train_stream)"),
                        **({"features_occurring_per_step": p_walk} if (criteo or sparse_tiles) else {}),
@@ -937,6 +1078,11 @@ def run_minibatch(args, rank, local_rank, world):
                                             "(TCC_EA0_RDREQ_128B / TCC_EA0_RDREQ = 1.00 in the same summary; DESIGN.md section 6.8)") if traffic else None,
                          "algorithmic_bytes_per_example": b_step / B, "dominant_kernel": dom, "kernels": per_kernel},
         }
+        if unit:
+            out["roofline"]["frac_with_unread_values"] = b_step_with_values / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["bytes_note"] = (f"one-hot rows: no kernel reads the value arrays, so SURVEY 8(d)'s step bytes ({b_step_with_values / B:.0f} per example at this state width) are priced "
+                                             f"without the 4-byte value stream ({b_step / B:.0f}); the two kernels' own bytes likewise (4 bytes per nonzero less in each); "
+                                             "`frac_with_unread_values` is the figure rounds 1-4 printed; `value_real_values` times the value-reading kernels")
         if world == 1 and all("fabric" in v for v in per_kernel.values()):
             fb = sum(v["fabric"]["bytes_per_launch"] for v in per_kernel.values()) * (rows_step / tile_rows if tile_rows else 1)
             out["roofline"]["fabric"] = {"bytes_per_step": fb, "frac": fb / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "line_bytes": 128,

@@ -1450,6 +1450,29 @@ int generate_iid_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64
   return FMX_OK;
 }
 
+static void drop_value_caches(fmx_matrix* m);
+// SURVEY 8(d)'s value variant ("val = 1.0f (variant: U(0,1))"): the stored values of a resident matrix redrawn uniform in (0, 1), entry i of global
+// row g from Philox(seed; g, i / 4 | stream 0x7A1)[i % 4] -- keyed like the column generators, so a shard draws what the whole matrix would.  One thread per
+// row; the kernels then read the value arrays (util/Smatrix.h:44-61: the reference's values are real floats).
+__global__ void synth_values_k(int64_t n, uint64_t seed, int64_t row_offset, const int64_t* __restrict__ row_ptr, float* __restrict__ val) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t g = (uint64_t)(row_offset + r);
+  const int64_t b = row_ptr[r], z = row_ptr[r + 1] - b;
+  for (int64_t i = 0; i < z; i += 4) {
+    const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(i >> 2), 0x7A1u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    for (int q = 0; q < 4 && i + q < z; ++q) val[b + i + q] = ((float)(ph.c[q] >> 9) + 0.5f) * (1.0f / 8388608.0f);   // 23 bits + the half: exact in fp32, never 0 or 1
+  }
+}
+
+int matrix_values_uniform(fmx_matrix* m, uint64_t seed, int64_t row_offset) {
+  if (m->n > 0) hipLaunchKernelGGL(synth_values_k, dim3((unsigned)((m->n + 127) / 128)), dim3(128), 0, nullptr, m->n, seed, row_offset, (const int64_t*)m->row_ptr, m->val);
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipDeviceSynchronize());
+  drop_value_caches(m);
+  return check_rows_sorted(m);   // no longer one-hot: unit_values and the field layout go
+}
+
 // SURVEY 8(d)'s ragged variant: "nnz/row = Poisson(30) clipped to [1, 64]", columns i.i.d. uniform over [0, p), sorted inside the row (repeats bumped).
 // Lengths by inversion of the Poisson CDF on one Philox word keyed (seed; global row): shard independent like every generator here.
 __global__ void synth_ragged_len_k(int64_t n, double mean, int lo, int hi, uint64_t seed, int64_t row_offset, int64_t* __restrict__ lens) {

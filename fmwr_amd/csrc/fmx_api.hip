@@ -1139,6 +1139,13 @@ int fmx_matrix_set_labels(fmx_matrix* m, const float* y) {
   return FMX_OK;
 }
 
+int fmx_matrix_synthetic_values(fmx_matrix* m, uint64_t seed, int64_t row_offset) {
+  FMX_CHECK(m != nullptr, FMX_ERR_INVALID, "NULL matrix");
+  FMX_CHECK(row_offset >= 0, FMX_ERR_INVALID, "row_offset must not be negative");
+  FMX_TRY(use_device(m->device));
+  return matrix_values_uniform(m, seed, row_offset);
+}
+
 int fmx_matrix_destroy(fmx_matrix* m) {
   if (m) (void)hipSetDevice(m->device);
   free_matrix(m);

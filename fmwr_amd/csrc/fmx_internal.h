@@ -524,6 +524,7 @@ int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_
 int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream);
 void strata_bounds(uint32_t p, int32_t z, std::vector<uint32_t>* out);
 int generate_ragged(int device, int64_t n, uint32_t p, double mean, int lo, int hi, uint64_t seed, int64_t row_offset, fmx_matrix** out);
+int matrix_values_uniform(fmx_matrix* m, uint64_t seed, int64_t row_offset);
 int generate_iid_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, int kind, double s_exp, hipStream_t stream);
 constexpr int FMX_MAX_FIELDS = 64;
 struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)

@@ -115,6 +115,11 @@ class Matrix:
         fb = np.ascontiguousarray(field_base, np.uint32)
         L.check(L.lib().fmx_matrix_set_fields(self.h, C.c_int32(int(n_dense)), C.c_int32(len(fb) - 1), _p(fb)))
 
+    def synthetic_values(self, seed, row_offset=0):
+        """Redraw every stored value uniform in (0, 1) on the device (fmx_matrix_synthetic_values: SURVEY 8(d)'s value variant); the matrix stops being one-hot."""
+        L.check(L.lib().fmx_matrix_synthetic_values(self.h, C.c_uint64(seed), C.c_int64(row_offset)))
+        return self
+
     def set_labels(self, y):
         y = np.ascontiguousarray(y, np.float32)
         if len(y) != self.n:

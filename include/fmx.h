@@ -214,6 +214,10 @@ int fmx_matrix_synthetic_iid(int device, int64_t n, uint32_t p, int32_t nnz_per_
  * i.i.d. uniform over [0, p), sorted inside the row, repeats bumped; values 1, labels +-1; shard independent (keyed by the global row). */
 int fmx_matrix_synthetic_ragged(int device, int64_t n, uint32_t p, double mean_nnz, int32_t min_nnz, int32_t max_nnz, uint64_t seed, int64_t row_offset,
                                 fmx_matrix** out);
+/* SURVEY 8(d)'s value variant: every stored value of a resident matrix redrawn uniform in (0, 1), keyed by (seed, global row = row_offset + r, entry) like the
+ * generators above (a shard draws what the whole matrix would).  The matrix stops being one-hot: its plans are dropped and the kernels read the value arrays
+ * from here on (util/Smatrix.h:44-61: the reference's values are real floats). */
+int fmx_matrix_synthetic_values(fmx_matrix* m, uint64_t seed, int64_t row_offset);
 int fmx_matrix_destroy(fmx_matrix* m);
 int fmx_matrix_info(const fmx_matrix* m, int64_t* n, uint32_t* p, int64_t* nnz);
 /* Copy rows [r0, r1) back to the host (row_ptr is rebased to 0); any pointer may be NULL. */

@@ -409,3 +409,17 @@ def test_shard_rows_partition():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it: the parent only spawns the launcher as a child (no torch import, no HIP call in
+    the parent) and relays the ranks' return code.  Here there is no GPU, so both ranks must stop with bench.py's own message, and the code must come back."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=root)
+    assert r.returncode != 0
+    assert "bench.py needs a GPU" in r.stderr, r.stderr[-1500:]
+    assert "launch N > 1 through" not in r.stderr

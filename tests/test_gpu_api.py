@@ -457,6 +457,51 @@ def test_the_ragged_generator_and_training_on_its_rows_against_the_oracle():
     assert util.rel_err(gv, mb.v.reshape(k, p)) < 1e-5 and util.rel_err(gw, mb.w) < 1e-5 and abs(gw0 - mb.w0.value) < 1e-5
 
 
+@pytest.mark.parametrize("gen", ["stratified", "iid", "ragged"])
+def test_the_value_variant_redraws_real_values_and_the_kernels_read_them(gen):
+    """fmx_matrix_synthetic_values ("val = 1.0f (variant: U(0,1))"): every stored value lands in (0, 1), exact in fp32 (23-bit draws + a half), keyed by
+    the global row (a shard draws what the whole matrix would), columns and labels untouched; the matrix stops being one-hot, so forward, mini-batch steps and
+    the sequential learner run the value-reading kernels -- checked against the oracle on the exported rows (util/Smatrix.h:44-61: real float values)."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k, z = 6_000, 5_000, 16, 30
+    make = {"stratified": lambda nn, off: engine.Matrix.synthetic(nn, p, z, 13, row_offset=off),
+            "iid": lambda nn, off: engine.Matrix.synthetic_iid(nn, p, z, 13, row_offset=off),
+            "ragged": lambda nn, off: engine.Matrix.synthetic_ragged(nn, p, float(z), 13, row_offset=off)}[gen]
+    m = make(n, 0)
+    rp0, col0, val0, y0 = m.export()
+    assert np.all(val0 == 1.0)
+    m.synthetic_values(77)
+    rp, col, val, y = m.export()
+    assert np.array_equal(rp, rp0) and np.array_equal(col, col0) and np.array_equal(y, y0)
+    assert val.min() > 0.0 and val.max() < 1.0 and abs(val.mean() - 0.5) < 0.01 and abs(val.std() - 12 ** -0.5) < 0.01
+    assert np.all(val.astype(np.float64) * 8388608.0 - 0.5 == np.floor(val.astype(np.float64) * 8388608.0))   # 23-bit draws, centred: never 0, never 1
+    assert len(np.unique(val)) > 0.95 * len(val)
+    tail = make(1_000, 5_000).synthetic_values(77, row_offset=5_000)                  # rows 5000.. of the same stream
+    assert np.array_equal(tail.export()[2], val[rp[5_000]:])
+    again = make(n, 0).synthetic_values(78)
+    assert not np.array_equal(again.export()[2], val)
+    w0, w, v = util.params(p, k, 9)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.CLASSIFICATION, k=k, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.05)
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_SGD, num_factor=k, l2_w1=1e-4, l2_v=1e-4, learn_rate=0.05)
+    e = engine.Engine(p, mode=L.MODE_MINIBATCH, batch_rows=2_000, **kw)
+    e.set_params(w0, w, v)
+    np.testing.assert_allclose(e.predict(m), oracle.predict_batch(P, X, w0, w, v.ravel()), rtol=0, atol=1e-5)
+    e.train(m, n)
+    mb = oracle.SgdMinibatch(P, X, y, w0, w, v.ravel())
+    for b in range(0, n, 2_000):
+        mb.step(b, b + 2_000)
+    gw0, gw, gv = e.get_params()
+    assert util.rel_err(gv, mb.v.reshape(k, p)) < 1e-5 and util.rel_err(gw, mb.w) < 1e-5 and abs(gw0 - mb.w0.value) < 1e-5
+    es = engine.Engine(p, mode=L.MODE_SEQUENTIAL, **kw)
+    es.set_params(w0, w, v)
+    es.train(m, 3_000)
+    ref = oracle.sgd_learn(P, X, y, w0, w, v.ravel(), 3_000)
+    assert util.rel_err(es.get_params()[2], ref["v"].reshape(k, p)) < 1e-10
+    with pytest.raises(L.FmxError):
+        L.check(L.lib().fmx_matrix_synthetic_values(None, 1, 0))
+
+
 def test_lane_groups_pulling_rows_changes_no_bit(monkeypatch):
     """Phase 1 on rows of differing lengths, opt-in form (FMX_ROWS_PULL=1, fm_rows_forward_dyn_k): the lane groups of a workgroup pull rows from a counter
     instead of owning one row each.  A row is still walked by one lane group in row order and stored under its own index, the w0 partial sums keep their

@@ -96,6 +96,26 @@ def test_bench_multirank_path_runs(tmp_path):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch_rows"] == 65536 and d["config"]["tile_rows"] == 32768
 
 
+def test_the_bare_n_gpu_command_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher (the driver's N = 1 command with N replaced): bench.py starts torch.distributed.run as a child
+    process before anything touches the GPU and relays rank 0's line and the return code (VERDICT r4 missing 1)."""
+    env = dict(os.environ, FMX_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rows", "400000", "--features", "50000", "--batch-rows", "32768", "--backend", "gloo", "--cpu-rows", "0"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch_rows"] == 65536 and d["config"]["parallelism"] == "dp2"
+    # a failing rank's code comes back through the launcher
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stream", "--backend", "gloo", "--cpu-rows", "0"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert bad.returncode != 0
+
+
 COMPACT_WORKER = r'''
 import os, sys, json
 import numpy as np, torch, torch.distributed as dist
