@@ -848,7 +848,7 @@ void als_graph_free(void* p) {
 }
 template <bool W>
 static bool sweep_graph_wanted(const fmx_matrix* m) {
-  if (m->als_approx) return false;
+  if (m->als_approx || m->als_tiled) return false;   // (a tiled level folds e->als_qnext and sizes its workspace on the host: not capturable)
   const char* v = getenv("FMX_ALS_GRAPH");
   return v && v[0] == '1' && (int)m->als_level_ptr.size() - 1 >= ALS_GRAPH_MIN_LEVELS;
 }
@@ -956,6 +956,25 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.qout_t = m->n; a.link = FMX_LINK_NONE;
     a.unit = m->unit_values;
     if (launch_rows_forward(e, a, false, true) != FMX_OK) d_Q = nullptr;
+  }
+  // a COMPLETE tiled plan (every level tiled, every row in every level: one-column-per-field data): the pairs travel in the list order of the level that
+  // consumes them next (fm_als_tiled.hip, the level-order form) -- per level one streaming sums + step kernel and one correct-and-permute kernel
+  if (d_Q && !d_qe_new && als_order_ready(m)) {
+    bool ok = false;
+    FMX_TRY(als_order_enter(e, m, d_qe, d_Q, &ok));
+    if (ok) {
+      const int S = als_order_levels(m);
+      for (int f = 0; f < e->k; ++f) {
+        set_dyn(e, dyn, f, alpha, h_lambda ? h_lambda[f] : 0.0, h_mu ? h_mu[f] : 0.0, d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
+        for (int s = 0; s < S; ++s) {
+          prof_begin(e, FMX_KERNEL_ALS_SWEEP);   // one level of one factor: the unit bench.py --solver als prices
+          const int st = als_order_level(e, m, s, dyn, (s == S - 1 && f + 1 < e->k) ? d_Q + (size_t)(f + 1) * m->n : nullptr);
+          prof_end(e);
+          FMX_TRY(st);
+        }
+      }
+      return als_order_exit(e, m, d_qe);
+    }
   }
   bool picked = false;   // the previous factor's last correction pass already stored this factor's q (tiled form)
   e->als_vf_slot = -1;

@@ -48,8 +48,15 @@ struct AlsTiled {
   int64_t* tile_base = nullptr;  // [n_tiles + 1] (device) first entry of each tile in trow / tval
   uint32_t* trow = nullptr;      // [entries + 1] row inside the tile
   float* tval = nullptr;         // [entries + 1] (null: unit values)
+  // The LEVEL-ORDER form of the V sweep (below): available when the plan is COMPLETE -- every level of the plan is a tiled one and every row holds exactly
+  // one feature of every level (one-column-per-field data) -- so that position i of tile t's level-s block, entry tile_base[t] + toff[t][lvl0_s] + i of
+  // trow / tval, is also a position of the tile's slice of a (q, e) array kept in level s's list order.
+  int complete = 0;
+  uint32_t* perm = nullptr;      // [n_slots][n] position, inside the same tile, that the row at position i of level s's order has in the order of level s + 1 (cyclic)
+  void* fidx = nullptr;          // [n_slots][n] index (inside its level) of the feature whose list position i belongs to (u16 / u32 like lfi)
   ~AlsTiled() {
     (void)hipFree(feats); (void)hipFree(lfi); (void)hipFree(lval); (void)hipFree(toff); (void)hipFree(tile_base); (void)hipFree(trow); (void)hipFree(tval);
+    (void)hipFree(perm); (void)hipFree(fidx);
   }
 };
 
@@ -121,6 +128,9 @@ static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s && *s ? atoi(s) : dflt;
 }
+
+struct AlsTiled;
+static int order_build(fmx_matrix* m, AlsTiled* T, hipStream_t stream);
 
 // Which levels of the exact plan go through the tiled form, and their plan.  Called at the end of build_plan (the CSC and the levels exist).
 // A failure to allocate leaves the matrix without a tiled plan (the column-walking kernels do every level then): never an error.
@@ -221,7 +231,81 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   hipLaunchKernelGGL(tiled_scatter_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, m->cval, w.rank_of, p, ts, nf1, T->toff, T->tile_base, T->trow, T->tval);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipStreamSynchronize(stream));
+  FMX_TRY(order_build(m, T.get(), stream));
   m->als_tiled = T.release();
+  return FMX_OK;
+}
+
+// ---- the level-order plan ----------------------------------------------------------------------------------------------------------------
+// complete: the level-s block of every tile holds exactly the tile's rows
+__global__ void order_complete_k(const uint32_t* __restrict__ toff, size_t nf1, const uint32_t* __restrict__ lvl0, const uint32_t* __restrict__ cnt, int n_slots, int n_tiles,
+                                 int64_t n, int tshift, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots * n_tiles) return;
+  const int s = i / n_tiles, t = i % n_tiles;
+  const int64_t r0 = (int64_t)t << tshift, r1 = min(n, r0 + ((int64_t)1 << tshift));
+  const uint32_t* off = toff + (size_t)t * nf1;
+  if ((int64_t)off[lvl0[s]] != (int64_t)s * (r1 - r0) || (int64_t)off[lvl0[s] + cnt[s]] != (int64_t)(s + 1) * (r1 - r0)) *bad = 1;
+}
+// inv[s][row] = position of the row in its tile's level-s order
+__global__ void order_inverse_k(const uint32_t* __restrict__ trow, const int64_t* __restrict__ tile_base, int64_t n, int tshift, int n_slots, uint32_t* __restrict__ inv) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (slot, position) flattened: slot-major
+  if (g >= (int64_t)n_slots * n) return;
+  const int s = (int)(g / n);
+  const int64_t at = g % n, t = at >> tshift, r0 = t << tshift, rows = min(n, r0 + ((int64_t)1 << tshift)) - r0;
+  const uint32_t row = trow[tile_base[t] + (int64_t)s * rows + (at - r0)];
+  inv[(size_t)s * n + r0 + row] = (uint32_t)(at - r0);
+}
+template <typename IT>
+__global__ void order_perm_k(const uint32_t* __restrict__ trow, const int64_t* __restrict__ tile_base, int64_t n, int tshift, int n_slots, const uint32_t* __restrict__ inv,
+                             const IT* __restrict__ lfi, uint32_t* __restrict__ perm, IT* __restrict__ fidx) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)n_slots * n) return;
+  const int s = (int)(g / n), s2 = s + 1 < n_slots ? s + 1 : 0;
+  const int64_t at = g % n, t = at >> tshift, r0 = t << tshift, rows = min(n, r0 + ((int64_t)1 << tshift)) - r0;
+  const int64_t row = r0 + trow[tile_base[t] + (int64_t)s * rows + (at - r0)];
+  perm[g] = inv[(size_t)s2 * n + row];
+  fidx[g] = lfi[(size_t)s * n + row];
+}
+
+// Called at the end of als_tiled_build: the extra arrays of the level-order form where the plan is complete.  Any failure (incomplete plan, no memory) just
+// leaves the form unavailable.  FMX_ALS_ORDER=0 switches it off (A/B runs, and the tests that compare the forms).
+static int order_build(fmx_matrix* m, AlsTiled* T, hipStream_t stream) {
+  if (env_int("FMX_ALS_ORDER", 1) == 0) return FMX_OK;
+  const int L = (int)m->als_level_ptr.size() - 1;
+  int nonempty = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t c = m->als_level_ptr[(size_t)l + 1] - m->als_level_ptr[(size_t)l], h = m->als_heavy_ptr[(size_t)l + 1] - m->als_heavy_ptr[(size_t)l];
+    const int64_t v = m->als_vh_ptr.empty() ? 0 : m->als_vh_ptr[(size_t)l + 1] - m->als_vh_ptr[(size_t)l];
+    if (c + h + v > 0) { ++nonempty; if (T->slot_of_level[(size_t)l] < 0) return FMX_OK; }   // a level that keeps the column-walking kernels
+  }
+  if (nonempty != T->n_slots || T->n_slots < 1 || m->nnz != (int64_t)T->n_slots * m->n) return FMX_OK;
+  auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
+  struct Tmp { uint32_t *lvl0 = nullptr, *cnt = nullptr, *inv = nullptr; int* bad = nullptr; ~Tmp() { (void)hipFree(lvl0); (void)hipFree(cnt); (void)hipFree(inv); (void)hipFree(bad); } } w;
+  const size_t sn = (size_t)T->n_slots * (size_t)m->n, isz = T->lfi16 ? 2 : 4;
+  if (!ok(hipMalloc(&w.lvl0, (size_t)T->n_slots * 4)) || !ok(hipMalloc(&w.cnt, (size_t)T->n_slots * 4)) || !ok(hipMalloc(&w.bad, sizeof(int)))) return FMX_OK;
+  FMX_HIP(hipMemcpyAsync(w.lvl0, T->lvl0.data(), (size_t)T->n_slots * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemcpyAsync(w.cnt, T->cnt.data(), (size_t)T->n_slots * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), stream));
+  const int pairs = T->n_slots * T->n_tiles;
+  hipLaunchKernelGGL(order_complete_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, T->toff, (size_t)T->n_feats + 1, w.lvl0, w.cnt, T->n_slots, T->n_tiles, m->n, T->tshift, w.bad);
+  int bad = 0;
+  FMX_HIP(hipMemcpyAsync(&bad, w.bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+  FMX_HIP(hipStreamSynchronize(stream));
+  if (bad) return FMX_OK;   // some row lacks a level (or holds two features of one): the level blocks are not the tiles' rows
+  if (!ok(hipMalloc(&w.inv, sn * 4)) || !ok(hipMalloc(&T->perm, sn * 4)) || !ok(hipMalloc(&T->fidx, sn * isz))) {
+    (void)hipFree(T->perm); (void)hipFree(T->fidx); T->perm = nullptr; T->fidx = nullptr;
+    return FMX_OK;
+  }
+  const unsigned grid = (unsigned)((sn + 255) / 256);
+  hipLaunchKernelGGL(order_inverse_k, dim3(grid), dim3(256), 0, stream, T->trow, T->tile_base, m->n, T->tshift, T->n_slots, w.inv);
+  if (T->lfi16) hipLaunchKernelGGL((order_perm_k<uint16_t>), dim3(grid), dim3(256), 0, stream, T->trow, T->tile_base, m->n, T->tshift, T->n_slots, (const uint32_t*)w.inv,
+                                   reinterpret_cast<const uint16_t*>(T->lfi), T->perm, reinterpret_cast<uint16_t*>(T->fidx));
+  else hipLaunchKernelGGL((order_perm_k<uint32_t>), dim3(grid), dim3(256), 0, stream, T->trow, T->tile_base, m->n, T->tshift, T->n_slots, (const uint32_t*)w.inv,
+                          reinterpret_cast<const uint32_t*>(T->lfi), T->perm, reinterpret_cast<uint32_t*>(T->fidx));
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipStreamSynchronize(stream));
+  T->complete = 1;
   return FMX_OK;
 }
 
@@ -493,5 +577,251 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
 }
 template int als_tiled_level<true>(fmx_engine*, fmx_matrix*, int, bool, double2*, const SweepDyn*, bool*);
 template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, bool, double2*, const SweepDyn*, bool*);
+
+
+// ---- the level-order form of the V sweep -------------------------------------------------------------------------------------------------
+// What bounds the three passes above is the one random 16-byte access per stored nonzero (the sums pass's gather: 13 M L2 requests and 92 us of a 181 us
+// level at configs[4], profiles/r04_pmc_summary_mcmc.json) PLUS two streaming passes over the pairs around it.  Here the (q, e) pairs are kept physically in
+// the list order of the level that consumes them next -- tile t's slice holds its rows sorted by (feature of level s, row) -- so that
+//   sums + step  als_order_sums_k   is a STREAM: a workgroup owns FB consecutive features of the level; inside a tile their lists are one contiguous run of
+//                                   pairs, which the workgroup copies into LDS (coalesced, 16 tiles' runs in flight) and whose lists its lane groups then walk
+//                                   there.  The sums of a feature never leave the workgroup: no per-tile partial sums, no separate step kernel -- the
+//                                   coordinate step of :318-336 is taken right there.  Fixed order (tile, entry), fixed lane-group combine: bitwise run to run.
+//   apply        als_order_apply_k  reads the pairs in level s's order (stream), the feature's (v_old, diff) by the entry's feature index (neighbouring
+//                                   entries share it), corrects (:341-350) and writes each pair to its position in level s + 1's order: a permutation inside
+//                                   the tile's slice -- the one random 16-byte access per nonzero that is left.  A tile's workgroups share an XCD and there are
+//                                   enough of them per tile that an XCD works on ONE slice at a time: the scattered writes merge in its L2.
+// The last level's apply of a factor writes into level 0's order and stores the NEXT factor's q (gathered by row from the factor-major table); entry and exit
+// of the sweep convert between row order and level 0's order.  Measured before building: profiles/r05_level_order_probe.txt.
+template <bool UNIT, int FB, int TB, int CH>
+__global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
+                                                               const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
+                                                               const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                                               double2* __restrict__ vstep) {
+  constexpr int LG = WG_THREADS / FB;          // lanes per feature: lane j of a group walks the tiles t with t % LG == j
+  __shared__ uint32_t o[TB][FB + 1];           // list offsets of the workgroup's features in the batch's tiles (relative to the level block)
+  __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
+  __shared__ int64_t xbase[TB];                // first entry of each tile's level block in tval
+  __shared__ double2 lp[CH];
+  __shared__ float lx[UNIT ? 1 : CH];
+  const uint32_t f0 = blockIdx.x * FB;
+  const int g = threadIdx.x / LG, lane = threadIdx.x % LG;
+  const uint32_t fi = f0 + g;
+  const bool live = fi < cnt;
+  const uint32_t feat = feats[live ? fi : cnt - 1];
+  const int f = dyn->f;
+  const double old = P[(size_t)feat * kp + f];
+  double mean = 0.0, var = 0.0;
+  for (int t0 = 0; t0 < n_tiles; t0 += TB) {
+    const int nb = min(TB, n_tiles - t0);
+    __syncthreads();                            // (the walkers of the previous batch are done with o / vstart / lp)
+    for (int i = threadIdx.x; i < nb * (FB + 1); i += WG_THREADS) {
+      const int tb = i / (FB + 1), j = i % (FB + 1);
+      const uint32_t* off = toff + (size_t)(t0 + tb) * nf1 + lvl0;
+      o[tb][j] = stream_load<true>(off + min(f0 + j, cnt)) - off[0];
+      if (j == 0 && !UNIT) xbase[tb] = tile_base[t0 + tb] + (int64_t)off[0];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t a = 0; for (int tb = 0; tb < nb; ++tb) { vstart[tb] = a; a += o[tb][FB] - o[tb][0]; } for (int tb = nb; tb <= TB; ++tb) vstart[tb] = a; }
+    __syncthreads();
+    const uint32_t total = vstart[TB];
+    for (uint32_t c0 = 0; c0 < total; c0 += CH) {
+      constexpr int PER = CH / WG_THREADS;
+      double2 pv[PER]; float xv[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t v = min(c0 + threadIdx.x + u * WG_THREADS, total - 1);
+        int tb = 0;
+#pragma unroll
+        for (int q = 1; q < TB; ++q) tb += v >= vstart[q] ? 1 : 0;
+        const size_t at = ((size_t)(t0 + tb) << tshift) + o[tb][0] + (v - vstart[tb]);
+        pv[u] = stream_load<true>(src + at);
+        xv[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + o[tb][0] + (v - vstart[tb]));
+      }
+      if (c0 > 0) __syncthreads();              // (the walkers are done with the previous chunk; this chunk's loads are already out)
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
+        if (v < total) { lp[v - c0] = pv[u]; if (!UNIT) lx[v - c0] = xv[u]; }
+      }
+      __syncthreads();
+      const uint32_t c1 = min(c0 + CH, total);
+      for (int tb = lane; tb < nb; tb += LG) {
+        const uint32_t a = max(vstart[tb] + o[tb][g] - o[tb][0], c0), b = min(vstart[tb] + o[tb][g + 1] - o[tb][0], c1);
+        for (uint32_t v = a; v < b; ++v) {
+          const double2 c = lp[v - c0];
+          const float x = UNIT ? 1.0f : lx[v - c0];
+          const float xx = x * x;
+          const double h = (double)x * c.x - (double)xx * old;   // :310-317
+          mean += h * c.y; var += h * h;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ofs = 1; ofs < LG; ofs <<= 1) { mean += __shfl_xor(mean, ofs); var += __shfl_xor(var, ofs); }   // (a + b == b + a: every lane of the group holds the same bits)
+  if (lane != 0 || !live) return;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  mean -= old * var;                               // :318
+  var = 1.0 / (lambda + alpha * var);              // :319
+  mean = -var * (alpha * mean - mu * lambda);      // :320
+  double nv = bad_number_t(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+  if (bad_number_t(nv)) { vstep[fi] = make_double2(old, nan("")); return; }  // CHECK_PARAM (:336): the old value stays; NaN tells the apply pass to leave the rows alone
+  P[(size_t)feat * kp + f] = nv;
+  vstep[fi] = make_double2(old, old - nv);
+}
+
+// blockIdx -> (tile, chunk) with a tile's workgroups consecutive in ONE XCD's share of the grid (as als_tile_sums_k)
+template <bool UNIT, int R, bool QNEXT, typename IT>
+__global__ __launch_bounds__(WG_THREADS) void als_order_apply_k(const double2* __restrict__ src, double2* __restrict__ dst, const IT* __restrict__ fidx, const uint32_t* __restrict__ perm,
+                                                                const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, const int64_t* __restrict__ tile_base,
+                                                                const float* __restrict__ tval, const uint32_t* __restrict__ trow, const double2* __restrict__ vstep,
+                                                                const double* __restrict__ qnext, int tshift, int n_tiles, int B, int64_t n) {
+  const int b = blockIdx.x;
+  const int x8 = b & 7, qd = b >> 3;
+  const int tile = (qd / B) * 8 + x8, chunk = qd % B;
+  if (tile >= n_tiles) return;
+  const int64_t base = (int64_t)tile << tshift;
+  const int64_t rows = min(n, base + ((int64_t)1 << tshift)) - base;
+  const int64_t ebase = (UNIT && !QNEXT) ? 0 : tile_base[tile] + (int64_t)toff[(size_t)tile * nf1 + lvl0];   // the tile's level block in trow / tval
+  const int64_t i0 = (int64_t)chunk * (WG_THREADS * R) + threadIdx.x;
+  double2 c[R], s[R]; uint32_t pm[R]; float xs[R]; double qn[R]; IT fx[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int64_t i = i0 + u * WG_THREADS, ic = i < rows ? i : rows - 1;
+    c[u] = stream_load<true>(src + base + ic);
+    fx[u] = stream_load<true>(fidx + base + ic);
+    pm[u] = stream_load<true>(perm + base + ic);
+    xs[u] = UNIT ? 1.0f : stream_load<true>(tval + ebase + ic);
+    qn[u] = QNEXT ? qnext[base + stream_load<true>(trow + ebase + ic)] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) s[u] = vstep[fx[u]];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int64_t i = i0 + u * WG_THREADS;
+    if (i >= rows) continue;
+    const bool skip = s[u].y != s[u].y;
+    const float xx = xs[u] * xs[u];
+    const double h = (double)xs[u] * c[u].x - (double)xx * s[u].x;
+    const double q2 = QNEXT ? qn[u] : (skip ? c[u].x : c[u].x - (double)xs[u] * s[u].y);   // :341-350
+    dst[base + pm[u]] = make_double2(q2, skip ? c[u].y : c[u].y - h * s[u].y);
+  }
+}
+
+// row order -> level 0's order (q of the first factor from the factor-major table, e from the pairs) and back (e only: q of the last factor is dead)
+__global__ void als_order_enter_k(const double2* __restrict__ qe, const double* __restrict__ Q0, const uint32_t* __restrict__ trow, const int64_t* __restrict__ tile_base,
+                                  int64_t n, int tshift, double2* __restrict__ dst) {
+  const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (at >= n) return;
+  const int64_t t = at >> tshift, r0 = t << tshift;
+  const int64_t row = r0 + trow[tile_base[t] + (at - r0)];   // (level 0's block is the first of the tile)
+  dst[at] = make_double2(Q0[row], qe[row].y);
+}
+__global__ void als_order_exit_k(const double2* __restrict__ src, const uint32_t* __restrict__ trow, const int64_t* __restrict__ tile_base, int64_t n, int tshift,
+                                 double2* __restrict__ qe) {
+  const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (at >= n) return;
+  const int64_t t = at >> tshift, r0 = t << tshift;
+  qe[r0 + trow[tile_base[t] + (at - r0)]] = src[at];
+}
+
+bool als_order_ready(const fmx_matrix* m) {
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  return T && T->complete && !m->als_approx;
+}
+
+static int order_buffers(fmx_engine* e, int64_t n) {
+  if (e->als_lo_rows >= n && e->als_lo[0] && e->als_lo[1]) return FMX_OK;
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]); e->als_lo[0] = e->als_lo[1] = nullptr; e->als_lo_rows = 0;
+  if (hipMalloc(&e->als_lo[0], (size_t)n * sizeof(double2)) != hipSuccess || hipMalloc(&e->als_lo[1], (size_t)n * sizeof(double2)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(e->als_lo[0]); e->als_lo[0] = nullptr;
+    return FMX_ERR_HIP;   // (the caller falls back to the three-pass form)
+  }
+  e->als_lo_rows = n;
+  return FMX_OK;
+}
+
+// enter: d_qe (row order; e current) + Q0 (q of the first factor, row order) -> buffer 0 in level 0's order.  *ok = false: no memory, use the other form.
+int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const double* d_Q0, bool* ok) {
+  *ok = false;
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (!T || !T->complete) return FMX_OK;
+  double2* ws_partial; double* ws_vf; double2* vstep;
+  if (order_buffers(e, m->n) != FMX_OK || tile_ws(e, T, &ws_partial, &ws_vf, &vstep) != FMX_OK) { (void)hipGetLastError(); return FMX_OK; }
+  hipLaunchKernelGGL(als_order_enter_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, d_qe, d_Q0, (const uint32_t*)T->trow, (const int64_t*)T->tile_base, m->n, T->tshift,
+                     reinterpret_cast<double2*>(e->als_lo[0]));
+  e->als_lo_cur = 0;
+  *ok = true;
+  return FMX_OK;
+}
+
+// one level (slot s = the s-th non-empty level) of one factor: sums + step, then apply into the next level's order; d_qnext (row order) on the last level
+// of a factor that has a successor
+int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, const double* d_qnext) {
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  double2 *partial = nullptr, *vstep = nullptr; double* vf = nullptr;
+  FMX_TRY(tile_ws(e, T, &partial, &vf, &vstep));
+  const uint32_t lvl0 = T->lvl0[(size_t)s], cnt = T->cnt[(size_t)s];
+  const size_t nf1 = (size_t)T->n_feats + 1;
+  const double2* src = reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]);
+  double2* dst = reinterpret_cast<double2*>(e->als_lo[1 - e->als_lo_cur]);
+  const dim3 blk(WG_THREADS);
+  static const int fb = env_int("FMX_ALS_ORDER_FB", 64);
+  static const int rr = env_int("FMX_ALS_ORDER_R", 1);
+#define FMX_OSUMS(UNITv, FBv, TBv, CHv)                                                                                                                       \
+  hipLaunchKernelGGL((als_order_sums_k<UNITv, FBv, TBv, CHv>), dim3((cnt + FBv - 1) / FBv), blk, 0, e->stream, (const uint32_t*)T->toff, nf1, lvl0, cnt, (const int64_t*)T->tile_base, \
+                     (const float*)T->tval, src, T->tshift, T->n_tiles, (const uint32_t*)(T->feats + lvl0), e->dV, e->kp64, dyn, vstep)
+#define FMX_OSUMS_U(FBv, TBv, CHv) do { if (T->unit) FMX_OSUMS(true, FBv, TBv, CHv); else FMX_OSUMS(false, FBv, TBv, CHv); } while (0)
+  switch (fb) {
+    case 32: FMX_OSUMS_U(32, 16, 2048); break;
+    case 128: FMX_OSUMS_U(128, 8, 4096); break;
+    default: FMX_OSUMS_U(64, 16, 2048); break;
+  }
+#undef FMX_OSUMS_U
+#undef FMX_OSUMS
+  const int64_t tile_rows = (int64_t)1 << T->tshift;
+  const void* fx = (const char*)T->fidx + (size_t)s * T->n * (T->lfi16 ? 2 : 4);
+  const uint32_t* pm = T->perm + (size_t)s * T->n;
+#define FMX_OAPPLY(UNITv, Rv, QNv)                                                                                                                            \
+  do {                                                                                                                                                        \
+    const int B = (int)((tile_rows + WG_THREADS * Rv - 1) / (WG_THREADS * Rv));                                                                                 \
+    const dim3 ag((unsigned)(((T->n_tiles + 7) / 8) * 8 * B));                                                                                                  \
+    if (T->lfi16) hipLaunchKernelGGL((als_order_apply_k<UNITv, Rv, QNv, uint16_t>), ag, blk, 0, e->stream, src, dst, (const uint16_t*)fx, pm, (const uint32_t*)T->toff, nf1, lvl0, \
+                                     (const int64_t*)T->tile_base, (const float*)T->tval, (const uint32_t*)T->trow, (const double2*)vstep, d_qnext, T->tshift, T->n_tiles, B, T->n); \
+    else hipLaunchKernelGGL((als_order_apply_k<UNITv, Rv, QNv, uint32_t>), ag, blk, 0, e->stream, src, dst, (const uint32_t*)fx, pm, (const uint32_t*)T->toff, nf1, lvl0,          \
+                            (const int64_t*)T->tile_base, (const float*)T->tval, (const uint32_t*)T->trow, (const double2*)vstep, d_qnext, T->tshift, T->n_tiles, B, T->n);          \
+  } while (0)
+#define FMX_OAPPLY_Q(UNITv, Rv) do { if (d_qnext) FMX_OAPPLY(UNITv, Rv, true); else FMX_OAPPLY(UNITv, Rv, false); } while (0)
+#define FMX_OAPPLY_R(Rv) do { if (T->unit) FMX_OAPPLY_Q(true, Rv); else FMX_OAPPLY_Q(false, Rv); } while (0)
+  switch (rr) {
+    case 2: FMX_OAPPLY_R(2); break;
+    case 4: FMX_OAPPLY_R(4); break;
+    default: FMX_OAPPLY_R(1); break;
+  }
+#undef FMX_OAPPLY_R
+#undef FMX_OAPPLY_Q
+#undef FMX_OAPPLY
+  e->als_lo_cur = 1 - e->als_lo_cur;
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int als_order_levels(const fmx_matrix* m) {
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  return T ? T->n_slots : 0;
+}
+
+// exit: the current buffer (level 0's order: the last apply of the last factor wrote there) back to d_qe in row order
+int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe) {
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  hipLaunchKernelGGL(als_order_exit_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), (const uint32_t*)T->trow,
+                     (const int64_t*)T->tile_base, m->n, T->tshift, d_qe);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
 
 }  // namespace fmx

@@ -700,7 +700,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws); (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]);
   als_graph_free(e->als_graph_w); als_graph_free(e->als_graph_v);
   if (e->side_fork) (void)hipEventDestroy(e->side_fork);
   if (e->side_join) (void)hipEventDestroy(e->side_join);
@@ -1922,6 +1922,16 @@ int fmx_als_tiled_info(fmx_engine* e, fmx_matrix* m, int32_t* levels_tiled, int6
   FMX_TRY(use_device(e->cfg.device));
   FMX_TRY(als_plan_info(e, m, nullptr, nullptr, nullptr, nullptr));
   return als_tiled_info(m, levels_tiled, tile_rows, n_tiles);
+}
+
+int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order) {
+  FMX_TRY(check_pair(e, m));
+  FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "the ALS sweeps run on the fp64 tables: create the engine with FMX_MODE_SEQUENTIAL");
+  FMX_CHECK(level_order != nullptr, FMX_ERR_INVALID, "NULL argument");
+  FMX_TRY(use_device(e->cfg.device));
+  FMX_TRY(als_plan_info(e, m, nullptr, nullptr, nullptr, nullptr));
+  *level_order = als_order_ready(m) ? 1 : 0;
+  return FMX_OK;
 }
 
 int fmx_als_train(fmx_engine* e, fmx_matrix* m, int32_t max_iter, int32_t with_v) {

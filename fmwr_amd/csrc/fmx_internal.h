@@ -281,6 +281,9 @@ struct fmx_engine {
   void* als_dyn = nullptr;         // device struct the sweep kernels read factor / alpha / lambda / mu / normals from (fm_als_kernels.hip)
   void* als_tile_ws = nullptr;     // tiled sweep: per (tile, feature) sums, the level's coordinates and steps (fm_als_tiled.hip; grow-only)
   size_t als_tile_ws_bytes = 0;
+  void* als_lo[2] = {nullptr, nullptr};  // level-order form of the V sweep (fm_als_tiled.hip): the two (q, e) arrays it alternates between (grow-only)
+  int64_t als_lo_rows = 0;
+  int als_lo_cur = 0;              // which of the two holds the pairs now
   const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
                                       // finished factor's q when that level is a tiled one (it then clears this pointer: the pick kernel is not needed)
   int als_vf_slot = -1, als_vf_buf = 0;  // tiled sweep: the tiled level whose coordinates the previous level's step kernel already gathered, and into which half
@@ -565,6 +568,12 @@ int als_tiled_info(const fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_row
 // last: no further level of this factor's sweep follows (the fold of the next factor's q, e->als_qnext, happens there)
 template <bool W>
 int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2* d_qe, const SweepDyn* dyn, bool* done);
+// the level-order form of the V sweep on complete plans (fm_als_tiled.hip)
+bool als_order_ready(const fmx_matrix* m);
+int als_order_levels(const fmx_matrix* m);
+int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const double* d_Q0, bool* ok);
+int als_order_level(fmx_engine* e, fmx_matrix* m, int slot, const SweepDyn* dyn, const double* d_qnext);
+int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe);
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 
 int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);

@@ -524,6 +524,12 @@ class Engine:
         L.check(L.lib().fmx_als_tiled_info(self.h, m.h, C.byref(lv), C.byref(tr), C.byref(nt)))
         return lv.value, tr.value, nt.value
 
+    def als_level_order(self, m):
+        """True when the V sweeps of this matrix take the level-order form (fmx_als_order_info: a complete tiled plan)."""
+        v = C.c_int32()
+        L.check(L.lib().fmx_als_order_info(self.h, m.h, C.byref(v)))
+        return bool(v.value)
+
     def als_train(self, m, max_iter, with_v=False):
         L.check(L.lib().fmx_als_train(self.h, m.h, C.c_int32(max_iter), C.c_int32(int(with_v))))
 

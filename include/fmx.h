@@ -415,6 +415,13 @@ int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* la
  * levels take that form (0: none), the rows per tile and the number of tiles; builds the plan if need be.  FMX_ALS_TILED=0 / 1 in the
  * environment forbids / forces the form wherever a level qualifies (1: any size, any width -- tests), FMX_ALS_TILE_ROWS sets the tile. */
 int fmx_als_tiled_info(fmx_engine* e, fmx_matrix* m, int32_t* levels_tiled, int64_t* tile_rows, int32_t* n_tiles);
+/* A COMPLETE tiled plan -- every level of the plan is a tiled one and every row holds exactly one feature of every level: one-column-per-field data, BASELINE.json
+ * configs[4]'s shape -- lets the V sweep keep the (q, e) pairs physically in the list order of the level that consumes them next (the LEVEL-ORDER form,
+ * fm_als_tiled.hip): per level one kernel streams the pairs, sums the lists and takes the coordinate steps (no per-tile partial sums), one kernel applies the
+ * corrections and writes every pair to its place in the next level's order (a permutation inside the tile's L2-resident slice: the one random 16-byte access
+ * per stored nonzero that is left).  Same arithmetic per entry as the other forms, sums associated in (tile, entry) order: 1e-10 against them and the oracle,
+ * bitwise run to run.  *level_order = 1 when the V sweeps of this matrix take that form (the w sweep keeps the three-pass form); FMX_ALS_ORDER=0 forbids it. */
+int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
  * w0 update (:162-188); w sweep (:190-270, the exact one-thread form) }.  As shipped the reference never sweeps V (its

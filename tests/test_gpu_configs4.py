@@ -82,6 +82,66 @@ def test_configs4_gibbs_vsweep_k16_matches_oracle(law):
     assert util.rel_err(gerr, rerr) < 1e-10
 
 
+@pytest.mark.parametrize("tile_rows,n", [(4096, 20_000), (2048, 16_384), (8192, 16_385)])
+@pytest.mark.parametrize("values,gibbs", [("ones", False), ("normal", True), ("normal", False), ("ones", True)])
+def test_configs4_level_order_sweep_matches_oracle_and_the_three_pass_form(monkeypatch, values, gibbs, tile_rows, n):
+    """The level-order form of the V sweep (fm_als_tiled.hip: the (q, e) pairs kept in the list order of the level that consumes them next -- a streaming
+    sums + step kernel and a correct-and-permute kernel per level) on one-column-per-field data, forced onto a small matrix: several tiles with a short last
+    one, a matrix of whole tiles, and a last tile of ONE row; one-hot and real values, ALS and Gibbs forms.  Against the oracle (1e-10), against the three-pass
+    tiled form (FMX_ALS_ORDER=0) and against itself (bitwise, two runs)."""
+    from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_TILE_ROWS", str(tile_rows))
+    p = 6_000
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 59, values)
+    w0, w, v = util.params(p, K, 31, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    lam = np.linspace(0.1, 0.5, K); mu = np.linspace(-0.05, 0.05, K)
+    z = np.random.default_rng(9).normal(0, 1, (K, p)) if gibbs else None
+    rv, rerr, _ = oracle.als_update_v(K, X, v.ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+    res = {}
+    for order in ("1", "1", "0"):
+        monkeypatch.setenv("FMX_ALS_ORDER", order)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        assert e.als_tiled(m)[0] == e.als_plan(m)[0] == Z
+        assert e.als_level_order(m) == (order == "1")
+        gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+        gv = e.get_params()[2]
+        assert util.rel_err(gv, rv.reshape(K, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+        # a second sweep from there (the pairs re-enter in row order)
+        gerr2 = e.als_vsweep(m, gerr, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+        res.setdefault(order, []).append((gv, gerr, e.get_params()[2], gerr2))
+        e.close(); m.close()
+    a, b = res["1"]
+    assert all(np.array_equal(x, y_) for x, y_ in zip(a, b))                       # bitwise run to run
+    for x, y_ in zip(a, res["0"][0]):
+        assert util.rel_err(x, y_) < 1e-10                                          # the three-pass form: the same sweeps, sums associated differently
+
+
+def test_configs4_level_order_needs_a_complete_plan(monkeypatch):
+    """Rows that lack a level (i.i.d. columns: many narrow levels) or levels that keep the column-walking kernels leave the plan incomplete: the V sweep
+    then takes the three-pass form level by level, as before."""
+    from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_TILE_ROWS", "4096")
+    n, p = 8_000, 3_000
+    rp, col, val, y = _problem(engine, L, "iid", n, p, 61, "ones")
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=4, mode=L.MODE_SEQUENTIAL)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert e.als_tiled(m)[0] > 0 and not e.als_level_order(m)
+    # one-column-per-field rows with one row cut short: a row lacks the last level
+    rp2, col2, val2, y2 = _problem(engine, L, "stratified", n, p, 61, "ones")
+    rp3 = rp2.copy(); rp3[-1] -= 1
+    m2 = engine.Matrix.from_csr(rp3, col2[:-1], val2[:-1], p, y2)
+    assert not e.als_level_order(m2)
+    m3 = engine.Matrix.from_csr(rp2, col2, val2, p, y2)
+    assert e.als_level_order(m3)
+
+
 @pytest.mark.parametrize("lg", [1, 4])
 @pytest.mark.parametrize("law,values,gibbs", [("stratified", "ones", False), ("stratified", "normal", True), ("iid", "normal", False), ("iid", "ones", True)])
 def test_configs4_row_tiled_sweep_matches_oracle(monkeypatch, law, values, gibbs, lg):
@@ -90,6 +150,7 @@ def test_configs4_row_tiled_sweep_matches_oracle(monkeypatch, law, values, gibbs
     field; the i.i.d. matrix has many narrow levels and rows that hold nothing at most of them.  ALS and Gibbs forms, one and four lanes per list."""
     from fmwr_amd import _lib as L, engine
     monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_ORDER", "0")   # (this test is about the three-pass form; the level-order form has its own)
     monkeypatch.setenv("FMX_ALS_TILE_ROWS", "4096")
     monkeypatch.setenv("FMX_ALS_TILE_LG", str(lg))
     n, p = 20_000, 6_000
