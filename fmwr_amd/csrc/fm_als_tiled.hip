@@ -593,15 +593,20 @@ template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, bool, double2
 //                                   enough of them per tile that an XCD works on ONE slice at a time: the scattered writes merge in its L2.
 // The last level's apply of a factor writes into level 0's order and stores the NEXT factor's q (gathered by row from the factor-major table); entry and exit
 // of the sweep convert between row order and level 0's order.  Measured before building: profiles/r05_level_order_probe.txt.
+// TB tiles' offsets are taken in at once (all of configs[4]'s 77): their runs of pairs, laid end to end, are one virtual sequence that the workgroup
+// streams in chunks of CH entries -- the next chunk's loads are in flight (registers) while the lane groups walk the current one in LDS.
 template <bool UNIT, int FB, int TB, int CH>
 __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
                                                                const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
                                                                const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
                                                                double2* __restrict__ vstep) {
-  constexpr int LG = WG_THREADS / FB;          // lanes per feature: lane j of a group walks the tiles t with t % LG == j
-  __shared__ uint32_t o[TB][FB + 1];           // list offsets of the workgroup's features in the batch's tiles (relative to the level block)
+  constexpr int LG = WG_THREADS / FB;          // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
+  constexpr int PER = CH / WG_THREADS;
+  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS, "TB: a power of two, one thread per tile in the prefix step");
+  __shared__ uint32_t o[TB][FB + 1];           // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry)
   __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
-  __shared__ int64_t xbase[TB];                // first entry of each tile's level block in tval
+  __shared__ uint32_t blk[TB];                 // position of each run's first pair inside its tile's level block
+  __shared__ int64_t xbase[UNIT ? 1 : TB];     // first entry of each tile's level block in tval
   __shared__ double2 lp[CH];
   __shared__ float lx[UNIT ? 1 : CH];
   const uint32_t f0 = blockIdx.x * FB;
@@ -612,41 +617,74 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
   const int f = dyn->f;
   const double old = P[(size_t)feat * kp + f];
   double mean = 0.0, var = 0.0;
+  // position v of the virtual sequence -> its tile of the batch (the last tb with vstart[tb] <= v; empty runs are skipped by construction)
+  auto tile_of = [&](uint32_t v) { int tb = 0;
+#pragma unroll
+    for (int st = TB / 2; st > 0; st >>= 1) tb += (vstart[tb + st] <= v) ? st : 0;
+    return tb; };
   for (int t0 = 0; t0 < n_tiles; t0 += TB) {
     const int nb = min(TB, n_tiles - t0);
     __syncthreads();                            // (the walkers of the previous batch are done with o / vstart / lp)
-    for (int i = threadIdx.x; i < nb * (FB + 1); i += WG_THREADS) {
-      const int tb = i / (FB + 1), j = i % (FB + 1);
-      const uint32_t* off = toff + (size_t)(t0 + tb) * nf1 + lvl0;
-      o[tb][j] = stream_load<true>(off + min(f0 + j, cnt)) - off[0];
-      if (j == 0 && !UNIT) xbase[tb] = tile_base[t0 + tb] + (int64_t)off[0];
+    {
+      // every thread's offset loads go out together, then land in LDS (a load-store loop would wait for one load per trip: 20 trips of ~2 us each at
+      // 77 tiles x 65 offsets)
+      constexpr int NV = (TB * (FB + 1) + WG_THREADS - 1) / WG_THREADS;
+      uint32_t ov[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int i = threadIdx.x + q * WG_THREADS;
+        const int tb = min(i / (FB + 1), nb - 1), j = i % (FB + 1);
+        ov[q] = stream_load<true>(toff + (size_t)(t0 + tb) * nf1 + lvl0 + min(f0 + j, cnt));
+      }
+      uint32_t bv = 0; int64_t tbv = 0;
+      if ((int)threadIdx.x < nb) { bv = stream_load<true>(toff + (size_t)(t0 + threadIdx.x) * nf1 + lvl0); if (!UNIT) tbv = tile_base[t0 + threadIdx.x]; }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int i = threadIdx.x + q * WG_THREADS;
+        if (i < nb * (FB + 1)) o[i / (FB + 1)][i % (FB + 1)] = ov[q];
+      }
+      if ((int)threadIdx.x < nb) { blk[threadIdx.x] = bv; if (!UNIT) xbase[threadIdx.x] = tbv + (int64_t)bv; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t a = 0; for (int tb = 0; tb < nb; ++tb) { vstart[tb] = a; a += o[tb][FB] - o[tb][0]; } for (int tb = nb; tb <= TB; ++tb) vstart[tb] = a; }
+    if (threadIdx.x < 64) {                     // exclusive prefix of the run lengths: one wave, TB / 64 values per lane
+      uint32_t carry = 0;
+      for (int b0 = 0; b0 < TB; b0 += 64) {
+        const int tb = b0 + threadIdx.x;
+        const uint32_t len = (tb < nb) ? o[tb][FB] - o[tb][0] : 0u;
+        uint32_t inc = len;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) { const uint32_t up = __shfl_up(inc, ofs); if ((int)threadIdx.x >= ofs) inc += up; }
+        if (tb < TB) vstart[tb] = carry + inc - len;
+        if (tb < nb) blk[tb] = o[tb][0] - blk[tb];      // the run's first pair inside the tile's level block
+        carry += __shfl(inc, 63);
+      }
+      if (threadIdx.x == 0) vstart[TB] = carry;
+    }
     __syncthreads();
     const uint32_t total = vstart[TB];
-    for (uint32_t c0 = 0; c0 < total; c0 += CH) {
-      constexpr int PER = CH / WG_THREADS;
-      double2 pv[PER]; float xv[PER];
+    double2 pv[PER]; float xv[PER];
+    auto fetch = [&](uint32_t c0) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const uint32_t v = min(c0 + threadIdx.x + u * WG_THREADS, total - 1);
-        int tb = 0;
-#pragma unroll
-        for (int q = 1; q < TB; ++q) tb += v >= vstart[q] ? 1 : 0;
-        const size_t at = ((size_t)(t0 + tb) << tshift) + o[tb][0] + (v - vstart[tb]);
-        pv[u] = stream_load<true>(src + at);
-        xv[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + o[tb][0] + (v - vstart[tb]));
+        const int tb = tile_of(v);
+        const uint32_t in_block = blk[tb] + (v - vstart[tb]);
+        pv[u] = stream_load<true>(src + ((size_t)(t0 + tb) << tshift) + in_block);
+        xv[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + in_block);
       }
-      if (c0 > 0) __syncthreads();              // (the walkers are done with the previous chunk; this chunk's loads are already out)
+    };
+    if (total > 0) fetch(0);
+    for (uint32_t c0 = 0; c0 < total; c0 += CH) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
         if (v < total) { lp[v - c0] = pv[u]; if (!UNIT) lx[v - c0] = xv[u]; }
       }
       __syncthreads();
+      if (c0 + CH < total) fetch(c0 + CH);      // in flight while the chunk in LDS is walked
       const uint32_t c1 = min(c0 + CH, total);
-      for (int tb = lane; tb < nb; tb += LG) {
+      const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
+      for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
         const uint32_t a = max(vstart[tb] + o[tb][g] - o[tb][0], c0), b = min(vstart[tb] + o[tb][g + 1] - o[tb][0], c1);
         for (uint32_t v = a; v < b; ++v) {
           const double2 c = lp[v - c0];
@@ -656,6 +694,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
           mean += h * c.y; var += h * h;
         }
       }
+      __syncthreads();                          // (the walkers are done with lp before the next chunk lands in it)
     }
   }
 #pragma unroll
@@ -770,16 +809,18 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
   const double2* src = reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]);
   double2* dst = reinterpret_cast<double2*>(e->als_lo[1 - e->als_lo_cur]);
   const dim3 blk(WG_THREADS);
-  static const int fb = env_int("FMX_ALS_ORDER_FB", 64);
+  static const int fb = env_int("FMX_ALS_ORDER_FB", 16);   // (16: 52 us, 32: 55 us, 64: 60 us per level at configs[4]; profiles/r05_order_ab*.txt)
   static const int rr = env_int("FMX_ALS_ORDER_R", 1);
 #define FMX_OSUMS(UNITv, FBv, TBv, CHv)                                                                                                                       \
   hipLaunchKernelGGL((als_order_sums_k<UNITv, FBv, TBv, CHv>), dim3((cnt + FBv - 1) / FBv), blk, 0, e->stream, (const uint32_t*)T->toff, nf1, lvl0, cnt, (const int64_t*)T->tile_base, \
                      (const float*)T->tval, src, T->tshift, T->n_tiles, (const uint32_t*)(T->feats + lvl0), e->dV, e->kp64, dyn, vstep)
 #define FMX_OSUMS_U(FBv, TBv, CHv) do { if (T->unit) FMX_OSUMS(true, FBv, TBv, CHv); else FMX_OSUMS(false, FBv, TBv, CHv); } while (0)
   switch (fb) {
-    case 32: FMX_OSUMS_U(32, 16, 2048); break;
-    case 128: FMX_OSUMS_U(128, 8, 4096); break;
-    default: FMX_OSUMS_U(64, 16, 2048); break;
+    case 16: FMX_OSUMS_U(16, 128, 1024); break;
+    case 17: FMX_OSUMS_U(16, 128, 2048); break;   // (16 features, chunks of 2048: tuning)
+    case 33: FMX_OSUMS_U(32, 128, 1024); break;   // (32 features, chunks of 1024: tuning)
+    case 64: FMX_OSUMS_U(64, 64, 2048); break;
+    default: FMX_OSUMS_U(32, 128, 2048); break;
   }
 #undef FMX_OSUMS_U
 #undef FMX_OSUMS

@@ -33,6 +33,9 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         elif "als_tile_sums_k" in name: kn = "als_tile_sums"                                # the row-tiled form: per (tile, feature) sums ...
         elif "als_tile_step_k" in name: kn = "als_tile_step"                                # ... the coordinate steps of the level ...
         elif "als_rows_apply_k" in name: kn = "als_rows_apply"                              # ... and the row-major rank-1 corrections
+        elif "als_order_sums_k" in name: kn = "als_order_sums"                              # the level-order form: stream + list sums + coordinate steps ...
+        elif "als_order_apply_k" in name and ", true, unsigned" not in name: kn = "als_order_apply"   # ... and correct-and-permute (the once-per-factor QNEXT variant kept apart)
+        elif "als_order_apply_k" in name: kn = "als_order_apply_qnext"
         elif "als_q_pick_k" in name: kn = "als_q_pick"
         else: continue
         a = acc[kn][row["Counter_Name"]]

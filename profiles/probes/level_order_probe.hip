@@ -126,6 +126,265 @@ __global__ __launch_bounds__(256) void apply_perm_k(const double2* __restrict__ 
   }
 }
 
+// what does the ACCESS PATTERN of K1 cost by itself?  workgroup b reads PIECE pairs of every tile (piece b of the tile's slice), 8 tiles in flight per thread
+// (thread = one pair of the piece); rot: workgroup b starts at tile b % n_tiles (decorrelates which slices are hot together); contig: the same bytes, contiguous
+template <int PIECE, bool ROT, bool CONTIG>
+__global__ __launch_bounds__(256) void pieces_k(const double2* __restrict__ src, int ts, int n_tiles, double* __restrict__ out) {
+  constexpr int TPI = 256 / PIECE;   // tiles covered by one load instruction of the workgroup
+  const int lane_e = threadIdx.x % PIECE, lane_t = threadIdx.x / PIECE;
+  double acc = 0.0;
+  const int t_rot = ROT ? blockIdx.x % n_tiles : 0;
+  for (int t0 = 0; t0 < n_tiles; t0 += TPI * 8) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int t = t0 + u * TPI + lane_t;
+      const bool in = t < n_tiles;
+      t = in ? (t + t_rot) % n_tiles : 0;
+      const size_t at = CONTIG ? ((size_t)blockIdx.x * n_tiles + t) * PIECE + lane_e : ((size_t)t << ts) + (size_t)blockIdx.x * PIECE + lane_e;
+      v[u] = ntload(src + at);
+      if (!in) v[u] = make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u].x * v[u].y;
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+
+// ---- the product's K1 (fm_als_tiled.hip: als_order_sums_k) with knock-out switches: MODE bit 0 = the LDS walk, bit 1 = the pair loads
+namespace fmx { constexpr int WG_THREADS = 256; struct SweepDyn { int f, pad; double alpha, lambda, mu; const double* znorm; };
+__device__ __forceinline__ bool bad_number_t(double x) { return isnan(x) || isinf(x); }
+template <bool NT, typename T> __device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+template <bool NT> __device__ __forceinline__ double2 stream_load(const double2* p) { const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p)); return make_double2(v.x, v.y); }
+template <bool UNIT, int FB, int TB, int CH, int MODE>
+__global__ __launch_bounds__(WG_THREADS) void k1_full_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
+                                                               const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
+                                                               const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                                               double2* __restrict__ vstep) {
+  constexpr int LG = WG_THREADS / FB;          // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
+  constexpr int PER = CH / WG_THREADS;
+  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS, "TB: a power of two, one thread per tile in the prefix step");
+  __shared__ uint32_t o[TB][FB + 1];           // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry)
+  __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
+  __shared__ uint32_t blk[TB];                 // position of each run's first pair inside its tile's level block
+  __shared__ int64_t xbase[UNIT ? 1 : TB];     // first entry of each tile's level block in tval
+  __shared__ double2 lp[CH];
+  __shared__ float lx[UNIT ? 1 : CH];
+  const uint32_t f0 = blockIdx.x * FB;
+  const int g = threadIdx.x / LG, lane = threadIdx.x % LG;
+  const uint32_t fi = f0 + g;
+  const bool live = fi < cnt;
+  const uint32_t feat = feats[live ? fi : cnt - 1];
+  const int f = dyn->f;
+  const double old = P[(size_t)feat * kp + f];
+  double mean = 0.0, var = 0.0;
+  // position v of the virtual sequence -> its tile of the batch (the last tb with vstart[tb] <= v; empty runs are skipped by construction)
+  auto tile_of = [&](uint32_t v) { int tb = 0;
+#pragma unroll
+    for (int st = TB / 2; st > 0; st >>= 1) tb += (vstart[tb + st] <= v) ? st : 0;
+    return tb; };
+  for (int t0 = 0; t0 < n_tiles; t0 += TB) {
+    const int nb = min(TB, n_tiles - t0);
+    __syncthreads();                            // (the walkers of the previous batch are done with o / vstart / lp)
+    {
+      // every thread's offset loads go out together, then land in LDS (a load-store loop would wait for one load per trip: 20 trips of ~2 us each at
+      // 77 tiles x 65 offsets)
+      constexpr int NV = (TB * (FB + 1) + WG_THREADS - 1) / WG_THREADS;
+      uint32_t ov[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int i = threadIdx.x + q * WG_THREADS;
+        const int tb = min(i / (FB + 1), nb - 1), j = i % (FB + 1);
+        ov[q] = stream_load<true>(toff + (size_t)(t0 + tb) * nf1 + lvl0 + min(f0 + j, cnt));
+      }
+      uint32_t bv = 0; int64_t tbv = 0;
+      if ((int)threadIdx.x < nb) { bv = stream_load<true>(toff + (size_t)(t0 + threadIdx.x) * nf1 + lvl0); if (!UNIT) tbv = tile_base[t0 + threadIdx.x]; }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int i = threadIdx.x + q * WG_THREADS;
+        if (i < nb * (FB + 1)) o[i / (FB + 1)][i % (FB + 1)] = ov[q];
+      }
+      if ((int)threadIdx.x < nb) { blk[threadIdx.x] = bv; if (!UNIT) xbase[threadIdx.x] = tbv + (int64_t)bv; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                     // exclusive prefix of the run lengths: one wave, TB / 64 values per lane
+      uint32_t carry = 0;
+      for (int b0 = 0; b0 < TB; b0 += 64) {
+        const int tb = b0 + threadIdx.x;
+        const uint32_t len = (tb < nb) ? o[tb][FB] - o[tb][0] : 0u;
+        uint32_t inc = len;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) { const uint32_t up = __shfl_up(inc, ofs); if ((int)threadIdx.x >= ofs) inc += up; }
+        if (tb < TB) vstart[tb] = carry + inc - len;
+        if (tb < nb) blk[tb] = o[tb][0] - blk[tb];      // the run's first pair inside the tile's level block
+        carry += __shfl(inc, 63);
+      }
+      if (threadIdx.x == 0) vstart[TB] = carry;
+    }
+    __syncthreads();
+    const uint32_t total = vstart[TB];
+    double2 pv[PER]; float xv[PER];
+    auto fetch = [&](uint32_t c0) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t v = min(c0 + threadIdx.x + u * WG_THREADS, total - 1);
+        const int tb = tile_of(v);
+        const uint32_t in_block = blk[tb] + (v - vstart[tb]);
+        pv[u] = (MODE & 2) ? stream_load<true>(src + ((size_t)(t0 + tb) << tshift) + in_block) : make_double2((double)in_block, 1.0);
+        xv[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + in_block);
+      }
+    };
+    if (total > 0) fetch(0);
+    for (uint32_t c0 = 0; c0 < total; c0 += CH) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
+        if (v < total) { lp[v - c0] = pv[u]; if (!UNIT) lx[v - c0] = xv[u]; }
+      }
+      __syncthreads();
+      if (c0 + CH < total) fetch(c0 + CH);      // in flight while the chunk in LDS is walked
+      const uint32_t c1 = min(c0 + CH, total);
+      const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
+      if (MODE & 1) for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
+        const uint32_t a = max(vstart[tb] + o[tb][g] - o[tb][0], c0), b = min(vstart[tb] + o[tb][g + 1] - o[tb][0], c1);
+        for (uint32_t v = a; v < b; ++v) {
+          const double2 c = lp[v - c0];
+          const float x = UNIT ? 1.0f : lx[v - c0];
+          const float xx = x * x;
+          const double h = (double)x * c.x - (double)xx * old;   // :310-317
+          mean += h * c.y; var += h * h;
+        }
+      }
+      __syncthreads();                          // (the walkers are done with lp before the next chunk lands in it)
+    }
+  }
+#pragma unroll
+  for (int ofs = 1; ofs < LG; ofs <<= 1) { mean += __shfl_xor(mean, ofs); var += __shfl_xor(var, ofs); }   // (a + b == b + a: every lane of the group holds the same bits)
+  if (lane != 0 || !live) return;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  mean -= old * var;                               // :318
+  var = 1.0 / (lambda + alpha * var);              // :319
+  mean = -var * (alpha * mean - mu * lambda);      // :320
+  double nv = bad_number_t(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+  if (bad_number_t(nv)) { vstep[fi] = make_double2(old, nan("")); return; }  // CHECK_PARAM (:336): the old value stays; NaN tells the apply pass to leave the rows alone
+  P[(size_t)feat * kp + f] = nv;
+  vstep[fi] = make_double2(old, old - nv);
+}
+
+}  // namespace fmx
+
+
+// ---- K1, lean: NIT tiles per trip, one LDS slot of S pairs per tile (every run of the workgroup's FB features in a tile is at most S pairs: checked by the
+// host), thread e of the workgroup loads pair e of each of the trip's runs (no search, no prefix: the mapping is static), the lanes of a feature's group walk
+// the trip's tiles; run bounds and list bounds come straight from global memory TWO trips ahead, the pairs one trip ahead: no load waits on another.
+namespace fmx {
+template <bool UNIT, int FB, int NIT, int S>
+__global__ __launch_bounds__(WG_THREADS) void k1_lean_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
+                                                        const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
+                                                        const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                                        double2* __restrict__ vstep) {
+  constexpr int LG = WG_THREADS / FB;          // lanes per feature
+  constexpr int TPL = (NIT + LG - 1) / LG;     // tiles per lane and trip
+  static_assert(S <= WG_THREADS, "");
+  __shared__ double2 lp[NIT][S];
+  __shared__ float lx[UNIT ? 1 : NIT * S];
+  const uint32_t f0 = blockIdx.x * FB;
+  const int g = threadIdx.x / LG, lane = threadIdx.x % LG;
+  const uint32_t fi = f0 + g;
+  const bool live = fi < cnt;
+  const uint32_t feat = feats[live ? fi : cnt - 1];
+  const int f = dyn->f;
+  const double old = P[(size_t)feat * kp + f];
+  const uint32_t fa = min(f0 + g, cnt), fb = min(f0 + g + 1, cnt), fend = min(f0 + FB, cnt);
+  double mean = 0.0, var = 0.0;
+  // run bounds of the trip's tiles: lane u of every wave loads tile u's three offsets with VECTOR loads (uniform scalar loads share the LDS counter: the
+  // walk's first LDS read would wait for them) and the values are read out of that lane when the pairs are fetched
+  struct Offs { uint32_t ra, rb, rbase, la[TPL], lb[TPL]; int64_t xb; };
+  const int wl = threadIdx.x & 63;
+  auto offsets = [&](int t0, Offs& o) {
+    {
+      const int t = min(t0 + min(wl, NIT - 1), n_tiles - 1);
+      const uint32_t* off = toff + (size_t)t * nf1 + lvl0;
+      o.ra = stream_load<true>(off + f0); o.rb = stream_load<true>(off + fend); o.rbase = stream_load<true>(off);
+      o.xb = UNIT ? 0 : stream_load<true>(tile_base + t);
+    }
+#pragma unroll
+    for (int q = 0; q < TPL; ++q) {
+      const int u = lane + q * LG;
+      const int t = min(t0 + u, n_tiles - 1);
+      const uint32_t* off = toff + (size_t)t * nf1 + lvl0;
+      const bool in = u < NIT && t0 + u < n_tiles;
+      o.la[q] = stream_load<true>(off + fa); o.lb[q] = in ? stream_load<true>(off + fb) : 0u;
+      if (!in) o.lb[q] = o.la[q];
+    }
+  };
+  double2 pv[NIT]; float xv[NIT];
+  uint32_t rl_cur[NIT];
+  auto fetch = [&](int t0, const Offs& o) {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int t = min(t0 + u, n_tiles - 1);
+      const uint32_t a = __builtin_amdgcn_readlane(o.ra, u), b = __builtin_amdgcn_readlane(o.rb, u), base = __builtin_amdgcn_readlane(o.rbase, u);
+      const uint32_t rl = (t0 + u < n_tiles) ? b - a : 0u;
+      rl_cur[u] = rl;
+      const uint32_t e = min((uint32_t)threadIdx.x, rl > 0 ? rl - 1 : 0u);
+      pv[u] = stream_load<true>(src + ((size_t)t << tshift) + (a - base) + e);
+      if (!UNIT) { const int64_t xb = ((int64_t)__builtin_amdgcn_readlane((int)(o.xb >> 32), u) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)o.xb, u);
+                   xv[u] = stream_load<true>(tval + xb + a + e); } else xv[u] = 1.0f;
+    }
+  };
+  Offs cur, nxt;
+  offsets(0, cur);
+  offsets(NIT, nxt);
+  fetch(0, cur);
+  for (int t0 = 0; t0 < n_tiles; t0 += NIT) {
+    uint32_t wa[TPL], wb[TPL];
+#pragma unroll
+    for (int q = 0; q < TPL; ++q) {   // this lane's lists, relative to their runs (the run start of tile u sits in lane u of cur.ra)
+      const int u = min(lane + q * LG, NIT - 1);
+      const uint32_t a0 = __shfl(cur.ra, u);
+      wa[q] = cur.la[q] - a0; wb[q] = cur.lb[q] - a0;
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u)
+      if (threadIdx.x < rl_cur[u]) { lp[u][threadIdx.x] = pv[u]; if (!UNIT) lx[u * S + threadIdx.x] = xv[u]; }
+    __syncthreads();
+    Offs after;
+    if (t0 + NIT < n_tiles) fetch(t0 + NIT, nxt);          // the next trip's pairs ...
+    if (t0 + 2 * NIT < n_tiles) offsets(t0 + 2 * NIT, after);   // ... and the bounds of the one after it, in flight while this trip's runs are walked
+    else { after.ra = after.rb = after.rbase = 0; after.xb = 0; for (int q = 0; q < TPL; ++q) { after.la[q] = 0; after.lb[q] = 0; } }
+#pragma unroll
+    for (int q = 0; q < TPL; ++q) {
+      const int u = lane + q * LG;
+      if (u < NIT)
+        for (uint32_t v = wa[q]; v < wb[q]; ++v) {
+          const double2 c = lp[u][v];
+          const float x = UNIT ? 1.0f : lx[u * S + v];
+          const float xx = x * x;
+          const double h = (double)x * c.x - (double)xx * old;
+          mean += h * c.y; var += h * h;
+        }
+    }
+    __syncthreads();
+    cur = nxt; nxt = after;
+  }
+#pragma unroll
+  for (int ofs = 1; ofs < LG; ofs <<= 1) { mean += __shfl_xor(mean, ofs); var += __shfl_xor(var, ofs); }
+  if (lane != 0 || !live) return;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  mean -= old * var;
+  var = 1.0 / (lambda + alpha * var);
+  mean = -var * (alpha * mean - mu * lambda);
+  double nv = bad_number_t(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+  if (bad_number_t(nv)) { vstep[fi] = make_double2(old, nan("")); return; }
+  P[(size_t)feat * kp + f] = nv;
+  vstep[fi] = make_double2(old, old - nv);
+}
+}  // namespace fmx
+
 int main(int argc, char** argv) {
   const int ts = argc > 1 ? atoi(argv[1]) : 17;
   const int n_tiles = argc > 2 ? atoi(argv[2]) : 77;
@@ -168,6 +427,32 @@ int main(int argc, char** argv) {
     printf("%-44s %8.1f us   %6.2f TB/s of %.0f MB\n", name, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12, bytes / 1e6);
   };
   timeit("copy 16-B pairs", [&] { hipLaunchKernelGGL(copy_k, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, 0, src, dst, n); }, 32.0 * n);
+#define PIECES(Pv, ROTv, CONTIGv) timeit("pieces of " #Pv " pairs/tile, rot=" #ROTv " contig=" #CONTIGv, [&] { hipLaunchKernelGGL((pieces_k<Pv, ROTv, CONTIGv>), dim3((unsigned)(T / Pv)), dim3(256), 0, 0, src, ts, n_tiles, vf); }, 16.0 * n);
+  PIECES(128, false, false) PIECES(128, true, false) PIECES(128, false, true) PIECES(256, false, false) PIECES(256, true, false) PIECES(256, false, true) PIECES(64, false, false) PIECES(64, true, false)
+  uint32_t* d_feats; int64_t* d_tb; fmx::SweepDyn* d_dyn; double* d_P;
+  { std::vector<uint32_t> hf(cnt); std::iota(hf.begin(), hf.end(), 0u); CK(hipMalloc(&d_feats, cnt * 4)); CK(hipMemcpy(d_feats, hf.data(), cnt * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_tb, (n_tiles + 1) * 8)); CK(hipMemset(d_tb, 0, (n_tiles + 1) * 8)); fmx::SweepDyn hd{0, 0, 1.0, 1.0, 0.0, nullptr}; CK(hipMalloc(&d_dyn, sizeof(hd)));
+    CK(hipMemcpy(d_dyn, &hd, sizeof(hd), hipMemcpyHostToDevice)); CK(hipMalloc(&d_P, cnt * 8)); CK(hipMemset(d_P, 0, cnt * 8)); }
+#define K1F(FBv, TBv, CHv, MODEv) timeit("product K1 FB=" #FBv " TB=" #TBv " CH=" #CHv " mode=" #MODEv, [&] { hipLaunchKernelGGL((fmx::k1_full_k<true, FBv, TBv, CHv, MODEv>), dim3((cnt + FBv - 1) / FBv), dim3(256), 0, 0, \
+    d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
+  K1F(32, 128, 2048, 3) K1F(32, 128, 2048, 2) K1F(32, 128, 2048, 1) K1F(32, 128, 2048, 0) K1F(16, 128, 1024, 3) K1F(16, 128, 1024, 2) K1F(16, 128, 1024, 0)
+  {  // the lean K1 against the generic one: same vstep?
+    double2* vs2; CK(hipMalloc(&vs2, cnt * 16)); CK(hipMemset(vs2, 0, cnt * 16)); CK(hipMemset(vstep, 0, cnt * 16));
+    uint32_t maxrun = 0; for (int t = 0; t < n_tiles; ++t) for (uint32_t b0 = 0; b0 < cnt; b0 += 32) { const uint32_t* off = toff.data() + (size_t)t * (cnt + 1); maxrun = std::max(maxrun, off[std::min(b0 + 32, cnt)] - off[b0]); }
+    printf("longest run of 32 features in a tile: %u pairs\n", maxrun);
+    CK(hipMemset(d_P, 0, cnt * 8));
+    hipLaunchKernelGGL((fmx::k1_full_k<true, 32, 128, 2048, 3>), dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep);
+    CK(hipMemset(d_P, 0, cnt * 8));
+    hipLaunchKernelGGL((fmx::k1_lean_k<true, 32, 8, 256>), dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vs2);
+    CK(hipDeviceSynchronize());
+    std::vector<double2> a(cnt), b(cnt); CK(hipMemcpy(a.data(), vstep, cnt * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), vs2, cnt * 16, hipMemcpyDeviceToHost));
+    double worst = 0.0; for (uint32_t i = 0; i < cnt; ++i) worst = std::max(worst, std::abs(a[i].y - b[i].y) / std::max(1e-300, std::abs(a[i].y)));
+    printf("lean vs generic K1: largest relative difference of a step %.3e\n", worst);
+    CK(hipMemset(d_P, 0, cnt * 8));
+  }
+#define K1L(FBv, NITv, Sv) timeit("lean K1 FB=" #FBv " NIT=" #NITv " S=" #Sv, [&] { hipLaunchKernelGGL((fmx::k1_lean_k<true, FBv, NITv, Sv>), dim3((cnt + FBv - 1) / FBv), dim3(256), 0, 0, \
+    d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
+  K1L(32, 8, 256) K1L(32, 8, 192) K1L(32, 12, 192) K1L(32, 16, 192) K1L(16, 16, 128) K1L(16, 8, 128) K1L(64, 8, 256) K1L(64, 4, 256)
   timeit("K1 sums+step LG=1 (256 features / WG)", [&] { hipLaunchKernelGGL(sums_step_k<1>, dim3((cnt + 255) / 256), dim3(256), 0, 0, d_toff, nf1, cnt, src, ts, n_tiles, vf, vstep); }, 16.0 * n);
   timeit("K1 sums+step LG=4 (64 features / WG)", [&] { hipLaunchKernelGGL(sums_step_k<4>, dim3((cnt + 63) / 64), dim3(256), 0, 0, d_toff, nf1, cnt, src, ts, n_tiles, vf, vstep); }, 16.0 * n);
   timeit("K1 sums+step LG=8 (32 features / WG)", [&] { hipLaunchKernelGGL(sums_step_k<8>, dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, cnt, src, ts, n_tiles, vf, vstep); }, 16.0 * n);
