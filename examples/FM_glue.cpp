@@ -71,6 +71,10 @@ static fmx_matrix* matrix_from_fm_matrix(List X, SEXP labels) {   // src/FM.cpp:
     // a dgCMatrix's own slots (x, i, p: R/fm_matrix.R keeping them instead of calling Matrix::t): col_idx then holds ROW indices and the
     // rows are made on the device
     IntegerVector col_ptr = X["col_ptr"];
+    // the library reads p[0 .. ncol] and i / x [0 .. nnz) on the host before it can validate anything: the lengths are checked here
+    if (col_ptr.size() != dim[1] + 1) stop("col_ptr must hold ncol + 1 column pointers");
+    if (col_idx.size() != value.size()) stop("the lengths of col_idx and value differ");
+    if (y && Rf_xlength(labels) != dim[0]) stop("target's length is not equal the number of cases...");
     fmx_check(fmx_matrix_from_dgc(0, dim[0], (uint32_t)dim[1], value.size(), value.begin(), col_idx.begin(), col_ptr.begin(), y, &m));
     return m;
   }

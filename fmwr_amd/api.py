@@ -138,6 +138,8 @@ def fm_matrix(data, labels=None, feature_names=None):
             feature_names = [f"V{j + 1}" for j in range(p)]
         elif len(feature_names) != p:
             raise ValueError("ncol(data) == length(feature_names) is not TRUE")
+        if data.nnz > np.iinfo(np.int32).max or n > np.iinfo(np.int32).max:
+            raise ValueError("a dgCMatrix's slots are 32-bit: more stored entries or rows than 2^31 - 1 (pass the rows as CSR instead)")   # (astype would wrap silently)
         features = {"value": data.data.astype(np.float64), "col_idx": data.indices.astype(np.int32), "col_ptr": data.indptr.astype(np.int32),
                     "dim": (n, p), "size": int(data.nnz)}
         return FmMatrix(features, labels, list(feature_names))
@@ -150,6 +152,8 @@ def fm_matrix(data, labels=None, feature_names=None):
         feature_names = [f"V{j + 1}" for j in range(p)]  # numpy has no colnames; R would stop("there's no feature_names")
     elif len(feature_names) != p:
         raise ValueError("ncol(data) == length(feature_names) is not TRUE")
+    if p > np.iinfo(np.int32).max:
+        raise ValueError("fm.matrix keeps col_idx as 32-bit integers: more columns than 2^31 - 1")   # (astype would wrap silently)
     features = {"value": X.data.astype(np.float64), "col_idx": X.indices.astype(np.int32),
                 "row_size": np.diff(X.indptr).astype(np.int32), "dim": (n, p), "size": int(X.nnz)}
     return FmMatrix(features, labels, list(feature_names))

@@ -133,7 +133,8 @@ struct AlsTiled;
 static int order_build(fmx_matrix* m, AlsTiled* T, hipStream_t stream);
 
 // Which levels of the exact plan go through the tiled form, and their plan.  Called at the end of build_plan (the CSC and the levels exist).
-// A failure to allocate leaves the matrix without a tiled plan (the column-walking kernels do every level then): never an error.
+// A failure to allocate -- here, or of the sweep's workspace later (als_tiled_level drops the plan then) -- leaves the matrix without a tiled plan (the
+// column-walking kernels do every level): never an error.
 int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   als_tiled_free(m);
   if (m->als_approx || m->n == 0 || m->nnz == 0) return FMX_OK;
@@ -496,7 +497,12 @@ int als_tiled_level(fmx_engine* e, fmx_matrix* m, int level, bool last, double2*
   const uint32_t lvl0 = T->lvl0[(size_t)s], cnt = T->cnt[(size_t)s];
   double2 *partial = nullptr, *vstep = nullptr;
   double* vf2 = nullptr;
-  FMX_TRY(tile_ws(e, T, &partial, &vf2, &vstep));
+  if (tile_ws(e, T, &partial, &vf2, &vstep) != FMX_OK) {
+    // no room for the per-tile sums: this matrix keeps the column-walking kernels from here on (one failed allocation, not one per level of every factor)
+    (void)hipGetLastError();
+    als_tiled_free(m);
+    return FMX_OK;   // *done == false: the caller runs als_level_k on this level
+  }
   double* P = W ? e->dw : e->dV;
   const size_t nf1 = (size_t)T->n_feats + 1;
   const dim3 blk(WG_THREADS);

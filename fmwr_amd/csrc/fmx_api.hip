@@ -1024,6 +1024,8 @@ int fmx_matrix_from_dgc(int device, int64_t nrow, uint32_t ncol, int64_t nnz, co
   FMX_TRY(ingest_host_arrays(t, x, true, i, true, col_size.data(), nullptr, nullptr, true, bad, &total));
   FMX_CHECK(bad[0] == ~0ull, FMX_ERR_INVALID, "row index %d out of range at entry %llu (%lld rows)", i[bad[0]], (unsigned long long)bad[0], (long long)nrow);
   FMX_TRY(build_full_csc(t, nullptr));
+  // the transpose's row-major arrays are done with: give them back before the result is allocated (otherwise three copies of the matrix are resident at once)
+  (void)hipFree(t->col); (void)hipFree(t->val); t->col = nullptr; t->val = nullptr;
   fmx_matrix* m = nullptr;
   FMX_TRY(alloc_matrix(device, nrow, ncol, nnz, labels != nullptr, &m));
   std::unique_ptr<fmx_matrix, void (*)(fmx_matrix*)> mg(m, free_matrix);

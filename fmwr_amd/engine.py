@@ -73,7 +73,11 @@ class Matrix:
         p = np.ascontiguousarray(p, np.int32)
         if len(p) != ncol + 1:
             raise ValueError("p must hold ncol + 1 column pointers")
+        if len(i) != len(x):
+            raise ValueError("the lengths of i and x differ")
         labels = None if labels is None else np.ascontiguousarray(labels, np.float64)
+        if labels is not None and len(labels) != nrow:
+            raise ValueError("target's length is not equal the number of cases...")
         h = C.c_void_p()
         L.check(L.lib().fmx_matrix_from_dgc(C.c_int(device), C.c_int64(nrow), C.c_uint32(ncol), C.c_int64(len(x)), _p(x), _p(i), _p(p), _p(labels), C.byref(h)))
         return cls._wrap(h)

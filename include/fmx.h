@@ -94,8 +94,17 @@ typedef struct fmx_config {
                               tables cache resident for large batches.  Same result up to the rounding of the
                               partial sums to the state type between tiles (fp32 unless state_fp64).           */
   int32_t state_fp64;      /* mini-batch mode: 0 = fp32 parameter/optimizer tables (default, half the HBM traffic),
-                              1 = the fp64 tables of the sequential mode (the reference's precision; per-row sums and
-                              the exchange buffer become fp64 too)                                               */
+                              1 = the fp64 tables of the sequential mode (the reference's precision, core/Model.h:26-42;
+                              per-row sums and the exchange buffer become fp64 too).
+                              WHICH MODES GUARANTEE north_star's "1e-5 relative on V" against the CPU restatement of the same
+                              algorithm: FMX_MODE_SEQUENTIAL (measured <= 1e-11, prediction signs exact) and FMX_MODE_MINIBATCH with
+                              state_fp64 = 1 (<= 6e-7 on every case tried, 1 650 fuzz seeds incl. diverging runs).  With fp32 state
+                              the bar holds on runs that do not amplify rounding -- all targeted tests and 1 641 of the 1 650 seeds --
+                              and NOT in general: on nine seeds the dynamics amplify the fp32 storage rounding beyond 1e-4, two of
+                              them short and tame (41 steps, |V| <= 286: w off by 1.8e-4; 10 steps, |V| <= 8.9: V off by 2.9e-4;
+                              profiles/r04_fuzz_more.txt; kept as fp64-state regression cases in tests/test_gpu_fuzz.py).  bench.py's
+                              headline is the fp32 mode (BASELINE.json configs[1] asks for fp32); the fp64-state figure and its
+                              roofline are printed beside it (other_configs."configs[1]_fp64_state").                          */
   int32_t exchange_chunks; /* 0/1: the exchange buffer is one block.  n > 1: it is laid out in n blocks of consecutive
                               features so that a multi-GPU driver can pipeline the exchange (fmx_grad_begin/_chunk/
                               _apply_chunk): the all-reduce of one block overlaps the gradient sums of the next.   */
@@ -471,8 +480,10 @@ int fmx_rows_tune_info(fmx_engine* e, int32_t* serial, double* ms_serial, double
 /* Which form of phase 1 large steps (and large forward passes) take on this matrix: 0 one lane group per row (the product form), 1 the flat form
  * (FMX_ROWS_FLAT=1 on rows of differing lengths: the entries of a block of rows as one stream cut evenly over the lane groups, a row's pieces combined in
  * entry order; replaces the per-row loop of core/Model.h:83-97), 2 lane groups pulling rows (FMX_ROWS_PULL=1).  Forms 1 and 2 are measurement records
- * (both slower, profiles/r04_ragged_forms.txt); form 1 associates a row's sums differently from forms 0 and 2 (same parity bars, other last bits) and
- * under it a row's bits still depend on the matrix alone. */
+ * (both slower, profiles/r04_ragged_forms.txt); form 1 associates a row's sums differently from forms 0 and 2 (same parity bars, other last bits).  Under it a
+ * row's bits depend on the matrix it is launched on: the shards of a cfg.n_gpus handle are re-based copies whose blocks of rows are cut elsewhere, so an N-GPU run
+ * and a one-GPU run of the same data differ in last bits under FMX_ROWS_FLAT=1 (they are bitwise equal under the product form), and the switch is read at every
+ * launch -- set it before the first call and leave it. */
 int fmx_matrix_rows_form(const fmx_matrix* m, int32_t* form);
 /* How the engine laid out its parameter tables: elements between consecutive features' V rows, and whether a feature's linear weight
  * sits inside its V row (fp32 mini-batch tables of at most 16 padded factors, from 3 M features up: out of the caches a nonzero then

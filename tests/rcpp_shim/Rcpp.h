@@ -15,6 +15,7 @@ typedef SEXPREC* SEXP;
 extern SEXP R_NilValue;
 bool Rf_isNull(SEXP);
 double* REAL(SEXP);
+long Rf_xlength(SEXP);   // (R_xlen_t in R)
 double Rf_rnorm(double mean, double sd);
 double Rf_rgamma(double shape, double scale);
 double norm_rand(void);
