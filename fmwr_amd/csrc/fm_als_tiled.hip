@@ -600,25 +600,29 @@ template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, bool, double2
 // The last level's apply of a factor writes into level 0's order and stores the NEXT factor's q (gathered by row from the factor-major table); entry and exit
 // of the sweep convert between row order and level 0's order.  Measured before building: profiles/r05_level_order_probe.txt.
 // TB tiles' offsets are taken in at once (all of configs[4]'s 77): their runs of pairs, laid end to end, are one virtual sequence that the workgroup
-// streams in chunks of CH entries -- the next chunk's loads are in flight (registers) while the lane groups walk the current one in LDS.
-template <bool UNIT, int FB, int TB, int CH>
-__global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
+// streams in chunks of CH entries.  What bounds such a kernel is BYTES IN FLIGHT: a load comes back after ~5 us under load, so 6 TB/s want ~30 MB outstanding
+// chip-wide (profiles/r05_level_order_probe*.txt: the bare access pattern streams at 6.3 TB/s with 33 MB in flight; a version with one chunk in flight per
+// workgroup sat at 3 TB/s whatever its tiling).  The loads therefore run DEPTH chunks ahead in registers -- the LDS only ever holds the chunk being walked --
+// and the grid is sized to ONE round of resident workgroups: `fb` features per workgroup (at most FBMAX), chosen by the host from the level's feature count.
+template <bool UNIT, int FBMAX, int TB, int CH, int DEPTH>
+__global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
                                                                const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
                                                                const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
                                                                double2* __restrict__ vstep) {
-  constexpr int LG = WG_THREADS / FB;          // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
+  constexpr int LG = WG_THREADS / FBMAX;       // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
   constexpr int PER = CH / WG_THREADS;
-  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS, "TB: a power of two, one thread per tile in the prefix step");
-  __shared__ uint32_t o[TB][FB + 1];           // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry)
+  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS && FBMAX == 64, "TB: a power of two, one thread per tile in the prefix step; one row of offsets per wave instruction");
+  __shared__ uint32_t o[TB][FBMAX];            // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry); fb <= FBMAX - 1
   __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
   __shared__ uint32_t blk[TB];                 // position of each run's first pair inside its tile's level block
   __shared__ int64_t xbase[UNIT ? 1 : TB];     // first entry of each tile's level block in tval
   __shared__ double2 lp[CH];
   __shared__ float lx[UNIT ? 1 : CH];
-  const uint32_t f0 = blockIdx.x * FB;
+  const uint32_t f0 = blockIdx.x * (uint32_t)fb;
   const int g = threadIdx.x / LG, lane = threadIdx.x % LG;
   const uint32_t fi = f0 + g;
-  const bool live = fi < cnt;
+  const bool live = g < fb && fi < cnt;
+  const int gc = min(g, fb - 1);               // (lane groups beyond fb walk empty lists)
   const uint32_t feat = feats[live ? fi : cnt - 1];
   const int f = dyn->f;
   const double old = P[(size_t)feat * kp + f];
@@ -632,22 +636,23 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
     const int nb = min(TB, n_tiles - t0);
     __syncthreads();                            // (the walkers of the previous batch are done with o / vstart / lp)
     {
-      // every thread's offset loads go out together, then land in LDS (a load-store loop would wait for one load per trip: 20 trips of ~2 us each at
-      // 77 tiles x 65 offsets)
-      constexpr int NV = (TB * (FB + 1) + WG_THREADS - 1) / WG_THREADS;
-      uint32_t ov[NV];
+      // every thread's offset loads go out together, then land in LDS (a load-store loop would wait for one load per trip): wave w takes the tiles
+      // w, w + 4, ... of the batch, lane j the offset of feature f0 + j (fb <= 63: one row of offsets is one wave instruction)
+      constexpr int TPW = TB / (WG_THREADS / 64);
+      const int wv = threadIdx.x >> 6, j = threadIdx.x & 63;
+      const uint32_t fj = min(f0 + (uint32_t)min(j, fb), cnt);
+      uint32_t ov[TPW];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const int i = threadIdx.x + q * WG_THREADS;
-        const int tb = min(i / (FB + 1), nb - 1), j = i % (FB + 1);
-        ov[q] = stream_load<true>(toff + (size_t)(t0 + tb) * nf1 + lvl0 + min(f0 + j, cnt));
+      for (int q = 0; q < TPW; ++q) {
+        const int tb = min(wv + q * (WG_THREADS / 64), nb - 1);
+        ov[q] = stream_load<true>(toff + (size_t)(t0 + tb) * nf1 + lvl0 + fj);
       }
       uint32_t bv = 0; int64_t tbv = 0;
       if ((int)threadIdx.x < nb) { bv = stream_load<true>(toff + (size_t)(t0 + threadIdx.x) * nf1 + lvl0); if (!UNIT) tbv = tile_base[t0 + threadIdx.x]; }
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const int i = threadIdx.x + q * WG_THREADS;
-        if (i < nb * (FB + 1)) o[i / (FB + 1)][i % (FB + 1)] = ov[q];
+      for (int q = 0; q < TPW; ++q) {
+        const int tb = wv + q * (WG_THREADS / 64);
+        if (tb < nb) o[tb][j] = ov[q];
       }
       if ((int)threadIdx.x < nb) { blk[threadIdx.x] = bv; if (!UNIT) xbase[threadIdx.x] = tbv + (int64_t)bv; }
     }
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
       uint32_t carry = 0;
       for (int b0 = 0; b0 < TB; b0 += 64) {
         const int tb = b0 + threadIdx.x;
-        const uint32_t len = (tb < nb) ? o[tb][FB] - o[tb][0] : 0u;
+        const uint32_t len = (tb < nb) ? o[tb][fb] - o[tb][0] : 0u;
         uint32_t inc = len;
 #pragma unroll
         for (int ofs = 1; ofs < 64; ofs <<= 1) { const uint32_t up = __shfl_up(inc, ofs); if ((int)threadIdx.x >= ofs) inc += up; }
@@ -668,39 +673,57 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
     }
     __syncthreads();
     const uint32_t total = vstart[TB];
-    double2 pv[PER]; float xv[PER];
-    auto fetch = [&](uint32_t c0) {
+    double2 pv[DEPTH][PER]; float xv[DEPTH][PER];
+    auto fetch = [&](double2 (&pb)[PER], float (&xb)[PER], uint32_t c0) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const uint32_t v = min(c0 + threadIdx.x + u * WG_THREADS, total - 1);
         const int tb = tile_of(v);
         const uint32_t in_block = blk[tb] + (v - vstart[tb]);
-        pv[u] = stream_load<true>(src + ((size_t)(t0 + tb) << tshift) + in_block);
-        xv[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + in_block);
+        pb[u] = stream_load<true>(src + ((size_t)(t0 + tb) << tshift) + in_block);
+        xb[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + in_block);
       }
     };
-    if (total > 0) fetch(0);
-    for (uint32_t c0 = 0; c0 < total; c0 += CH) {
+    // Every fetch is UNCONDITIONAL (positions past the end are clamped onto the last pair: one request per instruction): the number of loads outstanding at
+    // every wait is then a compile-time constant and the compiler emits counted waits -- with a fetch under a condition it waited for ALL loads before every
+    // LDS store (s_waitcnt vmcnt(0): the ISA of the first version), which is a prefetch depth of one whatever DEPTH says.
+    if (total > 0) {
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
-        if (v < total) { lp[v - c0] = pv[u]; if (!UNIT) lx[v - c0] = xv[u]; }
-      }
-      __syncthreads();
-      if (c0 + CH < total) fetch(c0 + CH);      // in flight while the chunk in LDS is walked
-      const uint32_t c1 = min(c0 + CH, total);
-      const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
-      for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
-        const uint32_t a = max(vstart[tb] + o[tb][g] - o[tb][0], c0), b = min(vstart[tb] + o[tb][g + 1] - o[tb][0], c1);
-        for (uint32_t v = a; v < b; ++v) {
-          const double2 c = lp[v - c0];
-          const float x = UNIT ? 1.0f : lx[v - c0];
-          const float xx = x * x;
-          const double h = (double)x * c.x - (double)xx * old;   // :310-317
-          mean += h * c.y; var += h * h;
+      for (int d = 0; d < DEPTH; ++d) fetch(pv[d], xv[d], (uint32_t)d * CH);
+      for (uint32_t cbase = 0; cbase < total; cbase += DEPTH * CH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+          const uint32_t c0 = cbase + (uint32_t)d * CH;   // (may lie past the end in the last round: nothing is stored or walked then)
+#pragma unroll
+          for (int u = 0; u < PER; ++u) {
+            const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
+            if (v < total) { lp[v - c0] = pv[d][u]; if (!UNIT) lx[v - c0] = xv[d][u]; }
+          }
+          __syncthreads();
+          fetch(pv[d], xv[d], c0 + DEPTH * CH);   // refill the registers just emptied: DEPTH chunks ahead
+          if (c0 < total) {
+            const uint32_t c1 = min(c0 + CH, total);
+            const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
+            for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
+              const uint32_t a = max(vstart[tb] + o[tb][gc] - o[tb][0], c0), b = min(vstart[tb] + o[tb][gc + 1] - o[tb][0], c1);
+              // four entries' LDS reads go out together (clamped onto the list's last entry, added under a test): a loop that reads one entry per trip
+              // pays the LDS latency per entry, and the longest list of the wave's 64 sets the trip count (ISA + timing: 2/3 of the kernel's time)
+              for (uint32_t v = a; v < b; v += 4) {
+                double2 c[4]; float x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const uint32_t vi = min(v + i, b - 1) - c0; c[i] = lp[vi]; x[i] = UNIT ? 1.0f : lx[vi]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float xx = x[i] * x[i];
+                  const double h = (double)x[i] * c[i].x - (double)xx * old;   // :310-317
+                  if (live && v + i < b) { mean += h * c[i].y; var += h * h; }
+                }
+              }
+            }
+          }
+          __syncthreads();                      // (the walkers are done with lp before the next chunk lands in it)
         }
       }
-      __syncthreads();                          // (the walkers are done with lp before the next chunk lands in it)
     }
   }
 #pragma unroll
@@ -815,18 +838,29 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
   const double2* src = reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]);
   double2* dst = reinterpret_cast<double2*>(e->als_lo[1 - e->als_lo_cur]);
   const dim3 blk(WG_THREADS);
-  static const int fb = env_int("FMX_ALS_ORDER_FB", 16);   // (16: 52 us, 32: 55 us, 64: 60 us per level at configs[4]; profiles/r05_order_ab*.txt)
+  // features per workgroup: one round of resident workgroups (the kernel's occupancy x the device's CUs), every workgroup the same share of the level.
+  // FMX_ALS_ORDER_FB pins it (tuning); FMX_ALS_ORDER_DEPTH = 1 / 2 / 3 chunks of loads ahead.
+  static const int fb_env = env_int("FMX_ALS_ORDER_FB", 0);
+  static const int depth = env_int("FMX_ALS_ORDER_DEPTH", 1);   // (measured: 1: 55.9, 2: 59.9, 3: 62.8 us per level at configs[4] -- the walk, not the loads, bounds the kernel; profiles/r05_order_ab*.txt)
   static const int rr = env_int("FMX_ALS_ORDER_R", 1);
-#define FMX_OSUMS(UNITv, FBv, TBv, CHv)                                                                                                                       \
-  hipLaunchKernelGGL((als_order_sums_k<UNITv, FBv, TBv, CHv>), dim3((cnt + FBv - 1) / FBv), blk, 0, e->stream, (const uint32_t*)T->toff, nf1, lvl0, cnt, (const int64_t*)T->tile_base, \
-                     (const float*)T->tval, src, T->tshift, T->n_tiles, (const uint32_t*)(T->feats + lvl0), e->dV, e->kp64, dyn, vstep)
-#define FMX_OSUMS_U(FBv, TBv, CHv) do { if (T->unit) FMX_OSUMS(true, FBv, TBv, CHv); else FMX_OSUMS(false, FBv, TBv, CHv); } while (0)
-  switch (fb) {
-    case 16: FMX_OSUMS_U(16, 128, 1024); break;
-    case 17: FMX_OSUMS_U(16, 128, 2048); break;   // (16 features, chunks of 2048: tuning)
-    case 33: FMX_OSUMS_U(32, 128, 1024); break;   // (32 features, chunks of 1024: tuning)
-    case 64: FMX_OSUMS_U(64, 64, 2048); break;
-    default: FMX_OSUMS_U(32, 128, 2048); break;
+  static int n_cus = 0;
+  if (n_cus == 0) { hipDeviceProp_t pr{}; n_cus = (hipGetDeviceProperties(&pr, e->cfg.device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+#define FMX_OSUMS(UNITv, DEPTHv)                                                                                                                            \
+  do {                                                                                                                                                      \
+    auto kern = als_order_sums_k<UNITv, 64, 128, 1024, DEPTHv>;                                                                                               \
+    static int per_cu = 0;                                                                                                                                    \
+    if (per_cu == 0) { int nbk = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, WG_THREADS, 0) == hipSuccess && nbk > 0) ? nbk : 2; }  \
+    const uint32_t slots = (uint32_t)(per_cu * n_cus);                                                                                                        \
+    int fbv = fb_env > 0 ? fb_env : (int)((cnt + slots - 1) / slots);                                                                                         \
+    fbv = fbv < 8 ? 8 : (fbv > 63 ? 63 : fbv);                                                                                                                \
+    hipLaunchKernelGGL(kern, dim3((cnt + fbv - 1) / fbv), blk, 0, e->stream, (const uint32_t*)T->toff, nf1, lvl0, cnt, fbv, (const int64_t*)T->tile_base,    \
+                       (const float*)T->tval, src, T->tshift, T->n_tiles, (const uint32_t*)(T->feats + lvl0), e->dV, e->kp64, dyn, vstep);                   \
+  } while (0)
+#define FMX_OSUMS_U(DEPTHv) do { if (T->unit) FMX_OSUMS(true, DEPTHv); else FMX_OSUMS(false, DEPTHv); } while (0)
+  switch (depth) {
+    case 1: FMX_OSUMS_U(1); break;
+    case 2: FMX_OSUMS_U(2); break;
+    default: FMX_OSUMS_U(3); break;
   }
 #undef FMX_OSUMS_U
 #undef FMX_OSUMS
