@@ -836,8 +836,17 @@ __global__ void fill_ones_k(float* __restrict__ x, int64_t n) {
 
 // Plan one tile: entries [t.base, t.base + t.cnt) of rows [t.r0, t.r0 + t.nrows), CSR arrays given explicitly (a streamed
 // tile has its own).  Enqueues on `stream`, never waits for it; t must come from plan_alloc with room for t.cnt entries.
+// Does a tile of field-structured rows with a dense prefix take the split + per-field sort path of plan_build?  (The streamed generator then writes the split's
+// outputs itself -- generate_fields_split_async -- and plan_build is told so: `presplit`.)
+bool plan_fields_split_applies(const PlanWorkspace& ws, int unit_values, int fixed_row_len, int dense_prefix, const std::vector<uint32_t>* field_base) {
+  const char* split_env = getenv("FMX_FIELDS_SPLIT");
+  const char* fq_env = getenv("FMX_FIELD_SORT");
+  return !(split_env && split_env[0] == '0') && !(fq_env && fq_env[0] == '0') && !unit_values && dense_prefix > 0 && fixed_row_len > dense_prefix && fixed_row_len <= 64 &&
+         field_base && (int)field_base->size() == fixed_row_len - dense_prefix + 1 && ws.fq_counts != nullptr;
+}
+
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
-               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix, const std::vector<uint32_t>* field_base) {
+               uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix, const std::vector<uint32_t>* field_base, bool presplit) {
   const int T = 256;
   const int64_t cnt = t.cnt;
   FMX_CHECK(cnt <= ws.max_cnt && p == ws.p, FMX_ERR_STATE, "plan workspace too small");
@@ -857,8 +866,9 @@ int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int
     if (field_sorted) {   // the fields' id ranges are known: 26 short sorts instead of one long one (field_sort above)
       FieldBases fb{};
       for (int c = 0; c < z - d; ++c) fb.base[c] = (*field_base)[(size_t)c];
-      hipLaunchKernelGGL(fields_split_local_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, val + t.base, t.nrows, z, d, fb,
-                         ws.keys_out, brow + t.base, bval + t.base, keys_in, 0);
+      if (!presplit)   // (a streamed tile's generator has written these arrays already)
+        hipLaunchKernelGGL(fields_split_local_k, dim3((unsigned)((t.nrows + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, col + t.base, val + t.base, t.nrows, z, d, fb,
+                           ws.keys_out, brow + t.base, bval + t.base, keys_in, 0);
       uint32_t* b_keys = reinterpret_cast<uint32_t*>(ws.vals_out);
       FMX_TRY(field_sort(*field_base, (uint32_t)t.nrows, keys_in, rows_in, b_keys, b_keys + n_cat, ws.keys_out + n_dense, brow + t.base + n_dense, ws.fq_counts,
                          ws.fq_totals, stream));
@@ -1579,6 +1589,69 @@ __global__ void synth_fields_k(int64_t n, FieldSpec fs, uint64_t seed, int64_t r
       val[at] = 1.0f;
     }
   }
+}
+
+// The streamed form: the same rows (the same Philox words), generated FS_ROWS rows at a time into LDS and written out THREE ways from there -- row-major
+// (col, val: what phase 1 reads), and the two outputs of fields_split_local_k (the dense columns' lists; the one-hot part field-major with the field's base taken
+// off: what the per-field sort reads) -- instead of writing the rows, reading them back and splitting them in a second kernel (82 MB written, 82 MB read and a
+// launch per 262 144-row step: 197 us of the ingest stream's 680, profiles/r05_kernel_stats_stream.csv).
+__global__ __launch_bounds__(256) void synth_fields_split_k(int64_t n, FieldSpec fs, uint64_t seed, int64_t row_offset, uint32_t* __restrict__ col, float* __restrict__ val,
+                                                            uint32_t* __restrict__ keys_sorted, uint32_t* __restrict__ brow, float* __restrict__ bval,
+                                                            uint32_t* __restrict__ keys_in) {
+  __shared__ uint32_t s_col[FS_ROWS * 64];
+  __shared__ float s_val[FS_ROWS * 64];
+  const int z = fs.n_dense + fs.n_fields, d = fs.n_dense;
+  const int gq = (z + 3) / 4;
+  const int64_t R0 = (int64_t)blockIdx.x * FS_ROWS;
+  const int rows = (int)(n - R0 < FS_ROWS ? n - R0 : FS_ROWS);
+  for (int it = threadIdx.x; it < rows * gq; it += 256) {   // one Philox block = entries 4 q .. 4 q + 3 of a row (as synth_fields_k)
+    const int r = it / gq;
+    const uint32_t q = (uint32_t)(it - r * gq);
+    const uint64_t g = (uint64_t)(row_offset + R0 + r);
+    const Philox ph = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), q, 0xF1E1D5u, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = 4 * (int)q + u;
+      if (i >= z) break;
+      const double uu = (double)ph.c[u] / 4294967296.0;
+      if (i < d) { s_col[r * z + i] = (uint32_t)i; s_val[r * z + i] = (float)uu; }
+      else {
+        const int f = i - d;
+        const double x = fs.skew == 1.0 ? uu : fs.skew == 2.0 ? uu * uu : fs.skew == 3.0 ? uu * uu * uu : pow(uu, fs.skew);
+        uint32_t id = (uint32_t)(x * (double)fs.vocab[f]);
+        if (id >= fs.vocab[f]) id = fs.vocab[f] - 1;
+        s_col[r * z + i] = fs.base[f] + id;
+        s_val[r * z + i] = 1.0f;
+      }
+    }
+  }
+  __syncthreads();
+  const int cnt = rows * z;
+  for (int i = threadIdx.x; i < cnt; i += 256) { col[R0 * z + i] = s_col[i]; val[R0 * z + i] = s_val[i]; }
+  for (int i = threadIdx.x; i < d * rows; i += 256) {   // the dense columns' lists (fields_split_local_k)
+    const int c = i / rows, r = i - c * rows;
+    const int64_t at = (int64_t)c * n + R0 + r;
+    keys_sorted[at] = s_col[r * z + c];
+    brow[at] = (uint32_t)(R0 + r);
+    bval[at] = s_val[r * z + c];
+  }
+  const int zc = z - d;
+  for (int i = threadIdx.x; i < zc * rows; i += 256) {   // the one-hot part, field-major, local ids
+    const int c = i / rows, r = i - c * rows;
+    const int64_t at = (int64_t)c * n + R0 + r;
+    keys_in[at] = s_col[r * z + d + c] - fs.base[c];
+    bval[(int64_t)d * n + at] = 1.0f;
+  }
+}
+
+int generate_fields_split_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream, uint32_t* keys_sorted, uint32_t* brow,
+                                float* bval, uint32_t* keys_in) {
+  const int z = fs.n_dense + fs.n_fields;
+  if (n > 0) hipLaunchKernelGGL(synth_fields_split_k, dim3((unsigned)((n + FS_ROWS - 1) / FS_ROWS)), dim3(256), 0, stream, n, fs, seed, row_offset, m->col, m->val, keys_sorted, brow, bval,
+                                keys_in);
+  hipLaunchKernelGGL(synth_rows_k, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, n, z, seed, row_offset, m->row_ptr, m->y);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
 }
 
 int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream) {

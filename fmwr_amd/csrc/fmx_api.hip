@@ -1331,12 +1331,18 @@ static int stream_ingest(fmx_source* S, int64_t t) {
   const int64_t rows = (t + 1) * S->B <= S->total_rows ? S->B : S->total_rows - t * S->B;
   if (s.used) FMX_HIP(hipStreamWaitEvent(S->ingest, s.trained, 0));  // the slot's previous step must have finished with its arrays
   m->n = rows; m->nnz = rows * S->z;
-  if (S->has_spec) FMX_TRY(generate_fields_async(m, rows, S->fs, S->seed, S->row_offset + t * S->B, S->ingest));
+  // Criteo-shaped steps: the generator writes the rows AND what the plan builder's split pass would make of them (fm_ingest.hip: synth_fields_split_k);
+  // FMX_STREAM_FUSED=0 keeps the two kernels (A/B runs; the tests compare the forms)
+  const std::vector<uint32_t>* fbase = m->field_base.empty() ? nullptr : &m->field_base;
+  const char* fe = getenv("FMX_STREAM_FUSED");
+  const bool fused = S->has_spec && rows > 0 && !(fe && fe[0] == '0') && plan_fields_split_applies(S->ws, m->unit_values, S->z, m->dense_prefix, fbase) &&
+                     S->fs.n_dense == m->dense_prefix;
+  if (fused) FMX_TRY(generate_fields_split_async(m, rows, S->fs, S->seed, S->row_offset + t * S->B, S->ingest, S->ws.keys_out, m->brow, m->bval, reinterpret_cast<uint32_t*>(S->ws.vals_in)));
+  else if (S->has_spec) FMX_TRY(generate_fields_async(m, rows, S->fs, S->seed, S->row_offset + t * S->B, S->ingest));
   else FMX_TRY(generate_synthetic_async(m, rows, S->z, S->seed, S->row_offset + t * S->B, S->ingest));
   auto& pl = m->plans[0];
   pl.r0 = 0; pl.nrows = rows; pl.base = 0; pl.cnt = rows * S->z;
-  FMX_TRY(plan_build(pl, S->ws, (uint32_t)S->p, m->row_ptr, m->col, m->val, m->brow, m->bval, S->ingest, m->unit_values, S->z, m->dense_prefix,
-                     m->field_base.empty() ? nullptr : &m->field_base));
+  FMX_TRY(plan_build(pl, S->ws, (uint32_t)S->p, m->row_ptr, m->col, m->val, m->brow, m->bval, S->ingest, m->unit_values, S->z, m->dense_prefix, fbase, fused));
   FMX_HIP(hipMemcpyAsync(s.h_counts, pl.dcounts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->ingest));
   if (S->owners > 1 && pl.feat) {  // the owner-major order of the tile's lists: the count is still on the device, so the whole directory is sorted
     FMX_TRY(plan_owner_build(pl, S->ows, S->owners, pl.own_cap, S->ingest));
@@ -1377,7 +1383,17 @@ int fmx_source_open(fmx_engine* e, const fmx_fields_spec* spec, int32_t nnz_per_
   S->owners = e->owner_parts;
   const int64_t cap_cnt = B * S->z;
   static const bool overlap = [] { const char* v = getenv("FMX_STREAM_OVERLAP"); return !(v && v[0] == '0'); }();
-  if (overlap) { FMX_HIP(hipStreamCreateWithFlags(&S->ingest, hipStreamNonBlocking)); S->own_stream = true; }
+  if (overlap) {
+    // FMX_STREAM_PRIO=1 gives the ingest stream the LOWEST priority the device offers (the ingest of step t + 2 has two steps of slack, the training kernels
+    // none).  MEASURED SLOWER, hence opt-in: the training kernels do get faster (0.62 against 0.67 ms per step) but the ingest then falls behind and the step
+    // waits for it (353 against 385 M examples/s, profiles/r05_stream_prio.txt) -- the ingest stream is itself on the critical path.
+    int least = 0, greatest = 0;
+    const char* pe = getenv("FMX_STREAM_PRIO");
+    if ((pe && pe[0] == '1') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      FMX_HIP(hipStreamCreateWithPriority(&S->ingest, hipStreamNonBlocking, least));
+    else { (void)hipGetLastError(); FMX_HIP(hipStreamCreateWithFlags(&S->ingest, hipStreamNonBlocking)); }
+    S->own_stream = true;
+  }
   else S->ingest = e->stream;
   FMX_TRY(S->ws.reserve(cap_cnt, (uint32_t)S->p, S->ingest));
   const bool dense = cap_cnt >= (int64_t)S->p;

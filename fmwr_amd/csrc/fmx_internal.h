@@ -498,7 +498,8 @@ int plan_alloc(fmx_matrix::TilePlan& t, uint32_t p, int64_t cap_cnt, bool dense)
 void plan_free(fmx_matrix::TilePlan& t);
 int plan_build(fmx_matrix::TilePlan& t, PlanWorkspace& ws, uint32_t p, const int64_t* row_ptr, const uint32_t* col, const float* val,
                uint32_t* brow, float* bval, hipStream_t stream, int unit_values, int fixed_row_len, int dense_prefix = 0,
-               const std::vector<uint32_t>* field_base = nullptr);
+               const std::vector<uint32_t>* field_base = nullptr, bool presplit = false);
+bool plan_fields_split_applies(const PlanWorkspace& ws, int unit_values, int fixed_row_len, int dense_prefix, const std::vector<uint32_t>* field_base);
 void plan_set_counts(fmx_matrix::TilePlan& t, uint32_t p, const uint32_t* h);
 int plan_ensure_dense(fmx_matrix* m, int64_t tile, hipStream_t stream);
 // scratch of the owner partition (a 4-bit radix sort of the directory), grow-only
@@ -536,6 +537,8 @@ struct FieldSpec {  // Criteo-shaped generator (passed to the kernel by value)
   uint32_t base[FMX_MAX_FIELDS], vocab[FMX_MAX_FIELDS];
 };
 int generate_fields_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream);
+int generate_fields_split_async(fmx_matrix* m, int64_t n, const FieldSpec& fs, uint64_t seed, int64_t row_offset, hipStream_t stream, uint32_t* keys_sorted, uint32_t* brow,
+                                float* bval, uint32_t* keys_in);
 int check_rows_sorted(fmx_matrix* m);
 int params_to_device(fmx_engine* e, const double* w, const double* v);
 int params_from_device(fmx_engine* e, double* w, double* v);

@@ -74,15 +74,19 @@ def test_configs3_shape_minibatch_matches_oracle_on_the_touched_features(reduce)
     assert np.array_equal(np.sign(out[np.abs(ref) > 1e-4]), np.sign(ref[np.abs(ref) > 1e-4]))
 
 
-def test_streamed_training_equals_resident_training():
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_streamed_training_equals_resident_training(monkeypatch, fused):
     """fmx_train_stream (rows generated step by step, each step's inverted index built two steps ahead of the step that trains on
     it, nothing kept) against the same rows trained from a resident matrix: bit for bit, for the uniform and for the
-    Criteo-shaped generator, sparse and dense tiles, a ragged last step."""
+    Criteo-shaped generator, sparse and dense tiles, a ragged last step.  fused: a Criteo-shaped step's generator also writes what the
+    plan builder's split pass would make of the rows (synth_fields_split_k; FMX_STREAM_FUSED=0: generate, then split)."""
     from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_STREAM_FUSED", fused)
     vocab = [50_000, 20_000, 3_000, 400, 30, 4]
     cases = [dict(p=200_000, z=12, fields=None, B=3000),          # sparse tiles: 36 000 entries against 200 000 features
              dict(p=4_000, z=12, fields=None, B=3000),            # dense tiles
-             dict(p=3 + sum(vocab), z=9, fields=(3, vocab, 2.5), B=2500)]   # heavy hitters: dense features and the small fields
+             dict(p=3 + sum(vocab), z=9, fields=(3, vocab, 2.5), B=2500),   # heavy hitters: dense features and the small fields
+             dict(p=13 + sum(engine.CRITEO_VOCAB[8:]) + 60_000 + 9_000, z=13 + 20, fields=(13, [60_000, 9_000] + engine.CRITEO_VOCAB[8:], 3.0), B=4099)]   # 13 dense + 20 fields, steps that are no multiple of 64 rows
     for c in cases:
         n = 4 * c["B"] + 777
         kw = dict(num_factor=8, learn_rate=0.05, l2_w1=1e-3, l2_v=1e-3, mode=L.MODE_MINIBATCH, batch_rows=c["B"])
