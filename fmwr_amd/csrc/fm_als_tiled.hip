@@ -604,6 +604,16 @@ template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, bool, double2
 // chip-wide (profiles/r05_level_order_probe*.txt: the bare access pattern streams at 6.3 TB/s with 33 MB in flight; a version with one chunk in flight per
 // workgroup sat at 3 TB/s whatever its tiling).  The loads therefore run DEPTH chunks ahead in registers -- the LDS only ever holds the chunk being walked --
 // and the grid is sized to ONE round of resident workgroups: `fb` features per workgroup (at most FBMAX), chosen by the host from the level's feature count.
+// -DFMX_K1_TIMING (profiles/probes/level_order_probe.hip builds this kernel with it): clock stamps between the phases, summed per phase over wave 0 of every
+// workgroup into fmx_k1_ticks[]; nothing in the product build
+#ifdef FMX_K1_TIMING
+__device__ unsigned long long fmx_k1_ticks[8];
+#define FMX_K1_STAMP(slot) do { const unsigned long long now_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&fmx_k1_ticks[slot], now_ - k1_last_); k1_last_ = now_; } while (0)
+#define FMX_K1_BEGIN unsigned long long k1_last_ = wall_clock64()
+#else
+#define FMX_K1_STAMP(slot) do {} while (0)
+#define FMX_K1_BEGIN do {} while (0)
+#endif
 template <bool UNIT, int FBMAX, int TB, int CH, int DEPTH>
 __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
                                                                const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
@@ -611,13 +621,15 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
                                                                double2* __restrict__ vstep) {
   constexpr int LG = WG_THREADS / FBMAX;       // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
   constexpr int PER = CH / WG_THREADS;
-  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS && FBMAX == 64, "TB: a power of two, one thread per tile in the prefix step; one row of offsets per wave instruction");
+  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS && TB <= 256 && FBMAX == 64, "TB: a power of two, one thread per tile in the prefix step; one row of offsets per wave instruction");
   __shared__ uint32_t o[TB][FBMAX];            // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry); fb <= FBMAX - 1
   __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
   __shared__ uint32_t blk[TB];                 // position of each run's first pair inside its tile's level block
   __shared__ int64_t xbase[UNIT ? 1 : TB];     // first entry of each tile's level block in tval
   __shared__ double2 lp[CH];
   __shared__ float lx[UNIT ? 1 : CH];
+  constexpr uint32_t MAPPED = 1u << 16;        // virtual positions the tile map covers (a batch of regular data: TB x fb x a few entries)
+  __shared__ uint8_t tmap[MAPPED / 64 + 1];    // tile of virtual position 64 k: tile_of() then needs one or two LDS reads instead of log2(TB) dependent ones
   const uint32_t f0 = blockIdx.x * (uint32_t)fb;
   const int g = threadIdx.x / LG, lane = threadIdx.x % LG;
   const uint32_t fi = f0 + g;
@@ -627,10 +639,19 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
   const int f = dyn->f;
   const double old = P[(size_t)feat * kp + f];
   double mean = 0.0, var = 0.0;
-  // position v of the virtual sequence -> its tile of the batch (the last tb with vstart[tb] <= v; empty runs are skipped by construction)
-  auto tile_of = [&](uint32_t v) { int tb = 0;
+  FMX_K1_BEGIN;
+  // position v of the virtual sequence -> its tile of the batch (the last tb with vstart[tb] <= v; empty runs are skipped by construction).  The binary
+  // search is log2(TB) DEPENDENT LDS reads: 16 of the kernel's 56 us when every load and every chunk's walk began with one (knock-outs,
+  // profiles/r05_k1_knockouts.txt).  tile_of() starts from a map of every 64th position instead and steps over at most a few short runs.
+  auto tile_search = [&](uint32_t v) { int tb = 0;
 #pragma unroll
     for (int st = TB / 2; st > 0; st >>= 1) tb += (vstart[tb + st] <= v) ? st : 0;
+    return tb; };
+  bool mapped = false;
+  auto tile_of = [&](uint32_t v) {
+    if (!mapped) return tile_search(v);
+    int tb = tmap[v >> 6];
+    while (vstart[tb + 1] <= v) ++tb;           // (v < total = vstart[TB]: ends at the latest at TB - 1)
     return tb; };
   for (int t0 = 0; t0 < n_tiles; t0 += TB) {
     const int nb = min(TB, n_tiles - t0);
@@ -673,6 +694,12 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
     }
     __syncthreads();
     const uint32_t total = vstart[TB];
+    mapped = total <= MAPPED;                    // (uniform)
+    if (mapped) {
+      for (uint32_t q = threadIdx.x; q * 64 < total; q += WG_THREADS) tmap[q] = (uint8_t)tile_search(q * 64);
+      __syncthreads();
+    }
+    FMX_K1_STAMP(0);                            // offsets + prefix + map
     double2 pv[DEPTH][PER]; float xv[DEPTH][PER];
     auto fetch = [&](double2 (&pb)[PER], float (&xb)[PER], uint32_t c0) {
 #pragma unroll
@@ -690,6 +717,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
     if (total > 0) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) fetch(pv[d], xv[d], (uint32_t)d * CH);
+      FMX_K1_STAMP(1);                          // the first fetches' address work
       for (uint32_t cbase = 0; cbase < total; cbase += DEPTH * CH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -699,29 +727,57 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
             const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
             if (v < total) { lp[v - c0] = pv[d][u]; if (!UNIT) lx[v - c0] = xv[d][u]; }
           }
+          FMX_K1_STAMP(2);                      // wait for the chunk's loads + LDS stores
           __syncthreads();
+          FMX_K1_STAMP(3);                      // barrier
           fetch(pv[d], xv[d], c0 + DEPTH * CH);   // refill the registers just emptied: DEPTH chunks ahead
+          FMX_K1_STAMP(4);                      // the refill's address work (searches) and issue
           if (c0 < total) {
             const uint32_t c1 = min(c0 + CH, total);
             const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
-            for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
-              const uint32_t a = max(vstart[tb] + o[tb][gc] - o[tb][0], c0), b = min(vstart[tb] + o[tb][gc + 1] - o[tb][0], c1);
-              // four entries' LDS reads go out together (clamped onto the list's last entry, added under a test): a loop that reads one entry per trip
-              // pays the LDS latency per entry, and the longest list of the wave's 64 sets the trip count (ISA + timing: 2/3 of the kernel's time)
-              for (uint32_t v = a; v < b; v += 4) {
-                double2 c[4]; float x[4];
+            // The walk is a chain of LDS latencies (list bounds, then entries): 25 of the kernel's 56 us when every lane took one list at a time
+            // (knock-outs, profiles/r05_k1_knockouts.txt).  A lane therefore takes TWO of its lists per trip -- their bounds are read together, then the
+            // first four entries of both (clamped, added under a test), then what is left of either.  Any fixed association is as good as any other.
+            auto entry = [&](uint32_t v, bool on) {
+              const double2 c = lp[v - c0];
+              const float x = UNIT ? 1.0f : lx[v - c0];
+              const float xx = x * x;
+              const double h = (double)x * c.x - (double)xx * old;   // :310-317
+              if (live && on) { mean += h * c.y; var += h * h; }
+            };
+            for (int tb = t_lo + lane; tb <= t_hi; tb += 2 * LG) {
+              const int tb2 = tb + LG <= t_hi ? tb + LG : tb;
+              const uint32_t s1 = vstart[tb], oa1 = o[tb][gc], ob1 = o[tb][gc + 1], oz1 = o[tb][0];
+              const uint32_t s2 = vstart[tb2], oa2 = o[tb2][gc], ob2 = o[tb2][gc + 1], oz2 = o[tb2][0];
+              const uint32_t a1 = max(s1 + oa1 - oz1, c0), b1 = min(s1 + ob1 - oz1, c1);
+              uint32_t a2 = max(s2 + oa2 - oz2, c0), b2 = min(s2 + ob2 - oz2, c1);
+              if (tb2 == tb) { a2 = 0; b2 = 0; }
+              double2 e1[4], e2[4]; float x1[4], x2[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const uint32_t vi = min(v + i, b - 1) - c0; c[i] = lp[vi]; x[i] = UNIT ? 1.0f : lx[vi]; }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  const float xx = x[i] * x[i];
-                  const double h = (double)x[i] * c[i].x - (double)xx * old;   // :310-317
-                  if (live && v + i < b) { mean += h * c[i].y; var += h * h; }
-                }
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t v1 = min(a1 + i, b1 > a1 ? b1 - 1 : a1) - c0, v2 = (b2 > a2 ? min(a2 + i, b2 - 1) : c0) - c0;
+                e1[i] = lp[v1 < CH ? v1 : 0]; e2[i] = lp[v2 < CH ? v2 : 0];
+                x1[i] = UNIT ? 1.0f : lx[v1 < CH ? v1 : 0]; x2[i] = UNIT ? 1.0f : lx[v2 < CH ? v2 : 0];
               }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float xx = x1[i] * x1[i];
+                const double h = (double)x1[i] * e1[i].x - (double)xx * old;   // :310-317
+                if (live && a1 + i < b1) { mean += h * e1[i].y; var += h * h; }
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float xx = x2[i] * x2[i];
+                const double h = (double)x2[i] * e2[i].x - (double)xx * old;
+                if (live && a2 + i < b2) { mean += h * e2[i].y; var += h * h; }
+              }
+              for (uint32_t v = a1 + 4; v < b1; ++v) entry(v, true);
+              for (uint32_t v = a2 + 4; v < b2; ++v) entry(v, true);
             }
           }
+          FMX_K1_STAMP(5);                      // the walk
           __syncthreads();                      // (the walkers are done with lp before the next chunk lands in it)
+          FMX_K1_STAMP(6);                      // barrier
         }
       }
     }

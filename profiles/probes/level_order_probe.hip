@@ -152,33 +152,44 @@ __global__ __launch_bounds__(256) void pieces_k(const double2* __restrict__ src,
 }
 
 
-// ---- the product's K1 (fm_als_tiled.hip: als_order_sums_k) with knock-out switches: MODE bit 0 = the LDS walk, bit 1 = the pair loads
+// ---- the product's K1 (fm_als_tiled.hip: als_order_sums_k, copied by profiles/probes/sync_k1.py) built with -DFMX_K1_TIMING: clock stamps between its phases
+#define FMX_K1_TIMING 1
 namespace fmx { constexpr int WG_THREADS = 256; struct SweepDyn { int f, pad; double alpha, lambda, mu; const double* znorm; };
 __device__ __forceinline__ bool bad_number_t(double x) { return isnan(x) || isinf(x); }
 template <bool NT, typename T> __device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
 template <bool NT> __device__ __forceinline__ double2 stream_load(const double2* p) { const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p)); return make_double2(v.x, v.y); }
-template <bool UNIT, int FB, int TB, int CH, int MODE>
-__global__ __launch_bounds__(WG_THREADS) void k1_full_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
+#ifdef FMX_K1_TIMING
+__device__ unsigned long long fmx_k1_ticks[8];
+#define FMX_K1_STAMP(slot) do { const unsigned long long now_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&fmx_k1_ticks[slot], now_ - k1_last_); k1_last_ = now_; } while (0)
+#define FMX_K1_BEGIN unsigned long long k1_last_ = wall_clock64()
+#else
+#define FMX_K1_STAMP(slot) do {} while (0)
+#define FMX_K1_BEGIN do {} while (0)
+#endif
+template <bool UNIT, int FBMAX, int TB, int CH, int DEPTH>
+__global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
                                                                const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
                                                                const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
                                                                double2* __restrict__ vstep) {
-  constexpr int LG = WG_THREADS / FB;          // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
+  constexpr int LG = WG_THREADS / FBMAX;       // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
   constexpr int PER = CH / WG_THREADS;
-  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS, "TB: a power of two, one thread per tile in the prefix step");
-  __shared__ uint32_t o[TB][FB + 1];           // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry)
+  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS && FBMAX == 64, "TB: a power of two, one thread per tile in the prefix step; one row of offsets per wave instruction");
+  __shared__ uint32_t o[TB][FBMAX];            // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry); fb <= FBMAX - 1
   __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
   __shared__ uint32_t blk[TB];                 // position of each run's first pair inside its tile's level block
   __shared__ int64_t xbase[UNIT ? 1 : TB];     // first entry of each tile's level block in tval
   __shared__ double2 lp[CH];
   __shared__ float lx[UNIT ? 1 : CH];
-  const uint32_t f0 = blockIdx.x * FB;
+  const uint32_t f0 = blockIdx.x * (uint32_t)fb;
   const int g = threadIdx.x / LG, lane = threadIdx.x % LG;
   const uint32_t fi = f0 + g;
-  const bool live = fi < cnt;
+  const bool live = g < fb && fi < cnt;
+  const int gc = min(g, fb - 1);               // (lane groups beyond fb walk empty lists)
   const uint32_t feat = feats[live ? fi : cnt - 1];
   const int f = dyn->f;
   const double old = P[(size_t)feat * kp + f];
   double mean = 0.0, var = 0.0;
+  FMX_K1_BEGIN;
   // position v of the virtual sequence -> its tile of the batch (the last tb with vstart[tb] <= v; empty runs are skipped by construction)
   auto tile_of = [&](uint32_t v) { int tb = 0;
 #pragma unroll
@@ -188,22 +199,23 @@ __global__ __launch_bounds__(WG_THREADS) void k1_full_k(const uint32_t* __restri
     const int nb = min(TB, n_tiles - t0);
     __syncthreads();                            // (the walkers of the previous batch are done with o / vstart / lp)
     {
-      // every thread's offset loads go out together, then land in LDS (a load-store loop would wait for one load per trip: 20 trips of ~2 us each at
-      // 77 tiles x 65 offsets)
-      constexpr int NV = (TB * (FB + 1) + WG_THREADS - 1) / WG_THREADS;
-      uint32_t ov[NV];
+      // every thread's offset loads go out together, then land in LDS (a load-store loop would wait for one load per trip): wave w takes the tiles
+      // w, w + 4, ... of the batch, lane j the offset of feature f0 + j (fb <= 63: one row of offsets is one wave instruction)
+      constexpr int TPW = TB / (WG_THREADS / 64);
+      const int wv = threadIdx.x >> 6, j = threadIdx.x & 63;
+      const uint32_t fj = min(f0 + (uint32_t)min(j, fb), cnt);
+      uint32_t ov[TPW];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const int i = threadIdx.x + q * WG_THREADS;
-        const int tb = min(i / (FB + 1), nb - 1), j = i % (FB + 1);
-        ov[q] = stream_load<true>(toff + (size_t)(t0 + tb) * nf1 + lvl0 + min(f0 + j, cnt));
+      for (int q = 0; q < TPW; ++q) {
+        const int tb = min(wv + q * (WG_THREADS / 64), nb - 1);
+        ov[q] = stream_load<true>(toff + (size_t)(t0 + tb) * nf1 + lvl0 + fj);
       }
       uint32_t bv = 0; int64_t tbv = 0;
       if ((int)threadIdx.x < nb) { bv = stream_load<true>(toff + (size_t)(t0 + threadIdx.x) * nf1 + lvl0); if (!UNIT) tbv = tile_base[t0 + threadIdx.x]; }
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const int i = threadIdx.x + q * WG_THREADS;
-        if (i < nb * (FB + 1)) o[i / (FB + 1)][i % (FB + 1)] = ov[q];
+      for (int q = 0; q < TPW; ++q) {
+        const int tb = wv + q * (WG_THREADS / 64);
+        if (tb < nb) o[tb][j] = ov[q];
       }
       if ((int)threadIdx.x < nb) { blk[threadIdx.x] = bv; if (!UNIT) xbase[threadIdx.x] = tbv + (int64_t)bv; }
     }
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(WG_THREADS) void k1_full_k(const uint32_t* __restri
       uint32_t carry = 0;
       for (int b0 = 0; b0 < TB; b0 += 64) {
         const int tb = b0 + threadIdx.x;
-        const uint32_t len = (tb < nb) ? o[tb][FB] - o[tb][0] : 0u;
+        const uint32_t len = (tb < nb) ? o[tb][fb] - o[tb][0] : 0u;
         uint32_t inc = len;
 #pragma unroll
         for (int ofs = 1; ofs < 64; ofs <<= 1) { const uint32_t up = __shfl_up(inc, ofs); if ((int)threadIdx.x >= ofs) inc += up; }
@@ -223,40 +235,65 @@ __global__ __launch_bounds__(WG_THREADS) void k1_full_k(const uint32_t* __restri
       if (threadIdx.x == 0) vstart[TB] = carry;
     }
     __syncthreads();
+    FMX_K1_STAMP(0);                            // offsets + prefix
     const uint32_t total = vstart[TB];
-    double2 pv[PER]; float xv[PER];
-    auto fetch = [&](uint32_t c0) {
+    double2 pv[DEPTH][PER]; float xv[DEPTH][PER];
+    auto fetch = [&](double2 (&pb)[PER], float (&xb)[PER], uint32_t c0) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const uint32_t v = min(c0 + threadIdx.x + u * WG_THREADS, total - 1);
         const int tb = tile_of(v);
         const uint32_t in_block = blk[tb] + (v - vstart[tb]);
-        pv[u] = (MODE & 2) ? stream_load<true>(src + ((size_t)(t0 + tb) << tshift) + in_block) : make_double2((double)in_block, 1.0);
-        xv[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + in_block);
+        pb[u] = stream_load<true>(src + ((size_t)(t0 + tb) << tshift) + in_block);
+        xb[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + in_block);
       }
     };
-    if (total > 0) fetch(0);
-    for (uint32_t c0 = 0; c0 < total; c0 += CH) {
+    // Every fetch is UNCONDITIONAL (positions past the end are clamped onto the last pair: one request per instruction): the number of loads outstanding at
+    // every wait is then a compile-time constant and the compiler emits counted waits -- with a fetch under a condition it waited for ALL loads before every
+    // LDS store (s_waitcnt vmcnt(0): the ISA of the first version), which is a prefetch depth of one whatever DEPTH says.
+    if (total > 0) {
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
-        if (v < total) { lp[v - c0] = pv[u]; if (!UNIT) lx[v - c0] = xv[u]; }
-      }
-      __syncthreads();
-      if (c0 + CH < total) fetch(c0 + CH);      // in flight while the chunk in LDS is walked
-      const uint32_t c1 = min(c0 + CH, total);
-      const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
-      if (MODE & 1) for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
-        const uint32_t a = max(vstart[tb] + o[tb][g] - o[tb][0], c0), b = min(vstart[tb] + o[tb][g + 1] - o[tb][0], c1);
-        for (uint32_t v = a; v < b; ++v) {
-          const double2 c = lp[v - c0];
-          const float x = UNIT ? 1.0f : lx[v - c0];
-          const float xx = x * x;
-          const double h = (double)x * c.x - (double)xx * old;   // :310-317
-          mean += h * c.y; var += h * h;
+      for (int d = 0; d < DEPTH; ++d) fetch(pv[d], xv[d], (uint32_t)d * CH);
+      FMX_K1_STAMP(1);                          // the first fetches' address work
+      for (uint32_t cbase = 0; cbase < total; cbase += DEPTH * CH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+          const uint32_t c0 = cbase + (uint32_t)d * CH;   // (may lie past the end in the last round: nothing is stored or walked then)
+#pragma unroll
+          for (int u = 0; u < PER; ++u) {
+            const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
+            if (v < total) { lp[v - c0] = pv[d][u]; if (!UNIT) lx[v - c0] = xv[d][u]; }
+          }
+          FMX_K1_STAMP(2);                      // wait for the chunk's loads + LDS stores
+          __syncthreads();
+          FMX_K1_STAMP(3);                      // barrier
+          fetch(pv[d], xv[d], c0 + DEPTH * CH);   // refill the registers just emptied: DEPTH chunks ahead
+          FMX_K1_STAMP(4);                      // the refill's address work (searches) and issue
+          if (c0 < total) {
+            const uint32_t c1 = min(c0 + CH, total);
+            const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
+            for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
+              const uint32_t a = max(vstart[tb] + o[tb][gc] - o[tb][0], c0), b = min(vstart[tb] + o[tb][gc + 1] - o[tb][0], c1);
+              // four entries' LDS reads go out together (clamped onto the list's last entry, added under a test): a loop that reads one entry per trip
+              // pays the LDS latency per entry, and the longest list of the wave's 64 sets the trip count (ISA + timing: 2/3 of the kernel's time)
+              for (uint32_t v = a; v < b; v += 4) {
+                double2 c[4]; float x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const uint32_t vi = min(v + i, b - 1) - c0; c[i] = lp[vi]; x[i] = UNIT ? 1.0f : lx[vi]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float xx = x[i] * x[i];
+                  const double h = (double)x[i] * c[i].x - (double)xx * old;   // :310-317
+                  if (live && v + i < b) { mean += h * c[i].y; var += h * h; }
+                }
+              }
+            }
+          }
+          FMX_K1_STAMP(5);                      // the walk
+          __syncthreads();                      // (the walkers are done with lp before the next chunk lands in it)
+          FMX_K1_STAMP(6);                      // barrier
         }
       }
-      __syncthreads();                          // (the walkers are done with lp before the next chunk lands in it)
     }
   }
 #pragma unroll
@@ -275,6 +312,158 @@ __global__ __launch_bounds__(WG_THREADS) void k1_full_k(const uint32_t* __restri
 
 }  // namespace fmx
 
+// ---- the product's K1 with knock-out switches (mode bits: 1 the LDS walk, 2 the pair loads, 4 the tile search of every load, 8 the chunk loop at all)
+#undef FMX_K1_TIMING
+#undef FMX_K1_STAMP
+#undef FMX_K1_BEGIN
+#define FMX_K1_STAMP(x) do {} while (0)
+#define FMX_K1_BEGIN do {} while (0)
+namespace fmx {
+template <bool UNIT, int FBMAX, int TB, int CH, int DEPTH>
+__global__ __launch_bounds__(WG_THREADS) void k1_ko_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
+                                                               const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
+                                                               const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                                               double2* __restrict__ vstep, int mode) {
+  constexpr int LG = WG_THREADS / FBMAX;       // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
+  constexpr int PER = CH / WG_THREADS;
+  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS && FBMAX == 64, "TB: a power of two, one thread per tile in the prefix step; one row of offsets per wave instruction");
+  __shared__ uint32_t o[TB][FBMAX];            // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry); fb <= FBMAX - 1
+  __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
+  __shared__ uint32_t blk[TB];                 // position of each run's first pair inside its tile's level block
+  __shared__ int64_t xbase[UNIT ? 1 : TB];     // first entry of each tile's level block in tval
+  __shared__ double2 lp[CH];
+  __shared__ float lx[UNIT ? 1 : CH];
+  const uint32_t f0 = blockIdx.x * (uint32_t)fb;
+  const int g = threadIdx.x / LG, lane = threadIdx.x % LG;
+  const uint32_t fi = f0 + g;
+  const bool live = g < fb && fi < cnt;
+  const int gc = min(g, fb - 1);               // (lane groups beyond fb walk empty lists)
+  const uint32_t feat = feats[live ? fi : cnt - 1];
+  const int f = dyn->f;
+  const double old = P[(size_t)feat * kp + f];
+  double mean = 0.0, var = 0.0;
+  
+  // position v of the virtual sequence -> its tile of the batch (the last tb with vstart[tb] <= v; empty runs are skipped by construction)
+  auto tile_of = [&](uint32_t v) { int tb = 0;
+#pragma unroll
+    for (int st = TB / 2; st > 0; st >>= 1) tb += (vstart[tb + st] <= v) ? st : 0;
+    return tb; };
+  for (int t0 = 0; t0 < n_tiles; t0 += TB) {
+    const int nb = min(TB, n_tiles - t0);
+    __syncthreads();                            // (the walkers of the previous batch are done with o / vstart / lp)
+    {
+      // every thread's offset loads go out together, then land in LDS (a load-store loop would wait for one load per trip): wave w takes the tiles
+      // w, w + 4, ... of the batch, lane j the offset of feature f0 + j (fb <= 63: one row of offsets is one wave instruction)
+      constexpr int TPW = TB / (WG_THREADS / 64);
+      const int wv = threadIdx.x >> 6, j = threadIdx.x & 63;
+      const uint32_t fj = min(f0 + (uint32_t)min(j, fb), cnt);
+      uint32_t ov[TPW];
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int tb = min(wv + q * (WG_THREADS / 64), nb - 1);
+        ov[q] = stream_load<true>(toff + (size_t)(t0 + tb) * nf1 + lvl0 + fj);
+      }
+      uint32_t bv = 0; int64_t tbv = 0;
+      if ((int)threadIdx.x < nb) { bv = stream_load<true>(toff + (size_t)(t0 + threadIdx.x) * nf1 + lvl0); if (!UNIT) tbv = tile_base[t0 + threadIdx.x]; }
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int tb = wv + q * (WG_THREADS / 64);
+        if (tb < nb) o[tb][j] = ov[q];
+      }
+      if ((int)threadIdx.x < nb) { blk[threadIdx.x] = bv; if (!UNIT) xbase[threadIdx.x] = tbv + (int64_t)bv; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                     // exclusive prefix of the run lengths: one wave, TB / 64 values per lane
+      uint32_t carry = 0;
+      for (int b0 = 0; b0 < TB; b0 += 64) {
+        const int tb = b0 + threadIdx.x;
+        const uint32_t len = (tb < nb) ? o[tb][fb] - o[tb][0] : 0u;
+        uint32_t inc = len;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) { const uint32_t up = __shfl_up(inc, ofs); if ((int)threadIdx.x >= ofs) inc += up; }
+        if (tb < TB) vstart[tb] = carry + inc - len;
+        if (tb < nb) blk[tb] = o[tb][0] - blk[tb];      // the run's first pair inside the tile's level block
+        carry += __shfl(inc, 63);
+      }
+      if (threadIdx.x == 0) vstart[TB] = carry;
+    }
+    __syncthreads();
+    
+    const uint32_t total = vstart[TB];
+    double2 pv[DEPTH][PER]; float xv[DEPTH][PER];
+    auto fetch = [&](double2 (&pb)[PER], float (&xb)[PER], uint32_t c0) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t v = min(c0 + threadIdx.x + u * WG_THREADS, total - 1);
+        const int tb = (mode & 4) ? tile_of(v) : (int)(v >> 12);
+        const uint32_t in_block = blk[tb] + (v - vstart[tb]);
+        if (mode & 2) pb[u] = stream_load<true>(src + ((size_t)(t0 + tb) << tshift) + in_block); else pb[u] = make_double2((double)in_block, 1.0);
+        xb[u] = UNIT ? 1.0f : stream_load<true>(tval + xbase[tb] + in_block);
+      }
+    };
+    // Every fetch is UNCONDITIONAL (positions past the end are clamped onto the last pair: one request per instruction): the number of loads outstanding at
+    // every wait is then a compile-time constant and the compiler emits counted waits -- with a fetch under a condition it waited for ALL loads before every
+    // LDS store (s_waitcnt vmcnt(0): the ISA of the first version), which is a prefetch depth of one whatever DEPTH says.
+    if ((mode & 8) && total > 0) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) fetch(pv[d], xv[d], (uint32_t)d * CH);
+      
+      for (uint32_t cbase = 0; cbase < total; cbase += DEPTH * CH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+          const uint32_t c0 = cbase + (uint32_t)d * CH;   // (may lie past the end in the last round: nothing is stored or walked then)
+#pragma unroll
+          for (int u = 0; u < PER; ++u) {
+            const uint32_t v = c0 + threadIdx.x + u * WG_THREADS;
+            if (v < total) { lp[v - c0] = pv[d][u]; if (!UNIT) lx[v - c0] = xv[d][u]; }
+          }
+          
+          __syncthreads();
+          
+          fetch(pv[d], xv[d], c0 + DEPTH * CH);   // refill the registers just emptied: DEPTH chunks ahead
+          
+          if ((mode & 1) && c0 < total) {
+            const uint32_t c1 = min(c0 + CH, total);
+            const int t_lo = tile_of(c0), t_hi = tile_of(c1 - 1);
+            for (int tb = t_lo + lane; tb <= t_hi; tb += LG) {
+              const uint32_t a = max(vstart[tb] + o[tb][gc] - o[tb][0], c0), b = min(vstart[tb] + o[tb][gc + 1] - o[tb][0], c1);
+              // four entries' LDS reads go out together (clamped onto the list's last entry, added under a test): a loop that reads one entry per trip
+              // pays the LDS latency per entry, and the longest list of the wave's 64 sets the trip count (ISA + timing: 2/3 of the kernel's time)
+              for (uint32_t v = a; v < b; v += 4) {
+                double2 c[4]; float x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const uint32_t vi = min(v + i, b - 1) - c0; c[i] = lp[vi]; x[i] = UNIT ? 1.0f : lx[vi]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float xx = x[i] * x[i];
+                  const double h = (double)x[i] * c[i].x - (double)xx * old;   // :310-317
+                  if (live && v + i < b) { mean += h * c[i].y; var += h * h; }
+                }
+              }
+            }
+          }
+          
+          __syncthreads();                      // (the walkers are done with lp before the next chunk lands in it)
+          
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ofs = 1; ofs < LG; ofs <<= 1) { mean += __shfl_xor(mean, ofs); var += __shfl_xor(var, ofs); }   // (a + b == b + a: every lane of the group holds the same bits)
+  if (lane != 0 || !live) return;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  mean -= old * var;                               // :318
+  var = 1.0 / (lambda + alpha * var);              // :319
+  mean = -var * (alpha * mean - mu * lambda);      // :320
+  double nv = bad_number_t(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+  if (bad_number_t(nv)) { vstep[fi] = make_double2(old, nan("")); return; }  // CHECK_PARAM (:336): the old value stays; NaN tells the apply pass to leave the rows alone
+  P[(size_t)feat * kp + f] = nv;
+  vstep[fi] = make_double2(old, old - nv);
+}
+
+}  // namespace fmx
 
 // ---- K1, lean: NIT tiles per trip, one LDS slot of S pairs per tile (every run of the workgroup's FB features in a tile is at most S pairs: checked by the
 // host), thread e of the workgroup loads pair e of each of the trip's runs (no search, no prefix: the mapping is static), the lanes of a feature's group walk
@@ -433,15 +622,27 @@ int main(int argc, char** argv) {
   { std::vector<uint32_t> hf(cnt); std::iota(hf.begin(), hf.end(), 0u); CK(hipMalloc(&d_feats, cnt * 4)); CK(hipMemcpy(d_feats, hf.data(), cnt * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_tb, (n_tiles + 1) * 8)); CK(hipMemset(d_tb, 0, (n_tiles + 1) * 8)); fmx::SweepDyn hd{0, 0, 1.0, 1.0, 0.0, nullptr}; CK(hipMalloc(&d_dyn, sizeof(hd)));
     CK(hipMemcpy(d_dyn, &hd, sizeof(hd), hipMemcpyHostToDevice)); CK(hipMalloc(&d_P, cnt * 8)); CK(hipMemset(d_P, 0, cnt * 8)); }
-#define K1F(FBv, TBv, CHv, MODEv) timeit("product K1 FB=" #FBv " TB=" #TBv " CH=" #CHv " mode=" #MODEv, [&] { hipLaunchKernelGGL((fmx::k1_full_k<true, FBv, TBv, CHv, MODEv>), dim3((cnt + FBv - 1) / FBv), dim3(256), 0, 0, \
-    d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
-  K1F(32, 128, 2048, 3) K1F(32, 128, 2048, 2) K1F(32, 128, 2048, 1) K1F(32, 128, 2048, 0) K1F(16, 128, 1024, 3) K1F(16, 128, 1024, 2) K1F(16, 128, 1024, 0)
+  auto k1_timed = [&](const char* name, auto kern, int fbv) {
+    unsigned long long z8[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(fmx::fmx_k1_ticks), z8, sizeof(z8)));
+    const unsigned grid = (cnt + fbv - 1) / fbv;
+    timeit(name, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, fbv, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
+    unsigned long long t8[8]; CK(hipMemcpyFromSymbol(t8, HIP_SYMBOL(fmx::fmx_k1_ticks), sizeof(t8)));
+    const double per = 1.0 / (23.0 * grid);   // 3 warm-up + 20 timed launches; ticks of the 100 MHz wall clock -> us per workgroup: x 0.01
+    printf("    per workgroup (us): offsets+prefix %.2f | first fetch %.2f | wait+store %.2f | barrier %.2f | refill %.2f | walk %.2f | barrier %.2f\n",
+           t8[0] * per * 0.01, t8[1] * per * 0.01, t8[2] * per * 0.01, t8[3] * per * 0.01, t8[4] * per * 0.01, t8[5] * per * 0.01, t8[6] * per * 0.01);
+  };
+#define K1KO(MODEv) timeit("product K1 (fb 44, depth 1) knock-out mode " #MODEv, [&] { hipLaunchKernelGGL((fmx::k1_ko_k<true, 64, 128, 1024, 1>), dim3((cnt + 43) / 44), dim3(256), 0, 0, \
+    d_toff, nf1, 0u, cnt, 44, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep, MODEv); }, 16.0 * n);
+  K1KO(15) K1KO(14) K1KO(13) K1KO(12) K1KO(10) K1KO(8) K1KO(0)
+  k1_timed("product K1 fb=44 depth 1", fmx::als_order_sums_k<true, 64, 128, 1024, 1>, 44);
+  k1_timed("product K1 fb=44 depth 3", fmx::als_order_sums_k<true, 64, 128, 1024, 3>, 44);
+  k1_timed("product K1 fb=33 depth 1", fmx::als_order_sums_k<true, 64, 128, 1024, 1>, 33);
   {  // the lean K1 against the generic one: same vstep?
     double2* vs2; CK(hipMalloc(&vs2, cnt * 16)); CK(hipMemset(vs2, 0, cnt * 16)); CK(hipMemset(vstep, 0, cnt * 16));
     uint32_t maxrun = 0; for (int t = 0; t < n_tiles; ++t) for (uint32_t b0 = 0; b0 < cnt; b0 += 32) { const uint32_t* off = toff.data() + (size_t)t * (cnt + 1); maxrun = std::max(maxrun, off[std::min(b0 + 32, cnt)] - off[b0]); }
     printf("longest run of 32 features in a tile: %u pairs\n", maxrun);
     CK(hipMemset(d_P, 0, cnt * 8));
-    hipLaunchKernelGGL((fmx::k1_full_k<true, 32, 128, 2048, 3>), dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep);
+    hipLaunchKernelGGL((fmx::als_order_sums_k<true, 64, 128, 1024, 1>), dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, 32, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep);
     CK(hipMemset(d_P, 0, cnt * 8));
     hipLaunchKernelGGL((fmx::k1_lean_k<true, 32, 8, 256>), dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vs2);
     CK(hipDeviceSynchronize());
