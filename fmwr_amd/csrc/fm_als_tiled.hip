@@ -52,6 +52,7 @@ struct AlsTiled {
   // one feature of every level (one-column-per-field data) -- so that position i of tile t's level-s block, entry tile_base[t] + toff[t][lvl0_s] + i of
   // trow / tval, is also a position of the tile's slice of a (q, e) array kept in level s's list order.
   int complete = 0;
+  uint32_t max_list = 0;         // longest (tile, feature) list of the plan (decides whether the sums kernel may keep its offsets in 16 bits)
   uint32_t* perm = nullptr;      // [n_slots][n] position, inside the same tile, that the row at position i of level s's order has in the order of level s + 1 (cyclic)
   void* fidx = nullptr;          // [n_slots][n] index (inside its level) of the feature whose list position i belongs to (u16 / u32 like lfi)
   ~AlsTiled() {
@@ -160,7 +161,11 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   if (mode < 0 && (double)n_slots * (double)m->n > 8.0 * (double)m->nnz + 1e6) return FMX_OK;   // the level-major copies would dwarf the matrix
   std::unique_ptr<AlsTiled> T(new AlsTiled());
   T->n = m->n;
-  int rows_want = env_int("FMX_ALS_TILE_ROWS", 131072);
+  // tile size: 131 072 rows (a 2 MB slice of pairs) for the three-pass form; 65 536 where the plan looks complete (every level tiled, one entry per row and
+  // level) and the V sweep will take the level-order form: its permuting scatter merges better in the L2 on 1 MB slices (apply kernel 92 against 107 us per level
+  // at configs[4], the sums kernel 65 against 57: 116.8 against 112.0 M examples/s, profiles/r05_order_ab11.txt).  FMX_ALS_TILE_ROWS pins it.
+  const bool order_candidate = env_int("FMX_ALS_ORDER", 1) != 0 && n_slots == L && m->nnz == (int64_t)n_slots * m->n;
+  int rows_want = env_int("FMX_ALS_TILE_ROWS", order_candidate ? 65536 : 131072);
   int ts = 4;
   while ((1 << (ts + 1)) <= rows_want && ts < 24) ++ts;
   T->tshift = ts;
@@ -248,6 +253,14 @@ __global__ void order_complete_k(const uint32_t* __restrict__ toff, size_t nf1, 
   const uint32_t* off = toff + (size_t)t * nf1;
   if ((int64_t)off[lvl0[s]] != (int64_t)s * (r1 - r0) || (int64_t)off[lvl0[s] + cnt[s]] != (int64_t)(s + 1) * (r1 - r0)) *bad = 1;
 }
+__global__ void order_max_list_k(const uint32_t* __restrict__ toff, size_t nf1, int n_tiles, uint32_t n_feats, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t len = 0;
+  if (i < (size_t)n_tiles * n_feats) { const size_t t = i / n_feats, f = i % n_feats; len = toff[t * nf1 + f + 1] - toff[t * nf1 + f]; }
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, ofs));
+  if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
+}
 // inv[s][row] = position of the row in its tile's level-s order
 __global__ void order_inverse_k(const uint32_t* __restrict__ trow, const int64_t* __restrict__ tile_base, int64_t n, int tshift, int n_slots, uint32_t* __restrict__ inv) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (slot, position) flattened: slot-major
@@ -297,6 +310,13 @@ static int order_build(fmx_matrix* m, AlsTiled* T, hipStream_t stream) {
   if (!ok(hipMalloc(&w.inv, sn * 4)) || !ok(hipMalloc(&T->perm, sn * 4)) || !ok(hipMalloc(&T->fidx, sn * isz))) {
     (void)hipFree(T->perm); (void)hipFree(T->fidx); T->perm = nullptr; T->fidx = nullptr;
     return FMX_OK;
+  }
+  {
+    uint32_t* d_max = reinterpret_cast<uint32_t*>(w.bad);   // (done with: reused for the maximum)
+    FMX_HIP(hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream));
+    const size_t pairs_tf = (size_t)T->n_tiles * T->n_feats;
+    hipLaunchKernelGGL(order_max_list_k, dim3((unsigned)((pairs_tf + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)T->toff, (size_t)T->n_feats + 1, T->n_tiles, T->n_feats, d_max);
+    FMX_HIP(hipMemcpyAsync(&T->max_list, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   }
   const unsigned grid = (unsigned)((sn + 255) / 256);
   hipLaunchKernelGGL(order_inverse_k, dim3(grid), dim3(256), 0, stream, T->trow, T->tile_base, m->n, T->tshift, T->n_slots, w.inv);
@@ -614,15 +634,18 @@ __device__ unsigned long long fmx_k1_ticks[8];
 #define FMX_K1_STAMP(slot) do {} while (0)
 #define FMX_K1_BEGIN do {} while (0)
 #endif
-template <bool UNIT, int FBMAX, int TB, int CH, int DEPTH>
-__global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
+// OT: the type the list offsets are kept in (relative to their run's first pair): uint16_t where no run of a workgroup's features inside a tile can pass 65 535
+// pairs (the host knows the longest (tile, feature) list), which halves the offsets' share of the LDS: four workgroups per CU instead of three, and TB = 256
+// tiles in one batch where the tiles are 65 536 rows.  MINW: workgroups per CU the register allocation is held to.
+template <bool UNIT, int FBMAX, int TB, int CH, int DEPTH, typename OT, int MINW>
+__global__ __launch_bounds__(WG_THREADS, MINW) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
                                                                const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
                                                                const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
                                                                double2* __restrict__ vstep) {
   constexpr int LG = WG_THREADS / FBMAX;       // lanes per feature: the tiles a chunk touches are dealt round-robin to the lanes of a group
   constexpr int PER = CH / WG_THREADS;
-  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS && TB <= 256 && FBMAX == 64, "TB: a power of two, one thread per tile in the prefix step; one row of offsets per wave instruction");
-  __shared__ uint32_t o[TB][FBMAX];            // list offsets of the workgroup's features in the batch's tiles (as stored: relative to the tile's first entry); fb <= FBMAX - 1
+  static_assert((TB & (TB - 1)) == 0 && TB <= WG_THREADS && FBMAX == 64, "TB: a power of two, one thread per tile in the prefix step; one row of offsets per wave instruction");
+  __shared__ OT o[TB][FBMAX];                  // list offsets of the workgroup's features in the batch's tiles, relative to the run's first pair (o[tb][0] = 0); fb <= FBMAX - 1
   __shared__ uint32_t vstart[TB + 1];          // the batch's runs laid end to end
   __shared__ uint32_t blk[TB];                 // position of each run's first pair inside its tile's level block
   __shared__ int64_t xbase[UNIT ? 1 : TB];     // first entry of each tile's level block in tval
@@ -673,21 +696,22 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
         const int tb = wv + q * (WG_THREADS / 64);
-        if (tb < nb) o[tb][j] = ov[q];
+        const uint32_t first = __shfl(ov[q], 0);   // (lane 0 holds the offset of feature f0: the run's first pair)
+        if (tb < nb) { o[tb][j] = (OT)(ov[q] - first); if (j == 0) blk[tb] = first; }
       }
-      if ((int)threadIdx.x < nb) { blk[threadIdx.x] = bv; if (!UNIT) xbase[threadIdx.x] = tbv + (int64_t)bv; }
+      __syncthreads();
+      if ((int)threadIdx.x < nb) { blk[threadIdx.x] -= bv; if (!UNIT) xbase[threadIdx.x] = tbv + (int64_t)bv; }   // the run's first pair inside the tile's level block
     }
     __syncthreads();
     if (threadIdx.x < 64) {                     // exclusive prefix of the run lengths: one wave, TB / 64 values per lane
       uint32_t carry = 0;
       for (int b0 = 0; b0 < TB; b0 += 64) {
         const int tb = b0 + threadIdx.x;
-        const uint32_t len = (tb < nb) ? o[tb][fb] - o[tb][0] : 0u;
+        const uint32_t len = (tb < nb) ? (uint32_t)o[tb][fb] : 0u;
         uint32_t inc = len;
 #pragma unroll
         for (int ofs = 1; ofs < 64; ofs <<= 1) { const uint32_t up = __shfl_up(inc, ofs); if ((int)threadIdx.x >= ofs) inc += up; }
         if (tb < TB) vstart[tb] = carry + inc - len;
-        if (tb < nb) blk[tb] = o[tb][0] - blk[tb];      // the run's first pair inside the tile's level block
         carry += __shfl(inc, 63);
       }
       if (threadIdx.x == 0) vstart[TB] = carry;
@@ -747,10 +771,10 @@ __global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* _
             };
             for (int tb = t_lo + lane; tb <= t_hi; tb += 2 * LG) {
               const int tb2 = tb + LG <= t_hi ? tb + LG : tb;
-              const uint32_t s1 = vstart[tb], oa1 = o[tb][gc], ob1 = o[tb][gc + 1], oz1 = o[tb][0];
-              const uint32_t s2 = vstart[tb2], oa2 = o[tb2][gc], ob2 = o[tb2][gc + 1], oz2 = o[tb2][0];
-              const uint32_t a1 = max(s1 + oa1 - oz1, c0), b1 = min(s1 + ob1 - oz1, c1);
-              uint32_t a2 = max(s2 + oa2 - oz2, c0), b2 = min(s2 + ob2 - oz2, c1);
+              const uint32_t s1 = vstart[tb], oa1 = o[tb][gc], ob1 = o[tb][gc + 1];
+              const uint32_t s2 = vstart[tb2], oa2 = o[tb2][gc], ob2 = o[tb2][gc + 1];
+              const uint32_t a1 = max(s1 + oa1, c0), b1 = min(s1 + ob1, c1);
+              uint32_t a2 = max(s2 + oa2, c0), b2 = min(s2 + ob2, c1);
               if (tb2 == tb) { a2 = 0; b2 = 0; }
               double2 e1[4], e2[4]; float x1[4], x2[4];
 #pragma unroll
@@ -895,15 +919,16 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
   double2* dst = reinterpret_cast<double2*>(e->als_lo[1 - e->als_lo_cur]);
   const dim3 blk(WG_THREADS);
   // features per workgroup: one round of resident workgroups (the kernel's occupancy x the device's CUs), every workgroup the same share of the level.
-  // FMX_ALS_ORDER_FB pins it (tuning); FMX_ALS_ORDER_DEPTH = 1 / 2 / 3 chunks of loads ahead.
+  // FMX_ALS_ORDER_FB pins it (tuning).  Which instantiation: 128 or 256 tiles per batch by the plan's tile count; 16-bit list offsets where no run of 63
+  // lists inside a tile can pass 65 535 pairs.
   static const int fb_env = env_int("FMX_ALS_ORDER_FB", 0);
-  static const int depth = env_int("FMX_ALS_ORDER_DEPTH", 1);   // (measured: 1: 55.9, 2: 59.9, 3: 62.8 us per level at configs[4] -- the walk, not the loads, bounds the kernel; profiles/r05_order_ab*.txt)
   static const int rr = env_int("FMX_ALS_ORDER_R", 1);
   static int n_cus = 0;
   if (n_cus == 0) { hipDeviceProp_t pr{}; n_cus = (hipGetDeviceProperties(&pr, e->cfg.device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
-#define FMX_OSUMS(UNITv, DEPTHv)                                                                                                                            \
+  const bool narrow = (uint64_t)T->max_list * 63u <= 65535u;
+#define FMX_OSUMS(UNITv, TBv, OTv, MINWv)                                                                                                                   \
   do {                                                                                                                                                      \
-    auto kern = als_order_sums_k<UNITv, 64, 128, 1024, DEPTHv>;                                                                                               \
+    auto kern = als_order_sums_k<UNITv, 64, TBv, 1024, 1, OTv, MINWv>;                                                                                        \
     static int per_cu = 0;                                                                                                                                    \
     if (per_cu == 0) { int nbk = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, WG_THREADS, 0) == hipSuccess && nbk > 0) ? nbk : 2; }  \
     const uint32_t slots = (uint32_t)(per_cu * n_cus);                                                                                                        \
@@ -912,12 +937,9 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
     hipLaunchKernelGGL(kern, dim3((cnt + fbv - 1) / fbv), blk, 0, e->stream, (const uint32_t*)T->toff, nf1, lvl0, cnt, fbv, (const int64_t*)T->tile_base,    \
                        (const float*)T->tval, src, T->tshift, T->n_tiles, (const uint32_t*)(T->feats + lvl0), e->dV, e->kp64, dyn, vstep);                   \
   } while (0)
-#define FMX_OSUMS_U(DEPTHv) do { if (T->unit) FMX_OSUMS(true, DEPTHv); else FMX_OSUMS(false, DEPTHv); } while (0)
-  switch (depth) {
-    case 1: FMX_OSUMS_U(1); break;
-    case 2: FMX_OSUMS_U(2); break;
-    default: FMX_OSUMS_U(3); break;
-  }
+#define FMX_OSUMS_U(TBv, OTv, MINWv) do { if (T->unit) FMX_OSUMS(true, TBv, OTv, MINWv); else FMX_OSUMS(false, TBv, OTv, MINWv); } while (0)
+  if (T->n_tiles <= 128) { if (narrow) FMX_OSUMS_U(128, uint16_t, 4); else FMX_OSUMS_U(128, uint32_t, 3); }
+  else { if (narrow) FMX_OSUMS_U(256, uint16_t, 3); else FMX_OSUMS_U(256, uint32_t, 1); }
 #undef FMX_OSUMS_U
 #undef FMX_OSUMS
   const int64_t tile_rows = (int64_t)1 << T->tshift;

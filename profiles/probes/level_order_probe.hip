@@ -662,6 +662,37 @@ int main(int argc, char** argv) {
 #define K2(Rv, NTv) { const int B = (int)((T + 256 * Rv - 1) / (256 * Rv)); const unsigned g = (unsigned)(((n_tiles + 7) / 8) * 8 * B); \
     timeit("K2 apply+permute R=" #Rv " NT=" #NTv, [&] { hipLaunchKernelGGL((apply_perm_k<Rv, NTv>), dim3(g), dim3(256), 0, 0, src, dst, d_fidx, d_perm, vstep, ts, n_tiles, B, n); }, 38.0 * n); }
   K2(4, true) K2(8, true) K2(8, false) K2(2, true) K2(1, true)
+
+  // ---- can the sums kernel of level l+1 hide under the apply kernel of level l?  K1 on a tile range needs only K2 of THOSE tiles done.  G groups of tiles:
+  // serial = K2(all) ; K1(all).  pipelined = K2(g0) ; { K2(g1) || K1(g0) } ; ... ; K1(g_last), on two streams with events.  (K1 then leaves per-group partial
+  // sums; the probe does not combine them: timing only.)
+  {
+    hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipEvent_t ev[64]; for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+    auto k2 = [&](int ta, int tb_, hipStream_t st) { const int nt = tb_ - ta; const int B = (int)(T / 256); const unsigned g = (unsigned)(((nt + 7) / 8) * 8 * B);
+      hipLaunchKernelGGL((apply_perm_k<1, true>), dim3(g), dim3(256), 0, st, src + ((size_t)ta << ts), dst + ((size_t)ta << ts), d_fidx + ((size_t)ta << ts), d_perm + ((size_t)ta << ts), vstep, ts, nt, B, (int64_t)nt << ts); };
+    auto k1 = [&](int ta, int tb_, hipStream_t st) { const int nt = tb_ - ta;
+      hipLaunchKernelGGL((fmx::k1_ko_k<true, 64, 128, 1024, 1>), dim3((cnt + 43) / 44), dim3(256), 0, st, d_toff + (size_t)ta * nf1, nf1, 0u, cnt, 44, d_tb, (const float*)nullptr, dst + ((size_t)ta << ts), ts, nt, d_feats, d_P, 1, d_dyn, vstep, 15); };
+    for (int G : {1, 2, 4, 8}) {
+      const int reps = 10;
+      float ms = 0;
+      for (int rep = -2; rep < reps; ++rep) {
+        if (rep == 0) { CK(hipDeviceSynchronize()); CK(hipEventRecord(t0, sa)); }
+        int e = 0;
+        for (int lvl = 0; lvl < 4; ++lvl) {   // four "levels" back to back: K2(l) on sa, K1(l+1) on sb, next level's K2 waits for the last K1
+          for (int g = 0; g < G; ++g) {
+            const int ta = n_tiles * g / G, tb_ = n_tiles * (g + 1) / G;
+            k2(ta, tb_, sa); CK(hipEventRecord(ev[e], sa)); CK(hipStreamWaitEvent(sb, ev[e], 0)); e = (e + 1) % 64;
+            k1(ta, tb_, sb);
+          }
+          CK(hipEventRecord(ev[e], sb)); CK(hipStreamWaitEvent(sa, ev[e], 0)); e = (e + 1) % 64;
+        }
+      }
+      CK(hipEventRecord(t1, sa)); CK(hipEventSynchronize(t1)); CK(hipEventElapsedTime(&ms, t0, t1));
+      printf("K2(l) + K1(l+1) in %d tile groups on two streams: %.1f us per level\n", G, ms / (reps * 4) * 1e3);
+    }
+  }
   // check: dst holds a permutation of the corrected pairs (sum of e preserved up to the corrections; here just a checksum of positions written)
   { std::vector<double2> h(n); CK(hipMemcpy(h.data(), dst, n * 16, hipMemcpyDeviceToHost)); int64_t zeros = 0; for (int64_t i = 0; i < n; ++i) zeros += (h[i].x == 0.0 && h[i].y == 0.0); printf("unwritten slots: %lld\n", (long long)zeros); }
   return 0;

@@ -284,27 +284,32 @@ def test_configs4_full_size_levels_descent_and_reproducibility():
     m.close()
 
 
-def test_configs4_full_size_row_tiled_form_equals_the_column_walking_form(monkeypatch):
-    """10 M x 1 M, k = 16: the default takes the row-tiled form for all 30 levels (77 tiles of 131 072 rows); FMX_ALS_TILED=0 walks the CSC columns.
-    One Gibbs sweep each from the same start: V (sampled rows) and the residual agree to 1e-10."""
+def test_configs4_full_size_level_order_and_row_tiled_forms_equal_the_column_walking_form(monkeypatch):
+    """10 M x 1 M, k = 16.  The default: a complete plan, so the V sweep takes the LEVEL-ORDER form (all 30 levels tiled, 153 tiles of 65 536 rows);
+    FMX_ALS_ORDER=0: the three-pass row-tiled form (77 tiles of 131 072 rows); FMX_ALS_TILED=0: the column-walking kernels.  One Gibbs sweep each from the
+    same start: V (sampled rows) and the residual agree to 1e-10; the level-order form twice: bit for bit."""
     from fmwr_amd import _lib as L, engine
-    out = []
-    for mode in (None, "0"):
-        if mode is not None:
-            monkeypatch.setenv("FMX_ALS_TILED", mode)
+    out = {}
+    for name, env in (("order", {}), ("order_again", {}), ("three_pass", {"FMX_ALS_ORDER": "0"}), ("columns", {"FMX_ALS_TILED": "0"})):
+        monkeypatch.delenv("FMX_ALS_ORDER", raising=False); monkeypatch.delenv("FMX_ALS_TILED", raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
         m = engine.Matrix.synthetic(N, P, Z, SEED)
         e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=K, mode=L.MODE_SEQUENTIAL)
         e.init_normal(SEED, 0.0, 0.1)
-        tiled, tile_rows, n_tiles = e.als_tiled(m)
-        assert (tiled, tile_rows, n_tiles) == ((Z, 131072, 77) if mode is None else (0, 0, 0))
+        want = {"order": (Z, 65536, 153), "order_again": (Z, 65536, 153), "three_pass": (Z, 131072, 77), "columns": (0, 0, 0)}[name]
+        assert e.als_tiled(m) == want
+        assert e.als_level_order(m) == name.startswith("order")
         d_err = util.DevBuf(N)
         L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(N), d_err.ptr, C.c_int(L.LINK_NONE)))
         e.sync()
         d_z = util.DevBuf.from_numpy(np.random.default_rng(12).normal(0, 1, (K, P)))
         e.vsweep_device(m, d_err.ptr.value, alpha=1.0, v_lambda=np.full(K, 1.0), dev_std_normals=d_z.ptr.value)
-        out.append((d_err.numpy(), e.get_rows(np.arange(0, P, 499, dtype=np.uint32))[1]))
+        out[name] = (d_err.numpy(), e.get_rows(np.arange(0, P, 499, dtype=np.uint32))[1])
         e.close(); d_err.free(); d_z.free(); m.close()
-    assert util.rel_err(out[0][0], out[1][0]) < 1e-10 and util.rel_err(out[0][1], out[1][1]) < 1e-10
+    assert np.array_equal(out["order"][0], out["order_again"][0]) and np.array_equal(out["order"][1], out["order_again"][1])
+    for name in ("order", "three_pass"):
+        assert util.rel_err(out[name][0], out["columns"][0]) < 1e-10 and util.rel_err(out[name][1], out["columns"][1]) < 1e-10
 
 
 def test_configs4_full_size_split_columns_equal_the_unsplit_form(monkeypatch):
