@@ -55,11 +55,25 @@ static fmx_config config_from_controls(List fm_controls, List solver_controls, d
   else if (s == "ALS") c.solver = FMX_SOLVER_ALS;                 // its R-side parameters are overridden by learner->init() in the reference too (SURVEY A-7)
   else c.solver = FMX_SOLVER_MCMC;
   c.min_target = min_t; c.max_target = max_t;                    // src/FM.cpp:89-96
-  c.mode = FMX_MODE_SEQUENTIAL;                                  // the reference's algorithm, one example per update
-  // Throughput mode: options("FM.threads") arrives as fm_controls$nthreads (src/FM.cpp:59,97) and becomes the number of GPUs --
-  // fmx_train then shards the rows over devices 0..n-1 and exchanges the gradient sums with RCCL inside the library:
-  //   c.mode = FMX_MODE_MINIBATCH; c.batch_rows = 262144; int32_t n = 0; fmx_device_count(&n);
-  //   c.n_gpus = std::min((int)fm_controls["nthreads"], (int)n);
+  c.mode = FMX_MODE_SEQUENTIAL;                                  // default: the reference's algorithm, one example per update (parity <= 1e-11)
+  // The throughput mode is ONE optional element of solver.control -- a non-breaking extension a maintainer adds to R/fm_solver_control.R
+  // (`engine = c("sequential", "minibatch", "minibatch_fp64")`, `batch_rows = 262144L`); lists without it behave as before:
+  //   "minibatch"      synchronous mini-batches, fp32 state: 846 M examples/s at configs[1]'s shape against 1.66 M (one MI355X)
+  //   "minibatch_fp64" the same with the reference's fp64 state: 616 M examples/s, 1e-5 on V guaranteed against the mini-batch restatement
+  // options("FM.threads") arrives as fm_controls$nthreads (src/FM.cpp:59,97) and becomes the number of GPUs there: fmx_train shards the rows over
+  // devices 0..n-1 and exchanges the gradient sums with RCCL inside the library.
+  if (solver_controls.containsElementNamed("engine") && (c.solver == FMX_SOLVER_SGD || c.solver == FMX_SOLVER_FTRL || c.solver == FMX_SOLVER_TDAP)) {
+    const std::string eng = as<std::string>(solver_controls["engine"]);
+    if (eng == "minibatch" || eng == "minibatch_fp64") {
+      c.mode = FMX_MODE_MINIBATCH;
+      c.state_fp64 = eng == "minibatch_fp64";
+      c.batch_rows = solver_controls.containsElementNamed("batch_rows") ? (int)solver_controls["batch_rows"] : 262144;
+      int32_t n_dev = 0;
+      fmx_check(fmx_device_count(&n_dev));
+      const int want = (int)fm_controls["nthreads"];
+      c.n_gpus = want > 1 ? (want < n_dev ? want : n_dev) : 1;
+    } else if (eng != "sequential") stop("solver.control(engine = ...) must be \"sequential\", \"minibatch\" or \"minibatch_fp64\"");
+  }
   return c;
 }
 
