@@ -259,7 +259,7 @@ __global__ void order_max_list_k(const uint32_t* __restrict__ toff, size_t nf1, 
   if (i < (size_t)n_tiles * n_feats) { const size_t t = i / n_feats, f = i % n_feats; len = toff[t * nf1 + f + 1] - toff[t * nf1 + f]; }
 #pragma unroll
   for (int ofs = 32; ofs > 0; ofs >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, ofs));
-  if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
+  if ((threadIdx.x & 63) == 0 && len > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, len);   // (an atomic only where it can still raise the value: 2.4 M waves on one word took 27 ms)
 }
 // inv[s][row] = position of the row in its tile's level-s order
 __global__ void order_inverse_k(const uint32_t* __restrict__ trow, const int64_t* __restrict__ tile_base, int64_t n, int tshift, int n_slots, uint32_t* __restrict__ inv) {
