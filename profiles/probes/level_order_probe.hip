@@ -574,6 +574,94 @@ __global__ __launch_bounds__(WG_THREADS) void k1_lean_k(const uint32_t* __restri
 }
 }  // namespace fmx
 
+
+// ---- K1, one WAVE per 16 features, no LDS arrays, no barrier: per tile the wave's run (<= 64 pairs in the regular case) is ONE load instruction, one pair per
+// lane; the four lanes of a feature fetch "their" entries of its list from the lanes that hold them (cross-lane reads).  Software pipeline over batches of NA
+// tiles: offsets two batches ahead, pairs one batch ahead -- no load of the loop waits on another.  Runs longer than 64 pairs: the rest straight from memory.
+namespace fmx {
+template <bool UNIT, int NA, bool TR>
+__global__ __launch_bounds__(256) void k1_wave_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
+                                                 const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
+                                                 const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                                 double2* __restrict__ vstep) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t f0 = wave * 16;
+  if (f0 >= cnt) return;
+  const int g = lane >> 2, j = lane & 3;
+  const uint32_t fi = f0 + g;
+  const bool live = fi < cnt;
+  const uint32_t feat = feats[live ? fi : cnt - 1];
+  const int f = dyn->f;
+  const double old = P[(size_t)feat * kp + f];
+  const uint32_t fo = min(f0 + (uint32_t)min(lane, 16), cnt);   // lanes 0..16 hold the offsets of features f0 .. f0 + 16
+  double mean = 0.0, var = 0.0;
+  auto sh = [&](double v, int from) { return __hiloint2double(__shfl(__double2hiint(v), from), __shfl(__double2loint(v), from)); };
+  struct Offs { uint32_t off[NA], base[NA]; };
+  struct Pairs { double2 pv[NA]; uint32_t r0[NA], rl[NA], la[NA], lb[NA]; };
+  auto load_offs = [&](int t0, Offs& o) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int t = min(t0 + u, n_tiles - 1);
+      const uint32_t* row = toff + (size_t)t * nf1 + lvl0;
+      o.off[u] = stream_load<true>(row + fo);
+      o.base[u] = stream_load<true>(row);
+    }
+  };
+  auto load_pairs = [&](int t0, const Offs& o, Pairs& p) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int t = min(t0 + u, n_tiles - 1);
+      const bool in = t0 + u < n_tiles;
+      p.r0[u] = __shfl(o.off[u], 0);
+      p.rl[u] = in ? __shfl(o.off[u], 16) - p.r0[u] : 0u;
+      p.la[u] = in ? __shfl(o.off[u], g) - p.r0[u] : 0u;
+      p.lb[u] = in ? __shfl(o.off[u], g + 1) - p.r0[u] : 0u;
+      const uint32_t e = min((uint32_t)lane, p.rl[u] > 0 ? p.rl[u] - 1 : 0u);
+      p.r0[u] -= o.base[u];   // the run's first pair inside the tile's level block
+      p.pv[u] = stream_load<true>(src + ((size_t)t << tshift) + p.r0[u] + e);
+    }
+  };
+  Offs o_next, o_after; Pairs cur, nxt;
+  load_offs(0, o_next);
+  load_offs(NA, o_after);
+  load_pairs(0, o_next, cur);
+  for (int t0 = 0; t0 < n_tiles; t0 += NA) {
+    load_pairs(t0 + NA, o_after, nxt);          // (past the end: clamped addresses, empty lists)
+    load_offs(t0 + 2 * NA, o_next);
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const uint32_t la = cur.la[u], lb = cur.lb[u], hi = min(lb, 64u);
+      for (uint32_t r = 0; __any(la + r < hi); r += 4) {   // (a UNIFORM trip count: a lane that left the loop could no longer lend its pair to the others)
+        const uint32_t idx = la + r + j;
+        const double qx = sh(cur.pv[u].x, (int)min(idx, 63u)), ey = sh(cur.pv[u].y, (int)min(idx, 63u));
+        const double h = qx - old;
+        if (live && idx < hi) { mean += h * ey; var += h * h; }
+      }
+      if (cur.rl[u] > 64) {   // a long run: the rest straight from memory
+        const int t = min(t0 + u, n_tiles - 1);
+        for (uint32_t idx = max(la, 64u) + j; idx < lb; idx += 4) {
+          const double2 c = src[((size_t)t << tshift) + cur.r0[u] + idx];
+          const double h = c.x - old;
+          if (live) { mean += h * c.y; var += h * h; }
+        }
+      }
+    }
+    cur = nxt; { Offs tmp = o_after; o_after = o_next; o_next = tmp; }
+  }
+  mean += __shfl_xor(mean, 1); var += __shfl_xor(var, 1);
+  mean += __shfl_xor(mean, 2); var += __shfl_xor(var, 2);
+  if (j != 0 || !live) return;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  mean -= old * var;
+  var = 1.0 / (lambda + alpha * var);
+  mean = -var * (alpha * mean - mu * lambda);
+  const double nv = mean;
+  P[(size_t)feat * kp + f] = nv;
+  vstep[fi] = make_double2(old, old - nv);
+}
+}  // namespace fmx
+
 int main(int argc, char** argv) {
   const int ts = argc > 1 ? atoi(argv[1]) : 17;
   const int n_tiles = argc > 2 ? atoi(argv[2]) : 77;
@@ -651,6 +739,26 @@ int main(int argc, char** argv) {
     printf("lean vs generic K1: largest relative difference of a step %.3e\n", worst);
     CK(hipMemset(d_P, 0, cnt * 8));
   }
+  {  // the wave kernel against the product's: same steps?
+    double2* vs2; CK(hipMalloc(&vs2, cnt * 16)); CK(hipMemset(vs2, 0, cnt * 16)); CK(hipMemset(vstep, 0, cnt * 16)); CK(hipMemset(d_P, 0, cnt * 8));
+    hipLaunchKernelGGL((fmx::als_order_sums_k<true, 64, 128, 1024, 1>), dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, 32, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep);
+    CK(hipMemset(d_P, 0, cnt * 8));
+    hipLaunchKernelGGL((fmx::k1_wave_k<true, 8, false>), dim3((cnt + 63) / 64), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vs2);
+    CK(hipDeviceSynchronize());
+    std::vector<double2> a(cnt), b(cnt); CK(hipMemcpy(a.data(), vstep, cnt * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), vs2, cnt * 16, hipMemcpyDeviceToHost));
+    double worst = 0.0; for (uint32_t i = 0; i < cnt; ++i) worst = std::max(worst, std::abs(a[i].y - b[i].y) / std::max(1e-300, std::abs(a[i].y)));
+    printf("wave K1 vs product K1: largest relative difference of a step %.3e\n", worst);
+    CK(hipMemset(d_P, 0, cnt * 8));
+  }
+#define K1W(NAv) timeit("wave K1 (16 features per wave, no LDS) tiles in flight " #NAv, [&] { hipLaunchKernelGGL((fmx::k1_wave_k<true, NAv, false>), dim3((cnt + 63) / 64), dim3(256), 0, 0, \
+    d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
+  K1W(4) K1W(8) K1W(16)
+  uint32_t* d_toffT;
+  { std::vector<uint32_t> tt((size_t)(cnt + 1) * n_tiles); for (int t = 0; t < n_tiles; ++t) for (uint32_t f = 0; f <= cnt; ++f) tt[(size_t)f * n_tiles + t] = toff[(size_t)t * (cnt + 1) + f];
+    CK(hipMalloc(&d_toffT, tt.size() * 4)); CK(hipMemcpy(d_toffT, tt.data(), tt.size() * 4, hipMemcpyHostToDevice)); }
+#define K1WT(NAv) timeit("wave K1, offsets [feature][tile], tiles in flight " #NAv, [&] { hipLaunchKernelGGL((fmx::k1_wave_k<true, NAv, true>), dim3((cnt + 63) / 64), dim3(256), 0, 0, \
+    d_toffT, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
+
 #define K1L(FBv, NITv, Sv) timeit("lean K1 FB=" #FBv " NIT=" #NITv " S=" #Sv, [&] { hipLaunchKernelGGL((fmx::k1_lean_k<true, FBv, NITv, Sv>), dim3((cnt + FBv - 1) / FBv), dim3(256), 0, 0, \
     d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
   K1L(32, 8, 256) K1L(32, 8, 192) K1L(32, 12, 192) K1L(32, 16, 192) K1L(16, 16, 128) K1L(16, 8, 128) K1L(64, 8, 256) K1L(64, 4, 256)

@@ -3,6 +3,8 @@ plus the synthetic generator against an independent numpy Philox4x32-10."""
 import numpy as np
 import pytest
 
+from tests import util
+
 pytestmark = pytest.mark.gpu
 
 N, P, Z, K, SEED, B = 10_000_000, 1_000_000, 30, 16, 20240001, 262_144
@@ -309,3 +311,39 @@ def test_iid_generators_rows_are_strictly_ascending_and_follow_their_law(fm):
         assert (0.005 < head < 0.02) if law == L.COLUMNS_UNIFORM else head > 0.4
         part = engine.Matrix.synthetic_iid(1000, p, z, 9, law, s_exp, row_offset=n - 1000).export()
         assert np.array_equal(part[1], col[(n - 1000) * z:]) and np.array_equal(part[3], y[n - 1000:])
+
+
+@pytest.mark.parametrize("solver", ["sgd", "ftrl"])
+def test_zipf_columns_train_like_the_oracle(fm, solver):
+    """SURVEY 8(d)'s conflict-stress variant at test size: Zipf(1.05) columns (a few features occur in most rows).  Mini-batch steps: the head features' lists
+    are long lists (segments of 1 024 entries on the side stream beside the short-list kernel); sequential learner: nearly every example conflicts with its
+    predecessor, so the windowed / pipelined kernels run groups of one.  Both against the oracle on the exported rows."""
+    import oracle
+    engine, L = fm
+    n, p, z, k = 12_000, 30_000, 30, 16
+    m = engine.Matrix.synthetic_iid(n, p, z, 21, L.COLUMNS_ZIPF, 1.05)
+    rp, col, val, y = m.export()
+    counts = np.bincount(col, minlength=p)
+    assert counts.max() > 4000 and np.sum(counts > 64) > 50          # heavy hitters: long lists in every 4 000-row step
+    w0, w, v = util.params(p, k, 5, stdev=0.05, fp32=True)
+    X = oracle.Matrix(rp, col, val, p)
+    ftrl = solver == "ftrl"
+    P = oracle.params(task=oracle.CLASSIFICATION, k=k, l2_regw=1e-4, l2_regv=1e-4, learn_rate=0.01, **(dict(l1_regw=1e-4, l1_regv=1e-4) if ftrl else {}))
+    kw = dict(task=L.TASK_CLASSIFICATION, solver=L.SOLVER_FTRL if ftrl else L.SOLVER_SGD, num_factor=k, l2_w1=1e-4, l2_v=1e-4, learn_rate=0.01,
+              l1_w1=1e-4 if ftrl else 0.0, l1_v=1e-4 if ftrl else 0.0)
+    e = engine.Engine(p, mode=L.MODE_MINIBATCH, batch_rows=4_000, **kw)
+    e.set_params(w0, w, v)
+    np.testing.assert_allclose(e.predict(m), oracle.predict_batch(P, X, w0, w, v.ravel()), rtol=0, atol=1e-5)
+    e.train(m, n)
+    mb = (oracle.FtrlMinibatch if ftrl else oracle.SgdMinibatch)(P, X, y, w0, w, v.ravel())
+    for b in range(0, n, 4_000):
+        mb.step(b, b + 4_000)
+    g0, gw, gv = e.get_params()
+    assert util.rel_err(gv, mb.v.reshape(k, p)) < 1e-5 and util.rel_err(gw, mb.w) < 1e-5 and abs(g0 - mb.w0.value) < 1e-5
+    es = engine.Engine(p, mode=L.MODE_SEQUENTIAL, **kw)
+    es.set_params(w0, w, v)
+    es.train(m, 3_000)
+    ref = (oracle.ftrl_learn if ftrl else oracle.sgd_learn)(P, X, y, w0, w, v.ravel(), 3_000)
+    s0, sw, sv = es.get_params()
+    assert util.rel_err(sv, ref["v"].reshape(k, p)) < 1e-10 and util.rel_err(sw, ref["w"]) < 1e-10 and abs(s0 - ref["w0"]) < 1e-10
+    assert np.array_equal(np.sign(es.predict(m)), np.sign(oracle.predict_batch(P, X, ref["w0"], ref["w"], ref["v"])))
