@@ -938,7 +938,8 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
                        (const float*)T->tval, src, T->tshift, T->n_tiles, (const uint32_t*)(T->feats + lvl0), e->dV, e->kp64, dyn, vstep);                   \
   } while (0)
 #define FMX_OSUMS_U(TBv, OTv, MINWv) do { if (T->unit) FMX_OSUMS(true, TBv, OTv, MINWv); else FMX_OSUMS(false, TBv, OTv, MINWv); } while (0)
-  if (T->n_tiles <= 128) { if (narrow) FMX_OSUMS_U(128, uint16_t, 4); else FMX_OSUMS_U(128, uint32_t, 3); }
+  // (four workgroups per CU for the 128-tile / 16-bit form fit the LDS but cost register spills and bought nothing: 57.0 against 53.7 us, profiles/r05_order_ab11.txt)
+  if (T->n_tiles <= 128) { if (narrow) FMX_OSUMS_U(128, uint16_t, 3); else FMX_OSUMS_U(128, uint32_t, 3); }
   else { if (narrow) FMX_OSUMS_U(256, uint16_t, 3); else FMX_OSUMS_U(256, uint32_t, 1); }
 #undef FMX_OSUMS_U
 #undef FMX_OSUMS
