@@ -662,6 +662,91 @@ __global__ __launch_bounds__(256) void k1_wave_k(const uint32_t* __restrict__ to
 }
 }  // namespace fmx
 
+
+// ---- K1, one wave per FW features, E = FW / 16 pairs per lane per tile, the sums kept in LDS accumulators OWNED BY THE WAVE and fed by ds_add_f64 (no other
+// wave ever touches them, a wave's LDS operations execute in order, and lanes of ONE instruction that hit the same accumulator are serialised by the LDS in a
+// fixed order: reproducible, checked by running twice).  No list walk, no search, no barrier: per tile the run bounds, E pair loads, E feature-index loads.
+namespace fmx {
+template <bool UNIT, int NA, int FW>
+__global__ __launch_bounds__(256) void k1_atom_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const uint16_t* __restrict__ fidx,
+                                                 const double2* __restrict__ src, int tshift, int n_tiles, const uint32_t* __restrict__ feats, double* __restrict__ P,
+                                                 int kp, const SweepDyn* __restrict__ dyn, double2* __restrict__ vstep) {
+  constexpr int E = FW / 16;
+  __shared__ double acc[4][FW][2];
+  __shared__ double oldv[4][FW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t f0 = (blockIdx.x * 4 + wv) * FW;
+  if (f0 >= cnt) return;
+  const uint32_t fend = min(f0 + (uint32_t)FW, cnt);
+  const int f = dyn->f;
+  for (int i = lane; i < FW; i += 64) {
+    const uint32_t fi = min(f0 + (uint32_t)i, cnt - 1);
+    oldv[wv][i] = P[(size_t)feats[fi] * kp + f];
+    acc[wv][i][0] = 0.0; acc[wv][i][1] = 0.0;
+  }
+  const uint32_t which = lane == 0 ? f0 : (lane == 1 ? fend : 0u);   // lanes 0, 1, 2: the run's first offset, its end, the level block's first offset
+  struct Offs { uint32_t o[NA]; };
+  struct Pairs { double2 pv[NA][E]; uint32_t fx[NA][E], rl[NA], r0[NA]; };
+  auto load_offs = [&](int t0, Offs& o) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int t = min(t0 + u, n_tiles - 1); o.o[u] = stream_load<true>(toff + (size_t)t * nf1 + lvl0 + which); }
+  };
+  auto load_pairs = [&](int t0, const Offs& o, Pairs& p) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int t = min(t0 + u, n_tiles - 1);
+      const uint32_t a = __builtin_amdgcn_readlane(o.o[u], 0), b = __builtin_amdgcn_readlane(o.o[u], 1), base = __builtin_amdgcn_readlane(o.o[u], 2);
+      p.rl[u] = t0 + u < n_tiles ? b - a : 0u;
+      p.r0[u] = a - base;
+#pragma unroll
+      for (int q = 0; q < E; ++q) {
+        const size_t at = ((size_t)t << tshift) + p.r0[u] + min((uint32_t)(lane + 64 * q), p.rl[u] > 0 ? p.rl[u] - 1 : 0u);
+        p.pv[u][q] = stream_load<true>(src + at);
+        p.fx[u][q] = stream_load<true>(fidx + at);
+      }
+    }
+  };
+  auto add = [&](double2 c, uint32_t fx) {
+    const int g = (int)(fx - f0);
+    const double h = c.x - oldv[wv][g];
+    unsafeAtomicAdd(&acc[wv][g][0], h * c.y);
+    unsafeAtomicAdd(&acc[wv][g][1], h * h);
+  };
+  Offs o_next, o_after; Pairs cur, nxt;
+  load_offs(0, o_next);
+  load_offs(NA, o_after);
+  load_pairs(0, o_next, cur);
+  for (int t0 = 0; t0 < n_tiles; t0 += NA) {
+    load_pairs(t0 + NA, o_after, nxt);
+    load_offs(t0 + 2 * NA, o_next);
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        if ((uint32_t)(lane + 64 * q) < cur.rl[u]) add(cur.pv[u][q], cur.fx[u][q]);
+      if (cur.rl[u] > 64u * E) {   // a long run: the rest in pieces of 64, straight from memory
+        const int t = min(t0 + u, n_tiles - 1);
+        for (uint32_t i = 64 * E + lane; __any(i < cur.rl[u]); i += 64)
+          if (i < cur.rl[u]) { const size_t at = ((size_t)t << tshift) + cur.r0[u] + i; add(src[at], fidx[at]); }
+      }
+    }
+    cur = nxt; { Offs tmp = o_after; o_after = o_next; o_next = tmp; }
+  }
+  for (int i = lane; i < FW && f0 + i < cnt; i += 64) {
+    const uint32_t fi = f0 + i;
+    const uint32_t feat = feats[fi];
+    double mean = acc[wv][i][0], var = acc[wv][i][1];
+    const double old = oldv[wv][i];
+    const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+    mean -= old * var;
+    var = 1.0 / (lambda + alpha * var);
+    mean = -var * (alpha * mean - mu * lambda);
+    P[(size_t)feat * kp + f] = mean;
+    vstep[fi] = make_double2(old, old - mean);
+  }
+}
+}  // namespace fmx
+
 int main(int argc, char** argv) {
   const int ts = argc > 1 ? atoi(argv[1]) : 17;
   const int n_tiles = argc > 2 ? atoi(argv[2]) : 77;
@@ -750,6 +835,22 @@ int main(int argc, char** argv) {
     printf("wave K1 vs product K1: largest relative difference of a step %.3e\n", worst);
     CK(hipMemset(d_P, 0, cnt * 8));
   }
+  {  // the LDS-atomic kernel against the product's: same steps?  twice: the same bits?
+    double2 *vs2, *vs3; CK(hipMalloc(&vs2, cnt * 16)); CK(hipMalloc(&vs3, cnt * 16)); CK(hipMemset(vs2, 0, cnt * 16)); CK(hipMemset(vs3, 0, cnt * 16)); CK(hipMemset(vstep, 0, cnt * 16)); CK(hipMemset(d_P, 0, cnt * 8));
+    hipLaunchKernelGGL((fmx::als_order_sums_k<true, 64, 128, 1024, 1>), dim3((cnt + 31) / 32), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, 32, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep);
+    CK(hipMemset(d_P, 0, cnt * 8));
+    hipLaunchKernelGGL((fmx::k1_atom_k<true, 8, 32>), dim3((cnt + 127) / 128), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, d_fidx, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vs2);
+    CK(hipMemset(d_P, 0, cnt * 8));
+    hipLaunchKernelGGL((fmx::k1_atom_k<true, 8, 32>), dim3((cnt + 127) / 128), dim3(256), 0, 0, d_toff, nf1, 0u, cnt, d_fidx, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vs3);
+    CK(hipDeviceSynchronize());
+    std::vector<double2> a(cnt), b(cnt), c(cnt); CK(hipMemcpy(a.data(), vstep, cnt * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), vs2, cnt * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(c.data(), vs3, cnt * 16, hipMemcpyDeviceToHost));
+    double worst = 0.0; size_t diff = 0; for (uint32_t i = 0; i < cnt; ++i) { worst = std::max(worst, std::abs(a[i].y - b[i].y) / std::max(1e-300, std::abs(a[i].y))); diff += (b[i].y != c[i].y) || (b[i].x != c[i].x); }
+    printf("LDS-atomic K1 vs product K1: largest relative difference of a step %.3e; two runs differ in %zu of %u steps\n", worst, diff, cnt);
+    CK(hipMemset(d_P, 0, cnt * 8));
+  }
+#define K1A(NAv, FWv) timeit("LDS-atomic K1, features per wave " #FWv ", tiles in flight " #NAv, [&] { hipLaunchKernelGGL((fmx::k1_atom_k<true, NAv, FWv>), dim3((cnt + 4 * FWv - 1) / (4 * FWv)), dim3(256), 0, 0, \
+    d_toff, nf1, 0u, cnt, d_fidx, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 18.0 * n);
+  K1A(4, 16) K1A(8, 16) K1A(4, 32) K1A(8, 32) K1A(16, 32) K1A(4, 64) K1A(8, 64) K1A(16, 64) K1A(4, 128) K1A(8, 128)
 #define K1W(NAv) timeit("wave K1 (16 features per wave, no LDS) tiles in flight " #NAv, [&] { hipLaunchKernelGGL((fmx::k1_wave_k<true, NAv, false>), dim3((cnt + 63) / 64), dim3(256), 0, 0, \
     d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
   K1W(4) K1W(8) K1W(16)
