@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void k1_wave_k(const uint32_t* __restrict__ to
 // wave ever touches them, a wave's LDS operations execute in order, and lanes of ONE instruction that hit the same accumulator are serialised by the LDS in a
 // fixed order: reproducible, checked by running twice).  No list walk, no search, no barrier: per tile the run bounds, E pair loads, E feature-index loads.
 namespace fmx {
-template <bool UNIT, int NA, int FW>
+template <bool UNIT, int NA, int FW, int MODE = 3>   // MODE bit 0: the LDS atomics; bit 1: the feature-index loads
 __global__ __launch_bounds__(256) void k1_atom_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const uint16_t* __restrict__ fidx,
                                                  const double2* __restrict__ src, int tshift, int n_tiles, const uint32_t* __restrict__ feats, double* __restrict__ P,
                                                  int kp, const SweepDyn* __restrict__ dyn, double2* __restrict__ vstep) {
@@ -702,15 +702,18 @@ __global__ __launch_bounds__(256) void k1_atom_k(const uint32_t* __restrict__ to
       for (int q = 0; q < E; ++q) {
         const size_t at = ((size_t)t << tshift) + p.r0[u] + min((uint32_t)(lane + 64 * q), p.rl[u] > 0 ? p.rl[u] - 1 : 0u);
         p.pv[u][q] = stream_load<true>(src + at);
-        p.fx[u][q] = stream_load<true>(fidx + at);
+        p.fx[u][q] = (MODE & 2) ? (uint32_t)stream_load<true>(fidx + at) : f0 + (uint32_t)(lane & 15);
       }
     }
   };
+  double dm = 0.0, dv = 0.0;
   auto add = [&](double2 c, uint32_t fx) {
     const int g = (int)(fx - f0);
-    const double h = c.x - oldv[wv][g];
-    unsafeAtomicAdd(&acc[wv][g][0], h * c.y);
-    unsafeAtomicAdd(&acc[wv][g][1], h * h);
+    if (MODE & 1) {
+      const double h = c.x - oldv[wv][g];
+      unsafeAtomicAdd(&acc[wv][g][0], h * c.y);
+      unsafeAtomicAdd(&acc[wv][g][1], h * h);
+    } else { const double h = c.x - (double)g; dm += h * c.y; dv += h * h; }
   };
   Offs o_next, o_after; Pairs cur, nxt;
   load_offs(0, o_next);
@@ -732,6 +735,7 @@ __global__ __launch_bounds__(256) void k1_atom_k(const uint32_t* __restrict__ to
     }
     cur = nxt; { Offs tmp = o_after; o_after = o_next; o_next = tmp; }
   }
+  if (!(MODE & 1)) { acc[wv][lane & (FW - 1)][0] = dm; acc[wv][lane & (FW - 1)][1] = dv; }
   for (int i = lane; i < FW && f0 + i < cnt; i += 64) {
     const uint32_t fi = f0 + i;
     const uint32_t feat = feats[fi];
@@ -850,7 +854,10 @@ int main(int argc, char** argv) {
   }
 #define K1A(NAv, FWv) timeit("LDS-atomic K1, features per wave " #FWv ", tiles in flight " #NAv, [&] { hipLaunchKernelGGL((fmx::k1_atom_k<true, NAv, FWv>), dim3((cnt + 4 * FWv - 1) / (4 * FWv)), dim3(256), 0, 0, \
     d_toff, nf1, 0u, cnt, d_fidx, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 18.0 * n);
-  K1A(4, 16) K1A(8, 16) K1A(4, 32) K1A(8, 32) K1A(16, 32) K1A(4, 64) K1A(8, 64) K1A(16, 64) K1A(4, 128) K1A(8, 128)
+  K1A(4, 16) K1A(8, 16) K1A(4, 32) K1A(8, 32)
+#define K1AM(NAv, FWv, MODEv) timeit("LDS-atomic K1, features per wave " #FWv ", tiles in flight " #NAv ", knock-out mode " #MODEv, [&] { hipLaunchKernelGGL((fmx::k1_atom_k<true, NAv, FWv, MODEv>), dim3((cnt + 4 * FWv - 1) / (4 * FWv)), dim3(256), 0, 0, \
+    d_toff, nf1, 0u, cnt, d_fidx, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 18.0 * n);
+  K1AM(4, 16, 2) K1AM(4, 16, 0) K1AM(8, 16, 0) K1AM(4, 32, 0) K1AM(8, 32, 0)
 #define K1W(NAv) timeit("wave K1 (16 features per wave, no LDS) tiles in flight " #NAv, [&] { hipLaunchKernelGGL((fmx::k1_wave_k<true, NAv, false>), dim3((cnt + 63) / 64), dim3(256), 0, 0, \
     d_toff, nf1, 0u, cnt, d_tb, (const float*)nullptr, src, ts, n_tiles, d_feats, d_P, 1, d_dyn, vstep); }, 16.0 * n);
   K1W(4) K1W(8) K1W(16)
