@@ -609,10 +609,11 @@ template int als_tiled_level<false>(fmx_engine*, fmx_matrix*, int, bool, double2
 // What bounds the three passes above is the one random 16-byte access per stored nonzero (the sums pass's gather: 13 M L2 requests and 92 us of a 181 us
 // level at configs[4], profiles/r04_pmc_summary_mcmc.json) PLUS two streaming passes over the pairs around it.  Here the (q, e) pairs are kept physically in
 // the list order of the level that consumes them next -- tile t's slice holds its rows sorted by (feature of level s, row) -- so that
-//   sums + step  als_order_sums_k   is a STREAM: a workgroup owns FB consecutive features of the level; inside a tile their lists are one contiguous run of
-//                                   pairs, which the workgroup copies into LDS (coalesced, 16 tiles' runs in flight) and whose lists its lane groups then walk
-//                                   there.  The sums of a feature never leave the workgroup: no per-tile partial sums, no separate step kernel -- the
-//                                   coordinate step of :318-336 is taken right there.  Fixed order (tile, entry), fixed lane-group combine: bitwise run to run.
+//   sums + step  als_order_sums_k   is a STREAM: a wave owns 16 consecutive features of the level; inside a tile their lists are one contiguous run of
+//                                   pairs (one load instruction), which the lanes add into the wave's own LDS accumulators by feature index.  The sums of
+//                                   a feature never leave the wave: no per-tile partial sums, no separate step kernel -- the coordinate step of :318-336 is
+//                                   taken right there.  Reproducible bit for bit (wave-owned accumulators, in-order LDS).  als_order_walk_k is the earlier
+//                                   form (a workgroup's runs staged through LDS, lists walked by lane groups): FMX_ALS_ORDER_SUMS=walk.
 //   apply        als_order_apply_k  reads the pairs in level s's order (stream), the feature's (v_old, diff) by the entry's feature index (neighbouring
 //                                   entries share it), corrects (:341-350) and writes each pair to its position in level s + 1's order: a permutation inside
 //                                   the tile's slice -- the one random 16-byte access per nonzero that is left.  A tile's workgroups share an XCD and there are
@@ -638,7 +639,7 @@ __device__ unsigned long long fmx_k1_ticks[8];
 // pairs (the host knows the longest (tile, feature) list), which halves the offsets' share of the LDS: four workgroups per CU instead of three, and TB = 256
 // tiles in one batch where the tiles are 65 536 rows.  MINW: workgroups per CU the register allocation is held to.
 template <bool UNIT, int FBMAX, int TB, int CH, int DEPTH, typename OT, int MINW>
-__global__ __launch_bounds__(WG_THREADS, MINW) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
+__global__ __launch_bounds__(WG_THREADS, MINW) void als_order_walk_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, int fb, const int64_t* __restrict__ tile_base,
                                                                const float* __restrict__ tval, const double2* __restrict__ src, int tshift, int n_tiles,
                                                                const uint32_t* __restrict__ feats, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
                                                                double2* __restrict__ vstep) {
@@ -820,6 +821,91 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void als_order_sums_k(const uint3
   vstep[fi] = make_double2(old, old - nv);
 }
 
+// The sums + step kernel the product takes [r5, last form]: ONE WAVE per 16 consecutive features of the level, one pair per lane per tile (the wave's run of a
+// tile is at most 64 pairs on regular data: one load instruction; longer runs: the rest in pieces of 64), the two sums of every feature kept in LDS
+// accumulators OWNED BY THE WAVE and fed by ds_add_f64.  No other wave ever touches them, a wave's LDS operations execute in order, and the lanes of ONE
+// instruction that hit the same accumulator are serialised by the LDS in a fixed order: the sums are reproducible bit for bit (tests: two sweeps, two engines),
+// in an association of their own like every other form (1e-10 against the oracle).  No list walk, no search, no barrier: per tile the run's bounds (three
+// offsets, two batches of tiles ahead), its pairs and feature indices (one batch ahead), ~30 instructions.  55 us per level at configs[4] against the
+// walking kernel's 65 (als_order_walk_k below, FMX_ALS_ORDER_SUMS=walk); what is left is the memory pattern itself (44-47 us with the adds knocked out:
+// profiles/r05_k1_atom_probe2.txt).
+template <bool UNIT, int NA, typename IT>
+__global__ __launch_bounds__(WG_THREADS) void als_order_sums_k(const uint32_t* __restrict__ toff, size_t nf1, uint32_t lvl0, uint32_t cnt, const int64_t* __restrict__ tile_base,
+                                                               const float* __restrict__ tval, const IT* __restrict__ fidx, const double2* __restrict__ src, int tshift,
+                                                               int n_tiles, const uint32_t* __restrict__ feats, double* __restrict__ P, int kp,
+                                                               const SweepDyn* __restrict__ dyn, double2* __restrict__ vstep) {
+  constexpr int WAVES = WG_THREADS / 64;
+  __shared__ double acc[WAVES][16][2];
+  __shared__ double oldv[WAVES][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t f0 = (blockIdx.x * WAVES + wv) * 16u;
+  if (f0 >= cnt) return;                          // (whole waves leave: nothing below synchronises across waves)
+  const uint32_t fend = min(f0 + 16u, cnt);
+  const int f = dyn->f;
+  if (lane < 16) {
+    const uint32_t fi = min(f0 + (uint32_t)lane, cnt - 1);
+    oldv[wv][lane] = P[(size_t)feats[fi] * kp + f];
+    acc[wv][lane][0] = 0.0; acc[wv][lane][1] = 0.0;
+  }
+  const uint32_t which = lane == 0 ? f0 : (lane == 1 ? fend : 0u);   // lanes 0, 1, 2 hold: the run's first offset, its end, the level block's first offset
+  struct Offs { uint32_t o[NA]; };
+  struct Run { double2 pv[NA]; float xv[NA]; uint32_t fx[NA], rl[NA]; size_t at0[NA]; int64_t x0[NA]; };
+  auto load_offs = [&](int t0, Offs& o) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int t = min(t0 + u, n_tiles - 1); o.o[u] = stream_load<true>(toff + (size_t)t * nf1 + lvl0 + which); }
+  };
+  auto load_run = [&](int t0, const Offs& o, Run& p) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int t = min(t0 + u, n_tiles - 1);
+      const uint32_t a = __builtin_amdgcn_readlane(o.o[u], 0), b = __builtin_amdgcn_readlane(o.o[u], 1), base = __builtin_amdgcn_readlane(o.o[u], 2);
+      p.rl[u] = t0 + u < n_tiles ? b - a : 0u;
+      p.at0[u] = ((size_t)t << tshift) + (a - base);              // the run's first pair (and feature index) in the level-ordered arrays
+      const uint32_t e = min((uint32_t)lane, p.rl[u] > 0 ? p.rl[u] - 1 : 0u);
+      p.pv[u] = stream_load<true>(src + p.at0[u] + e);
+      p.fx[u] = (uint32_t)stream_load<true>(fidx + p.at0[u] + e);
+      if (!UNIT) { p.x0[u] = tile_base[t] + (int64_t)a; p.xv[u] = stream_load<true>(tval + p.x0[u] + e); } else { p.x0[u] = 0; p.xv[u] = 1.0f; }
+    }
+  };
+  auto add = [&](double2 c, float x, uint32_t fx) {
+    const int g = (int)(fx - f0) & 15;
+    const float xx = x * x;
+    const double h = (double)x * c.x - (double)xx * oldv[wv][g];   // :310-317
+    unsafeAtomicAdd(&acc[wv][g][0], h * c.y);
+    unsafeAtomicAdd(&acc[wv][g][1], h * h);
+  };
+  Offs o_next, o_after; Run cur, nxt;
+  load_offs(0, o_next);
+  load_offs(NA, o_after);
+  load_run(0, o_next, cur);
+  for (int t0 = 0; t0 < n_tiles; t0 += NA) {
+    load_run(t0 + NA, o_after, nxt);              // (past the end: clamped addresses, empty runs)
+    load_offs(t0 + 2 * NA, o_next);
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      if ((uint32_t)lane < cur.rl[u]) add(cur.pv[u], cur.xv[u], cur.fx[u]);
+      if (cur.rl[u] > 64u)                        // a long run: the rest in pieces of 64, straight from memory
+        for (uint32_t i = 64u + lane; __any(i < cur.rl[u]); i += 64u)
+          if (i < cur.rl[u]) add(src[cur.at0[u] + i], UNIT ? 1.0f : tval[cur.x0[u] + i], (uint32_t)fidx[cur.at0[u] + i]);
+    }
+    cur = nxt; { const Offs tmp = o_after; o_after = o_next; o_next = tmp; }
+  }
+  if (lane >= 16 || f0 + (uint32_t)lane >= cnt) return;
+  const uint32_t fi = f0 + (uint32_t)lane;
+  const uint32_t feat = feats[fi];
+  double mean = acc[wv][lane][0], var = acc[wv][lane][1];
+  const double old = oldv[wv][lane];
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  mean -= old * var;                               // :318
+  var = 1.0 / (lambda + alpha * var);              // :319
+  mean = -var * (alpha * mean - mu * lambda);      // :320
+  const double nv = bad_number_t(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+  if (bad_number_t(nv)) { vstep[fi] = make_double2(old, nan("")); return; }  // CHECK_PARAM (:336): the old value stays; NaN tells the apply pass to leave the rows alone
+  P[(size_t)feat * kp + f] = nv;
+  vstep[fi] = make_double2(old, old - nv);
+}
+
 // blockIdx -> (tile, chunk) with a tile's workgroups consecutive in ONE XCD's share of the grid (as als_tile_sums_k)
 template <bool UNIT, int R, bool QNEXT, typename IT>
 __global__ __launch_bounds__(WG_THREADS) void als_order_apply_k(const double2* __restrict__ src, double2* __restrict__ dst, const IT* __restrict__ fidx, const uint32_t* __restrict__ perm,
@@ -928,7 +1014,7 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
   const bool narrow = (uint64_t)T->max_list * 63u <= 65535u;
 #define FMX_OSUMS(UNITv, TBv, OTv, MINWv)                                                                                                                   \
   do {                                                                                                                                                      \
-    auto kern = als_order_sums_k<UNITv, 64, TBv, 1024, 1, OTv, MINWv>;                                                                                        \
+    auto kern = als_order_walk_k<UNITv, 64, TBv, 1024, 1, OTv, MINWv>;                                                                                        \
     static int per_cu = 0;                                                                                                                                    \
     if (per_cu == 0) { int nbk = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, WG_THREADS, 0) == hipSuccess && nbk > 0) ? nbk : 2; }  \
     const uint32_t slots = (uint32_t)(per_cu * n_cus);                                                                                                        \
@@ -939,7 +1025,17 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
   } while (0)
 #define FMX_OSUMS_U(TBv, OTv, MINWv) do { if (T->unit) FMX_OSUMS(true, TBv, OTv, MINWv); else FMX_OSUMS(false, TBv, OTv, MINWv); } while (0)
   // (four workgroups per CU for the 128-tile / 16-bit form fit the LDS but cost register spills and bought nothing: 57.0 against 53.7 us, profiles/r05_order_ab11.txt)
-  if (T->n_tiles <= 128) { if (narrow) FMX_OSUMS_U(128, uint16_t, 3); else FMX_OSUMS_U(128, uint32_t, 3); }
+  static const bool walk = [] { const char* v = getenv("FMX_ALS_ORDER_SUMS"); return v && v[0] == 'w'; }();
+  if (!walk) {
+    // the product form: one wave per 16 features, wave-owned LDS accumulators (als_order_sums_k)
+    const dim3 sg((cnt + 63) / 64);
+    const void* fxs = (const char*)T->fidx + (size_t)s * T->n * (T->lfi16 ? 2 : 4);
+#define FMX_OATOM(UNITv, ITv) hipLaunchKernelGGL((als_order_sums_k<UNITv, 4, ITv>), sg, blk, 0, e->stream, (const uint32_t*)T->toff, nf1, lvl0, cnt, (const int64_t*)T->tile_base, \
+                                                 (const float*)T->tval, (const ITv*)fxs, src, T->tshift, T->n_tiles, (const uint32_t*)(T->feats + lvl0), e->dV, e->kp64, dyn, vstep)
+    if (T->unit) { if (T->lfi16) FMX_OATOM(true, uint16_t); else FMX_OATOM(true, uint32_t); }
+    else { if (T->lfi16) FMX_OATOM(false, uint16_t); else FMX_OATOM(false, uint32_t); }
+#undef FMX_OATOM
+  } else if (T->n_tiles <= 128) { if (narrow) FMX_OSUMS_U(128, uint16_t, 3); else FMX_OSUMS_U(128, uint32_t, 3); }
   else { if (narrow) FMX_OSUMS_U(256, uint16_t, 3); else FMX_OSUMS_U(256, uint32_t, 1); }
 #undef FMX_OSUMS_U
 #undef FMX_OSUMS
