@@ -751,6 +751,30 @@ __global__ __launch_bounds__(256) void k1_atom_k(const uint32_t* __restrict__ to
 }
 }  // namespace fmx
 
+
+// K2 with its source read in short pieces (what a feature-block-major array would give the apply kernel: a (tile, 16-feature block) piece is ~32-64 pairs):
+// thread i of a workgroup reads pair (piece(i / PL), i % PL) where the workgroup's 256 / PL pieces lie PSTRIDE pairs apart; the writes are K2's own scatter.
+template <int PL>
+__global__ __launch_bounds__(256) void apply_pieces_k(const double2* __restrict__ src, double2* __restrict__ dst, const uint16_t* __restrict__ fidx, const uint32_t* __restrict__ perm,
+                                                      const double2* __restrict__ vstep, int ts, int n_tiles, int B, int64_t n, int64_t pstride) {
+  const int b = blockIdx.x;
+  const int x = b & 7, q = b >> 3;
+  const int tile = (q / B) * 8 + x, chunk = q % B;
+  if (tile >= n_tiles) return;
+  const int64_t base = (int64_t)tile << ts;
+  const int64_t i = base + (int64_t)chunk * 256 + threadIdx.x;          // the entry whose perm / destination this thread handles (K2's own mapping)
+  // where its PAIR and feature index are read from: piece p of the workgroup, far from the others
+  const int p_ = threadIdx.x / PL, e_ = threadIdx.x % PL;
+  const int64_t at = (((int64_t)b * (256 / PL) + p_) * pstride + e_) % n;
+  const double2 c = ntload(src + at);
+  const uint32_t f = ntl(fidx + at);
+  const uint32_t pm = ntl(perm + (i < n ? i : n - 1));
+  const double2 s = vstep[f];
+  if (i >= n) return;
+  const double h = c.x - s.x;
+  dst[base + pm] = make_double2(c.x - s.y, c.y - h * s.y);
+}
+
 int main(int argc, char** argv) {
   const int ts = argc > 1 ? atoi(argv[1]) : 17;
   const int n_tiles = argc > 2 ? atoi(argv[2]) : 77;
@@ -909,6 +933,9 @@ int main(int argc, char** argv) {
       printf("K2(l) + K1(l+1) in %d tile groups on two streams: %.1f us per level\n", G, ms / (reps * 4) * 1e3);
     }
   }
+  { const int B = (int)(T / 256); const unsigned g = (unsigned)(((n_tiles + 7) / 8) * 8 * B);
+#define K2P(PLv) timeit("K2 apply+permute, source read in pieces of " #PLv " pairs", [&] { hipLaunchKernelGGL((apply_pieces_k<PLv>), dim3(g), dim3(256), 0, 0, src, dst, d_fidx, d_perm, vstep, ts, n_tiles, B, n, (int64_t)4999); }, 38.0 * n);
+    K2P(256) K2P(64) K2P(32) K2P(16) }
   // check: dst holds a permutation of the corrected pairs (sum of e preserved up to the corrections; here just a checksum of positions written)
   { std::vector<double2> h(n); CK(hipMemcpy(h.data(), dst, n * 16, hipMemcpyDeviceToHost)); int64_t zeros = 0; for (int64_t i = 0; i < n; ++i) zeros += (h[i].x == 0.0 && h[i].y == 0.0); printf("unwritten slots: %lld\n", (long long)zeros); }
   return 0;
