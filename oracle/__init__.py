@@ -3,6 +3,10 @@
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py -- never from fmwr_amd/ (tests/test_no_oracle_in_product.py
 enforces that).  Layouts follow the reference: V is factor-major [k][p] float64.
+
+PARITY UNPINNED for the training path in the contract's sense (see the header of fm_oracle.c): the reference holds no
+vectors for it and cannot be built here; the restatement is held by the reference-shipped probit tables, the FM identity
+of the reference's own test and independent property pins, and agrees with the survey session's Appendix-B literals.
 """
 import ctypes as C
 import os
