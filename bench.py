@@ -189,6 +189,16 @@ def e_unit(m):
     return bool(np.all(val == 1.0))
 
 
+def shape_tag(rows, features):
+    """'10Mx1M' for the configs' own shape, the actual dimensions otherwise (rehearsals and sweeps run smaller matrices through the same code)"""
+    def short(v):
+        for unit, name in ((1_000_000_000, "B"), (1_000_000, "M"), (1_000, "K")):
+            if v >= unit and v % unit == 0:
+                return f"{v // unit}{name}"
+        return str(v)
+    return f"{short(rows)}x{short(features)}"
+
+
 def cpu_model():
     """model string of the host CPU the cpu_baseline legs ran on ("state core count and CPU model")"""
     try:
@@ -636,7 +646,7 @@ def main_sweep(args, rank, local_rank, world):
             f"row-tiled: als_tile_sums_k ({n_tiles} tiles of {tile_rows} rows, each tile's (q, e) slice gathered from its XCD's L2) + als_tile_step_k + als_rows_apply_k (row-major corrections)"
             if tiled else "als_level_k (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q, e) per entry)")
     out = {
-        "metric": "V-sweep examples/sec, 10Mx1M sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
+        "metric": f"V-sweep examples/sec, {shape_tag(n, p)} sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
         "value": world * n * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {n}x{p}, {z} nnz/row, one column per stratum of [0, p) (fmx_matrix_synthetic: one-column-per-field data, the shape whose exact level "
@@ -811,7 +821,7 @@ def main_in_library(args):
     step_gbs = b_step / (dt / args.steps) / 1e9
     ginfo = e.group_info()
     return ({
-        "metric": f"training examples/sec, 10Mx1M sparse FM {args.solver.upper()}" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
+        "metric": f"training examples/sec, {shape_tag(args.rows, p)} sparse FM {args.solver.upper()}" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
         "value": done / dt, "unit": "examples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {args.rows}x{p}, {z} nnz/row, {'Criteo-shaped fields' if criteo else COLUMN_LAWS[args.columns]}, k={k}, {args.solver.upper()} mini-batch (BASELINE.json configs[{3 if criteo else (2 if ftrl else 1)}]{' shape, resident rows' if criteo else ''})",
@@ -1081,7 +1091,7 @@ def run_minibatch(args, rank, local_rank, world):
         step_gbs = b_step / (dt / args.steps) / 1e9   # per GPU: B rows of this rank per step
         traffic = per_kernel[dom]["traffic"]
         out = {
-            "metric": f"training examples/sec, 10Mx1M sparse FM {args.solver.upper()}" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
+            "metric": f"training examples/sec, {shape_tag(args.rows, p)} sparse FM {args.solver.upper()}" if not criteo else "training examples/sec, Criteo-shaped 33M-feature sparse FM SGD (configs[3] shape, resident rows)",
             "value": value, "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.state_fp64 else "f32", "data": "synthetic",
