@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libfmx.so")
-SOURCES = ["fmx_api.hip", "fm_batch_kernels.hip", "fm_seq_kernels.hip", "fm_ingest.hip", "fm_als_kernels.hip", "fm_als_tiled.hip", "fm_eval_kernels.hip", "fm_measure.hip", "fm_group.hip"]
+SOURCES = ["fmx_api.hip", "fm_batch_kernels.hip", "fm_seq_kernels.hip", "fm_ingest.hip", "fm_als_kernels.hip", "fm_als_tiled.hip", "fm_als_blocks.hip", "fm_eval_kernels.hip", "fm_measure.hip", "fm_group.hip"]
 HEADERS = [os.path.join(CSRC, "fmx_internal.h"), os.path.join(CSRC, "fm_probit.h"), os.path.join(CSRC, "fmx_test_hooks.h"), os.path.join(PKG, "..", "include", "fmx.h")]
 # -ffp-contract=off: the fp64 update formulas keep the reference's operation order (no FMA fusion)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",

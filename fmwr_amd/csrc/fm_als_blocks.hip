@@ -1,0 +1,396 @@
+// The BLOCK form of the level-order V sweep (MCMC_ALS_Learner::update_v, solver/MCMC_ALS_Learner.h:283-351): ONE kernel per level of one factor.
+//
+// The tile form (fm_als_tiled.hip, als_order_*) keeps the (q, e) pairs tile-major and needs two kernels per level with a chip-wide wait between them: the sums of a
+// feature come from every tile, so the pairs are read twice (sums, then corrections), and the permuting scatter of the corrections is 16 bytes at a time.
+// Here the level's array is FEATURE-BLOCK-MAJOR: the features of a level are cut into blocks of consecutive features holding at most R rows between them
+// (R = 8 192 pairs = 128 KB: one workgroup's LDS), and block B's region of the array holds exactly the rows of its features.  Everything a coordinate step of a
+// feature needs is then inside ONE workgroup:
+//   1. the block's region streams in (contiguous), every pair lands in LDS at its feature-sorted slot (u16 per pair: `perm_in`);
+//   2. lane groups sum their lists out of LDS (Sum h e, Sum h^2, :310-317), take the coordinate steps (:318-336) and correct their lists in place (:341-350): the
+//      sums never leave the workgroup, the pairs are read from memory ONCE per level, and nothing waits for another workgroup;
+//   3. the corrected pairs leave for the NEXT level's array, in which block B' keeps what it receives from block B as one contiguous RUN: the workgroup reads
+//      its pairs back out of LDS in destination order (u16 per pair: `gsrc`) and stores them at consecutive addresses run by run (u32 per pair: `dest`).
+// The runs are short (R^2 / n pairs: 6.7 at configs[4]) and unaligned; consecutive blocks run at the same time on the same XCD (blockIdx -> block below), so
+// the neighbouring runs of a line meet in that L2.  Measured before building (profiles/probes/block_level_probe.hip, profiles/r05_block_probe.txt): 89 us per
+// level at configs[4]'s shape against 59 + 96 us of the tile form's two kernels; a plain copy of the pairs takes 53 us.
+//
+// Arithmetic per entry as in every other form; the sums of a list are associated in (lane of the group, then butterfly) order over the list's rows ascending:
+// 1e-10 against the oracle and the other forms, bitwise run to run (tests/test_gpu_configs4.py).
+#include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
+#include <memory>
+
+#include <rocprim/rocprim.hpp>
+
+#include "fmx_internal.h"
+
+namespace fmx {
+
+namespace {
+
+constexpr int BLK_THREADS = 1024;
+constexpr int BLK_MAXF = 1024;       // most features in one block (their old values, ids and list bounds live in LDS)
+constexpr int BLK_R_UNIT = 8192;     // pairs per block: 128 KB of LDS
+constexpr int BLK_R_VAL = 6144;      // with a value per entry next to the pair: 96 + 24 KB
+
+struct AlsBlocks {
+  int64_t n = 0;
+  int L = 0, R = 0, unit = 0;
+  std::vector<uint32_t> nblk;     // per level
+  std::vector<size_t> boff;       // per level: first entry of the level in bbase / bfeat (nblk + 1 entries each)
+  std::vector<size_t> foff;       // per level: first entry of the level in loff (cnt + 1 entries each)
+  std::vector<int> lg;            // per level: lanes per list
+  uint32_t* bbase = nullptr;      // first position of every block in its level's array (= rows of the features before it)
+  uint32_t* bfeat = nullptr;      // first feature (index inside the level) of every block
+  uint32_t* loff = nullptr;       // per level [cnt + 1]: first position of every feature's list in slot order (feature-major, rows ascending)
+  uint16_t* perm_in = nullptr;    // [L][n] LDS slot of the pair at array position i (inside its block)
+  uint16_t* gsrc = nullptr;       // [L][n] per block, in destination order: the LDS slot ...
+  uint32_t* dest = nullptr;       // [L][n] ... and the position in the next level's array
+  float* xs = nullptr;            // [L][n] entry values in slot order (null: every value is 1.0f)
+  uint32_t* row0 = nullptr;       // [n] row at position i of level 0's array
+  uint32_t* drow = nullptr;       // [n] last level, destination order: the row (the next factor's q is gathered by it)
+  ~AlsBlocks() {
+    (void)hipFree(bbase); (void)hipFree(bfeat); (void)hipFree(loff); (void)hipFree(perm_in); (void)hipFree(gsrc); (void)hipFree(dest); (void)hipFree(xs);
+    (void)hipFree(row0); (void)hipFree(drow);
+  }
+};
+
+int env_int_b(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s && *s ? atoi(s) : dflt;
+}
+
+// ---- plan kernels ----------------------------------------------------------------------------------------------------------------------------
+// one wave per feature of the level: block and slot of every row of its list, the values in slot order
+__global__ __launch_bounds__(256) void blocks_rows_k(const uint32_t* __restrict__ feats, uint32_t cnt, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
+                                                     const float* __restrict__ cval, const uint32_t* __restrict__ loff, const uint16_t* __restrict__ blk_of_feat,
+                                                     const uint32_t* __restrict__ bbase, uint16_t* __restrict__ blkrow, uint16_t* __restrict__ slotrow, float* __restrict__ xs) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t fi = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  if (fi >= cnt) return;
+  const uint32_t j = feats[fi];
+  const int64_t b = col_ptr[j], e = col_ptr[j + 1];
+  const uint16_t blk = blk_of_feat[fi];
+  const uint32_t l0 = loff[fi], bb = bbase[blk];
+  for (int64_t t = b + lane; t < e; t += 64) {
+    const uint32_t r = crow[t];
+    blkrow[r] = blk;
+    slotrow[r] = (uint16_t)(l0 + (uint32_t)(t - b) - bb);
+    if (xs) xs[l0 + (uint32_t)(t - b)] = cval[t];
+  }
+}
+__global__ void blocks_keys_k(const uint16_t* __restrict__ blk_s, const uint16_t* __restrict__ blk_prev, int64_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  keys[r] = ((uint32_t)blk_s[r] << 16) | (uint32_t)blk_prev[r];
+  vals[r] = (uint32_t)r;
+}
+// perm_in[i] = slot of the row at position i
+__global__ void blocks_place_k(const uint32_t* __restrict__ rowat, const uint16_t* __restrict__ slotrow, int64_t n, uint16_t* __restrict__ perm_in) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  perm_in[i] = slotrow[rowat[i]];
+}
+// keys of the destination order: the block (this level) of the row at position i of the NEXT level's array
+__global__ void blocks_keys2_k(const uint32_t* __restrict__ rowat_next, const uint16_t* __restrict__ blk_s, int64_t n, uint16_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = blk_s[rowat_next[i]];
+  vals[i] = (uint32_t)i;
+}
+__global__ void blocks_dest_k(const uint32_t* __restrict__ sorted_pos, const uint32_t* __restrict__ rowat_next, const uint16_t* __restrict__ slotrow, int64_t n,
+                              uint32_t* __restrict__ dest, uint16_t* __restrict__ gsrc, uint32_t* __restrict__ drow) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t d = sorted_pos[k], r = rowat_next[d];
+  dest[k] = d;
+  gsrc[k] = slotrow[r];
+  if (drow) drow[k] = r;
+}
+
+// ---- the sweep -------------------------------------------------------------------------------------------------------------------------------
+typedef double blk_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_pair(const double2* p) { const blk_v2d v = __builtin_nontemporal_load(reinterpret_cast<const blk_v2d*>(p)); return make_double2(v.x, v.y); }
+template <typename T> __device__ __forceinline__ T nt_ld(const T* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ bool bad_number_b(double x) { return isnan(x) || isinf(x); }
+
+// blockIdx -> block: consecutive blocks share an XCD (workgroups are dealt round-robin over the eight XCDs) and run there at about the same time, so the runs
+// that neighbouring blocks write into one line of the next level's array meet in that XCD's L2 (73 against 89 us per level in the probe).  Placement is for
+// speed only.
+template <bool UNIT, int R, int LG, bool QNEXT>
+__global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* __restrict__ src, double2* __restrict__ dst, const uint32_t* __restrict__ bbase,
+                                                                 const uint32_t* __restrict__ bfeat, int nb, const uint32_t* __restrict__ loff, const uint32_t* __restrict__ feats,
+                                                                 const uint16_t* __restrict__ perm_in, const uint16_t* __restrict__ gsrc, const uint32_t* __restrict__ dest,
+                                                                 const float* __restrict__ xs, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                                                 const double* __restrict__ qnext, const uint32_t* __restrict__ drow, uint32_t n) {
+  constexpr int NT = BLK_THREADS, PT = R / NT, NG = NT / LG;
+  static_assert(R % NT == 0, "whole pairs per thread");
+  __shared__ double2 lp[R];
+  __shared__ float lx[UNIT ? 1 : R];
+  __shared__ double oldv[BLK_MAXF];
+  __shared__ uint32_t lfeat[BLK_MAXF];
+  __shared__ uint16_t lo[BLK_MAXF + 2];
+  const int per = (nb + 7) >> 3;
+  const int B = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (B >= nb) return;
+  const uint32_t b0 = bbase[B], rows = bbase[B + 1] - b0;
+  const uint32_t f0 = bfeat[B], nf = bfeat[B + 1] - f0;
+  const int f = dyn->f;
+  double2 v[PT]; uint16_t pa[PT], gs[PT]; uint32_t de[PT]; float xv[PT]; double qn[PT];
+  // every load goes out before anything is used; positions past the block's end are clamped onto its last pair (nothing of them is stored)
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const uint32_t i = threadIdx.x + u * NT, ic = min(b0 + min(i, rows ? rows - 1 : 0u), n - 1);   // (an empty block: features without rows still take their step)
+    v[u] = nt_pair(src + ic);
+    pa[u] = nt_ld(perm_in + ic);
+    xv[u] = UNIT ? 1.0f : nt_ld(xs + ic);
+  }
+  if (threadIdx.x < nf) {
+    const uint32_t ft = feats[f0 + threadIdx.x];
+    lfeat[threadIdx.x] = ft;
+    oldv[threadIdx.x] = P[(size_t)ft * kp + f];
+  }
+  if (threadIdx.x <= nf) lo[threadIdx.x] = (uint16_t)(loff[f0 + threadIdx.x] - b0);
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const uint32_t i = threadIdx.x + u * NT, ic = min(b0 + min(i, rows ? rows - 1 : 0u), n - 1);
+    gs[u] = nt_ld(gsrc + ic);
+    de[u] = nt_ld(dest + ic);
+    qn[u] = QNEXT ? qnext[nt_ld(drow + ic)] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const uint32_t i = threadIdx.x + u * NT;
+    if (i < rows) { lp[pa[u]] = v[u]; if (!UNIT) lx[i] = xv[u]; }
+  }
+  __syncthreads();
+  {
+    const int g = threadIdx.x / LG, l = threadIdx.x % LG;
+    const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+    const double* __restrict__ znorm = dyn->znorm;
+    for (uint32_t fi = g; fi < nf; fi += NG) {
+      const uint32_t a = lo[fi], b = lo[fi + 1];
+      const double old = oldv[fi];
+      double mean = 0.0, var = 0.0;
+      for (uint32_t t0 = a + l; t0 < b; t0 += 4 * LG) {
+        double2 c[4]; float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float xx = x[u] * x[u];
+          const double h = (double)x[u] * c[u].x - (double)xx * old;   // :310-317
+          if (t0 + u * LG < b) { mean += h * c[u].y; var += h * h; }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < LG; o <<= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }   // (a + b == b + a: every lane of the group holds the same bits)
+      mean -= old * var;                               // :318
+      var = 1.0 / (lambda + alpha * var);              // :319
+      mean = -var * (alpha * mean - mu * lambda);      // :320
+      const uint32_t feat = lfeat[fi];
+      const double nv = bad_number_b(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+      if (bad_number_b(nv)) continue;                  // CHECK_PARAM (:336): the old value stays and the rows keep their pairs
+      if (l == 0) P[(size_t)feat * kp + f] = nv;
+      const double diff = old - nv;
+      for (uint32_t t0 = a + l; t0 < b; t0 += 4 * LG) {
+        double2 c[4]; float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float xx = x[u] * x[u];
+          const double h = (double)x[u] * c[u].x - (double)xx * old;
+          if (t0 + u * LG < b) lp[t0 + u * LG] = make_double2(c[u].x - (double)x[u] * diff, c[u].y - h * diff);   // :341-350
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const uint32_t i = threadIdx.x + u * NT;
+    if (i < rows) { double2 c = lp[gs[u]]; if (QNEXT) c.x = qn[u]; dst[de[u]] = c; }
+  }
+}
+
+// row order -> level 0's array (q of the first factor from the factor-major table, e from the pairs) and back
+__global__ void als_block_enter_k(const double2* __restrict__ qe, const double* __restrict__ Q0, const uint32_t* __restrict__ row0, int64_t n, double2* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = row0[i];
+  dst[i] = make_double2(Q0[r], qe[r].y);
+}
+__global__ void als_block_exit_k(const double2* __restrict__ src, const uint32_t* __restrict__ row0, int64_t n, double2* __restrict__ qe) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  qe[row0[i]] = src[i];
+}
+
+}  // namespace
+
+void als_blocks_free(void* b) { delete reinterpret_cast<AlsBlocks*>(b); }
+
+// *out stays null where the form does not apply (a list longer than a block, too many blocks, no memory): never an error
+int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream_t stream) {
+  *out = nullptr;
+  const int64_t n = in.n;
+  const int L = in.n_slots;
+  if (L < 1 || n < 1 || n >= (1LL << 32)) return FMX_OK;
+  std::unique_ptr<AlsBlocks> Bk(new AlsBlocks());
+  Bk->n = n; Bk->L = L; Bk->unit = in.unit;
+  int R = in.unit ? BLK_R_UNIT : BLK_R_VAL;
+  const int r_env = env_int_b("FMX_ALS_BLOCK_ROWS", 0);   // (tests: several blocks on a small matrix; at most the kernel's capacity)
+  if (r_env > 0 && r_env < R) R = r_env;
+  Bk->R = R;
+  const int maxf = BLK_MAXF - 1;   // (thread nf of the workgroup loads the end of the last list: nf < BLK_THREADS)
+  // list lengths of every feature (the CSC's column pointers), blocks by greedy filling
+  std::vector<int64_t> cp((size_t)m->p + 1);
+  FMX_HIP(hipMemcpy(cp.data(), m->col_ptr, cp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  size_t n_feats = 0;
+  for (int s = 0; s < L; ++s) n_feats += in.cnt[s];
+  std::vector<uint32_t> h_loff(n_feats + (size_t)L), h_bbase, h_bfeat;
+  std::vector<uint16_t> h_blk_of_feat(n_feats);
+  Bk->nblk.assign((size_t)L, 0u); Bk->boff.assign((size_t)L, 0); Bk->foff.assign((size_t)L, 0); Bk->lg.assign((size_t)L, 64);
+  size_t fo = 0;
+  for (int s = 0; s < L; ++s) {
+    const uint32_t cnt = in.cnt[s];
+    const uint32_t* fs = in.h_feats + in.lvl0[s];
+    Bk->foff[(size_t)s] = fo;
+    Bk->boff[(size_t)s] = h_bbase.size();
+    uint64_t at = 0; uint32_t in_block = 0, feats_in_block = 0, nb = 0;
+    h_bbase.push_back(0u); h_bfeat.push_back(0u);
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const int64_t len = cp[(size_t)fs[i] + 1] - cp[(size_t)fs[i]];
+      if (len > R) return FMX_OK;                       // a list that no block holds: the tile form keeps this matrix
+      if (in_block + len > (uint32_t)R || feats_in_block == (uint32_t)maxf) {
+        h_bbase.push_back((uint32_t)at); h_bfeat.push_back(i); ++nb; in_block = 0; feats_in_block = 0;
+      }
+      h_loff[fo + i] = (uint32_t)at;
+      if (nb > 65534u) return FMX_OK;
+      h_blk_of_feat[fo - (size_t)s + i] = (uint16_t)nb;
+      at += (uint64_t)len; in_block += (uint32_t)len; ++feats_in_block;
+    }
+    if (at != (uint64_t)n) return FMX_OK;               // (a complete plan: every row once per level)
+    h_loff[fo + cnt] = (uint32_t)at;
+    h_bbase.push_back((uint32_t)at); h_bfeat.push_back(cnt); ++nb;
+    Bk->nblk[(size_t)s] = nb;
+    const double avg = cnt ? (double)n / cnt : 0.0;
+    Bk->lg[(size_t)s] = avg >= 48.0 ? 64 : (avg >= 12.0 ? 16 : (avg >= 3.0 ? 4 : 1));
+    fo += (size_t)cnt + 1;
+  }
+  // (h_blk_of_feat is indexed by feature position over all levels: fo - s = features before the level)
+  auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
+  struct Tmp {
+    uint16_t *blk_of_feat = nullptr, *blkrow = nullptr, *slotrow = nullptr, *keys16 = nullptr, *keys16o = nullptr;
+    uint32_t *rowat = nullptr, *keys = nullptr, *keys_o = nullptr, *vals = nullptr, *vals_o = nullptr;
+    void* sort_ws = nullptr;
+    ~Tmp() { (void)hipFree(blk_of_feat); (void)hipFree(blkrow); (void)hipFree(slotrow); (void)hipFree(keys16); (void)hipFree(keys16o); (void)hipFree(rowat); (void)hipFree(keys);
+             (void)hipFree(keys_o); (void)hipFree(vals); (void)hipFree(vals_o); (void)hipFree(sort_ws); }
+  } w;
+  const size_t sn = (size_t)L * (size_t)n;
+  size_t ws1 = 0, ws2 = 0;
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, ws1, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32, stream));
+  FMX_HIP(rocprim::radix_sort_pairs(nullptr, ws2, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 16, stream));
+  const size_t ws = ws1 > ws2 ? ws1 : ws2;
+  if (!ok(hipMalloc(&Bk->bbase, h_bbase.size() * 4)) || !ok(hipMalloc(&Bk->bfeat, h_bfeat.size() * 4)) || !ok(hipMalloc(&Bk->loff, h_loff.size() * 4)) ||
+      !ok(hipMalloc(&Bk->perm_in, sn * 2)) || !ok(hipMalloc(&Bk->gsrc, sn * 2)) || !ok(hipMalloc(&Bk->dest, sn * 4)) || (!in.unit && !ok(hipMalloc(&Bk->xs, sn * 4))) ||
+      !ok(hipMalloc(&Bk->row0, (size_t)n * 4)) || !ok(hipMalloc(&Bk->drow, (size_t)n * 4)) ||
+      !ok(hipMalloc(&w.blk_of_feat, (n_feats ? n_feats : 1) * 2)) || !ok(hipMalloc(&w.blkrow, sn * 2)) || !ok(hipMalloc(&w.slotrow, sn * 2)) || !ok(hipMalloc(&w.rowat, sn * 4)) ||
+      !ok(hipMalloc(&w.keys, (size_t)n * 4)) || !ok(hipMalloc(&w.keys_o, (size_t)n * 4)) || !ok(hipMalloc(&w.vals, (size_t)n * 4)) || !ok(hipMalloc(&w.vals_o, (size_t)n * 4)) ||
+      !ok(hipMalloc(&w.keys16, (size_t)n * 2)) || !ok(hipMalloc(&w.keys16o, (size_t)n * 2)) || !ok(hipMalloc(&w.sort_ws, ws ? ws : 16)))
+    return FMX_OK;
+  FMX_HIP(hipMemcpyAsync(Bk->bbase, h_bbase.data(), h_bbase.size() * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemcpyAsync(Bk->bfeat, h_bfeat.data(), h_bfeat.size() * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemcpyAsync(Bk->loff, h_loff.data(), h_loff.size() * 4, hipMemcpyHostToDevice, stream));
+  FMX_HIP(hipMemcpyAsync(w.blk_of_feat, h_blk_of_feat.data(), n_feats * 2, hipMemcpyHostToDevice, stream));
+  const unsigned row_grid = (unsigned)((n + 255) / 256);
+  size_t feats_before = 0;
+  for (int s = 0; s < L; ++s) {
+    const uint32_t cnt = in.cnt[s];
+    hipLaunchKernelGGL(blocks_rows_k, dim3((unsigned)(((size_t)cnt * 64 + 255) / 256)), dim3(256), 0, stream, in.d_feats + in.lvl0[s], cnt, (const int64_t*)m->col_ptr,
+                       (const uint32_t*)m->crow, (const float*)m->cval, (const uint32_t*)(Bk->loff + Bk->foff[(size_t)s]), (const uint16_t*)(w.blk_of_feat + feats_before),
+                       (const uint32_t*)(Bk->bbase + Bk->boff[(size_t)s]), w.blkrow + (size_t)s * n, w.slotrow + (size_t)s * n, Bk->xs ? Bk->xs + (size_t)s * n : nullptr);
+    feats_before += cnt;
+  }
+  // every level's array order: rows by (block at the level, block at the level before (cyclic: level 0 follows the last level), row)
+  for (int s = 0; s < L; ++s) {
+    const int sp = s > 0 ? s - 1 : L - 1;
+    hipLaunchKernelGGL(blocks_keys_k, dim3(row_grid), dim3(256), 0, stream, (const uint16_t*)(w.blkrow + (size_t)s * n), (const uint16_t*)(w.blkrow + (size_t)sp * n), n, w.keys, w.vals);
+    size_t wsz = ws;
+    FMX_HIP(rocprim::radix_sort_pairs(w.sort_ws, wsz, w.keys, w.keys_o, w.vals, w.rowat + (size_t)s * n, (size_t)n, 0, 32, stream));
+    hipLaunchKernelGGL(blocks_place_k, dim3(row_grid), dim3(256), 0, stream, (const uint32_t*)(w.rowat + (size_t)s * n), (const uint16_t*)(w.slotrow + (size_t)s * n), n,
+                       Bk->perm_in + (size_t)s * n);
+  }
+  // every block's destination order: its rows by their position in the next level's array
+  for (int s = 0; s < L; ++s) {
+    const int sn_ = s + 1 < L ? s + 1 : 0;
+    const uint32_t* rowat_next = w.rowat + (size_t)sn_ * n;
+    hipLaunchKernelGGL(blocks_keys2_k, dim3(row_grid), dim3(256), 0, stream, rowat_next, (const uint16_t*)(w.blkrow + (size_t)s * n), n, w.keys16, w.vals);
+    size_t wsz = ws;
+    FMX_HIP(rocprim::radix_sort_pairs(w.sort_ws, wsz, w.keys16, w.keys16o, w.vals, w.vals_o, (size_t)n, 0, 16, stream));
+    hipLaunchKernelGGL(blocks_dest_k, dim3(row_grid), dim3(256), 0, stream, (const uint32_t*)w.vals_o, rowat_next, (const uint16_t*)(w.slotrow + (size_t)s * n), n,
+                       Bk->dest + (size_t)s * n, Bk->gsrc + (size_t)s * n, s == L - 1 ? Bk->drow : nullptr);
+  }
+  FMX_HIP(hipMemcpyAsync(Bk->row0, w.rowat, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  FMX_HIP(hipGetLastError());
+  FMX_HIP(hipStreamSynchronize(stream));
+  *out = Bk.release();
+  return FMX_OK;
+}
+
+int als_blocks_info(const void* b, int32_t* block_rows, int32_t* blocks_level0) {
+  const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
+  if (block_rows) *block_rows = Bk ? Bk->R : 0;
+  if (blocks_level0) *blocks_level0 = Bk && !Bk->nblk.empty() ? (int32_t)Bk->nblk[0] : 0;
+  return FMX_OK;
+}
+
+int als_blocks_enter(fmx_engine* e, const void* b, const double2* d_qe, const double* d_Q0, double2* dst) {
+  const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
+  hipLaunchKernelGGL(als_block_enter_k, dim3((unsigned)((Bk->n + 255) / 256)), dim3(256), 0, e->stream, d_qe, d_Q0, (const uint32_t*)Bk->row0, Bk->n, dst);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe) {
+  const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
+  hipLaunchKernelGGL(als_block_exit_k, dim3((unsigned)((Bk->n + 255) / 256)), dim3(256), 0, e->stream, src, (const uint32_t*)Bk->row0, Bk->n, d_qe);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+// one level (slot s) of one factor; d_feats: the level's feature ids; d_qnext (row order): the last level of a factor that has a successor
+int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qnext) {
+  const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
+  const int nb = (int)Bk->nblk[(size_t)s];
+  const dim3 grid((unsigned)(((nb + 7) / 8) * 8)), blk(BLK_THREADS);
+  const uint32_t* bbase = Bk->bbase + Bk->boff[(size_t)s];
+  const uint32_t* bfeat = Bk->bfeat + Bk->boff[(size_t)s];
+  const uint32_t* loff = Bk->loff + Bk->foff[(size_t)s];
+  const uint16_t* pin = Bk->perm_in + (size_t)s * Bk->n;
+  const uint16_t* gs = Bk->gsrc + (size_t)s * Bk->n;
+  const uint32_t* de = Bk->dest + (size_t)s * Bk->n;
+  const float* xs = Bk->xs ? Bk->xs + (size_t)s * Bk->n : nullptr;
+  FMX_CHECK(!d_qnext || s == Bk->L - 1, FMX_ERR_STATE, "the next factor's q is folded into a factor's LAST level");
+#define FMX_BLK(UNITv, Rv, LGv, QNv)                                                                                                                              \
+  hipLaunchKernelGGL((als_block_level_k<UNITv, Rv, LGv, QNv>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, e->dV, e->kp64, dyn, d_qnext, \
+                     (const uint32_t*)Bk->drow, (uint32_t)Bk->n)
+#define FMX_BLK_Q(UNITv, Rv, LGv) do { if (d_qnext) FMX_BLK(UNITv, Rv, LGv, true); else FMX_BLK(UNITv, Rv, LGv, false); } while (0)
+#define FMX_BLK_L(UNITv, Rv)                                                                                                                                      \
+  do {                                                                                                                                                            \
+    switch (Bk->lg[(size_t)s]) {                                                                                                                                  \
+      case 64: FMX_BLK_Q(UNITv, Rv, 64); break;                                                                                                                   \
+      case 16: FMX_BLK_Q(UNITv, Rv, 16); break;                                                                                                                   \
+      case 4: FMX_BLK_Q(UNITv, Rv, 4); break;                                                                                                                     \
+      default: FMX_BLK_Q(UNITv, Rv, 1); break;                                                                                                                    \
+    }                                                                                                                                                             \
+  } while (0)
+  if (Bk->unit) FMX_BLK_L(true, BLK_R_UNIT); else FMX_BLK_L(false, BLK_R_VAL);
+#undef FMX_BLK_L
+#undef FMX_BLK_Q
+#undef FMX_BLK
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+
+}  // namespace fmx

@@ -55,7 +55,9 @@ struct AlsTiled {
   uint32_t max_list = 0;         // longest (tile, feature) list of the plan (decides whether the sums kernel may keep its offsets in 16 bits)
   uint32_t* perm = nullptr;      // [n_slots][n] position, inside the same tile, that the row at position i of level s's order has in the order of level s + 1 (cyclic)
   void* fidx = nullptr;          // [n_slots][n] index (inside its level) of the feature whose list position i belongs to (u16 / u32 like lfi)
+  void* blocks = nullptr;        // the BLOCK form of the level-order sweep (fm_als_blocks.hip), where it applies: perm / fidx are not built then
   ~AlsTiled() {
+    als_blocks_free(blocks);
     (void)hipFree(feats); (void)hipFree(lfi); (void)hipFree(lval); (void)hipFree(toff); (void)hipFree(tile_base); (void)hipFree(trow); (void)hipFree(tval);
     (void)hipFree(perm); (void)hipFree(fidx);
   }
@@ -131,7 +133,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 struct AlsTiled;
-static int order_build(fmx_matrix* m, AlsTiled* T, hipStream_t stream);
+static int order_build(fmx_matrix* m, AlsTiled* T, const std::vector<uint32_t>& h_feats, hipStream_t stream);
 
 // Which levels of the exact plan go through the tiled form, and their plan.  Called at the end of build_plan (the CSC and the levels exist).
 // A failure to allocate -- here, or of the sweep's workspace later (als_tiled_level drops the plan then) -- leaves the matrix without a tiled plan (the
@@ -237,7 +239,7 @@ int als_tiled_build(fmx_matrix* m, hipStream_t stream) {
   hipLaunchKernelGGL(tiled_scatter_k, dim3(col_grid), dim3(WG_THREADS), 0, stream, m->col_ptr, m->crow, m->cval, w.rank_of, p, ts, nf1, T->toff, T->tile_base, T->trow, T->tval);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipStreamSynchronize(stream));
-  FMX_TRY(order_build(m, T.get(), stream));
+  FMX_TRY(order_build(m, T.get(), feats, stream));
   m->als_tiled = T.release();
   return FMX_OK;
 }
@@ -284,8 +286,9 @@ __global__ void order_perm_k(const uint32_t* __restrict__ trow, const int64_t* _
 
 // Called at the end of als_tiled_build: the extra arrays of the level-order form where the plan is complete.  Any failure (incomplete plan, no memory) just
 // leaves the form unavailable.  FMX_ALS_ORDER=0 switches it off (A/B runs, and the tests that compare the forms).
-static int order_build(fmx_matrix* m, AlsTiled* T, hipStream_t stream) {
-  if (env_int("FMX_ALS_ORDER", 1) == 0) return FMX_OK;
+static int order_build(fmx_matrix* m, AlsTiled* T, const std::vector<uint32_t>& h_feats, hipStream_t stream) {
+  const int order_env = env_int("FMX_ALS_ORDER", 2);   // 0: never, 1: the tile form, 2 (default): the block form where it applies, else the tile form
+  if (order_env == 0) return FMX_OK;
   const int L = (int)m->als_level_ptr.size() - 1;
   int nonempty = 0;
   for (int l = 0; l < L; ++l) {
@@ -307,6 +310,11 @@ static int order_build(fmx_matrix* m, AlsTiled* T, hipStream_t stream) {
   FMX_HIP(hipMemcpyAsync(&bad, w.bad, sizeof(int), hipMemcpyDeviceToHost, stream));
   FMX_HIP(hipStreamSynchronize(stream));
   if (bad) return FMX_OK;   // some row lacks a level (or holds two features of one): the level blocks are not the tiles' rows
+  if (order_env != 1) {
+    const AlsBlocksIn in{m->n, T->n_slots, T->lvl0.data(), T->cnt.data(), h_feats.data(), T->feats, T->unit};
+    FMX_TRY(als_blocks_build(m, in, &T->blocks, stream));
+    if (T->blocks) { T->complete = 1; return FMX_OK; }
+  }
   if (!ok(hipMalloc(&w.inv, sn * 4)) || !ok(hipMalloc(&T->perm, sn * 4)) || !ok(hipMalloc(&T->fidx, sn * isz))) {
     (void)hipFree(T->perm); (void)hipFree(T->fidx); T->perm = nullptr; T->fidx = nullptr;
     return FMX_OK;
@@ -984,6 +992,13 @@ int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const dou
   *ok = false;
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
   if (!T || !T->complete) return FMX_OK;
+  if (T->blocks) {
+    if (order_buffers(e, m->n) != FMX_OK) { (void)hipGetLastError(); return FMX_OK; }
+    FMX_TRY(als_blocks_enter(e, T->blocks, d_qe, d_Q0, reinterpret_cast<double2*>(e->als_lo[0])));
+    e->als_lo_cur = 0;
+    *ok = true;
+    return FMX_OK;
+  }
   double2* ws_partial; double* ws_vf; double2* vstep;
   if (order_buffers(e, m->n) != FMX_OK || tile_ws(e, T, &ws_partial, &ws_vf, &vstep) != FMX_OK) { (void)hipGetLastError(); return FMX_OK; }
   hipLaunchKernelGGL(als_order_enter_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, d_qe, d_Q0, (const uint32_t*)T->trow, (const int64_t*)T->tile_base, m->n, T->tshift,
@@ -997,6 +1012,12 @@ int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const dou
 // of a factor that has a successor
 int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, const double* d_qnext) {
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (T->blocks) {
+    FMX_TRY(als_blocks_level(e, T->blocks, s, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), reinterpret_cast<double2*>(e->als_lo[1 - e->als_lo_cur]),
+                             T->feats + T->lvl0[(size_t)s], dyn, d_qnext));
+    e->als_lo_cur = 1 - e->als_lo_cur;
+    return FMX_OK;
+  }
   double2 *partial = nullptr, *vstep = nullptr; double* vf = nullptr;
   FMX_TRY(tile_ws(e, T, &partial, &vf, &vstep));
   const uint32_t lvl0 = T->lvl0[(size_t)s], cnt = T->cnt[(size_t)s];
@@ -1066,6 +1087,11 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
   return FMX_OK;
 }
 
+int als_order_form(const fmx_matrix* m) {
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  return (T && T->complete && !m->als_approx) ? (T->blocks ? 2 : 1) : 0;
+}
+
 int als_order_levels(const fmx_matrix* m) {
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
   return T ? T->n_slots : 0;
@@ -1074,6 +1100,7 @@ int als_order_levels(const fmx_matrix* m) {
 // exit: the current buffer (level 0's order: the last apply of the last factor wrote there) back to d_qe in row order
 int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe) {
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (T->blocks) return als_blocks_exit(e, T->blocks, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), d_qe);
   hipLaunchKernelGGL(als_order_exit_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), (const uint32_t*)T->trow,
                      (const int64_t*)T->tile_base, m->n, T->tshift, d_qe);
   FMX_HIP(hipGetLastError());

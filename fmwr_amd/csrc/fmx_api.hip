@@ -1948,7 +1948,7 @@ int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order) {
   FMX_CHECK(level_order != nullptr, FMX_ERR_INVALID, "NULL argument");
   FMX_TRY(use_device(e->cfg.device));
   FMX_TRY(als_plan_info(e, m, nullptr, nullptr, nullptr, nullptr));
-  *level_order = als_order_ready(m) ? 1 : 0;
+  *level_order = als_order_form(m);   // 0: none, 1: the tile form, 2: the block form (fm_als_blocks.hip)
   return FMX_OK;
 }
 

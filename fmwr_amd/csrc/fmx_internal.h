@@ -577,6 +577,22 @@ int als_order_levels(const fmx_matrix* m);
 int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const double* d_Q0, bool* ok);
 int als_order_level(fmx_engine* e, fmx_matrix* m, int slot, const SweepDyn* dyn, const double* d_qnext);
 int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe);
+// the BLOCK form of the level-order sweep (fm_als_blocks.hip): the level's array feature-block-major, ONE kernel per level.  Built by als_tiled_build on
+// complete plans whose lists all fit a block; *out stays null where it does not apply.
+struct AlsBlocksIn {
+  int64_t n; int n_slots;
+  const uint32_t *lvl0, *cnt;      // [n_slots] (host) first feature of every level in the feats arrays, features per level
+  const uint32_t* h_feats;         // (host) feature ids by (level, index)
+  const uint32_t* d_feats;         // (device) the same
+  int unit;                        // every stored value is 1.0f
+};
+int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream_t stream);
+void als_blocks_free(void* b);
+int als_blocks_info(const void* b, int32_t* block_rows, int32_t* blocks_level0);
+int als_blocks_enter(fmx_engine* e, const void* b, const double2* d_qe, const double* d_Q0, double2* dst);
+int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qnext);
+int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe);
+int als_order_form(const fmx_matrix* m);   // 0: none, 1: the tile form, 2: the block form
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 
 int evaluate_device(fmx_engine* e, const double* d_yhat, const float* d_y, int64_t n, int metric, double* result);

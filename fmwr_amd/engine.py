@@ -534,6 +534,12 @@ class Engine:
         L.check(L.lib().fmx_als_order_info(self.h, m.h, C.byref(v)))
         return bool(v.value)
 
+    def als_level_order_form(self, m):
+        """0: the V sweeps go level by level through the three-pass / column-walking kernels; 1: the tile form of the level-order sweep; 2: the block form."""
+        v = C.c_int32()
+        L.check(L.lib().fmx_als_order_info(self.h, m.h, C.byref(v)))
+        return int(v.value)
+
     def als_train(self, m, max_iter, with_v=False):
         L.check(L.lib().fmx_als_train(self.h, m.h, C.c_int32(max_iter), C.c_int32(int(with_v))))
 

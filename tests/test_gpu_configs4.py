@@ -122,6 +122,53 @@ def test_configs4_level_order_sweep_matches_oracle_and_the_three_pass_form(monke
         assert util.rel_err(x, y_) < 1e-10                                          # the three-pass form: the same sweeps, sums associated differently
 
 
+@pytest.mark.parametrize("block_rows,n,p", [(512, 20_000, 6_000), (1024, 16_384, 30_000), (0, 16_385, 6_000), (2048, 12_000, 150_000), (4096, 9_000, 600_000)])
+@pytest.mark.parametrize("values,gibbs", [("ones", False), ("normal", True), ("normal", False), ("ones", True)])
+def test_configs4_block_form_matches_oracle_and_the_other_forms(monkeypatch, values, gibbs, block_rows, n, p):
+    """The BLOCK form of the level-order V sweep (fm_als_blocks.hip: the level's array feature-block-major, one kernel per level -- a block's pairs stream into LDS,
+    its lists are summed, stepped and corrected there, and leave as runs for the next level's blocks), forced onto small matrices: many blocks per level, the
+    default capacity, lists of ~100, ~17, ~2.4 and ~0.5 rows (64, 16, 4 and 1 lanes per list; features WITHOUT rows still take their step), a last block of any
+    size; one-hot and real values, ALS and Gibbs.  Against the oracle (1e-10), against the tile form (FMX_ALS_ORDER=1) and the three-pass form (0), and against
+    itself (bitwise, two runs)."""
+    from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_TILE_ROWS", "4096")
+    if block_rows:
+        monkeypatch.setenv("FMX_ALS_BLOCK_ROWS", str(block_rows))
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 67, values)
+    w0, w, v = util.params(p, K, 37, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    # Gibbs draws on lists of a few rows under a weak prior are chaotic: a last-bit difference of one list's sums grows to 1e-7 .. O(1) over the 480 levels (V goes
+    # from 0.1 to ~1.5) in EVERY form that does not happen to add in the oracle's own order (profiles/probes/block_form_debug.py, gpurun record
+    # profiles/r05_block_form_gibbs_conditioning.txt: lambda 0.1-0.5: three-pass form 2.9e-7 / 0.35, block form 2.8e-7; lambda 10-20: all forms 2e-14).  The
+    # sampled cases therefore take a prior under which the sweep contracts; the ALS cases keep the weak one.
+    tol = 1e-10
+    lam = np.linspace(10.0, 20.0, K) if gibbs else np.linspace(0.1, 0.5, K); mu = np.linspace(-0.05, 0.05, K)
+    z = np.random.default_rng(11).normal(0, 1, (K, p)) if gibbs else None
+    rv, rerr, _ = oracle.als_update_v(K, X, v.ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+    res = {}
+    for order in ("2", "2", "1", "0"):
+        monkeypatch.setenv("FMX_ALS_ORDER", order)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        assert e.als_tiled(m)[0] == e.als_plan(m)[0] == Z
+        assert e.als_level_order_form(m) == int(order)
+        gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+        gv = e.get_params()[2]
+        assert util.rel_err(gv, rv.reshape(K, p)) < tol and util.rel_err(gerr, rerr) < tol
+        gerr2 = e.als_vsweep(m, gerr, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)   # a second sweep from there (the pairs re-enter in row order)
+        res.setdefault(order, []).append((gv, gerr, e.get_params()[2], gerr2))
+        e.close(); m.close()
+    a, b = res["2"]
+    assert all(np.array_equal(x, y_) for x, y_ in zip(a, b))                       # bitwise run to run
+    for other in ("1", "0"):
+        for x, y_ in zip(a, res[other][0]):
+            assert util.rel_err(x, y_) < tol                                        # the same sweeps, sums associated differently
+
+
 def test_configs4_level_order_needs_a_complete_plan(monkeypatch):
     """Rows that lack a level (i.i.d. columns: many narrow levels) or levels that keep the column-walking kernels leave the plan incomplete: the V sweep
     then takes the three-pass form level by level, as before."""
@@ -285,21 +332,22 @@ def test_configs4_full_size_levels_descent_and_reproducibility():
 
 
 def test_configs4_full_size_level_order_and_row_tiled_forms_equal_the_column_walking_form(monkeypatch):
-    """10 M x 1 M, k = 16.  The default: a complete plan, so the V sweep takes the LEVEL-ORDER form (all 30 levels tiled, 153 tiles of 65 536 rows);
-    FMX_ALS_ORDER=0: the three-pass row-tiled form (77 tiles of 131 072 rows); FMX_ALS_TILED=0: the column-walking kernels.  One Gibbs sweep each from the
-    same start: V (sampled rows) and the residual agree to 1e-10; the level-order form twice: bit for bit."""
+    """10 M x 1 M, k = 16.  The default: a complete plan whose lists all fit a block, so the V sweep takes the BLOCK form of the level-order sweep (one kernel
+    per level, fm_als_blocks.hip); FMX_ALS_ORDER=1: its tile form (two kernels per level, 153 tiles of 65 536 rows); FMX_ALS_ORDER=0: the three-pass row-tiled
+    form (77 tiles of 131 072 rows); FMX_ALS_TILED=0: the column-walking kernels.  One Gibbs sweep each from the same start: V (sampled rows) and the residual
+    agree to 1e-10; the block form twice: bit for bit."""
     from fmwr_amd import _lib as L, engine
     out = {}
-    for name, env in (("order", {}), ("order_again", {}), ("three_pass", {"FMX_ALS_ORDER": "0"}), ("columns", {"FMX_ALS_TILED": "0"})):
+    for name, env in (("order", {}), ("order_again", {}), ("order_tiles", {"FMX_ALS_ORDER": "1"}), ("three_pass", {"FMX_ALS_ORDER": "0"}), ("columns", {"FMX_ALS_TILED": "0"})):
         monkeypatch.delenv("FMX_ALS_ORDER", raising=False); monkeypatch.delenv("FMX_ALS_TILED", raising=False)
         for kk, vv in env.items():
             monkeypatch.setenv(kk, vv)
         m = engine.Matrix.synthetic(N, P, Z, SEED)
         e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=K, mode=L.MODE_SEQUENTIAL)
         e.init_normal(SEED, 0.0, 0.1)
-        want = {"order": (Z, 65536, 153), "order_again": (Z, 65536, 153), "three_pass": (Z, 131072, 77), "columns": (0, 0, 0)}[name]
+        want = {"order": (Z, 65536, 153), "order_again": (Z, 65536, 153), "order_tiles": (Z, 65536, 153), "three_pass": (Z, 131072, 77), "columns": (0, 0, 0)}[name]
         assert e.als_tiled(m) == want
-        assert e.als_level_order(m) == name.startswith("order")
+        assert e.als_level_order_form(m) == {"order": 2, "order_again": 2, "order_tiles": 1, "three_pass": 0, "columns": 0}[name]
         d_err = util.DevBuf(N)
         L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(N), d_err.ptr, C.c_int(L.LINK_NONE)))
         e.sync()
@@ -308,7 +356,7 @@ def test_configs4_full_size_level_order_and_row_tiled_forms_equal_the_column_wal
         out[name] = (d_err.numpy(), e.get_rows(np.arange(0, P, 499, dtype=np.uint32))[1])
         e.close(); d_err.free(); d_z.free(); m.close()
     assert np.array_equal(out["order"][0], out["order_again"][0]) and np.array_equal(out["order"][1], out["order_again"][1])
-    for name in ("order", "three_pass"):
+    for name in ("order", "order_tiles", "three_pass"):
         assert util.rel_err(out[name][0], out["columns"][0]) < 1e-10 and util.rel_err(out[name][1], out["columns"][1]) < 1e-10
 
 
