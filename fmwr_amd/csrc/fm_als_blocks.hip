@@ -39,6 +39,7 @@ struct AlsBlocks {
   std::vector<size_t> boff;       // per level: first entry of the level in bbase / bfeat (nblk + 1 entries each)
   std::vector<size_t> foff;       // per level: first entry of the level in loff (cnt + 1 entries each)
   std::vector<int> lg;            // per level: lanes per list
+  uint32_t last_cnt = 0;          // features of the last level
   uint32_t* bbase = nullptr;      // first position of every block in its level's array (= rows of the features before it)
   uint32_t* bfeat = nullptr;      // first feature (index inside the level) of every block
   uint32_t* loff = nullptr;       // per level [cnt + 1]: first position of every feature's list in slot order (feature-major, rows ascending)
@@ -47,10 +48,11 @@ struct AlsBlocks {
   uint32_t* dest = nullptr;       // [L][n] ... and the position in the next level's array
   float* xs = nullptr;            // [L][n] entry values in slot order (null: every value is 1.0f)
   uint32_t* row0 = nullptr;       // [n] row at position i of level 0's array
-  uint32_t* drow = nullptr;       // [n] last level, destination order: the row (the next factor's q is gathered by it)
+  uint32_t* colP = nullptr;       // [nnz] the CSR's columns with the rows in level 0's array order (every row holds L entries): the forward pass that builds q for all
+  float* valP = nullptr;          // [nnz] factors runs on this copy and leaves q in level 0's order -- a factor's first level takes its q in as a stream (null: unit values)
   ~AlsBlocks() {
     (void)hipFree(bbase); (void)hipFree(bfeat); (void)hipFree(loff); (void)hipFree(perm_in); (void)hipFree(gsrc); (void)hipFree(dest); (void)hipFree(xs);
-    (void)hipFree(row0); (void)hipFree(drow);
+    (void)hipFree(row0); (void)hipFree(colP); (void)hipFree(valP);
   }
 };
 
@@ -98,13 +100,22 @@ __global__ void blocks_keys2_k(const uint32_t* __restrict__ rowat_next, const ui
   vals[i] = (uint32_t)i;
 }
 __global__ void blocks_dest_k(const uint32_t* __restrict__ sorted_pos, const uint32_t* __restrict__ rowat_next, const uint16_t* __restrict__ slotrow, int64_t n,
-                              uint32_t* __restrict__ dest, uint16_t* __restrict__ gsrc, uint32_t* __restrict__ drow) {
+                              uint32_t* __restrict__ dest, uint16_t* __restrict__ gsrc) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const uint32_t d = sorted_pos[k], r = rowat_next[d];
   dest[k] = d;
   gsrc[k] = slotrow[r];
-  if (drow) drow[k] = r;
+}
+// the CSR with its rows in level 0's array order: L lanes-worth of entries per row (every row holds exactly L)
+__global__ void blocks_permute_csr_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val, const uint32_t* __restrict__ row0, int64_t n,
+                                     int L, uint32_t* __restrict__ colP, float* __restrict__ valP) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n * L) return;
+  const int64_t i = g / L; const int t = (int)(g % L);
+  const int64_t src = row_ptr[row0[i]] + t;
+  colP[g] = col[src];
+  if (valP) valP[g] = val[src];
 }
 
 // ---- the sweep -------------------------------------------------------------------------------------------------------------------------------
@@ -116,12 +127,12 @@ __device__ __forceinline__ bool bad_number_b(double x) { return isnan(x) || isin
 // blockIdx -> block: consecutive blocks share an XCD (workgroups are dealt round-robin over the eight XCDs) and run there at about the same time, so the runs
 // that neighbouring blocks write into one line of the next level's array meet in that XCD's L2 (73 against 89 us per level in the probe).  Placement is for
 // speed only.
-template <bool UNIT, int R, int LG, bool QNEXT>
+template <bool UNIT, int R, int LG, bool QIN>
 __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* __restrict__ src, double2* __restrict__ dst, const uint32_t* __restrict__ bbase,
                                                                  const uint32_t* __restrict__ bfeat, int nb, const uint32_t* __restrict__ loff, const uint32_t* __restrict__ feats,
                                                                  const uint16_t* __restrict__ perm_in, const uint16_t* __restrict__ gsrc, const uint32_t* __restrict__ dest,
                                                                  const float* __restrict__ xs, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
-                                                                 const double* __restrict__ qnext, const uint32_t* __restrict__ drow, uint32_t n) {
+                                                                 const double* __restrict__ qin, uint32_t n) {
   constexpr int NT = BLK_THREADS, PT = R / NT, NG = NT / LG;
   static_assert(R % NT == 0, "whole pairs per thread");
   __shared__ double2 lp[R];
@@ -143,6 +154,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
     v[u] = nt_pair(src + ic);
     pa[u] = nt_ld(perm_in + ic);
     xv[u] = UNIT ? 1.0f : nt_ld(xs + ic);
+    qn[u] = QIN ? nt_ld(qin + ic) : 0.0;   // a factor's FIRST level: this factor's q, in the array's own order (the pair still carries the previous factor's)
   }
   if (threadIdx.x < nf) {
     const uint32_t ft = feats[f0 + threadIdx.x];
@@ -155,12 +167,11 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
     const uint32_t i = threadIdx.x + u * NT, ic = min(b0 + min(i, rows ? rows - 1 : 0u), n - 1);
     gs[u] = nt_ld(gsrc + ic);
     de[u] = nt_ld(dest + ic);
-    qn[u] = QNEXT ? qnext[nt_ld(drow + ic)] : 0.0;
   }
 #pragma unroll
   for (int u = 0; u < PT; ++u) {
     const uint32_t i = threadIdx.x + u * NT;
-    if (i < rows) { lp[pa[u]] = v[u]; if (!UNIT) lx[i] = xv[u]; }
+    if (i < rows) { lp[pa[u]] = QIN ? make_double2(qn[u], v[u].y) : v[u]; if (!UNIT) lx[i] = xv[u]; }
   }
   __syncthreads();
   {
@@ -209,7 +220,126 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
 #pragma unroll
   for (int u = 0; u < PT; ++u) {
     const uint32_t i = threadIdx.x + u * NT;
-    if (i < rows) { double2 c = lp[gs[u]]; if (QNEXT) c.x = qn[u]; dst[de[u]] = c; }
+    if (i < rows) dst[de[u]] = lp[gs[u]];
+  }
+}
+
+// The same level as a PIPELINE over the blocks of one CU: one workgroup per CU stays resident and takes the blocks B, B + slots, B + 2 slots, ... of its XCD's
+// share (at any moment an XCD still works on consecutive blocks).  While block k is summed, stepped and corrected in LDS and its pairs leave, the pairs of
+// block k + 1 are already on their way into registers: the LDS phases (16 of the 89 us of a level in the probe) and the first loads' latency hide behind the
+// other block's memory traffic.  Every load is unconditional (a workgroup without a next block re-reads one pair of its current one), so the waits are counted.
+// Same bits as als_block_level_k: the same slots, the same lane groups, the same order.
+template <bool UNIT, int R, int LG>
+__global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const double2* __restrict__ src, double2* __restrict__ dst, const uint32_t* __restrict__ bbase,
+                                                                      const uint32_t* __restrict__ bfeat, int nb, const uint32_t* __restrict__ loff, const uint32_t* __restrict__ feats,
+                                                                      uint32_t cnt, const uint16_t* __restrict__ perm_in, const uint16_t* __restrict__ gsrc,
+                                                                      const uint32_t* __restrict__ dest, const float* __restrict__ xs, double* __restrict__ P, int kp,
+                                                                      const SweepDyn* __restrict__ dyn, uint32_t n) {
+  constexpr int NT = BLK_THREADS, PT = R / NT, NG = NT / LG;
+  __shared__ double2 lp[R];
+  __shared__ float lx[UNIT ? 1 : R];
+  __shared__ double oldv[BLK_MAXF];
+  __shared__ uint32_t lfeat[BLK_MAXF];
+  __shared__ uint16_t lo[BLK_MAXF + 2];
+  const int per = (nb + 7) >> 3, slots = (int)(gridDim.x >> 3);
+  const int xcd = (int)(blockIdx.x & 7);
+  int B = xcd * per + (int)(blockIdx.x >> 3);
+  const int Bend = min((xcd + 1) * per, nb);
+  if (B >= Bend) return;
+  const int f = dyn->f;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  const uint32_t tid = threadIdx.x;
+  uint32_t b0 = bbase[B], rows = bbase[B + 1] - b0, f0 = bfeat[B], nf = bfeat[B + 1] - f0;
+  double2 v[PT]; uint16_t pa[PT]; float xv[PT]; uint32_t ft, lov; double old;
+  auto load_in = [&](uint32_t b0_, uint32_t rows_, uint32_t f0_, uint32_t nf_, double2 (&v_)[PT], uint16_t (&pa_)[PT], float (&xv_)[PT], uint32_t& ft_, uint32_t& lov_) {
+    ft_ = feats[min(f0_ + min(tid, nf_ ? nf_ - 1 : 0u), cnt - 1)];
+    lov_ = loff[min(f0_ + min(tid, nf_), cnt)] - b0_;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const uint32_t i = tid + u * NT, ic = min(b0_ + min(i, rows_ ? rows_ - 1 : 0u), n - 1);
+      v_[u] = nt_pair(src + ic);
+      pa_[u] = nt_ld(perm_in + ic);
+      xv_[u] = UNIT ? 1.0f : nt_ld(xs + ic);
+    }
+  };
+  load_in(b0, rows, f0, nf, v, pa, xv, ft, lov);
+  old = P[(size_t)ft * kp + f];
+  for (;;) {
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const uint32_t i = tid + u * NT;
+      if (i < rows) { lp[pa[u]] = v[u]; if (!UNIT) lx[i] = xv[u]; }
+    }
+    if (tid < nf) { lfeat[tid] = ft; oldv[tid] = old; }
+    if (tid <= nf) lo[tid] = (uint16_t)lov;
+    __syncthreads();
+    // this block's way out, then the next block's way in: all in flight behind the LDS phase below
+    uint16_t gs[PT]; uint32_t de[PT];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const uint32_t i = tid + u * NT, ic = min(b0 + min(i, rows ? rows - 1 : 0u), n - 1);
+      gs[u] = nt_ld(gsrc + ic);
+      de[u] = nt_ld(dest + ic);
+    }
+    const int Bn = B + slots;
+    const bool more = Bn < Bend;   // (uniform)
+    const uint32_t b0n = more ? bbase[Bn] : b0, rowsn = more ? bbase[Bn + 1] - b0n : min(rows, 1u);
+    const uint32_t f0n = more ? bfeat[Bn] : f0, nfn = more ? bfeat[Bn + 1] - f0n : 0u;
+    double2 vn[PT]; uint16_t pan[PT]; float xvn[PT]; uint32_t ftn, lovn;
+    load_in(b0n, rowsn, f0n, nfn, vn, pan, xvn, ftn, lovn);
+    {
+      const int g = tid / LG, l = tid % LG;
+      for (uint32_t fi = g; fi < nf; fi += NG) {
+        const uint32_t a = lo[fi], b = lo[fi + 1];
+        const double oldf = oldv[fi];
+        double mean = 0.0, var = 0.0;
+        for (uint32_t t0 = a + l; t0 < b; t0 += 4 * LG) {
+          double2 c[4]; float x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float xx = x[u] * x[u];
+            const double h = (double)x[u] * c[u].x - (double)xx * oldf;   // :310-317
+            if (t0 + u * LG < b) { mean += h * c[u].y; var += h * h; }
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < LG; o <<= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }
+        mean -= oldf * var;                              // :318
+        var = 1.0 / (lambda + alpha * var);              // :319
+        mean = -var * (alpha * mean - mu * lambda);      // :320
+        const uint32_t feat = lfeat[fi];
+        const double nv = bad_number_b(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+        if (bad_number_b(nv)) continue;                  // CHECK_PARAM (:336)
+        if (l == 0) P[(size_t)feat * kp + f] = nv;
+        const double diff = oldf - nv;
+        for (uint32_t t0 = a + l; t0 < b; t0 += 4 * LG) {
+          double2 c[4]; float x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float xx = x[u] * x[u];
+            const double h = (double)x[u] * c[u].x - (double)xx * oldf;
+            if (t0 + u * LG < b) lp[t0 + u * LG] = make_double2(c[u].x - (double)x[u] * diff, c[u].y - h * diff);   // :341-350
+          }
+        }
+      }
+    }
+    const double oldn = P[(size_t)ftn * kp + f];   // (the next block's features: none of them is stepped by this block)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const uint32_t i = tid + u * NT;
+      if (i < rows) dst[de[u]] = lp[gs[u]];
+    }
+    if (!more) break;
+    __syncthreads();   // (the pairs have left the LDS before the next block lands in it)
+    B = Bn; b0 = b0n; rows = rowsn; f0 = f0n; nf = nfn; ft = ftn; lov = lovn; old = oldn;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) { v[u] = vn[u]; pa[u] = pan[u]; xv[u] = xvn[u]; }
   }
 }
 
@@ -218,7 +348,7 @@ __global__ void als_block_enter_k(const double2* __restrict__ qe, const double* 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t r = row0[i];
-  dst[i] = make_double2(Q0[r], qe[r].y);
+  dst[i] = make_double2(Q0[i], qe[r].y);   // (Q: built on the permuted CSR, already in this order)
 }
 __global__ void als_block_exit_k(const double2* __restrict__ src, const uint32_t* __restrict__ row0, int64_t n, double2* __restrict__ qe) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,6 +407,7 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
     const double avg = cnt ? (double)n / cnt : 0.0;
     Bk->lg[(size_t)s] = avg >= 48.0 ? 64 : (avg >= 12.0 ? 16 : (avg >= 3.0 ? 4 : 1));
     fo += (size_t)cnt + 1;
+    if (s == L - 1) Bk->last_cnt = cnt;
   }
   // (h_blk_of_feat is indexed by feature position over all levels: fo - s = features before the level)
   auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
@@ -294,7 +425,7 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
   const size_t ws = ws1 > ws2 ? ws1 : ws2;
   if (!ok(hipMalloc(&Bk->bbase, h_bbase.size() * 4)) || !ok(hipMalloc(&Bk->bfeat, h_bfeat.size() * 4)) || !ok(hipMalloc(&Bk->loff, h_loff.size() * 4)) ||
       !ok(hipMalloc(&Bk->perm_in, sn * 2)) || !ok(hipMalloc(&Bk->gsrc, sn * 2)) || !ok(hipMalloc(&Bk->dest, sn * 4)) || (!in.unit && !ok(hipMalloc(&Bk->xs, sn * 4))) ||
-      !ok(hipMalloc(&Bk->row0, (size_t)n * 4)) || !ok(hipMalloc(&Bk->drow, (size_t)n * 4)) ||
+      !ok(hipMalloc(&Bk->row0, (size_t)n * 4)) || !ok(hipMalloc(&Bk->colP, (size_t)n * L * 4)) || (!in.unit && !ok(hipMalloc(&Bk->valP, (size_t)n * L * 4))) ||
       !ok(hipMalloc(&w.blk_of_feat, (n_feats ? n_feats : 1) * 2)) || !ok(hipMalloc(&w.blkrow, sn * 2)) || !ok(hipMalloc(&w.slotrow, sn * 2)) || !ok(hipMalloc(&w.rowat, sn * 4)) ||
       !ok(hipMalloc(&w.keys, (size_t)n * 4)) || !ok(hipMalloc(&w.keys_o, (size_t)n * 4)) || !ok(hipMalloc(&w.vals, (size_t)n * 4)) || !ok(hipMalloc(&w.vals_o, (size_t)n * 4)) ||
       !ok(hipMalloc(&w.keys16, (size_t)n * 2)) || !ok(hipMalloc(&w.keys16o, (size_t)n * 2)) || !ok(hipMalloc(&w.sort_ws, ws ? ws : 16)))
@@ -329,13 +460,20 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
     size_t wsz = ws;
     FMX_HIP(rocprim::radix_sort_pairs(w.sort_ws, wsz, w.keys16, w.keys16o, w.vals, w.vals_o, (size_t)n, 0, 16, stream));
     hipLaunchKernelGGL(blocks_dest_k, dim3(row_grid), dim3(256), 0, stream, (const uint32_t*)w.vals_o, rowat_next, (const uint16_t*)(w.slotrow + (size_t)s * n), n,
-                       Bk->dest + (size_t)s * n, Bk->gsrc + (size_t)s * n, s == L - 1 ? Bk->drow : nullptr);
+                       Bk->dest + (size_t)s * n, Bk->gsrc + (size_t)s * n);
   }
   FMX_HIP(hipMemcpyAsync(Bk->row0, w.rowat, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(blocks_permute_csr_k, dim3((unsigned)(((size_t)n * L + 255) / 256)), dim3(256), 0, stream, (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const float*)m->val,
+                     (const uint32_t*)Bk->row0, n, L, Bk->colP, Bk->valP);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipStreamSynchronize(stream));
   *out = Bk.release();
   return FMX_OK;
+}
+
+void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP) {
+  const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
+  *colP = Bk->colP; *valP = Bk->valP;
 }
 
 int als_blocks_info(const void* b, int32_t* block_rows, int32_t* blocks_level0) {
@@ -359,8 +497,8 @@ int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d
   return FMX_OK;
 }
 
-// one level (slot s) of one factor; d_feats: the level's feature ids; d_qnext (row order): the last level of a factor that has a successor
-int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qnext) {
+// one level (slot s) of one factor; d_feats: the level's feature ids; d_qin (level 0's array order): this factor's q, taken in by its first level
+int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin) {
   const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
   const int nb = (int)Bk->nblk[(size_t)s];
   const dim3 grid((unsigned)(((nb + 7) / 8) * 8)), blk(BLK_THREADS);
@@ -371,11 +509,11 @@ int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, do
   const uint16_t* gs = Bk->gsrc + (size_t)s * Bk->n;
   const uint32_t* de = Bk->dest + (size_t)s * Bk->n;
   const float* xs = Bk->xs ? Bk->xs + (size_t)s * Bk->n : nullptr;
-  FMX_CHECK(!d_qnext || s == Bk->L - 1, FMX_ERR_STATE, "the next factor's q is folded into a factor's LAST level");
+  FMX_CHECK(!d_qin || s == 0, FMX_ERR_STATE, "a factor's q enters at its FIRST level");
 #define FMX_BLK(UNITv, Rv, LGv, QNv)                                                                                                                              \
-  hipLaunchKernelGGL((als_block_level_k<UNITv, Rv, LGv, QNv>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, e->dV, e->kp64, dyn, d_qnext, \
-                     (const uint32_t*)Bk->drow, (uint32_t)Bk->n)
-#define FMX_BLK_Q(UNITv, Rv, LGv) do { if (d_qnext) FMX_BLK(UNITv, Rv, LGv, true); else FMX_BLK(UNITv, Rv, LGv, false); } while (0)
+  hipLaunchKernelGGL((als_block_level_k<UNITv, Rv, LGv, QNv>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, e->dV, e->kp64, dyn, d_qin, \
+                     (uint32_t)Bk->n)
+#define FMX_BLK_Q(UNITv, Rv, LGv) do { if (d_qin) FMX_BLK(UNITv, Rv, LGv, true); else FMX_BLK(UNITv, Rv, LGv, false); } while (0)
 #define FMX_BLK_L(UNITv, Rv)                                                                                                                                      \
   do {                                                                                                                                                            \
     switch (Bk->lg[(size_t)s]) {                                                                                                                                  \
@@ -385,6 +523,33 @@ int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, do
       default: FMX_BLK_Q(UNITv, Rv, 1); break;                                                                                                                    \
     }                                                                                                                                                             \
   } while (0)
+  static const bool pipe = env_int_b("FMX_ALS_BLOCK_PIPE", 1) != 0;
+  if (pipe && !d_qin) {
+    // one resident workgroup per CU (the LDS admits one): `slots` of them per XCD, each walking its XCD's share of the blocks
+    static int n_cus = 0;
+    if (n_cus == 0) { hipDeviceProp_t pr{}; n_cus = (hipGetDeviceProperties(&pr, e->cfg.device) == hipSuccess && pr.multiProcessorCount >= 8) ? pr.multiProcessorCount : 256; }
+    const int per = (nb + 7) / 8;
+    const int slots = per < n_cus / 8 ? per : n_cus / 8;
+    const dim3 pgrid((unsigned)(slots * 8));
+    const uint32_t cnt = (uint32_t)(Bk->foff.size() > (size_t)s + 1 ? Bk->foff[(size_t)s + 1] - Bk->foff[(size_t)s] - 1 : Bk->last_cnt);
+#define FMX_BLKP(UNITv, Rv, LGv)                                                                                                                                  \
+  hipLaunchKernelGGL((als_block_level_pipe_k<UNITv, Rv, LGv>), pgrid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, cnt, pin, gs, de, xs, e->dV, e->kp64, dyn, \
+                     (uint32_t)Bk->n)
+#define FMX_BLKP_L(UNITv, Rv)                                                                                                                                     \
+  do {                                                                                                                                                            \
+    switch (Bk->lg[(size_t)s]) {                                                                                                                                  \
+      case 64: FMX_BLKP(UNITv, Rv, 64); break;                                                                                                                    \
+      case 16: FMX_BLKP(UNITv, Rv, 16); break;                                                                                                                    \
+      case 4: FMX_BLKP(UNITv, Rv, 4); break;                                                                                                                      \
+      default: FMX_BLKP(UNITv, Rv, 1); break;                                                                                                                     \
+    }                                                                                                                                                             \
+  } while (0)
+    if (Bk->unit) FMX_BLKP_L(true, BLK_R_UNIT); else FMX_BLKP_L(false, BLK_R_VAL);
+#undef FMX_BLKP_L
+#undef FMX_BLKP
+    FMX_HIP(hipGetLastError());
+    return FMX_OK;
+  }
   if (Bk->unit) FMX_BLK_L(true, BLK_R_UNIT); else FMX_BLK_L(false, BLK_R_VAL);
 #undef FMX_BLK_L
 #undef FMX_BLK_Q

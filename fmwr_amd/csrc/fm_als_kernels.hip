@@ -950,9 +950,12 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     }
     d_Q = e->als_Q;
   }
+  const uint32_t* colP = nullptr; const float* valP = nullptr;
+  e->als_q_level0 = 0;
+  if (d_Q && !d_qe_new) FMX_TRY(als_order_prepare(e, m, &colP, &valP));   // the block form: q in level 0's array order (the forward runs on the permuted CSR)
   if (d_Q) {
     RowsArgs a{};
-    a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
+    a.row_ptr = m->row_ptr; a.col = colP ? colP : m->col; a.val = colP ? valP : m->val; a.r0 = 0; a.nrows = m->n;
     a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.qout_t = m->n; a.link = FMX_LINK_NONE;
     a.unit = m->unit_values;
     if (launch_rows_forward(e, a, false, true) != FMX_OK) d_Q = nullptr;
@@ -968,7 +971,9 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
         set_dyn(e, dyn, f, alpha, h_lambda ? h_lambda[f] : 0.0, h_mu ? h_mu[f] : 0.0, d_znorm ? d_znorm + (size_t)f * m->p : nullptr);
         for (int s = 0; s < S; ++s) {
           prof_begin(e, FMX_KERNEL_ALS_SWEEP);   // one level of one factor: the unit bench.py --solver als prices
-          const int st = als_order_level(e, m, s, dyn, (s == S - 1 && f + 1 < e->k) ? d_Q + (size_t)(f + 1) * m->n : nullptr);
+          const double* d_q = e->als_q_level0 ? ((s == 0 && f > 0) ? d_Q + (size_t)f * m->n : nullptr)                      // block form: q enters at the first level
+                                              : ((s == S - 1 && f + 1 < e->k) ? d_Q + (size_t)(f + 1) * m->n : nullptr);   // tile form: the next q leaves the last
+          const int st = als_order_level(e, m, s, dyn, d_q);
           prof_end(e);
           FMX_TRY(st);
         }

@@ -987,13 +987,24 @@ static int order_buffers(fmx_engine* e, int64_t n) {
   return FMX_OK;
 }
 
+int als_order_prepare(fmx_engine* e, fmx_matrix* m, const uint32_t** colP, const float** valP) {
+  *colP = nullptr; *valP = nullptr;
+  e->als_q_level0 = 0;
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (!T || !T->complete || !T->blocks || m->als_approx) return FMX_OK;
+  if (order_buffers(e, m->n) != FMX_OK) { (void)hipGetLastError(); return FMX_OK; }
+  als_blocks_csr(T->blocks, colP, valP);
+  e->als_q_level0 = 1;
+  return FMX_OK;
+}
+
 // enter: d_qe (row order; e current) + Q0 (q of the first factor, row order) -> buffer 0 in level 0's order.  *ok = false: no memory, use the other form.
 int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const double* d_Q0, bool* ok) {
   *ok = false;
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
   if (!T || !T->complete) return FMX_OK;
   if (T->blocks) {
-    if (order_buffers(e, m->n) != FMX_OK) { (void)hipGetLastError(); return FMX_OK; }
+    if (!e->als_q_level0) return FMX_OK;   // (the q table is in row order: als_order_prepare found no room for the pair buffers; the other forms take the sweep)
     FMX_TRY(als_blocks_enter(e, T->blocks, d_qe, d_Q0, reinterpret_cast<double2*>(e->als_lo[0])));
     e->als_lo_cur = 0;
     *ok = true;
