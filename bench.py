@@ -165,7 +165,7 @@ def pmc_traffic(kernel, args):
     return best
 
 
-def pmc_traffic_sweep(args, tiled, ordered=False):
+def pmc_traffic_sweep(args, tiled, ordered=False, blocks=False):
     """configs[4]: HBM-side bytes of one level of one factor from the committed PMC summaries (profiles/r*_pmc_summary_mcmc*.json), or None."""
     import glob
     best = None
@@ -177,8 +177,12 @@ def pmc_traffic_sweep(args, tiled, ordered=False):
         a = d.get("_bench_args", [])
         if ("als" in a) != (args.solver == "als") or args.rows != 10_000_000 or args.features != 1_000_000:
             continue
+        if blocks:
+            if "als_block_level" in d and "fabric_bytes_per_launch" in d["als_block_level"]:   # (one kernel per level; exact bytes by request size, not the x2 bound)
+                best = (d["als_block_level"]["fabric_bytes_per_launch"], os.path.basename(f))
+            continue
         names = ("als_order_sums", "als_order_apply") if ordered else (("als_tile_sums", "als_tile_step", "als_rows_apply") if tiled else ("als_level",))
-        if all(nm in d and "traffic_bytes_per_launch" in d[nm] for nm in names) and (("als_level" in d) != tiled) and (("als_order_sums" in d) == ordered):
+        if all(nm in d and "traffic_bytes_per_launch" in d[nm] for nm in names) and (("als_level" in d) != tiled) and (("als_order_sums" in d) == ordered) and "als_block_level" not in d:
             best = (sum(d[nm]["traffic_bytes_per_launch"] for nm in names), os.path.basename(f))
     return best
 
@@ -637,10 +641,15 @@ def main_sweep(args, rank, local_rank, world):
     launches = levels * k
     tiled, tile_rows, n_tiles = e.als_tiled(m)
     ordered = bool(tiled) and e.als_level_order(m)
+    blocks = ordered and e.als_level_order_form(m) == 2
     b_launch = 40.0 * nnz / levels               # 40 B per stored nonzero per factor; one unit = one level of one factor
     gbs = b_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
     step_gbs = 40.0 * nnz * k / (dt / args.steps) / 1e9
-    form = (f"level-order: the (q, e) pairs kept in the list order of the level that consumes them next ({n_tiles} tiles of {tile_rows} rows): als_order_sums_k (streams the pairs, sums the lists, "
+    form = ("level-order, block form: the level's (q, e) array is feature-block-major (blocks of consecutive features holding at most 8192 rows); ONE kernel per level, "
+            "als_block_level_pipe_k: a resident workgroup per CU streams a block's pairs into LDS at their feature-sorted slots, sums its lists, takes the coordinate steps "
+            "and corrects the pairs there, and stores them as contiguous runs into the next level's blocks while the next block's pairs are already in flight"
+            if blocks else
+            f"level-order: the (q, e) pairs kept in the list order of the level that consumes them next ({n_tiles} tiles of {tile_rows} rows): als_order_sums_k (streams the pairs, sums the lists, "
             "takes the coordinate steps) + als_order_apply_k (corrections, every pair written to its place in the next level's order: a permutation inside the tile's L2-resident slice)"
             if ordered else
             f"row-tiled: als_tile_sums_k ({n_tiles} tiles of {tile_rows} rows, each tile's (q, e) slice gathered from its XCD's L2) + als_tile_step_k + als_rows_apply_k (row-major corrections)"
@@ -653,7 +662,7 @@ def main_sweep(args, rank, local_rank, world):
                                f"schedule is {z} levels; i.i.d. columns need thousands of dependent levels and take the approximate groups instead), k={k}, "
                                f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
                                f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
-                   "levels": levels, "largest_level": largest, "approximate": bool(approx), "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ordered,
+                   "levels": levels, "largest_level": largest, "approximate": bool(approx), "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
                    "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
                    "parallelism": f"replicas{world}" if world > 1 else "dp1"},
         "roofline": {"bound": "hbm", "kernel": "one level of one factor: " + form, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -662,11 +671,18 @@ def main_sweep(args, rank, local_rank, world):
                               "note": "40 B x nnz x k over the whole sweep's wall time (includes the one forward pass that builds q for all factors)"},
                      "q_build_forward_ms": fwd_ms / max(fwd_n, 1) if fwd_n else None},
     }
-    tr = pmc_traffic_sweep(args, bool(tiled), ordered)
+    tr = pmc_traffic_sweep(args, bool(tiled), ordered, blocks)
     if tr:
         out["roofline"]["traffic"] = tr[0]
-        out["roofline"]["traffic_source"] = f"profiles/{tr[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB summed over the launches of one level, separate --pmc passes; upper bound, DESIGN.md section 6"
-    if ordered:
+        out["roofline"]["traffic_source"] = (f"profiles/{tr[1]}: fabric bytes of one launch by request size (128 x RDREQ_128B + 64 x the other reads + WRITE_SIZE), separate --pmc passes" if blocks else
+                                             f"profiles/{tr[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB summed over the launches of one level, separate --pmc passes; upper bound, DESIGN.md section 6")
+    if blocks:
+        # what the one pass of a level has to move (design bytes): (q, e) 16 in and 16 out, LDS slot 2, slot in destination order 2, position in the next level's array 4 (+4 value)
+        vb = 0 if e_unit(m) else 4
+        design = (nnz / levels) * (16 + 16 + 2 + 2 + 4 + vb)
+        out["roofline"]["design_bytes_per_launch"] = design
+        out["roofline"]["design_frac"] = design / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if per_launch_ms > 0 else None
+    elif ordered:
         # what the two passes of a level have to move (design bytes): sums + step: (q, e) 16 (+4 value) per nonzero, the list offsets of every (tile, feature);
         # apply: (q, e) 16 in and 16 out, feature index 2, position in the next level's order 4 (+4 value) per nonzero
         vb = 0 if e_unit(m) else 4
@@ -689,7 +705,7 @@ def main_sweep(args, rank, local_rank, world):
         out["roofline"]["gather_ceiling"] = {"table_MB": n * 16 / 1e6, "row_bytes": 16, "ceiling_rows_per_s": r, "kernel_entries_per_s": got,
                                              "ceiling_frac": got / r if r else None,
                                              "note": "entries per second of a level over the measured rate of random 16-B gathers from the whole (q, e) table (the untiled form does a gather AND a scatter "
-                                                     "per entry against it: at most 0.5; the row-tiled and level-order forms keep their random accesses inside L2-resident slices and are not bound by it)"}
+                                                     "per entry against it: at most 0.5; the row-tiled and level-order forms keep their random accesses inside L2-resident slices or LDS and are not bound by it)"}
     if args.cpu_rows > 0:
         out["cpu_baseline"] = cpu_baseline(m, args, None)
     return out

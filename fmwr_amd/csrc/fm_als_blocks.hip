@@ -138,6 +138,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
   __shared__ double2 lp[R];
   __shared__ float lx[UNIT ? 1 : R];
   __shared__ double oldv[BLK_MAXF];
+  __shared__ double zn[BLK_MAXF];   // the features' standard normals (Gibbs): fetched with the old values, so that no load inside the list loop waits for the streams
   __shared__ uint32_t lfeat[BLK_MAXF];
   __shared__ uint16_t lo[BLK_MAXF + 2];
   const int per = (nb + 7) >> 3;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
     const uint32_t ft = feats[f0 + threadIdx.x];
     lfeat[threadIdx.x] = ft;
     oldv[threadIdx.x] = P[(size_t)ft * kp + f];
+    zn[threadIdx.x] = dyn->znorm ? dyn->znorm[ft] : 0.0;
   }
   if (threadIdx.x <= nf) lo[threadIdx.x] = (uint16_t)(loff[f0 + threadIdx.x] - b0);
 #pragma unroll
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
   {
     const int g = threadIdx.x / LG, l = threadIdx.x % LG;
     const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
-    const double* __restrict__ znorm = dyn->znorm;
+    const bool gibbs = dyn->znorm != nullptr;
     for (uint32_t fi = g; fi < nf; fi += NG) {
       const uint32_t a = lo[fi], b = lo[fi + 1];
       const double old = oldv[fi];
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
       var = 1.0 / (lambda + alpha * var);              // :319
       mean = -var * (alpha * mean - mu * lambda);      // :320
       const uint32_t feat = lfeat[fi];
-      const double nv = bad_number_b(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
+      const double nv = bad_number_b(var) ? 0.0 : (gibbs ? mean + sqrt(var) * zn[fi] : mean);
       if (bad_number_b(nv)) continue;                  // CHECK_PARAM (:336): the old value stays and the rows keep their pairs
       if (l == 0) P[(size_t)feat * kp + f] = nv;
       const double diff = old - nv;
@@ -225,10 +227,24 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
 }
 
 // The same level as a PIPELINE over the blocks of one CU: one workgroup per CU stays resident and takes the blocks B, B + slots, B + 2 slots, ... of its XCD's
-// share (at any moment an XCD still works on consecutive blocks).  While block k is summed, stepped and corrected in LDS and its pairs leave, the pairs of
-// block k + 1 are already on their way into registers: the LDS phases (16 of the 89 us of a level in the probe) and the first loads' latency hide behind the
-// other block's memory traffic.  Every load is unconditional (a workgroup without a next block re-reads one pair of its current one), so the waits are counted.
+// share (at any moment an XCD still works on consecutive blocks).  While block k is summed, stepped and corrected in LDS, the pairs of block k + 1 are on their
+// way into registers; while they are written to LDS, the stores of block k are still draining.  Three things make that hold on gfx950 (each read off the ISA):
+//   * loads and stores share ONE counter (vmcnt) and return out of order with respect to each other, so while both kinds are outstanding the compiler can only
+//     wait for everything: the prefetch is therefore waited for BEFORE the block's stores are issued (it had the whole LDS phase to land), and nothing loaded
+//     is first used after them -- the feature ids of a block arrive TWO blocks ahead so that its old values (loads that depend on them) go out with the prefetch;
+//   * __syncthreads() fences global memory too (s_waitcnt vmcnt(0) before s_barrier: the stores would have to be acknowledged before the next block may enter
+//     the LDS); the barriers here order LDS only (lds_barrier);
+//   * no memory operation sits under a condition -- lanes past the block's end store to a spare slot (lp[R], dst[n]) -- and no store sits inside the list loop.
 // Same bits as als_block_level_k: the same slots, the same lane groups, the same order.
+// -DFMX_BLK_KO=bits (profiles/probes/block_knockouts.sh, never the product build): knock-outs of the pipelined kernel, fixed at compile time -- 1: no list
+// loop; 2: the pairs leave for the block's own region (a linear store); 4: the LDS is written and read linearly (no slots); 8: no index loads.  Wrong results,
+// the time of what is left (profiles/r05_block_knockouts.txt).
+#ifndef FMX_BLK_KO
+#define FMX_BLK_KO 0
+#endif
+#define BLK_KO(bit) (((FMX_BLK_KO) & (bit)) != 0)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool UNIT, int R, int LG>
 __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const double2* __restrict__ src, double2* __restrict__ dst, const uint32_t* __restrict__ bbase,
                                                                       const uint32_t* __restrict__ bfeat, int nb, const uint32_t* __restrict__ loff, const uint32_t* __restrict__ feats,
@@ -236,9 +252,11 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
                                                                       const uint32_t* __restrict__ dest, const float* __restrict__ xs, double* __restrict__ P, int kp,
                                                                       const SweepDyn* __restrict__ dyn, uint32_t n) {
   constexpr int NT = BLK_THREADS, PT = R / NT, NG = NT / LG;
-  __shared__ double2 lp[R];
-  __shared__ float lx[UNIT ? 1 : R];
+  __shared__ double2 lp[R + 1];
+  __shared__ float lx[UNIT ? 1 : R + 1];
   __shared__ double oldv[BLK_MAXF];
+  __shared__ double newv[BLK_MAXF];   // the stepped coordinates: stored to P by one thread per feature after the list loop
+  __shared__ double zn[BLK_MAXF];
   __shared__ uint32_t lfeat[BLK_MAXF];
   __shared__ uint16_t lo[BLK_MAXF + 2];
   const int per = (nb + 7) >> 3, slots = (int)(gridDim.x >> 3);
@@ -248,49 +266,63 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
   if (B >= Bend) return;
   const int f = dyn->f;
   const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
-  const double* __restrict__ znorm = dyn->znorm;
+  const bool gibbs = dyn->znorm != nullptr;
+  const double* __restrict__ zsrc = gibbs ? dyn->znorm : P;   // (every load unconditional: the ALS form reads a word it does not use)
+  const size_t zmul = gibbs ? 1 : (size_t)kp;
   const uint32_t tid = threadIdx.x;
-  uint32_t b0 = bbase[B], rows = bbase[B + 1] - b0, f0 = bfeat[B], nf = bfeat[B + 1] - f0;
-  double2 v[PT]; uint16_t pa[PT]; float xv[PT]; uint32_t ft, lov; double old;
-  auto load_in = [&](uint32_t b0_, uint32_t rows_, uint32_t f0_, uint32_t nf_, double2 (&v_)[PT], uint16_t (&pa_)[PT], float (&xv_)[PT], uint32_t& ft_, uint32_t& lov_) {
-    ft_ = feats[min(f0_ + min(tid, nf_ ? nf_ - 1 : 0u), cnt - 1)];
-    lov_ = loff[min(f0_ + min(tid, nf_), cnt)] - b0_;
+  struct Geo { uint32_t b0, rows, f0, nf; };
+  auto geo = [&](int Bx) {   // a block past the workgroup's last: no rows, no features (its loads re-read one word of the last block)
+    const bool ok = Bx < Bend;
+    const int Bc = ok ? Bx : Bend - 1;
+    Geo g; g.b0 = bbase[Bc]; g.rows = ok ? bbase[Bc + 1] - g.b0 : 0u; g.f0 = bfeat[Bc]; g.nf = ok ? bfeat[Bc + 1] - g.f0 : 0u;
+    return g;
+  };
+  auto load_feat = [&](const Geo& g) { return feats[min(g.f0 + min(tid, g.nf ? g.nf - 1 : 0u), cnt - 1)]; };
+  auto load_pairs = [&](const Geo& g, double2 (&v_)[PT], uint16_t (&pa_)[PT], float (&xv_)[PT], uint32_t& lov_) {
+    lov_ = loff[min(g.f0 + min(tid, g.nf), cnt)] - g.b0;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
-      const uint32_t i = tid + u * NT, ic = min(b0_ + min(i, rows_ ? rows_ - 1 : 0u), n - 1);
+      const uint32_t i = tid + u * NT, ic = min(g.b0 + min(i, g.rows ? g.rows - 1 : 0u), n - 1);
       v_[u] = nt_pair(src + ic);
-      pa_[u] = nt_ld(perm_in + ic);
+      pa_[u] = BLK_KO(8) ? (uint16_t)i : nt_ld(perm_in + ic);
       xv_[u] = UNIT ? 1.0f : nt_ld(xs + ic);
     }
   };
-  load_in(b0, rows, f0, nf, v, pa, xv, ft, lov);
+  Geo cur = geo(B), nxt = geo(B + slots);
+  double2 v[PT]; uint16_t pa[PT]; float xv[PT]; uint32_t ft, lov, ftn; double old, zv;
+  ft = load_feat(cur);
+  ftn = load_feat(nxt);
+  load_pairs(cur, v, pa, xv, lov);
   old = P[(size_t)ft * kp + f];
+  zv = zsrc[(size_t)ft * zmul];
   for (;;) {
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
       const uint32_t i = tid + u * NT;
-      if (i < rows) { lp[pa[u]] = v[u]; if (!UNIT) lx[i] = xv[u]; }
+      lp[i < cur.rows ? (BLK_KO(4) ? i : (uint32_t)pa[u]) : (uint32_t)R] = v[u];
+      if (!UNIT) lx[i < cur.rows ? i : (uint32_t)R] = xv[u];
     }
-    if (tid < nf) { lfeat[tid] = ft; oldv[tid] = old; }
-    if (tid <= nf) lo[tid] = (uint16_t)lov;
-    __syncthreads();
-    // this block's way out, then the next block's way in: all in flight behind the LDS phase below
+    { const uint32_t ts = tid < cur.nf ? tid : (uint32_t)(BLK_MAXF - 1); lfeat[ts] = ft; oldv[ts] = old; newv[ts] = old; zn[ts] = zv; }   // (nf < BLK_MAXF: the last slot is spare)
+    lo[tid <= cur.nf ? tid : (uint32_t)(BLK_MAXF + 1)] = (uint16_t)lov;
+    lds_barrier();
+    // this block's way out, the next block's way in, the block after's feature ids: all in flight behind the LDS phase below
     uint16_t gs[PT]; uint32_t de[PT];
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
-      const uint32_t i = tid + u * NT, ic = min(b0 + min(i, rows ? rows - 1 : 0u), n - 1);
-      gs[u] = nt_ld(gsrc + ic);
-      de[u] = nt_ld(dest + ic);
+      const uint32_t i = tid + u * NT, ic = min(cur.b0 + min(i, cur.rows ? cur.rows - 1 : 0u), n - 1);
+      gs[u] = BLK_KO(8) ? (uint16_t)min(i, cur.rows ? cur.rows - 1 : 0u) : nt_ld(gsrc + ic);
+      de[u] = BLK_KO(8) ? ic : nt_ld(dest + ic);
     }
-    const int Bn = B + slots;
-    const bool more = Bn < Bend;   // (uniform)
-    const uint32_t b0n = more ? bbase[Bn] : b0, rowsn = more ? bbase[Bn + 1] - b0n : min(rows, 1u);
-    const uint32_t f0n = more ? bfeat[Bn] : f0, nfn = more ? bfeat[Bn + 1] - f0n : 0u;
-    double2 vn[PT]; uint16_t pan[PT]; float xvn[PT]; uint32_t ftn, lovn;
-    load_in(b0n, rowsn, f0n, nfn, vn, pan, xvn, ftn, lovn);
-    {
+    const bool more = B + slots < Bend;   // (uniform)
+    const Geo aft = geo(B + 2 * slots);
+    double2 vn[PT]; uint16_t pan[PT]; float xvn[PT]; uint32_t lovn;
+    load_pairs(nxt, vn, pan, xvn, lovn);
+    const double oldn = P[(size_t)ftn * kp + f];   // (the next block's features: none of them is stepped by this block)
+    const double zvn = zsrc[(size_t)ftn * zmul];
+    const uint32_t ftnn = load_feat(aft);
+    if (!BLK_KO(1)) {
       const int g = tid / LG, l = tid % LG;
-      for (uint32_t fi = g; fi < nf; fi += NG) {
+      for (uint32_t fi = g; fi < cur.nf; fi += NG) {
         const uint32_t a = lo[fi], b = lo[fi + 1];
         const double oldf = oldv[fi];
         double mean = 0.0, var = 0.0;
@@ -310,10 +342,9 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
         mean -= oldf * var;                              // :318
         var = 1.0 / (lambda + alpha * var);              // :319
         mean = -var * (alpha * mean - mu * lambda);      // :320
-        const uint32_t feat = lfeat[fi];
-        const double nv = bad_number_b(var) ? 0.0 : (znorm ? mean + sqrt(var) * znorm[feat] : mean);
-        if (bad_number_b(nv)) continue;                  // CHECK_PARAM (:336)
-        if (l == 0) P[(size_t)feat * kp + f] = nv;
+        const double nv = bad_number_b(var) ? 0.0 : (gibbs ? mean + sqrt(var) * zn[fi] : mean);
+        if (bad_number_b(nv)) continue;                  // CHECK_PARAM (:336): newv keeps the old value
+        if (l == 0) newv[fi] = nv;
         const double diff = oldf - nv;
         for (uint32_t t0 = a + l; t0 < b; t0 += 4 * LG) {
           double2 c[4]; float x[4];
@@ -328,16 +359,16 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
         }
       }
     }
-    const double oldn = P[(size_t)ftn * kp + f];   // (the next block's features: none of them is stepped by this block)
-    __syncthreads();
+    lds_barrier();
+    { const uint32_t ts = min(tid, cur.nf - 1); P[(size_t)lfeat[ts] * kp + f] = newv[ts]; }   // (threads past the last feature repeat its store: same address, same value)
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
       const uint32_t i = tid + u * NT;
-      if (i < rows) dst[de[u]] = lp[gs[u]];
+      dst[i < cur.rows ? (BLK_KO(2) ? cur.b0 + i : de[u]) : n] = lp[BLK_KO(4) ? min(i, (uint32_t)R) : (uint32_t)gs[u]];
     }
     if (!more) break;
-    __syncthreads();   // (the pairs have left the LDS before the next block lands in it)
-    B = Bn; b0 = b0n; rows = rowsn; f0 = f0n; nf = nfn; ft = ftn; lov = lovn; old = oldn;
+    lds_barrier();   // (the pairs have left the LDS -- not yet the CU -- before the next block lands in it)
+    B += slots; cur = nxt; nxt = aft; ft = ftn; ftn = ftnn; lov = lovn; old = oldn; zv = zvn;
 #pragma unroll
     for (int u = 0; u < PT; ++u) { v[u] = vn[u]; pa[u] = pan[u]; xv[u] = xvn[u]; }
   }

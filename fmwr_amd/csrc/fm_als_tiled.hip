@@ -978,7 +978,7 @@ static int order_buffers(fmx_engine* e, int64_t n) {
   if (e->als_lo_rows >= n && e->als_lo[0] && e->als_lo[1]) return FMX_OK;
   FMX_HIP(hipStreamSynchronize(e->stream));
   (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]); e->als_lo[0] = e->als_lo[1] = nullptr; e->als_lo_rows = 0;
-  if (hipMalloc(&e->als_lo[0], (size_t)n * sizeof(double2)) != hipSuccess || hipMalloc(&e->als_lo[1], (size_t)n * sizeof(double2)) != hipSuccess) {
+  if (hipMalloc(&e->als_lo[0], ((size_t)n + 1) * sizeof(double2)) != hipSuccess || hipMalloc(&e->als_lo[1], ((size_t)n + 1) * sizeof(double2)) != hipSuccess) {   // (+ 1: the spare pair the block form's masked-off lanes store to)
     (void)hipGetLastError();
     (void)hipFree(e->als_lo[0]); e->als_lo[0] = nullptr;
     return FMX_ERR_HIP;   // (the caller falls back to the three-pass form)

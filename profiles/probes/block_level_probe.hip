@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256) void copy_k(const double2* __restrict__ a, dou
   for (int u = 0; u < 8; ++u) { const int64_t i = i0 + u * 256; if (i < n) b[i] = v[u]; }
 }
 
+__device__ unsigned long long phase_ticks[8];
+#define STAMP(slot) do { if (MODE & 8) { const unsigned long long now_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&phase_ticks[slot], now_ - last_); last_ = now_; } } while (0)
 // MODE bit 0: the sums / step / correction phase runs; bit 1: the store goes to `dest` (else to the block's own region: a plain copy through LDS);
 // bit 2: blocks dealt so that consecutive blocks share an XCD
 template <int R, int NT_, int MODE, int LISTLEN>
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(NT_) void block_level_k(const double2* __restrict__
   int B = blockIdx.x;
   if (MODE & 4) { const int per = (nb + 7) / 8; B = (blockIdx.x & 7) * per + (blockIdx.x >> 3); if (B >= nb || (int)(blockIdx.x >> 3) >= per) return; }
   const uint32_t b0 = bbase[B], rows = bbase[B + 1] - b0;
+  unsigned long long last_ = wall_clock64();
   double2 v[PT]; uint16_t pa[PT], gs[PT]; uint32_t de[PT];
 #pragma unroll
   for (int u = 0; u < PT; ++u) {
@@ -54,8 +57,11 @@ __global__ __launch_bounds__(NT_) void block_level_k(const double2* __restrict__
     de[u] = (MODE & 2) ? ntl(dest + b0 + ic) : b0 + ic;
   }
 #pragma unroll
+  STAMP(0);   // issue of all loads
   for (int u = 0; u < PT; ++u) { const uint32_t i = threadIdx.x + u * NT_; if (i < rows) lp[pa[u]] = v[u]; }
+  STAMP(1);   // wait for the pairs + LDS scatter
   __syncthreads();
+  STAMP(2);   // barrier
   if (MODE & 1) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int K = (LISTLEN + 63) / 64;
@@ -72,10 +78,14 @@ __global__ __launch_bounds__(NT_) void block_level_k(const double2* __restrict__
 #pragma unroll
       for (int k = 0; k < K; ++k) { const uint32_t i = lo + lane + 64 * k; if (i < hi) lp[i] = make_double2(c[k].x - diff, c[k].y - h[k] * diff); }
     }
+    STAMP(3);   // sums, steps, corrections (wave 0's share)
     __syncthreads();
+    STAMP(4);   // barrier
   }
 #pragma unroll
   for (int u = 0; u < PT; ++u) { const uint32_t i = threadIdx.x + u * NT_; if (i < rows) dst[de[u]] = lp[gs[u]]; }
+  STAMP(5);     // LDS gather + issue of the stores
+  if (MODE & 8) { __builtin_amdgcn_s_waitcnt(0); STAMP(6); }   // the stores acknowledged
 }
 
 int main(int argc, char** argv) {
@@ -146,6 +156,14 @@ int main(int argc, char** argv) {
   RUN(1024, 3, "block kernel 1024 thr: runs + sums")
   RUN(1024, 6, "block kernel 1024 thr: runs, XCD-consecutive blocks")
   RUN(1024, 7, "block kernel 1024 thr: runs + sums, XCD-consecutive blocks")
+  {
+    unsigned long long z8[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(phase_ticks), z8, sizeof(z8)));
+    RUN(1024, 15, "block kernel 1024 thr: runs + sums, XCD-consec, phase stamps")
+    unsigned long long t8[8]; CK(hipMemcpyFromSymbol(t8, HIP_SYMBOL(phase_ticks), sizeof(t8)));
+    const double per = 0.01 / (23.0 * nb);   // 3 warm-up + 20 timed launches; 100 MHz ticks -> us per workgroup
+    printf("    per workgroup (us): issue loads %.2f | wait + LDS scatter %.2f | barrier %.2f | sums (wave 0) %.2f | barrier %.2f | LDS gather + store issue %.2f | stores acked %.2f\n",
+           t8[0] * per, t8[1] * per, t8[2] * per, t8[3] * per, t8[4] * per, t8[5] * per, t8[6] * per);
+  }
   RUN(512, 7, "block kernel 512 thr (16 pairs/thread): runs + sums, XCD-consec")
   RUN(512, 3, "block kernel 512 thr (16 pairs/thread): runs + sums")
   // check of the last full launch: every destination holds a finite pair
