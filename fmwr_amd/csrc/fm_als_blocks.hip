@@ -237,7 +237,8 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
 //   * no memory operation sits under a condition -- lanes past the block's end store to a spare slot (lp[R], dst[n]) -- and no store sits inside the list loop.
 // Same bits as als_block_level_k: the same slots, the same lane groups, the same order.
 // -DFMX_BLK_KO=bits (profiles/probes/block_knockouts.sh, never the product build): knock-outs of the pipelined kernel, fixed at compile time -- 1: no list
-// loop; 2: the pairs leave for the block's own region (a linear store); 4: the LDS is written and read linearly (no slots); 8: no index loads.  Wrong results,
+// loop; 2: the pairs leave for the block's own region (a linear store); 4: the LDS is written and read linearly (no slots); 8: no index loads (16, 32: A/B
+// builds with correct results: non-temporal pair stores; default-policy pair loads).  Wrong results,
 // the time of what is left (profiles/r05_block_knockouts.txt).
 #ifndef FMX_BLK_KO
 #define FMX_BLK_KO 0
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
       const uint32_t i = tid + u * NT, ic = min(g.b0 + min(i, g.rows ? g.rows - 1 : 0u), n - 1);
-      v_[u] = nt_pair(src + ic);
+      v_[u] = BLK_KO(32) ? src[ic] : nt_pair(src + ic);
       pa_[u] = BLK_KO(8) ? (uint16_t)i : nt_ld(perm_in + ic);
       xv_[u] = UNIT ? 1.0f : nt_ld(xs + ic);
     }
@@ -364,7 +365,10 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
       const uint32_t i = tid + u * NT;
-      dst[i < cur.rows ? (BLK_KO(2) ? cur.b0 + i : de[u]) : n] = lp[BLK_KO(4) ? min(i, (uint32_t)R) : (uint32_t)gs[u]];
+      const double2 c = lp[BLK_KO(4) ? min(i, (uint32_t)R) : (uint32_t)gs[u]];
+      double2* const at = dst + (i < cur.rows ? (BLK_KO(2) ? cur.b0 + i : de[u]) : n);
+      if (BLK_KO(16)) { blk_v2d cv; cv.x = c.x; cv.y = c.y; __builtin_nontemporal_store(cv, reinterpret_cast<blk_v2d*>(at)); }   // (16: non-temporal stores -- an A/B, not a knock-out)
+      else *at = c;
     }
     if (!more) break;
     lds_barrier();   // (the pairs have left the LDS -- not yet the CU -- before the next block lands in it)

@@ -429,7 +429,11 @@ int fmx_als_tiled_info(fmx_engine* e, fmx_matrix* m, int32_t* levels_tiled, int6
  * fm_als_tiled.hip): per level one kernel streams the pairs, sums the lists and takes the coordinate steps (no per-tile partial sums), one kernel applies the
  * corrections and writes every pair to its place in the next level's order (a permutation inside the tile's L2-resident slice: the one random 16-byte access
  * per stored nonzero that is left).  Same arithmetic per entry as the other forms, sums associated in (tile, entry) order: 1e-10 against them and the oracle,
- * bitwise run to run.  *level_order = 1 when the V sweeps of this matrix take that form (the w sweep keeps the three-pass form); FMX_ALS_ORDER=0 forbids it. */
+ * bitwise run to run.  Where, in addition, every feature's list fits a block of 8 192 rows (6 144 with real values), the sweep takes the BLOCK form
+ * (fm_als_blocks.hip): the level's array is feature-block-major and ONE kernel per level streams a block's pairs into LDS, sums its lists, takes the coordinate
+ * steps, corrects the pairs there and stores them as contiguous runs into the next level's blocks -- the pairs are read once per level and nothing waits for
+ * another workgroup (202 against 120 M examples/s at configs[4]).  *level_order = 2: the block form, 1: the tile form, 0: neither (the w sweep keeps the
+ * three-pass form).  FMX_ALS_ORDER=1 keeps the tile form, 0 forbids both. */
 int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;

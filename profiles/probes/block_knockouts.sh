@@ -1,7 +1,7 @@
 #!/bin/bash
 # Knock-outs of the block form's pipelined level kernel (fm_als_blocks.hip, -DFMX_BLK_KO=bits: compile-time, so that the register allocation of what is left is
 # its own): per-level launch time of what is left.  build (CPU box): profiles/probes/block_knockouts.sh build ; run (GPU box): profiles/probes/block_knockouts.sh
-KOS="1 2 3 4 8 12 15"
+KOS="${KOS:-1 2 3 4 8 12 15}"
 if [ "$1" = build ]; then
   python -m fmwr_amd.build > /dev/null
   for ko in $KOS; do
