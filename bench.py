@@ -706,6 +706,21 @@ def main_sweep(args, rank, local_rank, world):
                                              "ceiling_frac": got / r if r else None,
                                              "note": "entries per second of a level over the measured rate of random 16-B gathers from the whole (q, e) table (the untiled form does a gather AND a scatter "
                                                      "per entry against it: at most 0.5; the row-tiled and level-order forms keep their random accesses inside L2-resident slices or LDS and are not bound by it)"}
+    if blocks and world == 1:
+        # opt-in variant (fmx_als_carry_q): the sweep keeps q = X v_f current as it goes, so sweep t + 1 needs no forward pass to rebuild it.  NOT `value`: the reference
+        # recomputes q for every factor of every sweep, and `value` above does one forward pass per sweep for it
+        e.als_carry_q(True)
+        sweep(); fence()          # (this one still builds the table)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sweep()
+        fence()
+        dtc = time.perf_counter() - t0
+        e.als_carry_q(False)
+        ssc = float((d_err * d_err).sum().item())
+        out["value_q_carried"] = {"value": n * args.steps / dtc, "unit": "examples/s", "ms_per_step": dtc / args.steps * 1e3, "finite": bool(np.isfinite(ssc)),
+                                  "note": "fmx_als_carry_q(1): q = X v_f is written back as each factor's pairs move on and reused by the next sweep when V's 64-bit fingerprint is "
+                                          "unchanged (no forward pass; rebuilt every 64th sweep); agrees with the rebuilt form to ~1e-13 (tests/test_gpu_configs4.py)"}
     if args.cpu_rows > 0:
         out["cpu_baseline"] = cpu_baseline(m, args, None)
     return out
@@ -866,9 +881,14 @@ def compact_line(d):
         keep["roofline"]["kernels"] = {name: {kk: v[kk] for kk in ("avg_launch_ms", "frac", "ceiling_frac", "hbm_priced_frac", "traffic", "fabric") if kk in v} for name, v in r["kernels"].items()}
     if "gather_ceiling" in r:
         keep["roofline"]["ceiling_frac"] = r["gather_ceiling"].get("ceiling_frac")
-    for kk in ("cpu_baseline", "forward_rows_per_s", "ingest"):
+    for kk in ("cpu_baseline", "forward_rows_per_s", "ingest", "value_q_carried"):
         if kk in d:
             keep[kk] = d[kk]
+    if isinstance(r.get("step"), dict):
+        keep["roofline"]["step"] = r["step"]
+    for kk in ("level_order_form",):
+        if kk in d["config"]:
+            keep[kk] = d["config"][kk]
     for kk in ("batch_rows_per_gpu", "tile_rows", "features_occurring_per_step", "levels", "levels_row_tiled", "ingest_wait_s"):
         if kk in d["config"]:
             keep[kk] = d["config"][kk]

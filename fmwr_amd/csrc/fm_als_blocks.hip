@@ -35,6 +35,7 @@ constexpr int BLK_R_VAL = 6144;      // with a value per entry next to the pair:
 struct AlsBlocks {
   int64_t n = 0;
   int L = 0, R = 0, unit = 0;
+  uint64_t uid = 0;               // one per plan built (a q table carried from sweep to sweep belongs to ONE plan)
   std::vector<uint32_t> nblk;     // per level
   std::vector<size_t> boff;       // per level: first entry of the level in bbase / bfeat (nblk + 1 entries each)
   std::vector<size_t> foff;       // per level: first entry of the level in loff (cnt + 1 entries each)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
                                                                  const uint32_t* __restrict__ bfeat, int nb, const uint32_t* __restrict__ loff, const uint32_t* __restrict__ feats,
                                                                  const uint16_t* __restrict__ perm_in, const uint16_t* __restrict__ gsrc, const uint32_t* __restrict__ dest,
                                                                  const float* __restrict__ xs, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
-                                                                 const double* __restrict__ qin, uint32_t n) {
+                                                                 const double* __restrict__ qin, double* __restrict__ qprev_out, uint32_t n) {
   constexpr int NT = BLK_THREADS, PT = R / NT, NG = NT / LG;
   static_assert(R % NT == 0, "whole pairs per thread");
   __shared__ double2 lp[R];
@@ -173,7 +174,10 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
 #pragma unroll
   for (int u = 0; u < PT; ++u) {
     const uint32_t i = threadIdx.x + u * NT;
-    if (i < rows) { lp[pa[u]] = QIN ? make_double2(qn[u], v[u].y) : v[u]; if (!UNIT) lx[i] = xv[u]; }
+    if (i < rows) {
+      lp[pa[u]] = QIN ? make_double2(qn[u], v[u].y) : v[u]; if (!UNIT) lx[i] = xv[u];
+      if (QIN && qprev_out) qprev_out[b0 + i] = v[u].x;   // (q carried from sweep to sweep: the pair still holds the PREVIOUS factor's final q, in level 0's order)
+    }
   }
   __syncthreads();
   {
@@ -385,10 +389,20 @@ __global__ void als_block_enter_k(const double2* __restrict__ qe, const double* 
   const uint32_t r = row0[i];
   dst[i] = make_double2(Q0[i], qe[r].y);   // (Q: built on the permuted CSR, already in this order)
 }
-__global__ void als_block_exit_k(const double2* __restrict__ src, const uint32_t* __restrict__ row0, int64_t n, double2* __restrict__ qe) {
+__global__ void als_block_exit_k(const double2* __restrict__ src, const uint32_t* __restrict__ row0, int64_t n, double2* __restrict__ qe, double* __restrict__ qlast_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  qe[row0[i]] = src[i];
+  const double2 c = src[i];
+  qe[row0[i]] = c;
+  if (qlast_out) qlast_out[i] = c.x;   // (q carried from sweep to sweep: the last factor's final q)
+}
+// a 64-bit fingerprint of the fp64 V table: sum of (bits of element i) x (2 i + 1) modulo 2^64 -- integer adds commute, so any reduction order gives the same word
+__global__ __launch_bounds__(256) void als_vhash_k(const double* __restrict__ V, size_t count, unsigned long long* __restrict__ out) {
+  unsigned long long h = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) h += (unsigned long long)__double_as_longlong(V[i]) * (2ull * i + 1ull);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += ((unsigned long long)(unsigned)__shfl_xor((int)(h >> 32), o) << 32) + (unsigned)__shfl_xor((int)(h & 0xFFFFFFFFull), o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
 }
 
 }  // namespace
@@ -502,6 +516,7 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
                      (const uint32_t*)Bk->row0, n, L, Bk->colP, Bk->valP);
   FMX_HIP(hipGetLastError());
   FMX_HIP(hipStreamSynchronize(stream));
+  { static uint64_t next_uid = 0; Bk->uid = ++next_uid; }
   *out = Bk.release();
   return FMX_OK;
 }
@@ -509,6 +524,21 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
 void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP) {
   const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
   *colP = Bk->colP; *valP = Bk->valP;
+}
+
+uint64_t als_blocks_uid(const void* b) { return b ? reinterpret_cast<const AlsBlocks*>(b)->uid : 0; }
+
+// fingerprint of the engine's fp64 V table (waits for the stream)
+int als_vhash(fmx_engine* e, uint64_t* out) {
+  if (!e->als_hash_word) FMX_HIP(hipMalloc(&e->als_hash_word, sizeof(unsigned long long)));
+  FMX_HIP(hipMemsetAsync(e->als_hash_word, 0, sizeof(unsigned long long), e->stream));
+  const size_t count = (size_t)e->p * (size_t)e->kp64;
+  hipLaunchKernelGGL(als_vhash_k, dim3(2048), dim3(256), 0, e->stream, (const double*)e->dV, count, reinterpret_cast<unsigned long long*>(e->als_hash_word));
+  unsigned long long h = 0;
+  FMX_HIP(hipMemcpyAsync(&h, e->als_hash_word, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  *out = (uint64_t)h;
+  return FMX_OK;
 }
 
 int als_blocks_info(const void* b, int32_t* block_rows, int32_t* blocks_level0) {
@@ -525,15 +555,15 @@ int als_blocks_enter(fmx_engine* e, const void* b, const double2* d_qe, const do
   return FMX_OK;
 }
 
-int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe) {
+int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe, double* d_qlast_out) {
   const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
-  hipLaunchKernelGGL(als_block_exit_k, dim3((unsigned)((Bk->n + 255) / 256)), dim3(256), 0, e->stream, src, (const uint32_t*)Bk->row0, Bk->n, d_qe);
+  hipLaunchKernelGGL(als_block_exit_k, dim3((unsigned)((Bk->n + 255) / 256)), dim3(256), 0, e->stream, src, (const uint32_t*)Bk->row0, Bk->n, d_qe, d_qlast_out);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 
 // one level (slot s) of one factor; d_feats: the level's feature ids; d_qin (level 0's array order): this factor's q, taken in by its first level
-int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin) {
+int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin, double* d_qprev_out) {
   const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
   const int nb = (int)Bk->nblk[(size_t)s];
   const dim3 grid((unsigned)(((nb + 7) / 8) * 8)), blk(BLK_THREADS);
@@ -546,7 +576,7 @@ int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, do
   const float* xs = Bk->xs ? Bk->xs + (size_t)s * Bk->n : nullptr;
   FMX_CHECK(!d_qin || s == 0, FMX_ERR_STATE, "a factor's q enters at its FIRST level");
 #define FMX_BLK(UNITv, Rv, LGv, QNv)                                                                                                                              \
-  hipLaunchKernelGGL((als_block_level_k<UNITv, Rv, LGv, QNv>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, e->dV, e->kp64, dyn, d_qin, \
+  hipLaunchKernelGGL((als_block_level_k<UNITv, Rv, LGv, QNv>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, e->dV, e->kp64, dyn, d_qin, d_qprev_out, \
                      (uint32_t)Bk->n)
 #define FMX_BLK_Q(UNITv, Rv, LGv) do { if (d_qin) FMX_BLK(UNITv, Rv, LGv, true); else FMX_BLK(UNITv, Rv, LGv, false); } while (0)
 #define FMX_BLK_L(UNITv, Rv)                                                                                                                                      \
@@ -558,7 +588,7 @@ int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, do
       default: FMX_BLK_Q(UNITv, Rv, 1); break;                                                                                                                    \
     }                                                                                                                                                             \
   } while (0)
-  static const bool pipe = env_int_b("FMX_ALS_BLOCK_PIPE", 1) != 0;
+  const bool pipe = env_int_b("FMX_ALS_BLOCK_PIPE", 1) != 0;   // (read per launch: the tests compare the two kernels in one process)
   if (pipe && !d_qin) {
     // one resident workgroup per CU (the LDS admits one): `slots` of them per XCD, each walking its XCD's share of the blocks
     static int n_cus = 0;

@@ -944,7 +944,7 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     const size_t need = (size_t)m->n * e->kp64;
     if (e->als_Q_elems < need) {
       (void)hipStreamSynchronize(e->stream);
-      (void)hipFree(e->als_Q); e->als_Q = nullptr; e->als_Q_elems = 0;
+      (void)hipFree(e->als_Q); e->als_Q = nullptr; e->als_Q_elems = 0; e->als_q_have = 0;
       if (hipMalloc(&e->als_Q, need * sizeof(double)) == hipSuccess) e->als_Q_elems = need;
       else (void)hipGetLastError();  // no room for the table: fall back to one gather pass per factor
     }
@@ -953,7 +953,17 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
   const uint32_t* colP = nullptr; const float* valP = nullptr;
   e->als_q_level0 = 0;
   if (d_Q && !d_qe_new) FMX_TRY(als_order_prepare(e, m, &colP, &valP));   // the block form: q in level 0's array order (the forward runs on the permuted CSR)
-  if (d_Q) {
+  // q carried from the previous sweep (opt-in, block form): valid if it belongs to this plan and V is bit for bit what that sweep left
+  constexpr int ALS_CARRY_REFRESH = 64;
+  const bool carry = e->als_carry_q && colP != nullptr && d_Q != nullptr;
+  bool reuse = false;
+  if (carry && e->als_q_have && e->als_q_plan == als_order_plan_uid(m) && e->als_q_age < ALS_CARRY_REFRESH) {
+    uint64_t hsh = 0;
+    FMX_TRY(als_vhash(e, &hsh));
+    reuse = hsh == e->als_q_hash;
+  }
+  e->als_q_have = 0;
+  if (d_Q && !reuse) {
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = colP ? colP : m->col; a.val = colP ? valP : m->val; a.r0 = 0; a.nrows = m->n;
     a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.qout_t = m->n; a.link = FMX_LINK_NONE;
@@ -973,12 +983,18 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
           prof_begin(e, FMX_KERNEL_ALS_SWEEP);   // one level of one factor: the unit bench.py --solver als prices
           const double* d_q = e->als_q_level0 ? ((s == 0 && f > 0) ? d_Q + (size_t)f * m->n : nullptr)                      // block form: q enters at the first level
                                               : ((s == S - 1 && f + 1 < e->k) ? d_Q + (size_t)(f + 1) * m->n : nullptr);   // tile form: the next q leaves the last
-          const int st = als_order_level(e, m, s, dyn, d_q);
+          const int st = als_order_level(e, m, s, dyn, d_q, (carry && e->als_q_level0 && s == 0 && f > 0) ? d_Q + (size_t)(f - 1) * m->n : nullptr);
           prof_end(e);
           FMX_TRY(st);
         }
       }
-      return als_order_exit(e, m, d_qe);
+      FMX_TRY(als_order_exit(e, m, d_qe, (carry && e->als_q_level0) ? d_Q + (size_t)(e->k - 1) * m->n : nullptr));
+      if (carry && e->als_q_level0) {   // the table now holds X v_f of the new V, every factor
+        uint64_t hsh = 0;
+        FMX_TRY(als_vhash(e, &hsh));
+        e->als_q_hash = hsh; e->als_q_plan = als_order_plan_uid(m); e->als_q_age = reuse ? e->als_q_age + 1 : 1; e->als_q_have = 1;
+      }
+      return FMX_OK;
     }
   }
   bool picked = false;   // the previous factor's last correction pass already stored this factor's q (tiled form)

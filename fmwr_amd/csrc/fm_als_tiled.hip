@@ -1021,11 +1021,11 @@ int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const dou
 
 // one level (slot s = the s-th non-empty level) of one factor: sums + step, then apply into the next level's order; d_qnext (row order) on the last level
 // of a factor that has a successor
-int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, const double* d_qnext) {
+int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, const double* d_qnext, double* d_qprev_out) {
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
   if (T->blocks) {
     FMX_TRY(als_blocks_level(e, T->blocks, s, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), reinterpret_cast<double2*>(e->als_lo[1 - e->als_lo_cur]),
-                             T->feats + T->lvl0[(size_t)s], dyn, d_qnext));
+                             T->feats + T->lvl0[(size_t)s], dyn, d_qnext, d_qprev_out));
     e->als_lo_cur = 1 - e->als_lo_cur;
     return FMX_OK;
   }
@@ -1109,9 +1109,14 @@ int als_order_levels(const fmx_matrix* m) {
 }
 
 // exit: the current buffer (level 0's order: the last apply of the last factor wrote there) back to d_qe in row order
-int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe) {
+uint64_t als_order_plan_uid(const fmx_matrix* m) {
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
-  if (T->blocks) return als_blocks_exit(e, T->blocks, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), d_qe);
+  return T ? als_blocks_uid(T->blocks) : 0;
+}
+
+int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe, double* d_qlast_out) {
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (T->blocks) return als_blocks_exit(e, T->blocks, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), d_qe, d_qlast_out);
   hipLaunchKernelGGL(als_order_exit_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), (const uint32_t*)T->trow,
                      (const int64_t*)T->tile_base, m->n, T->tshift, d_qe);
   FMX_HIP(hipGetLastError());

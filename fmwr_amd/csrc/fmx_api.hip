@@ -700,7 +700,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws); (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws); (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]); (void)hipFree(e->als_hash_word);
   als_graph_free(e->als_graph_w); als_graph_free(e->als_graph_v);
   if (e->side_fork) (void)hipEventDestroy(e->side_fork);
   if (e->side_join) (void)hipEventDestroy(e->side_join);
@@ -1949,6 +1949,13 @@ int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order) {
   FMX_TRY(use_device(e->cfg.device));
   FMX_TRY(als_plan_info(e, m, nullptr, nullptr, nullptr, nullptr));
   *level_order = als_order_form(m);   // 0: none, 1: the tile form, 2: the block form (fm_als_blocks.hip)
+  return FMX_OK;
+}
+
+int fmx_als_carry_q(fmx_engine* e, int32_t on) {
+  FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
+  e->als_carry_q = on ? 1 : 0;
+  e->als_q_have = 0;
   return FMX_OK;
 }
 

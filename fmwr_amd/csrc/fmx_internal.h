@@ -285,6 +285,13 @@ struct fmx_engine {
   int64_t als_lo_rows = 0;
   int als_lo_cur = 0;              // which of the two holds the pairs now
   int als_q_level0 = 0;            // the q table of the sweep under way is in level 0's array order (block form: built on the permuted CSR)
+  // q carried from sweep to sweep (fmx_als_carry_q; block form only): after a V sweep the table holds X v_f for the NEW V of every factor (each factor's final q is
+  // written back as it leaves the pairs), so the next sweep needs no forward pass -- if V is still what the sweep left (a 64-bit fingerprint of the table) and the
+  // plan is the same one.  Rebuilt every ALS_CARRY_REFRESH sweeps against rounding drift.
+  int als_carry_q = 0;
+  int als_q_have = 0, als_q_age = 0;
+  uint64_t als_q_hash = 0, als_q_plan = 0;
+  void* als_hash_word = nullptr;
   const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
                                       // finished factor's q when that level is a tiled one (it then clears this pointer: the pick kernel is not needed)
   int als_vf_slot = -1, als_vf_buf = 0;  // tiled sweep: the tiled level whose coordinates the previous level's step kernel already gathered, and into which half
@@ -577,11 +584,12 @@ bool als_order_ready(const fmx_matrix* m);
 int als_order_levels(const fmx_matrix* m);
 int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const double* d_Q0, bool* ok);
 // d_qnext: the tile form folds the next factor's q (row order) into a factor's LAST level; the block form takes a factor's q (level 0's array order) in at its FIRST
-int als_order_level(fmx_engine* e, fmx_matrix* m, int slot, const SweepDyn* dyn, const double* d_qnext);
+int als_order_level(fmx_engine* e, fmx_matrix* m, int slot, const SweepDyn* dyn, const double* d_qnext, double* d_qprev_out = nullptr);
 // the block form builds q for all factors on a copy of the CSR whose rows are in level 0's array order: the copy (and the pair buffers, allocated here), or *colP =
 // null where the sweep will not take the block form (no such plan, no memory)
 int als_order_prepare(fmx_engine* e, fmx_matrix* m, const uint32_t** colP, const float** valP);
-int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe);
+int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe, double* d_qlast_out = nullptr);
+uint64_t als_order_plan_uid(const fmx_matrix* m);   // the block form's plan (0: none)
 // the BLOCK form of the level-order sweep (fm_als_blocks.hip): the level's array feature-block-major, ONE kernel per level.  Built by als_tiled_build on
 // complete plans whose lists all fit a block; *out stays null where it does not apply.
 struct AlsBlocksIn {
@@ -595,9 +603,11 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
 void als_blocks_free(void* b);
 int als_blocks_info(const void* b, int32_t* block_rows, int32_t* blocks_level0);
 int als_blocks_enter(fmx_engine* e, const void* b, const double2* d_qe, const double* d_Q0, double2* dst);
-int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin);
+int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin, double* d_qprev_out);
+uint64_t als_blocks_uid(const void* b);
+int als_vhash(fmx_engine* e, uint64_t* out);
 void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP);
-int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe);
+int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe, double* d_qlast_out);
 int als_order_form(const fmx_matrix* m);   // 0: none, 1: the tile form, 2: the block form
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 

@@ -540,6 +540,10 @@ class Engine:
         L.check(L.lib().fmx_als_order_info(self.h, m.h, C.byref(v)))
         return int(v.value)
 
+    def als_carry_q(self, on=True):
+        """Opt-in: the block form of the V sweep keeps q = X v_f current from sweep to sweep and skips the forward pass that rebuilds it (fmx_als_carry_q)."""
+        L.check(L.lib().fmx_als_carry_q(self.h, C.c_int32(int(on))))
+
     def als_train(self, m, max_iter, with_v=False):
         L.check(L.lib().fmx_als_train(self.h, m.h, C.c_int32(max_iter), C.c_int32(int(with_v))))
 

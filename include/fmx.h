@@ -435,6 +435,14 @@ int fmx_als_tiled_info(fmx_engine* e, fmx_matrix* m, int32_t* levels_tiled, int6
  * another workgroup (202 against 120 M examples/s at configs[4]).  *level_order = 2: the block form, 1: the tile form, 0: neither (the w sweep keeps the
  * three-pass form).  FMX_ALS_ORDER=1 keeps the tile form, 0 forbids both. */
 int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order);
+/* Opt-in (default off): carry q = X v_f from one V sweep to the next.  The reference recomputes q_f from scratch for every factor of every sweep
+ * (solver/MCMC_ALS_Learner.h:283-300); here one forward pass builds it for all factors (38 GB of V-row gathers at configs[4]: 7 of a sweep's 49 ms).  But a sweep
+ * itself keeps q current -- every correction of v_fj is applied to the rows' q (:341-350) -- so when a factor's last level is done its pairs hold X v_f for the NEW
+ * v_f.  With on = 1 the block form writes that back into the table as the pairs move on, and the next V sweep on the same plan skips the forward pass if the V
+ * table is bit for bit what the sweep left (a 64-bit fingerprint; set_params, training steps, another matrix or a rebuilt plan all force the rebuild, as does every
+ * 64th sweep, against rounding drift: each carried sweep adds ~1e-16 relative per level).  Results agree with the rebuilt form to ~1e-13: within the 1e-10 of the
+ * oracle tests, not bit for bit.  Other forms of the sweep ignore the switch. */
+int fmx_als_carry_q(fmx_engine* e, int32_t on);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
  * w0 update (:162-188); w sweep (:190-270, the exact one-thread form) }.  As shipped the reference never sweeps V (its

@@ -169,6 +169,71 @@ def test_configs4_block_form_matches_oracle_and_the_other_forms(monkeypatch, val
             assert util.rel_err(x, y_) < tol                                        # the same sweeps, sums associated differently
 
 
+def test_configs4_block_form_pipelined_and_plain_kernels_agree_bit_for_bit(monkeypatch):
+    """The block form's level kernel exists twice: one workgroup per block (als_block_level_k: what a factor's first level, which takes its q in, always runs) and
+    resident workgroups that prefetch their next block (als_block_level_pipe_k: every other level).  Same slots, same lane groups, same order: the same bits
+    (FMX_ALS_BLOCK_PIPE=0 sends every level through the first)."""
+    from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_TILE_ROWS", "4096")
+    monkeypatch.setenv("FMX_ALS_BLOCK_ROWS", "1024")
+    n, p = 30_000, 6_000
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 71, "normal")
+    w0, w, v = util.params(p, K, 41, stdev=0.1, fp32=False)
+    err0 = np.random.default_rng(3).normal(0, 1, n)
+    z = np.random.default_rng(13).normal(0, 1, (K, p))
+    out = {}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_BLOCK_PIPE", pipe)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        assert e.als_level_order_form(m) == 2
+        gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=np.full(K, 5.0), v_mu=np.zeros(K), std_normals=z)
+        out[pipe] = (gerr, e.get_params()[2])
+        e.close(); m.close()
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+
+
+@pytest.mark.parametrize("values,gibbs", [("ones", False), ("normal", True)])
+def test_configs4_carried_q_sweeps_match_the_oracle_and_notice_a_changed_v(monkeypatch, values, gibbs):
+    """fmx_als_carry_q: the block form writes every factor's final q back into the q table, and the next sweep on the same plan skips the forward pass that
+    rebuilds it -- if V is bit for bit what the sweep left.  Four sweeps in a row against four oracle sweeps (1e-10 each); then V is replaced through
+    set_params (the fingerprint differs: the table must be rebuilt) and a fifth sweep is compared with the oracle from there."""
+    from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_TILE_ROWS", "4096")
+    monkeypatch.setenv("FMX_ALS_BLOCK_ROWS", "1024")
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 73, values)
+    w0, w, v = util.params(p, K, 43, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    lam = np.linspace(10.0, 20.0, K) if gibbs else np.linspace(0.1, 0.5, K); mu = np.linspace(-0.05, 0.05, K)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    e.als_carry_q(True)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert e.als_level_order_form(m) == 2
+    rv, gerr = v.ravel().copy(), err.copy()
+    for it in range(4):
+        z = np.random.default_rng(100 + it).normal(0, 1, (K, p)) if gibbs else None
+        rv, rerr, _ = oracle.als_update_v(K, X, rv, gerr if it == 0 else rerr_prev, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+        gerr = e.als_vsweep(m, gerr, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+        assert util.rel_err(e.get_params()[2], rv.reshape(K, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10, it
+        rerr_prev = rerr
+    # V replaced from outside: the carried table is stale and must not be used
+    _, _, v2 = util.params(p, K, 47, stdev=0.1, fp32=False)
+    e.set_params(w0, w, v2)
+    err2 = oracle.predict_batch(P, X, w0, w, v2.ravel()) - y
+    z = np.random.default_rng(200).normal(0, 1, (K, p)) if gibbs else None
+    rv2, rerr2, _ = oracle.als_update_v(K, X, v2.ravel(), err2, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+    gerr2 = e.als_vsweep(m, err2, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    assert util.rel_err(e.get_params()[2], rv2.reshape(K, p)) < 1e-10 and util.rel_err(gerr2, rerr2) < 1e-10
+    e.close(); m.close()
+
+
 def test_configs4_level_order_needs_a_complete_plan(monkeypatch):
     """Rows that lack a level (i.i.d. columns: many narrow levels) or levels that keep the column-walking kernels leave the plan incomplete: the V sweep
     then takes the three-pass form level by level, as before."""
