@@ -721,6 +721,18 @@ def main_sweep(args, rank, local_rank, world):
         out["value_q_carried"] = {"value": n * args.steps / dtc, "unit": "examples/s", "ms_per_step": dtc / args.steps * 1e3, "finite": bool(np.isfinite(ssc)),
                                   "note": "fmx_als_carry_q(1): q = X v_f is written back as each factor's pairs move on and reused by the next sweep when V's 64-bit fingerprint is "
                                           "unchanged (no forward pass; rebuilt every 64th sweep); agrees with the rebuilt form to ~1e-13 (tests/test_gpu_configs4.py)"}
+    if world == 1:
+        # the whole learner iteration around the sweep -- forward, residual, w0 step, w sweep (30 levels, three-pass tiled form), V sweep (480 levels) --
+        # through fmx_als_train(with_v = 1) (MCMC_ALS_Learner::learn, :91-156, with the update_v call the shipped update_all leaves out)
+        try:
+            e.als_train(m, 1, with_v=True); fence()
+            t0 = time.perf_counter()
+            e.als_train(m, 2, with_v=True); fence()
+            dti = (time.perf_counter() - t0) / 2
+            out["learner_iteration"] = {"ms": dti * 1e3, "examples_per_s": n / dti,
+                                        "note": "one iteration of fmx_als_train(with_v = 1) at this shape: forward + residual + w0 + w sweep + V sweep, timed over two iterations"}
+        except Exception as ex:
+            out["learner_iteration"] = {"error": str(ex)}
     if args.cpu_rows > 0:
         out["cpu_baseline"] = cpu_baseline(m, args, None)
     return out
@@ -881,7 +893,7 @@ def compact_line(d):
         keep["roofline"]["kernels"] = {name: {kk: v[kk] for kk in ("avg_launch_ms", "frac", "ceiling_frac", "hbm_priced_frac", "traffic", "fabric") if kk in v} for name, v in r["kernels"].items()}
     if "gather_ceiling" in r:
         keep["roofline"]["ceiling_frac"] = r["gather_ceiling"].get("ceiling_frac")
-    for kk in ("cpu_baseline", "forward_rows_per_s", "ingest", "value_q_carried"):
+    for kk in ("cpu_baseline", "forward_rows_per_s", "ingest", "value_q_carried", "learner_iteration"):
         if kk in d:
             keep[kk] = d[kk]
     if isinstance(r.get("step"), dict):
