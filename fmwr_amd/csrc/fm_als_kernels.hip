@@ -968,6 +968,7 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     a.row_ptr = m->row_ptr; a.col = colP ? colP : m->col; a.val = colP ? valP : m->val; a.r0 = 0; a.nrows = m->n;
     a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Q; a.qout_t = m->n; a.link = FMX_LINK_NONE;
     a.unit = m->unit_values;
+    a.no_w = 1;
     if (launch_rows_forward(e, a, false, true) != FMX_OK) d_Q = nullptr;
   }
   // a COMPLETE tiled plan (every level tiled, every row in every level: one-column-per-field data): the pairs travel in the list order of the level that

@@ -288,6 +288,9 @@ __global__ __launch_bounds__(WGT) FMX_ROWS_WAVES_ATTR void fm_rows_forward_k(Row
   const T* __restrict__ Vt = reinterpret_cast<const T*>(a.V) + lig * VEC;
   const T* __restrict__ wt = a.w ? reinterpret_cast<const T*>(a.w) : reinterpret_cast<const T*>(a.V);  // always readable
   const bool k1 = h.k1 != 0;
+  // a launch that only wants the per-row factor sums (the q table of the ALS / Gibbs V sweep: no y_hat) has no use for w: every lane then reads w of feature 0 --
+  // one hot word instead of a second random request per entry (the load itself stays: unconditional, see below)
+  const uint32_t wsel = a.no_w ? 0u : 0xFFFFFFFFu;
 
   double s[VEC], q[VEC];
 #pragma unroll
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(WGT) FMX_ROWS_WAVES_ATTR void fm_rows_forward_k(Row
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
         vv[u] = gather_row(Vt + ((size_t)en[u].x << RowStride<T, LPR>::v(a.vsh)));
-        wv[u] = wt[(size_t)en[u].x << RowStride<T, LPR>::w(a.wsh)];  // (w-in-row layout: the same 128-byte line as the V row)
+        wv[u] = wt[(size_t)(en[u].x & wsel) << RowStride<T, LPR>::w(a.wsh)];  // (w-in-row layout: the same 128-byte line as the V row)
         if constexpr (WGT != 64) {
           // large steps over a cache-sized table: let these land before the next entry's requests go out (see FMX_U_LARGE above)
           if (a.serial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -366,6 +366,7 @@ struct RowsArgs {
   const double* pn_y;   // fast_pnorm table (FMX_LINK_PROBIT)
   int link;
   int unit;             // every value is 1.0f: a.val is not read
+  int no_w;             // the launch's y_hat is not wanted (qout only): the w gathers collapse onto one word (fm_rows_forward_k)
   int embed;            // EmbedMode: how the multiplier is folded into the S row (set by the launcher)
   int wg_threads;       // 64: one-wave workgroups (rows_wg_threads); anything else: WG_THREADS
   int split;            // 4: four lane groups share a row (rows_split; one-wave workgroups only); anything else: one
