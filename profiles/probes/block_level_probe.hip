@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NT_) void block_level_k(const double2* __restrict__
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
   const int nb = argc > 2 ? atoi(argv[2]) : 1290;       // blocks per level (rows per block: n / nb on average; capacity 8192)
-  const int R = 8192;
+  const int R = argc > 3 ? atoi(argv[3]) : 8192;   // block capacity (pairs): 8192 = one workgroup per CU (128 KB of LDS), 4096 = two
   printf("n = %lld rows, %d blocks per level (%.0f rows on average, runs of %.1f pairs)\n", (long long)n, nb, (double)n / nb, (double)n / nb / nb);
   std::mt19937_64 rng(11);
   // every row: its block at this level (A) and at the next (Bn), independent and uniform
@@ -115,6 +115,7 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> perm_in(n), gsrc(n);
   std::vector<uint32_t> dest(n);
   std::vector<uint32_t> order(R), lds_of(R);
+  const bool small = R <= 4096;
   std::vector<uint8_t> seen(n, 0);
   for (int a = 0; a < nb; ++a) {
     const uint32_t b0 = cntA[a], rows = cntA[a + 1] - b0;
@@ -150,6 +151,7 @@ int main(int argc, char** argv) {
   timeit("copy 16-B pairs", [&] { hipLaunchKernelGGL(copy_k, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, 0, flip ? dst : src, flip ? src : dst, n); flip ^= 1; }, 32.0 * n);
   const unsigned g8 = (unsigned)(((nb + 7) / 8) * 8);
 #define RUN(NTv, MODEv, name) timeit(name, [&] { hipLaunchKernelGGL((block_level_k<8192, NTv, MODEv, 300>), dim3((MODEv & 4) ? g8 : (unsigned)nb), dim3(NTv), 0, 0, flip ? dst : src, flip ? src : dst, d_bb, nb, d_pi, d_gs, d_de, vout); flip ^= 1; }, 40.0 * n);
+  if (!small) {
   RUN(1024, 0, "block kernel 1024 thr: through LDS, own region (no sums)")
   RUN(1024, 1, "block kernel 1024 thr: own region + sums/steps/corrections")
   RUN(1024, 2, "block kernel 1024 thr: runs into the next level's array")
@@ -166,6 +168,16 @@ int main(int argc, char** argv) {
   }
   RUN(512, 7, "block kernel 512 thr (16 pairs/thread): runs + sums, XCD-consec")
   RUN(512, 3, "block kernel 512 thr (16 pairs/thread): runs + sums")
+  } else {
+#define RUNS(NTv, MODEv, name) timeit(name, [&] { hipLaunchKernelGGL((block_level_k<4096, NTv, MODEv, 300>), dim3((MODEv & 4) ? g8 : (unsigned)nb), dim3(NTv), 0, 0, flip ? dst : src, flip ? src : dst, d_bb, nb, d_pi, d_gs, d_de, vout); flip ^= 1; }, 40.0 * n);
+    RUNS(512, 0, "4096-pair blocks, 512 thr (2 wg/CU): through LDS, own region")
+    RUNS(512, 1, "4096-pair blocks, 512 thr: own region + sums")
+    RUNS(512, 6, "4096-pair blocks, 512 thr: runs, XCD-consecutive")
+    RUNS(512, 7, "4096-pair blocks, 512 thr: runs + sums, XCD-consecutive")
+    RUNS(512, 3, "4096-pair blocks, 512 thr: runs + sums")
+    RUNS(256, 7, "4096-pair blocks, 256 thr (16 pairs/thread): runs + sums, XCD-consec")
+    RUNS(1024, 7, "4096-pair blocks, 1024 thr (4 pairs/thread): runs + sums, XCD-consec")
+  }
   // check of the last full launch: every destination holds a finite pair
   { std::vector<double2> h(n); CK(hipMemcpy(h.data(), flip ? src : dst, n * 16, hipMemcpyDeviceToHost)); double s = 0; for (int64_t i = 0; i < n; ++i) s += h[i].x; printf("checksum %.6f\n", s); }
   return 0;
