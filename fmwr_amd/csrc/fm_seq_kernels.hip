@@ -514,6 +514,8 @@ template <int KIND, int KL, int NZ> struct SeqWin {
   static constexpr int REGS = 2 * SL * (1 + SeqState<KIND>::N) + (Q > 1 ? 3 * SL : 0) + 120;
 #ifdef FMX_SEQ_NW16   // diagnostic build (profiles/variant_build.sh): 16 waves where the shape's registers are fewest -- the chain wave then has 15 examples per step to hide the workers' gathers behind
   static constexpr int NW = (KIND == UPD_SGD_L2 && KL == 16 && NZ == 32) ? 16 : (REGS > 270 ? 4 : 8);
+#elif defined(FMX_SEQ_NW)   // diagnostic build: any number of waves for that shape (-DFMX_SEQ_NW=10 / 12 / 14)
+  static constexpr int NW = (KIND == UPD_SGD_L2 && KL == 16 && NZ == 32) ? FMX_SEQ_NW : (REGS > 270 ? 4 : 8);
 #else
   static constexpr int NW = REGS > 270 ? 4 : 8;
 #endif
