@@ -125,10 +125,37 @@ __device__ __forceinline__ double2 nt_pair(const double2* p) { const blk_v2d v =
 template <typename T> __device__ __forceinline__ T nt_ld(const T* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ bool bad_number_b(double x) { return isnan(x) || isinf(x); }
 
+// one entry of a list, the coordinate step and the correction: the V sweep's (:310-350) and, with W, the w sweep's (update_w, :208-256) -- the arithmetic of
+// als_level_k / als_tile_*_k, operation for operation
+template <bool W>
+__device__ __forceinline__ void blk_acc(const double2 c, const float x, const double old, double& mean, double& var) {
+  if (W) { const double xd = (double)x; mean += c.y * xd - old * xd * xd; var += xd * xd; }                                            // :216-219
+  else { const float xx = x * x; const double h = (double)x * c.x - (double)xx * old; mean += h * c.y; var += h * h; }                 // :310-317
+}
+template <bool W>
+__device__ __forceinline__ double blk_step(double mean, double var, const double old, const double alpha, const double lambda, const double mu, const bool gibbs, const double z) {
+  if (W) {
+    var = 1.0 / (lambda + alpha * var);
+    mean = -var * (alpha * mean - mu * lambda);
+    return bad_number_b(var) ? 0.0 : (gibbs ? mean + var * z : mean);             // (the variance as Rf_rnorm's sd: :239, kept)
+  }
+  mean -= old * var;                               // :318
+  var = 1.0 / (lambda + alpha * var);              // :319
+  mean = -var * (alpha * mean - mu * lambda);      // :320
+  return bad_number_b(var) ? 0.0 : (gibbs ? mean + sqrt(var) * z : mean);
+}
+template <bool W>
+__device__ __forceinline__ double2 blk_fix(const double2 c, const float x, const double old, const double diff) {
+  if (W) return make_double2(c.x, c.y - (double)x * diff);                                                                             // :246-252
+  const float xx = x * x;
+  const double h = (double)x * c.x - (double)xx * old;
+  return make_double2(c.x - (double)x * diff, c.y - h * diff);                                                                         // :341-350
+}
+
 // blockIdx -> block: consecutive blocks share an XCD (workgroups are dealt round-robin over the eight XCDs) and run there at about the same time, so the runs
 // that neighbouring blocks write into one line of the next level's array meet in that XCD's L2 (73 against 89 us per level in the probe).  Placement is for
 // speed only.
-template <bool UNIT, int R, int LG, bool QIN>
+template <bool W, bool UNIT, int R, int LG, bool QIN>
 __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* __restrict__ src, double2* __restrict__ dst, const uint32_t* __restrict__ bbase,
                                                                  const uint32_t* __restrict__ bfeat, int nb, const uint32_t* __restrict__ loff, const uint32_t* __restrict__ feats,
                                                                  const uint16_t* __restrict__ perm_in, const uint16_t* __restrict__ gsrc, const uint32_t* __restrict__ dest,
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
   if (threadIdx.x < nf) {
     const uint32_t ft = feats[f0 + threadIdx.x];
     lfeat[threadIdx.x] = ft;
-    oldv[threadIdx.x] = P[(size_t)ft * kp + f];
+    oldv[threadIdx.x] = P[W ? (size_t)ft : (size_t)ft * kp + f];
     zn[threadIdx.x] = dyn->znorm ? dyn->znorm[ft] : 0.0;
   }
   if (threadIdx.x <= nf) lo[threadIdx.x] = (uint16_t)(loff[f0 + threadIdx.x] - b0);
@@ -193,32 +220,21 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float xx = x[u] * x[u];
-          const double h = (double)x[u] * c[u].x - (double)xx * old;   // :310-317
-          if (t0 + u * LG < b) { mean += h * c[u].y; var += h * h; }
-        }
+        for (int u = 0; u < 4; ++u) if (t0 + u * LG < b) blk_acc<W>(c[u], x[u], old, mean, var);
       }
 #pragma unroll
       for (int o = 1; o < LG; o <<= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }   // (a + b == b + a: every lane of the group holds the same bits)
-      mean -= old * var;                               // :318
-      var = 1.0 / (lambda + alpha * var);              // :319
-      mean = -var * (alpha * mean - mu * lambda);      // :320
       const uint32_t feat = lfeat[fi];
-      const double nv = bad_number_b(var) ? 0.0 : (gibbs ? mean + sqrt(var) * zn[fi] : mean);
+      const double nv = blk_step<W>(mean, var, old, alpha, lambda, mu, gibbs, zn[fi]);
       if (bad_number_b(nv)) continue;                  // CHECK_PARAM (:336): the old value stays and the rows keep their pairs
-      if (l == 0) P[(size_t)feat * kp + f] = nv;
+      if (l == 0) P[W ? (size_t)feat : (size_t)feat * kp + f] = nv;
       const double diff = old - nv;
       for (uint32_t t0 = a + l; t0 < b; t0 += 4 * LG) {
         double2 c[4]; float x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float xx = x[u] * x[u];
-          const double h = (double)x[u] * c[u].x - (double)xx * old;
-          if (t0 + u * LG < b) lp[t0 + u * LG] = make_double2(c[u].x - (double)x[u] * diff, c[u].y - h * diff);   // :341-350
-        }
+        for (int u = 0; u < 4; ++u) if (t0 + u * LG < b) lp[t0 + u * LG] = blk_fix<W>(c[u], x[u], old, diff);
       }
     }
   }
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_k(const double2* 
 #define BLK_KO(bit) (((FMX_BLK_KO) & (bit)) != 0)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool UNIT, int R, int LG>
+template <bool W, bool UNIT, int R, int LG>
 __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const double2* __restrict__ src, double2* __restrict__ dst, const uint32_t* __restrict__ bbase,
                                                                       const uint32_t* __restrict__ bfeat, int nb, const uint32_t* __restrict__ loff, const uint32_t* __restrict__ feats,
                                                                       uint32_t cnt, const uint16_t* __restrict__ perm_in, const uint16_t* __restrict__ gsrc,
@@ -272,8 +288,9 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
   const int f = dyn->f;
   const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
   const bool gibbs = dyn->znorm != nullptr;
+  const size_t pmul = W ? 1 : (size_t)kp, pofs = W ? 0 : (size_t)f;   // coordinate of feature j: P[j * pmul + pofs] (w[j], or V[j][f])
   const double* __restrict__ zsrc = gibbs ? dyn->znorm : P;   // (every load unconditional: the ALS form reads a word it does not use)
-  const size_t zmul = gibbs ? 1 : (size_t)kp;
+  const size_t zmul = gibbs ? 1 : pmul;
   const uint32_t tid = threadIdx.x;
   struct Geo { uint32_t b0, rows, f0, nf; };
   auto geo = [&](int Bx) {   // a block past the workgroup's last: no rows, no features (its loads re-read one word of the last block)
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
   ft = load_feat(cur);
   ftn = load_feat(nxt);
   load_pairs(cur, v, pa, xv, lov);
-  old = P[(size_t)ft * kp + f];
+  old = P[(size_t)ft * pmul + pofs];
   zv = zsrc[(size_t)ft * zmul];
   for (;;) {
 #pragma unroll
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
     const Geo aft = geo(B + 2 * slots);
     double2 vn[PT]; uint16_t pan[PT]; float xvn[PT]; uint32_t lovn;
     load_pairs(nxt, vn, pan, xvn, lovn);
-    const double oldn = P[(size_t)ftn * kp + f];   // (the next block's features: none of them is stepped by this block)
+    const double oldn = P[(size_t)ftn * pmul + pofs];   // (the next block's features: none of them is stepped by this block)
     const double zvn = zsrc[(size_t)ftn * zmul];
     const uint32_t ftnn = load_feat(aft);
     if (!BLK_KO(1)) {
@@ -336,18 +353,11 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
 #pragma unroll
           for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float xx = x[u] * x[u];
-            const double h = (double)x[u] * c[u].x - (double)xx * oldf;   // :310-317
-            if (t0 + u * LG < b) { mean += h * c[u].y; var += h * h; }
-          }
+          for (int u = 0; u < 4; ++u) if (t0 + u * LG < b) blk_acc<W>(c[u], x[u], oldf, mean, var);
         }
 #pragma unroll
         for (int o = 1; o < LG; o <<= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }
-        mean -= oldf * var;                              // :318
-        var = 1.0 / (lambda + alpha * var);              // :319
-        mean = -var * (alpha * mean - mu * lambda);      // :320
-        const double nv = bad_number_b(var) ? 0.0 : (gibbs ? mean + sqrt(var) * zn[fi] : mean);
+        const double nv = blk_step<W>(mean, var, oldf, alpha, lambda, mu, gibbs, zn[fi]);
         if (bad_number_b(nv)) continue;                  // CHECK_PARAM (:336): newv keeps the old value
         if (l == 0) newv[fi] = nv;
         const double diff = oldf - nv;
@@ -356,16 +366,12 @@ __global__ __launch_bounds__(BLK_THREADS) void als_block_level_pipe_k(const doub
 #pragma unroll
           for (int u = 0; u < 4; ++u) { const uint32_t t = min(t0 + u * LG, b - 1); c[u] = lp[t]; x[u] = UNIT ? 1.0f : lx[t]; }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float xx = x[u] * x[u];
-            const double h = (double)x[u] * c[u].x - (double)xx * oldf;
-            if (t0 + u * LG < b) lp[t0 + u * LG] = make_double2(c[u].x - (double)x[u] * diff, c[u].y - h * diff);   // :341-350
-          }
+          for (int u = 0; u < 4; ++u) if (t0 + u * LG < b) lp[t0 + u * LG] = blk_fix<W>(c[u], x[u], oldf, diff);
         }
       }
     }
     lds_barrier();
-    { const uint32_t ts = min(tid, cur.nf - 1); P[(size_t)lfeat[ts] * kp + f] = newv[ts]; }   // (threads past the last feature repeat its store: same address, same value)
+    { const uint32_t ts = min(tid, cur.nf - 1); P[(size_t)lfeat[ts] * pmul + pofs] = newv[ts]; }   // (threads past the last feature repeat its store: same address, same value)
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
       const uint32_t i = tid + u * NT;
@@ -387,13 +393,14 @@ __global__ void als_block_enter_k(const double2* __restrict__ qe, const double* 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t r = row0[i];
-  dst[i] = make_double2(Q0[i], qe[r].y);   // (Q: built on the permuted CSR, already in this order)
+  dst[i] = make_double2(Q0 ? Q0[i] : 0.0, qe[r].y);   // (Q: built on the permuted CSR, already in this order; the w sweep has no q)
 }
-__global__ void als_block_exit_k(const double2* __restrict__ src, const uint32_t* __restrict__ row0, int64_t n, double2* __restrict__ qe, double* __restrict__ qlast_out) {
+__global__ void als_block_exit_k(const double2* __restrict__ src, const uint32_t* __restrict__ row0, int64_t n, double2* __restrict__ qe, double* __restrict__ qlast_out, int e_only) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double2 c = src[i];
-  qe[row0[i]] = c;
+  if (e_only) qe[row0[i]].y = c.y;   // (the w sweep: the rows' q is none of its business)
+  else qe[row0[i]] = c;
   if (qlast_out) qlast_out[i] = c.x;   // (q carried from sweep to sweep: the last factor's final q)
 }
 // a 64-bit fingerprint of the fp64 V table: sum of (bits of element i) x (2 i + 1) modulo 2^64 -- integer adds commute, so any reduction order gives the same word
@@ -555,15 +562,15 @@ int als_blocks_enter(fmx_engine* e, const void* b, const double2* d_qe, const do
   return FMX_OK;
 }
 
-int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe, double* d_qlast_out) {
+int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe, double* d_qlast_out, bool e_only) {
   const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
-  hipLaunchKernelGGL(als_block_exit_k, dim3((unsigned)((Bk->n + 255) / 256)), dim3(256), 0, e->stream, src, (const uint32_t*)Bk->row0, Bk->n, d_qe, d_qlast_out);
+  hipLaunchKernelGGL(als_block_exit_k, dim3((unsigned)((Bk->n + 255) / 256)), dim3(256), 0, e->stream, src, (const uint32_t*)Bk->row0, Bk->n, d_qe, d_qlast_out, e_only ? 1 : 0);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
 }
 
 // one level (slot s) of one factor; d_feats: the level's feature ids; d_qin (level 0's array order): this factor's q, taken in by its first level
-int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin, double* d_qprev_out) {
+int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin, double* d_qprev_out, bool w_sweep) {
   const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
   const int nb = (int)Bk->nblk[(size_t)s];
   const dim3 grid((unsigned)(((nb + 7) / 8) * 8)), blk(BLK_THREADS);
@@ -574,10 +581,15 @@ int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, do
   const uint16_t* gs = Bk->gsrc + (size_t)s * Bk->n;
   const uint32_t* de = Bk->dest + (size_t)s * Bk->n;
   const float* xs = Bk->xs ? Bk->xs + (size_t)s * Bk->n : nullptr;
-  FMX_CHECK(!d_qin || s == 0, FMX_ERR_STATE, "a factor's q enters at its FIRST level");
+  FMX_CHECK(!d_qin || (s == 0 && !w_sweep), FMX_ERR_STATE, "a factor's q enters at its FIRST level");
+  double* const Pw = w_sweep ? e->dw : e->dV;
 #define FMX_BLK(UNITv, Rv, LGv, QNv)                                                                                                                              \
-  hipLaunchKernelGGL((als_block_level_k<UNITv, Rv, LGv, QNv>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, e->dV, e->kp64, dyn, d_qin, d_qprev_out, \
-                     (uint32_t)Bk->n)
+  do {                                                                                                                                                            \
+    if (w_sweep) hipLaunchKernelGGL((als_block_level_k<true, UNITv, Rv, LGv, false>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, Pw, e->kp64, dyn, \
+                                    d_qin, d_qprev_out, (uint32_t)Bk->n);                                                                                          \
+    else hipLaunchKernelGGL((als_block_level_k<false, UNITv, Rv, LGv, QNv>), grid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, pin, gs, de, xs, Pw, e->kp64, dyn, d_qin,  \
+                            d_qprev_out, (uint32_t)Bk->n);                                                                                                         \
+  } while (0)
 #define FMX_BLK_Q(UNITv, Rv, LGv) do { if (d_qin) FMX_BLK(UNITv, Rv, LGv, true); else FMX_BLK(UNITv, Rv, LGv, false); } while (0)
 #define FMX_BLK_L(UNITv, Rv)                                                                                                                                      \
   do {                                                                                                                                                            \
@@ -598,8 +610,12 @@ int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, do
     const dim3 pgrid((unsigned)(slots * 8));
     const uint32_t cnt = (uint32_t)(Bk->foff.size() > (size_t)s + 1 ? Bk->foff[(size_t)s + 1] - Bk->foff[(size_t)s] - 1 : Bk->last_cnt);
 #define FMX_BLKP(UNITv, Rv, LGv)                                                                                                                                  \
-  hipLaunchKernelGGL((als_block_level_pipe_k<UNITv, Rv, LGv>), pgrid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, cnt, pin, gs, de, xs, e->dV, e->kp64, dyn, \
-                     (uint32_t)Bk->n)
+  do {                                                                                                                                                            \
+    if (w_sweep) hipLaunchKernelGGL((als_block_level_pipe_k<true, UNITv, Rv, LGv>), pgrid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, cnt, pin, gs, de, xs, Pw, e->kp64, \
+                                    dyn, (uint32_t)Bk->n);                                                                                                         \
+    else hipLaunchKernelGGL((als_block_level_pipe_k<false, UNITv, Rv, LGv>), pgrid, blk, 0, e->stream, src, dst, bbase, bfeat, nb, loff, d_feats, cnt, pin, gs, de, xs, Pw, e->kp64, dyn,   \
+                            (uint32_t)Bk->n);                                                                                                                      \
+  } while (0)
 #define FMX_BLKP_L(UNITv, Rv)                                                                                                                                     \
   do {                                                                                                                                                            \
     switch (Bk->lg[(size_t)s]) {                                                                                                                                  \

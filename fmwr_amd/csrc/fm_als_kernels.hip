@@ -1097,7 +1097,9 @@ static int w_sweep_guarded(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     if (d_qe_new) FMX_HIP(hipMemcpyAsync(d_qe_new, d_qe, (size_t)m->n * sizeof(double2), hipMemcpyDeviceToDevice, e->stream));
     set_dyn(e, dyn, 0, alpha, lambda, mu, d_znorm);
     e->als_vf_slot = -1; e->als_qnext = nullptr;
-    sweep_once<true>(e, m, d_qe, d_qe_new, dyn);
+    bool blocks_done = false;
+    if (!d_qe_new) FMX_TRY(als_order_w_sweep(e, m, d_qe, dyn, &blocks_done));   // a complete plan whose lists fit a block: one kernel per level (fm_als_blocks.hip)
+    if (!blocks_done) sweep_once<true>(e, m, d_qe, d_qe_new, dyn);
     e->als_vf_slot = -1;
     bool redo = false;
     if (pass == 0) FMX_TRY(g.end(&redo));

@@ -1103,6 +1103,25 @@ int als_order_form(const fmx_matrix* m) {
   return (T && T->complete && !m->als_approx) ? (T->blocks ? 2 : 1) : 0;
 }
 
+int als_order_w_sweep(fmx_engine* e, fmx_matrix* m, double2* d_qe, const SweepDyn* dyn, bool* done) {
+  *done = false;
+  const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
+  if (!T || !T->complete || !T->blocks || m->als_approx) return FMX_OK;
+  static const bool on = env_int("FMX_ALS_BLOCK_W", 1) != 0;   // (A/B: the three-pass form for the w sweep)
+  if (!on) return FMX_OK;
+  if (order_buffers(e, m->n) != FMX_OK) { (void)hipGetLastError(); return FMX_OK; }
+  FMX_TRY(als_blocks_enter(e, T->blocks, d_qe, nullptr, reinterpret_cast<double2*>(e->als_lo[0])));
+  e->als_lo_cur = 0;
+  for (int s = 0; s < T->n_slots; ++s) {
+    FMX_TRY(als_blocks_level(e, T->blocks, s, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), reinterpret_cast<double2*>(e->als_lo[1 - e->als_lo_cur]),
+                             T->feats + T->lvl0[(size_t)s], dyn, nullptr, nullptr, true));
+    e->als_lo_cur = 1 - e->als_lo_cur;
+  }
+  FMX_TRY(als_blocks_exit(e, T->blocks, reinterpret_cast<const double2*>(e->als_lo[e->als_lo_cur]), d_qe, nullptr, true));
+  *done = true;
+  return FMX_OK;
+}
+
 int als_order_levels(const fmx_matrix* m) {
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
   return T ? T->n_slots : 0;

@@ -591,6 +591,8 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int slot, const SweepDyn* dyn,
 int als_order_prepare(fmx_engine* e, fmx_matrix* m, const uint32_t** colP, const float** valP);
 int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe, double* d_qlast_out = nullptr);
 uint64_t als_order_plan_uid(const fmx_matrix* m);   // the block form's plan (0: none)
+// the w sweep (update_w, :208-256) through the block form: one kernel per level; *done = false: no such plan (or no memory), the caller takes the other forms
+int als_order_w_sweep(fmx_engine* e, fmx_matrix* m, double2* d_qe, const SweepDyn* dyn, bool* done);
 // the BLOCK form of the level-order sweep (fm_als_blocks.hip): the level's array feature-block-major, ONE kernel per level.  Built by als_tiled_build on
 // complete plans whose lists all fit a block; *out stays null where it does not apply.
 struct AlsBlocksIn {
@@ -604,11 +606,11 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
 void als_blocks_free(void* b);
 int als_blocks_info(const void* b, int32_t* block_rows, int32_t* blocks_level0);
 int als_blocks_enter(fmx_engine* e, const void* b, const double2* d_qe, const double* d_Q0, double2* dst);
-int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin, double* d_qprev_out);
+int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin, double* d_qprev_out, bool w_sweep = false);
 uint64_t als_blocks_uid(const void* b);
 int als_vhash(fmx_engine* e, uint64_t* out);
 void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP);
-int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe, double* d_qlast_out);
+int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe, double* d_qlast_out, bool e_only = false);
 int als_order_form(const fmx_matrix* m);   // 0: none, 1: the tile form, 2: the block form
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);
 

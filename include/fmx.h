@@ -432,8 +432,7 @@ int fmx_als_tiled_info(fmx_engine* e, fmx_matrix* m, int32_t* levels_tiled, int6
  * bitwise run to run.  Where, in addition, every feature's list fits a block of 8 192 rows (6 144 with real values), the sweep takes the BLOCK form
  * (fm_als_blocks.hip): the level's array is feature-block-major and ONE kernel per level streams a block's pairs into LDS, sums its lists, takes the coordinate
  * steps, corrects the pairs there and stores them as contiguous runs into the next level's blocks -- the pairs are read once per level and nothing waits for
- * another workgroup (202 against 120 M examples/s at configs[4]).  *level_order = 2: the block form, 1: the tile form, 0: neither (the w sweep keeps the
- * three-pass form).  FMX_ALS_ORDER=1 keeps the tile form, 0 forbids both. */
+ * another workgroup (202 against 120 M examples/s at configs[4]).  *level_order = 2: the block form (V sweep and w sweep), 1: the tile form (V sweep; the w sweep keeps the three-pass form), 0: neither.  FMX_ALS_ORDER=1 keeps the tile form, 0 forbids both. */
 int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order);
 /* Opt-in (default off): carry q = X v_f from one V sweep to the next.  The reference recomputes q_f from scratch for every factor of every sweep
  * (solver/MCMC_ALS_Learner.h:283-300); here one forward pass builds it for all factors (38 GB of V-row gathers at configs[4]: 7 of a sweep's 49 ms).  But a sweep

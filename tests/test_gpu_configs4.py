@@ -287,8 +287,9 @@ def test_configs4_row_tiled_sweep_matches_oracle(monkeypatch, law, values, gibbs
 
 
 def test_configs4_row_tiled_learners_equal_the_column_walking_form(monkeypatch):
-    """The ALS learner's loop (w0, w sweep, V sweep) and the MCMC learner's (w0, w sweep with draws) through the tiled form and through the
-    column-walking kernels: the same sweeps, sums associated differently."""
+    """The ALS learner's loop (w0, w sweep, V sweep) and the MCMC learner's (w0, w sweep with draws) through the block form (w sweep AND V sweep: one kernel per
+    level, fm_als_blocks.hip; several blocks per level), the tile form of the V sweep (w sweep: three passes), the three-pass tiled form and the column-walking
+    kernels: the same sweeps, sums associated differently."""
     from fmwr_amd import _lib as L, engine
     n, p, k = 12_000, 3_000, 8
     rp, col, val, y = _problem(engine, L, "stratified", n, p, 57, "normal")
@@ -296,21 +297,26 @@ def test_configs4_row_tiled_learners_equal_the_column_walking_form(monkeypatch):
     g = np.random.default_rng(10)
     gam = g.gamma((1 + n) / 2, 1.0, (3, 2)); nor = g.normal(0, 1, (3, 2 + p))
     out = {}
-    for mode in ("1", "0"):
+    monkeypatch.setenv("FMX_ALS_BLOCK_ROWS", "1024")
+    for mode, order, form in (("1", "2", 2), ("1", "1", 1), ("1", "0", 0), ("0", "2", 0)):
         monkeypatch.setenv("FMX_ALS_TILED", mode)
+        monkeypatch.setenv("FMX_ALS_ORDER", order)
         monkeypatch.setenv("FMX_ALS_TILE_ROWS", "2048")
         m = engine.Matrix.from_csr(rp, col, val, p, y)
         e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
         e.set_params(w0, w, v)
         assert (e.als_tiled(m)[0] > 0) == (mode == "1")
+        assert e.als_level_order_form(m) == form
         e.als_train(m, 3, with_v=True)
         e2 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL)
         e2.set_params(w0, w, v)
         e2.mcmc_train(m, 3, gam, nor)
-        out[mode] = (e.get_params(), e2.get_params())
-    for a, b in zip(out["1"], out["0"]):
-        assert abs(a[0] - b[0]) < 1e-10 * max(1.0, abs(b[0]))
-        assert util.rel_err(a[1], b[1]) < 1e-10 and util.rel_err(a[2], b[2]) < 1e-10
+        out[(mode, order)] = (e.get_params(), e2.get_params())
+    ref = out[("0", "2")]
+    for key in (("1", "2"), ("1", "1"), ("1", "0")):
+        for a, b in zip(out[key], ref):
+            assert abs(a[0] - b[0]) < 1e-10 * max(1.0, abs(b[0])), key
+            assert util.rel_err(a[1], b[1]) < 1e-10 and util.rel_err(a[2], b[2]) < 1e-10, key
 
 
 def test_configs4_device_resident_sweep_equals_the_host_pointer_one():
