@@ -431,6 +431,28 @@ def test_configs4_full_size_level_order_and_row_tiled_forms_equal_the_column_wal
         assert util.rel_err(out[name][0], out["columns"][0]) < 1e-10 and util.rel_err(out[name][1], out["columns"][1]) < 1e-10
 
 
+def test_configs4_full_size_block_form_with_real_values_equals_the_tile_form(monkeypatch):
+    """10 M x 1 M, k = 16, the stored values redrawn U(0, 1) (SURVEY 8(d)'s value variant): the block form then works on 6 144-pair blocks with the entry values in
+    LDS beside the pairs.  One ALS sweep through it and through the tile form (FMX_ALS_ORDER=1) from the same start: V (sampled rows) and the residual to 1e-10."""
+    from fmwr_amd import _lib as L, engine
+    out = {}
+    for name, env in (("blocks", {}), ("tiles", {"FMX_ALS_ORDER": "1"})):
+        monkeypatch.delenv("FMX_ALS_ORDER", raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        m = engine.Matrix.synthetic(N, P, Z, SEED).synthetic_values(SEED + 1)
+        e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.init_normal(SEED, 0.0, 0.1)
+        assert e.als_level_order_form(m) == (2 if name == "blocks" else 1)
+        d_err = util.DevBuf(N)
+        L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(N), d_err.ptr, C.c_int(L.LINK_NONE)))
+        e.sync()
+        e.vsweep_device(m, d_err.ptr.value, alpha=1.0, v_lambda=np.full(K, 1.0))
+        out[name] = (d_err.numpy(), e.get_rows(np.arange(0, P, 499, dtype=np.uint32))[1])
+        e.close(); d_err.free(); m.close()
+    assert util.rel_err(out["blocks"][0], out["tiles"][0]) < 1e-10 and util.rel_err(out["blocks"][1], out["tiles"][1]) < 1e-10
+
+
 def test_configs4_full_size_split_columns_equal_the_unsplit_form(monkeypatch):
     """10 M rows x 1 M features in 30 one-hot fields of which four are tiny (3 to 40 values: columns of 0.25 M to 3.3 M entries,
     cut into segments over many workgroups, fm_als_kernels.hip als_vh_*): the same levels, and the sums of the uncut form to
