@@ -586,6 +586,8 @@ def main_sweep(args, rank, local_rank, world):
     gibbs = args.solver == "mcmc"
     dev = torch.device("cuda", local_rank)
     m = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=rank * n, device=local_rank)
+    if args.real_values:                         # SURVEY 8(d)'s value variant: U(0, 1) instead of the one-hot 1.0 (the sweep kernels then read the value arrays)
+        m.synthetic_values(args.seed + 1, row_offset=rank * n)
     e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank)
     e.init_normal(args.seed, 0.0, 0.01)          # V0 ~ N(0, 0.01), w0 = w = 0
     t0 = time.perf_counter()
@@ -721,6 +723,26 @@ def main_sweep(args, rank, local_rank, world):
         out["value_q_carried"] = {"value": n * args.steps / dtc, "unit": "examples/s", "ms_per_step": dtc / args.steps * 1e3, "finite": bool(np.isfinite(ssc)),
                                   "note": "fmx_als_carry_q(1): q = X v_f is written back as each factor's pairs move on and reused by the next sweep when V's 64-bit fingerprint is "
                                           "unchanged (no forward pass; rebuilt every 64th sweep); agrees with the rebuilt form to ~1e-13 (tests/test_gpu_configs4.py)"}
+    if world == 1 and not args.real_values and not args.no_extras:
+        # SURVEY 8(d)'s value variant, timed once per run: the same shape with U(0, 1) values (6 144-pair blocks, the entry values in LDS beside the pairs)
+        try:
+            m2 = engine.Matrix.synthetic(n, p, z, args.seed, device=local_rank).synthetic_values(args.seed + 1)
+            e2 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank)
+            e2.init_normal(args.seed, 0.0, 0.01)
+            d2 = torch.zeros(n, dtype=torch.float64, device=dev)
+            L.check(L.lib().fmx_predict_device(e2.h, m2.h, C.c_int64(0), C.c_int64(n), C.c_void_p(d2.data_ptr()), C.c_int(L.LINK_NONE)))
+            e2.sync()
+            sw2 = lambda: e2.vsweep_device(m2, d2.data_ptr(), alpha=1.0, v_lambda=lam, dev_std_normals=d_z.data_ptr() if gibbs else None)
+            sw2(); e2.sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                sw2()
+            e2.sync()
+            dtv = (time.perf_counter() - t0) / 2
+            out["value_real_values"] = {"value": n / dtv, "unit": "examples/s", "ms_per_step": dtv * 1e3, "level_order_form": e2.als_level_order_form(m2)}
+            e2.close(); m2.close(); del d2
+        except Exception as ex:
+            out["value_real_values"] = {"error": f"{type(ex).__name__}: {ex}"}
     if world == 1:
         # the whole learner iteration around the sweep -- forward, residual, w0 step, w sweep (30 levels, three-pass tiled form), V sweep (480 levels) --
         # through fmx_als_train(with_v = 1) (MCMC_ALS_Learner::learn, :91-156, with the update_v call the shipped update_all leaves out)
