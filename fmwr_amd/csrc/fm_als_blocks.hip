@@ -528,9 +528,10 @@ int als_blocks_build(fmx_matrix* m, const AlsBlocksIn& in, void** out, hipStream
   return FMX_OK;
 }
 
-void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP) {
+void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP, const uint32_t** row0) {
   const AlsBlocks* Bk = reinterpret_cast<const AlsBlocks*>(b);
   *colP = Bk->colP; *valP = Bk->valP;
+  if (row0) *row0 = Bk->row0;
 }
 
 uint64_t als_blocks_uid(const void* b) { return b ? reinterpret_cast<const AlsBlocks*>(b)->uid : 0; }

@@ -248,6 +248,19 @@ __global__ void als_residual_k(const double* __restrict__ yhat, const float* __r
   qe[r] = make_double2(0.0, e);
 }
 
+// the same from predictions in ANOTHER row order (position i holds row order[i]: the forward pass ran on the block form's permuted CSR)
+__global__ void als_residual_perm_k(const double* __restrict__ yhat_perm, const float* __restrict__ y, const uint32_t* __restrict__ order, int64_t n, double2* __restrict__ qe,
+                                    const double* __restrict__ dp_y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = order[i];
+  const double yh = yhat_perm[i];
+  double e;
+  if (dp_y == nullptr) e = yh - (double)y[r];
+  else e = (y[r] >= 0.0f) ? -fast_dpnorm(dp_y, -yh) : fast_dpnorm(dp_y, yh);
+  qe[r] = make_double2(0.0, e);
+}
+
 constexpr int ALS_SLAB = 4096;
 __global__ __launch_bounds__(WG_THREADS) void als_w0_partial_k(const double2* __restrict__ qe, int64_t n, const double* __restrict__ scal,
                                                               double* __restrict__ partials) {
@@ -929,6 +942,18 @@ static double2* sweep_pairs(fmx_engine* e, int64_t n) {
   return reinterpret_cast<double2*>(e->als_qe);
 }
 
+// the n x kp table of every factor's q (grow-only), or null where there is no room for it (the sweep then falls back to one gather pass per factor)
+static double* q_table(fmx_engine* e, fmx_matrix* m) {
+  const size_t need = (size_t)m->n * e->kp64;
+  if (e->als_Q_elems < need) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(e->als_Q); e->als_Q = nullptr; e->als_Q_elems = 0; e->als_q_have = 0; e->als_q_trusted = 0;
+    if (hipMalloc(&e->als_Q, need * sizeof(double)) == hipSuccess) e->als_Q_elems = need;
+    else (void)hipGetLastError();
+  }
+  return e->als_Q;
+}
+
 // V sweep over all factors on the interleaved (q, e) pairs
 static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double alpha, const double* h_lambda, const double* h_mu,
                            const double* d_znorm = nullptr) {
@@ -939,20 +964,10 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
   // q_f = X v_f only depends on column f of V, which no other factor's sweep touches: all k of them come out of ONE
   // row-gather pass (the forward kernel on the fp64 tables) instead of one gather per nonzero per factor.  The n x kp table lives
   // in the engine (grow-only): a sweep allocates nothing once the first one has run.
-  double* d_Q = nullptr;
-  {
-    const size_t need = (size_t)m->n * e->kp64;
-    if (e->als_Q_elems < need) {
-      (void)hipStreamSynchronize(e->stream);
-      (void)hipFree(e->als_Q); e->als_Q = nullptr; e->als_Q_elems = 0; e->als_q_have = 0;
-      if (hipMalloc(&e->als_Q, need * sizeof(double)) == hipSuccess) e->als_Q_elems = need;
-      else (void)hipGetLastError();  // no room for the table: fall back to one gather pass per factor
-    }
-    d_Q = e->als_Q;
-  }
+  double* d_Q = q_table(e, m);
   const uint32_t* colP = nullptr; const float* valP = nullptr;
   e->als_q_level0 = 0;
-  if (d_Q && !d_qe_new) FMX_TRY(als_order_prepare(e, m, &colP, &valP));   // the block form: q in level 0's array order (the forward runs on the permuted CSR)
+  if (d_Q && !d_qe_new) FMX_TRY(als_order_prepare(e, m, &colP, &valP, nullptr));   // the block form: q in level 0's array order (the forward runs on the permuted CSR)
   // q carried from the previous sweep (opt-in, block form): valid if it belongs to this plan and V is bit for bit what that sweep left
   constexpr int ALS_CARRY_REFRESH = 64;
   const bool carry = e->als_carry_q && colP != nullptr && d_Q != nullptr;
@@ -962,6 +977,10 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     FMX_TRY(als_vhash(e, &hsh));
     reuse = hsh == e->als_q_hash;
   }
+  // ... or built a moment ago by the learner's own forward pass (launch_als_train: the pass that computes y_hat leaves q beside it; nothing between it and this
+  // sweep touches V)
+  if (colP && d_Q && e->als_q_trusted != 0 && e->als_q_trusted == als_order_plan_uid(m)) reuse = true;
+  e->als_q_trusted = 0;
   e->als_q_have = 0;
   if (d_Q && !reuse) {
     RowsArgs a{};
@@ -1155,9 +1174,23 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = n;
     a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = d_yhat; a.link = FMX_LINK_NONE;
+    // With a V sweep to follow on a block-form plan, this forward pass runs on the plan's copy of the CSR (rows in level 0's array order) and leaves the q of every
+    // factor beside y_hat: nothing between here and the V sweep touches V, so the sweep's own pass over the matrix (5.5 of an iteration's 58 ms) is saved.
+    const uint32_t *colP = nullptr, *row0 = nullptr; const float* valP = nullptr;
+    double* d_Q = nullptr;
+    static const bool share = [] { const char* v = getenv("FMX_ALS_SHARE_FORWARD"); return !(v && v[0] == '0'); }();
+    if (share && with_v && e->k > 0 && !m->als_approx) {
+      if (als_order_prepare(e, m, &colP, &valP, &row0) != FMX_OK) colP = nullptr;
+      if (colP) d_Q = q_table(e, m);
+      if (!d_Q) colP = nullptr;
+    }
+    if (colP) { a.col = colP; a.val = valP; a.unit = m->unit_values; a.qout = d_Q; a.qout_t = n; }   // (one-hot matrices keep no copy of the values: valP is null and must not be read)
     st = launch_rows_forward(e, a, false, true);  // fm->predict_batch(train, train_err), :100
     if (st != FMX_OK) break;
-    hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, dp_y);
+    if (colP) {
+      hipLaunchKernelGGL(als_residual_perm_k, dim3(row_grid), dim3(256), 0, e->stream, (const double*)d_yhat, (const float*)m->y, row0, n, d_qe, dp_y);
+      e->als_q_trusted = als_order_plan_uid(m);
+    } else hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, dp_y);
     if (e->hyper.k0) {
       hipLaunchKernelGGL(als_w0_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, e->scal, d_part);
       hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, 1.0, 0.0, 0, 0.0);

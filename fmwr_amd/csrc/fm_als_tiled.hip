@@ -987,13 +987,14 @@ static int order_buffers(fmx_engine* e, int64_t n) {
   return FMX_OK;
 }
 
-int als_order_prepare(fmx_engine* e, fmx_matrix* m, const uint32_t** colP, const float** valP) {
+int als_order_prepare(fmx_engine* e, fmx_matrix* m, const uint32_t** colP, const float** valP, const uint32_t** row0) {
   *colP = nullptr; *valP = nullptr;
+  if (row0) *row0 = nullptr;
   e->als_q_level0 = 0;
   const AlsTiled* T = reinterpret_cast<const AlsTiled*>(m->als_tiled);
   if (!T || !T->complete || !T->blocks || m->als_approx) return FMX_OK;
   if (order_buffers(e, m->n) != FMX_OK) { (void)hipGetLastError(); return FMX_OK; }
-  als_blocks_csr(T->blocks, colP, valP);
+  als_blocks_csr(T->blocks, colP, valP, row0);
   e->als_q_level0 = 1;
   return FMX_OK;
 }

@@ -290,6 +290,7 @@ struct fmx_engine {
   // plan is the same one.  Rebuilt every ALS_CARRY_REFRESH sweeps against rounding drift.
   int als_carry_q = 0;
   int als_q_have = 0, als_q_age = 0;
+  uint64_t als_q_trusted = 0;      // plan uid: the table was filled a moment ago by the learner's own forward pass (launch_als_train) -- used once, no fingerprint needed
   uint64_t als_q_hash = 0, als_q_plan = 0;
   void* als_hash_word = nullptr;
   const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
@@ -588,7 +589,7 @@ int als_order_enter(fmx_engine* e, fmx_matrix* m, const double2* d_qe, const dou
 int als_order_level(fmx_engine* e, fmx_matrix* m, int slot, const SweepDyn* dyn, const double* d_qnext, double* d_qprev_out = nullptr);
 // the block form builds q for all factors on a copy of the CSR whose rows are in level 0's array order: the copy (and the pair buffers, allocated here), or *colP =
 // null where the sweep will not take the block form (no such plan, no memory)
-int als_order_prepare(fmx_engine* e, fmx_matrix* m, const uint32_t** colP, const float** valP);
+int als_order_prepare(fmx_engine* e, fmx_matrix* m, const uint32_t** colP, const float** valP, const uint32_t** row0);   // row0 (optional): the row at every position of that order
 int als_order_exit(fmx_engine* e, fmx_matrix* m, double2* d_qe, double* d_qlast_out = nullptr);
 uint64_t als_order_plan_uid(const fmx_matrix* m);   // the block form's plan (0: none)
 // the w sweep (update_w, :208-256) through the block form: one kernel per level; *done = false: no such plan (or no memory), the caller takes the other forms
@@ -609,7 +610,7 @@ int als_blocks_enter(fmx_engine* e, const void* b, const double2* d_qe, const do
 int als_blocks_level(fmx_engine* e, const void* b, int s, const double2* src, double2* dst, const uint32_t* d_feats, const SweepDyn* dyn, const double* d_qin, double* d_qprev_out, bool w_sweep = false);
 uint64_t als_blocks_uid(const void* b);
 int als_vhash(fmx_engine* e, uint64_t* out);
-void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP);
+void als_blocks_csr(const void* b, const uint32_t** colP, const float** valP, const uint32_t** row0);
 int als_blocks_exit(fmx_engine* e, const void* b, const double2* src, double2* d_qe, double* d_qlast_out, bool e_only = false);
 int als_order_form(const fmx_matrix* m);   // 0: none, 1: the tile form, 2: the block form
 int launch_als_vsweep_device(fmx_engine* e, fmx_matrix* m, double* d_error, double alpha, const double* h_lambda, const double* h_mu, const double* d_znorm);

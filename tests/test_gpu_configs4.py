@@ -286,13 +286,15 @@ def test_configs4_row_tiled_sweep_matches_oracle(monkeypatch, law, values, gibbs
     assert util.rel_err(gerr, rerr) < 1e-10
 
 
-def test_configs4_row_tiled_learners_equal_the_column_walking_form(monkeypatch):
+@pytest.mark.parametrize("values", ["normal", "ones"])
+def test_configs4_row_tiled_learners_equal_the_column_walking_form(monkeypatch, values):
     """The ALS learner's loop (w0, w sweep, V sweep) and the MCMC learner's (w0, w sweep with draws) through the block form (w sweep AND V sweep: one kernel per
     level, fm_als_blocks.hip; several blocks per level), the tile form of the V sweep (w sweep: three passes), the three-pass tiled form and the column-walking
-    kernels: the same sweeps, sums associated differently."""
+    kernels: the same sweeps, sums associated differently.  Real values and one-hot rows (a one-hot plan keeps no copy of the values: the ALS learner's forward
+    pass, which runs on the block form's permuted CSR and leaves q for the V sweep, must not read them)."""
     from fmwr_amd import _lib as L, engine
     n, p, k = 12_000, 3_000, 8
-    rp, col, val, y = _problem(engine, L, "stratified", n, p, 57, "normal")
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 57, values)
     w0, w, v = util.params(p, k, 37, stdev=0.1, fp32=False)
     g = np.random.default_rng(10)
     gam = g.gamma((1 + n) / 2, 1.0, (3, 2)); nor = g.normal(0, 1, (3, 2 + p))
