@@ -563,6 +563,37 @@ def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_
                                "note": "FMX_MODE_SEQUENTIAL: the reference's per-example algorithm in its visiting order (fp64 state); "
                                        "1e-5-on-V parity with the reference CPU path is asserted in THIS mode; `value` is the mini-batch mode"}
     seq.close()
+    # ... and as many of them as the chip has CUs: a grid of models (learning rate x L2, what fm.select's repeated fm.train calls walk) on ONE visiting order, one
+    # workgroup per model in one launch per 65 536 examples (fmx_train_grid); every model bit for bit its own fmx_train (tests/test_gpu_train_grid.py)
+    try:
+        if args.solver != "sgd":
+            raise KeyError("skip")   # (FTRL grids are built for k <= 16 only; the headline's SGD shape is what is timed)
+        N_GRID = 256
+        kw = engine_kwargs(args, L, 1, 0, 1, mode=L.MODE_SEQUENTIAL, state_fp64=0, tile_rows=0)
+        grid = []
+        for i in range(N_GRID):
+            kwi = dict(kw)
+            if args.solver == "sgd":
+                kwi.update(learn_rate=kw.get("learn_rate", 0.01) * (0.25 + 0.25 * (i % 16)), l2_w1=1e-4 * (1 + i // 16))
+            else:
+                kwi.update(alpha_w=0.02 * (1 + i % 16), alpha_v=0.02 * (1 + i // 16))
+            g = engine.Engine(p, **kwi)
+            g.init_normal(args.seed, 0.0, 0.01)
+            grid.append(g)
+        gcnt = 100_000 if args.solver == "sgd" else 30_000
+        engine.Engine.train_grid(grid, sub, 10_000)
+        t0 = time.perf_counter()
+        gdone = engine.Engine.train_grid(grid, sub, gcnt)
+        gdt = time.perf_counter() - t0
+        out["sequential_exact_grid"] = {"models": N_GRID, "value": N_GRID * gdone / gdt, "per_model": gdone / gdt, "unit": "examples/s",
+                                        "note": "fmx_train_grid: 256 reference-order learners (a 16 x 16 grid of hyper-parameters) side by side, one workgroup each, one visiting order; "
+                                                "each model's parameters are bit for bit what fmx_train alone gives it; `value` here counts every model's examples"}
+        for g in grid:
+            g.close()
+    except KeyError:
+        pass
+    except BaseException as ex:   # a side measurement must not take the line with it
+        out["sequential_exact_grid"] = {"error": f"{type(ex).__name__}: {ex}"}
     sub.close()
     if args.solver == "sgd":
         try:

@@ -23,7 +23,7 @@ KERNEL_ROWS_FORWARD, KERNEL_COLS_UPDATE, KERNEL_SCALAR, KERNEL_SEQ, KERNEL_ALS_S
 SYMBOLS = [
     "fmx_last_error", "fmx_device_count", "fmx_config_default", "fmx_engine_create", "fmx_engine_destroy", "fmx_set_params",
     "fmx_get_params", "fmx_engine_save", "fmx_engine_load", "fmx_matrix_from_rlist", "fmx_matrix_from_dgc", "fmx_matrix_from_csr", "fmx_matrix_synthetic", "fmx_matrix_synthetic_fields", "fmx_matrix_synthetic_iid", "fmx_matrix_synthetic_ragged", "fmx_matrix_synthetic_values", "fmx_train_stream", "fmx_matrix_set_labels", "fmx_matrix_set_fields", "fmx_matrix_destroy",
-    "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_order", "fmx_num_batches",
+    "fmx_matrix_info", "fmx_matrix_export", "fmx_matrix_scales", "fmx_matrix_normalize", "fmx_predict", "fmx_train", "fmx_train_grid", "fmx_train_order", "fmx_num_batches",
     "fmx_step", "fmx_grad", "fmx_grad_buffer", "fmx_grad_elem_bytes", "fmx_grad_layout", "fmx_grad_begin", "fmx_grad_chunk", "fmx_apply_chunk", "fmx_apply", "fmx_sync", "fmx_stream", "fmx_predict_device",
     "fmx_als_plan_info", "fmx_als_tiled_info", "fmx_als_order_info", "fmx_als_carry_q", "fmx_als_vsweep", "fmx_mcmc_vsweep", "fmx_als_train", "fmx_mcmc_train", "fmx_mcmc_train_from", "fmx_mcmc_v_hyper", "fmx_evaluate", "fmx_train_tracked", "fmx_trace_size", "fmx_trace_get", "fmx_trace_params",
     "fmx_profile_enable", "fmx_profile_get", "fmx_profile_reset", "fmx_rows_tune_info", "fmx_matrix_rows_form", "fmx_measure_gather", "fmx_measure_gather_occ", "fmx_measure_gather_matrix", "fmx_rccl_selftest",

@@ -797,7 +797,7 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window
 // and its association are those of fm_seq_window_k; results are bitwise the one-wave kernel's (tests/test_gpu_seq_window.py).
 // Not for TDAP (its w prox reads z_w by position, A-6: neighbours may not overlap at all).
 template <int KIND, int KL, int NZ>
-__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_pipe_k(SeqArgs a, WinArgs wa, Hyper h) {
+__device__ __forceinline__ void seq_pipe_body(const SeqArgs& a, const WinArgs& wa, const Hyper& h) {
   static_assert(KIND != UPD_TDAP, "TDAP keeps fm_seq_window_k");
   constexpr int NW = SeqWin<KIND, KL, NZ>::NW, W = NW - 1;
   constexpr int Q = SeqWin<KIND, KL, NZ>::Q;
@@ -990,6 +990,19 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_pipe_k
     a.scal[SC_W0] = w0; a.scal[SC_Z0] = z0; a.scal[SC_N0] = n0; a.scal[SC_UW] = uw; a.scal[SC_UV] = uv;
   }
 }
+template <int KIND, int KL, int NZ>
+__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_pipe_k(SeqArgs a, WinArgs wa, Hyper h) {
+  seq_pipe_body<KIND, KL, NZ>(a, wa, h);
+}
+// A GRID of models on ONE visiting order of ONE matrix (a hyper-parameter grid, the folds of fm.select's repeated fm.train calls): workgroup b is the learner of
+// model b -- its own parameter tables, optimizer state and hyper-parameters, the examples, their packing and their conflict plan shared.  Every model takes
+// exactly the steps its own single-model launch takes (tests: bit for bit); the chip runs as many reference-order learners as it has CUs.
+template <int KIND, int KL, int NZ>
+__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_pipe_grid_k(const SeqArgs* __restrict__ as, WinArgs wa, const Hyper* __restrict__ hs) {
+  const SeqArgs a = as[blockIdx.x];
+  const Hyper h = hs[blockIdx.x];
+  seq_pipe_body<KIND, KL, NZ>(a, wa, h);
+}
 
 // the windowed learner applies when every row is a fast row; FMX_SEQ_WINDOW=0 in the environment keeps the one-wave kernel
 // entries per packed row (32 or 64), or 0: the one-wave kernel
@@ -1118,6 +1131,80 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
     FMX_HIP(hipGetLastError());
   }
   return FMX_OK;
+}
+
+// n models (engines of one shape: p, k, update kind) trained on the SAME examples in the SAME order, one launch per chunk with one workgroup per model.
+// The examples' metadata, packing and conflict plan are made once, in es[0]'s workspace and on es[0]'s stream; the other engines' streams are idle for the
+// duration (the caller waits).  Only shapes the pipelined windowed kernel takes (fast rows; SGD-L2 any k <= 64, SGD-L1 / FTRL at k <= 16): anything else is an error.
+int launch_seq_learn_grid(fmx_engine* const* es, int n, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
+  fmx_engine* e = es[0];
+  if (count <= 0) return FMX_OK;
+  const int nz = window_mode(e, m);
+  FMX_CHECK(nz > 0, FMX_ERR_INVALID, "grid training needs rows of at most 64 (k <= 32) / 32 entries with ascending columns");
+  FMX_CHECK(e->hyper.kind != UPD_TDAP, FMX_ERR_INVALID, "grid training: TDAP keeps the single-model learner");
+  const int kl = e->k <= 16 ? 16 : (e->k <= 32 ? 32 : 64);
+  FMX_CHECK(e->hyper.kind == UPD_SGD_L2 || kl == 16, FMX_ERR_INVALID, "grid training: SGD-L1 and FTRL at k <= 16 only");
+  if (count > e->seq_cap) {
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
+    e->seq_b = nullptr; e->seq_len = nullptr; e->seq_y = nullptr; e->seq_cap = 0;
+    FMX_HIP(hipMalloc(&e->seq_b, (size_t)count * sizeof(int64_t)));
+    FMX_HIP(hipMalloc(&e->seq_len, (size_t)count * sizeof(int)));
+    FMX_HIP(hipMalloc(&e->seq_y, (size_t)count * sizeof(float)));
+    e->seq_cap = count;
+  }
+  hipLaunchKernelGGL(seq_prepare_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, d_order, count, m->row_ptr, m->y, e->seq_b, e->seq_len, e->seq_y);
+  const int64_t CHUNK = 1 << 16;
+  FMX_TRY(ensure_window_workspace(e, count < CHUNK ? count : CHUNK));
+  std::vector<SeqArgs> h_as((size_t)n);
+  std::vector<Hyper> h_hs((size_t)n);
+  SeqArgs* d_as = nullptr; Hyper* d_hs = nullptr;
+  FMX_HIP(hipMalloc(&d_as, (size_t)n * sizeof(SeqArgs)));
+  if (hipMalloc(&d_hs, (size_t)n * sizeof(Hyper)) != hipSuccess) { (void)hipFree(d_as); set_error("out of device memory"); return FMX_ERR_HIP; }
+  int st = FMX_OK;
+  for (int64_t off = 0; off < count && st == FMX_OK; off += CHUNK) {
+    const int cnt = (int)((count - off < CHUNK) ? count - off : CHUNK);
+    for (int b = 0; b < n; ++b) {
+      fmx_engine* g = es[b];
+      h_as[(size_t)b] = SeqArgs{m->row_ptr, m->col, m->val, m->y, d_order + off, cnt, e->seq_b + off, e->seq_len + off, e->seq_y + off, g->dV, g->dw, g->dsV, g->dsw, g->dnV, g->dnw,
+                                g->dt1V, g->dt1w, g->dt2V, g->dt2w, g->dt3V, g->dt3w, g->scal, g->k, g->kp64, m->rows_sorted};
+      h_hs[(size_t)b] = g->hyper;
+    }
+    // (the previous chunk's launch reads the argument arrays: wait for it before overwriting them -- chunks are 40 ms of work, the wait is nothing)
+    if (off > 0 && hipStreamSynchronize(e->stream) != hipSuccess) { set_error("grid learner failed"); st = FMX_ERR_HIP; break; }
+    if (hipMemcpyAsync(d_as, h_as.data(), (size_t)n * sizeof(SeqArgs), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync(d_hs, h_hs.data(), (size_t)n * sizeof(Hyper), hipMemcpyHostToDevice, e->stream) != hipSuccess) { set_error("upload of the grid's arguments failed"); st = FMX_ERR_HIP; break; }
+    const size_t pairs = (size_t)cnt * nz;
+    uint32_t* keys = e->seq_keys;
+    const size_t cap_pairs = (size_t)e->seq_wcap * WIN_NZ_MAX;
+    if (hipMemsetAsync(e->seq_conf, 0xFF, (size_t)cnt * sizeof(int), e->stream) != hipSuccess) { st = FMX_ERR_HIP; break; }
+    hipLaunchKernelGGL(seq_pack_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, e->seq_b + off, e->seq_len + off, cnt, nz, m->col, m->val, 0, (uint2*)e->seq_packed, keys,
+                       keys + 2 * cap_pairs, e->seq_conf);
+    size_t tb = e->seq_sort_tmp_bytes;
+    if (rocprim::radix_sort_pairs(e->seq_sort_tmp, tb, keys, keys + cap_pairs, keys + 2 * cap_pairs, keys + 3 * cap_pairs, pairs, 0, 32, e->stream) != hipSuccess) { st = FMX_ERR_HIP; break; }
+    hipLaunchKernelGGL(seq_conf_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, keys + cap_pairs, keys + 3 * cap_pairs, (int)pairs, e->seq_conf);
+    const WinArgs wa{(const uint2*)e->seq_packed, e->seq_len + off, e->seq_y + off, e->seq_conf, cnt};
+#define FMX_GRID(KIND, KL, NZ) hipLaunchKernelGGL((fm_seq_pipe_grid_k<KIND, KL, NZ>), dim3((unsigned)n), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, (const SeqArgs*)d_as, wa, (const Hyper*)d_hs)
+#define FMX_GRID_KIND(KIND)                                                                            \
+  do {                                                                                                 \
+    if (kl == 16) { if (nz == 32) FMX_GRID(KIND, 16, 32); else FMX_GRID(KIND, 16, 64); }               \
+    else if constexpr (KIND == UPD_SGD_L2) {                                                           \
+      if (kl == 32) { if (nz == 32) FMX_GRID(KIND, 32, 32); else FMX_GRID(KIND, 32, 64); }             \
+      else FMX_GRID(KIND, 64, 32);                                                                     \
+    }                                                                                                  \
+  } while (0)
+    switch (e->hyper.kind) {
+      case UPD_SGD_L2: FMX_GRID_KIND(UPD_SGD_L2); break;
+      case UPD_SGD_L1: FMX_GRID_KIND(UPD_SGD_L1); break;
+      default: FMX_GRID_KIND(UPD_FTRL); break;
+    }
+#undef FMX_GRID_KIND
+#undef FMX_GRID
+    if (hipGetLastError() != hipSuccess) { set_error("grid learner launch failed"); st = FMX_ERR_HIP; }
+  }
+  if (st == FMX_OK && hipStreamSynchronize(e->stream) != hipSuccess) { set_error("grid learner failed"); st = FMX_ERR_HIP; }
+  (void)hipFree(d_as); (void)hipFree(d_hs);
+  return st;
 }
 
 }  // namespace fmx

@@ -1280,6 +1280,50 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
   return FMX_OK;
 }
 
+// n models trained side by side on one matrix in the reference's visiting order (fm_seq_kernels.hip: one workgroup per model, the examples' plan shared)
+int fmx_train_grid(fmx_engine* const* engines, int32_t n_engines, fmx_matrix* m, int64_t max_iter, int64_t* examples_done) {
+  FMX_CHECK(engines != nullptr && n_engines >= 1, FMX_ERR_INVALID, "no engines");
+  FMX_CHECK(max_iter >= 0, FMX_ERR_INVALID, "max_iter must be >= 0");
+  if (examples_done) *examples_done = 0;
+  fmx_engine* e0 = engines[0];
+  for (int32_t b = 0; b < n_engines; ++b) {
+    fmx_engine* e = engines[b];
+    FMX_TRY(check_pair(e, m));
+    FMX_CHECK(seq_mode(e), FMX_ERR_STATE, "grid training runs the reference-order learner: create every engine with FMX_MODE_SEQUENTIAL");
+    FMX_CHECK(e->cfg.solver != FMX_SOLVER_ALS && e->cfg.solver != FMX_SOLVER_MCMC, FMX_ERR_STATE, "ALS / MCMC engines train through fmx_als_train / fmx_mcmc_train");
+    FMX_CHECK(!e->group, FMX_ERR_STATE, "grid training takes single-device engines");
+    FMX_CHECK(e->p == e0->p && e->k == e0->k && e->hyper.kind == e0->hyper.kind && e->cfg.device == e0->cfg.device && e->cfg.task == e0->cfg.task, FMX_ERR_INVALID,
+              "the engines of a grid share the feature count, factor.number, solver, task and device (engine %d differs)", (int)b);
+    FMX_CHECK(e->cfg.random_step <= 1, FMX_ERR_INVALID, "grid training shares ONE visiting order: random_step > 1 draws a model's own strides from libc rand()");
+    for (int32_t c = 0; c < b; ++c) FMX_CHECK(engines[c] != e, FMX_ERR_INVALID, "engine %d appears twice in the grid", (int)b);
+  }
+  FMX_CHECK(m->has_labels, FMX_ERR_STATE, "there are no labels in data");
+  if (max_iter == 0 || m->n == 0) return FMX_OK;
+  FMX_TRY(use_device(e0->cfg.device));
+  for (int32_t b = 1; b < n_engines; ++b) FMX_HIP(hipStreamSynchronize(engines[b]->stream));   // their tables are about to be used from engines[0]'s stream
+  const int64_t PIECE = 1 << 22;
+  VisitOrder vo(m->n, e0->cfg.random_step);
+  std::vector<int64_t> order;
+  int64_t done = 0;
+  while (done < max_iter) {
+    const int64_t want = max_iter - done < PIECE ? max_iter - done : PIECE;
+    const bool alive = vo.next(want, &order);
+    if (!order.empty()) {
+      int64_t* d = nullptr;
+      FMX_HIP(hipMalloc(&d, order.size() * sizeof(int64_t)));
+      int st = FMX_OK;
+      if (hipMemcpy(d, order.data(), order.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the visiting order failed"); st = FMX_ERR_HIP; }
+      if (st == FMX_OK) st = launch_seq_learn_grid(engines, (int)n_engines, m, d, (int64_t)order.size());   // (waits for the stream)
+      (void)hipFree(d);
+      FMX_TRY(st);
+    }
+    done += (int64_t)order.size();
+    if (!alive) break;
+  }
+  if (examples_done) *examples_done = done;
+  return FMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ streamed training
 // A stream of training steps over generated rows (BASELINE.json configs[3]: 4e9 rows never exist at once).  Three slots, ingest two
 // steps ahead: the engine's stream then holds  plan(t+1) | train(t) | plan(t+2) | train(t+1) ...  and the counts the host waits

@@ -481,6 +481,7 @@ void merge_ws_free(MergeWs* w);
 void merge_result(const fmx_engine* e, const uint32_t** pos, const uint32_t** roff, const uint32_t** rfeat, const uint32_t** d_n);
 
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count);
+int launch_seq_learn_grid(fmx_engine* const* es, int n, const fmx_matrix* m, const int64_t* d_order, int64_t count);   // n models, one order, one launch per chunk
 
 // ingest
 // scratch of the plan builder, sized for tiles of up to max_cnt entries over p features (grow-only)

@@ -540,6 +540,14 @@ class Engine:
         L.check(L.lib().fmx_als_order_info(self.h, m.h, C.byref(v)))
         return int(v.value)
 
+    @staticmethod
+    def train_grid(engines, m, max_iter):
+        """n reference-order learners side by side on one matrix and one visiting order (fmx_train_grid): every engine its own hyper-parameters and state."""
+        arr = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+        done = C.c_int64(0)
+        L.check(L.lib().fmx_train_grid(arr, C.c_int32(len(engines)), m.h, C.c_int64(max_iter), C.byref(done)))
+        return done.value
+
     def als_carry_q(self, on=True):
         """Opt-in: the block form of the V sweep keeps q = X v_f current from sweep to sweep and skips the forward pass that rebuilds it (fmx_als_carry_q)."""
         L.check(L.lib().fmx_als_carry_q(self.h, C.c_int32(int(on))))

@@ -250,6 +250,13 @@ int fmx_predict(fmx_engine* e, const fmx_matrix* m, double* out, int link);
  * MINIBATCH : consecutive batches of batch_rows rows, wrapping at the end of the matrix.
  * examples_done (may be NULL) receives the number actually processed. */
 int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
+/* A GRID of models trained side by side in the reference's own algorithm (SGD_Learner::learn / FTRL_Learner::learn, one update per example in the reference's
+ * visiting order): what R code does with repeated fm.train() calls over a grid of hyper-parameters (R/fm_select.R) becomes ONE launch per 65 536 examples with
+ * one workgroup per model -- the reference-order learner is a single workgroup bound by its scalar chain, so one model cannot use more of
+ * the chip, but 64 or 256 models can.  Every engine keeps its own parameters, optimizer state and hyper-parameters (learn_rate, regularisers, alpha / beta ...);
+ * the engines share the feature count, factor.number, solver, task, device and random_step = 1 (ONE visiting order), and the matrix.  Each model's result is bit for
+ * bit what fmx_train(engine, m, max_iter) alone gives it.  SGD (L1 / L2) and FTRL, rows of at most 32 entries (64 at k <= 32) with ascending columns; SGD-L1 and FTRL at k <= 16. */
+int fmx_train_grid(fmx_engine* const* engines, int32_t n_engines, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
 /* Same, but with an explicit visiting order (row ids, SEQUENTIAL mode only). */
 int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t count);
 
