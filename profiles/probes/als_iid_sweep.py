@@ -1,0 +1,21 @@
+"""The ALS V sweep on SURVEY 8(d)'s i.i.d. column law at configs[4]'s size: exact level schedule and the approximate groups (cfg.als_max_levels)."""
+import sys, time, ctypes as C
+import numpy as np
+sys.path.insert(0, ".")
+from fmwr_amd import _lib as L, engine
+from tests import util
+N, P, Z, K, SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 1_000_000, 30, 16, 20240001
+for cap in (0, 64):
+    m = engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_UNIFORM)
+    e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=cap)
+    e.init_normal(SEED, 0.0, 0.01)
+    t = time.perf_counter(); levels, largest, approx, _ = e.als_plan(m); tp = time.perf_counter() - t
+    d_err = util.DevBuf(N)
+    L.check(L.lib().fmx_predict_device(e.h, m.h, C.c_int64(0), C.c_int64(N), d_err.ptr, C.c_int(L.LINK_NONE)))
+    e.sync()
+    e.vsweep_device(m, d_err.ptr.value, alpha=1.0, v_lambda=np.full(K, 1.0)); e.sync()
+    t = time.perf_counter()
+    e.vsweep_device(m, d_err.ptr.value, alpha=1.0, v_lambda=np.full(K, 1.0)); e.sync()
+    dt = time.perf_counter() - t
+    print(f"als_max_levels={cap}: levels {levels} (largest {largest}), approximate {bool(approx)}, plan {tp:.2f} s, sweep {dt*1e3:.1f} ms = {N/dt/1e6:.1f} M examples/s", flush=True)
+    e.close(); d_err.free(); m.close()
