@@ -234,6 +234,30 @@ def test_configs4_carried_q_sweeps_match_the_oracle_and_notice_a_changed_v(monke
     e.close(); m.close()
 
 
+@pytest.mark.parametrize("k", [1, 5])
+def test_configs4_block_form_with_odd_factor_counts(monkeypatch, k):
+    """k = 1 and k = 5 (kp64 = 2 and 6: the padded layout of the fp64 tables, the stride of the q table): the block form against the oracle."""
+    from fmwr_amd import _lib as L, engine
+    monkeypatch.setenv("FMX_ALS_TILED", "1")
+    monkeypatch.setenv("FMX_ALS_TILE_ROWS", "4096")
+    monkeypatch.setenv("FMX_ALS_BLOCK_ROWS", "2048")
+    n, p = 15_000, 6_000
+    rp, col, val, y = _problem(engine, L, "stratified", n, p, 79, "normal")
+    w0, w, v = util.params(p, k, 53, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    lam = np.linspace(0.1, 0.5, k); mu = np.linspace(-0.05, 0.05, k)
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert e.als_level_order_form(m) == 2
+    gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu)
+    assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    e.close(); m.close()
+
+
 def test_configs4_level_order_needs_a_complete_plan(monkeypatch):
     """Rows that lack a level (i.i.d. columns: many narrow levels) or levels that keep the column-walking kernels leave the plan incomplete: the V sweep
     then takes the three-pass form level by level, as before."""
