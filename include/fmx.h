@@ -447,7 +447,8 @@ int fmx_als_order_info(fmx_engine* e, fmx_matrix* m, int32_t* level_order);
  * v_f.  With on = 1 the block form writes that back into the table as the pairs move on, and the next V sweep on the same plan skips the forward pass if the V
  * table is bit for bit what the sweep left (a 64-bit fingerprint; set_params, training steps, another matrix or a rebuilt plan all force the rebuild, as does every
  * 64th sweep, against rounding drift: each carried sweep adds ~1e-16 relative per level).  Results agree with the rebuilt form to ~1e-13: within the 1e-10 of the
- * oracle tests, not bit for bit.  Other forms of the sweep ignore the switch. */
+ * oracle tests, not bit for bit (the carried q keeps an ABSOLUTE rounding floor of ~1e-16 x the largest |q| since the last rebuild: a sweep that drives q towards zero by
+ * many orders of magnitude sees it; ten sweeps at configs[4]: 1e-15 from the rebuilt form, profiles/r05_block_soak.txt).  Other forms of the sweep ignore the switch. */
 int fmx_als_carry_q(fmx_engine* e, int32_t on);
 
 /* The ALS learner's training loop (MCMC_ALS_Learner::learn, :91-156; REGRESSION): max_iter times { forward; residual;
