@@ -1156,24 +1156,29 @@ int launch_seq_learn_grid(fmx_engine* const* es, int n, const fmx_matrix* m, con
   hipLaunchKernelGGL(seq_prepare_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, d_order, count, m->row_ptr, m->y, e->seq_b, e->seq_len, e->seq_y);
   const int64_t CHUNK = 1 << 16;
   FMX_TRY(ensure_window_workspace(e, count < CHUNK ? count : CHUNK));
-  std::vector<SeqArgs> h_as((size_t)n);
+  // the models' argument records: one array per chunk (the examples' pointers move with the chunk), all uploaded before the first launch -- nothing waits between chunks
+  const int64_t n_chunks = (count + CHUNK - 1) / CHUNK;
+  std::vector<SeqArgs> h_as((size_t)n * (size_t)n_chunks);
   std::vector<Hyper> h_hs((size_t)n);
   SeqArgs* d_as = nullptr; Hyper* d_hs = nullptr;
-  FMX_HIP(hipMalloc(&d_as, (size_t)n * sizeof(SeqArgs)));
+  FMX_HIP(hipMalloc(&d_as, h_as.size() * sizeof(SeqArgs)));
   if (hipMalloc(&d_hs, (size_t)n * sizeof(Hyper)) != hipSuccess) { (void)hipFree(d_as); set_error("out of device memory"); return FMX_ERR_HIP; }
-  int st = FMX_OK;
-  for (int64_t off = 0; off < count && st == FMX_OK; off += CHUNK) {
-    const int cnt = (int)((count - off < CHUNK) ? count - off : CHUNK);
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    const int64_t off = c * CHUNK;
+    const int64_t cnt = (count - off < CHUNK) ? count - off : CHUNK;
     for (int b = 0; b < n; ++b) {
       fmx_engine* g = es[b];
-      h_as[(size_t)b] = SeqArgs{m->row_ptr, m->col, m->val, m->y, d_order + off, cnt, e->seq_b + off, e->seq_len + off, e->seq_y + off, g->dV, g->dw, g->dsV, g->dsw, g->dnV, g->dnw,
-                                g->dt1V, g->dt1w, g->dt2V, g->dt2w, g->dt3V, g->dt3w, g->scal, g->k, g->kp64, m->rows_sorted};
-      h_hs[(size_t)b] = g->hyper;
+      h_as[(size_t)c * n + b] = SeqArgs{m->row_ptr, m->col, m->val, m->y, d_order + off, cnt, e->seq_b + off, e->seq_len + off, e->seq_y + off, g->dV, g->dw, g->dsV, g->dsw, g->dnV, g->dnw,
+                                        g->dt1V, g->dt1w, g->dt2V, g->dt2w, g->dt3V, g->dt3w, g->scal, g->k, g->kp64, m->rows_sorted};
     }
-    // (the previous chunk's launch reads the argument arrays: wait for it before overwriting them -- chunks are 40 ms of work, the wait is nothing)
-    if (off > 0 && hipStreamSynchronize(e->stream) != hipSuccess) { set_error("grid learner failed"); st = FMX_ERR_HIP; break; }
-    if (hipMemcpyAsync(d_as, h_as.data(), (size_t)n * sizeof(SeqArgs), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemcpyAsync(d_hs, h_hs.data(), (size_t)n * sizeof(Hyper), hipMemcpyHostToDevice, e->stream) != hipSuccess) { set_error("upload of the grid's arguments failed"); st = FMX_ERR_HIP; break; }
+  }
+  for (int b = 0; b < n; ++b) h_hs[(size_t)b] = es[b]->hyper;
+  int st = FMX_OK;
+  if (hipMemcpy(d_as, h_as.data(), h_as.size() * sizeof(SeqArgs), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_hs, h_hs.data(), (size_t)n * sizeof(Hyper), hipMemcpyHostToDevice) != hipSuccess) { set_error("upload of the grid's arguments failed"); st = FMX_ERR_HIP; }
+  for (int64_t off = 0; off < count && st == FMX_OK; off += CHUNK) {
+    const int cnt = (int)((count - off < CHUNK) ? count - off : CHUNK);
+    const SeqArgs* d_as_chunk = d_as + (size_t)(off / CHUNK) * n;
     const size_t pairs = (size_t)cnt * nz;
     uint32_t* keys = e->seq_keys;
     const size_t cap_pairs = (size_t)e->seq_wcap * WIN_NZ_MAX;
@@ -1184,7 +1189,7 @@ int launch_seq_learn_grid(fmx_engine* const* es, int n, const fmx_matrix* m, con
     if (rocprim::radix_sort_pairs(e->seq_sort_tmp, tb, keys, keys + cap_pairs, keys + 2 * cap_pairs, keys + 3 * cap_pairs, pairs, 0, 32, e->stream) != hipSuccess) { st = FMX_ERR_HIP; break; }
     hipLaunchKernelGGL(seq_conf_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, keys + cap_pairs, keys + 3 * cap_pairs, (int)pairs, e->seq_conf);
     const WinArgs wa{(const uint2*)e->seq_packed, e->seq_len + off, e->seq_y + off, e->seq_conf, cnt};
-#define FMX_GRID(KIND, KL, NZ) hipLaunchKernelGGL((fm_seq_pipe_grid_k<KIND, KL, NZ>), dim3((unsigned)n), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, (const SeqArgs*)d_as, wa, (const Hyper*)d_hs)
+#define FMX_GRID(KIND, KL, NZ) hipLaunchKernelGGL((fm_seq_pipe_grid_k<KIND, KL, NZ>), dim3((unsigned)n), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, d_as_chunk, wa, (const Hyper*)d_hs)
 #define FMX_GRID_KIND(KIND)                                                                            \
   do {                                                                                                 \
     if (kl == 16) { if (nz == 32) FMX_GRID(KIND, 16, 32); else FMX_GRID(KIND, 16, 64); }               \
