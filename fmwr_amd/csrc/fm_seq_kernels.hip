@@ -550,7 +550,7 @@ __global__ void seq_conf_k(const uint32_t* __restrict__ keys, const uint32_t* __
 }
 
 template <int KIND, int KL, int NZ>
-__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window_k(SeqArgs a, WinArgs wa, Hyper h) {
+__device__ __forceinline__ void seq_window_body(const SeqArgs& a, const WinArgs& wa, const Hyper& h) {
   constexpr int NW = SeqWin<KIND, KL, NZ>::NW;
   constexpr int Q = SeqWin<KIND, KL, NZ>::Q;
   constexpr int SL = SeqWin<KIND, KL, NZ>::SL;
@@ -779,6 +779,18 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window
 #endif
   }
 #undef FMX_T
+}
+template <int KIND, int KL, int NZ>
+__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window_k(SeqArgs a, WinArgs wa, Hyper h) {
+  seq_window_body<KIND, KL, NZ>(a, wa, h);
+}
+// the grid form (see fm_seq_pipe_grid_k below): workgroup b is the learner of model b -- the shapes the pipelined kernel does not take (TDAP, the reference's default
+// solver; SGD-L1 and FTRL at k > 16)
+template <int KIND, int KL, int NZ>
+__global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_window_grid_k(const SeqArgs* __restrict__ as, WinArgs wa, const Hyper* __restrict__ hs) {
+  const SeqArgs a = as[blockIdx.x];
+  const Hyper h = hs[blockIdx.x];
+  seq_window_body<KIND, KL, NZ>(a, wa, h);
 }
 
 // ---- pipelined windowed learner ---------------------------------------------------------------------------------------
@@ -1135,15 +1147,14 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
 
 // n models (engines of one shape: p, k, update kind) trained on the SAME examples in the SAME order, one launch per chunk with one workgroup per model.
 // The examples' metadata, packing and conflict plan are made once, in es[0]'s workspace and on es[0]'s stream; the other engines' streams are idle for the
-// duration (the caller waits).  Only shapes the pipelined windowed kernel takes (fast rows; SGD-L2 any k <= 64, SGD-L1 / FTRL at k <= 16): anything else is an error.
+// duration (the caller waits).  Every shape the windowed learners take (fast rows): the pipelined kernel where the single-model launcher picks it, the windowed one elsewhere.
 int launch_seq_learn_grid(fmx_engine* const* es, int n, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
   fmx_engine* e = es[0];
   if (count <= 0) return FMX_OK;
   const int nz = window_mode(e, m);
   FMX_CHECK(nz > 0, FMX_ERR_INVALID, "grid training needs rows of at most 64 (k <= 32) / 32 entries with ascending columns");
-  FMX_CHECK(e->hyper.kind != UPD_TDAP, FMX_ERR_INVALID, "grid training: TDAP keeps the single-model learner");
   const int kl = e->k <= 16 ? 16 : (e->k <= 32 ? 32 : 64);
-  FMX_CHECK(e->hyper.kind == UPD_SGD_L2 || kl == 16, FMX_ERR_INVALID, "grid training: SGD-L1 and FTRL at k <= 16 only");
+  FMX_CHECK(!(kl == 64 && nz == 64), FMX_ERR_INVALID, "grid training: rows of more than 32 entries need k <= 32");
   if (count > e->seq_cap) {
     FMX_HIP(hipStreamSynchronize(e->stream));
     (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
@@ -1183,28 +1194,40 @@ int launch_seq_learn_grid(fmx_engine* const* es, int n, const fmx_matrix* m, con
     uint32_t* keys = e->seq_keys;
     const size_t cap_pairs = (size_t)e->seq_wcap * WIN_NZ_MAX;
     if (hipMemsetAsync(e->seq_conf, 0xFF, (size_t)cnt * sizeof(int), e->stream) != hipSuccess) { st = FMX_ERR_HIP; break; }
-    hipLaunchKernelGGL(seq_pack_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, e->seq_b + off, e->seq_len + off, cnt, nz, m->col, m->val, 0, (uint2*)e->seq_packed, keys,
+    hipLaunchKernelGGL(seq_pack_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, e->seq_b + off, e->seq_len + off, cnt, nz, m->col, m->val,
+                       e->hyper.kind == UPD_TDAP ? 1 : 0, (uint2*)e->seq_packed, keys,
                        keys + 2 * cap_pairs, e->seq_conf);
     size_t tb = e->seq_sort_tmp_bytes;
     if (rocprim::radix_sort_pairs(e->seq_sort_tmp, tb, keys, keys + cap_pairs, keys + 2 * cap_pairs, keys + 3 * cap_pairs, pairs, 0, 32, e->stream) != hipSuccess) { st = FMX_ERR_HIP; break; }
     hipLaunchKernelGGL(seq_conf_k, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, e->stream, keys + cap_pairs, keys + 3 * cap_pairs, (int)pairs, e->seq_conf);
     const WinArgs wa{(const uint2*)e->seq_packed, e->seq_len + off, e->seq_y + off, e->seq_conf, cnt};
-#define FMX_GRID(KIND, KL, NZ) hipLaunchKernelGGL((fm_seq_pipe_grid_k<KIND, KL, NZ>), dim3((unsigned)n), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, d_as_chunk, wa, (const Hyper*)d_hs)
+    // the same choice of kernel per shape as the single-model launcher (launch_window_kind): the models' bits must be their single runs'
+    const int pm = pipe_mode();
+#define FMX_GRID_ONE(KIND, KL, NZ)                                                                                                                              \
+  do {                                                                                                                                                          \
+    bool piped = false;                                                                                                                                         \
+    if constexpr (KIND != UPD_TDAP) {                                                                                                                           \
+      if (pm == 2 || (pm == 1 && PipeFits<KIND, KL, NZ>::value)) {                                                                                              \
+        hipLaunchKernelGGL((fm_seq_pipe_grid_k<KIND, KL, NZ>), dim3((unsigned)n), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, d_as_chunk, wa, (const Hyper*)d_hs); \
+        piped = true;                                                                                                                                           \
+      }                                                                                                                                                         \
+    }                                                                                                                                                           \
+    if (!piped) hipLaunchKernelGGL((fm_seq_window_grid_k<KIND, KL, NZ>), dim3((unsigned)n), dim3(SeqWin<KIND, KL, NZ>::NW * 64), 0, e->stream, d_as_chunk, wa, (const Hyper*)d_hs); \
+  } while (0)
 #define FMX_GRID_KIND(KIND)                                                                            \
   do {                                                                                                 \
-    if (kl == 16) { if (nz == 32) FMX_GRID(KIND, 16, 32); else FMX_GRID(KIND, 16, 64); }               \
-    else if constexpr (KIND == UPD_SGD_L2) {                                                           \
-      if (kl == 32) { if (nz == 32) FMX_GRID(KIND, 32, 32); else FMX_GRID(KIND, 32, 64); }             \
-      else FMX_GRID(KIND, 64, 32);                                                                     \
-    }                                                                                                  \
+    if (kl == 16) { if (nz == 32) FMX_GRID_ONE(KIND, 16, 32); else FMX_GRID_ONE(KIND, 16, 64); }       \
+    else if (kl == 32) { if (nz == 32) FMX_GRID_ONE(KIND, 32, 32); else FMX_GRID_ONE(KIND, 32, 64); }  \
+    else FMX_GRID_ONE(KIND, 64, 32);                                                                   \
   } while (0)
     switch (e->hyper.kind) {
       case UPD_SGD_L2: FMX_GRID_KIND(UPD_SGD_L2); break;
       case UPD_SGD_L1: FMX_GRID_KIND(UPD_SGD_L1); break;
+      case UPD_TDAP: FMX_GRID_KIND(UPD_TDAP); break;
       default: FMX_GRID_KIND(UPD_FTRL); break;
     }
+#undef FMX_GRID_ONE
 #undef FMX_GRID_KIND
-#undef FMX_GRID
     if (hipGetLastError() != hipSuccess) { set_error("grid learner launch failed"); st = FMX_ERR_HIP; }
   }
   if (st == FMX_OK && hipStreamSynchronize(e->stream) != hipSuccess) { set_error("grid learner failed"); st = FMX_ERR_HIP; }

@@ -255,7 +255,8 @@ int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_
  * one workgroup per model -- the reference-order learner is a single workgroup bound by its scalar chain, so one model cannot use more of
  * the chip, but 64 or 256 models can.  Every engine keeps its own parameters, optimizer state and hyper-parameters (learn_rate, regularisers, alpha / beta ...);
  * the engines share the feature count, factor.number, solver, task, device and random_step = 1 (ONE visiting order), and the matrix.  Each model's result is bit for
- * bit what fmx_train(engine, m, max_iter) alone gives it.  SGD (L1 / L2) and FTRL, rows of at most 32 entries (64 at k <= 32) with ascending columns; SGD-L1 and FTRL at k <= 16. */
+ * bit what fmx_train(engine, m, max_iter) alone gives it.  SGD (L1 / L2), FTRL and TDAP (the reference's default solver); rows of at most 32 entries (64 at k <= 32) with
+ * ascending columns -- the shapes the windowed learners take. */
 int fmx_train_grid(fmx_engine* const* engines, int32_t n_engines, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
 /* Same, but with an explicit visiting order (row ids, SEQUENTIAL mode only). */
 int fmx_train_order(fmx_engine* e, fmx_matrix* m, const int64_t* order, int64_t count);

@@ -1,4 +1,5 @@
-"""fmx_train_grid: n reference-order learners side by side on one matrix and one visiting order (one workgroup per model, the examples' conflict plan shared).
+"""fmx_train_grid: n reference-order learners side by side on one matrix and one visiting order (one workgroup per model, the examples' conflict plan shared):
+SGD-L2 / SGD-L1 / FTRL / TDAP (the reference's default solver), the shapes the pipelined kernel takes and those that keep the windowed one.
 Every model must come out bit for bit as its own fmx_train call leaves it -- which the oracle tests pin to the reference's algorithm (tests/test_gpu_train.py)."""
 import numpy as np
 import pytest
@@ -8,7 +9,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("solver,k,z", [("sgd_l2", 16, 30), ("sgd_l2", 40, 12), ("sgd_l1", 8, 30), ("ftrl", 16, 20)])
+@pytest.mark.parametrize("solver,k,z", [("sgd_l2", 16, 30), ("sgd_l2", 40, 12), ("sgd_l1", 8, 30), ("ftrl", 16, 20), ("tdap", 6, 30), ("ftrl", 40, 16), ("sgd_l1", 24, 48)])
 def test_a_grid_of_models_equals_the_models_trained_one_by_one(solver, k, z):
     from fmwr_amd import _lib as L, engine
     n, p, iters = 30_000, 20_000, 90_000     # three passes over the matrix: the visiting order wraps (row 0 is never visited: SURVEY A-2)
@@ -19,6 +20,7 @@ def test_a_grid_of_models_equals_the_models_trained_one_by_one(solver, k, z):
         kw = dict(num_factor=k, mode=L.MODE_SEQUENTIAL, task=L.TASK_CLASSIFICATION)
         if solver == "sgd_l2": kw.update(solver=L.SOLVER_SGD, learn_rate=0.01 * (1 + i), l2_w1=1e-4 * (1 + i), l2_v=1e-4)
         elif solver == "sgd_l1": kw.update(solver=L.SOLVER_SGD, learn_rate=0.02 / (1 + i), l1_w1=1e-5 * (1 + i), l1_v=1e-5)
+        elif solver == "tdap": kw.update(solver=L.SOLVER_TDAP, alpha_w=0.05 * (1 + i), alpha_v=0.05, beta_w=1.0, beta_v=1.0, l1_w1=1e-3, l1_v=5e-4, l2_w1=1e-2, l2_v=1e-2, gamma=3e-4 * (1 + i))
         else: kw.update(solver=L.SOLVER_FTRL, alpha_w=0.05 * (1 + i), alpha_v=0.05, beta_w=1.0, beta_v=1.0, l1_w1=1e-4, l1_v=1e-4, l2_w1=1e-4, l2_v=1e-4)
         grid.append(kw)
     singles = []
