@@ -59,6 +59,8 @@ def parse(argv=None):
                     help="--workload uniform: the column law of the synthetic rows.  iid: SURVEY 8(d)'s primary law, columns i.i.d. uniform over [0, p), sorted inside the "
                          "row (fmx_matrix_synthetic_iid) -- the headline; stratified: one column per stratum of [0, p) (fmx_matrix_synthetic: what rounds 1-4 quoted `value` on, "
                          "kept in the line as `value_stratified_columns`); zipf: SURVEY 8(d)'s conflict-stress variant, exponent 1.05")
+    ap.add_argument("--sweep-iid", action="store_true",
+                    help="--solver als / mcmc: the V sweep on SURVEY 8(d)'s i.i.d. uniform columns in the COLOURED order (cfg.als_max_levels = -1); default: one column per stratum")
     ap.add_argument("--real-values", action="store_true", help="SURVEY 8(d)'s value variant: val ~ U(0,1) instead of 1 (fmx_matrix_synthetic_values): the kernels then read the value arrays")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
@@ -616,10 +618,15 @@ def main_sweep(args, rank, local_rank, world):
     z, k, p, n = args.nnz, args.factors, args.features, args.rows
     gibbs = args.solver == "mcmc"
     dev = torch.device("cuda", local_rank)
-    m = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=rank * n, device=local_rank)
+    iid = args.columns == "iid" and args.sweep_iid
+    if iid:   # SURVEY 8(d)'s i.i.d. law: no field structure -- the reference's feature order is a chain of ~20 000 levels there; the coloured order (exact steps, the engine's own order) is what is timed
+        m = engine.Matrix.synthetic_iid(n, p, z, args.seed, law=L.COLUMNS_UNIFORM, row_offset=rank * n, device=local_rank)
+    else:
+        m = engine.Matrix.synthetic(n, p, z, args.seed, row_offset=rank * n, device=local_rank)
     if args.real_values:                         # SURVEY 8(d)'s value variant: U(0, 1) instead of the one-hot 1.0 (the sweep kernels then read the value arrays)
         m.synthetic_values(args.seed + 1, row_offset=rank * n)
-    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank,
+                      als_max_levels=-1 if iid else 0)
     e.init_normal(args.seed, 0.0, 0.01)          # V0 ~ N(0, 0.01), w0 = w = 0
     t0 = time.perf_counter()
     levels, largest, approx, _ = e.als_plan(m)   # CSC of the whole matrix + the level plan: ingest, outside the timed region
@@ -691,11 +698,14 @@ def main_sweep(args, rank, local_rank, world):
         "metric": f"V-sweep examples/sec, {shape_tag(n, p)} sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
         "value": world * n * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic {n}x{p}, {z} nnz/row, one column per stratum of [0, p) (fmx_matrix_synthetic: one-column-per-field data, the shape whose exact level "
+        "config": {"workload": (f"synthetic {n}x{p}, {z} nnz/row, i.i.d. uniform columns (SURVEY 8(d)'s law): the COLOURED order of the sweep (cfg.als_max_levels = -1: every coordinate step exact, the "
+                                f"features visited in (colour, index) order of a colouring of the share-a-row graph instead of the reference's index order, which is a chain of ~20 000 dependent levels here), "
+                                f"k={k}, {'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns; a step = one sweep of all {k} factors") if iid else
+                               f"synthetic {n}x{p}, {z} nnz/row, one column per stratum of [0, p) (fmx_matrix_synthetic: one-column-per-field data, the shape whose exact level "
                                f"schedule is {z} levels; i.i.d. columns need thousands of dependent levels and take the approximate groups instead), k={k}, "
                                f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
                                f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
-                   "levels": levels, "largest_level": largest, "approximate": bool(approx), "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
+                   "levels": levels, "largest_level": largest, "approximate": bool(approx) and not iid, "feature_order": "coloured (exact steps)" if iid else "the reference's", "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
                    "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
                    "parallelism": f"replicas{world}" if world > 1 else "dp1"},
         "roofline": {"bound": "hbm", "kernel": "one level of one factor: " + form, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

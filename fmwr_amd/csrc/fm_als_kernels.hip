@@ -113,6 +113,115 @@ __global__ __launch_bounds__(WG_THREADS) void level_heavy_k(const uint32_t* __re
   if (threadIdx.x == 0 && atomicAdd(done_flag, 1) == (int)gridDim.x - 1) { *n_heavy = 0; *done_flag = 0; }
 }
 
+// ---- the COLOURED order (cfg.als_max_levels < 0) -----------------------------------------------------------------------------------------
+// The exact schedule keeps the reference's feature ORDER: feature j waits for every earlier feature it shares a row with, which on i.i.d. columns is a chain
+// of ~20 000 levels of ~50 features (10 M x 1 M: 310 K dependent launches per sweep of 16 factors: 5 M examples/s, profiles/r05_als_iid_sweep.txt).  A sweep that
+// may choose its own order -- any order is a Gauss-Seidel pass for ALS and a valid scan for the Gibbs sampler, but not the reference's numbers on the same
+// inputs -- only needs features of one level to share no row: a proper COLOURING of the "share a row" graph, a thousand-odd colours of a thousand features here.
+// The sweep then visits the features in (colour, index) order, every step exact (no snapshot, no guard): the oracle reproduces it on the relabelled matrix.
+// Colouring, deterministic (the plan, and with it the visiting order, must not depend on timing): rounds of
+//   assign   every uncoloured feature reads the colours FIXED IN EARLIER ROUNDS of all features it shares a row with (a bitset per wave in LDS) and takes the
+//            t-th free colour, t = hash(feature, round) mod COLOUR_SPREAD (neighbours that choose in the same round spread over several colours);
+//   resolve  a feature that chose the colour of a LOWER-indexed neighbour of the same round gives it up and stays for the next round.
+constexpr int COLOUR_MAX = 8192;       // bits of the per-wave set
+constexpr int COLOUR_SPREAD = 8;
+__device__ __forceinline__ uint32_t colour_hash(uint32_t a, uint32_t b) {
+  uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+  x ^= x >> 15; x *= 0xC2B2AE3Du; x ^= x >> 13;
+  return x;
+}
+__global__ __launch_bounds__(WG_THREADS) void colour_assign_k(const uint32_t* __restrict__ act, int n_act, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
+                                                              const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const int* fixed,
+                                                              int* chosen, int round, int spread, int* __restrict__ overflow) {   // (the refit passes run it with chosen == fixed)
+  constexpr int WORDS = COLOUR_MAX / 32, WPB = WG_THREADS / 64, PER = WORDS / 64;
+  __shared__ uint32_t forb[WPB][WORDS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int waves = (int)(gridDim.x * WPB);
+  for (int w = (int)(blockIdx.x * WPB + wv); w < n_act; w += waves) {
+    const uint32_t j = act[w];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) forb[wv][lane * PER + q] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t t = col_ptr[j] + lane; t < col_ptr[j + 1]; t += 64) {
+      const uint32_t r = crow[t];
+      const int64_t ub = row_ptr[r], ue = row_ptr[r + 1];
+      for (int64_t u = ub; u < ue; u += 8) {   // eight entries' columns, then their colours: independent loads in flight (a dependent pair per entry took 24 s of plan time at 10 M x 1 M)
+        uint32_t k[8]; int c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] = col[u + i < ue ? u + i : ue - 1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = fixed[k[i]];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (u + i < ue && c[i] >= 0 && k[i] != j) atomicOr(&forb[wv][c[i] >> 5], 1u << (c[i] & 31));   // (k == j: a feature being REFITTED may keep its own colour)
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the t-th free colour: lane l owns words l * PER .. (consecutive colours), an exclusive scan of the free counts finds the lane
+    uint32_t fw[PER]; int nfree = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { fw[q] = ~forb[wv][lane * PER + q]; nfree += __popc(fw[q]); }
+    int incl = nfree;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    const int total = __shfl(incl, 63);
+    const int want = total > 0 ? (int)(colour_hash(j, (uint32_t)round) % (uint32_t)(total < spread ? total : spread)) : 0;
+    const int before = incl - nfree;
+    int mine = -1;
+    if (total > 0 && want >= before && want < incl) {
+      int left = want - before;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int c = __popc(fw[q]);
+        if (mine < 0 && left < c) {
+          uint32_t wbits = fw[q];
+          for (int z = 0; z < left; ++z) wbits &= wbits - 1;   // drop the lowest `left` free bits
+          mine = (lane * PER + q) * 32 + (__ffs((int)wbits) - 1);
+        }
+        left -= c;
+      }
+    }
+    // (exactly one lane holds the answer)
+    const unsigned long long who = __ballot(mine >= 0);
+    if (who == 0ull) { if (lane == 0) { chosen[j] = -1; atomicExch(overflow, 1); } }
+    else if (mine >= 0) chosen[j] = mine;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+// lose[w] = 1: the feature's choice collides with a lower-indexed feature of the same round
+__global__ __launch_bounds__(WG_THREADS) void colour_resolve_k(const uint32_t* __restrict__ act, int n_act, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
+                                                               const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const int* __restrict__ fixed,
+                                                               const int* __restrict__ chosen, int* __restrict__ lose) {
+  const int lane = threadIdx.x & 63;
+  const int waves = (int)(gridDim.x * (WG_THREADS / 64));
+  for (int w = (int)(((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6); w < n_act; w += waves) {
+    const uint32_t j = act[w];
+    const int c = chosen[j];
+    bool bad = c < 0;
+    for (int64_t t = col_ptr[j] + lane; t < col_ptr[j + 1] && !bad; t += 64) {
+      const uint32_t r = crow[t];
+      const int64_t ub = row_ptr[r], ue = row_ptr[r + 1];
+      for (int64_t u = ub; u < ue; u += 8) {
+        uint32_t k[8]; int fx[8], ch[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] = col[u + i < ue ? u + i : ue - 1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fx[i] = fixed[k[i]]; ch[i] = chosen[k[i]]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (u + i < ue && k[i] < j && fx[i] < 0 && ch[i] == c) bad = true;   // (features fixed earlier never hold c: the assignment excluded their colours)
+      }
+    }
+    if (lane == 0) lose[w] = 0;
+    if (__any(bad) && lane == 0) lose[w] = 1;
+  }
+}
+// winners are fixed, losers form the next round's list (in this round's order: the list stays ascending)
+__global__ void colour_commit_k(const uint32_t* __restrict__ act, int n_act, const int* __restrict__ lose, const int* __restrict__ chosen, int* __restrict__ fixed) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_act && !lose[w]) fixed[act[w]] = chosen[act[w]];
+}
+
 // ---- per-factor cache q = X v_f (rows parallel; same ascending-feature association as :291-299) -------------------
 __global__ void als_q_init_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const float* __restrict__ val,
                              int64_t n, const double* __restrict__ V, int kp, int f, double2* __restrict__ qe) {
@@ -603,9 +712,95 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   FMX_HIP(hipMalloc(&d_changed, sizeof(int)));
   FMX_HIP(hipMemsetAsync(d_level, 0, (size_t)p * sizeof(int), stream));  // features that never occur stay at level 0
   bool approx = false;
+  bool coloured = false;
+  if (max_levels < 0 && m->n > 0 && m->nnz > 0) {
+    // cfg.als_max_levels < 0: the sweep may choose its own feature order -- levels = the colours of a proper colouring of the "share a row" graph (kernels above).
+    // Falls through to the exact schedule below where it does not apply (a column too long for one wave per feature, more colours than the kernel's set).
+    std::vector<int64_t> cph((size_t)p + 1);
+    FMX_HIP(hipMemcpy(cph.data(), m->col_ptr, cph.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> act;
+    bool too_long = false;
+    for (uint32_t j = 0; j < p; ++j) {
+      const int64_t len = cph[(size_t)j + 1] - cph[(size_t)j];
+      if (len > 0) act.push_back(j);
+      if (len > LEVEL_HEAVY) too_long = true;
+    }
+    if (!too_long && !act.empty()) {
+      struct Tmp {
+        int *fixed = nullptr, *chosen = nullptr, *lose = nullptr, *overflow = nullptr; uint32_t* act = nullptr;
+        ~Tmp() { (void)hipFree(fixed); (void)hipFree(chosen); (void)hipFree(lose); (void)hipFree(overflow); (void)hipFree(act); }
+      } w;
+      FMX_HIP(hipMalloc(&w.fixed, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.chosen, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.lose, act.size() * sizeof(int)));
+      FMX_HIP(hipMalloc(&w.overflow, sizeof(int))); FMX_HIP(hipMalloc(&w.act, act.size() * sizeof(uint32_t)));
+      FMX_HIP(hipMemsetAsync(w.fixed, 0xFF, (size_t)p * sizeof(int), stream));
+      FMX_HIP(hipMemsetAsync(w.chosen, 0xFF, (size_t)p * sizeof(int), stream));
+      FMX_HIP(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
+      std::vector<int> h_lose;
+      bool failed = false;
+      for (int round = 0; !act.empty(); ++round) {
+        const int na = (int)act.size();
+        FMX_HIP(hipMemcpyAsync(w.act, act.data(), (size_t)na * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        const unsigned grid = (unsigned)(na < 4 * 2048 ? (na + 3) / 4 : 2048);
+        hipLaunchKernelGGL(colour_assign_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
+                           (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.chosen, round, COLOUR_SPREAD, w.overflow);
+        hipLaunchKernelGGL(colour_resolve_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
+                           (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, (const int*)w.chosen, w.lose);
+        hipLaunchKernelGGL(colour_commit_k, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)w.act, na, (const int*)w.lose, (const int*)w.chosen, w.fixed);
+        h_lose.resize((size_t)na);
+        int h_over = 0;
+        FMX_HIP(hipMemcpyAsync(h_lose.data(), w.lose, (size_t)na * sizeof(int), hipMemcpyDeviceToHost, stream));
+        FMX_HIP(hipMemcpyAsync(&h_over, w.overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
+        FMX_HIP(hipStreamSynchronize(stream));
+        if (h_over || round > 4096) { failed = true; break; }
+        std::vector<uint32_t> next;
+        for (int i = 0; i < na; ++i) if (h_lose[(size_t)i]) next.push_back(act[(size_t)i]);
+        act.swap(next);
+      }
+      // The spread that makes the rounds converge also spreads the colours (one-column-per-field data: 240 colours where 30 do).  REFIT, class by class from the
+      // highest colour down: the features of one colour share no row, so all of them may move to their smallest free colour at once -- nothing they read changes
+      // in that launch -- and the colouring stays proper, never grows, and usually loses most of its upper classes (two passes).
+      for (int pass = 0; pass < 2 && !failed; ++pass) {
+        std::vector<int> col_now(p);
+        FMX_HIP(hipMemcpy(col_now.data(), w.fixed, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));
+        int top = -1;
+        for (uint32_t j = 0; j < p; ++j) if (col_now[j] > top) top = col_now[j];
+        std::vector<std::vector<uint32_t>> cls((size_t)(top + 1));
+        for (uint32_t j = 0; j < p; ++j) if (col_now[j] >= 0) cls[(size_t)col_now[j]].push_back(j);
+        std::vector<uint32_t> flat; std::vector<size_t> at((size_t)top + 2, 0);
+        for (int c = 0; c <= top; ++c) { at[(size_t)c] = flat.size(); flat.insert(flat.end(), cls[(size_t)c].begin(), cls[(size_t)c].end()); }
+        at[(size_t)top + 1] = flat.size();
+        if (flat.empty()) break;
+        FMX_HIP(hipMemcpyAsync(w.act, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));   // (w.act holds every occurring feature: flat is no longer)
+        for (int c = top; c >= 1; --c) {
+          const int na = (int)(at[(size_t)c + 1] - at[(size_t)c]);
+          if (na == 0) continue;
+          const unsigned grid = (unsigned)(na < 4 * 2048 ? (na + 3) / 4 : 2048);
+          hipLaunchKernelGGL(colour_assign_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)(w.act + at[(size_t)c]), na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
+                             (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.fixed, 0, 1, w.overflow);
+        }
+        int h_over = 0;
+        FMX_HIP(hipMemcpyAsync(&h_over, w.overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
+        FMX_HIP(hipStreamSynchronize(stream));
+        if (h_over) failed = true;
+      }
+      if (!failed) {
+        // colours -> levels 0 .. L - 1 without gaps (ascending colour); features that never occur stay at level 0
+        std::vector<int> col_of(p);
+        FMX_HIP(hipMemcpy(col_of.data(), w.fixed, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> remap((size_t)COLOUR_MAX, -1);
+        for (uint32_t j = 0; j < p; ++j) if (col_of[j] >= 0) remap[(size_t)col_of[j]] = 0;
+        int nl = 0;
+        for (int c = 0; c < COLOUR_MAX; ++c) if (remap[(size_t)c] == 0) remap[(size_t)c] = nl++;
+        for (uint32_t j = 0; j < p; ++j) col_of[j] = col_of[j] >= 0 ? remap[(size_t)col_of[j]] : 0;
+        FMX_HIP(hipMemcpy(d_level, col_of.data(), (size_t)p * sizeof(int), hipMemcpyHostToDevice));
+        coloured = true;
+      }
+    }
+  }
   const char* lv_env = getenv("FMX_ALS_LEVELS");  // FMX_ALS_LEVELS=relax: the round-1 builder (read per call: the tests compare the two)
   const bool relax = lv_env && lv_env[0] == 'r';
-  if (relax) {
+  if (coloured) {
+  } else if (relax) {
     // monotone relaxation to the fixed point; every sweep propagates along whole rows.  The "changed" flag is read back once per
     // CHECK sweeps.  max_levels > 0: give up after that many sweeps (a deep chain: i.i.d. or Zipf columns) and fall back to the
     // grouped sweep, whose groups need one pass.
@@ -754,6 +949,7 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
     FMX_HIP(hipMemcpy(m->als_vseg_e, seg_e.data(), seg_e.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   }
   m->als_approx = approx ? 1 : 0;
+  m->als_coloured = coloured ? 1 : 0;
   m->als_plan_cap = max_levels;
   m->als_level_of.assign(level.begin(), level.end());
   m->als_tiled_tried = 1;
@@ -1144,7 +1340,7 @@ int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* larges
   }
   if (levels) *levels = L;
   if (largest) *largest = big;
-  if (approx) *approx = m->als_approx;
+  if (approx) *approx = m->als_approx ? 1 : (m->als_coloured ? 2 : 0);   // 2: exact steps in a COLOURED feature order (cfg.als_max_levels < 0)
   if (level_of) for (size_t j = 0; j < m->als_level_of.size(); ++j) level_of[j] = m->als_level_of[j];
   return FMX_OK;
 }

@@ -181,6 +181,7 @@ struct fmx_matrix {
   std::vector<int64_t> als_vh_ptr, als_vseg_ptr;   // per level
   std::vector<int32_t> als_level_of;    // [p] level (exact plan) or group (approximate plan) of every feature
   int als_approx = 0;                   // the plan holds the groups of the approximate sweep, not exact levels
+  int als_coloured = 0;                 // the plan's levels are the colours of a colouring: exact steps, the engine's own feature order (cfg.als_max_levels < 0)
   int als_force_exact = 0;              // an approximate sweep raised the residual on this matrix: only exact plans from now on
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
   void* als_tiled = nullptr;            // row-tiled form of the wide levels of an exact plan (fm_als_tiled.hip: AlsTiled), or null

@@ -515,6 +515,12 @@ class Engine:
         L.check(L.lib().fmx_als_plan_info(self.h, m.h, C.byref(lv), C.byref(big), C.byref(ap), _p(lof)))
         return lv.value, big.value, bool(ap.value), lof[: self.p]
 
+    def als_plan_kind(self, m):
+        """0: the exact schedule (the reference's feature order); 1: the approximate groups (cfg.als_max_levels exceeded); 2: the coloured order (cfg.als_max_levels = -1)."""
+        ap = C.c_int32()
+        L.check(L.lib().fmx_als_plan_info(self.h, m.h, None, None, C.byref(ap), None))
+        return int(ap.value)
+
     def group_info(self):
         """a cfg.n_gpus handle: replicas, shared device or not, ordered device pairs / those with direct peer access, default exchange of sparse-tile steps"""
         v = [C.c_int32() for _ in range(5)]

@@ -1,11 +1,12 @@
-"""The ALS V sweep on SURVEY 8(d)'s i.i.d. column law at configs[4]'s size: exact level schedule and the approximate groups (cfg.als_max_levels)."""
+"""The ALS V sweep on SURVEY 8(d)'s i.i.d. column law at configs[4]'s size: the exact schedule (the reference's feature order), the approximate groups
+(cfg.als_max_levels > 0) and the coloured order (cfg.als_max_levels = -1: exact steps in the engine's own feature order)."""
 import sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, ".")
 from fmwr_amd import _lib as L, engine
 from tests import util
 N, P, Z, K, SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 1_000_000, 30, 16, 20240001
-for cap in (0, 64):
+for cap in (0, 64, -1):
     m = engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_UNIFORM)
     e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=cap)
     e.init_normal(SEED, 0.0, 0.01)
@@ -17,5 +18,5 @@ for cap in (0, 64):
     t = time.perf_counter()
     e.vsweep_device(m, d_err.ptr.value, alpha=1.0, v_lambda=np.full(K, 1.0)); e.sync()
     dt = time.perf_counter() - t
-    print(f"als_max_levels={cap}: levels {levels} (largest {largest}), approximate {bool(approx)}, plan {tp:.2f} s, sweep {dt*1e3:.1f} ms = {N/dt/1e6:.1f} M examples/s", flush=True)
+    print(f"als_max_levels={cap}: levels {levels} (largest {largest}), kind {e.als_plan_kind(m)} (0 exact order, 1 approximate groups, 2 coloured order), plan {tp:.2f} s, sweep {dt*1e3:.1f} ms = {N/dt/1e6:.1f} M examples/s", flush=True)
     e.close(); d_err.free(); m.close()

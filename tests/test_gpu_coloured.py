@@ -1,0 +1,79 @@
+"""cfg.als_max_levels = -1, the COLOURED order of the ALS / Gibbs sweeps: every coordinate step exact, the features visited in (colour, index) order of a proper
+colouring of the "share a row" graph instead of the reference's index order (on i.i.d. columns the reference's order is a chain of thousands of dependent levels).
+The claim is checked literally: relabel the features in the engine's order, and the ORACLE -- the reference's index-order sweep -- on the relabelled matrix must give
+the engine's numbers (1e-10)."""
+import numpy as np
+import pytest
+
+import oracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+K, Z = 8, 30
+
+
+def _relabel(rp, col, val, rank):
+    """the CSR with feature j renamed rank[j], rows re-sorted by the new names"""
+    n = len(rp) - 1
+    nc = rank[col].astype(np.int64)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    order = np.lexsort((nc, rows))
+    return rp.copy(), nc[order].astype(np.uint32), val[order]
+
+
+@pytest.mark.parametrize("gibbs,values", [(False, "ones"), (True, "normal")])
+def test_coloured_sweep_is_the_reference_sweep_on_the_relabelled_matrix(gibbs, values):
+    from fmwr_amd import _lib as L, engine
+    n, p = 12_000, 4_000
+    m0 = engine.Matrix.synthetic_iid(n, p, Z, 91, law=L.COLUMNS_UNIFORM)
+    rp, col, val, _ = m0.export(); m0.close()
+    if values == "normal":
+        val = np.random.default_rng(4).normal(0, 1, len(val)).astype(np.float32)
+    y = util.labels(n, 91, "regression")
+    w0, w, v = util.params(p, K, 61, stdev=0.1, fp32=False)
+    lam = np.linspace(10.0, 20.0, K) if gibbs else np.linspace(0.1, 0.5, K); mu = np.linspace(-0.05, 0.05, K)
+    z = np.random.default_rng(15).normal(0, 1, (K, p)) if gibbs else None
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=-1)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    levels, largest, _, level_of = e.als_plan(m)
+    level_of = level_of.copy()
+    assert e.als_plan_kind(m) == 2
+    # a proper colouring: no row holds two features of one level; far fewer levels than the reference's order needs
+    lv = level_of[col].reshape(n, Z)
+    assert all(len(np.unique(r)) == Z for r in lv[:: max(1, n // 500)]) and np.all(np.sort(lv, axis=1)[:, 1:] != np.sort(lv, axis=1)[:, :-1])
+    e_exact = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+    m_exact = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert levels < e_exact.als_plan(m_exact)[0] / 3
+    e_exact.close(); m_exact.close()
+    # the engine's order: (colour, index)
+    order = np.lexsort((np.arange(p), level_of))
+    rank = np.empty(p, np.int64); rank[order] = np.arange(p)
+    rp2, col2, val2 = _relabel(rp, col, val, rank)
+    X = oracle.Matrix(rp, col, val, p); X2 = oracle.Matrix(rp2, col2, val2, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    v2 = v[:, order]                                        # row f of V in the new names
+    z2 = z[:, order] if gibbs else None
+    rv2, rerr, _ = oracle.als_update_v(K, X2, np.ascontiguousarray(v2).ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=np.ascontiguousarray(z2).ravel() if gibbs else None)
+    rv = np.empty_like(v); rv[:, order] = rv2.reshape(K, p)
+    gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    assert util.rel_err(e.get_params()[2], rv) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    # the plan does not depend on timing: a second matrix, a second engine, the same colours
+    e3 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=-1)
+    m3 = engine.Matrix.from_csr(rp, col, val, p, y)
+    assert np.array_equal(e3.als_plan(m3)[3], level_of)
+    for x in (e, e3): x.close()
+    for x in (m, m3): x.close()
+
+
+def test_coloured_order_leaves_one_column_per_field_data_alone():
+    """30 fields = 30 colours at most: the plan is as wide as the exact one (which the block form then takes)."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 8_000, 3_000
+    m = engine.Matrix.synthetic(n, p, Z, 5)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=4, mode=L.MODE_SEQUENTIAL, als_max_levels=-1)
+    levels, _, _, level_of = e.als_plan(m)
+    assert levels <= 2 * Z and e.als_plan_kind(m) == 2
+    e.close(); m.close()
