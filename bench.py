@@ -618,7 +618,7 @@ def main_sweep(args, rank, local_rank, world):
     z, k, p, n = args.nnz, args.factors, args.features, args.rows
     gibbs = args.solver == "mcmc"
     dev = torch.device("cuda", local_rank)
-    iid = args.columns == "iid" and args.sweep_iid
+    iid = bool(args.sweep_iid)
     if iid:   # SURVEY 8(d)'s i.i.d. law: no field structure -- the reference's feature order is a chain of ~20 000 levels there; the coloured order (exact steps, the engine's own order) is what is timed
         m = engine.Matrix.synthetic_iid(n, p, z, args.seed, law=L.COLUMNS_UNIFORM, row_offset=rank * n, device=local_rank)
     else:
@@ -961,7 +961,7 @@ def compact_line(d):
             keep[kk] = d[kk]
     if isinstance(r.get("step"), dict):
         keep["roofline"]["step"] = r["step"]
-    for kk in ("level_order_form",):
+    for kk in ("level_order_form", "feature_order", "plan_build_s"):
         if kk in d["config"]:
             keep[kk] = d["config"][kk]
     for kk in ("batch_rows_per_gpu", "tile_rows", "features_occurring_per_step", "levels", "levels_row_tiled", "ingest_wait_s"):
@@ -981,6 +981,7 @@ def other_configs(args):
         ("configs[3]_resident", ["--workload", "criteo", "--steps", "30", "--warmup", "3", "--cpu-rows", "120000"], run_minibatch),
         ("configs[3]_streamed", ["--workload", "criteo", "--stream", "--steps", "30", "--warmup", "3"], main_stream),
         ("configs[4]", ["--solver", "mcmc", "--no-extras", "--steps", "4", "--warmup", "1", "--cpu-rows", "2000000"], main_sweep),
+        ("configs[4]_iid_columns", ["--solver", "mcmc", "--sweep-iid", "--no-extras", "--steps", "2", "--warmup", "1", "--cpu-rows", "0"], main_sweep),
     ]
     for name, argv, fn in runs:
         t0 = time.perf_counter()

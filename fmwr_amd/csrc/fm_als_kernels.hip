@@ -741,8 +741,10 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
         const int na = (int)act.size();
         FMX_HIP(hipMemcpyAsync(w.act, act.data(), (size_t)na * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         const unsigned grid = (unsigned)(na < 4 * 2048 ? (na + 3) / 4 : 2048);
+        // a colour holds at most n / (rows per feature) features: with S colours on offer a round fixes at most S classes' worth -- S grows with the crowd (150 rounds at S = 8)
+        const int spread = na / 2048 < COLOUR_SPREAD ? COLOUR_SPREAD : (na / 2048 > 1024 ? 1024 : na / 2048);
         hipLaunchKernelGGL(colour_assign_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
-                           (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.chosen, round, COLOUR_SPREAD, w.overflow);
+                           (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.chosen, round, spread, w.overflow);
         hipLaunchKernelGGL(colour_resolve_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
                            (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, (const int*)w.chosen, w.lose);
         hipLaunchKernelGGL(colour_commit_k, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)w.act, na, (const int*)w.lose, (const int*)w.chosen, w.fixed);
@@ -752,14 +754,15 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
         FMX_HIP(hipMemcpyAsync(&h_over, w.overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
         FMX_HIP(hipStreamSynchronize(stream));
         if (h_over || round > 4096) { failed = true; break; }
+        if (getenv("FMX_COLOUR_DEBUG")) fprintf(stderr, "colouring round %d: %d features choosing\n", round, na);
         std::vector<uint32_t> next;
         for (int i = 0; i < na; ++i) if (h_lose[(size_t)i]) next.push_back(act[(size_t)i]);
         act.swap(next);
       }
       // The spread that makes the rounds converge also spreads the colours (one-column-per-field data: 240 colours where 30 do).  REFIT, class by class from the
       // highest colour down: the features of one colour share no row, so all of them may move to their smallest free colour at once -- nothing they read changes
-      // in that launch -- and the colouring stays proper, never grows, and usually loses most of its upper classes (two passes).
-      for (int pass = 0; pass < 2 && !failed; ++pass) {
+      // in that launch -- and the colouring stays proper, never grows, and usually loses most of its upper classes (four passes).
+      for (int pass = 0; pass < 4 && !failed; ++pass) {
         std::vector<int> col_now(p);
         FMX_HIP(hipMemcpy(col_now.data(), w.fixed, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));
         int top = -1;
