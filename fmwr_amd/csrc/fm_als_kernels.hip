@@ -718,21 +718,28 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
     // Falls through to the exact schedule below where it does not apply (a column too long for one wave per feature, more colours than the kernel's set).
     std::vector<int64_t> cph((size_t)p + 1);
     FMX_HIP(hipMemcpy(cph.data(), m->col_ptr, cph.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> act;
-    bool too_long = false;
+    // Columns too long for one wave per feature (the heads of a skewed distribution: they meet almost every row, and each other) take a colour of their own each,
+    // first, in index order -- an exact pass over the heavy features, as the approximate form orders them -- and the light features colour around them.
+    std::vector<uint32_t> act, heavy_first;
     for (uint32_t j = 0; j < p; ++j) {
       const int64_t len = cph[(size_t)j + 1] - cph[(size_t)j];
-      if (len > 0) act.push_back(j);
-      if (len > LEVEL_HEAVY) too_long = true;
+      if (len > LEVEL_HEAVY) heavy_first.push_back(j);
+      else if (len > 0) act.push_back(j);
     }
-    if (!too_long && !act.empty()) {
+    const bool too_long = heavy_first.size() > (size_t)COLOUR_MAX / 2;
+    if (!too_long && !(act.empty() && heavy_first.empty())) {
       struct Tmp {
         int *fixed = nullptr, *chosen = nullptr, *lose = nullptr, *overflow = nullptr; uint32_t* act = nullptr;
         ~Tmp() { (void)hipFree(fixed); (void)hipFree(chosen); (void)hipFree(lose); (void)hipFree(overflow); (void)hipFree(act); }
       } w;
-      FMX_HIP(hipMalloc(&w.fixed, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.chosen, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.lose, act.size() * sizeof(int)));
-      FMX_HIP(hipMalloc(&w.overflow, sizeof(int))); FMX_HIP(hipMalloc(&w.act, act.size() * sizeof(uint32_t)));
-      FMX_HIP(hipMemsetAsync(w.fixed, 0xFF, (size_t)p * sizeof(int), stream));
+      const size_t n_occ = act.size() + heavy_first.size();
+      FMX_HIP(hipMalloc(&w.fixed, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.chosen, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.lose, (n_occ ? n_occ : 1) * sizeof(int)));
+      FMX_HIP(hipMalloc(&w.overflow, sizeof(int))); FMX_HIP(hipMalloc(&w.act, (n_occ ? n_occ : 1) * sizeof(uint32_t)));
+      {
+        std::vector<int> init(p, -1);
+        for (size_t i = 0; i < heavy_first.size(); ++i) init[heavy_first[i]] = (int)i;
+        FMX_HIP(hipMemcpy(w.fixed, init.data(), (size_t)p * sizeof(int), hipMemcpyHostToDevice));
+      }
       FMX_HIP(hipMemsetAsync(w.chosen, 0xFF, (size_t)p * sizeof(int), stream));
       FMX_HIP(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
       std::vector<int> h_lose;
@@ -768,7 +775,7 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
         int top = -1;
         for (uint32_t j = 0; j < p; ++j) if (col_now[j] > top) top = col_now[j];
         std::vector<std::vector<uint32_t>> cls((size_t)(top + 1));
-        for (uint32_t j = 0; j < p; ++j) if (col_now[j] >= 0) cls[(size_t)col_now[j]].push_back(j);
+        for (uint32_t j = 0; j < p; ++j) if (col_now[j] >= 0 && cph[(size_t)j + 1] - cph[(size_t)j] <= LEVEL_HEAVY) cls[(size_t)col_now[j]].push_back(j);   // (the heavy features keep their own colours)
         std::vector<uint32_t> flat; std::vector<size_t> at((size_t)top + 2, 0);
         for (int c = 0; c <= top; ++c) { at[(size_t)c] = flat.size(); flat.insert(flat.end(), cls[(size_t)c].begin(), cls[(size_t)c].end()); }
         at[(size_t)top + 1] = flat.size();

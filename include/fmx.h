@@ -125,7 +125,8 @@ typedef struct fmx_config {
                               sampler, but the numbers are not the reference's on the same inputs -- they are the reference's on
                               the matrix with its features relabelled in that order (fmx_als_plan_info's level_of gives it;
                               tests/test_gpu_coloured.py checks exactly that against the oracle).  i.i.d. columns at 10 M x 1 M:
-                              ~1 200 levels instead of 19 399.  Columns of more than 16 384 entries keep the exact schedule.   */
+                              ~1 200 levels instead of 19 399.  Columns of more than 16 384 entries (the heads of a skewed
+                              distribution) take a colour of their own each, first, in index order.                          */
   int32_t reserved0;
   int32_t gpus_share_device; /* 1: all N replicas live on `device` and exchange through a device kernel instead of RCCL
                               (rehearsals and tests on a one-GPU box; same sums, same order of ranks)                  */

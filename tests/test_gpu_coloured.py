@@ -77,3 +77,39 @@ def test_coloured_order_leaves_one_column_per_field_data_alone():
     levels, _, _, level_of = e.als_plan(m)
     assert levels <= 2 * Z and e.als_plan_kind(m) == 2
     e.close(); m.close()
+
+
+def test_coloured_sweep_on_zipf_columns_with_heavy_heads():
+    """Zipf(1.05) columns: the heads' columns (more than 16 384 entries) take a colour of their own each, first, in index order; the light features colour around
+    them.  Against the oracle on the relabelled matrix, as above."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k = 150_000, 20_000, 4
+    m0 = engine.Matrix.synthetic_iid(n, p, Z, 93, law=L.COLUMNS_ZIPF, zipf_s=1.05)
+    rp, col, val, _ = m0.export(); m0.close()
+    counts = np.bincount(col, minlength=p)
+    assert (counts > 16_384).sum() >= 2                      # there ARE heavy heads
+    y = util.labels(n, 93, "regression")
+    w0, w, v = util.params(p, k, 67, stdev=0.05, fp32=False)
+    lam = np.linspace(0.5, 1.0, k); mu = np.zeros(k)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-1)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    levels, _, _, level_of = e.als_plan(m)
+    level_of = level_of.copy()
+    assert e.als_plan_kind(m) == 2
+    heavy = np.flatnonzero(counts > 16_384)
+    assert np.array_equal(level_of[heavy], np.arange(len(heavy)))   # one colour each, first, in index order
+    lv = level_of[col].reshape(n, Z)
+    srt = np.sort(lv, axis=1)
+    assert np.all(srt[:, 1:] != srt[:, :-1])                 # proper
+    order = np.lexsort((np.arange(p), level_of))
+    rank = np.empty(p, np.int64); rank[order] = np.arange(p)
+    rp2, col2, val2 = _relabel(rp, col, val, rank)
+    X = oracle.Matrix(rp, col, val, p); X2 = oracle.Matrix(rp2, col2, val2, p)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    rv2, rerr, _ = oracle.als_update_v(k, X2, np.ascontiguousarray(v[:, order]).ravel(), err0, alpha=1.0, v_lambda=lam, v_mu=mu)
+    rv = np.empty_like(v); rv[:, order] = rv2.reshape(k, p)
+    gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam, v_mu=mu)
+    assert util.rel_err(e.get_params()[2], rv) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
+    e.close(); m.close()
