@@ -6,8 +6,9 @@ sys.path.insert(0, ".")
 from fmwr_amd import _lib as L, engine
 from tests import util
 N, P, Z, K, SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 1_000_000, 30, 16, 20240001
-for cap in (0, 64, -1):
-    m = engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_UNIFORM)
+ZIPF = len(sys.argv) > 2 and sys.argv[2] == "zipf"
+for cap in ((0, -1) if ZIPF else (0, 64, -1)):
+    m = engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_ZIPF if ZIPF else L.COLUMNS_UNIFORM, zipf_s=1.05)
     e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=cap)
     e.init_normal(SEED, 0.0, 0.01)
     t = time.perf_counter(); levels, largest, approx, _ = e.als_plan(m); tp = time.perf_counter() - t
