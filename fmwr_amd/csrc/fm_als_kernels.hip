@@ -113,6 +113,105 @@ __global__ __launch_bounds__(WG_THREADS) void level_heavy_k(const uint32_t* __re
   if (threadIdx.x == 0 && atomicAdd(done_flag, 1) == (int)gridDim.x - 1) { *n_heavy = 0; *done_flag = 0; }
 }
 
+// ---- the FEATURE-MAJOR coloured order (cfg.als_max_levels = -2) ----------------------------------------------------------------------------
+// als_level_k steps ONE factor of a level's features: per entry a random 16-byte gather and scatter of the row's (q_f, e) -- a whole line moved each way for 16 bytes
+// used, k times per sweep.  A sweep that chooses its own order may as well step ALL k factors of a feature while its rows are on the chip: the order becomes (colour,
+// feature, factor) -- still one exact coordinate step after the other -- and a row's state, e and the k values q_f = (X v_f)_r, kept together ([n][kp] doubles: one
+// 128-byte line at k = 16, next to the pair that holds e), is fetched ONCE per level the row takes part in instead of once per level and factor.
+// One workgroup per feature: its rows' q lines (8 lanes per row: whole lines), e and x land in LDS; then for f = 0 .. k - 1 every thread forms h for its rows
+// (:310-317), the block adds (waves in order: reproducible), every thread takes the step from the same sums (:318-336) and corrects its rows' e (registers) and q_f
+// (LDS) (:341-350); the lines go back.  Lists of up to `cap` rows (the level's longest, set by the launcher; the LDS holds cap x (kp + 1) doubles + cap words).
+__device__ __forceinline__ bool bad_number(double x);
+template <bool UNIT>
+__global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
+                                                               const float* __restrict__ cval, double* __restrict__ V, int k, int kp, double alpha, const double* __restrict__ lam_mu,
+                                                               const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe, int cap) {
+  extern __shared__ double lds_allf[];
+  const int qs = kp + 1;                                  // row stride of the q slab (odd: the threads of a wave read different banks)
+  double* sQ = lds_allf;                                  // [cap][qs]
+  uint32_t* sRow = reinterpret_cast<uint32_t*>(sQ + (size_t)cap * qs);   // [cap]
+  __shared__ double red[2][WG_THREADS / 64][2];           // (two sets, used alternately: ONE barrier per factor)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if ((int)blockIdx.x >= n_feats) return;
+  const uint32_t j = feats[blockIdx.x];
+  const int64_t b = col_ptr[j];
+  const int len = (int)(col_ptr[j + 1] - b);
+  constexpr int RPT = 4;                                  // rows per thread (cap <= RPT x 256): their e, x and h stay in registers
+  double er[RPT]; float xr[RPT]; uint32_t rr[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int i = tid + u * WG_THREADS;
+    const int64_t tc = i < len ? b + i : 0;               // (a slot past the list: entry 0 of the matrix, read and never used -- a feature without rows still takes its step)
+    rr[u] = crow[tc];
+    xr[u] = UNIT ? 1.0f : cval[tc];
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) er[u] = qe[rr[u]].y;
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len) sRow[i] = rr[u]; }
+  __syncthreads();
+  const int LQ = kp >> 1;                                 // lanes per row: each takes two factors (16 bytes) of the row's line
+  const int rpp = WG_THREADS / LQ;                        // rows per pass
+  const int grow = tid / LQ, part = tid % LQ;
+  for (int i0 = 0; i0 < len; i0 += 4 * rpp) {             // four passes' loads in flight
+    double2 v2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * rpp + grow, ic = (i < len && grow < rpp) ? i : 0;
+      v2[q] = *reinterpret_cast<const double2*>(Q + (size_t)sRow[ic] * kp + 2 * part);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * rpp + grow;
+      if (i < len && grow < rpp) { sQ[(size_t)i * qs + 2 * part] = v2[q].x; sQ[(size_t)i * qs + 2 * part + 1] = v2[q].y; }
+    }
+  }
+  __syncthreads();
+  for (int f = 0; f < k; ++f) {
+    const double old = V[(size_t)j * kp + f];             // (every thread the same word; thread 0 stores the new value only behind the barrier below)
+    double mean = 0.0, var = 0.0, hk[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int i = tid + u * WG_THREADS;
+      hk[u] = 0.0;
+      if (i < len) {
+        const float x = xr[u], xx = x * x;
+        const double h = (double)x * sQ[(size_t)i * qs + f] - (double)xx * old;   // :310-317
+        hk[u] = h; mean += h * er[u]; var += h * h;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }
+    if (lane == 0) { red[f & 1][wv][0] = mean; red[f & 1][wv][1] = var; }
+    __syncthreads();
+    // every thread takes the step itself from the same four pairs (the same bits): no second barrier to hand the result round
+    double m = 0.0, vr = 0.0;
+#pragma unroll
+    for (int w = 0; w < WG_THREADS / 64; ++w) { m += red[f & 1][w][0]; vr += red[f & 1][w][1]; }
+    const double lambda = lam_mu[2 * f], mu = lam_mu[2 * f + 1];
+    m -= old * vr;                                         // :318
+    vr = 1.0 / (lambda + alpha * vr);                      // :319
+    m = -vr * (alpha * m - mu * lambda);                   // :320
+    const double nv = bad_number(vr) ? 0.0 : (znorm ? m + sqrt(vr) * znorm[(size_t)f * zstride + j] : m);
+    if (bad_number(nv)) continue;                          // CHECK_PARAM (:336): keep the old value, skip the corrections (uniform: no barrier is skipped)
+    if (tid == 0) V[(size_t)j * kp + f] = nv;
+    const double diff = old - nv;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int i = tid + u * WG_THREADS;
+      if (i < len) { sQ[(size_t)i * qs + f] -= (double)xr[u] * diff; er[u] -= hk[u] * diff; }   // :341-350
+    }
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < len; i0 += rpp) {
+    const int i = i0 + grow;
+    if (i < len && grow < rpp)
+      *reinterpret_cast<double2*>(Q + (size_t)sRow[i] * kp + 2 * part) = make_double2(sQ[(size_t)i * qs + 2 * part], sQ[(size_t)i * qs + 2 * part + 1]);
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len) qe[rr[u]].y = er[u]; }
+}
+
 // ---- the COLOURED order (cfg.als_max_levels < 0) -----------------------------------------------------------------------------------------
 // The exact schedule keeps the reference's feature ORDER: feature j waits for every earlier feature it shares a row with, which on i.i.d. columns is a chain
 // of ~20 000 levels of ~50 features (10 M x 1 M: 310 K dependent launches per sweep of 16 factors: 5 M examples/s, profiles/r05_als_iid_sweep.txt).  A sweep that
@@ -958,6 +1057,9 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
     FMX_HIP(hipMemcpy(m->als_vseg_b, seg_b.data(), seg_b.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     FMX_HIP(hipMemcpy(m->als_vseg_e, seg_e.data(), seg_e.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   }
+  m->als_level_maxlen.assign((size_t)L, 0);
+  for (int l = 0; l < L; ++l)
+    for (uint32_t j : light[(size_t)l]) { const int64_t len = cp[(size_t)j + 1] - cp[(size_t)j]; if (len > m->als_level_maxlen[(size_t)l]) m->als_level_maxlen[(size_t)l] = len; }
   m->als_approx = approx ? 1 : 0;
   m->als_coloured = coloured ? 1 : 0;
   m->als_plan_cap = max_levels;
@@ -1171,6 +1273,49 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
   // row-gather pass (the forward kernel on the fp64 tables) instead of one gather per nonzero per factor.  The n x kp table lives
   // in the engine (grow-only): a sweep allocates nothing once the first one has run.
   double* d_Q = q_table(e, m);
+  // cfg.als_max_levels = -2 on a coloured plan of light lists: the FEATURE-MAJOR order -- all k factors of a feature while its rows' state is in LDS (als_level_allf_k)
+  if (m->als_coloured && m->als_plan_cap == -2 && !d_qe_new && e->k > 0) {
+    bool fits = m->als_heavy_ptr.back() == 0 && (m->als_vh_ptr.empty() || m->als_vh_ptr.back() == 0);
+    int64_t longest = 0;
+    for (int64_t v : m->als_level_maxlen) if (v > longest) longest = v;
+    fits = fits && longest <= 1024;
+    double* d_Qr = fits ? q_table(e, m) : nullptr;
+    if (d_Qr) {
+      RowsArgs a{};
+      a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
+      a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Qr; a.qout_t = 0; a.link = FMX_LINK_NONE;   // q of every factor, ROW-major: [n][kp]
+      a.unit = m->unit_values; a.no_w = 1;
+      e->als_q_have = 0; e->als_q_trusted = 0;
+      if (launch_rows_forward(e, a, false, true) == FMX_OK) {
+        std::vector<double> lm((size_t)2 * e->k, 0.0);
+        for (int f = 0; f < e->k; ++f) { lm[(size_t)2 * f] = h_lambda ? h_lambda[f] : 0.0; lm[(size_t)2 * f + 1] = h_mu ? h_mu[f] : 0.0; }
+        if (!e->als_lam_mu) FMX_HIP(hipMalloc(&e->als_lam_mu, (size_t)2 * 1024 * sizeof(double)));
+        FMX_HIP(hipMemcpyAsync(e->als_lam_mu, lm.data(), lm.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        FMX_HIP(hipStreamSynchronize(e->stream));   // (lm is a local)
+        static bool attr_set = false;
+        if (!attr_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          attr_set = true;
+        }
+        const int L = (int)m->als_level_ptr.size() - 1;
+        for (int l = 0; l < L; ++l) {
+          const int64_t l0 = m->als_level_ptr[(size_t)l], cnt = m->als_level_ptr[(size_t)l + 1] - l0;
+          if (cnt == 0) continue;
+          const int cap = (int)((m->als_level_maxlen[(size_t)l] + 63) / 64 * 64);
+          const size_t lds = (size_t)cap * (e->kp64 + 1) * sizeof(double) + (size_t)cap * sizeof(uint32_t);
+          prof_begin(e, FMX_KERNEL_ALS_SWEEP);
+          if (m->unit_values) hipLaunchKernelGGL((als_level_allf_k<true>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,
+                                                 (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap);
+          else hipLaunchKernelGGL((als_level_allf_k<false>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,
+                                  (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap);
+          prof_end(e);
+        }
+        FMX_HIP(hipGetLastError());
+        return FMX_OK;
+      }
+    }
+  }
   const uint32_t* colP = nullptr; const float* valP = nullptr;
   e->als_q_level0 = 0;
   if (d_Q && !d_qe_new) FMX_TRY(als_order_prepare(e, m, &colP, &valP, nullptr));   // the block form: q in level 0's array order (the forward runs on the permuted CSR)

@@ -633,7 +633,7 @@ int fmx_engine_create(const fmx_config* cfg, uint64_t num_features, fmx_engine**
   FMX_CHECK(cfg->mode == FMX_MODE_SEQUENTIAL || cfg->mode == FMX_MODE_MINIBATCH, FMX_ERR_INVALID, "unknown mode %d", cfg->mode);
   FMX_CHECK(cfg->random_step >= 1, FMX_ERR_INVALID, "random_step must be >= 1");
   FMX_CHECK(cfg->n_gpus >= 0, FMX_ERR_INVALID, "n_gpus must be >= 0");
-  FMX_CHECK(cfg->als_max_levels >= -1, FMX_ERR_INVALID, "als_max_levels must be >= 0, or -1 (the coloured order)");
+  FMX_CHECK(cfg->als_max_levels >= -2, FMX_ERR_INVALID, "als_max_levels must be >= 0, or -1 / -2 (the coloured orders)");
   FMX_CHECK(cfg->batch_reduce == FMX_REDUCE_MEAN || cfg->batch_reduce == FMX_REDUCE_SUM, FMX_ERR_INVALID, "unknown batch_reduce %d", cfg->batch_reduce);
   FMX_CHECK(num_features > 0 && num_features < (1ull << 32), FMX_ERR_INVALID, "number of features must be in 1..2^32-1");
   if (cfg->mode == FMX_MODE_MINIBATCH) FMX_CHECK(cfg->batch_rows >= 1 && cfg->tile_rows >= 0, FMX_ERR_INVALID, "batch_rows must be >= 1 and tile_rows >= 0");
@@ -700,7 +700,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws); (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]); (void)hipFree(e->als_hash_word);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws); (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]); (void)hipFree(e->als_hash_word); (void)hipFree(e->als_lam_mu);
   als_graph_free(e->als_graph_w); als_graph_free(e->als_graph_v);
   if (e->side_fork) (void)hipEventDestroy(e->side_fork);
   if (e->side_join) (void)hipEventDestroy(e->side_join);

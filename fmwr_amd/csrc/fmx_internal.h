@@ -182,6 +182,7 @@ struct fmx_matrix {
   std::vector<int32_t> als_level_of;    // [p] level (exact plan) or group (approximate plan) of every feature
   int als_approx = 0;                   // the plan holds the groups of the approximate sweep, not exact levels
   int als_coloured = 0;                 // the plan's levels are the colours of a colouring: exact steps, the engine's own feature order (cfg.als_max_levels < 0)
+  std::vector<int64_t> als_level_maxlen; // per level: the longest light column (sizes the LDS of the feature-major kernel)
   int als_force_exact = 0;              // an approximate sweep raised the residual on this matrix: only exact plans from now on
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
   void* als_tiled = nullptr;            // row-tiled form of the wide levels of an exact plan (fm_als_tiled.hip: AlsTiled), or null
@@ -294,6 +295,7 @@ struct fmx_engine {
   uint64_t als_q_trusted = 0;      // plan uid: the table was filled a moment ago by the learner's own forward pass (launch_als_train) -- used once, no fingerprint needed
   uint64_t als_q_hash = 0, als_q_plan = 0;
   void* als_hash_word = nullptr;
+  double* als_lam_mu = nullptr;    // (lambda_f, mu_f) of every factor for the feature-major sweep (cfg.als_max_levels = -2)
   const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
                                       // finished factor's q when that level is a tiled one (it then clears this pointer: the pick kernel is not needed)
   int als_vf_slot = -1, als_vf_buf = 0;  // tiled sweep: the tiled level whose coordinates the previous level's step kernel already gathered, and into which half

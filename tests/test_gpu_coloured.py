@@ -113,3 +113,81 @@ def test_coloured_sweep_on_zipf_columns_with_heavy_heads():
     gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam, v_mu=mu)
     assert util.rel_err(e.get_params()[2], rv) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10
     e.close(); m.close()
+
+
+def _numpy_sweep(rp, col, val, p, V, err, alpha, lam, mu, z, coords):
+    """The coordinate steps of MCMC_ALS_Learner::update_v (:283-351; SURVEY Appendix C.4) taken one after the other in the order `coords` gives them -- a plain
+    restatement (one vectorised step per coordinate) that keeps e and EVERY factor's q = X v_f current.  Pinned below against the oracle in the oracle's own order."""
+    n = len(rp) - 1
+    K = V.shape[0]
+    V = V.copy(); e = err.copy()
+    rows_of = np.repeat(np.arange(n), np.diff(rp))
+    order = np.argsort(col, kind="stable")
+    cp = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=p))])
+    crow, cval = rows_of[order], val[order].astype(np.float32)
+    Q = np.zeros((n, K))
+    for f in range(K):
+        np.add.at(Q[:, f], rows_of, val.astype(np.float64) * V[f, col])
+    for j, f in coords:
+        r = crow[cp[j]:cp[j + 1]]; x = cval[cp[j]:cp[j + 1]]
+        xx = (x * x).astype(np.float64); xd = x.astype(np.float64)
+        old = V[f, j]
+        h = xd * Q[r, f] - xx * old
+        mean = float(np.sum(h * e[r])); var = float(np.sum(h * h))
+        mean -= old * var
+        with np.errstate(divide="ignore", invalid="ignore"):
+            var = 1.0 / (lam[f] + alpha * var)
+            mean = -var * (alpha * mean - mu[f] * lam[f])
+            nv = 0.0 if not np.isfinite(var) else (mean + np.sqrt(var) * z[f, j] if z is not None else mean)
+        if not np.isfinite(nv):
+            continue
+        V[f, j] = nv
+        diff = old - nv
+        Q[r, f] -= xd * diff
+        e[r] -= h * diff
+    return V, e
+
+
+@pytest.mark.parametrize("gibbs,values", [(False, "ones"), (True, "normal")])
+def test_feature_major_coloured_sweep(gibbs, values):
+    """cfg.als_max_levels = -2: the coloured order with ALL factors of a feature stepped while its rows' state (e and every q_f) is on the chip -- the coordinates in
+    (colour, feature, factor) order.  Checked against the coordinate-by-coordinate restatement above, which is itself pinned against the oracle in the oracle's order."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k = 6_000, 1_500, 6
+    m0 = engine.Matrix.synthetic_iid(n, p, 20, 95, law=L.COLUMNS_UNIFORM)
+    rp, col, val, _ = m0.export(); m0.close()
+    if values == "normal":
+        val = np.random.default_rng(6).normal(0, 1, len(val)).astype(np.float32)
+    y = util.labels(n, 95, "regression")
+    w0, w, v = util.params(p, k, 71, stdev=0.1, fp32=False)
+    lam = np.linspace(10.0, 20.0, k) if gibbs else np.linspace(0.1, 0.5, k); mu = np.linspace(-0.05, 0.05, k)
+    z = np.random.default_rng(17).normal(0, 1, (k, p)) if gibbs else None
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    # the restatement in the oracle's order (factor outer, feature inner) IS the oracle
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+    nv, ne = _numpy_sweep(rp, col, val, p, v, err0, 1.1, lam, mu, z, [(j, f) for f in range(k) for j in range(p)])
+    assert util.rel_err(nv, rv.reshape(k, p)) < 1e-11 and util.rel_err(ne, rerr) < 1e-11
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    _, _, _, level_of = e.als_plan(m)
+    level_of = level_of.copy()
+    assert e.als_plan_kind(m) == 2
+    order = np.lexsort((np.arange(p), level_of))
+    fv, fe = _numpy_sweep(rp, col, val, p, v, err0, 1.1, lam, mu, z, [(int(j), f) for j in order for f in range(k)])
+    gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    assert util.rel_err(e.get_params()[2], fv) < 1e-10 and util.rel_err(gerr, fe) < 1e-10
+    # a second sweep from there, and reproducibility
+    gerr2 = e.als_vsweep(m, gerr, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    fv2, fe2 = _numpy_sweep(rp, col, val, p, fv, fe, 1.1, lam, mu, z, [(int(j), f) for j in order for f in range(k)])
+    assert util.rel_err(e.get_params()[2], fv2) < 1e-9 and util.rel_err(gerr2, fe2) < 1e-9
+    e2 = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+    e2.set_params(w0, w, v)
+    m2 = engine.Matrix.from_csr(rp, col, val, p, y)
+    g1 = e2.als_vsweep(m2, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    g2 = e2.als_vsweep(m2, g1, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    assert np.array_equal(g1, gerr) and np.array_equal(g2, gerr2) and np.array_equal(e2.get_params()[2], e.get_params()[2])   # bit for bit, run to run
+    for x_ in (e, e2): x_.close()
+    for x_ in (m, m2): x_.close()
