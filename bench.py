@@ -60,7 +60,8 @@ def parse(argv=None):
                          "row (fmx_matrix_synthetic_iid) -- the headline; stratified: one column per stratum of [0, p) (fmx_matrix_synthetic: what rounds 1-4 quoted `value` on, "
                          "kept in the line as `value_stratified_columns`); zipf: SURVEY 8(d)'s conflict-stress variant, exponent 1.05")
     ap.add_argument("--sweep-iid", action="store_true",
-                    help="--solver als / mcmc: the V sweep on SURVEY 8(d)'s i.i.d. uniform columns in the COLOURED order (cfg.als_max_levels = -1); default: one column per stratum")
+                    help="--solver als / mcmc: the V sweep on SURVEY 8(d)'s i.i.d. uniform columns in the feature-major COLOURED order (cfg.als_max_levels = -2); default: one column per stratum")
+    ap.add_argument("--sweep-factor-outer", action="store_true", help="--sweep-iid: the coloured order with the reference's factor-outer nesting (cfg.als_max_levels = -1)")
     ap.add_argument("--real-values", action="store_true", help="SURVEY 8(d)'s value variant: val ~ U(0,1) instead of 1 (fmx_matrix_synthetic_values): the kernels then read the value arrays")
     ap.add_argument("--seed", type=int, default=20240001)
     ap.add_argument("--state-fp64", action="store_true", help="experiment: fp64 parameter/optimizer state (default fp32)")
@@ -626,7 +627,7 @@ def main_sweep(args, rank, local_rank, world):
     if args.real_values:                         # SURVEY 8(d)'s value variant: U(0, 1) instead of the one-hot 1.0 (the sweep kernels then read the value arrays)
         m.synthetic_values(args.seed + 1, row_offset=rank * n)
     e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank,
-                      als_max_levels=-1 if iid else 0)
+                      als_max_levels=(-1 if args.sweep_factor_outer else -2) if iid else 0)
     e.init_normal(args.seed, 0.0, 0.01)          # V0 ~ N(0, 0.01), w0 = w = 0
     t0 = time.perf_counter()
     levels, largest, approx, _ = e.als_plan(m)   # CSC of the whole matrix + the level plan: ingest, outside the timed region
@@ -683,9 +684,15 @@ def main_sweep(args, rank, local_rank, world):
     ordered = bool(tiled) and e.als_level_order(m)
     blocks = ordered and e.als_level_order_form(m) == 2
     b_launch = 40.0 * nnz / levels               # 40 B per stored nonzero per factor; one unit = one level of one factor
+    if iid and not args.sweep_factor_outer:      # the feature-major form: one launch per level does all k factors of its features
+        launches = levels
+        b_launch *= k
     gbs = b_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
     step_gbs = 40.0 * nnz * k / (dt / args.steps) / 1e9
-    form = ("level-order, block form: the level's (q, e) array is feature-block-major (blocks of consecutive features holding at most 8192 rows); ONE kernel per level, "
+    form = (("als_level_k on the colours' levels (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q_f, e) per entry and factor)" if args.sweep_factor_outer else
+             "als_level_allf_k on the colours' levels: one workgroup per feature gathers its rows' state (e and the line of all k values q_f) into LDS, steps the k factors there, writes the lines back")
+            if iid else
+            "level-order, block form: the level's (q, e) array is feature-block-major (blocks of consecutive features holding at most 8192 rows); ONE kernel per level, "
             "als_block_level_pipe_k: a resident workgroup per CU streams a block's pairs into LDS at their feature-sorted slots, sums its lists, takes the coordinate steps "
             "and corrects the pairs there, and stores them as contiguous runs into the next level's blocks while the next block's pairs are already in flight"
             if blocks else
@@ -698,14 +705,15 @@ def main_sweep(args, rank, local_rank, world):
         "metric": f"V-sweep examples/sec, {shape_tag(n, p)} sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
         "value": world * n * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"synthetic {n}x{p}, {z} nnz/row, i.i.d. uniform columns (SURVEY 8(d)'s law): the COLOURED order of the sweep (cfg.als_max_levels = -1: every coordinate step exact, the "
-                                f"features visited in (colour, index) order of a colouring of the share-a-row graph instead of the reference's index order, which is a chain of ~20 000 dependent levels here), "
+        "config": {"workload": (f"synthetic {n}x{p}, {z} nnz/row, i.i.d. uniform columns (SURVEY 8(d)'s law): the COLOURED order of the sweep (cfg.als_max_levels = {-1 if args.sweep_factor_outer else -2}: every coordinate step "
+                                f"exact, the features visited in the order of a colouring of the share-a-row graph instead of the reference's index order, which is a chain of ~20 000 dependent levels here"
+                                + ("" if args.sweep_factor_outer else "; all k factors of a feature are stepped while its rows' state is on the chip: coordinates in (colour, feature, factor) order") + "), "
                                 f"k={k}, {'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns; a step = one sweep of all {k} factors") if iid else
                                f"synthetic {n}x{p}, {z} nnz/row, one column per stratum of [0, p) (fmx_matrix_synthetic: one-column-per-field data, the shape whose exact level "
                                f"schedule is {z} levels; i.i.d. columns need thousands of dependent levels and take the approximate groups instead), k={k}, "
                                f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
                                f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
-                   "levels": levels, "largest_level": largest, "approximate": bool(approx) and not iid, "feature_order": "coloured (exact steps)" if iid else "the reference's", "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
+                   "levels": levels, "largest_level": largest, "approximate": bool(approx) and not iid, "feature_order": ("coloured, factor outer (exact steps)" if args.sweep_factor_outer else "coloured, feature-major (exact steps)") if iid else "the reference's", "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
                    "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
                    "parallelism": f"replicas{world}" if world > 1 else "dp1"},
         "roofline": {"bound": "hbm", "kernel": "one level of one factor: " + form, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
