@@ -690,7 +690,8 @@ def main_sweep(args, rank, local_rank, world):
     gbs = b_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
     step_gbs = 40.0 * nnz * k / (dt / args.steps) / 1e9
     form = (("als_level_k on the colours' levels (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q_f, e) per entry and factor)" if args.sweep_factor_outer else
-             "als_level_allf_k on the colours' levels: one workgroup per feature gathers its rows' state (e and the line of all k values q_f) into LDS, steps the k factors there, writes the lines back")
+             "als_level_allf_wave_k on the colours' levels: ONE WAVE per feature gathers its rows' state (e and the 128-byte line of all k values q_f, 8 lanes per line) into registers, steps the k factors there "
+             "(wave sums by DPP, no barrier), writes the lines back; lists over 384 rows take a 256-thread workgroup (lines in registers to 512 rows, in LDS beyond)")
             if iid else
             "level-order, block form: the level's (q, e) array is feature-block-major (blocks of consecutive features holding at most 8192 rows); ONE kernel per level, "
             "als_block_level_pipe_k: a resident workgroup per CU streams a block's pairs into LDS at their feature-sorted slots, sums its lists, takes the coordinate steps "
@@ -727,7 +728,20 @@ def main_sweep(args, rank, local_rank, world):
         out["roofline"]["traffic"] = tr[0]
         out["roofline"]["traffic_source"] = (f"profiles/{tr[1]}: fabric bytes of one launch by request size (128 x RDREQ_128B + 64 x the other reads + WRITE_SIZE), separate --pmc passes" if blocks else
                                              f"profiles/{tr[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB summed over the launches of one level, separate --pmc passes; upper bound, DESIGN.md section 6")
-    if blocks:
+    if iid and not args.sweep_factor_outer:
+        # what a launch has to move (design bytes), per entry of the level: the row's line of k values in and out (2 x 8 k), e in and out (2 x 8), the row id 4 (+4 value);
+        # on the fabric every line is 128 bytes each way and e costs a whole line in (128) and a 64-byte write out
+        vb = 0 if e_unit(m) else 4
+        design = (nnz / levels) * (16 * k + 16 + 4 + vb)
+        fabric = (nnz / levels) * (2 * max(128, 8 * k) + 128 + 64 + 4 + vb)
+        out["roofline"]["design_bytes_per_launch"] = design
+        out["roofline"]["design_frac"] = design / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if per_launch_ms > 0 else None
+        out["roofline"]["fabric_estimate"] = {"bytes_per_launch": fabric, "achieved": fabric / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else None, "unit": "GB/s",
+                                              "note": "128-byte lines: the q line in and out, the (q, e) pair's line in for the 8 bytes of e, a 64-byte write for them out; a level's ~1 000 features start "
+                                                      "together, so its gathers, its steps and its stores follow each other chip-wide instead of overlapping (profiles/r05_allf_knockouts.txt)"}
+        out["roofline"]["note"] = ("`frac` prices SURVEY 8(d)'s 40 B per nonzero and factor -- what the reference's factor-outer order moves -- against this form's launch, which does all k factors "
+                                   "of its features at once and moves design_bytes_per_launch instead: frac is the contract's figure, design_frac what the kernel's own bytes make of the chip")
+    elif blocks:
         # what the one pass of a level has to move (design bytes): (q, e) 16 in and 16 out, LDS slot 2, slot in destination order 2, position in the next level's array 4 (+4 value)
         vb = 0 if e_unit(m) else 4
         design = (nnz / levels) * (16 + 16 + 2 + 2 + 4 + vb)

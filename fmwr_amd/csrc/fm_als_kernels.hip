@@ -120,16 +120,17 @@ __global__ __launch_bounds__(WG_THREADS) void level_heavy_k(const uint32_t* __re
 // 128-byte line at k = 16, next to the pair that holds e), is fetched ONCE per level the row takes part in instead of once per level and factor.
 // One workgroup per feature: its rows' q lines (8 lanes per row: whole lines), e and x land in LDS; then for f = 0 .. k - 1 every thread forms h for its rows
 // (:310-317), the block adds (waves in order: reproducible), every thread takes the step from the same sums (:318-336) and corrects its rows' e (registers) and q_f
-// (LDS) (:341-350); the lines go back.  Lists of up to `cap` rows (the level's longest, set by the launcher; the LDS holds cap x (kp + 1) doubles + cap words).
+// (LDS) (:341-350); the lines go back.  Lists of up to `cap` rows (the level's longest, set by the launcher; the LDS holds cap x kp + 2 kp doubles + cap words).
 __device__ __forceinline__ bool bad_number(double x);
 template <bool UNIT>
 __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
                                                                const float* __restrict__ cval, double* __restrict__ V, int k, int kp, double alpha, const double* __restrict__ lam_mu,
                                                                const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe, int cap) {
   extern __shared__ double lds_allf[];
-  const int qs = kp + 1;                                  // row stride of the q slab (odd: the threads of a wave read different banks)
-  double* sQ = lds_allf;                                  // [cap][qs]
-  uint32_t* sRow = reinterpret_cast<uint32_t*>(sQ + (size_t)cap * qs);   // [cap]
+  double* sQ = lds_allf;                                  // [kp][cap]: factor-major (a wave's threads read neighbouring rows of one factor: no bank conflicts, no padding)
+  double* sOld = sQ + (size_t)kp * cap;                   // [kp] the feature's coordinates as the level finds them
+  double* sZ = sOld + kp;                                 // [kp] its standard normals (Gibbs)
+  uint32_t* sRow = reinterpret_cast<uint32_t*>(sZ + kp);  // [cap]
   __shared__ double red[2][WG_THREADS / 64][2];           // (two sets, used alternately: ONE barrier per factor)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if ((int)blockIdx.x >= n_feats) return;
@@ -144,6 +145,10 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
     const int64_t tc = i < len ? b + i : 0;               // (a slot past the list: entry 0 of the matrix, read and never used -- a feature without rows still takes its step)
     rr[u] = crow[tc];
     xr[u] = UNIT ? 1.0f : cval[tc];
+  }
+  if (tid < k) {                                          // everything the k steps read from memory goes out now: nothing inside the factor loop waits for a load
+    sOld[tid] = V[(size_t)j * kp + tid];
+    sZ[tid] = znorm ? znorm[(size_t)tid * zstride + j] : 0.0;
   }
 #pragma unroll
   for (int u = 0; u < RPT; ++u) er[u] = qe[rr[u]].y;
@@ -163,12 +168,14 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = i0 + q * rpp + grow;
-      if (i < len && grow < rpp) { sQ[(size_t)i * qs + 2 * part] = v2[q].x; sQ[(size_t)i * qs + 2 * part + 1] = v2[q].y; }
+      if (i < len && grow < rpp) { sQ[(size_t)(2 * part) * cap + i] = v2[q].x; sQ[(size_t)(2 * part + 1) * cap + i] = v2[q].y; }
     }
   }
   __syncthreads();
+  const bool gibbs = znorm != nullptr;
   for (int f = 0; f < k; ++f) {
-    const double old = V[(size_t)j * kp + f];             // (every thread the same word; thread 0 stores the new value only behind the barrier below)
+    const double old = sOld[f];
+    const double* __restrict__ qf = sQ + (size_t)f * cap;
     double mean = 0.0, var = 0.0, hk[RPT];
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
       hk[u] = 0.0;
       if (i < len) {
         const float x = xr[u], xx = x * x;
-        const double h = (double)x * sQ[(size_t)i * qs + f] - (double)xx * old;   // :310-317
+        const double h = (double)x * qf[i] - (double)xx * old;   // :310-317
         hk[u] = h; mean += h * er[u]; var += h * h;
       }
     }
@@ -192,24 +199,264 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
     m -= old * vr;                                         // :318
     vr = 1.0 / (lambda + alpha * vr);                      // :319
     m = -vr * (alpha * m - mu * lambda);                   // :320
-    const double nv = bad_number(vr) ? 0.0 : (znorm ? m + sqrt(vr) * znorm[(size_t)f * zstride + j] : m);
+    const double nv = bad_number(vr) ? 0.0 : (gibbs ? m + sqrt(vr) * sZ[f] : m);
     if (bad_number(nv)) continue;                          // CHECK_PARAM (:336): keep the old value, skip the corrections (uniform: no barrier is skipped)
     if (tid == 0) V[(size_t)j * kp + f] = nv;
     const double diff = old - nv;
+    double* __restrict__ qw = sQ + (size_t)f * cap;
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
       const int i = tid + u * WG_THREADS;
-      if (i < len) { sQ[(size_t)i * qs + f] -= (double)xr[u] * diff; er[u] -= hk[u] * diff; }   // :341-350
+      if (i < len) { qw[i] -= (double)xr[u] * diff; er[u] -= hk[u] * diff; }   // :341-350
     }
   }
   __syncthreads();
   for (int i0 = 0; i0 < len; i0 += rpp) {
     const int i = i0 + grow;
     if (i < len && grow < rpp)
-      *reinterpret_cast<double2*>(Q + (size_t)sRow[i] * kp + 2 * part) = make_double2(sQ[(size_t)i * qs + 2 * part], sQ[(size_t)i * qs + 2 * part + 1]);
+      *reinterpret_cast<double2*>(Q + (size_t)sRow[i] * kp + 2 * part) = make_double2(sQ[(size_t)(2 * part) * cap + i], sQ[(size_t)(2 * part + 1) * cap + i]);
   }
 #pragma unroll
   for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len) qe[rr[u]].y = er[u]; }
+}
+
+// The same level with the rows' lines in REGISTERS (kp = 8 or 16, lists of up to 512 rows): thread t owns rows t and t + 256 -- their q lines (2 x kp doubles), e and x --
+// and the LDS only stages the transposition (lines arrive 8 lanes per row, whole lines; 256 rows x (kp + 1) doubles per pass).  35 KB of LDS and <= 128 registers: FOUR
+// workgroups per CU instead of the three (two, padded) the LDS-resident form fits -- on the i.i.d. law the colour classes hold ~1 000 features (FMX_COLOUR_DEBUG), more
+// than 768 resident workgroups and fewer than 1 024: one round of workgroups per launch instead of two.  Same thread -> row map, same order of every sum as
+// als_level_allf_k: bit for bit its results (tests/test_gpu_coloured.py).
+#ifndef FMX_ALLF_AHEAD
+#define FMX_ALLF_AHEAD 1
+#endif
+#ifndef FMX_ALLF_WPE
+#define FMX_ALLF_WPE 2
+#endif
+#ifndef FMX_ALLF_KO
+#define FMX_ALLF_KO 0   // diagnostic builds (profiles/probes/allf_knockouts.sh): 1 no factor loop, 2 no q lines moved, 4 no e moved
+#endif
+template <bool UNIT, int KP>
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void als_level_allf_reg_k(
+    const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval, double* __restrict__ V, int k,
+    double alpha, const double* __restrict__ lam_mu, const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe) {
+  constexpr int RPT = 2, TS = KP + 1, LQ = KP / 2, RPP = WG_THREADS / LQ, NSUB = WG_THREADS / RPP;   // NSUB = LQ sub-passes of RPP rows cover a pass of 256 rows
+  __shared__ double sT[WG_THREADS * TS];
+  __shared__ double sOld[KP], sZ[KP];
+  __shared__ uint32_t sRow[RPT * WG_THREADS];
+  __shared__ double red[2][WG_THREADS / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if ((int)blockIdx.x >= n_feats) return;
+  const uint32_t j = feats[blockIdx.x];
+  const int64_t b = col_ptr[j];
+  const int len = (int)(col_ptr[j + 1] - b);
+  double er[RPT]; float xr[RPT]; uint32_t rr[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int i = tid + u * WG_THREADS;
+    const int64_t tc = i < len ? b + i : 0;
+    rr[u] = crow[tc];
+    xr[u] = UNIT ? 1.0f : cval[tc];
+  }
+  if (tid < KP) {
+    sOld[tid] = tid < k ? V[(size_t)j * KP + tid] : 0.0;
+    sZ[tid] = (znorm && tid < k) ? znorm[(size_t)tid * zstride + j] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) er[u] = (FMX_ALLF_KO & 4) ? 0.5 : qe[rr[u]].y;
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) sRow[tid + u * WG_THREADS] = rr[u];   // (slots past the list hold entry 0's row: loaded, never stored)
+  __syncthreads();
+  const int grow = tid / LQ, part = tid % LQ;
+  const int npass = len > WG_THREADS ? 2 : 1;
+  double q[RPT][KP];
+  double2 v2[RPT][NSUB];
+#pragma unroll
+  for (int u = 0; u < RPT; ++u)
+    if (u < npass) {
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) v2[u][s] = (FMX_ALLF_KO & 2) ? make_double2(1.0, 2.0) : *reinterpret_cast<const double2*>(Q + (size_t)sRow[u * WG_THREADS + s * RPP + grow] * KP + 2 * part);
+    }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    if (u < npass) {
+      if (u > 0) __syncthreads();
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) { sT[(s * RPP + grow) * TS + 2 * part] = v2[u][s].x; sT[(s * RPP + grow) * TS + 2 * part + 1] = v2[u][s].y; }
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < KP; ++f) q[u][f] = sT[tid * TS + f];
+    } else {
+#pragma unroll
+      for (int f = 0; f < KP; ++f) q[u][f] = 0.0;
+    }
+  }
+  const bool gibbs = znorm != nullptr;
+#pragma unroll
+  for (int f = 0; f < KP; ++f) {
+    if (f < k && !(FMX_ALLF_KO & 1)) {
+      const double old = sOld[f];
+      double mean = 0.0, var = 0.0, hk[RPT];
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int i = tid + u * WG_THREADS;
+        hk[u] = 0.0;
+        if (i < len) {
+          const float x = xr[u], xx = x * x;
+          const double h = (double)x * q[u][f] - (double)xx * old;   // :310-317
+          hk[u] = h; mean += h * er[u]; var += h * h;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mean += __shfl_xor(mean, o); var += __shfl_xor(var, o); }
+      if (lane == 0) { red[f & 1][wv][0] = mean; red[f & 1][wv][1] = var; }
+      __syncthreads();
+      double m = 0.0, vr = 0.0;
+#pragma unroll
+      for (int w = 0; w < WG_THREADS / 64; ++w) { m += red[f & 1][w][0]; vr += red[f & 1][w][1]; }
+      const double lambda = lam_mu[2 * f], mu = lam_mu[2 * f + 1];
+      m -= old * vr;                                         // :318
+      vr = 1.0 / (lambda + alpha * vr);                      // :319
+      m = -vr * (alpha * m - mu * lambda);                   // :320
+      const double nv = bad_number(vr) ? 0.0 : (gibbs ? m + sqrt(vr) * sZ[f] : m);
+      if (!bad_number(nv)) {                                 // CHECK_PARAM (:336)
+        if (tid == 0) V[(size_t)j * KP + f] = nv;
+        const double diff = old - nv;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+          const int i = tid + u * WG_THREADS;
+          if (i < len) { q[u][f] -= (double)xr[u] * diff; er[u] -= hk[u] * diff; }   // :341-350
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    if (u < npass) {
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < KP; ++f) sT[tid * TS + f] = q[u][f];
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        const int i = u * WG_THREADS + s * RPP + grow;
+        if (i < len && (!(FMX_ALLF_KO & 2) || sT[(s * RPP + grow) * TS + 2 * part] == 1e300)) *reinterpret_cast<double2*>(Q + (size_t)sRow[i] * KP + 2 * part) = make_double2(sT[(s * RPP + grow) * TS + 2 * part], sT[(s * RPP + grow) * TS + 2 * part + 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len && (!(FMX_ALLF_KO & 4) || er[u] == 1e300)) qe[rr[u]].y = er[u]; }
+}
+
+// ONE WAVE per feature (kp = 8 or 16, lists of up to 64 x RPT rows, RPT <= 6).  The knock-outs of the 256-thread kernel (profiles/r05_allf_knockouts.txt) put 32 of a
+// level's 48 us in the factor loop: four waves per feature each pay the wave sum, the hand-over through LDS, the barrier and the step (a division and a square
+// root in fp64) -- about 250 instructions per wave and factor, issued by SIMDs that hold four such waves.  A list of 300 rows is five rows per lane of ONE wave:
+// no barrier, no LDS in the loop, one wave sum (row-wise by DPP, the four rows by readlane: every lane ends with the same bits) and one step per factor, a
+// quarter of the instructions; the feature's old coordinates and normals sit in lanes 0 .. kp - 1 and are read by readlane.  Lane t owns rows t, t + 64, ...
+#define FMX_DPP64(x, ctrl) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, false))
+__device__ __forceinline__ double lane_f64(double x, int lane) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane)); }
+__device__ __forceinline__ double wave_allsum(double x) {
+  x += FMX_DPP64(x, 0xB1);    // quad_perm [1,0,3,2]
+  x += FMX_DPP64(x, 0x4E);    // quad_perm [2,3,0,1]
+  x += FMX_DPP64(x, 0x141);   // row_half_mirror: the other quad of the eight
+  x += FMX_DPP64(x, 0x140);   // row_mirror: the other eight of the row of 16
+  return ((lane_f64(x, 0) + lane_f64(x, 16)) + lane_f64(x, 32)) + lane_f64(x, 48);
+}
+template <bool UNIT, int KP, int RPT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMX_ALLF_WPE, FMX_ALLF_WPE))) void als_level_allf_wave_k(
+    const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval, double* __restrict__ V, int k,
+    double alpha, const double* __restrict__ lam_mu, const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe) {
+  constexpr int TS = KP + 1, LQ = KP / 2, RPP = 64 / LQ, NSUB = LQ;   // a pass = 64 rows = NSUB loads of RPP rows (LQ lanes per row, 16 bytes each: whole lines)
+  __shared__ double sT[64 * TS];
+  __shared__ uint32_t sRow[RPT * 64];
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n_feats) return;
+  const uint32_t j = feats[blockIdx.x];
+  const int64_t b = col_ptr[j];
+  const int len = (int)(col_ptr[j + 1] - b);
+  // Slots past the list's end (the launcher sizes RPT for the level's LONGEST list) read entry 0 of the matrix -- one hot line -- and count as rows with x = 0, q = 0,
+  // e = 0: straight-line code, no branch per row anywhere; they are never stored.
+  double er[RPT]; float xr[RPT];
+  {
+    uint32_t rr[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int i = lane + u * 64;
+      const int64_t tc = i < len ? b + i : 0;
+      rr[u] = crow[tc];
+      xr[u] = i < len ? (UNIT ? 1.0f : cval[tc]) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) { const double ev = (FMX_ALLF_KO & 4) ? 0.5 : qe[rr[u]].y; er[u] = lane + u * 64 < len ? ev : 0.0; }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) sRow[lane + u * 64] = rr[u];
+  }
+  const double vold = lane < k ? V[(size_t)j * KP + (lane < KP ? lane : 0)] : 0.0;                        // lane f: the feature's coordinate f as the level finds it
+  const double vz = (znorm && lane < k) ? znorm[(size_t)(lane < KP ? lane : 0) * zstride + j] : 0.0;      //         and its standard normal (Gibbs)
+  const int grow = lane / LQ, part = lane % LQ;
+  double q[RPT][KP];
+  // the passes' gathers run AHEAD of the transposition (the list's lines arrive in RPT dependent round trips otherwise): pass u + AHEAD goes out before pass u is unpacked
+  constexpr int AHEAD = RPT < FMX_ALLF_AHEAD ? RPT : FMX_ALLF_AHEAD;   // (1, 2, 3, 6 ahead: the same sweep time to 3 % -- profiles/r05_allf_knockouts.txt)
+  double2 v2[RPT][NSUB];
+#define FMX_ALLF_ISSUE(u_)                                                                                                                         \
+  _Pragma("unroll") for (int s = 0; s < NSUB; ++s)                                                                                                   \
+    v2[u_][s] = (FMX_ALLF_KO & 2) ? make_double2(1.0, 2.0) : *reinterpret_cast<const double2*>(Q + (size_t)sRow[(u_) * 64 + s * RPP + grow] * KP + 2 * part)
+#pragma unroll
+  for (int u = 0; u < AHEAD; ++u) { FMX_ALLF_ISSUE(u); }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    if (u + AHEAD < RPT) { FMX_ALLF_ISSUE(u + AHEAD); }
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise hoists every pass's gathers to the top: 192 registers of lines in flight beside the 192 they unpack into)
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) { sT[(s * RPP + grow) * TS + 2 * part] = v2[u][s].x; sT[(s * RPP + grow) * TS + 2 * part + 1] = v2[u][s].y; }
+#pragma unroll
+    for (int f = 0; f < KP; ++f) { const double t = sT[lane * TS + f]; q[u][f] = lane + u * 64 < len ? t : 0.0; }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef FMX_ALLF_ISSUE
+  const bool gibbs = znorm != nullptr;
+  double vnew = vold;
+#pragma unroll
+  for (int f = 0; f < KP; ++f) {
+    if (f < k && !(FMX_ALLF_KO & 1)) {
+      const double old = lane_f64(vold, f);
+      double mean = 0.0, var = 0.0;
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const float x = xr[u], xx = x * x;
+        const double h = (double)x * q[u][f] - (double)xx * old;   // :310-317
+        mean += h * er[u]; var += h * h;
+      }
+      double m = wave_allsum(mean), vr = wave_allsum(var);
+      const double lambda = lam_mu[2 * f], mu = lam_mu[2 * f + 1];
+      m -= old * vr;                                         // :318
+      vr = 1.0 / (lambda + alpha * vr);                      // :319
+      m = -vr * (alpha * m - mu * lambda);                   // :320
+      const double nv = bad_number(vr) ? 0.0 : (gibbs ? m + sqrt(vr) * lane_f64(vz, f) : m);
+      if (!bad_number(nv)) {                                 // CHECK_PARAM (:336) -- the same in every lane: a scalar branch
+        if (lane == f) vnew = nv;
+        const double diff = old - nv;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+          const float x = xr[u], xx = x * x;
+          const double h = (double)x * q[u][f] - (double)xx * old;   // (formed again rather than kept: the registers would cost a wave of occupancy)
+          q[u][f] -= (double)x * diff; er[u] -= h * diff;            // :341-350
+        }
+      }
+    }
+  }
+  if (lane < k) V[(size_t)j * KP + lane] = vnew;
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+#pragma unroll
+    for (int f = 0; f < KP; ++f) sT[lane * TS + f] = q[u][f];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const int i = u * 64 + s * RPP + grow;
+      if (i < len && (!(FMX_ALLF_KO & 2) || sT[(s * RPP + grow) * TS + 2 * part] == 1e300))
+        *reinterpret_cast<double2*>(Q + (size_t)sRow[i] * KP + 2 * part) = make_double2(sT[(s * RPP + grow) * TS + 2 * part], sT[(s * RPP + grow) * TS + 2 * part + 1]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) { const int i = lane + u * 64; if (i < len && (!(FMX_ALLF_KO & 4) || er[u] == 1e300)) qe[sRow[i]].y = er[u]; }
 }
 
 // ---- the COLOURED order (cfg.als_max_levels < 0) -----------------------------------------------------------------------------------------
@@ -902,6 +1149,13 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
         for (int c = 0; c < COLOUR_MAX; ++c) if (remap[(size_t)c] == 0) remap[(size_t)c] = nl++;
         for (uint32_t j = 0; j < p; ++j) col_of[j] = col_of[j] >= 0 ? remap[(size_t)col_of[j]] : 0;
         FMX_HIP(hipMemcpy(d_level, col_of.data(), (size_t)p * sizeof(int), hipMemcpyHostToDevice));
+        if (getenv("FMX_COLOUR_DEBUG")) {   // the classes' sizes: a launch of the feature-major form is as long as its rounds of resident workgroups
+          std::vector<int> sz((size_t)(nl > 0 ? nl : 1), 0);
+          for (uint32_t j = 0; j < p; ++j) if (cph[(size_t)j + 1] > cph[(size_t)j]) sz[(size_t)col_of[j]]++;
+          fprintf(stderr, "colour classes (%d):", nl);
+          for (int c = 0; c < nl; c += (nl > 64 ? nl / 64 : 1)) fprintf(stderr, " %d", sz[(size_t)c]);
+          fprintf(stderr, "\n");
+        }
         coloured = true;
       }
     }
@@ -1299,12 +1553,31 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
           attr_set = true;
         }
         const int L = (int)m->als_level_ptr.size() - 1;
+        const char* form_env = getenv("FMX_ALS_ALLF_FORM");   // 1: the LDS-resident kernel everywhere, 2: no one-wave kernel (read per call: the tests compare the forms)
+        const int form = form_env ? atoi(form_env) : 0;
+        const bool in_regs = (e->kp64 == 8 || e->kp64 == 16) && form != 1;
         for (int l = 0; l < L; ++l) {
           const int64_t l0 = m->als_level_ptr[(size_t)l], cnt = m->als_level_ptr[(size_t)l + 1] - l0;
           if (cnt == 0) continue;
           const int cap = (int)((m->als_level_maxlen[(size_t)l] + 63) / 64 * 64);
-          const size_t lds = (size_t)cap * (e->kp64 + 1) * sizeof(double) + (size_t)cap * sizeof(uint32_t);
+          const size_t lds = ((size_t)cap * e->kp64 + 2 * (size_t)e->kp64) * sizeof(double) + (size_t)cap * sizeof(uint32_t);
           prof_begin(e, FMX_KERNEL_ALS_SWEEP);
+          if (in_regs && form != 2 && cap <= 384) {   // one wave per feature
+#define FMX_ALLF_WAVE(U, KPv, R) hipLaunchKernelGGL((als_level_allf_wave_k<U, KPv, R>), dim3((unsigned)cnt), dim3(64), 0, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, \
+                                 (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe)
+#define FMX_ALLF_WAVE_R(U, KPv) do { if (cap <= 128) FMX_ALLF_WAVE(U, KPv, 2); else if (cap <= 256) FMX_ALLF_WAVE(U, KPv, 4); else FMX_ALLF_WAVE(U, KPv, 6); } while (0)
+            if (e->kp64 == 16) { if (m->unit_values) FMX_ALLF_WAVE_R(true, 16); else FMX_ALLF_WAVE_R(false, 16); }
+            else { if (m->unit_values) FMX_ALLF_WAVE_R(true, 8); else FMX_ALLF_WAVE_R(false, 8); }
+#undef FMX_ALLF_WAVE_R
+#undef FMX_ALLF_WAVE
+          } else
+          if (in_regs && m->als_level_maxlen[(size_t)l] <= 512) {   // the rows' lines in registers: four workgroups per CU
+#define FMX_ALLF_REG(U, KPv) hipLaunchKernelGGL((als_level_allf_reg_k<U, KPv>), dim3((unsigned)cnt), dim3(WG_THREADS), 0, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, \
+                             (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe)
+            if (e->kp64 == 16) { if (m->unit_values) FMX_ALLF_REG(true, 16); else FMX_ALLF_REG(false, 16); }
+            else { if (m->unit_values) FMX_ALLF_REG(true, 8); else FMX_ALLF_REG(false, 8); }
+#undef FMX_ALLF_REG
+          } else
           if (m->unit_values) hipLaunchKernelGGL((als_level_allf_k<true>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,
                                                  (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap);
           else hipLaunchKernelGGL((als_level_allf_k<false>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,

@@ -191,3 +191,46 @@ def test_feature_major_coloured_sweep(gibbs, values):
     assert np.array_equal(g1, gerr) and np.array_equal(g2, gerr2) and np.array_equal(e2.get_params()[2], e.get_params()[2])   # bit for bit, run to run
     for x_ in (e, e2): x_.close()
     for x_ in (m, m2): x_.close()
+
+
+@pytest.mark.parametrize("n,p,k,rows", [(12_000, 600, 16, "384 < rows <= 512: the 256-thread register kernel"), (12_000, 300, 16, "rows > 512: the LDS-resident kernel"),
+                                        (9_000, 2_000, 8, "lists of ~90 rows, k = kp = 8: one wave, two rows per lane"), (9_000, 700, 11, "~260 rows, k < kp = 16: one wave, six rows per lane"),
+                                        (9_000, 1_000, 16, "~180 rows: one wave, four rows per lane")])
+def test_feature_major_kernel_forms(n, p, k, rows, monkeypatch):
+    """The feature-major level runs as one WAVE per feature where a list fits its registers (kp 8 or 16, up to 384 rows: als_level_allf_wave_k), as a 256-thread
+    workgroup with the lines in registers up to 512 rows (als_level_allf_reg_k) and with the lines in LDS beyond (als_level_allf_k).  The two workgroup forms share the
+    thread -> row map and the order of every sum: bit for bit equal.  The one-wave form adds in its own order: equal to rounding, and to the restatement."""
+    from fmwr_amd import _lib as L, engine
+    m0 = engine.Matrix.synthetic_iid(n, p, 20, 314, law=L.COLUMNS_UNIFORM)
+    rp, col, val, _ = m0.export(); m0.close()
+    val = np.random.default_rng(8).uniform(0.2, 1.0, len(val)).astype(np.float32)
+    y = util.labels(n, 314, "regression")
+    w0, w, v = util.params(p, k, 72, stdev=0.1, fp32=False)
+    lam = np.linspace(10.0, 20.0, k); mu = np.linspace(-0.05, 0.05, k)
+    z = np.random.default_rng(18).normal(0, 1, (k, p))
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(oracle.params(task=oracle.REGRESSION, k=k), X, w0, w, v.ravel()) - y
+    out = {}
+    for form in ("0", "0", "1", "2"):
+        monkeypatch.setenv("FMX_ALS_ALLF_FORM", form)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        _, _, _, level_of = e.als_plan(m)
+        level_of = level_of.copy()
+        assert e.als_plan_kind(m) == 2
+        g1 = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+        g2 = e.als_vsweep(m, g1, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+        res = (g1, g2, e.get_params()[2].copy())
+        if form in out:
+            for a, b in zip(out[form], res):
+                assert np.array_equal(a, b)            # run to run: bit for bit
+        out[form] = res
+        e.close(); m.close()
+    for a, b in zip(out["1"], out["2"]):
+        assert np.array_equal(a, b)
+    for a, b in zip(out["0"], out["1"]):
+        assert util.rel_err(a, b) < 1e-10
+    order = np.lexsort((np.arange(p), level_of))
+    fv, fe = _numpy_sweep(rp, col, val, p, v, err0, 1.1, lam, mu, z, [(int(j), f) for j in order for f in range(k)])
+    assert util.rel_err(out["0"][0], fe) < 1e-10
