@@ -126,7 +126,17 @@ typedef struct fmx_config {
                               the matrix with its features relabelled in that order (fmx_als_plan_info's level_of gives it;
                               tests/test_gpu_coloured.py checks exactly that against the oracle).  i.i.d. columns at 10 M x 1 M:
                               ~1 200 levels instead of 19 399.  Columns of more than 16 384 entries (the heads of a skewed
-                              distribution) take a colour of their own each, first, in index order.                          */
+                              distribution) take a colour of their own each, first, in index order.
+                              -2: the coloured order, FEATURE-MAJOR.  Same colouring, but all k factors of a feature are stepped
+                              while its rows' state is on the chip: the coordinates in (colour, feature, factor) order instead of
+                              the reference's factor-outer nesting (every step still exact).  A row's q_f = (X v_f)_r for all f
+                              lie together ([n][kp] doubles: one 128-byte line at k = 16) and move once per level the row takes
+                              part in instead of once per level and factor.  Levels whose lists are of up to 384 rows (kp = 8 or
+                              16) run as ONE WAVE per feature with the lines in registers, up to 512 rows as a 256-thread
+                              workgroup, up to 1 024 with the lines in LDS; a plan with longer or heavy lists runs as -1.
+                              i.i.d. columns at 10 M x 1 M, k = 16: 213 M examples/s per ALS sweep, 206 M Gibbs (-1: 42.6 /
+                              36.7 M; the reference's order: 5.0 M).  tests/test_gpu_coloured.py checks it coordinate by
+                              coordinate against a restatement that is itself pinned to the oracle.                          */
   int32_t reserved0;
   int32_t gpus_share_device; /* 1: all N replicas live on `device` and exchange through a device kernel instead of RCCL
                               (rehearsals and tests on a one-GPU box; same sums, same order of ranks)                  */
@@ -431,7 +441,7 @@ int fmx_vsweep_device(fmx_engine* e, fmx_matrix* m, void* dev_error_f64, double 
 
 /* The exact sweeps process the features in LEVELS (features of a level share no row, levels in ascending order reproduce the
  * reference's index-order Gauss-Seidel): how many levels (or, with cfg.als_max_levels exceeded, groups of the approximate
- * form: `approximate` = 1; with cfg.als_max_levels = -1, colours of the coloured order: `approximate` = 2) this matrix needs, the size of the largest, and every
+ * form: `approximate` = 1; with cfg.als_max_levels = -1 or -2, colours of the coloured order: `approximate` = 2) this matrix needs, the size of the largest, and every
  * feature's level / group / colour. */
 int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level, int32_t* approximate,
                       int32_t* level_of_feature /* [p] or NULL */);
