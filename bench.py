@@ -61,6 +61,7 @@ def parse(argv=None):
                          "kept in the line as `value_stratified_columns`); zipf: SURVEY 8(d)'s conflict-stress variant, exponent 1.05")
     ap.add_argument("--sweep-iid", action="store_true",
                     help="--solver als / mcmc: the V sweep on SURVEY 8(d)'s i.i.d. uniform columns in the feature-major COLOURED order (cfg.als_max_levels = -2); default: one column per stratum")
+    ap.add_argument("--sweep-feature-major", action="store_true", help="--solver als / mcmc on the default one-column-per-stratum matrix: cfg.als_max_levels = -2 (the exact schedule's levels as colours, all k factors of a feature stepped together)")
     ap.add_argument("--sweep-factor-outer", action="store_true", help="--sweep-iid: the coloured order with the reference's factor-outer nesting (cfg.als_max_levels = -1)")
     ap.add_argument("--real-values", action="store_true", help="SURVEY 8(d)'s value variant: val ~ U(0,1) instead of 1 (fmx_matrix_synthetic_values): the kernels then read the value arrays")
     ap.add_argument("--seed", type=int, default=20240001)
@@ -620,6 +621,7 @@ def main_sweep(args, rank, local_rank, world):
     gibbs = args.solver == "mcmc"
     dev = torch.device("cuda", local_rank)
     iid = bool(args.sweep_iid)
+    fmajor = (iid and not args.sweep_factor_outer) or bool(args.sweep_feature_major)   # cfg.als_max_levels = -2
     if iid:   # SURVEY 8(d)'s i.i.d. law: no field structure -- the reference's feature order is a chain of ~20 000 levels there; the coloured order (exact steps, the engine's own order) is what is timed
         m = engine.Matrix.synthetic_iid(n, p, z, args.seed, law=L.COLUMNS_UNIFORM, row_offset=rank * n, device=local_rank)
     else:
@@ -627,7 +629,7 @@ def main_sweep(args, rank, local_rank, world):
     if args.real_values:                         # SURVEY 8(d)'s value variant: U(0, 1) instead of the one-hot 1.0 (the sweep kernels then read the value arrays)
         m.synthetic_values(args.seed + 1, row_offset=rank * n)
     e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank,
-                      als_max_levels=(-1 if args.sweep_factor_outer else -2) if iid else 0)
+                      als_max_levels=-2 if fmajor else -1 if iid else 0)
     e.init_normal(args.seed, 0.0, 0.01)          # V0 ~ N(0, 0.01), w0 = w = 0
     t0 = time.perf_counter()
     levels, largest, approx, _ = e.als_plan(m)   # CSC of the whole matrix + the level plan: ingest, outside the timed region
@@ -684,7 +686,7 @@ def main_sweep(args, rank, local_rank, world):
     ordered = bool(tiled) and e.als_level_order(m)
     blocks = ordered and e.als_level_order_form(m) == 2
     b_launch = 40.0 * nnz / levels               # 40 B per stored nonzero per factor; one unit = one level of one factor
-    if iid and not args.sweep_factor_outer:      # the feature-major form: one launch per level does all k factors of its features
+    if fmajor:                                   # the feature-major form: one launch per level does all k factors of its features
         launches = levels
         b_launch *= k
     gbs = b_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
@@ -692,7 +694,7 @@ def main_sweep(args, rank, local_rank, world):
     form = (("als_level_k on the colours' levels (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q_f, e) per entry and factor)" if args.sweep_factor_outer else
              "als_level_allf_wave_k on the colours' levels: ONE WAVE per feature gathers its rows' state (e and the 128-byte line of all k values q_f, 8 lanes per line) into registers, steps the k factors there "
              "(wave sums by DPP, no barrier), writes the lines back; lists over 384 rows take a 256-thread workgroup (lines in registers to 512 rows, in LDS beyond)")
-            if iid else
+            if iid or fmajor else
             "level-order, block form: the level's (q, e) array is feature-block-major (blocks of consecutive features holding at most 8192 rows); ONE kernel per level, "
             "als_block_level_pipe_k: a resident workgroup per CU streams a block's pairs into LDS at their feature-sorted slots, sums its lists, takes the coordinate steps "
             "and corrects the pairs there, and stores them as contiguous runs into the next level's blocks while the next block's pairs are already in flight"
@@ -710,11 +712,15 @@ def main_sweep(args, rank, local_rank, world):
                                 f"exact, the features visited in the order of a colouring of the share-a-row graph instead of the reference's index order, which is a chain of ~20 000 dependent levels here"
                                 + ("" if args.sweep_factor_outer else "; all k factors of a feature are stepped while its rows' state is on the chip: coordinates in (colour, feature, factor) order") + "), "
                                 f"k={k}, {'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns; a step = one sweep of all {k} factors") if iid else
+                               f"synthetic {n}x{p}, {z} nnz/row, one column per stratum of [0, p) (fmx_matrix_synthetic): cfg.als_max_levels = -2 -- the exact schedule's {z} levels serve as the colours "
+                               f"(the reference's own feature order) and all k factors of a feature are stepped while its rows' state is on the chip: coordinates in (level, feature, factor) order instead of the "
+                               f"reference's factor-outer nesting; every step exact, NOT the reference's numbers (configs[4] proper is the line without this flag), k={k}, "
+                               f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns; a step = one sweep of all {k} factors" if fmajor else
                                f"synthetic {n}x{p}, {z} nnz/row, one column per stratum of [0, p) (fmx_matrix_synthetic: one-column-per-field data, the shape whose exact level "
                                f"schedule is {z} levels; i.i.d. columns need thousands of dependent levels and take the approximate groups instead), k={k}, "
                                f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
                                f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
-                   "levels": levels, "largest_level": largest, "approximate": bool(approx) and not iid, "feature_order": ("coloured, factor outer (exact steps)" if args.sweep_factor_outer else "coloured, feature-major (exact steps)") if iid else "the reference's", "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
+                   "levels": levels, "largest_level": largest, "approximate": bool(approx) and not (iid or fmajor), "feature_order": ("coloured, factor outer (exact steps)" if args.sweep_factor_outer else "coloured, feature-major (exact steps)") if iid else "the reference's feature order, all k factors of a feature together (exact steps; the reference nests factor outer)" if fmajor else "the reference's", "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
                    "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
                    "parallelism": f"replicas{world}" if world > 1 else "dp1"},
         "roofline": {"bound": "hbm", "kernel": "one level of one factor: " + form, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -728,7 +734,7 @@ def main_sweep(args, rank, local_rank, world):
         out["roofline"]["traffic"] = tr[0]
         out["roofline"]["traffic_source"] = (f"profiles/{tr[1]}: fabric bytes of one launch by request size (128 x RDREQ_128B + 64 x the other reads + WRITE_SIZE), separate --pmc passes" if blocks else
                                              f"profiles/{tr[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB summed over the launches of one level, separate --pmc passes; upper bound, DESIGN.md section 6")
-    if iid and not args.sweep_factor_outer:
+    if fmajor:
         # what a launch has to move (design bytes), per entry of the level: the row's line of k values in and out (2 x 8 k), e in and out (2 x 8), the row id 4 (+4 value);
         # on the fabric every line is 128 bytes each way and e costs a whole line in (128) and a 64-byte write out
         vb = 0 if e_unit(m) else 4
@@ -1004,6 +1010,7 @@ def other_configs(args):
         ("configs[3]_streamed", ["--workload", "criteo", "--stream", "--steps", "30", "--warmup", "3"], main_stream),
         ("configs[4]", ["--solver", "mcmc", "--no-extras", "--steps", "4", "--warmup", "1", "--cpu-rows", "2000000"], main_sweep),
         ("configs[4]_iid_columns", ["--solver", "mcmc", "--sweep-iid", "--no-extras", "--steps", "2", "--warmup", "1", "--cpu-rows", "0"], main_sweep),
+        ("configs[4]_feature_major", ["--solver", "mcmc", "--sweep-feature-major", "--no-extras", "--steps", "2", "--warmup", "1", "--cpu-rows", "0"], main_sweep),
     ]
     for name, argv, fn in runs:
         t0 = time.perf_counter()

@@ -1059,9 +1059,71 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   FMX_HIP(hipMemsetAsync(d_level, 0, (size_t)p * sizeof(int), stream));  // features that never occur stay at level 0
   bool approx = false;
   bool coloured = false;
+  // the exact schedule by a frontier walk; cap > 0: give up after cap (+ one batch of) rounds -- a deep chain
+  auto frontier_walk = [&](int cap, bool& gave_up) -> int {
+    // frontier walk: rounds are enqueued CHECK at a time (an empty frontier makes a round a no-op), then the number of features
+    // placed so far is read back; done when every occurring feature has its level
+    struct Tmp {
+      int *pos = nullptr, *ready = nullptr, *cnt = nullptr;
+      uint32_t *f0 = nullptr, *f1 = nullptr, *heavy = nullptr;
+      unsigned long long* assigned = nullptr;
+      ~Tmp() { (void)hipFree(pos); (void)hipFree(ready); (void)hipFree(cnt); (void)hipFree(f0); (void)hipFree(f1); (void)hipFree(assigned); (void)hipFree(heavy); }
+    } w;
+    FMX_HIP(hipMalloc(&w.pos, (size_t)m->n * sizeof(int)));
+    FMX_HIP(hipMalloc(&w.ready, (size_t)p * sizeof(int)));
+    FMX_HIP(hipMalloc(&w.cnt, 5 * sizeof(int)));  // three rotating frontier counts, the heavy list's count, its done flag
+    FMX_HIP(hipMalloc(&w.f0, (size_t)p * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&w.f1, (size_t)p * sizeof(uint32_t)));
+    FMX_HIP(hipMalloc(&w.assigned, sizeof(unsigned long long)));
+    FMX_HIP(hipMemsetAsync(w.pos, 0, (size_t)m->n * sizeof(int), stream));
+    FMX_HIP(hipMemsetAsync(w.ready, 0, (size_t)p * sizeof(int), stream));
+    FMX_HIP(hipMemsetAsync(w.cnt, 0, 5 * sizeof(int), stream));
+    FMX_HIP(hipMemsetAsync(w.assigned, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(level_heads_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->n, m->col_ptr, w.ready, w.f0, w.cnt);
+    std::vector<int64_t> cph((size_t)p + 1);
+    FMX_HIP(hipMemcpyAsync(cph.data(), m->col_ptr, cph.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    FMX_HIP(hipStreamSynchronize(stream));
+    unsigned long long occurring = 0, n_heavy = 0;
+    for (uint32_t j = 0; j < p; ++j) {
+      occurring += cph[(size_t)j + 1] > cph[(size_t)j] ? 1 : 0;
+      n_heavy += cph[(size_t)j + 1] - cph[(size_t)j] > LEVEL_HEAVY ? 1 : 0;
+    }
+    FMX_HIP(hipMalloc(&w.heavy, (n_heavy ? n_heavy : 1) * sizeof(uint32_t)));
+    const int CHECK = 64;
+    int round = 0;
+    for (;;) {
+      for (int q = 0; q < CHECK; ++q, ++round)
+      {
+        hipLaunchKernelGGL(level_round_k, dim3(512), dim3(WG_THREADS), 0, stream, round % 2 ? w.f1 : w.f0, round % 2 ? w.f0 : w.f1, w.cnt, round, m->row_ptr, m->col,
+                           m->col_ptr, m->crow, w.pos, w.ready, d_level, w.assigned, w.heavy, w.cnt + 3);
+        if (n_heavy)
+          hipLaunchKernelGGL(level_heavy_k, dim3(512), dim3(WG_THREADS), 0, stream, w.heavy, w.cnt + 3, round % 2 ? w.f0 : w.f1, w.cnt, round, m->row_ptr, m->col,
+                             m->col_ptr, m->crow, w.pos, w.ready, w.cnt + 4);
+      }
+      unsigned long long done = 0;
+      FMX_HIP(hipMemcpyAsync(&done, w.assigned, sizeof(done), hipMemcpyDeviceToHost, stream));
+      FMX_HIP(hipStreamSynchronize(stream));
+      // (`assigned` counts the frontier each round STARTED with: the last round's features are placed once the count is complete)
+      if (done >= occurring) break;
+      if (cap > 0 && round >= cap + CHECK) { gave_up = true; break; }
+      FMX_CHECK((int64_t)round <= (int64_t)p + 2 * CHECK, FMX_ERR_STATE, "level scheduling did not converge (a row holds a column twice?)");
+    }
+    return FMX_OK;
+  };
   if (max_levels < 0 && m->n > 0 && m->nnz > 0) {
     // cfg.als_max_levels < 0: the sweep may choose its own feature order -- levels = the colours of a proper colouring of the "share a row" graph (kernels above).
     // Falls through to the exact schedule below where it does not apply (a column too long for one wave per feature, more colours than the kernel's set).
+    // The levels of the EXACT schedule are themselves a proper colouring -- in the reference's own feature order -- and on field-structured data (one column per field
+    // and row) there are as many as fields: taken when the walk finishes within COLOUR_EXACT_ROUNDS rounds (a speculative colouring spreads such data over a
+    // thousand classes; the sweep's numbers are then the reference's for -1).  A deep chain (i.i.d. columns: 19 399 levels at 10 M x 1 M) gives up after two read-backs.
+    {
+      constexpr int COLOUR_EXACT_ROUNDS = 64;
+      bool gave_up = false;
+      FMX_TRY(frontier_walk(COLOUR_EXACT_ROUNDS, gave_up));
+      if (!gave_up) coloured = true;
+      else FMX_HIP(hipMemsetAsync(d_level, 0, (size_t)p * sizeof(int), stream));
+    }
+    if (!coloured) {
     std::vector<int64_t> cph((size_t)p + 1);
     FMX_HIP(hipMemcpy(cph.data(), m->col_ptr, cph.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
     // Columns too long for one wave per feature (the heads of a skewed distribution: they meet almost every row, and each other) take a colour of their own each,
@@ -1159,6 +1221,7 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
         coloured = true;
       }
     }
+    }
   }
   const char* lv_env = getenv("FMX_ALS_LEVELS");  // FMX_ALS_LEVELS=relax: the round-1 builder (read per call: the tests compare the two)
   const bool relax = lv_env && lv_env[0] == 'r';
@@ -1182,53 +1245,9 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
       FMX_CHECK(sweeps <= (int64_t)p + CHECK, FMX_ERR_STATE, "level scheduling did not converge");
     }
   } else if (m->n > 0 && m->nnz > 0) {
-    // frontier walk: rounds are enqueued CHECK at a time (an empty frontier makes a round a no-op), then the number of features
-    // placed so far is read back; done when every occurring feature has its level
-    struct Tmp {
-      int *pos = nullptr, *ready = nullptr, *cnt = nullptr;
-      uint32_t *f0 = nullptr, *f1 = nullptr, *heavy = nullptr;
-      unsigned long long* assigned = nullptr;
-      ~Tmp() { (void)hipFree(pos); (void)hipFree(ready); (void)hipFree(cnt); (void)hipFree(f0); (void)hipFree(f1); (void)hipFree(assigned); (void)hipFree(heavy); }
-    } w;
-    FMX_HIP(hipMalloc(&w.pos, (size_t)m->n * sizeof(int)));
-    FMX_HIP(hipMalloc(&w.ready, (size_t)p * sizeof(int)));
-    FMX_HIP(hipMalloc(&w.cnt, 5 * sizeof(int)));  // three rotating frontier counts, the heavy list's count, its done flag
-    FMX_HIP(hipMalloc(&w.f0, (size_t)p * sizeof(uint32_t)));
-    FMX_HIP(hipMalloc(&w.f1, (size_t)p * sizeof(uint32_t)));
-    FMX_HIP(hipMalloc(&w.assigned, sizeof(unsigned long long)));
-    FMX_HIP(hipMemsetAsync(w.pos, 0, (size_t)m->n * sizeof(int), stream));
-    FMX_HIP(hipMemsetAsync(w.ready, 0, (size_t)p * sizeof(int), stream));
-    FMX_HIP(hipMemsetAsync(w.cnt, 0, 5 * sizeof(int), stream));
-    FMX_HIP(hipMemsetAsync(w.assigned, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(level_heads_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, stream, m->row_ptr, m->col, m->n, m->col_ptr, w.ready, w.f0, w.cnt);
-    std::vector<int64_t> cph((size_t)p + 1);
-    FMX_HIP(hipMemcpyAsync(cph.data(), m->col_ptr, cph.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FMX_HIP(hipStreamSynchronize(stream));
-    unsigned long long occurring = 0, n_heavy = 0;
-    for (uint32_t j = 0; j < p; ++j) {
-      occurring += cph[(size_t)j + 1] > cph[(size_t)j] ? 1 : 0;
-      n_heavy += cph[(size_t)j + 1] - cph[(size_t)j] > LEVEL_HEAVY ? 1 : 0;
-    }
-    FMX_HIP(hipMalloc(&w.heavy, (n_heavy ? n_heavy : 1) * sizeof(uint32_t)));
-    const int CHECK = 64;
-    int round = 0;
-    for (;;) {
-      for (int q = 0; q < CHECK; ++q, ++round)
-      {
-        hipLaunchKernelGGL(level_round_k, dim3(512), dim3(WG_THREADS), 0, stream, round % 2 ? w.f1 : w.f0, round % 2 ? w.f0 : w.f1, w.cnt, round, m->row_ptr, m->col,
-                           m->col_ptr, m->crow, w.pos, w.ready, d_level, w.assigned, w.heavy, w.cnt + 3);
-        if (n_heavy)
-          hipLaunchKernelGGL(level_heavy_k, dim3(512), dim3(WG_THREADS), 0, stream, w.heavy, w.cnt + 3, round % 2 ? w.f0 : w.f1, w.cnt, round, m->row_ptr, m->col,
-                             m->col_ptr, m->crow, w.pos, w.ready, w.cnt + 4);
-      }
-      unsigned long long done = 0;
-      FMX_HIP(hipMemcpyAsync(&done, w.assigned, sizeof(done), hipMemcpyDeviceToHost, stream));
-      FMX_HIP(hipStreamSynchronize(stream));
-      // (`assigned` counts the frontier each round STARTED with: the last round's features are placed once the count is complete)
-      if (done >= occurring) break;
-      if (max_levels > 0 && round >= max_levels + CHECK) { approx = true; break; }
-      FMX_CHECK((int64_t)round <= (int64_t)p + 2 * CHECK, FMX_ERR_STATE, "level scheduling did not converge (a row holds a column twice?)");
-    }
+    bool gave_up = false;
+    FMX_TRY(frontier_walk(max_levels > 0 ? max_levels : 0, gave_up));
+    if (gave_up) approx = true;
   }
   std::vector<int> level(p);
   FMX_HIP(hipMemcpy(level.data(), d_level, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));

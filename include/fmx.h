@@ -136,7 +136,10 @@ typedef struct fmx_config {
                               workgroup, up to 1 024 with the lines in LDS; a plan with longer or heavy lists runs as -1.
                               i.i.d. columns at 10 M x 1 M, k = 16: 213 M examples/s per ALS sweep, 206 M Gibbs (-1: 42.6 /
                               36.7 M; the reference's order: 5.0 M).  tests/test_gpu_coloured.py checks it coordinate by
-                              coordinate against a restatement that is itself pinned to the oracle.                          */
+                              coordinate against a restatement that is itself pinned to the oracle.
+                              Both: a matrix whose EXACT schedule is shallow (at most ~128 levels: one column per field and row)
+                              keeps those levels as its colours -- the reference's own feature order; -1 is then bit for bit
+                              the exact plan, -2 only interchanges the nesting (10 M x 1 M, 30 fields: 329 M examples/s).    */
   int32_t reserved0;
   int32_t gpus_share_device; /* 1: all N replicas live on `device` and exchange through a device kernel instead of RCCL
                               (rehearsals and tests on a one-GPU box; same sums, same order of ranks)                  */

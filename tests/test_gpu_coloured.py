@@ -234,3 +234,24 @@ def test_feature_major_kernel_forms(n, p, k, rows, monkeypatch):
     order = np.lexsort((np.arange(p), level_of))
     fv, fe = _numpy_sweep(rp, col, val, p, v, err0, 1.1, lam, mu, z, [(int(j), f) for j in order for f in range(k)])
     assert util.rel_err(out["0"][0], fe) < 1e-10
+
+
+def test_field_structured_data_takes_the_exact_levels_as_colours():
+    """One column per field and row: the exact schedule's levels (as many as fields) ARE a proper colouring, in the reference's own feature order -- a coloured plan
+    takes them instead of colouring speculatively (which spreads such data over hundreds of classes), so cfg.als_max_levels = -1 gives the reference's numbers there,
+    bit for bit the exact plan's."""
+    from fmwr_amd import _lib as L, engine
+    n, p, z, k = 20_000, 3_000, 10, 5
+    res = []
+    for cap in (0, -1):
+        m = engine.Matrix.synthetic(n, p, z, 77)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=cap)
+        e.init_normal(5, 0.0, 0.1)
+        levels, largest, _, level_of = e.als_plan(m)
+        assert levels == z and e.als_plan_kind(m) == (2 if cap else 0)
+        err0 = np.random.default_rng(3).normal(0, 1, n)
+        g = e.als_vsweep(m, err0, alpha=1.0, v_lambda=np.full(k, 0.5))
+        res.append((level_of.copy(), g, e.get_params()[2].copy()))
+        e.close(); m.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
