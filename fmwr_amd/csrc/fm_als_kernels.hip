@@ -1485,6 +1485,14 @@ static hipGraphExec_t sweep_graph(fmx_engine* e, fmx_matrix* m, double2* d_qe, c
   return g->exec;
 }
 
+// does the feature-major form (cfg.als_max_levels = -2) run on this plan?  A coloured plan of light lists of at most 1 024 rows; otherwise the sweep nests factor outer, as -1
+static bool allf_applies(const fmx_engine* e, const fmx_matrix* m) {
+  if (!m->als_coloured || m->als_plan_cap != -2 || e->k <= 0) return false;
+  if (m->als_heavy_ptr.empty() || m->als_heavy_ptr.back() != 0 || (!m->als_vh_ptr.empty() && m->als_vh_ptr.back() != 0)) return false;
+  for (int64_t v : m->als_level_maxlen) if (v > 1024) return false;
+  return true;
+}
+
 // one sweep of the w coordinates or of one factor, by replay when the plan is deep
 template <bool W>
 static void sweep_once(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2* d_qe_new, SweepDyn* dyn) {
@@ -1547,12 +1555,8 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
   // in the engine (grow-only): a sweep allocates nothing once the first one has run.
   double* d_Q = q_table(e, m);
   // cfg.als_max_levels = -2 on a coloured plan of light lists: the FEATURE-MAJOR order -- all k factors of a feature while its rows' state is in LDS (als_level_allf_k)
-  if (m->als_coloured && m->als_plan_cap == -2 && !d_qe_new && e->k > 0) {
-    bool fits = m->als_heavy_ptr.back() == 0 && (m->als_vh_ptr.empty() || m->als_vh_ptr.back() == 0);
-    int64_t longest = 0;
-    for (int64_t v : m->als_level_maxlen) if (v > longest) longest = v;
-    fits = fits && longest <= 1024;
-    double* d_Qr = fits ? q_table(e, m) : nullptr;
+  if (allf_applies(e, m) && !d_qe_new) {
+    double* d_Qr = q_table(e, m);
     if (d_Qr) {
       RowsArgs a{};
       a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
@@ -1787,7 +1791,7 @@ int als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* larges
   }
   if (levels) *levels = L;
   if (largest) *largest = big;
-  if (approx) *approx = m->als_approx ? 1 : (m->als_coloured ? 2 : 0);   // 2: exact steps in a COLOURED feature order (cfg.als_max_levels < 0)
+  if (approx) *approx = m->als_approx ? 1 : (m->als_coloured ? (allf_applies(e, m) ? 3 : 2) : 0);   // 2: exact steps in a COLOURED feature order (cfg.als_max_levels < 0); 3: and nested feature-major (-2)
   if (level_of) for (size_t j = 0; j < m->als_level_of.size(); ++j) level_of[j] = m->als_level_of[j];
   return FMX_OK;
 }

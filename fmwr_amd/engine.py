@@ -516,7 +516,7 @@ class Engine:
         return lv.value, big.value, bool(ap.value), lof[: self.p]
 
     def als_plan_kind(self, m):
-        """0: the exact schedule (the reference's feature order); 1: the approximate groups (cfg.als_max_levels exceeded); 2: the coloured order (cfg.als_max_levels = -1; -2: its feature-major form)."""
+        """0: the exact schedule (the reference's feature order); 1: the approximate groups (cfg.als_max_levels exceeded); 2: the coloured order (cfg.als_max_levels = -1, or -2 on a plan with long or heavy lists); 3: the coloured order nested feature-major (-2)."""
         ap = C.c_int32()
         L.check(L.lib().fmx_als_plan_info(self.h, m.h, None, None, C.byref(ap), None))
         return int(ap.value)

@@ -444,7 +444,7 @@ int fmx_vsweep_device(fmx_engine* e, fmx_matrix* m, void* dev_error_f64, double 
 
 /* The exact sweeps process the features in LEVELS (features of a level share no row, levels in ascending order reproduce the
  * reference's index-order Gauss-Seidel): how many levels (or, with cfg.als_max_levels exceeded, groups of the approximate
- * form: `approximate` = 1; with cfg.als_max_levels = -1 or -2, colours of the coloured order: `approximate` = 2) this matrix needs, the size of the largest, and every
+ * form: `approximate` = 1; with cfg.als_max_levels = -1 or -2, colours of the coloured order: `approximate` = 2, or 3 when the V sweep of a -2 plan nests feature-major -- light lists of at most 1 024 rows; 2 there means it nests factor outer, as -1) this matrix needs, the size of the largest, and every
  * feature's level / group / colour. */
 int fmx_als_plan_info(fmx_engine* e, fmx_matrix* m, int64_t* levels, int64_t* largest_level, int32_t* approximate,
                       int32_t* level_of_feature /* [p] or NULL */);

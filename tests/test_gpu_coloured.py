@@ -174,7 +174,7 @@ def test_feature_major_coloured_sweep(gibbs, values):
     m = engine.Matrix.from_csr(rp, col, val, p, y)
     _, _, _, level_of = e.als_plan(m)
     level_of = level_of.copy()
-    assert e.als_plan_kind(m) == 2
+    assert e.als_plan_kind(m) == 3
     order = np.lexsort((np.arange(p), level_of))
     fv, fe = _numpy_sweep(rp, col, val, p, v, err0, 1.1, lam, mu, z, [(int(j), f) for j in order for f in range(k)])
     gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
@@ -218,7 +218,7 @@ def test_feature_major_kernel_forms(n, p, k, rows, monkeypatch):
         m = engine.Matrix.from_csr(rp, col, val, p, y)
         _, _, _, level_of = e.als_plan(m)
         level_of = level_of.copy()
-        assert e.als_plan_kind(m) == 2
+        assert e.als_plan_kind(m) == 3
         g1 = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
         g2 = e.als_vsweep(m, g1, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
         res = (g1, g2, e.get_params()[2].copy())
@@ -255,3 +255,40 @@ def test_field_structured_data_takes_the_exact_levels_as_colours():
         e.close(); m.close()
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("k,p,n,note", [(1, 800, 4_000, "kp = 2: the LDS-resident kernel"), (3, 800, 4_000, "kp = 4"), (20, 900, 5_000, "kp = 32: sixteen lanes per row"),
+                                        (4, 40, 30_000, "lists of ~7 500 rows: NOT feature-major -- the sweep nests factor outer, as -1")])
+def test_feature_major_edges(k, p, n, note):
+    """Factor counts outside the register kernels' (kp 8 / 16), columns that never occur and empty rows; and a plan whose lists are too long for the feature-major
+    form: fmx_als_plan_info says which nesting a -2 plan takes (3 feature-major, 2 factor outer) and the sweep agrees with the restatement in THAT order."""
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(k * 1000 + p)
+    z = 10
+    rows = []
+    for r in range(n):
+        if r % 97 == 0:
+            rows.append(np.zeros(0, np.int64)); continue                       # an empty row
+        rows.append(np.sort(rng.choice(np.arange(3, p), size=min(z, p - 3), replace=False)))   # columns 0..2 never occur
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows).astype(np.uint32)
+    val = rng.uniform(0.2, 1.0, len(col)).astype(np.float32)
+    y = util.labels(n, 5, "regression")
+    w0, w, v = util.params(p, k, 73, stdev=0.1, fp32=False)
+    lam = np.linspace(10.0, 20.0, k); mu = np.linspace(-0.05, 0.05, k)
+    zz = rng.normal(0, 1, (k, p))
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(oracle.params(task=oracle.REGRESSION, k=k), X, w0, w, v.ravel()) - y
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    _, _, _, level_of = e.als_plan(m)
+    level_of = level_of.copy()
+    kind = e.als_plan_kind(m)
+    assert kind == (2 if "NOT" in note else 3)
+    order = np.lexsort((np.arange(p), level_of))
+    coords = [(int(j), f) for j in order for f in range(k)] if kind == 3 else [(int(j), f) for f in range(k) for j in order]
+    fv, fe = _numpy_sweep(rp, col, val, p, v, err0, 1.1, lam, mu, zz, coords)
+    g = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=zz)
+    assert util.rel_err(g, fe) < 1e-10 and util.rel_err(e.get_params()[2], fv) < 1e-10
+    e.close(); m.close()
