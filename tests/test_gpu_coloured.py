@@ -292,3 +292,62 @@ def test_feature_major_edges(k, p, n, note):
     g = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=zz)
     assert util.rel_err(g, fe) < 1e-10 and util.rel_err(e.get_params()[2], fv) < 1e-10
     e.close(); m.close()
+
+
+def test_learners_on_a_feature_major_plan():
+    """The learners' loops on a cfg.als_max_levels = -2 plan.  The w sweep goes in (colour, index) order: without a V sweep the ALS learner IS the oracle's learner on
+    the relabelled matrix.  With the V sweep nested feature-major there is no oracle run to compare with -- exact coordinate steps of the least-squares
+    objective never raise it, in any order, and the run is bit for bit reproducible; the MCMC learner's draws stay finite and reproducible."""
+    from fmwr_amd import _lib as L, engine
+    n, p, k = 5_000, 1_200, 8
+    m0 = engine.Matrix.synthetic_iid(n, p, Z, 41, law=L.COLUMNS_UNIFORM)
+    rp, col, val, _ = m0.export(); m0.close()
+    val = np.random.default_rng(2).uniform(0.3, 1.0, len(val)).astype(np.float32)
+    y = util.labels(n, 41, "regression")
+    w0, w, v = util.params(p, k, 19, stdev=0.1, fp32=False)
+    def engine_(solver):
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=solver, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+        e.set_params(w0, w, v)
+        return e
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    e = engine_(L.SOLVER_ALS)
+    _, _, _, level_of = e.als_plan(m)
+    level_of = level_of.copy()
+    assert e.als_plan_kind(m) == 3
+    # (a) w0 + w sweeps only: the oracle's learner on the relabelled matrix
+    order = np.lexsort((np.arange(p), level_of))
+    rank = np.empty(p, np.int64); rank[order] = np.arange(p)
+    rp2, col2, val2 = _relabel(rp, col, val, rank)
+    P = oracle.params(task=oracle.REGRESSION, k=k)
+    ow0, ow, ov = oracle.als_learn(P, oracle.Matrix(rp2, col2, val2, p), y, w0, w[order], np.ascontiguousarray(v[:, order]).ravel(), 3, with_v=False)
+    e.als_train(m, 3, with_v=False)
+    g0, gw, gv = e.get_params()
+    assert abs(g0 - ow0) < 1e-10 and util.rel_err(gw[order], ow) < 1e-10 and np.array_equal(gv, v)
+    e.close()
+    # (b) with the V sweep: the objective never rises, the run repeats bit for bit
+    X = oracle.Matrix(rp, col, val, p)
+    def objective(par):
+        a0, aw, av = par
+        r = oracle.predict_batch(P, X, a0, aw, av.ravel()) - y
+        return float(r @ r)          # (the ALS learner steps with alpha = 1 and every lambda 0: fmo_als_learn_traced)
+    runs = []
+    for _ in range(2):
+        e = engine_(L.SOLVER_ALS)
+        obj = [objective((w0, w, v))]
+        for it in range(3):
+            e.als_train(m, 1, with_v=True)
+            obj.append(objective(e.get_params()))
+        assert all(b <= a * (1 + 1e-12) for a, b in zip(obj, obj[1:])) and obj[-1] < 0.9 * obj[0], obj
+        runs.append(e.get_params()); e.close()
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    # (c) the MCMC learner on the same plan
+    g = np.random.default_rng(10)
+    gam = g.gamma((1 + n) / 2, 1.0, (3, 2)); nor = g.normal(0, 1, (3, 2 + p))
+    runs = []
+    for _ in range(2):
+        e = engine_(L.SOLVER_MCMC)
+        e.mcmc_train(m, 3, gam, nor)
+        runs.append(e.get_params()); e.close()
+    assert np.isfinite(runs[0][2]).all() and np.isfinite(runs[0][1]).all()
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    m.close()
