@@ -777,7 +777,7 @@ def main_sweep(args, rank, local_rank, world):
                                              "ceiling_frac": got / r if r else None,
                                              "note": "entries per second of a level over the measured rate of random 16-B gathers from the whole (q, e) table (the untiled form does a gather AND a scatter "
                                                      "per entry against it: at most 0.5; the row-tiled and level-order forms keep their random accesses inside L2-resident slices or LDS and are not bound by it)"}
-    if blocks and world == 1:
+    if blocks and world == 1 and not fmajor:
         # opt-in variant (fmx_als_carry_q): the sweep keeps q = X v_f current as it goes, so sweep t + 1 needs no forward pass to rebuild it.  NOT `value`: the reference
         # recomputes q for every factor of every sweep, and `value` above does one forward pass per sweep for it
         e.als_carry_q(True)
@@ -1009,8 +1009,8 @@ def other_configs(args):
         ("configs[3]_resident", ["--workload", "criteo", "--steps", "30", "--warmup", "3", "--cpu-rows", "120000"], run_minibatch),
         ("configs[3]_streamed", ["--workload", "criteo", "--stream", "--steps", "30", "--warmup", "3"], main_stream),
         ("configs[4]", ["--solver", "mcmc", "--no-extras", "--steps", "4", "--warmup", "1", "--cpu-rows", "2000000"], main_sweep),
-        ("configs[4]_iid_columns", ["--solver", "mcmc", "--sweep-iid", "--no-extras", "--steps", "2", "--warmup", "1", "--cpu-rows", "0"], main_sweep),
-        ("configs[4]_feature_major", ["--solver", "mcmc", "--sweep-feature-major", "--no-extras", "--steps", "2", "--warmup", "1", "--cpu-rows", "0"], main_sweep),
+        ("configs[4]_iid_columns", ["--solver", "mcmc", "--sweep-iid", "--no-extras", "--steps", "4", "--warmup", "2", "--cpu-rows", "0"], main_sweep),
+        ("configs[4]_feature_major", ["--solver", "mcmc", "--sweep-feature-major", "--no-extras", "--steps", "4", "--warmup", "2", "--cpu-rows", "0"], main_sweep),
     ]
     for name, argv, fn in runs:
         t0 = time.perf_counter()
