@@ -1486,6 +1486,7 @@ static hipGraphExec_t sweep_graph(fmx_engine* e, fmx_matrix* m, double2* d_qe, c
 }
 
 // does the feature-major form (cfg.als_max_levels = -2) run on this plan?  A coloured plan of light lists of at most 1 024 rows; otherwise the sweep nests factor outer, as -1
+constexpr uint64_t ALLF_TRUSTED = 0xA11FA11FA11FA11Full;   // e->als_q_trusted of a row-major table: the matrix uid under this mask (a block-form table carries its plan's uid)
 static bool allf_applies(const fmx_engine* e, const fmx_matrix* m) {
   if (!m->als_coloured || m->als_plan_cap != -2 || e->k <= 0) return false;
   if (m->als_heavy_ptr.empty() || m->als_heavy_ptr.back() != 0 || (!m->als_vh_ptr.empty() && m->als_vh_ptr.back() != 0)) return false;
@@ -1562,8 +1563,9 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
       a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
       a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Qr; a.qout_t = 0; a.link = FMX_LINK_NONE;   // q of every factor, ROW-major: [n][kp]
       a.unit = m->unit_values; a.no_w = 1;
+      const bool trusted = e->als_q_trusted == (m->uid ^ ALLF_TRUSTED);   // the learner's own forward pass of this iteration left the table (launch_als_train): V untouched since
       e->als_q_have = 0; e->als_q_trusted = 0;
-      if (launch_rows_forward(e, a, false, true) == FMX_OK) {
+      if (trusted || launch_rows_forward(e, a, false, true) == FMX_OK) {
         std::vector<double> lm((size_t)2 * e->k, 0.0);
         for (int f = 0; f < e->k; ++f) { lm[(size_t)2 * f] = h_lambda ? h_lambda[f] : 0.0; lm[(size_t)2 * f + 1] = h_mu ? h_mu[f] : 0.0; }
         if (!e->als_lam_mu) FMX_HIP(hipMalloc(&e->als_lam_mu, (size_t)2 * 1024 * sizeof(double)));
@@ -1826,7 +1828,11 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     const uint32_t *colP = nullptr, *row0 = nullptr; const float* valP = nullptr;
     double* d_Q = nullptr;
     static const bool share = [] { const char* v = getenv("FMX_ALS_SHARE_FORWARD"); return !(v && v[0] == '0'); }();
-    if (share && with_v && e->k > 0 && !m->als_approx) {
+    const bool fmajor = share && with_v && allf_applies(e, m);   // a feature-major plan (-2): the sweep wants q ROW-major, rows in the matrix's own order
+    if (fmajor) {
+      d_Q = q_table(e, m);
+      if (d_Q) { a.unit = m->unit_values; a.qout = d_Q; a.qout_t = 0; }
+    } else if (share && with_v && e->k > 0 && !m->als_approx) {
       if (als_order_prepare(e, m, &colP, &valP, &row0) != FMX_OK) colP = nullptr;
       if (colP) d_Q = q_table(e, m);
       if (!d_Q) colP = nullptr;
@@ -1837,7 +1843,10 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     if (colP) {
       hipLaunchKernelGGL(als_residual_perm_k, dim3(row_grid), dim3(256), 0, e->stream, (const double*)d_yhat, (const float*)m->y, row0, n, d_qe, dp_y);
       e->als_q_trusted = als_order_plan_uid(m);
-    } else hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, dp_y);
+    } else {
+      hipLaunchKernelGGL(als_residual_k, dim3(row_grid), dim3(256), 0, e->stream, d_yhat, m->y, n, d_qe, dp_y);
+      if (fmajor && d_Q) e->als_q_trusted = m->uid ^ ALLF_TRUSTED;
+    }
     if (e->hyper.k0) {
       hipLaunchKernelGGL(als_w0_partial_k, dim3((unsigned)np), dim3(WG_THREADS), 0, e->stream, d_qe, n, e->scal, d_part);
       hipLaunchKernelGGL(als_w0_final_k, dim3(1), dim3(WG_THREADS), 0, e->stream, d_part, np, n, e->scal, e->hyper.reg0, 1.0, 0.0, 0, 0.0);
