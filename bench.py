@@ -169,7 +169,7 @@ def pmc_traffic(kernel, args):
     return best
 
 
-def pmc_traffic_sweep(args, tiled, ordered=False, blocks=False):
+def pmc_traffic_sweep(args, tiled, ordered=False, blocks=False, fmajor=False):
     """configs[4]: HBM-side bytes of one level of one factor from the committed PMC summaries (profiles/r*_pmc_summary_mcmc*.json), or None."""
     import glob
     best = None
@@ -180,6 +180,12 @@ def pmc_traffic_sweep(args, tiled, ordered=False, blocks=False):
             continue
         a = d.get("_bench_args", [])
         if ("als" in a) != (args.solver == "als") or args.rows != 10_000_000 or args.features != 1_000_000:
+            continue
+        if any((flag in a) != bool(getattr(args, flag[2:].replace("-", "_"))) for flag in ("--sweep-iid", "--sweep-feature-major", "--sweep-factor-outer", "--real-values")):
+            continue                                       # (another column law, nesting or value law: another kernel's counters)
+        if fmajor:
+            if "als_level_allf" in d and "fabric_bytes_per_launch" in d["als_level_allf"]:
+                best = (d["als_level_allf"]["fabric_bytes_per_launch"], os.path.basename(f))
             continue
         if blocks:
             if "als_block_level" in d and "fabric_bytes_per_launch" in d["als_block_level"]:   # (one kernel per level; exact bytes by request size, not the x2 bound)
@@ -729,10 +735,10 @@ def main_sweep(args, rank, local_rank, world):
                               "note": "40 B x nnz x k over the whole sweep's wall time (includes the one forward pass that builds q for all factors)"},
                      "q_build_forward_ms": fwd_ms / max(fwd_n, 1) if fwd_n else None},
     }
-    tr = pmc_traffic_sweep(args, bool(tiled), ordered, blocks)
+    tr = pmc_traffic_sweep(args, bool(tiled), ordered, blocks, fmajor)
     if tr:
         out["roofline"]["traffic"] = tr[0]
-        out["roofline"]["traffic_source"] = (f"profiles/{tr[1]}: fabric bytes of one launch by request size (128 x RDREQ_128B + 64 x the other reads + WRITE_SIZE), separate --pmc passes" if blocks else
+        out["roofline"]["traffic_source"] = (f"profiles/{tr[1]}: fabric bytes of one launch by request size (128 x RDREQ_128B + 64 x the other reads + WRITE_SIZE), separate --pmc passes" if blocks or fmajor else
                                              f"profiles/{tr[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB summed over the launches of one level, separate --pmc passes; upper bound, DESIGN.md section 6")
     if fmajor:
         # what a launch has to move (design bytes), per entry of the level: the row's line of k values in and out (2 x 8 k), e in and out (2 x 8), the row id 4 (+4 value);

@@ -29,6 +29,7 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         elif "fm_rows_forward" in name: kn = "fm_rows_forward_predict"                      # bench's forward-only pass (all rows)
         elif "fm_cols_update" in name: kn = "fm_cols_update"
         elif "fm_scalar" in name: kn = "fm_scalar_update"
+        elif "als_level_allf_" in name: kn = "als_level_allf"                                # the feature-major coloured sweep (cfg.als_max_levels = -2): one launch per colour, all k factors (wave / register / LDS forms together)
         elif "als_level_k" in name: kn = "als_level"                                        # configs[4]: one level of one factor (the untiled form)
         elif "als_tile_sums_k" in name: kn = "als_tile_sums"                                # the row-tiled form: per (tile, feature) sums ...
         elif "als_tile_step_k" in name: kn = "als_tile_step"                                # ... the coordinate steps of the level ...
