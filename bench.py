@@ -752,7 +752,8 @@ def main_sweep(args, rank, local_rank, world):
                                               "note": "128-byte lines: the q line in and out, the (q, e) pair's line in for the 8 bytes of e, a 64-byte write for them out; a level's ~1 000 features start "
                                                       "together, so its gathers, its steps and its stores follow each other chip-wide instead of overlapping (profiles/r05_allf_knockouts.txt)"}
         out["roofline"]["note"] = ("`frac` prices SURVEY 8(d)'s 40 B per nonzero and factor -- what the reference's factor-outer order moves -- against this form's launch, which does all k factors "
-                                   "of its features at once and moves design_bytes_per_launch instead: frac is the contract's figure, design_frac what the kernel's own bytes make of the chip")
+                                   "of its features at once and moves design_bytes_per_launch instead: frac is the contract's figure, design_frac what the kernel's own bytes make of the chip.  avg_launch_ms is a HIP-event pair around the launch: on i.i.d. columns the launch is ~34 us "
+                                   "(rocprofv3 --kernel-trace --stats of this command: profiles/r05c_kernel_stats_mcmc_iid.csv, 34.1 us) and the pair adds ~4 us to it")
     elif blocks:
         # what the one pass of a level has to move (design bytes): (q, e) 16 in and 16 out, LDS slot 2, slot in destination order 2, position in the next level's array 4 (+4 value)
         vb = 0 if e_unit(m) else 4
