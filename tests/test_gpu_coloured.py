@@ -351,3 +351,37 @@ def test_learners_on_a_feature_major_plan():
     assert np.isfinite(runs[0][2]).all() and np.isfinite(runs[0][1]).all()
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
     m.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_feature_major_fuzz(seed):
+    """Random shapes through the feature-major sweep: k 1 ... 20, 1 ... 24 entries per row, lists of a few to ~900 rows, real or unit values, ALS or Gibbs,
+    a handful of empty rows -- whatever kernel form each level takes, against the restatement in the order the plan reports."""
+    from fmwr_amd import _lib as L, engine
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(1, 21)); z = int(rng.integers(1, 25))
+    p = int(rng.integers(max(z + 1, 30), 1500)); n = int(rng.integers(200, 9000))
+    gibbs = bool(rng.integers(0, 2)); unit = bool(rng.integers(0, 2))
+    lens = np.where(rng.random(n) < 0.02, 0, z)
+    rp = np.zeros(n + 1, np.int64); rp[1:] = np.cumsum(lens)
+    col = np.concatenate([np.sort(rng.choice(p, size=l, replace=False)) for l in lens if l > 0] or [np.zeros(0, np.int64)]).astype(np.uint32)
+    val = np.ones(len(col), np.float32) if unit else rng.uniform(-1.0, 1.0, len(col)).astype(np.float32)
+    y = util.labels(n, seed, "regression")
+    w0, w, v = util.params(p, k, seed + 5, stdev=0.1, fp32=False)
+    lam = np.linspace(10.0, 20.0, k) if gibbs else np.linspace(0.1, 0.9, k); mu = np.linspace(-0.05, 0.05, k)
+    zz = rng.normal(0, 1, (k, p)) if gibbs else None
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(oracle.params(task=oracle.REGRESSION, k=k), X, w0, w, v.ravel()) - y
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    _, _, _, level_of = e.als_plan(m)
+    level_of = level_of.copy()
+    kind = e.als_plan_kind(m)
+    assert kind in (2, 3)
+    order = np.lexsort((np.arange(p), level_of))
+    coords = [(int(j), f) for j in order for f in range(k)] if kind == 3 else [(int(j), f) for f in range(k) for j in order]
+    fv, fe = _numpy_sweep(rp, col, val, p, v, err0, 0.9, lam, mu, zz, coords)
+    g = e.als_vsweep(m, err0, alpha=0.9, v_lambda=lam, v_mu=mu, std_normals=zz)
+    assert util.rel_err(g, fe) < 1e-9 and util.rel_err(e.get_params()[2], fv) < 1e-9, (k, z, p, n, gibbs, unit, kind)
+    e.close(); m.close()
