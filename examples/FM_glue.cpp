@@ -74,6 +74,15 @@ static fmx_config config_from_controls(List fm_controls, List solver_controls, d
       c.n_gpus = want > 1 ? (want < n_dev ? want : n_dev) : 1;
     } else if (eng != "sequential") stop("solver.control(engine = ...) must be \"sequential\", \"minibatch\" or \"minibatch_fp64\"");
   }
+  // ALS / MCMC: the ORDER of the coordinate sweeps is another optional element (`sweep_order = c("reference", "coloured", "feature_major")`, include/fmx.h
+  // cfg.als_max_levels): "reference" keeps the reference's feature order and factor-outer nesting (its numbers); the other two take every step exactly but in an order
+  // the engine chooses -- what makes matrices without field structure fast (i.i.d. columns: 5 M -> 43 M -> 213 M examples/s per sweep).
+  if (solver_controls.containsElementNamed("sweep_order") && (c.solver == FMX_SOLVER_ALS || c.solver == FMX_SOLVER_MCMC)) {
+    const std::string ord = as<std::string>(solver_controls["sweep_order"]);
+    if (ord == "coloured") c.als_max_levels = -1;
+    else if (ord == "feature_major") c.als_max_levels = -2;
+    else if (ord != "reference") stop("solver.control(sweep_order = ...) must be \"reference\", \"coloured\" or \"feature_major\"");
+  }
   return c;
 }
 
