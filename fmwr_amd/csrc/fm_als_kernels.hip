@@ -471,24 +471,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMX_ALLF_WPE
 //   resolve  a feature that chose the colour of a LOWER-indexed neighbour of the same round gives it up and stays for the next round.
 constexpr int COLOUR_MAX = 8192;       // bits of the per-wave set
 constexpr int COLOUR_SPREAD = 8;
+constexpr int COLOUR_TEAM_BELOW = 4096;   // fewer features than this in a launch: a workgroup walks each (colour_assign_k<true>)
 __device__ __forceinline__ uint32_t colour_hash(uint32_t a, uint32_t b) {
   uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
   x ^= x >> 15; x *= 0xC2B2AE3Du; x ^= x >> 13;
   return x;
 }
+// TEAM = false: a wave per feature (crowded rounds: every SIMD has features to walk); TEAM = true: a WORKGROUP per feature -- a small class (the refit passes launch one
+// class of ~1 000 features at a time, the late rounds a few thousand) is latency-bound with one wave walking 300 rows x 30 entries, four waves walk them in a quarter
+// of the time.  Same forbidden set, same choice.
+template <bool TEAM>
 __global__ __launch_bounds__(WG_THREADS) void colour_assign_k(const uint32_t* __restrict__ act, int n_act, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
                                                               const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const int* fixed,
-                                                              int* chosen, int round, int spread, int* __restrict__ overflow) {   // (the refit passes run it with chosen == fixed)
+                                                              int* chosen, int round, int spread, int* __restrict__ overflow, int scan) {   // (the refit passes run it with chosen == fixed; scan = 0: nothing is fixed yet -- round 0 without heavy columns --, no neighbour can forbid anything)
   constexpr int WORDS = COLOUR_MAX / 32, WPB = WG_THREADS / 64, PER = WORDS / 64;
-  __shared__ uint32_t forb[WPB][WORDS];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int waves = (int)(gridDim.x * WPB);
-  for (int w = (int)(blockIdx.x * WPB + wv); w < n_act; w += waves) {
+  __shared__ uint32_t forb[TEAM ? 1 : WPB][WORDS];
+  const int lane = threadIdx.x & 63, wv = TEAM ? 0 : (int)(threadIdx.x >> 6);
+  const int step = TEAM ? (int)gridDim.x : (int)(gridDim.x * WPB);
+  const int tl = TEAM ? (int)threadIdx.x : lane, tn = TEAM ? WG_THREADS : 64;   // this thread's place among the walkers of one feature
+  for (int w = TEAM ? (int)blockIdx.x : (int)(blockIdx.x * WPB + (threadIdx.x >> 6)); w < n_act; w += step) {
     const uint32_t j = act[w];
+    if (TEAM) { for (int q = threadIdx.x; q < WORDS; q += WG_THREADS) forb[0][q] = 0u; __syncthreads(); }
+    else {
 #pragma unroll
-    for (int q = 0; q < PER; ++q) forb[wv][lane * PER + q] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    for (int64_t t = col_ptr[j] + lane; t < col_ptr[j + 1]; t += 64) {
+      for (int q = 0; q < PER; ++q) forb[wv][lane * PER + q] = 0u;
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int64_t t = col_ptr[j] + tl; scan && t < col_ptr[j + 1]; t += tn) {
       const uint32_t r = crow[t];
       const int64_t ub = row_ptr[r], ue = row_ptr[r + 1];
       for (int64_t u = ub; u < ue; u += 8) {   // eight entries' columns, then their colours: independent loads in flight (a dependent pair per entry took 24 s of plan time at 10 M x 1 M)
@@ -502,36 +511,38 @@ __global__ __launch_bounds__(WG_THREADS) void colour_assign_k(const uint32_t* __
           if (u + i < ue && c[i] >= 0 && k[i] != j) atomicOr(&forb[wv][c[i] >> 5], 1u << (c[i] & 31));   // (k == j: a feature being REFITTED may keep its own colour)
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    // the t-th free colour: lane l owns words l * PER .. (consecutive colours), an exclusive scan of the free counts finds the lane
-    uint32_t fw[PER]; int nfree = 0;
+    if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    if (!TEAM || threadIdx.x < 64) {
+      // the t-th free colour: lane l owns words l * PER .. (consecutive colours), an exclusive scan of the free counts finds the lane
+      uint32_t fw[PER]; int nfree = 0;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) { fw[q] = ~forb[wv][lane * PER + q]; nfree += __popc(fw[q]); }
-    int incl = nfree;
+      for (int q = 0; q < PER; ++q) { fw[q] = ~forb[wv][lane * PER + q]; nfree += __popc(fw[q]); }
+      int incl = nfree;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-    const int total = __shfl(incl, 63);
-    const int want = total > 0 ? (int)(colour_hash(j, (uint32_t)round) % (uint32_t)(total < spread ? total : spread)) : 0;
-    const int before = incl - nfree;
-    int mine = -1;
-    if (total > 0 && want >= before && want < incl) {
-      int left = want - before;
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+      const int total = __shfl(incl, 63);
+      const int want = total > 0 ? (int)(colour_hash(j, (uint32_t)round) % (uint32_t)(total < spread ? total : spread)) : 0;
+      const int before = incl - nfree;
+      int mine = -1;
+      if (total > 0 && want >= before && want < incl) {
+        int left = want - before;
 #pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int c = __popc(fw[q]);
-        if (mine < 0 && left < c) {
-          uint32_t wbits = fw[q];
-          for (int z = 0; z < left; ++z) wbits &= wbits - 1;   // drop the lowest `left` free bits
-          mine = (lane * PER + q) * 32 + (__ffs((int)wbits) - 1);
+        for (int q = 0; q < PER; ++q) {
+          const int c = __popc(fw[q]);
+          if (mine < 0 && left < c) {
+            uint32_t wbits = fw[q];
+            for (int z = 0; z < left; ++z) wbits &= wbits - 1;   // drop the lowest `left` free bits
+            mine = (lane * PER + q) * 32 + (__ffs((int)wbits) - 1);
+          }
+          left -= c;
         }
-        left -= c;
       }
+      // (exactly one lane holds the answer)
+      const unsigned long long who = __ballot(mine >= 0);
+      if (who == 0ull) { if (lane == 0) { chosen[j] = -1; atomicExch(overflow, 1); } }
+      else if (mine >= 0) chosen[j] = mine;
     }
-    // (exactly one lane holds the answer)
-    const unsigned long long who = __ballot(mine >= 0);
-    if (who == 0ull) { if (lane == 0) { chosen[j] = -1; atomicExch(overflow, 1); } }
-    else if (mine >= 0) chosen[j] = mine;
-    __builtin_amdgcn_wave_barrier();
+    if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   }
 }
 // lose[w] = 1: the feature's choice collides with a lower-indexed feature of the same round
@@ -561,6 +572,38 @@ __global__ __launch_bounds__(WG_THREADS) void colour_resolve_k(const uint32_t* _
     if (lane == 0) lose[w] = 0;
     if (__any(bad) && lane == 0) lose[w] = 1;
   }
+}
+// The same test ROW by row, for crowded rounds: two features collide iff they share a row, so a row that looks at the colours its own unfixed entries chose finds every
+// collision it hosts -- 30 gathers per row instead of the 8 700 per feature of the walk above (10 M x 1 M i.i.d.: 0.3 G against 8.7 G reads in round 0).  LPR lanes per
+// row (columns ascend inside a row: the LATER entry of an equal pair is the higher index and loses); lose_f is per FEATURE, zeroed before, flag stores only.
+template <int LPR>
+__global__ __launch_bounds__(WG_THREADS) void colour_resolve_rows_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, const int* __restrict__ fixed,
+                                                                    const int* __restrict__ chosen, int* __restrict__ lose_f) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, g = lane / LPR, li = lane % LPR;
+  const int64_t waves = (int64_t)gridDim.x * (WG_THREADS / 64);
+  for (int64_t r0 = (((int64_t)blockIdx.x * WG_THREADS + threadIdx.x) >> 6) * RPW; r0 < n; r0 += waves * RPW) {   // (uniform per wave: the shuffles below see all lanes)
+    const int64_t row = r0 + g;
+    int c = -1; uint32_t k = 0;
+    if (row < n) {
+      const int64_t ub = row_ptr[row];
+      if (li < (int)(row_ptr[row + 1] - ub)) {
+        k = col[ub + li];
+        c = fixed[k] < 0 ? chosen[k] : -1;   // an entry that is choosing this round
+      }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int d = 1; d < LPR; ++d) {
+      const int o = __shfl_up(c, d, LPR);
+      if (li >= d && c >= 0 && o == c) bad = true;
+    }
+    if (bad) lose_f[k] = 1;
+  }
+}
+__global__ void colour_lose_gather_k(const uint32_t* __restrict__ act, int n_act, const int* __restrict__ lose_f, const int* __restrict__ chosen, int* __restrict__ lose) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_act) lose[w] = (lose_f[act[w]] != 0 || chosen[act[w]] < 0) ? 1 : 0;
 }
 // winners are fixed, losers form the next round's list (in this round's order: the list stays ascending)
 __global__ void colour_commit_k(const uint32_t* __restrict__ act, int n_act, const int* __restrict__ lose, const int* __restrict__ chosen, int* __restrict__ fixed) {
@@ -1137,12 +1180,15 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
     const bool too_long = heavy_first.size() > (size_t)COLOUR_MAX / 2;
     if (!too_long && !(act.empty() && heavy_first.empty())) {
       struct Tmp {
-        int *fixed = nullptr, *chosen = nullptr, *lose = nullptr, *overflow = nullptr; uint32_t* act = nullptr;
-        ~Tmp() { (void)hipFree(fixed); (void)hipFree(chosen); (void)hipFree(lose); (void)hipFree(overflow); (void)hipFree(act); }
+        int *fixed = nullptr, *chosen = nullptr, *lose = nullptr, *overflow = nullptr, *lose_f = nullptr; uint32_t* act = nullptr;
+        ~Tmp() { (void)hipFree(fixed); (void)hipFree(chosen); (void)hipFree(lose); (void)hipFree(overflow); (void)hipFree(act); (void)hipFree(lose_f); }
       } w;
       const size_t n_occ = act.size() + heavy_first.size();
       FMX_HIP(hipMalloc(&w.fixed, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.chosen, (size_t)p * sizeof(int))); FMX_HIP(hipMalloc(&w.lose, (n_occ ? n_occ : 1) * sizeof(int)));
       FMX_HIP(hipMalloc(&w.overflow, sizeof(int))); FMX_HIP(hipMalloc(&w.act, (n_occ ? n_occ : 1) * sizeof(uint32_t)));
+      FMX_HIP(hipMalloc(&w.lose_f, (size_t)p * sizeof(int)));
+      const char* rows_env = getenv("FMX_COLOUR_ROWS");   // =0: the collisions of every round by the feature walk (read per plan: the tests compare the plans)
+      const bool rows_ok = m->max_row_len <= 64 && !(rows_env && rows_env[0] == '0');
       {
         std::vector<int> init(p, -1);
         for (size_t i = 0; i < heavy_first.size(); ++i) init[heavy_first[i]] = (int)i;
@@ -1158,8 +1204,18 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
         const unsigned grid = (unsigned)(na < 4 * 2048 ? (na + 3) / 4 : 2048);
         // a colour holds at most n / (rows per feature) features: with S colours on offer a round fixes at most S classes' worth -- S grows with the crowd (150 rounds at S = 8)
         const int spread = na / 2048 < COLOUR_SPREAD ? COLOUR_SPREAD : (na / 2048 > 1024 ? 1024 : na / 2048);
-        hipLaunchKernelGGL(colour_assign_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
-                           (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.chosen, round, spread, w.overflow);
+        const int scan = (round == 0 && heavy_first.empty()) ? 0 : 1;
+        if (na < COLOUR_TEAM_BELOW) hipLaunchKernelGGL((colour_assign_k<true>), dim3((unsigned)na), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
+                                                       (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.chosen, round, spread, w.overflow, scan);
+        else hipLaunchKernelGGL((colour_assign_k<false>), dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
+                                (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.chosen, round, spread, w.overflow, scan);
+        // a crowded round asks the ROWS for its collisions (30 reads per row) -- a feature's walk reads 30 per row of its list: cheaper once few features are left
+        if (rows_ok && (double)na * ((double)m->nnz / (double)(p ? p : 1)) > (double)m->n) {
+          FMX_HIP(hipMemsetAsync(w.lose_f, 0, (size_t)p * sizeof(int), stream));
+          if (m->max_row_len <= 32) hipLaunchKernelGGL((colour_resolve_rows_k<32>), dim3(4096), dim3(WG_THREADS), 0, stream, (const int64_t*)m->row_ptr, (const uint32_t*)m->col, m->n, (const int*)w.fixed, (const int*)w.chosen, w.lose_f);
+          else hipLaunchKernelGGL((colour_resolve_rows_k<64>), dim3(4096), dim3(WG_THREADS), 0, stream, (const int64_t*)m->row_ptr, (const uint32_t*)m->col, m->n, (const int*)w.fixed, (const int*)w.chosen, w.lose_f);
+          hipLaunchKernelGGL(colour_lose_gather_k, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)w.act, na, (const int*)w.lose_f, (const int*)w.chosen, w.lose);
+        } else
         hipLaunchKernelGGL(colour_resolve_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)w.act, na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
                            (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, (const int*)w.chosen, w.lose);
         hipLaunchKernelGGL(colour_commit_k, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)w.act, na, (const int*)w.lose, (const int*)w.chosen, w.fixed);
@@ -1177,7 +1233,9 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
       // The spread that makes the rounds converge also spreads the colours (one-column-per-field data: 240 colours where 30 do).  REFIT, class by class from the
       // highest colour down: the features of one colour share no row, so all of them may move to their smallest free colour at once -- nothing they read changes
       // in that launch -- and the colouring stays proper, never grows, and usually loses most of its upper classes (four passes).
-      for (int pass = 0; pass < 4 && !failed; ++pass) {
+      const char* refit_env = getenv("FMX_COLOUR_REFIT");   // passes of the refit (default 4; read per plan: profiles/r05_colour_refit.txt)
+      const int refit_passes = refit_env ? atoi(refit_env) : 4;
+      for (int pass = 0; pass < refit_passes && !failed; ++pass) {
         std::vector<int> col_now(p);
         FMX_HIP(hipMemcpy(col_now.data(), w.fixed, (size_t)p * sizeof(int), hipMemcpyDeviceToHost));
         int top = -1;
@@ -1193,8 +1251,10 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
           const int na = (int)(at[(size_t)c + 1] - at[(size_t)c]);
           if (na == 0) continue;
           const unsigned grid = (unsigned)(na < 4 * 2048 ? (na + 3) / 4 : 2048);
-          hipLaunchKernelGGL(colour_assign_k, dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)(w.act + at[(size_t)c]), na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
-                             (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.fixed, 0, 1, w.overflow);
+          if (na < COLOUR_TEAM_BELOW) hipLaunchKernelGGL((colour_assign_k<true>), dim3((unsigned)na), dim3(WG_THREADS), 0, stream, (const uint32_t*)(w.act + at[(size_t)c]), na, (const int64_t*)m->col_ptr,
+                                                         (const uint32_t*)m->crow, (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.fixed, 0, 1, w.overflow, 1);
+          else hipLaunchKernelGGL((colour_assign_k<false>), dim3(grid), dim3(WG_THREADS), 0, stream, (const uint32_t*)(w.act + at[(size_t)c]), na, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow,
+                                  (const int64_t*)m->row_ptr, (const uint32_t*)m->col, (const int*)w.fixed, w.fixed, 0, 1, w.overflow, 1);
         }
         int h_over = 0;
         FMX_HIP(hipMemcpyAsync(&h_over, w.overflow, sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -385,3 +385,21 @@ def test_feature_major_fuzz(seed):
     g = e.als_vsweep(m, err0, alpha=0.9, v_lambda=lam, v_mu=mu, std_normals=zz)
     assert util.rel_err(g, fe) < 1e-9 and util.rel_err(e.get_params()[2], fv) < 1e-9, (k, z, p, n, gibbs, unit, kind)
     e.close(); m.close()
+
+
+@pytest.mark.parametrize("z,law", [(20, "uniform"), (40, "uniform"), (20, "zipf")])
+def test_row_wise_collision_test_gives_the_same_colouring(z, law, monkeypatch):
+    """Crowded rounds of the colouring find their collisions row by row (colour_resolve_rows_k: 32 or 64 lanes per row), sparse ones by the features' walk: the same
+    losers, so the same plan whichever runs (FMX_COLOUR_ROWS=0: the walk everywhere)."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 40_000, 6_000
+    plans = []
+    for rows in ("1", "0"):
+        monkeypatch.setenv("FMX_COLOUR_ROWS", rows)
+        m = engine.Matrix.synthetic_iid(n, p, z, 12, law=L.COLUMNS_ZIPF if law == "zipf" else L.COLUMNS_UNIFORM, zipf_s=1.05)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=4, mode=L.MODE_SEQUENTIAL, als_max_levels=-1)
+        levels, largest, _, level_of = e.als_plan(m)
+        assert e.als_plan_kind(m) == 2 and levels > 130          # (deeper than the exact walk's cut-off: the colouring ran)
+        plans.append((levels, largest, level_of.copy()))
+        e.close(); m.close()
+    assert plans[0][0] == plans[1][0] and plans[0][1] == plans[1][1] and np.array_equal(plans[0][2], plans[1][2])
