@@ -1631,12 +1631,9 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
         if (!e->als_lam_mu) FMX_HIP(hipMalloc(&e->als_lam_mu, (size_t)2 * 1024 * sizeof(double)));
         FMX_HIP(hipMemcpyAsync(e->als_lam_mu, lm.data(), lm.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         FMX_HIP(hipStreamSynchronize(e->stream));   // (lm is a local)
-        static bool attr_set = false;
-        if (!attr_set) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-          attr_set = true;
-        }
+        // (per sweep, not once per process: the attribute belongs to the CURRENT device's copy of the kernel, and engines may live on several devices)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         const int L = (int)m->als_level_ptr.size() - 1;
         const char* form_env = getenv("FMX_ALS_ALLF_FORM");   // 1: the LDS-resident kernel everywhere, 2: no one-wave kernel (read per call: the tests compare the forms)
         const int form = form_env ? atoi(form_env) : 0;
