@@ -6,6 +6,9 @@ sys.path.insert(0, ".")
 from fmwr_amd import _lib as L, engine
 from tests import util
 N, P, Z, K, SEED = 10_000_000, 1_000_000, 30, 16, 20240001
+if os.environ.get("BALLAST_GB"):   # experiment (profiles/r05_alloc_placement.txt): hold the first GBs of device memory so that the tables land beyond them
+    import torch
+    _ballast = torch.empty(int(float(os.environ["BALLAST_GB"]) * (1 << 30)), dtype=torch.uint8, device="cuda")
 STRAT = len(sys.argv) > 1 and sys.argv[1] == "stratified"   # configs[4]'s own generator (one column per stratum and row): ~30 colours of ~33 000 features
 m = engine.Matrix.synthetic(N, P, Z, SEED) if STRAT else engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_UNIFORM, zipf_s=1.05)
 e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
