@@ -125,7 +125,7 @@ __device__ __forceinline__ bool bad_number(double x);
 template <bool UNIT>
 __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow,
                                                                const float* __restrict__ cval, double* __restrict__ V, int k, int kp, double alpha, const double* __restrict__ lam_mu,
-                                                               const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe, int cap) {
+                                                               const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe, int cap, int eil) {   // eil: e rides in the line's spare last slot (k < kp) instead of the pair table
   extern __shared__ double lds_allf[];
   double* sQ = lds_allf;                                  // [kp][cap]: factor-major (a wave's threads read neighbouring rows of one factor: no bank conflicts, no padding)
   double* sOld = sQ + (size_t)kp * cap;                   // [kp] the feature's coordinates as the level finds them
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
     sZ[tid] = znorm ? znorm[(size_t)tid * zstride + j] : 0.0;
   }
 #pragma unroll
-  for (int u = 0; u < RPT; ++u) er[u] = qe[rr[u]].y;
+  for (int u = 0; u < RPT; ++u) er[u] = eil ? 0.0 : qe[rr[u]].y;
 #pragma unroll
   for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len) sRow[i] = rr[u]; }
   __syncthreads();
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
     }
   }
   __syncthreads();
+  if (eil) {
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len) er[u] = sQ[(size_t)(kp - 1) * cap + i]; }
+  }
   const bool gibbs = znorm != nullptr;
   for (int f = 0; f < k; ++f) {
     const double old = sOld[f];
@@ -210,6 +214,10 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
       if (i < len) { qw[i] -= (double)xr[u] * diff; er[u] -= hk[u] * diff; }   // :341-350
     }
   }
+  if (eil) {
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len) sQ[(size_t)(kp - 1) * cap + i] = er[u]; }
+  }
   __syncthreads();
   for (int i0 = 0; i0 < len; i0 += rpp) {
     const int i = i0 + grow;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
       *reinterpret_cast<double2*>(Q + (size_t)sRow[i] * kp + 2 * part) = make_double2(sQ[(size_t)(2 * part) * cap + i], sQ[(size_t)(2 * part + 1) * cap + i]);
   }
 #pragma unroll
-  for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len) qe[rr[u]].y = er[u]; }
+  for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len && !eil) qe[rr[u]].y = er[u]; }
 }
 
 // The same level with the rows' lines in REGISTERS (kp = 8 or 16, lists of up to 512 rows): thread t owns rows t and t + 256 -- their q lines (2 x kp doubles), e and x --
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_allf_k(const uint32_t* _
 #ifndef FMX_ALLF_KO
 #define FMX_ALLF_KO 0   // diagnostic builds (profiles/probes/allf_knockouts.sh): 1 no factor loop, 2 no q lines moved, 4 no e moved
 #endif
-template <bool UNIT, int KP>
+template <bool UNIT, int KP, bool EIL>   // EIL: e rides in the line's spare last slot (k < kp) instead of the pair table
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void als_level_allf_reg_k(
     const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval, double* __restrict__ V, int k,
     double alpha, const double* __restrict__ lam_mu, const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe) {
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     sZ[tid] = (znorm && tid < k) ? znorm[(size_t)tid * zstride + j] : 0.0;
   }
 #pragma unroll
-  for (int u = 0; u < RPT; ++u) er[u] = (FMX_ALLF_KO & 4) ? 0.5 : qe[rr[u]].y;
+  for (int u = 0; u < RPT; ++u) er[u] = (EIL || (FMX_ALLF_KO & 4)) ? 0.5 : qe[rr[u]].y;
 #pragma unroll
   for (int u = 0; u < RPT; ++u) sRow[tid + u * WG_THREADS] = rr[u];   // (slots past the list hold entry 0's row: loaded, never stored)
   __syncthreads();
@@ -288,6 +296,10 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
       for (int f = 0; f < KP; ++f) q[u][f] = 0.0;
     }
+  }
+  if (EIL) {
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) er[u] = q[u][KP - 1];
   }
   const bool gibbs = znorm != nullptr;
 #pragma unroll
@@ -328,6 +340,10 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       }
     }
   }
+  if (EIL) {
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) q[u][KP - 1] = er[u];
+  }
 #pragma unroll
   for (int u = 0; u < RPT; ++u) {
     if (u < npass) {
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
   }
 #pragma unroll
-  for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (i < len && (!(FMX_ALLF_KO & 4) || er[u] == 1e300)) qe[rr[u]].y = er[u]; }
+  for (int u = 0; u < RPT; ++u) { const int i = tid + u * WG_THREADS; if (!EIL && i < len && (!(FMX_ALLF_KO & 4) || er[u] == 1e300)) qe[rr[u]].y = er[u]; }
 }
 
 // ONE WAVE per feature (kp = 8 or 16, lists of up to 64 x RPT rows, RPT <= 6).  The knock-outs of the 256-thread kernel (profiles/r05_allf_knockouts.txt) put 32 of a
@@ -360,7 +376,7 @@ __device__ __forceinline__ double wave_allsum(double x) {
   x += FMX_DPP64(x, 0x140);   // row_mirror: the other eight of the row of 16
   return ((lane_f64(x, 0) + lane_f64(x, 16)) + lane_f64(x, 32)) + lane_f64(x, 48);
 }
-template <bool UNIT, int KP, int RPT>
+template <bool UNIT, int KP, int RPT, bool EIL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMX_ALLF_WPE, FMX_ALLF_WPE))) void als_level_allf_wave_k(
     const uint32_t* __restrict__ feats, int n_feats, const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval, double* __restrict__ V, int k,
     double alpha, const double* __restrict__ lam_mu, const double* __restrict__ znorm, int64_t zstride, double* __restrict__ Q, double2* __restrict__ qe) {
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMX_ALLF_WPE
       xr[u] = i < len ? (UNIT ? 1.0f : cval[tc]) : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < RPT; ++u) { const double ev = (FMX_ALLF_KO & 4) ? 0.5 : qe[rr[u]].y; er[u] = lane + u * 64 < len ? ev : 0.0; }
+    for (int u = 0; u < RPT; ++u) { const double ev = (EIL || (FMX_ALLF_KO & 4)) ? 0.5 : qe[rr[u]].y; er[u] = lane + u * 64 < len ? ev : 0.0; }
 #pragma unroll
     for (int u = 0; u < RPT; ++u) sRow[lane + u * 64] = rr[u];
   }
@@ -412,6 +428,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMX_ALLF_WPE
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef FMX_ALLF_ISSUE
+  if (EIL) {   // (slots past the list's end were unpacked as zeros: e = 0 there too)
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) er[u] = q[u][KP - 1];
+  }
   const bool gibbs = znorm != nullptr;
   double vnew = vold;
 #pragma unroll
@@ -444,6 +464,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMX_ALLF_WPE
     }
   }
   if (lane < k) V[(size_t)j * KP + lane] = vnew;
+  if (EIL) {
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) q[u][KP - 1] = er[u];
+  }
 #pragma unroll
   for (int u = 0; u < RPT; ++u) {
 #pragma unroll
@@ -456,7 +480,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMX_ALLF_WPE
     }
   }
 #pragma unroll
-  for (int u = 0; u < RPT; ++u) { const int i = lane + u * 64; if (i < len && (!(FMX_ALLF_KO & 4) || er[u] == 1e300)) qe[sRow[i]].y = er[u]; }
+  for (int u = 0; u < RPT; ++u) { const int i = lane + u * 64; if (!EIL && i < len && (!(FMX_ALLF_KO & 4) || er[u] == 1e300)) qe[sRow[i]].y = er[u]; }
+}
+
+// k < kp: the row's line has a spare last slot, and e rides there for the length of a feature-major sweep -- the 8 bytes of e otherwise cost a 128-byte line in and a
+// partial line out per row and level, 43 % of a row's memory time (profiles/r05_allf_knockouts.txt (e)).  In from the pairs before the first level, back after the last.
+__global__ void allf_e_enter_k(double* __restrict__ Q, const double2* __restrict__ qe, int64_t n, int kp) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) Q[(size_t)r * kp + (kp - 1)] = qe[r].y;
+}
+__global__ void allf_e_exit_k(const double* __restrict__ Q, double2* __restrict__ qe, int64_t n, int kp) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) qe[r].y = Q[(size_t)r * kp + (kp - 1)];
 }
 
 // ---- the COLOURED order (cfg.als_max_levels < 0) -----------------------------------------------------------------------------------------
@@ -1638,34 +1673,45 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
         const char* form_env = getenv("FMX_ALS_ALLF_FORM");   // 1: the LDS-resident kernel everywhere, 2: no one-wave kernel (read per call: the tests compare the forms)
         const int form = form_env ? atoi(form_env) : 0;
         const bool in_regs = (e->kp64 == 8 || e->kp64 == 16) && form != 1;
+        // k < kp: e rides in the spare last slot of the rows' lines for the length of the sweep (allf_e_enter_k above); FMX_ALS_ALLF_EIL=0: in the pair table as at k = kp (tests: the same bits)
+        const char* eil_env = getenv("FMX_ALS_ALLF_EIL");
+        const bool eil = e->k < e->kp64 && !(eil_env && eil_env[0] == '0');
+        const unsigned row_grid = (unsigned)((m->n + 255) / 256);
+        if (eil) hipLaunchKernelGGL(allf_e_enter_k, dim3(row_grid), dim3(256), 0, e->stream, d_Qr, (const double2*)d_qe, m->n, e->kp64);
         for (int l = 0; l < L; ++l) {
           const int64_t l0 = m->als_level_ptr[(size_t)l], cnt = m->als_level_ptr[(size_t)l + 1] - l0;
           if (cnt == 0) continue;
           const int cap = (int)((m->als_level_maxlen[(size_t)l] + 63) / 64 * 64);
           const size_t lds = ((size_t)cap * e->kp64 + 2 * (size_t)e->kp64) * sizeof(double) + (size_t)cap * sizeof(uint32_t);
           prof_begin(e, FMX_KERNEL_ALS_SWEEP);
+#define FMX_ALLF_ARGS (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, alpha, \
+                      (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe
           if (in_regs && form != 2 && cap <= 384) {   // one wave per feature
-#define FMX_ALLF_WAVE(U, KPv, R) hipLaunchKernelGGL((als_level_allf_wave_k<U, KPv, R>), dim3((unsigned)cnt), dim3(64), 0, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, \
-                                 (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe)
-#define FMX_ALLF_WAVE_R(U, KPv) do { if (cap <= 128) FMX_ALLF_WAVE(U, KPv, 2); else if (cap <= 256) FMX_ALLF_WAVE(U, KPv, 4); else FMX_ALLF_WAVE(U, KPv, 6); } while (0)
-            if (e->kp64 == 16) { if (m->unit_values) FMX_ALLF_WAVE_R(true, 16); else FMX_ALLF_WAVE_R(false, 16); }
-            else { if (m->unit_values) FMX_ALLF_WAVE_R(true, 8); else FMX_ALLF_WAVE_R(false, 8); }
+#define FMX_ALLF_WAVE(U, KPv, R, E) hipLaunchKernelGGL((als_level_allf_wave_k<U, KPv, R, E>), dim3((unsigned)cnt), dim3(64), 0, e->stream, FMX_ALLF_ARGS)
+#define FMX_ALLF_WAVE_R(U, KPv, E) do { if (cap <= 128) FMX_ALLF_WAVE(U, KPv, 2, E); else if (cap <= 256) FMX_ALLF_WAVE(U, KPv, 4, E); else FMX_ALLF_WAVE(U, KPv, 6, E); } while (0)
+#define FMX_ALLF_WAVE_E(U, KPv) do { if (eil) FMX_ALLF_WAVE_R(U, KPv, true); else FMX_ALLF_WAVE_R(U, KPv, false); } while (0)
+            if (e->kp64 == 16) { if (m->unit_values) FMX_ALLF_WAVE_E(true, 16); else FMX_ALLF_WAVE_E(false, 16); }
+            else { if (m->unit_values) FMX_ALLF_WAVE_E(true, 8); else FMX_ALLF_WAVE_E(false, 8); }
+#undef FMX_ALLF_WAVE_E
 #undef FMX_ALLF_WAVE_R
 #undef FMX_ALLF_WAVE
-          } else
-          if (in_regs && m->als_level_maxlen[(size_t)l] <= 512) {   // the rows' lines in registers: four workgroups per CU
-#define FMX_ALLF_REG(U, KPv) hipLaunchKernelGGL((als_level_allf_reg_k<U, KPv>), dim3((unsigned)cnt), dim3(WG_THREADS), 0, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, \
-                             (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe)
-            if (e->kp64 == 16) { if (m->unit_values) FMX_ALLF_REG(true, 16); else FMX_ALLF_REG(false, 16); }
-            else { if (m->unit_values) FMX_ALLF_REG(true, 8); else FMX_ALLF_REG(false, 8); }
+          } else if (in_regs && m->als_level_maxlen[(size_t)l] <= 512) {   // the rows' lines in registers: four workgroups per CU
+#define FMX_ALLF_REG(U, KPv, E) hipLaunchKernelGGL((als_level_allf_reg_k<U, KPv, E>), dim3((unsigned)cnt), dim3(WG_THREADS), 0, e->stream, FMX_ALLF_ARGS)
+#define FMX_ALLF_REG_E(U, KPv) do { if (eil) FMX_ALLF_REG(U, KPv, true); else FMX_ALLF_REG(U, KPv, false); } while (0)
+            if (e->kp64 == 16) { if (m->unit_values) FMX_ALLF_REG_E(true, 16); else FMX_ALLF_REG_E(false, 16); }
+            else { if (m->unit_values) FMX_ALLF_REG_E(true, 8); else FMX_ALLF_REG_E(false, 8); }
+#undef FMX_ALLF_REG_E
 #undef FMX_ALLF_REG
-          } else
-          if (m->unit_values) hipLaunchKernelGGL((als_level_allf_k<true>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,
-                                                 (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap);
-          else hipLaunchKernelGGL((als_level_allf_k<false>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,
-                                  (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap);
+          } else if (m->unit_values)
+            hipLaunchKernelGGL((als_level_allf_k<true>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,
+                               (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap, eil ? 1 : 0);
+          else
+            hipLaunchKernelGGL((als_level_allf_k<false>), dim3((unsigned)cnt), dim3(WG_THREADS), lds, e->stream, (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr,
+                               (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap, eil ? 1 : 0);
+#undef FMX_ALLF_ARGS
           prof_end(e);
         }
+        if (eil) hipLaunchKernelGGL(allf_e_exit_k, dim3(row_grid), dim3(256), 0, e->stream, (const double*)d_Qr, d_qe, m->n, e->kp64);
         FMX_HIP(hipGetLastError());
         return FMX_OK;
       }

@@ -403,3 +403,32 @@ def test_row_wise_collision_test_gives_the_same_colouring(z, law, monkeypatch):
         plans.append((levels, largest, level_of.copy()))
         e.close(); m.close()
     assert plans[0][0] == plans[1][0] and plans[0][1] == plans[1][1] and np.array_equal(plans[0][2], plans[1][2])
+
+
+@pytest.mark.parametrize("k,n,p", [(11, 9_000, 700), (5, 9_000, 1_500), (13, 12_000, 300), (3, 6_000, 600)])
+def test_e_in_the_lines_spare_slot(k, n, p, monkeypatch):
+    """k < kp: for the length of a feature-major sweep e rides in the spare last slot of the rows' lines (one line per row and level instead of a line and a pair);
+    FMX_ALS_ALLF_EIL=0 keeps it in the pair table as at k = kp.  Only where e is stored differs: the same bits (wave, 256-thread and LDS kernels; kp 4, 8, 16)."""
+    from fmwr_amd import _lib as L, engine
+    m0 = engine.Matrix.synthetic_iid(n, p, 20, 55, law=L.COLUMNS_UNIFORM)
+    rp, col, val, _ = m0.export(); m0.close()
+    val = np.random.default_rng(9).uniform(0.2, 1.0, len(val)).astype(np.float32)
+    y = util.labels(n, 55, "regression")
+    w0, w, v = util.params(p, k, 75, stdev=0.1, fp32=False)
+    lam = np.linspace(10.0, 20.0, k)
+    z = np.random.default_rng(19).normal(0, 1, (k, p))
+    err0 = np.random.default_rng(20).normal(0, 1, n)
+    out = []
+    for eil in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_ALLF_EIL", eil)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        e.als_plan(m)
+        assert e.als_plan_kind(m) == 3
+        g1 = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, std_normals=z)
+        g2 = e.als_vsweep(m, g1, alpha=1.1, v_lambda=lam, std_normals=z)
+        out.append((g1, g2, e.get_params()[2].copy()))
+        e.close(); m.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
