@@ -294,12 +294,13 @@ def test_feature_major_edges(k, p, n, note):
     e.close(); m.close()
 
 
-def test_learners_on_a_feature_major_plan():
+@pytest.mark.parametrize("k", [8, 6])   # (6: k < kp = 8 -- e rides in the lines' spare slot during the V sweep)
+def test_learners_on_a_feature_major_plan(k):
     """The learners' loops on a cfg.als_max_levels = -2 plan.  The w sweep goes in (colour, index) order: without a V sweep the ALS learner IS the oracle's learner on
     the relabelled matrix.  With the V sweep nested feature-major there is no oracle run to compare with -- exact coordinate steps of the least-squares
     objective never raise it, in any order, and the run is bit for bit reproducible; the MCMC learner's draws stay finite and reproducible."""
     from fmwr_amd import _lib as L, engine
-    n, p, k = 5_000, 1_200, 8
+    n, p = 5_000, 1_200
     m0 = engine.Matrix.synthetic_iid(n, p, Z, 41, law=L.COLUMNS_UNIFORM)
     rp, col, val, _ = m0.export(); m0.close()
     val = np.random.default_rng(2).uniform(0.3, 1.0, len(val)).astype(np.float32)
