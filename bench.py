@@ -784,7 +784,7 @@ def main_sweep(args, rank, local_rank, world):
                                              "ceiling_frac": got / r if r else None,
                                              "note": "entries per second of a level over the measured rate of random 16-B gathers from the whole (q, e) table (the untiled form does a gather AND a scatter "
                                                      "per entry against it: at most 0.5; the row-tiled and level-order forms keep their random accesses inside L2-resident slices or LDS and are not bound by it)"}
-    if blocks and world == 1 and not fmajor:
+    if (blocks or fmajor) and world == 1:
         # opt-in variant (fmx_als_carry_q): the sweep keeps q = X v_f current as it goes, so sweep t + 1 needs no forward pass to rebuild it.  NOT `value`: the reference
         # recomputes q for every factor of every sweep, and `value` above does one forward pass per sweep for it
         e.als_carry_q(True)
@@ -797,8 +797,10 @@ def main_sweep(args, rank, local_rank, world):
         e.als_carry_q(False)
         ssc = float((d_err * d_err).sum().item())
         out["value_q_carried"] = {"value": n * args.steps / dtc, "unit": "examples/s", "ms_per_step": dtc / args.steps * 1e3, "finite": bool(np.isfinite(ssc)),
-                                  "note": "fmx_als_carry_q(1): q = X v_f is written back as each factor's pairs move on and reused by the next sweep when V's 64-bit fingerprint is "
-                                          "unchanged (no forward pass; rebuilt every 64th sweep); agrees with the rebuilt form to ~1e-13 (tests/test_gpu_configs4.py)"}
+                                  "note": ("fmx_als_carry_q(1): the feature-major sweep corrects every q_f of every row as it goes, so the table it leaves is X v_f of the new V; reused by the next sweep when V's 64-bit "
+                                           "fingerprint is unchanged (no forward pass; rebuilt every 64th sweep); agrees with the rebuilt form to rounding (tests/test_gpu_coloured.py)") if fmajor else
+                                          ("fmx_als_carry_q(1): q = X v_f is written back as each factor's pairs move on and reused by the next sweep when V's 64-bit fingerprint is "
+                                           "unchanged (no forward pass; rebuilt every 64th sweep); agrees with the rebuilt form to ~1e-13 (tests/test_gpu_configs4.py)")}
     if world == 1 and not args.real_values and not args.no_extras:
         # SURVEY 8(d)'s value variant, timed once per run: the same shape with U(0, 1) values (6 144-pair blocks, the entry values in LDS beside the pairs)
         try:

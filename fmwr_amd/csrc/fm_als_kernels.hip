@@ -1659,8 +1659,18 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
       a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Qr; a.qout_t = 0; a.link = FMX_LINK_NONE;   // q of every factor, ROW-major: [n][kp]
       a.unit = m->unit_values; a.no_w = 1;
       const bool trusted = e->als_q_trusted == (m->uid ^ ALLF_TRUSTED);   // the learner's own forward pass of this iteration left the table (launch_als_train): V untouched since
+      // ... or carried from the previous sweep (opt-in, fmx_als_carry_q): the sweep corrects every q_f of every row as it goes, so the table it leaves IS X v_f of the
+      // new V (to rounding); valid while V is bit for bit what that sweep left (64-bit fingerprint) and for 64 sweeps at most
+      bool carried = false;
+      const uint64_t carry_key = (m->uid ^ ALLF_TRUSTED) ^ ((uint64_t)m->value_generation << 40);   // (this matrix, these values)
+      if (!trusted && e->als_carry_q && e->als_q_have && e->als_q_plan == carry_key && e->als_q_age < 64) {
+        uint64_t hsh = 0;
+        FMX_TRY(als_vhash(e, &hsh));
+        carried = hsh == e->als_q_hash;
+      }
+      const int carried_age = carried ? e->als_q_age : 0;
       e->als_q_have = 0; e->als_q_trusted = 0;
-      if (trusted || launch_rows_forward(e, a, false, true) == FMX_OK) {
+      if (trusted || carried || launch_rows_forward(e, a, false, true) == FMX_OK) {
         std::vector<double> lm((size_t)2 * e->k, 0.0);
         for (int f = 0; f < e->k; ++f) { lm[(size_t)2 * f] = h_lambda ? h_lambda[f] : 0.0; lm[(size_t)2 * f + 1] = h_mu ? h_mu[f] : 0.0; }
         if (!e->als_lam_mu) FMX_HIP(hipMalloc(&e->als_lam_mu, (size_t)2 * 1024 * sizeof(double)));
@@ -1712,6 +1722,11 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
           prof_end(e);
         }
         if (eil) hipLaunchKernelGGL(allf_e_exit_k, dim3(row_grid), dim3(256), 0, e->stream, (const double*)d_Qr, d_qe, m->n, e->kp64);
+        if (e->als_carry_q) {   // the table now holds X v_f of the new V, every factor (at k < kp the spare slot holds e: the next sweep's enter overwrites it)
+          uint64_t hsh = 0;
+          FMX_TRY(als_vhash(e, &hsh));
+          e->als_q_hash = hsh; e->als_q_plan = carry_key; e->als_q_age = carried_age + 1; e->als_q_have = 1;
+        }
         FMX_HIP(hipGetLastError());
         return FMX_OK;
       }

@@ -555,7 +555,7 @@ class Engine:
         return done.value
 
     def als_carry_q(self, on=True):
-        """Opt-in: the block form of the V sweep keeps q = X v_f current from sweep to sweep and skips the forward pass that rebuilds it (fmx_als_carry_q)."""
+        """Opt-in: the block form and the feature-major form (als_max_levels = -2) of the V sweep keep q = X v_f current from sweep to sweep and skip the forward pass that rebuilds it (fmx_als_carry_q)."""
         L.check(L.lib().fmx_als_carry_q(self.h, C.c_int32(int(on))))
 
     def als_train(self, m, max_iter, with_v=False):

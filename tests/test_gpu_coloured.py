@@ -433,3 +433,35 @@ def test_e_in_the_lines_spare_slot(k, n, p, monkeypatch):
         e.close(); m.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("k", [16, 12])
+def test_feature_major_carried_q(k):
+    """fmx_als_carry_q on a feature-major plan: the sweep corrects every q_f as it goes, so the table it leaves is X v_f of the new V and the next sweep skips its forward
+    pass -- as long as V is bit for bit what the sweep left (fingerprint) and the matrix's values are the same.  Agrees with the rebuilt form to rounding; a
+    fmx_set_params or redrawn values in between are noticed."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 9_000, 900
+    w0, w, v = util.params(p, k, 76, stdev=0.1, fp32=False)
+    lam = np.linspace(0.2, 0.8, k)
+    err0 = np.random.default_rng(4).normal(0, 1, n)
+    res = {}
+    for carry in (True, False):
+        m = engine.Matrix.synthetic_iid(n, p, 20, 78, law=L.COLUMNS_UNIFORM).synthetic_values(3)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=-2)
+        e.set_params(w0, w, v)
+        e.als_carry_q(carry)
+        assert e.als_plan(m)[0] > 0 and e.als_plan_kind(m) == 3
+        g = err0
+        out = []
+        for it in range(4):
+            g = e.als_vsweep(m, g, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
+        e.set_params(w0, w, v * 0.5)                               # V replaced behind the table's back
+        g = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
+        g = e.als_vsweep(m, g, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
+        m.synthetic_values(8)                                      # the matrix's values redrawn: q = X v is another table
+        g = e.als_vsweep(m, g, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
+        res[carry] = out
+        e.close(); m.close()
+    for (ga, va), (gb, vb) in zip(res[True], res[False]):
+        assert util.rel_err(ga, gb) < 1e-10 and util.rel_err(va, vb) < 1e-10
