@@ -11,7 +11,9 @@ tiles.  N > 1: one process per GPU (torch.distributed / RCCL), each rank owns a 
 sums, exchanges them (dense: the (k+2)*p buffer is all-reduced in pipelined blocks; compact: records of the occurring
 features are all-gathered), every replica applies the same update ("scaling": "weak": per-GPU rows per step are fixed).
 
-Rank 0 prints ONE JSON line.  `value` is whole-job examples/s of the timed steps.  `roofline` prices the step in SURVEY
+Rank 0's LAST stdout line is the ONE JSON line the driver parses (driver_line(): at most LINE_LIMIT = 4000 bytes -- metric, config, roofline, cpu_baseline and a
+flat summary of the side runs); everything else the run measured is printed BEFORE it as one line prefixed `DETAILS ` and left in bench_details.json.
+`value` is whole-job examples/s of the timed steps.  `roofline` prices the step in SURVEY
 8(d)'s algorithmic bytes (the headline `frac`) and each of the two kernels on its own bytes and HIP-event time, next to the
 measured ceiling of the access pattern (`ceiling_frac`).  At N == 1 the same line also carries what `value` leaves out:
 `end_to_end` (with the one-off per-tile CSC build), `value_fp64_state`, `small_batch`, `sequential_exact` (the mode the
@@ -62,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--sweep-iid", action="store_true",
                     help="--solver als / mcmc: the V sweep on SURVEY 8(d)'s i.i.d. uniform columns in the feature-major COLOURED order (cfg.als_max_levels = -2); default: one column per stratum")
     ap.add_argument("--sweep-feature-major", action="store_true", help="--solver als / mcmc on the default one-column-per-stratum matrix: cfg.als_max_levels = -2 (the exact schedule's levels as colours, all k factors of a feature stepped together)")
+    ap.add_argument("--sweep-exact", action="store_true", help="--sweep-iid: the reference's own index order on the i.i.d. law (cfg.als_max_levels = 0: the exact schedule, ~19 400 dependent levels at 10 M x 1 M) -- "
+                    "configs[4] on SURVEY 8(d)'s law with the reference's numbers")
     ap.add_argument("--sweep-factor-outer", action="store_true", help="--sweep-iid: the coloured order with the reference's factor-outer nesting (cfg.als_max_levels = -1)")
     ap.add_argument("--real-values", action="store_true", help="SURVEY 8(d)'s value variant: val ~ U(0,1) instead of 1 (fmx_matrix_synthetic_values): the kernels then read the value arrays")
     ap.add_argument("--seed", type=int, default=20240001)
@@ -181,7 +185,7 @@ def pmc_traffic_sweep(args, tiled, ordered=False, blocks=False, fmajor=False):
         a = d.get("_bench_args", [])
         if ("als" in a) != (args.solver == "als") or args.rows != 10_000_000 or args.features != 1_000_000:
             continue
-        if any((flag in a) != bool(getattr(args, flag[2:].replace("-", "_"))) for flag in ("--sweep-iid", "--sweep-feature-major", "--sweep-factor-outer", "--real-values")):
+        if any((flag in a) != bool(getattr(args, flag[2:].replace("-", "_"))) for flag in ("--sweep-iid", "--sweep-feature-major", "--sweep-factor-outer", "--sweep-exact", "--real-values")):
             continue                                       # (another column law, nesting or value law: another kernel's counters)
         if fmajor:
             if "als_level_allf" in d and "fabric_bytes_per_launch" in d["als_level_allf"]:
@@ -627,7 +631,8 @@ def main_sweep(args, rank, local_rank, world):
     gibbs = args.solver == "mcmc"
     dev = torch.device("cuda", local_rank)
     iid = bool(args.sweep_iid)
-    fmajor = (iid and not args.sweep_factor_outer) or bool(args.sweep_feature_major)   # cfg.als_max_levels = -2
+    exact_iid = iid and bool(args.sweep_exact)                                           # cfg.als_max_levels = 0 on the i.i.d. law: the reference's order, a chain of dependent levels
+    fmajor = (iid and not args.sweep_factor_outer and not exact_iid) or bool(args.sweep_feature_major)   # cfg.als_max_levels = -2
     if iid:   # SURVEY 8(d)'s i.i.d. law: no field structure -- the reference's feature order is a chain of ~20 000 levels there; the coloured order (exact steps, the engine's own order) is what is timed
         m = engine.Matrix.synthetic_iid(n, p, z, args.seed, law=L.COLUMNS_UNIFORM, row_offset=rank * n, device=local_rank)
     else:
@@ -635,7 +640,7 @@ def main_sweep(args, rank, local_rank, world):
     if args.real_values:                         # SURVEY 8(d)'s value variant: U(0, 1) instead of the one-hot 1.0 (the sweep kernels then read the value arrays)
         m.synthetic_values(args.seed + 1, row_offset=rank * n)
     e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, device=local_rank,
-                      als_max_levels=-2 if fmajor else -1 if iid else 0)
+                      als_max_levels=-2 if fmajor else 0 if exact_iid else -1 if iid else 0)
     e.init_normal(args.seed, 0.0, 0.01)          # V0 ~ N(0, 0.01), w0 = w = 0
     t0 = time.perf_counter()
     levels, largest, approx, _ = e.als_plan(m)   # CSC of the whole matrix + the level plan: ingest, outside the timed region
@@ -697,24 +702,32 @@ def main_sweep(args, rank, local_rank, world):
         b_launch *= k
     gbs = b_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
     step_gbs = 40.0 * nnz * k / (dt / args.steps) / 1e9
-    form = (("als_level_k on the colours' levels (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q_f, e) per entry and factor)" if args.sweep_factor_outer else
-             "als_level_allf_wave_k on the colours' levels: ONE WAVE per feature gathers its rows' state (e and the 128-byte line of all k values q_f, 8 lanes per line) into registers, steps the k factors there "
-             "(wave sums by DPP, no barrier), writes the lines back; lists over 384 rows take a 256-thread workgroup (lines in registers to 512 rows, in LDS beyond)")
-            if iid or fmajor else
-            "level-order, block form: the level's (q, e) array is feature-block-major (blocks of consecutive features holding at most 8192 rows); ONE kernel per level, "
-            "als_block_level_pipe_k: a resident workgroup per CU streams a block's pairs into LDS at their feature-sorted slots, sums its lists, takes the coordinate steps "
-            "and corrects the pairs there, and stores them as contiguous runs into the next level's blocks while the next block's pairs are already in flight"
-            if blocks else
-            f"level-order: the (q, e) pairs kept in the list order of the level that consumes them next ({n_tiles} tiles of {tile_rows} rows): als_order_sums_k (streams the pairs, sums the lists, "
-            "takes the coordinate steps) + als_order_apply_k (corrections, every pair written to its place in the next level's order: a permutation inside the tile's L2-resident slice)"
-            if ordered else
-            f"row-tiled: als_tile_sums_k ({n_tiles} tiles of {tile_rows} rows, each tile's (q, e) slice gathered from its XCD's L2) + als_tile_step_k + als_rows_apply_k (row-major corrections)"
-            if tiled else "als_level_k (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q, e) per entry)")
+    if exact_iid:
+        form = ("the exact schedule on i.i.d. columns: the reference's index order as levels of row-disjoint features, every level a dependent step of the sweep "
+                "(at most ~100 short lists: latency, not bytes)")
+    elif iid and args.sweep_factor_outer:
+        form = "als_level_k on the colours' levels (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q_f, e) per entry and factor)"
+    elif iid or fmajor:
+        form = ("als_level_allf_wave_k on the colours' levels: ONE WAVE per feature gathers its rows' state (e and the 128-byte line of all k values q_f, 8 lanes per line) into registers, steps the k "
+                "factors there (wave sums by DPP, no barrier), writes the lines back; lists over 384 rows take a 256-thread workgroup (lines in registers to 512 rows, in LDS beyond)")
+    elif blocks:
+        form = ("level-order, block form: the level's (q, e) array is feature-block-major (blocks of consecutive features holding at most 8192 rows); ONE kernel per level, "
+                "als_block_level_pipe_k: a resident workgroup per CU streams a block's pairs into LDS at their feature-sorted slots, sums its lists, takes the coordinate steps "
+                "and corrects the pairs there, and stores them as contiguous runs into the next level's blocks while the next block's pairs are already in flight")
+    elif ordered:
+        form = (f"level-order: the (q, e) pairs kept in the list order of the level that consumes them next ({n_tiles} tiles of {tile_rows} rows): als_order_sums_k (streams the pairs, sums the lists, "
+                "takes the coordinate steps) + als_order_apply_k (corrections, every pair written to its place in the next level's order: a permutation inside the tile's L2-resident slice)")
+    elif tiled:
+        form = f"row-tiled: als_tile_sums_k ({n_tiles} tiles of {tile_rows} rows, each tile's (q, e) slice gathered from its XCD's L2) + als_tile_step_k + als_rows_apply_k (row-major corrections)"
+    else:
+        form = "als_level_k (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q, e) per entry)"
     out = {
         "metric": f"V-sweep examples/sec, {shape_tag(n, p)} sparse FM " + ("MCMC Gibbs" if gibbs else "ALS") + " sweep over V columns",
         "value": world * n * args.steps / dt, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"synthetic {n}x{p}, {z} nnz/row, i.i.d. uniform columns (SURVEY 8(d)'s law): the COLOURED order of the sweep (cfg.als_max_levels = {-1 if args.sweep_factor_outer else -2}: every coordinate step "
+        "config": {"workload": (f"synthetic {n}x{p}, {z} nnz/row, i.i.d. uniform columns (SURVEY 8(d)'s law), the reference's index order (cfg.als_max_levels = 0: the exact schedule), k={k}, "
+                                f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4] on the contract's column law); a step = one sweep of all {k} factors") if exact_iid else
+                               (f"synthetic {n}x{p}, {z} nnz/row, i.i.d. uniform columns (SURVEY 8(d)'s law): the COLOURED order of the sweep (cfg.als_max_levels = {-1 if args.sweep_factor_outer else -2}: every coordinate step "
                                 f"exact, the features visited in the order of a colouring of the share-a-row graph instead of the reference's index order, which is a chain of ~20 000 dependent levels here"
                                 + ("" if args.sweep_factor_outer else "; all k factors of a feature are stepped while its rows' state is on the chip: coordinates in (colour, feature, factor) order") + "), "
                                 f"k={k}, {'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns; a step = one sweep of all {k} factors") if iid else
@@ -726,7 +739,7 @@ def main_sweep(args, rank, local_rank, world):
                                f"schedule is {z} levels; i.i.d. columns need thousands of dependent levels and take the approximate groups instead), k={k}, "
                                f"{'MCMC.solver Gibbs' if gibbs else 'ALS.solver'} sweep over V columns (BASELINE.json configs[4]); "
                                f"a step = one sweep of all {k} factors over all rows (every example is visited once per factor)",
-                   "levels": levels, "largest_level": largest, "approximate": bool(approx) and not (iid or fmajor), "feature_order": ("coloured, factor outer (exact steps)" if args.sweep_factor_outer else "coloured, feature-major (exact steps)") if iid else "the reference's feature order, all k factors of a feature together (exact steps; the reference nests factor outer)" if fmajor else "the reference's", "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
+                   "levels": levels, "largest_level": largest, "approximate": bool(approx) and not (iid or fmajor), "feature_order": "the reference's" if exact_iid else ("coloured, factor outer (exact steps)" if args.sweep_factor_outer else "coloured, feature-major (exact steps)") if iid else "the reference's feature order, all k factors of a feature together (exact steps; the reference nests factor outer)" if fmajor else "the reference's", "levels_per_step": launches, "levels_row_tiled": tiled, "level_order_form": ("blocks" if blocks else "tiles") if ordered else False,
                    "plan_build_s": plan_s, "residual_sum_squares": [ss0, ss1], "state": "fp64 V[p][k], fp64 (q, e) pairs per row",
                    "parallelism": f"replicas{world}" if world > 1 else "dp1"},
         "roofline": {"bound": "hbm", "kernel": "one level of one factor: " + form, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -736,8 +749,20 @@ def main_sweep(args, rank, local_rank, world):
                      "q_build_forward_ms": fwd_ms / max(fwd_n, 1) if fwd_n else None},
     }
     tr = pmc_traffic_sweep(args, bool(tiled), ordered, blocks, fmajor)
+    out["roofline"]["frac_basis"] = "algorithmic"
     if tr:
         out["roofline"]["traffic"] = tr[0]
+        out["roofline"]["traffic_ratio"] = tr[0] / b_launch
+        if tr[0] < 0.95 * b_launch and per_launch_ms > 0:
+            # the launch moves FEWER bytes than SURVEY 8(d) prices for it (this form does not do what the formula's 40 B describe): the priced figure is a speed-up over the
+            # priced design, not memory utilisation.  `frac` = counted bytes / time / peak; the priced figure stays beside it as `effective_frac`
+            rf = out["roofline"]
+            rf["effective_achieved"], rf["effective_frac"] = rf["achieved"], rf["frac"]
+            rf["achieved"] = tr[0] / (per_launch_ms * 1e-3) / 1e9
+            rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
+            rf["frac_basis"] = "traffic"
+            rf["frac_basis_note"] = ("counter traffic of one launch (traffic_source) over this run's launch time / peak; effective_frac = SURVEY 8(d)'s 40 B per nonzero and factor over the same time, "
+                                     "bytes this form does not move")
         out["roofline"]["traffic_source"] = (f"profiles/{tr[1]}: fabric bytes of one launch by request size (128 x RDREQ_128B + 64 x the other reads + WRITE_SIZE), separate --pmc passes" if blocks or fmajor else
                                              f"profiles/{tr[1]}: (FETCH_SIZE*2 + WRITE_SIZE) KiB summed over the launches of one level, separate --pmc passes; upper bound, DESIGN.md section 6")
     if fmajor:
@@ -821,7 +846,7 @@ def main_sweep(args, rank, local_rank, world):
             e2.close(); m2.close(); del d2
         except Exception as ex:
             out["value_real_values"] = {"error": f"{type(ex).__name__}: {ex}"}
-    if world == 1:
+    if world == 1 and not exact_iid:
         # the whole learner iteration around the sweep -- forward, residual, w0 step, w sweep (30 levels, three-pass tiled form), V sweep (480 levels) --
         # through fmx_als_train(with_v = 1) (MCMC_ALS_Learner::learn, :91-156, with the update_v call the shipped update_all leaves out)
         try:
@@ -980,6 +1005,105 @@ def main_in_library(args):
     })
 
 
+LINE_LIMIT = 4000   # bytes of the LAST stdout line (the driver parses that line; r05's 26.7 KB line came back unparsed)
+
+
+def _num(x):
+    """floats to 6 significant digits (the line's budget is bytes)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.6g}")
+
+
+def _cap(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
+
+
+def _frac_entry(d):
+    """one `other_configs` summary entry: what a side run is worth in four figures"""
+    if d is None or "error" in d:
+        return d
+    r = d.get("roofline", {})
+    e = {"value": _num(d["value"]), "ms_per_step": _num(d["ms_per_step"]), "frac": _num(r.get("frac")), "frac_basis": r.get("frac_basis", "algorithmic")}
+    for kk in ("effective_frac", "traffic_ratio"):
+        if r.get(kk) is not None:
+            e[kk] = _num(r[kk])
+    cb = d.get("cpu_baseline")
+    if isinstance(cb, dict) and "value" in cb:
+        e["cpu_value"] = _num(cb["value"])
+    return e
+
+
+def driver_line(d):
+    """The ONE line the driver parses: BASELINE.json's metric / config, `roofline`, `cpu_baseline` and a flat summary of the side runs, at most LINE_LIMIT
+    bytes.  Everything else the run measured goes to an earlier stdout line prefixed `DETAILS ` and to bench_details.json (emit())."""
+    r, cfg = d.get("roofline", {}), d.get("config", {})
+    line = {kk: _num(d[kk]) for kk in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if kk in d}
+    line["config"] = {"workload": _cap(cfg.get("workload"), 300)}
+    for kk in ("batch_rows_per_gpu", "global_batch_rows", "state", "parallelism", "levels", "feature_order", "learn_rate"):
+        if kk in cfg:
+            line["config"][kk] = _cap(_num(cfg[kk]), 120)
+    if isinstance(cfg.get("exchange"), (str, dict)):
+        line["config"]["exchange"] = _cap(cfg["exchange"] if isinstance(cfg["exchange"], str) else cfg["exchange"].get("form"), 160)
+    rl = {}
+    for kk in ("bound", "kernel", "dominant_kernel", "achieved", "peak", "unit", "frac", "frac_basis", "effective_frac", "frac_with_unread_values", "traffic", "traffic_ratio", "traffic_source",
+               "algorithmic_bytes_per_example", "algorithmic_bytes_per_launch", "avg_launch_ms"):
+        if kk in r:
+            rl[kk] = _cap(_num(r[kk]), 200 if kk == "kernel" else 120)
+    if isinstance(rl.get("traffic_source"), str):
+        rl["traffic_source"] = rl["traffic_source"].split(":")[0]
+    if isinstance(r.get("fabric"), dict):
+        rl["fabric_frac"] = _num(r["fabric"].get("frac"))
+    if isinstance(r.get("step"), dict):
+        rl["step_frac"] = _num(r["step"].get("frac"))
+    if isinstance(r.get("kernels"), dict):
+        rl["kernels"] = {name: {kk: _num(v[kk]) for kk in ("avg_launch_ms", "frac", "ceiling_frac") if v.get(kk) is not None} for name, v in r["kernels"].items()}
+        for name, v in r["kernels"].items():
+            if isinstance(v.get("fabric"), dict):
+                rl["kernels"][name]["fabric_frac"] = _num(v["fabric"].get("frac"))
+    line["roofline"] = rl
+    cb = d.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {kk: _cap(_num(cb[kk]), 160) for kk in ("value", "unit", "cores", "cpu_model", "kind", "sample") if kk in cb}
+        if isinstance(cb.get("all_cores"), dict):
+            line["cpu_baseline"]["all_cores"] = {kk: _num(cb["all_cores"][kk]) for kk in ("cores", "hogwild_examples_per_s", "forward_rows_per_s") if kk in cb["all_cores"]}
+    if isinstance(d.get("other_configs"), dict):
+        line["other_configs"] = {name: _frac_entry(v) if not (isinstance(v, dict) and "error" in v) else {"error": _cap(v["error"], 120)} for name, v in d["other_configs"].items()}
+    side = {}
+    for kk in ("sequential_exact", "sequential_reassociated", "sequential_exact_grid", "value_stratified_columns", "value_iid_uniform", "value_real_values", "value_zipf_columns", "value_ragged_rows",
+               "scaling_reference", "value_q_carried"):
+        if isinstance(d.get(kk), dict) and "value" in d[kk]:
+            side[kk] = _num(d[kk]["value"])
+    if "forward_rows_per_s" in d:
+        side["forward_rows_per_s"] = _num(d["forward_rows_per_s"])
+    if isinstance(d.get("end_to_end"), dict):
+        side["end_to_end_one_epoch"] = _num(d["end_to_end"].get("one_epoch_examples_per_s"))
+    if side:
+        line["side"] = side
+    line["details"] = "bench_details.json; the stdout line prefixed DETAILS"
+    # the budget is a contract: shed the optional parts, in this order, rather than print a line the driver cannot read
+    for shed in ("side", "other_configs"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(shed, None)
+    n = len(json.dumps(line))
+    if n > LINE_LIMIT:
+        raise AssertionError(f"the driver's line is {n} bytes (limit {LINE_LIMIT})")
+    return line
+
+
+def emit(out):
+    """stdout: `DETAILS <everything the run measured>` first, then -- LAST -- the compact line the driver parses; the full object is also left in bench_details.json"""
+    full = json.dumps(out)
+    try:
+        with open(os.path.join(os.environ.get("FMX_BENCH_DETAILS_DIR", ROOT), "bench_details.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError:
+        pass
+    print("DETAILS " + full, flush=True)
+    print(json.dumps(driver_line(out)), flush=True)
+
+
 def compact_line(d):
     """what `other_configs` keeps of a full bench line"""
     if d is None:
@@ -987,7 +1111,7 @@ def compact_line(d):
     r = d.get("roofline", {})
     keep = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
             "workload": d["config"]["workload"],
-            "roofline": {kk: r[kk] for kk in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_note", "frac_with_unread_values", "fabric", "survey_priced_frac", "design_frac", "avg_launch_ms", "algorithmic_bytes_per_launch",
+            "roofline": {kk: r[kk] for kk in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_basis", "effective_frac", "traffic_ratio", "frac_note", "frac_with_unread_values", "fabric", "survey_priced_frac", "design_frac", "avg_launch_ms", "algorithmic_bytes_per_launch",
                                               "algorithmic_bytes_per_example", "traffic") if kk in r}}
     if "kernels" in r:
         keep["roofline"]["kernels"] = {name: {kk: v[kk] for kk in ("avg_launch_ms", "frac", "ceiling_frac", "hbm_priced_frac", "traffic", "fabric") if kk in v} for name, v in r["kernels"].items()}
@@ -1018,6 +1142,7 @@ def other_configs(args):
         ("configs[3]_resident", ["--workload", "criteo", "--steps", "30", "--warmup", "3", "--cpu-rows", "120000"], run_minibatch),
         ("configs[3]_streamed", ["--workload", "criteo", "--stream", "--steps", "30", "--warmup", "3"], main_stream),
         ("configs[4]", ["--solver", "mcmc", "--no-extras", "--steps", "4", "--warmup", "1", "--cpu-rows", "2000000"], main_sweep),
+        ("configs[4]_iid_exact", ["--solver", "mcmc", "--sweep-iid", "--sweep-exact", "--no-extras", "--steps", "1", "--warmup", "1", "--cpu-rows", "0"], main_sweep),
         ("configs[4]_iid_columns", ["--solver", "mcmc", "--sweep-iid", "--no-extras", "--steps", "4", "--warmup", "2", "--cpu-rows", "0"], main_sweep),
         ("configs[4]_feature_major", ["--solver", "mcmc", "--sweep-feature-major", "--no-extras", "--steps", "4", "--warmup", "2", "--cpu-rows", "0"], main_sweep),
     ]
@@ -1060,7 +1185,7 @@ def main():
     if args.in_library:
         if world != 1:
             raise SystemExit("--in-library is one process for all GPUs: start it without torch.distributed.run")
-        print(json.dumps(main_in_library(args)), flush=True)
+        emit(main_in_library(args))
         return
     if world != args.gpus:
         if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
@@ -1094,7 +1219,7 @@ def main():
         if out is not None and headline and not args.no_other_configs and not args.no_extras:
             out["other_configs"] = other_configs(args)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1282,6 +1407,11 @@ def run_minibatch(args, rank, local_rank, world):
                                          "note": "what the step's launches really move across the fabric (the L2's reads counted by size + writes, PMC) over the step time / HBM peak: "
                                                  "a miss fetches a whole 128-byte line, so the random 64-byte rows of k = 16 fp32 tables cost twice their algorithmic bytes and `frac` on "
                                                  "algorithmic bytes cannot pass 0.5 on the gather-bound part (DESIGN.md section 6.8)"}
+        out["roofline"]["frac_basis"] = "algorithmic"
+        if "fabric" in out["roofline"]:
+            out["roofline"]["traffic_ratio"] = out["roofline"]["fabric"]["bytes_per_step"] / b_step     # counted fabric bytes of a step over its algorithmic bytes
+        elif traffic:
+            out["roofline"]["traffic_ratio"] = traffic / per_kernel[dom]["algorithmic_bytes_per_launch"]
         if fwd_rate is not None:
             out["forward_rows_per_s"] = fwd_rate
         if world == 1:
@@ -1297,7 +1427,10 @@ def run_minibatch(args, rank, local_rank, world):
         design_step = tiles_per_step * (b_fwd + b_upd)
         rf["design_bytes_per_example"] = design_step / B
         if rf["frac"] > 1.0:
-            rf["survey_priced_frac"] = rf["frac"]
+            rf["survey_priced_frac"] = rf["effective_frac"] = rf["frac"]
+            rf["frac_basis"] = "design"
+            if "fabric" in rf:
+                rf["traffic_ratio"] = rf["fabric"]["bytes_per_step"] / design_step
             rf["frac"] = design_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
             rf["achieved"] = design_step / (dt / args.steps) / 1e9
             rf["frac_note"] = ("SURVEY 8(d) prices a read-modify-write of theta, z, n per OCCURRENCE (the reference's per-example loop); the two-phase design touches "
