@@ -47,7 +47,7 @@ class Config(C.Structure):
         ("random_step", C.c_int32), ("mode", C.c_int32), ("batch_rows", C.c_int64),
         ("min_target", C.c_double), ("max_target", C.c_double),
         ("device", C.c_int32), ("batch_reduce", C.c_int32), ("gamma", C.c_double), ("tile_rows", C.c_int64),
-        ("state_fp64", C.c_int32), ("exchange_chunks", C.c_int32), ("n_gpus", C.c_int32), ("als_max_levels", C.c_int32), ("reserved0", C.c_int32), ("gpus_share_device", C.c_int32),
+        ("state_fp64", C.c_int32), ("exchange_chunks", C.c_int32), ("n_gpus", C.c_int32), ("als_max_levels", C.c_int32), ("seq_reassociate", C.c_int32), ("gpus_share_device", C.c_int32),
     ]
 
 

@@ -1016,6 +1016,210 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_pipe_g
   seq_pipe_body<KIND, KL, NZ>(a, wa, h);
 }
 
+// ---- reassociated reference-order learner (cfg.seq_reassociate) -------------------------------------------------------
+// The reference's algorithm, its visiting order, one update per example, fp64 -- but the FORWARD's sum is formed as the reference's
+// formula read as mathematics, y_hat = w0 + (sum_j w_j x_j + sum_f 0.5 (s_f^2 - q_f)), instead of the 1 + nnz + k ordered additions
+// that start at w0 (core/Model.h:77-100).  In that association only w0 carries a recurrence from one example to the next
+// (solver/SGD_Learner.h:100-112): the row part r is a fixed tree over the example's own lanes, and the chain is
+// `pred = w0 + r; mult; w0 step` -- three dependent operations instead of fifty.  Results differ from the bitwise kernels in the last bits
+// of y_hat (and of s_f: its nnz products are summed per lane block, then across the blocks); they are the same from run to run (every
+// tree is fixed, and an example never reads a parameter before the earlier examples that touch it have stored theirs).
+//
+// One workgroup: wave 0 is the chain, waves 1..W own the examples t = w - 1, w - 1 + W, ... of the launch.  No barrier after the start:
+// the waves meet through tagged LDS slots (ring of R = a multiple of W, so a slot is always written by the same wave, in order):
+//   f_r[t % R] = t + 1     worker -> chain: r (and the label) of example t are in the slot;
+//   f_m[t % R] = t + 1     chain -> worker: the multiplier (and the cumulative L1 penalties) of example t are in the slot;
+//   f_done[t % R] = t + 1  worker -> workers: example t's stores are complete (released at workgroup scope).
+// Example t may gather once every example <= conf[t] (the last earlier one sharing a feature with it, seq_conf_k) is done: the examples
+// between finish in any order, so the test covers all of them -- lane s looks at slot s, whose latest tag must have reached the largest
+// example <= conf[t] of its residue class (one LDS read per lane, one ballot).  Progress: the chain takes the examples in order; example
+// t waits only for examples before it (its conflicts, its owner's previous example), so by induction every wait ends.
+template <int KIND, int KL, int NZ> struct SeqRe {
+  static constexpr int Q = 64 / KL, SL = NZ / Q, NS = SeqState<KIND>::N;
+  // a worker holds ONE example: SL x (1 + state) doubles of V-side parameters + the slots' columns and values; 16 waves leave 128 VGPRs per lane
+  static constexpr int REGS = 2 * SL * (1 + NS) + 3 * SL + 56;
+#ifdef FMX_SEQ_RE_NW
+  static constexpr int NW = FMX_SEQ_RE_NW;
+#else
+  static constexpr int NW = REGS <= 112 ? 16 : 8;   // (FTRL at k <= 16 spills 31 VGPRs at 16 waves: 8)
+#endif
+  static constexpr int W = NW - 1;
+  static constexpr int R = (64 / W) * W;   // 60 (15 workers), 63 (7)
+};
+
+template <int KIND, int KL, int NZ>
+__global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc_k(SeqArgs a, WinArgs wa, Hyper h) {
+  static_assert(KIND != UPD_TDAP, "TDAP keeps fm_seq_window_k (its w prox reads z_w by position, A-6)");
+  using S = SeqRe<KIND, KL, NZ>;
+  constexpr int W = S::W, R = S::R, Q = S::Q, SL = S::SL, NS = S::NS, NS1 = NS > 0 ? NS : 1;
+  __shared__ double s_r[R], s_mult[R], s_uw[R], s_uv[R];
+  __shared__ float s_y[R];
+  __shared__ int f_r[R], f_m[R], f_done[R];
+  __shared__ int s_abort;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = a.k, kp = a.kp, count = wa.count;
+  const bool k0 = h.k0 != 0, k1 = h.k1 != 0;
+  for (int i = threadIdx.x; i < R; i += blockDim.x) { f_r[i] = 0; f_m[i] = 0; f_done[i] = 0; }
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();   // the only barrier: every wave reaches it before the roles part
+  // Every wait below is bounded: a wave that has polled ~1e6 times (tens of milliseconds; a legitimate wait is microseconds) raises s_abort, every other wait
+  // sees it within 1024 polls, all waves leave, and w0 comes back NaN -- a wrong plan (conf[]) or a lost tag then fails a test instead of hanging the device.
+  int spins = 0;
+  auto stuck = [&]() {
+    if ((++spins & 1023) != 0) return false;
+    if (spins > (1 << 20)) __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+  };
+
+  if (wave == 0) {
+    // ---------------------------------------------------------------- the chain: examples in order, as many as are ready at once
+    double w0 = a.scal[SC_W0], z0 = a.scal[SC_Z0], n0 = a.scal[SC_N0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
+    constexpr int B = 16;   // examples looked at per poll
+    int e = 0;
+    while (e < count) {
+      const int te = e + lane;
+      const int slot = te % R;
+      const bool look = lane < B && te < count;
+      const bool ready = look && __hip_atomic_load(&f_r[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == te + 1;
+      const unsigned long long mask = __ballot(ready);
+      const int n = __builtin_ctzll(~mask);   // the leading ready ones (mask has at most B bits set)
+      if (n == 0) {
+        if (stuck()) { if (lane == 0) a.scal[SC_W0] = __longlong_as_double(0x7FF8000000000000ll); return; }
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      spins = 0;
+      const double r = lane < n ? s_r[slot] : 0.0;
+      const float y = lane < n ? s_y[slot] : 0.0f;
+      double my_mult = 0.0, my_uw = 0.0, my_uv = 0.0;
+      for (int i = 0; i < n; ++i) {
+        if constexpr (KIND == UPD_SGD_L1) { uw += h.lr * h.regw; uv += h.lr * h.regv; }  // SGD_Learner.h:92-97
+        const double pred = (k0 ? w0 : 0.0) + bcast(r, i);
+        const double mult = seq_grad_mult(h, pred, bcast(y, i));
+        if (k0) {
+          if constexpr (KIND == UPD_FTRL) {
+            const double n_old = n0;
+            n0 += mult * mult;
+            const double delta = (sqrt(n0) - sqrt(n_old)) / h.alpha_w;
+            z0 += mult - delta * w0;
+          } else w0 -= h.lr * (mult + h.reg0 * w0);
+        }
+        if constexpr (KIND == UPD_FTRL) w0 = -z0 * h.alpha_w / (h.beta_w + sqrt(n0));
+        if (lane == i) { my_mult = mult; my_uw = uw; my_uv = uv; }
+      }
+      if (lane < n) {
+        s_mult[slot] = my_mult; s_uw[slot] = my_uw; s_uv[slot] = my_uv;
+        __hip_atomic_store(&f_m[slot], te + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      e += n;
+    }
+    if (lane == 0) { a.scal[SC_W0] = w0; a.scal[SC_Z0] = z0; a.scal[SC_N0] = n0; a.scal[SC_UW] = uw; a.scal[SC_UV] = uv; }
+    return;
+  }
+
+  // ------------------------------------------------------------------ a worker: examples ww, ww + W, ...
+  const int ww = wave - 1;
+  const int fq = lane / KL, ff = lane % KL;  // this lane's nonzero block and factor (V side)
+  const bool fv = ff < k;
+  const int fl = fv ? ff : 0;
+  struct Meta { int conf_t, len; uint2 en; float y; };
+  auto fetch = [&](int t) {  // unconditional loads on a clamped index: every use is guarded by its own range test
+    Meta mt;
+    const int tt = t < count - 1 ? t : count - 1;
+    mt.conf_t = wa.conf[tt];
+    mt.len = wa.ex_len[tt];
+    mt.en = wa.packed[(size_t)tt * NZ + (lane & (NZ - 1))];
+    mt.y = wa.ex_y[tt];
+    return mt;
+  };
+  Meta cur = fetch(ww);
+  for (int t = ww; t < count; t += W) {
+    const int slot = t % R;
+    const Meta nxt = fetch(t + W);   // travels behind this example's work
+    // every example <= conf[t] must have stored its parameters
+    const int c = cur.conf_t;
+    if (c >= 0) {
+      const int back = ((c - lane) % R + R) % R;          // lane = slot: the largest example <= c of this residue class is c - back
+      const int want = lane < R && c - back >= 0 ? c - back + 1 : 0;
+      for (;;) {
+        const int got = lane < R ? __hip_atomic_load(&f_done[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        if (__ballot(got >= want) == ~0ull) break;
+        if (stuck()) return;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      spins = 0;
+    }
+    // ---------------------------------------------------------------- A: gathers, the factor sums, the row part of y_hat
+    const int len = cur.len;
+    const bool tv = lane < len;
+    const uint32_t mycol = tv ? cur.en.x : 0u;
+    const double myx = tv ? (double)__uint_as_float(cur.en.y) : 0.0;
+    double myw = a.w[mycol];
+    double stw[NS1];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) stw[j] = seq_state_ptr<KIND>(a, true, j)[mycol];
+    uint32_t cu[SL];
+    double xu[SL], vv[SL], stv[NS1][SL];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {  // slot j of this lane is nonzero u = j * Q + fq (idle slots: column 0, x = 0)
+      if constexpr (Q == 1) { cu[j] = bcast(mycol, j); xu[j] = bcast(myx, j); }
+      else { cu[j] = (uint32_t)__shfl((int)mycol, j * Q + fq); xu[j] = __shfl(myx, j * Q + fq); }
+      const size_t at = (size_t)cu[j] * kp + fl;
+      vv[j] = a.V[at];
+#pragma unroll
+      for (int n = 0; n < NS; ++n) stv[n][j] = seq_state_ptr<KIND>(a, false, n)[at];
+    }
+    double s1 = 0.0, q1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {  // this block's nonzeros, in slot order
+      const double tmp = vv[j] * xu[j];
+      s1 += tmp;
+      q1 += tmp * tmp;
+    }
+#pragma unroll
+    for (int o = KL; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); q1 += __shfl_xor(q1, o); }  // across the Q blocks (a + b == b + a: the same bits in every block)
+    double part = (lane < NZ ? (k1 ? myw : 0.0) * myx : 0.0) + ((lane < KL && fv) ? 0.5 * (s1 * s1 - q1) : 0.0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) {
+      s_r[slot] = part; s_y[slot] = cur.y;
+      __hip_atomic_store(&f_r[slot], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // ---------------------------------------------------------------- the multiplier
+    while (__hip_atomic_load(&f_m[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t + 1) {
+      if (stuck()) return;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    spins = 0;
+    const double mult = s_mult[slot], euw = s_uw[slot], euv = s_uv[slot];
+    // ---------------------------------------------------------------- C: the example's update, from registers
+    if (tv && (k1 || KIND == UPD_FTRL)) {
+      coord_seq<KIND>(h, true, k1, myw, myx, mult, euw, stw);
+      a.w[mycol] = myw;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) if (k1) seq_state_ptr<KIND>(a, true, j)[mycol] = stw[j];
+    }
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const size_t at = (size_t)cu[j] * kp + ff;
+      if (j * Q + fq < len && fv) {
+        double th = vv[j];
+        double st[NS1];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) st[n] = stv[n][j];
+        const double grad = s1 * xu[j] - th * xu[j] * xu[j];
+        coord_seq<KIND>(h, false, true, th, grad, mult, euv, st);
+        a.V[at] = th;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) seq_state_ptr<KIND>(a, false, n)[at] = st[n];
+      }
+    }
+    // the stores complete (release), then the tag: whoever waits for this example gathers after it
+    if (lane == 0) __hip_atomic_store(&f_done[slot], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cur = nxt;
+  }
+}
+
 // the windowed learner applies when every row is a fast row; FMX_SEQ_WINDOW=0 in the environment keeps the one-wave kernel
 // entries per packed row (32 or 64), or 0: the one-wave kernel
 static int window_mode(const fmx_engine* e, const fmx_matrix* m) {
@@ -1059,9 +1263,23 @@ static int pipe_mode() {
   return !s ? 1 : (s[0] == '1' ? 0 : (s[0] == '2' ? 2 : 1));  // 0 never, 1 where it fits, 2 always
 }
 
+// cfg.seq_reassociate (FMX_SEQ_REASSOC=0/1 in the environment overrides it, read per call: the tests run every case in both forms)
+static bool reassoc_mode(const fmx_engine* e) {
+  const char* s = getenv("FMX_SEQ_REASSOC");
+  return s && s[0] ? s[0] != '0' : e->cfg.seq_reassociate != 0;
+}
+
 template <int KIND>
 static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa, int nz) {
   if constexpr (KIND != UPD_TDAP) {
+    if (reassoc_mode(e)) {
+#define FMX_RE(KL, NZ) hipLaunchKernelGGL((fm_seq_reassoc_k<KIND, KL, NZ>), dim3(1), dim3(SeqRe<KIND, KL, NZ>::NW * 64), 0, e->stream, a, wa, e->hyper)
+      if (e->k <= 16) { if (nz == 32) FMX_RE(16, 32); else FMX_RE(16, 64); }
+      else if (e->k <= 32) { if (nz == 32) FMX_RE(32, 32); else FMX_RE(32, 64); }
+      else FMX_RE(64, 32);
+#undef FMX_RE
+      return;
+    }
     const int pm = pipe_mode();
 #define FMX_PIPE(KL, NZ)                                                                                                                            \
   if (pm == 2 || (pm == 1 && PipeFits<KIND, KL, NZ>::value)) {                                                                                      \
