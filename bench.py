@@ -577,6 +577,19 @@ def side_measurements(args, L, engine, m, v0, value, csc_build_s, kernels, tile_
                                "note": "FMX_MODE_SEQUENTIAL: the reference's per-example algorithm in its visiting order (fp64 state); "
                                        "1e-5-on-V parity with the reference CPU path is asserted in THIS mode; `value` is the mini-batch mode"}
     seq.close()
+    # the same learner with the forward's sum reassociated (cfg.seq_reassociate: y_hat = w0 + (row part), only w0 chains the examples): the reference's algorithm, order and
+    # precision, <= 1e-10 on V against the oracle with exact prediction signs (tests/test_gpu_seq_reassoc.py); what the glue's default `engine = "sequential"` runs for SGD
+    if args.solver == "sgd":
+        seq = engine.Engine(p, **engine_kwargs(args, L, 1, 0, 1, mode=L.MODE_SEQUENTIAL, state_fp64=0, tile_rows=0, seq_reassociate=1))
+        seq.set_params(0.0, None, v0.astype(np.float64))
+        seq.train(sub, 20_000)
+        t0 = time.perf_counter()
+        done = seq.train(sub, 2 * cnt)
+        out["sequential_reassociated"] = {"value": done / (time.perf_counter() - t0), "unit": "examples/s",
+                                          "note": "FMX_MODE_SEQUENTIAL with cfg.seq_reassociate = 1 (fm_seq_reassoc_k): one update per example in the reference's visiting order, fp64; the forward's sum is "
+                                                  "w0 + (a fixed tree over the row), so the chain per example is pred = w0 + r, the multiplier, the w0 step; <= 1e-10 on V against the oracle, "
+                                                  "signs exact, the same bits from run to run"}
+        seq.close()
     # ... and as many of them as the chip has CUs: a grid of models (learning rate x L2, what fm.select's repeated fm.train calls walk) on ONE visiting order, one
     # workgroup per model in one launch per 65 536 examples (fmx_train_grid); every model bit for bit its own fmx_train (tests/test_gpu_train_grid.py)
     try:

@@ -55,9 +55,10 @@ static fmx_config config_from_controls(List fm_controls, List solver_controls, d
   else if (s == "ALS") c.solver = FMX_SOLVER_ALS;                 // its R-side parameters are overridden by learner->init() in the reference too (SURVEY A-7)
   else c.solver = FMX_SOLVER_MCMC;
   c.min_target = min_t; c.max_target = max_t;                    // src/FM.cpp:89-96
-  c.mode = FMX_MODE_SEQUENTIAL;                                  // default: the reference's algorithm, one example per update (parity <= 1e-11)
+  c.mode = FMX_MODE_SEQUENTIAL;                                  // default: the reference's algorithm, its visiting order, one example per update, fp64
+  c.seq_reassociate = 1;                                         // SGD: y_hat summed as w0 + (row part) -- <= 1e-10 on V, signs exact, 3.9 M examples/s; "sequential_bitwise" below turns it off
   // The throughput mode is ONE optional element of solver.control -- a non-breaking extension a maintainer adds to R/fm_solver_control.R
-  // (`engine = c("sequential", "minibatch", "minibatch_fp64")`, `batch_rows = 262144L`); lists without it behave as before:
+  // (`engine = c("sequential", "sequential_bitwise", "minibatch", "minibatch_fp64")`, `batch_rows = 262144L`); lists without it behave as before:
   //   "minibatch"      synchronous mini-batches, fp32 state: 846 M examples/s at configs[1]'s shape against 1.66 M (one MI355X)
   //   "minibatch_fp64" the same with the reference's fp64 state: 616 M examples/s, 1e-5 on V guaranteed against the mini-batch restatement
   // options("FM.threads") arrives as fm_controls$nthreads (src/FM.cpp:59,97) and becomes the number of GPUs there: fmx_train shards the rows over
@@ -72,7 +73,8 @@ static fmx_config config_from_controls(List fm_controls, List solver_controls, d
       fmx_check(fmx_device_count(&n_dev));
       const int want = (int)fm_controls["nthreads"];
       c.n_gpus = want > 1 ? (want < n_dev ? want : n_dev) : 1;
-    } else if (eng != "sequential") stop("solver.control(engine = ...) must be \"sequential\", \"minibatch\" or \"minibatch_fp64\"");
+    } else if (eng == "sequential_bitwise") c.seq_reassociate = 0;   // the reference's association of the forward's sum: <= 1e-11 on V, 1.65 M examples/s
+    else if (eng != "sequential") stop("solver.control(engine = ...) must be \"sequential\", \"sequential_bitwise\", \"minibatch\" or \"minibatch_fp64\"");
   }
   // ALS / MCMC: the ORDER of the coordinate sweeps is another optional element (`sweep_order = c("reference", "coloured", "feature_major")`, include/fmx.h
   // cfg.als_max_levels): "reference" keeps the reference's feature order and factor-outer nesting (its numbers); the other two take every step exactly but in an order

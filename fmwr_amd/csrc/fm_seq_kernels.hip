@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/rocprim.hpp>
 
@@ -1034,6 +1035,36 @@ __global__ __launch_bounds__((SeqWin<KIND, KL, NZ>::NW * 64)) void fm_seq_pipe_g
 // between finish in any order, so the test covers all of them -- lane s looks at slot s, whose latest tag must have reached the largest
 // example <= conf[t] of its residue class (one LDS read per lane, one ballot).  Progress: the chain takes the examples in order; example
 // t waits only for examples before it (its conflicts, its owner's previous example), so by induction every wait ends.
+// The gradient multiplier of the reassociated chain.  Regression: as seq_grad_mult.  Classification: the reference's -y (1 - 1 / (1 + exp(-y y_hat)))
+// (solver/SGD_Learner.h:187-190) evaluated as -y / (1 + exp(a)), a = y y_hat clamped to [-750, 700] (1 + e^700 is finite; beyond the clamps the value is 1 or
+// below 1e-304) -- no cancellation (2 ulp of the exact value; within 2.3e-16 ABSOLUTE of the reference's expression, whose own rounding error is of that size).  It is on the one dependent chain of the mode, so its depth is what counts: the exponential's polynomial (the device
+// library's degree-11 minimax coefficients) is summed in Estrin's order (depth 4 instead of 11), the reciprocal of 1 + t in (1, 2] is v_rcp_f64 + two Newton steps
+// instead of the IEEE division's eleven dependent operations.  NaN stays NaN.
+__device__ __forceinline__ double seq_grad_mult_re(const Hyper& h, double y_hat, float y) {
+  if (h.task == FMX_TASK_REGRESSION) return seq_grad_mult(h, y_hat, y);
+  auto B = [](unsigned long long u) { return __longlong_as_double((long long)u); };
+  const double yd = (double)y;
+  const double a = yd * y_hat;
+  const double x = fmin(fmax(a, -750.0), 700.0);
+  const double n = __builtin_rint(x * B(0x3ff71547652b82feull));                       // x / ln 2, to nearest
+  double r = __builtin_fma(n, B(0xbfe62e42fefa39efull), x);                            // x - n ln2 (hi, lo)
+  r = __builtin_fma(n, B(0xbc7abc9e3b39803full), r);
+  const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+  const double p01 = 1.0 + r;
+  const double p23 = __builtin_fma(B(0x3fc5555555555511ull), r, B(0x3fe000000000000bull));
+  const double p45 = __builtin_fma(B(0x3f81111111122322ull), r, B(0x3fa55555555502a1ull));
+  const double p67 = __builtin_fma(B(0x3f2a01a014761f6eull), r, B(0x3f56c16c1852b7b0ull));
+  const double p89 = __builtin_fma(B(0x3ec71dee623fde64ull), r, B(0x3efa01997c89e6b0ull));
+  const double pab = __builtin_fma(B(0x3e5ade156a5dcb37ull), r, B(0x3e928af3fca7ab0cull));
+  const double q0 = __builtin_fma(p23, r2, p01), q1 = __builtin_fma(p67, r2, p45), q2 = __builtin_fma(pab, r2, p89);
+  const double t = ldexp(__builtin_fma(q2, r8, __builtin_fma(q1, r4, q0)), (int)n);
+  const double d = 1.0 + t;
+  double xr = __builtin_amdgcn_rcp(d);
+  xr = __builtin_fma(xr, __builtin_fma(-d, xr, 1.0), xr);
+  xr = __builtin_fma(xr, __builtin_fma(-d, xr, 1.0), xr);
+  return -yd * (a != a ? a : xr);
+}
+
 template <int KIND, int KL, int NZ> struct SeqRe {
   static constexpr int Q = 64 / KL, SL = NZ / Q, NS = SeqState<KIND>::N;
   // a worker holds ONE example: SL x (1 + state) doubles of V-side parameters + the slots' columns and values; 16 waves leave 128 VGPRs per lane
@@ -1041,7 +1072,7 @@ template <int KIND, int KL, int NZ> struct SeqRe {
 #ifdef FMX_SEQ_RE_NW
   static constexpr int NW = FMX_SEQ_RE_NW;
 #else
-  static constexpr int NW = REGS <= 112 ? 16 : 8;   // (FTRL at k <= 16 spills 31 VGPRs at 16 waves: 8)
+  static constexpr int NW = REGS <= 112 ? 16 : 8;   // (k > 16 or rows of 33..64 entries: 174-256 VGPRs, two waves per SIMD)
 #endif
   static constexpr int W = NW - 1;
   static constexpr int R = (64 / W) * W;   // 60 (15 workers), 63 (7)
@@ -1049,7 +1080,9 @@ template <int KIND, int KL, int NZ> struct SeqRe {
 
 template <int KIND, int KL, int NZ>
 __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc_k(SeqArgs a, WinArgs wa, Hyper h) {
-  static_assert(KIND != UPD_TDAP, "TDAP keeps fm_seq_window_k (its w prox reads z_w by position, A-6)");
+  // SGD only.  FTRL's chain carries square roots and divisions of its own and its workers' prox arithmetic is what bounds it: with the flag it ran 650 K examples/s
+  // against the pipelined kernel's 716 K at k = 16 (profiles/r06_seq_reassoc.txt), so FTRL -- and TDAP, whose w prox reads z_w by position (A-6) -- ignore the flag.
+  static_assert(KIND == UPD_SGD_L2 || KIND == UPD_SGD_L1, "the reassociated learner is built for the SGD kinds");
   using S = SeqRe<KIND, KL, NZ>;
   constexpr int W = S::W, R = S::R, Q = S::Q, SL = S::SL, NS = S::NS, NS1 = NS > 0 ? NS : 1;
   __shared__ double s_r[R], s_mult[R], s_uw[R], s_uv[R];
@@ -1073,9 +1106,16 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
 
   if (wave == 0) {
     // ---------------------------------------------------------------- the chain: examples in order, as many as are ready at once
-    double w0 = a.scal[SC_W0], z0 = a.scal[SC_Z0], n0 = a.scal[SC_N0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
+    double w0 = a.scal[SC_W0], uw = a.scal[SC_UW], uv = a.scal[SC_UV];
     constexpr int B = 16;   // examples looked at per poll
     int e = 0;
+    __builtin_amdgcn_s_setprio(3);   // the chain is the critical path of the workgroup: its instructions go first on the SIMD it shares with three workers
+#ifdef FMX_SEQ_TIMING
+    unsigned long long tIdle = 0, tBusy = 0, nBatch = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+#define FMX_TC(acc) do { c1 = __builtin_amdgcn_s_memtime(); acc += c1 - c0; c0 = c1; } while (0)
+#else
+#define FMX_TC(acc) do { } while (0)
+#endif
     while (e < count) {
       const int te = e + lane;
       const int slot = te % R;
@@ -1086,34 +1126,44 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
       if (n == 0) {
         if (stuck()) { if (lane == 0) a.scal[SC_W0] = __longlong_as_double(0x7FF8000000000000ll); return; }
         __builtin_amdgcn_s_sleep(1);
+        FMX_TC(tIdle);
         continue;
       }
       spins = 0;
       const double r = lane < n ? s_r[slot] : 0.0;
       const float y = lane < n ? s_y[slot] : 0.0f;
-      double my_mult = 0.0, my_uw = 0.0, my_uv = 0.0;
+      auto batch = [&](auto K0) {
+      constexpr bool k0 = decltype(K0)::value;   // (a uniform branch outside the loop instead of two selects on w0 inside the chain)
       for (int i = 0; i < n; ++i) {
         if constexpr (KIND == UPD_SGD_L1) { uw += h.lr * h.regw; uv += h.lr * h.regv; }  // SGD_Learner.h:92-97
         const double pred = (k0 ? w0 : 0.0) + bcast(r, i);
-        const double mult = seq_grad_mult(h, pred, bcast(y, i));
-        if (k0) {
-          if constexpr (KIND == UPD_FTRL) {
-            const double n_old = n0;
-            n0 += mult * mult;
-            const double delta = (sqrt(n0) - sqrt(n_old)) / h.alpha_w;
-            z0 += mult - delta * w0;
-          } else w0 -= h.lr * (mult + h.reg0 * w0);
+        const double mult = seq_grad_mult_re(h, pred, bcast(y, i));
+        if (k0) w0 -= h.lr * (mult + h.reg0 * w0);   // SGD_Learner.h:100-112
+        // handed over at once (not at the end of the batch: the owners of a batch would otherwise get their multipliers together, post their next sums together,
+        // and the chain would sit idle in between -- measured: 43 % of its time)
+        // The tag is a RELAXED store behind a compiler fence: a wave's LDS operations execute in program order, so the slot's data is in place when the tag is --
+        // a release store would make the chain wait (s_waitcnt lgkmcnt(0)) for its own write before every tag.
+        if (lane == i) {
+          s_mult[slot] = mult;
+          if constexpr (KIND == UPD_SGD_L1) { s_uw[slot] = uw; s_uv[slot] = uv; }
+          __atomic_signal_fence(__ATOMIC_SEQ_CST);
+          __hip_atomic_store(&f_m[slot], te + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if constexpr (KIND == UPD_FTRL) w0 = -z0 * h.alpha_w / (h.beta_w + sqrt(n0));
-        if (lane == i) { my_mult = mult; my_uw = uw; my_uv = uv; }
       }
-      if (lane < n) {
-        s_mult[slot] = my_mult; s_uw[slot] = my_uw; s_uv[slot] = my_uv;
-        __hip_atomic_store(&f_m[slot], te + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+      };
+      if (k0) batch(std::true_type{}); else batch(std::false_type{});
       e += n;
+#ifdef FMX_SEQ_TIMING
+      ++nBatch;
+#endif
+      FMX_TC(tBusy);
     }
-    if (lane == 0) { a.scal[SC_W0] = w0; a.scal[SC_Z0] = z0; a.scal[SC_N0] = n0; a.scal[SC_UW] = uw; a.scal[SC_UV] = uv; }
+#ifdef FMX_SEQ_TIMING
+    if (lane == 0) printf("reassoc chain: %d examples in %llu batches (%.2f per batch); memtime ticks per example: idle %.1f  busy %.1f\n", count, nBatch, (double)count / nBatch,
+                          (double)tIdle / count, (double)tBusy / count);
+#endif
+#undef FMX_TC
+    if (lane == 0) { a.scal[SC_W0] = w0; a.scal[SC_UW] = uw; a.scal[SC_UV] = uv; }
     return;
   }
 
@@ -1133,6 +1183,12 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
     return mt;
   };
   Meta cur = fetch(ww);
+#ifdef FMX_SEQ_TIMING
+  unsigned long long tW = 0, tA = 0, tM = 0, tC = 0, tD = 0, nE = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+#define FMX_TW(acc) do { c1 = __builtin_amdgcn_s_memtime(); acc += c1 - c0; c0 = c1; } while (0)
+#else
+#define FMX_TW(acc) do { } while (0)
+#endif
   for (int t = ww; t < count; t += W) {
     const int slot = t % R;
     const Meta nxt = fetch(t + W);   // travels behind this example's work
@@ -1149,6 +1205,7 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
       }
       spins = 0;
     }
+    FMX_TW(tW);
     // ---------------------------------------------------------------- A: gathers, the factor sums, the row part of y_hat
     const int len = cur.len;
     const bool tv = lane < len;
@@ -1183,21 +1240,24 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     if (lane == 0) {
       s_r[slot] = part; s_y[slot] = cur.y;
-      __hip_atomic_store(&f_r[slot], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      __hip_atomic_store(&f_r[slot], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS order, as for f_m)
     }
+    FMX_TW(tA);
     // ---------------------------------------------------------------- the multiplier
     while (__hip_atomic_load(&f_m[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t + 1) {
       if (stuck()) return;
       __builtin_amdgcn_s_sleep(1);
     }
     spins = 0;
-    const double mult = s_mult[slot], euw = s_uw[slot], euv = s_uv[slot];
+    const double mult = s_mult[slot], euw = KIND == UPD_SGD_L1 ? s_uw[slot] : 0.0, euv = KIND == UPD_SGD_L1 ? s_uv[slot] : 0.0;
+    FMX_TW(tM);
     // ---------------------------------------------------------------- C: the example's update, from registers
-    if (tv && (k1 || KIND == UPD_FTRL)) {
-      coord_seq<KIND>(h, true, k1, myw, myx, mult, euw, stw);
+    if (tv && k1) {
+      coord_seq<KIND>(h, true, true, myw, myx, mult, euw, stw);
       a.w[mycol] = myw;
 #pragma unroll
-      for (int j = 0; j < NS; ++j) if (k1) seq_state_ptr<KIND>(a, true, j)[mycol] = stw[j];
+      for (int j = 0; j < NS; ++j) seq_state_ptr<KIND>(a, true, j)[mycol] = stw[j];
     }
 #pragma unroll
     for (int j = 0; j < SL; ++j) {
@@ -1214,10 +1274,20 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
         for (int n = 0; n < NS; ++n) seq_state_ptr<KIND>(a, false, n)[at] = st[n];
       }
     }
+    FMX_TW(tC);
     // the stores complete (release), then the tag: whoever waits for this example gathers after it
     if (lane == 0) __hip_atomic_store(&f_done[slot], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     cur = nxt;
+#ifdef FMX_SEQ_TIMING
+    ++nE;
+#endif
+    FMX_TW(tD);
   }
+#ifdef FMX_SEQ_TIMING
+  if (ww == 0 && lane == 0 && nE) printf("reassoc worker 0: %llu examples; memtime ticks per example: conflict wait %.0f  A %.0f  mult wait %.0f  C %.0f  release %.0f\n", nE,
+                                         (double)tW / nE, (double)tA / nE, (double)tM / nE, (double)tC / nE, (double)tD / nE);
+#endif
+#undef FMX_TW
 }
 
 // the windowed learner applies when every row is a fast row; FMX_SEQ_WINDOW=0 in the environment keeps the one-wave kernel
@@ -1271,7 +1341,7 @@ static bool reassoc_mode(const fmx_engine* e) {
 
 template <int KIND>
 static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa, int nz) {
-  if constexpr (KIND != UPD_TDAP) {
+  if constexpr (KIND == UPD_SGD_L2 || KIND == UPD_SGD_L1) {
     if (reassoc_mode(e)) {
 #define FMX_RE(KL, NZ) hipLaunchKernelGGL((fm_seq_reassoc_k<KIND, KL, NZ>), dim3(1), dim3(SeqRe<KIND, KL, NZ>::NW * 64), 0, e->stream, a, wa, e->hyper)
       if (e->k <= 16) { if (nz == 32) FMX_RE(16, 32); else FMX_RE(16, 64); }
@@ -1280,6 +1350,8 @@ static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& w
 #undef FMX_RE
       return;
     }
+  }
+  if constexpr (KIND != UPD_TDAP) {
     const int pm = pipe_mode();
 #define FMX_PIPE(KL, NZ)                                                                                                                            \
   if (pm == 2 || (pm == 1 && PipeFits<KIND, KL, NZ>::value)) {                                                                                      \

@@ -19,15 +19,19 @@ def _movielens_shaped(n=100_000, users=943, items=1682, seed=0):
     return X, rating
 
 
+@pytest.mark.parametrize("mode", ["sequential", "sequential_bitwise"])
 @pytest.mark.parametrize("task", ["REGRESSION", "CLASSIFICATION"])
-def test_config0_movielens_shaped_sgd(task):
+def test_config0_movielens_shaped_sgd(task, mode):
+    """configs[0] at full size through the mirror of the R API, in both reference-order forms: "sequential" (the default: SGD's forward sum reassociated,
+    cfg.seq_reassociate) and "sequential_bitwise" (the reference's association).  p = 2625 and two entries per row: nearly every example shares a feature with
+    one of its neighbours, so the reassociated learner's waves hand the parameters to each other through the done tags for the whole run."""
     import fmwr_amd as fm
     X, rating = _movielens_shaped()
     y = rating if task == "REGRESSION" else (rating >= 4).astype(np.float64)  # {0,1} labels -> {-1,+1} (R/fm_train.R:112-122)
     data = fm.fm_matrix(X, y)
     ctl = [fm.model_control(task, **{"factor.number": 8, "L2.w1": 1e-3, "L2.v": 1e-3, "v.init_stdev": 0.05}),
            fm.solver_control(max_iter=100_000, solver=fm.SGD_solver(learn_rate=0.02))]
-    fit = fm.fm_train(data, normalize=False, control=ctl, seed=42, mode="sequential")
+    fit = fm.fm_train(data, normalize=False, control=ctl, seed=42, mode=mode)
     # oracle run from the same V0
     k, p, n = 8, X.shape[1], X.shape[0]
     v0 = np.random.default_rng(42).normal(0.0, 0.05, (k, p))
@@ -38,7 +42,7 @@ def test_config0_movielens_shaped_sgd(task):
     ref = oracle.sgd_learn(P, Xo, yy.astype(np.float32), 0.0, np.zeros(p), v0.ravel(), 100_000)
     rv = ref["v"].reshape(k, p)
     assert np.max(np.abs(fit["Model"]["v"] - rv)) <= 1e-5 * np.max(np.abs(rv))       # north_star: 1e-5 relative on V
-    assert np.max(np.abs(fit["Model"]["v"] - rv)) <= 1e-10 * np.max(np.abs(rv))      # in fact ~1e-15
+    assert np.max(np.abs(fit["Model"]["v"] - rv)) <= (1e-10 if mode == "sequential" else 1e-13) * np.max(np.abs(rv))
     assert abs(fit["Model"]["w0"] - ref["w0"]) < 1e-10
     pred = fm.predict(fit, data, normalize=False)
     raw = oracle.predict_batch(P, Xo, ref["w0"], ref["w"], ref["v"])
