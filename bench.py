@@ -1053,7 +1053,7 @@ def driver_line(d):
     r, cfg = d.get("roofline", {}), d.get("config", {})
     line = {kk: _num(d[kk]) for kk in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if kk in d}
     line["config"] = {"workload": _cap(cfg.get("workload"), 300)}
-    for kk in ("batch_rows_per_gpu", "global_batch_rows", "state", "parallelism", "levels", "feature_order", "learn_rate"):
+    for kk in ("batch_rows_per_gpu", "tile_rows", "global_batch_rows", "state", "parallelism", "levels", "feature_order", "learn_rate"):
         if kk in cfg:
             line["config"][kk] = _cap(_num(cfg[kk]), 120)
     if isinstance(cfg.get("exchange"), (str, dict)):
