@@ -770,6 +770,174 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
   }
 }
 
+// ---- deep exact plans: the level loop inside ONE launch -----------------------------------------------------------------------------------
+// The reference's index order on columns without field structure is a CHAIN: 19 399 dependent levels of at most 109 features at 10 M x 1 M, 30 per row.  One
+// launch per level costs ~6.5 us (a wave's four dependent memory rounds -- feature id, column bounds, entries, (q, e) pairs -- plus the kernel boundary) for a
+// microsecond of work: 310 384 launches, 2.0 s per sweep.  Here a factor's whole sweep is one launch of PERSIST_WAVES co-resident one-wave workgroups: wave g takes the
+// features g, g + NW, ... of every level, and the levels are ordered by ONE monotonic counter of completed features -- a feature of level l may start once
+// done >= level_ptr[l] (every feature of the levels before it has stored its corrections).  What a step reads that another wave wrote in this launch -- the
+// (q, e) pairs -- moves write-through: 16-byte sc1 stores, drained (s_waitcnt vmcnt(0)) before the wave's agent-scope add, and sc1 loads issued after the poll
+// has matched; no fence on either side (MI355X_MICROARCH.md, visibility: sc1 stores and loads + an atomic counter are valid under any workgroup placement).
+// Everything static -- the level's feature, its column bounds, rows and values, its own V entry (only this step writes it) -- is fetched BEFORE the wait.
+// Same arithmetic, same order per feature as als_level_k / als_w_level_k: the same bits (tests/test_gpu_configs4.py).
+// Every wait is bounded: ~4e6 polls (seconds; a legitimate wait is microseconds) raise ctl[1], every other wait then ends, and the host reports the sweep failed.
+// Workgroups of ONE wave: the wave that stores is the wave that drains and signals, the wave that polls is the wave that loads (the hand-off form the guide lists: one
+// lane of each storing workgroup signals for all that workgroup's stores; the polling wave loads after its poll has matched).
+constexpr int PERSIST_WAVES = 128, PERSIST_CTL_WORDS = 16;
+__device__ __forceinline__ double2 pair_load_sc1(__amdgpu_buffer_rsrc_t r, uint32_t row) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(row * 16u), 0, 16);   // aux 16 = sc1: past this CU's L1
+  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+__device__ __forceinline__ void pair_store_sc1(__amdgpu_buffer_rsrc_t r, uint32_t row, double2 c) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t v;
+  v.x = (uint32_t)__double2loint(c.x); v.y = (uint32_t)__double2hiint(c.x); v.z = (uint32_t)__double2loint(c.y); v.w = (uint32_t)__double2hiint(c.y);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 16u), 0, 16);                  // write-through
+}
+
+template <bool W>
+__global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __restrict__ feats, const int64_t* __restrict__ level_ptr, int L,
+                                                                  const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
+                                                                  double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, double2* qe, uint32_t qe_bytes,
+                                                                  unsigned int* ctl) {
+  const int f = W ? 0 : dyn->f;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  const int lane = threadIdx.x;
+  const int gw = (int)blockIdx.x, NW = (int)gridDim.x;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(qe, 0, (int)qe_bytes, 0x00020000);
+  unsigned int spins = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t l0 = level_ptr[l], l1 = level_ptr[l + 1];
+    for (int64_t j = l0 + gw; j < l1; j += NW) {
+      // ---- static: before the wait
+      const uint32_t i = feats[j];
+      const int64_t b = col_ptr[i], e = col_ptr[i + 1];
+      const size_t pi = W ? (size_t)i : (size_t)i * kp + f;
+      const double v_old = P[pi];
+      const double zi = znorm ? znorm[i] : 0.0;
+      float kx[ALS_KEEP];
+      uint32_t kr[ALS_KEEP];
+      double2 kc[ALS_KEEP];
+#pragma unroll
+      for (int s = 0; s < ALS_KEEP; ++s) { kx[s] = 0.f; kr[s] = 0u; }
+      auto load_static = [&](int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+          const int64_t t = b + lane + 64 * s;
+          const int64_t tc = t < e ? t : 0;
+          kx[s] = cval[tc];
+          kr[s] = crow[tc];
+        }
+      };
+      load_static(0, 2);
+      if (e - b > 128) load_static(2, ALS_KEEP);
+      // ---- every feature of the levels before this one has stored its corrections
+      for (;;) {
+        if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)l0) break;
+        if ((++spins & 255u) == 0) {
+          if (spins > (1u << 22)) __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      spins = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: the loads below stay below the poll)
+      // ---- sums (:310-317), entries lane, lane + 64, ...
+      auto load_pairs = [&](int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) kc[s] = pair_load_sc1(rs, kr[s]);
+#pragma unroll
+        for (int s = s0; s < s1; ++s) if (b + lane + 64 * s >= e) { kx[s] = 0.f; kc[s] = make_double2(0.0, 0.0); }
+      };
+#pragma unroll
+      for (int s = 0; s < ALS_KEEP; ++s) kc[s] = make_double2(0.0, 0.0);
+      load_pairs(0, 2);
+      if (e - b > 128) load_pairs(2, ALS_KEEP);
+      double a_mean = 0.0, a_var = 0.0;
+      if constexpr (W) {
+        // the w step adds in pairs of slots (als_w_level_k: WU = 2 entries per lane and round)
+#pragma unroll
+        for (int s = 0; s < ALS_KEEP; ++s) {
+          if (b + lane + 64 * s < e) {
+            const double x = (double)kx[s];
+            a_mean += kc[s].y * x - v_old * x * x;
+            a_var += x * x;
+          }
+        }
+        for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+          const double x = (double)cval[t];
+          const double2 c = pair_load_sc1(rs, crow[t]);
+          a_mean += c.y * x - v_old * x * x;
+          a_var += x * x;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < ALS_KEEP; ++s) {
+          const float xx = kx[s] * kx[s];
+          const double h = (double)kx[s] * kc[s].x - (double)xx * v_old;  // x = 0 for the padding slots: h = 0
+          a_mean += h * kc[s].y;
+          a_var += h * h;
+        }
+        for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+          const float x = cval[t];
+          const float xx = x * x;
+          const double2 c = pair_load_sc1(rs, crow[t]);
+          const double h = (double)x * c.x - (double)xx * v_old;
+          a_mean += h * c.y;
+          a_var += h * h;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        a_mean += __shfl_xor(a_mean, off);
+        a_var += __shfl_xor(a_var, off);
+      }
+      double v_new;
+      if constexpr (W) {
+        a_var = 1.0 / (lambda + alpha * a_var);
+        a_mean = -a_var * (alpha * a_mean - mu * lambda);
+        v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + a_var * zi : a_mean);   // (:239: the variance where a standard deviation belongs; kept)
+      } else {
+        a_mean -= v_old * a_var;                               // :318
+        a_var = 1.0 / (lambda + alpha * a_var);                // :319
+        a_mean = -a_var * (alpha * a_mean - mu * lambda);      // :320
+        v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + sqrt(a_var) * zi : a_mean);
+      }
+      if (!bad_number(v_new)) {                                // CHECK_PARAM (:336): otherwise keep the old value, skip the corrections
+        if (lane == 0) P[pi] = v_new;
+        const double v_diff = v_old - v_new;
+#pragma unroll
+        for (int s = 0; s < ALS_KEEP; ++s) {                   // :341-350 from the kept entries
+          if (b + lane + 64 * s < e) {
+            if constexpr (W) pair_store_sc1(rs, kr[s], make_double2(kc[s].x, kc[s].y - (double)kx[s] * v_diff));
+            else {
+              const float xx = kx[s] * kx[s];
+              const double h = (double)kx[s] * kc[s].x - (double)xx * v_old;
+              pair_store_sc1(rs, kr[s], make_double2(kc[s].x - (double)kx[s] * v_diff, kc[s].y - h * v_diff));
+            }
+          }
+        }
+        for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+          const float x = cval[t];
+          const uint32_t r = crow[t];
+          const double2 c = pair_load_sc1(rs, r);
+          if constexpr (W) pair_store_sc1(rs, r, make_double2(c.x, c.y - (double)x * v_diff));
+          else {
+            const float xx = x * x;
+            const double h = (double)x * c.x - (double)xx * v_old;
+            pair_store_sc1(rs, r, make_double2(c.x - (double)x * v_diff, c.y - h * v_diff));
+          }
+        }
+      }
+      // ---- drained, then counted: whoever reads done >= level_ptr[l + 1] finds this feature's pairs in memory
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- w0 and w sweeps of the ALS learner (MCMC_ALS_Learner.h:162-270, ALS branch, the exact one-thread form) -------------
 __global__ void als_residual_k(const double* __restrict__ yhat, const float* __restrict__ y, int64_t n, double2* __restrict__ qe,
                                const double* __restrict__ dp_y) {
@@ -1126,6 +1294,7 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   }
   als_tiled_free(m); m->als_tiled_tried = 0;
   (void)hipFree(m->als_feats); m->als_feats = nullptr;
+  (void)hipFree(m->als_level_ptr_dev); m->als_level_ptr_dev = nullptr;
   (void)hipFree(m->als_heavy); m->als_heavy = nullptr;
   (void)hipFree(m->als_vh); (void)hipFree(m->als_vh_seg0); (void)hipFree(m->als_vseg_feat); (void)hipFree(m->als_vseg_b); (void)hipFree(m->als_vseg_e); (void)hipFree(m->als_vh_work);
   m->als_vh = nullptr; m->als_vh_seg0 = nullptr; m->als_vseg_feat = nullptr; m->als_vseg_b = nullptr; m->als_vseg_e = nullptr; m->als_vh_work = nullptr;
@@ -1589,9 +1758,49 @@ static bool allf_applies(const fmx_engine* e, const fmx_matrix* m) {
   return true;
 }
 
+// Does the persistent form take this plan?  A deep exact plan of light columns only (no workgroup-wide or segmented columns, no tiled levels), a pair table a
+// buffer descriptor can address.  FMX_ALS_PERSIST=0 keeps one launch per level (the tests compare the two: the same bits).
+constexpr int PERSIST_MIN_LEVELS = 64;
+static bool persist_applies(const fmx_matrix* m) {
+  const char* v = getenv("FMX_ALS_PERSIST");
+  if (v && v[0] == '0') return false;
+  if (m->als_approx || m->als_tiled) return false;
+  if ((int)m->als_level_ptr.size() - 1 < PERSIST_MIN_LEVELS) return false;
+  if (!m->als_heavy_ptr.empty() && m->als_heavy_ptr.back() != 0) return false;
+  if (!m->als_vh_ptr.empty() && m->als_vh_ptr.back() != 0) return false;
+  return (uint64_t)m->n * sizeof(double2) <= 0xFFFFFFF0ull && m->als_level_ptr.back() < (int64_t)0xFFFFFFFFll;
+}
+template <bool W>
+static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const SweepDyn* dyn) {
+  const int L = (int)m->als_level_ptr.size() - 1;
+  if (!m->als_level_ptr_dev) {
+    FMX_HIP(hipMalloc(&m->als_level_ptr_dev, m->als_level_ptr.size() * sizeof(int64_t)));
+    FMX_HIP(hipMemcpy(m->als_level_ptr_dev, m->als_level_ptr.data(), m->als_level_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  }
+  if (!e->als_persist_ctl) FMX_HIP(hipMalloc(&e->als_persist_ctl, PERSIST_CTL_WORDS * sizeof(unsigned int)));
+  FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, PERSIST_CTL_WORDS * sizeof(unsigned int), e->stream));   // the counter and the abort word, every launch
+  prof_begin(e, FMX_KERNEL_ALS_SWEEP);
+  hipLaunchKernelGGL((als_exact_persist_k<W>), dim3(PERSIST_WAVES), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
+                     (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, W ? e->dw : e->dV, e->kp64, dyn, d_qe,
+                     (uint32_t)((uint64_t)m->n * sizeof(double2)), e->als_persist_ctl);
+  prof_end(e);
+  FMX_HIP(hipGetLastError());
+  return FMX_OK;
+}
+// after the sweeps of a call: did a wait of the persistent form give up?  (never seen; a lost update would otherwise be silent)
+static int persist_check(fmx_engine* e) {
+  if (!e->als_persist_ctl) return FMX_OK;
+  unsigned int ctl[2] = {0, 0};
+  FMX_HIP(hipMemcpyAsync(ctl, e->als_persist_ctl, sizeof(ctl), hipMemcpyDeviceToHost, e->stream));
+  FMX_HIP(hipStreamSynchronize(e->stream));
+  FMX_CHECK(ctl[1] == 0, FMX_ERR_HIP, "the persistent sweep gave up waiting after %u features (its workgroups were not all running?): V and the residual are part-way through a sweep", ctl[0]);
+  return FMX_OK;
+}
+
 // one sweep of the w coordinates or of one factor, by replay when the plan is deep
 template <bool W>
 static void sweep_once(fmx_engine* e, fmx_matrix* m, double2* d_qe, double2* d_qe_new, SweepDyn* dyn) {
+  if (!d_qe_new && persist_applies(m) && sweep_persist<W>(e, m, d_qe, dyn) == FMX_OK) return;
   if (sweep_graph_wanted<W>(m)) {
     hipGraphExec_t x = sweep_graph<W>(e, m, d_qe, dyn);
     if (x && hipGraphLaunch(x, e->stream) == hipSuccess) return;
@@ -1801,6 +2010,7 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     e->als_qnext = nullptr;
   }
   e->als_vf_slot = -1;
+  if (!d_qe_new && persist_applies(m)) FMX_TRY(persist_check(e));
   return FMX_OK;
 }
 
@@ -1885,7 +2095,10 @@ static int w_sweep_guarded(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     e->als_vf_slot = -1; e->als_qnext = nullptr;
     bool blocks_done = false;
     if (!d_qe_new) FMX_TRY(als_order_w_sweep(e, m, d_qe, dyn, &blocks_done));   // a complete plan whose lists fit a block: one kernel per level (fm_als_blocks.hip)
-    if (!blocks_done) sweep_once<true>(e, m, d_qe, d_qe_new, dyn);
+    if (!blocks_done) {
+      sweep_once<true>(e, m, d_qe, d_qe_new, dyn);
+      if (!d_qe_new && persist_applies(m)) FMX_TRY(persist_check(e));
+    }
     e->als_vf_slot = -1;
     bool redo = false;
     if (pass == 0) FMX_TRY(g.end(&redo));

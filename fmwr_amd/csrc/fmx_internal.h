@@ -185,6 +185,7 @@ struct fmx_matrix {
   std::vector<int64_t> als_level_maxlen; // per level: the longest light column (sizes the LDS of the feature-major kernel)
   int als_force_exact = 0;              // an approximate sweep raised the residual on this matrix: only exact plans from now on
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
+  int64_t* als_level_ptr_dev = nullptr; // als_level_ptr on the device (the persistent form of a deep exact sweep walks the levels inside ONE launch), uploaded on first use
   void* als_tiled = nullptr;            // row-tiled form of the wide levels of an exact plan (fm_als_tiled.hip: AlsTiled), or null
   int als_tiled_tried = 0;              // the tiled plan was built, or found not to apply, for the current plan and values
 };
@@ -296,6 +297,7 @@ struct fmx_engine {
   uint64_t als_q_hash = 0, als_q_plan = 0;
   void* als_hash_word = nullptr;
   double* als_lam_mu = nullptr;    // (lambda_f, mu_f) of every factor for the feature-major sweep (cfg.als_max_levels = -2)
+  unsigned int* als_persist_ctl = nullptr;   // 64 bytes: {features done, abort, ...} of the persistent deep sweep (als_exact_persist_k), zeroed before every launch
   const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
                                       // finished factor's q when that level is a tiled one (it then clears this pointer: the pick kernel is not needed)
   int als_vf_slot = -1, als_vf_buf = 0;  // tiled sweep: the tiled level whose coordinates the previous level's step kernel already gathered, and into which half

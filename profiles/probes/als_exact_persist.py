@@ -1,0 +1,28 @@
+"""configs[4] on SURVEY 8(d)'s i.i.d. columns in the reference's own order (cfg.als_max_levels = 0): one launch per level (FMX_ALS_PERSIST=0) against the persistent
+form (one launch per factor).  usage: python profiles/probes/als_exact_persist.py [rows] [sweeps]"""
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+from fmwr_amd import _lib as L, engine
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+p, z, k = 1_000_000, 30, 16
+m = engine.Matrix.synthetic_iid(n, p, z, 20240001, law=L.COLUMNS_UNIFORM)
+for persist in ("1", "0"):
+    os.environ["FMX_ALS_PERSIST"] = persist
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=0)
+    e.init_normal(20240001, 0.0, 0.01)
+    levels, largest, approx, _ = e.als_plan(m)
+    d_err = torch.randn(n, dtype=torch.float64, device="cuda")
+    ss0 = float((d_err * d_err).sum())
+    e.vsweep_device(m, d_err.data_ptr(), alpha=1.0); e.sync()
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        e.vsweep_device(m, d_err.data_ptr(), alpha=1.0)
+    e.sync()
+    dt = (time.perf_counter() - t0) / sweeps
+    ss1 = float((d_err * d_err).sum())
+    print(f"FMX_ALS_PERSIST={persist}: levels {levels} (largest {largest}), sweep {dt * 1e3:.1f} ms = {n / dt / 1e6:.2f} M examples/s = {dt / (levels * k) * 1e6:.2f} us per level; "
+          f"sum e^2 {ss0:.6e} -> {ss1:.6e}; V checksum {float(np.sum(e.get_rows(np.arange(0, p, 997, dtype=np.uint32))[1])):.17g}", flush=True)
+    e.close()

@@ -569,3 +569,59 @@ def test_deep_plans_replayed_as_a_graph_equal_the_eager_launches(monkeypatch):
             out[(flag, gibbs)] = (err, e.get_params()[2])
     for gibbs in (False, True):
         assert np.array_equal(out[("1", gibbs)][0], out[("0", gibbs)][0]) and np.array_equal(out[("1", gibbs)][1], out[("0", gibbs)][1])
+
+
+@pytest.mark.parametrize("values,gibbs", [("ones", False), ("normal", True), ("normal", False), ("ones", True)])
+def test_configs4_deep_exact_plan_in_one_launch_per_factor(monkeypatch, values, gibbs):
+    """SURVEY 8(d)'s i.i.d. columns in the reference's own index order: a chain of dependent levels (20 K x 6 K, 30 per row: more than 1 000).  The persistent form
+    (als_exact_persist_k: the level loop inside one launch per factor, the levels ordered by a counter of completed features, the (q, e) pairs handed between waves by
+    write-through stores and L1-bypassing loads) must give bit for bit what one launch per level gives (FMX_ALS_PERSIST=0), twice, and the oracle's numbers to 1e-10."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "iid", n, p, 47, values)
+    w0, w, v = util.params(p, K, 23, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    P = oracle.params(task=oracle.REGRESSION, k=K)
+    err0 = oracle.predict_batch(P, X, w0, w, v.ravel()) - y
+    lam = np.linspace(0.2, 0.6, K); mu = np.linspace(-0.05, 0.05, K)
+    z = np.random.default_rng(11).normal(0, 1, (K, p)) if gibbs else None
+    rv, rerr, _ = oracle.als_update_v(K, X, v.ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+    res = []
+    for persist in ("1", "1", "0"):
+        monkeypatch.setenv("FMX_ALS_PERSIST", persist)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        levels, largest, approx, _ = e.als_plan(m)
+        assert not approx and levels > 1_000
+        gerr = e.als_vsweep(m, err0, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+        gerr = e.als_vsweep(m, gerr, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z) if not gibbs else gerr   # a second sweep on the first one's state (ALS)
+        res.append((e.get_params()[2], gerr))
+        e.close(); m.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
+    if gibbs:
+        assert util.rel_err(res[0][0], rv.reshape(K, p)) < 1e-10 and util.rel_err(res[0][1], rerr) < 1e-10
+    else:
+        rv2, rerr2, _ = oracle.als_update_v(K, X, rv, rerr, alpha=1.1, v_lambda=lam, v_mu=mu)
+        assert util.rel_err(res[0][0], rv2.reshape(K, p)) < 1e-10 and util.rel_err(res[0][1], rerr2) < 1e-10
+
+
+def test_configs4_deep_exact_plan_learner_w_sweep_in_one_launch(monkeypatch):
+    """The ALS learner on the same chain-shaped plan: its w sweep (update_w, :208-256) takes the persistent form too; iterations with and without the V sweep, bit
+    for bit the one-launch-per-level form."""
+    from fmwr_amd import _lib as L, engine
+    n, p = 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "iid", n, p, 53, "normal")
+    w0, w, v = util.params(p, K, 29, stdev=0.05, fp32=False)
+    res = []
+    for persist in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_PERSIST", persist)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, l2_w1=0.1, l2_v=0.1)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        e.als_train(m, 2, with_v=True)
+        res.append(e.get_params())
+        e.close(); m.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert not np.array_equal(res[0][1], w)
