@@ -783,7 +783,12 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
 // Every wait is bounded: ~4e6 polls (seconds; a legitimate wait is microseconds) raise ctl[1], every other wait then ends, and the host reports the sweep failed.
 // Workgroups of ONE wave: the wave that stores is the wave that drains and signals, the wave that polls is the wave that loads (the hand-off form the guide lists: one
 // lane of each storing workgroup signals for all that workgroup's stores; the polling wave loads after its poll has matched).
-constexpr int PERSIST_WAVES = 128, PERSIST_CTL_WORDS = 16;
+// The counter is kept in PERSIST_REPL replicas, each on a line of its own: a finishing wave adds to every replica with ONE instruction (one lane per replica), a
+// waiting wave polls the replica gw % PERSIST_REPL -- one word polled by all 128 waves and added to by a hundred per level is a queue at one memory channel.
+#ifndef FMX_PERSIST_REPL
+#define FMX_PERSIST_REPL 32
+#endif
+constexpr int PERSIST_WAVES = 128, PERSIST_REPL = FMX_PERSIST_REPL, PERSIST_LINE_WORDS = 32, PERSIST_CTL_WORDS = (PERSIST_REPL + 1) * PERSIST_LINE_WORDS;   // + the abort word's line
 __device__ __forceinline__ double2 pair_load_sc1(__amdgpu_buffer_rsrc_t r, uint32_t row) {
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(row * 16u), 0, 16);   // aux 16 = sc1: past this CU's L1
@@ -796,11 +801,32 @@ __device__ __forceinline__ void pair_store_sc1(__amdgpu_buffer_rsrc_t r, uint32_
   __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 16u), 0, 16);                  // write-through
 }
 
+// The wave sum of als_level_k -- x += shfl_xor(x, 32), 16, 8, 4, 2, 1 -- with the same tree, hence the same bits, without the LDS crossbar: the halves and the
+// rows meet through gfx950's v_permlane32_swap / v_permlane16_swap (both results added: a + b == b + a), the lanes of a row through DPP row rotations
+// (after the 32-, 16- and 8-steps a lane's value depends on its index mod 8 only, so the lane 4 (2, 1) to its right holds what lane ^ 4 (2, 1) holds).
+__device__ __forceinline__ double butterfly_allsum(double x) {
+  {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+  {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+  x += FMX_DPP64(x, 0x128);   // row_ror:8
+  x += FMX_DPP64(x, 0x124);   // row_ror:4
+  x += FMX_DPP64(x, 0x122);   // row_ror:2
+  x += FMX_DPP64(x, 0x121);   // row_ror:1
+  return x;
+}
+
 template <bool W>
 __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __restrict__ feats, const int64_t* __restrict__ level_ptr, int L,
-                                                                  const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
-                                                                  double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, double2* qe, uint32_t qe_bytes,
-                                                                  unsigned int* ctl) {
+                                                          const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
+                                                          double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, double2* qe, uint32_t qe_bytes,
+                                                          unsigned int* ctl) {
   const int f = W ? 0 : dyn->f;
   const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
   const double* __restrict__ znorm = dyn->znorm;
@@ -808,134 +834,181 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
   const int gw = (int)blockIdx.x, NW = (int)gridDim.x;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(qe, 0, (int)qe_bytes, 0x00020000);
   unsigned int spins = 0;
-  for (int l = 0; l < L; ++l) {
-    const int64_t l0 = level_ptr[l], l1 = level_ptr[l + 1];
-    for (int64_t j = l0 + gw; j < l1; j += NW) {
-      // ---- static: before the wait
-      const uint32_t i = feats[j];
-      const int64_t b = col_ptr[i], e = col_ptr[i + 1];
-      const size_t pi = W ? (size_t)i : (size_t)i * kp + f;
-      const double v_old = P[pi];
-      const double zi = znorm ? znorm[i] : 0.0;
-      float kx[ALS_KEEP];
-      uint32_t kr[ALS_KEEP];
-      double2 kc[ALS_KEEP];
+  unsigned int* const my_ctr = ctl + (gw % PERSIST_REPL) * PERSIST_LINE_WORDS;
+  unsigned int* const abort_w = ctl + PERSIST_REPL * PERSIST_LINE_WORDS;
+#ifdef FMX_PERSIST_TIMING
+  unsigned long long tP = 0, tG = 0, tC = 0, tD = 0, nF = 0, nPoll = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+#define FMX_TP(acc) do { c1 = __builtin_amdgcn_s_memtime(); acc += c1 - c0; c0 = c1; } while (0)
+#else
+#define FMX_TP(acc) do { } while (0)
+#endif
+  // this wave's features, in order: positions gw, gw + NW, ... of every level.  (l, l0, j) walks them; false at the end of the plan
+  int l = 0;
+  int64_t l0 = level_ptr[0], j = l0 + gw - NW;
+  auto advance = [&]() {
+    j += NW;
+    for (;;) {
+      const int64_t l1 = level_ptr[l + 1];
+      if (j < l1) return true;
+      if (++l >= L) return false;
+      l0 = l1;
+      j = l0 + gw;
+    }
+  };
+  // The static part of a step -- the feature, its column's bounds, rows and values, its own parameter (only this step writes it), its normal -- is three
+  // dependent memory rounds (2.4 us: as long as everything else of a step together).  It is fetched one feature AHEAD, each round issued behind one of the current
+  // step's own waits (the poll, the pair gather, the store drain), so it costs the chain nothing.
+  struct Stat { int64_t l0, b, e; uint32_t i; double v_old, zi; float kx[ALS_KEEP]; uint32_t kr[ALS_KEEP]; };
+  auto round1 = [&](Stat& st) { st.l0 = l0; st.i = feats[j]; };
+  auto round2 = [&](Stat& st) {
+    st.b = col_ptr[st.i]; st.e = col_ptr[st.i + 1];
+    st.v_old = P[W ? (size_t)st.i : (size_t)st.i * kp + f];
+    st.zi = znorm ? znorm[st.i] : 0.0;
+  };
+  auto round3 = [&](Stat& st) {
 #pragma unroll
-      for (int s = 0; s < ALS_KEEP; ++s) { kx[s] = 0.f; kr[s] = 0u; }
-      auto load_static = [&](int s0, int s1) {
-#pragma unroll
-        for (int s = s0; s < s1; ++s) {
-          const int64_t t = b + lane + 64 * s;
-          const int64_t tc = t < e ? t : 0;
-          kx[s] = cval[tc];
-          kr[s] = crow[tc];
-        }
-      };
-      load_static(0, 2);
-      if (e - b > 128) load_static(2, ALS_KEEP);
-      // ---- every feature of the levels before this one has stored its corrections
+    for (int s = 0; s < ALS_KEEP; ++s) {
+      const int64_t t = st.b + lane + 64 * s;
+      const int64_t tc = t < st.e ? t : 0;   // (unconditional on a clamped index: a branch would put a wait at its join)
+      st.kx[s] = cval[tc];
+      st.kr[s] = crow[tc];
+    }
+  };
+  Stat cur, nxt;
+  bool have = advance();
+  if (have) { round1(cur); round2(cur); round3(cur); }
+  while (have) {
+    FMX_TP(tD);
+    const bool have_next = advance();
+    if (have_next) round1(nxt);
+    // ---- every feature of the levels before this one has stored its corrections.  ONE poll at a time (four in flight a quarter of a trip apart were tried: the
+    // replicas' lines then queue and a level takes 4.2 us instead of 3.8), and a wave whose turn is levels away -- on average 76 of the 128 have no feature in the
+    // level being swept -- sleeps by its distance instead of competing with the waves whose turn is next
+    {
+      const unsigned int want = (unsigned int)cur.l0;
       for (;;) {
-        if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)l0) break;
+#ifdef FMX_PERSIST_TIMING
+        ++nPoll;
+#endif
+        const unsigned int seen = __hip_atomic_load(my_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= want) break;
         if ((++spins & 255u) == 0) {
-          if (spins > (1u << 22)) __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+          if (spins > (1u << 22)) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
         }
-        __builtin_amdgcn_s_sleep(2);
+        const unsigned int away = want - seen;      // features still to finish before this wave's turn (a level holds at most a few hundred)
+        if (away > 512u) __builtin_amdgcn_s_sleep(127);
+        else if (away > 160u) __builtin_amdgcn_s_sleep(40);
+        else __builtin_amdgcn_s_sleep(2);
       }
-      spins = 0;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: the loads below stay below the poll)
-      // ---- sums (:310-317), entries lane, lane + 64, ...
-      auto load_pairs = [&](int s0, int s1) {
+    }
+    spins = 0;
+    FMX_TP(tP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: the loads below stay below the poll)
+    const int64_t b = cur.b, e = cur.e;
+    const double v_old = cur.v_old;
+    const int ns = (int)((e - b + 63) >> 6);   // live slots of the column (wave-uniform): the padding slots' zero terms add nothing, so they are not computed
+    // ---- the pairs of the column's rows: entries lane, lane + 64, ... (:310-317)
+    double2 kc[ALS_KEEP];
 #pragma unroll
-        for (int s = s0; s < s1; ++s) kc[s] = pair_load_sc1(rs, kr[s]);
+    for (int s = 0; s < ALS_KEEP; ++s) kc[s] = pair_load_sc1(rs, cur.kr[s]);
+    if (have_next) round2(nxt);
 #pragma unroll
-        for (int s = s0; s < s1; ++s) if (b + lane + 64 * s >= e) { kx[s] = 0.f; kc[s] = make_double2(0.0, 0.0); }
-      };
+    for (int s = 0; s < ALS_KEEP; ++s) if (b + lane + 64 * s >= e) { cur.kx[s] = 0.f; kc[s] = make_double2(0.0, 0.0); }
+#ifdef FMX_PERSIST_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    FMX_TP(tG);
+    double a_mean = 0.0, a_var = 0.0;
+    if constexpr (W) {
 #pragma unroll
-      for (int s = 0; s < ALS_KEEP; ++s) kc[s] = make_double2(0.0, 0.0);
-      load_pairs(0, 2);
-      if (e - b > 128) load_pairs(2, ALS_KEEP);
-      double a_mean = 0.0, a_var = 0.0;
-      if constexpr (W) {
-        // the w step adds in pairs of slots (als_w_level_k: WU = 2 entries per lane and round)
-#pragma unroll
-        for (int s = 0; s < ALS_KEEP; ++s) {
-          if (b + lane + 64 * s < e) {
-            const double x = (double)kx[s];
-            a_mean += kc[s].y * x - v_old * x * x;
-            a_var += x * x;
-          }
-        }
-        for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
-          const double x = (double)cval[t];
-          const double2 c = pair_load_sc1(rs, crow[t]);
-          a_mean += c.y * x - v_old * x * x;
+      for (int s = 0; s < ALS_KEEP; ++s) {
+        if (s < ns && b + lane + 64 * s < e) {
+          const double x = (double)cur.kx[s];
+          a_mean += kc[s].y * x - v_old * x * x;
           a_var += x * x;
         }
-      } else {
+      }
+      for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+        const double x = (double)cval[t];
+        const double2 c = pair_load_sc1(rs, crow[t]);
+        a_mean += c.y * x - v_old * x * x;
+        a_var += x * x;
+      }
+    } else {
 #pragma unroll
-        for (int s = 0; s < ALS_KEEP; ++s) {
-          const float xx = kx[s] * kx[s];
-          const double h = (double)kx[s] * kc[s].x - (double)xx * v_old;  // x = 0 for the padding slots: h = 0
+      for (int s = 0; s < ALS_KEEP; ++s) {
+        if (s < ns) {
+          const float xx = cur.kx[s] * cur.kx[s];
+          const double h = (double)cur.kx[s] * kc[s].x - (double)xx * v_old;  // x = 0 for a lane past the column's end: h = 0
           a_mean += h * kc[s].y;
           a_var += h * h;
         }
-        for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
-          const float x = cval[t];
-          const float xx = x * x;
-          const double2 c = pair_load_sc1(rs, crow[t]);
-          const double h = (double)x * c.x - (double)xx * v_old;
-          a_mean += h * c.y;
-          a_var += h * h;
-        }
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        a_mean += __shfl_xor(a_mean, off);
-        a_var += __shfl_xor(a_var, off);
+      for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+        const float x = cval[t];
+        const float xx = x * x;
+        const double2 c = pair_load_sc1(rs, crow[t]);
+        const double h = (double)x * c.x - (double)xx * v_old;
+        a_mean += h * c.y;
+        a_var += h * h;
       }
-      double v_new;
-      if constexpr (W) {
-        a_var = 1.0 / (lambda + alpha * a_var);
-        a_mean = -a_var * (alpha * a_mean - mu * lambda);
-        v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + a_var * zi : a_mean);   // (:239: the variance where a standard deviation belongs; kept)
-      } else {
-        a_mean -= v_old * a_var;                               // :318
-        a_var = 1.0 / (lambda + alpha * a_var);                // :319
-        a_mean = -a_var * (alpha * a_mean - mu * lambda);      // :320
-        v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + sqrt(a_var) * zi : a_mean);
-      }
-      if (!bad_number(v_new)) {                                // CHECK_PARAM (:336): otherwise keep the old value, skip the corrections
-        if (lane == 0) P[pi] = v_new;
-        const double v_diff = v_old - v_new;
-#pragma unroll
-        for (int s = 0; s < ALS_KEEP; ++s) {                   // :341-350 from the kept entries
-          if (b + lane + 64 * s < e) {
-            if constexpr (W) pair_store_sc1(rs, kr[s], make_double2(kc[s].x, kc[s].y - (double)kx[s] * v_diff));
-            else {
-              const float xx = kx[s] * kx[s];
-              const double h = (double)kx[s] * kc[s].x - (double)xx * v_old;
-              pair_store_sc1(rs, kr[s], make_double2(kc[s].x - (double)kx[s] * v_diff, kc[s].y - h * v_diff));
-            }
-          }
-        }
-        for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
-          const float x = cval[t];
-          const uint32_t r = crow[t];
-          const double2 c = pair_load_sc1(rs, r);
-          if constexpr (W) pair_store_sc1(rs, r, make_double2(c.x, c.y - (double)x * v_diff));
-          else {
-            const float xx = x * x;
-            const double h = (double)x * c.x - (double)xx * v_old;
-            pair_store_sc1(rs, r, make_double2(c.x - (double)x * v_diff, c.y - h * v_diff));
-          }
-        }
-      }
-      // ---- drained, then counted: whoever reads done >= level_ptr[l + 1] finds this feature's pairs in memory
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (have_next) round3(nxt);
+    a_mean = butterfly_allsum(a_mean);
+    a_var = butterfly_allsum(a_var);
+    double v_new;
+    if constexpr (W) {
+      a_var = 1.0 / (lambda + alpha * a_var);
+      a_mean = -a_var * (alpha * a_mean - mu * lambda);
+      v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + a_var * cur.zi : a_mean);   // (:239: the variance where a standard deviation belongs; kept)
+    } else {
+      a_mean -= v_old * a_var;                               // :318
+      a_var = 1.0 / (lambda + alpha * a_var);                // :319
+      a_mean = -a_var * (alpha * a_mean - mu * lambda);      // :320
+      v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + sqrt(a_var) * cur.zi : a_mean);
+    }
+    if (!bad_number(v_new)) {                                // CHECK_PARAM (:336): otherwise keep the old value, skip the corrections
+      if (lane == 0) P[W ? (size_t)cur.i : (size_t)cur.i * kp + f] = v_new;
+      const double v_diff = v_old - v_new;
+#pragma unroll
+      for (int s = 0; s < ALS_KEEP; ++s) {                   // :341-350 from the kept entries
+        if (b + lane + 64 * s < e) {
+          if constexpr (W) pair_store_sc1(rs, cur.kr[s], make_double2(kc[s].x, kc[s].y - (double)cur.kx[s] * v_diff));
+          else {
+            const float xx = cur.kx[s] * cur.kx[s];
+            const double h = (double)cur.kx[s] * kc[s].x - (double)xx * v_old;
+            pair_store_sc1(rs, cur.kr[s], make_double2(kc[s].x - (double)cur.kx[s] * v_diff, kc[s].y - h * v_diff));
+          }
+        }
+      }
+      for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+        const float x = cval[t];
+        const uint32_t r = crow[t];
+        const double2 c = pair_load_sc1(rs, r);
+        if constexpr (W) pair_store_sc1(rs, r, make_double2(c.x, c.y - (double)x * v_diff));
+        else {
+          const float xx = x * x;
+          const double h = (double)x * c.x - (double)xx * v_old;
+          pair_store_sc1(rs, r, make_double2(c.x - (double)x * v_diff, c.y - h * v_diff));
+        }
+      }
+    }
+    // ---- drained, then counted: whoever reads done >= level_ptr[l + 1] finds this feature's pairs in memory
+    FMX_TP(tC);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < PERSIST_REPL) __hip_atomic_fetch_add(ctl + lane * PERSIST_LINE_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef FMX_PERSIST_TIMING
+    ++nF;
+#endif
+    cur = nxt;
+    have = have_next;
   }
+#ifdef FMX_PERSIST_TIMING
+  if ((gw == 0 || gw == 77) && lane == 0 && nF) printf("persist wave %d: %llu features, %.1f polls each; memtime ticks per feature: poll %.0f  gather %.0f  step+stores %.0f  drain+add+loop %.0f\n", gw, nF,
+                                        (double)nPoll / nF, (double)tP / nF, (double)tG / nF, (double)tC / nF, (double)tD / nF);
+#endif
+#undef FMX_TP
 }
 
 // ---- w0 and w sweeps of the ALS learner (MCMC_ALS_Learner.h:162-270, ALS branch, the exact one-thread form) -------------
@@ -1791,7 +1864,8 @@ static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const Swee
 static int persist_check(fmx_engine* e) {
   if (!e->als_persist_ctl) return FMX_OK;
   unsigned int ctl[2] = {0, 0};
-  FMX_HIP(hipMemcpyAsync(ctl, e->als_persist_ctl, sizeof(ctl), hipMemcpyDeviceToHost, e->stream));
+  FMX_HIP(hipMemcpyAsync(ctl, e->als_persist_ctl, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
+  FMX_HIP(hipMemcpyAsync(ctl + 1, e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
   FMX_HIP(hipStreamSynchronize(e->stream));
   FMX_CHECK(ctl[1] == 0, FMX_ERR_HIP, "the persistent sweep gave up waiting after %u features (its workgroups were not all running?): V and the residual are part-way through a sweep", ctl[0]);
   return FMX_OK;
