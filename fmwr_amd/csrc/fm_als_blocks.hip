@@ -403,10 +403,18 @@ __global__ void als_block_exit_k(const double2* __restrict__ src, const uint32_t
   else qe[row0[i]] = c;
   if (qlast_out) qlast_out[i] = c.x;   // (q carried from sweep to sweep: the last factor's final q)
 }
-// a 64-bit fingerprint of the fp64 V table: sum of (bits of element i) x (2 i + 1) modulo 2^64 -- integer adds commute, so any reduction order gives the same word
+// a 64-bit fingerprint of the fp64 V table: sum over i of mix(bits of element i XOR i x golden ratio) modulo 2^64, mix = splitmix64's finaliser -- integer adds commute, so
+// any reduction order gives the same word; every element is scrambled before it is summed (the round-5 form summed bits x (2 i + 1): linear, so sign flips of an even number
+// of entries, V -> -V included, cancelled -- ADVICE r5).  A backstop only: every host-side writer of V drops the carried table explicitly (als_q_invalidate).
+__device__ __forceinline__ unsigned long long vhash_mix(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
 __global__ __launch_bounds__(256) void als_vhash_k(const double* __restrict__ V, size_t count, unsigned long long* __restrict__ out) {
   unsigned long long h = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) h += (unsigned long long)__double_as_longlong(V[i]) * (2ull * i + 1ull);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+    h += vhash_mix((unsigned long long)__double_as_longlong(V[i]) ^ ((unsigned long long)i * 0x9E3779B97F4A7C15ull));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) h += ((unsigned long long)(unsigned)__shfl_xor((int)(h >> 32), o) << 32) + (unsigned)__shfl_xor((int)(h & 0xFFFFFFFFull), o);
   if ((threadIdx.x & 63) == 0) atomicAdd(out, h);

@@ -1824,10 +1824,22 @@ static hipGraphExec_t sweep_graph(fmx_engine* e, fmx_matrix* m, double2* d_qe, c
 
 // does the feature-major form (cfg.als_max_levels = -2) run on this plan?  A coloured plan of light lists of at most 1 024 rows; otherwise the sweep nests factor outer, as -1
 constexpr uint64_t ALLF_TRUSTED = 0xA11FA11FA11FA11Full;   // e->als_q_trusted of a row-major table: the matrix uid under this mask (a block-form table carries its plan's uid)
+// Levels whose lists the register kernels do not take (kp other than 8 / 16, or more than 512 rows) keep the rows' lines in LDS: (cap kp + 2 kp) doubles + cap row ids, which must fit
+// the 150 KB the kernel is allowed -- 1 024 rows at kp <= 16, 577 at kp = 32, 296 at kp = 64, 148 at kp = 128 (the bound used to ignore kp, and a level that did not fit failed
+// at its launch, in the middle of a sweep).  A plan with such a level nests factor outer, as -1.
+constexpr size_t ALLF_LDS_LIMIT = 150 * 1024;
+static size_t allf_lds_bytes(int64_t maxlen, int kp) {
+  const size_t cap = (size_t)((maxlen + 63) / 64 * 64);
+  return (cap * (size_t)kp + 2 * (size_t)kp) * sizeof(double) + cap * sizeof(uint32_t);
+}
 static bool allf_applies(const fmx_engine* e, const fmx_matrix* m) {
   if (!m->als_coloured || m->als_plan_cap != -2 || e->k <= 0) return false;
   if (m->als_heavy_ptr.empty() || m->als_heavy_ptr.back() != 0 || (!m->als_vh_ptr.empty() && m->als_vh_ptr.back() != 0)) return false;
-  for (int64_t v : m->als_level_maxlen) if (v > 1024) return false;
+  const bool in_regs = e->kp64 == 8 || e->kp64 == 16;
+  for (int64_t v : m->als_level_maxlen) {
+    if (v > 1024) return false;
+    if (!(in_regs && v <= 512) && allf_lds_bytes(v, e->kp64) > ALLF_LDS_LIMIT) return false;
+  }
   return true;
 }
 
@@ -1936,7 +1948,8 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
   // cfg.als_max_levels = -2 on a coloured plan of light lists: the FEATURE-MAJOR order -- all k factors of a feature while its rows' state is in LDS (als_level_allf_k)
   if (allf_applies(e, m) && !d_qe_new) {
     double* d_Qr = q_table(e, m);
-    if (d_Qr) {
+    FMX_CHECK(d_Qr != nullptr, FMX_ERR_HIP, "out of device memory: the feature-major sweep keeps an n x kp table of doubles (%.1f GB)", (double)m->n * e->kp64 * 8e-9);
+    {
       RowsArgs a{};
       a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = m->n;
       a.V = e->dV; a.w = e->dw; a.vs = e->kp64; a.ws = 1; a.scal = e->scal; a.yhat = nullptr; a.qout = d_Qr; a.qout_t = 0; a.link = FMX_LINK_NONE;   // q of every factor, ROW-major: [n][kp]
@@ -1953,15 +1966,17 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
       }
       const int carried_age = carried ? e->als_q_age : 0;
       e->als_q_have = 0; e->als_q_trusted = 0;
-      if (trusted || carried || launch_rows_forward(e, a, false, true) == FMX_OK) {
+      // (a failing forward pass is an error of the sweep, not a reason to change the nesting: fmx_als_plan_info has told the caller "feature-major" -- ADVICE r5)
+      if (!(trusted || carried)) FMX_TRY(launch_rows_forward(e, a, false, true));
+      {
         std::vector<double> lm((size_t)2 * e->k, 0.0);
         for (int f = 0; f < e->k; ++f) { lm[(size_t)2 * f] = h_lambda ? h_lambda[f] : 0.0; lm[(size_t)2 * f + 1] = h_mu ? h_mu[f] : 0.0; }
         if (!e->als_lam_mu) FMX_HIP(hipMalloc(&e->als_lam_mu, (size_t)2 * 1024 * sizeof(double)));
         FMX_HIP(hipMemcpyAsync(e->als_lam_mu, lm.data(), lm.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         FMX_HIP(hipStreamSynchronize(e->stream));   // (lm is a local)
         // (per sweep, not once per process: the attribute belongs to the CURRENT device's copy of the kernel, and engines may live on several devices)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        FMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ALLF_LDS_LIMIT));
+        FMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&als_level_allf_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ALLF_LDS_LIMIT));
         const int L = (int)m->als_level_ptr.size() - 1;
         const char* form_env = getenv("FMX_ALS_ALLF_FORM");   // 1: the LDS-resident kernel everywhere, 2: no one-wave kernel (read per call: the tests compare the forms)
         const int form = form_env ? atoi(form_env) : 0;
@@ -1975,7 +1990,7 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
           const int64_t l0 = m->als_level_ptr[(size_t)l], cnt = m->als_level_ptr[(size_t)l + 1] - l0;
           if (cnt == 0) continue;
           const int cap = (int)((m->als_level_maxlen[(size_t)l] + 63) / 64 * 64);
-          const size_t lds = ((size_t)cap * e->kp64 + 2 * (size_t)e->kp64) * sizeof(double) + (size_t)cap * sizeof(uint32_t);
+          const size_t lds = allf_lds_bytes(m->als_level_maxlen[(size_t)l], e->kp64);
           prof_begin(e, FMX_KERNEL_ALS_SWEEP);
 #define FMX_ALLF_ARGS (const uint32_t*)(m->als_feats + l0), (int)cnt, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, alpha, \
                       (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe
@@ -2003,6 +2018,7 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
                                (const uint32_t*)m->crow, (const float*)m->cval, e->dV, e->k, e->kp64, alpha, (const double*)e->als_lam_mu, d_znorm, (int64_t)m->p, d_Qr, d_qe, cap, eil ? 1 : 0);
 #undef FMX_ALLF_ARGS
           prof_end(e);
+          FMX_HIP(hipGetLastError());   // (per level: a launch that fails must not be followed by the levels after it)
         }
         if (eil) hipLaunchKernelGGL(allf_e_exit_k, dim3(row_grid), dim3(256), 0, e->stream, (const double*)d_Qr, d_qe, m->n, e->kp64);
         if (e->als_carry_q) {   // the table now holds X v_f of the new V, every factor (at k < kp the spare slot holds e: the next sweep's enter overwrites it)
@@ -2027,6 +2043,7 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
     FMX_TRY(als_vhash(e, &hsh));
     reuse = hsh == e->als_q_hash;
   }
+  const bool reuse_carried = reuse;   // (a table the learner's forward pass built a moment ago is fresh: its age starts at 1)
   // ... or built a moment ago by the learner's own forward pass (launch_als_train: the pass that computes y_hat leaves q beside it; nothing between it and this
   // sweep touches V)
   if (colP && d_Q && e->als_q_trusted != 0 && e->als_q_trusted == als_order_plan_uid(m)) reuse = true;
@@ -2062,7 +2079,7 @@ static int v_sweep_enqueue(fmx_engine* e, fmx_matrix* m, double2* d_qe, double a
       if (carry && e->als_q_level0) {   // the table now holds X v_f of the new V, every factor
         uint64_t hsh = 0;
         FMX_TRY(als_vhash(e, &hsh));
-        e->als_q_hash = hsh; e->als_q_plan = als_order_plan_uid(m); e->als_q_age = reuse ? e->als_q_age + 1 : 1; e->als_q_have = 1;
+        e->als_q_hash = hsh; e->als_q_plan = als_order_plan_uid(m); e->als_q_age = reuse_carried ? e->als_q_age + 1 : 1; e->als_q_have = 1;
       }
       return FMX_OK;
     }
@@ -2224,6 +2241,9 @@ int launch_als_train(fmx_engine* e, fmx_matrix* m, int max_iter, int with_v) {
     set_error("out of device memory"); return FMX_ERR_HIP;
   }
   int st = FMX_OK;
+  // "the forward pass of this iteration left q beside y_hat" is a promise for the V sweep of the SAME iteration only: whatever way this call ends -- an error between
+  // the two included -- the flag does not outlive it
+  struct TrustGuard { fmx_engine* e; ~TrustGuard() { e->als_q_trusted = 0; } } trust_guard{e};
   for (int it = 0; it < max_iter && st == FMX_OK; ++it) {
     RowsArgs a{};
     a.row_ptr = m->row_ptr; a.col = m->col; a.val = m->val; a.r0 = 0; a.nrows = n;

@@ -1042,13 +1042,18 @@ int als_order_level(fmx_engine* e, fmx_matrix* m, int s, const SweepDyn* dyn, co
   // lists inside a tile can pass 65 535 pairs.
   static const int fb_env = env_int("FMX_ALS_ORDER_FB", 0);
   static const int rr = env_int("FMX_ALS_ORDER_R", 1);
-  static int n_cus = 0;
+  // (per DEVICE: engines may live on several -- ADVICE r5; 64 devices is more than a node holds)
+  constexpr int MAX_DEV = 64;
+  const int dev_slot = (e->cfg.device >= 0 && e->cfg.device < MAX_DEV) ? e->cfg.device : 0;
+  static int n_cus_dev[MAX_DEV] = {};
+  int& n_cus = n_cus_dev[dev_slot];
   if (n_cus == 0) { hipDeviceProp_t pr{}; n_cus = (hipGetDeviceProperties(&pr, e->cfg.device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
   const bool narrow = (uint64_t)T->max_list * 63u <= 65535u;
 #define FMX_OSUMS(UNITv, TBv, OTv, MINWv)                                                                                                                   \
   do {                                                                                                                                                      \
     auto kern = als_order_walk_k<UNITv, 64, TBv, 1024, 1, OTv, MINWv>;                                                                                        \
-    static int per_cu = 0;                                                                                                                                    \
+    static int per_cu_dev[MAX_DEV] = {};                                                                                                                      \
+    int& per_cu = per_cu_dev[dev_slot];                                                                                                                       \
     if (per_cu == 0) { int nbk = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, WG_THREADS, 0) == hipSuccess && nbk > 0) ? nbk : 2; }  \
     const uint32_t slots = (uint32_t)(per_cu * n_cus);                                                                                                        \
     int fbv = fb_env > 0 ? fb_env : (int)((cnt + slots - 1) / slots);                                                                                         \

@@ -1373,6 +1373,7 @@ static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& w
 int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
   FMX_CHECK(e->k <= 64 * FI, FMX_ERR_INVALID, "sequential mode supports factor.number <= %d", 64 * FI);
   if (count <= 0) return FMX_OK;
+  e->als_q_invalidate();   // (this learner writes the fp64 V table)
   if (count > e->seq_cap) {  // grow-only workspace; stream order makes reuse across calls safe
     FMX_HIP(hipStreamSynchronize(e->stream));
     (void)hipFree(e->seq_b); (void)hipFree(e->seq_len); (void)hipFree(e->seq_y);
@@ -1441,6 +1442,7 @@ int launch_seq_learn(fmx_engine* e, const fmx_matrix* m, const int64_t* d_order,
 int launch_seq_learn_grid(fmx_engine* const* es, int n, const fmx_matrix* m, const int64_t* d_order, int64_t count) {
   fmx_engine* e = es[0];
   if (count <= 0) return FMX_OK;
+  for (int b = 0; b < n; ++b) es[b]->als_q_invalidate();
   const int nz = window_mode(e, m);
   FMX_CHECK(nz > 0, FMX_ERR_INVALID, "grid training needs rows of at most 64 (k <= 32) / 32 entries with ascending columns");
   const int kl = e->k <= 16 ? 16 : (e->k <= 32 ? 32 : 64);

@@ -717,6 +717,7 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
   FMX_HIP(hipMemcpy(e->scal + SC_W0, &w0, sizeof(double), hipMemcpyHostToDevice));
   // R's vectors go over as they are (V: k x p column-major = p rows of k doubles) and are narrowed and laid out by kernels (fm_ingest.hip:
   // params_to_device); null = zeros, with no p-sized host buffer either way (p = 33 M, k = 32: 8.4 GB of doubles)
+  e->als_q_invalidate();
   FMX_TRY(params_to_device(e, w, v));
   e->trace_iters.clear(); e->trace_evals.clear(); e->trace_params.clear();
   FMX_TRY(reset_optimizer_state(e));  // learner->init() zeroes q/u (SGD_Learner.h:61-69) and z/n (FTRL_Learner.h:50-55)
@@ -779,6 +780,7 @@ static int rows_io(fmx_engine* e, const uint32_t* ids, int64_t n, double* w, dou
 
 int fmx_get_rows(fmx_engine* e, const uint32_t* ids, int64_t n, double* w, double* v) { return rows_io(e, ids, n, w, v, false); }
 int fmx_set_rows(fmx_engine* e, const uint32_t* ids, int64_t n, const double* w, const double* v) {
+  if (e) e->als_q_invalidate();
   FMX_TRY(rows_io(e, ids, n, const_cast<double*>(w), const_cast<double*>(v), true));
   if (e->group) FMX_TRY(group_set_rows(e, ids, n, w, v));  // every replica holds the full model
   return FMX_OK;
@@ -911,6 +913,7 @@ int fmx_engine_load(fmx_engine* e, const char* path) {
   FMX_CHECK(e != nullptr && path != nullptr, FMX_ERR_INVALID, "NULL argument");
   FMX_TRY(use_device(e->cfg.device));
   FMX_HIP(hipStreamSynchronize(e->stream));
+  e->als_q_invalidate();
   FILE* f = fopen(path, "rb");
   FMX_CHECK(f != nullptr, FMX_ERR_INVALID, "cannot open %s", path);
   CkptHeader h{}, want = ckpt_header(e);

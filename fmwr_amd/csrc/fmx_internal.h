@@ -297,6 +297,9 @@ struct fmx_engine {
   uint64_t als_q_hash = 0, als_q_plan = 0;
   void* als_hash_word = nullptr;
   double* als_lam_mu = nullptr;    // (lambda_f, mu_f) of every factor for the feature-major sweep (cfg.als_max_levels = -2)
+  // every writer of the fp64 V table other than the sweeps themselves calls this: a q table carried from an earlier sweep (fmx_als_carry_q) or left by the learner's own
+  // forward pass no longer describes V
+  void als_q_invalidate() { als_q_have = 0; als_q_trusted = 0; }
   unsigned int* als_persist_ctl = nullptr;   // 64 bytes: {features done, abort, ...} of the persistent deep sweep (als_exact_persist_k), zeroed before every launch
   const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
                                       // finished factor's q when that level is a tiled one (it then clears this pointer: the pick kernel is not needed)

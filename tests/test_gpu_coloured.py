@@ -258,7 +258,8 @@ def test_field_structured_data_takes_the_exact_levels_as_colours():
 
 
 @pytest.mark.parametrize("k,p,n,note", [(1, 800, 4_000, "kp = 2: the LDS-resident kernel"), (3, 800, 4_000, "kp = 4"), (20, 900, 5_000, "kp = 32: sixteen lanes per row"),
-                                        (4, 40, 30_000, "lists of ~7 500 rows: NOT feature-major -- the sweep nests factor outer, as -1")])
+                                        (4, 40, 30_000, "lists of ~7 500 rows: NOT feature-major -- the sweep nests factor outer, as -1"),
+                                        (20, 103, 8_000, "kp = 32 and lists of ~800 rows: NOT feature-major -- their lines would need 230 KB of LDS (577 rows fit at kp = 32)")])
 def test_feature_major_edges(k, p, n, note):
     """Factor counts outside the register kernels' (kp 8 / 16), columns that never occur and empty rows; and a plan whose lists are too long for the feature-major
     form: fmx_als_plan_info says which nesting a -2 plan takes (3 feature-major, 2 factor outer) and the sweep agrees with the restatement in THAT order."""
@@ -460,6 +461,13 @@ def test_feature_major_carried_q(k):
         g = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
         g = e.als_vsweep(m, g, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
         m.synthetic_values(8)                                      # the matrix's values redrawn: q = X v is another table
+        g = e.als_vsweep(m, g, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
+        vn = e.get_params()[2].copy(); vn[0] = -vn[0]; vn[1] = -vn[1]   # two factor columns negated: an even number of sign bits (a linear fingerprint is blind to it)
+        e.set_params(w0, w, vn)
+        g = e.als_vsweep(m, g, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
+        ids = np.arange(0, p, 7, dtype=np.uint32)                  # ... and rows rewritten through fmx_set_rows
+        rw, rv_ = e.get_rows(ids)
+        e.set_rows(ids, rw, -rv_)
         g = e.als_vsweep(m, g, alpha=1.0, v_lambda=lam); out.append((g.copy(), e.get_params()[2].copy()))
         res[carry] = out
         e.close(); m.close()

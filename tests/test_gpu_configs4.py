@@ -231,6 +231,15 @@ def test_configs4_carried_q_sweeps_match_the_oracle_and_notice_a_changed_v(monke
     rv2, rerr2, _ = oracle.als_update_v(K, X, v2.ravel(), err2, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
     gerr2 = e.als_vsweep(m, err2, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
     assert util.rel_err(e.get_params()[2], rv2.reshape(K, p)) < 1e-10 and util.rel_err(gerr2, rerr2) < 1e-10
+    # ... and a change a LINEAR fingerprint cannot see (two factor columns negated flip an even number of sign bits; round 5's sum of bits x (2 i + 1) was
+    # unchanged by that): set_params drops the carried table explicitly, whatever V looks like
+    v3 = e.get_params()[2].copy()
+    v3[0] = -v3[0]; v3[1] = -v3[1]
+    e.set_params(w0, w, v3)
+    err3 = oracle.predict_batch(P, X, w0, w, v3.ravel()) - y
+    rv3, rerr3, _ = oracle.als_update_v(K, X, v3.ravel(), err3, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
+    gerr3 = e.als_vsweep(m, err3, alpha=1.1, v_lambda=lam, v_mu=mu, std_normals=z)
+    assert util.rel_err(e.get_params()[2], rv3.reshape(K, p)) < 1e-10 and util.rel_err(gerr3, rerr3) < 1e-10
     e.close(); m.close()
 
 
