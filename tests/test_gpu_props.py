@@ -56,6 +56,13 @@ def big(fm):
     return engine.Matrix.synthetic(N, P, Z, SEED)
 
 
+@pytest.fixture(scope="module")
+def big_iid(fm):
+    """the headline's own matrix (bench.py's default: SURVEY 8(d)'s primary column law, fmx_matrix_synthetic_iid)"""
+    engine, L = fm
+    return engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_UNIFORM)
+
+
 def test_generator_matches_numpy_philox(fm):
     engine, L = fm
     for (n, p, z, off) in [(5000, 1000, 7, 0), (3000, 1_000_000, 30, 9_999_000), (100, 64, 64, 2 ** 33)]:
@@ -164,6 +171,79 @@ def test_full_size_training_is_reproducible_and_lr0_is_identity(fm, big):
     e.sync()
     w0, w, v = e.get_params()
     assert w0 == 0.5 and np.all(w == 0) and np.array_equal(v, v0)
+
+
+def test_full_size_iid_headline_matrix(fm, big_iid):
+    """The 10 M x 1 M matrix the headline is quoted on (i.i.d. uniform columns, sorted inside the row, repeats bumped: Z distinct columns per row) -- the closed-form
+    forward, the first SUM-mode step against host counts (a full batch and the ragged last one), bitwise reproducibility of six steps, lr = 0 as the identity, a
+    slab generated on its own equal to the same rows of the whole (the full-size properties ran on the stratified generator only)."""
+    engine, L = fm
+    rp, col, val, y = big_iid.export(0, 200_000)
+    c = col.reshape(-1, Z).astype(np.int64)
+    assert np.all(np.diff(rp) == Z) and np.all(val == 1.0) and np.all(np.diff(c, axis=1) > 0) and c.max() < P
+    # columns are NOT stratified here: position i of a row ranges over (almost) all of [0, p)
+    assert c[:, 0].max() > P // 4 and c[:, Z - 1].min() < 3 * P // 4
+    e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH)
+    a = (np.arange(1, K + 1) / 64.0)
+    e.set_params(0.25, np.full(P, 0.5), np.repeat(a[:, None], P, axis=1))
+    out = e.predict(big_iid)
+    np.testing.assert_allclose(out, 0.25 + Z * 0.5 + 0.5 * (Z * Z - Z) * np.sum(a * a), rtol=1e-13)
+    sub = engine.Matrix.synthetic_iid(50_000, P, Z, SEED, law=L.COLUMNS_UNIFORM, row_offset=7_000_000)
+    np.testing.assert_array_equal(sub.export()[1], big_iid.export(7_000_000, 7_050_000)[1])
+    np.testing.assert_array_equal(e.predict(sub), out[7_000_000:7_050_000])
+    e.close(); sub.close()
+    lr = 0.125
+    e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH, batch_rows=B, batch_reduce=L.REDUCE_SUM, learn_rate=lr)
+    nb = e.num_batches(big_iid)
+    for batch in (0, nb - 1):
+        e.set_params(0.0, None, None)
+        e.step(big_iid, batch)
+        e.sync()
+        w0, w, v = e.get_params()
+        r0 = batch * B
+        _, bcol, _, by = big_iid.export(r0, min(r0 + B, N))
+        assert w0 == lr * 0.5 * float(np.sum(by.astype(np.float64)))
+        np.testing.assert_allclose(w, lr * 0.5 * np.bincount(bcol, weights=np.repeat(by.astype(np.float64), Z), minlength=P), rtol=0, atol=1e-6)
+        assert np.all(v == 0.0)
+    e.close()
+    v0 = np.random.default_rng(3).normal(0, 0.01, (K, P)).astype(np.float32).astype(np.float64)
+    res = []
+    for _ in range(2):
+        e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH, batch_rows=B, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4)
+        e.set_params(0.0, None, v0)
+        for b in range(6):
+            e.step(big_iid, b)
+        e.sync()
+        res.append(e.get_params())
+        e.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.all(np.isfinite(res[0][2])) and np.any(res[0][2] != v0)
+    e = engine.Engine(P, num_factor=K, mode=L.MODE_MINIBATCH, batch_rows=B, learn_rate=0.0)
+    e.set_params(0.5, None, v0)
+    e.step(big_iid, 1)
+    e.sync()
+    w0, w, v = e.get_params()
+    assert w0 == 0.5 and np.all(w == 0) and np.array_equal(v, v0)
+    e.close()
+
+
+def test_full_size_iid_reference_order_learners_agree(fm, big_iid):
+    """The reference-order SGD learner over 150 000 examples of the headline matrix (random strides 1..3, three launches): the reassociated form (cfg.seq_reassociate)
+    within 1e-10 of the bitwise windowed kernel on V, w and w0, and bit for bit itself on a second run."""
+    import oracle
+    engine, L = fm
+    order = oracle.visit_order(N, 3, 150_000, seed=11)
+    v0 = np.random.default_rng(6).normal(0, 0.01, (K, P))
+    out = []
+    for re in (1, 1, 0):
+        e = engine.Engine(P, solver=L.SOLVER_SGD, num_factor=K, learn_rate=0.01, l2_w1=1e-4, l2_v=1e-4, mode=L.MODE_SEQUENTIAL, seq_reassociate=re)
+        e.set_params(0.0, None, v0)
+        e.train_order(big_iid, order)
+        out.append(e.get_params())
+        e.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert abs(out[0][0] - out[2][0]) < 1e-10 and util.rel_err(out[0][2], out[2][2]) < 1e-10 and util.rel_err(out[0][1], out[2][1]) < 1e-10
+    assert np.any(out[0][2] != v0)
 
 
 def test_full_size_tiling_and_exchange_forms_agree(fm, big):
