@@ -112,37 +112,19 @@ typedef struct fmx_config {
                               device .. device+N-1, one replica each, and all-reduces the gradient sums between steps with
                               RCCL -- what the reference's `nthreads` (options("FM.threads"), src/FM.cpp:59,97) becomes
                               here.  batch_rows stays "rows per step per GPU".  fmx_get_params / fmx_predict use replica 0. */
-  int32_t als_max_levels;  /* ALS / MCMC sweeps.  0: always the exact schedule (levels of row-disjoint features, the reference's
-                              index-order Gauss-Seidel reproduced).  L > 0: a matrix that needs more than L levels -- i.i.d. or
-                              Zipf columns need thousands, each a dependent launch -- is swept in the reference's own approximate
-                              parallel form instead (solver/MCMC_ALS_Learner.h:200-268): the features of a group step against the
-                              same snapshot of the residual, corrections are merged; groups = largest position of a feature in
-                              its rows.  For one-column-per-field data both forms coincide.
-                              -1: the COLOURED order.  Every step is exact (no snapshot, no merged corrections), but the sweep
-                              visits the features in an order of the engine's choosing instead of the reference's index order:
-                              levels = the colours of a proper colouring of the "share a row" graph (deterministic), visited in
-                              (colour, index) order.  Any order is a Gauss-Seidel pass for ALS and a valid scan for the Gibbs
-                              sampler, but the numbers are not the reference's on the same inputs -- they are the reference's on
-                              the matrix with its features relabelled in that order (fmx_als_plan_info's level_of gives it;
-                              tests/test_gpu_coloured.py checks exactly that against the oracle).  i.i.d. columns at 10 M x 1 M:
-                              ~1 200 levels instead of 19 399.  Columns of more than 16 384 entries (the heads of a skewed
-                              distribution) take a colour of their own each, first, in index order.
-                              -2: the coloured order, FEATURE-MAJOR.  Same colouring, but all k factors of a feature are stepped
-                              while its rows' state is on the chip: the coordinates in (colour, feature, factor) order instead of
-                              the reference's factor-outer nesting (every step still exact).  A row's q_f = (X v_f)_r for all f
-                              lie together ([n][kp] doubles: one 128-byte line at k = 16) and move once per level the row takes
-                              part in instead of once per level and factor.  Levels whose lists are of up to 384 rows (kp = 8 or
-                              16) run as ONE WAVE per feature with the lines in registers, up to 512 rows as a 256-thread
-                              workgroup, up to 1 024 with the lines in LDS; a plan with longer or heavy lists runs as -1.
-                              i.i.d. columns at 10 M x 1 M, k = 16: 213 M examples/s per ALS sweep, 206 M Gibbs (-1: 42.6 /
-                              36.7 M; the reference's order: 5.0 M).  tests/test_gpu_coloured.py checks it coordinate by
-                              coordinate against a restatement that is itself pinned to the oracle.
-                              At k < kp (k not a power of two) the row's line has a spare last slot and e rides there for the
-                              length of the sweep: one line per row and level instead of a line and a pair (k = 12: 283 M on
-                              i.i.d. columns, 445 M on field data, against 230 / 300 M with e in the pair table).
-                              Both: a matrix whose EXACT schedule is shallow (at most ~128 levels: one column per field and row)
-                              keeps those levels as its colours -- the reference's own feature order; -1 is then bit for bit
-                              the exact plan, -2 only interchanges the nesting (10 M x 1 M, 30 fields: 329 M examples/s).    */
+  int32_t als_max_levels;  /* ALS / MCMC sweeps: the ORDER of the coordinate steps (history and measurements: DESIGN.md section 6; no further values will be added).
+                               0  the exact schedule: levels of row-disjoint features, the reference's index-order Gauss-Seidel reproduced (its numbers).
+                                  Deep plans (columns without field structure: thousands of dependent levels) sweep a factor in ONE launch (als_exact_persist_k).
+                              L>0 a matrix that needs more than L levels is swept in the reference's own approximate parallel form instead
+                                  (solver/MCMC_ALS_Learner.h:200-268: the features of a group step against one snapshot of the residual), under a guard that
+                                  falls back to 0 if the residual rises.  For one-column-per-field data both forms coincide.
+                              -1  the COLOURED order: every step exact, the features visited in (colour, index) order of a deterministic colouring of the
+                                  "share a row" graph -- the reference's numbers on the matrix relabelled in that order (fmx_als_plan_info's level_of gives it),
+                                  not on the matrix as given.  A matrix whose exact schedule is shallow (<= ~128 levels) keeps those levels as its colours:
+                                  -1 is then bit for bit 0.
+                              -2  the coloured order nested FEATURE-MAJOR: all k factors of a feature stepped together, coordinates in (colour, feature, factor)
+                                  order (the reference nests factor outer); every step exact.  Applies to plans of light lists of at most 1 024 rows whose rows'
+                                  lines fit the LDS at this k (577 rows at k = 17..32, 296 at k <= 64); other plans run as -1 (fmx_als_plan_info: kind 2).        */
   int32_t seq_reassociate; /* FMX_MODE_SEQUENTIAL, SGD (L2 or cumulative L1) on rows of at most 32 (64 at k <= 32) ascending columns.  0 (default): the forward's sum in
                               the reference's association, y_hat = ((w0 + w_j1 x_j1) + ...) + 0.5 (s_1^2 - q_1) + ... (core/Model.h:77-100) -- the oracle's
                               bits up to the device exp().  1: the same formula summed as w0 + (row part), the row part a fixed tree; only w0 then
@@ -282,9 +264,10 @@ int fmx_predict(fmx_engine* e, const fmx_matrix* m, double* out, int link);
  * examples_done (may be NULL) receives the number actually processed. */
 int fmx_train(fmx_engine* e, fmx_matrix* m, int64_t max_iter, int64_t* examples_done);
 /* A GRID of models trained side by side in the reference's own algorithm (SGD_Learner::learn / FTRL_Learner::learn, one update per example in the reference's
- * visiting order): what R code does with repeated fm.train() calls over a grid of hyper-parameters (R/fm_select.R) becomes ONE launch per 65 536 examples with
- * one workgroup per model -- the reference-order learner is a single workgroup bound by its scalar chain, so one model cannot use more of
- * the chip, but 64 or 256 models can.  Every engine keeps its own parameters, optimizer state and hyper-parameters (learn_rate, regularisers, alpha / beta ...);
+ * visiting order).  NO COUNTERPART IN THE REFERENCE: its R/fm_select.R:22-66 picks the best SNAPSHOT of one fit's trace, it does not train a grid; this entry is
+ * what a user's own loop of fm.train() calls over hyper-parameters becomes -- ONE launch per 65 536 examples with one workgroup per model (the reference-order
+ * learner is a single workgroup bound by its scalar chain, DESIGN.md section 4: one model cannot use more of the chip, 64 or 256 models can).  An extension, not
+ * a row of SURVEY section 8.  Every engine keeps its own parameters, optimizer state and hyper-parameters (learn_rate, regularisers, alpha / beta ...);
  * the engines share the feature count, factor.number, solver, task, device and random_step = 1 (ONE visiting order), and the matrix.  Each model's result is bit for
  * bit what fmx_train(engine, m, max_iter) alone gives it.  SGD (L1 / L2), FTRL and TDAP (the reference's default solver); rows of at most 32 entries (64 at k <= 32) with
  * ascending columns -- the shapes the windowed learners take. */
