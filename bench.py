@@ -709,6 +709,11 @@ def main_sweep(args, rank, local_rank, world):
     tiled, tile_rows, n_tiles = e.als_tiled(m)
     ordered = bool(tiled) and e.als_level_order(m)
     blocks = ordered and e.als_level_order_form(m) == 2
+    if exact_iid:
+        # a deep exact plan sweeps a factor in ONE persistent launch (als_exact_persist_k): the HIP events see one launch per factor, the unit stays one level of one
+        # factor -- the sweep's wall time over its levels x k dependent level steps (latency, not bytes: profiles/r06_als_exact_persist.txt)
+        per_launch_ms = dt / args.steps / launches * 1e3
+        lvl_n = launches * args.steps
     b_launch = 40.0 * nnz / levels               # 40 B per stored nonzero per factor; one unit = one level of one factor
     if fmajor:                                   # the feature-major form: one launch per level does all k factors of its features
         launches = levels
