@@ -788,19 +788,17 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
 #ifndef FMX_PERSIST_REPL
 #define FMX_PERSIST_REPL 32
 #endif
-constexpr int PERSIST_WAVES = 128, PERSIST_REPL = FMX_PERSIST_REPL, PERSIST_LINE_WORDS = 32, PERSIST_CTL_WORDS = (PERSIST_REPL + 1) * PERSIST_LINE_WORDS + PERSIST_WAVES;   // + the abort word's line + the one-XCD form's progress words
+constexpr int PERSIST_WAVES = 128, PERSIST_REPL = FMX_PERSIST_REPL, PERSIST_LINE_WORDS = 32, PERSIST_CTL_WORDS = (PERSIST_REPL + 1) * PERSIST_LINE_WORDS;   // + the abort word's line
 __device__ __forceinline__ double2 pair_load_sc1(__amdgpu_buffer_rsrc_t r, uint32_t row) {
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(row * 16u), 0, 16);   // aux 16 = sc1: past this CU's L1
   return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
 }
-template <bool XCD = false>
 __device__ __forceinline__ void pair_store_sc1(__amdgpu_buffer_rsrc_t r, uint32_t row, double2 c) {
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t v;
   v.x = (uint32_t)__double2loint(c.x); v.y = (uint32_t)__double2hiint(c.x); v.z = (uint32_t)__double2loint(c.y); v.w = (uint32_t)__double2hiint(c.y);
-  if constexpr (XCD) __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 16u), 0, 0);    // every wave of the launch sits behind ONE L2: the line stays there (see PERSIST_XCD)
-  else __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 16u), 0, 16);                // write-through
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 16u), 0, 16);                  // write-through
 }
 
 // The wave sum of als_level_k -- x += shfl_xor(x, 32), 16, 8, 4, 2, 1 -- with the same tree, hence the same bits, without the LDS crossbar: the halves and the
@@ -824,7 +822,7 @@ __device__ __forceinline__ double butterfly_allsum(double x) {
   return x;
 }
 
-template <bool W, bool XCD>
+template <bool W>
 __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __restrict__ feats, const int64_t* __restrict__ level_ptr, int L,
                                                           const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
                                                           double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, double2* qe, uint32_t qe_bytes,
@@ -833,46 +831,11 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
   const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
   const double* __restrict__ znorm = dyn->znorm;
   const int lane = threadIdx.x;
-  int gw = (int)blockIdx.x, NW = (int)gridDim.x;
+  const int gw = (int)blockIdx.x, NW = (int)gridDim.x;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(qe, 0, (int)qe_bytes, 0x00020000);
   unsigned int spins = 0;
-  unsigned int* const abort_w = ctl + PERSIST_REPL * PERSIST_LINE_WORDS;
-  if constexpr (XCD) {
-    // PERSIST_XCD: the sweep's waves on ONE XCD.  Eight times the waves are launched; a workgroup reads which XCD it runs on (HW_REG_XCC_ID), the first to arrive
-    // names its XCD the sweep's, the workgroups of that XCD take tickets (their rank), everybody else leaves -- after checking in, so that the ranked ones know
-    // how many they are.  All waves then share one L2: the pairs are stored PLAIN (the line stays in that L2) and gathered past the L1 as before; the placement is
-    // read from the hardware, never assumed (fewer waves on that XCD than expected only make the sweep slower).
-    const unsigned int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // XCC_ID[3:0]
-    unsigned int target = 0u, ticket = 0u;
-    if (lane == 0) {   // ONE lane: the workgroup is one participant
-      unsigned int expected = 0u;
-      __hip_atomic_compare_exchange_strong(abort_w + 3, &expected, xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      target = __hip_atomic_load(abort_w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (target == xcc + 1u) ticket = __hip_atomic_fetch_add(abort_w + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(abort_w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    target = (unsigned int)__builtin_amdgcn_readfirstlane((int)target);
-    ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-    const bool mine = target == xcc + 1u;
-    if (!mine) return;
-    while (__hip_atomic_load(abort_w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-      if (++spins > (1u << 22)) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    spins = 0;
-    gw = (int)ticket;
-    NW = (int)__hip_atomic_load(abort_w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (NW > PERSIST_WAVES) NW = PERSIST_WAVES;   // (a lane looks after two waves' progress words)
-    if (gw >= NW) return;
-  }
-  // PERSIST_XCD: no counter at all -- wave w keeps ITS OWN count of completed features in prog[w] (a plain store: the line stays in the XCD's L2), and a waiting wave reads
-  // all of them past its L1 (two words per lane, `nt` loads: L2-served) and compares each with what that wave owes before this level, which follows from the plan alone:
-  // need_w(l) = sum over the levels l' < l of the positions w, w + NW, ... below cnt(l').  Atomics and sc1 accesses leave the L2 for the fabric (measured: the one-XCD
-  // form WITH them took 8.3 us per level, every wave behind one XCD's port); these stay inside it.
-  unsigned int* const prog = abort_w + PERSIST_LINE_WORDS;
-  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(prog, 0, PERSIST_WAVES * 4, 0x00020000);
-  unsigned int need0 = 0u, need1 = 0u, my_done = 0u;   // lanes' running need_w for w = lane, lane + 64
   unsigned int* const my_ctr = ctl + (gw % PERSIST_REPL) * PERSIST_LINE_WORDS;
+  unsigned int* const abort_w = ctl + PERSIST_REPL * PERSIST_LINE_WORDS;
 #ifdef FMX_PERSIST_TIMING
   unsigned long long tP = 0, tG = 0, tC = 0, tD = 0, nF = 0, nPoll = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
 #define FMX_TP(acc) do { c1 = __builtin_amdgcn_s_memtime(); acc += c1 - c0; c0 = c1; } while (0)
@@ -887,11 +850,6 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
     for (;;) {
       const int64_t l1 = level_ptr[l + 1];
       if (j < l1) return true;
-      if constexpr (XCD) {   // level l is left behind: what every wave owes grows by its positions in it
-        const int cnt = (int)(l1 - l0);
-        need0 += (lane < NW && cnt > lane) ? (unsigned int)((cnt - lane - 1) / NW + 1) : 0u;
-        need1 += (lane + 64 < NW && cnt > lane + 64) ? (unsigned int)((cnt - lane - 65) / NW + 1) : 0u;
-      }
       if (++l >= L) return false;
       l0 = l1;
       j = l0 + gw;
@@ -900,8 +858,8 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
   // The static part of a step -- the feature, its column's bounds, rows and values, its own parameter (only this step writes it), its normal -- is three
   // dependent memory rounds (2.4 us: as long as everything else of a step together).  It is fetched one feature AHEAD, each round issued behind one of the current
   // step's own waits (the poll, the pair gather, the store drain), so it costs the chain nothing.
-  struct Stat { int64_t l0, b, e; uint32_t i; double v_old, zi; float kx[ALS_KEEP]; uint32_t kr[ALS_KEEP]; unsigned int need0, need1; };
-  auto round1 = [&](Stat& st) { st.l0 = l0; st.i = feats[j]; st.need0 = need0; st.need1 = need1; };
+  struct Stat { int64_t l0, b, e; uint32_t i; double v_old, zi; float kx[ALS_KEEP]; uint32_t kr[ALS_KEEP]; };
+  auto round1 = [&](Stat& st) { st.l0 = l0; st.i = feats[j]; };
   auto round2 = [&](Stat& st) {
     st.b = col_ptr[st.i]; st.e = col_ptr[st.i + 1];
     st.v_old = P[W ? (size_t)st.i : (size_t)st.i * kp + f];
@@ -926,22 +884,7 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
     // ---- every feature of the levels before this one has stored its corrections.  ONE poll at a time (four in flight a quarter of a trip apart were tried: the
     // replicas' lines then queue and a level takes 4.2 us instead of 3.8), and a wave whose turn is levels away -- on average 76 of the 128 have no feature in the
     // level being swept -- sleeps by its distance instead of competing with the waves whose turn is next
-    if constexpr (XCD) {
-      for (;;) {
-#ifdef FMX_PERSIST_TIMING
-        ++nPoll;
-#endif
-        const unsigned int v0 = __builtin_amdgcn_raw_buffer_load_b32(prs, lane * 4, 0, 2);          // aux 2 = nt: past the L1, served by the L2
-        const unsigned int v1 = __builtin_amdgcn_raw_buffer_load_b32(prs, (lane + 64) * 4, 0, 2);
-        if (__ballot(v0 >= cur.need0 && v1 >= cur.need1) == ~0ull) break;
-        if ((++spins & 255u) == 0) {
-          if (spins > (1u << 22)) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_sleep(2);
-      }
-    } else {
+    {
       const unsigned int want = (unsigned int)cur.l0;
       for (;;) {
 #ifdef FMX_PERSIST_TIMING
@@ -1031,11 +974,11 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
 #pragma unroll
       for (int s = 0; s < ALS_KEEP; ++s) {                   // :341-350 from the kept entries
         if (b + lane + 64 * s < e) {
-          if constexpr (W) pair_store_sc1<XCD>(rs, cur.kr[s], make_double2(kc[s].x, kc[s].y - (double)cur.kx[s] * v_diff));
+          if constexpr (W) pair_store_sc1(rs, cur.kr[s], make_double2(kc[s].x, kc[s].y - (double)cur.kx[s] * v_diff));
           else {
             const float xx = cur.kx[s] * cur.kx[s];
             const double h = (double)cur.kx[s] * kc[s].x - (double)xx * v_old;
-            pair_store_sc1<XCD>(rs, cur.kr[s], make_double2(kc[s].x - (double)cur.kx[s] * v_diff, kc[s].y - h * v_diff));
+            pair_store_sc1(rs, cur.kr[s], make_double2(kc[s].x - (double)cur.kx[s] * v_diff, kc[s].y - h * v_diff));
           }
         }
       }
@@ -1043,21 +986,18 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
         const float x = cval[t];
         const uint32_t r = crow[t];
         const double2 c = pair_load_sc1(rs, r);
-        if constexpr (W) pair_store_sc1<XCD>(rs, r, make_double2(c.x, c.y - (double)x * v_diff));
+        if constexpr (W) pair_store_sc1(rs, r, make_double2(c.x, c.y - (double)x * v_diff));
         else {
           const float xx = x * x;
           const double h = (double)x * c.x - (double)xx * v_old;
-          pair_store_sc1<XCD>(rs, r, make_double2(c.x - (double)x * v_diff, c.y - h * v_diff));
+          pair_store_sc1(rs, r, make_double2(c.x - (double)x * v_diff, c.y - h * v_diff));
         }
       }
     }
     // ---- drained, then counted: whoever reads done >= level_ptr[l + 1] finds this feature's pairs in memory
     FMX_TP(tC);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (XCD) {
-      ++my_done;
-      if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(my_done, prs, gw * 4, 0, 0);   // plain: into the XCD's L2, where the waiting waves read it
-    } else if (lane < PERSIST_REPL) __hip_atomic_fetch_add(ctl + lane * PERSIST_LINE_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < PERSIST_REPL) __hip_atomic_fetch_add(ctl + lane * PERSIST_LINE_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef FMX_PERSIST_TIMING
     ++nF;
 #endif
@@ -1924,14 +1864,10 @@ static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const Swee
   }
   if (!e->als_persist_ctl) FMX_HIP(hipMalloc(&e->als_persist_ctl, PERSIST_CTL_WORDS * sizeof(unsigned int)));
   FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, PERSIST_CTL_WORDS * sizeof(unsigned int), e->stream));   // the counter and the abort word, every launch
-  const char* xv = getenv("FMX_ALS_PERSIST_XCD");   // read per call (the tests compare the forms)
-  const bool xcd = xv && xv[0] == '1';
   prof_begin(e, FMX_KERNEL_ALS_SWEEP);
-#define FMX_PERSIST_ARGS (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L, (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, \
-                         W ? e->dw : e->dV, e->kp64, dyn, d_qe, (uint32_t)((uint64_t)m->n * sizeof(double2)), e->als_persist_ctl
-  if (xcd) hipLaunchKernelGGL((als_exact_persist_k<W, true>), dim3(8 * PERSIST_WAVES), dim3(64), 0, e->stream, FMX_PERSIST_ARGS);
-  else hipLaunchKernelGGL((als_exact_persist_k<W, false>), dim3(PERSIST_WAVES), dim3(64), 0, e->stream, FMX_PERSIST_ARGS);
-#undef FMX_PERSIST_ARGS
+  hipLaunchKernelGGL((als_exact_persist_k<W>), dim3(PERSIST_WAVES), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
+                     (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, W ? e->dw : e->dV, e->kp64, dyn, d_qe,
+                     (uint32_t)((uint64_t)m->n * sizeof(double2)), e->als_persist_ctl);
   prof_end(e);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -1943,11 +1879,6 @@ static int persist_check(fmx_engine* e) {
   FMX_HIP(hipMemcpyAsync(ctl, e->als_persist_ctl, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
   FMX_HIP(hipMemcpyAsync(ctl + 1, e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
   FMX_HIP(hipStreamSynchronize(e->stream));
-  if (getenv("FMX_ALS_PERSIST_VERBOSE")) {
-    unsigned int w[4] = {0, 0, 0, 0};
-    FMX_HIP(hipMemcpy(w, e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, sizeof(w), hipMemcpyDeviceToHost));
-    fprintf(stderr, "fmx: persistent sweep: %u features done; one-XCD form: %u workgroups checked in, %u on XCD %d\n", ctl[0], w[1], w[2], (int)w[3] - 1);
-  }
   FMX_CHECK(ctl[1] == 0, FMX_ERR_HIP, "the persistent sweep gave up waiting after %u features (its workgroups were not all running?): V and the residual are part-way through a sweep", ctl[0]);
   return FMX_OK;
 }
