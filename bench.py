@@ -166,8 +166,9 @@ def pmc_traffic(kernel, args):
                 and k == args.factors and (33_000_000 if crit else opt("--features", 1_000_000)) == args.features and opt("--rows", 8_000_000 if crit else 10_000_000) == args.rows
                 and (39 if crit else opt("--nnz", 30)) == args.nnz and solver == args.solver and ("--state-fp64" in a) == bool(args.state_fp64)
                 and (a[a.index("--workload") + 1] if "--workload" in a else "uniform") == args.workload
-                # summaries made before --columns existed (rounds 1-4) ran the stratified generator
-                and (crit or (a[a.index("--columns") + 1] if "--columns" in a else "stratified") == args.columns) and ("--real-values" in a) == bool(args.real_values))
+                # summaries made before --columns existed (rounds 1-4) ran the stratified generator; from round 5 on the default law is i.i.d. uniform
+                and (crit or (a[a.index("--columns") + 1] if "--columns" in a else ("stratified" if os.path.basename(f)[:3] < "r05" else "iid")) == args.columns)
+                and ("--real-values" in a) == bool(args.real_values))
         if same and kernel in d and "traffic_bytes_per_launch" in d[kernel]:
             best = (d[kernel]["traffic_bytes_per_launch"], os.path.basename(f), d[kernel].get("fabric_bytes_per_launch"), d[kernel].get("fabric_reads_128B_frac"))
     return best
