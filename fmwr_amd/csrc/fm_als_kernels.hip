@@ -1853,6 +1853,11 @@ static bool persist_applies(const fmx_matrix* m) {
   if ((int)m->als_level_ptr.size() - 1 < PERSIST_MIN_LEVELS) return false;
   if (!m->als_heavy_ptr.empty() && m->als_heavy_ptr.back() != 0) return false;
   if (!m->als_vh_ptr.empty() && m->als_vh_ptr.back() != 0) return false;
+  // NARROW levels only: a wave takes a level's positions g, g + 128, ... one after the other, so a level of a thousand features (a coloured plan's classes) would be eight
+  // dependent steps per wave where one launch per level runs them side by side
+  int64_t widest = 0;
+  for (size_t l = 0; l + 1 < m->als_level_ptr.size(); ++l) widest = std::max(widest, m->als_level_ptr[l + 1] - m->als_level_ptr[l]);
+  if (widest > 2 * PERSIST_WAVES) return false;
   return (uint64_t)m->n * sizeof(double2) <= 0xFFFFFFF0ull && m->als_level_ptr.back() < (int64_t)0xFFFFFFFFll;
 }
 template <bool W>

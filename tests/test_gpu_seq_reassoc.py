@@ -136,3 +136,14 @@ def test_fuzz_against_the_one_wave_kernel(seed):
     scale = lambda x: max(float(np.max(np.abs(x))) if np.size(x) else 0.0, 1e-300)
     assert abs(a[0] - b[0]) <= TOL * max(1.0, abs(b[0])), (c, p, n, nnz, max_nnz, rstep)
     assert np.max(np.abs(a[1] - b[1]), initial=0.0) <= TOL * scale(b[1]) and np.max(np.abs(a[2] - b[2]), initial=0.0) <= TOL * scale(b[2]), (c, p, n, nnz, max_nnz, rstep)
+
+
+@pytest.mark.parametrize("count", [1, 2, 7, 14, 15, 16, 29, 31, 59, 60, 61, 121])
+def test_launches_shorter_than_the_ring(count):
+    """Fewer examples than worker waves (15), than ring slots (60), one more and one less: waves without an example leave at once, the chain stops at `count`."""
+    c = sw.SOLVERS["sgd_l2"]
+    a, ctx = _run_re("tiny", c, 3000, 400, 12, count)
+    b, _ = sw._run("tiny", c, 3000, 400, 12, count, window=False)
+    assert abs(a[0] - b[0]) < TOL and util.rel_err(a[1], b[1]) < TOL and util.rel_err(a[2], b[2]) < TOL
+    P, rp, col, val, y, w0, w, v, order = ctx
+    assert len(order) == count
