@@ -12,7 +12,8 @@ sums, exchanges them (dense: the (k+2)*p buffer is all-reduced in pipelined bloc
 features are all-gathered), every replica applies the same update ("scaling": "weak": per-GPU rows per step are fixed).
 
 Rank 0's LAST stdout line is the ONE JSON line the driver parses (driver_line(): at most LINE_LIMIT = 4000 bytes -- metric, config, roofline, cpu_baseline and a
-flat summary of the side runs); everything else the run measured is printed BEFORE it as one line prefixed `DETAILS ` and left in bench_details.json.
+flat summary of the side runs); everything else the run measured is printed BEFORE it as lines prefixed `DETAILS ` (one key per line, long values in numbered pieces: no line
+over 4 000 bytes) and left in bench_details.json.
 `value` is whole-job examples/s of the timed steps.  `roofline` prices the step in SURVEY
 8(d)'s algorithmic bytes (the headline `frac`) and each of the two kernels on its own bytes and HIP-event time, next to the
 measured ceiling of the access pattern (`ceiling_frac`).  At N == 1 the same line also carries what `value` leaves out:
@@ -1055,7 +1056,7 @@ def _frac_entry(d):
 
 def driver_line(d):
     """The ONE line the driver parses: BASELINE.json's metric / config, `roofline`, `cpu_baseline` and a flat summary of the side runs, at most LINE_LIMIT
-    bytes.  Everything else the run measured goes to an earlier stdout line prefixed `DETAILS ` and to bench_details.json (emit())."""
+    bytes.  Everything else the run measured goes to earlier stdout lines prefixed `DETAILS ` and to bench_details.json (emit())."""
     r, cfg = d.get("roofline", {}), d.get("config", {})
     line = {kk: _num(d[kk]) for kk in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if kk in d}
     line["config"] = {"workload": _cap(cfg.get("workload"), 300)}
@@ -1099,7 +1100,7 @@ def driver_line(d):
         side["end_to_end_one_epoch"] = _num(d["end_to_end"].get("one_epoch_examples_per_s"))
     if side:
         line["side"] = side
-    line["details"] = "bench_details.json; the stdout line prefixed DETAILS"
+    line["details"] = "bench_details.json; the stdout lines prefixed DETAILS"
     # the budget is a contract: shed the optional parts, in this order, rather than print a line the driver cannot read
     for shed in ("side", "other_configs"):
         if len(json.dumps(line)) <= LINE_LIMIT:
@@ -1111,15 +1112,53 @@ def driver_line(d):
     return line
 
 
+DETAIL_PIECE = 3800   # no stdout line is longer than the driver's line may be: whatever reads this output line by line, or keeps only its tail, meets nothing it cannot hold
+
+
+def detail_lines(out):
+    """Everything the run measured as lines `DETAILS <key> [i/n] <json text or a piece of it>`: one top-level key per line (`other_configs` one side run per line), values whose
+    text is longer than DETAIL_PIECE cut into numbered pieces (concatenate the pieces of a key in order to get its JSON back: details_from_lines())."""
+    items = []
+    for k, v in out.items():
+        if k == "other_configs" and isinstance(v, dict):
+            items.extend((f"other_configs.{kk}", vv) for kk, vv in v.items())
+        else:
+            items.append((k, v))
+    for k, v in items:
+        text = json.dumps(v)
+        pieces = [text[i:i + DETAIL_PIECE] for i in range(0, len(text), DETAIL_PIECE)] or [""]
+        for i, piece in enumerate(pieces):
+            yield f"DETAILS {k} [{i + 1}/{len(pieces)}] {piece}"
+
+
+def details_from_lines(lines):
+    """the inverse of detail_lines() (tests, and whoever reads a saved stdout)"""
+    acc = {}
+    for ln in lines:
+        if not ln.startswith("DETAILS "):
+            continue
+        _, key, _, piece = ln.split(" ", 3)
+        acc[key] = acc.get(key, "") + piece
+    out = {}
+    for key, text in acc.items():
+        v = json.loads(text)
+        if key.startswith("other_configs."):
+            out.setdefault("other_configs", {})[key[len("other_configs."):]] = v
+        else:
+            out[key] = v
+    return out
+
+
 def emit(out):
-    """stdout: `DETAILS <everything the run measured>` first, then -- LAST -- the compact line the driver parses; the full object is also left in bench_details.json"""
-    full = json.dumps(out)
+    """stdout: the DETAILS lines (everything the run measured, no line over DETAIL_PIECE + a short prefix) first, then -- LAST -- the compact line the driver parses; the full
+    object is also left in bench_details.json"""
     try:
         with open(os.path.join(os.environ.get("FMX_BENCH_DETAILS_DIR", ROOT), "bench_details.json"), "w") as f:
-            f.write(full + "\n")
+            f.write(json.dumps(out) + "\n")
     except OSError:
         pass
-    print("DETAILS " + full, flush=True)
+    for ln in detail_lines(out):
+        print(ln, flush=True)
     print(json.dumps(driver_line(out)), flush=True)
 
 

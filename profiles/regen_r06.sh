@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 O=gpurun_out/regen6
 rm -rf $O; mkdir -p $O
 python3 bench.py > $O/bench_default.out 2> $O/bench_default.err; echo "bench default rc=$?"
-tail -n 1 $O/bench_default.out > $O/bench_default_line.json; grep '^DETAILS ' $O/bench_default.out | sed 's/^DETAILS //' > $O/bench_default_details.json
+tail -n 1 $O/bench_default.out > $O/bench_default_line.json; cp bench_details.json $O/bench_default_details.json
 python3 bench.py --solver mcmc --sweep-iid --sweep-exact --steps 2 --warmup 1 --cpu-rows 0 > $O/bench_mcmc_iid_exact.out 2>/dev/null; echo "bench mcmc iid exact rc=$?"
 # per-kernel averages: the SAME command line as the headline's timed region (no side runs), under rocprofv3 --kernel-trace --stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sgd -- python3 bench.py --cpu-rows 0 --no-extras > $O/bench_sgd_under_rocprof.out 2> $O/rocprof_sgd.err; echo "rocprof sgd rc=$?"
