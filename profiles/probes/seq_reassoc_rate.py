@@ -1,5 +1,5 @@
 """The reference-order learner at configs[1]'s shape (10 M x 1 M stream's first 2 M rows, 30 entries per row, k = 16): the bitwise pipelined kernel against the
-reassociated one (cfg.seq_reassociate: only w0 chains the examples).  usage: python profiles/probes/seq_reassoc_rate.py [solver: sgd|sgd_l1|ftrl] [k] [iid|stratified] [entries per row]"""
+reassociated one (cfg.seq_reassociate: only w0 chains the examples).  usage: python profiles/probes/seq_reassoc_rate.py [solver: sgd|sgd_l1|ftrl|tdap] [k] [iid|stratified] [entries per row]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -16,6 +16,8 @@ if solver == "sgd_l1":
     kw.update(solver=L.SOLVER_SGD, l1_w1=1e-4, l1_v=1e-4)
 elif solver == "ftrl":
     kw.update(solver=L.SOLVER_FTRL, l1_w1=1e-4, l1_v=1e-4)
+elif solver == "tdap":
+    kw.update(solver=L.SOLVER_TDAP, l1_w1=1e-4, l1_v=1e-4)
 else:
     kw.update(solver=L.SOLVER_SGD)
 res = {}

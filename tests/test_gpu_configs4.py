@@ -634,3 +634,33 @@ def test_configs4_deep_exact_plan_learner_w_sweep_in_one_launch(monkeypatch):
         e.close(); m.close()
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     assert not np.array_equal(res[0][1], w)
+
+
+def test_configs4_deep_exact_plan_with_columns_longer_than_the_kept_slots(monkeypatch):
+    """Columns of ~600 entries (more than the 512 a wave keeps in registers: the persistent kernel's tail loop reads and writes its pairs past the L1 too) on a
+    chain-shaped plan: bit for bit the one-launch-per-level form, the oracle to 1e-10."""
+    from fmwr_amd import _lib as L, engine
+    k, n, p, z = 4, 60_000, 3_000, 30
+    m0 = engine.Matrix.synthetic_iid(n, p, z, 61, law=L.COLUMNS_UNIFORM)
+    rp, col, val, _ = m0.export(); m0.close()
+    val = np.random.default_rng(3).uniform(0.3, 1.0, len(val)).astype(np.float32)
+    y = util.labels(n, 61, "regression")
+    assert np.bincount(col, minlength=p).max() > 8 * 64
+    w0, w, v = util.params(p, k, 37, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(oracle.params(task=oracle.REGRESSION, k=k), X, w0, w, v.ravel()) - y
+    lam = np.linspace(0.5, 1.0, k)
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=1.0, v_lambda=lam)
+    res = []
+    for persist in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_PERSIST", persist)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        levels, largest, approx, _ = e.als_plan(m)
+        assert not approx and levels > 1_000 and largest <= 256
+        gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam)
+        res.append((e.get_params()[2], gerr))
+        e.close(); m.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert util.rel_err(res[0][0], rv.reshape(k, p)) < 1e-10 and util.rel_err(res[0][1], rerr) < 1e-10
