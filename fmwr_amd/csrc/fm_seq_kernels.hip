@@ -1072,7 +1072,9 @@ template <int KIND, int KL, int NZ> struct SeqRe {
 #ifdef FMX_SEQ_RE_NW
   static constexpr int NW = FMX_SEQ_RE_NW;
 #else
-  static constexpr int NW = REGS <= 112 ? 16 : 8;   // (k > 16 or rows of 33..64 entries: 174-256 VGPRs, two waves per SIMD)
+  // measured (profiles/r06_seq_reassoc.txt): 16 waves where a worker fits 128 VGPRs (SGD-L2, k <= 16, rows of <= 32 entries), 12 (168 VGPRs: three waves per SIMD) for the
+  // next size up (SGD-L1 at k <= 16; SGD-L2 at k <= 32 or rows of 33..64 entries: +8..11 % over 8 waves, and over 16 with spills), 8 beyond
+  static constexpr int NW = REGS <= 100 ? 16 : (REGS <= 140 ? 12 : 8);
 #endif
   static constexpr int W = NW - 1;
   static constexpr int R = (64 / W) * W;   // 60 (15 workers), 63 (7)
