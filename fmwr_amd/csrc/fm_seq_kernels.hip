@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
       const unsigned long long mask = __ballot(ready);
       const int n = __builtin_ctzll(~mask);   // the leading ready ones (mask has at most B bits set)
       if (n == 0) {
-        if (stuck()) { if (lane == 0) a.scal[SC_W0] = __longlong_as_double(0x7FF8000000000000ll); return; }
+        if (stuck()) { if (lane == 0) { a.scal[SC_W0] = __longlong_as_double(0x7FF8000000000000ll); a.scal[SC_SEQ_ABORT] = 1.0; } return; }
         __builtin_amdgcn_s_sleep(1);
         FMX_TC(tIdle);
         continue;

@@ -726,10 +726,20 @@ int fmx_set_params(fmx_engine* e, double w0, const double* w, const double* v) {
   return FMX_OK;
 }
 
+// the reassociated reference-order learner's bounded waits gave up in an earlier launch: its parameters are part-way through a chunk (never seen; a silent NaN otherwise)
+static int seq_abort_check(fmx_engine* e) {
+  if (!e->cfg.seq_reassociate && !getenv("FMX_SEQ_REASSOC")) return FMX_OK;
+  double flag = 0.0;
+  FMX_HIP(hipMemcpy(&flag, e->scal + SC_SEQ_ABORT, sizeof(double), hipMemcpyDeviceToHost));
+  FMX_CHECK(flag == 0.0, FMX_ERR_HIP, "the reassociated sequential learner gave up waiting inside a launch (its workgroup's waves did not all run?): the parameters are not a valid state");
+  return FMX_OK;
+}
+
 int fmx_get_params(fmx_engine* e, double* w0, double* w, double* v) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   FMX_TRY(use_device(e->cfg.device));
   FMX_HIP(hipStreamSynchronize(e->stream));
+  FMX_TRY(seq_abort_check(e));
   if (w0) FMX_HIP(hipMemcpy(w0, e->scal + SC_W0, sizeof(double), hipMemcpyDeviceToHost));
   FMX_TRY(params_from_device(e, w, v));   // widened and packed on the device, copied down in pieces (fm_ingest.hip)
   return FMX_OK;
@@ -1921,6 +1931,7 @@ int fmx_sync(fmx_engine* e) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   hipError_t err = hipStreamSynchronize(e->stream);
   FMX_CHECK(err == hipSuccess, FMX_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(err));
+  FMX_TRY(seq_abort_check(e));
   return FMX_OK;
 }
 

@@ -75,6 +75,7 @@ enum Scalar : int {
   SC_T_NU = 7,     // TDAP nu_w0 (u_w0 lives in SC_N0, z_w0 in SC_Z0)
   SC_T_DELTA = 8,  // TDAP delta_w0
   SC_T_H = 9,      // TDAP h_w0
+  SC_SEQ_ABORT = 10,  // the reassociated learner's bounded waits gave up (never seen): non-zero until the next fmx_set_params; fmx_get_params / fmx_sync report it
   SC_COUNT = 12
 };
 
