@@ -34,7 +34,7 @@ SYMBOLS = [
 
 
 # fmwr_amd/csrc/fmx_test_hooks.h: exported for the GPU tests, not part of the C ABI
-TEST_HOOKS = ["fmx_debug_fail_next_plan_build", "fmx_debug_fail_next_comm_init"]
+TEST_HOOKS = ["fmx_debug_fail_next_plan_build", "fmx_debug_fail_next_comm_init", "fmx_debug_lose_next_seq_multiplier", "fmx_debug_stall_next_persistent_sweep"]
 
 
 class Config(C.Structure):

@@ -12,6 +12,7 @@
 // fp64 throughout, like the reference; x*x is a float product there (:314,:345) and here.
 // q and e live interleaved as one {q[r], e[r]} pair per row, so a stored nonzero costs one 16-byte gather (one line)
 // per pass instead of two.
+#include <atomic>
 #include <cmath>
 #include <ctime>
 
@@ -826,7 +827,7 @@ template <bool W>
 __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __restrict__ feats, const int64_t* __restrict__ level_ptr, int L,
                                                           const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
                                                           double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn, double2* qe, uint32_t qe_bytes,
-                                                          unsigned int* ctl) {
+                                                          unsigned int* ctl, int debug_skip) {
   const int f = W ? 0 : dyn->f;
   const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
   const double* __restrict__ znorm = dyn->znorm;
@@ -997,7 +998,8 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
     // ---- drained, then counted: whoever reads done >= level_ptr[l + 1] finds this feature's pairs in memory
     FMX_TP(tC);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane < PERSIST_REPL) __hip_atomic_fetch_add(ctl + lane * PERSIST_LINE_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < PERSIST_REPL && !(debug_skip && gw == 0 && cur.l0 == level_ptr[0]))   // (test hook: wave 0's first feature is never counted)
+      __hip_atomic_fetch_add(ctl + lane * PERSIST_LINE_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef FMX_PERSIST_TIMING
     ++nF;
 #endif
@@ -1846,6 +1848,8 @@ static bool allf_applies(const fmx_engine* e, const fmx_matrix* m) {
 // Does the persistent form take this plan?  A deep exact plan of light columns only (no workgroup-wide or segmented columns, no tiled levels), a pair table a
 // buffer descriptor can address.  FMX_ALS_PERSIST=0 keeps one launch per level (the tests compare the two: the same bits).
 constexpr int PERSIST_MIN_LEVELS = 64;
+static std::atomic<int> g_stall_next_persistent_sweep{0};
+void debug_stall_next_persistent_sweep() { g_stall_next_persistent_sweep.store(1); }
 static bool persist_applies(const fmx_matrix* m) {
   const char* v = getenv("FMX_ALS_PERSIST");
   if (v && v[0] == '0') return false;
@@ -1867,12 +1871,18 @@ static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const Swee
     FMX_HIP(hipMalloc(&m->als_level_ptr_dev, m->als_level_ptr.size() * sizeof(int64_t)));
     FMX_HIP(hipMemcpy(m->als_level_ptr_dev, m->als_level_ptr.data(), m->als_level_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   }
-  if (!e->als_persist_ctl) FMX_HIP(hipMalloc(&e->als_persist_ctl, PERSIST_CTL_WORDS * sizeof(unsigned int)));
-  FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, PERSIST_CTL_WORDS * sizeof(unsigned int), e->stream));   // the counter and the abort word, every launch
+  if (!e->als_persist_ctl) {
+    FMX_HIP(hipMalloc(&e->als_persist_ctl, PERSIST_CTL_WORDS * sizeof(unsigned int)));
+    FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, PERSIST_CTL_WORDS * sizeof(unsigned int), e->stream));
+  }
+  // the counter's replicas, every launch.  The abort word (the line after them) is STICKY: a launch that gave up must still be known when the sweep's last factor has
+  // run (persist_check reads and clears it); the launches after it leave at their first look at it
+  FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, (size_t)PERSIST_REPL * PERSIST_LINE_WORDS * sizeof(unsigned int), e->stream));
   prof_begin(e, FMX_KERNEL_ALS_SWEEP);
+  const int debug_skip = g_stall_next_persistent_sweep.exchange(0) > 0 ? 1 : 0;
   hipLaunchKernelGGL((als_exact_persist_k<W>), dim3(PERSIST_WAVES), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
                      (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, W ? e->dw : e->dV, e->kp64, dyn, d_qe,
-                     (uint32_t)((uint64_t)m->n * sizeof(double2)), e->als_persist_ctl);
+                     (uint32_t)((uint64_t)m->n * sizeof(double2)), e->als_persist_ctl, debug_skip);
   prof_end(e);
   FMX_HIP(hipGetLastError());
   return FMX_OK;
@@ -1884,6 +1894,7 @@ static int persist_check(fmx_engine* e) {
   FMX_HIP(hipMemcpyAsync(ctl, e->als_persist_ctl, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
   FMX_HIP(hipMemcpyAsync(ctl + 1, e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
   FMX_HIP(hipStreamSynchronize(e->stream));
+  if (ctl[1] != 0) (void)hipMemset(e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, 0, sizeof(unsigned int));   // reported once: the next sweep starts clean
   FMX_CHECK(ctl[1] == 0, FMX_ERR_HIP, "the persistent sweep gave up waiting after %u features (its workgroups were not all running?): V and the residual are part-way through a sweep", ctl[0]);
   return FMX_OK;
 }

@@ -14,6 +14,7 @@
 // hold a column twice and take a one-lane serial path instead).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <type_traits>
 
@@ -528,6 +529,7 @@ struct WinArgs {
   const float* ex_y;
   const int* conf;      // [count] last earlier example sharing a feature (-1: none; t itself: must run alone)
   int count;
+  int debug_lose;       // test hook (fmx_debug_lose_next_seq_multiplier): the reassociated learner's worker never sees the multiplier tagged with this value (0: off)
 };
 
 __global__ void seq_pack_k(const int64_t* __restrict__ ex_b, const int* __restrict__ ex_len, int count, int nz, const uint32_t* __restrict__ col,
@@ -1247,7 +1249,7 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
     }
     FMX_TW(tA);
     // ---------------------------------------------------------------- the multiplier
-    while (__hip_atomic_load(&f_m[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t + 1) {
+    while (__hip_atomic_load(&f_m[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t + 1 || t + 1 == wa.debug_lose) {
       if (stuck()) return;
       __builtin_amdgcn_s_sleep(1);
     }
@@ -1335,6 +1337,9 @@ static int pipe_mode() {
   return !s ? 1 : (s[0] == '1' ? 0 : (s[0] == '2' ? 2 : 1));  // 0 never, 1 where it fits, 2 always
 }
 
+static std::atomic<int> g_lose_next_seq_multiplier{0};
+void debug_lose_next_seq_multiplier() { g_lose_next_seq_multiplier.store(1); }
+
 // cfg.seq_reassociate (FMX_SEQ_REASSOC=0/1 in the environment overrides it, read per call: the tests run every case in both forms)
 static bool reassoc_mode(const fmx_engine* e) {
   const char* s = getenv("FMX_SEQ_REASSOC");
@@ -1345,7 +1350,9 @@ template <int KIND>
 static void launch_window_kind(fmx_engine* e, const SeqArgs& a, const WinArgs& wa, int nz) {
   if constexpr (KIND == UPD_SGD_L2 || KIND == UPD_SGD_L1) {
     if (reassoc_mode(e)) {
-#define FMX_RE(KL, NZ) hipLaunchKernelGGL((fm_seq_reassoc_k<KIND, KL, NZ>), dim3(1), dim3(SeqRe<KIND, KL, NZ>::NW * 64), 0, e->stream, a, wa, e->hyper)
+      WinArgs war = wa;
+      if (wa.count > 8 && g_lose_next_seq_multiplier.exchange(0) > 0) war.debug_lose = 8;   // (test hook: example 7's multiplier is never seen)
+#define FMX_RE(KL, NZ) hipLaunchKernelGGL((fm_seq_reassoc_k<KIND, KL, NZ>), dim3(1), dim3(SeqRe<KIND, KL, NZ>::NW * 64), 0, e->stream, a, war, e->hyper)
       if (e->k <= 16) { if (nz == 32) FMX_RE(16, 32); else FMX_RE(16, 64); }
       else if (e->k <= 32) { if (nz == 32) FMX_RE(32, 32); else FMX_RE(32, 64); }
       else FMX_RE(64, 32);

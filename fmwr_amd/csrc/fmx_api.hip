@@ -2063,6 +2063,8 @@ int fmx_rccl_selftest(int32_t n, double* max_err) { return group_rccl_selftest(n
 
 int fmx_debug_fail_next_plan_build(void) { debug_fail_next_plan_build(); return FMX_OK; }
 int fmx_debug_fail_next_comm_init(void) { debug_fail_next_comm_init(); return FMX_OK; }
+int fmx_debug_lose_next_seq_multiplier(void) { debug_lose_next_seq_multiplier(); return FMX_OK; }
+int fmx_debug_stall_next_persistent_sweep(void) { debug_stall_next_persistent_sweep(); return FMX_OK; }
 int fmx_group_info(fmx_engine* e, int32_t* n_replicas, int32_t* share_device, int32_t* peer_pairs, int32_t* peer_pairs_direct, int32_t* sparse_exchange) {
   FMX_CHECK(e != nullptr, FMX_ERR_INVALID, "NULL engine");
   return group_info(e, n_replicas, share_device, peer_pairs, peer_pairs_direct, sparse_exchange);

@@ -543,6 +543,8 @@ int rows_pack(fmx_engine* e, const uint32_t* d_ids, int64_t n, void* d_rows, boo
 void drop_plans(fmx_matrix* m);
 int build_batch_csc(fmx_matrix* m, int64_t batch_rows, int64_t tile_rows, hipStream_t stream);
 void debug_fail_next_plan_build();
+void debug_lose_next_seq_multiplier();        // fm_seq_kernels.hip
+void debug_stall_next_persistent_sweep();     // fm_als_kernels.hip
 int build_full_csc(fmx_matrix* m, hipStream_t stream);
 int generate_synthetic(fmx_matrix* m, int32_t nnz_per_row, uint64_t seed, int64_t row_offset);
 int generate_synthetic_async(fmx_matrix* m, int64_t n, int32_t z, uint64_t seed, int64_t row_offset, hipStream_t stream);

@@ -11,6 +11,12 @@ int fmx_debug_fail_next_plan_build(void);
 /* the next fmx_engine_create with cfg.n_gpus > 1 fails where the communicator is initialised -- after the other replicas were created -- as
  * ncclCommInitAll failing on a later device would (tests/test_gpu_group.py: the error path tears everything down, the next create works) */
 int fmx_debug_fail_next_comm_init(void);
+/* the next launch of the reassociated reference-order learner (cfg.seq_reassociate) never sees the multiplier of its example 7: that worker's bounded wait gives up, every
+ * other wait follows, and fmx_get_params / fmx_sync must report FMX_ERR_HIP instead of handing out the NaN (tests/test_gpu_seq_reassoc.py) */
+int fmx_debug_lose_next_seq_multiplier(void);
+/* in the next persistent exact sweep (als_exact_persist_k) wave 0 does not count its first feature: the level never completes, the bounded waits give up, and the sweep
+ * must fail with FMX_ERR_HIP (tests/test_gpu_configs4.py).  Takes a few seconds: the waits are bounded generously */
+int fmx_debug_stall_next_persistent_sweep(void);
 #ifdef __cplusplus
 }
 #endif

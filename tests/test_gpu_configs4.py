@@ -664,3 +664,27 @@ def test_configs4_deep_exact_plan_with_columns_longer_than_the_kept_slots(monkey
         e.close(); m.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert util.rel_err(res[0][0], rv.reshape(k, p)) < 1e-10 and util.rel_err(res[0][1], rerr) < 1e-10
+
+
+def test_configs4_persistent_sweep_that_gives_up_is_reported():
+    """Fault injection (fmx_debug_stall_next_persistent_sweep: one wave's first feature is never counted, so the level never completes): every bounded wait gives up and the
+    sweep fails with FMX_ERR_HIP instead of hanging or returning a half-swept model as if it were whole; the next sweep on the same engine is right again."""
+    from fmwr_amd import _lib as L, engine
+    k, n, p = 4, 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "iid", n, p, 67, "ones")
+    w0, w, v = util.params(p, k, 41, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(oracle.params(task=oracle.REGRESSION, k=k), X, w0, w, v.ravel()) - y
+    lam = np.linspace(0.5, 1.0, k)
+    rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=1.0, v_lambda=lam)
+    e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+    e.set_params(w0, w, v)
+    m = engine.Matrix.from_csr(rp, col, val, p, y)
+    levels, largest, approx, _ = e.als_plan(m)
+    assert levels > 1_000 and largest <= 256
+    L.check(L.lib().fmx_debug_stall_next_persistent_sweep())
+    with pytest.raises(Exception, match="gave up waiting"):
+        e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam)
+    e.set_params(w0, w, v)
+    gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam)
+    assert util.rel_err(e.get_params()[2], rv.reshape(k, p)) < 1e-10 and util.rel_err(gerr, rerr) < 1e-10

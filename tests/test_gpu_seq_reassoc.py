@@ -147,3 +147,26 @@ def test_launches_shorter_than_the_ring(count):
     assert abs(a[0] - b[0]) < TOL and util.rel_err(a[1], b[1]) < TOL and util.rel_err(a[2], b[2]) < TOL
     P, rp, col, val, y, w0, w, v, order = ctx
     assert len(order) == count
+
+
+def test_a_wait_that_gives_up_is_reported_not_returned_as_nan():
+    """Fault injection (fmx_debug_lose_next_seq_multiplier: a worker never sees its example's multiplier): the bounded waits end the launch, and fmx_sync / fmx_get_params
+    say so (FMX_ERR_HIP) instead of handing out a NaN; fmx_set_params clears the state and the same engine trains correctly again."""
+    from fmwr_amd import engine, _lib as L
+    c = sw.SOLVERS["sgd_l2"]
+    a, ctx = _run_re("giveup", c, 3000, 600, 12, 500)     # the healthy run, for reference
+    P, rp, col, val, y, w0, w, v, order = ctx
+    e = engine.Engine(3000, task=P.task, solver=L.SOLVER_SGD, num_factor=P.k, l2_w0=P.l2_reg0, l2_w1=P.l2_regw, l2_v=P.l2_regv, learn_rate=P.learn_rate,
+                      mode=L.MODE_SEQUENTIAL, seq_reassociate=1, min_target=P.min_target, max_target=P.max_target)
+    m = engine.Matrix.from_csr(rp, col, val, 3000, y)
+    e.set_params(w0, w, v)
+    L.check(L.lib().fmx_debug_lose_next_seq_multiplier())
+    e.train_order(m, order)
+    with pytest.raises(Exception, match="gave up waiting"):
+        e.get_params()
+    with pytest.raises(Exception, match="gave up waiting"):
+        e.sync()
+    e.set_params(w0, w, v)
+    e.train_order(m, order)
+    got = e.get_params()
+    assert got[0] == a[0] and np.array_equal(got[1], a[1]) and np.array_equal(got[2], a[2])
