@@ -12,8 +12,8 @@ sums, exchanges them (dense: the (k+2)*p buffer is all-reduced in pipelined bloc
 features are all-gathered), every replica applies the same update ("scaling": "weak": per-GPU rows per step are fixed).
 
 Rank 0's LAST stdout line is the ONE JSON line the driver parses (driver_line(): at most LINE_LIMIT = 4000 bytes -- metric, config, roofline, cpu_baseline and a
-flat summary of the side runs); everything else the run measured is printed BEFORE it as lines prefixed `DETAILS ` (one key per line, long values in numbered pieces: no line
-over 4 000 bytes) and left in bench_details.json.
+flat summary of the side runs) and the ONLY stdout line; everything else the run measured goes to stderr as lines prefixed `DETAILS ` (one key per line, long values in
+numbered pieces: no line over 4 000 bytes) and is left in bench_details.json.
 `value` is whole-job examples/s of the timed steps.  `roofline` prices the step in SURVEY
 8(d)'s algorithmic bytes (the headline `frac`) and each of the two kernels on its own bytes and HIP-event time, next to the
 measured ceiling of the access pattern (`ceiling_frac`).  At N == 1 the same line also carries what `value` leaves out:
@@ -1056,7 +1056,7 @@ def _frac_entry(d):
 
 def driver_line(d):
     """The ONE line the driver parses: BASELINE.json's metric / config, `roofline`, `cpu_baseline` and a flat summary of the side runs, at most LINE_LIMIT
-    bytes.  Everything else the run measured goes to earlier stdout lines prefixed `DETAILS ` and to bench_details.json (emit())."""
+    bytes.  Everything else the run measured goes to stderr lines prefixed `DETAILS ` and to bench_details.json (emit())."""
     r, cfg = d.get("roofline", {}), d.get("config", {})
     line = {kk: _num(d[kk]) for kk in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if kk in d}
     line["config"] = {"workload": _cap(cfg.get("workload"), 300)}
@@ -1100,7 +1100,7 @@ def driver_line(d):
         side["end_to_end_one_epoch"] = _num(d["end_to_end"].get("one_epoch_examples_per_s"))
     if side:
         line["side"] = side
-    line["details"] = "bench_details.json; the stdout lines prefixed DETAILS"
+    line["details"] = "bench_details.json; the stderr lines prefixed DETAILS"
     # the budget is a contract: shed the optional parts, in this order, rather than print a line the driver cannot read
     for shed in ("side", "other_configs"):
         if len(json.dumps(line)) <= LINE_LIMIT:
@@ -1150,15 +1150,20 @@ def details_from_lines(lines):
 
 
 def emit(out):
-    """stdout: the DETAILS lines (everything the run measured, no line over DETAIL_PIECE + a short prefix) first, then -- LAST -- the compact line the driver parses; the full
-    object is also left in bench_details.json"""
+    """stdout carries exactly ONE line: the compact JSON line the driver parses (the contract's "rank 0 prints ONE JSON line" -- whatever the driver does with stdout, the
+    whole of it, its tail or its last line, it finds that line and nothing else).  Everything else the run measured goes to stderr as DETAILS lines (no line over
+    DETAIL_PIECE + a short prefix), printed BEFORE the line, and to bench_details.json.  FMX_BENCH_DETAILS=stdout puts the DETAILS lines on stdout instead (ahead of
+    the line), =off drops them."""
     try:
         with open(os.path.join(os.environ.get("FMX_BENCH_DETAILS_DIR", ROOT), "bench_details.json"), "w") as f:
             f.write(json.dumps(out) + "\n")
     except OSError:
         pass
-    for ln in detail_lines(out):
-        print(ln, flush=True)
+    where = os.environ.get("FMX_BENCH_DETAILS", "stderr")
+    if where != "off":
+        stream = sys.stdout if where == "stdout" else sys.stderr
+        for ln in detail_lines(out):
+            print(ln, file=stream, flush=True)
     print(json.dumps(driver_line(out)), flush=True)
 
 

@@ -50,16 +50,27 @@ def test_driver_line_sheds_before_it_overflows():
     assert "roofline" in line and "cpu_baseline" in line
 
 
-def test_emit_prints_details_first_and_the_compact_line_last(tmp_path, monkeypatch):
+def test_emit_puts_one_line_on_stdout_and_the_details_on_stderr(tmp_path, monkeypatch):
+    from contextlib import redirect_stderr
     monkeypatch.setenv("FMX_BENCH_DETAILS_DIR", str(tmp_path))
-    buf = io.StringIO()
-    with redirect_stdout(buf):
+    monkeypatch.delenv("FMX_BENCH_DETAILS", raising=False)
+    out, err = io.StringIO(), io.StringIO()
+    with redirect_stdout(out), redirect_stderr(err):
         bench.emit(_full())
-    lines = buf.getvalue().strip().split("\n")
-    assert len(lines) > 10 and all(ln.startswith("DETAILS ") for ln in lines[:-1])
-    assert max(len(ln) for ln in lines) <= bench.LINE_LIMIT            # no line the driver's reader could choke on, the details included
-    last = json.loads(lines[-1])
-    assert len(lines[-1]) <= bench.LINE_LIMIT and last["metric"] and last["roofline"]["frac"] > 0
-    assert len([ln for ln in lines if ln.startswith("{")]) == 1       # exactly one JSON line
+    # stdout: the ONE line, whole, parseable as it stands -- however the driver reads it
+    text = out.getvalue()
+    assert text.count("\n") == 1 and len(text) <= bench.LINE_LIMIT + 1
+    last = json.loads(text)
+    assert last["metric"] and last["roofline"]["frac"] > 0 and last["cpu_baseline"]["value"] > 0
+    # stderr: the details, line by line, none longer than the driver's own line may be; they add up to the full object, which is also in the file
+    lines = err.getvalue().strip().split("\n")
+    assert len(lines) > 10 and all(ln.startswith("DETAILS ") for ln in lines) and max(len(ln) for ln in lines) <= bench.LINE_LIMIT
     full = json.load(open(tmp_path / "bench_details.json"))
     assert bench.details_from_lines(lines) == full == _full()
+    # FMX_BENCH_DETAILS=stdout: the details ahead of the line on stdout, the line still last; =off: the line alone
+    monkeypatch.setenv("FMX_BENCH_DETAILS", "stdout")
+    out = io.StringIO()
+    with redirect_stdout(out):
+        bench.emit(_full())
+    ls = out.getvalue().strip().split("\n")
+    assert json.loads(ls[-1])["value"] == last["value"] and all(ln.startswith("DETAILS ") for ln in ls[:-1])
