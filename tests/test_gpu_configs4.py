@@ -437,6 +437,31 @@ def test_configs4_full_size_levels_descent_and_reproducibility():
     m.close()
 
 
+def test_configs4_full_size_iid_columns_in_the_reference_order(monkeypatch):
+    """10 M x 1 M, k = 16, SURVEY 8(d)'s i.i.d. columns under the exact schedule (cfg.als_max_levels = 0): a chain of ~19 400 dependent levels of at most ~110 features.
+    One ALS sweep (310 000 level steps) through the persistent form (one launch per factor), again, and through one launch per level (FMX_ALS_PERSIST=0) from the same start:
+    the whole residual and V's sampled rows bit for bit, and the residual falls."""
+    from fmwr_amd import _lib as L, engine
+    m = engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_UNIFORM)
+    err0 = np.random.default_rng(7).normal(0, 1, N)
+    res = []
+    for persist in ("1", "1", "0"):
+        monkeypatch.setenv("FMX_ALS_PERSIST", persist)
+        e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=0)
+        e.init_normal(SEED, 0.0, 0.01)
+        levels, largest, approx, _ = e.als_plan(m)
+        assert not approx and levels > 10_000 and largest <= 256
+        d_err = util.DevBuf(N)
+        d_err.upload(err0)
+        e.vsweep_device(m, d_err.ptr.value, alpha=1.0)
+        res.append((d_err.numpy(), e.get_rows(np.arange(0, P, 97, dtype=np.uint32))[1]))
+        e.close(); d_err.free()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
+    assert float(np.dot(res[0][0], res[0][0])) < 0.5 * float(np.dot(err0, err0))
+    m.close()
+
+
 def test_configs4_full_size_level_order_and_row_tiled_forms_equal_the_column_walking_form(monkeypatch):
     """10 M x 1 M, k = 16.  The default: a complete plan whose lists all fit a block, so the V sweep takes the BLOCK form of the level-order sweep (one kernel
     per level, fm_als_blocks.hip); FMX_ALS_ORDER=1: its tile form (two kernels per level, 153 tiles of 65 536 rows); FMX_ALS_ORDER=0: the three-pass row-tiled
