@@ -321,6 +321,7 @@ def cpu_baseline(m, args, v0):
 
 
 LR_BASE, LR_BASE_ROWS = 0.01, 262_144
+PREWARM_S = 0.15   # seconds of untimed steps before the warm-up steps (run_minibatch)
 
 
 def learn_rate_for(global_rows):
@@ -1347,6 +1348,19 @@ def run_minibatch(args, rank, local_rank, world):
     if B >= 65536:
         for i in range(16):
             one_step(i)
+    # ... and the device itself settles: in a fresh process the first tens of milliseconds of heavy work run below the steady rate (clocks ramp: profiles/r05_alloc_placement.txt,
+    # r06_timed_region.txt -- the same K steps read 0.332 ms each 6 ms into the process's first burst and 0.308 ms later).  Untimed steps for PREWARM_S seconds, the same
+    # number on every rank, before the W warm-up steps the caller asked for; `value` is the steady-state rate whatever K and W are
+    prewarm = int(os.environ.get("FMX_BENCH_PREWARM_STEPS", "-1"))
+    if prewarm < 0:
+        t_w = time.perf_counter()
+        for i in range(8):
+            one_step(i)
+        e.sync()
+        per = max((time.perf_counter() - t_w) / 8, 1e-5)
+        prewarm = int(min(2000, PREWARM_S / per))
+    for i in range(prewarm):
+        one_step(i)
     for i in range(args.warmup):
         one_step(i)
     fence()
