@@ -1359,6 +1359,10 @@ def run_minibatch(args, rank, local_rank, world):
         e.sync()
         per = max((time.perf_counter() - t_w) / 8, 1e-5)
         prewarm = int(min(2000, PREWARM_S / per))
+        if world > 1:   # every rank must take the same number of steps (each one is a collective): the largest count any rank arrived at
+            t = torch.tensor([prewarm], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            prewarm = int(t.item())
     for i in range(prewarm):
         one_step(i)
     for i in range(args.warmup):
