@@ -1079,7 +1079,7 @@ template <int KIND, int KL, int NZ> struct SeqRe {
   static constexpr int NW = REGS <= 100 ? 16 : (REGS <= 140 ? 12 : 8);
 #endif
   static constexpr int W = NW - 1;
-  static constexpr int R = (64 / W) * W;   // 60 (15 workers), 63 (7)
+  static constexpr int R = (64 / W) * W;   // ring slots, a multiple of W (a slot is always written by the same wave, in order): 60 (15 workers), 55 (11), 63 (7)
 };
 
 template <int KIND, int KL, int NZ>
@@ -1100,7 +1100,8 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
   if (threadIdx.x == 0) s_abort = 0;
   __syncthreads();   // the only barrier: every wave reaches it before the roles part
   // Every wait below is bounded: a wave that has polled ~1e6 times (tens of milliseconds; a legitimate wait is microseconds) raises s_abort, every other wait
-  // sees it within 1024 polls, all waves leave, and w0 comes back NaN -- a wrong plan (conf[]) or a lost tag then fails a test instead of hanging the device.
+  // sees it within 1024 polls, all waves leave, w0 comes back NaN and scal[SC_SEQ_ABORT] is set (fmx_get_params / fmx_sync then return FMX_ERR_HIP) -- a wrong plan
+  // (conf[]) or a lost tag fails loudly instead of hanging the device (tests/test_gpu_seq_reassoc.py injects one).
   int spins = 0;
   auto stuck = [&]() {
     if ((++spins & 1023) != 0) return false;
