@@ -781,7 +781,8 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
 // has matched; no fence on either side (MI355X_MICROARCH.md, visibility: sc1 stores and loads + an atomic counter are valid under any workgroup placement).
 // Everything static -- the level's feature, its column bounds, rows and values, its own V entry (only this step writes it) -- is fetched BEFORE the wait.
 // Same arithmetic, same order per feature as als_level_k / als_w_level_k: the same bits (tests/test_gpu_configs4.py).
-// Every wait is bounded: ~4e6 polls (seconds; a legitimate wait is microseconds) raise ctl[1], every other wait then ends, and the host reports the sweep failed.
+// Every wait is bounded: ~4e6 polls (seconds; a legitimate wait is microseconds) raise the abort word (the line after the replicas; STICKY until the host has read it, so
+// a give-up in an early factor's launch is still known after the last one), every other wait then ends, and the host reports the sweep failed (persist_check).
 // Workgroups of ONE wave: the wave that stores is the wave that drains and signals, the wave that polls is the wave that loads (the hand-off form the guide lists: one
 // lane of each storing workgroup signals for all that workgroup's stores; the polling wave loads after its poll has matched).
 // The counter is kept in PERSIST_REPL replicas, each on a line of its own: a finishing wave adds to every replica with ONE instruction (one lane per replica), a
