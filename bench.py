@@ -1195,6 +1195,27 @@ def compact_line(d):
     return keep
 
 
+def in_child_process(argv):
+    """`python bench.py <argv>` as a CHILD process (this process keeps its GPU context and waits; nothing is exec'd); returns the child's full object (its bench_details.json,
+    written to a directory of its own) with `process: "child"` noted in its config, or None if the child failed (the caller then runs the same thing here).
+    Used for the streamed configs[3] line: a streamed job is a process of its own, and inside this long process it reads ~6 % low -- the 8 GB parameter table of its engine is
+    then allocated from device memory that the runs before it have cut up (profiles/r06_stream_queue_occupancy.txt: 402 M alone, 379 M after the headline's run in one
+    process, 400 M after a run that had just freed a table of the same size)."""
+    import subprocess
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            env = dict(os.environ, FMX_BENCH_DETAILS_DIR=tmp, FMX_BENCH_DETAILS="off")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return None
+            d = json.load(open(os.path.join(tmp, "bench_details.json")))
+        d.setdefault("config", {})["process"] = "child: python bench.py " + " ".join(argv)
+        return d
+    except Exception:
+        return None
+
+
 def other_configs(args):
     """BASELINE.json configs[2], [3] (rows resident and streamed) and [4], each run here, in this process, right after the headline line -- the driver's
     command (`bench.py --gpus 1 --steps K --warmup W`) witnesses all five configs.  Same code paths as `bench.py --solver ftrl`,
@@ -1213,9 +1234,14 @@ def other_configs(args):
     for name, argv, fn in runs:
         t0 = time.perf_counter()
         try:
-            a = parse(argv + ["--seed", str(args.seed), "--columns", args.columns, "--no-other-configs"])
-            a.cpu_one_core_only = True
-            line = fn(a, 0, 0, 1)
+            argv_full = argv + ["--seed", str(args.seed), "--columns", args.columns, "--no-other-configs"]
+            line = None
+            if fn is main_stream and os.environ.get("FMX_BENCH_STREAM_INPROCESS") != "1":
+                line = in_child_process(argv_full)
+            if line is None:
+                a = parse(argv_full)
+                a.cpu_one_core_only = True
+                line = fn(a, 0, 0, 1)
             out[name] = compact_line(line)
             out[name]["wall_s"] = time.perf_counter() - t0
         except BaseException as ex:   # a failing side run must not take the headline line with it
