@@ -1014,6 +1014,277 @@ __global__ __launch_bounds__(64) void als_exact_persist_k(const uint32_t* __rest
 #undef FMX_TP
 }
 
+// ---- the same sweep with NO counter: the rows' records order the steps themselves ----------------------------------------------------------
+// What a level of the counter form costs is four dependent fabric trips (store drain -> add -> poll -> pair gather) and the slowest of its ~51 waves.  But a step
+// does not need "every feature of the levels before": it needs, for each of its rows, the correction of the ONE feature that touched that row last -- in the
+// reference's index order the column before it in the row.  So the row's state carries that fact with it.  A row's record is 32 bytes, four 8-byte words
+//     { q.lo | tag << 32,  q.hi | tag << 32,  e.lo | tag << 32,  e.hi | tag << 32 }        tag = how many features have corrected this row in this launch
+// and entry t of a column knows its RANK inside its row (als_rank: uint16 per entry, built once per plan).  The step loads its rows' records (two sc1 b128 loads per
+// row) and takes a record when all four tags equal the entry's rank -- else it loads that record again; it stores the corrected record with tag rank + 1 (two sc1
+// b128 stores) and goes on: no drain, no add, no poll of anything but the data.  Needs nothing of the memory system but that an aligned 8-byte word is stored and
+// loaded whole (a record whose four tags agree with the rank is the predecessor's record, word by word: tags only grow inside a launch, and nobody else writes the
+// row between its predecessor and this step), and that an sc1 store becomes visible to an sc1 load in the end -- what the counter form asks of its counter.
+// The wave that holds the lowest unfinished feature of the plan can always run (its predecessors are all of lower levels, hence finished), so the launch ends; every
+// wait is bounded like the counter form's.  Same arithmetic in the same order per feature: the same bits as als_level_k.
+typedef uint32_t rec_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rec_u32x4_t rec_load(__amdgpu_buffer_rsrc_t r, uint32_t row, int half) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(row * 32u + (uint32_t)half * 16u), 0, 16);   // aux 16 = sc1
+}
+__device__ __forceinline__ void rec_store(__amdgpu_buffer_rsrc_t r, uint32_t row, int half, double x, uint32_t tag) {
+  rec_u32x4_t v;
+  v.x = (uint32_t)__double2loint(x); v.y = tag; v.z = (uint32_t)__double2hiint(x); v.w = tag;
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 32u + (uint32_t)half * 16u), 0, 16);
+}
+__device__ __forceinline__ double rec_value(rec_u32x4_t v) { return __hiloint2double((int)v.z, (int)v.x); }
+__device__ __forceinline__ bool rec_is(rec_u32x4_t v, uint32_t tag) { return v.y == tag && v.w == tag; }
+
+__global__ void als_rec_pack_k(const double2* __restrict__ qe, uint32_t* __restrict__ rec, int64_t n) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const double2 c = qe[r];
+  rec_u32x4_t a, b;
+  a.x = (uint32_t)__double2loint(c.x); a.y = 0u; a.z = (uint32_t)__double2hiint(c.x); a.w = 0u;
+  b.x = (uint32_t)__double2loint(c.y); b.y = 0u; b.z = (uint32_t)__double2hiint(c.y); b.w = 0u;
+  reinterpret_cast<rec_u32x4_t*>(rec)[2 * r] = a;
+  reinterpret_cast<rec_u32x4_t*>(rec)[2 * r + 1] = b;
+}
+__global__ void als_rec_unpack_k(const uint32_t* __restrict__ rec, double2* __restrict__ qe, int64_t n) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const rec_u32x4_t a = reinterpret_cast<const rec_u32x4_t*>(rec)[2 * r], b = reinterpret_cast<const rec_u32x4_t*>(rec)[2 * r + 1];
+  qe[r] = make_double2(rec_value(a), rec_value(b));
+}
+// rank of every column-major entry inside its ROW (rows strictly ascending in col, a column's rows ascending: the entry of (r, j) in column j by bisection)
+__global__ void als_rank_k(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, int64_t n, const int64_t* __restrict__ col_ptr,
+                           const uint32_t* __restrict__ crow, uint16_t* __restrict__ rank, int* __restrict__ longest) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t b = row_ptr[r], e = row_ptr[r + 1];
+  if (e - b > 65535) { atomicMax(longest, 65536); return; }
+  for (int64_t u = b; u < e; ++u) {
+    const uint32_t j = col[u];
+    int64_t lo = col_ptr[j], hi = col_ptr[j + 1] - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (crow[mid] < (uint32_t)r) lo = mid + 1; else hi = mid;
+    }
+    rank[lo] = (uint16_t)(u - b);
+  }
+}
+
+constexpr int FLOW_WAVES = 256;
+template <bool W>
+__global__ __launch_bounds__(64) void als_exact_flow_k(const uint32_t* __restrict__ feats, const int64_t* __restrict__ level_ptr, int L,
+                                                       const int64_t* __restrict__ col_ptr, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
+                                                       const uint16_t* __restrict__ crank, double* __restrict__ P, int kp, const SweepDyn* __restrict__ dyn,
+                                                       uint32_t* rec, uint32_t rec_bytes, unsigned int* abort_w, int debug_skip) {
+  const int f = W ? 0 : dyn->f;
+  const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
+  const double* __restrict__ znorm = dyn->znorm;
+  const int lane = threadIdx.x;
+  const int gw = (int)blockIdx.x, NW = (int)gridDim.x;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)rec_bytes, 0x00020000);
+  unsigned int spins = 0;
+#ifdef FMX_PERSIST_TIMING
+  unsigned long long tG = 0, tC = 0, tD = 0, nF = 0, nPoll = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+#define FMX_TP(acc) do { c1 = __builtin_amdgcn_s_memtime(); acc += c1 - c0; c0 = c1; } while (0)
+#else
+#define FMX_TP(acc) do { } while (0)
+#endif
+  // this wave's features: positions gw, gw + NW, ... of the WHOLE plan (not of every level: nothing here is level-synchronous, and a wave that held a feature of every
+  // level would be the chain itself -- its own serial step, 4.9 us, for every level)
+  const int64_t first = level_ptr[0], last = level_ptr[L];
+  int64_t j = first + gw - NW;
+  auto advance = [&]() { j += NW; return j < last; };
+  // the static part of a step, fetched one feature ahead (als_exact_persist_k), with the entries' ranks
+  struct Stat { int64_t j, b, e; uint32_t i; double v_old, zi; float kx[ALS_KEEP]; uint32_t kr[ALS_KEEP], kt[ALS_KEEP]; };
+  auto round1 = [&](Stat& st) { st.j = j; st.i = feats[j]; };
+  auto round2 = [&](Stat& st) {
+    st.b = col_ptr[st.i]; st.e = col_ptr[st.i + 1];
+    st.v_old = P[W ? (size_t)st.i : (size_t)st.i * kp + f];
+    st.zi = znorm ? znorm[st.i] : 0.0;
+  };
+  auto round3 = [&](Stat& st) {
+#pragma unroll
+    for (int s = 0; s < ALS_KEEP; ++s) {
+      const int64_t t = st.b + lane + 64 * s;
+      const int64_t tc = t < st.e ? t : 0;
+      st.kx[s] = cval[tc];
+      st.kr[s] = crow[tc];
+      st.kt[s] = crank[tc];
+    }
+  };
+  // a record of the column's tail (entries past the kept ones; a column of more than 512): waited for lane by lane
+  auto wait_record = [&](uint32_t row, uint32_t tag, rec_u32x4_t& a, rec_u32x4_t& b) -> bool {
+    for (;;) {
+      if constexpr (!W) a = rec_load(rs, row, 0);
+      b = rec_load(rs, row, 1);
+      if ((W || rec_is(a, tag)) && rec_is(b, tag)) return true;
+      if ((++spins & 255u) == 0) {
+        if (spins > (1u << 22)) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
+  Stat cur, nxt;
+  bool have = advance();
+  if (have) { round1(cur); round2(cur); round3(cur); }
+  while (have) {
+    FMX_TP(tD);
+    const bool have_next = advance();
+    if (have_next) round1(nxt);
+    const int64_t b = cur.b, e = cur.e;
+    const double v_old = cur.v_old;
+    const int ns = (int)((e - b + 63) >> 6);
+    // ---- the records of the column's rows, each taken once its tags say the row's previous feature has corrected it
+    rec_u32x4_t ha[ALS_KEEP], hb[ALS_KEEP];
+#pragma unroll
+    for (int s = 0; s < ALS_KEEP; ++s) {
+      if (s < ns) {
+        if constexpr (!W) ha[s] = rec_load(rs, cur.kr[s], 0);
+        hb[s] = rec_load(rs, cur.kr[s], 1);
+      }
+    }
+    if (have_next) round2(nxt);
+    unsigned int late = 0;
+#pragma unroll
+    for (int s = 0; s < ALS_KEEP; ++s)
+      if (s < ns && b + lane + 64 * s < e && !((W || rec_is(ha[s], cur.kt[s])) && rec_is(hb[s], cur.kt[s]))) late |= 1u << s;
+    while (__builtin_amdgcn_ballot_w64(late != 0u) != 0ull) {
+#ifdef FMX_PERSIST_TIMING
+      ++nPoll;
+#endif
+      if ((++spins & 255u) == 0) {
+        if (spins > (1u << 22)) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int s = 0; s < ALS_KEEP; ++s) {
+        if (late & (1u << s)) {
+          if constexpr (!W) ha[s] = rec_load(rs, cur.kr[s], 0);
+          hb[s] = rec_load(rs, cur.kr[s], 1);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < ALS_KEEP; ++s)
+        if ((late & (1u << s)) && (W || rec_is(ha[s], cur.kt[s])) && rec_is(hb[s], cur.kt[s])) late &= ~(1u << s);
+    }
+    spins = 0;
+    double2 kc[ALS_KEEP];
+#pragma unroll
+    for (int s = 0; s < ALS_KEEP; ++s) {
+      if (s < ns && b + lane + 64 * s < e) kc[s] = make_double2(W ? 0.0 : rec_value(ha[s]), rec_value(hb[s]));
+      else { cur.kx[s] = 0.f; kc[s] = make_double2(0.0, 0.0); }
+    }
+    FMX_TP(tG);
+    double a_mean = 0.0, a_var = 0.0;
+    if constexpr (W) {
+#pragma unroll
+      for (int s = 0; s < ALS_KEEP; ++s) {
+        if (s < ns && b + lane + 64 * s < e) {
+          const double x = (double)cur.kx[s];
+          a_mean += kc[s].y * x - v_old * x * x;
+          a_var += x * x;
+        }
+      }
+      for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+        const double x = (double)cval[t];
+        rec_u32x4_t qa, qb;
+        if (!wait_record(crow[t], crank[t], qa, qb)) return;
+        a_mean += rec_value(qb) * x - v_old * x * x;
+        a_var += x * x;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < ALS_KEEP; ++s) {
+        if (s < ns) {
+          const float xx = cur.kx[s] * cur.kx[s];
+          const double h = (double)cur.kx[s] * kc[s].x - (double)xx * v_old;
+          a_mean += h * kc[s].y;
+          a_var += h * h;
+        }
+      }
+      for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+        const float x = cval[t];
+        const float xx = x * x;
+        rec_u32x4_t qa, qb;
+        if (!wait_record(crow[t], crank[t], qa, qb)) return;
+        const double h = (double)x * rec_value(qa) - (double)xx * v_old;
+        a_mean += h * rec_value(qb);
+        a_var += h * h;
+      }
+    }
+    if (have_next) round3(nxt);
+    a_mean = butterfly_allsum(a_mean);
+    a_var = butterfly_allsum(a_var);
+    double v_new;
+    if constexpr (W) {
+      a_var = 1.0 / (lambda + alpha * a_var);
+      a_mean = -a_var * (alpha * a_mean - mu * lambda);
+      v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + a_var * cur.zi : a_mean);
+    } else {
+      a_mean -= v_old * a_var;
+      a_var = 1.0 / (lambda + alpha * a_var);
+      a_mean = -a_var * (alpha * a_mean - mu * lambda);
+      v_new = bad_number(a_var) ? 0.0 : (znorm ? a_mean + sqrt(a_var) * cur.zi : a_mean);
+    }
+    // CHECK_PARAM (:336): a bad value keeps the old one and skips the corrections -- the records still move on (their tags), unchanged
+    const bool keep = bad_number(v_new);
+    if (!keep && lane == 0) P[W ? (size_t)cur.i : (size_t)cur.i * kp + f] = v_new;
+    const double v_diff = v_old - v_new;
+    const uint32_t bump = (debug_skip && cur.j == first) ? 0u : 1u;   // (test hook: the plan's first feature leaves its rows' tags where they were)
+#pragma unroll
+    for (int s = 0; s < ALS_KEEP; ++s) {
+      if (s < ns && b + lane + 64 * s < e) {
+        double nq = kc[s].x, ne = kc[s].y;
+        if (!keep) {
+          if constexpr (W) ne = kc[s].y - (double)cur.kx[s] * v_diff;
+          else {
+            const float xx = cur.kx[s] * cur.kx[s];
+            const double h = (double)cur.kx[s] * kc[s].x - (double)xx * v_old;
+            nq = kc[s].x - (double)cur.kx[s] * v_diff;
+            ne = kc[s].y - h * v_diff;
+          }
+        }
+        if constexpr (!W) rec_store(rs, cur.kr[s], 0, nq, cur.kt[s] + bump);
+        rec_store(rs, cur.kr[s], 1, ne, cur.kt[s] + bump);
+      }
+    }
+    for (int64_t t = b + lane + 64 * ALS_KEEP; t < e; t += 64) {
+      const float x = cval[t];
+      const uint32_t r = crow[t], tag = crank[t];
+      rec_u32x4_t qa, qb;
+      if (!wait_record(r, tag, qa, qb)) return;
+      double nq = W ? 0.0 : rec_value(qa), ne = rec_value(qb);
+      if (!keep) {
+        if constexpr (W) ne = ne - (double)x * v_diff;
+        else {
+          const float xx = x * x;
+          const double h = (double)x * nq - (double)xx * v_old;
+          const double q0 = nq;
+          nq = q0 - (double)x * v_diff;
+          ne = ne - h * v_diff;
+        }
+      }
+      if constexpr (!W) rec_store(rs, r, 0, nq, tag + bump);
+      rec_store(rs, r, 1, ne, tag + bump);
+    }
+    FMX_TP(tC);
+#ifdef FMX_PERSIST_TIMING
+    ++nF;
+#endif
+    cur = nxt;
+    have = have_next;
+  }
+#ifdef FMX_PERSIST_TIMING
+  if ((gw == 0 || gw == 77) && lane == 0 && nF) printf("flow wave %d: %llu features, %.1f re-polls each; memtime ticks per feature: records %.0f  step+stores %.0f  loop %.0f\n", gw, nF,
+                                        (double)nPoll / nF, (double)tG / nF, (double)tC / nF, (double)tD / nF);
+#endif
+#undef FMX_TP
+}
+
 // ---- w0 and w sweeps of the ALS learner (MCMC_ALS_Learner.h:162-270, ALS branch, the exact one-thread form) -------------
 __global__ void als_residual_k(const double* __restrict__ yhat, const float* __restrict__ y, int64_t n, double2* __restrict__ qe,
                                const double* __restrict__ dp_y) {
@@ -1371,6 +1642,7 @@ static int build_plan(fmx_matrix* m, hipStream_t stream, int max_levels = 0) {
   als_tiled_free(m); m->als_tiled_tried = 0;
   (void)hipFree(m->als_feats); m->als_feats = nullptr;
   (void)hipFree(m->als_level_ptr_dev); m->als_level_ptr_dev = nullptr;
+  (void)hipFree(m->als_rank); m->als_rank = nullptr; m->als_rank_state = 0;
   (void)hipFree(m->als_heavy); m->als_heavy = nullptr;
   (void)hipFree(m->als_vh); (void)hipFree(m->als_vh_seg0); (void)hipFree(m->als_vseg_feat); (void)hipFree(m->als_vseg_b); (void)hipFree(m->als_vseg_e); (void)hipFree(m->als_vh_work);
   m->als_vh = nullptr; m->als_vh_seg0 = nullptr; m->als_vseg_feat = nullptr; m->als_vseg_b = nullptr; m->als_vseg_e = nullptr; m->als_vh_work = nullptr;
@@ -1865,6 +2137,35 @@ static bool persist_applies(const fmx_matrix* m) {
   if (widest > 2 * PERSIST_WAVES) return false;
   return (uint64_t)m->n * sizeof(double2) <= 0xFFFFFFF0ull && m->als_level_ptr.back() < (int64_t)0xFFFFFFFFll;
 }
+// the record-ordered form (als_exact_flow_k) where the rows' ranks fit its tags; FMX_ALS_PERSIST=counter keeps the counter form (als_exact_persist_k)
+static int flow_prepare(fmx_engine* e, fmx_matrix* m, bool& ok) {
+  ok = false;
+  const char* v = getenv("FMX_ALS_PERSIST");
+  if (v && v[0] == 'c') return FMX_OK;
+  if ((uint64_t)m->n * 32ull > 0xFFFFFFF0ull || !m->rows_sorted) return FMX_OK;
+  if (m->als_rank_state == 0) {
+    int* d_longest = nullptr;
+    FMX_HIP(hipMalloc(&d_longest, sizeof(int)));
+    FMX_HIP(hipMemsetAsync(d_longest, 0, sizeof(int), e->stream));
+    FMX_HIP(hipMalloc(&m->als_rank, (size_t)(m->nnz ? m->nnz : 1) * sizeof(uint16_t)));
+    hipLaunchKernelGGL(als_rank_k, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, e->stream, (const int64_t*)m->row_ptr, (const uint32_t*)m->col, m->n,
+                       (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, m->als_rank, d_longest);
+    int longest = 0;
+    FMX_HIP(hipMemcpyAsync(&longest, d_longest, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    FMX_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_longest);
+    m->als_rank_state = longest > 65535 ? -1 : 1;
+    if (m->als_rank_state < 0) { (void)hipFree(m->als_rank); m->als_rank = nullptr; }
+  }
+  if (m->als_rank_state < 0) return FMX_OK;
+  if (e->als_rec_rows < m->n) {
+    (void)hipFree(e->als_rec); e->als_rec = nullptr; e->als_rec_rows = 0;
+    FMX_HIP(hipMalloc(&e->als_rec, (size_t)m->n * 32));
+    e->als_rec_rows = m->n;
+  }
+  ok = true;
+  return FMX_OK;
+}
 template <bool W>
 static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const SweepDyn* dyn) {
   const int L = (int)m->als_level_ptr.size() - 1;
@@ -1876,11 +2177,28 @@ static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const Swee
     FMX_HIP(hipMalloc(&e->als_persist_ctl, PERSIST_CTL_WORDS * sizeof(unsigned int)));
     FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, PERSIST_CTL_WORDS * sizeof(unsigned int), e->stream));
   }
+  const int debug_skip = g_stall_next_persistent_sweep.exchange(0) > 0 ? 1 : 0;
+  bool flow = false;
+  FMX_TRY(flow_prepare(e, m, flow));
+  if (flow) {
+    // (q, e) pairs -> tagged records (tag 0: nobody has corrected the row in this launch), the sweep, records -> pairs: two streaming passes of 48 bytes per row
+    const unsigned grid = (unsigned)((m->n + 255) / 256);
+    prof_begin(e, FMX_KERNEL_ALS_SWEEP);
+    hipLaunchKernelGGL(als_rec_pack_k, dim3(grid), dim3(256), 0, e->stream, (const double2*)d_qe, e->als_rec, m->n);
+    const char* fw = getenv("FMX_ALS_FLOW_WAVES");
+    const int flow_waves = fw && atoi(fw) > 0 && atoi(fw) <= 2048 ? atoi(fw) : FLOW_WAVES;
+    hipLaunchKernelGGL((als_exact_flow_k<W>), dim3((unsigned)flow_waves), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
+                       (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, (const uint16_t*)m->als_rank, W ? e->dw : e->dV, e->kp64, dyn,
+                       e->als_rec, (uint32_t)((uint64_t)m->n * 32ull), e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, debug_skip);
+    hipLaunchKernelGGL(als_rec_unpack_k, dim3(grid), dim3(256), 0, e->stream, (const uint32_t*)e->als_rec, d_qe, m->n);
+    prof_end(e);
+    FMX_HIP(hipGetLastError());
+    return FMX_OK;
+  }
   // the counter's replicas, every launch.  The abort word (the line after them) is STICKY: a launch that gave up must still be known when the sweep's last factor has
   // run (persist_check reads and clears it); the launches after it leave at their first look at it
   FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, (size_t)PERSIST_REPL * PERSIST_LINE_WORDS * sizeof(unsigned int), e->stream));
   prof_begin(e, FMX_KERNEL_ALS_SWEEP);
-  const int debug_skip = g_stall_next_persistent_sweep.exchange(0) > 0 ? 1 : 0;
   hipLaunchKernelGGL((als_exact_persist_k<W>), dim3(PERSIST_WAVES), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
                      (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, W ? e->dw : e->dV, e->kp64, dyn, d_qe,
                      (uint32_t)((uint64_t)m->n * sizeof(double2)), e->als_persist_ctl, debug_skip);
@@ -1896,7 +2214,7 @@ static int persist_check(fmx_engine* e) {
   FMX_HIP(hipMemcpyAsync(ctl + 1, e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
   FMX_HIP(hipStreamSynchronize(e->stream));
   if (ctl[1] != 0) (void)hipMemset(e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, 0, sizeof(unsigned int));   // reported once: the next sweep starts clean
-  FMX_CHECK(ctl[1] == 0, FMX_ERR_HIP, "the persistent sweep gave up waiting after %u features (its workgroups were not all running?): V and the residual are part-way through a sweep", ctl[0]);
+  FMX_CHECK(ctl[1] == 0, FMX_ERR_HIP, "the persistent sweep gave up waiting (its workgroups were not all running?): V and the residual are part-way through a sweep");
   return FMX_OK;
 }
 

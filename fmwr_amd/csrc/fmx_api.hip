@@ -216,7 +216,7 @@ void free_matrix(fmx_matrix* m) {
   if (!m) return;
   (void)hipFree(m->row_ptr); (void)hipFree(m->col); (void)hipFree(m->val); (void)hipFree(m->y);
   drop_plans(m);
-  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats); (void)hipFree(m->als_heavy); (void)hipFree(m->als_level_ptr_dev);
+  (void)hipFree(m->col_ptr); (void)hipFree(m->crow); (void)hipFree(m->cval); (void)hipFree(m->als_feats); (void)hipFree(m->als_heavy); (void)hipFree(m->als_level_ptr_dev); (void)hipFree(m->als_rank);
   (void)hipFree(m->als_vh); (void)hipFree(m->als_vh_seg0); (void)hipFree(m->als_vseg_feat); (void)hipFree(m->als_vseg_b); (void)hipFree(m->als_vseg_e); (void)hipFree(m->als_vh_work);
   als_tiled_free(m);
   delete m;
@@ -700,7 +700,7 @@ int fmx_engine_destroy(fmx_engine* e) {
   (void)hipFree(e->seq_packed); (void)hipFree(e->seq_conf); (void)hipFree(e->seq_keys); (void)hipFree(e->seq_sort_tmp);
   (void)hipFree(e->long_partial); (void)hipFree(e->probit);
   (void)hipFree(e->S); (void)hipFree(e->amul); (void)hipFree(e->partials); (void)hipFree(e->gbuf);
-  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws); (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]); (void)hipFree(e->als_hash_word); (void)hipFree(e->als_lam_mu); (void)hipFree(e->als_persist_ctl);
+  (void)hipFree(e->crec); (void)hipFree(e->ctail); merge_ws_free(e->merge); (void)hipFree(e->als_qe_new); (void)hipFree(e->als_Q); (void)hipFree(e->als_qe); (void)hipFree(e->als_dyn); (void)hipFree(e->als_backup); (void)hipFree(e->als_tile_ws); (void)hipFree(e->als_lo[0]); (void)hipFree(e->als_lo[1]); (void)hipFree(e->als_hash_word); (void)hipFree(e->als_lam_mu); (void)hipFree(e->als_persist_ctl); (void)hipFree(e->als_rec);
   als_graph_free(e->als_graph_w); als_graph_free(e->als_graph_v);
   if (e->side_fork) (void)hipEventDestroy(e->side_fork);
   if (e->side_join) (void)hipEventDestroy(e->side_join);

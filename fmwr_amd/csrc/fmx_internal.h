@@ -187,6 +187,8 @@ struct fmx_matrix {
   int als_force_exact = 0;              // an approximate sweep raised the residual on this matrix: only exact plans from now on
   int als_plan_cap = -1;                // cfg.als_max_levels the plan was built for
   int64_t* als_level_ptr_dev = nullptr; // als_level_ptr on the device (the persistent form of a deep exact sweep walks the levels inside ONE launch), uploaded on first use
+  uint16_t* als_rank = nullptr;         // rank of every column-major entry inside its row (als_exact_flow_k's expected tags), built on first use
+  int als_rank_state = 0;               // 0 not built, 1 built, -1 does not apply (a row of more than 65 535 entries)
   void* als_tiled = nullptr;            // row-tiled form of the wide levels of an exact plan (fm_als_tiled.hip: AlsTiled), or null
   int als_tiled_tried = 0;              // the tiled plan was built, or found not to apply, for the current plan and values
 };
@@ -301,6 +303,8 @@ struct fmx_engine {
   // every writer of the fp64 V table other than the sweeps themselves calls this: a q table carried from an earlier sweep (fmx_als_carry_q) or left by the learner's own
   // forward pass no longer describes V
   void als_q_invalidate() { als_q_have = 0; als_q_trusted = 0; }
+  uint32_t* als_rec = nullptr;               // 32-byte tagged (q, e) records of als_exact_flow_k, als_rec_rows of them
+  int64_t als_rec_rows = 0;
   unsigned int* als_persist_ctl = nullptr;   // 64 bytes: {features done, abort, ...} of the persistent deep sweep (als_exact_persist_k), zeroed before every launch
   const double* als_qnext = nullptr;  // V sweep: q of the NEXT factor (one double per row), which the last level's correction pass stores in place of the
                                       // finished factor's q when that level is a tiled one (it then clears this pointer: the pick kernel is not needed)

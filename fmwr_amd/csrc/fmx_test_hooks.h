@@ -14,8 +14,9 @@ int fmx_debug_fail_next_comm_init(void);
 /* the next launch of the reassociated reference-order learner (cfg.seq_reassociate) never sees the multiplier of its example 7: that worker's bounded wait gives up, every
  * other wait follows, and fmx_get_params / fmx_sync must report FMX_ERR_HIP instead of handing out the NaN (tests/test_gpu_seq_reassoc.py) */
 int fmx_debug_lose_next_seq_multiplier(void);
-/* in the next persistent exact sweep (als_exact_persist_k) wave 0 does not count its first feature: the level never completes, the bounded waits give up, and the sweep
- * must fail with FMX_ERR_HIP (tests/test_gpu_configs4.py).  Takes a few seconds: the waits are bounded generously */
+/* in the next persistent exact sweep the plan's first feature does not hand its rows on (als_exact_flow_k: their tags stay where they were; als_exact_persist_k: it is
+ * never counted): the features after it never become ready, the bounded waits give up, and the sweep must fail with FMX_ERR_HIP (tests/test_gpu_configs4.py).
+ * Takes a few seconds: the waits are bounded generously */
 int fmx_debug_stall_next_persistent_sweep(void);
 #ifdef __cplusplus
 }

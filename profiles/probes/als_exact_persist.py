@@ -1,5 +1,6 @@
 """configs[4] on SURVEY 8(d)'s i.i.d. columns in the reference's own order (cfg.als_max_levels = 0): one launch per level (FMX_ALS_PERSIST=0) against the persistent
-form (one launch per factor).  usage: python profiles/probes/als_exact_persist.py [rows] [sweeps]"""
+forms (one launch per factor): "1" = the default (record-ordered, als_exact_flow_k), "counter" = als_exact_persist_k.
+usage: python profiles/probes/als_exact_persist.py [rows] [sweeps] [forms, comma separated]"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -9,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 p, z, k = 1_000_000, 30, 16
 m = engine.Matrix.synthetic_iid(n, p, z, 20240001, law=L.COLUMNS_UNIFORM)
-for persist in ("1", "1", "0"):
+for persist in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("1", "1", "counter", "0")):
     os.environ["FMX_ALS_PERSIST"] = persist
     e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL, als_max_levels=0)
     e.init_normal(20240001, 0.0, 0.01)

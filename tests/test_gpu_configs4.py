@@ -439,13 +439,13 @@ def test_configs4_full_size_levels_descent_and_reproducibility():
 
 def test_configs4_full_size_iid_columns_in_the_reference_order(monkeypatch):
     """10 M x 1 M, k = 16, SURVEY 8(d)'s i.i.d. columns under the exact schedule (cfg.als_max_levels = 0): a chain of ~19 400 dependent levels of at most ~110 features.
-    One ALS sweep (310 000 level steps) through the persistent form (one launch per factor), again, and through one launch per level (FMX_ALS_PERSIST=0) from the same start:
-    the whole residual and V's sampled rows bit for bit, and the residual falls."""
+    One ALS sweep (310 000 level steps) through the record-ordered form (one launch per factor, the default), again, through the counter form (FMX_ALS_PERSIST=counter) and
+    through one launch per level (FMX_ALS_PERSIST=0) from the same start: the whole residual and V's sampled rows bit for bit, and the residual falls."""
     from fmwr_amd import _lib as L, engine
     m = engine.Matrix.synthetic_iid(N, P, Z, SEED, law=L.COLUMNS_UNIFORM)
     err0 = np.random.default_rng(7).normal(0, 1, N)
     res = []
-    for persist in ("1", "1", "0"):
+    for persist in ("1", "1", "0", "counter"):
         monkeypatch.setenv("FMX_ALS_PERSIST", persist)
         e = engine.Engine(P, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, als_max_levels=0)
         e.init_normal(SEED, 0.0, 0.01)
@@ -458,6 +458,7 @@ def test_configs4_full_size_iid_columns_in_the_reference_order(monkeypatch):
         e.close(); d_err.free()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
+    assert np.array_equal(res[0][0], res[3][0]) and np.array_equal(res[0][1], res[3][1])
     assert float(np.dot(res[0][0], res[0][0])) < 0.5 * float(np.dot(err0, err0))
     m.close()
 
@@ -607,9 +608,10 @@ def test_deep_plans_replayed_as_a_graph_equal_the_eager_launches(monkeypatch):
 
 @pytest.mark.parametrize("values,gibbs", [("ones", False), ("normal", True), ("normal", False), ("ones", True)])
 def test_configs4_deep_exact_plan_in_one_launch_per_factor(monkeypatch, values, gibbs):
-    """SURVEY 8(d)'s i.i.d. columns in the reference's own index order: a chain of dependent levels (20 K x 6 K, 30 per row: more than 1 000).  The persistent form
-    (als_exact_persist_k: the level loop inside one launch per factor, the levels ordered by a counter of completed features, the (q, e) pairs handed between waves by
-    write-through stores and L1-bypassing loads) must give bit for bit what one launch per level gives (FMX_ALS_PERSIST=0), twice, and the oracle's numbers to 1e-10."""
+    """SURVEY 8(d)'s i.i.d. columns in the reference's own index order: a chain of dependent levels (20 K x 6 K, 30 per row: more than 1 000).  The persistent forms --
+    als_exact_flow_k (the default: one launch per factor, every row's record tagged with the number of features that have corrected it, a step takes a record once the
+    tag equals its entry's rank in the row) and als_exact_persist_k (FMX_ALS_PERSIST=counter: the levels ordered by a counter of completed features) -- must give bit
+    for bit what one launch per level gives (FMX_ALS_PERSIST=0), the default twice, and the oracle's numbers to 1e-10."""
     from fmwr_amd import _lib as L, engine
     n, p = 20_000, 6_000
     rp, col, val, y = _problem(engine, L, "iid", n, p, 47, values)
@@ -621,7 +623,7 @@ def test_configs4_deep_exact_plan_in_one_launch_per_factor(monkeypatch, values, 
     z = np.random.default_rng(11).normal(0, 1, (K, p)) if gibbs else None
     rv, rerr, _ = oracle.als_update_v(K, X, v.ravel(), err0, alpha=1.1, v_lambda=lam, v_mu=mu, znorm=z.ravel() if gibbs else None)
     res = []
-    for persist in ("1", "1", "0"):
+    for persist in ("1", "1", "0", "counter"):
         monkeypatch.setenv("FMX_ALS_PERSIST", persist)
         e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_MCMC if gibbs else L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL)
         e.set_params(w0, w, v)
@@ -634,6 +636,7 @@ def test_configs4_deep_exact_plan_in_one_launch_per_factor(monkeypatch, values, 
         e.close(); m.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
+    assert np.array_equal(res[0][0], res[3][0]) and np.array_equal(res[0][1], res[3][1])
     if gibbs:
         assert util.rel_err(res[0][0], rv.reshape(K, p)) < 1e-10 and util.rel_err(res[0][1], rerr) < 1e-10
     else:
@@ -649,7 +652,7 @@ def test_configs4_deep_exact_plan_learner_w_sweep_in_one_launch(monkeypatch):
     rp, col, val, y = _problem(engine, L, "iid", n, p, 53, "normal")
     w0, w, v = util.params(p, K, 29, stdev=0.05, fp32=False)
     res = []
-    for persist in ("1", "0"):
+    for persist in ("1", "0", "counter"):
         monkeypatch.setenv("FMX_ALS_PERSIST", persist)
         e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=K, mode=L.MODE_SEQUENTIAL, l2_w1=0.1, l2_v=0.1)
         e.set_params(w0, w, v)
@@ -657,7 +660,8 @@ def test_configs4_deep_exact_plan_learner_w_sweep_in_one_launch(monkeypatch):
         e.als_train(m, 2, with_v=True)
         res.append(e.get_params())
         e.close(); m.close()
-    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    for other in res[1:]:
+        assert res[0][0] == other[0] and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
     assert not np.array_equal(res[0][1], w)
 
 
@@ -677,7 +681,7 @@ def test_configs4_deep_exact_plan_with_columns_longer_than_the_kept_slots(monkey
     lam = np.linspace(0.5, 1.0, k)
     rv, rerr, _ = oracle.als_update_v(k, X, v.ravel(), err0, alpha=1.0, v_lambda=lam)
     res = []
-    for persist in ("1", "0"):
+    for persist in ("1", "0", "counter"):
         monkeypatch.setenv("FMX_ALS_PERSIST", persist)
         e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
         e.set_params(w0, w, v)
@@ -687,13 +691,70 @@ def test_configs4_deep_exact_plan_with_columns_longer_than_the_kept_slots(monkey
         gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam)
         res.append((e.get_params()[2], gerr))
         e.close(); m.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1])
     assert util.rel_err(res[0][0], rv.reshape(k, p)) < 1e-10 and util.rel_err(res[0][1], rerr) < 1e-10
 
 
-def test_configs4_persistent_sweep_that_gives_up_is_reported():
-    """Fault injection (fmx_debug_stall_next_persistent_sweep: one wave's first feature is never counted, so the level never completes): every bounded wait gives up and the
-    sweep fails with FMX_ERR_HIP instead of hanging or returning a half-swept model as if it were whole; the next sweep on the same engine is right again."""
+def test_configs4_deep_exact_plan_steps_that_keep_their_old_value(monkeypatch):
+    """CHECK_PARAM (MCMC_ALS_Learner.h:336): a step whose new value is not a number keeps the old one and skips its corrections.  In the record-ordered form the rows'
+    tags must still move on (the next feature of the row waits for them): a residual with one NaN in it makes ~30 such steps per factor; all three forms agree bit
+    for bit (NaNs in the same places) and none hangs."""
+    from fmwr_amd import _lib as L, engine
+    k, n, p = 4, 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "iid", n, p, 71, "normal")
+    w0, w, v = util.params(p, k, 43, stdev=0.1, fp32=False)
+    X = oracle.Matrix(rp, col, val, p)
+    err0 = oracle.predict_batch(oracle.params(task=oracle.REGRESSION, k=k), X, w0, w, v.ravel()) - y
+    err0[1234] = np.nan
+    lam = np.linspace(0.5, 1.0, k)
+    res = []
+    for persist in ("1", "0", "counter"):
+        monkeypatch.setenv("FMX_ALS_PERSIST", persist)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=lam)
+        res.append((e.get_params()[2], gerr))
+        e.close(); m.close()
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0], equal_nan=True) and np.array_equal(res[0][1], other[1], equal_nan=True)
+    kept = col[rp[1234]:rp[1235]]
+    assert np.array_equal(res[0][0][:, kept], v[:, kept]) and np.isnan(res[0][1][1234]) and np.isfinite(np.delete(res[0][1], 1234)).all()
+
+
+def test_configs4_rows_too_long_for_the_records_tags(monkeypatch):
+    """A row of 70 000 entries: its entries' ranks do not fit the 16 bits als_rank keeps, the record-ordered form declines and the counter form runs the plan (a chain
+    of 70 000 levels through that row); bit for bit the one-launch-per-level form."""
+    from fmwr_amd import _lib as L, engine
+    k, n, p = 2, 500, 70_000
+    rng = np.random.default_rng(5)
+    rows = [np.arange(p, dtype=np.uint32)] + [np.sort(rng.choice(p, 20, replace=False)).astype(np.uint32) for _ in range(n - 1)]
+    rp = np.zeros(n + 1, dtype=np.int64); rp[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows); val = rng.uniform(0.5, 1.0, len(col)).astype(np.float32)
+    y = util.labels(n, 73, "regression")
+    w0, w, v = util.params(p, k, 47, stdev=0.1, fp32=False)
+    err0 = rng.normal(0, 1, n)
+    res = []
+    for persist in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_PERSIST", persist)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        levels, largest, approx, _ = e.als_plan(m)
+        assert not approx and levels == p
+        gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=np.full(k, 0.7))
+        res.append((e.get_params()[2], gerr))
+        e.close(); m.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("form", ["1", "counter"])
+def test_configs4_persistent_sweep_that_gives_up_is_reported(monkeypatch, form):
+    """Fault injection (fmx_debug_stall_next_persistent_sweep: the plan's first feature never hands its rows on -- their tags stay where they were / it is never counted):
+    every bounded wait gives up and the sweep fails with FMX_ERR_HIP instead of hanging or returning a half-swept model as if it were whole; the next sweep on the same
+    engine is right again."""
+    monkeypatch.setenv("FMX_ALS_PERSIST", form)
     from fmwr_amd import _lib as L, engine
     k, n, p = 4, 20_000, 6_000
     rp, col, val, y = _problem(engine, L, "iid", n, p, 67, "ones")
