@@ -713,7 +713,7 @@ def main_sweep(args, rank, local_rank, world):
     ordered = bool(tiled) and e.als_level_order(m)
     blocks = ordered and e.als_level_order_form(m) == 2
     if exact_iid:
-        # a deep exact plan sweeps a factor in ONE persistent launch (als_exact_persist_k): the HIP events see one launch per factor, the unit stays one level of one
+        # a deep exact plan sweeps a factor in ONE persistent launch (als_exact_flow_k): the HIP events see one launch per factor, the unit stays one level of one
         # factor -- the sweep's wall time over its levels x k dependent level steps (latency, not bytes: profiles/r06_als_exact_persist.txt)
         per_launch_ms = dt / args.steps / launches * 1e3
         lvl_n = launches * args.steps
@@ -725,7 +725,8 @@ def main_sweep(args, rank, local_rank, world):
     step_gbs = 40.0 * nnz * k / (dt / args.steps) / 1e9
     if exact_iid:
         form = ("the exact schedule on i.i.d. columns: the reference's index order as levels of row-disjoint features, every level a dependent step of the sweep "
-                "(at most ~100 short lists: latency, not bytes)")
+                "(at most ~100 short lists: latency, not bytes); one launch per factor, als_exact_flow_k: a step takes a row's record once its tag says the row's previous "
+                "feature has corrected it")
     elif iid and args.sweep_factor_outer:
         form = "als_level_k on the colours' levels (one wave per feature walks its CSC column: a random 16-byte gather and scatter of (q_f, e) per entry and factor)"
     elif iid or fmajor:

@@ -772,6 +772,8 @@ __global__ __launch_bounds__(WG_THREADS) void als_level_k(const uint32_t* __rest
 }
 
 // ---- deep exact plans: the level loop inside ONE launch -----------------------------------------------------------------------------------
+// (Two forms.  This one orders the LEVELS by a counter of completed features; als_exact_flow_k below, the default, orders the STEPS by the rows' own records and is
+// a third faster -- 2.62 against 3.71 us per level; this one stays for rows whose ranks do not fit the records' tags and as FMX_ALS_PERSIST=counter.)
 // The reference's index order on columns without field structure is a CHAIN: 19 399 dependent levels of at most 109 features at 10 M x 1 M, 30 per row.  One
 // launch per level costs ~6.5 us (a wave's four dependent memory rounds -- feature id, column bounds, entries, (q, e) pairs -- plus the kernel boundary) for a
 // microsecond of work: 310 384 launches, 2.0 s per sweep.  Here a factor's whole sweep is one launch of PERSIST_WAVES co-resident one-wave workgroups: wave g takes the
@@ -1072,6 +1074,9 @@ __global__ void als_rank_k(const int64_t* __restrict__ row_ptr, const uint32_t* 
   }
 }
 
+#ifndef FMX_FLOW_SLEEP
+#define FMX_FLOW_SLEEP 1
+#endif
 constexpr int FLOW_WAVES = 256;
 template <bool W>
 __global__ __launch_bounds__(64) void als_exact_flow_k(const uint32_t* __restrict__ feats, const int64_t* __restrict__ level_ptr, int L,
@@ -1080,7 +1085,9 @@ __global__ __launch_bounds__(64) void als_exact_flow_k(const uint32_t* __restric
                                                        uint32_t* rec, uint32_t rec_bytes, unsigned int* abort_w, int debug_skip) {
   const int f = W ? 0 : dyn->f;
   const double alpha = dyn->alpha, lambda = dyn->lambda, mu = dyn->mu;
-  const double* __restrict__ znorm = dyn->znorm;
+  // (a pointer read from memory is a generic one to the compiler: its loads would be FLAT, and a flat load in flight makes every vector-memory wait a vmcnt(0) --
+  // the polls below could not overlap.  It is device memory.)
+  const __attribute__((address_space(1))) double* const znorm = (const __attribute__((address_space(1))) double*)dyn->znorm;
   const int lane = threadIdx.x;
   const int gw = (int)blockIdx.x, NW = (int)gridDim.x;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)rec_bytes, 0x00020000);
@@ -1159,7 +1166,7 @@ __global__ __launch_bounds__(64) void als_exact_flow_k(const uint32_t* __restric
         if (spins > (1u << 22)) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
       }
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(FMX_FLOW_SLEEP);
 #pragma unroll
       for (int s = 0; s < ALS_KEEP; ++s) {
         if (late & (1u << s)) {
@@ -2142,7 +2149,8 @@ static int flow_prepare(fmx_engine* e, fmx_matrix* m, bool& ok) {
   ok = false;
   const char* v = getenv("FMX_ALS_PERSIST");
   if (v && v[0] == 'c') return FMX_OK;
-  if ((uint64_t)m->n * 32ull > 0xFFFFFFF0ull || !m->rows_sorted) return FMX_OK;
+  // (the ranks are those of the reference's INDEX order -- the feature before an entry's in its row is the column before it; a coloured plan visits in another order)
+  if ((uint64_t)m->n * 32ull > 0xFFFFFFF0ull || !m->rows_sorted || m->als_coloured) return FMX_OK;
   if (m->als_rank_state == 0) {
     int* d_longest = nullptr;
     FMX_HIP(hipMalloc(&d_longest, sizeof(int)));

@@ -40,6 +40,7 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         elif "als_block_level_pipe_k" in name: kn = "als_block_level"                       # the block form (fm_als_blocks.hip): ONE kernel per level ...
         elif "als_block_level_k" in name: kn = "als_block_level_qin" if ", true>" in name else "als_block_level_plain"   # ... a factor's first level (takes its q in as a stream) / the unpipelined form
         elif "als_exact_persist_k" in name: kn = "als_exact_persist"                        # a deep exact plan: one launch per FACTOR (the level loop inside)
+        elif "als_exact_flow_k" in name: kn = "als_exact_flow"                              # ... in its record-ordered form (the default since r6's second session)
         elif "als_q_pick_k" in name: kn = "als_q_pick"
         else: continue
         a = acc[kn][row["Counter_Name"]]
