@@ -49,6 +49,31 @@ __device__ __forceinline__ double bcast(double v, int lane) {
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 __device__ __forceinline__ float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
+// Wave sums without the LDS crossbar (the reassociated learner's workers: fifteen waves' ds_bpermutes were what made every LDS poll of the workgroup a ~500-clock
+// trip).  x + x[lane ^ 32] and x + x[lane ^ 16] through gfx950's v_permlane32_swap / v_permlane16_swap (both results added: a + b == b + a, the bits of
+// x += __shfl_xor(x, 32 / 16)); the whole butterfly 32, 16, 8, 4, 2, 1 with DPP row rotations for the last four (after the 32-, 16- and 8-steps a lane's value
+// depends on its index mod 8 only, so the lane 4 (2, 1) to its right holds what lane ^ 4 (2, 1) holds): the same tree, the same bits as the __shfl_xor loop.
+#define FMX_SEQ_DPP64(x, ctrl) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, false))
+__device__ __forceinline__ double xor32_add(double x) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double xor16_add(double x) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double seq_butterfly_allsum(double x) {
+  x = xor32_add(x);
+  x = xor16_add(x);
+  x += FMX_SEQ_DPP64(x, 0x128);   // row_ror:8
+  x += FMX_SEQ_DPP64(x, 0x124);   // row_ror:4
+  x += FMX_SEQ_DPP64(x, 0x122);   // row_ror:2
+  x += FMX_SEQ_DPP64(x, 0x121);   // row_ror:1
+  return x;
+}
+
 __device__ __forceinline__ double seq_grad_mult(const Hyper& h, double y_hat, float y) {
   if (h.task == FMX_TASK_REGRESSION) {
     y_hat = fmin(h.max_t, y_hat);
@@ -1215,7 +1240,8 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
     const int len = cur.len;
     const bool tv = lane < len;
     const uint32_t mycol = tv ? cur.en.x : 0u;
-    const double myx = tv ? (double)__uint_as_float(cur.en.y) : 0.0;
+    const uint32_t myxf = tv ? cur.en.y : 0u;          // (the value's float bits: one word through the shuffle below instead of the double's two)
+    const double myx = (double)__uint_as_float(myxf);
     double myw = a.w[mycol];
     double stw[NS1];
 #pragma unroll
@@ -1225,7 +1251,7 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
 #pragma unroll
     for (int j = 0; j < SL; ++j) {  // slot j of this lane is nonzero u = j * Q + fq (idle slots: column 0, x = 0)
       if constexpr (Q == 1) { cu[j] = bcast(mycol, j); xu[j] = bcast(myx, j); }
-      else { cu[j] = (uint32_t)__shfl((int)mycol, j * Q + fq); xu[j] = __shfl(myx, j * Q + fq); }
+      else { cu[j] = (uint32_t)__shfl((int)mycol, j * Q + fq); xu[j] = (double)__uint_as_float((uint32_t)__shfl((int)myxf, j * Q + fq)); }
       const size_t at = (size_t)cu[j] * kp + fl;
       vv[j] = a.V[at];
 #pragma unroll
@@ -1238,11 +1264,11 @@ __global__ __launch_bounds__((SeqRe<KIND, KL, NZ>::NW * 64)) void fm_seq_reassoc
       s1 += tmp;
       q1 += tmp * tmp;
     }
-#pragma unroll
-    for (int o = KL; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); q1 += __shfl_xor(q1, o); }  // across the Q blocks (a + b == b + a: the same bits in every block)
+    // across the Q blocks (a + b == b + a: the same bits in every block); the steps of x += __shfl_xor(x, o), o = KL .. 32, without the LDS
+    if constexpr (KL <= 16) { s1 = xor16_add(s1); q1 = xor16_add(q1); }
+    if constexpr (KL <= 32) { s1 = xor32_add(s1); q1 = xor32_add(q1); }
     double part = (lane < NZ ? (k1 ? myw : 0.0) * myx : 0.0) + ((lane < KL && fv) ? 0.5 * (s1 * s1 - q1) : 0.0);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    part = seq_butterfly_allsum(part);
     if (lane == 0) {
       s_r[slot] = part; s_y[slot] = cur.y;
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
