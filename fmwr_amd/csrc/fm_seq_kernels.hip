@@ -896,7 +896,8 @@ __device__ __forceinline__ void seq_pipe_body(const SeqArgs& a, const WinArgs& w
     R.len = mt.len;
     const bool tv = lane < R.len;
     R.mycol = tv ? mt.en.x : 0u;
-    R.myx = tv ? (double)__uint_as_float(mt.en.y) : 0.0;
+    const uint32_t myxf = tv ? mt.en.y : 0u;      // (the value travels through the shuffles as its float: one word instead of the double's two)
+    R.myx = (double)__uint_as_float(myxf);
     double q1 = 0.0;
     double xu[QN];
     R.s1 = 0.0;
@@ -907,7 +908,7 @@ __device__ __forceinline__ void seq_pipe_body(const SeqArgs& a, const WinArgs& w
     for (int j = 0; j < SL; ++j) {
       uint32_t cj;
       if constexpr (Q == 1) cj = bcast(R.mycol, j);
-      else { cj = (uint32_t)__shfl((int)R.mycol, j * Q + fq); xu[j] = __shfl(R.myx, j * Q + fq); }
+      else { cj = (uint32_t)__shfl((int)R.mycol, j * Q + fq); xu[j] = (double)__uint_as_float((uint32_t)__shfl((int)myxf, j * Q + fq)); }
       const size_t at = (size_t)cj * kp + fl;
       R.vv[j] = a.V[at];
 #pragma unroll
@@ -941,7 +942,7 @@ __device__ __forceinline__ void seq_pipe_body(const SeqArgs& a, const WinArgs& w
       uint32_t cj;
       double xj;
       if constexpr (Q == 1) { cj = bcast(R.mycol, j); xj = bcast(R.myx, j); }
-      else { cj = (uint32_t)__shfl((int)R.mycol, j * Q + fq); xj = __shfl(R.myx, j * Q + fq); }
+      else { cj = (uint32_t)__shfl((int)R.mycol, j * Q + fq); xj = (double)__uint_as_float((uint32_t)__shfl((int)__float_as_uint((float)R.myx), j * Q + fq)); }
       const size_t at = (size_t)cj * kp + ff;
       if (j * Q + fq < R.len && fv) {
         double th = R.vv[j];
