@@ -441,7 +441,7 @@ def time_to_quality(args, L, engine, v0):
         e.sync()
         return e
 
-    e = engine_for(mode=L.MODE_SEQUENTIAL, seq_reassociate=1)   # the reference-order learner as the glue runs it by default (round 6: 3.9 M examples/s instead of 1.65 M)
+    e = engine_for(mode=L.MODE_SEQUENTIAL, seq_reassociate=1)   # the reference-order learner as the glue runs it by default (round 6: 4.0 M examples/s instead of 1.65 M)
     t0 = time.perf_counter()
     done = e.train(train, 2_000_000)
     e.sync()

@@ -56,10 +56,10 @@ static fmx_config config_from_controls(List fm_controls, List solver_controls, d
   else c.solver = FMX_SOLVER_MCMC;
   c.min_target = min_t; c.max_target = max_t;                    // src/FM.cpp:89-96
   c.mode = FMX_MODE_SEQUENTIAL;                                  // default: the reference's algorithm, its visiting order, one example per update, fp64
-  c.seq_reassociate = 1;                                         // SGD: y_hat summed as w0 + (row part) -- <= 1e-10 on V, signs exact, 3.9 M examples/s; "sequential_bitwise" below turns it off
+  c.seq_reassociate = 1;                                         // SGD: y_hat summed as w0 + (row part) -- <= 1e-10 on V, signs exact, 4.0 M examples/s; "sequential_bitwise" below turns it off
   // The throughput mode is ONE optional element of solver.control -- a non-breaking extension a maintainer adds to R/fm_solver_control.R
   // (`engine = c("sequential", "sequential_bitwise", "minibatch", "minibatch_fp64")`, `batch_rows = 262144L`); lists without it behave as before:
-  //   "minibatch"      synchronous mini-batches, fp32 state: 847 M examples/s at configs[1]'s shape against 3.9 M (one MI355X)
+  //   "minibatch"      synchronous mini-batches, fp32 state: 847 M examples/s at configs[1]'s shape against 4.0 M (one MI355X)
   //   "minibatch_fp64" the same with the reference's fp64 state: 616 M examples/s, 1e-5 on V guaranteed against the mini-batch restatement
   // options("FM.threads") arrives as fm_controls$nthreads (src/FM.cpp:59,97) and becomes the number of GPUs there: fmx_train shards the rows over
   // devices 0..n-1 and exchanges the gradient sums with RCCL inside the library.

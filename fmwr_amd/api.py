@@ -292,7 +292,7 @@ def fm_train(data, normalize=True, control=None, seed=None, mode="sequential", b
     """fm.train() -- R/fm_train.R:70-127.  `control` is a list of *.control objects.  V0 ~ N(v.init_mean, v.init_stdev)
     is drawn here (the reference draws it from R's RNG inside Model::init, core/Model.h:63-72); `seed` makes it repeatable.
     mode="sequential" is the reference's algorithm (its visiting order, one update per example, fp64; for SGD the forward's sum is reassociated so that only
-    w0 chains the examples -- cfg.seq_reassociate: <= 1e-10 on V against the CPU restatement, 3.9 M examples/s); mode="sequential_bitwise" keeps the reference's association
+    w0 chains the examples -- cfg.seq_reassociate: <= 1e-10 on V against the CPU restatement, 4.0 M examples/s); mode="sequential_bitwise" keeps the reference's association
     (<= 1e-11, 1.65 M examples/s); mode="minibatch" the synchronous mini-batch engine (fp32 state),
     mode="minibatch_fp64" the same engine on fp64 state."""
     if not isinstance(data, FmMatrix):

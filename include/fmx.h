@@ -130,7 +130,7 @@ typedef struct fmx_config {
                               bits up to the device exp().  1: the same formula summed as w0 + (row part), the row part a fixed tree; only w0 then
                               chains one example to the next (solver/SGD_Learner.h:100-112).  The reference's algorithm, visiting order and
                               precision; the last bits of y_hat differ (<= 1e-10 on V against the oracle, prediction signs exact on every parity
-                              case; the same bits from run to run).  3.9 M examples/s against 1.65 M at configs[1]'s shape.  FTRL, TDAP and other row
+                              case; the same bits from run to run).  4.0 M examples/s against 1.65 M at configs[1]'s shape.  FTRL, TDAP and other row
                               shapes ignore the flag (they run the bitwise kernels).                                                              */
   int32_t gpus_share_device; /* 1: all N replicas live on `device` and exchange through a device kernel instead of RCCL
                               (rehearsals and tests on a one-GPU box; same sums, same order of ranks)                  */
