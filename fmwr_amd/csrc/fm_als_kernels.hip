@@ -2144,6 +2144,26 @@ static bool persist_applies(const fmx_matrix* m) {
   if (widest > 2 * PERSIST_WAVES) return false;
   return (uint64_t)m->n * sizeof(double2) <= 0xFFFFFFF0ull && m->als_level_ptr.back() < (int64_t)0xFFFFFFFFll;
 }
+// A persistent sweep's waves wait for one another: every one of them must be RUNNING.  No more one-wave workgroups than the device holds of this kernel at once (its
+// registers decide: als_exact_flow_k<false> takes 227, eight waves per CU -- 256 of them fit a whole MI355X eight times over, a 32-CU partition exactly); both forms
+// work with any number of waves.  (Cached per device; 0 from the runtime = unknown: as asked.)
+template <bool FLOW, bool W>   // (one cache per kernel: the two W variants of a form have the same function type)
+static int resident_waves(const fmx_engine* e, int want) {
+  constexpr int MAX_DEV = 64;
+  static int cap[MAX_DEV] = {};
+  const int slot = (e->cfg.device >= 0 && e->cfg.device < MAX_DEV) ? e->cfg.device : 0;
+  if (cap[slot] == 0) {
+    int cus = 0, per = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device) != hipSuccess) cus = 0;
+    hipError_t st;
+    if constexpr (FLOW) st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, als_exact_flow_k<W>, 64, 0);
+    else st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, als_exact_persist_k<W>, 64, 0);
+    if (st != hipSuccess) per = 0;
+    (void)hipGetLastError();
+    cap[slot] = cus > 0 && per > 0 ? cus * per : -1;
+  }
+  return cap[slot] > 0 && cap[slot] < want ? cap[slot] : want;
+}
 // the record-ordered form (als_exact_flow_k) where the rows' ranks fit its tags; FMX_ALS_PERSIST=counter keeps the counter form (als_exact_persist_k)
 static int flow_prepare(fmx_engine* e, fmx_matrix* m, bool& ok) {
   ok = false;
@@ -2194,7 +2214,7 @@ static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const Swee
     prof_begin(e, FMX_KERNEL_ALS_SWEEP);
     hipLaunchKernelGGL(als_rec_pack_k, dim3(grid), dim3(256), 0, e->stream, (const double2*)d_qe, e->als_rec, m->n);
     const char* fw = getenv("FMX_ALS_FLOW_WAVES");
-    const int flow_waves = fw && atoi(fw) > 0 && atoi(fw) <= 2048 ? atoi(fw) : FLOW_WAVES;
+    const int flow_waves = resident_waves<true, W>(e, fw && atoi(fw) > 0 && atoi(fw) <= 2048 ? atoi(fw) : FLOW_WAVES);
     hipLaunchKernelGGL((als_exact_flow_k<W>), dim3((unsigned)flow_waves), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
                        (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, (const uint16_t*)m->als_rank, W ? e->dw : e->dV, e->kp64, dyn,
                        e->als_rec, (uint32_t)((uint64_t)m->n * 32ull), e->als_persist_ctl + PERSIST_REPL * PERSIST_LINE_WORDS, debug_skip);
@@ -2207,7 +2227,7 @@ static int sweep_persist(fmx_engine* e, fmx_matrix* m, double2* d_qe, const Swee
   // run (persist_check reads and clears it); the launches after it leave at their first look at it
   FMX_HIP(hipMemsetAsync(e->als_persist_ctl, 0, (size_t)PERSIST_REPL * PERSIST_LINE_WORDS * sizeof(unsigned int), e->stream));
   prof_begin(e, FMX_KERNEL_ALS_SWEEP);
-  hipLaunchKernelGGL((als_exact_persist_k<W>), dim3(PERSIST_WAVES), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
+  hipLaunchKernelGGL((als_exact_persist_k<W>), dim3((unsigned)resident_waves<false, W>(e, PERSIST_WAVES)), dim3(64), 0, e->stream, (const uint32_t*)m->als_feats, (const int64_t*)m->als_level_ptr_dev, L,
                      (const int64_t*)m->col_ptr, (const uint32_t*)m->crow, (const float*)m->cval, W ? e->dw : e->dV, e->kp64, dyn, d_qe,
                      (uint32_t)((uint64_t)m->n * sizeof(double2)), e->als_persist_ctl, debug_skip);
   prof_end(e);

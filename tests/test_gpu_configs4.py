@@ -696,6 +696,28 @@ def test_configs4_deep_exact_plan_with_columns_longer_than_the_kept_slots(monkey
     assert util.rel_err(res[0][0], rv.reshape(k, p)) < 1e-10 and util.rel_err(res[0][1], rerr) < 1e-10
 
 
+@pytest.mark.parametrize("waves", ["1", "7", "2048"])
+def test_configs4_record_ordered_sweep_with_any_number_of_waves(monkeypatch, waves):
+    """als_exact_flow_k deals the plan's positions over however many one-wave workgroups it is given (FMX_ALS_FLOW_WAVES; never more than the device holds at once):
+    one wave alone, seven, as many as fit -- bit for bit one launch per level."""
+    from fmwr_amd import _lib as L, engine
+    k, n, p = 3, 20_000, 6_000
+    rp, col, val, y = _problem(engine, L, "iid", n, p, 79, "normal")
+    w0, w, v = util.params(p, k, 53, stdev=0.1, fp32=False)
+    err0 = np.random.default_rng(13).normal(0, 1, n)
+    res = []
+    for persist in ("1", "0"):
+        monkeypatch.setenv("FMX_ALS_PERSIST", persist)
+        monkeypatch.setenv("FMX_ALS_FLOW_WAVES", waves)
+        e = engine.Engine(p, task=L.TASK_REGRESSION, solver=L.SOLVER_ALS, num_factor=k, mode=L.MODE_SEQUENTIAL)
+        e.set_params(w0, w, v)
+        m = engine.Matrix.from_csr(rp, col, val, p, y)
+        gerr = e.als_vsweep(m, err0, alpha=1.0, v_lambda=np.full(k, 0.8))
+        res.append((e.get_params()[2], gerr))
+        e.close(); m.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_configs4_deep_exact_plan_steps_that_keep_their_old_value(monkeypatch):
     """CHECK_PARAM (MCMC_ALS_Learner.h:336): a step whose new value is not a number keeps the old one and skips its corrections.  In the record-ordered form the rows'
     tags must still move on (the next feature of the row waits for them): a residual with one NaN in it makes ~30 such steps per factor; all three forms agree bit
